@@ -1,0 +1,148 @@
+/*
+ * npi_gnn.h -- C ABI of the MI355X (gfx950) message-passing engine for NPI-GNN's conv hot path.
+ *
+ * Drop-in boundary: the reference reaches this path through the PyG
+ * `nn.Conv` module interface -- `SAGEConv(in,128)` constructed at reference src/classes.py:48,50,52
+ * and called as `conv(x, edge_index)` at src/classes.py:62,66,70; backward through autograd at
+ * src/train_with_twoDataset.PY:54.  The arithmetic lives in torch-geometric 1.4.2 / torch-scatter
+ * (un-vendored, reference README.md:11).  The reference has no FFI of its own for this path; the
+ * entry points below are what a ctypes binding inside a PyG-style `MessagePassing.propagate`
+ * replacement binds.  Each entry point names the PyG-1.4.2 op it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (PyTorch's caching allocator);
+ *     the library never allocates, frees or retains device memory;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call is asynchronous on it and performs no host synchronisation;
+ *   - return value: 0 = ok, <0 = error (text via npi_last_error(), thread-local); no C++
+ *     exception crosses the ABI, nothing calls exit();
+ *   - node ids in CSR arrays are int32 (N + E + 1 < 2^31); the COO input is int64 as PyG hands it
+ *     over (`edge_index` LongTensor [2,E], row 0 = source j, row 1 = target i).
+ */
+#ifndef NPI_GNN_H
+#define NPI_GNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPI_OK 0
+#define NPI_ERR_ARG (-1)      /* bad argument (null pointer, negative size, unsupported width) */
+#define NPI_ERR_LAUNCH (-2)   /* HIP launch / runtime error */
+#define NPI_ERR_WORKSPACE (-3)/* workspace too small */
+
+/* edges of the self-loop-augmented CSR that one wavefront ("item") reduces */
+#define NPI_ITEM_EDGES 256
+
+/* data types of feature matrices */
+#define NPI_F32 0
+#define NPI_BF16 1
+
+const char* npi_last_error(void);
+int npi_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph build.  Replaces PyG `add_remaining_self_loops` (SAGEConv.forward / GCNConv.norm) and
+ * the implicit "group messages by target" that torch_scatter does with atomics: a STABLE LSD
+ * radix sort of the COO columns by `key` node, so that within one row the entries keep their
+ * edge_index order and the appended self loop comes last -- exactly the accumulation order of
+ * the reference's CPU scatter.
+ *
+ *   key_nodes[E], val_nodes[E] : int64 device arrays.  CSR-by-target: key = edge_index[1],
+ *                                val = edge_index[0].  CSR-by-source (transpose, for backward):
+ *                                swap them.
+ *   Columns with key == val (existing self loops) and columns with an id outside [0,N) are
+ *   dropped; the latter also set bit 0 of status[0].
+ *   add_self_loops != 0 appends (i,i) as the LAST entry of every row.
+ *
+ *   rowptr[N+1]  : int32, rowptr[N] = nnz (device-side; nnz <= E + N)
+ *   col[E+N]     : int32 neighbour (val) node per entry
+ *   eid[E+N]     : int32 original column in edge_index, -1 for an appended self loop (may be NULL)
+ *   rowidx[E+N]  : int32 key node per entry, i.e. the sorted COO row (may be NULL)
+ *   item_row[npi_num_items(E+N)+1] : int32 first row of every NPI_ITEM_EDGES-entry item
+ *   status[1]    : int32 device word, bit 0 = out-of-range id seen
+ * ------------------------------------------------------------------------------------------ */
+int64_t npi_csr_workspace_bytes(int64_t E, int64_t N);
+int64_t npi_num_items(int64_t nnz_max);
+int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
+                  int add_self_loops,
+                  int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* rowidx,
+                  int32_t* item_row, int32_t* status,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* inverse map for per-edge data that lives in one CSR's entry order and is needed in the other's:
+ * pos_of[e] for e in [0,E) = entry index of edge column e in the CSR given by (eid, nnz_max), or -1 */
+int npi_edge_positions(const int32_t* eid, const int32_t* rowptr, int64_t N, int64_t nnz_max,
+                       int64_t E, int32_t* pos_of, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Segmented row reduction over a CSR -- replaces `torch.index_select(x, 0, edge_index[0])`
+ * followed by `torch_scatter.scatter_{add,mean}(x_j, edge_index[1], dim_size=N)`
+ * (PyG MessagePassing.propagate, reached from reference src/classes.py:62,66,70), without
+ * materialising the [E+N, F] message tensor and without float atomics:
+ *
+ *     out[i, :] = scale_i * sum_{p in [rowptr[i], rowptr[i+1])}  w[p] * x[col[p], :]  (+ bias[:])
+ *
+ *   mean != 0  : scale_i = 1 / max(rowptr[i+1]-rowptr[i], 1)   (scatter_mean)
+ *   w == NULL  : all ones (SAGE);  otherwise one f32 per CSR entry (GCN norm / GAT alpha)
+ *   x, out     : [N, F] row-major, leading dimension ldx / ldo (elements), dtype f32 or bf16
+ *                (bf16 storage, f32 accumulation)
+ *   carry      : f32 scratch, 2 * npi_num_items(nnz_max) * F elements, for rows cut by an
+ *                item boundary (combined in item order => bitwise reproducible)
+ * ------------------------------------------------------------------------------------------ */
+int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t F);
+int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+               const float* w, int64_t N, int64_t nnz_max,
+               const void* x, int64_t ldx, void* out, int64_t ldo, int64_t F, int dtype,
+               int mean, const float* bias, float* carry, void* stream);
+
+/* GCNConv.norm (PyG 1.4.2): deg[j] = sum of weights of entries in row j of the BY-SOURCE CSR
+ * (deg == NULL: unweighted, the row lengths of deg_rowptr are used);
+ * norm[p] = deg^-1/2[rowidx[p]] * w[p] * deg^-1/2[col[p]] for the entries of either CSR
+ * (w == NULL: ones; deg^-1/2 of 0 is 0 as PyG masks inf). */
+int npi_row_weight_sum(const int32_t* rowptr, const float* w, int64_t N, float* deg, void* stream);
+int npi_gcn_norm(const int32_t* rowidx, const int32_t* col, const int32_t* rowptr, const float* w,
+                 const float* deg, const int32_t* deg_rowptr, int64_t N, int64_t nnz_max, float* norm,
+                 void* stream);
+/* inv_cnt[i] = 1 / max(rowptr[i+1] - rowptr[i], 1): the scatter_mean divisor, needed again by the
+ * backward (dX = A^T D^-1 dAgg) */
+int npi_row_inv_count(const int32_t* rowptr, int64_t N, float* inv_cnt, void* stream);
+/* per-entry weights from per-edge weights: w_entry[p] = eid[p] >= 0 ? edge_w[eid[p]] : loop_w
+ * (loop weight of node i = loop_w_node[i] if given else fill) */
+int npi_entry_weights(const int32_t* eid, const int32_t* rowidx, const int32_t* rowptr,
+                      const float* edge_w, const float* loop_w_node, float fill,
+                      int64_t N, int64_t nnz_max, float* w_entry, void* stream);
+int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense projection on the matrix cores -- replaces `torch.matmul(aggr_out, self.weight) + bias`
+ * (SAGEConv.update / GCNConv.forward) and its autograd backward.  f32 in / f32 accumulate on
+ * v_mfma_f32_32x32x2_f32 (exact f32, needed for the 1e-4 parity bar).
+ *
+ *   npi_linear_fwd      : C[M,N]  = act( rowscale_m * (A[M,K] @ W[K,N]) + bias[N] )
+ *   npi_linear_bwd_data : dA[M,K] = rowscale_m * (dC[M,N] @ W[K,N]^T)
+ *   npi_linear_bwd_weight: dW[K,N] = A[M,K]^T @ dC[M,N],  db[N] = colsum(dC)   (db may be NULL)
+ *                          deterministic split over M; workspace f32
+ * ------------------------------------------------------------------------------------------ */
+int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                   const float* rowscale, float* C, int64_t ldc,
+                   int64_t M, int64_t K, int64_t N, int relu, void* stream);
+int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
+                        const float* rowscale, float* dA, int64_t ldda,
+                        int64_t M, int64_t K, int64_t N, void* stream);
+/* out[N] = column sums of X[M,N] (GCNConv bias gradient); workspace f32, ceil(M/4096)*N elements */
+int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
+               int64_t workspace_elems, void* stream);
+int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, int64_t N);
+int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t lddc,
+                          float* dW, int64_t lddw, float* db,
+                          int64_t M, int64_t K, int64_t N,
+                          float* workspace, int64_t workspace_elems, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPI_GNN_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of ``libnpi_gnn.so`` (the C ABI of ``include/npi_gnn.h``).
+
+There is NO CPU fallback: every wrapper raises if the library is missing or if a tensor is not
+on an AMD GPU.  PyTorch only lends device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch  # noqa: F401  (must be imported first: the .so binds to torch's libamdhip64.so.7)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnpi_gnn.so")
+
+NPI_F32 = 0
+NPI_BF16 = 1
+ITEM_EDGES = 256
+
+_P = c_void_p
+_I = c_int64
+
+# name -> (restype, argtypes); mirrors include/npi_gnn.h one to one
+PROTOTYPES = {
+    "npi_last_error": (c_char_p, []),
+    "npi_abi_version": (c_int, []),
+    "npi_csr_workspace_bytes": (_I, [_I, _I]),
+    "npi_num_items": (_I, [_I]),
+    "npi_csr_build": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "npi_edge_positions": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
+    "npi_segsum_carry_elems": (_I, [_I, _I]),
+    "npi_segsum": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
+    "npi_row_weight_sum": (c_int, [_P, _P, _I, _P, _P]),
+    "npi_gcn_norm": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "npi_row_inv_count": (c_int, [_P, _I, _P, _P]),
+    "npi_entry_weights": (c_int, [_P, _P, _P, _P, _P, c_float, _I, _I, _P, _P]),
+    "npi_permute_f32": (c_int, [_P, _P, _I, c_float, _P, _P]),
+    "npi_linear_fwd": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, _P]),
+    "npi_linear_bwd_data": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "npi_colsum": (c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
+    "npi_linear_bwd_weight_workspace_elems": (_I, [_I, _I, _I]),
+    "npi_linear_bwd_weight": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P]),
+}
+
+_lib = None
+
+
+class NpiError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the C-ABI library and attach prototypes.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise NpiError(
+            f"{path} is missing: the HIP extension has not been built "
+            "(run `python -m npi_gnn_amd.build`).  npi_gnn_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().npi_last_error()
+        raise NpiError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def require_gpu(*tensors) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NpiError("npi_gnn_amd kernels run on MI355X (HIP) tensors only; got a "
+                           f"{t.device} tensor.  There is no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise NpiError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

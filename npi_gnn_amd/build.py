@@ -1,0 +1,70 @@
+"""Build the gfx950 C-ABI library in-tree: ``npi_gnn_amd/libnpi_gnn.so``.
+
+``python -m npi_gnn_amd.build`` or ``__graft_entry__.build()``.  hipcc cross-compiles without a GPU.
+The library links only against the HIP runtime; when loaded after ``import torch`` the loader
+binds it to the ``libamdhip64.so.7`` PyTorch has already mapped (same SONAME), so streams and
+device pointers are shared with torch.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnpi_gnn.so")
+SOURCES = ["csr_build.hip", "segsum.hip", "gemm_f32.hip", "graph_ops.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+        os.path.join(HERE, "..", "include", "npi_gnn.h"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fno-gpu-rdc",
+               "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- hipcc failed on {src} ---\n{out}\n")
+        elif verbose or out.strip():
+            sys.stderr.write(out)
+    if failed:
+        raise RuntimeError("hipcc compilation failed")
+    tmp = LIB + ".tmp"
+    subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp] + objs)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

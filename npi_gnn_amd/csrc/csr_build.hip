@@ -1,0 +1,358 @@
+// COO (int64, as PyG hands it over) -> destination-sorted CSR (int32) with the self loop of
+// add_remaining_self_loops appended as the LAST entry of every row.
+//
+// Replaces, for reference src/classes.py:62,66,70 (SAGEConv.forward -> PyG 1.4.2
+// utils.add_remaining_self_loops + the per-target grouping torch_scatter does with atomics).
+//
+// Stable LSD radix sort on the key node id (8-bit digits, ceil(log2(N+1)/8) passes):
+// entries of a row keep their edge_index order, so the reduction order equals the
+// reference's CPU scatter order and every run is bitwise identical.
+#include "npi_common.h"
+#include <stdarg.h>
+
+namespace npi {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / WAVE;
+constexpr int SORT_ITEMS = 16;                       // keys per lane
+constexpr int SORT_WAVE_TILE = WAVE * SORT_ITEMS;    // 1024 keys per wave, striped: key j*64+lane
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
+constexpr int RADIX = 256;
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+// key = key node, or N (sentinel, sorts behind every row) for dropped columns
+__global__ void make_keys_kernel(const int64_t* __restrict__ key_nodes,
+                                 const int64_t* __restrict__ val_nodes, int64_t E, int64_t N,
+                                 uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                 int32_t* __restrict__ status) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t k = key_nodes[e], v = val_nodes[e];
+    bool bad = (k < 0) | (k >= N) | (v < 0) | (v >= N);
+    if (bad) atomicOr(status, 1);
+    keys[e] = (bad || k == v) ? (uint32_t)N : (uint32_t)k;
+    vals[e] = (int32_t)e;
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks,
+                  int32_t* __restrict__ counts) {
+    __shared__ int hist[RADIX];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        int64_t i = base + j * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & (RADIX - 1)], 1);
+    }
+    __syncthreads();
+    counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];   // digit-major
+}
+
+// ---- exclusive scan of an int32 array (three launches) -------------------------------------
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds /*[SCAN_THREADS]*/, int* total) {
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        int t = (threadIdx.x >= off) ? lds[threadIdx.x - off] : 0;
+        __syncthreads();
+        lds[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int incl = lds[threadIdx.x];
+    *total = lds[SCAN_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_tiles_kernel(int32_t* __restrict__ data, int64_t n, int32_t* __restrict__ tile_sums) {
+    __shared__ int lds[SCAN_THREADS];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        v[j] = (base + j < n) ? data[base + j] : 0;
+        s += v[j];
+    }
+    int total;
+    int excl = block_exclusive_scan(s, lds, &total);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < n) data[base + j] = excl;
+        excl += v[j];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_sums_kernel(int32_t* __restrict__ sums, int64_t n) {   // one workgroup
+    __shared__ int lds[SCAN_THREADS];
+    int carry = 0;
+    for (int64_t base = 0; base < n; base += SCAN_THREADS) {
+        int64_t i = base + threadIdx.x;
+        int v = (i < n) ? sums[i] : 0;
+        int total;
+        int excl = block_exclusive_scan(v, lds, &total);
+        if (i < n) sums[i] = carry + excl;
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_add_kernel(int32_t* __restrict__ data, int64_t n, const int32_t* __restrict__ tile_sums) {
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int add = tile_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < n) data[base + j] += add;
+}
+
+// ---- stable scatter of one radix pass ----------------------------------------------------------
+__global__ void __launch_bounds__(SORT_THREADS)
+radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                     uint32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out,
+                     int64_t n, int shift, int nblocks, const int32_t* __restrict__ offsets) {
+    __shared__ int wcnt[SORT_WAVES][RADIX];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < SORT_WAVES * RADIX; i += SORT_THREADS) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * SORT_WAVE_TILE;
+    uint32_t key[SORT_ITEMS];
+    int32_t val[SORT_ITEMS];
+    int rank[SORT_ITEMS];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        int64_t i = base + j * WAVE + lane;
+        bool valid = i < n;
+        key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[j] = valid ? vals_in[i] : 0;
+        // tail lanes rank as digit 255 of the last tile: they sort behind everything and are not written
+        int digit = valid ? (int)((key[j] >> shift) & (RADIX - 1)) : (RADIX - 1);
+        uint64_t same = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            bool bit = (digit >> b) & 1;
+            uint64_t m = __ballot(bit);
+            same &= bit ? m : ~m;
+        }
+        int before = __popcll(same & lt_mask);
+        int prev = wcnt[wave][digit];
+        __builtin_amdgcn_wave_barrier();
+        if (before == 0) wcnt[wave][digit] = prev + __popcll(same);
+        __builtin_amdgcn_wave_barrier();
+        rank[j] = prev + before;
+    }
+    __syncthreads();
+    {   // thread d owns digit d: turn per-wave counts into global start offsets
+        int d = threadIdx.x;
+        int off = offsets[(int64_t)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            int c = wcnt[w][d];
+            wcnt[w][d] = off;
+            off += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        int64_t i = base + j * WAVE + lane;
+        if (i < n) {
+            int digit = (int)((key[j] >> shift) & (RADIX - 1));
+            int pos = wcnt[wave][digit] + rank[j];
+            keys_out[pos] = key[j];
+            vals_out[pos] = val[j];
+        }
+    }
+}
+
+// rowptr0[r] = first sorted position with key >= r, r in [0, N]
+__global__ void row_bounds_kernel(const uint32_t* __restrict__ keys, int64_t E, int64_t N,
+                                  int32_t* __restrict__ rowptr0) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > N) return;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint32_t)r) lo = mid + 1; else hi = mid;
+    }
+    rowptr0[r] = (int32_t)lo;
+}
+
+__global__ void fill_entries_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                    const int64_t* __restrict__ val_nodes, int64_t E, int64_t N,
+                                    int loops, int32_t* __restrict__ col, int32_t* __restrict__ eid,
+                                    int32_t* __restrict__ rowidx) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E) return;
+    uint32_t k = keys[p];
+    if (k >= (uint32_t)N) return;
+    int32_t e = vals[p];
+    int64_t q = p + (loops ? (int64_t)k : 0);
+    col[q] = (int32_t)val_nodes[e];
+    if (eid) eid[q] = e;
+    if (rowidx) rowidx[q] = (int32_t)k;
+}
+
+__global__ void fill_rows_kernel(const int32_t* __restrict__ rowptr0, int64_t N, int loops,
+                                 int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                 int32_t* __restrict__ eid, int32_t* __restrict__ rowidx) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > N) return;
+    int32_t add = loops ? (int32_t)r : 0;
+    rowptr[r] = rowptr0[r] + add;
+    if (loops && r < N) {
+        int64_t q = (int64_t)rowptr0[r + 1] + r;     // last entry of row r
+        col[q] = (int32_t)r;
+        if (eid) eid[q] = -1;
+        if (rowidx) rowidx[q] = (int32_t)r;
+    }
+}
+
+// item_row[i] = row holding entry i*NPI_ITEM_EDGES (item 0 starts at row 0 so that leading empty
+// rows get written); N for items past nnz.
+__global__ void item_rows_kernel(const int32_t* __restrict__ rowptr, int64_t N, int64_t n_items,
+                                 int32_t* __restrict__ item_row) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_items) return;
+    int64_t nnz = rowptr[N];
+    int64_t k = i * NPI_ITEM_EDGES;
+    if (i == 0) { item_row[0] = 0; return; }
+    if (k >= nnz) { item_row[i] = (int32_t)N; return; }
+    // upper_bound(rowptr[0..N], k) - 1
+    int64_t lo = 0, hi = N + 1;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)rowptr[mid] <= k) lo = mid + 1; else hi = mid;
+    }
+    item_row[i] = (int32_t)(lo - 1);
+}
+
+__global__ void edge_positions_kernel(const int32_t* __restrict__ eid, const int32_t* __restrict__ rowptr,
+                                      int64_t N, int64_t nnz_max, int32_t* __restrict__ pos_of) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz_max || p >= rowptr[N]) return;
+    int32_t e = eid[p];
+    if (e >= 0) pos_of[e] = (int32_t)p;
+}
+
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct SortLayout {
+    int64_t nblocks, counts_len, ntiles;
+    int64_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_counts, off_tiles, off_rowptr0, total;
+};
+
+static SortLayout sort_layout(int64_t E, int64_t N) {
+    SortLayout L;
+    L.nblocks = ceil_div(E > 0 ? E : 1, SORT_TILE);
+    L.counts_len = L.nblocks * RADIX;
+    L.ntiles = ceil_div(L.counts_len, SCAN_TILE);
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { int64_t r = o; o += align_up(bytes, 256); return r; };
+    int64_t Ee = E > 0 ? E : 1;
+    L.off_keys_a = take(Ee * 4);
+    L.off_keys_b = take(Ee * 4);
+    L.off_vals_a = take(Ee * 4);
+    L.off_vals_b = take(Ee * 4);
+    L.off_counts = take(L.counts_len * 4);
+    L.off_tiles = take(L.ntiles * 4);
+    L.off_rowptr0 = take((N + 1) * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace npi
+
+using namespace npi;
+
+extern "C" const char* npi_last_error(void) { return npi::g_err; }
+extern "C" int npi_abi_version(void) { return 1; }
+
+extern "C" int64_t npi_csr_workspace_bytes(int64_t E, int64_t N) {
+    if (E < 0 || N < 0) return -1;
+    return sort_layout(E, N).total;
+}
+
+extern "C" int64_t npi_num_items(int64_t nnz_max) {
+    return nnz_max <= 0 ? 0 : ceil_div(nnz_max, NPI_ITEM_EDGES);
+}
+
+extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
+                             int add_self_loops, int32_t* rowptr, int32_t* col, int32_t* eid,
+                             int32_t* rowidx, int32_t* item_row, int32_t* status,
+                             void* workspace, int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(E >= 0 && N >= 0, "npi_csr_build: negative size");
+    NPI_REQUIRE(E + N + 1 < (int64_t)0x7fffffff, "npi_csr_build: E + N does not fit int32");
+    NPI_REQUIRE(rowptr && item_row && status && workspace, "npi_csr_build: null output");
+    NPI_REQUIRE(E == 0 || (key_nodes && val_nodes && col), "npi_csr_build: null edge arrays");
+    SortLayout L = sort_layout(E, N);
+    if (workspace_bytes < L.total) {
+        set_error("npi_csr_build: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.total);
+        return NPI_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    uint32_t* keys_a = (uint32_t*)(ws + L.off_keys_a);
+    uint32_t* keys_b = (uint32_t*)(ws + L.off_keys_b);
+    int32_t* vals_a = (int32_t*)(ws + L.off_vals_a);
+    int32_t* vals_b = (int32_t*)(ws + L.off_vals_b);
+    int32_t* counts = (int32_t*)(ws + L.off_counts);
+    int32_t* tiles = (int32_t*)(ws + L.off_tiles);
+    int32_t* rowptr0 = (int32_t*)(ws + L.off_rowptr0);
+
+    (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+    if (E > 0) {
+        make_keys_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(key_nodes, val_nodes, E, N, keys_a, vals_a, status);
+        int bits = 1;
+        while (((int64_t)1 << bits) <= N) ++bits;       // keys lie in [0, N]
+        int passes = (bits + 7) / 8;
+        for (int p = 0; p < passes; ++p) {
+            int shift = 8 * p;
+            radix_hist_kernel<<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, E, shift, (int)L.nblocks, counts);
+            scan_tiles_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
+            scan_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(tiles, L.ntiles);
+            scan_add_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
+            radix_scatter_kernel<<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, E, shift, (int)L.nblocks, counts);
+            uint32_t* tk = keys_a; keys_a = keys_b; keys_b = tk;
+            int32_t* tv = vals_a; vals_a = vals_b; vals_b = tv;
+        }
+    }
+    row_bounds_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(keys_a, E, N, rowptr0);
+    if (E > 0)
+        fill_entries_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(keys_a, vals_a, val_nodes, E, N, add_self_loops, col, eid, rowidx);
+    fill_rows_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(rowptr0, N, add_self_loops, rowptr, col, eid, rowidx);
+    int64_t n_items = npi_num_items(E + (add_self_loops ? N : 0));
+    item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, item_row);
+    return check_launch("npi_csr_build");
+}
+
+extern "C" int npi_edge_positions(const int32_t* eid, const int32_t* rowptr, int64_t N, int64_t nnz_max,
+                                  int64_t E, int32_t* pos_of, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(E >= 0 && nnz_max >= 0, "npi_edge_positions: negative size");
+    if (E > 0) fill_i32_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(pos_of, E, -1);
+    if (nnz_max > 0)
+        edge_positions_kernel<<<(unsigned)ceil_div(nnz_max, 256), 256, 0, stream>>>(eid, rowptr, N, nnz_max, pos_of);
+    return check_launch("npi_edge_positions");
+}

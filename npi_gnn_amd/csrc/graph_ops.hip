@@ -1,0 +1,121 @@
+// Per-entry weight plumbing for the weighted convs: GCNConv.norm (PyG 1.4.2, a7 in SURVEY.md 8(a))
+// and edge_weight handling of add_remaining_self_loops.  Integer/index work plus one rsqrt per
+// entry; all arrays are in CSR entry order (see csr_build.hip).
+#include "npi_common.h"
+
+namespace npi {
+
+// deg[r] = sum of w over row r, lanes stride the row, fixed-order wave reduction (deterministic)
+__global__ void __launch_bounds__(256)
+row_weight_sum_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ w, int N,
+                      float* __restrict__ deg) {
+    const int lane = lane_id();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int b = rowptr[r], e = rowptr[r + 1];
+    float s = 0.f;
+    for (int p = b + lane; p < e; p += WAVE) s += w[p];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, WAVE);
+    if (lane == 0) deg[r] = s;
+}
+
+__device__ __forceinline__ float inv_sqrt_or_zero(float d) {
+    // PyG: deg.pow(-0.5); inf -> 0
+    return d > 0.f ? 1.0f / sqrtf(d) : 0.f;
+}
+
+__global__ void gcn_norm_kernel(const int32_t* __restrict__ rowidx, const int32_t* __restrict__ col,
+                                const int32_t* __restrict__ rowptr, const float* __restrict__ w,
+                                const float* __restrict__ deg, const int32_t* __restrict__ deg_rowptr,
+                                int N, int64_t nnz_max, float* __restrict__ norm) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz_max || p >= rowptr[N]) return;
+    const int a = rowidx[p], b = col[p];
+    float da, db;
+    if (deg) { da = deg[a]; db = deg[b]; }
+    else { da = (float)(deg_rowptr[a + 1] - deg_rowptr[a]); db = (float)(deg_rowptr[b + 1] - deg_rowptr[b]); }
+    const float wp = w ? w[p] : 1.f;
+    norm[p] = inv_sqrt_or_zero(db) * wp * inv_sqrt_or_zero(da);
+}
+
+__global__ void entry_weights_kernel(const int32_t* __restrict__ eid, const int32_t* __restrict__ rowidx,
+                                     const int32_t* __restrict__ rowptr, const float* __restrict__ edge_w,
+                                     const float* __restrict__ loop_w_node, float fill, int N,
+                                     int64_t nnz_max, float* __restrict__ w_entry) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz_max || p >= rowptr[N]) return;
+    const int e = eid[p];
+    float v;
+    if (e >= 0) v = edge_w ? edge_w[e] : 1.f;
+    else v = loop_w_node ? loop_w_node[rowidx[p]] : fill;
+    w_entry[p] = v;
+}
+
+__global__ void row_inv_count_kernel(const int32_t* __restrict__ rowptr, int N, float* __restrict__ inv) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    inv[i] = 1.f / (float)max(rowptr[i + 1] - rowptr[i], 1);
+}
+
+__global__ void permute_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ index,
+                                   int64_t n, float fill, float* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = index[i];
+    dst[i] = j >= 0 ? src[j] : fill;
+}
+
+}  // namespace npi
+
+using namespace npi;
+
+extern "C" int npi_row_weight_sum(const int32_t* rowptr, const float* w, int64_t N, float* deg, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0, "npi_row_weight_sum: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && w && deg, "npi_row_weight_sum: null pointer");
+    row_weight_sum_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, w, (int)N, deg);
+    return check_launch("npi_row_weight_sum");
+}
+
+extern "C" int npi_gcn_norm(const int32_t* rowidx, const int32_t* col, const int32_t* rowptr,
+                            const float* w, const float* deg, const int32_t* deg_rowptr, int64_t N,
+                            int64_t nnz_max, float* norm, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && nnz_max >= 0, "npi_gcn_norm: bad size");
+    if (nnz_max == 0) return NPI_OK;
+    NPI_REQUIRE(rowidx && col && rowptr && norm && (deg || deg_rowptr), "npi_gcn_norm: null pointer");
+    gcn_norm_kernel<<<(unsigned)ceil_div(nnz_max, 256), 256, 0, stream>>>(rowidx, col, rowptr, w, deg, deg_rowptr, (int)N, nnz_max, norm);
+    return check_launch("npi_gcn_norm");
+}
+
+extern "C" int npi_entry_weights(const int32_t* eid, const int32_t* rowidx, const int32_t* rowptr,
+                                 const float* edge_w, const float* loop_w_node, float fill, int64_t N,
+                                 int64_t nnz_max, float* w_entry, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && nnz_max >= 0, "npi_entry_weights: bad size");
+    if (nnz_max == 0) return NPI_OK;
+    NPI_REQUIRE(eid && rowidx && rowptr && w_entry, "npi_entry_weights: null pointer");
+    entry_weights_kernel<<<(unsigned)ceil_div(nnz_max, 256), 256, 0, stream>>>(eid, rowidx, rowptr, edge_w, loop_w_node, fill, (int)N, nnz_max, w_entry);
+    return check_launch("npi_entry_weights");
+}
+
+extern "C" int npi_row_inv_count(const int32_t* rowptr, int64_t N, float* inv_cnt, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0, "npi_row_inv_count: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && inv_cnt, "npi_row_inv_count: null pointer");
+    row_inv_count_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(rowptr, (int)N, inv_cnt);
+    return check_launch("npi_row_inv_count");
+}
+
+extern "C" int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(n >= 0, "npi_permute_f32: bad size");
+    if (n == 0) return NPI_OK;
+    NPI_REQUIRE(src && index && dst, "npi_permute_f32: null pointer");
+    permute_f32_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(src, index, n, fill, dst);
+    return check_launch("npi_permute_f32");
+}

@@ -1,0 +1,43 @@
+// Shared helpers for the gfx950 kernels behind include/npi_gnn.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/npi_gnn.h"
+
+namespace npi {
+
+constexpr int WAVE = 64;
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return NPI_ERR_LAUNCH;
+    }
+    return NPI_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// value of `v` in lane `l` (l wave-uniform) as a scalar
+__device__ __forceinline__ int bcast_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float bcast_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+}  // namespace npi
+
+#define NPI_REQUIRE(cond, msg)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            npi::set_error("%s", msg);         \
+            return NPI_ERR_ARG;                \
+        }                                      \
+    } while (0)

@@ -1,0 +1,122 @@
+"""Device-resident adjacency for the conv hot path: destination-sorted CSR (+ its transpose).
+
+Takes the ``edge_index`` LongTensor ``[2, E]`` exactly as PyG's ``Batch`` collate hands it to the
+conv (row 0 = source j, row 1 = target i; reference ``src/classes.py:701-704`` emits both
+directions) and builds, on the GPU, what PyG 1.4.2's ``add_remaining_self_loops`` + scatter would
+produce implicitly.  A ``CSRGraph`` may be passed to the convs in place of ``edge_index`` so that a
+static full-batch graph (BASELINE.json configs 3-5) is sorted once instead of once per layer call.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, load, ptr, require_gpu, stream_ptr
+
+_DEBUG = False
+
+
+def set_debug(flag: bool) -> None:
+    """When on, every graph build synchronises and raises on out-of-range node ids
+    (PyG/torch raise IndexError/RuntimeError there)."""
+    global _DEBUG
+    _DEBUG = bool(flag)
+
+
+@dataclass
+class CSRSide:
+    """One orientation.  ``rowptr[N+1]``, ``col/eid/rowidx[nnz_max]`` int32 in entry order;
+    ``item_row`` maps every 256-entry item to its first row; ``rowptr[N]`` is nnz on device."""
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    eid: torch.Tensor
+    rowidx: torch.Tensor
+    item_row: torch.Tensor
+    status: torch.Tensor
+    nnz_max: int
+    n_items: int
+    _inv_cnt: Optional[torch.Tensor] = None
+    _carry: Dict[int, torch.Tensor] = field(default_factory=dict)
+
+
+def _build_side(key: torch.Tensor, val: torch.Tensor, E: int, N: int, self_loops: bool) -> CSRSide:
+    lib = load()
+    dev = require_gpu(key, val)
+    nnz_max = E + (N if self_loops else 0)
+    n_items = int(lib.npi_num_items(nnz_max))
+    i32 = dict(dtype=torch.int32, device=dev)
+    rowptr = torch.empty(N + 1, **i32)
+    col = torch.empty(max(nnz_max, 1), **i32)
+    eid = torch.empty(max(nnz_max, 1), **i32)
+    rowidx = torch.empty(max(nnz_max, 1), **i32)
+    item_row = torch.empty(n_items + 1, **i32)
+    status = torch.empty(1, **i32)
+    ws_bytes = int(lib.npi_csr_workspace_bytes(E, N))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.npi_csr_build(ptr(key), ptr(val), E, N, 1 if self_loops else 0, ptr(rowptr), ptr(col),
+                            ptr(eid), ptr(rowidx), ptr(item_row), ptr(status), ptr(ws), ws_bytes,
+                            stream_ptr(dev)), "npi_csr_build")
+    if _DEBUG and int(status.item()) & 1:
+        raise IndexError("edge_index holds a node id outside [0, num_nodes)")
+    return CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
+
+
+class CSRGraph:
+    """Self-loop-augmented adjacency of one (batched) graph on one GPU.
+
+    ``by_dst`` groups entries by target node (forward aggregation, PyG flow ``source_to_target``);
+    ``by_src`` groups them by source node (backward: dX = A^T ...), built lazily."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, self_loops: bool = True):
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("edge_index must be a LongTensor of shape [2, E]")
+        require_gpu(edge_index)
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(edge_index.size(1))
+        self.self_loops = bool(self_loops)
+        self.device = edge_index.device
+        # rows of a [2,E] tensor are contiguous when the tensor is; otherwise copy (index plumbing)
+        self._src = edge_index[0].contiguous()
+        self._dst = edge_index[1].contiguous()
+        self.by_dst = _build_side(self._dst, self._src, self.num_edges, self.num_nodes, self.self_loops)
+        self._by_src: Optional[CSRSide] = None
+
+    @property
+    def by_src(self) -> CSRSide:
+        if self._by_src is None:
+            self._by_src = _build_side(self._src, self._dst, self.num_edges, self.num_nodes, self.self_loops)
+        return self._by_src
+
+    def inv_count(self, side: CSRSide) -> torch.Tensor:
+        """1 / max(row length, 1): the scatter_mean divisor (count includes the self loop)."""
+        if side._inv_cnt is None:
+            out = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
+            check(load().npi_row_inv_count(ptr(side.rowptr), self.num_nodes, ptr(out), stream_ptr(self.device)),
+                  "npi_row_inv_count")
+            side._inv_cnt = out
+        return side._inv_cnt
+
+    def carry(self, side: CSRSide, F: int) -> torch.Tensor:
+        """f32 scratch for rows cut by an item boundary; reused across calls of the same width."""
+        buf = side._carry.get(F)
+        if buf is None:
+            n = int(load().npi_segsum_carry_elems(side.nnz_max, F))
+            buf = torch.empty(n, dtype=torch.float32, device=self.device)
+            side._carry[F] = buf
+        return buf
+
+    def nnz(self) -> int:
+        """Entries incl. self loops (device read; synchronises)."""
+        return int(self.by_dst.rowptr[-1].item())
+
+
+def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:
+    if isinstance(edge_index_or_graph, CSRGraph):
+        g = edge_index_or_graph
+        if g.num_nodes != num_nodes:
+            raise ValueError(f"CSRGraph was built for {g.num_nodes} nodes, x has {num_nodes}")
+        return g
+    return CSRGraph(edge_index_or_graph, num_nodes)

@@ -1,0 +1,120 @@
+"""``nn.Module``s with the PyG 1.4.2 conv signatures, parameter names and initialisers, so that
+NPI-GNN's ``Net_1`` (reference ``src/classes.py:45-82``) and its train loop
+(``src/train_with_twoDataset.PY:46-57``) run unchanged with::
+
+    from npi_gnn_amd.nn import SAGEConv, GCNConv
+
+``state_dict`` keys are ``weight [in, out]`` (``x @ W`` orientation, not ``nn.Linear``'s) and
+``bias [out]``, so the reference's checkpoints (``result/<proj>/model_<k>_fold/<epoch>``, loaded at
+``src/test.py:41``) load as they are.  ``forward`` also accepts a prebuilt ``CSRGraph`` in place of
+``edge_index`` (static full-batch graphs: sort once).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+from torch.nn import Parameter
+
+from . import functional as F_
+from .graph import CSRGraph, as_graph
+
+
+def _uniform(size: int, tensor: Optional[torch.Tensor]) -> None:
+    """PyG ``inits.uniform``: U(-1/sqrt(size), 1/sqrt(size))."""
+    if tensor is not None:
+        bound = 1.0 / math.sqrt(size)
+        tensor.data.uniform_(-bound, bound)
+
+
+def _glorot(tensor: Optional[torch.Tensor]) -> None:
+    """PyG ``inits.glorot``: U(+-sqrt(6/(fan_in+fan_out))) over the last two dims."""
+    if tensor is not None:
+        stdv = math.sqrt(6.0 / (tensor.size(-2) + tensor.size(-1)))
+        tensor.data.uniform_(-stdv, stdv)
+
+
+class SAGEConv(nn.Module):
+    """``SAGEConv(in_channels, out_channels, normalize=False, concat=False, bias=True)`` --
+    mean over in-neighbours and the node itself, then ``@ weight + bias``.  Both parameters are
+    initialised U(+-1/sqrt(in_channels)) as in PyG 1.4.2."""
+
+    def __init__(self, in_channels: int, out_channels: int, normalize: bool = False, concat: bool = False,
+                 bias: bool = True, **kwargs):
+        super().__init__()
+        if concat:
+            raise NotImplementedError("SAGEConv(concat=True) is not used by NPI-GNN and not implemented")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.normalize = normalize
+        self.concat = concat
+        self.weight = Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        _uniform(self.weight.size(0), self.weight)
+        _uniform(self.weight.size(0), self.bias)
+
+    def forward(self, x, edge_index, edge_weight=None, size=None):
+        if edge_weight is not None or size is not None:
+            raise NotImplementedError("SAGEConv: edge_weight / bipartite size are not used by NPI-GNN")
+        return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
+
+
+class GCNConv(nn.Module):
+    """``GCNConv(in_channels, out_channels, improved=False, cached=False, bias=True,
+    normalize=True)``; ``weight`` glorot, ``bias`` zeros (PyG 1.4.2)."""
+
+    def __init__(self, in_channels: int, out_channels: int, improved: bool = False, cached: bool = False,
+                 bias: bool = True, normalize: bool = True, **kwargs):
+        super().__init__()
+        if not normalize:
+            raise NotImplementedError("GCNConv(normalize=False) is not implemented")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.improved = improved
+        self.cached = cached
+        self.normalize = normalize
+        self.weight = Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        _glorot(self.weight)
+        if self.bias is not None:
+            self.bias.data.zero_()
+        self.cached_result = None
+        self.cached_num_edges = None
+
+    def forward(self, x, edge_index, edge_weight=None):
+        norm = None
+        if self.cached and self.cached_result is not None:
+            E = edge_index.num_edges if isinstance(edge_index, CSRGraph) else edge_index.size(1)
+            if E != self.cached_num_edges:
+                raise RuntimeError(
+                    f"Cached {self.cached_num_edges} number of edges, but found {E}. Please disable "
+                    "the caching behavior of this layer by removing the `cached=True` argument in its "
+                    "constructor.")
+            norm = self.cached_result
+        if norm is None:
+            graph = as_graph(edge_index, x.size(0))
+            norm = F_.GCNNorm(graph, edge_weight, self.improved)
+            if self.cached:
+                self.cached_result = norm
+                self.cached_num_edges = graph.num_edges
+        return F_.gcn_conv(x, None, self.weight, self.bias, norm=norm)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

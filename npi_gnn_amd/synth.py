@@ -1,0 +1,59 @@
+"""Synthetic ncRNA-protein bipartite interaction graphs shaped like the reference's
+(SURVEY.md 8(d), config C4/C5): node ids [0, n_rna) are ncRNAs, [n_rna, N) proteins (~10:1 as in
+NPInter2: 4,636 : 449); every undirected pair is emitted in both directions like reference
+``src/classes.py:701-704``; no duplicate pairs, no self loops; the protein side is Zipf-skewed so
+that the heaviest protein holds ~5.4 % of all pairs (NPInter2: 1,121 of 20,824), the RNA side is
+uniform.  Pure numpy on the host -- input construction, not part of the timed path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def _zipf_probs(n: int, top_share: float) -> np.ndarray:
+    """p_i ~ 1/(i + q), q solved so that p_0 = top_share."""
+    i = np.arange(n, dtype=np.float64)
+    lo, hi = 1e-3, 1e4
+    for _ in range(80):
+        q = (lo * hi) ** 0.5
+        p = 1.0 / (i + q)
+        share = p[0] / p.sum()
+        if share > top_share:
+            lo = q
+        else:
+            hi = q
+    p = 1.0 / (i + q)
+    return p / p.sum()
+
+
+def bipartite_edge_index(num_nodes: int, num_directed_edges: int, seed: int = 20260310,
+                         top_share: float = 0.054) -> torch.Tensor:
+    """LongTensor [2, E] (E = num_directed_edges, even), both directions, unsorted (shuffled)."""
+    assert num_directed_edges % 2 == 0
+    pairs = num_directed_edges // 2
+    n_prot = max(1, num_nodes // 10)
+    n_rna = num_nodes - n_prot
+    rng = np.random.default_rng(seed)
+    p = _zipf_probs(n_prot, top_share)
+    # a protein cannot have more distinct partners than there are RNAs
+    cdf = np.cumsum(p)
+    got = np.empty(0, dtype=np.int64)
+    need = pairs
+    while need > 0:
+        m = int(need * 1.15) + 1024
+        rna = rng.integers(0, n_rna, size=m, dtype=np.int64)
+        prot = np.searchsorted(cdf, rng.random(m), side="right").clip(0, n_prot - 1).astype(np.int64)
+        key = np.concatenate([got, rna * n_prot + prot])
+        got = np.unique(key)
+        if got.size > pairs:
+            got = rng.permutation(got)[:pairs]
+        need = pairs - got.size
+    rna = got // n_prot
+    prot = got % n_prot + n_rna
+    perm = rng.permutation(pairs)
+    rna, prot = rna[perm], prot[perm]
+    src = np.concatenate([rna, prot])
+    dst = np.concatenate([prot, rna])
+    perm2 = rng.permutation(2 * pairs)
+    return torch.from_numpy(np.stack([src[perm2], dst[perm2]]))

@@ -1,0 +1,85 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/npi_gnn.h
+declares, the host-side mirror of the PyG interface has the reference's parameter layout, and the
+product path refuses to run without the GPU (there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import npi_gnn_amd
+from npi_gnn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "npi_gnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(npi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m npi_gnn_amd.build` (or __graft_entry__.build())"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared_symbols()
+    assert len(names) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/npi_gnn.h but not exported"
+    assert set(names) == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
+
+
+def test_size_queries_without_gpu():
+    lib = _lib.load()
+    assert lib.npi_abi_version() == 1
+    assert lib.npi_num_items(0) == 0
+    assert lib.npi_num_items(1) == 1
+    assert lib.npi_num_items(256) == 1
+    assert lib.npi_num_items(257) == 2
+    assert lib.npi_csr_workspace_bytes(1000, 10) > 16 * 1000
+    assert lib.npi_segsum_carry_elems(1000, 256) == 2 * 4 * 256
+    assert lib.npi_linear_bwd_weight_workspace_elems(1000, 256, 256) >= 256 * 256
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = _lib.load()
+    rc = lib.npi_segsum(None, None, None, None, -1, 0, None, 0, None, 0, 4, 0, 0, None, None, None)
+    assert rc == -1
+    assert b"npi_segsum" in lib.npi_last_error()
+
+
+def test_modules_mirror_pyg_parameter_layout():
+    conv = npi_gnn_amd.SAGEConv(178, 128)
+    sd = conv.state_dict()
+    assert list(sd) == ["weight", "bias"]
+    assert tuple(sd["weight"].shape) == (178, 128) and tuple(sd["bias"].shape) == (128,)
+    bound = 1.0 / (178 ** 0.5)
+    assert float(sd["weight"].abs().max()) <= bound and float(sd["bias"].abs().max()) <= bound
+    g = npi_gnn_amd.GCNConv(178, 64)
+    assert tuple(g.weight.shape) == (178, 64) and float(g.bias.abs().max()) == 0.0
+    # a reference-style checkpoint slice loads unchanged
+    conv.load_state_dict({"weight": torch.zeros(178, 128), "bias": torch.ones(128)})
+    assert float(conv.bias.sum()) == 128.0
+
+
+def test_no_cpu_fallback():
+    conv = npi_gnn_amd.SAGEConv(8, 4)
+    x = torch.randn(5, 8)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 3]])
+    with pytest.raises(npi_gnn_amd.NpiError):
+        conv(x, ei)
+    with pytest.raises(npi_gnn_amd.NpiError):
+        npi_gnn_amd.CSRGraph(ei, 5)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "npi_gnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,257 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same seeded inputs.
+
+Bar (north_star): node/edge indexing bit-exact; fp32 outputs within 1e-4 of the PyG-style CPU path.
+Tolerances are written per test: values are O(1) so `atol=1e-4, rtol=1e-4` is the 1e-4 bar.
+"""
+import numpy as np
+import pytest
+import torch
+
+import npi_gnn_amd as npi
+from npi_gnn_amd import functional as NF
+from oracle import ref_conv as R
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+RTOL = 1e-4
+
+
+def rand_edges(N, E, seed, hub=None):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    if hub is not None:                       # a few very heavy target rows (skew: reference max deg 1121)
+        n_h = E // 3
+        ei[1, :n_h] = hub
+    return ei
+
+
+def csr_reference(key, val, N, loops=True):
+    """numpy restatement of the build contract: drop key==val, stable sort by key, loop last."""
+    key, val = key.numpy(), val.numpy()
+    keep = key != val
+    eids = np.nonzero(keep)[0]
+    order = np.argsort(key[keep], kind="stable")
+    k_s, v_s, e_s = key[keep][order], val[keep][order], eids[order]
+    rows_col, rows_eid, rows_idx, rowptr = [], [], [], [0]
+    bounds = np.searchsorted(k_s, np.arange(N + 1))
+    for r in range(N):
+        c = list(v_s[bounds[r]:bounds[r + 1]])
+        e = list(e_s[bounds[r]:bounds[r + 1]])
+        if loops:
+            c.append(r)
+            e.append(-1)
+        rows_col += c
+        rows_eid += e
+        rows_idx += [r] * len(c)
+        rowptr.append(len(rows_col))
+    return (np.array(rowptr, np.int32), np.array(rows_col, np.int32), np.array(rows_eid, np.int32),
+            np.array(rows_idx, np.int32))
+
+
+@pytest.mark.parametrize("N,E,loops", [(1, 0, True), (5, 0, True), (7, 20, True), (300, 5000, True),
+                                       (300, 5000, False), (5000, 200000, True), (70000, 300000, True)])
+def test_csr_build_is_bit_exact(dev, N, E, loops):
+    ei = rand_edges(N, E, seed=N + E) if E else torch.zeros((2, 0), dtype=torch.long)
+    g = npi.CSRGraph(ei.to(dev), N, self_loops=loops)
+    for side, key, val in ((g.by_dst, ei[1], ei[0]), (g.by_src, ei[0], ei[1])):
+        rowptr, col, eid, rowidx = csr_reference(key, val, N, loops)
+        nnz = int(rowptr[-1])
+        assert np.array_equal(side.rowptr.cpu().numpy(), rowptr)
+        assert np.array_equal(side.col.cpu().numpy()[:nnz], col)
+        assert np.array_equal(side.eid.cpu().numpy()[:nnz], eid)
+        assert np.array_equal(side.rowidx.cpu().numpy()[:nnz], rowidx)
+        # item_row[i] = row holding entry 256 i
+        ir = side.item_row.cpu().numpy()
+        for i in range(1, side.n_items):
+            k = 256 * i
+            if k < nnz:
+                assert rowptr[ir[i]] <= k < rowptr[ir[i] + 1]
+        assert int(side.status.item()) == 0
+
+
+def test_csr_build_flags_out_of_range_ids(dev):
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]])
+    g = npi.CSRGraph(ei.to(dev), 3)
+    assert int(g.by_dst.status.item()) == 1
+    assert g.by_dst.rowptr.cpu().tolist() == [0, 1, 3, 5]      # bad column dropped
+    npi.set_debug(True)
+    try:
+        with pytest.raises(IndexError):
+            npi.CSRGraph(ei.to(dev), 3)
+    finally:
+        npi.set_debug(False)
+
+
+def _segsum_oracle(ei, N, x, w_entry_fn=None, mean=False, loops=True):
+    ei2 = R.add_remaining_self_loops(ei, None, 1.0, N)[0] if loops else ei[:, ei[0] != ei[1]]
+    msg = x.index_select(0, ei2[0])
+    return (R.scatter_mean if mean else R.scatter_add)(msg, ei2[1], N)
+
+
+@pytest.mark.parametrize("F", [1, 3, 64, 65, 128, 178, 256, 300, 512, 1100])
+@pytest.mark.parametrize("mean", [False, True])
+def test_segsum_widths(dev, F, mean):
+    N, E = 700, 9000
+    ei = rand_edges(N, E, seed=F, hub=5)       # row 5 has ~3000 entries: cut across ~12 items
+    x = torch.randn(N, F, generator=torch.Generator().manual_seed(1))
+    g = npi.CSRGraph(ei.to(dev), N)
+    out = NF.segsum(g, g.by_dst, x.to(dev), mean=mean).cpu()
+    ref = _segsum_oracle(ei, N, x.double(), mean=mean).float()
+    assert torch.allclose(out, ref, atol=ATOL * (1 if mean else 30), rtol=RTOL)
+    out_t = NF.segsum(g, g.by_src, x.to(dev), mean=mean).cpu()
+    ref_t = _segsum_oracle(ei.flip(0), N, x.double(), mean=mean).float()
+    assert torch.allclose(out_t, ref_t, atol=ATOL * (1 if mean else 30), rtol=RTOL)
+
+
+def test_segsum_empty_rows_and_no_self_loops(dev):
+    N, F = 2000, 256
+    ei = rand_edges(600, 3000, seed=3) + 700           # rows [0,700) and [1300,2000) are empty
+    x = torch.randn(N, F)
+    g = npi.CSRGraph(ei.to(dev), N, self_loops=False)
+    out = NF.segsum(g, g.by_dst, x.to(dev)).cpu()
+    ref = _segsum_oracle(ei, N, x.double(), loops=False).float()
+    assert torch.allclose(out, ref, atol=1e-3, rtol=RTOL)
+    assert float(out[:700].abs().max()) == 0.0 and float(out[1300:].abs().max()) == 0.0
+
+
+def test_segsum_weighted_and_bias(dev):
+    N, E, F = 900, 20000, 256
+    ei = rand_edges(N, E, seed=11, hub=17)
+    x = torch.randn(N, F)
+    g = npi.CSRGraph(ei.to(dev), N)
+    nnz = g.nnz()
+    w = torch.rand(nnz)
+    bias = torch.randn(F)
+    out = NF.segsum(g, g.by_dst, x.to(dev), w=w.to(dev), bias=bias.to(dev)).cpu()
+    col = g.by_dst.col.cpu().long()[:nnz]
+    row = g.by_dst.rowidx.cpu().long()[:nnz]
+    ref = torch.zeros(N, F, dtype=torch.float64).index_add_(0, row, w.double().view(-1, 1) * x.double()[col]) + bias.double()
+    assert torch.allclose(out, ref.float(), atol=2e-3, rtol=RTOL)
+
+
+def test_segsum_is_bitwise_reproducible(dev):
+    N, E, F = 3000, 100000, 256
+    ei = rand_edges(N, E, seed=5, hub=1)
+    x = torch.randn(N, F).to(dev)
+    g = npi.CSRGraph(ei.to(dev), N)
+    a = NF.segsum(g, g.by_dst, x, mean=True)
+    b = NF.segsum(g, g.by_dst, x, mean=True)
+    g2 = npi.CSRGraph(ei.to(dev), N)
+    c = NF.segsum(g2, g2.by_dst, x, mean=True)
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1, 1), (37, 178, 128), (300, 128, 128), (1000, 256, 256),
+                                   (129, 65, 2), (513, 64, 300)])
+def test_linear_fwd_bwd(dev, M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    rs = torch.rand(M, generator=g) + 0.5
+    dc = torch.randn(M, N, generator=g)
+    out = NF.linear_fwd(a.to(dev), w.to(dev), b.to(dev)).cpu()
+    assert torch.allclose(out, (a.double() @ w.double() + b.double()).float(), atol=ATOL, rtol=RTOL)
+    out = NF.linear_fwd(a.to(dev), w.to(dev), b.to(dev), rowscale=rs.to(dev), relu=True).cpu()
+    ref = torch.relu(rs.double().view(-1, 1) * (a.double() @ w.double()) + b.double()).float()
+    assert torch.allclose(out, ref, atol=ATOL, rtol=RTOL)
+    da = NF.linear_bwd_data(dc.to(dev), w.to(dev), rowscale=rs.to(dev)).cpu()
+    ref = (rs.double().view(-1, 1) * (dc.double() @ w.double().t())).float()
+    assert torch.allclose(da, ref, atol=ATOL * 4, rtol=RTOL)
+    dw, db = NF.linear_bwd_weight(a.to(dev), dc.to(dev))
+    assert torch.allclose(dw.cpu(), (a.double().t() @ dc.double()).float(), atol=ATOL * max(1, M ** 0.5), rtol=RTOL)
+    assert torch.allclose(db.cpu(), dc.double().sum(0).float(), atol=ATOL * max(1, M ** 0.5), rtol=RTOL)
+    assert torch.allclose(NF.colsum(dc.to(dev)).cpu(), dc.double().sum(0).float(), atol=ATOL * max(1, M ** 0.5), rtol=RTOL)
+
+
+def test_linear_bwd_weight_large_m_split(dev):
+    M, K, N = 200_000, 256, 256
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(M, K, generator=g)
+    dc = torch.randn(M, N, generator=g)
+    dw, db = NF.linear_bwd_weight(a.to(dev), dc.to(dev))
+    ref = (a.double().t() @ dc.double())
+    err = (dw.cpu().double() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 1e-5
+
+
+def _layer_case(N, E, Fi, Fo, seed, symmetric):
+    ei = rand_edges(N, E, seed, hub=3)
+    if symmetric:
+        ei = torch.cat([ei, ei.flip(0)], dim=1)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Fi, generator=g)
+    W = (torch.rand(Fi, Fo, generator=g) * 2 - 1) / Fi ** 0.5
+    b = (torch.rand(Fo, generator=g) * 2 - 1) / Fi ** 0.5
+    go = torch.randn(N, Fo, generator=g)
+    return ei, x, W, b, go
+
+
+@pytest.mark.parametrize("N,E,Fi,Fo,sym", [(50, 120, 178, 128, True), (4000, 30000, 128, 128, True),
+                                           (4000, 30000, 256, 256, False), (2500, 9000, 65, 64, False)])
+def test_sage_conv_fwd_bwd_matches_oracle(dev, N, E, Fi, Fo, sym):
+    ei, x, W, b, go = _layer_case(N, E, Fi, Fo, 7, sym)
+    ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(x, ei, W, b, go)
+    xd = x.to(dev).requires_grad_(True)
+    Wd = W.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    out = npi.sage_conv(xd, ei.to(dev), Wd, bd)
+    out.backward(go.to(dev))
+    assert torch.allclose(out.detach().cpu(), ref_out, atol=ATOL, rtol=RTOL)
+    assert torch.allclose(xd.grad.cpu(), ref_dx, atol=ATOL, rtol=RTOL)
+    assert torch.allclose(Wd.grad.cpu(), ref_dw, atol=ATOL * N ** 0.5, rtol=1e-3)
+    assert torch.allclose(bd.grad.cpu(), ref_db, atol=ATOL * N ** 0.5, rtol=1e-3)
+
+
+def test_sage_direction_on_directed_toy(dev):
+    x = torch.tensor([[1.0, 10.0], [3.0, 30.0], [5.0, 50.0]])
+    ei = torch.tensor([[0, 0], [1, 2]])                      # 0->1, 0->2
+    W = torch.eye(2)
+    out = npi.sage_conv(x.to(dev), ei.to(dev), W.to(dev), None).cpu()
+    assert out.tolist() == [[1.0, 10.0], [2.0, 20.0], [3.0, 30.0]]
+
+
+@pytest.mark.parametrize("weighted,improved", [(False, False), (True, False), (False, True)])
+def test_gcn_conv_fwd_bwd_matches_oracle(dev, weighted, improved):
+    N, E, Fi, Fo = 3000, 25000, 178, 256
+    ei, x, W, b, go = _layer_case(N, E, Fi, Fo, 9, symmetric=not weighted)
+    ew = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(1)) + 0.1 if weighted else None
+    xr = x.clone().requires_grad_(True)
+    Wr = W.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = R.gcn_conv(xr, ei, Wr, br, ew, improved)
+    ref.backward(go)
+    xd = x.to(dev).requires_grad_(True)
+    Wd = W.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    out = npi.gcn_conv(xd, ei.to(dev), Wd, bd, None if ew is None else ew.to(dev), improved)
+    out.backward(go.to(dev))
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=ATOL, rtol=RTOL)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, atol=ATOL, rtol=RTOL)
+    assert torch.allclose(Wd.grad.cpu(), Wr.grad, atol=ATOL * N ** 0.5, rtol=1e-3)
+    assert torch.allclose(bd.grad.cpu(), br.grad, atol=ATOL * N ** 0.5, rtol=1e-3)
+
+
+def test_modules_drop_into_a_net1_style_stack(dev):
+    """conv -> relu -> conv, loss.backward(), optimizer.step(): the reference's call pattern
+    (src/classes.py:62-70, src/train_with_twoDataset.PY:46-57) with the module interface."""
+    torch.manual_seed(0)
+    N, E = 1500, 6000
+    ei = rand_edges(N, E, 1)
+    ei = torch.cat([ei, ei.flip(0)], 1).to(dev)
+    x = torch.randn(N, 178, device=dev)
+    c1, c2 = npi.SAGEConv(178, 128).to(dev), npi.SAGEConv(128, 128).to(dev)
+    opt = torch.optim.Adam(list(c1.parameters()) + list(c2.parameters()), lr=1e-3, weight_decay=1e-3)
+    graph = npi.CSRGraph(ei, N)
+    h = torch.relu(c2(torch.relu(c1(x, ei)), graph))          # edge_index or prebuilt graph
+    sd1 = {k: v.detach().cpu().clone() for k, v in c1.state_dict().items()}
+    sd2 = {k: v.detach().cpu().clone() for k, v in c2.state_dict().items()}
+    ref = torch.relu(R.sage_conv(torch.relu(R.sage_conv(x.cpu(), ei.cpu(), sd1["weight"], sd1["bias"])),
+                                 ei.cpu(), sd2["weight"], sd2["bias"]))
+    assert torch.allclose(h.detach().cpu(), ref, atol=ATOL, rtol=RTOL)
+    loss = h.pow(2).mean()
+    loss.backward()
+    opt.step()
+    assert c1.weight.grad is not None and torch.isfinite(c1.weight.grad).all()
+    assert not torch.equal(c1.weight.detach().cpu(), sd1["weight"])
