@@ -166,12 +166,13 @@ class GCNNorm:
             if edge_weight is not None:
                 require_gpu(edge_weight)
                 edge_weight = _f32c(edge_weight.detach(), "edge_weight")
-                # add_remaining_self_loops: an existing self loop's weight becomes the loop weight
-                src, dst = graph._src, graph._dst
-                m = src == dst
-                if bool(m.any()):
-                    loop_w = torch.full((N,), fill, dtype=torch.float32, device=dev)
-                    loop_w[src[m]] = edge_weight[m]
+            # add_remaining_self_loops: an existing self loop's weight (GCNConv.norm passes ones when
+            # edge_weight is None) becomes that node's loop weight instead of `fill`
+            src, dst = graph._src, graph._dst
+            m = src == dst
+            if bool(m.any()):
+                loop_w = torch.full((N,), fill, dtype=torch.float32, device=dev)
+                loop_w[src[m]] = edge_weight[m] if edge_weight is not None else 1.0
             for k, side in enumerate(sides):
                 we = torch.empty(max(side.nnz_max, 1), dtype=torch.float32, device=dev)
                 check(lib.npi_entry_weights(ptr(side.eid), ptr(side.rowidx), ptr(side.rowptr), ptr(edge_weight),

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (tools/profile_bench.sh) into the files kept under profiles/:
+  <tag>_kernel_stats.csv   the --kernel-trace --stats summary, as rocprofv3 wrote it
+  <tag>_pmc_summary.json   per-kernel mean FETCH_SIZE / WRITE_SIZE (KB, raw) from the separate --pmc passes
+usage: tools/rocprof_summary.py gpurun_out/prof_<tag> <tag> [fetch_scale]
+fetch_scale = calibration factor for FETCH_SIZE in the segsum access pattern (tools/pmc_calibrate.py)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def per_kernel(path):
+    d = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return {}
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: {"launches": len(v), "mean_KB": sum(v) / len(v)} for k, v in d.items()}
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    scale = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "profiles")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
+    fetch = per_kernel(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"))
+    write = per_kernel(os.path.join(src, "pmc_write", "write_counter_collection.csv"))
+    summ = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, {}), write.get(k, {})
+        if max(f.get("mean_KB", 0), w.get("mean_KB", 0)) < 1000:
+            continue
+        summ[k.split("(")[0]] = {"FETCH_SIZE_KB_raw": f.get("mean_KB"), "WRITE_SIZE_KB": w.get("mean_KB"),
+                                 "launches": f.get("launches") or w.get("launches")}
+    res = {"note": "raw rocprofv3 counters, separate --pmc passes; FETCH_SIZE on gfx950 under-reports wide "
+                   "coalesced reads (MI355X_MICROARCH.md, HBM): multiply by fetch_scale for the segsum pattern",
+           "fetch_scale_segsum": scale, "kernels": summ}
+    json.dump(res, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
+    seg = [v for k, v in summ.items() if "segsum_kernel" in k]
+    if seg and scale:
+        b = sum((v["FETCH_SIZE_KB_raw"] * scale + v["WRITE_SIZE_KB"]) * 1024 for v in seg) / len(seg)
+        json.dump({"segsum_kernel_bytes_per_launch": b, "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json"},
+                  open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
