@@ -94,6 +94,7 @@ struct Epilogue {
     const float* bias;       // [N] or null
     const float* rowscale;   // [M] or null
     int relu;
+    float* colsum;           // BMODE 0 only: per-split column sums of B, [gridDim.z][N], or null
 };
 
 // C[M,N] (+ split-K slabs) = A(m,k) * B(k,n)
@@ -114,6 +115,8 @@ gemm_f32_kernel(const float* __restrict__ A, int64_t lda, const float* __restric
     const int kbeg = blockIdx.z * kchunk;
     const int kend = min(K, kbeg + kchunk);
     C += (int64_t)blockIdx.z * slab_stride;
+    const bool do_colsum = (ep.colsum != nullptr) && (blockIdx.y == 0);
+    float csum = 0.f;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -179,9 +182,15 @@ gemm_f32_kernel(const float* __restrict__ A, int64_t lda, const float* __restric
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
+        if (BMODE == 0 && do_colsum && threadIdx.x < BN) {   // db: column sums of the staged dC tile
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) csum += bs[k * RPITCH + threadIdx.x];
+        }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
+    if (BMODE == 0 && do_colsum && threadIdx.x < BN && n0 + (int)threadIdx.x < N)
+        ep.colsum[(int64_t)blockIdx.z * N + n0 + threadIdx.x] = csum;
 
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -262,7 +271,7 @@ extern "C" int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64
     NPI_REQUIRE(A && W && C, "npi_linear_fwd: null pointer");
     NPI_REQUIRE(lda >= K && ldw >= N && ldc >= N, "npi_linear_fwd: leading dimension too small");
     dim3 grid((unsigned)ceil_div(N, BN), (unsigned)ceil_div(M, BM), 1);
-    Epilogue ep{bias, rowscale, relu};
+    Epilogue ep{bias, rowscale, relu, nullptr};
     const bool v4 = vec4_ok(A, lda, K) && vec4_ok(W, ldw, N);
     if (v4) gemm_f32_kernel<0, 0, true><<<grid, GEMM_THREADS, 0, stream>>>(A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, (int)K, 0, ep);
     else    gemm_f32_kernel<0, 0, false><<<grid, GEMM_THREADS, 0, stream>>>(A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, (int)K, 0, ep);
@@ -280,7 +289,7 @@ extern "C" int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W
     NPI_REQUIRE(dC && W && dA, "npi_linear_bwd_data: null pointer");
     NPI_REQUIRE(lddc >= N && ldw >= N && ldda >= K, "npi_linear_bwd_data: leading dimension too small");
     dim3 grid((unsigned)ceil_div(K, BN), (unsigned)ceil_div(M, BM), 1);
-    Epilogue ep{nullptr, rowscale, 0};
+    Epilogue ep{nullptr, rowscale, 0, nullptr};
     // B(k = n_contract, n = k_out) = W[k_out * ldw + n_contract]  -> BMODE 1
     const bool v4 = vec4_ok(dC, lddc, N) && vec4_ok(W, ldw, N);
     if (v4) gemm_f32_kernel<0, 1, true><<<grid, GEMM_THREADS, 0, stream>>>(dC, lddc, W, ldw, dA, ldda, (int)M, (int)K, (int)N, (int)N, 0, ep);
@@ -308,9 +317,7 @@ extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, i
     if (M < 0 || K <= 0 || N <= 0) return -1;
     int64_t tiles = ceil_div(K, BM) * ceil_div(N, BN);
     int64_t splits = pick_splits(M, tiles);
-    int64_t a = splits * K * N;
-    int64_t b = ceil_div(M > 0 ? M : 1, COLSUM_ROWS) * N;
-    return (a > b ? a : b) + 64;
+    return splits * K * N + splits * N + 64;      // dW slabs, then db slabs
 }
 
 // dW[K,N] = A[M,K]^T @ dC[M,N] (contract over M), db[N] = colsum(dC)
@@ -330,17 +337,13 @@ extern "C" int npi_linear_bwd_weight(const float* A, int64_t lda, const float* d
     const int splits = pick_splits(M, tiles);
     const int kchunk = (int)(ceil_div(ceil_div(M > 0 ? M : 1, splits), BK) * BK);
     dim3 grid((unsigned)ceil_div(N, BN), (unsigned)ceil_div(K, BM), (unsigned)splits);
-    Epilogue ep{nullptr, nullptr, 0};
+    float* db_slabs = workspace + (int64_t)splits * K * N;
+    Epilogue ep{nullptr, nullptr, 0, db ? db_slabs : nullptr};   // db fused: colsum of the staged dC tiles
     // output rows = K (features of A), cols = N, contraction over M:  A(m=k_feat, k=node) = A[node*lda + k_feat]
     const bool v4 = vec4_ok(A, lda, K) && vec4_ok(dC, lddc, N);
     if (v4) gemm_f32_kernel<1, 0, true><<<grid, GEMM_THREADS, 0, stream>>>(A, lda, dC, lddc, workspace, N, (int)K, (int)N, (int)M, kchunk, K * N, ep);
     else    gemm_f32_kernel<1, 0, false><<<grid, GEMM_THREADS, 0, stream>>>(A, lda, dC, lddc, workspace, N, (int)K, (int)N, (int)M, kchunk, K * N, ep);
     slab_reduce_kernel<<<(unsigned)ceil_div(K * N, 256), 256, 0, stream>>>(workspace, K * N, splits, (int)K, (int)N, N, dW, lddw);
-    if (db) {
-        const int nchunks = (int)ceil_div(M > 0 ? M : 1, COLSUM_ROWS);
-        dim3 cg((unsigned)ceil_div(N, 64), (unsigned)nchunks);
-        colsum_partial_kernel<<<cg, 256, 0, stream>>>(dC, lddc, (int)M, (int)N, COLSUM_ROWS, workspace);
-        slab_reduce_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(workspace, N, nchunks, 1, (int)N, N, db, N);
-    }
+    if (db) slab_reduce_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(db_slabs, N, splits, 1, (int)N, N, db, N);
     return check_launch("npi_linear_bwd_weight");
 }

@@ -192,15 +192,23 @@ segsum_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ co
     }
 }
 
-// The item holding a cut row's FIRST entry sums that row's partials in item order.
+// The item holding a cut row's FIRST entry sums that row's partials: one 4-wave workgroup per item.
+// Short chains (the common case: tail of item i + head of item i+1) are summed by wave 0; a long
+// chain (hub row: ~1,600 partials at C4) is split into 4 contiguous slices, one per wave, 8 loads
+// in flight each, and the slice sums are added in slice order -- a fixed order, so still bitwise
+// reproducible.
+constexpr int FIX_COOP_MIN = 16;     // chain length from which all 4 waves cooperate
+constexpr int FIX_U = 8;
+
 template <int VEC, int NCH, bool MEAN, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
 segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
                     int N, int n_items, float* __restrict__ out, int64_t ldo, int F,
                     const float* __restrict__ carry, const float* __restrict__ bias) {
+    __shared__ float red[SEG_WAVES][NCH * VEC * WAVE];
     const int lane = lane_id();
-    const int item = uniform_i(blockIdx.x * SEG_WAVES + (threadIdx.x >> 6));
-    if (item >= n_items) return;
+    const int wave = uniform_i(threadIdx.x >> 6);
+    const int item = blockIdx.x;
     const int nnz = rowptr[N];
     const int k0 = item * T;
     const int k1 = k0 + T;
@@ -210,6 +218,12 @@ segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restric
     if (rs >= k1 || rs < k0) return;                     // not cut here / owned by an earlier item
     const int re = uniform_i(rowptr[r + 1]);
     const int last = (re - 1) / T;
+    const int L = last - item;                           // head partials to add (>= 1)
+    const bool coop = L >= FIX_COOP_MIN;                 // workgroup-uniform
+    if (!coop && wave != 0) return;
+    const int per = coop ? (L + SEG_WAVES - 1) / SEG_WAVES : L;
+    const int jb = item + 1 + wave * per;
+    const int je = min(jb + per, last + 1);
 
     bool act[NCH];
     int foff[NCH];
@@ -221,13 +235,36 @@ segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restric
     float acc[NCH][VEC];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (act[c]) load_row<VEC>(carry + ((int64_t)item * 2 + 1) * F + foff[c], acc[c]);
+        // wave 0 starts from the owner's tail partial, the other slices from zero
+        if (act[c] && wave == 0) load_row<VEC>(carry + ((int64_t)item * 2 + 1) * F + foff[c], acc[c]);
         else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) acc[c][q] = 0.f;
         }
     }
-    for (int j = item + 1; j <= last; ++j) {
+    int j = jb;
+    for (; j + FIX_U <= je; j += FIX_U) {
+        float v[FIX_U][NCH][VEC];
+#pragma unroll
+        for (int u = 0; u < FIX_U; ++u) {
+            const float* src = carry + ((int64_t)(j + u) * 2 + 0) * F;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (act[c]) load_row<VEC>(src + foff[c], v[u][c]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[u][c][q] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FIX_U; ++u)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[c][q] += v[u][c][q];
+    }
+    for (; j < je; ++j) {
         const float* src = carry + ((int64_t)j * 2 + 0) * F;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -238,6 +275,22 @@ segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restric
                 for (int q = 0; q < VEC; ++q) acc[c][q] += v[q];
             }
         }
+    }
+    if (coop) {
+        if (wave != 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) red[wave][(c * VEC + q) * WAVE + lane] = acc[c][q];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < SEG_WAVES; ++w)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[c][q] += red[w][(c * VEC + q) * WAVE + lane];
     }
     float s = 1.f;
     if (MEAN) s = 1.f / (float)max(re - rs, 1);
@@ -262,8 +315,9 @@ static int launch_segsum(const int32_t* rowptr, const int32_t* col, const int32_
     if (w) { if (mean) NPI_SEG_LAUNCH(true, true); else NPI_SEG_LAUNCH(true, false); }
     else   { if (mean) NPI_SEG_LAUNCH(false, true); else NPI_SEG_LAUNCH(false, false); }
 #undef NPI_SEG_LAUNCH
-    if (mean) segsum_fixup_kernel<VEC, NCH, true, EXACT><<<grid, block, 0, stream>>>(rowptr, item_row, N, n_items, out, ldo, F, carry, bias);
-    else      segsum_fixup_kernel<VEC, NCH, false, EXACT><<<grid, block, 0, stream>>>(rowptr, item_row, N, n_items, out, ldo, F, carry, bias);
+    dim3 fgrid((unsigned)n_items);      // one workgroup per item
+    if (mean) segsum_fixup_kernel<VEC, NCH, true, EXACT><<<fgrid, block, 0, stream>>>(rowptr, item_row, N, n_items, out, ldo, F, carry, bias);
+    else      segsum_fixup_kernel<VEC, NCH, false, EXACT><<<fgrid, block, 0, stream>>>(rowptr, item_row, N, n_items, out, ldo, F, carry, bias);
     return check_launch("npi_segsum");
 }
 
