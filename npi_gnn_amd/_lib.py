@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 import torch  # noqa: F401  (must be imported first: the .so binds to torch's libamdhip64.so.7)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnpi_gnn.so")
+LIB_PATH = os.environ.get("NPI_GNN_LIB") or os.path.join(HERE, "libnpi_gnn.so")   # env override: kernel A/B experiments
 
 NPI_F32 = 0
 NPI_BF16 = 1

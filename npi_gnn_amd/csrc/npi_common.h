@@ -31,6 +31,14 @@ __device__ __forceinline__ float bcast_f(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a wave-uniform pointer, forced into an SGPR pair
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
 
 }  // namespace npi
 
