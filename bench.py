@@ -8,7 +8,7 @@ JSON line.  A "step" is one pass of the hot path over the whole graph: one SAGEC
 of reference src/classes.py:62 + src/train_with_twoDataset.PY:52-54, with x and the graph already
 resident in HBM.  Workload = BASELINE.json configs[3] ("C4"): N = 1M nodes, E = 20M directed edges,
 hidden = 256, fp32 -- it fits one GPU, so N=1 runs the full graph; N>1 shards the same graph by
-destination rows (strong scaling).
+destination rows (strong scaling; npi_gnn_amd/dist.py).
 """
 from __future__ import annotations
 
@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=100_000, help="bounded CPU-baseline sample (1/10 scale)")
     ap.add_argument("--cpu-edges", type=int, default=2_000_000)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (npi_gnn_amd.dist) even with one rank")
     return ap.parse_args()
 
 
@@ -118,7 +120,7 @@ def main():
     seg_events = []                       # (start, end) HIP events around every npi_segsum launch
     NF._PROFILE = None
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         t0 = time.time()
         graph = npi.CSRGraph(ei.to(dev), N)
         _ = graph.by_src
@@ -149,16 +151,15 @@ def main():
         torch.cuda.synchronize()
         t_build = time.time() - t0
         layer = ND.ShardedSAGELayer(sg, W.to(dev), bias.to(dev))
-        lo, hi = sg.row_range
-        x = x_full[lo:hi].to(dev).requires_grad_(True)
-        go = go_full[lo:hi].to(dev)
+        x = sg.shard(x_full).to(dev).requires_grad_(True)      # rows rank, rank + W, ... (strided ownership)
+        go = sg.shard(go_full).to(dev)
 
         def step():
             layer.zero_grad()
             x.grad = None
             out = layer(x)
             out.backward(go)
-        n_rows_local, nnz_local = hi - lo, sg.local_nnz
+        n_rows_local, nnz_local = sg.n_local, sg.local_nnz
 
     def barrier():
         if world > 1:
@@ -207,7 +208,7 @@ def main():
             "config": {"workload": f"C4 synthetic ncRNA-protein bipartite graph, N={N} nodes, E={E} directed edges "
                                    f"(both directions, Zipf-skewed protein side), 1 {args.conv.upper()}Conv layer "
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
-                       "parallelism": "single GPU" if world == 1 else f"destination-row shards x{world}, all-gather over RCCL",
+                       "parallelism": "single GPU" if world == 1 else f"destination-row shards (strided ownership) x{world}, all-gather of row shards over RCCL",
                        "csr_build_s": round(t_build, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -72,6 +72,17 @@ int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E,
                   int32_t* item_row, int32_t* status,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Same build with separate row and column id spaces, for a destination-row SHARD of the graph on
+ * one GPU: keys are local row ids in [0, N), values index a feature table of
+ * n_cols rows (e.g. the all-gathered x of every rank); the appended self loop of row r gets
+ * column r + loop_col_offset; drop_equal == 0 keeps key == val columns (the caller has already
+ * removed the global self loops). */
+int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
+                     int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int drop_equal,
+                     int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* rowidx,
+                     int32_t* item_row, int32_t* status,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
 /* inverse map for per-edge data that lives in one CSR's entry order and is needed in the other's:
  * pos_of[e] for e in [0,E) = entry index of edge column e in the CSR given by (eid, nnz_max), or -1 */
 int npi_edge_positions(const int32_t* eid, const int32_t* rowptr, int64_t N, int64_t nnz_max,

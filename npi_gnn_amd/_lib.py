@@ -28,6 +28,7 @@ PROTOTYPES = {
     "npi_csr_workspace_bytes": (_I, [_I, _I]),
     "npi_num_items": (_I, [_I]),
     "npi_csr_build": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "npi_csr_build_ex": (c_int, [_P, _P, _I, _I, _I, c_int, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "npi_edge_positions": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "npi_segsum_carry_elems": (_I, [_I, _I]),
     "npi_segsum": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),

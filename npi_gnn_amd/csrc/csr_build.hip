@@ -34,14 +34,15 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 // key = key node, or N (sentinel, sorts behind every row) for dropped columns
 __global__ void make_keys_kernel(const int64_t* __restrict__ key_nodes,
                                  const int64_t* __restrict__ val_nodes, int64_t E, int64_t N,
+                                 int64_t n_cols, int drop_equal,
                                  uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
                                  int32_t* __restrict__ status) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     int64_t k = key_nodes[e], v = val_nodes[e];
-    bool bad = (k < 0) | (k >= N) | (v < 0) | (v >= N);
+    bool bad = (k < 0) | (k >= N) | (v < 0) | (v >= n_cols);
     if (bad) atomicOr(status, 1);
-    keys[e] = (bad || k == v) ? (uint32_t)N : (uint32_t)k;
+    keys[e] = (bad || (drop_equal && k == v)) ? (uint32_t)N : (uint32_t)k;
     vals[e] = (int32_t)e;
 }
 
@@ -212,6 +213,7 @@ __global__ void fill_entries_kernel(const uint32_t* __restrict__ keys, const int
 }
 
 __global__ void fill_rows_kernel(const int32_t* __restrict__ rowptr0, int64_t N, int loops,
+                                 int32_t loop_col_offset,
                                  int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
                                  int32_t* __restrict__ eid, int32_t* __restrict__ rowidx) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,7 +222,7 @@ __global__ void fill_rows_kernel(const int32_t* __restrict__ rowptr0, int64_t N,
     rowptr[r] = rowptr0[r] + add;
     if (loops && r < N) {
         int64_t q = (int64_t)rowptr0[r + 1] + r;     // last entry of row r
-        col[q] = (int32_t)r;
+        col[q] = (int32_t)r + loop_col_offset;
         if (eid) eid[q] = -1;
         if (rowidx) rowidx[q] = (int32_t)r;
     }
@@ -302,9 +304,20 @@ extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes,
                              int add_self_loops, int32_t* rowptr, int32_t* col, int32_t* eid,
                              int32_t* rowidx, int32_t* item_row, int32_t* status,
                              void* workspace, int64_t workspace_bytes, void* stream_) {
+    return npi_csr_build_ex(key_nodes, val_nodes, E, N, N, add_self_loops, 0, 1, rowptr, col, eid, rowidx,
+                            item_row, status, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
+                                int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int drop_equal,
+                                int32_t* rowptr, int32_t* col, int32_t* eid,
+                                int32_t* rowidx, int32_t* item_row, int32_t* status,
+                                void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(E >= 0 && N >= 0, "npi_csr_build: negative size");
+    NPI_REQUIRE(E >= 0 && N >= 0 && n_cols >= 0, "npi_csr_build: negative size");
     NPI_REQUIRE(E + N + 1 < (int64_t)0x7fffffff, "npi_csr_build: E + N does not fit int32");
+    NPI_REQUIRE(n_cols < (int64_t)0x7fffffff && loop_col_offset >= 0 && loop_col_offset + N <= (n_cols > N ? n_cols : N),
+                "npi_csr_build: column range does not fit");
     NPI_REQUIRE(rowptr && item_row && status && workspace, "npi_csr_build: null output");
     NPI_REQUIRE(E == 0 || (key_nodes && val_nodes && col), "npi_csr_build: null edge arrays");
     SortLayout L = sort_layout(E, N);
@@ -323,7 +336,7 @@ extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes,
 
     (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
     if (E > 0) {
-        make_keys_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(key_nodes, val_nodes, E, N, keys_a, vals_a, status);
+        make_keys_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(key_nodes, val_nodes, E, N, n_cols, drop_equal, keys_a, vals_a, status);
         int bits = 1;
         while (((int64_t)1 << bits) <= N) ++bits;       // keys lie in [0, N]
         int passes = (bits + 7) / 8;
@@ -341,7 +354,7 @@ extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes,
     row_bounds_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(keys_a, E, N, rowptr0);
     if (E > 0)
         fill_entries_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(keys_a, vals_a, val_nodes, E, N, add_self_loops, col, eid, rowidx);
-    fill_rows_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(rowptr0, N, add_self_loops, rowptr, col, eid, rowidx);
+    fill_rows_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(rowptr0, N, add_self_loops, (int32_t)loop_col_offset, rowptr, col, eid, rowidx);
     int64_t n_items = npi_num_items(E + (add_self_loops ? N : 0));
     item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, item_row);
     return check_launch("npi_csr_build");

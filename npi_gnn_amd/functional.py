@@ -36,12 +36,12 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     reduction (``npi_segsum``)."""
     dev = require_gpu(x, w, bias)
     x = _f32c(x, "x")
-    N, F = graph.num_nodes, x.size(1)
-    if x.size(0) != N:
-        raise ValueError(f"x has {x.size(0)} rows, graph has {N} nodes")
+    N, F = side.n_rows, x.size(1)                  # `graph` may be None for a stand-alone (sharded) side
+    if x.size(0) != side.n_cols:
+        raise ValueError(f"x has {x.size(0)} rows, the adjacency indexes a table of {side.n_cols}")
     if out is None:
         out = torch.empty((N, F), dtype=torch.float32, device=dev)
-    carry = graph.carry(side, F)
+    carry = side.carry(F)
     prof = _PROFILE
     if prof is not None:        # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

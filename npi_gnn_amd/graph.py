@@ -40,11 +40,36 @@ class CSRSide:
     n_items: int
     _inv_cnt: Optional[torch.Tensor] = None
     _carry: Dict[int, torch.Tensor] = field(default_factory=dict)
+    n_rows: int = -1          # output rows (key id space)
+    n_cols: int = -1          # rows of the feature table the entries index (== n_rows unless sharded)
+
+    def inv_count(self) -> torch.Tensor:
+        """1 / max(row length, 1): the scatter_mean divisor (count includes the self loop)."""
+        if self._inv_cnt is None:
+            dev = self.rowptr.device
+            out = torch.empty(self.n_rows, dtype=torch.float32, device=dev)
+            check(load().npi_row_inv_count(ptr(self.rowptr), self.n_rows, ptr(out), stream_ptr(dev)),
+                  "npi_row_inv_count")
+            self._inv_cnt = out
+        return self._inv_cnt
+
+    def carry(self, F: int) -> torch.Tensor:
+        """f32 scratch for rows cut by an item boundary; reused across calls of the same width."""
+        buf = self._carry.get(F)
+        if buf is None:
+            n = int(load().npi_segsum_carry_elems(self.nnz_max, F))
+            buf = torch.empty(n, dtype=torch.float32, device=self.rowptr.device)
+            self._carry[F] = buf
+        return buf
 
 
-def _build_side(key: torch.Tensor, val: torch.Tensor, E: int, N: int, self_loops: bool) -> CSRSide:
+def build_side(key: torch.Tensor, val: torch.Tensor, n_rows: int, n_cols: int, self_loops: bool = True,
+               loop_col_offset: int = 0, drop_equal: bool = True) -> CSRSide:
+    """CSR over ``n_rows`` key rows whose entries index a table of ``n_cols`` rows
+    (``npi_csr_build_ex``); with ``n_cols == n_rows`` and the defaults this is the plain build."""
     lib = load()
     dev = require_gpu(key, val)
+    E, N = int(key.numel()), int(n_rows)
     nnz_max = E + (N if self_loops else 0)
     n_items = int(lib.npi_num_items(nnz_max))
     i32 = dict(dtype=torch.int32, device=dev)
@@ -56,12 +81,19 @@ def _build_side(key: torch.Tensor, val: torch.Tensor, E: int, N: int, self_loops
     status = torch.empty(1, **i32)
     ws_bytes = int(lib.npi_csr_workspace_bytes(E, N))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.npi_csr_build(ptr(key), ptr(val), E, N, 1 if self_loops else 0, ptr(rowptr), ptr(col),
-                            ptr(eid), ptr(rowidx), ptr(item_row), ptr(status), ptr(ws), ws_bytes,
-                            stream_ptr(dev)), "npi_csr_build")
+    check(lib.npi_csr_build_ex(ptr(key), ptr(val), E, N, int(n_cols), 1 if self_loops else 0,
+                               int(loop_col_offset), 1 if drop_equal else 0, ptr(rowptr), ptr(col), ptr(eid),
+                               ptr(rowidx), ptr(item_row), ptr(status), ptr(ws), ws_bytes, stream_ptr(dev)),
+          "npi_csr_build_ex")
     if _DEBUG and int(status.item()) & 1:
         raise IndexError("edge_index holds a node id outside [0, num_nodes)")
-    return CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
+    side = CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
+    side.n_rows, side.n_cols = N, int(n_cols)
+    return side
+
+
+def _build_side(key: torch.Tensor, val: torch.Tensor, E: int, N: int, self_loops: bool) -> CSRSide:
+    return build_side(key, val, N, N, self_loops)
 
 
 class CSRGraph:
@@ -91,22 +123,10 @@ class CSRGraph:
         return self._by_src
 
     def inv_count(self, side: CSRSide) -> torch.Tensor:
-        """1 / max(row length, 1): the scatter_mean divisor (count includes the self loop)."""
-        if side._inv_cnt is None:
-            out = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
-            check(load().npi_row_inv_count(ptr(side.rowptr), self.num_nodes, ptr(out), stream_ptr(self.device)),
-                  "npi_row_inv_count")
-            side._inv_cnt = out
-        return side._inv_cnt
+        return side.inv_count()
 
     def carry(self, side: CSRSide, F: int) -> torch.Tensor:
-        """f32 scratch for rows cut by an item boundary; reused across calls of the same width."""
-        buf = side._carry.get(F)
-        if buf is None:
-            n = int(load().npi_segsum_carry_elems(side.nnz_max, F))
-            buf = torch.empty(n, dtype=torch.float32, device=self.device)
-            side._carry[F] = buf
-        return buf
+        return side.carry(F)
 
     def nnz(self) -> int:
         """Entries incl. self loops (device read; synchronises)."""

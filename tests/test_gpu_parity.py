@@ -255,3 +255,45 @@ def test_modules_drop_into_a_net1_style_stack(dev):
     opt.step()
     assert c1.weight.grad is not None and torch.isfinite(c1.weight.grad).all()
     assert not torch.equal(c1.weight.detach().cpu(), sd1["weight"])
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_sharded_backend_virtual_ranks_on_one_gpu(dev, world):
+    """with one GPU, run the W shards one after the other and emulate the all-gather,
+    to validate the sharded CSR (local rows x gathered-table columns) and both aggregation directions."""
+    from npi_gnn_amd import dist as ND
+    N, E, F = 5003, 60000, 256
+    ei = rand_edges(N, E, seed=21, hub=7)
+    x = torch.randn(N, F, generator=torch.Generator().manual_seed(2))
+    part = ND.StridedPartition(N, world)
+    table = torch.zeros(part.table_rows(), F)
+    table[part.padded(torch.arange(N))] = x
+    table_d = table.to(dev)
+    ref_fwd = R.sage_aggregate(x, ei)
+    ei2 = R.add_remaining_self_loops(ei, None, 1.0, N)[0]
+    ref_bwd = R.scatter_add(x.index_select(0, ei2[1]), ei2[0], N)      # transpose aggregation (sum)
+    outs_f, outs_b = [], []
+    for r in range(world):
+        by_dst, by_src = ND.local_edges(ei.to(dev), part, r)
+        be = ND.HipBackend(by_dst, by_src, part.n_local(r), part.table_rows(), r * part.n_per)
+        outs_f.append(be.aggregate_mean(table_d).cpu())
+        outs_b.append(be.aggregate_t(table_d).cpu())
+        cnt = torch.bincount(ei2[1], minlength=N).float()
+        assert torch.allclose(be.inv_count().cpu(), 1.0 / part.shard(cnt, r))
+    assert torch.allclose(part.unshard(outs_f), ref_fwd, atol=ATOL, rtol=RTOL)
+    assert torch.allclose(part.unshard(outs_b), ref_bwd, atol=ATOL * 30, rtol=RTOL)
+
+
+def test_sharded_layer_world1_matches_single_gpu_layer(dev):
+    from npi_gnn_amd import dist as ND
+    ei, x, W, b, go = _layer_case(3000, 20000, 256, 256, 5, True)
+    sg = ND.ShardedGraph(ei, 3000, 0, 1, dev)
+    layer = ND.ShardedSAGELayer(sg, W.to(dev), b.to(dev))
+    xl = x.to(dev).requires_grad_(True)
+    out = layer(xl)
+    out.backward(go.to(dev))
+    ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(x, ei, W, b, go)
+    assert torch.allclose(out.detach().cpu(), ref_out, atol=ATOL, rtol=RTOL)
+    assert torch.allclose(xl.grad.cpu(), ref_dx, atol=ATOL, rtol=RTOL)
+    assert torch.allclose(layer.weight.grad.cpu(), ref_dw, atol=ATOL * 60, rtol=1e-3)
+    assert torch.allclose(layer.bias.grad.cpu(), ref_db, atol=ATOL * 60, rtol=1e-3)
