@@ -153,6 +153,52 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
                           int64_t M, int64_t K, int64_t N,
                           float* workspace, int64_t workspace_elems, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * GATConv (PyG 1.4.2; absent from the reference tree, BASELINE.json configs[4]).  H heads of C
+ * channels, hfeat = x @ W is [N, H*C]; att is [H, 2C] (first C multiply the TARGET's features).
+ * The attention coefficient alpha of an entry is never stored: it is recomputed from four
+ * per-node, per-head scalars [N, H] -- a_dst, a_src (npi_gat_scores), m, s (npi_gat_softmax_stats):
+ *     alpha(i <- j) = exp(leaky_relu(a_dst[i] + a_src[j]) - m[i]) / (s[i] + 1e-16)
+ *
+ *   npi_gat_scores        `(cat[x_i, x_j] * att).sum(-1)` split into its two dot products
+ *   npi_gat_softmax_stats `utils.softmax`: scatter_max + scatter_add(exp) per target row
+ *   npi_gat_aggregate     by_source == 0: out[i] = sum_p alpha_p hfeat[col p] (+ bias)          (forward)
+ *                         by_source != 0: out[j] = sum_q alpha_q x[col q] + g_dst[j] att[:C] + g_src[j] att[C:]
+ *                                         over the by-source CSR                                (backward, d hfeat)
+ *   npi_gat_rowdot        D[i,h] = <a[i,h,:], b[i,h,:] - bias[h,:]>      (= sum_p alpha_p dalpha_p)
+ *   npi_gat_edge_grad     dz[p,h] = alpha_p (<dout_i, hfeat_j> - D_i) * leaky_relu'(z_p), by-target entry order
+ *   npi_seg_rowsum        out[r,h] = sum_{p in row r} vals[map ? map[p] : p, h]
+ *   npi_entry_transpose_map  map[q] = by-target position of by-source entry q
+ *   npi_gat_att_grad      datt[h,:C] = sum_i g_dst[i,h] hfeat[i,h,:],  datt[h,C:] likewise with g_src
+ * ------------------------------------------------------------------------------------------ */
+int npi_gat_scores(const float* hfeat, int64_t ldh, const float* att, int64_t N, int64_t H, int64_t C,
+                   float* a_dst, float* a_src, void* stream);
+int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                          const float* a_dst, const float* a_src, int64_t N, int64_t nnz_max, int64_t H,
+                          float negative_slope, float* m, float* s, void* stream);
+int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                      int64_t N, int64_t nnz_max, const float* x, int64_t ldx, float* out, int64_t ldo,
+                      int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
+                      const float* s, float negative_slope, int by_source, const float* bias,
+                      const float* g_dst, const float* g_src, const float* att,
+                      float* carry, void* stream);
+int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                   int64_t N, int64_t H, int64_t C, float* D, void* stream);
+int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                      int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
+                      const float* dout, int64_t ldd, int64_t H, int64_t C,
+                      const float* a_dst, const float* a_src, const float* m, const float* s,
+                      const float* D, float negative_slope, float* dz, void* stream);
+int npi_seg_rowsum(const int32_t* rowptr, const float* vals, const int32_t* map, int64_t N, int64_t H,
+                   float* out, void* stream);
+int npi_entry_transpose_map(const int32_t* src_eid, const int32_t* src_rowidx, const int32_t* src_rowptr,
+                            const int32_t* dst_rowptr, const int32_t* pos_dst_of_edge, int64_t N,
+                            int64_t nnz_max, int32_t* map, void* stream);
+int64_t npi_gat_att_grad_workspace_elems(int64_t N, int64_t H, int64_t C);
+int npi_gat_att_grad(const float* hfeat, int64_t ldh, const float* g_dst, const float* g_src,
+                     int64_t N, int64_t H, int64_t C, float* datt, float* workspace,
+                     int64_t workspace_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

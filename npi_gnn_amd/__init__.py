@@ -3,13 +3,13 @@
 Only what the path needs: ``csrc/`` (hand-written gfx950 kernels + the C ABI of
 ``include/npi_gnn.h``), ``graph`` (device CSR build), ``functional`` / ``nn`` (the PyG
 ``nn.Conv`` interface the reference calls at ``src/classes.py:48-52,62-70``) and ``dist``
-(edge/row sharding over RCCL).  The package directory is ``npi_gnn_amd`` because a hyphen cannot
+(row sharding over RCCL).  The package directory is ``npi_gnn_amd`` because a hyphen cannot
 be imported.
 """
 from ._lib import LIB_PATH, NpiError, load  # noqa: F401
 from .graph import CSRGraph, as_graph, set_debug  # noqa: F401
-from .functional import GCNNorm, gcn_conv, sage_conv, segsum  # noqa: F401
-from .nn import GCNConv, SAGEConv  # noqa: F401
+from .functional import GCNNorm, gat_conv, gcn_conv, sage_conv, segsum  # noqa: F401
+from .nn import GATConv, GCNConv, SAGEConv  # noqa: F401
 
-__all__ = ["CSRGraph", "as_graph", "set_debug", "GCNNorm", "gcn_conv", "sage_conv", "segsum",
-           "GCNConv", "SAGEConv", "NpiError", "load", "LIB_PATH"]
+__all__ = ["CSRGraph", "as_graph", "set_debug", "GCNNorm", "gat_conv", "gcn_conv", "sage_conv", "segsum",
+           "GATConv", "GCNConv", "SAGEConv", "NpiError", "load", "LIB_PATH"]

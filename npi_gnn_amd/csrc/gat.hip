@@ -1,0 +1,406 @@
+// GATConv (PyG 1.4.2; SURVEY.md 8(a) row a8, BASELINE.json configs[4]) on the destination-sorted CSR.
+//   h = x W;  e_p = leaky_relu(<h_i, att[:C]> + <h_j, att[C:]>) for entry p = (i <- j), self loops included;
+//   alpha = softmax of e over the entries of row i (exp(e - max) / (sum + 1e-16));  out_i = sum_p alpha_p h_j (+ b)
+// GATConv is absent from the reference tree ("parity unpinned"); the formulas are the
+// published PyG 1.4.2 ones.
+//
+// alpha is never stored: every kernel recomputes it from four per-node, per-head scalars
+// (a_dst, a_src, row max m, row sum s), so the same numbers serve the by-target CSR (forward) and
+// the by-source CSR (backward) and no per-edge array has to be permuted between the two.
+// The weighted aggregation itself is segsum.hip's kernel in W_GAT_DST / W_GAT_SRC mode.
+#include "segsum.h"
+
+namespace npi {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+__device__ __forceinline__ float lrelu_(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// a_dst[i,h] = <h[i,h,:], att[h,:C]>, a_src[i,h] = <h[i,h,:], att[h,C:]>; one wave per node
+__global__ void __launch_bounds__(256)
+gat_scores_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ att, int N, int H, int C,
+                  float* __restrict__ a_dst, float* __restrict__ a_src) {
+    const int lane = lane_id();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    for (int hd = 0; hd < H; ++hd) {
+        const float* __restrict__ row = h + (int64_t)i * ldh + (int64_t)hd * C;
+        const float* __restrict__ at = att + (int64_t)hd * 2 * C;
+        float pd = 0.f, ps = 0.f;
+        for (int c = lane; c < C; c += WAVE) {
+            const float v = row[c];
+            pd = fmaf(v, at[c], pd);
+            ps = fmaf(v, at[C + c], ps);
+        }
+        pd = wave_sum(pd);
+        ps = wave_sum(ps);
+        if (lane == 0) {
+            a_dst[(int64_t)i * H + hd] = pd;
+            a_src[(int64_t)i * H + hd] = ps;
+        }
+    }
+}
+
+// D[i,h] = <a[i,h,:], b[i,h,:] - bias[h,:]>   (softmax backward: sum_p alpha_p dalpha_p = <dout_i, out_i - b>)
+__global__ void __launch_bounds__(256)
+gat_rowdot_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                  const float* __restrict__ bias, int N, int H, int C, float* __restrict__ D) {
+    const int lane = lane_id();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    for (int hd = 0; hd < H; ++hd) {
+        const float* __restrict__ ra = a + (int64_t)i * lda + (int64_t)hd * C;
+        const float* __restrict__ rb = b + (int64_t)i * ldb + (int64_t)hd * C;
+        float p = 0.f;
+        for (int c = lane; c < C; c += WAVE) p = fmaf(ra[c], rb[c] - (bias ? bias[hd * C + c] : 0.f), p);
+        p = wave_sum(p);
+        if (lane == 0) D[(int64_t)i * H + hd] = p;
+    }
+}
+
+// ---- segment softmax statistics: m[i,h] = max_p e_p, s[i,h] = sum_p exp(e_p - m) -------------------
+constexpr int GAT_HEAVY = 4096;      // rows longer than this go to the workgroup-per-row kernel
+
+__global__ void __launch_bounds__(256)
+gat_softmax_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                        const float* __restrict__ a_dst, const float* __restrict__ a_src, int N, int H,
+                        float slope, float* __restrict__ m, float* __restrict__ s) {
+    const int lane = lane_id();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int b = rowptr[i], e = rowptr[i + 1];
+    if (e - b > GAT_HEAVY) return;
+    for (int hd = 0; hd < H; ++hd) {
+        const float ad = a_dst[(int64_t)i * H + hd];
+        float mx = -3.0e38f;
+        for (int p = b + lane; p < e; p += WAVE) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
+        mx = wave_max(mx);
+        if (e == b) mx = 0.f;
+        float sum = 0.f;
+        for (int p = b + lane; p < e; p += WAVE) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
+        sum = wave_sum(sum);
+        if (lane == 0) {
+            m[(int64_t)i * H + hd] = mx;
+            s[(int64_t)i * H + hd] = sum;
+        }
+    }
+}
+
+// one workgroup per 256-entry item; it owns the heavy rows whose FIRST entry lies in the item
+__global__ void __launch_bounds__(256)
+gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                         const int32_t* __restrict__ item_row, const float* __restrict__ a_dst,
+                         const float* __restrict__ a_src, int N, int H, float slope,
+                         float* __restrict__ m, float* __restrict__ s) {
+    __shared__ int heavy[256];
+    __shared__ int n_heavy;
+    __shared__ float red[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int item = blockIdx.x;
+    const int nnz = rowptr[N];
+    const int k0 = item * NPI_ITEM_EDGES, k1 = k0 + NPI_ITEM_EDGES;
+    if (k0 >= nnz) return;
+    if (t == 0) n_heavy = 0;
+    __syncthreads();
+    int first = item_row[item];
+    if (rowptr[first] < k0) ++first;                 // that row started in an earlier item
+    const int r = first + t;
+    if (r < N) {
+        const int b = rowptr[r];
+        if (b < k1 && b < nnz && rowptr[r + 1] - b > GAT_HEAVY) heavy[atomicAdd(&n_heavy, 1)] = r;
+    }
+    __syncthreads();
+    const int nh = n_heavy;
+    for (int q = 0; q < nh; ++q) {
+        const int i = heavy[q];
+        const int b = rowptr[i], e = rowptr[i + 1];
+        for (int hd = 0; hd < H; ++hd) {
+            const float ad = a_dst[(int64_t)i * H + hd];
+            float mx = -3.0e38f;
+            for (int p = b + t; p < e; p += 256) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
+            mx = wave_max(mx);
+            if (lane == 0) red[wave] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            __syncthreads();
+            float sum = 0.f;
+            for (int p = b + t; p < e; p += 256) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
+            sum = wave_sum(sum);
+            if (lane == 0) red[wave] = sum;
+            __syncthreads();
+            if (t == 0) {
+                m[(int64_t)i * H + hd] = mx;
+                s[(int64_t)i * H + hd] = (red[0] + red[1]) + (red[2] + red[3]);    // fixed order
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- backward: per-entry score gradient over the by-target CSR ------------------------------------------
+//   dalpha_p = <dout_i[h], hfeat_j[h]>;  de_p = alpha_p (dalpha_p - D_i);  dz_p = de_p * lrelu'(z_p)
+// one wave per 256-entry item; dout_i is reloaded when the row changes, hfeat_j gathered per entry
+template <int NCH>
+__global__ void __launch_bounds__(256)
+gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                     const int32_t* __restrict__ rowidx, int N, int n_items,
+                     const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ dout, int64_t ldd,
+                     int H, int C, const float* __restrict__ a_dst, const float* __restrict__ a_src,
+                     const float* __restrict__ m, const float* __restrict__ s, const float* __restrict__ D,
+                     float slope, float* __restrict__ dz) {
+    constexpr int U = (NCH <= 2) ? 4 : 2;
+    const int lane = lane_id();
+    const int item = uniform_i(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= n_items) return;
+    const int nnz = rowptr[N];
+    const int k0 = item * NPI_ITEM_EDGES;
+    if (k0 >= nnz) return;
+    const int k1 = min(k0 + NPI_ITEM_EDGES, nnz);
+    const int F = H * C;
+    bool act[NCH];
+    int foff[NCH], hd[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        foff[c] = (c * WAVE + lane) * 4;
+        act[c] = foff[c] < F;
+        hd[c] = act[c] ? foff[c] / C : -1;
+    }
+    float4 dr[NCH];
+    int cur = -1;
+    for (int kb = k0; kb < k1; kb += WAVE) {
+        const int nb = min(WAVE, k1 - kb);
+        const int cv = (lane < nb) ? col[kb + lane] : 0;
+        const int rv = (lane < nb) ? rowidx[kb + lane] : 0;
+        for (int j = 0; j < nb; j += U) {
+            float4 hv[U][NCH];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cu = bcast_i(cv, min(j + u, nb - 1));
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    hv[u][c] = act[c] ? *reinterpret_cast<const float4*>(hfeat + (int64_t)cu * ldh + foff[c])
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u >= nb) break;
+                const int i = bcast_i(rv, j + u);
+                const int cu = bcast_i(cv, j + u);
+                if (i != cur) {
+                    cur = i;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        dr[c] = act[c] ? *reinterpret_cast<const float4*>(dout + (int64_t)i * ldd + foff[c])
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                for (int h = 0; h < H; ++h) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        if (hd[c] == h)
+                            p += dr[c].x * hv[u][c].x + dr[c].y * hv[u][c].y + dr[c].z * hv[u][c].z + dr[c].w * hv[u][c].w;
+                    p = wave_sum(p);
+                    if (lane == 0) {
+                        const int64_t ii = (int64_t)i * H + h;
+                        const float z = a_dst[ii] + a_src[(int64_t)cu * H + h];
+                        const float alpha = expf(lrelu_(z, slope) - m[ii]) / (s[ii] + 1e-16f);
+                        const float de = alpha * (p - D[ii]);
+                        dz[(int64_t)(kb + j + u) * H + h] = de * (z > 0.f ? 1.f : slope);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// out[r,h] = sum over the entries p of row r of vals[idx(p), h], idx = map ? map[p] : p; wave per row
+__global__ void __launch_bounds__(256)
+seg_rowsum_scalar_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals,
+                         const int32_t* __restrict__ map, int N, int H, float* __restrict__ out) {
+    const int lane = lane_id();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int b = rowptr[r], e = rowptr[r + 1];
+    for (int hd = 0; hd < H; ++hd) {
+        float sum = 0.f;
+        for (int p = b + lane; p < e; p += WAVE) {
+            const int64_t q = map ? map[p] : p;
+            sum += vals[q * H + hd];
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) out[(int64_t)r * H + hd] = sum;
+    }
+}
+
+// map[q] = position in the by-target CSR of by-source entry q (same directed edge; loops map to loops)
+__global__ void entry_transpose_map_kernel(const int32_t* __restrict__ src_eid, const int32_t* __restrict__ src_rowidx,
+                                           const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ dst_rowptr,
+                                           const int32_t* __restrict__ pos_dst_of_edge, int N, int64_t nnz_max,
+                                           int32_t* __restrict__ map) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz_max || q >= src_rowptr[N]) return;
+    const int e = src_eid[q];
+    map[q] = e >= 0 ? pos_dst_of_edge[e] : dst_rowptr[src_rowidx[q] + 1] - 1;
+}
+
+// datt partials: part[chunk][0][h*C+c] = sum_i g_dst[i,h] hfeat[i,h*C+c], part[chunk][1][..] with g_src
+constexpr int ATT_ROWS = 2048;
+__global__ void __launch_bounds__(256)
+gat_att_grad_partial_kernel(const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ g_dst,
+                            const float* __restrict__ g_src, int N, int H, int C, float* __restrict__ part) {
+    const int F = H * C;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    const int hd = c / C;
+    const int rbeg = blockIdx.y * ATT_ROWS, rend = min(N, rbeg + ATT_ROWS);
+    float sd = 0.f, ss = 0.f;
+    for (int i = rbeg; i < rend; ++i) {
+        const float v = hfeat[(int64_t)i * ldh + c];
+        sd = fmaf(g_dst[(int64_t)i * H + hd], v, sd);
+        ss = fmaf(g_src[(int64_t)i * H + hd], v, ss);
+    }
+    part[((int64_t)blockIdx.y * 2 + 0) * F + c] = sd;
+    part[((int64_t)blockIdx.y * 2 + 1) * F + c] = ss;
+}
+__global__ void gat_att_grad_reduce_kernel(const float* __restrict__ part, int nchunks, int H, int C,
+                                           float* __restrict__ datt) {
+    const int F = H * C;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over 2*F
+    if (idx >= 2 * F) return;
+    const int which = idx / F, c = idx % F;
+    float sum = 0.f;
+    for (int z = 0; z < nchunks; ++z) sum += part[((int64_t)z * 2 + which) * F + c];
+    const int hd = c / C, cc = c % C;
+    datt[(int64_t)hd * 2 * C + which * C + cc] = sum;
+}
+
+}  // namespace npi
+
+using namespace npi;
+
+extern "C" int npi_gat_scores(const float* h, int64_t ldh, const float* att, int64_t N, int64_t H, int64_t C,
+                              float* a_dst, float* a_src, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && H > 0 && C > 0 && ldh >= H * C, "npi_gat_scores: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(h && att && a_dst && a_src, "npi_gat_scores: null pointer");
+    gat_scores_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(h, ldh, att, (int)N, (int)H, (int)C, a_dst, a_src);
+    return check_launch("npi_gat_scores");
+}
+
+extern "C" int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                              int64_t N, int64_t H, int64_t C, float* D, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && H > 0 && C > 0, "npi_gat_rowdot: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(a && b && D, "npi_gat_rowdot: null pointer");
+    gat_rowdot_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, D);
+    return check_launch("npi_gat_rowdot");
+}
+
+extern "C" int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                                     const float* a_dst, const float* a_src, int64_t N, int64_t nnz_max, int64_t H,
+                                     float slope, float* m, float* s, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && H > 0 && nnz_max >= 0, "npi_gat_softmax_stats: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && item_row && a_dst && a_src && m && s, "npi_gat_softmax_stats: null pointer");
+    gat_softmax_rows_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, col, a_dst, a_src, (int)N, (int)H, slope, m, s);
+    const int64_t n_items = npi_num_items(nnz_max);
+    if (n_items > 0)
+        gat_softmax_heavy_kernel<<<(unsigned)n_items, 256, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)H, slope, m, s);
+    return check_launch("npi_gat_softmax_stats");
+}
+
+extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                                 int64_t N, int64_t nnz_max, const float* x, int64_t ldx, float* out, int64_t ldo,
+                                 int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
+                                 const float* s, float slope, int by_source, const float* bias,
+                                 const float* g_dst, const float* g_src, const float* att,
+                                 float* carry, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && nnz_max > 0 && H > 0 && C > 0, "npi_gat_aggregate: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && col && item_row && x && out && a_dst && a_src && m && s && carry, "npi_gat_aggregate: null pointer");
+    NPI_REQUIRE(ldx >= H * C && ldo >= H * C, "npi_gat_aggregate: leading dimension too small");
+    SegParams P{};
+    P.rowptr = rowptr; P.col = col; P.item_row = item_row;
+    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
+    P.x = x; P.ldx = ldx; P.out = out; P.ldo = ldo; P.F = (int)(H * C);
+    P.carry = carry; P.w = nullptr; P.bias = bias;
+    P.H = (int)H; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.m = m; P.s = s; P.slope = slope;
+    P.g_dst = g_dst; P.g_src = g_src; P.att = att;
+    return segsum_run(P, by_source ? W_GAT_SRC : W_GAT_DST, 0, nnz_max, stream);
+}
+
+extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                                 int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
+                                 const float* dout, int64_t ldd, int64_t H, int64_t C,
+                                 const float* a_dst, const float* a_src, const float* m, const float* s,
+                                 const float* D, float slope, float* dz, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && nnz_max >= 0 && H > 0 && C > 0, "npi_gat_edge_grad: bad size");
+    if (N == 0 || nnz_max == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && col && rowidx && hfeat && dout && a_dst && a_src && m && s && D && dz, "npi_gat_edge_grad: null pointer");
+    const int64_t F = H * C;
+    NPI_REQUIRE(F % 4 == 0 && C % 4 == 0 && ldh % 4 == 0 && ldd % 4 == 0 && F <= 1024 &&
+                ((uintptr_t)hfeat % 16 == 0) && ((uintptr_t)dout % 16 == 0),
+                "npi_gat_edge_grad: needs 16-B aligned rows, out_channels % 4 == 0, heads*out_channels <= 1024");
+    const int n_items = (int)npi_num_items(nnz_max);
+    const unsigned grid = (unsigned)ceil_div(n_items, 4);
+    const int nch = (int)ceil_div(F, 256);
+#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz)
+    if (nch == 1) NPI_EG(1); else if (nch == 2) NPI_EG(2); else if (nch == 3) NPI_EG(3); else NPI_EG(4);
+#undef NPI_EG
+    return check_launch("npi_gat_edge_grad");
+}
+
+extern "C" int npi_seg_rowsum(const int32_t* rowptr, const float* vals, const int32_t* map, int64_t N, int64_t H,
+                              float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && H > 0, "npi_seg_rowsum: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && vals && out, "npi_seg_rowsum: null pointer");
+    seg_rowsum_scalar_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out);
+    return check_launch("npi_seg_rowsum");
+}
+
+extern "C" int npi_entry_transpose_map(const int32_t* src_eid, const int32_t* src_rowidx, const int32_t* src_rowptr,
+                                       const int32_t* dst_rowptr, const int32_t* pos_dst_of_edge, int64_t N,
+                                       int64_t nnz_max, int32_t* map, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && nnz_max >= 0, "npi_entry_transpose_map: bad size");
+    if (nnz_max == 0) return NPI_OK;
+    NPI_REQUIRE(src_eid && src_rowidx && src_rowptr && dst_rowptr && map, "npi_entry_transpose_map: null pointer");
+    entry_transpose_map_kernel<<<(unsigned)ceil_div(nnz_max, 256), 256, 0, stream>>>(src_eid, src_rowidx, src_rowptr, dst_rowptr, pos_dst_of_edge, (int)N, nnz_max, map);
+    return check_launch("npi_entry_transpose_map");
+}
+
+extern "C" int64_t npi_gat_att_grad_workspace_elems(int64_t N, int64_t H, int64_t C) {
+    return ceil_div(N > 0 ? N : 1, ATT_ROWS) * 2 * H * C;
+}
+
+extern "C" int npi_gat_att_grad(const float* hfeat, int64_t ldh, const float* g_dst, const float* g_src,
+                                int64_t N, int64_t H, int64_t C, float* datt, float* workspace,
+                                int64_t workspace_elems, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && H > 0 && C > 0, "npi_gat_att_grad: bad size");
+    NPI_REQUIRE(hfeat && g_dst && g_src && datt && workspace, "npi_gat_att_grad: null pointer");
+    if (workspace_elems < npi_gat_att_grad_workspace_elems(N, H, C)) {
+        set_error("npi_gat_att_grad: workspace too small");
+        return NPI_ERR_WORKSPACE;
+    }
+    const int nchunks = (int)ceil_div(N > 0 ? N : 1, ATT_ROWS);
+    const int F = (int)(H * C);
+    gat_att_grad_partial_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)nchunks), 256, 0, stream>>>(hfeat, ldh, g_dst, g_src, (int)N, (int)H, (int)C, workspace);
+    gat_att_grad_reduce_kernel<<<(unsigned)ceil_div(2 * F, 256), 256, 0, stream>>>(workspace, nchunks, (int)H, (int)C, datt);
+    return check_launch("npi_gat_att_grad");
+}

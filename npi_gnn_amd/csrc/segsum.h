@@ -1,0 +1,37 @@
+// Parameter block of the segmented-reduction kernel (segsum.hip), shared with gat.hip.
+#pragma once
+#include "npi_common.h"
+
+namespace npi {
+
+enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3 };
+
+struct SegParams {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const int32_t* item_row;
+    int N, n_items;
+    const float* x;
+    int64_t ldx;
+    float* out;
+    int64_t ldo;
+    int F;
+    float* carry;
+    const float* w;          // W_ARRAY: one weight per entry
+    const float* bias;       // [F] or null, added after scaling
+    // GAT: H heads of C channels (F == H * C), per-node per-head scalars [N, H]
+    int H, C;
+    const float* a_dst;
+    const float* a_src;
+    const float* m;          // row max of the scores
+    const float* s;          // row sum of exp(score - max)
+    float slope;             // leaky_relu negative slope
+    // W_GAT_SRC epilogue: out[j, h, c] += g_dst[j,h] * att[h, c] + g_src[j,h] * att[h, C + c]
+    const float* g_dst;
+    const float* g_src;
+    const float* att;        // [H, 2C]
+};
+
+int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, hipStream_t stream);
+
+}  // namespace npi

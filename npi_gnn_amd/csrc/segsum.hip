@@ -12,7 +12,15 @@
 // entry has been added -- so a 540k-entry hub row and a 3-entry row cost the same per entry.
 // Rows cut by an item boundary leave f32 partial sums in `carry`; the item that holds the row's
 // first entry adds them up in item order (segsum_fixup_kernel) => bitwise reproducible.
-#include "npi_common.h"
+//
+// The per-entry weight comes in four flavours (WMODE):
+//   W_NONE     1                                   SAGEConv (mean or sum)
+//   W_ARRAY    w[p]                                GCNConv norm, any per-entry weight
+//   W_GAT_DST  exp(lrelu(a_dst[row] + a_src[col]) - m[row]), row scale 1/(s[row] + 1e-16)
+//              = GATConv's softmax(alpha) * x_j on the by-target CSR, alpha never stored
+//   W_GAT_SRC  the same alpha seen from the by-source CSR (backward: d h_j = sum_i alpha_ij d out_i),
+//              plus the rank-1 terms of the attention-score gradient in the epilogue
+#include "segsum.h"
 
 namespace npi {
 
@@ -34,85 +42,128 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&d)
     if constexpr (VEC == 4) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
 }
 template <int VEC>
-__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d)[VEC], float s) {
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d)[VEC]) {
     using V = typename vec_of<VEC>::type;
     V v;
-    if constexpr (VEC == 1) { v = d[0] * s; }
-    if constexpr (VEC == 2) { v.x = d[0] * s; v.y = d[1] * s; }
-    if constexpr (VEC == 4) { v.x = d[0] * s; v.y = d[1] * s; v.z = d[2] * s; v.w = d[3] * s; }
+    if constexpr (VEC == 1) { v = d[0]; }
+    if constexpr (VEC == 2) { v.x = d[0]; v.y = d[1]; }
+    if constexpr (VEC == 4) { v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3]; }
     *reinterpret_cast<V*>(p) = v;
 }
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // rows in flight per wavefront: ~32 VGPRs of outstanding loads
 template <int VEC, int NCH> struct inflight { static constexpr int value = (32 / (VEC * NCH)) > 8 ? 8 : ((32 / (VEC * NCH)) < 2 ? 2 : (32 / (VEC * NCH))); };
 
-template <int VEC, int NCH, bool WEIGHTED, bool MEAN, bool EXACT>
+// lane geometry shared by the main and the fix-up kernel
+template <int VEC, int NCH, int WMODE, bool EXACT>
+struct Lanes {
+    bool act[NCH];
+    int foff[NCH];
+    int hd[NCH];       // head of this lane's columns in chunk c (GAT modes)
+    __device__ __forceinline__ void init(const SegParams& P) {
+        const int lane = lane_id();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            foff[c] = (c * WAVE + lane) * VEC;
+            act[c] = EXACT ? true : (foff[c] < P.F);
+            hd[c] = (WMODE >= W_GAT_DST && act[c]) ? foff[c] / P.C : 0;
+        }
+    }
+};
+
+// scale, bias and epilogue of a finished row r, then the store
+template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+__device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, NCH, WMODE, EXACT>& L,
+                                           const float (&acc)[NCH][VEC], int r, int row_len) {
+    float* __restrict__ dst = P.out + (int64_t)r * P.ldo;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (!L.act[c]) continue;
+        float sc = 1.f;
+        if (MEAN) sc = 1.f / (float)max(row_len, 1);
+        if (WMODE == W_GAT_DST) sc = 1.f / (P.s[(int64_t)r * P.H + L.hd[c]] + 1e-16f);
+        float t[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            t[q] = fmaf(acc[c][q], sc, P.bias ? P.bias[L.foff[c] + q] : 0.f);
+        }
+        if (WMODE == W_GAT_SRC && P.g_dst != nullptr) {
+            const int h = L.hd[c];
+            const float gd = P.g_dst[(int64_t)r * P.H + h], gs = P.g_src[(int64_t)r * P.H + h];
+            const float* __restrict__ at = P.att + (int64_t)h * 2 * P.C + (L.foff[c] - h * P.C);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) t[q] += gd * at[q] + gs * at[P.C + q];
+        }
+        store_row<VEC>(dst + L.foff[c], t);
+    }
+}
+
+template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
-segsum_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-              const int32_t* __restrict__ item_row, const float* __restrict__ w,
-              int N, int n_items, const float* __restrict__ x, int64_t ldx,
-              float* __restrict__ out, int64_t ldo, int F, float* __restrict__ carry,
-              const float* __restrict__ bias) {
+segsum_kernel(SegParams P) {
     constexpr int U = inflight<VEC, NCH>::value;
     const int lane = lane_id();
     const int item = uniform_i(blockIdx.x * SEG_WAVES + (threadIdx.x >> 6));
-    if (item >= n_items) return;
-    const int nnz = rowptr[N];
+    if (item >= P.n_items) return;
+    const int N = P.N;
+    const int nnz = P.rowptr[N];
     const int k0 = item * T;
     if (k0 >= nnz) return;
     const int k1 = min(k0 + T, nnz);
+    const int F = P.F;
 
-    bool act[NCH];
-    int foff[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        foff[c] = (c * WAVE + lane) * VEC;
-        act[c] = EXACT ? true : (foff[c] < F);
-    }
+    Lanes<VEC, NCH, WMODE, EXACT> L;
+    L.init(P);
 
-    int r = uniform_i(item_row[item]);
-    int row_start = uniform_i(rowptr[r]);
+    int r = uniform_i(P.item_row[item]);
+    int row_start = uniform_i(P.rowptr[r]);
     bool head = row_start < k0;          // row r began in an earlier item
     // window of upcoming row ends: lane l holds rowptr[r + 1 + l]
-    int wbase = r;
-    int rend_v = rowptr[min(wbase + 1 + lane, N)];
+    int rend_v = P.rowptr[min(r + 1 + lane, N)];
     int ri = 0;
     int row_end = bcast_i(rend_v, 0);
 
     float acc[NCH][VEC];
-    float bv[NCH][VEC];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            acc[c][v] = 0.f;
-            bv[c][v] = (bias && act[c]) ? bias[foff[c] + v] : 0.f;
-        }
+        for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
 
-    auto write_row = [&](float* __restrict__ dst, float s) {
+    // per-row constants of the GAT weight (per lane: the head of its columns)
+    float rs_a[NCH], rs_m[NCH];
+    auto open_row = [&]() {
+        if (WMODE == W_GAT_DST) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            if (act[c]) store_row<VEC>(dst + foff[c], acc[c], s);
-    };
-    auto write_out = [&](float* __restrict__ dst, float s) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            if (act[c]) {
-                float t[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) t[v] = fmaf(acc[c][v], s, bv[c][v]);
-                store_row<VEC>(dst + foff[c], t, 1.f);
+            for (int c = 0; c < NCH; ++c) {
+                const int64_t i = (int64_t)min(r, N - 1) * P.H + L.hd[c];
+                rs_a[c] = P.a_dst[i];
+                rs_m[c] = P.m[i];
             }
+        } else if (WMODE == W_GAT_SRC) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                rs_a[c] = P.a_src[(int64_t)min(r, N - 1) * P.H + L.hd[c]];
+                rs_m[c] = 0.f;
+            }
+        }
+    };
+    open_row();
+
+    auto write_carry = [&](int slot) {
+        float* __restrict__ dst = P.carry + ((int64_t)item * 2 + slot) * F;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (L.act[c]) store_row<VEC>(dst + L.foff[c], acc[c]);
     };
     // row r is complete (its last entry has been accumulated, or it is empty)
     auto close_row = [&]() {
         if (head) {
-            write_row(carry + ((int64_t)item * 2 + 0) * F, 1.f);
+            write_carry(0);
             head = false;
         } else {
-            float s = 1.f;
-            if (MEAN) s = 1.f / (float)max(row_end - row_start, 1);
-            write_out(out + (int64_t)r * ldo, s);
+            finish_row<VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, row_end - row_start);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -121,30 +172,48 @@ segsum_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ co
         ++r;
         row_start = row_end;
         if (++ri == WAVE) {
-            wbase = r;
-            rend_v = rowptr[min(wbase + 1 + lane, N)];
+            rend_v = P.rowptr[min(r + 1 + lane, N)];
             ri = 0;
         }
         row_end = bcast_i(rend_v, ri);
+        if (WMODE >= W_GAT_DST) open_row();
+    };
+
+    // one gathered row (+ its weight) into the accumulators
+    auto entry_weight = [&](int c, float g0, float g1, float g2, float ws) -> float {
+        if (WMODE == W_ARRAY) return ws;
+        if (WMODE == W_GAT_DST) return expf(lrelu(rs_a[c] + g0, P.slope) - rs_m[c]);
+        if (WMODE == W_GAT_SRC) return expf(lrelu(g0 + rs_a[c], P.slope) - g1) * g2;
+        return 1.f;
     };
 
     for (int kb = k0; kb < k1; kb += WAVE) {
         const int nb = min(WAVE, k1 - kb);
-        const int cv = (lane < nb) ? col[kb + lane] : 0;
+        const int cv = (lane < nb) ? P.col[kb + lane] : 0;
         float wv = 1.f;
-        if (WEIGHTED) wv = (lane < nb) ? w[kb + lane] : 0.f;
+        if (WMODE == W_ARRAY) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
         int j = 0;
         for (; j + U <= nb; j += U) {
             float v[U][NCH][VEC];
+            float g0[U][NCH], g1[U][NCH], g2[U][NCH];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float* src = x + (int64_t)bcast_i(cv, j + u) * ldx;
+                const int cu = bcast_i(cv, j + u);
+                const float* src = P.x + (int64_t)cu * P.ldx;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    if (act[c]) load_row<VEC>(src + foff[c], v[u][c]);
+                    if (L.act[c]) load_row<VEC>(src + L.foff[c], v[u][c]);
                     else {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) v[u][c][q] = 0.f;
+                    }
+                    g0[u][c] = g1[u][c] = g2[u][c] = 0.f;
+                    if (WMODE == W_GAT_DST) g0[u][c] = P.a_src[(int64_t)cu * P.H + L.hd[c]];
+                    if (WMODE == W_GAT_SRC) {
+                        const int64_t i = (int64_t)cu * P.H + L.hd[c];
+                        g0[u][c] = P.a_dst[i];
+                        g1[u][c] = P.m[i];
+                        g2[u][c] = 1.f / (P.s[i] + 1e-16f);
                     }
                 }
             }
@@ -152,43 +221,57 @@ segsum_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ co
             for (int u = 0; u < U; ++u) {
                 const int k = kb + j + u;
                 while (k == row_end) close_row();
-                const float ws = WEIGHTED ? bcast_f(wv, j + u) : 1.f;
+                const float ws = (WMODE == W_ARRAY) ? bcast_f(wv, j + u) : 1.f;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c)
+                for (int c = 0; c < NCH; ++c) {
+                    const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
 #pragma unroll
                     for (int q = 0; q < VEC; ++q)
-                        acc[c][q] = WEIGHTED ? fmaf(ws, v[u][c][q], acc[c][q]) : (acc[c][q] + v[u][c][q]);
+                        acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[u][c][q]) : fmaf(we, v[u][c][q], acc[c][q]);
+                }
             }
         }
         for (; j < nb; ++j) {       // ragged tail of the last item only
             float v[NCH][VEC];
-            const float* src = x + (int64_t)bcast_i(cv, j) * ldx;
+            float g0[NCH], g1[NCH], g2[NCH];
+            const int cu = bcast_i(cv, j);
+            const float* src = P.x + (int64_t)cu * P.ldx;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (act[c]) load_row<VEC>(src + foff[c], v[c]);
+                if (L.act[c]) load_row<VEC>(src + L.foff[c], v[c]);
                 else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) v[c][q] = 0.f;
                 }
+                g0[c] = g1[c] = g2[c] = 0.f;
+                if (WMODE == W_GAT_DST) g0[c] = P.a_src[(int64_t)cu * P.H + L.hd[c]];
+                if (WMODE == W_GAT_SRC) {
+                    const int64_t i = (int64_t)cu * P.H + L.hd[c];
+                    g0[c] = P.a_dst[i];
+                    g1[c] = P.m[i];
+                    g2[c] = 1.f / (P.s[i] + 1e-16f);
+                }
             }
             const int k = kb + j;
             while (k == row_end) close_row();
-            const float ws = WEIGHTED ? bcast_f(wv, j) : 1.f;
+            const float ws = (WMODE == W_ARRAY) ? bcast_f(wv, j) : 1.f;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+            for (int c = 0; c < NCH; ++c) {
+                const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
 #pragma unroll
                 for (int q = 0; q < VEC; ++q)
-                    acc[c][q] = WEIGHTED ? fmaf(ws, v[c][q], acc[c][q]) : (acc[c][q] + v[c][q]);
+                    acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[c][q]) : fmaf(we, v[c][q], acc[c][q]);
+            }
         }
     }
     // entries exhausted at k1
     if (row_end == k1) {
         close_row();                                     // row r ends exactly here
-        while (r < N && row_end == k1) close_row();      // empty rows behind it (out = 0)
+        while (r < N && row_end == k1) close_row();      // empty rows behind it (out = bias)
     } else if (head) {
-        write_row(carry + ((int64_t)item * 2 + 0) * F, 1.f);   // one row spans the whole item
+        write_carry(0);                                  // one row spans the whole item
     } else {
-        write_row(carry + ((int64_t)item * 2 + 1) * F, 1.f);   // row continues in the next item
+        write_carry(1);                                  // row continues in the next item
     }
 }
 
@@ -200,43 +283,37 @@ segsum_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ co
 constexpr int FIX_COOP_MIN = 16;     // chain length from which all 4 waves cooperate
 constexpr int FIX_U = 8;
 
-template <int VEC, int NCH, bool MEAN, bool EXACT>
+template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
-segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
-                    int N, int n_items, float* __restrict__ out, int64_t ldo, int F,
-                    const float* __restrict__ carry, const float* __restrict__ bias) {
+segsum_fixup_kernel(SegParams P) {
     __shared__ float red[SEG_WAVES][NCH * VEC * WAVE];
     const int lane = lane_id();
     const int wave = uniform_i(threadIdx.x >> 6);
     const int item = blockIdx.x;
-    const int nnz = rowptr[N];
+    const int N = P.N, F = P.F;
+    const int nnz = P.rowptr[N];
     const int k0 = item * T;
     const int k1 = k0 + T;
     if (k1 >= nnz) return;                               // last item: nothing continues
-    const int r = uniform_i(item_row[item + 1]);         // row holding entry k1
-    const int rs = uniform_i(rowptr[r]);
+    const int r = uniform_i(P.item_row[item + 1]);       // row holding entry k1
+    const int rs = uniform_i(P.rowptr[r]);
     if (rs >= k1 || rs < k0) return;                     // not cut here / owned by an earlier item
-    const int re = uniform_i(rowptr[r + 1]);
+    const int re = uniform_i(P.rowptr[r + 1]);
     const int last = (re - 1) / T;
-    const int L = last - item;                           // head partials to add (>= 1)
-    const bool coop = L >= FIX_COOP_MIN;                 // workgroup-uniform
+    const int len = last - item;                         // head partials to add (>= 1)
+    const bool coop = len >= FIX_COOP_MIN;               // workgroup-uniform
     if (!coop && wave != 0) return;
-    const int per = coop ? (L + SEG_WAVES - 1) / SEG_WAVES : L;
+    const int per = coop ? (len + SEG_WAVES - 1) / SEG_WAVES : len;
     const int jb = item + 1 + wave * per;
     const int je = min(jb + per, last + 1);
 
-    bool act[NCH];
-    int foff[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        foff[c] = (c * WAVE + lane) * VEC;
-        act[c] = EXACT ? true : (foff[c] < F);
-    }
+    Lanes<VEC, NCH, WMODE, EXACT> L;
+    L.init(P);
     float acc[NCH][VEC];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         // wave 0 starts from the owner's tail partial, the other slices from zero
-        if (act[c] && wave == 0) load_row<VEC>(carry + ((int64_t)item * 2 + 1) * F + foff[c], acc[c]);
+        if (L.act[c] && wave == 0) load_row<VEC>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);
         else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) acc[c][q] = 0.f;
@@ -247,10 +324,10 @@ segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restric
         float v[FIX_U][NCH][VEC];
 #pragma unroll
         for (int u = 0; u < FIX_U; ++u) {
-            const float* src = carry + ((int64_t)(j + u) * 2 + 0) * F;
+            const float* src = P.carry + ((int64_t)(j + u) * 2 + 0) * F;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (act[c]) load_row<VEC>(src + foff[c], v[u][c]);
+                if (L.act[c]) load_row<VEC>(src + L.foff[c], v[u][c]);
                 else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) v[u][c][q] = 0.f;
@@ -265,12 +342,12 @@ segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restric
                 for (int q = 0; q < VEC; ++q) acc[c][q] += v[u][c][q];
     }
     for (; j < je; ++j) {
-        const float* src = carry + ((int64_t)j * 2 + 0) * F;
+        const float* src = P.carry + ((int64_t)j * 2 + 0) * F;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             float v[VEC];
-            if (act[c]) {
-                load_row<VEC>(src + foff[c], v);
+            if (L.act[c]) {
+                load_row<VEC>(src + L.foff[c], v);
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[c][q] += v[q];
             }
@@ -292,48 +369,37 @@ segsum_fixup_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restric
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[c][q] += red[w][(c * VEC + q) * WAVE + lane];
     }
-    float s = 1.f;
-    if (MEAN) s = 1.f / (float)max(re - rs, 1);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-        if (act[c]) {
-            float t[VEC];
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) t[q] = fmaf(acc[c][q], s, bias ? bias[foff[c] + q] : 0.f);
-            store_row<VEC>(out + (int64_t)r * ldo + foff[c], t, 1.f);
-        }
+    finish_row<VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, re - rs);
+}
+
+template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+static void launch_one(const SegParams& P, hipStream_t stream) {
+    dim3 grid((unsigned)ceil_div(P.n_items, SEG_WAVES)), block(SEG_THREADS);
+    segsum_kernel<VEC, NCH, WMODE, MEAN, EXACT><<<grid, block, 0, stream>>>(P);
+    segsum_fixup_kernel<VEC, NCH, WMODE, MEAN, EXACT><<<dim3((unsigned)P.n_items), block, 0, stream>>>(P);   // one workgroup per item
 }
 
 template <int VEC, int NCH, bool EXACT>
-static int launch_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
-                         const float* w, int N, int n_items, const float* x, int64_t ldx, float* out,
-                         int64_t ldo, int F, int mean, float* carry, const float* bias, hipStream_t stream) {
-    dim3 grid((unsigned)ceil_div(n_items, SEG_WAVES)), block(SEG_THREADS);
-#define NPI_SEG_LAUNCH(WT, MN)                                                                         \
-    segsum_kernel<VEC, NCH, WT, MN, EXACT><<<grid, block, 0, stream>>>(rowptr, col, item_row, w, N,    \
-                                                                       n_items, x, ldx, out, ldo, F, carry, bias)
-    if (w) { if (mean) NPI_SEG_LAUNCH(true, true); else NPI_SEG_LAUNCH(true, false); }
-    else   { if (mean) NPI_SEG_LAUNCH(false, true); else NPI_SEG_LAUNCH(false, false); }
-#undef NPI_SEG_LAUNCH
-    dim3 fgrid((unsigned)n_items);      // one workgroup per item
-    if (mean) segsum_fixup_kernel<VEC, NCH, true, EXACT><<<fgrid, block, 0, stream>>>(rowptr, item_row, N, n_items, out, ldo, F, carry, bias);
-    else      segsum_fixup_kernel<VEC, NCH, false, EXACT><<<fgrid, block, 0, stream>>>(rowptr, item_row, N, n_items, out, ldo, F, carry, bias);
+static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t stream) {
+    if (wmode == W_NONE) { if (mean) launch_one<VEC, NCH, W_NONE, true, EXACT>(P, stream); else launch_one<VEC, NCH, W_NONE, false, EXACT>(P, stream); }
+    else if (wmode == W_ARRAY) { if (mean) launch_one<VEC, NCH, W_ARRAY, true, EXACT>(P, stream); else launch_one<VEC, NCH, W_ARRAY, false, EXACT>(P, stream); }
+    else if (wmode == W_GAT_DST) {
+        if constexpr (VEC == 4) launch_one<VEC, NCH, W_GAT_DST, false, EXACT>(P, stream);
+    } else {
+        if constexpr (VEC == 4) launch_one<VEC, NCH, W_GAT_SRC, false, EXACT>(P, stream);
+    }
     return check_launch("npi_segsum");
 }
 
 template <int VEC>
-static int dispatch_nch(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
-                        const float* w, int N, int n_items, const float* x, int64_t ldx, float* out,
-                        int64_t ldo, int F, int mean, float* carry, const float* bias, hipStream_t stream) {
+static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t stream) {
     const int per = WAVE * VEC;
-    const int nch = (int)ceil_div(F, per);
-    const bool exact = (F % per) == 0;
-#define NPI_SEG_CASE(NC)                                                                                  \
-    case NC:                                                                                              \
-        return exact ? launch_segsum<VEC, NC, true>(rowptr, col, item_row, w, N, n_items, x, ldx, out,    \
-                                                    ldo, F, mean, carry, bias, stream)                          \
-                     : launch_segsum<VEC, NC, false>(rowptr, col, item_row, w, N, n_items, x, ldx, out,   \
-                                                     ldo, F, mean, carry, bias, stream)
+    const int nch = (int)ceil_div(P.F, per);
+    const bool exact = (P.F % per) == 0;
+#define NPI_SEG_CASE(NC)                                                                    \
+    case NC:                                                                                \
+        return exact ? launch_segsum<VEC, NC, true>(P, wmode, mean, stream)                 \
+                     : launch_segsum<VEC, NC, false>(P, wmode, mean, stream)
     switch (nch) {
         NPI_SEG_CASE(1);
         NPI_SEG_CASE(2);
@@ -342,8 +408,43 @@ static int dispatch_nch(const int32_t* rowptr, const int32_t* col, const int32_t
         default: break;
     }
 #undef NPI_SEG_CASE
-    set_error("npi_segsum: feature width %d needs %d chunks (max 4)", F, nch);
+    set_error("npi_segsum: feature width %d needs %d chunks (max 4)", P.F, nch);
     return NPI_ERR_ARG;
+}
+
+// shared by npi_segsum and npi_gat_aggregate (gat.hip)
+int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, hipStream_t stream) {
+    const int64_t F = P.F;
+    const float* x = P.x;
+    float* out = P.out;
+    const float* bias = P.bias;
+    // widest vector the row pitch and base alignment allow
+    auto aligned = [&](int v) {
+        return (F % v == 0) && (P.ldx % v == 0) && (P.ldo % v == 0) &&
+               (((uintptr_t)x % (4 * v)) == 0) && (((uintptr_t)out % (4 * v)) == 0) &&
+               (((uintptr_t)P.carry % (4 * v)) == 0);
+    };
+    const int vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
+    if (wmode >= W_GAT_DST) {
+        if (vec != 4 || P.C % 4 != 0 || F > 4 * WAVE * 4) {
+            set_error("npi_gat_aggregate: needs 16-B aligned rows, out_channels %% 4 == 0 and heads*out_channels <= 1024");
+            return NPI_ERR_ARG;
+        }
+    }
+    // feature columns handled per launch: 4 chunks of 64 lanes x vec
+    const int64_t span = (int64_t)4 * WAVE * vec;
+    int rc = NPI_OK;
+    for (int64_t f0 = 0; f0 < F && rc == NPI_OK; f0 += span) {
+        SegParams Q = P;
+        Q.F = (int)((F - f0 < span) ? (F - f0) : span);       // carry rows are Q.F wide for this column block
+        Q.x = x + f0;
+        Q.out = out + f0;
+        Q.bias = bias ? bias + f0 : nullptr;
+        if (vec == 4) rc = dispatch_nch<4>(Q, wmode, mean, stream);
+        else if (vec == 2) rc = dispatch_nch<2>(Q, wmode, mean, stream);
+        else rc = dispatch_nch<1>(Q, wmode, mean, stream);
+    }
+    return rc;
 }
 
 }  // namespace npi
@@ -365,31 +466,18 @@ extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32
     NPI_REQUIRE(ldx >= F && ldo >= F, "npi_segsum: leading dimension < F");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && item_row && x_ && out_ && carry, "npi_segsum: null pointer");
-    const float* x = (const float*)x_;
-    float* out = (float*)out_;
     const int64_t n_items = npi_num_items(nnz_max);
     if (n_items == 0) {     // no entries at all: every row is empty
         NPI_REQUIRE(bias == nullptr, "npi_segsum: bias with an entry-free graph is not supported");
-        (void)hipMemset2DAsync(out, ldo * sizeof(float), 0, F * sizeof(float), N, stream);
+        (void)hipMemset2DAsync(out_, ldo * sizeof(float), 0, F * sizeof(float), N, stream);
         return check_launch("npi_segsum(memset)");
     }
     NPI_REQUIRE(col != nullptr, "npi_segsum: null col");
-    // widest vector the row pitch and base alignment allow
-    auto aligned = [&](int v) {
-        return (F % v == 0) && (ldx % v == 0) && (ldo % v == 0) &&
-               (((uintptr_t)x % (4 * v)) == 0) && (((uintptr_t)out % (4 * v)) == 0) &&
-               (((uintptr_t)carry % (4 * v)) == 0);
-    };
-    const int vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
-    // feature columns handled per launch: 4 chunks of 64 lanes x vec
-    const int64_t span = (int64_t)4 * WAVE * vec;
-    int rc = NPI_OK;
-    for (int64_t f0 = 0; f0 < F && rc == NPI_OK; f0 += span) {
-        const int Fc = (int)((F - f0 < span) ? (F - f0) : span);
-        // carry rows are Fc wide for this column block
-        if (vec == 4) rc = dispatch_nch<4>(rowptr, col, item_row, w, (int)N, (int)n_items, x + f0, ldx, out + f0, ldo, Fc, mean, carry, bias ? bias + f0 : nullptr, stream);
-        else if (vec == 2) rc = dispatch_nch<2>(rowptr, col, item_row, w, (int)N, (int)n_items, x + f0, ldx, out + f0, ldo, Fc, mean, carry, bias ? bias + f0 : nullptr, stream);
-        else rc = dispatch_nch<1>(rowptr, col, item_row, w, (int)N, (int)n_items, x + f0, ldx, out + f0, ldo, Fc, mean, carry, bias ? bias + f0 : nullptr, stream);
-    }
-    return rc;
+    SegParams P{};
+    P.rowptr = rowptr; P.col = col; P.item_row = item_row;
+    P.N = (int)N; P.n_items = (int)n_items;
+    P.x = (const float*)x_; P.ldx = ldx; P.out = (float*)out_; P.ldo = ldo; P.F = (int)F;
+    P.carry = carry; P.w = w; P.bias = bias;
+    P.H = 1; P.C = (int)F;
+    return segsum_run(P, w ? W_ARRAY : W_NONE, mean, nnz_max, stream);
 }

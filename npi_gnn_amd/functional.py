@@ -239,3 +239,119 @@ def gcn_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[t
     if norm is None:
         norm = GCNNorm(as_graph(edge_index, x.size(0)), edge_weight, improved)
     return _GcnConvFn.apply(x, weight, bias, norm)
+
+
+# ---------------------------------------------------------------------------------------------
+# GATConv
+# ---------------------------------------------------------------------------------------------
+def _transpose_map(graph: CSRGraph) -> torch.Tensor:
+    """by-target position of every by-source entry (same directed edge; loop -> loop), cached."""
+    tm = getattr(graph, "_tmap", None)
+    if tm is None:
+        lib = load()
+        dev, N, E = graph.device, graph.num_nodes, graph.num_edges
+        d, s_ = graph.by_dst, graph.by_src
+        st = stream_ptr(dev)
+        pos = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        check(lib.npi_edge_positions(ptr(d.eid), ptr(d.rowptr), N, d.nnz_max, E, ptr(pos), st), "npi_edge_positions")
+        tm = torch.empty(max(s_.nnz_max, 1), dtype=torch.int32, device=dev)
+        check(lib.npi_entry_transpose_map(ptr(s_.eid), ptr(s_.rowidx), ptr(s_.rowptr), ptr(d.rowptr), ptr(pos), N,
+                                          s_.nnz_max, ptr(tm), st), "npi_entry_transpose_map")
+        graph._tmap = tm
+    return tm
+
+
+def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
+                   g_src=None, att=None):
+    dev = x.device
+    out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
+    check(load().npi_gat_aggregate(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
+                                   ptr(x), x.stride(0), ptr(out), out.stride(0), H, C, ptr(a_dst), ptr(a_src),
+                                   ptr(m), ptr(s), float(slope), 1 if by_source else 0, ptr(bias), ptr(g_dst),
+                                   ptr(g_src), ptr(att), ptr(side.carry(H * C)), stream_ptr(dev)), "npi_gat_aggregate")
+    return out
+
+
+class _GatConvFn(torch.autograd.Function):
+    """Returns the concatenated heads [N, H*C] (bias fused when given)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float):
+        lib = load()
+        dev = x.device
+        st = stream_ptr(dev)
+        N, H = graph.num_nodes, int(heads)
+        C = weight.size(1) // H
+        att2 = _f32c(att.reshape(H, 2 * C), "att")
+        hfeat = linear_fwd(x, weight)                                        # x @ W
+        f32 = dict(dtype=torch.float32, device=dev)
+        a_dst, a_src = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
+        check(lib.npi_gat_scores(ptr(hfeat), hfeat.stride(0), ptr(att2), N, H, C, ptr(a_dst), ptr(a_src), st),
+              "npi_gat_scores")
+        m, s = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
+        d = graph.by_dst
+        check(lib.npi_gat_softmax_stats(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), ptr(a_dst), ptr(a_src), N,
+                                        d.nnz_max, H, float(slope), ptr(m), ptr(s), st), "npi_gat_softmax_stats")
+        out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias)
+        ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, att2, hfeat, a_dst, a_src, m, s, out,
+                              bias if bias is not None else torch.empty(0, device=dev))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, att2, hfeat, a_dst, a_src, m, s, out, bias = ctx.saved_tensors
+        graph: CSRGraph = ctx.graph
+        H, C, slope = ctx.H, ctx.C, ctx.slope
+        lib = load()
+        dev = x.device
+        st = stream_ptr(dev)
+        N = graph.num_nodes
+        grad_out = _f32c(grad_out, "grad_out")
+        d, sr = graph.by_dst, graph.by_src
+        f32 = dict(dtype=torch.float32, device=dev)
+        db = colsum(grad_out) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        # D_i = <dOut_i, out_i - b> = sum_p alpha_p dalpha_p  (softmax backward)
+        D = torch.empty((N, H), **f32)
+        check(lib.npi_gat_rowdot(ptr(grad_out), grad_out.stride(0), ptr(out), out.stride(0),
+                                 ptr(bias) if ctx.has_bias else 0, N, H, C, ptr(D), st), "npi_gat_rowdot")
+        # dz per by-target entry, then its row sums in both orientations
+        dz = torch.empty((max(d.nnz_max, 1), H), **f32)
+        check(lib.npi_gat_edge_grad(ptr(d.rowptr), ptr(d.col), ptr(d.rowidx), N, d.nnz_max, ptr(hfeat), hfeat.stride(0),
+                                    ptr(grad_out), grad_out.stride(0), H, C, ptr(a_dst), ptr(a_src), ptr(m), ptr(s),
+                                    ptr(D), slope, ptr(dz), st), "npi_gat_edge_grad")
+        g_dst, g_src = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
+        check(lib.npi_seg_rowsum(ptr(d.rowptr), ptr(dz), 0, N, H, ptr(g_dst), st), "npi_seg_rowsum")
+        check(lib.npi_seg_rowsum(ptr(sr.rowptr), ptr(dz), ptr(_transpose_map(graph)), N, H, ptr(g_src), st),
+              "npi_seg_rowsum")
+        # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
+        dh = _gat_aggregate(graph, sr, grad_out, H, C, a_dst, a_src, m, s, slope, True,
+                            g_dst=g_dst, g_src=g_src, att=att2)
+        datt = None
+        if ctx.needs_input_grad[2]:
+            n_ws = int(lib.npi_gat_att_grad_workspace_elems(N, H, C))
+            ws = torch.empty(n_ws, **f32)
+            datt = torch.empty((H, 2 * C), **f32)
+            check(lib.npi_gat_att_grad(ptr(hfeat), hfeat.stride(0), ptr(g_dst), ptr(g_src), N, H, C, ptr(datt),
+                                       ptr(ws), n_ws, st), "npi_gat_att_grad")
+            datt = datt.view(1, H, 2 * C)
+        dw = dx = None
+        if ctx.needs_input_grad[1]:
+            dw, _ = linear_bwd_weight(x, dh, want_bias=False)
+        if ctx.needs_input_grad[0]:
+            dx = linear_bwd_data(dh, weight)
+        return dx, dw, datt, db, None, None, None
+
+
+def gat_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, att: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, heads: int = 1, concat: bool = True,
+             negative_slope: float = 0.2) -> torch.Tensor:
+    """PyG 1.4.2 ``GATConv.forward`` (dropout = 0) on MI355X; ``att`` is ``[1, H, 2C]``."""
+    require_gpu(x, weight, att, bias)
+    graph = as_graph(edge_index, x.size(0))
+    if concat:
+        return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope)
+    out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope)
+    out = out.view(x.size(0), heads, -1).mean(dim=1)          # head average (concat=False)
+    return out + bias if bias is not None else out

@@ -70,6 +70,43 @@ class SAGEConv(nn.Module):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
 
 
+class GATConv(nn.Module):
+    """``GATConv(in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout=0,
+    bias=True)`` (PyG 1.4.2): ``weight [in, heads*out]`` and ``att [1, heads, 2*out]`` glorot,
+    ``bias`` zeros (``[heads*out]`` if concat else ``[out]``).  Not used by the reference
+    (BASELINE.json configs[4] only)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
+                 negative_slope: float = 0.2, dropout: float = 0.0, bias: bool = True, **kwargs):
+        super().__init__()
+        if dropout != 0:
+            raise NotImplementedError("GATConv: attention dropout is not implemented")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.weight = Parameter(torch.empty(in_channels, heads * out_channels))
+        self.att = Parameter(torch.empty(1, heads, 2 * out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(heads * out_channels if concat else out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        _glorot(self.weight)
+        _glorot(self.att)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, edge_index, size=None):
+        if size is not None:
+            raise NotImplementedError("GATConv: bipartite `size` is not implemented")
+        return F_.gat_conv(x, edge_index, self.weight, self.att, self.bias, self.heads, self.concat,
+                           self.negative_slope)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"
+
+
 class GCNConv(nn.Module):
     """``GCNConv(in_channels, out_channels, improved=False, cached=False, bias=True,
     normalize=True)``; ``weight`` glorot, ``bias`` zeros (PyG 1.4.2)."""

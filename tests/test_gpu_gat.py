@@ -1,0 +1,74 @@
+"""GATConv on the HIP path vs the CPU oracle (PyG 1.4.2 formulas restated; parity unpinned by any
+reference artifact -- SURVEY.md 8(c)).  Gradients of the oracle come from torch autograd through the
+restated ops (themselves gradcheck'ed in fp64 in test_oracle_cpu.py-style below)."""
+import pytest
+import torch
+
+import npi_gnn_amd as npi
+from oracle import ref_conv as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(N, E, Fi, H, C, seed, hub=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    if hub:
+        ei[1, : E // 3] = 3                    # one target with ~E/3 entries: workgroup-per-row softmax path
+        ei[0, E // 3: E // 2] = 5              # one heavy source row for the backward
+    x = torch.randn(N, Fi, generator=g)
+    W = (torch.rand(Fi, H * C, generator=g) * 2 - 1) * (6.0 / (Fi + H * C)) ** 0.5
+    att = (torch.rand(1, H, 2 * C, generator=g) * 2 - 1) * (6.0 / (H + 2 * C)) ** 0.5 * 3.0
+    b = torch.randn(H * C, generator=g) * 0.1
+    go = torch.randn(N, H * C, generator=g)
+    return ei, x, W, att, b, go
+
+
+@pytest.mark.parametrize("N,E,Fi,H,C", [(60, 300, 16, 1, 8), (3000, 40000, 128, 1, 256), (2000, 20000, 64, 4, 64),
+                                        (1500, 12000, 178, 2, 32)])
+def test_gat_conv_fwd_bwd_matches_oracle(dev, N, E, Fi, H, C):
+    ei, x, W, att, b, go = _case(N, E, Fi, H, C, seed=N)
+    xr, Wr, ar, br = (t.clone().requires_grad_(True) for t in (x, W, att, b))
+    ref = R.gat_conv(xr, ei, Wr, ar, br, heads=H)
+    ref.backward(go)
+    xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+    out = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=H)
+    out.backward(go.to(dev))
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, atol=2e-4, rtol=1e-3)
+    scale = max(1.0, N ** 0.5)
+    assert torch.allclose(Wd.grad.cpu(), Wr.grad, atol=1e-4 * scale, rtol=1e-3)
+    assert torch.allclose(ad.grad.cpu(), ar.grad, atol=1e-4 * scale, rtol=1e-3)
+    assert torch.allclose(bd.grad.cpu(), br.grad, atol=1e-4 * scale, rtol=1e-3)
+
+
+def test_gat_heavy_row_softmax(dev):
+    """> 4096 entries on one target row: the workgroup-per-row statistics kernel."""
+    N, E, Fi, H, C = 9000, 30000, 32, 1, 64
+    ei, x, W, att, b, go = _case(N, E, Fi, H, C, seed=1)
+    ref = R.gat_conv(x, ei, W, att, b, heads=H)
+    out = npi.gat_conv(x.to(dev), ei.to(dev), W.to(dev), att.to(dev), b.to(dev), heads=H)
+    assert torch.allclose(out.cpu(), ref, atol=1e-4, rtol=1e-4)
+
+
+def test_gat_module_concat_false_and_state_dict(dev):
+    torch.manual_seed(0)
+    N, E = 500, 3000
+    ei = torch.randint(0, N, (2, E))
+    x = torch.randn(N, 32)
+    conv = npi.GATConv(32, 16, heads=3, concat=False)
+    assert [tuple(v.shape) for v in conv.state_dict().values()] == [(32, 48), (1, 3, 32), (16,)]
+    ref = R.gat_conv(x, ei, conv.weight.detach(), conv.att.detach(), conv.bias.detach(), heads=3, concat=False)
+    conv = conv.to(dev)
+    out = conv(x.to(dev), ei.to(dev))
+    assert torch.allclose(out.detach().cpu(), ref, atol=1e-4, rtol=1e-4)
+    out.sum().backward()
+    assert conv.att.grad is not None and torch.isfinite(conv.att.grad).all()
+
+
+def test_gat_is_bitwise_reproducible(dev):
+    ei, x, W, att, b, go = _case(4000, 60000, 64, 1, 256, seed=4)
+    args = [t.to(dev) for t in (x, ei, W, att, b)]
+    a = npi.gat_conv(*args)
+    c = npi.gat_conv(*args)
+    assert torch.equal(a, c)
