@@ -4,33 +4,34 @@
 // GCNConv.forward (reached from reference src/classes.py:62,66,70) and its autograd backward
 // (src/train_with_twoDataset.PY:54):  dA = dC W^T,  dW = A^T dC,  db = colsum(dC).
 //
-// 128x128 output tile per 256-thread workgroup, 2x2 wavefronts, each a 2x2 grid of 32x32 MFMA
-// tiles (64 accumulator VGPRs), BK = 32, double-buffered LDS, 2 workgroups per CU.
+// 256-thread workgroup = 2x2 wavefronts, each wavefront a TM x TN grid of 32x32 MFMA tiles
+// (block tile 64 TM x 64 TN), BK = 32, double-buffered LDS.
 // Two kernels share the tile code:
-//   FAST  : full interior tiles with K % 32 == 0 and 16-B aligned rows.  Every staging load is
-//           `global_load_dwordx4 v, v_off, s[base]` -- a per-lane 32-bit byte offset computed once
-//           and a scalar base bumped per k-step -- so a k-step is ONE basic block without address
-//           VALU or exec-mask branches and the loads / LDS stores interleave with the 64 MFMAs.
+//   FAST  : full interior tiles with K % 32 == 0 and 16-B aligned rows.  Every staging load is a
+//           per-lane 32-bit byte offset computed once plus a scalar base bumped per k-step, pinned
+//           at the top of the k-step, so a k-step has no address VALU and no exec-mask branches.
 //           (A bare MFMA loop sustains 155 TF on this chip; what separates a tiled kernel from it
 //           is the issue time of everything that is not an MFMA, not bandwidth or latency.)
-//   EDGE  : the same tile with guarded loads/stores, for the ragged strips at the matrix edges,
+//           Tile 128x256 (TM=2, TN=4; 128 accumulator VGPRs, one workgroup per CU) when the
+//           output is >= 256 wide: A is read once and there are half as many LDS reads, stores,
+//           barriers and staging instructions per MFMA as with 128x128.
+//   EDGE  : 128x128 tile with guarded loads/stores, for the ragged strips at the matrix edges,
 //           K tails and unaligned operands (F = 178, 65).
 // LDS images are chosen so that fragment reads are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0):
 //   operand contiguous along K in memory -> image [row][BK+4], fragment = one ds_read_b128 holding
 //       k = 8g + 4h + {0,1,2,3}  (h = lane>>5) -- the k order inside a group of 8 is permuted the
 //       same way for A and B, which a sum over k does not care about;
-//   operand contiguous along M/N in memory -> image [k][128+4], fragment = ds_read_b32 per k.
+//   operand contiguous along M/N in memory -> image [k][rows+4], fragment = ds_read_b32 per k.
 #include "npi_common.h"
+#include <stdlib.h>
 
 namespace npi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BK = 32;
 constexpr int GEMM_THREADS = 256;
 constexpr int KPITCH = BK + 4;      // [row][k] image
-constexpr int RPITCH = 128 + 4;     // [k][row] image
-constexpr int TILE_FLOATS = 128 * KPITCH;   // 4608 >= 32 * RPITCH (4224)
 
 struct Epilogue {
     const float* bias;       // [N] or null
@@ -38,160 +39,6 @@ struct Epilogue {
     int relu;
     float* colsum;           // BMODE 0 only: per-split column sums of B, [splits][N], or null
 };
-
-// ---- guarded global -> register staging (EDGE kernel) ---------------------------------------------
-// K-contiguous operand: element (row, k) at base[row * ld + k]; tile rows [r0, r0+128), k [k0, k0+32)
-template <bool VEC4>
-__device__ __forceinline__ void gload_kcontig(const float* __restrict__ base, int64_t ld, int r0,
-                                              int rmax, int k0, int kmax, float4 (&reg)[4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int row = r0 + (t >> 3) + 32 * p;
-        const int k = k0 + (t & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < rmax) {
-            const float* src = base + (int64_t)row * ld + k;
-            if (VEC4) {
-                if (k < kmax) v = *reinterpret_cast<const float4*>(src);
-            } else {
-                if (k + 0 < kmax) v.x = src[0];
-                if (k + 1 < kmax) v.y = src[1];
-                if (k + 2 < kmax) v.z = src[2];
-                if (k + 3 < kmax) v.w = src[3];
-            }
-        }
-        reg[p] = v;
-    }
-}
-// row-contiguous operand: element (k, c) at base[k * ld + c]; tile k [k0,k0+32), c [c0, c0+128)
-template <bool VEC4>
-__device__ __forceinline__ void gload_rcontig(const float* __restrict__ base, int64_t ld, int c0,
-                                              int cmax, int k0, int kmax, float4 (&reg)[4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int k = k0 + (t >> 5) + 8 * p;
-        const int c = c0 + (t & 31) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < kmax) {
-            const float* src = base + (int64_t)k * ld + c;
-            if (VEC4) {
-                if (c < cmax) v = *reinterpret_cast<const float4*>(src);
-            } else {
-                if (c + 0 < cmax) v.x = src[0];
-                if (c + 1 < cmax) v.y = src[1];
-                if (c + 2 < cmax) v.z = src[2];
-                if (c + 3 < cmax) v.w = src[3];
-            }
-        }
-        reg[p] = v;
-    }
-}
-__device__ __forceinline__ void lstore_kcontig(float* __restrict__ img, const float4 (&reg)[4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<float4*>(img + ((t >> 3) + 32 * p) * KPITCH + (t & 7) * 4) = reg[p];
-}
-__device__ __forceinline__ void lstore_rcontig(float* __restrict__ img, const float4 (&reg)[4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<float4*>(img + ((t >> 5) + 8 * p) * RPITCH + (t & 31) * 4) = reg[p];
-}
-
-// ---- one k-step of MFMAs on the staged tile ----------------------------------------------------------
-template <int AMODE, int BMODE>
-__device__ __forceinline__ void mma_step(const float* __restrict__ as, const float* __restrict__ bs,
-                                         int wm, int wn, int li, int lh, f32x16 (&acc)[2][2]) {
-    float af[2][2][4], bf[2][2][4];
-    auto read_frags = [&](int g, float (&fa)[2][4], float (&fb)[2][4]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wm * 64 + i * 32 + li;
-            if (AMODE == 0) {
-                float4 v = *reinterpret_cast<const float4*>(as + row * KPITCH + g * 8 + lh * 4);
-                fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) fa[i][s] = as[(g * 8 + lh * 4 + s) * RPITCH + row];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = wn * 64 + j * 32 + li;
-            if (BMODE == 0) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) fb[j][s] = bs[(g * 8 + lh * 4 + s) * RPITCH + c];
-            } else {
-                float4 v = *reinterpret_cast<const float4*>(bs + c * KPITCH + g * 8 + lh * 4);
-                fb[j][0] = v.x; fb[j][1] = v.y; fb[j][2] = v.z; fb[j][3] = v.w;
-            }
-        }
-    };
-    read_frags(0, af[0], bf[0]);
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-        const int cur = g & 1;
-        if (g + 1 < BK / 8) read_frags(g + 1, af[cur ^ 1], bf[cur ^ 1]);   // one k-group ahead
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
-    }
-}
-
-// ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5).
-// Every operand is fetched BEFORE the store loop: a load inside it makes hipcc wait vmcnt(0) per
-// element, which also drains the preceding store (64 serialised stores per lane).
-template <bool GUARD>
-__device__ __forceinline__ void store_tile(float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
-                                           int wm, int wn, int li, int lh, const f32x16 (&acc)[2][2],
-                                           const Epilogue& ep) {
-    float rsv[2][16];
-    float bv[2];
-    if (ep.rowscale != nullptr) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int r = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-                rsv[i][q] = ep.rowscale[GUARD ? min(r, M - 1) : r];
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) rsv[i][q] = 1.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = n0 + wn * 64 + j * 32 + li;
-        bv[j] = (ep.bias != nullptr) ? ep.bias[GUARD ? min(c, N - 1) : c] : 0.f;
-    }
-    const bool relu_on = ep.relu != 0;
-    float* __restrict__ cbase = C + (int64_t)(m0 + wm * 64 + 4 * lh) * ldc + (n0 + wn * 64 + li);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int ro = i * 32 + (q & 3) + 8 * (q >> 2);
-                float v = fmaf(acc[i][j][q], rsv[i][q], bv[j]);
-                v = (relu_on && v < 0.f) ? 0.f : v;          // keeps NaN, like torch.relu
-                if (!GUARD) {
-                    cbase[(int64_t)ro * ldc + j * 32] = v;
-                } else {
-                    const int r = m0 + wm * 64 + 4 * lh + ro, c = n0 + wn * 64 + j * 32 + li;
-                    if (r < M && c < N) cbase[(int64_t)ro * ldc + j * 32] = v;
-                }
-            }
-}
 
 // C[M,N] (+ split-K slabs) = A(m,k) * B(k,n) over the tile grid starting at (tm0, tn0)
 //   AMODE 0: A(m,k) = A[m*lda + k]     AMODE 1: A(m,k) = A[k*lda + m]
@@ -203,15 +50,199 @@ struct GemmArgs {
     float* C; int64_t ldc;
     int M, N, K;            // extents of the m / n / contraction index
     int kchunk;             // multiple of BK
-    int tm0, tn0;           // first tile of this launch's grid
+    int tm0, tn0;           // first tile of this launch's grid (in units of the kernel's tile)
     int64_t slab_stride;
     Epilogue ep;
 };
 
-template <int AMODE, int BMODE>
-__global__ void __launch_bounds__(GEMM_THREADS, 2)
+// Up to 8 staging registers with compile-time slot access.  (A float4 ARRAY indexed in an unrolled
+// loop is demoted to scratch / LDS by hipcc once a sched_barrier sits between its writes and reads.)
+struct Slots {
+    float4 v0, v1, v2, v3, v4, v5, v6, v7;
+    template <int P> __device__ __forceinline__ float4& at() {
+        if constexpr (P == 0) return v0; else if constexpr (P == 1) return v1;
+        else if constexpr (P == 2) return v2; else if constexpr (P == 3) return v3;
+        else if constexpr (P == 4) return v4; else if constexpr (P == 5) return v5;
+        else if constexpr (P == 6) return v6; else return v7;
+    }
+};
+template <int I> struct IC { static constexpr int value = I; };
+template <int P, int NP, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (P < NP) {
+        f(IC<P>{});
+        static_for<P + 1, NP>(f);
+    }
+}
+
+// geometry of one operand's staging: ROWS = tile extent along m (or n)
+template <int MODE_KCONTIG, int ROWS>
+struct Stage {
+    // K-contiguous: image [ROWS][KPITCH]; a thread moves float4 #(t&7) of rows (t>>3) + 32 p
+    // row-contiguous: image [BK][ROWS+4]; a thread moves float4 #(t % RQ) of k-rows t / RQ + KR p
+    static constexpr int RQ = ROWS / 4;                 // float4 per k-row (row-contiguous)
+    static constexpr int KR = GEMM_THREADS / RQ;        // k-rows per pass
+    static constexpr int NP = MODE_KCONTIG ? ROWS / 32 : BK / KR;   // float4 per thread
+    static constexpr int PITCH = MODE_KCONTIG ? KPITCH : ROWS + 4;
+    static constexpr int FLOATS = MODE_KCONTIG ? ROWS * KPITCH : BK * (ROWS + 4);
+    __device__ static __forceinline__ int row_of(int t, int p) { return MODE_KCONTIG ? (t >> 3) + 32 * p : (t % RQ) * 4; }
+    __device__ static __forceinline__ int k_of(int t, int p) { return MODE_KCONTIG ? (t & 7) * 4 : t / RQ + KR * p; }
+    // float offset inside the LDS image
+    __device__ static __forceinline__ int lds_off(int t, int p) {
+        return MODE_KCONTIG ? ((t >> 3) + 32 * p) * KPITCH + (t & 7) * 4 : (t / RQ + KR * p) * (ROWS + 4) + (t % RQ) * 4;
+    }
+    // byte offset from the tile's scalar base in global memory
+    __device__ static __forceinline__ uint32_t gl_off(int t, int p, int64_t ld) {
+        return MODE_KCONTIG ? (uint32_t)((((t >> 3) + 32 * p) * ld + (t & 7) * 4) * 4)
+                            : (uint32_t)(((t / RQ + KR * p) * ld + (t % RQ) * 4) * 4);
+    }
+};
+
+// guarded load of staging slot p (EDGE kernel): rows beyond rmax / k beyond kmax read as zero
+template <int MODE_KCONTIG, int ROWS, bool VEC4>
+__device__ __forceinline__ float4 guarded_load(const float* __restrict__ base, int64_t ld, int r0, int rmax,
+                                               int k0, int kmax, int t, int p) {
+    using S = Stage<MODE_KCONTIG, ROWS>;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r = r0 + S::row_of(t, p);
+    const int k = k0 + S::k_of(t, p);
+    if (MODE_KCONTIG) {
+        if (r < rmax) {
+            const float* src = base + (int64_t)r * ld + k;
+            if (VEC4) { if (k < kmax) v = *reinterpret_cast<const float4*>(src); }
+            else {
+                if (k + 0 < kmax) v.x = src[0];
+                if (k + 1 < kmax) v.y = src[1];
+                if (k + 2 < kmax) v.z = src[2];
+                if (k + 3 < kmax) v.w = src[3];
+            }
+        }
+    } else {
+        if (k < kmax) {
+            const float* src = base + (int64_t)k * ld + r;
+            if (VEC4) { if (r < rmax) v = *reinterpret_cast<const float4*>(src); }
+            else {
+                if (r + 0 < rmax) v.x = src[0];
+                if (r + 1 < rmax) v.y = src[1];
+                if (r + 2 < rmax) v.z = src[2];
+                if (r + 3 < rmax) v.w = src[3];
+            }
+        }
+    }
+    return v;
+}
+
+// ---- one k-step of MFMAs on the staged tile ----------------------------------------------------------
+template <int AMODE, int BMODE, int TM, int TN>
+__device__ __forceinline__ void mma_step(const float* __restrict__ as, const float* __restrict__ bs,
+                                         int wm, int wn, int li, int lh, f32x16 (&acc)[TM][TN]) {
+    constexpr int APITCH = Stage<AMODE == 0, 64 * TM>::PITCH;
+    constexpr int BPITCH = Stage<BMODE == 1, 64 * TN>::PITCH;
+    float a0[TM][4], a1[TM][4], b0[TN][4], b1[TN][4];
+    auto read_frags = [&](int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * (32 * TM) + i * 32 + li;
+            if (AMODE == 0) {
+                float4 v = *reinterpret_cast<const float4*>(as + row * APITCH + g * 8 + lh * 4);
+                fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fa[i][s] = as[(g * 8 + lh * 4 + s) * APITCH + row];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = wn * (32 * TN) + j * 32 + li;
+            if (BMODE == 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fb[j][s] = bs[(g * 8 + lh * 4 + s) * BPITCH + c];
+            } else {
+                float4 v = *reinterpret_cast<const float4*>(bs + c * BPITCH + g * 8 + lh * 4);
+                fb[j][0] = v.x; fb[j][1] = v.y; fb[j][2] = v.z; fb[j][3] = v.w;
+            }
+        }
+    };
+    auto mma_group = [&](const float (&fa)[TM][4], const float (&fb)[TN][4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    };
+    // BK / 8 = 4 k-groups, fragments read one group ahead; the two buffers are named (not indexed by
+    // g & 1): a runtime-looking index makes hipcc demote the arrays to LDS / scratch
+    static_assert(BK / 8 == 4, "k-group pipeline below is written for BK = 32");
+    read_frags(0, a0, b0);
+    read_frags(1, a1, b1);
+    mma_group(a0, b0);
+    read_frags(2, a0, b0);
+    mma_group(a1, b1);
+    read_frags(3, a1, b1);
+    mma_group(a0, b0);
+    mma_group(a1, b1);
+}
+
+// ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5).
+// Every operand is fetched BEFORE the store loop: a load inside it makes hipcc wait vmcnt(0) per
+// element, which also drains the preceding store (64 serialised stores per lane).
+template <bool GUARD, int TM, int TN>
+__device__ __forceinline__ void store_tile(float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                           int wm, int wn, int li, int lh, const f32x16 (&acc)[TM][TN],
+                                           const Epilogue& ep) {
+    float rsv[TM][16];
+    float bv[TN];
+    const int mw = m0 + wm * (32 * TM), nw = n0 + wn * (32 * TN);
+    if (ep.rowscale != nullptr) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = mw + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+                rsv[i][q] = ep.rowscale[GUARD ? min(r, M - 1) : r];
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rsv[i][q] = 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = nw + j * 32 + li;
+        bv[j] = (ep.bias != nullptr) ? ep.bias[GUARD ? min(c, N - 1) : c] : 0.f;
+    }
+    const bool relu_on = ep.relu != 0;
+    float* __restrict__ cbase = C + (int64_t)(mw + 4 * lh) * ldc + (nw + li);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ro = i * 32 + (q & 3) + 8 * (q >> 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = fmaf(acc[i][j][q], rsv[i][q], bv[j]);
+                v = (relu_on && v < 0.f) ? 0.f : v;          // keeps NaN, like torch.relu
+                if (!GUARD) {
+                    cbase[(int64_t)ro * ldc + j * 32] = v;
+                } else {
+                    const int r = mw + 4 * lh + ro, c = nw + j * 32 + li;
+                    if (r < M && c < N) cbase[(int64_t)ro * ldc + j * 32] = v;
+                }
+            }
+        }
+}
+
+template <int AMODE, int BMODE, int TM, int TN>
+__global__ void __launch_bounds__(GEMM_THREADS, (TM * TN > 4) ? 1 : 2)
 gemm_fast_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    using SA = Stage<AMODE == 0, BM>;
+    using SB = Stage<BMODE == 1, BN>;
+    constexpr int AF = SA::FLOATS, BF = SB::FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[2][AF + BF];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -223,15 +254,7 @@ gemm_fast_kernel(GemmArgs a) {
     const int kend = min(a.K, kbeg + a.kchunk);
     const int nk = max(kend - kbeg, 0) / BK;                 // K % BK == 0 on this path
 
-    // per-lane byte offsets inside a tile slab (computed once) + scalar bases (bumped per k-step)
-    uint32_t voa[4], vob[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        voa[p] = (AMODE == 0) ? (uint32_t)((((t >> 3) + 32 * p) * a.lda + (t & 7) * 4) * 4)
-                              : (uint32_t)((((t >> 5) + 8 * p) * a.lda + (t & 31) * 4) * 4);
-        vob[p] = (BMODE == 0) ? (uint32_t)((((t >> 5) + 8 * p) * a.ldb + (t & 31) * 4) * 4)
-                              : (uint32_t)((((t >> 3) + 32 * p) * a.ldb + (t & 7) * 4) * 4);
-    }
+    // scalar bases, bumped per k-step; per-lane offsets are loop-invariant expressions of t
     const char* sa = reinterpret_cast<const char*>(
         (AMODE == 0) ? a.A + (int64_t)m0 * a.lda + kbeg : a.A + (int64_t)kbeg * a.lda + m0);
     const char* sb = reinterpret_cast<const char*>(
@@ -239,53 +262,53 @@ gemm_fast_kernel(GemmArgs a) {
     const int64_t step_a = ((AMODE == 0) ? (int64_t)BK : (int64_t)BK * a.lda) * 4;
     const int64_t step_b = ((BMODE == 0) ? (int64_t)BK * a.ldb : (int64_t)BK) * 4;
 
-    // Staging registers are named scalars (not arrays behind a lambda) so they stay in VGPRs.
-    // readfirstlane keeps the bases in SGPRs; loop strength reduction would otherwise give every
-    // load address its own 64-bit VGPR induction variable.
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define NPI_GLOAD()                                                                   \
-    do {                                                                              \
-        const char* ua = uniform_ptr(sa);                                             \
-        const char* ub = uniform_ptr(sb);                                             \
-        ra0 = *reinterpret_cast<const float4*>(ua + voa[0]);                          \
-        ra1 = *reinterpret_cast<const float4*>(ua + voa[1]);                          \
-        ra2 = *reinterpret_cast<const float4*>(ua + voa[2]);                          \
-        ra3 = *reinterpret_cast<const float4*>(ua + voa[3]);                          \
-        rb0 = *reinterpret_cast<const float4*>(ub + vob[0]);                          \
-        rb1 = *reinterpret_cast<const float4*>(ub + vob[1]);                          \
-        rb2 = *reinterpret_cast<const float4*>(ub + vob[2]);                          \
-        rb3 = *reinterpret_cast<const float4*>(ub + vob[3]);                          \
-        sa += step_a;                                                                 \
-        sb += step_b;                                                                 \
+    // Staging registers: fully unrolled constant indices keep them in VGPRs.  readfirstlane keeps
+    // the bases in SGPRs (loop strength reduction would otherwise give every load address its own
+    // 64-bit VGPR induction variable).
+    // Staging registers are plain named locals moved by macros: arrays, structs or lambdas that
+    // capture them by reference end up in scratch / LDS once a sched_barrier sits between the
+    // loads and the LDS stores (seen in the ISA, round 1).
+    static_assert(SA::NP == 4 && (SB::NP == 4 || SB::NP == 8), "staging macros below assume these counts");
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+#define NPI_LD(P, base, S, ld) (*reinterpret_cast<const float4*>((base) + S::gl_off(t, P, ld)))
+#define NPI_GLOAD()                                                                  \
+    do {                                                                             \
+        const char* ua = uniform_ptr(sa);                                            \
+        const char* ub = uniform_ptr(sb);                                            \
+        ra0 = NPI_LD(0, ua, SA, a.lda); ra1 = NPI_LD(1, ua, SA, a.lda);              \
+        ra2 = NPI_LD(2, ua, SA, a.lda); ra3 = NPI_LD(3, ua, SA, a.lda);              \
+        rb0 = NPI_LD(0, ub, SB, a.ldb); rb1 = NPI_LD(1, ub, SB, a.ldb);              \
+        rb2 = NPI_LD(2, ub, SB, a.ldb); rb3 = NPI_LD(3, ub, SB, a.ldb);              \
+        if constexpr (SB::NP == 8) {                                                 \
+            rb4 = NPI_LD(4, ub, SB, a.ldb); rb5 = NPI_LD(5, ub, SB, a.ldb);          \
+            rb6 = NPI_LD(6, ub, SB, a.ldb); rb7 = NPI_LD(7, ub, SB, a.ldb);          \
+        }                                                                            \
+        sa += step_a;                                                                \
+        sb += step_b;                                                                \
     } while (0)
-    // LDS byte offsets of this lane's four 16-B staging slots per operand (fixed for the kernel)
-    const int la = (AMODE == 0) ? ((t >> 3) * KPITCH + (t & 7) * 4) : ((t >> 5) * RPITCH + (t & 31) * 4);
-    const int lb = (BMODE == 0) ? ((t >> 5) * RPITCH + (t & 31) * 4) : ((t >> 3) * KPITCH + (t & 7) * 4);
-    constexpr int LSA = (AMODE == 0) ? 32 * KPITCH : 8 * RPITCH;
-    constexpr int LSB = (BMODE == 0) ? 8 * RPITCH : 32 * KPITCH;
-#define NPI_LSTORE(buf)                                                               \
-    do {                                                                              \
-        float* pa = lds[buf][0] + la;                                                 \
-        float* pb = lds[buf][1] + lb;                                                 \
-        *reinterpret_cast<float4*>(pa + 0 * LSA) = ra0;                               \
-        *reinterpret_cast<float4*>(pa + 1 * LSA) = ra1;                               \
-        *reinterpret_cast<float4*>(pa + 2 * LSA) = ra2;                               \
-        *reinterpret_cast<float4*>(pa + 3 * LSA) = ra3;                               \
-        *reinterpret_cast<float4*>(pb + 0 * LSB) = rb0;                               \
-        *reinterpret_cast<float4*>(pb + 1 * LSB) = rb1;                               \
-        *reinterpret_cast<float4*>(pb + 2 * LSB) = rb2;                               \
-        *reinterpret_cast<float4*>(pb + 3 * LSB) = rb3;                               \
+#define NPI_ST(P, buf, off0, S, v) (*reinterpret_cast<float4*>(lds[buf] + (off0) + S::lds_off(t, P)) = (v))
+#define NPI_LSTORE(buf)                                                              \
+    do {                                                                             \
+        NPI_ST(0, buf, 0, SA, ra0); NPI_ST(1, buf, 0, SA, ra1);                      \
+        NPI_ST(2, buf, 0, SA, ra2); NPI_ST(3, buf, 0, SA, ra3);                      \
+        NPI_ST(0, buf, AF, SB, rb0); NPI_ST(1, buf, AF, SB, rb1);                    \
+        NPI_ST(2, buf, AF, SB, rb2); NPI_ST(3, buf, AF, SB, rb3);                    \
+        if constexpr (SB::NP == 8) {                                                 \
+            NPI_ST(4, buf, AF, SB, rb4); NPI_ST(5, buf, AF, SB, rb5);                \
+            NPI_ST(6, buf, AF, SB, rb6); NPI_ST(7, buf, AF, SB, rb7);                \
+        }                                                                            \
     } while (0)
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     const bool do_colsum = (BMODE == 0) && (a.ep.colsum != nullptr) && (m0 == 0);
     float csum = 0.f;
+    constexpr int BPITCH = SB::PITCH;
 
     if (nk > 0) {
         NPI_GLOAD();
@@ -298,10 +321,10 @@ gemm_fast_kernel(GemmArgs a) {
         // keep the loads at the TOP of the k-step: hipcc otherwise sinks them below the MFMAs and
         // then waits for them at once, exposing the whole memory latency every step
         __builtin_amdgcn_sched_barrier(0);
-        mma_step<AMODE, BMODE>(lds[buf][0], lds[buf][1], wm, wn, li, lh, acc);
+        mma_step<AMODE, BMODE, TM, TN>(lds[buf], lds[buf] + AF, wm, wn, li, lh, acc);
         if (do_colsum && t < BN) {
 #pragma unroll 8
-            for (int k = 0; k < BK; ++k) csum += lds[buf][1][k * RPITCH + t];
+            for (int k = 0; k < BK; ++k) csum += lds[buf][AF + k * BPITCH + t];
         }
         __builtin_amdgcn_sched_barrier(0);
         NPI_LSTORE(buf ^ 1);
@@ -310,21 +333,27 @@ gemm_fast_kernel(GemmArgs a) {
     }
 #undef NPI_GLOAD
 #undef NPI_LSTORE
+#undef NPI_LD
+#undef NPI_ST
     if (nk > 0) {                                    // last k-step: nothing left to stage
-        mma_step<AMODE, BMODE>(lds[buf][0], lds[buf][1], wm, wn, li, lh, acc);
+        mma_step<AMODE, BMODE, TM, TN>(lds[buf], lds[buf] + AF, wm, wn, li, lh, acc);
         if (do_colsum && t < BN) {
 #pragma unroll 8
-            for (int k = 0; k < BK; ++k) csum += lds[buf][1][k * RPITCH + t];
+            for (int k = 0; k < BK; ++k) csum += lds[buf][AF + k * BPITCH + t];
         }
     }
     if (do_colsum && t < BN) a.ep.colsum[(int64_t)z * a.N + n0 + t] = csum;
-    store_tile<false>(a.C + (int64_t)z * a.slab_stride, a.ldc, a.M, a.N, m0, n0, wm, wn, li, lh, acc, a.ep);
+    store_tile<false, TM, TN>(a.C + (int64_t)z * a.slab_stride, a.ldc, a.M, a.N, m0, n0, wm, wn, li, lh, acc, a.ep);
 }
 
 template <int AMODE, int BMODE, bool VEC4>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
 gemm_edge_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];
+    constexpr int TM = 2, TN = 2, BM = 128, BN = 128;
+    using SA = Stage<AMODE == 0, BM>;
+    using SB = Stage<BMODE == 1, BN>;
+    constexpr int AF = SA::FLOATS, BF = SB::FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[2][AF + BF];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -336,22 +365,24 @@ gemm_edge_kernel(GemmArgs a) {
     const int kend = min(a.K, kbeg + a.kchunk);
     const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
-    float4 ra[4], rb[4];
+    float4 ra[SA::NP], rb[SB::NP];
     auto gload = [&](int k0) {
-        if (AMODE == 0) gload_kcontig<VEC4>(a.A, a.lda, m0, a.M, k0, kend, ra);
-        else            gload_rcontig<VEC4>(a.A, a.lda, m0, a.M, k0, kend, ra);
-        if (BMODE == 0) gload_rcontig<VEC4>(a.B, a.ldb, n0, a.N, k0, kend, rb);
-        else            gload_kcontig<VEC4>(a.B, a.ldb, n0, a.N, k0, kend, rb);
+#pragma unroll
+        for (int p = 0; p < SA::NP; ++p) ra[p] = guarded_load<AMODE == 0, BM, VEC4>(a.A, a.lda, m0, a.M, k0, kend, t, p);
+#pragma unroll
+        for (int p = 0; p < SB::NP; ++p) rb[p] = guarded_load<BMODE == 1, BN, VEC4>(a.B, a.ldb, n0, a.N, k0, kend, t, p);
     };
     auto lstore = [&](int buf) {
-        if (AMODE == 0) lstore_kcontig(lds[buf][0], ra); else lstore_rcontig(lds[buf][0], ra);
-        if (BMODE == 0) lstore_rcontig(lds[buf][1], rb); else lstore_kcontig(lds[buf][1], rb);
+#pragma unroll
+        for (int p = 0; p < SA::NP; ++p) *reinterpret_cast<float4*>(lds[buf] + SA::lds_off(t, p)) = ra[p];
+#pragma unroll
+        for (int p = 0; p < SB::NP; ++p) *reinterpret_cast<float4*>(lds[buf] + AF + SB::lds_off(t, p)) = rb[p];
     };
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     const bool do_colsum = (BMODE == 0) && (a.ep.colsum != nullptr) && (m0 == 0);
@@ -365,16 +396,16 @@ gemm_edge_kernel(GemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
-        mma_step<AMODE, BMODE>(lds[buf][0], lds[buf][1], wm, wn, li, lh, acc);
+        mma_step<AMODE, BMODE, TM, TN>(lds[buf], lds[buf] + AF, wm, wn, li, lh, acc);
         if (do_colsum && t < BN) {
 #pragma unroll 8
-            for (int k = 0; k < BK; ++k) csum += lds[buf][1][k * RPITCH + t];
+            for (int k = 0; k < BK; ++k) csum += lds[buf][AF + k * SB::PITCH + t];
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
     if (do_colsum && t < BN && n0 + t < a.N) a.ep.colsum[(int64_t)z * a.N + n0 + t] = csum;
-    store_tile<true>(a.C + (int64_t)z * a.slab_stride, a.ldc, a.M, a.N, m0, n0, wm, wn, li, lh, acc, a.ep);
+    store_tile<true, TM, TN>(a.C + (int64_t)z * a.slab_stride, a.ldc, a.M, a.N, m0, n0, wm, wn, li, lh, acc, a.ep);
 }
 
 // out[r, c] = sum_z slabs[z][r, c]  (z ascending: deterministic)
@@ -433,18 +464,27 @@ static int pick_splits(int64_t M, int64_t tiles) {
     return (int)(s < 1 ? 1 : s);
 }
 
-// Cover the (M x N) tile grid with the FAST kernel on full tiles and the EDGE kernel on the two
-// ragged strips.  `splits` slabs along the contraction; the fast path needs K % BK == 0.
+// Cover the (M x N) output with the FAST kernel on full tiles and the 128x128 EDGE kernel on the
+// two ragged strips.  `splits` slabs along the contraction; the fast path needs K % BK == 0.
 template <int AMODE, int BMODE>
 static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream) {
-    const int tm = (int)ceil_div(a.M, BM), tn = (int)ceil_div(a.N, BN);
     const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0);
-    const int fm = fast_ok ? a.M / BM : 0, fn = fast_ok ? a.N / BN : 0;    // full tiles
+    // 128 x 256 tile (one workgroup per CU): measured 3-10 % SLOWER than 128 x 128 at C4 (round 1:
+    // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms), so it is opt-in (NPI_GEMM_WIDE=1)
+    static const bool wide_enabled = [] { const char* e = getenv("NPI_GEMM_WIDE"); return e && e[0] == '1'; }();
+    const bool wide = wide_enabled && fast_ok && a.N >= 256 && a.M >= 128;
+    const int bm = 128, bn = wide ? 256 : 128;
+    const int fm = fast_ok ? a.M / bm : 0, fn = fast_ok ? a.N / bn : 0;    // full tiles
     if (fm > 0 && fn > 0) {
         GemmArgs f = a;
         f.tm0 = 0; f.tn0 = 0;
-        gemm_fast_kernel<AMODE, BMODE><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
+        if (wide) gemm_fast_kernel<AMODE, BMODE, 2, 4><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
+        else      gemm_fast_kernel<AMODE, BMODE, 2, 2><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
     }
+    // edge strips in 128 x 128 tiles
+    const int tm = (int)ceil_div(a.M, 128), tn = (int)ceil_div(a.N, 128);
+    const int em = (fm > 0 && fn > 0) ? fm * bm / 128 : 0;       // first edge tile row
+    const int en = (fm > 0 && fn > 0) ? fn * bn / 128 : 0;       // first edge tile column
     auto edge = [&](int tm0, int tn0, int nm, int nn) {
         if (nm <= 0 || nn <= 0) return;
         GemmArgs e = a;
@@ -452,9 +492,9 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream) {
         if (v4) gemm_edge_kernel<AMODE, BMODE, true><<<dim3(nn, nm, splits), GEMM_THREADS, 0, stream>>>(e);
         else    gemm_edge_kernel<AMODE, BMODE, false><<<dim3(nn, nm, splits), GEMM_THREADS, 0, stream>>>(e);
     };
-    if (fm > 0 && fn > 0) {
-        edge(fm, 0, tm - fm, tn);        // bottom strip (all columns)
-        edge(0, fn, fm, tn - fn);        // right strip (full rows only)
+    if (em > 0 && en > 0) {
+        edge(em, 0, tm - em, tn);        // bottom strip (all columns)
+        edge(0, en, em, tn - en);        // right strip (full rows only)
     } else {
         edge(0, 0, tm, tn);
     }
@@ -517,7 +557,7 @@ extern "C" int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, flo
 // multiple of BK goes through `splits` slabs (fast path) and the < BK remainder through one
 // extra slab (guarded).
 static void bwd_weight_plan(int64_t M, int64_t K, int64_t N, int& splits, int& kchunk, int64_t& m_main) {
-    const int64_t tiles = ceil_div(K, BM) * ceil_div(N, BN);
+    const int64_t tiles = ceil_div(K, 128) * ceil_div(N, 128);
     m_main = (M / BK) * BK;
     splits = pick_splits(m_main > 0 ? m_main : 1, tiles);
     kchunk = (int)(ceil_div(ceil_div(m_main > 0 ? m_main : 1, splits), BK) * BK);

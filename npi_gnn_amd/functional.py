@@ -9,6 +9,7 @@ Formulas (PyG 1.4.2):
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -18,6 +19,18 @@ from .graph import CSRGraph, CSRSide, as_graph
 
 
 _PROFILE = None     # bench.py sets this to a list to collect (start, end) events per segsum launch
+
+# measured at C4 (round 1): 8.82 -> 8.74 ms per step (both kernels fill the chip), so off by default
+OVERLAP_STREAMS = os.environ.get("NPI_OVERLAP_STREAMS", "0") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _SIDE_STREAMS[dev] = s
+    return s
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -125,13 +138,30 @@ class _SageConvFn(torch.autograd.Function):
         graph: CSRGraph = ctx.graph
         grad_out = _f32c(grad_out, "grad_out")
         dx = dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        want_x = ctx.needs_input_grad[0]
+        side = None
+        if want_w and want_x and OVERLAP_STREAMS:
+            # dW = aggT dOut is MFMA-bound and independent of the dX chain, whose segsum is HBM-bound:
+            # run it on a second HIP stream so the two share the chip instead of queueing
+            dev = grad_out.device
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
+            for t in (dw, db, agg, grad_out):
+                if t is not None:
+                    t.record_stream(side)
+        elif want_w:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)       # aggT dOut, colsum
-        if ctx.needs_input_grad[0]:
+        if want_x:
             # dAgg = dOut W^T, pre-divided by the in-count of its row (fused epilogue), then
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
             dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst))
             dx = segsum(graph, graph.by_src, dagg, mean=False)
+        if side is not None:
+            torch.cuda.current_stream(grad_out.device).wait_stream(side)
         return dx, dw, db, None
 
 
