@@ -153,6 +153,19 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
                           int64_t M, int64_t K, int64_t N,
                           float* workspace, int64_t workspace_elems, void* stream);
 
+/* The same three GEMMs with A / W / C / bias / dW / db stored as `dtype` (NPI_F32 or NPI_BF16; bf16
+ * storage, f32 MFMA accumulation, f32 rowscale and workspace) -- BASELINE.json configs[1]. */
+int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                     const float* rowscale, void* C, int64_t ldc,
+                     int64_t M, int64_t K, int64_t N, int relu, int dtype, void* stream);
+int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+                          const float* rowscale, void* dA, int64_t ldda,
+                          int64_t M, int64_t K, int64_t N, int dtype, void* stream);
+int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t lddc,
+                            void* dW, int64_t lddw, void* db,
+                            int64_t M, int64_t K, int64_t N,
+                            float* workspace, int64_t workspace_elems, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GATConv (PyG 1.4.2; absent from the reference tree, BASELINE.json configs[4]).  H heads of C
  * channels, hfeat = x @ W is [N, H*C]; att is [H, 2C] (first C multiply the TARGET's features).

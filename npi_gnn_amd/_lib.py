@@ -42,6 +42,9 @@ PROTOTYPES = {
     "npi_colsum": (c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_linear_bwd_weight_workspace_elems": (_I, [_I, _I, _I]),
     "npi_linear_bwd_weight": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "npi_linear_fwd_t": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, _P]),
+    "npi_linear_bwd_data_t": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, _P]),
+    "npi_linear_bwd_weight_t": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, _P]),
     "npi_gat_scores": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "npi_gat_softmax_stats": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P]),
     "npi_gat_aggregate": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,

@@ -338,7 +338,7 @@ extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, cons
     P.carry = carry; P.w = nullptr; P.bias = bias;
     P.H = (int)H; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.m = m; P.s = s; P.slope = slope;
     P.g_dst = g_dst; P.g_src = g_src; P.att = att;
-    return segsum_run(P, by_source ? W_GAT_SRC : W_GAT_DST, 0, nnz_max, stream);
+    return segsum_run(P, by_source ? W_GAT_SRC : W_GAT_DST, 0, nnz_max, NPI_F32, stream);
 }
 
 extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,

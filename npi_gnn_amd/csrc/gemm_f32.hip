@@ -98,9 +98,22 @@ struct Stage {
     }
 };
 
+// storage element types of the EDGE kernel: float, or bf16 carried as uint16_t (f32 MFMA accumulation)
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                       __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = __builtin_bit_cast(bf16_t, (__bf16)v); }
+
 // guarded load of staging slot p (EDGE kernel): rows beyond rmax / k beyond kmax read as zero
-template <int MODE_KCONTIG, int ROWS, bool VEC4>
-__device__ __forceinline__ float4 guarded_load(const float* __restrict__ base, int64_t ld, int r0, int rmax,
+template <int MODE_KCONTIG, int ROWS, bool VEC4, typename T>
+__device__ __forceinline__ float4 guarded_load(const T* __restrict__ base, int64_t ld, int r0, int rmax,
                                                int k0, int kmax, int t, int p) {
     using S = Stage<MODE_KCONTIG, ROWS>;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -108,24 +121,24 @@ __device__ __forceinline__ float4 guarded_load(const float* __restrict__ base, i
     const int k = k0 + S::k_of(t, p);
     if (MODE_KCONTIG) {
         if (r < rmax) {
-            const float* src = base + (int64_t)r * ld + k;
-            if (VEC4) { if (k < kmax) v = *reinterpret_cast<const float4*>(src); }
+            const T* src = base + (int64_t)r * ld + k;
+            if (VEC4) { if (k < kmax) v = ld4(src); }
             else {
-                if (k + 0 < kmax) v.x = src[0];
-                if (k + 1 < kmax) v.y = src[1];
-                if (k + 2 < kmax) v.z = src[2];
-                if (k + 3 < kmax) v.w = src[3];
+                if (k + 0 < kmax) v.x = ld1(src + 0);
+                if (k + 1 < kmax) v.y = ld1(src + 1);
+                if (k + 2 < kmax) v.z = ld1(src + 2);
+                if (k + 3 < kmax) v.w = ld1(src + 3);
             }
         }
     } else {
         if (k < kmax) {
-            const float* src = base + (int64_t)k * ld + r;
-            if (VEC4) { if (r < rmax) v = *reinterpret_cast<const float4*>(src); }
+            const T* src = base + (int64_t)k * ld + r;
+            if (VEC4) { if (r < rmax) v = ld4(src); }
             else {
-                if (r + 0 < rmax) v.x = src[0];
-                if (r + 1 < rmax) v.y = src[1];
-                if (r + 2 < rmax) v.z = src[2];
-                if (r + 3 < rmax) v.w = src[3];
+                if (r + 0 < rmax) v.x = ld1(src + 0);
+                if (r + 1 < rmax) v.y = ld1(src + 1);
+                if (r + 2 < rmax) v.z = ld1(src + 2);
+                if (r + 3 < rmax) v.w = ld1(src + 3);
             }
         }
     }
@@ -188,8 +201,8 @@ __device__ __forceinline__ void mma_step(const float* __restrict__ as, const flo
 // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5).
 // Every operand is fetched BEFORE the store loop: a load inside it makes hipcc wait vmcnt(0) per
 // element, which also drains the preceding store (64 serialised stores per lane).
-template <bool GUARD, int TM, int TN>
-__device__ __forceinline__ void store_tile(float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+template <bool GUARD, int TM, int TN, typename T = float>
+__device__ __forceinline__ void store_tile(T* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
                                            int wm, int wn, int li, int lh, const f32x16 (&acc)[TM][TN],
                                            const Epilogue& ep) {
     float rsv[TM][16];
@@ -212,10 +225,10 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, int64_t ldc, i
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int c = nw + j * 32 + li;
-        bv[j] = (ep.bias != nullptr) ? ep.bias[GUARD ? min(c, N - 1) : c] : 0.f;
+        bv[j] = (ep.bias != nullptr) ? ld1(reinterpret_cast<const T*>(ep.bias) + (GUARD ? min(c, N - 1) : c)) : 0.f;
     }
     const bool relu_on = ep.relu != 0;
-    float* __restrict__ cbase = C + (int64_t)(mw + 4 * lh) * ldc + (nw + li);
+    T* __restrict__ cbase = C + (int64_t)(mw + 4 * lh) * ldc + (nw + li);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -226,10 +239,10 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, int64_t ldc, i
                 float v = fmaf(acc[i][j][q], rsv[i][q], bv[j]);
                 v = (relu_on && v < 0.f) ? 0.f : v;          // keeps NaN, like torch.relu
                 if (!GUARD) {
-                    cbase[(int64_t)ro * ldc + j * 32] = v;
+                    st1(cbase + (int64_t)ro * ldc + j * 32, v);
                 } else {
                     const int r = mw + 4 * lh + ro, c = nw + j * 32 + li;
-                    if (r < M && c < N) cbase[(int64_t)ro * ldc + j * 32] = v;
+                    if (r < M && c < N) st1(cbase + (int64_t)ro * ldc + j * 32, v);
                 }
             }
         }
@@ -346,7 +359,8 @@ gemm_fast_kernel(GemmArgs a) {
     store_tile<false, TM, TN>(a.C + (int64_t)z * a.slab_stride, a.ldc, a.M, a.N, m0, n0, wm, wn, li, lh, acc, a.ep);
 }
 
-template <int AMODE, int BMODE, bool VEC4>
+// TI: element type of A and B; TO: element type of C and bias (f32 slabs for the split-K dW)
+template <int AMODE, int BMODE, bool VEC4, typename TI = float, typename TO = float>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
 gemm_edge_kernel(GemmArgs a) {
     constexpr int TM = 2, TN = 2, BM = 128, BN = 128;
@@ -368,9 +382,9 @@ gemm_edge_kernel(GemmArgs a) {
     float4 ra[SA::NP], rb[SB::NP];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < SA::NP; ++p) ra[p] = guarded_load<AMODE == 0, BM, VEC4>(a.A, a.lda, m0, a.M, k0, kend, t, p);
+        for (int p = 0; p < SA::NP; ++p) ra[p] = guarded_load<AMODE == 0, BM, VEC4, TI>(reinterpret_cast<const TI*>(a.A), a.lda, m0, a.M, k0, kend, t, p);
 #pragma unroll
-        for (int p = 0; p < SB::NP; ++p) rb[p] = guarded_load<BMODE == 1, BN, VEC4>(a.B, a.ldb, n0, a.N, k0, kend, t, p);
+        for (int p = 0; p < SB::NP; ++p) rb[p] = guarded_load<BMODE == 1, BN, VEC4, TI>(reinterpret_cast<const TI*>(a.B), a.ldb, n0, a.N, k0, kend, t, p);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -405,18 +419,19 @@ gemm_edge_kernel(GemmArgs a) {
         __syncthreads();
     }
     if (do_colsum && t < BN && n0 + t < a.N) a.ep.colsum[(int64_t)z * a.N + n0 + t] = csum;
-    store_tile<true, TM, TN>(a.C + (int64_t)z * a.slab_stride, a.ldc, a.M, a.N, m0, n0, wm, wn, li, lh, acc, a.ep);
+    store_tile<true, TM, TN, TO>(reinterpret_cast<TO*>(a.C) + (int64_t)z * a.slab_stride, a.ldc, a.M, a.N, m0, n0, wm, wn, li, lh, acc, a.ep);
 }
 
 // out[r, c] = sum_z slabs[z][r, c]  (z ascending: deterministic)
+template <typename TO>
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nslab,
-                                   int rows, int cols, int64_t ld_slab, float* __restrict__ out, int64_t ldo) {
+                                   int rows, int cols, int64_t ld_slab, TO* __restrict__ out, int64_t ldo) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * cols) return;
     int r = (int)(i / cols), c = (int)(i % cols);
     float s = 0.f;
     for (int z = 0; z < nslab; ++z) s += slabs[(int64_t)z * slab_stride + (int64_t)r * ld_slab + c];
-    out[(int64_t)r * ldo + c] = s;
+    st1(out + (int64_t)r * ldo + c, s);
 }
 
 // partial column sums of X[M, N] over row chunks: part[chunk][c].  Lanes walk a row 16 B each
@@ -452,8 +467,8 @@ colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, fl
         part[(int64_t)blockIdx.y * N + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent) {
-    return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0) && (inner_extent % 4 == 0);
+static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4) {
+    return ((uintptr_t)p % (4 * es) == 0) && (ld % 4 == 0) && (inner_extent % 4 == 0);
 }
 
 static int pick_splits(int64_t M, int64_t tiles) {
@@ -466,9 +481,10 @@ static int pick_splits(int64_t M, int64_t tiles) {
 
 // Cover the (M x N) output with the FAST kernel on full tiles and the 128x128 EDGE kernel on the
 // two ragged strips.  `splits` slabs along the contraction; the fast path needs K % BK == 0.
+// dtype_in: storage of A and B; dtype_out: storage of C and bias.  bf16 runs the guarded kernel only.
 template <int AMODE, int BMODE>
-static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream) {
-    const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0);
+static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32) {
+    const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && dtype_in == NPI_F32 && dtype_out == NPI_F32;
     // 128 x 256 tile (one workgroup per CU): measured 3-10 % SLOWER than 128 x 128 at C4 (round 1:
     // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms), so it is opt-in (NPI_GEMM_WIDE=1)
     static const bool wide_enabled = [] { const char* e = getenv("NPI_GEMM_WIDE"); return e && e[0] == '1'; }();
@@ -489,8 +505,17 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream) {
         if (nm <= 0 || nn <= 0) return;
         GemmArgs e = a;
         e.tm0 = tm0; e.tn0 = tn0;
-        if (v4) gemm_edge_kernel<AMODE, BMODE, true><<<dim3(nn, nm, splits), GEMM_THREADS, 0, stream>>>(e);
-        else    gemm_edge_kernel<AMODE, BMODE, false><<<dim3(nn, nm, splits), GEMM_THREADS, 0, stream>>>(e);
+        const dim3 g(nn, nm, splits);
+        if (dtype_in == NPI_BF16 && dtype_out == NPI_BF16) {
+            if (v4) gemm_edge_kernel<AMODE, BMODE, true, bf16_t, bf16_t><<<g, GEMM_THREADS, 0, stream>>>(e);
+            else    gemm_edge_kernel<AMODE, BMODE, false, bf16_t, bf16_t><<<g, GEMM_THREADS, 0, stream>>>(e);
+        } else if (dtype_in == NPI_BF16) {
+            if (v4) gemm_edge_kernel<AMODE, BMODE, true, bf16_t, float><<<g, GEMM_THREADS, 0, stream>>>(e);
+            else    gemm_edge_kernel<AMODE, BMODE, false, bf16_t, float><<<g, GEMM_THREADS, 0, stream>>>(e);
+        } else {
+            if (v4) gemm_edge_kernel<AMODE, BMODE, true><<<g, GEMM_THREADS, 0, stream>>>(e);
+            else    gemm_edge_kernel<AMODE, BMODE, false><<<g, GEMM_THREADS, 0, stream>>>(e);
+        }
     };
     if (em > 0 && en > 0) {
         edge(em, 0, tm - em, tn);        // bottom strip (all columns)
@@ -504,36 +529,53 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream) {
 
 using namespace npi;
 
-extern "C" int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                              const float* rowscale, float* C, int64_t ldc, int64_t M, int64_t K,
-                              int64_t N, int relu, void* stream_) {
+static inline const float* fp(const void* p) { return reinterpret_cast<const float*>(p); }
+static inline const void* advance(const void* p, int64_t elems, int es) { return reinterpret_cast<const char*>(p) + elems * es; }
+
+extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                                const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
+                                int64_t N, int relu, int dtype, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_fwd: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_fwd: size > int32");
+    NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_fwd: bad dtype");
     if (M == 0) return NPI_OK;
     NPI_REQUIRE(A && W && C, "npi_linear_fwd: null pointer");
     NPI_REQUIRE(lda >= K && ldw >= N && ldc >= N, "npi_linear_fwd: leading dimension too small");
-    GemmArgs a{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
-               Epilogue{bias, rowscale, relu, nullptr}};
-    launch_gemm<0, 0>(vec4_ok(A, lda, K) && vec4_ok(W, ldw, N), a, 1, stream);
+    const int es = dtype == NPI_BF16 ? 2 : 4;
+    GemmArgs a{fp(A), lda, fp(W), ldw, (float*)C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
+               Epilogue{fp(bias), rowscale, relu, nullptr}};
+    launch_gemm<0, 0>(vec4_ok(A, lda, K, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
     return check_launch("npi_linear_fwd");
+}
+extern "C" int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                              const float* rowscale, float* C, int64_t ldc, int64_t M, int64_t K,
+                              int64_t N, int relu, void* stream_) {
+    return npi_linear_fwd_t(A, lda, W, ldw, bias, rowscale, C, ldc, M, K, N, relu, NPI_F32, stream_);
 }
 
 // dA[M,K] = rowscale * (dC[M,N] @ W[K,N]^T): GEMM with "K" = N (contracted), output width K
-extern "C" int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
-                                   const float* rowscale, float* dA, int64_t ldda, int64_t M, int64_t K,
-                                   int64_t N, void* stream_) {
+extern "C" int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+                                     const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
+                                     int64_t N, int dtype, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_data: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_data: size > int32");
+    NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_bwd_data: bad dtype");
     if (M == 0) return NPI_OK;
     NPI_REQUIRE(dC && W && dA, "npi_linear_bwd_data: null pointer");
     NPI_REQUIRE(lddc >= N && ldw >= N && ldda >= K, "npi_linear_bwd_data: leading dimension too small");
+    const int es = dtype == NPI_BF16 ? 2 : 4;
     // B(k = n_contract, n = k_out) = W[k_out * ldw + n_contract]  -> BMODE 1
-    GemmArgs a{dC, lddc, W, ldw, dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
+    GemmArgs a{fp(dC), lddc, fp(W), ldw, (float*)dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
                Epilogue{nullptr, rowscale, 0, nullptr}};
-    launch_gemm<0, 1>(vec4_ok(dC, lddc, N) && vec4_ok(W, ldw, N), a, 1, stream);
+    launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
     return check_launch("npi_linear_bwd_data");
+}
+extern "C" int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
+                                   const float* rowscale, float* dA, int64_t ldda, int64_t M, int64_t K,
+                                   int64_t N, void* stream_) {
+    return npi_linear_bwd_data_t(dC, lddc, W, ldw, rowscale, dA, ldda, M, K, N, NPI_F32, stream_);
 }
 
 extern "C" int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
@@ -549,7 +591,7 @@ extern "C" int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, flo
     dim3 cg((unsigned)ceil_div(N, 256), (unsigned)nchunks);
     if (vec4_ok(X, ldx, N)) colsum_partial_kernel<true><<<cg, 256, 0, stream>>>(X, ldx, (int)M, (int)N, workspace);
     else                    colsum_partial_kernel<false><<<cg, 256, 0, stream>>>(X, ldx, (int)M, (int)N, workspace);
-    slab_reduce_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(workspace, N, nchunks, 1, (int)N, N, out, N);
+    slab_reduce_kernel<float><<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(workspace, N, nchunks, 1, (int)N, N, out, N);
     return check_launch("npi_colsum");
 }
 
@@ -571,36 +613,49 @@ extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, i
     return (int64_t)(splits + 1) * K * N + (int64_t)(splits + 1) * N + 64;      // dW slabs, then db slabs
 }
 
-// dW[K,N] = A[M,K]^T @ dC[M,N] (contract over M), db[N] = colsum(dC)
-extern "C" int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t lddc,
-                                     float* dW, int64_t lddw, float* db, int64_t M, int64_t K, int64_t N,
-                                     float* workspace, int64_t workspace_elems, void* stream_) {
+// dW[K,N] = A[M,K]^T @ dC[M,N] (contract over M), db[N] = colsum(dC); A, dC, dW, db stored as `dtype`
+extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t lddc,
+                                       void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
+                                       float* workspace, int64_t workspace_elems, int dtype, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_weight: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_weight: size > int32");
+    NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_bwd_weight: bad dtype");
     NPI_REQUIRE(A && dC && dW && workspace, "npi_linear_bwd_weight: null pointer");
     NPI_REQUIRE(lda >= K && lddc >= N && lddw >= N, "npi_linear_bwd_weight: leading dimension too small");
     if (workspace_elems < npi_linear_bwd_weight_workspace_elems(M, K, N)) {
         set_error("npi_linear_bwd_weight: workspace too small");
         return NPI_ERR_WORKSPACE;
     }
+    const int es = dtype == NPI_BF16 ? 2 : 4;
     int splits, kchunk;
     int64_t m_main;
     bwd_weight_plan(M, K, N, splits, kchunk, m_main);
     const int nslab = splits + 1;
     float* db_slabs = workspace + (int64_t)nslab * K * N;
-    const bool v4 = vec4_ok(A, lda, K) && vec4_ok(dC, lddc, N);
+    const bool v4 = vec4_ok(A, lda, K, es) && vec4_ok(dC, lddc, N, es);
     // output rows = K (features of A), cols = N; A(m = feature, k = node) = A[node*lda + feature]
-    // main part: nodes [0, m_main) in `splits` slabs
-    GemmArgs a{A, lda, dC, lddc, workspace, N, (int)K, (int)N, (int)m_main, kchunk, 0, 0, K * N,
+    // main part: nodes [0, m_main) in `splits` f32 slabs
+    GemmArgs a{fp(A), lda, fp(dC), lddc, workspace, N, (int)K, (int)N, (int)m_main, kchunk, 0, 0, K * N,
                Epilogue{nullptr, nullptr, 0, db ? db_slabs : nullptr}};
-    launch_gemm<1, 0>(v4, a, splits, stream);
+    launch_gemm<1, 0>(v4, a, splits, stream, dtype, NPI_F32);
     // remainder: nodes [m_main, M) into slab `splits` (a zero slab when there is none)
-    GemmArgs r{A + m_main * lda, lda, dC + m_main * lddc, lddc, workspace + (int64_t)splits * K * N, N,
-               (int)K, (int)N, (int)(M - m_main), BK, 0, 0, K * N,
+    GemmArgs r{fp(advance(A, m_main * lda, es)), lda, fp(advance(dC, m_main * lddc, es)), lddc,
+               workspace + (int64_t)splits * K * N, N, (int)K, (int)N, (int)(M - m_main), BK, 0, 0, K * N,
                Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)splits * N : nullptr}};
-    launch_gemm<1, 0>(false, r, 1, stream);
-    slab_reduce_kernel<<<(unsigned)ceil_div(K * N, 256), 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, dW, lddw);
-    if (db) slab_reduce_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, db, N);
+    launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
+    const unsigned gw = (unsigned)ceil_div(K * N, 256), gb = (unsigned)ceil_div(N, 256);
+    if (dtype == NPI_BF16) {
+        slab_reduce_kernel<bf16_t><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (bf16_t*)dW, lddw);
+        if (db) slab_reduce_kernel<bf16_t><<<gb, 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, (bf16_t*)db, N);
+    } else {
+        slab_reduce_kernel<float><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (float*)dW, lddw);
+        if (db) slab_reduce_kernel<float><<<gb, 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, (float*)db, N);
+    }
     return check_launch("npi_linear_bwd_weight");
+}
+extern "C" int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t lddc,
+                                     float* dW, int64_t lddw, float* db, int64_t M, int64_t K, int64_t N,
+                                     float* workspace, int64_t workspace_elems, void* stream_) {
+    return npi_linear_bwd_weight_t(A, lda, dC, lddc, dW, lddw, db, M, K, N, workspace, workspace_elems, NPI_F32, stream_);
 }

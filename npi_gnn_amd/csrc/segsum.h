@@ -32,6 +32,7 @@ struct SegParams {
     const float* att;        // [H, 2C]
 };
 
-int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, hipStream_t stream);
+// x / out / bias are stored as `dtype` (NPI_F32 or NPI_BF16; the struct's float* are reinterpreted)
+int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hipStream_t stream);
 
 }  // namespace npi

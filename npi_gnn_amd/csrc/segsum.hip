@@ -26,28 +26,59 @@ namespace npi {
 
 constexpr int SEG_THREADS = 256;
 constexpr int SEG_WAVES = SEG_THREADS / WAVE;
-constexpr int T = NPI_ITEM_EDGES;
+constexpr int ITEM = NPI_ITEM_EDGES;
 
-template <int VEC> struct vec_of;
-template <> struct vec_of<1> { using type = float; };
-template <> struct vec_of<2> { using type = float2; };
-template <> struct vec_of<4> { using type = float4; };
-
-template <int VEC>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&d)[VEC]) {
-    using V = typename vec_of<VEC>::type;
-    V v = *reinterpret_cast<const V*>(p);
-    if constexpr (VEC == 1) { d[0] = v; }
-    if constexpr (VEC == 2) { d[0] = v.x; d[1] = v.y; }
-    if constexpr (VEC == 4) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+// storage element types: float, or bf16 carried as uint16_t (f32 accumulation either way)
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
+    return __builtin_bit_cast(bf16_t, (__bf16)v);          // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
 }
-template <int VEC>
-__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&d)[VEC]) {
-    using V = typename vec_of<VEC>::type;
+
+template <typename T, int VEC> struct vec_of;
+template <> struct vec_of<float, 1> { using type = float; };
+template <> struct vec_of<float, 2> { using type = float2; };
+template <> struct vec_of<float, 4> { using type = float4; };
+template <> struct vec_of<bf16_t, 1> { using type = uint16_t; };
+template <> struct vec_of<bf16_t, 2> { using type = uint32_t; };
+template <> struct vec_of<bf16_t, 4> { using type = uint2; };
+
+template <int VEC, typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, float (&d)[VEC]) {
+    using V = typename vec_of<T, VEC>::type;
+    V v = *reinterpret_cast<const V*>(p);
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (VEC == 1) { d[0] = v; }
+        if constexpr (VEC == 2) { d[0] = v.x; d[1] = v.y; }
+        if constexpr (VEC == 4) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    } else {
+        if constexpr (VEC == 1) { d[0] = to_f32((bf16_t)v); }
+        if constexpr (VEC == 2) { d[0] = __uint_as_float(v << 16); d[1] = __uint_as_float(v & 0xffff0000u); }
+        if constexpr (VEC == 4) {
+            d[0] = __uint_as_float(v.x << 16); d[1] = __uint_as_float(v.x & 0xffff0000u);
+            d[2] = __uint_as_float(v.y << 16); d[3] = __uint_as_float(v.y & 0xffff0000u);
+        }
+    }
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void store_row(T* __restrict__ p, const float (&d)[VEC]) {
+    using V = typename vec_of<T, VEC>::type;
     V v;
-    if constexpr (VEC == 1) { v = d[0]; }
-    if constexpr (VEC == 2) { v.x = d[0]; v.y = d[1]; }
-    if constexpr (VEC == 4) { v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3]; }
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (VEC == 1) { v = d[0]; }
+        if constexpr (VEC == 2) { v.x = d[0]; v.y = d[1]; }
+        if constexpr (VEC == 4) { v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3]; }
+    } else {
+        if constexpr (VEC == 1) { v = from_f32<bf16_t>(d[0]); }
+        if constexpr (VEC == 2) { v = (uint32_t)from_f32<bf16_t>(d[0]) | ((uint32_t)from_f32<bf16_t>(d[1]) << 16); }
+        if constexpr (VEC == 4) {
+            v.x = (uint32_t)from_f32<bf16_t>(d[0]) | ((uint32_t)from_f32<bf16_t>(d[1]) << 16);
+            v.y = (uint32_t)from_f32<bf16_t>(d[2]) | ((uint32_t)from_f32<bf16_t>(d[3]) << 16);
+        }
+    }
     *reinterpret_cast<V*>(p) = v;
 }
 
@@ -74,10 +105,11 @@ struct Lanes {
 };
 
 // scale, bias and epilogue of a finished row r, then the store
-template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, NCH, WMODE, EXACT>& L,
                                            const float (&acc)[NCH][VEC], int r, int row_len) {
-    float* __restrict__ dst = P.out + (int64_t)r * P.ldo;
+    T* __restrict__ dst = reinterpret_cast<T*>(P.out) + (int64_t)r * P.ldo;
+    const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (!L.act[c]) continue;
@@ -87,7 +119,7 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
         float t[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            t[q] = fmaf(acc[c][q], sc, P.bias ? P.bias[L.foff[c] + q] : 0.f);
+            t[q] = fmaf(acc[c][q], sc, bias ? to_f32(bias[L.foff[c] + q]) : 0.f);
         }
         if (WMODE == W_GAT_SRC && P.g_dst != nullptr) {
             const int h = L.hd[c];
@@ -96,11 +128,11 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
 #pragma unroll
             for (int q = 0; q < VEC; ++q) t[q] += gd * at[q] + gs * at[P.C + q];
         }
-        store_row<VEC>(dst + L.foff[c], t);
+        store_row<VEC, T>(dst + L.foff[c], t);
     }
 }
 
-template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
 segsum_kernel(SegParams P) {
     constexpr int U = inflight<VEC, NCH>::value;
@@ -109,10 +141,11 @@ segsum_kernel(SegParams P) {
     if (item >= P.n_items) return;
     const int N = P.N;
     const int nnz = P.rowptr[N];
-    const int k0 = item * T;
+    const int k0 = item * ITEM;
     if (k0 >= nnz) return;
-    const int k1 = min(k0 + T, nnz);
+    const int k1 = min(k0 + ITEM, nnz);
     const int F = P.F;
+    const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
 
     Lanes<VEC, NCH, WMODE, EXACT> L;
     L.init(P);
@@ -155,7 +188,7 @@ segsum_kernel(SegParams P) {
         float* __restrict__ dst = P.carry + ((int64_t)item * 2 + slot) * F;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
-            if (L.act[c]) store_row<VEC>(dst + L.foff[c], acc[c]);
+            if (L.act[c]) store_row<VEC, float>(dst + L.foff[c], acc[c]);
     };
     // row r is complete (its last entry has been accumulated, or it is empty)
     auto close_row = [&]() {
@@ -163,7 +196,7 @@ segsum_kernel(SegParams P) {
             write_carry(0);
             head = false;
         } else {
-            finish_row<VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, row_end - row_start);
+            finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, row_end - row_start);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -199,10 +232,10 @@ segsum_kernel(SegParams P) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cu = bcast_i(cv, j + u);
-                const float* src = P.x + (int64_t)cu * P.ldx;
+                const T* src = xT + (int64_t)cu * P.ldx;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    if (L.act[c]) load_row<VEC>(src + L.foff[c], v[u][c]);
+                    if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[u][c]);
                     else {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) v[u][c][q] = 0.f;
@@ -235,10 +268,10 @@ segsum_kernel(SegParams P) {
             float v[NCH][VEC];
             float g0[NCH], g1[NCH], g2[NCH];
             const int cu = bcast_i(cv, j);
-            const float* src = P.x + (int64_t)cu * P.ldx;
+            const T* src = xT + (int64_t)cu * P.ldx;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (L.act[c]) load_row<VEC>(src + L.foff[c], v[c]);
+                if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[c]);
                 else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) v[c][q] = 0.f;
@@ -283,7 +316,7 @@ segsum_kernel(SegParams P) {
 constexpr int FIX_COOP_MIN = 16;     // chain length from which all 4 waves cooperate
 constexpr int FIX_U = 8;
 
-template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
 segsum_fixup_kernel(SegParams P) {
     __shared__ float red[SEG_WAVES][NCH * VEC * WAVE];
@@ -292,14 +325,14 @@ segsum_fixup_kernel(SegParams P) {
     const int item = blockIdx.x;
     const int N = P.N, F = P.F;
     const int nnz = P.rowptr[N];
-    const int k0 = item * T;
-    const int k1 = k0 + T;
+    const int k0 = item * ITEM;
+    const int k1 = k0 + ITEM;
     if (k1 >= nnz) return;                               // last item: nothing continues
     const int r = uniform_i(P.item_row[item + 1]);       // row holding entry k1
     const int rs = uniform_i(P.rowptr[r]);
     if (rs >= k1 || rs < k0) return;                     // not cut here / owned by an earlier item
     const int re = uniform_i(P.rowptr[r + 1]);
-    const int last = (re - 1) / T;
+    const int last = (re - 1) / ITEM;
     const int len = last - item;                         // head partials to add (>= 1)
     const bool coop = len >= FIX_COOP_MIN;               // workgroup-uniform
     if (!coop && wave != 0) return;
@@ -313,7 +346,7 @@ segsum_fixup_kernel(SegParams P) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         // wave 0 starts from the owner's tail partial, the other slices from zero
-        if (L.act[c] && wave == 0) load_row<VEC>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);
+        if (L.act[c] && wave == 0) load_row<VEC, float>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);
         else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) acc[c][q] = 0.f;
@@ -327,7 +360,7 @@ segsum_fixup_kernel(SegParams P) {
             const float* src = P.carry + ((int64_t)(j + u) * 2 + 0) * F;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (L.act[c]) load_row<VEC>(src + L.foff[c], v[u][c]);
+                if (L.act[c]) load_row<VEC, float>(src + L.foff[c], v[u][c]);
                 else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) v[u][c][q] = 0.f;
@@ -347,7 +380,7 @@ segsum_fixup_kernel(SegParams P) {
         for (int c = 0; c < NCH; ++c) {
             float v[VEC];
             if (L.act[c]) {
-                load_row<VEC>(src + L.foff[c], v);
+                load_row<VEC, float>(src + L.foff[c], v);
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[c][q] += v[q];
             }
@@ -369,37 +402,37 @@ segsum_fixup_kernel(SegParams P) {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[c][q] += red[w][(c * VEC + q) * WAVE + lane];
     }
-    finish_row<VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, re - rs);
+    finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, re - rs);
 }
 
-template <int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 static void launch_one(const SegParams& P, hipStream_t stream) {
     dim3 grid((unsigned)ceil_div(P.n_items, SEG_WAVES)), block(SEG_THREADS);
-    segsum_kernel<VEC, NCH, WMODE, MEAN, EXACT><<<grid, block, 0, stream>>>(P);
-    segsum_fixup_kernel<VEC, NCH, WMODE, MEAN, EXACT><<<dim3((unsigned)P.n_items), block, 0, stream>>>(P);   // one workgroup per item
+    segsum_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<grid, block, 0, stream>>>(P);
+    segsum_fixup_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<dim3((unsigned)P.n_items), block, 0, stream>>>(P);   // one workgroup per item
 }
 
-template <int VEC, int NCH, bool EXACT>
+template <typename T, int VEC, int NCH, bool EXACT>
 static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t stream) {
-    if (wmode == W_NONE) { if (mean) launch_one<VEC, NCH, W_NONE, true, EXACT>(P, stream); else launch_one<VEC, NCH, W_NONE, false, EXACT>(P, stream); }
-    else if (wmode == W_ARRAY) { if (mean) launch_one<VEC, NCH, W_ARRAY, true, EXACT>(P, stream); else launch_one<VEC, NCH, W_ARRAY, false, EXACT>(P, stream); }
+    if (wmode == W_NONE) { if (mean) launch_one<T, VEC, NCH, W_NONE, true, EXACT>(P, stream); else launch_one<T, VEC, NCH, W_NONE, false, EXACT>(P, stream); }
+    else if (wmode == W_ARRAY) { if (mean) launch_one<T, VEC, NCH, W_ARRAY, true, EXACT>(P, stream); else launch_one<T, VEC, NCH, W_ARRAY, false, EXACT>(P, stream); }
     else if (wmode == W_GAT_DST) {
-        if constexpr (VEC == 4) launch_one<VEC, NCH, W_GAT_DST, false, EXACT>(P, stream);
+        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, false, EXACT>(P, stream);
     } else {
-        if constexpr (VEC == 4) launch_one<VEC, NCH, W_GAT_SRC, false, EXACT>(P, stream);
+        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC, false, EXACT>(P, stream);
     }
     return check_launch("npi_segsum");
 }
 
-template <int VEC>
+template <typename T, int VEC>
 static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t stream) {
     const int per = WAVE * VEC;
     const int nch = (int)ceil_div(P.F, per);
     const bool exact = (P.F % per) == 0;
 #define NPI_SEG_CASE(NC)                                                                    \
     case NC:                                                                                \
-        return exact ? launch_segsum<VEC, NC, true>(P, wmode, mean, stream)                 \
-                     : launch_segsum<VEC, NC, false>(P, wmode, mean, stream)
+        return exact ? launch_segsum<T, VEC, NC, true>(P, wmode, mean, stream)              \
+                     : launch_segsum<T, VEC, NC, false>(P, wmode, mean, stream)
     switch (nch) {
         NPI_SEG_CASE(1);
         NPI_SEG_CASE(2);
@@ -413,21 +446,22 @@ static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t str
 }
 
 // shared by npi_segsum and npi_gat_aggregate (gat.hip)
-int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, hipStream_t stream) {
+int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hipStream_t stream) {
     const int64_t F = P.F;
-    const float* x = P.x;
-    float* out = P.out;
-    const float* bias = P.bias;
+    const int es = (dtype == NPI_BF16) ? 2 : 4;              // bytes per stored element
+    const char* x = reinterpret_cast<const char*>(P.x);
+    char* out = reinterpret_cast<char*>(P.out);
+    const char* bias = reinterpret_cast<const char*>(P.bias);
     // widest vector the row pitch and base alignment allow
     auto aligned = [&](int v) {
         return (F % v == 0) && (P.ldx % v == 0) && (P.ldo % v == 0) &&
-               (((uintptr_t)x % (4 * v)) == 0) && (((uintptr_t)out % (4 * v)) == 0) &&
+               (((uintptr_t)x % (es * v)) == 0) && (((uintptr_t)out % (es * v)) == 0) &&
                (((uintptr_t)P.carry % (4 * v)) == 0);
     };
     const int vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
     if (wmode >= W_GAT_DST) {
-        if (vec != 4 || P.C % 4 != 0 || F > 4 * WAVE * 4) {
-            set_error("npi_gat_aggregate: needs 16-B aligned rows, out_channels %% 4 == 0 and heads*out_channels <= 1024");
+        if (dtype != NPI_F32 || vec != 4 || P.C % 4 != 0 || F > 4 * WAVE * 4) {
+            set_error("npi_gat_aggregate: needs f32, 16-B aligned rows, out_channels %% 4 == 0 and heads*out_channels <= 1024");
             return NPI_ERR_ARG;
         }
     }
@@ -437,12 +471,18 @@ int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, hipStream_t st
     for (int64_t f0 = 0; f0 < F && rc == NPI_OK; f0 += span) {
         SegParams Q = P;
         Q.F = (int)((F - f0 < span) ? (F - f0) : span);       // carry rows are Q.F wide for this column block
-        Q.x = x + f0;
-        Q.out = out + f0;
-        Q.bias = bias ? bias + f0 : nullptr;
-        if (vec == 4) rc = dispatch_nch<4>(Q, wmode, mean, stream);
-        else if (vec == 2) rc = dispatch_nch<2>(Q, wmode, mean, stream);
-        else rc = dispatch_nch<1>(Q, wmode, mean, stream);
+        Q.x = reinterpret_cast<const float*>(x + f0 * es);
+        Q.out = reinterpret_cast<float*>(out + f0 * es);
+        Q.bias = bias ? reinterpret_cast<const float*>(bias + f0 * es) : nullptr;
+        if (dtype == NPI_BF16) {
+            if (vec == 4) rc = dispatch_nch<bf16_t, 4>(Q, wmode, mean, stream);
+            else if (vec == 2) rc = dispatch_nch<bf16_t, 2>(Q, wmode, mean, stream);
+            else rc = dispatch_nch<bf16_t, 1>(Q, wmode, mean, stream);
+        } else {
+            if (vec == 4) rc = dispatch_nch<float, 4>(Q, wmode, mean, stream);
+            else if (vec == 2) rc = dispatch_nch<float, 2>(Q, wmode, mean, stream);
+            else rc = dispatch_nch<float, 1>(Q, wmode, mean, stream);
+        }
     }
     return rc;
 }
@@ -462,14 +502,15 @@ extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32
                           float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(N >= 0 && nnz_max >= 0 && F > 0, "npi_segsum: bad size");
-    NPI_REQUIRE(dtype == NPI_F32, "npi_segsum: only f32 features are implemented");
+    NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_segsum: dtype must be NPI_F32 or NPI_BF16");
     NPI_REQUIRE(ldx >= F && ldo >= F, "npi_segsum: leading dimension < F");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && item_row && x_ && out_ && carry, "npi_segsum: null pointer");
     const int64_t n_items = npi_num_items(nnz_max);
     if (n_items == 0) {     // no entries at all: every row is empty
         NPI_REQUIRE(bias == nullptr, "npi_segsum: bias with an entry-free graph is not supported");
-        (void)hipMemset2DAsync(out_, ldo * sizeof(float), 0, F * sizeof(float), N, stream);
+        const size_t es = (dtype == NPI_BF16) ? 2 : 4;
+        (void)hipMemset2DAsync(out_, ldo * es, 0, F * es, N, stream);
         return check_launch("npi_segsum(memset)");
     }
     NPI_REQUIRE(col != nullptr, "npi_segsum: null col");
@@ -479,5 +520,5 @@ extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32
     P.x = (const float*)x_; P.ldx = ldx; P.out = (float*)out_; P.ldo = ldo; P.F = (int)F;
     P.carry = carry; P.w = w; P.bias = bias;
     P.H = 1; P.C = (int)F;
-    return segsum_run(P, w ? W_ARRAY : W_NONE, mean, nnz_max, stream);
+    return segsum_run(P, w ? W_ARRAY : W_NONE, mean, nnz_max, dtype, stream);
 }

@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import NPI_F32, check, load, ptr, require_gpu, stream_ptr
+from ._lib import NPI_BF16, NPI_F32, check, load, ptr, require_gpu, stream_ptr
 from .graph import CSRGraph, CSRSide, as_graph
 
 
@@ -39,6 +39,19 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _fc(t: torch.Tensor, name: str, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 or bfloat16 storage (bf16: f32 accumulation inside the kernels); all operands alike."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"{name} must be float32 or bfloat16 (got {t.dtype})")
+    if like is not None and t.dtype != like.dtype:
+        raise TypeError(f"{name} is {t.dtype} but the other operand is {like.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _code(t: torch.Tensor) -> int:
+    return NPI_BF16 if t.dtype == torch.bfloat16 else NPI_F32
+
+
 # ---------------------------------------------------------------------------------------------
 # raw ops
 # ---------------------------------------------------------------------------------------------
@@ -48,19 +61,21 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     """out[i] = scale_i * sum_{p in row i} w[p] * x[col[p]] (+ bias): fused gather + segmented
     reduction (``npi_segsum``)."""
     dev = require_gpu(x, w, bias)
-    x = _f32c(x, "x")
+    x = _fc(x, "x")
+    if bias is not None:
+        bias = _fc(bias, "bias", x)
     N, F = side.n_rows, x.size(1)                  # `graph` may be None for a stand-alone (sharded) side
     if x.size(0) != side.n_cols:
         raise ValueError(f"x has {x.size(0)} rows, the adjacency indexes a table of {side.n_cols}")
     if out is None:
-        out = torch.empty((N, F), dtype=torch.float32, device=dev)
+        out = torch.empty((N, F), dtype=x.dtype, device=dev)
     carry = side.carry(F)
     prof = _PROFILE
     if prof is not None:        # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(dev))
     check(load().npi_segsum(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), ptr(w), N, side.nnz_max,
-                            ptr(x), x.stride(0), ptr(out), out.stride(0), F, NPI_F32, 1 if mean else 0,
+                            ptr(x), x.stride(0), ptr(out), out.stride(0), F, _code(x), 1 if mean else 0,
                             ptr(bias), ptr(carry), stream_ptr(dev)), "npi_segsum")
     if prof is not None:
         ev1.record(torch.cuda.current_stream(dev))
@@ -71,12 +86,15 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                rowscale: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     dev = require_gpu(a, weight, bias, rowscale)
-    a, weight = _f32c(a, "a"), _f32c(weight, "weight")
+    a = _fc(a, "a")
+    weight = _fc(weight, "weight", a)
+    if bias is not None:
+        bias = _fc(bias, "bias", a)
     M, K = a.shape
     N = weight.size(1)
-    out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    check(load().npi_linear_fwd(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
-                                ptr(out), out.stride(0), M, K, N, 1 if relu else 0, stream_ptr(dev)),
+    out = torch.empty((M, N), dtype=a.dtype, device=dev)
+    check(load().npi_linear_fwd_t(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
+                                  ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a), stream_ptr(dev)),
           "npi_linear_fwd")
     return out
 
@@ -84,27 +102,30 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
 def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
                     rowscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     dev = require_gpu(dc, weight, rowscale)
-    dc, weight = _f32c(dc, "dC"), _f32c(weight, "weight")
+    dc = _fc(dc, "dC")
+    weight = _fc(weight, "weight", dc)
     M, N = dc.shape
     K = weight.size(0)
-    da = torch.empty((M, K), dtype=torch.float32, device=dev)
-    check(load().npi_linear_bwd_data(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
-                                     ptr(da), da.stride(0), M, K, N, stream_ptr(dev)), "npi_linear_bwd_data")
+    da = torch.empty((M, K), dtype=dc.dtype, device=dev)
+    check(load().npi_linear_bwd_data_t(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
+                                       ptr(da), da.stride(0), M, K, N, _code(dc), stream_ptr(dev)),
+          "npi_linear_bwd_data")
     return da
 
 
 def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True):
     dev = require_gpu(a, dc)
-    a, dc = _f32c(a, "a"), _f32c(dc, "dC")
+    a = _fc(a, "a")
+    dc = _fc(dc, "dC", a)
     M, K = a.shape
     N = dc.size(1)
     lib = load()
     n_ws = int(lib.npi_linear_bwd_weight_workspace_elems(M, K, N))
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
-    dw = torch.empty((K, N), dtype=torch.float32, device=dev)
-    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
-    check(lib.npi_linear_bwd_weight(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
-                                    M, K, N, ptr(ws), n_ws, stream_ptr(dev)), "npi_linear_bwd_weight")
+    dw = torch.empty((K, N), dtype=a.dtype, device=dev)
+    db = torch.empty(N, dtype=a.dtype, device=dev) if want_bias else None
+    check(lib.npi_linear_bwd_weight_t(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
+                                      M, K, N, ptr(ws), n_ws, _code(a), stream_ptr(dev)), "npi_linear_bwd_weight")
     return dw, db
 
 
@@ -136,7 +157,7 @@ class _SageConvFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         agg, weight = ctx.saved_tensors
         graph: CSRGraph = ctx.graph
-        grad_out = _f32c(grad_out, "grad_out")
+        grad_out = _fc(grad_out, "grad_out", agg)
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]

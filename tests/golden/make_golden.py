@@ -100,6 +100,49 @@ def main():
                os.path.join(HERE, "npinter2_katp.pt"))
     print("npinter2_katp.pt", x.shape, "max |dP| oracle vs logged", err)
 
+    # ---- full NPInter2 graph for BASELINE.json configs 1-3 (full-batch stacks without pooling) -------
+    # N = 5,085 (4,636 ncRNA + 449 protein), 20,824 undirected = 41,648 directed edges;
+    # x = [label = 1 | node2vec (fold 0) | k-mer], F = 178.  Expected outputs are the ORACLE's (no
+    # reference artifact runs full-batch: parity unpinned for these stacks).
+    proj = kat.Project("NPInter2", "1223_1", 0)
+    pairs = torch.tensor(proj.pos + proj.neg, dtype=torch.long).t()          # [2, 20824] (rna, protein)
+    ei = torch.cat([pairs, pairs.flip(0)], dim=1)                             # both directions (src/classes.py:701-704)
+    assert ei.size(1) == 41648 and proj.num_nodes == 5085
+    x = torch.cat([torch.ones(proj.num_nodes, 1, dtype=torch.float64), proj.feat], dim=1).float()
+    sd = kat.load_checkpoint("1223_1", 0, 50)
+    g = torch.Generator().manual_seed(7)
+
+    def glorot(i, o):
+        a = (6.0 / (i + o)) ** 0.5
+        return (torch.rand(i, o, generator=g) * 2 - 1) * a
+    gcn64 = [(glorot(178, 64), torch.zeros(64)), (glorot(64, 64), torch.zeros(64))]
+    gcn256 = [(glorot(178, 256), torch.zeros(256)), (glorot(256, 256), torch.zeros(256)), (glorot(256, 256), torch.zeros(256))]
+    with torch.no_grad():
+        h = x
+        sage_out = []
+        for k in (1, 2, 3):                                                    # config 2: Net_1's convs without pooling
+            h = torch.relu(R.sage_conv(h, ei, sd[f"conv{k}.weight"], sd[f"conv{k}.bias"]))
+            sage_out.append(h)
+        h = x
+        for W, b in gcn64:                                                     # config 1
+            h = torch.relu(R.gcn_conv(h, ei, W, b))
+        c1 = h
+        h = x
+        for W, b in gcn256:                                                    # config 3 (on the NPInter2 graph)
+            h = torch.relu(R.gcn_conv(h, ei, W, b))
+        c3 = h
+    # expected outputs are kept for a fixed sample of rows only (the heaviest node + 399 random ones)
+    deg = torch.bincount(ei[1], minlength=proj.num_nodes)
+    rows = torch.cat([deg.argmax().view(1), torch.randperm(proj.num_nodes, generator=g)[:399]]).sort().values
+    torch.save({"x": x, "edge_index": ei.to(torch.int32), "rows": rows,
+                "sage_weights": [(sd[f"conv{k}.weight"], sd[f"conv{k}.bias"]) for k in (1, 2, 3)],
+                "sage3_out": sage_out[-1][rows], "sage1_out": sage_out[0][rows], "gcn64": gcn64, "gcn64_out": c1[rows],
+                "gcn256": gcn256, "gcn256_out": c3[rows],
+                "source": "NPInter2.xlsx + set_negativeInteractionKey_all + node2vec/k-mer of project 1223_1 fold 0; "
+                          "conv weights of result/1223_1/model_0_fold/50; GCN weights seeded glorot"},
+               os.path.join(HERE, "npinter2_graph.pt"))
+    print("npinter2_graph.pt", x.shape, ei.shape)
+
     # ---- expected confusion matrices recoverable from the logs ----------------------
     table = {"1223_1": {"0/5": [1970, 113, 1922, 161], "0/25": [1980, 103, 1929, 154], "0/50": [1994, 89, 1901, 182],
                         "3/50": [1879, 203, 1993, 89], "1/50": [2033, 50, 1844, 239], "2/50": [1945, 137, 1970, 112],

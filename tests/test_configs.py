@@ -1,0 +1,103 @@
+"""BASELINE.json configs 1-3 on the bundled NPInter2 interaction graph (fixture
+tests/golden/npinter2_graph.pt: 5,085 nodes, 41,648 directed edges, F = 178):
+  config 1  2-layer GCNConv hidden 64, CPU oracle forward (plumbing)
+  config 2  3-layer SAGEConv hidden 128, bf16 storage, full-batch on one MI355X vs the fp32 CPU oracle
+  config 3  3-layer GCNConv hidden 256 on one MI355X (fp32)
+Expected outputs are the oracle's own (no reference artifact runs these stacks: parity unpinned)."""
+import os
+
+import pytest
+import torch
+
+from oracle import ref_conv as R
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    d = torch.load(os.path.join(G, "npinter2_graph.pt"), map_location="cpu", weights_only=False)
+    d["edge_index"] = d["edge_index"].long()
+    return d
+
+
+def test_config1_gcn_oracle_forward_cpu(fx):
+    assert fx["x"].shape == (5085, 178) and fx["edge_index"].shape == (2, 41648)
+    deg = torch.bincount(fx["edge_index"][1], minlength=5085)
+    assert int(deg.max()) == 1121                      # max degree 1121 of 20,824 undirected edges
+    h = fx["x"]
+    with torch.no_grad():
+        for W, b in fx["gcn64"]:
+            h = torch.relu(R.gcn_conv(h, fx["edge_index"], W, b))
+    assert torch.allclose(h[fx["rows"]], fx["gcn64_out"], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_config2_sage3_bf16_full_batch(dev, fx):
+    """bf16 storage / f32 accumulate vs the fp32 oracle: tolerance is bf16's (8 significant bits
+    per stored activation, three layers deep), not the 1e-4 fp32 bar."""
+    import npi_gnn_amd as npi
+    ei = fx["edge_index"].to(dev)
+    graph = npi.CSRGraph(ei, 5085)
+    h = fx["x"].to(dev).to(torch.bfloat16)
+    with torch.no_grad():
+        for W, b in fx["sage_weights"]:
+            h = torch.relu(npi.sage_conv(h, graph, W.to(dev).to(torch.bfloat16), b.to(dev).to(torch.bfloat16)))
+    assert h.dtype == torch.bfloat16
+    ref = fx["sage3_out"]
+    err = (h.float().cpu()[fx["rows"]] - ref).abs()
+    assert float(err.max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
+    assert float(err.mean()) <= 4e-3 * max(1.0, float(ref.abs().mean()))
+
+
+@pytest.mark.gpu
+def test_config2_sage_bf16_backward(dev, fx):
+    import npi_gnn_amd as npi
+    ei = fx["edge_index"]
+    W, b = fx["sage_weights"][1]                       # 128 -> 128
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5085, 128, generator=g)
+    go = torch.randn(5085, 128, generator=g)
+    # oracle on the bf16-rounded inputs, in fp32
+    xr, Wr, br, gor = (t.to(torch.bfloat16).float() for t in (x, W, b, go))
+    ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(xr, ei, Wr, br, gor)
+    xd = x.to(dev).to(torch.bfloat16).requires_grad_(True)
+    Wd = W.to(dev).to(torch.bfloat16).requires_grad_(True)
+    bd = b.to(dev).to(torch.bfloat16).requires_grad_(True)
+    out = npi.sage_conv(xd, ei.to(dev), Wd, bd)
+    out.backward(go.to(dev).to(torch.bfloat16))
+
+    def close(a, ref, rel):
+        return float((a.float().cpu() - ref).abs().max()) <= rel * float(ref.abs().max())
+    assert close(out.detach(), ref_out, 2e-2)
+    assert close(xd.grad, ref_dx, 2e-2)
+    assert close(Wd.grad, ref_dw, 2e-2)
+    assert close(bd.grad, ref_db, 2e-2)
+
+
+@pytest.mark.gpu
+def test_config3_gcn3_hidden256_fp32(dev, fx):
+    import npi_gnn_amd as npi
+    ei = fx["edge_index"].to(dev)
+    convs = []
+    for W, b in fx["gcn256"]:
+        c = npi.GCNConv(W.size(0), W.size(1), cached=True).to(dev)
+        c.load_state_dict({"weight": W, "bias": b})
+        convs.append(c)
+    h = fx["x"].to(dev)
+    with torch.no_grad():
+        for c in convs:
+            h = torch.relu(c(h, ei))
+    assert torch.allclose(h.cpu()[fx["rows"]], fx["gcn256_out"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_config2_shape_fp32_sage3_matches_1e4(dev, fx):
+    import npi_gnn_amd as npi
+    ei = fx["edge_index"].to(dev)
+    graph = npi.CSRGraph(ei, 5085)
+    h = fx["x"].to(dev)
+    with torch.no_grad():
+        for W, b in fx["sage_weights"]:
+            h = torch.relu(npi.sage_conv(h, graph, W.to(dev), b.to(dev)))
+    assert torch.allclose(h.cpu()[fx["rows"]], fx["sage3_out"], atol=1e-4, rtol=1e-4)
