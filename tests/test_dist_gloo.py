@@ -67,7 +67,9 @@ def _worker(rank, world, port, N, E, F, q):
         xl = sg.shard(x).clone().requires_grad_(True)
         out = layer(xl)
         out.backward(sg.shard(go))
-        q.put((rank, out.detach(), xl.grad, layer.weight.grad, layer.bias.grad))
+        # numpy arrays are pickled by value (torch tensors travel through shared-memory files that
+        # vanish when this process exits)
+        q.put((rank,) + tuple(t.detach().numpy().copy() for t in (out, xl.grad, layer.weight.grad, layer.bias.grad)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -93,7 +95,7 @@ def test_sharded_layer_matches_single_process_oracle(world, N):
     res = {}
     for _ in range(world):
         r, out, dx, dw, db = q.get(timeout=180)
-        res[r] = (out, dx, dw, db)
+        res[r] = tuple(torch.from_numpy(a) for a in (out, dx, dw, db))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
