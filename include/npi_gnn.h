@@ -212,6 +212,31 @@ int npi_gat_att_grad(const float* hfeat, int64_t ldh, const float* g_dst, const 
                      int64_t N, int64_t H, int64_t C, float* datt, float* workspace,
                      int64_t workspace_elems, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Between-layer steps of Net_1 (reference src/classes.py:63-64,67-68,71-72),
+ * forward only: PyG 1.4.2 TopKPooling(ratio) and the [global_max_pool || global_mean_pool] readout.
+ * `batch` is the PyG Batch vector (int64, non-decreasing); graph_ptr[B+1] its segment starts.
+ *   npi_topk_score      score_i = tanh(<x_i, w> / ||w||)
+ *   npi_graph_bounds    graph_ptr from batch
+ *   npi_topk_select     per graph keep ceil(ratio n_g) best (score desc, index asc): out_ptr[B+1],
+ *                       perm[out_ptr[B]], remap[N] (new id or -1); status bit 1 = a graph > 16384 nodes
+ *   npi_topk_gather     x' = x[perm] * score[perm], batch' = batch[perm], score' = score[perm]
+ *   npi_filter_adj      surviving edges, relabelled, original order; count[0] on device
+ *   npi_readout_max_mean  out[g] = [max_i x_i || mean_i x_i]  ([B, 2F])
+ * ------------------------------------------------------------------------------------------ */
+int npi_topk_score(const float* x, int64_t ldx, const float* w, int64_t N, int64_t F, float* score, void* stream);
+int npi_graph_bounds(const int64_t* batch, int64_t N, int64_t B, int32_t* graph_ptr, void* stream);
+int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
+                    int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, void* stream);
+int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
+                    const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
+                    float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream);
+int64_t npi_filter_adj_workspace_elems(int64_t E);
+int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
+                   int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, void* stream);
+int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
+                         float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,13 @@ PROTOTYPES = {
     "npi_entry_transpose_map": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_gat_att_grad_workspace_elems": (_I, [_I, _I, _I]),
     "npi_gat_att_grad": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "npi_topk_score": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
+    "npi_graph_bounds": (c_int, [_P, _I, _I, _P, _P]),
+    "npi_topk_select": (c_int, [_P, _P, _I, _I, c_float, _P, _P, _P, _P, _P]),
+    "npi_topk_gather": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "npi_filter_adj_workspace_elems": (_I, [_I]),
+    "npi_filter_adj": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "npi_readout_max_mean": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
 }
 
 _lib = None

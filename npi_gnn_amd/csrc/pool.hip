@@ -1,0 +1,321 @@
+// Between-layer steps of the reference's Net_1 (reference src/classes.py:63-64,
+// 67-68, 71-72): PyG 1.4.2 TopKPooling(ratio) and the [global_max_pool || global_mean_pool] readout,
+// forward only (inference: src/methods.py:87-96, src/test.py, src/case_study*.py).
+//
+//   score_i = tanh(<x_i, w> / ||w||)
+//   per graph g (nodes are contiguous per graph in a PyG Batch): keep the k_g = ceil(ratio n_g) highest
+//       scores, descending, ties by lower node index (a stable descending sort)
+//   x' = x[perm] * score[perm],  batch' = batch[perm]
+//   filter_adj: keep the edges whose two ends survive, relabelled, in their original order
+//   readout[g] = [max_i x'_i || mean_i x'_i]
+//
+// Integer / index work is bit-exact; sums are in a fixed order (reproducible).
+#include "npi_common.h"
+
+namespace npi {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// score[i] = tanh(<x_i, w> / ||w||_2); one wave per node
+__global__ void __launch_bounds__(256)
+topk_score_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, int N, int F,
+                  float* __restrict__ score) {
+    const int lane = lane_id();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    float dot = 0.f, nn = 0.f;
+    for (int c = lane; c < F; c += WAVE) {
+        const float wc = w[c];
+        dot = fmaf(x[(int64_t)i * ldx + c], wc, dot);
+        nn = fmaf(wc, wc, nn);
+    }
+    dot = wsum(dot);
+    nn = wsum(nn);
+    if (lane == 0) score[i] = tanhf(dot / sqrtf(nn));
+}
+
+// graph_ptr[g] = first node with batch >= g (batch is non-decreasing), g in [0, B]
+__global__ void graph_bounds_kernel(const int64_t* __restrict__ batch, int64_t N, int64_t B,
+                                    int32_t* __restrict__ graph_ptr) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > B) return;
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (batch[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    graph_ptr[g] = (int32_t)lo;
+}
+
+// out_ptr[g] = sum_{g' < g} ceil(ratio * n_g'); one workgroup, B is small (graphs per batch)
+__global__ void __launch_bounds__(256)
+topk_counts_kernel(const int32_t* __restrict__ graph_ptr, int B, float ratio, int32_t* __restrict__ out_ptr) {
+    __shared__ int lds[256];
+    int carry = 0;
+    for (int base = 0; base < B; base += 256) {
+        const int g = base + threadIdx.x;
+        int k = 0;
+        if (g < B) {
+            const int n = graph_ptr[g + 1] - graph_ptr[g];
+            k = (int)ceilf(ratio * (float)n);
+            k = min(k, n);
+        }
+        lds[threadIdx.x] = k;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int t = (threadIdx.x >= off) ? lds[threadIdx.x - off] : 0;
+            __syncthreads();
+            lds[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (g < B) out_ptr[g] = carry + lds[threadIdx.x] - k;
+        carry += lds[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_ptr[B] = carry;
+}
+
+// sortable key: ascending key order == (score descending, node index ascending)
+__device__ __forceinline__ uint64_t topk_key(float s, uint32_t idx) {
+    uint32_t u = __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // ascending float order as unsigned
+    return ((uint64_t)(~u) << 32) | idx;                  // ~u: descending score
+}
+
+// One workgroup per graph: bitonic sort of (score, index) keys in LDS, write the k best node ids.
+// The instantiation <CAP, LO> handles graphs with LO < n_g <= CAP (CAP a power of two).
+template <int CAP, int LO>
+__global__ void __launch_bounds__(CAP > 1024 ? 1024 : 256)
+topk_select_kernel(const float* __restrict__ score, const int32_t* __restrict__ graph_ptr,
+                   const int32_t* __restrict__ out_ptr, int B, int32_t* __restrict__ perm,
+                   int32_t* __restrict__ remap, int32_t* __restrict__ too_big) {
+    __shared__ uint64_t keys[CAP];
+    const int g = blockIdx.x;
+    const int nb = graph_ptr[g], n = graph_ptr[g + 1] - nb;
+    if (n > CAP) { if (CAP > 1024 && threadIdx.x == 0) atomicOr(too_big, 2); return; }
+    if (n <= LO) return;                                  // the smaller instantiation handles it
+    const int T = blockDim.x;
+    for (int i = threadIdx.x; i < CAP; i += T) keys[i] = (i < n) ? topk_key(score[nb + i], (uint32_t)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= CAP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < CAP; i += T) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = keys[i], b = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int ob = out_ptr[g], kk = out_ptr[g + 1] - ob;
+    for (int i = threadIdx.x; i < kk; i += T) {
+        const int node = nb + (int)(keys[i] & 0xffffffffu);
+        perm[ob + i] = node;
+        remap[node] = ob + i;
+    }
+}
+
+// x'[q] = x[perm[q]] * score[perm[q]], batch'[q] = batch[perm[q]]; one wave per output row
+__global__ void __launch_bounds__(256)
+topk_gather_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ score,
+                   const int64_t* __restrict__ batch, const int32_t* __restrict__ perm,
+                   const int32_t* __restrict__ out_ptr, int B, int F, float* __restrict__ xo, int64_t ldo,
+                   int64_t* __restrict__ batch_o, float* __restrict__ score_o) {
+    const int lane = lane_id();
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= out_ptr[B]) return;
+    const int i = perm[q];
+    const float s = score[i];
+    for (int c = lane; c < F; c += WAVE) xo[(int64_t)q * ldo + c] = x[(int64_t)i * ldx + c] * s;
+    if (lane == 0) {
+        batch_o[q] = batch[i];
+        score_o[q] = s;
+    }
+}
+
+// ---- filter_adj: order-preserving compaction of the surviving edges -------------------------------------
+constexpr int FA_TILE = 2048;      // edges per workgroup (256 threads x 8)
+__global__ void __launch_bounds__(256)
+filter_flag_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E,
+                   const int32_t* __restrict__ remap, int32_t* __restrict__ tile_counts) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    const int64_t base = (int64_t)blockIdx.x * FA_TILE;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t e = base + j * 256 + threadIdx.x;
+        if (e < E) c += (remap[src[e]] >= 0 && remap[dst[e]] >= 0) ? 1 : 0;
+    }
+    c = (int)wsum((float)c);          // <= 512 per wave: exact in f32
+    if (lane_id() == 0) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = cnt;
+}
+__global__ void __launch_bounds__(256)
+scan_small_kernel(int32_t* __restrict__ v, int n, int32_t* __restrict__ total) {   // exclusive scan, one workgroup
+    __shared__ int lds[256];
+    int carry = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const int val = i < n ? v[i] : 0;
+        lds[threadIdx.x] = val;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int t = (threadIdx.x >= off) ? lds[threadIdx.x - off] : 0;
+            __syncthreads();
+            lds[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) v[i] = carry + lds[threadIdx.x] - val;
+        carry += lds[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+// each workgroup re-walks its tile in edge order: wave w handles edges [w*512, w*512+512) of the tile in
+// 8 steps of 64 consecutive edges, so ballot ranks give the original order
+__global__ void __launch_bounds__(256)
+filter_write_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E,
+                    const int32_t* __restrict__ remap, const int32_t* __restrict__ tile_off,
+                    int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst) {
+    __shared__ int wcnt[4];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t wbase = (int64_t)blockIdx.x * FA_TILE + wave * 512;
+    int64_t s[8], d[8];
+    bool keep[8];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t e = wbase + j * 64 + lane;
+        keep[j] = false;
+        if (e < E) {
+            const int rs = remap[src[e]], rd = remap[dst[e]];
+            keep[j] = rs >= 0 && rd >= 0;
+            s[j] = rs; d[j] = rd;
+        }
+        c += __popcll(__ballot(keep[j]));
+    }
+    if (lane == 0) wcnt[wave] = c;
+    __syncthreads();
+    int off = tile_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint64_t m = __ballot(keep[j]);
+        if (keep[j]) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            out_src[pos] = s[j];
+            out_dst[pos] = d[j];
+        }
+        off += __popcll(m);
+    }
+}
+
+// readout[g] = [max over the graph's rows || mean]; one workgroup per graph, a thread per column
+__global__ void __launch_bounds__(256)
+readout_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ graph_ptr, int B, int F,
+               float* __restrict__ out /* [B, 2F] */) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    const int b = graph_ptr[g], e = graph_ptr[g + 1];
+    float mx = -3.0e38f, sum = 0.f;
+    for (int i = b; i < e; ++i) {
+        const float v = x[(int64_t)i * ldx + c];
+        mx = fmaxf(mx, v);
+        sum += v;
+    }
+    out[(int64_t)g * 2 * F + c] = (e > b) ? mx : 0.f;
+    out[(int64_t)g * 2 * F + F + c] = sum / (float)max(e - b, 1);
+}
+
+__global__ void fill_i32_pool_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace npi
+
+using namespace npi;
+
+extern "C" int npi_topk_score(const float* x, int64_t ldx, const float* w, int64_t N, int64_t F, float* score,
+                              void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && F > 0 && ldx >= F, "npi_topk_score: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(x && w && score, "npi_topk_score: null pointer");
+    topk_score_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(x, ldx, w, (int)N, (int)F, score);
+    return check_launch("npi_topk_score");
+}
+
+extern "C" int npi_graph_bounds(const int64_t* batch, int64_t N, int64_t B, int32_t* graph_ptr, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && B >= 0 && N < 0x7fffffff, "npi_graph_bounds: bad size");
+    NPI_REQUIRE(graph_ptr && (N == 0 || batch), "npi_graph_bounds: null pointer");
+    graph_bounds_kernel<<<(unsigned)ceil_div(B + 1, 256), 256, 0, stream>>>(batch, N, B, graph_ptr);
+    return check_launch("npi_graph_bounds");
+}
+
+// perm[out_ptr[B]] (node ids, graph-major, score-descending), remap[N] (new id or -1), out_ptr[B+1];
+// status[0] bit 1 is set when a graph has more than 16384 nodes (unsupported)
+extern "C" int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
+                               int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && B >= 0 && ratio > 0.f && ratio <= 1.f, "npi_topk_select: bad argument");
+    NPI_REQUIRE(out_ptr && status && (N == 0 || (score && graph_ptr && perm && remap)), "npi_topk_select: null pointer");
+    (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+    if (N > 0) fill_i32_pool_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(remap, N, -1);
+    topk_counts_kernel<<<1, 256, 0, stream>>>(graph_ptr, (int)B, ratio, out_ptr);
+    if (B > 0) {
+        topk_select_kernel<1024, -1><<<(unsigned)B, 256, 0, stream>>>(score, graph_ptr, out_ptr, (int)B, perm, remap, status);
+        topk_select_kernel<16384, 1024><<<(unsigned)B, 1024, 0, stream>>>(score, graph_ptr, out_ptr, (int)B, perm, remap, status);
+    }
+    return check_launch("npi_topk_select");
+}
+
+extern "C" int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
+                               const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
+                               float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(B >= 0 && F > 0 && n_out_max >= 0, "npi_topk_gather: bad size");
+    if (n_out_max == 0) return NPI_OK;
+    NPI_REQUIRE(x && score && batch && perm && out_ptr && xo && batch_o && score_o, "npi_topk_gather: null pointer");
+    topk_gather_kernel<<<(unsigned)ceil_div(n_out_max, 4), 256, 0, stream>>>(x, ldx, score, batch, perm, out_ptr, (int)B, (int)F, xo, ldo, batch_o, score_o);
+    return check_launch("npi_topk_gather");
+}
+
+extern "C" int64_t npi_filter_adj_workspace_elems(int64_t E) { return ceil_div(E > 0 ? E : 1, FA_TILE) + 2; }
+
+// out_src/out_dst: capacity E; count[0] = number of surviving edges (device)
+extern "C" int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
+                              int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace,
+                              void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(E >= 0 && E < 0x7fffffff, "npi_filter_adj: bad size");
+    NPI_REQUIRE(count && workspace, "npi_filter_adj: null pointer");
+    if (E == 0) { (void)hipMemsetAsync(count, 0, sizeof(int32_t), stream); return check_launch("npi_filter_adj"); }
+    NPI_REQUIRE(src && dst && remap && out_src && out_dst, "npi_filter_adj: null pointer");
+    const int ntiles = (int)ceil_div(E, FA_TILE);
+    filter_flag_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace);
+    scan_small_kernel<<<1, 256, 0, stream>>>(workspace, ntiles, count);
+    filter_write_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, out_src, out_dst);
+    return check_launch("npi_filter_adj");
+}
+
+extern "C" int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
+                                    float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(B >= 0 && F > 0, "npi_readout_max_mean: bad size");
+    if (B == 0) return NPI_OK;
+    NPI_REQUIRE(x && graph_ptr && out, "npi_readout_max_mean: null pointer");
+    readout_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)B), 256, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, out);
+    return check_launch("npi_readout_max_mean");
+}

@@ -1,0 +1,108 @@
+"""TopKPooling / readout kernels against the oracle, and the WHOLE Net_1
+forward on the MI355X against the reference's own logged results (golden fixtures)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import npi_gnn_amd as npi
+from npi_gnn_amd import pool as NP
+from oracle import kat, ref_conv as R
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(G, name), map_location="cpu", weights_only=False)
+
+
+class Net1(torch.nn.Module):
+    """The wiring of the reference's Net_1 (src/classes.py:45-82) with this package's modules:
+    3 x (SAGEConv -> relu -> TopKPooling(0.5) -> [gmp || gap]) summed -> MLP -> log_softmax."""
+
+    def __init__(self, num_node_features, num_of_classes=2):
+        super().__init__()
+        self.conv1, self.pool1 = npi.SAGEConv(num_node_features, 128), NP.TopKPooling(128, ratio=0.5)
+        self.conv2, self.pool2 = npi.SAGEConv(128, 128), NP.TopKPooling(128, ratio=0.5)
+        self.conv3, self.pool3 = npi.SAGEConv(128, 128), NP.TopKPooling(128, ratio=0.5)
+        self.lin1 = torch.nn.Linear(256, 128)
+        self.lin2 = torch.nn.Linear(128, 64)
+        self.lin3 = torch.nn.Linear(64, num_of_classes)
+
+    def forward(self, x, edge_index, batch):
+        acc = None
+        for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
+            x = F.relu(conv(x, edge_index))
+            x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
+            r = torch.cat([NP.global_max_pool(x, batch), NP.global_mean_pool(x, batch)], dim=1)
+            acc = r if acc is None else acc + r
+        x = F.relu(self.lin1(acc))
+        x = F.dropout(x, p=0.5, training=self.training)
+        x = F.relu(self.lin2(x))
+        return F.log_softmax(self.lin3(x), dim=-1)
+
+
+def test_topk_pool_matches_oracle_bit_exact_indices(dev):
+    fx = load("npinter2_small.pt")
+    x = torch.relu(fx["conv_out"][0])                       # what pool1 sees
+    ei, batch = fx["edge_index"], fx["batch"]
+    w = fx["state_dict"]["pool1.weight"]
+    xo, eo, bo, perm, sc = R.topk_pool(x, ei, batch, w, 0.5)
+    gx, ge, _, gb, gperm, gsc = NP.topk_pool(x.to(dev), ei.to(dev), batch.to(dev), w.to(dev), 0.5)
+    assert torch.equal(gperm.cpu(), perm)
+    assert torch.equal(gb.cpu(), bo)
+    assert torch.equal(ge.cpu(), eo)
+    assert torch.allclose(gx.cpu(), xo, atol=1e-6, rtol=1e-6)
+    assert torch.allclose(gsc.cpu(), sc, atol=1e-6)
+    nb = int(bo.max()) + 1
+    assert torch.allclose(NP.global_max_mean_pool(gx, gb).cpu(), R.readout(xo, bo, nb), atol=1e-6, rtol=1e-6)
+
+
+def test_topk_large_graph_and_ties(dev):
+    g = torch.Generator().manual_seed(0)
+    n1, n2 = 5000, 37                                        # 5000 > 1024: the 16384-capacity sort
+    x = torch.randn(n1 + n2, 16, generator=g)
+    x[100:110] = x[100]                                      # identical rows => identical scores: index order
+    batch = torch.cat([torch.zeros(n1, dtype=torch.long), torch.ones(n2, dtype=torch.long)])
+    ei = torch.randint(0, n1 + n2, (2, 20000), generator=g)
+    w = torch.randn(1, 16, generator=g)
+    xo, eo, bo, perm, sc = R.topk_pool(x, ei, batch, w, 0.5)
+    gx, ge, _, gb, gperm, gsc = NP.topk_pool(x.to(dev), ei.to(dev), batch.to(dev), w.to(dev), 0.5)
+    assert gperm.numel() == 2500 + 19
+    assert torch.equal(gperm.cpu(), perm) and torch.equal(ge.cpu(), eo)
+    assert torch.allclose(gx.cpu(), xo, atol=1e-6, rtol=1e-6)
+
+
+def _run_net1(dev, fx, n_graphs):
+    model = Net1(fx["x"].size(1)).to(dev)
+    model.load_state_dict({k: v.to(dev) for k, v in fx["state_dict"].items()})      # reference checkpoint, unchanged
+    model.eval()
+    return model(fx["x"].to(dev), fx["edge_index"].to(dev), fx["batch"].to(dev)).detach().cpu()
+
+
+def test_whole_net1_on_gpu_reproduces_reference_log_rpi369(dev):
+    """result/1228_1/log_0.txt: Accuracy 0.62838 ... = TP 42 FN 32 TN 51 FP 23, with every layer of the
+    reference model (convs, pooling, readout) on the MI355X."""
+    fx = load("rpi369_fold0.pt")
+    logp = _run_net1(dev, fx, fx["y"].numel())
+    cm = kat.confusion(logp, fx["y"])
+    assert cm == (42, 32, 51, 23)
+    assert ["%.5f" % v for v in R.metrics_from_confusion(*cm)] == fx["logged_metrics"]
+    assert torch.allclose(logp, fx["logp"], atol=1e-4, rtol=1e-4)
+
+
+def test_whole_net1_on_gpu_reproduces_case_study_probabilities(dev):
+    fx = load("npinter2_katp.pt")
+    logp = _run_net1(dev, fx, fx["p_positive_logged"].numel())
+    err = (logp[:, 1].double().exp() - fx["p_positive_logged"]).abs().max()
+    assert float(err) <= 1e-5
+
+
+def test_pooling_refuses_training_mode(dev):
+    pool = NP.TopKPooling(8).to(dev)
+    x = torch.randn(10, 8, device=dev, requires_grad=True)
+    ei = torch.randint(0, 10, (2, 20), device=dev)
+    with pytest.raises(NotImplementedError):
+        pool(x, ei, None, torch.zeros(10, dtype=torch.long, device=dev))
