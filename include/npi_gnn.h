@@ -202,8 +202,8 @@ int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       const float* dout, int64_t ldd, int64_t H, int64_t C,
                       const float* a_dst, const float* a_src, const float* m, const float* s,
                       const float* D, float negative_slope, float* dz, void* stream);
-int npi_seg_rowsum(const int32_t* rowptr, const float* vals, const int32_t* map, int64_t N, int64_t H,
-                   float* out, void* stream);
+int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
+                   int64_t N, int64_t nnz_max, int64_t H, float* out, void* stream);
 int npi_entry_transpose_map(const int32_t* src_eid, const int32_t* src_rowidx, const int32_t* src_rowptr,
                             const int32_t* dst_rowptr, const int32_t* pos_dst_of_edge, int64_t N,
                             int64_t nnz_max, int32_t* map, void* stream);

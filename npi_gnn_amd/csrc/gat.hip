@@ -94,53 +94,104 @@ gat_softmax_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __res
     }
 }
 
-// one workgroup per 256-entry item; it owns the heavy rows whose FIRST entry lies in the item
-__global__ void __launch_bounds__(256)
+// Heavy rows (hub proteins: 400k entries at C4) get a whole 1024-thread workgroup.  One workgroup per
+// 256-entry item; it owns the heavy rows whose FIRST entry lies in the item (found without any list
+// building pass: the rows starting inside the item are item_row[item] (+1) ... ).
+constexpr int HEAVY_THREADS = 1024;
+constexpr int HEAVY_WAVES = HEAVY_THREADS / WAVE;
+
+// returns the number of heavy rows starting in this item; their ids are in heavy[]
+__device__ __forceinline__ int find_heavy_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
+                                               int N, int item, int* heavy, int* n_heavy) {
+    const int t = threadIdx.x;
+    const int nnz = rowptr[N];
+    const int k0 = item * NPI_ITEM_EDGES, k1 = k0 + NPI_ITEM_EDGES;
+    if (k0 >= nnz) return 0;                           // workgroup-uniform
+    if (t == 0) *n_heavy = 0;
+    __syncthreads();
+    int first = item_row[item];
+    if (rowptr[first] < k0) ++first;                   // that row started in an earlier item
+    const int r = first + t;
+    if (t < NPI_ITEM_EDGES && r < N) {
+        const int b = rowptr[r];
+        if (b < k1 && b < nnz && rowptr[r + 1] - b > GAT_HEAVY) heavy[atomicAdd(n_heavy, 1)] = r;
+    }
+    __syncthreads();
+    return *n_heavy;
+}
+
+// fixed-order sum / max of one value per wave
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < HEAVY_WAVES; ++w) s += red[w];
+    __syncthreads();
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = red[0];
+#pragma unroll
+    for (int w = 1; w < HEAVY_WAVES; ++w) s = fmaxf(s, red[w]);
+    __syncthreads();
+    return s;
+}
+
+__global__ void __launch_bounds__(HEAVY_THREADS)
 gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                          const int32_t* __restrict__ item_row, const float* __restrict__ a_dst,
                          const float* __restrict__ a_src, int N, int H, float slope,
                          float* __restrict__ m, float* __restrict__ s) {
-    __shared__ int heavy[256];
+    __shared__ int heavy[NPI_ITEM_EDGES];
     __shared__ int n_heavy;
-    __shared__ float red[4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int item = blockIdx.x;
-    const int nnz = rowptr[N];
-    const int k0 = item * NPI_ITEM_EDGES, k1 = k0 + NPI_ITEM_EDGES;
-    if (k0 >= nnz) return;
-    if (t == 0) n_heavy = 0;
-    __syncthreads();
-    int first = item_row[item];
-    if (rowptr[first] < k0) ++first;                 // that row started in an earlier item
-    const int r = first + t;
-    if (r < N) {
-        const int b = rowptr[r];
-        if (b < k1 && b < nnz && rowptr[r + 1] - b > GAT_HEAVY) heavy[atomicAdd(&n_heavy, 1)] = r;
-    }
-    __syncthreads();
-    const int nh = n_heavy;
+    __shared__ float red[HEAVY_WAVES];
+    const int t = threadIdx.x;
+    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, heavy, &n_heavy);
     for (int q = 0; q < nh; ++q) {
         const int i = heavy[q];
         const int b = rowptr[i], e = rowptr[i + 1];
         for (int hd = 0; hd < H; ++hd) {
             const float ad = a_dst[(int64_t)i * H + hd];
             float mx = -3.0e38f;
-            for (int p = b + t; p < e; p += 256) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
-            mx = wave_max(mx);
-            if (lane == 0) red[wave] = mx;
-            __syncthreads();
-            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            __syncthreads();
+            for (int p = b + t; p < e; p += HEAVY_THREADS) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
+            mx = block_max(mx, red);
             float sum = 0.f;
-            for (int p = b + t; p < e; p += 256) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
-            sum = wave_sum(sum);
-            if (lane == 0) red[wave] = sum;
-            __syncthreads();
+            for (int p = b + t; p < e; p += HEAVY_THREADS) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
+            sum = block_sum(sum, red);
             if (t == 0) {
                 m[(int64_t)i * H + hd] = mx;
-                s[(int64_t)i * H + hd] = (red[0] + red[1]) + (red[2] + red[3]);    // fixed order
+                s[(int64_t)i * H + hd] = sum;
             }
-            __syncthreads();
+        }
+    }
+}
+
+// row sums of per-entry scalars for the heavy rows (see seg_rowsum_scalar_kernel below for the rest)
+__global__ void __launch_bounds__(HEAVY_THREADS)
+seg_rowsum_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
+                        const float* __restrict__ vals, const int32_t* __restrict__ map, int N, int H,
+                        float* __restrict__ out) {
+    __shared__ int heavy[NPI_ITEM_EDGES];
+    __shared__ int n_heavy;
+    __shared__ float red[HEAVY_WAVES];
+    const int t = threadIdx.x;
+    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, heavy, &n_heavy);
+    for (int q = 0; q < nh; ++q) {
+        const int r = heavy[q];
+        const int b = rowptr[r], e = rowptr[r + 1];
+        for (int hd = 0; hd < H; ++hd) {
+            float sum = 0.f;
+            for (int p = b + t; p < e; p += HEAVY_THREADS) {
+                const int64_t idx = map ? map[p] : p;
+                sum += vals[idx * H + hd];
+            }
+            sum = block_sum(sum, red);
+            if (t == 0) out[(int64_t)r * H + hd] = sum;
         }
     }
 }
@@ -148,6 +199,7 @@ gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __re
 // ---- backward: per-entry score gradient over the by-target CSR ------------------------------------------
 //   dalpha_p = <dout_i[h], hfeat_j[h]>;  de_p = alpha_p (dalpha_p - D_i);  dz_p = de_p * lrelu'(z_p)
 // one wave per 256-entry item; dout_i is reloaded when the row changes, hfeat_j gathered per entry
+constexpr int EDGE_HMAX = 8;        // heads whose per-entry dots are staged through LDS
 template <int NCH>
 __global__ void __launch_bounds__(256)
 gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -175,6 +227,11 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
     }
     float4 dr[NCH];
     int cur = -1;
+    // per-entry dot products of one 64-entry block are parked in LDS, then all 64 lanes turn them
+    // into dz together (exp, loads and the store leave the serial per-entry chain)
+    __shared__ float pbuf[4][WAVE * EDGE_HMAX];
+    float* __restrict__ pb = pbuf[threadIdx.x >> 6];
+    const bool staged = H <= EDGE_HMAX;
     for (int kb = k0; kb < k1; kb += WAVE) {
         const int nb = min(WAVE, k1 - kb);
         const int cv = (lane < nb) ? col[kb + lane] : 0;
@@ -208,7 +265,9 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                         if (hd[c] == h)
                             p += dr[c].x * hv[u][c].x + dr[c].y * hv[u][c].y + dr[c].z * hv[u][c].z + dr[c].w * hv[u][c].w;
                     p = wave_sum(p);
-                    if (lane == 0) {
+                    if (staged) {
+                        if (lane == 0) pb[(j + u) * H + h] = p;
+                    } else if (lane == 0) {
                         const int64_t ii = (int64_t)i * H + h;
                         const float z = a_dst[ii] + a_src[(int64_t)cu * H + h];
                         const float alpha = expf(lrelu_(z, slope) - m[ii]) / (s[ii] + 1e-16f);
@@ -218,17 +277,33 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                 }
             }
         }
+        if (staged) {
+            __builtin_amdgcn_wave_barrier();
+            for (int t0 = 0; t0 < nb * H; t0 += WAVE) {        // uniform trip count: the shuffles need every lane
+                const int t = t0 + lane;
+                const int en = min(t / H, nb - 1), h = t - (t / H) * H;
+                const int i = __shfl(rv, en, WAVE), cu = __shfl(cv, en, WAVE);
+                if (t >= nb * H) continue;
+                const int64_t ii = (int64_t)i * H + h;
+                const float z = a_dst[ii] + a_src[(int64_t)cu * H + h];
+                const float alpha = expf(lrelu_(z, slope) - m[ii]) / (s[ii] + 1e-16f);
+                const float de = alpha * (pb[t] - D[ii]);
+                dz[(int64_t)kb * H + t] = de * (z > 0.f ? 1.f : slope);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
 // out[r,h] = sum over the entries p of row r of vals[idx(p), h], idx = map ? map[p] : p; wave per row
 __global__ void __launch_bounds__(256)
 seg_rowsum_scalar_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals,
-                         const int32_t* __restrict__ map, int N, int H, float* __restrict__ out) {
+                         const int32_t* __restrict__ map, int N, int H, float* __restrict__ out, int skip_heavy) {
     const int lane = lane_id();
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= N) return;
     const int b = rowptr[r], e = rowptr[r + 1];
+    if (skip_heavy && e - b > GAT_HEAVY) return;       // seg_rowsum_heavy_kernel owns it
     for (int hd = 0; hd < H; ++hd) {
         float sum = 0.f;
         for (int p = b + lane; p < e; p += WAVE) {
@@ -252,7 +327,7 @@ __global__ void entry_transpose_map_kernel(const int32_t* __restrict__ src_eid, 
 }
 
 // datt partials: part[chunk][0][h*C+c] = sum_i g_dst[i,h] hfeat[i,h*C+c], part[chunk][1][..] with g_src
-constexpr int ATT_ROWS = 2048;
+constexpr int ATT_ROWS = 256;       // 3,906 workgroups at C4: enough loads in flight to stream hfeat
 __global__ void __launch_bounds__(256)
 gat_att_grad_partial_kernel(const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ g_dst,
                             const float* __restrict__ g_src, int N, int H, int C, float* __restrict__ part) {
@@ -270,16 +345,27 @@ gat_att_grad_partial_kernel(const float* __restrict__ hfeat, int64_t ldh, const 
     part[((int64_t)blockIdx.y * 2 + 0) * F + c] = sd;
     part[((int64_t)blockIdx.y * 2 + 1) * F + c] = ss;
 }
-__global__ void gat_att_grad_reduce_kernel(const float* __restrict__ part, int nchunks, int H, int C,
-                                           float* __restrict__ datt) {
+// 32 columns x 32 chunk lanes per workgroup; the lanes are folded in a fixed order (deterministic)
+__global__ void __launch_bounds__(1024)
+gat_att_grad_reduce_kernel(const float* __restrict__ part, int nchunks, int H, int C, float* __restrict__ datt) {
+    __shared__ float red[32][33];
     const int F = H * C;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over 2*F
-    if (idx >= 2 * F) return;
-    const int which = idx / F, c = idx % F;
+    const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + cl;                      // over 2*F
     float sum = 0.f;
-    for (int z = 0; z < nchunks; ++z) sum += part[((int64_t)z * 2 + which) * F + c];
-    const int hd = c / C, cc = c % C;
-    datt[(int64_t)hd * 2 * C + which * C + cc] = sum;
+    if (idx < 2 * F) {
+        const int which = idx / F, c = idx % F;
+        for (int z = zl; z < nchunks; z += 32) sum += part[((int64_t)z * 2 + which) * F + c];
+    }
+    red[zl][cl] = sum;
+    __syncthreads();
+    if (zl == 0 && idx < 2 * F) {
+        float tot = 0.f;
+        for (int z = 0; z < 32; ++z) tot += red[z][cl];
+        const int which = idx / F, c = idx % F;
+        const int hd = c / C, cc = c % C;
+        datt[(int64_t)hd * 2 * C + which * C + cc] = tot;
+    }
 }
 
 }  // namespace npi
@@ -316,7 +402,7 @@ extern "C" int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, 
     gat_softmax_rows_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, col, a_dst, a_src, (int)N, (int)H, slope, m, s);
     const int64_t n_items = npi_num_items(nnz_max);
     if (n_items > 0)
-        gat_softmax_heavy_kernel<<<(unsigned)n_items, 256, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)H, slope, m, s);
+        gat_softmax_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)H, slope, m, s);
     return check_launch("npi_gat_softmax_stats");
 }
 
@@ -363,13 +449,17 @@ extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, cons
     return check_launch("npi_gat_edge_grad");
 }
 
-extern "C" int npi_seg_rowsum(const int32_t* rowptr, const float* vals, const int32_t* map, int64_t N, int64_t H,
-                              float* out, void* stream_) {
+extern "C" int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
+                              int64_t N, int64_t nnz_max, int64_t H, float* out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && H > 0, "npi_seg_rowsum: bad size");
+    NPI_REQUIRE(N >= 0 && H > 0 && nnz_max >= 0, "npi_seg_rowsum: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && vals && out, "npi_seg_rowsum: null pointer");
-    seg_rowsum_scalar_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out);
+    const int64_t n_items = item_row ? npi_num_items(nnz_max) : 0;
+    // rows up to 4096 entries: one wave each; longer ones: one 1024-thread workgroup each
+    seg_rowsum_scalar_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out, n_items > 0 ? 1 : 0);
+    if (n_items > 0)
+        seg_rowsum_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)H, out);
     return check_launch("npi_seg_rowsum");
 }
 
@@ -401,6 +491,6 @@ extern "C" int npi_gat_att_grad(const float* hfeat, int64_t ldh, const float* g_
     const int nchunks = (int)ceil_div(N > 0 ? N : 1, ATT_ROWS);
     const int F = (int)(H * C);
     gat_att_grad_partial_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)nchunks), 256, 0, stream>>>(hfeat, ldh, g_dst, g_src, (int)N, (int)H, (int)C, workspace);
-    gat_att_grad_reduce_kernel<<<(unsigned)ceil_div(2 * F, 256), 256, 0, stream>>>(workspace, nchunks, (int)H, (int)C, datt);
+    gat_att_grad_reduce_kernel<<<(unsigned)ceil_div(2 * F, 32), 1024, 0, stream>>>(workspace, nchunks, (int)H, (int)C, datt);
     return check_launch("npi_gat_att_grad");
 }

@@ -373,9 +373,10 @@ class _GatConvFn(torch.autograd.Function):
                                     ptr(grad_out), grad_out.stride(0), H, C, ptr(a_dst), ptr(a_src), ptr(m), ptr(s),
                                     ptr(D), slope, ptr(dz), st), "npi_gat_edge_grad")
         g_dst, g_src = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
-        check(lib.npi_seg_rowsum(ptr(d.rowptr), ptr(dz), 0, N, H, ptr(g_dst), st), "npi_seg_rowsum")
-        check(lib.npi_seg_rowsum(ptr(sr.rowptr), ptr(dz), ptr(_transpose_map(graph)), N, H, ptr(g_src), st),
+        check(lib.npi_seg_rowsum(ptr(d.rowptr), ptr(d.item_row), ptr(dz), 0, N, d.nnz_max, H, ptr(g_dst), st),
               "npi_seg_rowsum")
+        check(lib.npi_seg_rowsum(ptr(sr.rowptr), ptr(sr.item_row), ptr(dz), ptr(_transpose_map(graph)), N, sr.nnz_max,
+                                 H, ptr(g_src), st), "npi_seg_rowsum")
         # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
         dh = _gat_aggregate(graph, sr, grad_out, H, C, a_dst, a_src, m, s, slope, True,
                             g_dst=g_dst, g_src=g_src, att=att2)

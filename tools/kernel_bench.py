@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--gat", action="store_true")
+    ap.add_argument("--heads", type=int, default=1)
     a = ap.parse_args()
     if not (a.gemm or a.seg):
         a.gemm = a.seg = True
@@ -67,6 +69,24 @@ def main():
             print(f"{name:26s} median {med:8.3f} ms  min {best:8.3f} ms  {nbytes / (med * 1e-3) / 1e9:8.1f} GB/s algorithmic", flush=True)
         med, best = timeit(lambda: npi.CSRGraph(ei, N), a.rounds)
         print(f"{'csr build (by_dst)':26s} median {med:8.3f} ms  min {best:8.3f} ms")
+        xb = x.to(torch.bfloat16)
+        nbytes_b = E * (F * 2 + 4) + N * (2 * F * 2 + 4)
+        med, best = timeit(lambda: NF.segsum(graph, graph.by_dst, xb, mean=True), a.rounds)
+        print(f"{'segsum fwd bf16 storage':26s} median {med:8.3f} ms  min {best:8.3f} ms  {nbytes_b / (med * 1e-3) / 1e9:8.1f} GB/s algorithmic", flush=True)
+        if a.gat:
+            H = a.heads
+            C = F // H
+            Wg = (torch.randn(F, F, generator=g) / F ** 0.5).to(dev).requires_grad_(True)
+            att = (torch.randn(1, H, 2 * C, generator=g) * 0.1).to(dev).requires_grad_(True)
+            bg = torch.zeros(F, device=dev, requires_grad=True)
+            xg = x.clone().requires_grad_(True)
+            go = torch.randn(N, F, generator=g).to(dev)
+
+            def gat_step():
+                xg.grad = Wg.grad = att.grad = bg.grad = None
+                npi.gat_conv(xg, graph, Wg, att, bg, heads=H).backward(go)
+            med, best = timeit(gat_step, max(3, a.rounds // 2))
+            print(f"{'GATConv fwd+bwd (H=%d)' % H:26s} median {med:8.3f} ms  min {best:8.3f} ms  {E / (med * 1e-3) / 1e9:6.3f} G edges/s", flush=True)
 
 
 if __name__ == "__main__":
