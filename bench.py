@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--cpu-edges", type=int, default=2_000_000)
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (npi_gnn_amd.dist) even with one rank")
+    ap.add_argument("--partition", choices=["hubs", "rows"], default="hubs",
+                    help="N>1: replicate the protein side and exchange only hub rows (hubs), or a plain "
+                         "destination-row split with an all-gather of every row (rows)")
     return ap.parse_args()
 
 
@@ -49,6 +52,15 @@ def algorithmic_bytes(nnz_rows_edges: int, n_rows: int, F: int, s: int = 4) -> i
     the self loop is an ordinary CSR entry here, so its row read + index are the per-node terms."""
     E, N = nnz_rows_edges, n_rows
     return E * (F * s + 4) + N * (2 * F * s + 4)
+
+
+def parallelism(args, world):
+    if world == 1 and not args.force_sharded:
+        return "single GPU"
+    if args.partition == "hubs":
+        return (f"vertex cut x{world}: ncRNA rows owned in strides, protein rows replicated; per direction one "
+                "all-gather of protein rows + one reduce-scatter of partial protein sums over RCCL")
+    return f"destination-row shards (strided ownership) x{world}, all-gather of every row over RCCL"
 
 
 def cpu_baseline(args):
@@ -143,15 +155,16 @@ def main():
             else:
                 out = conv(x, graph)
             out.backward(go)
-        n_rows_local, nnz_local = N, E + N
+        seg_launch_bytes = [algorithmic_bytes(E, N, F)]
     else:
         from npi_gnn_amd import dist as ND
         t0 = time.time()
-        sg = ND.ShardedGraph(ei, N, rank, world, dev)
+        from npi_gnn_amd.synth import protein_mask
+        sg = ND.ShardedGraph(ei, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None)
         torch.cuda.synchronize()
         t_build = time.time() - t0
         layer = ND.ShardedSAGELayer(sg, W.to(dev), bias.to(dev))
-        x = sg.shard(x_full).to(dev).requires_grad_(True)      # rows rank, rank + W, ... (strided ownership)
+        x = sg.shard(x_full).to(dev).requires_grad_(True)      # this rank's rows: its ncRNAs, then its proteins
         go = sg.shard(go_full).to(dev)
 
         def step():
@@ -159,7 +172,10 @@ def main():
             x.grad = None
             out = layer(x)
             out.backward(go)
-        n_rows_local, nnz_local = sg.n_local, sg.local_nnz
+        # per direction this rank launches side A (its rows) and, with hubs, side B (partial hub sums)
+        seg_launch_bytes = [algorithmic_bytes(sg.A.nnz_max - sg.n_local, sg.n_local, F)]
+        if sg.B is not None:
+            seg_launch_bytes.append(algorithmic_bytes(sg.B.nnz_max, sg.part.hub_rows, F) - sg.part.hub_rows * F * 4)
 
     def barrier():
         if world > 1:
@@ -189,11 +205,11 @@ def main():
     # dominant kernel: segsum (fwd + bwd launches have the same algorithmic bytes when F_in == F_out)
     seg_ms = [s.elapsed_time(e) for s, e in seg_events]
     seg_avg_ms = sum(seg_ms) / max(len(seg_ms), 1)
-    alg_bytes = algorithmic_bytes(nnz_local - n_rows_local, n_rows_local, F)
+    alg_bytes = sum(seg_launch_bytes) / len(seg_launch_bytes)          # average over the launches of one direction
     achieved = alg_bytes / (seg_avg_ms * 1e-3) / 1e9 if seg_ms else 0.0
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and world == 1 and (N, E, F) == (1_000_000, 20_000_000, 256):
+    if os.path.exists(pmc_path) and world == 1 and not args.force_sharded and (N, E, F) == (1_000_000, 20_000_000, 256):
         try:
             traffic = json.load(open(pmc_path)).get("segsum_kernel_bytes_per_launch")
         except Exception:
@@ -208,7 +224,7 @@ def main():
             "config": {"workload": f"C4 synthetic ncRNA-protein bipartite graph, N={N} nodes, E={E} directed edges "
                                    f"(both directions, Zipf-skewed protein side), 1 {args.conv.upper()}Conv layer "
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
-                       "parallelism": "single GPU" if world == 1 else f"destination-row shards (strided ownership) x{world}, all-gather of row shards over RCCL",
+                       "parallelism": parallelism(args, world),
                        "csr_build_s": round(t_build, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

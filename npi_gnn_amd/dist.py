@@ -3,26 +3,38 @@
 The reference is single-process (no distributed code); this is the build's own
 multi-GPU form of the same layer (BASELINE.json configs[3]).
 
-Partition: node i is OWNED by rank ``i % W`` as local row ``i // W`` (strided ownership).  On the
-bipartite NPI graphs, where ncRNA ids come first and the ~10x fewer, ~10x heavier protein ids last,
-striding gives every rank the same share of light and heavy rows, so rows AND entries balance
-(a contiguous row split puts all proteins on one rank: 7x entry imbalance at C4).
+Partition: a vertex cut with REPLICATED HUBS.  Nodes are split into hubs H (on the ncRNA-protein
+graphs: the protein side, ~10x fewer and ~10x heavier nodes) and light nodes L (the ncRNAs).
+Both sets are owned in strides (the k-th hub by rank ``k % W``, the k-th light node likewise), so
+every rank holds the same share of light and heavy rows.  No light-light edge may exist (bipartite
+graphs have none; ``auto_hubs`` promotes one endpoint of any such edge).  Per edge ``j -> i``:
 
-Each rank keeps the CSR rows of the nodes it owns, with column ids that index the ALL-GATHERED
-feature table (rank-major: row ``(j % W) * n_per + j // W``), so the gathered buffer is used as it
-arrives -- no re-packing copy.  Per layer:
+  i light            computed by owner(i): x_j is local (never: j light) or a hub row      -> side A
+  i hub,  j hub      computed by owner(i) from the gathered hub table                      -> side A
+  i hub,  j light    PARTIAL sum computed by owner(j), reduce-scattered to owner(i)        -> side B
 
-  forward :  table = all_gather(x_local)            [W*n_per, F]   <- the one exchange step
-             agg   = segsum_mean(by_dst_local, table)               (same kernel as single GPU)
-             out   = agg @ W + b                                     (local rows only)
-  backward:  dagg  = (dOut @ W^T) / cnt                              (local rows)
-             table = all_gather(dagg)                                <- exchange, overlapped with:
-             dW,db = agg^T dOut, colsum(dOut);  all_reduce(dW, db)   (512 KiB)
-             dX    = segsum(by_src_local, table)
+so the only rows that ever cross xGMI are hub rows: one all-gather of the hub features and one
+reduce-scatter of the partial hub sums per direction -- 2 x |H| x F floats instead of the
+|N| x F all-gather a plain destination-row split needs (C4: 0.2 GB instead of 1.02 GB per
+direction).  With every node a hub (``hub_mask=None``) side B is empty and the scheme IS the plain
+destination-row split with an all-gather of all rows; that is the fallback for graphs without a
+small hub side.
 
-No reduction of partial node embeddings is needed (a destination-row split computes whole rows),
-which is what replaces the north-star's "all-reduce of partial embeddings": for an edge split the
-[N, F] all-reduce costs 2x the bytes of this all-gather (SURVEY.md 8(e) cost table).
+Local row order on rank r: its light nodes first, then the hubs it owns.  Side A reads a table
+``[gathered hub rows (W * h_per, rank-major, padded) ; local light rows]`` that the all-gather
+fills in place; side B reads the rank's own rows directly, so it runs while the all-gather is in
+flight, and the reduce-scatter of its result overlaps side A and (backward) the weight-gradient GEMM:
+
+  forward :  hubs  = all_gather(x_own[hub rows])                     | part = segsum(B, x_own)
+             hsum  = reduce_scatter(part)                            | agg  = segsum_mean(A, table)
+             agg[hub rows] = (agg * cnt_A + hsum) / cnt ;  out = agg @ W + b
+  backward:  dagg  = (dOut @ W^T) / cnt
+             hubs  = all_gather(dagg[hub rows])                      | part = segsum(B^T, dagg)
+             hsum  = reduce_scatter(part)                            | dW, db (+ all_reduce, 256 KiB)
+             dX    = segsum(A^T, table) ;  dX[hub rows] += hsum
+
+Sums of partials arrive in RCCL's order, so multi-GPU results match the single-GPU ones to fp32
+rounding (tests: 1e-5), not bit for bit.
 
 The local compute is a small backend object so that the partition + exchange logic can be
 exercised on CPU with gloo (tests/test_dist_gloo.py injects a torch backend); the product backend
@@ -30,89 +42,166 @@ is ``HipBackend`` and there is no CPU fallback in this package.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 import torch.distributed as dist
 from torch import nn
 
 
-class StridedPartition:
-    def __init__(self, num_nodes: int, world: int):
+def auto_hubs(edge_index: torch.Tensor, num_nodes: int, ratio: float = 2.0, max_fraction: float = 0.5):
+    """Hub mask from degrees: nodes with total degree > ``ratio`` x mean, plus the heavier endpoint of
+    every remaining light-light edge.  Returns None (all rows exchanged) when hubs would exceed
+    ``max_fraction`` of the nodes."""
+    src, dst = edge_index[0], edge_index[1]
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    deg = torch.bincount(src, minlength=num_nodes) + torch.bincount(dst, minlength=num_nodes)
+    hub = deg.float() > ratio * deg.float().mean()
+    ll = ~hub[src] & ~hub[dst]
+    if bool(ll.any()):
+        s, d = src[ll], dst[ll]
+        hub[torch.where(deg[s] > deg[d], s, d)] = True
+    if int(hub.sum()) > max_fraction * num_nodes:
+        return None
+    return hub
+
+
+class HubPartition:
+    """Strided ownership of light nodes and of hubs; see the module docstring."""
+
+    def __init__(self, num_nodes: int, world: int, hub_mask: Optional[torch.Tensor] = None, device=None):
         self.N, self.W = int(num_nodes), int(world)
-        self.n_per = (self.N + self.W - 1) // self.W          # padded rows per rank in the gathered table
+        if hub_mask is None:
+            hub_mask = torch.ones(self.N, dtype=torch.bool, device=device)
+        self.hub = hub_mask.to(device=device, dtype=torch.bool)
+        if self.hub.numel() != self.N:
+            raise ValueError("hub_mask must have one entry per node")
+        h = torch.cumsum(self.hub, 0) - 1
+        l = torch.cumsum(~self.hub, 0) - 1
+        self.index = torch.where(self.hub, h, l)                  # rank among hubs / among light nodes
+        self.nH = int(self.hub.sum())
+        self.nL = self.N - self.nH
+        self.h_per = (self.nH + self.W - 1) // self.W             # padded hub rows per rank
+        self.hub_rows = self.W * self.h_per
 
-    def n_local(self, rank: int) -> int:
-        return (self.N - rank + self.W - 1) // self.W if rank < self.N else 0
+    def _count(self, total: int, rank: int) -> int:
+        return (total - rank + self.W - 1) // self.W if rank < total else 0
 
-    def table_rows(self) -> int:
-        return self.W * self.n_per
+    def n_light(self, rank: int) -> int:
+        return self._count(self.nL, rank)
 
-    def padded(self, ids: torch.Tensor) -> torch.Tensor:
-        """global node id -> row of the all-gathered (rank-major, padded) table"""
-        return (ids % self.W) * self.n_per + ids // self.W
+    def n_hub(self, rank: int) -> int:
+        return self._count(self.nH, rank)
+
+    def owner(self, ids: torch.Tensor) -> torch.Tensor:
+        return self.index[ids] % self.W
+
+    def local(self, ids: torch.Tensor) -> torch.Tensor:
+        """position inside the owner's light block (light ids) or hub block (hub ids)"""
+        return self.index[ids] // self.W
+
+    def hub_row(self, ids: torch.Tensor) -> torch.Tensor:
+        """hub id -> row of the all-gathered (rank-major, padded) hub table"""
+        k = self.index[ids]
+        return (k % self.W) * self.h_per + k // self.W
+
+    def own_ids(self, rank: int) -> torch.Tensor:
+        """global ids of the rows of rank ``rank`` in local order (light nodes, then hubs)"""
+        ids = torch.arange(self.N, device=self.hub.device)
+        mine = self.index % self.W == rank
+        return torch.cat([ids[mine & ~self.hub], ids[mine & self.hub]])
 
     def shard(self, x_full: torch.Tensor, rank: int) -> torch.Tensor:
-        return x_full[rank::self.W]
+        return x_full[self.own_ids(rank).to(x_full.device)]
 
     def unshard(self, parts) -> torch.Tensor:
         out = torch.empty((self.N,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
         for r, p in enumerate(parts):
-            out[r::self.W] = p
+            out[self.own_ids(r).to(p.device)] = p
         return out
 
 
-def local_edges(edge_index: torch.Tensor, part: StridedPartition, rank: int):
-    """(key, val) of this rank's two CSR sides: keys are local rows, values rows of the gathered
-    table; global self loops are removed here (the builder appends one loop per row)."""
-    src, dst = edge_index[0], edge_index[1]
+def local_sides(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: int):
+    """(key, val, n_rows, n_cols) of side A and side B of rank ``rank`` for messages ``src -> dst``
+    (call with the two swapped for the transposed sides).  Global self loops are dropped and one
+    loop per local row is appended LAST, which is where add_remaining_self_loops puts it."""
+    dev = src.device
     keep = src != dst
-    md = keep & (dst % part.W == rank)
-    ms = keep & (src % part.W == rank)
-    by_dst = ((dst[md] // part.W).contiguous(), part.padded(src[md]).contiguous())
-    by_src = ((src[ms] // part.W).contiguous(), part.padded(dst[ms]).contiguous())
-    return by_dst, by_src
+    src, dst = src[keep], dst[keep]
+    hub_s, hub_d = part.hub[src], part.hub[dst]
+    if bool((~hub_s & ~hub_d).any()):
+        raise ValueError("HubPartition: an edge joins two light nodes; mark one endpoint as a hub (auto_hubs)")
+    nL, nH = part.n_light(rank), part.n_hub(rank)
+    mine_d = part.owner(dst) == rank
+    # side A: rows = local order; table = [hub table ; local light rows]
+    a = mine_d & hub_s                                             # (light or hub) <- hub
+    key_a = torch.where(hub_d[a], nL + part.local(dst[a]), part.local(dst[a]))
+    val_a = part.hub_row(src[a])
+    rows = torch.arange(nL + nH, device=dev)
+    loop_col = torch.cat([part.hub_rows + rows[:nL], rank * part.h_per + rows[:nH]])
+    side_a = (torch.cat([key_a, rows]), torch.cat([val_a, loop_col]), nL + nH, part.hub_rows + nL)
+    # side B: rows = hub table rows; sources = this rank's light rows, read from its own block
+    b = hub_d & ~hub_s & (part.owner(src) == rank)
+    side_b = (part.hub_row(dst[b]), part.local(src[b]), part.hub_rows, nL + nH)
+    return side_a, side_b
 
 
-def all_gather_rows(x_local: torch.Tensor, part: StridedPartition, group=None, async_op: bool = False):
-    """[n_local, F] -> [W * n_per, F] rank-major table (one pad row on the short ranks)."""
-    F = x_local.size(1)
-    if x_local.size(0) != part.n_per:
-        buf = x_local.new_zeros((part.n_per, F))
-        buf[: x_local.size(0)] = x_local
+# tests set this to push a world-size-1 run through RCCL as well (the one-GPU box's only way to
+# exercise the real collectives); normally a single rank just copies
+ALWAYS_COMMUNICATE = False
+
+
+def _solo(world: int) -> bool:
+    return world == 1 and not ALWAYS_COMMUNICATE
+
+
+def _portable(group) -> bool:
+    return dist.get_backend(group) != "nccl"
+
+
+def all_gather_rows(block: torch.Tensor, out: torch.Tensor, world: int, group=None, async_op: bool = False):
+    """block [h_per, F] of every rank -> out [W * h_per, F] (rank-major)"""
+    if _solo(world):
+        out.copy_(block)
+        return None
+    if _portable(group):                                           # gloo (CPU tests, one-GPU test rigs)
+        work = dist.all_gather(list(out.view(world, block.size(0), -1).unbind(0)), block, group=group,
+                               async_op=async_op)
     else:
-        buf = x_local.contiguous()
-    table = x_local.new_empty((part.table_rows(), F))
-    if part.W == 1:
-        table.copy_(buf)
-        return table, None
-    if dist.get_backend(group) == "nccl":
-        work = dist.all_gather_into_tensor(table, buf, group=group, async_op=async_op)
-    else:
-        chunks = list(table.view(part.W, part.n_per, F).unbind(0))
-        work = dist.all_gather(chunks, buf, group=group, async_op=async_op)
-    return table, (work if async_op else None)
+        work = dist.all_gather_into_tensor(out, block, group=group, async_op=async_op)
+    return work if async_op else None
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def reduce_scatter_rows(part_sums: torch.Tensor, out: torch.Tensor, rank: int, world: int, group=None,
+                        async_op: bool = False):
+    """part_sums [W * h_per, F] of every rank -> out [h_per, F] = sum over ranks of block ``rank``"""
+    if _solo(world):
+        out.copy_(part_sums)
+        return None
+    if _portable(group):
+        dist.all_reduce(part_sums, group=group)
+        out.copy_(part_sums.view(world, out.size(0), -1)[rank])
+        return _Done() if async_op else None
+    work = dist.reduce_scatter_tensor(out, part_sums, group=group, async_op=async_op)
+    return work if async_op else None
 
 
 class HipBackend:
     """Local compute of one rank on its MI355X through the C ABI."""
 
-    def __init__(self, by_dst, by_src, n_local: int, table_rows: int, loop_col_offset: int):
+    def make_side(self, key, val, n_rows: int, n_cols: int):
         from .graph import build_side
-        self.dst = build_side(by_dst[0], by_dst[1], n_local, table_rows, True, loop_col_offset, False)
-        self.src = build_side(by_src[0], by_src[1], n_local, table_rows, True, loop_col_offset, False)
-        self.local_nnz = int(by_dst[0].numel()) + n_local
+        return build_side(key.contiguous(), val.contiguous(), n_rows, n_cols, False, 0, False)
 
-    def aggregate_mean(self, table):
+    def segsum(self, side, table, mean: bool = False):
         from . import functional as NF
-        return NF.segsum(None, self.dst, table, mean=True)
-
-    def aggregate_t(self, table):
-        from . import functional as NF
-        return NF.segsum(None, self.src, table)
-
-    def inv_count(self):
-        return self.dst.inv_count()
+        return NF.segsum(None, side, table, mean=mean)
 
     def linear_fwd(self, a, w, b):
         from . import functional as NF
@@ -128,29 +217,71 @@ class HipBackend:
 
 
 class ShardedGraph:
-    """This rank's shard of the (self-loop-augmented) graph."""
+    """This rank's shard of the (self-loop-augmented) graph: sides A, B and their transposes."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, device,
-                 backend_factory=None, group=None):
-        self.part = StridedPartition(num_nodes, world)
+                 backend=None, group=None, hub_mask: Optional[torch.Tensor] = None):
+        self.part = part = HubPartition(num_nodes, world, hub_mask, device)
         self.rank, self.world, self.group = rank, world, group
-        self.n_local = self.part.n_local(rank)
+        self.nL, self.nH = part.n_light(rank), part.n_hub(rank)
+        self.n_local = self.nL + self.nH
+        self.exchange_partials = part.nL > 0                      # same answer on every rank
+        self.backend = be = backend or HipBackend()
         ei = edge_index.to(device)
-        by_dst, by_src = local_edges(ei, self.part, rank)
-        factory = backend_factory or HipBackend
-        self.backend = factory(by_dst, by_src, self.n_local, self.part.table_rows(), rank * self.part.n_per)
-        self.local_nnz = int(by_dst[0].numel()) + self.n_local
+        src, dst = ei[0], ei[1]
+        a, b = local_sides(src, dst, part, rank)
+        at, bt = local_sides(dst, src, part, rank)
+        self.A, self.At = be.make_side(*a), be.make_side(*at)
+        self.B = be.make_side(*b) if self.exchange_partials else None
+        self.Bt = be.make_side(*bt) if self.exchange_partials else None
+        self.local_nnz = int(a[0].numel()) + int(b[0].numel())    # entries this rank walks per direction
+        # 1 / (in-degree + 1) of the local rows; for hub rows also the share of it that side A holds
+        keep = src != dst
+        cnt = torch.bincount(dst[keep], minlength=num_nodes).to(torch.float32) + 1.0
+        own = part.own_ids(rank)
+        self.inv_cnt = (1.0 / cnt[own]).contiguous()
+        self.cnt_a_hub = torch.bincount(a[0], minlength=self.n_local)[self.nL:].to(torch.float32).view(-1, 1)
+        self.own = own
 
     def shard(self, x_full: torch.Tensor) -> torch.Tensor:
-        return self.part.shard(x_full, self.rank)
+        return x_full[self.own.to(x_full.device)]
+
+
+def _exchange_start(sg: ShardedGraph, rows: torch.Tensor, side_b):
+    """Launch the all-gather of the hub rows of ``rows`` and the reduce-scatter of side B's partial
+    hub sums.  Returns (table for side A, its pending work, reduced hub sums or None, its pending work)."""
+    part, be, W = sg.part, sg.backend, sg.world
+    F = rows.size(1)
+    table = rows.new_empty((part.hub_rows + sg.nL, F))
+    block = rows[sg.nL:]
+    if sg.nH != part.h_per:                                        # short rank: one zero pad row
+        block = rows.new_zeros((part.h_per, F))
+        block[: sg.nH] = rows[sg.nL:]
+    g_work = all_gather_rows(block.contiguous(), table[: part.hub_rows], W, sg.group, async_op=not _solo(W))
+    table[part.hub_rows:] = rows[: sg.nL]
+    hsum = r_work = None
+    if sg.exchange_partials:
+        partial = be.segsum(side_b, rows)                          # no remote input: overlaps the all-gather
+        hsum = rows.new_empty((part.h_per, F))
+        r_work = reduce_scatter_rows(partial, hsum, sg.rank, W, sg.group, async_op=not _solo(W))
+    return table, g_work, hsum, r_work
 
 
 class _ShardedSageFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_local, weight, bias, sg: ShardedGraph):
+    def forward(ctx, x_own, weight, bias, sg: ShardedGraph):
         be = sg.backend
-        table, _ = all_gather_rows(x_local, sg.part, sg.group)
-        agg = be.aggregate_mean(table)
+        x_own = x_own.contiguous()
+        table, g_work, hsum, r_work = _exchange_start(sg, x_own, sg.B)
+        if g_work is not None:
+            g_work.wait()
+        agg = be.segsum(sg.A, table, mean=True)
+        if hsum is not None:
+            if r_work is not None:
+                r_work.wait()
+            if sg.nH:
+                inv = sg.inv_cnt[sg.nL:].view(-1, 1)
+                agg[sg.nL:] = (agg[sg.nL:] * sg.cnt_a_hub + hsum[: sg.nH]) * inv
         out = be.linear_fwd(agg, weight, bias)
         ctx.sg = sg
         ctx.has_bias = bias is not None
@@ -164,27 +295,33 @@ class _ShardedSageFn(torch.autograd.Function):
         be = sg.backend
         grad_out = grad_out.contiguous()
         dx = dw = db = None
-        work = table = None
+        started = None
         if ctx.needs_input_grad[0]:
-            dagg = be.linear_bwd_data(grad_out, weight, be.inv_count())
-            table, work = all_gather_rows(dagg, sg.part, sg.group, async_op=sg.world > 1)
+            dagg = be.linear_bwd_data(grad_out, weight, sg.inv_cnt)
+            started = _exchange_start(sg, dagg, sg.Bt)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)     # overlaps the all-gather
-            if sg.world > 1:
+            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)     # overlaps the exchange
+            if not _solo(sg.world):
                 dist.all_reduce(dw, group=sg.group)
                 if db is not None:
                     dist.all_reduce(db, group=sg.group)
-        if ctx.needs_input_grad[0]:
-            if work is not None:
-                work.wait()
-            dx = be.aggregate_t(table)
+        if started is not None:
+            table, g_work, hsum, r_work = started
+            if g_work is not None:
+                g_work.wait()
+            dx = be.segsum(sg.At, table)
+            if hsum is not None:
+                if r_work is not None:
+                    r_work.wait()
+                if sg.nH:
+                    dx[sg.nL:] += hsum[: sg.nH]
         return dx, dw, db, None
 
 
 class ShardedSAGELayer(nn.Module):
     """SAGEConv (PyG 1.4.2 semantics, mean over in-neighbours and self, then ``@ W + b``) on a sharded
-    graph.  Input and output are this rank's rows (nodes ``rank, rank + W, ...``); parameters are
-    replicated and their gradients all-reduced, as data-parallel training expects."""
+    graph.  Input and output are this rank's rows (``ShardedGraph.own``: light nodes, then hubs);
+    parameters are replicated and their gradients all-reduced, as data-parallel training expects."""
 
     def __init__(self, sg: ShardedGraph, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
         super().__init__()
@@ -192,5 +329,5 @@ class ShardedSAGELayer(nn.Module):
         self.weight = nn.Parameter(weight.clone())
         self.bias = nn.Parameter(bias.clone()) if bias is not None else None
 
-    def forward(self, x_local: torch.Tensor) -> torch.Tensor:
-        return _ShardedSageFn.apply(x_local, self.weight, self.bias, self.sg)
+    def forward(self, x_own: torch.Tensor) -> torch.Tensor:
+        return _ShardedSageFn.apply(x_own, self.weight, self.bias, self.sg)

@@ -27,6 +27,12 @@ def _zipf_probs(n: int, top_share: float) -> np.ndarray:
     return p / p.sum()
 
 
+def protein_mask(num_nodes: int) -> torch.Tensor:
+    """bool [N]: the protein side of ``bipartite_edge_index(num_nodes, ...)`` (the last tenth of the ids)"""
+    n_prot = max(1, num_nodes // 10)
+    return torch.arange(num_nodes) >= num_nodes - n_prot
+
+
 def bipartite_edge_index(num_nodes: int, num_directed_edges: int, seed: int = 20260310,
                          top_share: float = 0.054) -> torch.Tensor:
     """LongTensor [2, E] (E = num_directed_edges, even), both directions, unsorted (shuffled)."""

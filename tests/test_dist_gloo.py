@@ -16,24 +16,16 @@ from oracle import ref_conv as R
 class TorchBackend:
     """Stand-in for HipBackend: same contract, plain torch ops."""
 
-    def __init__(self, by_dst, by_src, n_local, table_rows, loop_col_offset):
-        self.kd, self.vd = by_dst
-        self.ks, self.vs = by_src
-        self.n, self.loop = n_local, loop_col_offset + torch.arange(n_local)
-        self.cnt = torch.bincount(self.kd, minlength=n_local).float() + 1.0
+    def make_side(self, key, val, n_rows, n_cols):
+        return key, val, n_rows, n_cols
 
-    def _agg(self, k, v, table):
-        out = torch.zeros(self.n, table.size(1)).index_add_(0, k, table[v])
-        return out + table[self.loop]
-
-    def aggregate_mean(self, table):
-        return self._agg(self.kd, self.vd, table) / self.cnt.view(-1, 1)
-
-    def aggregate_t(self, table):
-        return self._agg(self.ks, self.vs, table)
-
-    def inv_count(self):
-        return 1.0 / self.cnt
+    def segsum(self, side, table, mean=False):
+        key, val, n_rows, n_cols = side
+        assert table.size(0) == n_cols
+        out = torch.zeros(n_rows, table.size(1)).index_add_(0, key, table[val])
+        if mean:
+            out = out / torch.bincount(key, minlength=n_rows).clamp(min=1).float().view(-1, 1)
+        return out
 
     def linear_fwd(self, a, w, b):
         return a @ w + (b if b is not None else 0)
@@ -45,24 +37,39 @@ class TorchBackend:
         return a.t() @ dc, (dc.sum(0) if want_bias else None)
 
 
-def _case(N, E, F, seed=0):
+def _case(N, E, F, kind, seed=0):
+    """kind: 'any' = arbitrary digraph (every row is exchanged), 'bipartite' = ncRNA-protein shape with
+    the protein side as hubs, 'auto' = the same with hubs found from degrees"""
     g = torch.Generator().manual_seed(seed)
-    ei = torch.randint(0, N, (2, E), generator=g)          # includes some self loops and duplicates
-    ei[1, : E // 4] = 3                                     # a hub row
+    hub = None
+    if kind == "any":
+        ei = torch.randint(0, N, (2, E), generator=g)      # includes some self loops and duplicates
+        ei[1, : E // 4] = 3                                 # a hub row
+    else:
+        n_rna = N - max(N // 8, 2)
+        rna = torch.randint(0, n_rna, (E // 2,), generator=g)
+        pro = n_rna + (torch.rand(E // 2, generator=g) ** 3 * (N - n_rna)).long().clamp(max=N - n_rna - 1)
+        ei = torch.cat([torch.stack([rna, pro]), torch.stack([pro, rna])], 1)
+        ei = torch.cat([ei, torch.tensor([[N - 1, 0], [N - 1, 0]])], 1)      # self loops on a hub and a light node
+        if kind == "bipartite":
+            hub = torch.arange(N) >= n_rna
+        else:
+            hub = ND.auto_hubs(ei, N, ratio=2.0, max_fraction=0.9)
+            assert hub is not None and 0 < int(hub.sum()) < N
     x = torch.randn(N, F, generator=g)
     W = torch.randn(F, F, generator=g) / F ** 0.5
     b = torch.randn(F, generator=g)
     go = torch.randn(N, F, generator=g)
-    return ei, x, W, b, go
+    return ei, x, W, b, go, hub
 
 
-def _worker(rank, world, port, N, E, F, q):
+def _worker(rank, world, port, N, E, F, kind, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ei, x, W, b, go = _case(N, E, F)
-        sg = ND.ShardedGraph(ei, N, rank, world, torch.device("cpu"), backend_factory=TorchBackend)
+        ei, x, W, b, go, hub = _case(N, E, F, kind)
+        sg = ND.ShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub)
         layer = ND.ShardedSAGELayer(sg, W, b)
         xl = sg.shard(x).clone().requires_grad_(True)
         out = layer(xl)
@@ -83,13 +90,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,N", [(2, 101), (3, 64)])
-def test_sharded_layer_matches_single_process_oracle(world, N):
+@pytest.mark.parametrize("world,N,kind", [(2, 101, "any"), (3, 64, "any"), (2, 203, "bipartite"),
+                                          (3, 160, "bipartite"), (2, 120, "auto")])
+def test_sharded_layer_matches_single_process_oracle(world, N, kind):
     E, F = 900, 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, E, F, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, E, F, kind, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -99,9 +107,9 @@ def test_sharded_layer_matches_single_process_oracle(world, N):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ei, x, W, b, go = _case(N, E, F)
+    ei, x, W, b, go, hub = _case(N, E, F, kind)
     ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(x, ei, W, b, go)
-    part = ND.StridedPartition(N, world)
+    part = ND.HubPartition(N, world, hub)
     out = part.unshard([res[r][0] for r in range(world)])
     dx = part.unshard([res[r][1] for r in range(world)])
     assert torch.allclose(out, ref_out, atol=1e-5, rtol=1e-5)
@@ -112,14 +120,30 @@ def test_sharded_layer_matches_single_process_oracle(world, N):
 
 
 def test_partition_maps():
-    part = ND.StridedPartition(10, 4)
-    assert [part.n_local(r) for r in range(4)] == [3, 3, 2, 2] and part.n_per == 3
-    ids = torch.arange(10)
-    tab = part.padded(ids)
-    assert tab.tolist() == [0, 3, 6, 9, 1, 4, 7, 10, 2, 5]
+    hub = torch.tensor([0, 0, 0, 1, 0, 0, 1, 1, 0, 0], dtype=torch.bool)
+    part = ND.HubPartition(10, 2, hub)
+    assert (part.nL, part.nH, part.h_per, part.hub_rows) == (7, 3, 2, 4)
+    assert [part.n_light(r) for r in range(2)] == [4, 3] and [part.n_hub(r) for r in range(2)] == [2, 1]
+    assert part.own_ids(0).tolist() == [0, 2, 5, 9, 3, 7] and part.own_ids(1).tolist() == [1, 4, 8, 6]
+    assert part.hub_row(torch.tensor([3, 6, 7])).tolist() == [0, 2, 1]
     x = torch.arange(10.0).view(-1, 1)
-    assert torch.equal(part.unshard([part.shard(x, r) for r in range(4)]), x)
-    # every rank's by-dst edges cover exactly the non-loop edges once
-    ei = torch.tensor([[0, 1, 2, 3, 4, 4], [1, 1, 3, 2, 4, 0]])
-    tot = sum(ND.local_edges(ei, part, r)[0][0].numel() for r in range(4))
-    assert tot == 4            # (1,1) and (4,4) are self loops
+    assert torch.equal(part.unshard([part.shard(x, r) for r in range(2)]), x)
+    # all-hub partition == plain strided destination rows
+    full = ND.HubPartition(10, 4)
+    assert full.nL == 0 and full.own_ids(1).tolist() == [1, 5, 9]
+    assert full.hub_row(torch.arange(10)).tolist() == [0, 3, 6, 9, 1, 4, 7, 10, 2, 5]
+    # every non-loop edge lands in exactly one side of one rank, per direction
+    ei = torch.tensor([[0, 3, 6, 7, 4, 4, 3], [3, 1, 7, 2, 6, 4, 3]])
+    tot = 0
+    for r in range(2):
+        a, b = ND.local_sides(ei[0], ei[1], part, r)
+        tot += a[0].numel() - a[2] + b[0].numel()          # side A carries one loop per local row
+    assert tot == 5                                         # (4,4) and (3,3) are self loops
+    with pytest.raises(ValueError):
+        ND.local_sides(torch.tensor([0]), torch.tensor([1]), part, 0)     # light-light edge
+
+
+def test_auto_hubs_falls_back_when_there_is_no_small_hub_side():
+    g = torch.Generator().manual_seed(0)
+    ei = torch.randint(0, 50, (2, 400), generator=g)
+    assert ND.auto_hubs(ei, 50) is None
