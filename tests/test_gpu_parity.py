@@ -257,31 +257,52 @@ def test_modules_drop_into_a_net1_style_stack(dev):
     assert not torch.equal(c1.weight.detach().cpu(), sd1["weight"])
 
 
+@pytest.mark.parametrize("hubs", [False, True])
 @pytest.mark.parametrize("world", [1, 3, 8])
-def test_sharded_backend_virtual_ranks_on_one_gpu(dev, world):
-    """with one GPU, run the W shards one after the other and emulate the all-gather,
-    to validate the sharded CSR (local rows x gathered-table columns) and both aggregation directions."""
+def test_sharded_backend_virtual_ranks_on_one_gpu(dev, world, hubs):
+    """with one GPU, run the W shards one after the other and emulate the all-gather of
+    hub rows and the reduce-scatter of partial hub sums, to validate the sharded CSR sides (A: local rows
+    x [hub table ; local light rows], B: hub rows x local rows) in both aggregation directions."""
     from npi_gnn_amd import dist as ND
-    N, E, F = 5003, 60000, 256
-    ei = rand_edges(N, E, seed=21, hub=7)
+    from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
+    F = 256
+    if hubs:
+        N = 5003
+        ei = bipartite_edge_index(N, 60000, seed=21)
+        mask = protein_mask(N)
+    else:
+        N = 5003
+        ei = rand_edges(N, 60000, seed=21, hub=7)
+        mask = None
     x = torch.randn(N, F, generator=torch.Generator().manual_seed(2))
-    part = ND.StridedPartition(N, world)
-    table = torch.zeros(part.table_rows(), F)
-    table[part.padded(torch.arange(N))] = x
-    table_d = table.to(dev)
     ref_fwd = R.sage_aggregate(x, ei)
     ei2 = R.add_remaining_self_loops(ei, None, 1.0, N)[0]
     ref_bwd = R.scatter_add(x.index_select(0, ei2[1]), ei2[0], N)      # transpose aggregation (sum)
-    outs_f, outs_b = [], []
-    for r in range(world):
-        by_dst, by_src = ND.local_edges(ei.to(dev), part, r)
-        be = ND.HipBackend(by_dst, by_src, part.n_local(r), part.table_rows(), r * part.n_per)
-        outs_f.append(be.aggregate_mean(table_d).cpu())
-        outs_b.append(be.aggregate_t(table_d).cpu())
-        cnt = torch.bincount(ei2[1], minlength=N).float()
-        assert torch.allclose(be.inv_count().cpu(), 1.0 / part.shard(cnt, r))
-    assert torch.allclose(part.unshard(outs_f), ref_fwd, atol=ATOL, rtol=RTOL)
-    assert torch.allclose(part.unshard(outs_b), ref_bwd, atol=ATOL * 30, rtol=RTOL)
+    sgs = [ND.ShardedGraph(ei, N, r, world, dev, hub_mask=mask) for r in range(world)]
+    part = sgs[0].part
+    own = [sg.shard(x).to(dev) for sg in sgs]
+    hub_table = torch.zeros(part.hub_rows, F, device=dev)
+    for r, sg in enumerate(sgs):
+        hub_table[r * part.h_per: r * part.h_per + sg.nH] = own[r][sg.nL:]
+    be = sgs[0].backend
+    for side_a, side_b, mean, ref in (("A", "B", True, ref_fwd), ("At", "Bt", False, ref_bwd)):
+        partial = [be.segsum(getattr(sg, side_b), own[r]) for r, sg in enumerate(sgs)] if sgs[0].exchange_partials else None
+        outs = []
+        for r, sg in enumerate(sgs):
+            table = torch.cat([hub_table, own[r][: sg.nL]])
+            agg = be.segsum(getattr(sg, side_a), table, mean=mean)
+            if partial is not None and sg.nH:
+                hsum = sum(p[r * part.h_per: r * part.h_per + sg.nH] for p in partial)
+                if mean:
+                    agg[sg.nL:] = (agg[sg.nL:] * sg.cnt_a_hub + hsum) * sg.inv_cnt[sg.nL:].view(-1, 1)
+                else:
+                    agg[sg.nL:] += hsum
+            outs.append(agg.cpu())
+        got = part.unshard(outs)
+        assert torch.allclose(got, ref, atol=ATOL * (1 if mean else 30), rtol=RTOL)
+    cnt = torch.bincount(ei2[1], minlength=N).float()
+    for sg in sgs:
+        assert torch.allclose(sg.inv_cnt.cpu(), 1.0 / cnt[sg.own.cpu()])
 
 
 def test_sharded_layer_world1_matches_single_gpu_layer(dev):
