@@ -130,14 +130,22 @@ int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fil
 
 /* ------------------------------------------------------------------------------------------
  * Dense projection on the matrix cores -- replaces `torch.matmul(aggr_out, self.weight) + bias`
- * (SAGEConv.update / GCNConv.forward) and its autograd backward.  f32 in / f32 accumulate on
- * v_mfma_f32_32x32x2_f32 (exact f32, needed for the 1e-4 parity bar).
+ * (SAGEConv.update / GCNConv.forward) and its autograd backward.  f32 in, f32 out, f32 accumulate on
+ * the matrix cores, error at f32-rounding level in both arithmetics (see npi_gemm_mode).
  *
  *   npi_linear_fwd      : C[M,N]  = act( rowscale_m * (A[M,K] @ W[K,N]) + bias[N] )
  *   npi_linear_bwd_data : dA[M,K] = rowscale_m * (dC[M,N] @ W[K,N]^T)
  *   npi_linear_bwd_weight: dW[K,N] = A[M,K]^T @ dC[M,N],  db[N] = colsum(dC)   (db may be NULL)
  *                          deterministic split over M; workspace f32
  * ------------------------------------------------------------------------------------------ */
+/* GEMM arithmetic of the f32 entry points: 0 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 3-way bf16
+ * split of both operands on the bf16 matrix cores (six v_mfma_f32_32x32x16_bf16 per product tile, f32
+ * accumulate, error at f32-rounding level; csrc/gemm_f32.hip).  Returns the previous mode; any other
+ * argument only queries.  Process-wide; initial value 1 unless env NPI_GEMM_SPLIT=0.
+ * Used by npi_linear_fwd and npi_linear_bwd_data on full 128 x 128 tiles when K % 32 == 0 and rows are
+ * 16-byte aligned; everything else (ragged strips, dW, bf16 storage) runs the exact-f32 kernels. */
+int npi_gemm_mode(int mode);
+
 int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                    const float* rowscale, float* C, int64_t ldc,
                    int64_t M, int64_t K, int64_t N, int relu, void* stream);

@@ -24,6 +24,7 @@
 //   operand contiguous along M/N in memory -> image [k][rows+4], fragment = ds_read_b32 per k.
 #include "npi_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace npi {
 
@@ -467,6 +468,321 @@ colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, fl
         part[(int64_t)blockIdx.y * N + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ---- f32 GEMM on the bf16 matrix cores: 3-way split ------------------------------------------------
+// x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): three bf16 carry the 24
+// significand bits of an f32 (the remainder is <= 2^-25 |x|; exponent range is the f32 one).  The
+// product a*b is then the six bf16 x bf16 terms of order <= 2,
+//     a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0),      dropped terms <= 3 * 2^-24 |a b|,
+// each exact in the f32 accumulator of v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs cost 6/16 of the
+// f32 MFMA time for the same tile, and the result carries f32-rounding-level error (measured in
+// tools/gemm_accuracy.py against an fp64 product, next to the exact-f32 kernel).
+// Limits: an Inf in A or B gives NaN (Inf - Inf in the split), not Inf.
+//
+// Kernel S1 (fwd, bwd_data): A [M, K] f32, K-contiguous, split in registers on its way into LDS;
+// B comes as three pre-split bf16 planes [n][K] (split_planes_kernel; W is small).  128 x 128 tile,
+// BK = 32, 2 x 2 waves, one LDS buffer (60 KiB) + register prefetch, two workgroups per CU: while one
+// splits and stores, the other issues MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+constexpr int SPITCH = 80;                         // bytes per [row][32 bf16] image row (64 + 16 pad)
+constexpr int SPLANE = 128 * SPITCH;               // one 128-row plane image
+
+__device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
+    f32x2v v = {x, y};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));    // x in the low half
+}
+__device__ __forceinline__ void split3_pair(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = pack_bf16(x, y);
+    x -= __uint_as_float(p0 << 16);
+    y -= __uint_as_float(p0 & 0xffff0000u);
+    p1 = pack_bf16(x, y);
+    x -= __uint_as_float(p1 << 16);
+    y -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16(x, y);
+}
+// the three planes of a float4 (k .. k+3), as 8-byte LDS stores
+typedef float f32x4r __attribute__((ext_vector_type(4)));      // native 128-bit register values (inline-asm operands)
+typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_store(float4 v, char* img);
+__device__ __forceinline__ void split3_store(f32x4r v, char* img) { split3_store(make_float4(v.x, v.y, v.z, v.w), img); }
+__device__ __forceinline__ void split3_store(float4 v, char* img) {
+    uint32_t a0, a1, a2, b0, b1, b2;
+    split3_pair(v.x, v.y, a0, a1, a2);
+    split3_pair(v.z, v.w, b0, b1, b2);
+    *reinterpret_cast<uint2*>(img) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(img + SPLANE) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(img + 2 * SPLANE) = make_uint2(a2, b2);
+}
+
+// planes[p][k / 32][n][k % 32] (bf16, K % 32 == 0) of B(k, n): BMODE 0: B[k*ldb + n], BMODE 1: B[n*ldb + k].
+// k-step major: the 128 x 32 tile of one k-step is 8 KiB of contiguous memory per plane, so the
+// producer's loads are whole cache lines (with [n][K] rows each load instruction touched 32 lines for
+// 32 B each and the CU's address path, not the MFMA, set the pace).
+__global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, int K, int N, int bmode,
+                                    uint16_t* __restrict__ planes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    const float x = bmode == 0 ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k];
+    uint32_t p0, p1, p2;
+    split3_pair(x, 0.f, p0, p1, p2);
+    const int64_t o = ((int64_t)(k >> 5) * N + n) * 32 + (k & 31);
+    planes[o] = (uint16_t)p0;
+    planes[(int64_t)N * K + o] = (uint16_t)p1;
+    planes[2 * (int64_t)N * K + o] = (uint16_t)p2;
+}
+
+struct SplitArgs {
+    const float* A; int64_t lda;
+    const uint16_t* Bp;      // [3][K/32][N][32]
+    float* C; int64_t ldc;
+    int M, N, K;
+    Epilogue ep;
+    int tiles_m, tiles_n;    // full 128 x 128 tiles to cover (persistent kernel)
+    unsigned long long* dbg; // diagnostic builds (-DNPI_X_STAMP) only
+};
+
+// Kernel S1w: the same arithmetic, persistent and wave-specialised.  768 threads = 4 consumer waves
+// (fragment reads + MFMAs, nothing else) + 8 producer waves (global loads, the split, LDS stores), one
+// consumer and two producers per SIMD, so the matrix pipe and the VALU/LDS-store work overlap by construction instead of
+// by instruction scheduling.  LDS double-buffered (120 KiB, one workgroup per CU), ONE barrier per
+// k-step; a workgroup walks a sequence of tiles with the producer running ahead across tile
+// boundaries, so only the first tile of a workgroup exposes a load latency.  Tiles that share their
+// A rows (same m-tile, other n-tile) go to neighbouring slots of one XCD: the second read of A hits
+// that XCD's L2.
+constexpr int WS_THREADS = 768;                    // 4 consumer + 8 producer waves: per SIMD one MFMA wave and two staging waves
+
+struct TileWalk {
+    int q, kt;          // position: tile sequence number, k-step
+    int mt, nt;
+    int qend, G, nk, tiles_m, tiles_n;
+    __device__ __forceinline__ void decode() {
+        // q -> (m-tile, n-tile): q & 7 = XCD of the workgroup (round-robin dispatch), consecutive slots of an
+        // XCD take the n-tiles of one m-tile
+        for (;;) {
+            if (q >= qend) return;
+            nt = (q >> 3) % tiles_n;
+            mt = ((q >> 3) / tiles_n) * 8 + (q & 7);
+            if (mt < tiles_m) return;
+            q += G;
+        }
+    }
+    __device__ __forceinline__ void init(int b, int G_, int nk_, int tm, int tn) {
+        G = G_; nk = nk_; tiles_m = tm; tiles_n = tn;
+        qend = ((tm + 7) / 8) * 8 * tn;
+        q = b; kt = 0;
+        decode();
+    }
+    __device__ __forceinline__ bool valid() const { return q < qend; }
+    __device__ __forceinline__ void next() {
+        if (++kt == nk) { kt = 0; q += G; decode(); }
+    }
+};
+
+__global__ void __launch_bounds__(WS_THREADS, 1)
+gemm_split_ws_kernel(SplitArgs a) {
+    constexpr int TM = 2, TN = 2;
+    constexpr int BUF = 6 * SPLANE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];         // per buffer: A planes 0..2, B planes 0..2
+    const int t = threadIdx.x;
+    const int wave = uniform_i(t >> 6);
+    const int nk = a.K / BK;
+    TileWalk w;
+    w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n);
+    if (!w.valid()) return;                                 // no tile for this workgroup (uniform)
+
+    if (wave >= 4) {
+        // ---------------- producer ----------------
+        const int pt = t - 256;
+        // every address is a wave-uniform base (SGPR pair, recomputed per step from the walk) plus a per-thread
+        // 32-bit byte offset fixed for the whole kernel: no address VALU and no address temporaries in the
+        // loop (hipcc parked those in registers of the load ring and then waited on loads still in flight)
+        const int64_t b_plane = (int64_t)a.N * a.K * 2;
+        // A: float4 #(pt & 7) of rows (pt >> 3) and (pt >> 3) + 64;  B: 16-B chunk pt of each plane's 8 KiB tile
+        const uint32_t oa0 = (uint32_t)(((int64_t)(pt >> 3) * a.lda + (pt & 7) * 4) * 4);
+        const uint32_t oa1 = oa0 + (uint32_t)(a.lda * 64 * 4);
+        const uint32_t ob = (uint32_t)pt * 16;
+        char* la = lds + (pt >> 3) * SPITCH + (pt & 7) * 8;
+        char* lb = lds + 3 * SPLANE + (pt >> 2) * SPITCH + (pt & 3) * 16;               // chunk c -> row c / 4, 16-B slot c % 4
+        TileWalk wl = w;                                    // load position (runs ahead of the store position w)
+        // register ring of 4 k-steps: three steps of loads are in flight while the fourth is split and
+        // stored (one step of A per CU in flight is 16 KiB per ~2 us of loaded HBM latency = 2 TB/s chip-wide)
+#define NPI_WDECL(S) f32x4r S##a0, S##a1; u32x4r S##b0, S##b1, S##b2
+        NPI_WDECL(r0); NPI_WDECL(r1); NPI_WDECL(r2); NPI_WDECL(r3);
+        // The loads and their waits are written in assembly: hipcc's own vmcnt bookkeeping loses the ring at
+        // the loop back-edge (it waited vmcnt(2..6) in one of the four steps) and parks address temporaries
+        // in ring registers.  global_load dst, v_off, s[base]: wave-uniform base, fixed per-thread offset.
+#define NPI_GL(dst, off, base, IMM)                                                                    \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(off), "s"(base) : "memory")
+#define NPI_WLOAD(S)                                                                                   \
+    do {                                                                                               \
+        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.mt * 128 * a.lda + wl.kt * BK) * 4);      \
+        const char* gb0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * a.N + wl.nt * 128) * (BK * 2));    \
+        const char* gb1 = uniform_ptr(gb0 + b_plane);                                                  \
+        const char* gb2 = uniform_ptr(gb0 + 2 * b_plane);                                              \
+        NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0);                                          \
+        NPI_GL(S##b0, ob, gb0, 0); NPI_GL(S##b1, ob, gb1, 0); NPI_GL(S##b2, ob, gb2, 0);               \
+        wl.next();                                                                                     \
+    } while (0)
+        // wait until only the 15 loads of the three younger sets are in flight; the set is an in/out operand
+        // so that no use of it can be scheduled above the wait
+#define NPI_WWAIT(S)                                                                                   \
+        asm volatile("s_waitcnt vmcnt(15)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##b0), "+v"(S##b1), "+v"(S##b2) : : "memory")
+#define NPI_WSTORE(OFF, S)                                                                             \
+    do {                                                                                               \
+        split3_store(S##a0, la + (OFF));                                                               \
+        split3_store(S##a1, la + (OFF) + 64 * SPITCH);                                                 \
+        *reinterpret_cast<u32x4r*>(lb + (OFF)) = S##b0;                                                \
+        *reinterpret_cast<u32x4r*>(lb + (OFF) + SPLANE) = S##b1;                                       \
+        *reinterpret_cast<u32x4r*>(lb + (OFF) + 2 * SPLANE) = S##b2;                                   \
+    } while (0)
+        // one k-step: refill the set freed by the previous step, split + store set CUR
+#ifdef NPI_X_STAMP
+        unsigned long long pT0, pT1, pT2, pT3, pTw, pLoad = 0, pSplit = 0, pBar = 0, pSteps = 0, pWait = 0;
+#define NPI_WSTEP(OFF, CUR, FREE)                                                                      \
+        pT0 = __builtin_amdgcn_s_memtime();                                                            \
+        NPI_WLOAD(FREE);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        pTw = __builtin_amdgcn_s_memtime();                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        NPI_WWAIT(CUR);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        pT1 = __builtin_amdgcn_s_memtime();                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        NPI_WSTORE(OFF, CUR);                                                                          \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        pT2 = __builtin_amdgcn_s_memtime();                                                            \
+        __syncthreads();                                                                               \
+        pT3 = __builtin_amdgcn_s_memtime();                                                            \
+        pLoad += pTw - pT0; pWait += pT1 - pTw; pSplit += pT2 - pT1; pBar += pT3 - pT2; ++pSteps;                          \
+        w.next();                                                                                      \
+        if (!w.valid()) break
+#else
+#define NPI_WSTEP(OFF, CUR, FREE)                                                                      \
+        NPI_WLOAD(FREE);                                                                               \
+        NPI_WWAIT(CUR);                                                                                \
+        NPI_WSTORE(OFF, CUR);                                                                          \
+        __syncthreads();                                                                               \
+        w.next();                                                                                      \
+        if (!w.valid()) break
+#endif
+        // Loads are UNCONDITIONAL: past the last step the walk keeps pointing at a valid tile and the data
+        // is dropped.  With `if (more) load` the number of loads in flight is not a compile-time fact, and
+        // hipcc must then wait for ALL younger loads (vmcnt(9..0)) before touching the oldest set -- the
+        // ring would hold one step, not three.
+        NPI_WLOAD(r0);
+        NPI_WLOAD(r1);
+        NPI_WLOAD(r2);
+        while (w.valid()) {
+            NPI_WSTEP(0, r0, r3);
+            NPI_WSTEP(BUF, r1, r0);
+            NPI_WSTEP(0, r2, r1);
+            NPI_WSTEP(BUF, r3, r2);
+        }
+#undef NPI_WSTEP
+#undef NPI_WDECL
+#undef NPI_WWAIT
+#undef NPI_GL
+#ifdef NPI_X_STAMP
+        if (a.dbg && blockIdx.x == 17 && t == 256) { a.dbg[0] = pLoad; a.dbg[1] = pSplit; a.dbg[2] = pBar; a.dbg[3] = pSteps; a.dbg[10] = pWait; }
+#endif
+#undef NPI_WLOAD
+#undef NPI_WSTORE
+        return;
+    }
+
+    // ---------------- consumer ----------------
+    const int lane = t & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const char* fa = lds + (wm * 64 + li) * SPITCH + lh * 16;
+    const char* fb = lds + 3 * SPLANE + (wn * 64 + li) * SPITCH + lh * 16;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    int par = 0;
+#ifdef NPI_X_STAMP
+    unsigned long long cT0, cT1, cT2, cT3, cBar = 0, cMma = 0, cEpi = 0, cSteps = 0;
+    const unsigned long long cStart = __builtin_amdgcn_s_memtime(), rStart = __builtin_amdgcn_s_memrealtime();
+#endif
+    while (w.valid()) {
+#ifdef NPI_X_STAMP
+        cT0 = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();                                    // buffer `par` holds this k-step
+#ifdef NPI_X_STAMP
+        cT1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        const char* pa = fa + par * BUF;
+        const char* pb = fb + par * BUF;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(pa + p * SPLANE + i * 32 * SPITCH + kb * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[j][p] = *reinterpret_cast<const bf16x8*>(pb + p * SPLANE + j * 32 * SPITCH + kb * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        par ^= 1;
+#ifdef NPI_X_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        cT2 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (w.kt == nk - 1) {
+            store_tile<false, TM, TN>(a.C, a.ldc, a.M, a.N, w.mt * 128, w.nt * 128, wm, wn, li, lh, acc, a.ep);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        }
+#ifdef NPI_X_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        cT3 = __builtin_amdgcn_s_memtime();
+        cBar += cT1 - cT0; cMma += cT2 - cT1; cEpi += cT3 - cT2; ++cSteps;
+#endif
+        w.next();
+    }
+#ifdef NPI_X_STAMP
+    if (a.dbg && blockIdx.x == 17 && t == 0) {
+        a.dbg[4] = cBar; a.dbg[5] = cMma; a.dbg[6] = cEpi; a.dbg[7] = cSteps;
+        a.dbg[8] = __builtin_amdgcn_s_memtime() - cStart; a.dbg[9] = __builtin_amdgcn_s_memrealtime() - rStart;
+    }
+#endif
+}
+
+// 0 = exact f32 MFMA, 1 = 3-way bf16 split (fwd / bwd_data interior tiles; the default, NPI_GEMM_SPLIT=0 turns it off)
+static int g_gemm_mode = [] { const char* e = getenv("NPI_GEMM_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+
 static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4) {
     return ((uintptr_t)p % (4 * es) == 0) && (ld % 4 == 0) && (inner_extent % 4 == 0);
 }
@@ -491,7 +807,38 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int
     const bool wide = wide_enabled && fast_ok && a.N >= 256 && a.M >= 128;
     const int bm = 128, bn = wide ? 256 : 128;
     const int fm = fast_ok ? a.M / bm : 0, fn = fast_ok ? a.N / bn : 0;    // full tiles
-    if (fm > 0 && fn > 0) {
+    const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && g_gemm_mode != 0 && a.ep.colsum == nullptr;
+    if (fm > 0 && fn > 0 && split) {
+        // stream-ordered scratch for the three bf16 planes of B (W is small: 3 * 2 * K * N bytes)
+        uint16_t* planes = nullptr;
+        const int64_t nel = (int64_t)a.N * a.K;
+        if (hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)nel * 6, stream) != hipSuccess || planes == nullptr) {
+            (void)hipGetLastError();
+            set_error("gemm: hipMallocAsync of the split planes failed");
+            return;
+        }
+        split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes);
+        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, fm, fn, nullptr};
+#ifdef NPI_X_STAMP
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 16 * 8); }
+        (void)hipMemsetAsync(dbg, 0, 16 * 8, stream);
+        sa.dbg = dbg;
+#endif
+        {
+            const int64_t ntiles = (int64_t)fm * fn;
+            const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
+            gemm_split_ws_kernel<<<grid, WS_THREADS, 0, stream>>>(sa);
+#ifdef NPI_X_STAMP
+            unsigned long long h[16];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[stamp] producer: load-issue %llu vmwait %llu split+store %llu barrier %llu steps %llu | consumer: barrier %llu reads+mfma %llu epilogue %llu steps %llu | total %llu cyc, clock %.0f MHz\n",
+                    h[0], h[10], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9] ? 100.0 * h[8] / h[9] : 0.0);
+#endif
+        }
+        (void)hipFreeAsync(planes, stream);
+    } else if (fm > 0 && fn > 0) {
         GemmArgs f = a;
         f.tm0 = 0; f.tn0 = 0;
         if (wide) gemm_fast_kernel<AMODE, BMODE, 2, 4><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
@@ -531,6 +878,12 @@ using namespace npi;
 
 static inline const float* fp(const void* p) { return reinterpret_cast<const float*>(p); }
 static inline const void* advance(const void* p, int64_t elems, int es) { return reinterpret_cast<const char*>(p) + elems * es; }
+
+extern "C" int npi_gemm_mode(int mode) {
+    const int prev = g_gemm_mode;
+    if (mode == 0 || mode == 1) g_gemm_mode = mode;
+    return prev;
+}
 
 extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                                 const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,

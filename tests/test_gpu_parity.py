@@ -318,3 +318,35 @@ def test_sharded_layer_world1_matches_single_gpu_layer(dev):
     assert torch.allclose(xl.grad.cpu(), ref_dx, atol=ATOL, rtol=RTOL)
     assert torch.allclose(layer.weight.grad.cpu(), ref_dw, atol=ATOL * 60, rtol=1e-3)
     assert torch.allclose(layer.bias.grad.cpu(), ref_db, atol=ATOL * 60, rtol=1e-3)
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 256, 256), (128 * 5 + 3, 128, 384), (4096, 64, 128), (130, 256, 128)])
+def test_split_bf16_gemm_is_f32_accurate(dev, M, K, N):
+    """npi_gemm_mode 1 (3-way bf16 split on the bf16 matrix cores) against an fp64 product: its error must
+    be at the level of the exact-f32 kernel's (mode 0), through fwd (bias, rowscale, relu) and bwd_data,
+    including the seam between the split interior tiles and the exact ragged strip."""
+    from npi_gnn_amd._lib import load
+    lib = load()
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    rs = torch.rand(M, generator=g).to(dev)
+    dC = torch.randn(M, N, generator=g).to(dev)
+    ref_f = torch.relu(rs.double().view(-1, 1) * (A.double() @ W.double()) + b.double())
+    ref_b = rs.double().view(-1, 1) * (dC.double() @ W.double().t())
+    prev = lib.npi_gemm_mode(-1)
+    try:
+        err = {}
+        for mode in (0, 1):
+            lib.npi_gemm_mode(mode)
+            cf = NF.linear_fwd(A, W, b, rowscale=rs, relu=True)
+            cb = NF.linear_bwd_data(dC, W, rs)
+            err[mode] = (float((cf.double() - ref_f).abs().max() / ref_f.abs().max()),
+                         float((cb.double() - ref_b).abs().max() / ref_b.abs().max()))
+            again = NF.linear_fwd(A, W, b, rowscale=rs, relu=True)
+            assert torch.equal(cf, again)                      # run-to-run bitwise reproducible
+        for e0, e1 in zip(err[0], err[1]):
+            assert e1 < 2e-6 and e1 < 3 * e0 + 1e-7, err
+    finally:
+        lib.npi_gemm_mode(prev)
