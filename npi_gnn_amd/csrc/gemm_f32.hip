@@ -230,23 +230,35 @@ __device__ __forceinline__ void store_tile(T* __restrict__ C, int64_t ldc, int M
     }
     const bool relu_on = ep.relu != 0;
     T* __restrict__ cbase = C + (int64_t)(mw + 4 * lh) * ldc + (nw + li);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int ro = i * 32 + (q & 3) + 8 * (q >> 2);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float v = fmaf(acc[i][j][q], rsv[i][q], bv[j]);
-                v = (relu_on && v < 0.f) ? 0.f : v;          // keeps NaN, like torch.relu
-                if (!GUARD) {
-                    st1(cbase + (int64_t)ro * ldc + j * 32, v);
-                } else {
-                    const int r = mw + 4 * lh + ro, c = nw + j * 32 + li;
-                    if (r < M && c < N) st1(cbase + (int64_t)ro * ldc + j * 32, v);
-                }
-            }
+    // the common case (no row scale, no relu) is one add per element: two separate store loops under a
+    // wave-uniform branch (written as one loop hipcc turns the choice into per-element selects)
+    auto put = [&](int ro, int j, float v) {
+        if (!GUARD) {
+            st1(cbase + (int64_t)ro * ldc + j * 32, v);
+        } else {
+            const int r = mw + 4 * lh + ro, c = nw + j * 32 + li;
+            if (r < M && c < N) st1(cbase + (int64_t)ro * ldc + j * 32, v);
         }
+    };
+    if (!relu_on && ep.rowscale == nullptr) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) put(i * 32 + (q & 3) + 8 * (q >> 2), j, acc[i][j][q] + bv[j]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = fmaf(acc[i][j][q], rsv[i][q], bv[j]);
+                    v = (relu_on && v < 0.f) ? 0.f : v;      // keeps NaN, like torch.relu
+                    put(i * 32 + (q & 3) + 8 * (q >> 2), j, v);
+                }
+    }
 }
 
 template <int AMODE, int BMODE, int TM, int TN>
@@ -478,16 +490,26 @@ colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, fl
 // tools/gemm_accuracy.py against an fp64 product, next to the exact-f32 kernel).
 // Limits: an Inf in A or B gives NaN (Inf - Inf in the split), not Inf.
 //
-// Kernel S1 (fwd, bwd_data): A [M, K] f32, K-contiguous, split in registers on its way into LDS;
-// B comes as three pre-split bf16 planes [n][K] (split_planes_kernel; W is small).  128 x 128 tile,
-// BK = 32, 2 x 2 waves, one LDS buffer (60 KiB) + register prefetch, two workgroups per CU: while one
-// splits and stores, the other issues MFMAs.
+// Kernel (fwd, bwd_data): C[M, N] = A[M, K] B(K, N).  A is f32, K-contiguous, split in registers on its
+// way into LDS; B (the small weight matrix) comes as three pre-split bf16 planes (split_planes_kernel).
+// Persistent and wave-specialised: a workgroup = 4 consumer waves (fragment reads + MFMAs + epilogue,
+// a 2 x 2 grid of 64 x 32 TN wave tiles) + 4 producer waves (global loads, the split, LDS stores), one of
+// each per SIMD, so the matrix pipe and the VALU / LDS-store work overlap by construction rather than
+// by instruction scheduling.  Tile 128 x 64 TN (TN = 4 when N % 256 == 0: every A element is then split
+// once for 256 output columns), BK = 16, LDS double-buffered, ONE barrier per k-step; the producer
+// keeps a ring of four k-steps of loads in flight and runs across tile boundaries, so only the first
+// tile of a workgroup exposes a load latency.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4r __attribute__((ext_vector_type(4)));      // native 128-bit register values (inline-asm operands)
+typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
-constexpr int SPITCH = 80;                         // bytes per [row][32 bf16] image row (64 + 16 pad)
-constexpr int SPLANE = 128 * SPITCH;               // one 128-row plane image
+constexpr int SK = 16;                             // k-step of the split kernel = one 32x32x16 MFMA block
+// LDS plane image: [row][16 bf16] = 32-byte rows, no padding; the two 16-byte halves of a row are swapped
+// on rows with bit 3 set, which makes the ds_read_b128 fragment reads (lane -> row, half lane>>5)
+// bank-conflict free for the 16-lane groups the hardware forms
+__device__ __forceinline__ int simg(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
 
 __device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
     f32x2v v = {x, y};
@@ -502,24 +524,19 @@ __device__ __forceinline__ void split3_pair(float x, float y, uint32_t& p0, uint
     y -= __uint_as_float(p1 & 0xffff0000u);
     p2 = pack_bf16(x, y);
 }
-// the three planes of a float4 (k .. k+3), as 8-byte LDS stores
-typedef float f32x4r __attribute__((ext_vector_type(4)));      // native 128-bit register values (inline-asm operands)
-typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split3_store(float4 v, char* img);
-__device__ __forceinline__ void split3_store(f32x4r v, char* img) { split3_store(make_float4(v.x, v.y, v.z, v.w), img); }
-__device__ __forceinline__ void split3_store(float4 v, char* img) {
+// the three planes of four consecutive k, as 8-byte LDS stores; `plane` = bytes between plane images
+__device__ __forceinline__ void split3_store(f32x4r v, char* img, int plane) {
     uint32_t a0, a1, a2, b0, b1, b2;
     split3_pair(v.x, v.y, a0, a1, a2);
     split3_pair(v.z, v.w, b0, b1, b2);
     *reinterpret_cast<uint2*>(img) = make_uint2(a0, b0);
-    *reinterpret_cast<uint2*>(img + SPLANE) = make_uint2(a1, b1);
-    *reinterpret_cast<uint2*>(img + 2 * SPLANE) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(img + plane) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(img + 2 * plane) = make_uint2(a2, b2);
 }
 
-// planes[p][k / 32][n][k % 32] (bf16, K % 32 == 0) of B(k, n): BMODE 0: B[k*ldb + n], BMODE 1: B[n*ldb + k].
-// k-step major: the 128 x 32 tile of one k-step is 8 KiB of contiguous memory per plane, so the
-// producer's loads are whole cache lines (with [n][K] rows each load instruction touched 32 lines for
-// 32 B each and the CU's address path, not the MFMA, set the pace).
+// planes[p][k / 16][n][k % 16] (bf16, K % 16 == 0) of B(k, n): BMODE 0: B[k*ldb + n], BMODE 1: B[n*ldb + k].
+// k-step major: the BN x 16 tile of one k-step is BN * 32 contiguous bytes per plane, so the producer's
+// loads are whole cache lines.
 __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, int K, int N, int bmode,
                                     uint16_t* __restrict__ planes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,7 +545,7 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
     const float x = bmode == 0 ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k];
     uint32_t p0, p1, p2;
     split3_pair(x, 0.f, p0, p1, p2);
-    const int64_t o = ((int64_t)(k >> 5) * N + n) * 32 + (k & 31);
+    const int64_t o = ((int64_t)(k / SK) * N + n) * SK + (k % SK);
     planes[o] = (uint16_t)p0;
     planes[(int64_t)N * K + o] = (uint16_t)p1;
     planes[2 * (int64_t)N * K + o] = (uint16_t)p2;
@@ -536,23 +553,15 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
 
 struct SplitArgs {
     const float* A; int64_t lda;
-    const uint16_t* Bp;      // [3][K/32][N][32]
+    const uint16_t* Bp;      // [3][K/16][N][16]
     float* C; int64_t ldc;
     int M, N, K;
     Epilogue ep;
-    int tiles_m, tiles_n;    // full 128 x 128 tiles to cover (persistent kernel)
+    int tiles_m, tiles_n;    // full 128 x (64 TN) tiles to cover
     unsigned long long* dbg; // diagnostic builds (-DNPI_X_STAMP) only
 };
 
-// Kernel S1w: the same arithmetic, persistent and wave-specialised.  768 threads = 4 consumer waves
-// (fragment reads + MFMAs, nothing else) + 8 producer waves (global loads, the split, LDS stores), one
-// consumer and two producers per SIMD, so the matrix pipe and the VALU/LDS-store work overlap by construction instead of
-// by instruction scheduling.  LDS double-buffered (120 KiB, one workgroup per CU), ONE barrier per
-// k-step; a workgroup walks a sequence of tiles with the producer running ahead across tile
-// boundaries, so only the first tile of a workgroup exposes a load latency.  Tiles that share their
-// A rows (same m-tile, other n-tile) go to neighbouring slots of one XCD: the second read of A hits
-// that XCD's L2.
-constexpr int WS_THREADS = 768;                    // 4 consumer + 8 producer waves: per SIMD one MFMA wave and two staging waves
+constexpr int WS_THREADS = 512;
 
 struct TileWalk {
     int q, kt;          // position: tile sequence number, k-step
@@ -560,7 +569,7 @@ struct TileWalk {
     int qend, G, nk, tiles_m, tiles_n;
     __device__ __forceinline__ void decode() {
         // q -> (m-tile, n-tile): q & 7 = XCD of the workgroup (round-robin dispatch), consecutive slots of an
-        // XCD take the n-tiles of one m-tile
+        // XCD take the n-tiles of one m-tile (their A rows then hit that XCD's L2)
         for (;;) {
             if (q >= qend) return;
             nt = (q >> 3) % tiles_n;
@@ -581,14 +590,18 @@ struct TileWalk {
     }
 };
 
+template <int TN>
 __global__ void __launch_bounds__(WS_THREADS, 1)
 gemm_split_ws_kernel(SplitArgs a) {
-    constexpr int TM = 2, TN = 2;
-    constexpr int BUF = 6 * SPLANE;
-    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];         // per buffer: A planes 0..2, B planes 0..2
+    constexpr int TM = 2;
+    constexpr int BN = 64 * TN;                       // 128 or 256 output columns per tile
+    constexpr int APL = 128 * 32, BPL = BN * 32;      // bytes of one A / B plane image
+    constexpr int BUF = 3 * APL + 3 * BPL;            // one stage: A planes 0..2, B planes 0..2
+    constexpr int NB = BN / 128;                      // 16-byte B chunks per producer thread and plane
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int t = threadIdx.x;
     const int wave = uniform_i(t >> 6);
-    const int nk = a.K / BK;
+    const int nk = a.K / SK;
     TileWalk w;
     w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n);
     if (!w.valid()) return;                                 // no tile for this workgroup (uniform)
@@ -596,71 +609,67 @@ gemm_split_ws_kernel(SplitArgs a) {
     if (wave >= 4) {
         // ---------------- producer ----------------
         const int pt = t - 256;
-        // every address is a wave-uniform base (SGPR pair, recomputed per step from the walk) plus a per-thread
-        // 32-bit byte offset fixed for the whole kernel: no address VALU and no address temporaries in the
-        // loop (hipcc parked those in registers of the load ring and then waited on loads still in flight)
+        // Every address is a wave-uniform base (SGPR pair, recomputed per step from the walk) plus a per-thread
+        // 32-bit byte offset fixed for the whole kernel.
+        // A: float4 #(pt & 3) of rows (pt >> 2) and (pt >> 2) + 64;  B: the NB consecutive 16-B chunks NB pt ... of each plane's tile
         const int64_t b_plane = (int64_t)a.N * a.K * 2;
-        // A: float4 #(pt & 7) of rows (pt >> 3) and (pt >> 3) + 64;  B: 16-B chunk pt of each plane's 8 KiB tile
-        const uint32_t oa0 = (uint32_t)(((int64_t)(pt >> 3) * a.lda + (pt & 7) * 4) * 4);
+        const uint32_t oa0 = (uint32_t)(((int64_t)(pt >> 2) * a.lda + (pt & 3) * 4) * 4);
         const uint32_t oa1 = oa0 + (uint32_t)(a.lda * 64 * 4);
-        const uint32_t ob = (uint32_t)pt * 16;
-        char* la = lds + (pt >> 3) * SPITCH + (pt & 7) * 8;
-        char* lb = lds + 3 * SPLANE + (pt >> 2) * SPITCH + (pt & 3) * 16;               // chunk c -> row c / 4, 16-B slot c % 4
+        const uint32_t ob = (uint32_t)pt * (16 * NB);
+        const int ar = pt >> 2, ac = pt & 3;
+        char* la0 = lds + simg(ar, ac >> 1) + (ac & 1) * 8;
+        char* la1 = lds + simg(ar + 64, ac >> 1) + (ac & 1) * 8;
+        // chunk c -> row c / 2, half c % 2
+        char* lb0 = lds + 3 * APL + (NB == 2 ? simg(pt, 0) : simg(pt >> 1, pt & 1));
+        char* lb1 = lds + 3 * APL + simg(pt, 1);
         TileWalk wl = w;                                    // load position (runs ahead of the store position w)
-        // register ring of 4 k-steps: three steps of loads are in flight while the fourth is split and
-        // stored (one step of A per CU in flight is 16 KiB per ~2 us of loaded HBM latency = 2 TB/s chip-wide)
-#define NPI_WDECL(S) f32x4r S##a0, S##a1; u32x4r S##b0, S##b1, S##b2
+        // Register ring of 4 k-steps: three steps of loads are in flight while the fourth is split and stored.
+        // The loads and their waits are written in assembly: hipcc's own vmcnt bookkeeping loses the ring at the
+        // loop back-edge (it drained to vmcnt(2..6) in one of the four steps) and parks address temporaries in
+        // ring registers.  global_load dst, v_off, s[base]: wave-uniform base, fixed per-thread offset.
+        // Loads are UNCONDITIONAL: past the last step the walk keeps pointing at a valid tile and the data is
+        // dropped (with `if (more) load` the number of loads in flight is not a compile-time fact).
+#define NPI_WDECL(S) f32x4r S##a0, S##a1; u32x4r S##b0, S##b1, S##b2, S##b3, S##b4, S##b5
         NPI_WDECL(r0); NPI_WDECL(r1); NPI_WDECL(r2); NPI_WDECL(r3);
-        // The loads and their waits are written in assembly: hipcc's own vmcnt bookkeeping loses the ring at
-        // the loop back-edge (it waited vmcnt(2..6) in one of the four steps) and parks address temporaries
-        // in ring registers.  global_load dst, v_off, s[base]: wave-uniform base, fixed per-thread offset.
 #define NPI_GL(dst, off, base, IMM)                                                                    \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(off), "s"(base) : "memory")
 #define NPI_WLOAD(S)                                                                                   \
     do {                                                                                               \
-        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.mt * 128 * a.lda + wl.kt * BK) * 4);      \
-        const char* gb0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * a.N + wl.nt * 128) * (BK * 2));    \
+        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.mt * 128 * a.lda + wl.kt * SK) * 4);      \
+        const char* gb0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * a.N + wl.nt * BN) * (SK * 2));     \
         const char* gb1 = uniform_ptr(gb0 + b_plane);                                                  \
         const char* gb2 = uniform_ptr(gb0 + 2 * b_plane);                                              \
         NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0);                                          \
         NPI_GL(S##b0, ob, gb0, 0); NPI_GL(S##b1, ob, gb1, 0); NPI_GL(S##b2, ob, gb2, 0);               \
+        if constexpr (NB == 2) {                                                                       \
+            NPI_GL(S##b3, ob, gb0, 16); NPI_GL(S##b4, ob, gb1, 16); NPI_GL(S##b5, ob, gb2, 16);        \
+        }                                                                                              \
         wl.next();                                                                                     \
     } while (0)
-        // wait until only the 15 loads of the three younger sets are in flight; the set is an in/out operand
-        // so that no use of it can be scheduled above the wait
+        // wait until only the loads of the three younger sets are in flight; the set is an in/out operand so
+        // that no use of it can be scheduled above the wait
 #define NPI_WWAIT(S)                                                                                   \
-        asm volatile("s_waitcnt vmcnt(15)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##b0), "+v"(S##b1), "+v"(S##b2) : : "memory")
+    do {                                                                                               \
+        if constexpr (NB == 2)                                                                         \
+            asm volatile("s_waitcnt vmcnt(24)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##b0), "+v"(S##b1), "+v"(S##b2), \
+                         "+v"(S##b3), "+v"(S##b4), "+v"(S##b5) : : "memory");                          \
+        else                                                                                           \
+            asm volatile("s_waitcnt vmcnt(15)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##b0), "+v"(S##b1), "+v"(S##b2) : : "memory"); \
+    } while (0)
 #define NPI_WSTORE(OFF, S)                                                                             \
     do {                                                                                               \
-        split3_store(S##a0, la + (OFF));                                                               \
-        split3_store(S##a1, la + (OFF) + 64 * SPITCH);                                                 \
-        *reinterpret_cast<u32x4r*>(lb + (OFF)) = S##b0;                                                \
-        *reinterpret_cast<u32x4r*>(lb + (OFF) + SPLANE) = S##b1;                                       \
-        *reinterpret_cast<u32x4r*>(lb + (OFF) + 2 * SPLANE) = S##b2;                                   \
+        split3_store(S##a0, la0 + (OFF), APL);                                                         \
+        split3_store(S##a1, la1 + (OFF), APL);                                                         \
+        *reinterpret_cast<u32x4r*>(lb0 + (OFF)) = S##b0;                                               \
+        *reinterpret_cast<u32x4r*>(lb0 + (OFF) + BPL) = S##b1;                                         \
+        *reinterpret_cast<u32x4r*>(lb0 + (OFF) + 2 * BPL) = S##b2;                                     \
+        if constexpr (NB == 2) {                                                                       \
+            *reinterpret_cast<u32x4r*>(lb1 + (OFF)) = S##b3;                                           \
+            *reinterpret_cast<u32x4r*>(lb1 + (OFF) + BPL) = S##b4;                                     \
+            *reinterpret_cast<u32x4r*>(lb1 + (OFF) + 2 * BPL) = S##b5;                                 \
+        }                                                                                              \
     } while (0)
         // one k-step: refill the set freed by the previous step, split + store set CUR
-#ifdef NPI_X_STAMP
-        unsigned long long pT0, pT1, pT2, pT3, pTw, pLoad = 0, pSplit = 0, pBar = 0, pSteps = 0, pWait = 0;
-#define NPI_WSTEP(OFF, CUR, FREE)                                                                      \
-        pT0 = __builtin_amdgcn_s_memtime();                                                            \
-        NPI_WLOAD(FREE);                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        pTw = __builtin_amdgcn_s_memtime();                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        NPI_WWAIT(CUR);                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        pT1 = __builtin_amdgcn_s_memtime();                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        NPI_WSTORE(OFF, CUR);                                                                          \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        pT2 = __builtin_amdgcn_s_memtime();                                                            \
-        __syncthreads();                                                                               \
-        pT3 = __builtin_amdgcn_s_memtime();                                                            \
-        pLoad += pTw - pT0; pWait += pT1 - pTw; pSplit += pT2 - pT1; pBar += pT3 - pT2; ++pSteps;                          \
-        w.next();                                                                                      \
-        if (!w.valid()) break
-#else
 #define NPI_WSTEP(OFF, CUR, FREE)                                                                      \
         NPI_WLOAD(FREE);                                                                               \
         NPI_WWAIT(CUR);                                                                                \
@@ -668,11 +677,6 @@ gemm_split_ws_kernel(SplitArgs a) {
         __syncthreads();                                                                               \
         w.next();                                                                                      \
         if (!w.valid()) break
-#endif
-        // Loads are UNCONDITIONAL: past the last step the walk keeps pointing at a valid tile and the data
-        // is dropped.  With `if (more) load` the number of loads in flight is not a compile-time fact, and
-        // hipcc must then wait for ALL younger loads (vmcnt(9..0)) before touching the oldest set -- the
-        // ring would hold one step, not three.
         NPI_WLOAD(r0);
         NPI_WLOAD(r1);
         NPI_WLOAD(r2);
@@ -686,9 +690,6 @@ gemm_split_ws_kernel(SplitArgs a) {
 #undef NPI_WDECL
 #undef NPI_WWAIT
 #undef NPI_GL
-#ifdef NPI_X_STAMP
-        if (a.dbg && blockIdx.x == 17 && t == 256) { a.dbg[0] = pLoad; a.dbg[1] = pSplit; a.dbg[2] = pBar; a.dbg[3] = pSteps; a.dbg[10] = pWait; }
-#endif
 #undef NPI_WLOAD
 #undef NPI_WSTORE
         return;
@@ -698,8 +699,11 @@ gemm_split_ws_kernel(SplitArgs a) {
     const int lane = t & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const char* fa = lds + (wm * 64 + li) * SPITCH + lh * 16;
-    const char* fb = lds + 3 * SPLANE + (wn * 64 + li) * SPITCH + lh * 16;
+    int offa[TM], offb[TN];                                 // byte offsets of this lane's fragments inside a plane image
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offa[i] = simg(wm * 64 + i * 32 + li, lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offb[j] = 3 * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -708,56 +712,34 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     int par = 0;
-#ifdef NPI_X_STAMP
-    unsigned long long cT0, cT1, cT2, cT3, cBar = 0, cMma = 0, cEpi = 0, cSteps = 0;
-    const unsigned long long cStart = __builtin_amdgcn_s_memtime(), rStart = __builtin_amdgcn_s_memrealtime();
-#endif
     while (w.valid()) {
-#ifdef NPI_X_STAMP
-        cT0 = __builtin_amdgcn_s_memtime();
-#endif
-        __syncthreads();                                    // buffer `par` holds this k-step
-#ifdef NPI_X_STAMP
-        cT1 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        const char* pa = fa + par * BUF;
-        const char* pb = fb + par * BUF;
+        __syncthreads();                                    // stage `par` holds this k-step
+        const char* st = lds + par * BUF;
+        bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 af[TM][3], bf[TN][3];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + offa[i] + p * APL);
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[i][p] = *reinterpret_cast<const bf16x8*>(pa + p * SPLANE + i * 32 * SPITCH + kb * 32);
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + offb[j] + p * BPL);
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bf[j][p] = *reinterpret_cast<const bf16x8*>(pb + p * SPLANE + j * 32 * SPITCH + kb * 32);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        }
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
         par ^= 1;
-#ifdef NPI_X_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        cT2 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (w.kt == nk - 1) {
-            store_tile<false, TM, TN>(a.C, a.ldc, a.M, a.N, w.mt * 128, w.nt * 128, wm, wn, li, lh, acc, a.ep);
+            store_tile<false, TM, TN>(a.C, a.ldc, a.M, a.N, w.mt * 128, w.nt * BN, wm, wn, li, lh, acc, a.ep);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -765,19 +747,8 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
         }
-#ifdef NPI_X_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        cT3 = __builtin_amdgcn_s_memtime();
-        cBar += cT1 - cT0; cMma += cT2 - cT1; cEpi += cT3 - cT2; ++cSteps;
-#endif
         w.next();
     }
-#ifdef NPI_X_STAMP
-    if (a.dbg && blockIdx.x == 17 && t == 0) {
-        a.dbg[4] = cBar; a.dbg[5] = cMma; a.dbg[6] = cEpi; a.dbg[7] = cSteps;
-        a.dbg[8] = __builtin_amdgcn_s_memtime() - cStart; a.dbg[9] = __builtin_amdgcn_s_memrealtime() - rStart;
-    }
-#endif
 }
 
 // 0 = exact f32 MFMA, 1 = 3-way bf16 split (fwd / bwd_data interior tiles; the default, NPI_GEMM_SPLIT=0 turns it off)
@@ -818,25 +789,13 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int
             return;
         }
         split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes);
-        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, fm, fn, nullptr};
-#ifdef NPI_X_STAMP
-        static unsigned long long* dbg = nullptr;
-        if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 16 * 8); }
-        (void)hipMemsetAsync(dbg, 0, 16 * 8, stream);
-        sa.dbg = dbg;
-#endif
-        {
-            const int64_t ntiles = (int64_t)fm * fn;
-            const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
-            gemm_split_ws_kernel<<<grid, WS_THREADS, 0, stream>>>(sa);
-#ifdef NPI_X_STAMP
-            unsigned long long h[16];
-            (void)hipStreamSynchronize(stream);
-            (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[stamp] producer: load-issue %llu vmwait %llu split+store %llu barrier %llu steps %llu | consumer: barrier %llu reads+mfma %llu epilogue %llu steps %llu | total %llu cyc, clock %.0f MHz\n",
-                    h[0], h[10], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9] ? 100.0 * h[8] / h[9] : 0.0);
-#endif
-        }
+        const bool wide_n = (a.N % 256 == 0);                // 128 x 256 tiles: each A element is split once
+        const int tn = wide_n ? a.N / 256 : fn;
+        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, fm, tn, nullptr};
+        const int64_t ntiles = (int64_t)fm * tn;
+        const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
+        if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
+        else        gemm_split_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(sa);
         (void)hipFreeAsync(planes, stream);
     } else if (fm > 0 && fn > 0) {
         GemmArgs f = a;
