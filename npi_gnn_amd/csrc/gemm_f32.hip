@@ -551,6 +551,47 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
     planes[2 * (int64_t)N * K + o] = (uint16_t)p2;
 }
 
+// Epilogue of the split kernel.  Its MFMAs are issued with the operands swapped (B fragment first), so an
+// accumulator tile is C^T: the lane owns ONE row of C (m = lane & 31) and its registers run along the
+// columns, n = 8 (q >> 2) + 4 (lane >> 5) + (q & 3): four consecutive columns per register quad, i.e.
+// 16-byte stores.  (With the natural orientation a lane owns a column and every store is 4 bytes; a wave
+// may have 64 stores in flight, so the 1 GB of C then drains at 64 x 256 B per write round trip per wave --
+// measured 0.45 ms of a 0.9 ms kernel.)
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
+                                             const f32x16 (&acc)[TM][TN], const Epilogue& ep) {
+    float4 bv[TN][4];
+    float rs[TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bv[j][g] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + nw + j * 32 + 8 * g + 4 * lh)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rs[i] = ep.rowscale ? ep.rowscale[mw + i * 32 + li] : 1.f;
+    const bool relu_on = ep.relu != 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float* __restrict__ crow = C + (int64_t)(mw + i * 32 + li) * ldc + nw + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = fmaf(acc[i][j][4 * g + 0], rs[i], bv[j][g].x);
+                v.y = fmaf(acc[i][j][4 * g + 1], rs[i], bv[j][g].y);
+                v.z = fmaf(acc[i][j][4 * g + 2], rs[i], bv[j][g].z);
+                v.w = fmaf(acc[i][j][4 * g + 3], rs[i], bv[j][g].w);
+                if (relu_on) {                               // keeps NaN, like torch.relu
+                    v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                    v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                }
+                *reinterpret_cast<float4*>(crow + j * 32 + 8 * g) = v;
+            }
+    }
+}
+
 struct SplitArgs {
     const float* A; int64_t lda;
     const uint16_t* Bp;      // [3][K/16][N][16]
@@ -558,7 +599,6 @@ struct SplitArgs {
     int M, N, K;
     Epilogue ep;
     int tiles_m, tiles_n;    // full 128 x (64 TN) tiles to cover
-    unsigned long long* dbg; // diagnostic builds (-DNPI_X_STAMP) only
 };
 
 constexpr int WS_THREADS = 512;
@@ -729,17 +769,18 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+                // B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][2], af[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
         par ^= 1;
         if (w.kt == nk - 1) {
-            store_tile<false, TM, TN>(a.C, a.ldc, a.M, a.N, w.mt * 128, w.nt * BN, wm, wn, li, lh, acc, a.ep);
+            store_tile_t<TM, TN>(a.C, a.ldc, w.mt * 128 + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc, a.ep);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -778,7 +819,8 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int
     const bool wide = wide_enabled && fast_ok && a.N >= 256 && a.M >= 128;
     const int bm = 128, bn = wide ? 256 : 128;
     const int fm = fast_ok ? a.M / bm : 0, fn = fast_ok ? a.N / bn : 0;    // full tiles
-    const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && g_gemm_mode != 0 && a.ep.colsum == nullptr;
+    const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && g_gemm_mode != 0 && a.ep.colsum == nullptr &&
+                       ((uintptr_t)a.C % 16 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
     if (fm > 0 && fn > 0 && split) {
         // stream-ordered scratch for the three bf16 planes of B (W is small: 3 * 2 * K * N bytes)
         uint16_t* planes = nullptr;
@@ -791,7 +833,7 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int
         split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes);
         const bool wide_n = (a.N % 256 == 0);                // 128 x 256 tiles: each A element is split once
         const int tn = wide_n ? a.N / 256 : fn;
-        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, fm, tn, nullptr};
+        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, fm, tn};
         const int64_t ntiles = (int64_t)fm * tn;
         const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
         if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
