@@ -1,4 +1,6 @@
-// Dense feature projection on the CDNA4 matrix cores, exact f32 (v_mfma_f32_32x32x2_f32).
+// Dense feature projection on the CDNA4 matrix cores: exact f32 (v_mfma_f32_32x32x2_f32) kernels, and -- for
+// fwd / bwd_data interior tiles, the default -- an f32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16
+// (second half of this file).
 //
 // Replaces `torch.matmul(aggr_out, self.weight) + self.bias` of PyG 1.4.2 SAGEConv.update /
 // GCNConv.forward (reached from reference src/classes.py:62,66,70) and its autograd backward
