@@ -245,6 +245,26 @@ int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int3
 int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
                          float* out, void* stream);
 
+/* Backward of the pooling layer (autograd of reference src/classes.py:63-72 in the train loop,
+ * src/train_with_twoDataset.PY:52-54).  x is the layer INPUT, perm/score the forward's results.
+ *   npi_topk_gather_bwd : per kept row i = perm[p]:  ds = <dxo[p], x[i]> (+ dscore_o[p], may be NULL),
+ *                         dz = ds (1 - score_i^2),  dx[i] = dxo[p] score_i + dz w / ||w||;  dx must be
+ *                         zero-filled by the caller (dropped rows get no gradient);  dzv[p] = dz,
+ *                         dzz[p] = dz * (x_i . w / ||w||) feed the weight gradient.
+ *   npi_topk_weight_grad: dw[f] = sum_p dzv[p] x[perm[p], f] / ||w|| - w[f] sum_p dzz[p] / ||w||^2
+ *                         (deterministic two-level sum; workspace f32).
+ *   npi_readout_max_mean_bwd: dx[i, c] = dout[g, F + c] / n_g + (i = first arg-max row of column c in graph g
+ *                         ? dout[g, c] : 0); `out` is the forward's [B, 2F] result. */
+int npi_topk_gather_bwd(const float* x, int64_t ldx, const float* score, const float* w, const int32_t* perm,
+                        int64_t n_out, int64_t F, const float* dxo, int64_t lddxo, const float* dscore_o,
+                        float* dx, int64_t lddx, float* dzv, float* dzz, void* stream);
+int64_t npi_topk_weight_grad_workspace_elems(int64_t n_out, int64_t F);
+int npi_topk_weight_grad(const float* x, int64_t ldx, const int32_t* perm, const float* dzv, const float* dzz,
+                         int64_t n_out, int64_t F, const float* w, float* dw, float* workspace,
+                         int64_t workspace_elems, void* stream);
+int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
+                             const float* out, const float* dout, float* dx, int64_t lddx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

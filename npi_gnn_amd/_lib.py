@@ -63,6 +63,10 @@ PROTOTYPES = {
     "npi_filter_adj_workspace_elems": (_I, [_I]),
     "npi_filter_adj": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "npi_readout_max_mean": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
+    "npi_topk_gather_bwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "npi_topk_weight_grad_workspace_elems": (_I, [_I, _I]),
+    "npi_topk_weight_grad": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "npi_readout_max_mean_bwd": (c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
 }
 
 _lib = None

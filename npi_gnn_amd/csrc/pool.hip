@@ -237,6 +237,99 @@ readout_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restri
     out[(int64_t)g * 2 * F + F + c] = sum / (float)max(e - b, 1);
 }
 
+
+// ---- backward of the gate x[perm] * score[perm] and of score = tanh(x.w / ||w||) --------------------
+// one wave per kept node p (row i = perm[p]):
+//   ds = <dxo[p], x[i]> (+ dscore_o[p]);  dz = ds (1 - s^2);  dx[i] = dxo[p] s + dz w / ||w||
+//   dzv[p] = dz,  dzz[p] = dz z  with z = <x[i], w> / ||w||   (inputs of the weight gradient)
+// rows that were not kept receive no gradient: dx must come in zero-filled.
+__global__ void __launch_bounds__(256)
+topk_gather_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ score,
+                       const float* __restrict__ w, const int32_t* __restrict__ perm, int n_out, int F,
+                       const float* __restrict__ dxo, int64_t lddxo, const float* __restrict__ dscore_o,
+                       float* __restrict__ dx, int64_t lddx, float* __restrict__ dzv, float* __restrict__ dzz) {
+    const int lane = lane_id();
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_out) return;
+    const int i = perm[p];
+    const float* __restrict__ xr = x + (int64_t)i * ldx;
+    const float* __restrict__ gr = dxo + (int64_t)p * lddxo;
+    float ds = 0.f, dot = 0.f, nn = 0.f;
+    for (int c = lane; c < F; c += WAVE) {
+        const float wc = w[c], xv = xr[c];
+        ds = fmaf(gr[c], xv, ds);
+        dot = fmaf(xv, wc, dot);
+        nn = fmaf(wc, wc, nn);
+    }
+    ds = wsum(ds);
+    dot = wsum(dot);
+    nn = wsum(nn);
+    const float inv_norm = 1.f / sqrtf(nn);
+    const float sc = score[i];
+    if (dscore_o) ds += dscore_o[p];
+    const float dz = ds * (1.f - sc * sc);
+    float* __restrict__ dr = dx + (int64_t)i * lddx;
+    for (int c = lane; c < F; c += WAVE) dr[c] = fmaf(gr[c], sc, dz * w[c] * inv_norm);
+    if (lane == 0) {
+        dzv[p] = dz;
+        dzz[p] = dz * dot * inv_norm;
+    }
+}
+
+// dw partials over chunks of POOLW_ROWS kept nodes: part[chunk][f] = sum_p dzv[p] x[perm[p], f]; part[chunk][F] = sum_p dzz[p]
+constexpr int POOLW_ROWS = 256;
+__global__ void __launch_bounds__(256)
+topk_weight_grad_partial_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ perm,
+                                const float* __restrict__ dzv, const float* __restrict__ dzz, int n_out, int F,
+                                float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c > F) return;                                 // column F carries the scalar sum
+    const int pb = blockIdx.y * POOLW_ROWS, pe = min(n_out, pb + POOLW_ROWS);
+    float s = 0.f;
+    if (c < F) {
+        for (int p = pb; p < pe; ++p) s = fmaf(dzv[p], x[(int64_t)perm[p] * ldx + c], s);
+    } else {
+        for (int p = pb; p < pe; ++p) s += dzz[p];
+    }
+    part[(int64_t)blockIdx.y * (F + 1) + c] = s;
+}
+// dw[f] = (sum_chunks part[.][f]) / ||w|| - w[f] (sum_chunks part[.][F]) / ||w||^2, chunks in ascending order
+__global__ void __launch_bounds__(256)
+topk_weight_grad_reduce_kernel(const float* __restrict__ part, int nchunks, const float* __restrict__ w, int F,
+                               float* __restrict__ dw) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    float nn = 0.f;
+    for (int k = 0; k < F; ++k) nn = fmaf(w[k], w[k], nn);
+    float s = 0.f, z = 0.f;
+    for (int q = 0; q < nchunks; ++q) {
+        s += part[(int64_t)q * (F + 1) + c];
+        z += part[(int64_t)q * (F + 1) + F];
+    }
+    dw[c] = s / sqrtf(nn) - w[c] * z / nn;
+}
+
+// backward of [max || mean]: dx[i, c] = dout[g, F + c] / n_g + (i is the FIRST row of graph g with x = max ? dout[g, c] : 0)
+// (a single arg-max row takes the gradient, as torch_scatter's scatter_max backward does)
+__global__ void __launch_bounds__(256)
+readout_bwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ graph_ptr, int B, int F,
+                   const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dx, int64_t lddx) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    const int b = graph_ptr[g], e = graph_ptr[g + 1];
+    if (e <= b) return;
+    const float mx = out[(int64_t)g * 2 * F + c];
+    const float dmx = dout[(int64_t)g * 2 * F + c];
+    const float dmean = dout[(int64_t)g * 2 * F + F + c] / (float)(e - b);
+    bool found = false;
+    for (int i = b; i < e; ++i) {
+        const bool take = !found && x[(int64_t)i * ldx + c] == mx;
+        found = found || take;
+        dx[(int64_t)i * lddx + c] = dmean + (take ? dmx : 0.f);
+    }
+}
+
 __global__ void fill_i32_pool_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -318,4 +411,48 @@ extern "C" int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* 
     NPI_REQUIRE(x && graph_ptr && out, "npi_readout_max_mean: null pointer");
     readout_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)B), 256, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, out);
     return check_launch("npi_readout_max_mean");
+}
+
+extern "C" int npi_topk_gather_bwd(const float* x, int64_t ldx, const float* score, const float* w, const int32_t* perm,
+                                   int64_t n_out, int64_t F, const float* dxo, int64_t lddxo, const float* dscore_o,
+                                   float* dx, int64_t lddx, float* dzv, float* dzz, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(n_out >= 0 && F > 0 && n_out < 0x7fffffff, "npi_topk_gather_bwd: bad size");
+    if (n_out == 0) return NPI_OK;
+    NPI_REQUIRE(x && score && w && perm && dxo && dx && dzv && dzz, "npi_topk_gather_bwd: null pointer");
+    topk_gather_bwd_kernel<<<(unsigned)ceil_div(n_out, 4), 256, 0, stream>>>(x, ldx, score, w, perm, (int)n_out, (int)F, dxo,
+                                                                              lddxo, dscore_o, dx, lddx, dzv, dzz);
+    return check_launch("npi_topk_gather_bwd");
+}
+
+extern "C" int64_t npi_topk_weight_grad_workspace_elems(int64_t n_out, int64_t F) {
+    return ceil_div(n_out > 0 ? n_out : 1, POOLW_ROWS) * (F + 1);
+}
+
+extern "C" int npi_topk_weight_grad(const float* x, int64_t ldx, const int32_t* perm, const float* dzv, const float* dzz,
+                                    int64_t n_out, int64_t F, const float* w, float* dw, float* workspace,
+                                    int64_t workspace_elems, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(n_out >= 0 && F > 0 && n_out < 0x7fffffff, "npi_topk_weight_grad: bad size");
+    NPI_REQUIRE(x && perm && dzv && dzz && w && dw && workspace, "npi_topk_weight_grad: null pointer");
+    if (workspace_elems < npi_topk_weight_grad_workspace_elems(n_out, F)) {
+        set_error("npi_topk_weight_grad: workspace too small");
+        return NPI_ERR_WORKSPACE;
+    }
+    const int nchunks = (int)ceil_div(n_out > 0 ? n_out : 1, POOLW_ROWS);
+    topk_weight_grad_partial_kernel<<<dim3((unsigned)ceil_div(F + 1, 256), (unsigned)nchunks), 256, 0, stream>>>(
+        x, ldx, perm, dzv, dzz, (int)n_out, (int)F, workspace);
+    topk_weight_grad_reduce_kernel<<<(unsigned)ceil_div(F, 256), 256, 0, stream>>>(workspace, nchunks, w, (int)F, dw);
+    return check_launch("npi_topk_weight_grad");
+}
+
+extern "C" int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
+                                        const float* out, const float* dout, float* dx, int64_t lddx, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(B >= 0 && F > 0, "npi_readout_max_mean_bwd: bad size");
+    if (B == 0) return NPI_OK;
+    NPI_REQUIRE(x && graph_ptr && out && dout && dx, "npi_readout_max_mean_bwd: null pointer");
+    readout_bwd_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)B), 256, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, out,
+                                                                                          dout, dx, lddx);
+    return check_launch("npi_readout_max_mean_bwd");
 }

@@ -1,11 +1,14 @@
-"""Between-layer steps of the reference's ``Net_1`` on MI355X, forward only (inference):
-PyG 1.4.2 ``TopKPooling(in_channels, ratio)`` and ``global_max_pool`` / ``global_mean_pool``
-(reference ``src/classes.py:49,51,53,63-64,67-68,71-72``).
+"""Between-layer steps of the reference's ``Net_1`` on MI355X: PyG 1.4.2
+``TopKPooling(in_channels, ratio)`` and ``global_max_pool`` / ``global_mean_pool``
+(reference ``src/classes.py:49,51,53,63-64,67-68,71-72``), forward and
+backward.
 
-With these and ``npi_gnn_amd.nn.SAGEConv`` the whole ``Net_1`` forward (``src/classes.py:59-82``) is
-GPU-resident for the evaluation / case-study flows (``src/methods.py:87-96``, ``src/test.py``,
-``src/case_study*.py``).  Training THROUGH the pooling layer (its backward) is not implemented:
-in ``train()`` mode the module raises; in ``eval()`` mode the output is detached.
+With these and ``npi_gnn_amd.nn.SAGEConv`` the whole ``Net_1`` (``src/classes.py:59-82``) is
+GPU-resident for the train loop (``src/train_with_twoDataset.PY:52-54``) and for the evaluation /
+case-study flows (``src/methods.py:87-96``, ``src/test.py``, ``src/case_study*.py``).  Gradients flow
+to the layer input (kept rows only, as in PyG: the selection itself is not differentiable), to
+``TopKPooling.weight`` and through ``[max || mean]``; ``edge_index`` / ``batch`` / ``perm`` are index
+outputs.
 """
 from __future__ import annotations
 
@@ -37,9 +40,9 @@ def graph_ptr(batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Te
     return gp
 
 
-def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, weight: torch.Tensor,
-              ratio: float = 0.5, num_graphs: Optional[int] = None):
-    """``TopKPooling.forward`` -> ``(x', edge_index', None, batch', perm, score[perm])``."""
+def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, weight: torch.Tensor,
+                   ratio: float = 0.5, num_graphs: Optional[int] = None):
+    """forward kernels; returns the public tuple plus (score [N], perm int32 [n_out]) for the backward"""
     lib = load()
     dev = require_gpu(x, edge_index, batch, weight)
     x = _f32(x.detach())
@@ -74,11 +77,57 @@ def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, we
     check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
           "npi_filter_adj")
     e_out = int(count.item())
-    return xo, out_ei[:, :e_out].contiguous(), None, batch_o, perm[:n_out].long(), score_o
+    return (xo, out_ei[:, :e_out].contiguous(), None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
 
 
-def global_max_mean_pool(x: torch.Tensor, batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Tensor:
-    """``cat([global_max_pool(x, batch), global_mean_pool(x, batch)], dim=1)`` -> ``[B, 2F]``."""
+class _TopKPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, edge_index, batch, ratio, num_graphs):
+        (xo, ei_o, _, batch_o, perm, score_o), (score, perm32) = _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)
+        ctx.save_for_backward(x.detach(), weight.detach(), score, perm32)
+        ctx.mark_non_differentiable(ei_o, batch_o, perm)
+        return xo, score_o, ei_o, batch_o, perm
+
+    @staticmethod
+    def backward(ctx, dxo, dscore_o, *_unused):
+        x, weight, score, perm = ctx.saved_tensors
+        lib = load()
+        dev = x.device
+        x = _f32(x)
+        w = _f32(weight.reshape(-1))
+        N, F = x.shape
+        n_out = perm.numel()
+        st = stream_ptr(dev)
+        dxo = _f32(dxo) if dxo is not None else torch.zeros((n_out, F), dtype=torch.float32, device=dev)
+        dso = _f32(dscore_o) if dscore_o is not None else None
+        dx = torch.zeros((N, F), dtype=torch.float32, device=dev)          # dropped rows get no gradient
+        dzv = torch.empty(max(n_out, 1), dtype=torch.float32, device=dev)
+        dzz = torch.empty(max(n_out, 1), dtype=torch.float32, device=dev)
+        check(lib.npi_topk_gather_bwd(ptr(x), x.stride(0), ptr(score), ptr(w), ptr(perm), n_out, F, ptr(dxo),
+                                      dxo.stride(0), ptr(dso), ptr(dx), dx.stride(0), ptr(dzv), ptr(dzz), st),
+              "npi_topk_gather_bwd")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(F, dtype=torch.float32, device=dev)
+            n_ws = int(lib.npi_topk_weight_grad_workspace_elems(n_out, F))
+            ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            check(lib.npi_topk_weight_grad(ptr(x), x.stride(0), ptr(perm), ptr(dzv), ptr(dzz), n_out, F, ptr(w), ptr(dw),
+                                           ptr(ws), n_ws, st), "npi_topk_weight_grad")
+            dw = dw.view_as(weight)
+        return (dx if ctx.needs_input_grad[0] else None), dw, None, None, None, None
+
+
+def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, weight: torch.Tensor,
+              ratio: float = 0.5, num_graphs: Optional[int] = None):
+    """``TopKPooling.forward`` -> ``(x', edge_index', None, batch', perm, score[perm])``; differentiable in
+    ``x`` and ``weight``."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        xo, score_o, ei_o, batch_o, perm = _TopKPoolFn.apply(x, weight, edge_index, batch, ratio, num_graphs)
+        return xo, ei_o, None, batch_o, perm, score_o
+    return _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)[0]
+
+
+def _readout_fwd(x: torch.Tensor, batch: torch.Tensor, num_graphs: Optional[int]):
     dev = require_gpu(x, batch)
     x = _f32(x.detach())
     gp = graph_ptr(batch, num_graphs)
@@ -86,7 +135,33 @@ def global_max_mean_pool(x: torch.Tensor, batch: torch.Tensor, num_graphs: Optio
     out = torch.empty((B, 2 * F), dtype=torch.float32, device=dev)
     check(load().npi_readout_max_mean(ptr(x), x.stride(0), ptr(gp), B, F, ptr(out), stream_ptr(dev)),
           "npi_readout_max_mean")
-    return out
+    return out, x, gp
+
+
+class _ReadoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, batch, num_graphs):
+        out, xc, gp = _readout_fwd(x, batch, num_graphs)
+        ctx.save_for_backward(xc, gp, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gp, out = ctx.saved_tensors
+        dev = x.device
+        dout = _f32(dout)
+        B, F = gp.numel() - 1, x.size(1)
+        dx = torch.zeros_like(x)                                           # rows outside every graph (none in PyG batches)
+        check(load().npi_readout_max_mean_bwd(ptr(x), x.stride(0), ptr(gp), B, F, ptr(out), ptr(dout), ptr(dx),
+                                              dx.stride(0), stream_ptr(dev)), "npi_readout_max_mean_bwd")
+        return dx, None, None
+
+
+def global_max_mean_pool(x: torch.Tensor, batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Tensor:
+    """``cat([global_max_pool(x, batch), global_mean_pool(x, batch)], dim=1)`` -> ``[B, 2F]``; differentiable in ``x``."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _ReadoutFn.apply(x, batch, num_graphs)
+    return _readout_fwd(x, batch, num_graphs)[0]
 
 
 def global_max_pool(x, batch, size=None):
@@ -112,9 +187,6 @@ class TopKPooling(nn.Module):
         self.weight.data.uniform_(-bound, bound)
 
     def forward(self, x, edge_index, edge_attr=None, batch=None):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("TopKPooling on MI355X is forward-only (call model.eval()); the backward "
-                                      "through the pooling layer is not implemented")
         if edge_attr is not None:
             raise NotImplementedError("TopKPooling: edge_attr is not used by NPI-GNN")
         if batch is None:

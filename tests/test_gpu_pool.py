@@ -30,6 +30,7 @@ class Net1(torch.nn.Module):
         self.lin1 = torch.nn.Linear(256, 128)
         self.lin2 = torch.nn.Linear(128, 64)
         self.lin3 = torch.nn.Linear(64, num_of_classes)
+        self.dropout_p = 0.5
 
     def forward(self, x, edge_index, batch):
         acc = None
@@ -39,7 +40,7 @@ class Net1(torch.nn.Module):
             r = torch.cat([NP.global_max_pool(x, batch), NP.global_mean_pool(x, batch)], dim=1)
             acc = r if acc is None else acc + r
         x = F.relu(self.lin1(acc))
-        x = F.dropout(x, p=0.5, training=self.training)
+        x = F.dropout(x, p=self.dropout_p, training=self.training)
         x = F.relu(self.lin2(x))
         return F.log_softmax(self.lin3(x), dim=-1)
 
@@ -100,9 +101,85 @@ def test_whole_net1_on_gpu_reproduces_case_study_probabilities(dev):
     assert float(err) <= 1e-5
 
 
-def test_pooling_refuses_training_mode(dev):
-    pool = NP.TopKPooling(8).to(dev)
-    x = torch.randn(10, 8, device=dev, requires_grad=True)
-    ei = torch.randint(0, 10, (2, 20), device=dev)
-    with pytest.raises(NotImplementedError):
-        pool(x, ei, None, torch.zeros(10, dtype=torch.long, device=dev))
+def _batch_case(seed, sizes, F):
+    g = torch.Generator().manual_seed(seed)
+    batch = torch.cat([torch.full((n,), b, dtype=torch.long) for b, n in enumerate(sizes)])
+    N = batch.numel()
+    x = torch.randn(N, F, generator=g)
+    w = torch.randn(1, F, generator=g)
+    starts = torch.cumsum(torch.tensor([0] + list(sizes[:-1])), 0)
+    src, dst = [], []
+    for b, n in enumerate(sizes):
+        if n == 0:
+            continue
+        e = torch.randint(0, n, (2, 3 * n), generator=g) + starts[b]
+        src.append(e[0]); dst.append(e[1])
+    ei = torch.stack([torch.cat(src), torch.cat(dst)])
+    return x, ei, batch, w
+
+
+@pytest.mark.parametrize("sizes,F", [((7, 1, 30, 2, 65), 128), ((300, 5), 64), ((40,), 178)])
+def test_topk_pool_backward_matches_oracle_autograd(dev, sizes, F):
+    x, ei, batch, w = _batch_case(11, sizes, F)
+    g = torch.Generator().manual_seed(5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xo, eo, bo, perm, sc = R.topk_pool(xr, ei, batch, wr, 0.5)
+    go, gs = torch.randn(xo.shape, generator=g), torch.randn(sc.shape, generator=g)
+    (xo * go).sum().add((sc * gs).sum()).backward()
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    gx, ge, _, gb, gperm, gsc = NP.topk_pool(xg, ei.to(dev), batch.to(dev), wg, 0.5)
+    assert torch.equal(gperm.cpu(), perm)
+    ((gx * go.to(dev)).sum() + (gsc * gs.to(dev)).sum()).backward()
+    assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(wg.grad.cpu(), wr.grad, atol=1e-4, rtol=1e-4)
+    dropped = torch.ones(x.size(0), dtype=torch.bool)
+    dropped[perm] = False
+    assert float(xg.grad.cpu()[dropped].abs().max()) == 0.0          # the selection is not differentiable
+
+
+def test_readout_backward_matches_oracle_autograd(dev):
+    x, ei, batch, w = _batch_case(3, (9, 1, 33, 120), 128)
+    nb = 4
+    xr = x.clone().requires_grad_(True)
+    go = torch.randn(nb, 256, generator=torch.Generator().manual_seed(1))
+    (R.readout(xr, batch, nb) * go).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    (NP.global_max_mean_pool(xg, batch.to(dev), nb) * go.to(dev)).sum().backward()
+    assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-5)
+    # the two halves as the reference calls them (gmp, gap): gradients add up
+    xg2 = x.to(dev).requires_grad_(True)
+    r = torch.cat([NP.global_max_pool(xg2, batch.to(dev), nb), NP.global_mean_pool(xg2, batch.to(dev), nb)], dim=1)
+    (r * go.to(dev)).sum().backward()
+    assert torch.allclose(xg2.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-5)
+
+
+def test_net1_training_step_gradients_match_oracle(dev):
+    """One step of the reference's train loop (src/train_with_twoDataset.PY:49-55: nll_loss on the
+    log-softmax output, backward) on the RPI369 fold-0 batch with the reference checkpoint: every
+    parameter gradient of Net_1 -- convs, TopKPooling weights, MLP -- from the MI355X path against
+    autograd through the oracle."""
+    fx = load("rpi369_fold0.pt")
+    y = fx["y"].long()
+    sd = {k: v.clone().requires_grad_(True) for k, v in fx["state_dict"].items()}
+    logp_ref = R.net1_forward(sd, fx["x"], fx["edge_index"], fx["batch"], y.numel())
+    loss_ref = F.nll_loss(logp_ref, y)
+    loss_ref.backward()
+    model = Net1(fx["x"].size(1)).to(dev)
+    model.load_state_dict({k: v.to(dev) for k, v in fx["state_dict"].items()})
+    model.train()
+    model.dropout_p = 0.0                                     # the oracle restates the eval-mode wiring (no dropout)
+    logp = model(fx["x"].to(dev), fx["edge_index"].to(dev), fx["batch"].to(dev))
+    loss = F.nll_loss(logp, y.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
+    for name, prm in model.named_parameters():
+        ref = sd[name].grad
+        assert prm.grad is not None, name
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((prm.grad.cpu() - ref).abs().max()) / scale
+        assert err < 2e-4, (name, err, scale)
+    # and an optimiser step moves the pooling weights too
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    before = model.pool1.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, model.pool1.weight.detach())
