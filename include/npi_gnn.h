@@ -265,6 +265,27 @@ int npi_topk_weight_grad(const float* x, int64_t ldx, const int32_t* perm, const
 int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
                              const float* out, const float* dout, float* dx, int64_t lddx, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * One-hop enclosing-subgraph extraction + PyG Batch collate.  Replaces the
+ * per-sample Python loops of local_subgraph_generation (reference src/classes.py:652-733) and the
+ * DataLoader collate in front of Net_1.  Interaction graph = CSR over node serial numbers:
+ * ptr[N+1], nbr[nnz] partners in interaction_list order (npi_csr_build keeps it), ok[nnz] = pair usable
+ * (not in set_allInteractionKey_cannotUse, src/generate_dataset.py:296-299).  keys[B][2] = (rna, protein)
+ * targets.  Local node order of a sample: rna, protein, usable partners of the rna, then of the protein;
+ * pairs: target first, then in that same order, each in both directions ((rna, protein) first).
+ *   npi_subgraph_sizes   : node_off[B+1], pair_off[B+1] (exclusive prefix sums; directed edges = 2 pairs);
+ *                          workspace int32[2B]
+ *   npi_subgraph_fill    : node_id[n], batch[n] (int64), edge_src/edge_dst[2 * pairs] (int64, batch-global ids)
+ *   npi_subgraph_features: x[row] = [row is a target ? 0 : 1 | feat[node_id[row]][0..Ff)]
+ * ------------------------------------------------------------------------------------------ */
+int npi_subgraph_sizes(const int32_t* ptr, const int32_t* nbr, const uint8_t* ok, const int32_t* keys, int64_t B,
+                       int32_t* node_off, int32_t* pair_off, int32_t* workspace, void* stream);
+int npi_subgraph_fill(const int32_t* ptr, const int32_t* nbr, const uint8_t* ok, const int32_t* keys, int64_t B,
+                      const int32_t* node_off, const int32_t* pair_off, int32_t* node_id, int64_t* batch,
+                      int64_t* edge_src, int64_t* edge_dst, void* stream);
+int npi_subgraph_features(const float* feat, int64_t ldf, int64_t Ff, const int32_t* node_id, const int64_t* batch,
+                          const int32_t* node_off, int64_t n, float* x, int64_t ldx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

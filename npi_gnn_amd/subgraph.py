@@ -1,0 +1,87 @@
+"""One-hop enclosing subgraphs, extracted and collated on the MI355X.
+
+The reference builds every sample with per-node Python dict / set loops at dataset-build time
+(``local_subgraph_generation``, reference ``src/classes.py:652-733``) and collates 200 of them per
+step through the PyG ``DataLoader``.  ``InteractionGraph.batch(keys)`` produces the same batch --
+``x [n, 1 + F]`` (structural label | node2vec | k-mer), ``edge_index [2, e]`` int64, ``batch [n]`` --
+for any list of target pairs directly in HBM, ready for ``Net_1`` (wire format of SURVEY.md 8(f)-3).
+
+Node order and features are bit-identical to the reference's; the edges are the same set, emitted
+in list order (target pair, pairs of the RNA, pairs of the protein) instead of the reference's
+Python-``set`` iteration order, which is a CPython hashing detail.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, load, ptr, require_gpu, stream_ptr
+from .graph import build_side
+
+
+class InteractionGraph:
+    """The whole ncRNA-protein interaction graph of one project/fold, resident on the GPU.
+
+    ``pairs [P, 2]``: (rna_serial, protein_serial) in ``interaction_list`` order (positives, then
+    negatives; reference ``src/generate_dataset.py:224-305``).  ``usable [P]``: False for the pairs in
+    ``set_allInteractionKey_cannotUse`` (the fold's test keys, ``:296-299``).  ``feat [N, F]``: node
+    features by serial number.  Pairs must be unique and rna / protein serials disjoint.
+    """
+
+    def __init__(self, pairs: torch.Tensor, usable: torch.Tensor, feat: torch.Tensor, num_nodes: Optional[int] = None,
+                 check_input: bool = True):
+        dev = require_gpu(pairs, usable, feat)
+        if feat.dtype != torch.float32:
+            raise TypeError("feat must be float32")
+        pairs = pairs.to(torch.int64)
+        P = pairs.size(0)
+        self.num_nodes = N = int(num_nodes) if num_nodes is not None else feat.size(0)
+        if feat.size(0) < N:
+            raise ValueError("feat has fewer rows than num_nodes")
+        if check_input and P:
+            code = pairs[:, 0] * N + pairs[:, 1]
+            if torch.unique(code).numel() != P:
+                raise ValueError("InteractionGraph: duplicate (rna, protein) pairs")
+            is_rna = torch.zeros(N, dtype=torch.bool, device=dev)
+            is_rna[pairs[:, 0]] = True
+            if bool(is_rna[pairs[:, 1]].any()):
+                raise ValueError("InteractionGraph: a serial number is used both as rna and as protein")
+        # CSR over serial numbers; the builder's stable sort keeps interaction_list order inside a row
+        key = torch.cat([pairs[:, 0], pairs[:, 1]]).contiguous()
+        val = torch.cat([pairs[:, 1], pairs[:, 0]]).contiguous()
+        side = build_side(key, val, N, N, False, 0, False)
+        self.ptr, self.nbr = side.rowptr, side.col
+        eid = side.eid[: 2 * P].to(torch.int64)
+        self.ok = usable.to(device=dev, dtype=torch.bool)[eid % P].to(torch.uint8).contiguous() if P else \
+            torch.zeros(1, dtype=torch.uint8, device=dev)
+        self.feat = feat.contiguous()
+        self.device = dev
+
+    def batch(self, keys: torch.Tensor, return_node_id: bool = False):
+        """``keys [B, 2]`` (rna_serial, protein_serial) -> ``x, edge_index, batch`` of the B enclosing subgraphs."""
+        lib = load()
+        dev = self.device
+        keys = keys.to(device=dev, dtype=torch.int32).contiguous()
+        B = keys.size(0)
+        st = stream_ptr(dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        node_off = torch.empty(B + 1, **i32)
+        pair_off = torch.empty(B + 1, **i32)
+        ws = torch.empty(max(2 * B, 1), **i32)
+        check(lib.npi_subgraph_sizes(ptr(self.ptr), ptr(self.nbr), ptr(self.ok), ptr(keys), B, ptr(node_off), ptr(pair_off),
+                                     ptr(ws), st), "npi_subgraph_sizes")
+        # output sizes are data dependent: one device read per batch
+        n, npairs = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
+        Ff = self.feat.size(1)
+        node_id = torch.empty(max(n, 1), **i32)
+        bvec = torch.empty(n, dtype=torch.int64, device=dev)
+        ei = torch.empty((2, 2 * npairs), dtype=torch.int64, device=dev)
+        x = torch.empty((n, 1 + Ff), dtype=torch.float32, device=dev)
+        check(lib.npi_subgraph_fill(ptr(self.ptr), ptr(self.nbr), ptr(self.ok), ptr(keys), B, ptr(node_off), ptr(pair_off),
+                                    ptr(node_id), ptr(bvec), ptr(ei[0]), ptr(ei[1]), st), "npi_subgraph_fill")
+        check(lib.npi_subgraph_features(ptr(self.feat), self.feat.stride(0), Ff, ptr(node_id), ptr(bvec), ptr(node_off), n,
+                                        ptr(x), x.stride(0), st), "npi_subgraph_features")
+        if return_node_id:
+            return x, ei, bvec, node_id[:n]
+        return x, ei, bvec

@@ -103,6 +103,43 @@ def main():
     t_cpu = timeit(lambda: R.net1_forward(sd, x, ei, batch, 200), 5)
     print(f"Net_1 inference per batch: GPU {t_gpu:.3f} ms   CPU oracle {t_cpu:.1f} ms")
 
+    # whole Net_1 TRAINING step (reference src/train_with_twoDataset.PY:49-55: forward, nll_loss, backward, Adam)
+    y = torch.randint(0, 2, (200,))
+    yd = y.to(dev)
+
+    def net1(sdict, xx, ee, bb, gpu):
+        h, e, acc = xx, ee, None
+        for k in (1, 2, 3):
+            if gpu:
+                h = F.relu(npi.sage_conv(h, e, sdict[f"conv{k}.weight"], sdict[f"conv{k}.bias"]))
+                h, e, _, bb, _, _ = NP.topk_pool(h, e, bb, sdict[f"pool{k}.weight"], 0.5, num_graphs=200)
+                r = NP.global_max_mean_pool(h, bb, 200)
+            else:
+                h = F.relu(R.sage_conv(h, e, sdict[f"conv{k}.weight"], sdict[f"conv{k}.bias"]))
+                h, e, bb, _, _ = R.topk_pool(h, e, bb, sdict[f"pool{k}.weight"], 0.5)
+                r = R.readout(h, bb, 200)
+            acc = r if acc is None else acc + r
+        z = F.relu(F.linear(acc, sdict["lin1.weight"], sdict["lin1.bias"]))
+        z = F.relu(F.linear(z, sdict["lin2.weight"], sdict["lin2.bias"]))
+        return F.log_softmax(F.linear(z, sdict["lin3.weight"], sdict["lin3.bias"]), -1)
+
+    pg = {k: v.clone().requires_grad_(True) for k, v in sdd.items()}
+    pc = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    og, oc = torch.optim.Adam(pg.values(), lr=1e-3), torch.optim.Adam(pc.values(), lr=1e-3)
+
+    def gpu_train():
+        og.zero_grad(set_to_none=True)
+        F.nll_loss(net1(pg, xd.detach(), eid, bd, True), yd).backward()
+        og.step()
+
+    def cpu_train():
+        oc.zero_grad(set_to_none=True)
+        F.nll_loss(net1(pc, x, ei, batch, False), y).backward()
+        oc.step()
+    t_gpu = timeit(gpu_train, 30, torch.cuda.synchronize)
+    t_cpu = timeit(cpu_train, 5)
+    print(f"Net_1 training step per batch (fwd + loss + bwd + Adam): GPU {t_gpu:.3f} ms   CPU oracle {t_cpu:.1f} ms")
+
 
 if __name__ == "__main__":
     main()
