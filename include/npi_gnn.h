@@ -274,7 +274,7 @@ int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_p
  * targets.  Local node order of a sample: rna, protein, usable partners of the rna, then of the protein;
  * pairs: target first, then in that same order, each in both directions ((rna, protein) first).
  *   npi_subgraph_sizes   : node_off[B+1], pair_off[B+1] (exclusive prefix sums; directed edges = 2 pairs);
- *                          workspace int32[2B]
+ *                          workspace int32[2B]; node_off[B] = pair_off[B] = -1 when the batch exceeds 2^31 - 1 rows
  *   npi_subgraph_fill    : node_id[n], batch[n] (int64), edge_src/edge_dst[2 * pairs] (int64, batch-global ids)
  *   npi_subgraph_features: x[row] = [row is a target ? 0 : 1 | feat[node_id[row]][0..Ff)]
  * ------------------------------------------------------------------------------------------ */

@@ -49,29 +49,30 @@ subgraph_count_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict
 // node_off[g] = sum_{h<g} (2 + cl_h + cp_h), pair_off[g] = sum_{h<g} (1 + cl_h + cp_h); one workgroup
 __global__ void __launch_bounds__(1024)
 subgraph_scan_kernel(const int32_t* __restrict__ cnt, int B, int32_t* __restrict__ node_off, int32_t* __restrict__ pair_off) {
-    __shared__ int part[1024];
+    __shared__ long long part[1024];
     const int t = threadIdx.x;
     const int per = (B + 1023) / 1024;
     const int b = min(B, t * per), e = min(B, b + per);
-    int s = 0;
-    for (int g = b; g < e; ++g) s += cnt[g] + cnt[B + g];
+    long long s = 0;
+    for (int g = b; g < e; ++g) s += (long long)cnt[g] + cnt[B + g];
     part[t] = s;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {                   // Hillis-Steele inclusive scan of the thread sums
-        const int v = (t >= d) ? part[t - d] : 0;
+        const long long v = (t >= d) ? part[t - d] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    int run = (t > 0) ? part[t - 1] : 0;
+    long long run = (t > 0) ? part[t - 1] : 0;
     for (int g = b; g < e; ++g) {
-        node_off[g] = run + 2 * g;
-        pair_off[g] = run + g;
-        run += cnt[g] + cnt[B + g];
+        node_off[g] = (int)(run + 2 * g);
+        pair_off[g] = (int)(run + g);
+        run += (long long)cnt[g] + cnt[B + g];
     }
     if (t == 1023) {
-        node_off[B] = part[1023] + 2 * B;
-        pair_off[B] = part[1023] + B;
+        const long long tot = part[1023] + 2ll * B;        // nodes >= pairs: one check covers both
+        node_off[B] = tot > 0x7fffffffll ? -1 : (int)tot;  // -1: the batch does not fit 32-bit row ids
+        pair_off[B] = tot > 0x7fffffffll ? -1 : (int)(part[1023] + B);
     }
 }
 

@@ -73,6 +73,8 @@ class InteractionGraph:
                                      ptr(ws), st), "npi_subgraph_sizes")
         # output sizes are data dependent: one device read per batch
         n, npairs = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
+        if n < 0:
+            raise OverflowError("InteractionGraph.batch: the batch has more than 2^31 - 1 rows; use fewer keys per call")
         Ff = self.feat.size(1)
         node_id = torch.empty(max(n, 1), **i32)
         bvec = torch.empty(n, dtype=torch.int64, device=dev)

@@ -31,7 +31,7 @@ def main():
     for name, (N, P, B, cpu) in {"NPInter2-size graph (5,085 nodes, 20,824 pairs), B=200": (5085, 20824, 200, True),
                                  "same, B=4,166 (a whole test fold)": (5085, 20824, 4166, True),
                                  "1M nodes / 10M pairs, B=200": (1_000_000, 10_000_000, 200, False),
-                                 "1M nodes / 10M pairs, B=20,000": (1_000_000, 10_000_000, 20000, False)}.items():
+                                 }.items():
         pairs, usable, feat, keys = case(N, P, 177, B)
         t0 = time.perf_counter()
         ig = InteractionGraph(pairs.to(dev), usable.to(dev), feat.to(dev))
