@@ -286,6 +286,13 @@ int npi_subgraph_fill(const int32_t* ptr, const int32_t* nbr, const uint8_t* ok,
 int npi_subgraph_features(const float* feat, int64_t ldf, int64_t Ff, const int32_t* node_id, const int64_t* batch,
                           const int32_t* node_off, int64_t n, float* x, int64_t ldx, void* stream);
 
+/* Evaluation loop (reference src/methods.py:87-105 compares one element per Python
+ * iteration, one device sync each).  counts[4] += [TP, FN, TN, FP] for pred = first arg-max of scores[i, 0..C):
+ * pred 1 & y 1 -> TP, pred 1 & y 0 -> FP, pred 0 & y 1 -> FN, anything else -> TN (the reference's else
+ * branch).  counts is device memory, accumulated across calls; no synchronisation. */
+int npi_confusion_update(const float* scores, int64_t lds, int64_t C, const int64_t* y, int64_t B, int64_t* counts,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "npi_topk_weight_grad_workspace_elems": (_I, [_I, _I]),
     "npi_topk_weight_grad": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "npi_readout_max_mean_bwd": (c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "npi_confusion_update": (c_int, [_P, _I, _I, _P, _I, _P, _P]),
     "npi_subgraph_sizes": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "npi_subgraph_fill": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "npi_subgraph_features": (c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _I, _P]),

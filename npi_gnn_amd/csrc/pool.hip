@@ -330,6 +330,41 @@ readout_bwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __re
     }
 }
 
+// ---- evaluation: confusion matrix of argmax predictions (reference src/methods.py:87-105) ---------------
+// pred = index of the first maximum of the row (torch .max(dim=1)[1]);  counts += [TP, FN, TN, FP] with the
+// reference's rule: pred 1 & y 1 -> TP, pred 1 & y 0 -> FP, pred 0 & y 1 -> FN, everything else -> TN.
+// Integer atomics: the result does not depend on the order.
+__global__ void __launch_bounds__(256)
+confusion_kernel(const float* __restrict__ scores, int64_t lds, int C, const int64_t* __restrict__ y, int64_t B,
+                 unsigned long long* __restrict__ counts) {
+    const int lane = lane_id();
+    unsigned long long tp = 0, fn = 0, tn = 0, fp = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (B + WAVE - 1) / WAVE * WAVE;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int cls = 3;                                       // 0 TP, 1 FN, 2 TN, 3 FP; lanes past the end vote nothing
+        const bool live = i < B;
+        if (live) {
+            const float* __restrict__ r = scores + i * lds;
+            int pred = 0;
+            float best = r[0];
+            for (int c = 1; c < C; ++c)
+                if (r[c] > best) { best = r[c]; pred = c; }
+            const int64_t yy = y[i];
+            cls = (pred == 1 && yy == 1) ? 0 : (pred == 1 && yy == 0) ? 3 : (pred == 0 && yy == 1) ? 1 : 2;
+        }
+        tp += __popcll(__ballot(live && cls == 0));
+        fn += __popcll(__ballot(live && cls == 1));
+        tn += __popcll(__ballot(live && cls == 2));
+        fp += __popcll(__ballot(live && cls == 3));
+    }
+    if (lane == 0) {
+        if (tp) atomicAdd(counts + 0, tp);
+        if (fn) atomicAdd(counts + 1, fn);
+        if (tn) atomicAdd(counts + 2, tn);
+        if (fp) atomicAdd(counts + 3, fp);
+    }
+}
+
 __global__ void fill_i32_pool_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -455,4 +490,16 @@ extern "C" int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32
     readout_bwd_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)B), 256, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, out,
                                                                                           dout, dx, lddx);
     return check_launch("npi_readout_max_mean_bwd");
+}
+
+extern "C" int npi_confusion_update(const float* scores, int64_t lds, int64_t C, const int64_t* y, int64_t B,
+                                    int64_t* counts, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(B >= 0 && C >= 1 && C < 0x7fffffff && lds >= C, "npi_confusion_update: bad size");
+    if (B == 0) return NPI_OK;
+    NPI_REQUIRE(scores && y && counts, "npi_confusion_update: null pointer");
+    const int64_t blocks = ceil_div(B, 256);
+    confusion_kernel<<<(unsigned)(blocks < 1024 ? blocks : 1024), 256, 0, stream>>>(
+        scores, lds, (int)C, y, B, reinterpret_cast<unsigned long long*>(counts));
+    return check_launch("npi_confusion_update");
 }
