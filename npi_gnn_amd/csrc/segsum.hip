@@ -21,6 +21,7 @@
 //   W_GAT_SRC  the same alpha seen from the by-source CSR (backward: d h_j = sum_i alpha_ij d out_i),
 //              plus the rank-1 terms of the attention-score gradient in the epilogue
 #include "segsum.h"
+#include <stdlib.h>
 
 namespace npi {
 
@@ -308,6 +309,120 @@ segsum_kernel(SegParams P) {
     }
 }
 
+// Narrow rows (F <= 32 VEC: hidden = 128 or 64 in f32, the reference's own model width): one row is only
+// half / a quarter of a wave instruction, so G = 2 or 4 ENTRIES are gathered per instruction -- lane group
+// g = lane / (64 / G) fetches entry G j + g -- and every group keeps its own partial sum of the open row.
+// Entries are still added in entry order (group 0, a possible row close, group 1, ...); at a row close
+// the G partials are folded across the lane groups (xor shuffles) and group 0 stores.  Same items, carry
+// format and fix-up kernel as the wide path; W_NONE / W_ARRAY only.
+template <typename T, int VEC, int G, int WMODE, bool MEAN>
+__global__ void __launch_bounds__(SEG_THREADS)
+segsum_group_kernel(SegParams P) {
+    constexpr int LG = WAVE / G;                           // lanes per entry group
+    constexpr int U = 8 / G < 2 ? 2 : 8 / G;               // wave instructions in flight (U * G rows)
+    const int lane = lane_id();
+    const int item = uniform_i(blockIdx.x * SEG_WAVES + (threadIdx.x >> 6));
+    if (item >= P.n_items) return;
+    const int N = P.N;
+    const int nnz = P.rowptr[N];
+    const int k0 = item * ITEM;
+    if (k0 >= nnz) return;
+    const int k1 = min(k0 + ITEM, nnz);
+    const int F = P.F;
+    const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
+    const int grp = lane / LG;
+    const int foff = (lane % LG) * VEC;
+    const bool act = foff < F;
+
+    int r = uniform_i(P.item_row[item]);
+    int row_start = uniform_i(P.rowptr[r]);
+    bool head = row_start < k0;
+    int rend_v = P.rowptr[min(r + 1 + lane, N)];
+    int ri = 0;
+    int row_end = bcast_i(rend_v, 0);
+
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+
+    auto fold = [&](float (&t)[VEC]) {                     // sum of the G group partials, in every lane
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float v = acc[q];
+#pragma unroll
+            for (int off = WAVE / 2; off >= LG; off >>= 1) v += __shfl_xor(v, off, WAVE);
+            t[q] = v;
+        }
+    };
+    auto close_row = [&]() {
+        float t[VEC];
+        fold(t);
+        if (head) {
+            if (act && grp == 0) store_row<VEC, float>(P.carry + ((int64_t)item * 2 + 0) * F + foff, t);
+            head = false;
+        } else if (act && grp == 0) {
+            const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
+            const float sc = MEAN ? 1.f / (float)max(row_end - row_start, 1) : 1.f;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) t[q] = fmaf(t[q], sc, bias ? to_f32(bias[foff + q]) : 0.f);
+            store_row<VEC, T>(reinterpret_cast<T*>(P.out) + (int64_t)r * P.ldo + foff, t);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        ++r;
+        row_start = row_end;
+        if (++ri == WAVE) {
+            rend_v = P.rowptr[min(r + 1 + lane, N)];
+            ri = 0;
+        }
+        row_end = bcast_i(rend_v, ri);
+    };
+
+    for (int kb = k0; kb < k1; kb += WAVE) {
+        const int nb = min(WAVE, k1 - kb);
+        const int cv = (lane < nb) ? P.col[kb + lane] : 0;
+        float wv = 1.f;
+        if (WMODE == W_ARRAY) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
+        for (int j = 0; j < nb; j += U * G) {
+            float v[U][VEC];
+            float we[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = j + u * G + grp;             // this lane group's entry of wave instruction u
+                const int cu = __shfl(cv, min(e, nb - 1), WAVE);
+                we[u] = (WMODE == W_ARRAY) ? __shfl(wv, min(e, nb - 1), WAVE) : 1.f;
+                if (act && e < nb) load_row<VEC, T>(xT + (int64_t)cu * P.ldx + foff, v[u]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int e = j + u * G + g;           // wave-uniform
+                    if (e >= nb) break;
+                    while (kb + e == row_end) close_row();
+                    if (grp == g) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q)
+                            acc[q] = (WMODE == W_NONE) ? (acc[q] + v[u][q]) : fmaf(we[u], v[u][q], acc[q]);
+                    }
+                }
+            }
+        }
+    }
+    if (row_end == k1) {
+        close_row();
+        while (r < N && row_end == k1) close_row();
+    } else {
+        float t[VEC];
+        fold(t);
+        if (act && grp == 0) store_row<VEC, float>(P.carry + ((int64_t)item * 2 + (head ? 0 : 1)) * F + foff, t);
+    }
+}
+
 // The item holding a cut row's FIRST entry sums that row's partials: one 4-wave workgroup per item.
 // Short chains (the common case: tail of item i + head of item i+1) are summed by wave 0; a long
 // chain (hub row: ~1,600 partials at C4) is split into 4 contiguous slices, one per wave, 8 loads
@@ -412,8 +527,29 @@ static void launch_one(const SegParams& P, hipStream_t stream) {
     segsum_fixup_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<dim3((unsigned)P.n_items), block, 0, stream>>>(P);   // one workgroup per item
 }
 
+template <typename T, int VEC, int G, int WMODE, bool MEAN>
+static void launch_group(const SegParams& P, hipStream_t stream) {
+    dim3 grid((unsigned)ceil_div(P.n_items, SEG_WAVES)), block(SEG_THREADS);
+    segsum_group_kernel<T, VEC, G, WMODE, MEAN><<<grid, block, 0, stream>>>(P);
+    segsum_fixup_kernel<T, VEC, 1, WMODE, MEAN, false><<<dim3((unsigned)P.n_items), block, 0, stream>>>(P);
+}
+template <typename T, int VEC, int G>
+static int launch_group_modes(const SegParams& P, int wmode, int mean, hipStream_t stream) {
+    if (wmode == W_NONE) { if (mean) launch_group<T, VEC, G, W_NONE, true>(P, stream); else launch_group<T, VEC, G, W_NONE, false>(P, stream); }
+    else                 { if (mean) launch_group<T, VEC, G, W_ARRAY, true>(P, stream); else launch_group<T, VEC, G, W_ARRAY, false>(P, stream); }
+    return check_launch("npi_segsum");
+}
+
 template <typename T, int VEC, int NCH, bool EXACT>
 static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t stream) {
+    if constexpr (NCH == 1 && !EXACT) {
+        // narrow rows: several entries per wave instruction (NPI_SEG_NARROW=0 keeps the one-entry kernel)
+        static const bool narrow_on = [] { const char* e = getenv("NPI_SEG_NARROW"); return !(e && e[0] == '0'); }();
+        if (narrow_on && wmode <= W_ARRAY) {
+            if (P.F <= 16 * VEC) return launch_group_modes<T, VEC, 4>(P, wmode, mean, stream);
+            if (P.F <= 32 * VEC) return launch_group_modes<T, VEC, 2>(P, wmode, mean, stream);
+        }
+    }
     if (wmode == W_NONE) { if (mean) launch_one<T, VEC, NCH, W_NONE, true, EXACT>(P, stream); else launch_one<T, VEC, NCH, W_NONE, false, EXACT>(P, stream); }
     else if (wmode == W_ARRAY) { if (mean) launch_one<T, VEC, NCH, W_ARRAY, true, EXACT>(P, stream); else launch_one<T, VEC, NCH, W_ARRAY, false, EXACT>(P, stream); }
     else if (wmode == W_GAT_DST) {

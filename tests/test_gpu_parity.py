@@ -104,8 +104,9 @@ def test_segsum_widths(dev, F, mean):
     assert torch.allclose(out_t, ref_t, atol=ATOL * (1 if mean else 30), rtol=RTOL)
 
 
-def test_segsum_empty_rows_and_no_self_loops(dev):
-    N, F = 2000, 256
+@pytest.mark.parametrize("F", [256, 128, 64, 20])            # 128 / 64 / 20: the several-entries-per-instruction kernel
+def test_segsum_empty_rows_and_no_self_loops(dev, F):
+    N = 2000
     ei = rand_edges(600, 3000, seed=3) + 700           # rows [0,700) and [1300,2000) are empty
     x = torch.randn(N, F)
     g = npi.CSRGraph(ei.to(dev), N, self_loops=False)
@@ -115,8 +116,9 @@ def test_segsum_empty_rows_and_no_self_loops(dev):
     assert float(out[:700].abs().max()) == 0.0 and float(out[1300:].abs().max()) == 0.0
 
 
-def test_segsum_weighted_and_bias(dev):
-    N, E, F = 900, 20000, 256
+@pytest.mark.parametrize("F", [256, 128, 64, 20])
+def test_segsum_weighted_and_bias(dev, F):
+    N, E = 900, 20000
     ei = rand_edges(N, E, seed=11, hub=17)
     x = torch.randn(N, F)
     g = npi.CSRGraph(ei.to(dev), N)
@@ -130,8 +132,9 @@ def test_segsum_weighted_and_bias(dev):
     assert torch.allclose(out, ref.float(), atol=2e-3, rtol=RTOL)
 
 
-def test_segsum_is_bitwise_reproducible(dev):
-    N, E, F = 3000, 100000, 256
+@pytest.mark.parametrize("F", [256, 128, 64])
+def test_segsum_is_bitwise_reproducible(dev, F):
+    N, E = 3000, 100000
     ei = rand_edges(N, E, seed=5, hub=1)
     x = torch.randn(N, F).to(dev)
     g = npi.CSRGraph(ei.to(dev), N)
