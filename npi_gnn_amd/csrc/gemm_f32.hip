@@ -802,8 +802,19 @@ static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4)
 }
 
 static int pick_splits(int64_t M, int64_t tiles) {
-    // dW: reduction over M (nodes).  Aim for ~4 tiles per CU, at least 8 k-steps each.
-    int64_t want = ceil_div(1024, tiles);
+    // dW: reduction over M (nodes).  About one workgroup per CU, at least 8 k-steps each.
+    // one workgroup per CU: as fast alone as 4 per CU (8.03 vs 8.01 ms per step at C4) and it leaves room for the
+    // backward aggregation to co-run on every CU (functional.py, OVERLAP_STREAMS); NPI_DW_CTAS overrides
+    static const int64_t ctas = [] {
+        const char* e = getenv("NPI_DW_CTAS");
+        long v = e ? atol(e) : 0;
+        if (v <= 0) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) v = cus;
+        }
+        return (int64_t)(v > 0 ? v : 256);
+    }();
+    int64_t want = ceil_div(ctas, tiles);
     int64_t maxs = ceil_div(M, (int64_t)BK * 8);
     int64_t s = want < maxs ? want : maxs;
     return (int)(s < 1 ? 1 : s);

@@ -20,8 +20,13 @@ from .graph import CSRGraph, CSRSide, as_graph
 
 _PROFILE = None     # bench.py sets this to a list to collect (start, end) events per segsum launch
 
-# measured at C4 (round 1): 8.82 -> 8.74 ms per step (both kernels fill the chip), so off by default
-OVERLAP_STREAMS = os.environ.get("NPI_OVERLAP_STREAMS", "0") != "0"
+# dW = agg^T dOut (MFMA-bound, launched as ONE workgroup per CU so that it leaves wave slots, LDS and
+# registers free) runs on a side stream under the dX chain, whose aggregation is HBM-bound: the two then
+# share every CU instead of queueing.  Measured at C4: 7.86 -> 7.34 ms per step.  (With the dW grid
+# filling the chip twice over, as before, the same overlap gained 1 %.)  Only for graphs large enough
+# for the kernels to outlast the stream bookkeeping; NPI_OVERLAP_STREAMS=0 turns it off.
+OVERLAP_STREAMS = os.environ.get("NPI_OVERLAP_STREAMS", "1") != "0"
+OVERLAP_MIN_ROWS = 100_000
 _SIDE_STREAMS = {}
 
 
@@ -162,7 +167,7 @@ class _SageConvFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
         side = None
-        if want_w and want_x and OVERLAP_STREAMS:
+        if want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS:
             # dW = aggT dOut is MFMA-bound and independent of the dX chain, whose segsum is HBM-bound:
             # run it on a second HIP stream so the two share the chip instead of queueing
             dev = grad_out.device
