@@ -166,28 +166,29 @@ class _SageConvFn(torch.autograd.Function):
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
-        side = None
-        if want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS:
-            # dW = aggT dOut is MFMA-bound and independent of the dX chain, whose segsum is HBM-bound:
-            # run it on a second HIP stream so the two share the chip instead of queueing
-            dev = grad_out.device
-            main = torch.cuda.current_stream(dev)
-            side = _side_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
-            for t in (dw, db, agg, grad_out):
-                if t is not None:
-                    t.record_stream(side)
-        elif want_w:
+        overlap = want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS
+        if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)       # aggT dOut, colsum
         if want_x:
             # dAgg = dOut W^T, pre-divided by the in-count of its row (fused epilogue), then
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
             dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst))
+            if overlap:
+                # dW is independent of the dX chain: it starts on a second HIP stream once dAgg's GEMM is
+                # through (two GEMM kernels cannot share a SIMD's registers) and shares the CUs with the
+                # HBM-bound aggregation below
+                dev = grad_out.device
+                main = torch.cuda.current_stream(dev)
+                side = _side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
+                for t in (dw, db, agg, grad_out):
+                    if t is not None:
+                        t.record_stream(side)
             dx = segsum(graph, graph.by_src, dagg, mean=False)
-        if side is not None:
-            torch.cuda.current_stream(grad_out.device).wait_stream(side)
+            if overlap:
+                main.wait_stream(side)
         return dx, dw, db, None
 
 
