@@ -824,7 +824,7 @@ static int pick_splits(int64_t M, int64_t tiles) {
 // two ragged strips.  `splits` slabs along the contraction; the fast path needs K % BK == 0.
 // dtype_in: storage of A and B; dtype_out: storage of C and bias.  bf16 runs the guarded kernel only.
 template <int AMODE, int BMODE>
-static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32) {
+static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32) {
     const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && dtype_in == NPI_F32 && dtype_out == NPI_F32;
     // 128 x 256 tile (one workgroup per CU): measured 3-10 % SLOWER than 128 x 128 at C4 (round 1:
     // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms), so it is opt-in (NPI_GEMM_WIDE=1)
@@ -841,7 +841,7 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int
         if (hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)nel * 6, stream) != hipSuccess || planes == nullptr) {
             (void)hipGetLastError();
             set_error("gemm: hipMallocAsync of the split planes failed");
-            return;
+            return NPI_ERR_LAUNCH;
         }
         split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes);
         const bool wide_n = (a.N % 256 == 0);                // 128 x 256 tiles: each A element is split once
@@ -884,6 +884,7 @@ static void launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int
     } else {
         edge(0, 0, tm, tn);
     }
+    return NPI_OK;
 }
 
 }  // namespace npi
@@ -912,8 +913,8 @@ extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64
     const int es = dtype == NPI_BF16 ? 2 : 4;
     GemmArgs a{fp(A), lda, fp(W), ldw, (float*)C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
                Epilogue{fp(bias), rowscale, relu, nullptr}};
-    launch_gemm<0, 0>(vec4_ok(A, lda, K, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
-    return check_launch("npi_linear_fwd");
+    const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, K, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
+    return rc != NPI_OK ? rc : check_launch("npi_linear_fwd");
 }
 extern "C" int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                               const float* rowscale, float* C, int64_t ldc, int64_t M, int64_t K,
@@ -936,8 +937,8 @@ extern "C" int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W
     // B(k = n_contract, n = k_out) = W[k_out * ldw + n_contract]  -> BMODE 1
     GemmArgs a{fp(dC), lddc, fp(W), ldw, (float*)dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
                Epilogue{nullptr, rowscale, 0, nullptr}};
-    launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
-    return check_launch("npi_linear_bwd_data");
+    const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
+    return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data");
 }
 extern "C" int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
                                    const float* rowscale, float* dA, int64_t ldda, int64_t M, int64_t K,
@@ -1005,12 +1006,12 @@ extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* d
     // main part: nodes [0, m_main) in `splits` f32 slabs
     GemmArgs a{fp(A), lda, fp(dC), lddc, workspace, N, (int)K, (int)N, (int)m_main, kchunk, 0, 0, K * N,
                Epilogue{nullptr, nullptr, 0, db ? db_slabs : nullptr}};
-    launch_gemm<1, 0>(v4, a, splits, stream, dtype, NPI_F32);
+    (void)launch_gemm<1, 0>(v4, a, splits, stream, dtype, NPI_F32);          // AMODE 1 never takes the allocating path
     // remainder: nodes [m_main, M) into slab `splits` (a zero slab when there is none)
     GemmArgs r{fp(advance(A, m_main * lda, es)), lda, fp(advance(dC, m_main * lddc, es)), lddc,
                workspace + (int64_t)splits * K * N, N, (int)K, (int)N, (int)(M - m_main), BK, 0, 0, K * N,
                Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)splits * N : nullptr}};
-    launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
+    (void)launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
     const unsigned gw = (unsigned)ceil_div(K * N, 256), gb = (unsigned)ceil_div(N, 256);
     if (dtype == NPI_BF16) {
         slab_reduce_kernel<bf16_t><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (bf16_t*)dW, lddw);

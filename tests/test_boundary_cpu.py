@@ -52,6 +52,32 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"npi_segsum" in lib.npi_last_error()
 
 
+def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
+    """status -1 and a message naming the entry point; nothing is launched (this box has no GPU)"""
+    lib = _lib.load()
+    N = None
+    calls = {
+        "npi_csr_build_ex": lambda: lib.npi_csr_build_ex(N, N, -1, 4, 4, 1, 0, 1, N, N, N, N, N, N, N, 0, N),
+        "npi_linear_fwd": lambda: lib.npi_linear_fwd(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, N),
+        "npi_linear_bwd_data": lambda: lib.npi_linear_bwd_data(N, 0, N, 0, N, N, 0, 8, 8, -3, N),
+        "npi_linear_bwd_weight": lambda: lib.npi_linear_bwd_weight(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, N),
+        "npi_colsum": lambda: lib.npi_colsum(N, 0, -1, 8, N, N, 0, N),
+        "npi_gat_scores": lambda: lib.npi_gat_scores(N, 0, N, 8, 0, 4, N, N, N),
+        "npi_topk_score": lambda: lib.npi_topk_score(N, 0, N, 8, 0, N, N),
+        "npi_readout_max_mean": lambda: lib.npi_readout_max_mean(N, 0, N, 2, 0, N, N),
+        "npi_topk_gather_bwd": lambda: lib.npi_topk_gather_bwd(N, 0, N, N, N, -1, 8, N, 0, N, N, 0, N, N, N),
+        "npi_subgraph_sizes": lambda: lib.npi_subgraph_sizes(N, N, N, N, -1, N, N, N, N),
+        "npi_subgraph_features": lambda: lib.npi_subgraph_features(N, 0, 0, N, N, N, 4, N, 0, N),
+        "npi_confusion_update": lambda: lib.npi_confusion_update(N, 0, 0, N, 4, N, N),
+    }
+    for name, call in calls.items():
+        assert call() == -1, name
+        stem = name[:-3] if name.endswith("_ex") else name           # npi_csr_build_ex reports as npi_csr_build
+        assert stem.encode() in lib.npi_last_error(), (name, lib.npi_last_error())
+    assert lib.npi_linear_bwd_weight_workspace_elems(-1, 8, 8) == -1
+    assert lib.npi_gemm_mode(-1) in (0, 1)                      # query only
+
+
 def test_modules_mirror_pyg_parameter_layout():
     conv = npi_gnn_amd.SAGEConv(178, 128)
     sd = conv.state_dict()
@@ -74,6 +100,15 @@ def test_no_cpu_fallback():
         conv(x, ei)
     with pytest.raises(npi_gnn_amd.NpiError):
         npi_gnn_amd.CSRGraph(ei, 5)
+    from npi_gnn_amd import metrics, pool, subgraph
+    with pytest.raises(npi_gnn_amd.NpiError):
+        pool.topk_pool(x, ei, torch.zeros(5, dtype=torch.long), torch.randn(1, 8))
+    with pytest.raises(npi_gnn_amd.NpiError):
+        pool.global_max_mean_pool(x, torch.zeros(5, dtype=torch.long))
+    with pytest.raises(npi_gnn_amd.NpiError):
+        subgraph.InteractionGraph(torch.tensor([[0, 3]]), torch.tensor([True]), torch.randn(5, 8))
+    with pytest.raises(npi_gnn_amd.NpiError):
+        metrics.confusion_update(torch.randn(4, 2), torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long))
 
 
 def test_product_package_never_imports_the_oracle():
