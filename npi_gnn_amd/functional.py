@@ -19,6 +19,28 @@ from .graph import CSRGraph, CSRSide, as_graph
 
 
 _PROFILE = None     # bench.py sets this to a list to collect (start, end) events per segsum launch
+_PROFILE_GEMM = None  # likewise (name, flops, start, end) per projection GEMM, on the stream it is launched on
+
+
+class _gemm_events:
+    """HIP events around one GEMM entry point when bench.py asked for them (a no-op otherwise)."""
+
+    def __init__(self, name, flops, dev):
+        self.rec = _PROFILE_GEMM
+        if self.rec is not None:
+            self.name, self.flops, self.dev = name, flops, dev
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.e1.record(torch.cuda.current_stream(self.dev))
+            self.rec.append((self.name, self.flops, self.e0, self.e1))
+        return False
 
 # dW = agg^T dOut (MFMA-bound, launched as ONE workgroup per CU so that it leaves wave slots, LDS and
 # registers free) runs on a side stream under the dX chain, whose aggregation is HBM-bound: the two then
@@ -98,9 +120,10 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     M, K = a.shape
     N = weight.size(1)
     out = torch.empty((M, N), dtype=a.dtype, device=dev)
-    check(load().npi_linear_fwd_t(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
-                                  ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a), stream_ptr(dev)),
-          "npi_linear_fwd")
+    with _gemm_events("fwd", 2.0 * M * K * N, dev):
+        check(load().npi_linear_fwd_t(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
+                                      ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a), stream_ptr(dev)),
+              "npi_linear_fwd")
     return out
 
 
@@ -112,9 +135,10 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
     M, N = dc.shape
     K = weight.size(0)
     da = torch.empty((M, K), dtype=dc.dtype, device=dev)
-    check(load().npi_linear_bwd_data_t(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
-                                       ptr(da), da.stride(0), M, K, N, _code(dc), stream_ptr(dev)),
-          "npi_linear_bwd_data")
+    with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
+        check(load().npi_linear_bwd_data_t(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
+                                           ptr(da), da.stride(0), M, K, N, _code(dc), stream_ptr(dev)),
+              "npi_linear_bwd_data")
     return da
 
 
@@ -129,8 +153,9 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True)
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     dw = torch.empty((K, N), dtype=a.dtype, device=dev)
     db = torch.empty(N, dtype=a.dtype, device=dev) if want_bias else None
-    check(lib.npi_linear_bwd_weight_t(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
-                                      M, K, N, ptr(ws), n_ws, _code(a), stream_ptr(dev)), "npi_linear_bwd_weight")
+    with _gemm_events("bwd_weight", 2.0 * M * K * N, dev):
+        check(lib.npi_linear_bwd_weight_t(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
+                                          M, K, N, ptr(ws), n_ws, _code(a), stream_ptr(dev)), "npi_linear_bwd_weight")
     return dw, db
 
 
