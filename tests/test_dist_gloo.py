@@ -91,7 +91,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,N,kind", [(2, 101, "any"), (3, 64, "any"), (2, 203, "bipartite"),
-                                          (3, 160, "bipartite"), (2, 120, "auto")])
+                                          (3, 160, "bipartite"), (2, 120, "auto"), (8, 333, "bipartite"),
+                                          (4, 61, "any")])
 def test_sharded_layer_matches_single_process_oracle(world, N, kind):
     E, F = 900, 16
     ctx = mp.get_context("spawn")
