@@ -561,18 +561,10 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
 // measured 0.45 ms of a 0.9 ms kernel.)
 template <int TM, int TN>
 __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
-                                             const f32x16 (&acc)[TM][TN], const Epilogue& ep) {
-    float4 bv[TN][4];
-    float rs[TM];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bv[j][g] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + nw + j * 32 + 8 * g + 4 * lh)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) rs[i] = ep.rowscale ? ep.rowscale[mw + i * 32 + li] : 1.f;
-    const bool relu_on = ep.relu != 0;
+                                             const f32x16 (&acc)[TM][TN], const float* __restrict__ bias_lds /* this wave's
+                                             first column, or null */, const float (&rs)[TM], bool relu_on) {
+    // bias comes from an LDS copy made once per workgroup and the row scales were fetched at the start of the
+    // tile: a global load here would put a full memory round trip in front of every tile's stores
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         float* __restrict__ crow = C + (int64_t)(mw + i * 32 + li) * ldc + nw + 4 * lh;
@@ -580,11 +572,13 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const float4 b = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + j * 32 + 8 * g + 4 * lh)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 v;
-                v.x = fmaf(acc[i][j][4 * g + 0], rs[i], bv[j][g].x);
-                v.y = fmaf(acc[i][j][4 * g + 1], rs[i], bv[j][g].y);
-                v.z = fmaf(acc[i][j][4 * g + 2], rs[i], bv[j][g].z);
-                v.w = fmaf(acc[i][j][4 * g + 3], rs[i], bv[j][g].w);
+                v.x = fmaf(acc[i][j][4 * g + 0], rs[i], b.x);
+                v.y = fmaf(acc[i][j][4 * g + 1], rs[i], b.y);
+                v.z = fmaf(acc[i][j][4 * g + 2], rs[i], b.z);
+                v.w = fmaf(acc[i][j][4 * g + 3], rs[i], b.w);
                 if (relu_on) {                               // keeps NaN, like torch.relu
                     v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
                     v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
@@ -641,6 +635,7 @@ gemm_split_ws_kernel(SplitArgs a) {
     constexpr int BUF = 3 * APL + 3 * BPL;            // one stage: A planes 0..2, B planes 0..2
     constexpr int NB = BN / 128;                      // 16-byte B chunks per producer thread and plane
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float bias_s[2][BN];  // bias slice of the current tile's columns, by tile parity
     const int t = threadIdx.x;
     const int wave = uniform_i(t >> 6);
     const int nk = a.K / SK;
@@ -754,7 +749,25 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     int par = 0;
+    int tsel = 1;                                           // bias_s half of the current tile (flips per tile)
+    float rs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rs[i] = 1.f;
+    const bool relu_on = a.ep.relu != 0;
     while (w.valid()) {
+        if (w.kt == 0) {
+            // start of a tile: the row scales of this lane's rows (used 16 k-steps later) and the bias slice of the
+            // tile's columns, into the half of bias_s that the tile before the previous one used -- every consumer
+            // wave has passed at least one barrier since it last read that half; the barrier below publishes it
+            tsel ^= 1;
+            if (a.ep.rowscale) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rs[i] = a.ep.rowscale[w.mt * 128 + wm * 64 + i * 32 + li];
+            }
+            if (a.ep.bias) {
+                for (int c = t; c < BN; c += 256) bias_s[tsel][c] = a.ep.bias[w.nt * BN + c];
+            }
+        }
         __syncthreads();                                    // stage `par` holds this k-step
         const char* st = lds + par * BUF;
         bf16x8 af[TM][3], bf[TN][3];
@@ -782,7 +795,8 @@ gemm_split_ws_kernel(SplitArgs a) {
             }
         par ^= 1;
         if (w.kt == nk - 1) {
-            store_tile_t<TM, TN>(a.C, a.ldc, w.mt * 128 + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc, a.ep);
+            store_tile_t<TM, TN>(a.C, a.ldc, w.mt * 128 + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
+                                 a.ep.bias ? bias_s[tsel] + wn * (32 * TN) : nullptr, rs, relu_on);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
