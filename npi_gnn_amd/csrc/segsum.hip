@@ -424,115 +424,166 @@ segsum_group_kernel(SegParams P) {
     }
 }
 
-// The item holding a cut row's FIRST entry sums that row's partials: one 4-wave workgroup per item.
-// Short chains (the common case: tail of item i + head of item i+1) are summed by wave 0; a long
-// chain (hub row: ~1,600 partials at C4) is split into 4 contiguous slices, one per wave, 8 loads
-// in flight each, and the slice sums are added in slice order -- a fixed order, so still bitwise
-// reproducible.
-constexpr int FIX_COOP_MIN = 16;     // chain length from which all 4 waves cooperate
+// Fix-up: the item holding a cut row's FIRST entry (the "owner") sums that row's partials in item order.
+// A workgroup takes FIX_SPAN items.  One thread per item finds out whether it owns a cut row and how long its
+// chain of partials is (three dependent index loads -- paid once per span, not once per workgroup as with a
+// workgroup per item); then each wave walks its share of the span's owners and adds up the SHORT chains (the
+// common case: tail of item i + head of item i + 1); finally the whole workgroup takes the span's LONG
+// chains (a hub row: ~1,600 partials at C4) one by one: 4 contiguous slices, one per wave with 8 loads in
+// flight, slice sums added in slice order.  Every order of addition is fixed by the data, never by
+// scheduling => bitwise reproducible.
+constexpr int FIX_COOP_MIN = 16;     // chain length from which the whole workgroup cooperates
 constexpr int FIX_U = 8;
+constexpr int FIX_SPAN = 64;         // items per workgroup (16 / 32: same time -- the hub row's chain sets it: ~40 us at C4)
+
+// (owner?, row, first entry, end entry, chain length) of `item`
+__device__ __forceinline__ bool fix_owner(const SegParams& P, int item, int nnz, int& r, int& rs, int& re, int& len) {
+    const int k0 = item * ITEM, k1 = k0 + ITEM;
+    if (item >= P.n_items || k1 >= nnz) return false;            // last item: nothing continues
+    r = P.item_row[item + 1];                                     // row holding entry k1
+    rs = P.rowptr[r];
+    if (rs >= k1 || rs < k0) return false;                        // not cut here / owned by an earlier item
+    re = P.rowptr[r + 1];
+    len = (re - 1) / ITEM - item;                                 // head partials to add (>= 1)
+    return true;
+}
 
 template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
 segsum_fixup_kernel(SegParams P) {
+    __shared__ int s_row[FIX_SPAN], s_rs[FIX_SPAN], s_re[FIX_SPAN], s_len[FIX_SPAN];
     __shared__ float red[SEG_WAVES][NCH * VEC * WAVE];
     const int lane = lane_id();
     const int wave = uniform_i(threadIdx.x >> 6);
-    const int item = blockIdx.x;
+    const int base = blockIdx.x * FIX_SPAN;
     const int N = P.N, F = P.F;
     const int nnz = P.rowptr[N];
-    const int k0 = item * ITEM;
-    const int k1 = k0 + ITEM;
-    if (k1 >= nnz) return;                               // last item: nothing continues
-    const int r = uniform_i(P.item_row[item + 1]);       // row holding entry k1
-    const int rs = uniform_i(P.rowptr[r]);
-    if (rs >= k1 || rs < k0) return;                     // not cut here / owned by an earlier item
-    const int re = uniform_i(P.rowptr[r + 1]);
-    const int last = (re - 1) / ITEM;
-    const int len = last - item;                         // head partials to add (>= 1)
-    const bool coop = len >= FIX_COOP_MIN;               // workgroup-uniform
-    if (!coop && wave != 0) return;
-    const int per = coop ? (len + SEG_WAVES - 1) / SEG_WAVES : len;
-    const int jb = item + 1 + wave * per;
-    const int je = min(jb + per, last + 1);
-
+    if (threadIdx.x < FIX_SPAN) {
+        int r = -1, rs = 0, re = 0, len = 0;
+        const bool own = fix_owner(P, base + threadIdx.x, nnz, r, rs, re, len);
+        s_row[threadIdx.x] = own ? r : -1;
+        s_rs[threadIdx.x] = rs; s_re[threadIdx.x] = re; s_len[threadIdx.x] = own ? len : 0;
+    }
+    __syncthreads();
     Lanes<VEC, NCH, WMODE, EXACT> L;
     L.init(P);
-    float acc[NCH][VEC];
+    // short chains: one wave each
+    for (int q = wave; q < FIX_SPAN; q += SEG_WAVES) {
+        const int r = s_row[q], len = s_len[q];
+        if (r < 0 || len >= FIX_COOP_MIN) continue;              // wave-uniform
+        const int item = base + q;
+        float acc[NCH][VEC];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        // wave 0 starts from the owner's tail partial, the other slices from zero
-        if (L.act[c] && wave == 0) load_row<VEC, float>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);
-        else {
+        for (int c = 0; c < NCH; ++c) {
+            if (L.act[c]) load_row<VEC, float>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);   // the owner's tail partial
+            else {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[c][q] = 0.f;
+                for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
+            }
         }
-    }
-    int j = jb;
-    for (; j + FIX_U <= je; j += FIX_U) {
-        float v[FIX_U][NCH][VEC];
-#pragma unroll
-        for (int u = 0; u < FIX_U; ++u) {
-            const float* src = P.carry + ((int64_t)(j + u) * 2 + 0) * F;
+        for (int j = 1; j <= len; ++j) {
+            const float* src = P.carry + ((int64_t)(item + j) * 2 + 0) * F;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (L.act[c]) load_row<VEC, float>(src + L.foff[c], v[u][c]);
-                else {
+                float v[VEC];
+                if (L.act[c]) {
+                    load_row<VEC, float>(src + L.foff[c], v);
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) v[u][c][q] = 0.f;
+                    for (int k = 0; k < VEC; ++k) acc[c][k] += v[k];
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < FIX_U; ++u)
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[c][q] += v[u][c][q];
+        finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
     }
-    for (; j < je; ++j) {
-        const float* src = P.carry + ((int64_t)j * 2 + 0) * F;
+    // long chains: the whole workgroup, one chain after the other (s_* are read-only from here on)
+    for (int q = 0; q < FIX_SPAN; ++q) {
+        const int r = s_row[q], len = s_len[q];
+        if (r < 0 || len < FIX_COOP_MIN) continue;               // workgroup-uniform
+        const int item = base + q;
+        const int per = (len + SEG_WAVES - 1) / SEG_WAVES;
+        const int jb = item + 1 + wave * per;
+        const int je = min(jb + per, item + len + 1);
+        float acc[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            float v[VEC];
-            if (L.act[c]) {
-                load_row<VEC, float>(src + L.foff[c], v);
+            // wave 0 starts from the owner's tail partial, the other slices from zero
+            if (L.act[c] && wave == 0) load_row<VEC, float>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);
+            else {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[c][q] += v[q];
+                for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
             }
         }
-    }
-    if (coop) {
+        int j = jb;
+        for (; j + FIX_U <= je; j += FIX_U) {
+            float v[FIX_U][NCH][VEC];
+#pragma unroll
+            for (int u = 0; u < FIX_U; ++u) {
+                const float* src = P.carry + ((int64_t)(j + u) * 2 + 0) * F;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (L.act[c]) load_row<VEC, float>(src + L.foff[c], v[u][c]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) v[u][c][k] = 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FIX_U; ++u)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[c][k] += v[u][c][k];
+        }
+        for (; j < je; ++j) {
+            const float* src = P.carry + ((int64_t)j * 2 + 0) * F;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float v[VEC];
+                if (L.act[c]) {
+                    load_row<VEC, float>(src + L.foff[c], v);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[c][k] += v[k];
+                }
+            }
+        }
         if (wave != 0) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) red[wave][(c * VEC + q) * WAVE + lane] = acc[c][q];
+                for (int k = 0; k < VEC; ++k) red[wave][(c * VEC + k) * WAVE + lane] = acc[c][k];
         }
         __syncthreads();
-        if (wave != 0) return;
+        if (wave == 0) {
 #pragma unroll
-        for (int w = 1; w < SEG_WAVES; ++w)
+            for (int w = 1; w < SEG_WAVES; ++w)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+                for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[c][q] += red[w][(c * VEC + q) * WAVE + lane];
+                    for (int k = 0; k < VEC; ++k) acc[c][k] += red[w][(c * VEC + k) * WAVE + lane];
+            finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
+        }
+        __syncthreads();                                          // red is reused by the next long chain
     }
-    finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, re - rs);
+}
+
+template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+static void launch_fixup(const SegParams& P, hipStream_t stream) {
+    segsum_fixup_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<dim3((unsigned)ceil_div(P.n_items, FIX_SPAN)), dim3(SEG_THREADS), 0, stream>>>(P);
 }
 
 template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
 static void launch_one(const SegParams& P, hipStream_t stream) {
     dim3 grid((unsigned)ceil_div(P.n_items, SEG_WAVES)), block(SEG_THREADS);
     segsum_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<grid, block, 0, stream>>>(P);
-    segsum_fixup_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<dim3((unsigned)P.n_items), block, 0, stream>>>(P);   // one workgroup per item
+    launch_fixup<T, VEC, NCH, WMODE, MEAN, EXACT>(P, stream);
 }
 
 template <typename T, int VEC, int G, int WMODE, bool MEAN>
 static void launch_group(const SegParams& P, hipStream_t stream) {
     dim3 grid((unsigned)ceil_div(P.n_items, SEG_WAVES)), block(SEG_THREADS);
     segsum_group_kernel<T, VEC, G, WMODE, MEAN><<<grid, block, 0, stream>>>(P);
-    segsum_fixup_kernel<T, VEC, 1, WMODE, MEAN, false><<<dim3((unsigned)P.n_items), block, 0, stream>>>(P);
+    launch_fixup<T, VEC, 1, WMODE, MEAN, false>(P, stream);
 }
 template <typename T, int VEC, int G>
 static int launch_group_modes(const SegParams& P, int wmode, int mean, hipStream_t stream) {
