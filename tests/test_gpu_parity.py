@@ -353,3 +353,44 @@ def test_split_bf16_gemm_is_f32_accurate(dev, M, K, N):
             assert e1 < 2e-6 and e1 < 3 * e0 + 1e-7, err
     finally:
         lib.npi_gemm_mode(prev)
+
+
+def test_training_step_is_hip_graph_capturable(dev):
+    """No kernel on the path synchronises, allocates outside the stream order or reads sizes back: a full-batch
+    fwd + bwd on a fixed graph captures into one HIP graph and replays bit-identically (tools/graph_capture_bench.py)."""
+    N, E, F = 3000, 20000, 128
+    ei = rand_edges(N, E, seed=9, hub=3).to(dev)
+    graph = npi.CSRGraph(ei, N)
+    _ = graph.by_src
+    torch.manual_seed(0)
+    convs = torch.nn.ModuleList([npi.SAGEConv(F, F), npi.SAGEConv(F, F)]).to(dev)
+    x = torch.randn(N, F, device=dev)
+
+    def step():
+        for p in convs.parameters():
+            p.grad = None
+        h = x
+        for c in convs:
+            h = torch.relu(c(h, graph))
+        loss = h.pow(2).mean()
+        loss.backward()
+        return loss
+
+    ref_loss = step().detach().clone()
+    ref = [p.grad.clone() for p in convs.parameters()]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    for p in convs.parameters():
+        p.grad = None
+    with torch.cuda.graph(g):
+        static_loss = step()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_loss.detach(), ref_loss)
+    for p, r in zip(convs.parameters(), ref):
+        assert torch.equal(p.grad, r)
