@@ -34,7 +34,7 @@ extern "C" {
 #define NPI_ERR_WORKSPACE (-3)/* workspace too small */
 
 /* edges of the self-loop-augmented CSR that one wavefront ("item") reduces */
-#define NPI_ITEM_EDGES 256
+#define NPI_ITEM_EDGES 256    /* large graphs; CSRs with capacity nnz_max < 2^20 use 64 (npi_item_edges) */
 
 /* data types of feature matrices */
 #define NPI_F32 0
@@ -65,6 +65,7 @@ int npi_abi_version(void);
  *   status[1]    : int32 device word, bit 0 = out-of-range id seen
  * ------------------------------------------------------------------------------------------ */
 int64_t npi_csr_workspace_bytes(int64_t E, int64_t N);
+int64_t npi_item_edges(int64_t nnz_max);   /* entries per item for a CSR of capacity nnz_max: 64 or NPI_ITEM_EDGES */
 int64_t npi_num_items(int64_t nnz_max);
 int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
                   int add_self_loops,

@@ -16,7 +16,6 @@ LIB_PATH = os.environ.get("NPI_GNN_LIB") or os.path.join(HERE, "libnpi_gnn.so") 
 
 NPI_F32 = 0
 NPI_BF16 = 1
-ITEM_EDGES = 256
 
 _P = c_void_p
 _I = c_int64
@@ -26,6 +25,7 @@ PROTOTYPES = {
     "npi_last_error": (c_char_p, []),
     "npi_abi_version": (c_int, []),
     "npi_csr_workspace_bytes": (_I, [_I, _I]),
+    "npi_item_edges": (_I, [_I]),
     "npi_num_items": (_I, [_I]),
     "npi_csr_build": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "npi_csr_build_ex": (c_int, [_P, _P, _I, _I, _I, c_int, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -228,14 +228,14 @@ __global__ void fill_rows_kernel(const int32_t* __restrict__ rowptr0, int64_t N,
     }
 }
 
-// item_row[i] = row holding entry i*NPI_ITEM_EDGES (item 0 starts at row 0 so that leading empty
+// item_row[i] = row holding entry i*item (item 0 starts at row 0 so that leading empty
 // rows get written); N for items past nnz.
-__global__ void item_rows_kernel(const int32_t* __restrict__ rowptr, int64_t N, int64_t n_items,
+__global__ void item_rows_kernel(const int32_t* __restrict__ rowptr, int64_t N, int64_t n_items, int item,
                                  int32_t* __restrict__ item_row) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_items) return;
     int64_t nnz = rowptr[N];
-    int64_t k = i * NPI_ITEM_EDGES;
+    int64_t k = i * item;
     if (i == 0) { item_row[0] = 0; return; }
     if (k >= nnz) { item_row[i] = (int32_t)N; return; }
     // upper_bound(rowptr[0..N], k) - 1
@@ -296,8 +296,10 @@ extern "C" int64_t npi_csr_workspace_bytes(int64_t E, int64_t N) {
     return sort_layout(E, N).total;
 }
 
+extern "C" int64_t npi_item_edges(int64_t nnz_max) { return npi::item_edges_for(nnz_max); }
+
 extern "C" int64_t npi_num_items(int64_t nnz_max) {
-    return nnz_max <= 0 ? 0 : ceil_div(nnz_max, NPI_ITEM_EDGES);
+    return nnz_max <= 0 ? 0 : ceil_div(nnz_max, (int64_t)npi::item_edges_for(nnz_max));
 }
 
 extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
@@ -355,8 +357,9 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
     if (E > 0)
         fill_entries_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(keys_a, vals_a, val_nodes, E, N, add_self_loops, col, eid, rowidx);
     fill_rows_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(rowptr0, N, add_self_loops, (int32_t)loop_col_offset, rowptr, col, eid, rowidx);
-    int64_t n_items = npi_num_items(E + (add_self_loops ? N : 0));
-    item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, item_row);
+    const int64_t nnz_max = E + (add_self_loops ? N : 0);
+    int64_t n_items = npi_num_items(nnz_max);
+    item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, item_edges_for(nnz_max), item_row);
     return check_launch("npi_csr_build");
 }
 

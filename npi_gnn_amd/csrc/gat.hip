@@ -102,17 +102,17 @@ constexpr int HEAVY_WAVES = HEAVY_THREADS / WAVE;
 
 // returns the number of heavy rows starting in this item; their ids are in heavy[]
 __device__ __forceinline__ int find_heavy_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
-                                               int N, int item, int* heavy, int* n_heavy) {
+                                               int N, int item, int item_edges, int* heavy, int* n_heavy) {
     const int t = threadIdx.x;
     const int nnz = rowptr[N];
-    const int k0 = item * NPI_ITEM_EDGES, k1 = k0 + NPI_ITEM_EDGES;
+    const int k0 = item * item_edges, k1 = k0 + item_edges;
     if (k0 >= nnz) return 0;                           // workgroup-uniform
     if (t == 0) *n_heavy = 0;
     __syncthreads();
     int first = item_row[item];
     if (rowptr[first] < k0) ++first;                   // that row started in an earlier item
     const int r = first + t;
-    if (t < NPI_ITEM_EDGES && r < N) {
+    if (t < item_edges && r < N) {
         const int b = rowptr[r];
         if (b < k1 && b < nnz && rowptr[r + 1] - b > GAT_HEAVY) heavy[atomicAdd(n_heavy, 1)] = r;
     }
@@ -146,12 +146,12 @@ __global__ void __launch_bounds__(HEAVY_THREADS)
 gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                          const int32_t* __restrict__ item_row, const float* __restrict__ a_dst,
                          const float* __restrict__ a_src, int N, int H, float slope,
-                         float* __restrict__ m, float* __restrict__ s) {
+                         float* __restrict__ m, float* __restrict__ s, int item_edges) {
     __shared__ int heavy[NPI_ITEM_EDGES];
     __shared__ int n_heavy;
     __shared__ float red[HEAVY_WAVES];
     const int t = threadIdx.x;
-    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, heavy, &n_heavy);
+    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, item_edges, heavy, &n_heavy);
     for (int q = 0; q < nh; ++q) {
         const int i = heavy[q];
         const int b = rowptr[i], e = rowptr[i + 1];
@@ -175,12 +175,12 @@ gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __re
 __global__ void __launch_bounds__(HEAVY_THREADS)
 seg_rowsum_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
                         const float* __restrict__ vals, const int32_t* __restrict__ map, int N, int H,
-                        float* __restrict__ out) {
+                        float* __restrict__ out, int item_edges) {
     __shared__ int heavy[NPI_ITEM_EDGES];
     __shared__ int n_heavy;
     __shared__ float red[HEAVY_WAVES];
     const int t = threadIdx.x;
-    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, heavy, &n_heavy);
+    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, item_edges, heavy, &n_heavy);
     for (int q = 0; q < nh; ++q) {
         const int r = heavy[q];
         const int b = rowptr[r], e = rowptr[r + 1];
@@ -203,7 +203,7 @@ constexpr int EDGE_HMAX = 8;        // heads whose per-entry dots are staged thr
 template <int NCH>
 __global__ void __launch_bounds__(256)
 gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                     const int32_t* __restrict__ rowidx, int N, int n_items,
+                     const int32_t* __restrict__ rowidx, int N, int n_items, int item_edges,
                      const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ dout, int64_t ldd,
                      int H, int C, const float* __restrict__ a_dst, const float* __restrict__ a_src,
                      const float* __restrict__ m, const float* __restrict__ s, const float* __restrict__ D,
@@ -213,9 +213,9 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
     const int item = uniform_i(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= n_items) return;
     const int nnz = rowptr[N];
-    const int k0 = item * NPI_ITEM_EDGES;
+    const int k0 = item * item_edges;
     if (k0 >= nnz) return;
-    const int k1 = min(k0 + NPI_ITEM_EDGES, nnz);
+    const int k1 = min(k0 + item_edges, nnz);
     const int F = H * C;
     bool act[NCH];
     int foff[NCH], hd[NCH];
@@ -402,7 +402,7 @@ extern "C" int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, 
     gat_softmax_rows_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, col, a_dst, a_src, (int)N, (int)H, slope, m, s);
     const int64_t n_items = npi_num_items(nnz_max);
     if (n_items > 0)
-        gat_softmax_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)H, slope, m, s);
+        gat_softmax_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)H, slope, m, s, item_edges_for(nnz_max));
     return check_launch("npi_gat_softmax_stats");
 }
 
@@ -443,7 +443,7 @@ extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, cons
     const int n_items = (int)npi_num_items(nnz_max);
     const unsigned grid = (unsigned)ceil_div(n_items, 4);
     const int nch = (int)ceil_div(F, 256);
-#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz)
+#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, item_edges_for(nnz_max), hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz)
     if (nch == 1) NPI_EG(1); else if (nch == 2) NPI_EG(2); else if (nch == 3) NPI_EG(3); else NPI_EG(4);
 #undef NPI_EG
     return check_launch("npi_gat_edge_grad");
@@ -459,7 +459,7 @@ extern "C" int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, co
     // rows up to 4096 entries: one wave each; longer ones: one 1024-thread workgroup each
     seg_rowsum_scalar_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out, n_items > 0 ? 1 : 0);
     if (n_items > 0)
-        seg_rowsum_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)H, out);
+        seg_rowsum_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)H, out, item_edges_for(nnz_max));
     return check_launch("npi_seg_rowsum");
 }
 

@@ -40,6 +40,13 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
 
+// Entries per work item ("item" = what one wavefront reduces) as a function of the CSR's capacity: small graphs
+// (the reference's 200-subgraph batches, the bundled full graphs) get 64-entry items -- four times as many
+// wavefronts, a quarter of the serial chain each -- large ones NPI_ITEM_EDGES.  Every entry point derives it
+// from the same nnz_max, so item_row, carry and the kernels always agree.
+constexpr int64_t NPI_SMALL_GRAPH_ENTRIES = 1 << 20;
+__host__ __device__ inline int item_edges_for(int64_t nnz_max) { return nnz_max < NPI_SMALL_GRAPH_ENTRIES ? 64 : NPI_ITEM_EDGES; }
+
 }  // namespace npi
 
 #define NPI_REQUIRE(cond, msg)                 \

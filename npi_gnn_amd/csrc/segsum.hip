@@ -27,7 +27,6 @@ namespace npi {
 
 constexpr int SEG_THREADS = 256;
 constexpr int SEG_WAVES = SEG_THREADS / WAVE;
-constexpr int ITEM = NPI_ITEM_EDGES;
 
 // storage element types: float, or bf16 carried as uint16_t (f32 accumulation either way)
 typedef uint16_t bf16_t;
@@ -142,9 +141,9 @@ segsum_kernel(SegParams P) {
     if (item >= P.n_items) return;
     const int N = P.N;
     const int nnz = P.rowptr[N];
-    const int k0 = item * ITEM;
+    const int k0 = item * P.item;
     if (k0 >= nnz) return;
-    const int k1 = min(k0 + ITEM, nnz);
+    const int k1 = min(k0 + P.item, nnz);
     const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
 
@@ -326,9 +325,9 @@ segsum_group_kernel(SegParams P) {
     if (item >= P.n_items) return;
     const int N = P.N;
     const int nnz = P.rowptr[N];
-    const int k0 = item * ITEM;
+    const int k0 = item * P.item;
     if (k0 >= nnz) return;
-    const int k1 = min(k0 + ITEM, nnz);
+    const int k1 = min(k0 + P.item, nnz);
     const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
     const int grp = lane / LG;
@@ -438,13 +437,13 @@ constexpr int FIX_SPAN = 64;         // items per workgroup (16 / 32: same time 
 
 // (owner?, row, first entry, end entry, chain length) of `item`
 __device__ __forceinline__ bool fix_owner(const SegParams& P, int item, int nnz, int& r, int& rs, int& re, int& len) {
-    const int k0 = item * ITEM, k1 = k0 + ITEM;
+    const int k0 = item * P.item, k1 = k0 + P.item;
     if (item >= P.n_items || k1 >= nnz) return false;            // last item: nothing continues
     r = P.item_row[item + 1];                                     // row holding entry k1
     rs = P.rowptr[r];
     if (rs >= k1 || rs < k0) return false;                        // not cut here / owned by an earlier item
     re = P.rowptr[r + 1];
-    len = (re - 1) / ITEM - item;                                 // head partials to add (>= 1)
+    len = (re - 1) / P.item - item;                                 // head partials to add (>= 1)
     return true;
 }
 
@@ -636,6 +635,7 @@ static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t str
 // shared by npi_segsum and npi_gat_aggregate (gat.hip)
 int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hipStream_t stream) {
     const int64_t F = P.F;
+    P.item = item_edges_for(nnz_max);
     const int es = (dtype == NPI_BF16) ? 2 : 4;              // bytes per stored element
     const char* x = reinterpret_cast<const char*>(P.x);
     char* out = reinterpret_cast<char*>(P.out);

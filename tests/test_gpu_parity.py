@@ -50,7 +50,8 @@ def csr_reference(key, val, N, loops=True):
 
 
 @pytest.mark.parametrize("N,E,loops", [(1, 0, True), (5, 0, True), (7, 20, True), (300, 5000, True),
-                                       (300, 5000, False), (5000, 200000, True), (70000, 300000, True)])
+                                       (300, 5000, False), (5000, 200000, True), (70000, 300000, True),
+                                       (3000, 1_100_000, True)])      # the last one: 256-entry items
 def test_csr_build_is_bit_exact(dev, N, E, loops):
     ei = rand_edges(N, E, seed=N + E) if E else torch.zeros((2, 0), dtype=torch.long)
     g = npi.CSRGraph(ei.to(dev), N, self_loops=loops)
@@ -61,10 +62,13 @@ def test_csr_build_is_bit_exact(dev, N, E, loops):
         assert np.array_equal(side.col.cpu().numpy()[:nnz], col)
         assert np.array_equal(side.eid.cpu().numpy()[:nnz], eid)
         assert np.array_equal(side.rowidx.cpu().numpy()[:nnz], rowidx)
-        # item_row[i] = row holding entry 256 i
+        # item_row[i] = row holding entry item_edges * i (64-entry items below 2^20 entries of capacity, else 256)
+        from npi_gnn_amd._lib import load as _load
+        item_edges = int(_load().npi_item_edges(side.nnz_max))
+        assert item_edges == (64 if side.nnz_max < (1 << 20) else 256)
         ir = side.item_row.cpu().numpy()
         for i in range(1, side.n_items):
-            k = 256 * i
+            k = item_edges * i
             if k < nnz:
                 assert rowptr[ir[i]] <= k < rowptr[ir[i] + 1]
         assert int(side.status.item()) == 0
@@ -192,7 +196,9 @@ def _layer_case(N, E, Fi, Fo, seed, symmetric):
 
 
 @pytest.mark.parametrize("N,E,Fi,Fo,sym", [(50, 120, 178, 128, True), (4000, 30000, 128, 128, True),
-                                           (4000, 30000, 256, 256, False), (2500, 9000, 65, 64, False)])
+                                           (4000, 30000, 256, 256, False), (2500, 9000, 65, 64, False),
+                                           (30000, 1_100_000, 64, 64, False),     # >= 2^20 entries: 256-entry items
+                                           (20000, 1_080_000, 128, 32, False)])
 def test_sage_conv_fwd_bwd_matches_oracle(dev, N, E, Fi, Fo, sym):
     ei, x, W, b, go = _layer_case(N, E, Fi, Fo, 7, sym)
     ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(x, ei, W, b, go)
