@@ -592,7 +592,7 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
                     v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
                     v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
                 }
-                *reinterpret_cast<float4*>(crow + j * 32 + 8 * g) = v;
+                *reinterpret_cast<float4*>(crow + j * 32 + 8 * g) = v;       // (non-temporal stores: 13 % slower)
             }
     }
 }
