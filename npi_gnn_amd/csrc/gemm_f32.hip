@@ -527,13 +527,15 @@ __device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));    // x in the low half
 }
 __device__ __forceinline__ void split3_pair(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = pack_bf16(x, y);
-    x -= __uint_as_float(p0 << 16);
-    y -= __uint_as_float(p0 & 0xffff0000u);
-    p1 = pack_bf16(x, y);
-    x -= __uint_as_float(p1 << 16);
-    y -= __uint_as_float(p1 & 0xffff0000u);
-    p2 = pack_bf16(x, y);
+    // two-element vectors: the subtractions become one v_pk_add_f32 per stage
+    f32x2v v = {x, y};
+    p0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+    f32x2v h0 = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
+    v = v - h0;
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+    f32x2v h1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+    v = v - h1;
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
 }
 // the three planes of four consecutive k, as 8-byte LDS stores; `plane` = bytes between plane images
 __device__ __forceinline__ void split3_store(f32x4r v, char* img, int plane) {
