@@ -507,9 +507,10 @@ colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, fl
 // a 2 x 2 grid of 64 x 32 TN wave tiles) + 4 producer waves (global loads, the split, LDS stores), one of
 // each per SIMD, so the matrix pipe and the VALU / LDS-store work overlap by construction rather than
 // by instruction scheduling.  Tile 128 x 64 TN (TN = 4 when N % 256 == 0: every A element is then split
-// once for 256 output columns), BK = 16, LDS double-buffered, ONE barrier per k-step; the producer
-// keeps a ring of four k-steps of loads in flight and runs across tile boundaries, so only the first
-// tile of a workgroup exposes a load latency.
+// once for 256 output columns), BK = 16, FOUR LDS stages handed over through per-stage LDS counters (no barrier in
+// the main loop: the producer runs up to three k-steps ahead, so a consumer's epilogue does not stop it); the
+// producer keeps a ring of four k-steps of loads in flight and runs across tile boundaries, so only the
+// first tile of a workgroup exposes a load latency.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -637,6 +638,15 @@ struct TileWalk {
     }
 };
 
+// LDS hand-over counters of the split kernel (workgroup scope)
+__device__ __forceinline__ void wait_ge(int* flag, int target) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void signal(int* flag) {      // one count per wave, after the wave's LDS traffic is complete
+    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
+    if (lane_id() == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int TN>
 __global__ void __launch_bounds__(WS_THREADS, 1)
 gemm_split_ws_kernel(SplitArgs a) {
@@ -645,14 +655,22 @@ gemm_split_ws_kernel(SplitArgs a) {
     constexpr int APL = 128 * 32, BPL = BN * 32;      // bytes of one A / B plane image
     constexpr int BUF = 3 * APL + 3 * BPL;            // one stage: A planes 0..2, B planes 0..2
     constexpr int NB = BN / 128;                      // 16-byte B chunks per producer thread and plane
-    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
-    __shared__ __attribute__((aligned(16))) float bias_s[2][BN];  // bias slice of the current tile's columns, by tile parity
+    constexpr int NST = 4;                            // LDS stages (4 x 36 KiB at TN = 4)
+    __shared__ __attribute__((aligned(16))) char lds[NST * BUF];
+    __shared__ __attribute__((aligned(16))) float bias_s[4][2][32 * TN];   // per consumer wave: bias of its columns, by tile parity
+    // hand-over counters, one pair per stage, only ever incremented: the 4 producer waves add to full[s] when their
+    // part of a k-step is in stage s, the 4 consumer waves add to empty[s] when their fragments are in registers.
+    // No barrier in the main loop: the producer runs up to NST - 1 k-steps ahead, so a consumer epilogue (10 k
+    // cycles of stores) no longer stops it, and the consumer finds the next stages ready when it returns.
+    __shared__ int full[NST], empty[NST];
     const int t = threadIdx.x;
     const int wave = uniform_i(t >> 6);
     const int nk = a.K / SK;
     TileWalk w;
     w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n);
     if (!w.valid()) return;                                 // no tile for this workgroup (uniform)
+    if (t < NST) { full[t] = 0; empty[t] = 0; }
+    __syncthreads();
 
     if (wave >= 4) {
         // ---------------- producer ----------------
@@ -718,21 +736,22 @@ gemm_split_ws_kernel(SplitArgs a) {
         }                                                                                              \
     } while (0)
         // one k-step: refill the set freed by the previous step, split + store set CUR
-#define NPI_WSTEP(OFF, CUR, FREE)                                                                      \
+#define NPI_WSTEP(ST, CUR, FREE)                                                                       \
         NPI_WLOAD(FREE);                                                                               \
+        if (round > 0) wait_ge(&empty[ST], 4 * round);       /* the consumers are done with this stage's previous use */ \
         NPI_WWAIT(CUR);                                                                                \
-        NPI_WSTORE(OFF, CUR);                                                                          \
-        __syncthreads();                                                                               \
+        NPI_WSTORE((ST) * BUF, CUR);                                                                   \
+        signal(&full[ST]);                                                                             \
         w.next();                                                                                      \
         if (!w.valid()) break
         NPI_WLOAD(r0);
         NPI_WLOAD(r1);
         NPI_WLOAD(r2);
-        while (w.valid()) {
+        for (int round = 0; w.valid(); ++round) {
             NPI_WSTEP(0, r0, r3);
-            NPI_WSTEP(BUF, r1, r0);
-            NPI_WSTEP(0, r2, r1);
-            NPI_WSTEP(BUF, r3, r2);
+            NPI_WSTEP(1, r1, r0);
+            NPI_WSTEP(2, r2, r1);
+            NPI_WSTEP(3, r3, r2);
         }
 #undef NPI_WSTEP
 #undef NPI_WDECL
@@ -759,28 +778,29 @@ gemm_split_ws_kernel(SplitArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    int par = 0;
-    int tsel = 1;                                           // bias_s half of the current tile (flips per tile)
+    int tsel = 1, bias_nt = -1;                             // bias_s half in use, and the n-tile whose bias it holds
     float rs[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) rs[i] = 1.f;
     const bool relu_on = a.ep.relu != 0;
+    int g = 0;                                              // k-steps consumed so far: stage g % NST, use g / NST
     while (w.valid()) {
         if (w.kt == 0) {
-            // start of a tile: the row scales of this lane's rows (used 16 k-steps later) and the bias slice of the
-            // tile's columns, into the half of bias_s that the tile before the previous one used -- every consumer
-            // wave has passed at least one barrier since it last read that half; the barrier below publishes it
-            tsel ^= 1;
+            // start of a tile: the row scales of this lane's rows and the bias of this wave's columns (into the
+            // wave's own LDS slot: written and, 16 k-steps later, read by the same wave -- in order, no hand-over)
             if (a.ep.rowscale) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) rs[i] = a.ep.rowscale[w.mt * 128 + wm * 64 + i * 32 + li];
             }
-            if (a.ep.bias) {
-                for (int c = t; c < BN; c += 256) bias_s[tsel][c] = a.ep.bias[w.nt * BN + c];
+            if (a.ep.bias && w.nt != bias_nt) {             // only when the column block changes (never, for N = 64 TN): the
+                tsel ^= 1;                                  // copy waits on vmcnt(0), i.e. also on the previous tile's stores
+                bias_nt = w.nt;
+                for (int c = lane; c < 32 * TN; c += WAVE) bias_s[wave][tsel][c] = a.ep.bias[w.nt * BN + wn * (32 * TN) + c];
             }
         }
-        __syncthreads();                                    // stage `par` holds this k-step
-        const char* st = lds + par * BUF;
+        const int stg = g & (NST - 1);
+        wait_ge(&full[stg], 4 * ((g >> 2) + 1));            // all four producer waves have filled the stage
+        const char* st = lds + stg * BUF;
         bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -790,24 +810,36 @@ gemm_split_ws_kernel(SplitArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + offb[j] + p * BPL);
+        // All 18 reads are issued above this point (the empty asm is a compiler barrier for memory operations);
+        // the first tile's MFMAs start as soon as THEIR fragments arrive, and the stage is handed back -- which
+        // needs every read complete -- while those MFMAs execute.
+        asm volatile("" ::: "memory");
+#define NPI_MMA6(I, J)                                                                                 \
+        do {                                                                                           \
+            f32x16 c = acc[I][J];                                                                      \
+            /* B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t) */ \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][2], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][2], af[I][0], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][1], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][1], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][0], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][0], c, 0, 0, 0);               \
+            acc[I][J] = c;                                                                             \
+        } while (0)
+        NPI_MMA6(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        signal(&empty[stg]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                f32x16 c = acc[i][j];
-                // B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t)
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][2], af[i][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][0], c, 0, 0, 0);
-                acc[i][j] = c;
-            }
-        par ^= 1;
+            for (int j = 0; j < TN; ++j)
+                if (i + j > 0) NPI_MMA6(i, j);
+#undef NPI_MMA6
+        ++g;
         if (w.kt == nk - 1) {
             store_tile_t<TM, TN>(a.C, a.ldc, w.mt * 128 + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
-                                 a.ep.bias ? bias_s[tsel] + wn * (32 * TN) : nullptr, rs, relu_on);
+                                 a.ep.bias ? bias_s[wave][tsel] : nullptr, rs, relu_on);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
