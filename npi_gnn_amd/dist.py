@@ -215,6 +215,13 @@ class HipBackend:
         from . import functional as NF
         return NF.linear_bwd_weight(a, dc, want_bias)
 
+    def side_stream(self, like):
+        """second HIP stream for the weight-gradient GEMM, or None when the shard is too small to gain"""
+        from . import functional as NF
+        if not NF.OVERLAP_STREAMS or like.size(0) < NF.OVERLAP_MIN_ROWS:
+            return None
+        return NF._side_stream(like.device)
+
 
 class ShardedGraph:
     """This rank's shard of the (self-loop-augmented) graph: sides A, B and their transposes."""
@@ -296,15 +303,24 @@ class _ShardedSageFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         dx = dw = db = None
         started = None
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0]:
             dagg = be.linear_bwd_data(grad_out, weight, sg.inv_cnt)
             started = _exchange_start(sg, dagg, sg.Bt)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)     # overlaps the exchange
-            if not _solo(sg.world):
-                dist.all_reduce(dw, group=sg.group)
-                if db is not None:
-                    dist.all_reduce(db, group=sg.group)
+        # dW is independent of the dX chain.  On the GPU backend it runs (one workgroup per CU) on a side stream
+        # under the HBM-bound aggregation, as in the single-GPU layer; otherwise in line, under the exchange.
+        side = be.side_stream(grad_out) if (want_w and started is not None and hasattr(be, "side_stream")) else None
+        if want_w:
+            if side is not None:
+                main = torch.cuda.current_stream(grad_out.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
+                for t in (dw, db, agg, grad_out):
+                    if t is not None:
+                        t.record_stream(side)
+            else:
+                dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
         if started is not None:
             table, g_work, hsum, r_work = started
             if g_work is not None:
@@ -315,6 +331,13 @@ class _ShardedSageFn(torch.autograd.Function):
                     r_work.wait()
                 if sg.nH:
                     dx[sg.nL:] += hsum[: sg.nH]
+        if want_w:
+            if side is not None:
+                torch.cuda.current_stream(grad_out.device).wait_stream(side)
+            if not _solo(sg.world):
+                dist.all_reduce(dw, group=sg.group)
+                if db is not None:
+                    dist.all_reduce(db, group=sg.group)
         return dx, dw, db, None
 
 
