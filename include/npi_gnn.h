@@ -195,9 +195,10 @@ int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t 
  * ------------------------------------------------------------------------------------------ */
 int npi_gat_scores(const float* hfeat, int64_t ldh, const float* att, int64_t N, int64_t H, int64_t C,
                    float* a_dst, float* a_src, void* stream);
+int64_t npi_gat_heavy_workspace_elems(int64_t nnz_max, int64_t H);   /* f32 scratch of npi_gat_softmax_stats / npi_seg_rowsum */
 int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
                           const float* a_dst, const float* a_src, int64_t N, int64_t nnz_max, int64_t H,
-                          float negative_slope, float* m, float* s, void* stream);
+                          float slope, float* m, float* s, float* workspace, int64_t workspace_elems, void* stream);
 int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
                       int64_t N, int64_t nnz_max, const float* x, int64_t ldx, float* out, int64_t ldo,
                       int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
@@ -212,7 +213,8 @@ int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       const float* a_dst, const float* a_src, const float* m, const float* s,
                       const float* D, float negative_slope, float* dz, void* stream);
 int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
-                   int64_t N, int64_t nnz_max, int64_t H, float* out, void* stream);
+                   int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
+                   void* stream);
 int npi_entry_transpose_map(const int32_t* src_eid, const int32_t* src_rowidx, const int32_t* src_rowptr,
                             const int32_t* dst_rowptr, const int32_t* pos_dst_of_edge, int64_t N,
                             int64_t nnz_max, int32_t* map, void* stream);

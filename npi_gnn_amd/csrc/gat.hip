@@ -94,30 +94,64 @@ gat_softmax_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __res
     }
 }
 
-// Heavy rows (hub proteins: 400k entries at C4) get a whole 1024-thread workgroup.  One workgroup per
-// 256-entry item; it owns the heavy rows whose FIRST entry lies in the item (found without any list
-// building pass: the rows starting inside the item are item_row[item] (+1) ... ).
+// Heavy rows (hub proteins: 400k entries at C4, 2M at C5) are cut into SEGMENTS of HEAVY_SEG_ITEMS items, one
+// 1024-thread workgroup per segment, so a hub row is spread over dozens of CUs instead of serialising on one.
+// There is one workgroup per item; it takes (a) the first segment of the heavy row that STARTS in its item (at
+// most one: a heavy row is longer than an item) and (b) the continuing segment that starts at its first entry, if
+// the row passing through is heavy and (item - first_item(row)) is a multiple of HEAVY_SEG_ITEMS.  A segment's
+// partial goes to workspace slot 2 item + (0: first segment, 1: continuing); the workgroup that finishes LAST
+// (per-row counter, indexed by the row's first item) folds the partials in segment order -- a fixed order, so
+// the result does not depend on which workgroup that is.
 constexpr int HEAVY_THREADS = 1024;
 constexpr int HEAVY_WAVES = HEAVY_THREADS / WAVE;
+constexpr int HEAVY_SEG_ITEMS = 64;
 
-// returns the number of heavy rows starting in this item; their ids are in heavy[]
-__device__ __forceinline__ int find_heavy_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
-                                               int N, int item, int item_edges, int* heavy, int* n_heavy) {
-    const int t = threadIdx.x;
+struct HeavySeg {
+    int row, b, e;      // row and entry range of the segment
+    int fi, k, nseg;    // first item of the row, index of this segment, segments of the row
+};
+
+// segments this workgroup (item) owns: returns a bit mask (1: first segment in seg[0], 2: continuing in seg[1])
+__device__ __forceinline__ int heavy_segments(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
+                                              int N, int n_items, int item, int IE, HeavySeg (&seg)[2]) {
     const int nnz = rowptr[N];
-    const int k0 = item * item_edges, k1 = k0 + item_edges;
-    if (k0 >= nnz) return 0;                           // workgroup-uniform
-    if (t == 0) *n_heavy = 0;
-    __syncthreads();
-    int first = item_row[item];
-    if (rowptr[first] < k0) ++first;                   // that row started in an earlier item
-    const int r = first + t;
-    if (t < item_edges && r < N) {
-        const int b = rowptr[r];
-        if (b < k1 && b < nnz && rowptr[r + 1] - b > GAT_HEAVY) heavy[atomicAdd(n_heavy, 1)] = r;
+    const int64_t k0 = (int64_t)item * IE, k1 = k0 + IE;
+    int mask = 0;
+    if (k0 >= nnz) return 0;
+    const int span = HEAVY_SEG_ITEMS * IE;
+    // (b) the row that contains entry k0 and started before it
+    const int r0 = item_row[item];
+    const int b0 = rowptr[r0];
+    if (b0 < k0) {
+        const int e0 = rowptr[r0 + 1];
+        if (e0 - b0 > GAT_HEAVY) {
+            const int fi = b0 / IE;
+            if ((item - fi) % HEAVY_SEG_ITEMS == 0) {
+                seg[1].row = r0; seg[1].b = (int)k0; seg[1].e = (int)min((int64_t)e0, k0 + span);
+                seg[1].fi = fi; seg[1].k = (item - fi) / HEAVY_SEG_ITEMS;
+                seg[1].nseg = ((e0 - 1) / IE - fi) / HEAVY_SEG_ITEMS + 1;
+                mask |= 2;
+            }
+        }
     }
-    __syncthreads();
-    return *n_heavy;
+    // (a) the row that starts in this item and reaches past its end
+    if (k1 < nnz && item + 1 <= n_items) {
+        const int r1 = item_row[item + 1];                 // row holding entry k1
+        const int b1 = rowptr[r1];
+        if (b1 >= k0 && b1 < k1) {
+            const int e1 = rowptr[r1 + 1];
+            if (e1 - b1 > GAT_HEAVY) {
+                seg[0].row = r1; seg[0].b = b1; seg[0].e = (int)min((int64_t)e1, k0 + span);
+                seg[0].fi = item; seg[0].k = 0;
+                seg[0].nseg = ((e1 - 1) / IE - item) / HEAVY_SEG_ITEMS + 1;
+                mask |= 1;
+            }
+        }
+    }
+    return mask;
+}
+__device__ __forceinline__ int heavy_slot(const HeavySeg& g, int k) {          // workspace slot of segment k of g's row
+    return k == 0 ? 2 * g.fi : 2 * (g.fi + k * HEAVY_SEG_ITEMS) + 1;
 }
 
 // fixed-order sum / max of one value per wave
@@ -141,32 +175,60 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     __syncthreads();
     return s;
 }
+// partials written by OTHER workgroups are read past this CU's L1
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// thread 0 publishes the segment's partial and learns whether its workgroup is the last one of the row
+__device__ __forceinline__ bool heavy_arrive(int* cnt, const HeavySeg& g, int* flag) {
+    if (threadIdx.x == 0) {
+        __threadfence();                                   // the partial is visible before the count
+        *flag = (atomicAdd(cnt + g.fi, 1) == g.nseg - 1);
+        __threadfence();
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();
+    return last;
+}
 
+// part[slot][H][2] = (max, sum of exp(. - max)) of a segment; the last workgroup merges them like an online softmax
 __global__ void __launch_bounds__(HEAVY_THREADS)
 gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                          const int32_t* __restrict__ item_row, const float* __restrict__ a_dst,
-                         const float* __restrict__ a_src, int N, int H, float slope,
-                         float* __restrict__ m, float* __restrict__ s, int item_edges) {
-    __shared__ int heavy[NPI_ITEM_EDGES];
-    __shared__ int n_heavy;
+                         const float* __restrict__ a_src, int N, int n_items, int H, float slope,
+                         float* __restrict__ m, float* __restrict__ s, int item_edges,
+                         float* __restrict__ part, int* __restrict__ cnt) {
     __shared__ float red[HEAVY_WAVES];
+    __shared__ int flag;
     const int t = threadIdx.x;
-    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, item_edges, heavy, &n_heavy);
-    for (int q = 0; q < nh; ++q) {
-        const int i = heavy[q];
-        const int b = rowptr[i], e = rowptr[i + 1];
+    HeavySeg seg[2];
+    const int mask = heavy_segments(rowptr, item_row, N, n_items, blockIdx.x, item_edges, seg);   // workgroup-uniform
+    for (int q = 0; q < 2; ++q) {
+        if (!(mask & (1 << q))) continue;
+        const HeavySeg g = seg[q];
+        const int i = g.row;
+        float* __restrict__ mine = part + (int64_t)heavy_slot(g, g.k) * H * 2;
         for (int hd = 0; hd < H; ++hd) {
             const float ad = a_dst[(int64_t)i * H + hd];
             float mx = -3.0e38f;
-            for (int p = b + t; p < e; p += HEAVY_THREADS) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
+            for (int p = g.b + t; p < g.e; p += HEAVY_THREADS) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
             mx = block_max(mx, red);
             float sum = 0.f;
-            for (int p = b + t; p < e; p += HEAVY_THREADS) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
+            for (int p = g.b + t; p < g.e; p += HEAVY_THREADS) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
             sum = block_sum(sum, red);
-            if (t == 0) {
-                m[(int64_t)i * H + hd] = mx;
-                s[(int64_t)i * H + hd] = sum;
+            if (t == 0) { mine[hd * 2] = mx; mine[hd * 2 + 1] = sum; }
+        }
+        if (heavy_arrive(cnt, g, &flag) && t < H) {
+            float M = -3.0e38f;
+            for (int k = 0; k < g.nseg; ++k) M = fmaxf(M, ld_agent(part + ((int64_t)heavy_slot(g, k) * H + t) * 2));
+            float S = 0.f;
+            for (int k = 0; k < g.nseg; ++k) {
+                const float* pk = part + ((int64_t)heavy_slot(g, k) * H + t) * 2;
+                S += ld_agent(pk + 1) * expf(ld_agent(pk) - M);
             }
+            m[(int64_t)i * H + t] = M;
+            s[(int64_t)i * H + t] = S;
         }
     }
 }
@@ -174,24 +236,30 @@ gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __re
 // row sums of per-entry scalars for the heavy rows (see seg_rowsum_scalar_kernel below for the rest)
 __global__ void __launch_bounds__(HEAVY_THREADS)
 seg_rowsum_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
-                        const float* __restrict__ vals, const int32_t* __restrict__ map, int N, int H,
-                        float* __restrict__ out, int item_edges) {
-    __shared__ int heavy[NPI_ITEM_EDGES];
-    __shared__ int n_heavy;
+                        const float* __restrict__ vals, const int32_t* __restrict__ map, int N, int n_items, int H,
+                        float* __restrict__ out, int item_edges, float* __restrict__ part, int* __restrict__ cnt) {
     __shared__ float red[HEAVY_WAVES];
+    __shared__ int flag;
     const int t = threadIdx.x;
-    const int nh = find_heavy_rows(rowptr, item_row, N, blockIdx.x, item_edges, heavy, &n_heavy);
-    for (int q = 0; q < nh; ++q) {
-        const int r = heavy[q];
-        const int b = rowptr[r], e = rowptr[r + 1];
+    HeavySeg seg[2];
+    const int mask = heavy_segments(rowptr, item_row, N, n_items, blockIdx.x, item_edges, seg);
+    for (int q = 0; q < 2; ++q) {
+        if (!(mask & (1 << q))) continue;
+        const HeavySeg g = seg[q];
+        float* __restrict__ mine = part + (int64_t)heavy_slot(g, g.k) * H;
         for (int hd = 0; hd < H; ++hd) {
             float sum = 0.f;
-            for (int p = b + t; p < e; p += HEAVY_THREADS) {
+            for (int p = g.b + t; p < g.e; p += HEAVY_THREADS) {
                 const int64_t idx = map ? map[p] : p;
                 sum += vals[idx * H + hd];
             }
             sum = block_sum(sum, red);
-            if (t == 0) out[(int64_t)r * H + hd] = sum;
+            if (t == 0) mine[hd] = sum;
+        }
+        if (heavy_arrive(cnt, g, &flag) && t < H) {
+            float S = 0.f;
+            for (int k = 0; k < g.nseg; ++k) S += ld_agent(part + (int64_t)heavy_slot(g, k) * H + t);
+            out[(int64_t)g.row * H + t] = S;
         }
     }
 }
@@ -392,17 +460,31 @@ extern "C" int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64
     return check_launch("npi_gat_rowdot");
 }
 
+extern "C" int64_t npi_gat_heavy_workspace_elems(int64_t nnz_max, int64_t H) {
+    const int64_t items = npi_num_items(nnz_max);
+    return 4 * items * (H > 0 ? H : 1) + items + 64;      // segment partials (2 slots x 2 values per item and head), row counters
+}
+
 extern "C" int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
                                      const float* a_dst, const float* a_src, int64_t N, int64_t nnz_max, int64_t H,
-                                     float slope, float* m, float* s, void* stream_) {
+                                     float slope, float* m, float* s, float* workspace, int64_t workspace_elems,
+                                     void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && H > 0 && nnz_max >= 0, "npi_gat_softmax_stats: bad size");
+    NPI_REQUIRE(N >= 0 && H > 0 && H <= HEAVY_THREADS && nnz_max >= 0, "npi_gat_softmax_stats: bad size");
     if (N == 0) return NPI_OK;
-    NPI_REQUIRE(rowptr && item_row && a_dst && a_src && m && s, "npi_gat_softmax_stats: null pointer");
+    NPI_REQUIRE(rowptr && item_row && a_dst && a_src && m && s && workspace, "npi_gat_softmax_stats: null pointer");
+    if (workspace_elems < npi_gat_heavy_workspace_elems(nnz_max, H)) {
+        set_error("npi_gat_softmax_stats: workspace too small");
+        return NPI_ERR_WORKSPACE;
+    }
     gat_softmax_rows_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, col, a_dst, a_src, (int)N, (int)H, slope, m, s);
     const int64_t n_items = npi_num_items(nnz_max);
-    if (n_items > 0)
-        gat_softmax_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)H, slope, m, s, item_edges_for(nnz_max));
+    if (n_items > 0) {
+        int* cnt = reinterpret_cast<int*>(workspace + 4 * n_items * H);
+        (void)hipMemsetAsync(cnt, 0, (size_t)n_items * sizeof(int), stream);
+        gat_softmax_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)n_items,
+                                                                                 (int)H, slope, m, s, item_edges_for(nnz_max), workspace, cnt);
+    }
     return check_launch("npi_gat_softmax_stats");
 }
 
@@ -450,16 +532,28 @@ extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, cons
 }
 
 extern "C" int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
-                              int64_t N, int64_t nnz_max, int64_t H, float* out, void* stream_) {
+                              int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
+                              void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && H > 0 && nnz_max >= 0, "npi_seg_rowsum: bad size");
+    NPI_REQUIRE(N >= 0 && H > 0 && H <= HEAVY_THREADS && nnz_max >= 0, "npi_seg_rowsum: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && vals && out, "npi_seg_rowsum: null pointer");
     const int64_t n_items = item_row ? npi_num_items(nnz_max) : 0;
-    // rows up to 4096 entries: one wave each; longer ones: one 1024-thread workgroup each
+    if (n_items > 0) {
+        NPI_REQUIRE(workspace != nullptr, "npi_seg_rowsum: null workspace");
+        if (workspace_elems < npi_gat_heavy_workspace_elems(nnz_max, H)) {
+            set_error("npi_seg_rowsum: workspace too small");
+            return NPI_ERR_WORKSPACE;
+        }
+    }
+    // rows up to 4096 entries: one wave each; longer ones: 1024-thread workgroups over 64-item segments
     seg_rowsum_scalar_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out, n_items > 0 ? 1 : 0);
-    if (n_items > 0)
-        seg_rowsum_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)H, out, item_edges_for(nnz_max));
+    if (n_items > 0) {
+        int* cnt = reinterpret_cast<int*>(workspace + 4 * n_items * H);
+        (void)hipMemsetAsync(cnt, 0, (size_t)n_items * sizeof(int), stream);
+        seg_rowsum_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)n_items, (int)H, out,
+                                                                                item_edges_for(nnz_max), workspace, cnt);
+    }
     return check_launch("npi_seg_rowsum");
 }
 

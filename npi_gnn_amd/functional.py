@@ -372,8 +372,10 @@ class _GatConvFn(torch.autograd.Function):
               "npi_gat_scores")
         m, s = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
         d = graph.by_dst
+        n_hw = int(lib.npi_gat_heavy_workspace_elems(d.nnz_max, H))
+        hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
         check(lib.npi_gat_softmax_stats(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), ptr(a_dst), ptr(a_src), N,
-                                        d.nnz_max, H, float(slope), ptr(m), ptr(s), st), "npi_gat_softmax_stats")
+                                        d.nnz_max, H, float(slope), ptr(m), ptr(s), ptr(hws), n_hw, st), "npi_gat_softmax_stats")
         out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
         ctx.has_bias = bias is not None
@@ -404,10 +406,12 @@ class _GatConvFn(torch.autograd.Function):
                                     ptr(grad_out), grad_out.stride(0), H, C, ptr(a_dst), ptr(a_src), ptr(m), ptr(s),
                                     ptr(D), slope, ptr(dz), st), "npi_gat_edge_grad")
         g_dst, g_src = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
-        check(lib.npi_seg_rowsum(ptr(d.rowptr), ptr(d.item_row), ptr(dz), 0, N, d.nnz_max, H, ptr(g_dst), st),
+        n_hw = int(lib.npi_gat_heavy_workspace_elems(max(d.nnz_max, sr.nnz_max), H))
+        hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
+        check(lib.npi_seg_rowsum(ptr(d.rowptr), ptr(d.item_row), ptr(dz), 0, N, d.nnz_max, H, ptr(g_dst), ptr(hws), n_hw, st),
               "npi_seg_rowsum")
         check(lib.npi_seg_rowsum(ptr(sr.rowptr), ptr(sr.item_row), ptr(dz), ptr(_transpose_map(graph)), N, sr.nnz_max,
-                                 H, ptr(g_src), st), "npi_seg_rowsum")
+                                 H, ptr(g_src), ptr(hws), n_hw, st), "npi_seg_rowsum")
         # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
         dh = _gat_aggregate(graph, sr, grad_out, H, C, a_dst, a_src, m, s, slope, True,
                             g_dst=g_dst, g_src=g_src, att=att2)
