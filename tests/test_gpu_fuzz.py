@@ -1,0 +1,68 @@
+"""Randomised shapes against the oracle: CSR build bit-exact (row pointers, column / edge ids in reference
+order), aggregation in both orientations against an fp64 oracle, and the shapes that sit on the internal
+boundaries -- rows ending exactly at a 64- / 256-entry item boundary, entry counts that are exact multiples
+of the item size, all-empty graphs, one giant row."""
+import numpy as np
+import pytest
+import torch
+
+import npi_gnn_amd as npi
+from npi_gnn_amd import functional as NF
+from oracle import ref_conv as R
+from test_gpu_parity import csr_reference
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(dev, ei, N, F, loops, mean, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, F, generator=g)
+    graph = npi.CSRGraph(ei.to(dev), N, self_loops=loops)
+    for side, key, val in ((graph.by_dst, ei[1], ei[0]), (graph.by_src, ei[0], ei[1])):
+        rowptr, col, eid, rowidx = csr_reference(key, val, N, loops)
+        nnz = int(rowptr[-1])
+        assert np.array_equal(side.rowptr.cpu().numpy(), rowptr)
+        assert np.array_equal(side.col.cpu().numpy()[:nnz], col)
+        assert np.array_equal(side.eid.cpu().numpy()[:nnz], eid)
+        out = NF.segsum(graph, side, x.to(dev), mean=mean).cpu()
+        ref = torch.zeros(N, F, dtype=torch.float64)
+        if nnz:
+            ref.index_add_(0, torch.from_numpy(rowidx).long(), x.double()[torch.from_numpy(col).long()])
+        if mean:
+            ref = ref / torch.from_numpy(np.diff(rowptr)).clamp(min=1).double().view(-1, 1)
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((out.double() - ref).abs().max()) <= 2e-5 * scale, (N, ei.size(1), F, loops, mean)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_graphs(dev, seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(1, 3000))
+    E = int(rng.integers(0, 20000))
+    F = int(rng.choice([1, 7, 64, 128, 178, 256, 300]))
+    ei = torch.from_numpy(rng.integers(0, N, size=(2, E)))
+    if E and rng.random() < 0.5:
+        ei[1, : E // 2] = int(rng.integers(0, N))            # a hub target
+    if E and rng.random() < 0.3:
+        ei[0, E // 2:] = int(rng.integers(0, N))             # a hub source
+    _check(dev, ei, N, F, bool(rng.random() < 0.7), bool(rng.random() < 0.5), seed)
+
+
+@pytest.mark.parametrize("deg,N,F", [(63, 40, 128), (64, 40, 256), (255, 9, 64), (256, 9, 256), (128, 33, 178), (1, 500, 128)])
+def test_rows_on_item_boundaries(dev, deg, N, F):
+    """every row has `deg` distinct in-neighbours: with the self loop (or without) rows end exactly on item boundaries"""
+    src = torch.cat([(torch.arange(deg) + r + 1) % max(N, deg + 2) for r in range(N)])
+    dst = torch.arange(N).repeat_interleave(deg)
+    M = max(N, deg + 2)
+    ei = torch.stack([src, dst])
+    for loops in (True, False):
+        _check(dev, ei, M, F, loops, True, deg)
+
+
+def test_degenerate_graphs(dev):
+    _check(dev, torch.zeros((2, 0), dtype=torch.long), 1, 64, True, True, 0)            # one node, no edge
+    _check(dev, torch.zeros((2, 0), dtype=torch.long), 300, 256, True, False, 0)        # only self loops
+    _check(dev, torch.tensor([[0, 1, 2], [0, 1, 2]]), 3, 128, True, True, 0)            # only explicit self loops
+    ei = torch.stack([torch.arange(1, 5000), torch.zeros(4999, dtype=torch.long)])      # one giant row
+    _check(dev, ei, 5000, 128, True, True, 1)
+    _check(dev, ei.flip(0), 5000, 256, False, False, 2)                                 # one giant source row, no loops
