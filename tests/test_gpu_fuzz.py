@@ -48,7 +48,8 @@ def test_random_graphs(dev, seed):
     _check(dev, ei, N, F, bool(rng.random() < 0.7), bool(rng.random() < 0.5), seed)
 
 
-@pytest.mark.parametrize("deg,N,F", [(63, 40, 128), (64, 40, 256), (255, 9, 64), (256, 9, 256), (128, 33, 178), (1, 500, 128)])
+@pytest.mark.parametrize("deg,N,F", [(63, 40, 128), (64, 40, 256), (255, 9, 64), (256, 9, 256), (128, 33, 178), (1, 500, 128),
+                                     (255, 4200, 64), (256, 4200, 32)])        # the last two: > 2^20 entries, 256-entry items
 def test_rows_on_item_boundaries(dev, deg, N, F):
     """every row has `deg` distinct in-neighbours: with the self loop (or without) rows end exactly on item boundaries"""
     src = torch.cat([(torch.arange(deg) + r + 1) % max(N, deg + 2) for r in range(N)])
