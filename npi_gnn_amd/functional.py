@@ -55,7 +55,7 @@ _SIDE_STREAMS = {}
 def _side_stream(dev) -> "torch.cuda.Stream":
     s = _SIDE_STREAMS.get(dev)
     if s is None:
-        s = torch.cuda.Stream(device=dev)
+        s = torch.cuda.Stream(device=dev)          # (a high-priority stream made no difference)
         _SIDE_STREAMS[dev] = s
     return s
 
