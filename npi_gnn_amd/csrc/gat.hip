@@ -304,6 +304,47 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
         const int nb = min(WAVE, k1 - kb);
         const int cv = (lane < nb) ? col[kb + lane] : 0;
         const int rv = (lane < nb) ? rowidx[kb + lane] : 0;
+        if (NCH == 1 && H == 1) {
+            // One head, one chunk: 8 entries at a time.  Each lane has the partial dot product of its 4 columns for
+            // each of the 8 entries; instead of 8 full wave reductions (6 cross-lane steps each) the 8 values are
+            // reduce-SCATTERED -- every xor step halves the number of entries a lane still carries -- 4 + 2 + 1 + 3
+            // = 10 cross-lane steps, after which lane group l >> 3 holds the sum of entry (l >> 3).
+            const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+            const int e_of_lane = (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
+            for (int j = 0; j < nb; j += 8) {
+                float4 hv8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int cu = bcast_i(cv, min(j + u, nb - 1));
+                    hv8[u] = act[0] ? *reinterpret_cast<const float4*>(hfeat + (int64_t)cu * ldh + foff[0])
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    p[u] = 0.f;
+                    if (j + u < nb) {                          // wave-uniform
+                        const int i = bcast_i(rv, j + u);
+                        if (i != cur) {
+                            cur = i;
+                            dr[0] = act[0] ? *reinterpret_cast<const float4*>(dout + (int64_t)i * ldd + foff[0])
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        p[u] = dr[0].x * hv8[u].x + dr[0].y * hv8[u].y + dr[0].z * hv8[u].z + dr[0].w * hv8[u].w;
+                    }
+                }
+                float w4[4], w2[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w4[k] = (b5 ? p[k + 4] : p[k]) + __shfl_xor(b5 ? p[k] : p[k + 4], 32, WAVE);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) w2[k] = (b4 ? w4[k + 2] : w4[k]) + __shfl_xor(b4 ? w4[k] : w4[k + 2], 16, WAVE);
+                float y = (b3 ? w2[1] : w2[0]) + __shfl_xor(b3 ? w2[0] : w2[1], 8, WAVE);
+                y += __shfl_xor(y, 4, WAVE);
+                y += __shfl_xor(y, 2, WAVE);
+                y += __shfl_xor(y, 1, WAVE);
+                if ((lane & 7) == 0 && j + e_of_lane < nb) pb[j + e_of_lane] = y;
+            }
+        } else
         for (int j = 0; j < nb; j += U) {
             float4 hv[U][NCH];
 #pragma unroll
