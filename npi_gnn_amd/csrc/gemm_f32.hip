@@ -860,16 +860,17 @@ static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4)
 
 static int pick_splits(int64_t M, int64_t tiles) {
     // dW: reduction over M (nodes).  About one workgroup per CU, at least 8 k-steps each.
-    // one workgroup per CU: as fast alone as 4 per CU (8.03 vs 8.01 ms per step at C4) and it leaves room for the
-    // backward aggregation to co-run on every CU (functional.py, OVERLAP_STREAMS); NPI_DW_CTAS overrides
+    // about three workgroups per four CUs: alone as fast as 4 per CU (8.03 vs 8.01 ms per step at C4), and it leaves
+    // room for the backward aggregation to co-run on every CU (functional.py, OVERLAP_STREAMS).  Step time at C4 by
+    // workgroup count: 128: 7.50, 160-224: 7.11-7.12, 256: 7.22, 384: 7.38, 512: 7.55 ms.  NPI_DW_CTAS overrides
     static const int64_t ctas = [] {
         const char* e = getenv("NPI_DW_CTAS");
         long v = e ? atol(e) : 0;
         if (v <= 0) {
             int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) v = cus;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) v = (3 * cus) / 4;
         }
-        return (int64_t)(v > 0 ? v : 256);
+        return (int64_t)(v > 0 ? v : 192);
     }();
     int64_t want = ceil_div(ctas, tiles);
     int64_t maxs = ceil_div(M, (int64_t)BK * 8);

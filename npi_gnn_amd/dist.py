@@ -307,37 +307,42 @@ class _ShardedSageFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dagg = be.linear_bwd_data(grad_out, weight, sg.inv_cnt)
             started = _exchange_start(sg, dagg, sg.Bt)
-        # dW is independent of the dX chain.  On the GPU backend it runs (one workgroup per CU) on a side stream
-        # under the HBM-bound aggregation, as in the single-GPU layer; otherwise in line, under the exchange.
+        # dW is independent of the dX chain.  On the GPU backend it is launched here, on this stream, so that it is
+        # resident before the aggregation -- sent to a second stream -- fills the CUs (see functional._SageConvFn);
+        # other backends run everything in line.
         side = be.side_stream(grad_out) if (want_w and started is not None and hasattr(be, "side_stream")) else None
+        main = torch.cuda.current_stream(grad_out.device) if side is not None else None
+        if side is not None:
+            side.wait_stream(main)
         if want_w:
-            if side is not None:
-                main = torch.cuda.current_stream(grad_out.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
-                for t in (dw, db, agg, grad_out):
-                    if t is not None:
-                        t.record_stream(side)
-            else:
-                dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
+            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
         if started is not None:
             table, g_work, hsum, r_work = started
-            if g_work is not None:
-                g_work.wait()
-            dx = be.segsum(sg.At, table)
-            if hsum is not None:
-                if r_work is not None:
-                    r_work.wait()
-                if sg.nH:
-                    dx[sg.nL:] += hsum[: sg.nH]
-        if want_w:
+
+            def finish():
+                if g_work is not None:
+                    g_work.wait()
+                out = be.segsum(sg.At, table)
+                if hsum is not None:
+                    if r_work is not None:
+                        r_work.wait()
+                    if sg.nH:
+                        out[sg.nL:] += hsum[: sg.nH]
+                return out
             if side is not None:
-                torch.cuda.current_stream(grad_out.device).wait_stream(side)
-            if not _solo(sg.world):
-                dist.all_reduce(dw, group=sg.group)
-                if db is not None:
-                    dist.all_reduce(db, group=sg.group)
+                with torch.cuda.stream(side):
+                    dx = finish()
+                for t in (table, hsum):
+                    if t is not None:
+                        t.record_stream(side)
+                dx.record_stream(main)
+                main.wait_stream(side)
+            else:
+                dx = finish()
+        if want_w and not _solo(sg.world):
+            dist.all_reduce(dw, group=sg.group)
+            if db is not None:
+                dist.all_reduce(db, group=sg.group)
         return dx, dw, db, None
 
 

@@ -44,7 +44,7 @@ class _gemm_events:
 
 # dW = agg^T dOut (MFMA-bound, launched as ONE workgroup per CU so that it leaves wave slots, LDS and
 # registers free) runs on a side stream under the dX chain, whose aggregation is HBM-bound: the two then
-# share every CU instead of queueing.  Measured at C4: 7.86 -> 7.34 ms per step.  (With the dW grid
+# share every CU instead of queueing.  Measured at C4: 8.0 -> 7.1 ms per step.  (With the dW grid
 # filling the chip twice over, as before, the same overlap gained 1 %.)  Only for graphs large enough
 # for the kernels to outlast the stream bookkeeping; NPI_OVERLAP_STREAMS=0 turns it off.
 OVERLAP_STREAMS = os.environ.get("NPI_OVERLAP_STREAMS", "1") != "0"
@@ -199,21 +199,22 @@ class _SageConvFn(torch.autograd.Function):
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
             dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst))
             if overlap:
-                # dW is independent of the dX chain: it starts on a second HIP stream once dAgg's GEMM is
-                # through (two GEMM kernels cannot share a SIMD's registers) and shares the CUs with the
-                # HBM-bound aggregation below
+                # dW is independent of the dX chain.  It is launched on THIS stream right behind dAgg's GEMM, one
+                # workgroup per CU, so that it is resident everywhere before the aggregation -- sent to a second HIP
+                # stream -- fills the remaining wave slots; the two then share every CU.  (The other way round the
+                # aggregation wins the race, takes every register of every SIMD, and dW only starts when it is over.)
                 dev = grad_out.device
                 main = torch.cuda.current_stream(dev)
                 side = _side_stream(dev)
-                side.wait_stream(main)
+                side.wait_stream(main)                               # dAgg is complete for the side stream
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
                 with torch.cuda.stream(side):
-                    dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
-                for t in (dw, db, agg, grad_out):
-                    if t is not None:
-                        t.record_stream(side)
-            dx = segsum(graph, graph.by_src, dagg, mean=False)
-            if overlap:
+                    dx = segsum(graph, graph.by_src, dagg, mean=False)
+                dagg.record_stream(side)                             # allocated on main, read on side
+                dx.record_stream(main)                               # allocated on side, consumed on main
                 main.wait_stream(side)
+            else:
+                dx = segsum(graph, graph.by_src, dagg, mean=False)
         return dx, dw, db, None
 
 
