@@ -851,6 +851,225 @@ gemm_split_ws_kernel(SplitArgs a) {
     }
 }
 
+// ---- bf16 storage: the same persistent producer / consumer pipeline on plain bf16 MFMAs ---------------------
+// A [M, K] and C [M, N] are bf16, accumulation f32 (v_mfma_f32_32x32x16_bf16, one product per tile pair).
+// A k-step is 64 wide: a stage holds FOUR 16-wide k-blocks in the 32-byte-row image of the split kernel, so the
+// work between two hand-overs is 32 MFMAs per consumer wave; three stages.  The producer only copies
+// (global_load_dwordx4 -> ds_write_b128): the kernel is HBM-bound.  B = the weight matrix, re-laid once per call
+// into k-block-major order by bf16_blocks_kernel.
+__global__ void bf16_blocks_kernel(const uint16_t* __restrict__ B, int64_t ldb, int K, int N, int bmode,
+                                   uint16_t* __restrict__ blocks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    blocks[((int64_t)(k / SK) * N + n) * SK + (k % SK)] = bmode == 0 ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k];
+}
+
+struct Bf16Args {
+    const uint16_t* A; int64_t lda;
+    const uint16_t* Bp;      // [K/16][N][16]
+    uint16_t* C; int64_t ldc;
+    int M, N, K;
+    const uint16_t* bias;    // bf16 [N] or null
+    const float* rowscale;   // f32 [M] or null
+    int relu;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ uint32_t pack2_bf16(float x, float y) {
+    f32x2v v = {x, y};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+}
+
+template <int TN>
+__global__ void __launch_bounds__(WS_THREADS, 1)
+gemm_bf16_ws_kernel(Bf16Args a) {
+    constexpr int TM = 2;
+    constexpr int BN = 64 * TN;
+    constexpr int APL = 128 * 32, BPL = BN * 32;      // bytes of one 16-wide k-block image of A / B
+    constexpr int KB = 4;                             // k-blocks per stage (k-step 64)
+    constexpr int BUF = KB * (APL + BPL);
+    constexpr int NST = 3;
+    constexpr int NB = BN / 128;                      // 16-byte B chunks per producer thread and k-block
+    __shared__ __attribute__((aligned(16))) char lds[NST * BUF];
+    __shared__ __attribute__((aligned(16))) float bias_s[4][2][32 * TN];
+    __shared__ int full[NST], empty[NST];
+    const int t = threadIdx.x;
+    const int wave = uniform_i(t >> 6);
+    const int nk = a.K / (SK * KB);
+    TileWalk w;
+    w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n);
+    if (!w.valid()) return;
+    if (t < NST) { full[t] = 0; empty[t] = 0; }
+    __syncthreads();
+
+    if (wave >= 4) {
+        // ---------------- producer: copy ----------------
+        const int pt = t - 256;
+        // A: the 64 contiguous bytes (pt & 1) of row pt >> 1 = chunks 4 (pt & 1) .. + 3 of its 128-byte k-step;
+        // chunk c lies in k-block c >> 1, half c & 1.   B: NB chunks of every k-block.
+        const uint32_t oa = (uint32_t)(((int64_t)(pt >> 1) * a.lda) * 2 + (pt & 1) * 64);
+        const uint32_t ob = (uint32_t)pt * (16 * NB);
+        const int64_t b_blk = (int64_t)a.N * SK * 2;                 // bytes between consecutive k-blocks of Bp
+        char* la = lds + ((pt & 1) * 2) * APL + simg(pt >> 1, 0);    // chunk i of the thread: k-block (pt & 1) * 2 + (i >> 1), half i & 1
+        char* la_h = lds + ((pt & 1) * 2) * APL + simg(pt >> 1, 1);
+        char* lb0 = lds + KB * APL + (NB == 2 ? simg(pt, 0) : simg(pt >> 1, pt & 1));
+        char* lb1 = lds + KB * APL + simg(pt, 1);
+        TileWalk wl = w;
+#define NPI_BDECL(S) u32x4r S##a0, S##a1, S##a2, S##a3, S##b0, S##b1, S##b2, S##b3, S##b4, S##b5, S##b6, S##b7
+        NPI_BDECL(r0); NPI_BDECL(r1); NPI_BDECL(r2);
+#define NPI_GL(dst, off, base, IMM)                                                                    \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(off), "s"(base) : "memory")
+#define NPI_BLOAD(S)                                                                                   \
+    do {                                                                                               \
+        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.mt * 128 * a.lda + wl.kt * (SK * KB)) * 2);   \
+        const char* g0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * KB * a.N + wl.nt * BN) * (SK * 2));     \
+        const char* g1 = uniform_ptr(g0 + b_blk);                                                      \
+        const char* g2 = uniform_ptr(g0 + 2 * b_blk);                                                  \
+        const char* g3 = uniform_ptr(g0 + 3 * b_blk);                                                  \
+        NPI_GL(S##a0, oa, ga, 0); NPI_GL(S##a1, oa, ga, 16); NPI_GL(S##a2, oa, ga, 32); NPI_GL(S##a3, oa, ga, 48); \
+        NPI_GL(S##b0, ob, g0, 0); NPI_GL(S##b1, ob, g1, 0); NPI_GL(S##b2, ob, g2, 0); NPI_GL(S##b3, ob, g3, 0);     \
+        if constexpr (NB == 2) {                                                                       \
+            NPI_GL(S##b4, ob, g0, 16); NPI_GL(S##b5, ob, g1, 16); NPI_GL(S##b6, ob, g2, 16); NPI_GL(S##b7, ob, g3, 16); \
+        }                                                                                              \
+        wl.next();                                                                                     \
+    } while (0)
+#define NPI_BWAIT(S)                                                                                   \
+    do {                                                                                               \
+        if constexpr (NB == 2)                                                                         \
+            asm volatile("s_waitcnt vmcnt(24)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##a2), "+v"(S##a3), "+v"(S##b0), "+v"(S##b1), \
+                         "+v"(S##b2), "+v"(S##b3), "+v"(S##b4), "+v"(S##b5), "+v"(S##b6), "+v"(S##b7) : : "memory");   \
+        else                                                                                           \
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##a2), "+v"(S##a3), "+v"(S##b0), "+v"(S##b1), \
+                         "+v"(S##b2), "+v"(S##b3) : : "memory");                                       \
+    } while (0)
+#define NPI_BSTORE(OFF, S)                                                                             \
+    do {                                                                                               \
+        *reinterpret_cast<u32x4r*>(la + (OFF)) = S##a0;                                                \
+        *reinterpret_cast<u32x4r*>(la_h + (OFF)) = S##a1;                                              \
+        *reinterpret_cast<u32x4r*>(la + (OFF) + APL) = S##a2;                                          \
+        *reinterpret_cast<u32x4r*>(la_h + (OFF) + APL) = S##a3;                                        \
+        *reinterpret_cast<u32x4r*>(lb0 + (OFF)) = S##b0;                                               \
+        *reinterpret_cast<u32x4r*>(lb0 + (OFF) + BPL) = S##b1;                                         \
+        *reinterpret_cast<u32x4r*>(lb0 + (OFF) + 2 * BPL) = S##b2;                                     \
+        *reinterpret_cast<u32x4r*>(lb0 + (OFF) + 3 * BPL) = S##b3;                                     \
+        if constexpr (NB == 2) {                                                                       \
+            *reinterpret_cast<u32x4r*>(lb1 + (OFF)) = S##b4;                                           \
+            *reinterpret_cast<u32x4r*>(lb1 + (OFF) + BPL) = S##b5;                                     \
+            *reinterpret_cast<u32x4r*>(lb1 + (OFF) + 2 * BPL) = S##b6;                                 \
+            *reinterpret_cast<u32x4r*>(lb1 + (OFF) + 3 * BPL) = S##b7;                                 \
+        }                                                                                              \
+    } while (0)
+#define NPI_BSTEP(ST, CUR, FREE)                                                                       \
+        NPI_BLOAD(FREE);                                                                               \
+        if (round > 0) wait_ge(&empty[ST], 4 * round);                                                 \
+        NPI_BWAIT(CUR);                                                                                \
+        NPI_BSTORE((ST) * BUF, CUR);                                                                   \
+        signal(&full[ST]);                                                                             \
+        w.next();                                                                                      \
+        if (!w.valid()) break
+        NPI_BLOAD(r0);
+        NPI_BLOAD(r1);
+        for (int round = 0; w.valid(); ++round) {
+            NPI_BSTEP(0, r0, r2);
+            NPI_BSTEP(1, r1, r0);
+            NPI_BSTEP(2, r2, r1);
+        }
+#undef NPI_BSTEP
+#undef NPI_BSTORE
+#undef NPI_BWAIT
+#undef NPI_BLOAD
+#undef NPI_GL
+#undef NPI_BDECL
+        return;
+    }
+
+    // ---------------- consumer ----------------
+    const int lane = t & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int offa[TM], offb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offa[i] = simg(wm * 64 + i * 32 + li, lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offb[j] = KB * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    int tsel = 1, bias_nt = -1;
+    float rs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rs[i] = 1.f;
+    const bool relu_on = a.relu != 0;
+    int g = 0, stg = 0;
+    while (w.valid()) {
+        if (w.kt == 0) {
+            if (a.rowscale) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rs[i] = a.rowscale[w.mt * 128 + wm * 64 + i * 32 + li];
+            }
+            if (a.bias && w.nt != bias_nt) {
+                tsel ^= 1;
+                bias_nt = w.nt;
+                for (int c = lane; c < 32 * TN; c += WAVE)
+                    bias_s[wave][tsel][c] = __uint_as_float((uint32_t)a.bias[w.nt * BN + wn * (32 * TN) + c] << 16);
+            }
+        }
+        wait_ge(&full[stg], 4 * (g / NST + 1));
+        const char* st = lds + stg * BUF;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + offa[i] + kb * APL);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(st + offb[j] + kb * BPL);
+            if (kb == KB - 1) {                              // every read of the stage has been issued: hand it back
+                asm volatile("" ::: "memory");
+                signal(&empty[stg]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // transposed tile
+        }
+        ++g;
+        stg = (stg + 1 == NST) ? 0 : stg + 1;
+        if (w.kt == nk - 1) {
+            // a lane owns row li of each 32-row tile; registers 4 g .. 4 g + 3 are four consecutive columns: 8-byte stores
+            const float* __restrict__ bl = a.bias ? bias_s[wave][tsel] : nullptr;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                uint16_t* __restrict__ crow = a.C + (int64_t)(w.mt * 128 + wm * 64 + i * 32 + li) * a.ldc + w.nt * BN + wn * (32 * TN) + 4 * lh;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float4 b = bl ? *reinterpret_cast<const float4*>(bl + j * 32 + 8 * q4 + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        float v0 = fmaf(acc[i][j][4 * q4 + 0], rs[i], b.x), v1 = fmaf(acc[i][j][4 * q4 + 1], rs[i], b.y);
+                        float v2 = fmaf(acc[i][j][4 * q4 + 2], rs[i], b.z), v3 = fmaf(acc[i][j][4 * q4 + 3], rs[i], b.w);
+                        if (relu_on) {
+                            v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; v2 = v2 < 0.f ? 0.f : v2; v3 = v3 < 0.f ? 0.f : v3;
+                        }
+                        *reinterpret_cast<uint2*>(crow + j * 32 + 8 * q4) = make_uint2(pack2_bf16(v0, v1), pack2_bf16(v2, v3));
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        }
+        w.next();
+    }
+}
+
 // 0 = exact f32 MFMA, 1 = 3-way bf16 split (fwd / bwd_data interior tiles; the default, NPI_GEMM_SPLIT=0 turns it off)
 static int g_gemm_mode = [] { const char* e = getenv("NPI_GEMM_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
 
@@ -890,6 +1109,40 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     const bool wide = wide_enabled && fast_ok && a.N >= 256 && a.M >= 128;
     const int bm = 128, bn = wide ? 256 : 128;
     const int fm = fast_ok ? a.M / bm : 0, fn = fast_ok ? a.N / bn : 0;    // full tiles
+    // bf16 storage: interior tiles on the bf16 MFMA pipeline (K % 64 == 0, 16-byte aligned rows); the rest guarded
+    const bool bf16_ws = AMODE == 0 && splits == 1 && dtype_in == NPI_BF16 && dtype_out == NPI_BF16 && a.ep.colsum == nullptr &&
+                         a.K % 64 == 0 && a.N % 128 == 0 && a.M >= 128 && (a.lda % 8 == 0) && (a.ldc % 4 == 0) &&
+                         ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.C % 8 == 0) && g_gemm_mode != 0;
+    if (bf16_ws) {
+        uint16_t* blocks = nullptr;
+        const int64_t nel = (int64_t)a.N * a.K;
+        if (hipMallocAsync(reinterpret_cast<void**>(&blocks), (size_t)nel * 2, stream) != hipSuccess || blocks == nullptr) {
+            (void)hipGetLastError();
+            set_error("gemm: hipMallocAsync of the bf16 weight blocks failed");
+            return NPI_ERR_LAUNCH;
+        }
+        bf16_blocks_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(reinterpret_cast<const uint16_t*>(a.B), a.ldb, a.K, a.N, BMODE, blocks);
+        const int bfm = a.M / 128;
+        const bool wide_n = (a.N % 256 == 0);
+        const int btn = wide_n ? a.N / 256 : a.N / 128;
+        Bf16Args ba{reinterpret_cast<const uint16_t*>(a.A), a.lda, blocks, reinterpret_cast<uint16_t*>(a.C), a.ldc, a.M, a.N, a.K,
+                    reinterpret_cast<const uint16_t*>(a.ep.bias), a.ep.rowscale, a.ep.relu, bfm, btn};
+        const int64_t ntiles = (int64_t)bfm * btn;
+        const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);
+        if (wide_n) gemm_bf16_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(ba);
+        else        gemm_bf16_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(ba);
+        (void)hipFreeAsync(blocks, stream);
+        // the ragged bottom strip (M % 128 rows) goes through the guarded kernel below
+        const int tm_all = (int)ceil_div(a.M, 128), tn_all = (int)ceil_div(a.N, 128);
+        if (tm_all > bfm) {
+            GemmArgs e = a;
+            e.tm0 = bfm; e.tn0 = 0;
+            const dim3 g(tn_all, tm_all - bfm, 1);
+            if (v4) gemm_edge_kernel<AMODE, BMODE, true, bf16_t, bf16_t><<<g, GEMM_THREADS, 0, stream>>>(e);
+            else    gemm_edge_kernel<AMODE, BMODE, false, bf16_t, bf16_t><<<g, GEMM_THREADS, 0, stream>>>(e);
+        }
+        return NPI_OK;
+    }
     const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && g_gemm_mode != 0 && a.ep.colsum == nullptr &&
                        ((uintptr_t)a.C % 16 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
     if (fm > 0 && fn > 0 && split) {

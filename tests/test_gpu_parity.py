@@ -400,3 +400,26 @@ def test_training_step_is_hip_graph_capturable(dev):
     assert torch.equal(static_loss.detach(), ref_loss)
     for p, r in zip(convs.parameters(), ref):
         assert torch.equal(p.grad, r)
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 256, 256), (128 * 5 + 3, 128, 384), (4096, 64, 128), (130, 192, 128), (777, 256, 512)])
+def test_bf16_mfma_gemm_matches_f32_reference(dev, M, K, N):
+    """bf16 storage: fwd (bias, rowscale, relu) and bwd_data through gemm_bf16_ws_kernel (K % 64 == 0) against an f32
+    product of the SAME bf16-rounded inputs -- the only difference allowed is the rounding of the bf16 output."""
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    rs = torch.rand(M, generator=g)
+    dC = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    ref_f = torch.relu(rs.view(-1, 1) * (A.float() @ W.float()) + b.float())
+    ref_b = rs.view(-1, 1) * (dC.float() @ W.float().t())
+    cf = NF.linear_fwd(A.to(dev), W.to(dev), b.to(dev), rowscale=rs.to(dev), relu=True)
+    cb = NF.linear_bwd_data(dC.to(dev), W.to(dev), rs.to(dev))
+    assert cf.dtype == torch.bfloat16 and cb.dtype == torch.bfloat16
+    for got, ref in ((cf, ref_f), (cb, ref_b)):
+        err = (got.float().cpu() - ref).abs()
+        assert float((err / (ref.abs() + 1.0)).max()) < 1e-2           # one bf16 rounding of the result (2^-8)
+        assert float(err.mean()) < 2e-3 * max(1.0, float(ref.abs().mean()))
+    again = NF.linear_fwd(A.to(dev), W.to(dev), b.to(dev), rowscale=rs.to(dev), relu=True)
+    assert torch.equal(cf, again)

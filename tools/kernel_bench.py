@@ -55,7 +55,14 @@ def main():
                          ("colsum", lambda: NF.colsum(dC))):
             med, best = timeit(fn, a.rounds)
             print(f"{name:26s} median {med:8.3f} ms  min {best:8.3f} ms  {fl / (med * 1e-3) / 1e12:7.1f} TF/s(median)", flush=True)
-        del A, dC
+        Ab, dCb, Wb, bb = A.to(torch.bfloat16), dC.to(torch.bfloat16), W.to(torch.bfloat16), b.to(torch.bfloat16)
+        for name, fn in (("linear_fwd bf16", lambda: NF.linear_fwd(Ab, Wb, bb)),
+                         ("linear_bwd_data bf16", lambda: NF.linear_bwd_data(dCb, Wb, rs)),
+                         ("linear_bwd_weight bf16", lambda: NF.linear_bwd_weight(Ab, dCb, True))):
+            med, best = timeit(fn, a.rounds)
+            print(f"{name:26s} median {med:8.3f} ms  min {best:8.3f} ms  {fl / (med * 1e-3) / 1e12:7.1f} TF/s(median)  "
+                  f"{(2.0 * N * F * 2) / (med * 1e-3) / 1e9:7.0f} GB/s in+out", flush=True)
+        del A, dC, Ab, dCb
     if a.seg:
         from npi_gnn_amd.synth import bipartite_edge_index
         ei = bipartite_edge_index(N, E).to(dev)
