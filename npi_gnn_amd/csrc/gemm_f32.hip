@@ -263,9 +263,11 @@ __device__ __forceinline__ void store_tile(T* __restrict__ C, int64_t ldc, int M
     }
 }
 
-template <int AMODE, int BMODE, int TM, int TN>
+// TI: storage type of A and B (float, or bf16 converted to f32 on its way into LDS -- the dW of the bf16 path)
+template <int AMODE, int BMODE, int TM, int TN, typename TI = float>
 __global__ void __launch_bounds__(GEMM_THREADS, (TM * TN > 4) ? 1 : 2)
 gemm_fast_kernel(GemmArgs a) {
+    constexpr int ES = sizeof(TI);
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using SA = Stage<AMODE == 0, BM>;
     using SB = Stage<BMODE == 1, BN>;
@@ -283,12 +285,12 @@ gemm_fast_kernel(GemmArgs a) {
     const int nk = max(kend - kbeg, 0) / BK;                 // K % BK == 0 on this path
 
     // scalar bases, bumped per k-step; per-lane offsets are loop-invariant expressions of t
-    const char* sa = reinterpret_cast<const char*>(
-        (AMODE == 0) ? a.A + (int64_t)m0 * a.lda + kbeg : a.A + (int64_t)kbeg * a.lda + m0);
-    const char* sb = reinterpret_cast<const char*>(
-        (BMODE == 0) ? a.B + (int64_t)kbeg * a.ldb + n0 : a.B + (int64_t)n0 * a.ldb + kbeg);
-    const int64_t step_a = ((AMODE == 0) ? (int64_t)BK : (int64_t)BK * a.lda) * 4;
-    const int64_t step_b = ((BMODE == 0) ? (int64_t)BK * a.ldb : (int64_t)BK) * 4;
+    const char* sa = reinterpret_cast<const char*>(a.A) +
+        ((AMODE == 0) ? (int64_t)m0 * a.lda + kbeg : (int64_t)kbeg * a.lda + m0) * ES;
+    const char* sb = reinterpret_cast<const char*>(a.B) +
+        ((BMODE == 0) ? (int64_t)kbeg * a.ldb + n0 : (int64_t)n0 * a.ldb + kbeg) * ES;
+    const int64_t step_a = ((AMODE == 0) ? (int64_t)BK : (int64_t)BK * a.lda) * ES;
+    const int64_t step_b = ((BMODE == 0) ? (int64_t)BK * a.ldb : (int64_t)BK) * ES;
 
     // Staging registers: fully unrolled constant indices keep them in VGPRs.  readfirstlane keeps
     // the bases in SGPRs (loop strength reduction would otherwise give every load address its own
@@ -298,7 +300,7 @@ gemm_fast_kernel(GemmArgs a) {
     // loads and the LDS stores (seen in the ISA, round 1).
     static_assert(SA::NP == 4 && (SB::NP == 4 || SB::NP == 8), "staging macros below assume these counts");
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
-#define NPI_LD(P, base, S, ld) (*reinterpret_cast<const float4*>((base) + S::gl_off(t, P, ld)))
+#define NPI_LD(P, base, S, ld) ld4(reinterpret_cast<const TI*>((base) + S::gl_off(t, P, ld) / (4 / ES)))
 #define NPI_GLOAD()                                                                  \
     do {                                                                             \
         const char* ua = uniform_ptr(sa);                                            \
@@ -1102,11 +1104,12 @@ static int pick_splits(int64_t M, int64_t tiles) {
 // dtype_in: storage of A and B; dtype_out: storage of C and bias.  bf16 runs the guarded kernel only.
 template <int AMODE, int BMODE>
 static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32) {
-    const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && dtype_in == NPI_F32 && dtype_out == NPI_F32;
+    const bool bf16_in = dtype_in == NPI_BF16 && dtype_out == NPI_F32;          // dW of the bf16 path: bf16 operands, f32 slabs
+    const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && ((dtype_in == NPI_F32 && dtype_out == NPI_F32) || bf16_in);
     // 128 x 256 tile (one workgroup per CU): measured 3-10 % SLOWER than 128 x 128 at C4 (round 1:
     // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms), so it is opt-in (NPI_GEMM_WIDE=1)
     static const bool wide_enabled = [] { const char* e = getenv("NPI_GEMM_WIDE"); return e && e[0] == '1'; }();
-    const bool wide = wide_enabled && fast_ok && a.N >= 256 && a.M >= 128;
+    const bool wide = wide_enabled && fast_ok && !bf16_in && a.N >= 256 && a.M >= 128;
     const int bm = 128, bn = wide ? 256 : 128;
     const int fm = fast_ok ? a.M / bm : 0, fn = fast_ok ? a.N / bn : 0;    // full tiles
     // bf16 storage: interior tiles on the bf16 MFMA pipeline (K % 64 == 0, 16-byte aligned rows); the rest guarded
@@ -1166,8 +1169,9 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     } else if (fm > 0 && fn > 0) {
         GemmArgs f = a;
         f.tm0 = 0; f.tn0 = 0;
-        if (wide) gemm_fast_kernel<AMODE, BMODE, 2, 4><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
-        else      gemm_fast_kernel<AMODE, BMODE, 2, 2><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
+        if (bf16_in)   gemm_fast_kernel<AMODE, BMODE, 2, 2, bf16_t><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
+        else if (wide) gemm_fast_kernel<AMODE, BMODE, 2, 4><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
+        else           gemm_fast_kernel<AMODE, BMODE, 2, 2><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
     }
     // edge strips in 128 x 128 tiles
     const int tm = (int)ceil_div(a.M, 128), tn = (int)ceil_div(a.N, 128);
