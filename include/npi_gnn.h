@@ -34,7 +34,9 @@ extern "C" {
 #define NPI_ERR_WORKSPACE (-3)/* workspace too small */
 
 /* edges of the self-loop-augmented CSR that one wavefront ("item") reduces */
+#ifndef NPI_ITEM_EDGES
 #define NPI_ITEM_EDGES 256    /* large graphs; CSRs with capacity nnz_max < 2^20 use 64 (npi_item_edges) */
+#endif
 
 /* data types of feature matrices */
 #define NPI_F32 0
