@@ -158,6 +158,10 @@ int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t l
 /* out[N] = column sums of X[M,N] (GCNConv bias gradient); workspace f32, ceil(M/2048)*N elements */
 int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
                int64_t workspace_elems, void* stream);
+/* Grid regime of npi_linear_bwd_weight: 0 (default) = the kernel has the GPU to itself (~4 workgroups per CU),
+ * 1 = it shares the CUs with an HBM-bound kernel on another stream (about 3 workgroups per 4 CUs).
+ * Returns the previous value; any other argument only queries.  Process-wide. */
+int npi_dw_shared(int shared);
 int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, int64_t N);
 int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t lddc,
                           float* dW, int64_t lddw, float* db,

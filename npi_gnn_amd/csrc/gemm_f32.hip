@@ -1079,11 +1079,15 @@ static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4)
     return ((uintptr_t)p % (4 * es) == 0) && (ld % 4 == 0) && (inner_extent % 4 == 0);
 }
 
-static int pick_splits(int64_t M, int64_t tiles) {
-    // dW: reduction over M (nodes).  About one workgroup per CU, at least 8 k-steps each.
-    // about three workgroups per four CUs: alone as fast as 4 per CU (8.03 vs 8.01 ms per step at C4), and it leaves
-    // room for the backward aggregation to co-run on every CU (functional.py, OVERLAP_STREAMS).  Step time at C4 by
-    // workgroup count: 128: 7.50, 160-224: 7.11-7.12, 256: 7.22, 384: 7.38, 512: 7.55 ms.  NPI_DW_CTAS overrides
+// Workgroups of the dW GEMM (reduction over the nodes, split into slabs).  Two regimes:
+//   alone   : ~4 workgroups per CU (1,024): fastest when nothing else runs (1.30 ms at C4);
+//   shared  : about three workgroups per four CUs -- as a light resident it leaves room for the backward
+//             aggregation to co-run on every CU (functional.py, OVERLAP_STREAMS).  Step time at C4 by workgroup
+//             count: 128: 7.50, 160-224: 7.11-7.12, 256: 7.22, 384: 7.38, 512: 7.55 ms; alone that grid takes 1.77 ms.
+// The caller says which one applies (npi_dw_shared); NPI_DW_CTAS overrides the shared count.
+static int g_dw_shared = 0;
+static int64_t dw_workgroups(bool shared) {
+    if (!shared) return 1024;
     static const int64_t ctas = [] {
         const char* e = getenv("NPI_DW_CTAS");
         long v = e ? atol(e) : 0;
@@ -1093,8 +1097,11 @@ static int pick_splits(int64_t M, int64_t tiles) {
         }
         return (int64_t)(v > 0 ? v : 192);
     }();
-    int64_t want = ceil_div(ctas, tiles);
-    int64_t maxs = ceil_div(M, (int64_t)BK * 8);
+    return ctas;
+}
+static int pick_splits(int64_t M, int64_t tiles, bool shared) {
+    int64_t want = ceil_div(dw_workgroups(shared), tiles);
+    int64_t maxs = ceil_div(M, (int64_t)BK * 8);                 // at least 8 k-steps per slab
     int64_t s = want < maxs ? want : maxs;
     return (int)(s < 1 ? 1 : s);
 }
@@ -1281,18 +1288,24 @@ extern "C" int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, flo
 // dW: the contraction runs over the nodes.  Node count is arbitrary, so the part that is a
 // multiple of BK goes through `splits` slabs (fast path) and the < BK remainder through one
 // extra slab (guarded).
-static void bwd_weight_plan(int64_t M, int64_t K, int64_t N, int& splits, int& kchunk, int64_t& m_main) {
+static void bwd_weight_plan(int64_t M, int64_t K, int64_t N, bool shared, int& splits, int& kchunk, int64_t& m_main) {
     const int64_t tiles = ceil_div(K, 128) * ceil_div(N, 128);
     m_main = (M / BK) * BK;
-    splits = pick_splits(m_main > 0 ? m_main : 1, tiles);
+    splits = pick_splits(m_main > 0 ? m_main : 1, tiles, shared);
     kchunk = (int)(ceil_div(ceil_div(m_main > 0 ? m_main : 1, splits), BK) * BK);
+}
+
+extern "C" int npi_dw_shared(int shared) {
+    const int prev = g_dw_shared;
+    if (shared == 0 || shared == 1) g_dw_shared = shared;
+    return prev;
 }
 
 extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, int64_t N) {
     if (M < 0 || K <= 0 || N <= 0) return -1;
     int splits, kchunk;
     int64_t m_main;
-    bwd_weight_plan(M, K, N, splits, kchunk, m_main);
+    bwd_weight_plan(M, K, N, /*shared=*/false, splits, kchunk, m_main);          // the regime with more slabs: enough for both
     return (int64_t)(splits + 1) * K * N + (int64_t)(splits + 1) * N + 64;      // dW slabs, then db slabs
 }
 
@@ -1313,7 +1326,7 @@ extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* d
     const int es = dtype == NPI_BF16 ? 2 : 4;
     int splits, kchunk;
     int64_t m_main;
-    bwd_weight_plan(M, K, N, splits, kchunk, m_main);
+    bwd_weight_plan(M, K, N, g_dw_shared != 0, splits, kchunk, m_main);
     const int nslab = splits + 1;
     float* db_slabs = workspace + (int64_t)nslab * K * N;
     const bool v4 = vec4_ok(A, lda, K, es) && vec4_ok(dC, lddc, N, es);

@@ -211,9 +211,9 @@ class HipBackend:
         from . import functional as NF
         return NF.linear_bwd_data(dc, w, rowscale)
 
-    def linear_bwd_weight(self, a, dc, want_bias):
+    def linear_bwd_weight(self, a, dc, want_bias, shared=False):
         from . import functional as NF
-        return NF.linear_bwd_weight(a, dc, want_bias)
+        return NF.linear_bwd_weight(a, dc, want_bias, shared=shared)
 
     def side_stream(self, like):
         """second HIP stream for the weight-gradient GEMM, or None when the shard is too small to gain"""
@@ -315,7 +315,8 @@ class _ShardedSageFn(torch.autograd.Function):
         if side is not None:
             side.wait_stream(main)
         if want_w:
-            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
+            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias, shared=True) if side is not None else \
+                be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
         if started is not None:
             table, g_work, hsum, r_work = started
 

@@ -142,7 +142,8 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
     return da
 
 
-def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True):
+def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False):
+    """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid, see npi_dw_shared)."""
     dev = require_gpu(a, dc)
     a = _fc(a, "a")
     dc = _fc(dc, "dC", a)
@@ -153,6 +154,7 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True)
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     dw = torch.empty((K, N), dtype=a.dtype, device=dev)
     db = torch.empty(N, dtype=a.dtype, device=dev) if want_bias else None
+    lib.npi_dw_shared(1 if shared else 0)
     with _gemm_events("bwd_weight", 2.0 * M * K * N, dev):
         check(lib.npi_linear_bwd_weight_t(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
                                           M, K, N, ptr(ws), n_ws, _code(a), stream_ptr(dev)), "npi_linear_bwd_weight")
@@ -207,7 +209,7 @@ class _SageConvFn(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 side = _side_stream(dev)
                 side.wait_stream(main)                               # dAgg is complete for the side stream
-                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True)
                 with torch.cuda.stream(side):
                     dx = segsum(graph, graph.by_src, dagg, mean=False)
                 dagg.record_stream(side)                             # allocated on main, read on side
