@@ -1,6 +1,7 @@
 // Between-layer steps of the reference's Net_1 (reference src/classes.py:63-64,
 // 67-68, 71-72): PyG 1.4.2 TopKPooling(ratio) and the [global_max_pool || global_mean_pool] readout,
-// forward only (inference: src/methods.py:87-96, src/test.py, src/case_study*.py).
+// forward (inference: src/methods.py:87-96, src/test.py, src/case_study*.py) and backward (training:
+// src/train_with_twoDataset.PY:52-54).
 //
 //   score_i = tanh(<x_i, w> / ||w||)
 //   per graph g (nodes are contiguous per graph in a PyG Batch): keep the k_g = ceil(ratio n_g) highest
@@ -10,6 +11,8 @@
 //   readout[g] = [max_i x'_i || mean_i x'_i]
 //
 // Integer / index work is bit-exact; sums are in a fixed order (reproducible).
+#include <algorithm>
+#include <initializer_list>
 #include "npi_common.h"
 
 namespace npi {
@@ -219,22 +222,88 @@ filter_write_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__
     }
 }
 
-// readout[g] = [max over the graph's rows || mean]; one workgroup per graph, a thread per column
-__global__ void __launch_bounds__(256)
-readout_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ graph_ptr, int B, int F,
-               float* __restrict__ out /* [B, 2F] */) {
-    const int g = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= F) return;
-    const int b = graph_ptr[g], e = graph_ptr[g + 1];
-    float mx = -3.0e38f, sum = 0.f;
-    for (int i = b; i < e; ++i) {
-        const float v = x[(int64_t)i * ldx + c];
-        mx = fmaxf(mx, v);
-        sum += v;
+// Rows x column groups: a workgroup of POOL_THREADS handles one graph and `cgb` groups of VEC adjacent columns with
+// POOL_THREADS / cgb row lanes striding over the graph's rows (F = 128: 32 groups of 4 columns x 32 row lanes), so a
+// 900-row graph is ~30 independent 16-byte loads per thread instead of 900 dependent ones.  The lane partials meet in
+// LDS and are combined in lane order: the result does not depend on scheduling.
+constexpr int POOL_THREADS = 1024;
+
+template <int VEC> struct VecLoad;
+template <> struct VecLoad<1> { typedef float T; };
+template <> struct VecLoad<2> { typedef float2 T; };
+template <> struct VecLoad<4> { typedef float4 T; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
+    typename VecLoad<VEC>::T t = *reinterpret_cast<const typename VecLoad<VEC>::T*>(p);
+    const float* f = reinterpret_cast<const float*>(&t);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = f[k];
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[VEC]) {
+    typename VecLoad<VEC>::T t;
+    float* f = reinterpret_cast<float*>(&t);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) f[k] = v[k];
+    *reinterpret_cast<typename VecLoad<VEC>::T*>(p) = t;
+}
+
+// widest VEC in {4, 2, 1} that divides F and every leading dimension and keeps every base pointer aligned
+static int pool_vec(int64_t F, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
+    for (int v = 4; v > 1; v >>= 1) {
+        bool ok = F % v == 0;
+        for (int64_t l : lds) ok = ok && l % v == 0;
+        for (const void* p : ptrs) ok = ok && ((uintptr_t)p % (v * sizeof(float))) == 0;
+        if (ok) return v;
     }
-    out[(int64_t)g * 2 * F + c] = (e > b) ? mx : 0.f;
-    out[(int64_t)g * 2 * F + F + c] = sum / (float)max(e - b, 1);
+    return 1;
+}
+static int pool_groups_per_block(int64_t F, int vec) { return (int)std::min<int64_t>(ceil_div(F, vec), POOL_THREADS); }
+
+// readout[g] = [max over the graph's rows || mean over the graph's rows]; an empty graph gives zeros
+template <int VEC>
+__global__ void __launch_bounds__(POOL_THREADS)
+readout_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ graph_ptr, int B, int F, int cgb,
+               float* __restrict__ out /* [B, 2F] */) {
+    __shared__ float mx_s[POOL_THREADS * VEC];
+    __shared__ float sum_s[POOL_THREADS * VEC];
+    const int g = blockIdx.x;
+    const int lanes = POOL_THREADS / cgb;
+    const int cgi = threadIdx.x % cgb, rl = threadIdx.x / cgb;
+    const int c0 = (blockIdx.y * cgb + cgi) * VEC;
+    const int b = graph_ptr[g], e = graph_ptr[g + 1];
+    const bool live = rl < lanes && c0 < F;
+    float mx[VEC], sum[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { mx[k] = -3.0e38f; sum[k] = 0.f; }
+    if (live) {
+#pragma unroll 4
+        for (int i = b + rl; i < e; i += lanes) {
+            float v[VEC];
+            load_vec<VEC>(x + (int64_t)i * ldx + c0, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { mx[k] = fmaxf(mx[k], v[k]); sum[k] += v[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            mx_s[(rl * cgb + cgi) * VEC + k] = mx[k];
+            sum_s[(rl * cgb + cgi) * VEC + k] = sum[k];
+        }
+    }
+    __syncthreads();
+    const int cols = cgb * VEC;
+    for (int t = threadIdx.x; t < cols; t += POOL_THREADS) {
+        const int c = blockIdx.y * cols + t;
+        if (c >= F) continue;
+        float m = -3.0e38f, sm = 0.f;
+        for (int r = 0; r < lanes; ++r) {
+            m = fmaxf(m, mx_s[r * cols + t]);
+            sm += sum_s[r * cols + t];
+        }
+        out[(int64_t)g * 2 * F + c] = (e > b) ? m : 0.f;
+        out[(int64_t)g * 2 * F + F + c] = sm / (float)max(e - b, 1);
+    }
 }
 
 
@@ -278,55 +347,126 @@ topk_gather_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __
 
 // dw partials over chunks of POOLW_ROWS kept nodes: part[chunk][f] = sum_p dzv[p] x[perm[p], f]; part[chunk][F] = sum_p dzz[p]
 constexpr int POOLW_ROWS = 256;
-__global__ void __launch_bounds__(256)
+template <int VEC>
+__global__ void __launch_bounds__(POOL_THREADS)
 topk_weight_grad_partial_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ perm,
-                                const float* __restrict__ dzv, const float* __restrict__ dzz, int n_out, int F,
+                                const float* __restrict__ dzv, const float* __restrict__ dzz, int n_out, int F, int cgb,
                                 float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c > F) return;                                 // column F carries the scalar sum
-    const int pb = blockIdx.y * POOLW_ROWS, pe = min(n_out, pb + POOLW_ROWS);
-    float s = 0.f;
-    if (c < F) {
-        for (int p = pb; p < pe; ++p) s = fmaf(dzv[p], x[(int64_t)perm[p] * ldx + c], s);
-    } else {
-        for (int p = pb; p < pe; ++p) s += dzz[p];
+    __shared__ float s_s[POOL_THREADS * VEC];
+    __shared__ float z_s[POOL_THREADS];
+    const int lanes = POOL_THREADS / cgb;
+    const int cgi = threadIdx.x % cgb, rl = threadIdx.x / cgb;
+    const int c0 = (blockIdx.y * cgb + cgi) * VEC;
+    const int pb = blockIdx.x * POOLW_ROWS, pe = min(n_out, pb + POOLW_ROWS);
+    const bool live = rl < lanes && c0 < F;
+    const bool scalar = blockIdx.y == 0 && cgi == 0 && rl < lanes;      // these lanes also sum dzz (column F)
+    float s[VEC], z = 0.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+    if (live) {
+#pragma unroll 4
+        for (int p = pb + rl; p < pe; p += lanes) {
+            float v[VEC];
+            load_vec<VEC>(x + (int64_t)perm[p] * ldx + c0, v);
+            const float d = dzv[p];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s[k] = fmaf(d, v[k], s[k]);
+            if (scalar) z += dzz[p];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s_s[(rl * cgb + cgi) * VEC + k] = s[k];
     }
-    part[(int64_t)blockIdx.y * (F + 1) + c] = s;
+    if (scalar) z_s[rl] = z;
+    __syncthreads();
+    const int cols = cgb * VEC;
+    for (int t = threadIdx.x; t < cols; t += POOL_THREADS) {
+        const int c = blockIdx.y * cols + t;
+        if (c >= F) continue;
+        float acc = 0.f;
+        for (int r = 0; r < lanes; ++r) acc += s_s[r * cols + t];
+        part[(int64_t)blockIdx.x * (F + 1) + c] = acc;
+    }
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int r = 0; r < lanes; ++r) acc += z_s[r];
+        part[(int64_t)blockIdx.x * (F + 1) + F] = acc;
+    }
 }
-// dw[f] = (sum_chunks part[.][f]) / ||w|| - w[f] (sum_chunks part[.][F]) / ||w||^2, chunks in ascending order
+// dw[f] = (sum_chunks part[.][f]) / ||w|| - w[f] (sum_chunks part[.][F]) / ||w||^2
+// 64 columns x 4 chunk lanes per workgroup (the chunk loop is a chain of dependent-latency loads otherwise);
+// lanes are combined in lane order, so the sum order is fixed.
 __global__ void __launch_bounds__(256)
 topk_weight_grad_reduce_kernel(const float* __restrict__ part, int nchunks, const float* __restrict__ w, int F,
                                float* __restrict__ dw) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= F) return;
-    float nn = 0.f;
-    for (int k = 0; k < F; ++k) nn = fmaf(w[k], w[k], nn);
-    float s = 0.f, z = 0.f;
-    for (int q = 0; q < nchunks; ++q) {
-        s += part[(int64_t)q * (F + 1) + c];
-        z += part[(int64_t)q * (F + 1) + F];
+    __shared__ float s_s[4][64], z_s[4], n_s[4];
+    const int col = threadIdx.x & 63, ql = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    float s = 0.f, z = 0.f, nn = 0.f;
+    if (c < F) {
+#pragma unroll 8
+        for (int q = ql; q < nchunks; q += 4) s += part[(int64_t)q * (F + 1) + c];
     }
-    dw[c] = s / sqrtf(nn) - w[c] * z / nn;
+    for (int q = ql * 64 + col; q < nchunks; q += 256) z += part[(int64_t)q * (F + 1) + F];
+    for (int k = ql * 64 + col; k < F; k += 256) nn = fmaf(w[k], w[k], nn);
+    z = wsum(z);
+    nn = wsum(nn);
+    s_s[ql][col] = s;
+    if (col == 0) { z_s[ql] = z; n_s[ql] = nn; }
+    __syncthreads();
+    if (ql == 0 && c < F) {
+        const float st = (s_s[0][col] + s_s[1][col]) + (s_s[2][col] + s_s[3][col]);
+        const float zt = (z_s[0] + z_s[1]) + (z_s[2] + z_s[3]);
+        const float nt = (n_s[0] + n_s[1]) + (n_s[2] + n_s[3]);
+        dw[c] = st / sqrtf(nt) - w[c] * zt / nt;
+    }
 }
 
 // backward of [max || mean]: dx[i, c] = dout[g, F + c] / n_g + (i is the FIRST row of graph g with x = max ? dout[g, c] : 0)
 // (a single arg-max row takes the gradient, as torch_scatter's scatter_max backward does)
-__global__ void __launch_bounds__(256)
-readout_bwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ graph_ptr, int B, int F,
+template <int VEC>
+__global__ void __launch_bounds__(POOL_THREADS)
+readout_bwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ graph_ptr, int B, int F, int cgb,
                    const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dx, int64_t lddx) {
-    const int g = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= F) return;
+    __shared__ int first_s[POOL_THREADS * VEC];
+    const int g = blockIdx.x;
+    const int lanes = POOL_THREADS / cgb;
+    const int cgi = threadIdx.x % cgb, rl = threadIdx.x / cgb;
+    const int c0 = (blockIdx.y * cgb + cgi) * VEC;
     const int b = graph_ptr[g], e = graph_ptr[g + 1];
-    if (e <= b) return;
-    const float mx = out[(int64_t)g * 2 * F + c];
-    const float dmx = dout[(int64_t)g * 2 * F + c];
-    const float dmean = dout[(int64_t)g * 2 * F + F + c] / (float)(e - b);
-    bool found = false;
-    for (int i = b; i < e; ++i) {
-        const bool take = !found && x[(int64_t)i * ldx + c] == mx;
-        found = found || take;
-        dx[(int64_t)i * lddx + c] = dmean + (take ? dmx : 0.f);
+    if (e <= b) return;                                    // uniform over the workgroup
+    const bool live = rl < lanes && c0 < F;
+    float mx[VEC], dmx[VEC], dmean[VEC];
+    int first[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) first[k] = 0x7fffffff;
+    if (live) {
+        load_vec<VEC>(out + (int64_t)g * 2 * F + c0, mx);
+        load_vec<VEC>(dout + (int64_t)g * 2 * F + c0, dmx);
+        load_vec<VEC>(dout + (int64_t)g * 2 * F + F + c0, dmean);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dmean[k] /= (float)(e - b);
+#pragma unroll 4
+        for (int i = b + rl; i < e; i += lanes) {          // first row of this lane's stride that holds the maximum
+            float v[VEC];
+            load_vec<VEC>(x + (int64_t)i * ldx + c0, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) first[k] = (v[k] == mx[k]) ? min(first[k], i) : first[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) first_s[(rl * cgb + cgi) * VEC + k] = first[k];
+    }
+    __syncthreads();
+    if (!live) return;
+    for (int r = 0; r < lanes; ++r) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) first[k] = min(first[k], first_s[(r * cgb + cgi) * VEC + k]);
+    }
+#pragma unroll 4
+    for (int i = b + rl; i < e; i += lanes) {
+        float v[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = dmean[k] + (i == first[k] ? dmx[k] : 0.f);
+        store_vec<VEC>(dx + (int64_t)i * lddx + c0, v);
     }
 }
 
@@ -444,7 +584,12 @@ extern "C" int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* 
     NPI_REQUIRE(B >= 0 && F > 0, "npi_readout_max_mean: bad size");
     if (B == 0) return NPI_OK;
     NPI_REQUIRE(x && graph_ptr && out, "npi_readout_max_mean: null pointer");
-    readout_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)B), 256, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, out);
+    const int vec = pool_vec(F, {ldx}, {x});
+    const int cgb = pool_groups_per_block(F, vec);
+    const dim3 grid((unsigned)B, (unsigned)ceil_div(ceil_div(F, vec), cgb));
+    if (vec == 4) readout_kernel<4><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out);
+    else if (vec == 2) readout_kernel<2><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out);
+    else readout_kernel<1><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out);
     return check_launch("npi_readout_max_mean");
 }
 
@@ -475,9 +620,16 @@ extern "C" int npi_topk_weight_grad(const float* x, int64_t ldx, const int32_t* 
         return NPI_ERR_WORKSPACE;
     }
     const int nchunks = (int)ceil_div(n_out > 0 ? n_out : 1, POOLW_ROWS);
-    topk_weight_grad_partial_kernel<<<dim3((unsigned)ceil_div(F + 1, 256), (unsigned)nchunks), 256, 0, stream>>>(
-        x, ldx, perm, dzv, dzz, (int)n_out, (int)F, workspace);
-    topk_weight_grad_reduce_kernel<<<(unsigned)ceil_div(F, 256), 256, 0, stream>>>(workspace, nchunks, w, (int)F, dw);
+    const int vec = pool_vec(F, {ldx}, {x});
+    const int cgb = pool_groups_per_block(F, vec);
+    const dim3 grid((unsigned)nchunks, (unsigned)ceil_div(ceil_div(F, vec), cgb));
+    if (vec == 4)
+        topk_weight_grad_partial_kernel<4><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, perm, dzv, dzz, (int)n_out, (int)F, cgb, workspace);
+    else if (vec == 2)
+        topk_weight_grad_partial_kernel<2><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, perm, dzv, dzz, (int)n_out, (int)F, cgb, workspace);
+    else
+        topk_weight_grad_partial_kernel<1><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, perm, dzv, dzz, (int)n_out, (int)F, cgb, workspace);
+    topk_weight_grad_reduce_kernel<<<(unsigned)ceil_div(F, 64), 256, 0, stream>>>(workspace, nchunks, w, (int)F, dw);
     return check_launch("npi_topk_weight_grad");
 }
 
@@ -487,8 +639,15 @@ extern "C" int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32
     NPI_REQUIRE(B >= 0 && F > 0, "npi_readout_max_mean_bwd: bad size");
     if (B == 0) return NPI_OK;
     NPI_REQUIRE(x && graph_ptr && out && dout && dx, "npi_readout_max_mean_bwd: null pointer");
-    readout_bwd_kernel<<<dim3((unsigned)ceil_div(F, 256), (unsigned)B), 256, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, out,
-                                                                                          dout, dx, lddx);
+    const int vec = pool_vec(2 * F, {ldx, lddx, F}, {x, dx, out, dout});
+    const int cgb = pool_groups_per_block(F, vec);
+    const dim3 grid((unsigned)B, (unsigned)ceil_div(ceil_div(F, vec), cgb));
+    if (vec == 4)
+        readout_bwd_kernel<4><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx);
+    else if (vec == 2)
+        readout_bwd_kernel<2><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx);
+    else
+        readout_bwd_kernel<1><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx);
     return check_launch("npi_readout_max_mean_bwd");
 }
 

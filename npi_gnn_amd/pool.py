@@ -60,15 +60,7 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     status = torch.empty(1, **i32)
     check(lib.npi_topk_select(ptr(score), ptr(gp), N, B, float(ratio), ptr(out_ptr), ptr(perm), ptr(remap),
                               ptr(status), st), "npi_topk_select")
-    # sizes of the outputs are data dependent: one device read, as PyG's own implementation has
-    n_out = int(out_ptr[-1].item()) if B else 0
-    if int(status.item()) & 2:
-        raise NotImplementedError("TopKPooling: a graph has more than 16384 nodes")
-    xo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
-    batch_o = torch.empty(n_out, dtype=torch.int64, device=dev)
-    score_o = torch.empty(n_out, dtype=torch.float32, device=dev)
-    check(lib.npi_topk_gather(ptr(x), x.stride(0), ptr(score), ptr(batch.contiguous()), ptr(perm), ptr(out_ptr), B, F,
-                              n_out, ptr(xo), xo.stride(0), ptr(batch_o), ptr(score_o), st), "npi_topk_gather")
+    # filter_adj needs only the old->new id map, so it runs before the sizes are known
     E = edge_index.size(1)
     src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
     out_ei = torch.empty((2, max(E, 1)), dtype=torch.int64, device=dev)
@@ -76,8 +68,16 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     ws = torch.empty(int(lib.npi_filter_adj_workspace_elems(E)), **i32)
     check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
           "npi_filter_adj")
-    e_out = int(count.item())
-    return (xo, out_ei[:, :e_out].contiguous(), None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
+    # sizes of the outputs are data dependent: ONE device read per pooling layer (PyG's own implementation has several)
+    n_out, flags, e_out = torch.cat([out_ptr[-1:], status, count]).tolist() if B else (0, 0, 0)
+    if flags & 2:
+        raise NotImplementedError("TopKPooling: a graph has more than 16384 nodes")
+    xo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
+    batch_o = torch.empty(n_out, dtype=torch.int64, device=dev)
+    score_o = torch.empty(n_out, dtype=torch.float32, device=dev)
+    check(lib.npi_topk_gather(ptr(x), x.stride(0), ptr(score), ptr(batch.contiguous()), ptr(perm), ptr(out_ptr), B, F,
+                              n_out, ptr(xo), xo.stride(0), ptr(batch_o), ptr(score_o), st), "npi_topk_gather")
+    return (xo, out_ei[:, :e_out], None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
 
 
 class _TopKPoolFn(torch.autograd.Function):

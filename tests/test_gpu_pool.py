@@ -153,6 +153,53 @@ def test_readout_backward_matches_oracle_autograd(dev):
     assert torch.allclose(xg2.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("sizes,F,view", [
+    ((9, 1, 33, 120), 128, False),          # 16-byte column groups
+    ((2500, 0, 3, 1100), 128, False),       # graphs longer than the row lanes, an empty graph in the middle
+    ((40, 17), 178, False),                 # F = 178: 8-byte groups
+    ((40, 17, 5), 7, False),                # odd width: scalar columns
+    ((64, 31), 128, True),                  # a column view of a wider matrix: rows not 16-byte aligned
+    ((5, 6), 1300, False),                  # more column groups than one workgroup holds
+])
+def test_readout_forward_backward_shapes(dev, sizes, F, view):
+    g = torch.Generator().manual_seed(17)
+    batch = torch.cat([torch.full((n,), b, dtype=torch.long) for b, n in enumerate(sizes)])
+    nb = len(sizes)
+    N = batch.numel()
+    wide = torch.randn(N, F + 1, generator=g)
+    x = wide[:, 1:].contiguous()
+    go = torch.randn(nb, 2 * F, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = R.readout(xr, batch, nb)
+    (ref * go).sum().backward()
+    if view:
+        wd = wide.clone()
+        wd[:, 1:] = x
+        xg = wd.to(dev)[:, 1:].requires_grad_(True)
+    else:
+        xg = x.to(dev).requires_grad_(True)
+    out = NP.global_max_mean_pool(xg, batch.to(dev), nb)
+    full = torch.tensor([n > 0 for n in sizes])
+    assert torch.allclose(out.detach().cpu()[full], ref.detach()[full], atol=2e-6, rtol=1e-5)
+    assert float(out.detach().cpu()[~full].abs().sum()) == 0.0      # an empty graph reads out zeros, as torch_scatter fills
+    (out * go.to(dev)).sum().backward()
+    assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-5)
+
+
+def test_readout_max_gradient_goes_to_the_first_of_tied_rows(dev):
+    """torch_scatter's scatter_max backward routes the gradient to ONE arg-max row; ties resolve to the lowest row."""
+    x = torch.randn(700, 128, generator=torch.Generator().manual_seed(2))
+    x[650] = x.max(dim=0).values + 1.0                            # the column maxima, three times
+    x[40] = x[650]
+    x[333] = x[650]
+    batch = torch.zeros(700, dtype=torch.long)
+    xg = x.to(dev).requires_grad_(True)
+    NP.global_max_pool(xg, batch.to(dev), 1).sum().backward()
+    expect = torch.zeros_like(x)
+    expect[40] = 1.0
+    assert torch.equal(xg.grad.cpu(), expect)
+
+
 def test_net1_training_step_gradients_match_oracle(dev):
     """One step of the reference's train loop (src/train_with_twoDataset.PY:49-55: nll_loss on the
     log-softmax output, backward) on the RPI369 fold-0 batch with the reference checkpoint: every

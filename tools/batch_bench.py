@@ -47,6 +47,7 @@ def timeit(fn, n=20, sync=None):
 
 
 def main():
+    train_only = "--train-only" in sys.argv       # for rocprofv3: only the training step, 30 + 3 iterations
     dev = torch.device("cuda:0")
     x, ei, batch = make_batch()
     N, E = x.size(0), ei.size(1)
@@ -62,6 +63,12 @@ def main():
         xd.grad = None
         conv.zero_grad()
         conv(xd, eid).backward(god)
+    if not train_only:
+        small_parts(gpu_layer, x, ei, W, b, go, E, conv, xd, eid, god, N)
+    net1_parts(dev, x, ei, batch, xd, eid, train_only)
+
+
+def small_parts(gpu_layer, x, ei, W, b, go, E, conv, xd, eid, god, N):
     t_gpu = timeit(gpu_layer, 50, torch.cuda.synchronize)
     t_cpu = timeit(lambda: R.sage_layer_fwd_bwd(x, ei, W, b, go), 5)
     print(f"conv1 fwd+bwd incl. CSR build: GPU {t_gpu:.3f} ms ({E / t_gpu / 1e3:.1f} M edges/s)   "
@@ -76,6 +83,8 @@ def main():
     print(f"conv1 fwd+bwd, prebuilt CSR:   GPU {timeit(gpu_layer_prebuilt, 50, torch.cuda.synchronize):.3f} ms")
     print(f"CSRGraph build (both sides):   GPU {timeit(lambda: npi.CSRGraph(eid, N).by_src, 50, torch.cuda.synchronize):.3f} ms")
 
+
+def net1_parts(dev, x, ei, batch, xd, eid, train_only):
     # whole Net_1 inference
     sd = {f"conv{k}.weight": torch.randn(178 if k == 1 else 128, 128) * 0.1 for k in (1, 2, 3)}
     sd.update({f"conv{k}.bias": torch.zeros(128) for k in (1, 2, 3)})
@@ -96,12 +105,13 @@ def main():
             z = F.relu(F.linear(acc, sdd["lin1.weight"], sdd["lin1.bias"]))
             z = F.relu(F.linear(z, sdd["lin2.weight"], sdd["lin2.bias"]))
             return F.log_softmax(F.linear(z, sdd["lin3.weight"], sdd["lin3.bias"]), -1)
-    ref = R.net1_forward(sd, x, ei, batch, 200)
-    out = gpu_net1().cpu()
-    print("Net_1 forward GPU vs oracle max |d logp| =", float((out - ref).abs().max()))
-    t_gpu = timeit(gpu_net1, 30, torch.cuda.synchronize)
-    t_cpu = timeit(lambda: R.net1_forward(sd, x, ei, batch, 200), 5)
-    print(f"Net_1 inference per batch: GPU {t_gpu:.3f} ms   CPU oracle {t_cpu:.1f} ms")
+    if not train_only:
+        ref = R.net1_forward(sd, x, ei, batch, 200)
+        out = gpu_net1().cpu()
+        print("Net_1 forward GPU vs oracle max |d logp| =", float((out - ref).abs().max()))
+        t_gpu = timeit(gpu_net1, 30, torch.cuda.synchronize)
+        t_cpu = timeit(lambda: R.net1_forward(sd, x, ei, batch, 200), 5)
+        print(f"Net_1 inference per batch: GPU {t_gpu:.3f} ms   CPU oracle {t_cpu:.1f} ms")
 
     # whole Net_1 TRAINING step (reference src/train_with_twoDataset.PY:49-55: forward, nll_loss, backward, Adam)
     y = torch.randint(0, 2, (200,))
@@ -137,7 +147,7 @@ def main():
         F.nll_loss(net1(pc, x, ei, batch, False), y).backward()
         oc.step()
     t_gpu = timeit(gpu_train, 30, torch.cuda.synchronize)
-    t_cpu = timeit(cpu_train, 5)
+    t_cpu = float("nan") if train_only else timeit(cpu_train, 5)
     print(f"Net_1 training step per batch (fwd + loss + bwd + Adam): GPU {t_gpu:.3f} ms   CPU oracle {t_cpu:.1f} ms")
 
 
