@@ -30,6 +30,7 @@ constexpr int RADIX = 256;
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+static_assert(SCAN_THREADS == SORT_THREADS && SORT_THREADS == 256, "one thread per radix digit");
 
 // key = key node, or N (sentinel, sorts behind every row) for dropped columns
 __global__ void make_keys_kernel(const int64_t* __restrict__ key_nodes,
@@ -123,6 +124,11 @@ scan_add_kernel(int32_t* __restrict__ data, int64_t n, const int32_t* __restrict
 }
 
 // ---- stable scatter of one radix pass ----------------------------------------------------------
+// SCANNED: `offsets` is the exclusive scan of the digit-major tile histograms (three scan launches before this one).
+// !SCANNED (at most SMALL_SORT_TILES tiles -- the reference's 200-subgraph batches, launch-bound): `offsets` holds the
+// raw histograms and every workgroup derives its own start offsets from them, two launches per pass instead of five.
+constexpr int SMALL_SORT_TILES = 64;
+template <bool SCANNED>
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out,
@@ -163,7 +169,21 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const int32_t* __rest
     __syncthreads();
     {   // thread d owns digit d: turn per-wave counts into global start offsets
         int d = threadIdx.x;
-        int off = offsets[(int64_t)d * nblocks + blockIdx.x];
+        int off;
+        if (SCANNED) {
+            off = offsets[(int64_t)d * nblocks + blockIdx.x];
+        } else {
+            __shared__ int scan_s[SCAN_THREADS];
+            const int32_t* __restrict__ h = offsets + (int64_t)d * nblocks;
+            int total = 0, before = 0;
+            for (int t = 0; t < nblocks; ++t) {
+                const int c = h[t];
+                before += (t < (int)blockIdx.x) ? c : 0;
+                total += c;
+            }
+            int all;
+            off = block_exclusive_scan(total, scan_s, &all) + before;   // keys with a smaller digit + same digit in earlier tiles
+        }
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) {
             int c = wcnt[w][d];
@@ -184,44 +204,40 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const int32_t* __rest
     }
 }
 
-// rowptr0[r] = first sorted position with key >= r, r in [0, N]
-__global__ void row_bounds_kernel(const uint32_t* __restrict__ keys, int64_t E, int64_t N,
-                                  int32_t* __restrict__ rowptr0) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > N) return;
+__device__ __forceinline__ int64_t first_key_at_least(const uint32_t* __restrict__ keys, int64_t E, int64_t r) {
     int64_t lo = 0, hi = E;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
         if (keys[mid] < (uint32_t)r) lo = mid + 1; else hi = mid;
     }
-    rowptr0[r] = (int32_t)lo;
+    return lo;
 }
 
-__global__ void fill_entries_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                    const int64_t* __restrict__ val_nodes, int64_t E, int64_t N,
-                                    int loops, int32_t* __restrict__ col, int32_t* __restrict__ eid,
-                                    int32_t* __restrict__ rowidx) {
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= E) return;
-    uint32_t k = keys[p];
-    if (k >= (uint32_t)N) return;
-    int32_t e = vals[p];
-    int64_t q = p + (loops ? (int64_t)k : 0);
-    col[q] = (int32_t)val_nodes[e];
-    if (eid) eid[q] = e;
-    if (rowidx) rowidx[q] = (int32_t)k;
-}
-
-__global__ void fill_rows_kernel(const int32_t* __restrict__ rowptr0, int64_t N, int loops,
-                                 int32_t loop_col_offset,
-                                 int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
-                                 int32_t* __restrict__ eid, int32_t* __restrict__ rowidx) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// One launch writes the whole CSR from the sorted (key, column) stream.
+// Workgroups [0, entry_blocks): entry p of the sorted stream lands at p (+ key when every row gets a self loop behind it).
+// Workgroups behind them: row r -- rowptr[r] = first sorted position with key >= r (+ r), and the appended self loop.
+__global__ void __launch_bounds__(256)
+fill_csr_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                const int64_t* __restrict__ val_nodes, int64_t E, int64_t N, int loops, int32_t loop_col_offset,
+                unsigned entry_blocks, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                int32_t* __restrict__ eid, int32_t* __restrict__ rowidx) {
+    if (blockIdx.x < entry_blocks) {
+        int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (p >= E) return;
+        uint32_t k = keys[p];
+        if (k >= (uint32_t)N) return;
+        int32_t e = vals[p];
+        int64_t q = p + (loops ? (int64_t)k : 0);
+        col[q] = (int32_t)val_nodes[e];
+        if (eid) eid[q] = e;
+        if (rowidx) rowidx[q] = (int32_t)k;
+        return;
+    }
+    int64_t r = (int64_t)(blockIdx.x - entry_blocks) * 256 + threadIdx.x;
     if (r > N) return;
-    int32_t add = loops ? (int32_t)r : 0;
-    rowptr[r] = rowptr0[r] + add;
+    rowptr[r] = (int32_t)(first_key_at_least(keys, E, r) + (loops ? r : 0));
     if (loops && r < N) {
-        int64_t q = (int64_t)rowptr0[r + 1] + r;     // last entry of row r
+        int64_t q = first_key_at_least(keys, E, r + 1) + r;     // behind the last entry of row r
         col[q] = (int32_t)r + loop_col_offset;
         if (eid) eid[q] = -1;
         if (rowidx) rowidx[q] = (int32_t)r;
@@ -262,7 +278,7 @@ __global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
 
 struct SortLayout {
     int64_t nblocks, counts_len, ntiles;
-    int64_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_counts, off_tiles, off_rowptr0, total;
+    int64_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_counts, off_tiles, total;
 };
 
 static SortLayout sort_layout(int64_t E, int64_t N) {
@@ -279,7 +295,6 @@ static SortLayout sort_layout(int64_t E, int64_t N) {
     L.off_vals_b = take(Ee * 4);
     L.off_counts = take(L.counts_len * 4);
     L.off_tiles = take(L.ntiles * 4);
-    L.off_rowptr0 = take((N + 1) * 4);
     L.total = o;
     return L;
 }
@@ -334,7 +349,6 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
     int32_t* vals_b = (int32_t*)(ws + L.off_vals_b);
     int32_t* counts = (int32_t*)(ws + L.off_counts);
     int32_t* tiles = (int32_t*)(ws + L.off_tiles);
-    int32_t* rowptr0 = (int32_t*)(ws + L.off_rowptr0);
 
     (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
     if (E > 0) {
@@ -345,18 +359,21 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
         for (int p = 0; p < passes; ++p) {
             int shift = 8 * p;
             radix_hist_kernel<<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, E, shift, (int)L.nblocks, counts);
-            scan_tiles_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
-            scan_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(tiles, L.ntiles);
-            scan_add_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
-            radix_scatter_kernel<<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, E, shift, (int)L.nblocks, counts);
+            if (L.nblocks <= SMALL_SORT_TILES) {
+                radix_scatter_kernel<false><<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, E, shift, (int)L.nblocks, counts);
+            } else {
+                scan_tiles_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
+                scan_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(tiles, L.ntiles);
+                scan_add_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
+                radix_scatter_kernel<true><<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, E, shift, (int)L.nblocks, counts);
+            }
             uint32_t* tk = keys_a; keys_a = keys_b; keys_b = tk;
             int32_t* tv = vals_a; vals_a = vals_b; vals_b = tv;
         }
     }
-    row_bounds_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(keys_a, E, N, rowptr0);
-    if (E > 0)
-        fill_entries_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(keys_a, vals_a, val_nodes, E, N, add_self_loops, col, eid, rowidx);
-    fill_rows_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(rowptr0, N, add_self_loops, (int32_t)loop_col_offset, rowptr, col, eid, rowidx);
+    const unsigned entry_blocks = (unsigned)ceil_div(E, 256);
+    fill_csr_kernel<<<entry_blocks + (unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(
+        keys_a, vals_a, val_nodes, E, N, add_self_loops, (int32_t)loop_col_offset, entry_blocks, rowptr, col, eid, rowidx);
     const int64_t nnz_max = E + (add_self_loops ? N : 0);
     int64_t n_items = npi_num_items(nnz_max);
     item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, item_edges_for(nnz_max), item_row);

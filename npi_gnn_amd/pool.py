@@ -34,6 +34,9 @@ def graph_ptr(batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Te
     if batch.dtype != torch.int64:
         raise TypeError("batch must be a LongTensor")
     N = batch.numel()
+    known = getattr(batch, "_npi_graph_ptr", None)          # left by topk_pool on the batch vector it produced
+    if known is not None and (num_graphs is None or int(num_graphs) == known.numel() - 1):
+        return known
     B = int(num_graphs) if num_graphs is not None else (int(batch[-1].item()) + 1 if N else 0)
     gp = torch.empty(B + 1, dtype=torch.int32, device=dev)
     check(load().npi_graph_bounds(ptr(batch.contiguous()), N, B, ptr(gp), stream_ptr(dev)), "npi_graph_bounds")
@@ -77,6 +80,9 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     score_o = torch.empty(n_out, dtype=torch.float32, device=dev)
     check(lib.npi_topk_gather(ptr(x), x.stride(0), ptr(score), ptr(batch.contiguous()), ptr(perm), ptr(out_ptr), B, F,
                               n_out, ptr(xo), xo.stride(0), ptr(batch_o), ptr(score_o), st), "npi_topk_gather")
+    # the kept-row offsets ARE the segment starts of the pooled batch vector: the readout and the next pooling
+    # layer take them from here instead of searching `batch_o` again
+    batch_o._npi_graph_ptr = out_ptr
     return (xo, out_ei[:, :e_out], None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
 
 

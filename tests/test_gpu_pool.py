@@ -186,6 +186,17 @@ def test_readout_forward_backward_shapes(dev, sizes, F, view):
     assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-5)
 
 
+def test_pooled_batch_carries_its_segment_starts(dev):
+    """topk_pool leaves the kept-row offsets on the batch vector it returns; they must equal a fresh search."""
+    x, ei, batch, w = _batch_case(4, (7, 0, 30, 2, 65, 1), 128)
+    _, _, _, bo, _, _ = NP.topk_pool(x.to(dev), ei.to(dev), batch.to(dev), w.to(dev), 0.5, num_graphs=6)
+    carried = NP.graph_ptr(bo, 6)
+    fresh = NP.graph_ptr(bo.clone(), 6)
+    assert carried is getattr(bo, "_npi_graph_ptr")
+    assert torch.equal(carried.cpu(), fresh.cpu())
+    assert torch.equal(NP.graph_ptr(bo, 9).cpu()[:7], fresh.cpu())     # another graph count: searched again
+
+
 def test_readout_max_gradient_goes_to_the_first_of_tied_rows(dev):
     """torch_scatter's scatter_max backward routes the gradient to ONE arg-max row; ties resolve to the lowest row."""
     x = torch.randn(700, 128, generator=torch.Generator().manual_seed(2))
