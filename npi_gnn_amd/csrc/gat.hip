@@ -69,27 +69,81 @@ gat_rowdot_kernel(const float* __restrict__ a, int64_t lda, const float* __restr
 // ---- segment softmax statistics: m[i,h] = max_p e_p, s[i,h] = sum_p exp(e_p - m) -------------------
 constexpr int GAT_HEAVY = 4096;      // rows longer than this go to the workgroup-per-row kernel
 
+// LG lanes per row, WAVE / LG rows per wave: the typical row of these graphs has ~20 entries (an ncRNA with its
+// partners and its self loop), a third of a wavefront.  Rows much longer than the group (a protein) are then taken
+// by the whole wave, one after the other; rows above GAT_HEAVY belong to the segment kernel.
+template <int LG> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LG / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+template <int LG> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = LG / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+constexpr int GROUP_WIDE = 8;        // a row longer than GROUP_WIDE * LG entries is worth the whole wave
+
+static int row_group_lanes(int64_t nnz_max, int64_t N) {
+    const int64_t avg = nnz_max / (N > 0 ? N : 1);
+    return avg <= 12 ? 8 : avg <= 24 ? 16 : avg <= 48 ? 32 : 64;
+}
+
+// (max, sum of exp(. - max)) of row i, head hd, over entries [b, e) with lanes gl, gl + LG, ...
+template <int LG>
+__device__ __forceinline__ void softmax_row(const int32_t* __restrict__ col, const float* __restrict__ a_src, int H, int hd,
+                                            float ad, int b, int e, int gl, float slope, float& mx, float& sum) {
+    // the lane's first entry stays in a register: rows that fit the group (most of them) gather a_src once, not twice
+    const bool has0 = b + gl < e;
+    const float z0 = has0 ? lrelu_(ad + a_src[(int64_t)col[b + gl] * H + hd], slope) : -3.0e38f;
+    mx = z0;
+    for (int p = b + gl + LG; p < e; p += LG) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
+    mx = group_max<LG>(mx);
+    if (e == b) mx = 0.f;
+    sum = has0 ? expf(z0 - mx) : 0.f;
+    for (int p = b + gl + LG; p < e; p += LG) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
+    sum = group_sum<LG>(sum);
+}
+
+template <int LG>
 __global__ void __launch_bounds__(256)
 gat_softmax_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                         const float* __restrict__ a_dst, const float* __restrict__ a_src, int N, int H,
                         float slope, float* __restrict__ m, float* __restrict__ s) {
+    constexpr int G = WAVE / LG;
     const int lane = lane_id();
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= N) return;
-    const int b = rowptr[i], e = rowptr[i + 1];
-    if (e - b > GAT_HEAVY) return;
-    for (int hd = 0; hd < H; ++hd) {
-        const float ad = a_dst[(int64_t)i * H + hd];
-        float mx = -3.0e38f;
-        for (int p = b + lane; p < e; p += WAVE) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
-        mx = wave_max(mx);
-        if (e == b) mx = 0.f;
-        float sum = 0.f;
-        for (int p = b + lane; p < e; p += WAVE) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
-        sum = wave_sum(sum);
-        if (lane == 0) {
-            m[(int64_t)i * H + hd] = mx;
-            s[(int64_t)i * H + hd] = sum;
+    const int grp = lane / LG, gl = lane % LG;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
+    if (row0 >= N) return;
+    const int i = row0 + grp;
+    const bool have = i < N;
+    const int b = have ? rowptr[i] : 0, e = have ? rowptr[i + 1] : 0;
+    const bool heavy = e - b > GAT_HEAVY;
+    const bool wide = LG < WAVE && !heavy && e - b > GROUP_WIDE * LG;
+    if (have && !heavy && !wide) {
+        for (int hd = 0; hd < H; ++hd) {
+            float mx, sum;
+            softmax_row<LG>(col, a_src, H, hd, a_dst[(int64_t)i * H + hd], b, e, gl, slope, mx, sum);
+            if (gl == 0) {
+                m[(int64_t)i * H + hd] = mx;
+                s[(int64_t)i * H + hd] = sum;
+            }
+        }
+    }
+    if (LG < WAVE) {
+        uint64_t todo = __ballot(wide && gl == 0);
+        while (todo) {                                     // wave-uniform
+            const int from = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const int wb = __shfl(b, from, WAVE), we = __shfl(e, from, WAVE), wi = __shfl(i, from, WAVE);
+            for (int hd = 0; hd < H; ++hd) {
+                float mx, sum;
+                softmax_row<WAVE>(col, a_src, H, hd, a_dst[(int64_t)wi * H + hd], wb, we, lane, slope, mx, sum);
+                if (lane == 0) {
+                    m[(int64_t)wi * H + hd] = mx;
+                    s[(int64_t)wi * H + hd] = sum;
+                }
+            }
         }
     }
 }
@@ -105,6 +159,7 @@ gat_softmax_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __res
 constexpr int HEAVY_THREADS = 1024;
 constexpr int HEAVY_WAVES = HEAVY_THREADS / WAVE;
 constexpr int HEAVY_SEG_ITEMS = 64;
+constexpr int HEAVY_GRID = 2048;     // workgroups walking the segment list (8 per CU)
 
 struct HeavySeg {
     int row, b, e;      // row and entry range of the segment
@@ -154,6 +209,43 @@ __device__ __forceinline__ int heavy_slot(const HeavySeg& g, int k) {          /
     return k == 0 ? 2 * g.fi : 2 * (g.fi + k * HEAVY_SEG_ITEMS) + 1;
 }
 
+// The heavy segments of a CSR are few (a row needs > GAT_HEAVY entries): a scout launch -- one THREAD per item --
+// lists them as item * 2 + q, and the 1024-thread kernels run over that list instead of over every item
+// (82 k mostly idle workgroups at C4 before: 0.3-0.5 ms per launch of pure dispatch).  The order of the list is
+// whatever the atomics make it; it does not matter: every segment writes its own slot and the fold order is fixed.
+__host__ __device__ inline int64_t heavy_list_capacity(int64_t nnz_max) {
+    const int64_t ie = item_edges_for(nnz_max);
+    const int64_t items = (nnz_max + ie - 1) / ie;
+    const int64_t bound = nnz_max / (HEAVY_SEG_ITEMS * ie) + 2 * (nnz_max / GAT_HEAVY) + 4;   // sum over heavy rows of (len / span + 2)
+    return bound < 2 * items ? bound : 2 * items;
+}
+__global__ void __launch_bounds__(256)
+heavy_list_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row, int N, int n_items, int item_edges,
+                  int capacity, int* __restrict__ cnt, int* __restrict__ count, int* __restrict__ list) {
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= n_items) return;
+    cnt[item] = 0;                                         // the per-row arrival counters (indexed by first item)
+    HeavySeg seg[2];
+    const int mask = heavy_segments(rowptr, item_row, N, n_items, item, item_edges, seg);
+    for (int q = 0; q < 2; ++q) {
+        if (!(mask & (1 << q))) continue;
+        const int at = atomicAdd(count, 1);
+        if (at < capacity) list[at] = item * 2 + q;
+    }
+}
+// the segment workgroup `w` of the list owns (workgroup-uniform); false: nothing to do
+__device__ __forceinline__ bool heavy_take(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row, int N,
+                                           int n_items, int item_edges, const int* __restrict__ count,
+                                           const int* __restrict__ list, int w, HeavySeg& g) {
+    if (w >= *count) return false;
+    const int code = list[w];
+    HeavySeg seg[2];
+    const int mask = heavy_segments(rowptr, item_row, N, n_items, code >> 1, item_edges, seg);
+    if (!(mask & (1 << (code & 1)))) return false;         // cannot happen: the scout saw the same CSR
+    g = seg[code & 1];
+    return true;
+}
+
 // fixed-order sum / max of one value per wave
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -198,15 +290,13 @@ gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __re
                          const int32_t* __restrict__ item_row, const float* __restrict__ a_dst,
                          const float* __restrict__ a_src, int N, int n_items, int H, float slope,
                          float* __restrict__ m, float* __restrict__ s, int item_edges,
-                         float* __restrict__ part, int* __restrict__ cnt) {
+                         float* __restrict__ part, int* __restrict__ cnt, const int* __restrict__ count,
+                         const int* __restrict__ list) {
     __shared__ float red[HEAVY_WAVES];
     __shared__ int flag;
     const int t = threadIdx.x;
-    HeavySeg seg[2];
-    const int mask = heavy_segments(rowptr, item_row, N, n_items, blockIdx.x, item_edges, seg);   // workgroup-uniform
-    for (int q = 0; q < 2; ++q) {
-        if (!(mask & (1 << q))) continue;
-        const HeavySeg g = seg[q];
+    HeavySeg g;
+    for (int w = blockIdx.x; heavy_take(rowptr, item_row, N, n_items, item_edges, count, list, w, g); w += gridDim.x) {   // workgroup-uniform
         const int i = g.row;
         float* __restrict__ mine = part + (int64_t)heavy_slot(g, g.k) * H * 2;
         for (int hd = 0; hd < H; ++hd) {
@@ -237,15 +327,13 @@ gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __re
 __global__ void __launch_bounds__(HEAVY_THREADS)
 seg_rowsum_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
                         const float* __restrict__ vals, const int32_t* __restrict__ map, int N, int n_items, int H,
-                        float* __restrict__ out, int item_edges, float* __restrict__ part, int* __restrict__ cnt) {
+                        float* __restrict__ out, int item_edges, float* __restrict__ part, int* __restrict__ cnt,
+                        const int* __restrict__ count, const int* __restrict__ list) {
     __shared__ float red[HEAVY_WAVES];
     __shared__ int flag;
     const int t = threadIdx.x;
-    HeavySeg seg[2];
-    const int mask = heavy_segments(rowptr, item_row, N, n_items, blockIdx.x, item_edges, seg);
-    for (int q = 0; q < 2; ++q) {
-        if (!(mask & (1 << q))) continue;
-        const HeavySeg g = seg[q];
+    HeavySeg g;
+    for (int w = blockIdx.x; heavy_take(rowptr, item_row, N, n_items, item_edges, count, list, w, g); w += gridDim.x) {
         float* __restrict__ mine = part + (int64_t)heavy_slot(g, g.k) * H;
         for (int hd = 0; hd < H; ++hd) {
             float sum = 0.f;
@@ -404,23 +492,50 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
     }
 }
 
-// out[r,h] = sum over the entries p of row r of vals[idx(p), h], idx = map ? map[p] : p; wave per row
+// out[r,h] = sum over the entries p of row r of vals[idx(p), h], idx = map ? map[p] : p; LG lanes per row like
+// gat_softmax_rows_kernel
+template <int LG>
+__device__ __forceinline__ float rowsum_row(const float* __restrict__ vals, const int32_t* __restrict__ map, int H, int hd,
+                                            int b, int e, int gl) {
+    float sum = 0.f;
+    for (int p = b + gl; p < e; p += LG) {
+        const int64_t q = map ? map[p] : p;
+        sum += vals[q * H + hd];
+    }
+    return group_sum<LG>(sum);
+}
+
+template <int LG>
 __global__ void __launch_bounds__(256)
 seg_rowsum_scalar_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals,
                          const int32_t* __restrict__ map, int N, int H, float* __restrict__ out, int skip_heavy) {
+    constexpr int G = WAVE / LG;
     const int lane = lane_id();
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= N) return;
-    const int b = rowptr[r], e = rowptr[r + 1];
-    if (skip_heavy && e - b > GAT_HEAVY) return;       // seg_rowsum_heavy_kernel owns it
-    for (int hd = 0; hd < H; ++hd) {
-        float sum = 0.f;
-        for (int p = b + lane; p < e; p += WAVE) {
-            const int64_t q = map ? map[p] : p;
-            sum += vals[q * H + hd];
+    const int grp = lane / LG, gl = lane % LG;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
+    if (row0 >= N) return;
+    const int r = row0 + grp;
+    const bool have = r < N;
+    const int b = have ? rowptr[r] : 0, e = have ? rowptr[r + 1] : 0;
+    const bool heavy = skip_heavy && e - b > GAT_HEAVY;    // seg_rowsum_heavy_kernel owns it
+    const bool wide = LG < WAVE && !heavy && e - b > GROUP_WIDE * LG;
+    if (have && !heavy && !wide) {
+        for (int hd = 0; hd < H; ++hd) {
+            const float sum = rowsum_row<LG>(vals, map, H, hd, b, e, gl);
+            if (gl == 0) out[(int64_t)r * H + hd] = sum;
         }
-        sum = wave_sum(sum);
-        if (lane == 0) out[(int64_t)r * H + hd] = sum;
+    }
+    if (LG < WAVE) {
+        uint64_t todo = __ballot(wide && gl == 0);
+        while (todo) {
+            const int from = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const int wb = __shfl(b, from, WAVE), we = __shfl(e, from, WAVE), wr = __shfl(r, from, WAVE);
+            for (int hd = 0; hd < H; ++hd) {
+                const float sum = rowsum_row<WAVE>(vals, map, H, hd, wb, we, lane);
+                if (lane == 0) out[(int64_t)wr * H + hd] = sum;
+            }
+        }
     }
 }
 
@@ -503,7 +618,8 @@ extern "C" int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64
 
 extern "C" int64_t npi_gat_heavy_workspace_elems(int64_t nnz_max, int64_t H) {
     const int64_t items = npi_num_items(nnz_max);
-    return 4 * items * (H > 0 ? H : 1) + items + 64;      // segment partials (2 slots x 2 values per item and head), row counters
+    // segment partials (2 slots x 2 values per item and head), row counters, segment count, segment list
+    return 4 * items * (H > 0 ? H : 1) + items + 1 + heavy_list_capacity(nnz_max) + 64;
 }
 
 extern "C" int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
@@ -518,13 +634,25 @@ extern "C" int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, 
         set_error("npi_gat_softmax_stats: workspace too small");
         return NPI_ERR_WORKSPACE;
     }
-    gat_softmax_rows_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, col, a_dst, a_src, (int)N, (int)H, slope, m, s);
+    switch (row_group_lanes(nnz_max, N)) {
+#define NPI_ROWS(LG) gat_softmax_rows_kernel<LG><<<(unsigned)ceil_div(N, 4 * (WAVE / LG)), 256, 0, stream>>>(rowptr, col, a_dst, a_src, (int)N, (int)H, slope, m, s)
+        case 8: NPI_ROWS(8); break;
+        case 16: NPI_ROWS(16); break;
+        case 32: NPI_ROWS(32); break;
+        default: NPI_ROWS(64); break;
+#undef NPI_ROWS
+    }
     const int64_t n_items = npi_num_items(nnz_max);
     if (n_items > 0) {
         int* cnt = reinterpret_cast<int*>(workspace + 4 * n_items * H);
-        (void)hipMemsetAsync(cnt, 0, (size_t)n_items * sizeof(int), stream);
-        gat_softmax_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)n_items,
-                                                                                 (int)H, slope, m, s, item_edges_for(nnz_max), workspace, cnt);
+        int* count = cnt + n_items;
+        int* list = count + 1;
+        const int cap = (int)heavy_list_capacity(nnz_max);
+        const int ie = item_edges_for(nnz_max);
+        (void)hipMemsetAsync(count, 0, sizeof(int), stream);
+        heavy_list_kernel<<<(unsigned)ceil_div(n_items, 256), 256, 0, stream>>>(rowptr, item_row, (int)N, (int)n_items, ie, cap, cnt, count, list);
+        gat_softmax_heavy_kernel<<<(unsigned)(cap < HEAVY_GRID ? cap : HEAVY_GRID), HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)n_items,
+                                                                             (int)H, slope, m, s, ie, workspace, cnt, count, list);
     }
     return check_launch("npi_gat_softmax_stats");
 }
@@ -588,12 +716,24 @@ extern "C" int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, co
         }
     }
     // rows up to 4096 entries: one wave each; longer ones: 1024-thread workgroups over 64-item segments
-    seg_rowsum_scalar_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out, n_items > 0 ? 1 : 0);
+    switch (row_group_lanes(nnz_max, N)) {
+#define NPI_ROWS(LG) seg_rowsum_scalar_kernel<LG><<<(unsigned)ceil_div(N, 4 * (WAVE / LG)), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out, n_items > 0 ? 1 : 0)
+        case 8: NPI_ROWS(8); break;
+        case 16: NPI_ROWS(16); break;
+        case 32: NPI_ROWS(32); break;
+        default: NPI_ROWS(64); break;
+#undef NPI_ROWS
+    }
     if (n_items > 0) {
         int* cnt = reinterpret_cast<int*>(workspace + 4 * n_items * H);
-        (void)hipMemsetAsync(cnt, 0, (size_t)n_items * sizeof(int), stream);
-        seg_rowsum_heavy_kernel<<<(unsigned)n_items, HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)n_items, (int)H, out,
-                                                                                item_edges_for(nnz_max), workspace, cnt);
+        int* count = cnt + n_items;
+        int* list = count + 1;
+        const int cap = (int)heavy_list_capacity(nnz_max);
+        const int ie = item_edges_for(nnz_max);
+        (void)hipMemsetAsync(count, 0, sizeof(int), stream);
+        heavy_list_kernel<<<(unsigned)ceil_div(n_items, 256), 256, 0, stream>>>(rowptr, item_row, (int)N, (int)n_items, ie, cap, cnt, count, list);
+        seg_rowsum_heavy_kernel<<<(unsigned)(cap < HEAVY_GRID ? cap : HEAVY_GRID), HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)n_items, (int)H, out,
+                                                                            ie, workspace, cnt, count, list);
     }
     return check_launch("npi_seg_rowsum");
 }
