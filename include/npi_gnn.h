@@ -184,9 +184,12 @@ int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t 
 /* ------------------------------------------------------------------------------------------
  * GATConv (PyG 1.4.2; absent from the reference tree, BASELINE.json configs[4]).  H heads of C
  * channels, hfeat = x @ W is [N, H*C]; att is [H, 2C] (first C multiply the TARGET's features).
- * The attention coefficient alpha of an entry is never stored: it is recomputed from four
- * per-node, per-head scalars [N, H] -- a_dst, a_src (npi_gat_scores), m, s (npi_gat_softmax_stats):
+ * The attention coefficient alpha of an entry is recomputed from four per-node, per-head scalars
+ * [N, H] -- a_dst, a_src (npi_gat_scores), m, s (npi_gat_softmax_stats):
  *     alpha(i <- j) = exp(leaky_relu(a_dst[i] + a_src[j]) - m[i]) / (s[i] + 1e-16)
+ * The backward may keep the alpha that npi_gat_edge_grad computes anyway (alpha_out [nnz_max, H], by-target
+ * entry order) and hand it to the by-source npi_gat_aggregate (alpha + alpha_map = npi_entry_transpose_map;
+ * one head): reading a weight back is cheaper there than the exp and the divide per entry.  Both NULL: recompute.
  *
  *   npi_gat_scores        `(cat[x_i, x_j] * att).sum(-1)` split into its two dot products
  *   npi_gat_softmax_stats `utils.softmax`: scatter_max + scatter_add(exp) per target row
@@ -210,6 +213,7 @@ int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
                       const float* s, float negative_slope, int by_source, const float* bias,
                       const float* g_dst, const float* g_src, const float* att,
+                      const float* alpha, const int32_t* alpha_map,
                       float* carry, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                    int64_t N, int64_t H, int64_t C, float* D, void* stream);
@@ -217,7 +221,7 @@ int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
                       const float* dout, int64_t ldd, int64_t H, int64_t C,
                       const float* a_dst, const float* a_src, const float* m, const float* s,
-                      const float* D, float negative_slope, float* dz, void* stream);
+                      const float* D, float negative_slope, float* dz, float* alpha_out, void* stream);
 int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
                    int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
                    void* stream);

@@ -51,9 +51,9 @@ PROTOTYPES = {
     "npi_gat_heavy_workspace_elems": (_I, [_I, _I]),
     "npi_gat_softmax_stats": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _I, _P]),
     "npi_gat_aggregate": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
-                                  _P, _P, _P, _P, _P, _P]),
+                                  _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
-    "npi_gat_edge_grad": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float, _P, _P]),
+    "npi_gat_edge_grad": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "npi_seg_rowsum": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_entry_transpose_map": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_gat_att_grad_workspace_elems": (_I, [_I, _I, _I]),

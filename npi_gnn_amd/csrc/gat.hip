@@ -363,7 +363,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                      const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ dout, int64_t ldd,
                      int H, int C, const float* __restrict__ a_dst, const float* __restrict__ a_src,
                      const float* __restrict__ m, const float* __restrict__ s, const float* __restrict__ D,
-                     float slope, float* __restrict__ dz) {
+                     float slope, float* __restrict__ dz, float* __restrict__ alpha_out) {
     constexpr int U = (NCH <= 2) ? 4 : 2;
     const int lane = lane_id();
     const int item = uniform_i(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -470,6 +470,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                         const float alpha = expf(lrelu_(z, slope) - m[ii]) / (s[ii] + 1e-16f);
                         const float de = alpha * (p - D[ii]);
                         dz[(int64_t)(kb + j + u) * H + h] = de * (z > 0.f ? 1.f : slope);
+                        if (alpha_out) alpha_out[(int64_t)(kb + j + u) * H + h] = alpha;
                     }
                 }
             }
@@ -486,6 +487,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                 const float alpha = expf(lrelu_(z, slope) - m[ii]) / (s[ii] + 1e-16f);
                 const float de = alpha * (pb[t] - D[ii]);
                 dz[(int64_t)kb * H + t] = de * (z > 0.f ? 1.f : slope);
+                if (alpha_out) alpha_out[(int64_t)kb * H + t] = alpha;
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -662,6 +664,7 @@ extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, cons
                                  int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
                                  const float* s, float slope, int by_source, const float* bias,
                                  const float* g_dst, const float* g_src, const float* att,
+                                 const float* alpha, const int32_t* alpha_map,
                                  float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && H > 0 && C > 0, "npi_gat_aggregate: bad size");
@@ -675,6 +678,11 @@ extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, cons
     P.carry = carry; P.w = nullptr; P.bias = bias;
     P.H = (int)H; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.m = m; P.s = s; P.slope = slope;
     P.g_dst = g_dst; P.g_src = g_src; P.att = att;
+    if (alpha != nullptr) {       // the weights of npi_gat_edge_grad, read back through the transpose map (one head, by source)
+        NPI_REQUIRE(by_source && H == 1 && alpha_map != nullptr, "npi_gat_aggregate: alpha needs by_source, one head and alpha_map");
+        P.w = alpha; P.wmap = alpha_map;
+        return segsum_run(P, W_GAT_SRC_PRE, 0, nnz_max, NPI_F32, stream);
+    }
     return segsum_run(P, by_source ? W_GAT_SRC : W_GAT_DST, 0, nnz_max, NPI_F32, stream);
 }
 
@@ -682,7 +690,7 @@ extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, cons
                                  int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
                                  const float* dout, int64_t ldd, int64_t H, int64_t C,
                                  const float* a_dst, const float* a_src, const float* m, const float* s,
-                                 const float* D, float slope, float* dz, void* stream_) {
+                                 const float* D, float slope, float* dz, float* alpha_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(N >= 0 && nnz_max >= 0 && H > 0 && C > 0, "npi_gat_edge_grad: bad size");
     if (N == 0 || nnz_max == 0) return NPI_OK;
@@ -694,7 +702,7 @@ extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, cons
     const int n_items = (int)npi_num_items(nnz_max);
     const unsigned grid = (unsigned)ceil_div(n_items, 4);
     const int nch = (int)ceil_div(F, 256);
-#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, item_edges_for(nnz_max), hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz)
+#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, item_edges_for(nnz_max), hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz, alpha_out)
     if (nch == 1) NPI_EG(1); else if (nch == 2) NPI_EG(2); else if (nch == 3) NPI_EG(3); else NPI_EG(4);
 #undef NPI_EG
     return check_launch("npi_gat_edge_grad");

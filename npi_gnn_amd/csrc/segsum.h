@@ -4,7 +4,7 @@
 
 namespace npi {
 
-enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3 };
+enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4 };
 
 struct SegParams {
     const int32_t* rowptr;
@@ -18,7 +18,8 @@ struct SegParams {
     int64_t ldo;
     int F;
     float* carry;
-    const float* w;          // W_ARRAY: one weight per entry
+    const float* w;          // W_ARRAY: one weight per entry; W_GAT_SRC_PRE: alpha per by-target entry
+    const int32_t* wmap;     // W_GAT_SRC_PRE: entry p takes w[wmap[p]] (by-source entry -> by-target position)
     const float* bias;       // [F] or null, added after scaling
     // GAT: H heads of C channels (F == H * C), per-node per-head scalars [N, H]
     int H, C;

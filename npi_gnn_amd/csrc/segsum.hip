@@ -18,6 +18,8 @@
 //   W_ARRAY    w[p]                                GCNConv norm, any per-entry weight
 //   W_GAT_DST  exp(lrelu(a_dst[row] + a_src[col]) - m[row]), row scale 1/(s[row] + 1e-16)
 //              = GATConv's softmax(alpha) * x_j on the by-target CSR, alpha never stored
+//   W_GAT_SRC_PRE  W_GAT_SRC with alpha read back (w[wmap[p]], one head) instead of recomputed: the per-entry
+//              exp / divide of W_GAT_SRC costs more VALU time than the row it weighs costs memory time
 //   W_GAT_SRC  the same alpha seen from the by-source CSR (backward: d h_j = sum_i alpha_ij d out_i),
 //              plus the rank-1 terms of the attention-score gradient in the epilogue
 #include "segsum.h"
@@ -121,7 +123,7 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
         for (int q = 0; q < VEC; ++q) {
             t[q] = fmaf(acc[c][q], sc, bias ? to_f32(bias[L.foff[c] + q]) : 0.f);
         }
-        if (WMODE == W_GAT_SRC && P.g_dst != nullptr) {
+        if ((WMODE == W_GAT_SRC || WMODE == W_GAT_SRC_PRE) && P.g_dst != nullptr) {
             const int h = L.hd[c];
             const float gd = P.g_dst[(int64_t)r * P.H + h], gs = P.g_src[(int64_t)r * P.H + h];
             const float* __restrict__ at = P.att + (int64_t)h * 2 * P.C + (L.foff[c] - h * P.C);
@@ -214,7 +216,7 @@ segsum_kernel(SegParams P) {
 
     // one gathered row (+ its weight) into the accumulators
     auto entry_weight = [&](int c, float g0, float g1, float g2, float ws) -> float {
-        if (WMODE == W_ARRAY) return ws;
+        if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE) return ws;
         if (WMODE == W_GAT_DST) return expf(lrelu(rs_a[c] + g0, P.slope) - rs_m[c]);
         if (WMODE == W_GAT_SRC) return expf(lrelu(g0 + rs_a[c], P.slope) - g1) * g2;
         return 1.f;
@@ -225,6 +227,7 @@ segsum_kernel(SegParams P) {
         const int cv = (lane < nb) ? P.col[kb + lane] : 0;
         float wv = 1.f;
         if (WMODE == W_ARRAY) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
+        if (WMODE == W_GAT_SRC_PRE) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
         int j = 0;
         for (; j + U <= nb; j += U) {
             float v[U][NCH][VEC];
@@ -254,7 +257,7 @@ segsum_kernel(SegParams P) {
             for (int u = 0; u < U; ++u) {
                 const int k = kb + j + u;
                 while (k == row_end) close_row();
-                const float ws = (WMODE == W_ARRAY) ? bcast_f(wv, j + u) : 1.f;
+                const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE) ? bcast_f(wv, j + u) : 1.f;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
@@ -287,7 +290,7 @@ segsum_kernel(SegParams P) {
             }
             const int k = kb + j;
             while (k == row_end) close_row();
-            const float ws = (WMODE == W_ARRAY) ? bcast_f(wv, j) : 1.f;
+            const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE) ? bcast_f(wv, j) : 1.f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
@@ -605,6 +608,8 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
     else if (wmode == W_ARRAY) { if (mean) launch_one<T, VEC, NCH, W_ARRAY, true, EXACT>(P, stream); else launch_one<T, VEC, NCH, W_ARRAY, false, EXACT>(P, stream); }
     else if (wmode == W_GAT_DST) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, false, EXACT>(P, stream);
+    } else if (wmode == W_GAT_SRC_PRE) {
+        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, false, EXACT>(P, stream);
     } else {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC, false, EXACT>(P, stream);
     }

@@ -347,13 +347,14 @@ def _transpose_map(graph: CSRGraph) -> torch.Tensor:
 
 
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
-                   g_src=None, att=None):
+                   g_src=None, att=None, alpha=None, alpha_map=None):
     dev = x.device
     out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
     check(load().npi_gat_aggregate(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
                                    ptr(x), x.stride(0), ptr(out), out.stride(0), H, C, ptr(a_dst), ptr(a_src),
                                    ptr(m), ptr(s), float(slope), 1 if by_source else 0, ptr(bias), ptr(g_dst),
-                                   ptr(g_src), ptr(att), ptr(side.carry(H * C)), stream_ptr(dev)), "npi_gat_aggregate")
+                                   ptr(g_src), ptr(att), ptr(alpha), ptr(alpha_map), ptr(side.carry(H * C)),
+                                   stream_ptr(dev)), "npi_gat_aggregate")
     return out
 
 
@@ -405,9 +406,11 @@ class _GatConvFn(torch.autograd.Function):
                                  ptr(bias) if ctx.has_bias else 0, N, H, C, ptr(D), st), "npi_gat_rowdot")
         # dz per by-target entry, then its row sums in both orientations
         dz = torch.empty((max(d.nnz_max, 1), H), **f32)
+        # one head: keep the alpha this kernel computes; the by-source pass reads it back through the transpose map
+        alpha = torch.empty((max(d.nnz_max, 1), H), **f32) if H == 1 else None
         check(lib.npi_gat_edge_grad(ptr(d.rowptr), ptr(d.col), ptr(d.rowidx), N, d.nnz_max, ptr(hfeat), hfeat.stride(0),
                                     ptr(grad_out), grad_out.stride(0), H, C, ptr(a_dst), ptr(a_src), ptr(m), ptr(s),
-                                    ptr(D), slope, ptr(dz), st), "npi_gat_edge_grad")
+                                    ptr(D), slope, ptr(dz), ptr(alpha), st), "npi_gat_edge_grad")
         g_dst, g_src = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
         n_hw = int(lib.npi_gat_heavy_workspace_elems(max(d.nnz_max, sr.nnz_max), H))
         hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
@@ -417,7 +420,8 @@ class _GatConvFn(torch.autograd.Function):
                                  H, ptr(g_src), ptr(hws), n_hw, st), "npi_seg_rowsum")
         # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
         dh = _gat_aggregate(graph, sr, grad_out, H, C, a_dst, a_src, m, s, slope, True,
-                            g_dst=g_dst, g_src=g_src, att=att2)
+                            g_dst=g_dst, g_src=g_src, att=att2, alpha=alpha,
+                            alpha_map=_transpose_map(graph) if alpha is not None else None)
         datt = None
         if ctx.needs_input_grad[2]:
             n_ws = int(lib.npi_gat_att_grad_workspace_elems(N, H, C))
