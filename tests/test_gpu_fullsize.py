@@ -1,4 +1,4 @@
-"""The headline configuration at its FULL size (BASELINE.json configs[3], "C4": N = 1M nodes, E = 20M directed
+"""The headline configuration (and C5, below) at its FULL size (BASELINE.json configs[3], "C4": N = 1M nodes, E = 20M directed
 edges, hidden 256 -- the workload bench.py times), checked on the MI355X through properties that do not need a
 CPU run of that size, plus the PyG-style restatement (oracle/ref_conv.py: index_select -> index_add -> divide ->
 matmul, device-agnostic torch) executed on the same GPU as the checker.
@@ -175,3 +175,72 @@ def test_c4_gat_forward_matches_restatement_and_fp64_on_the_hubs(c4):
             alpha = torch.softmax(e, 0)
             truth = alpha @ h[nb] + b.double()
             assert float((out[i].double() - truth).abs().max()) < 1e-5
+
+
+# ---- configs[4] ("C5"): N = 4M nodes, E = 100M directed edges, GATConv hidden 256, one head --------------------
+N5, E5 = 4_000_000, 100_000_000
+
+
+@pytest.fixture(scope="module")
+def c5(dev):
+    torch.cuda.empty_cache()
+    ei = bipartite_edge_index(N5, E5, seed=2).to(dev)
+    graph = npi.CSRGraph(ei, N5)
+    torch.manual_seed(11)
+    x = torch.randn(N5, F, device=dev)
+    yield ei, graph, x
+    del graph, x, ei
+    torch.cuda.empty_cache()
+
+
+def test_c5_aggregation_conservation_and_adjoint(c5):
+    ei, graph, x = c5
+    side, tside = graph.by_dst, graph.by_src
+    assert int(side.rowptr[-1]) == E5 + N5 and int(side.status.item()) == 0
+    sx = NF.segsum(graph, side, x)
+    out_deg = (torch.bincount(ei[0], minlength=N5) + 1).double()
+    want = torch.zeros(F, dtype=torch.float64, device=x.device)
+    got = torch.zeros(F, dtype=torch.float64, device=x.device)
+    for r0 in range(0, N5, 1_000_000):                               # fp64 copies of a million rows at a time
+        want += (out_deg[r0:r0 + 1_000_000, None] * x[r0:r0 + 1_000_000].double()).sum(0)
+        got += sx[r0:r0 + 1_000_000].double().sum(0)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-6
+    y = torch.randn(N5, F, device=x.device)
+    ty = NF.segsum(graph, tside, y)
+    lhs = rhs = n1 = n2 = 0.0
+    for r0 in range(0, N5, 1_000_000):
+        sl = slice(r0, r0 + 1_000_000)
+        lhs += float((sx[sl].double() * y[sl].double()).sum())
+        rhs += float((x[sl].double() * ty[sl].double()).sum())
+        n1 += float(sx[sl].double().pow(2).sum())
+        n2 += float(y[sl].double().pow(2).sum())
+    assert abs(lhs - rhs) <= 1e-7 * (n1 * n2) ** 0.5
+
+
+def test_c5_gat_forward_rows_against_fp64_formula(c5):
+    """512 random target rows, the 4 heaviest (2M entries) and 4 rows around the heavy-row threshold, each against
+    softmax_j leaky_relu(a_dst.h_i + a_src.h_j) over in(i) U {i} evaluated in fp64."""
+    ei, graph, x = c5
+    dev = x.device
+    g = torch.Generator().manual_seed(13)
+    W = ((torch.rand(F, F, generator=g) * 2 - 1) * (6.0 / (2 * F)) ** 0.5).to(dev)
+    att = ((torch.rand(1, 1, 2 * F, generator=g) * 2 - 1) * (6.0 / (1 + 2 * F)) ** 0.5 * 3.0).to(dev)
+    b = (torch.randn(F, generator=g) * 0.1).to(dev)
+    with torch.no_grad():
+        out = npi.gat_conv(x, graph, W, att, b, heads=1)
+        Wd = W.double()
+        a_dst, a_src = att.double().view(-1)[:F], att.double().view(-1)[F:]
+        side = graph.by_dst
+        rowptr, col = side.rowptr.long(), side.col.long()
+        in_deg = rowptr[1:] - rowptr[:-1]
+        near = torch.argsort((in_deg - 4096).abs())[:4]                  # both sides of the wave / workgroup split
+        rows = torch.cat([torch.randint(0, N5, (512,), generator=g).to(dev), torch.topk(in_deg, 4).indices, near])
+        worst = 0.0
+        for i in rows.tolist():
+            nb = col[rowptr[i]:rowptr[i + 1]]                            # in-neighbours and the closing self loop
+            h_nb = x[nb].double() @ Wd
+            h_i = x[i].double() @ Wd
+            e = torch.nn.functional.leaky_relu((h_i * a_dst).sum() + h_nb @ a_src, 0.2)
+            truth = torch.softmax(e, 0) @ h_nb + b.double()
+            worst = max(worst, float((out[i].double() - truth).abs().max()))
+        assert worst < 1e-5, worst
