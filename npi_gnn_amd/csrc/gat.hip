@@ -66,6 +66,81 @@ gat_rowdot_kernel(const float* __restrict__ a, int64_t lda, const float* __restr
     }
 }
 
+// 16-byte variants of the two per-node dot-product kernels (C % 4 == 0, 16-byte aligned rows): one head of a row is
+// one wave instruction at C = 256, and a wave keeps ROWS_PER_WAVE rows in flight instead of one
+constexpr int ROWS_PER_WAVE = 4;
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+__global__ void __launch_bounds__(256)
+gat_scores_vec_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ att, int N, int H, int C,
+                      float* __restrict__ a_dst, float* __restrict__ a_src) {
+    const int lane = lane_id();
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE;
+    if (i0 >= N) return;
+    const int C4 = C >> 2;
+    for (int hd = 0; hd < H; ++hd) {
+        const float4* __restrict__ at = reinterpret_cast<const float4*>(att + (int64_t)hd * 2 * C);
+        float pd[ROWS_PER_WAVE], ps[ROWS_PER_WAVE];
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) pd[r] = ps[r] = 0.f;
+        for (int c = lane; c < C4; c += WAVE) {
+            const float4 ad = at[c], as = at[C4 + c];
+            float4 v[ROWS_PER_WAVE];
+#pragma unroll
+            for (int r = 0; r < ROWS_PER_WAVE; ++r)
+                v[r] = *(reinterpret_cast<const float4*>(h + (int64_t)min(i0 + r, N - 1) * ldh + (int64_t)hd * C) + c);
+#pragma unroll
+            for (int r = 0; r < ROWS_PER_WAVE; ++r) { pd[r] += dot4(v[r], ad); ps[r] += dot4(v[r], as); }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+            const float d = wave_sum(pd[r]), sc = wave_sum(ps[r]);
+            if (lane == 0 && i0 + r < N) {
+                a_dst[(int64_t)(i0 + r) * H + hd] = d;
+                a_src[(int64_t)(i0 + r) * H + hd] = sc;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gat_rowdot_vec_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                      const float* __restrict__ bias, int N, int H, int C, float* __restrict__ D) {
+    const int lane = lane_id();
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE;
+    if (i0 >= N) return;
+    const int C4 = C >> 2;
+    for (int hd = 0; hd < H; ++hd) {
+        float p[ROWS_PER_WAVE];
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) p[r] = 0.f;
+        for (int c = lane; c < C4; c += WAVE) {
+            const float4 bs = bias ? *(reinterpret_cast<const float4*>(bias + (int64_t)hd * C) + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 va[ROWS_PER_WAVE], vb[ROWS_PER_WAVE];
+#pragma unroll
+            for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+                const int64_t i = min(i0 + r, N - 1);
+                va[r] = *(reinterpret_cast<const float4*>(a + i * lda + (int64_t)hd * C) + c);
+                vb[r] = *(reinterpret_cast<const float4*>(b + i * ldb + (int64_t)hd * C) + c);
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+                p[r] = fmaf(va[r].x, vb[r].x - bs.x, p[r]);
+                p[r] = fmaf(va[r].y, vb[r].y - bs.y, p[r]);
+                p[r] = fmaf(va[r].z, vb[r].z - bs.z, p[r]);
+                p[r] = fmaf(va[r].w, vb[r].w - bs.w, p[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+            const float d = wave_sum(p[r]);
+            if (lane == 0 && i0 + r < N) D[(int64_t)(i0 + r) * H + hd] = d;
+        }
+    }
+}
+
+static bool rows16(const void* p, int64_t ld, int64_t C) { return C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p % 16) == 0; }
+
 // ---- segment softmax statistics: m[i,h] = max_p e_p, s[i,h] = sum_p exp(e_p - m) -------------------
 constexpr int GAT_HEAVY = 4096;      // rows longer than this go to the workgroup-per-row kernel
 
@@ -563,6 +638,7 @@ gat_att_grad_partial_kernel(const float* __restrict__ hfeat, int64_t ldh, const 
     const int hd = c / C;
     const int rbeg = blockIdx.y * ATT_ROWS, rend = min(N, rbeg + ATT_ROWS);
     float sd = 0.f, ss = 0.f;
+#pragma unroll 8
     for (int i = rbeg; i < rend; ++i) {
         const float v = hfeat[(int64_t)i * ldh + c];
         sd = fmaf(g_dst[(int64_t)i * H + hd], v, sd);
@@ -604,7 +680,10 @@ extern "C" int npi_gat_scores(const float* h, int64_t ldh, const float* att, int
     NPI_REQUIRE(N >= 0 && H > 0 && C > 0 && ldh >= H * C, "npi_gat_scores: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(h && att && a_dst && a_src, "npi_gat_scores: null pointer");
-    gat_scores_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(h, ldh, att, (int)N, (int)H, (int)C, a_dst, a_src);
+    if (rows16(h, ldh, C) && ((uintptr_t)att % 16) == 0)
+        gat_scores_vec_kernel<<<(unsigned)ceil_div(N, 4 * ROWS_PER_WAVE), 256, 0, stream>>>(h, ldh, att, (int)N, (int)H, (int)C, a_dst, a_src);
+    else
+        gat_scores_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(h, ldh, att, (int)N, (int)H, (int)C, a_dst, a_src);
     return check_launch("npi_gat_scores");
 }
 
@@ -614,7 +693,10 @@ extern "C" int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64
     NPI_REQUIRE(N >= 0 && H > 0 && C > 0, "npi_gat_rowdot: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(a && b && D, "npi_gat_rowdot: null pointer");
-    gat_rowdot_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, D);
+    if (rows16(a, lda, C) && rows16(b, ldb, C) && ((uintptr_t)bias % 16) == 0)
+        gat_rowdot_vec_kernel<<<(unsigned)ceil_div(N, 4 * ROWS_PER_WAVE), 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, D);
+    else
+        gat_rowdot_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, D);
     return check_launch("npi_gat_rowdot");
 }
 

@@ -474,7 +474,8 @@ colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, fl
     const int rend = min(M, rbeg + COLSUM_ROWS);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < N) {
-        for (int r = rbeg + wave; r < rend; r += 4) {
+#pragma unroll 8
+        for (int r = rbeg + wave; r < rend; r += 4) {                      // independent loads: keep 8 rows in flight
             const float* src = X + (int64_t)r * ldx + c;
             if (VEC4) {
                 float4 v = *reinterpret_cast<const float4*>(src);
