@@ -67,3 +67,63 @@ def test_degenerate_graphs(dev):
     ei = torch.stack([torch.arange(1, 5000), torch.zeros(4999, dtype=torch.long)])      # one giant row
     _check(dev, ei, 5000, 128, True, True, 1)
     _check(dev, ei.flip(0), 5000, 256, False, False, 2)                                 # one giant source row, no loops
+
+
+# ---- between-layer steps: TopKPooling + filter_adj + readout on random batches ---------------------------------
+@pytest.mark.parametrize("seed", range(16))
+def test_random_pooling_batches(dev, seed):
+    """graph sizes 0..2,500 (so both LDS sort capacities and empty graphs occur), ratios incl. the reference's 0.5,
+    duplicated rows (tied scores: lower index wins), widths that are / are not multiples of 4; indices bit-exact."""
+    from npi_gnn_amd import pool as NP
+    rng = np.random.default_rng(1000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    n_graphs = int(rng.integers(1, 40))
+    sizes = rng.choice([0, 1, 2, 3, 7, 64, 65, 300, 1024, 1025, 2500], size=n_graphs,
+                       p=[.08, .1, .1, .1, .15, .1, .1, .12, .05, .05, .05])
+    if sizes.sum() == 0:
+        sizes[0] = 5
+    sizes = [int(v) for v in sizes]
+    F = int(rng.choice([1, 6, 16, 128, 178]))
+    ratio = float(rng.choice([0.5, 0.5, 0.25, 0.8, 1.0]))
+    batch = torch.cat([torch.full((n,), b, dtype=torch.long) for b, n in enumerate(sizes)])
+    N = batch.numel()
+    x = torch.randn(N, F, generator=g)
+    if N > 8:                                                # ties: a quarter of the rows are copies of earlier rows
+        idx = torch.from_numpy(rng.integers(0, N, size=N // 4))
+        x[idx] = x[torch.from_numpy(rng.integers(0, N, size=N // 4))]
+    w = torch.randn(1, F, generator=g)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    src, dst = [], []
+    for b, n in enumerate(sizes):
+        if n:
+            e = torch.from_numpy(rng.integers(0, n, size=(2, 2 * n))) + int(starts[b])
+            src.append(e[0]); dst.append(e[1])
+    ei = torch.stack([torch.cat(src), torch.cat(dst)])
+    (gx, ge, _, gb, gperm, gsc), (score_gpu, _) = NP._topk_pool_fwd(x.to(dev), ei.to(dev), batch.to(dev), w.to(dev), ratio,
+                                                                   num_graphs=n_graphs)
+    # scores: float rounding only (tanh and the dot product are not bit-identical across libraries)
+    score = torch.tanh((x * w.view(1, -1)).sum(-1) / w.norm(p=2))
+    assert torch.allclose(score_gpu.cpu(), score, atol=1e-6)
+    # selection: integer work, bit-exact GIVEN the scores -- k = ceil(ratio * n) in float32 like PyG 1.4.2, descending,
+    # ties to the lower index, graphs in order; two scores one ulp apart would otherwise make the order a coin toss
+    sg = score_gpu.cpu()
+    perm = []
+    for b_, n in enumerate(sizes):
+        k = int(torch.ceil(torch.tensor(ratio, dtype=torch.float32) * torch.tensor(float(n), dtype=torch.float32)))
+        o = torch.sort(sg[int(starts[b_]): int(starts[b_]) + n], descending=True, stable=True).indices[:k]
+        perm.append(o + int(starts[b_]))
+    perm = torch.cat(perm)
+    assert torch.equal(gperm.cpu(), perm), (sizes, F, ratio)
+    remap = torch.full((N,), -1, dtype=torch.long)
+    remap[perm] = torch.arange(perm.numel())
+    r_, c_ = remap[ei[0]], remap[ei[1]]
+    keep = (r_ >= 0) & (c_ >= 0)
+    eo, bo = torch.stack([r_[keep], c_[keep]]), batch[perm]
+    xo, sc = x[perm] * sg[perm].view(-1, 1), sg[perm]
+    assert torch.equal(gb.cpu(), bo) and torch.equal(ge.cpu(), eo)
+    assert torch.allclose(gx.cpu(), xo, atol=1e-6, rtol=1e-6) and torch.equal(gsc.cpu(), sc)
+    ro = NP.global_max_mean_pool(gx, gb, n_graphs).cpu()
+    ref = R.readout(xo, bo, n_graphs)
+    kept = torch.bincount(bo, minlength=n_graphs) > 0
+    assert torch.allclose(ro[kept], ref[kept], atol=1e-5, rtol=1e-5)
+    assert float(ro[~kept].abs().sum()) == 0.0               # a graph without nodes reads out zeros
