@@ -74,6 +74,12 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_subgraph_sizes": lambda: lib.npi_subgraph_sizes(N, N, N, N, -1, N, N, N, N),
         "npi_subgraph_features": lambda: lib.npi_subgraph_features(N, 0, 0, N, N, N, 4, N, 0, N),
         "npi_confusion_update": lambda: lib.npi_confusion_update(N, 0, 0, N, 4, N, N),
+        # alpha read-back is a by-source, one-head, mapped mode: a forward call carrying it is refused (pointers are only
+        # compared with NULL before that check, never dereferenced on the host)
+        "npi_gat_aggregate": lambda: lib.npi_gat_aggregate(8, 8, 8, 4, 16, 8, 4, 8, 4, 1, 4, 8, 8, 8, 8, 0.2, 0, N, N, N, N,
+                                                           8, N, 8, N),
+        "npi_gat_edge_grad": lambda: lib.npi_gat_edge_grad(N, N, N, 4, 16, N, 4, N, 4, 0, 4, N, N, N, N, N, 0.2, N, N, N),
+        "npi_seg_rowsum": lambda: lib.npi_seg_rowsum(N, N, N, N, -1, 0, 1, N, N, 0, N),
     }
     for name, call in calls.items():
         assert call() == -1, name
