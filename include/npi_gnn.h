@@ -155,7 +155,10 @@ int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, con
 int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
                         const float* rowscale, float* dA, int64_t ldda,
                         int64_t M, int64_t K, int64_t N, void* stream);
-/* out[N] = column sums of X[M,N] (GCNConv bias gradient); workspace f32, ceil(M/2048)*N elements */
+/* out[N] = column sums of X[M,N] (GCNConv / GATConv bias gradient).  workspace f32: npi_colsum_workspace_elems(M, N)
+ * elements for the finest row chunking; ceil(M/2048)*N is the minimum that is accepted (coarser chunks, slower on
+ * small M). */
+int64_t npi_colsum_workspace_elems(int64_t M, int64_t N);
 int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
                int64_t workspace_elems, void* stream);
 /* Grid regime of npi_linear_bwd_weight: 0 (default) = the kernel has the GPU to itself (~4 workgroups per CU),

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "npi_gemm_mode": (c_int, [c_int]),
     "npi_linear_fwd": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, _P]),
     "npi_linear_bwd_data": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "npi_colsum_workspace_elems": (_I, [_I, _I]),
     "npi_colsum": (c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_dw_shared": (c_int, [c_int]),
     "npi_linear_bwd_weight_workspace_elems": (_I, [_I, _I, _I]),

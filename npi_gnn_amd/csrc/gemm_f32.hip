@@ -462,16 +462,22 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int64_t slab
 
 // partial column sums of X[M, N] over row chunks: part[chunk][c].  Lanes walk a row 16 B each
 // (a 256-column row is one 1 KiB wave instruction); the 4 waves of a workgroup take rows r, r+1, ...
-constexpr int COLSUM_ROWS = 2048;
+constexpr int COLSUM_ROWS = 2048;      // most rows per workgroup (and the chunking the documented minimum workspace implies)
+// rows per workgroup: about 1,024 workgroups per 256 columns, 16..COLSUM_ROWS rows each (a 5,085-row matrix is 3 workgroups
+// of 2,048 rows otherwise: 30 us of serial loads for 5 MB)
+static int colsum_rows(int64_t M) {
+    const int64_t r = ceil_div(M > 0 ? M : 1, 1024);
+    return (int)(r < 16 ? 16 : r > COLSUM_ROWS ? COLSUM_ROWS : r);
+}
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
-colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, float* __restrict__ part) {
+colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, int rows, float* __restrict__ part) {
     __shared__ float red[4][256];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
-    const int rbeg = blockIdx.y * COLSUM_ROWS;
-    const int rend = min(M, rbeg + COLSUM_ROWS);
+    const int rbeg = blockIdx.y * rows;
+    const int rend = min(M, rbeg + rows);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < N) {
 #pragma unroll 8
@@ -1269,19 +1275,27 @@ extern "C" int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W
     return npi_linear_bwd_data_t(dC, lddc, W, ldw, rowscale, dA, ldda, M, K, N, NPI_F32, stream_);
 }
 
+extern "C" int64_t npi_colsum_workspace_elems(int64_t M, int64_t N) {
+    if (M < 0 || N <= 0) return -1;
+    return ceil_div(M > 0 ? M : 1, (int64_t)colsum_rows(M)) * N;
+}
+
 extern "C" int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
                           int64_t workspace_elems, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && N > 0 && M < 0x7fffffff && N < 0x7fffffff, "npi_colsum: bad size");
     NPI_REQUIRE(X && out && workspace && ldx >= N, "npi_colsum: bad argument");
-    const int nchunks = (int)ceil_div(M > 0 ? M : 1, COLSUM_ROWS);
+    // the finest chunking the caller's workspace allows, down to colsum_rows(M) (npi_colsum_workspace_elems asks for that)
+    int rows = colsum_rows(M);
+    if (workspace_elems / N < ceil_div(M > 0 ? M : 1, rows)) rows = COLSUM_ROWS;
+    const int nchunks = (int)ceil_div(M > 0 ? M : 1, rows);
     if (workspace_elems < (int64_t)nchunks * N) {
         set_error("npi_colsum: workspace too small");
         return NPI_ERR_WORKSPACE;
     }
     dim3 cg((unsigned)ceil_div(N, 256), (unsigned)nchunks);
-    if (vec4_ok(X, ldx, N)) colsum_partial_kernel<true><<<cg, 256, 0, stream>>>(X, ldx, (int)M, (int)N, workspace);
-    else                    colsum_partial_kernel<false><<<cg, 256, 0, stream>>>(X, ldx, (int)M, (int)N, workspace);
+    if (vec4_ok(X, ldx, N)) colsum_partial_kernel<true><<<cg, 256, 0, stream>>>(X, ldx, (int)M, (int)N, rows, workspace);
+    else                    colsum_partial_kernel<false><<<cg, 256, 0, stream>>>(X, ldx, (int)M, (int)N, rows, workspace);
     slab_reduce_kernel<float><<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(workspace, N, nchunks, 1, (int)N, N, out, N);
     return check_launch("npi_colsum");
 }

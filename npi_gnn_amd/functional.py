@@ -165,7 +165,7 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     dev = require_gpu(x)
     x = _f32c(x, "x")
     M, N = x.shape
-    n_ws = ((max(M, 1) + 2047) // 2048) * N
+    n_ws = int(load().npi_colsum_workspace_elems(M, N))
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     out = torch.empty(N, dtype=torch.float32, device=dev)
     check(load().npi_colsum(ptr(x), x.stride(0), M, N, ptr(out), ptr(ws), n_ws, stream_ptr(dev)), "npi_colsum")
