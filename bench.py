@@ -198,6 +198,10 @@ def main():
     barrier()
     NF._PROFILE = seg_events
     NF._PROFILE_GEMM = gemm_events
+    comm_events = []                      # (tag, start, end) around every wait on a collective (sharded path only)
+    if world > 1 or args.force_sharded:
+        from npi_gnn_amd import dist as ND_
+        ND_._COMM_PROFILE = comm_events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -205,6 +209,8 @@ def main():
     dt = time.perf_counter() - t0
     NF._PROFILE = None
     NF._PROFILE_GEMM = None
+    if world > 1 or args.force_sharded:
+        ND_._COMM_PROFILE = None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -239,7 +245,17 @@ def main():
     # shares every CU with the backward aggregation (that sharing is the point of launching it one workgroup per CU)
     solo = [v for k, v in gem.items() if k != "bwd_weight"]
     solo_flops, solo_ms = sum(v[0] for v in solo), sum(v[1] for v in solo)
+    # the communication that was NOT hidden -- how long a stream stood still at each wait on a collective
+    exposed = {}
+    for tag, e0, e1 in comm_events:
+        exposed[tag] = exposed.get(tag, 0.0) + e0.elapsed_time(e1)
+    exchange = None
+    if world > 1:
+        exchange = {"exposed_ms_per_step": sum(exposed.values()) / args.steps,
+                    "by_collective_ms_per_step": {k: v / args.steps for k, v in sorted(exposed.items())},
+                    "note": "rank 0; stall of the waiting stream at each collective (HIP events around work.wait())"}
     extra = {
+        "exchange": exchange,
         "aggregation_only": {"edges_per_s": (E * args.steps / (seg_total_ms * 1e-3)) if seg_ms and world == 1 else None,
                              "ms_per_step": seg_total_ms / args.steps if seg_ms else None,
                              "note": "gather + segmented reduction, forward + transposed backward launches of one layer"},

@@ -151,6 +151,26 @@ def local_sides(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: 
 # exercise the real collectives); normally a single rank just copies
 ALWAYS_COMMUNICATE = False
 
+# bench.py sets this to a list: every wait on a collective then leaves (tag, start event, end event) recorded on the
+# waiting stream -- the time that stream stood still for the exchange, i.e. the communication that was NOT hidden
+# behind side B / dW / the local aggregation (exposed-comm time is reported separately).
+_COMM_PROFILE = None
+
+
+def _wait(work, tag: str, ref: torch.Tensor) -> None:
+    if work is None:
+        return
+    prof = _COMM_PROFILE
+    if prof is None or not ref.is_cuda:
+        work.wait()
+        return
+    s = torch.cuda.current_stream(ref.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    work.wait()
+    e1.record(s)
+    prof.append((tag, e0, e1))
+
 
 def _solo(world: int) -> bool:
     return world == 1 and not ALWAYS_COMMUNICATE
@@ -280,12 +300,10 @@ class _ShardedSageFn(torch.autograd.Function):
         be = sg.backend
         x_own = x_own.contiguous()
         table, g_work, hsum, r_work = _exchange_start(sg, x_own, sg.B)
-        if g_work is not None:
-            g_work.wait()
+        _wait(g_work, "fwd_all_gather", table)
         agg = be.segsum(sg.A, table, mean=True)
         if hsum is not None:
-            if r_work is not None:
-                r_work.wait()
+            _wait(r_work, "fwd_reduce_scatter", hsum)
             if sg.nH:
                 inv = sg.inv_cnt[sg.nL:].view(-1, 1)
                 agg[sg.nL:] = (agg[sg.nL:] * sg.cnt_a_hub + hsum[: sg.nH]) * inv
@@ -321,12 +339,10 @@ class _ShardedSageFn(torch.autograd.Function):
             table, g_work, hsum, r_work = started
 
             def finish():
-                if g_work is not None:
-                    g_work.wait()
+                _wait(g_work, "bwd_all_gather", table)
                 out = be.segsum(sg.At, table)
                 if hsum is not None:
-                    if r_work is not None:
-                        r_work.wait()
+                    _wait(r_work, "bwd_reduce_scatter", hsum)
                     if sg.nH:
                         out[sg.nL:] += hsum[: sg.nH]
                 return out
@@ -341,9 +357,9 @@ class _ShardedSageFn(torch.autograd.Function):
             else:
                 dx = finish()
         if want_w and not _solo(sg.world):
-            dist.all_reduce(dw, group=sg.group)
+            _wait(dist.all_reduce(dw, group=sg.group, async_op=True), "bwd_all_reduce_dw", dw)
             if db is not None:
-                dist.all_reduce(db, group=sg.group)
+                _wait(dist.all_reduce(db, group=sg.group, async_op=True), "bwd_all_reduce_db", db)
         return dx, dw, db, None
 
 

@@ -134,6 +134,7 @@ def _rccl_solo_worker(port, q):
         from npi_gnn_amd import dist as ND
         from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
         ND.ALWAYS_COMMUNICATE = True          # a single rank normally copies; go through RCCL instead
+        ND._COMM_PROFILE = comm = []          # bench.py's exposed-communication hook
         N, E, F = 20000, 300000, 128
         ei = bipartite_edge_index(N, E, seed=3)
         g = torch.Generator().manual_seed(5)
@@ -159,7 +160,9 @@ def _rccl_solo_worker(port, q):
             def rel(a, b):                   # max error relative to the largest reference magnitude
                 return float((a.detach() - b.detach()).abs().max() / b.detach().abs().max())
             errs.append((rel(out, ref[sg.own]), rel(xl.grad, xr.grad[sg.own]), rel(layer.weight.grad, conv.weight.grad)))
-        q.put(errs)
+        tags = sorted({t for t, _, _ in comm})
+        stall_ms = [e0.elapsed_time(e1) for _, e0, e1 in comm]
+        q.put((errs, tags, min(stall_ms), max(stall_ms)))
     finally:
         dist.destroy_process_group()
 
@@ -171,8 +174,12 @@ def test_collectives_through_rccl_with_one_rank(dev):
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_solo_worker, args=(_free_port(), q))
     p.start()
-    errs = q.get(timeout=300)
+    errs, tags, stall_min, stall_max = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0
+    # every wait on a collective is bracketed by HIP events on the waiting stream (hubs: gather + reduce-scatter per direction)
+    assert tags == ["bwd_all_gather", "bwd_all_reduce_db", "bwd_all_reduce_dw", "bwd_reduce_scatter", "fwd_all_gather",
+                    "fwd_reduce_scatter"]
+    assert 0.0 <= stall_min <= stall_max < 1000.0
     for e_out, e_dx, e_dw in errs:
         assert e_out < 1e-5 and e_dx < 1e-5 and e_dw < 1e-5
