@@ -172,15 +172,45 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def entry_weights(graph: CSRGraph, edge_weight: Optional[torch.Tensor], fill: float = 1.0):
+    """``edge_weight [E]`` in the entry order of both orientations, self loops included
+    (``add_remaining_self_loops(edge_index, edge_weight, fill, N)``: an existing self loop's weight becomes that
+    node's loop weight, every other node's loop weighs ``fill``).  Returns ``[by_dst, by_src]``."""
+    lib = load()
+    dev = graph.device
+    N = graph.num_nodes
+    s = stream_ptr(dev)
+    loop_w = None
+    if edge_weight is not None:
+        require_gpu(edge_weight)
+        edge_weight = _f32c(edge_weight.detach(), "edge_weight")
+        if edge_weight.numel() != graph.num_edges:
+            raise ValueError(f"edge_weight has {edge_weight.numel()} entries, edge_index {graph.num_edges} columns")
+    src, dst = graph._src, graph._dst
+    m = src == dst
+    if bool(m.any()):
+        loop_w = torch.full((N,), fill, dtype=torch.float32, device=dev)
+        loop_w[src[m]] = edge_weight[m] if edge_weight is not None else 1.0
+    out = []
+    for side in (graph.by_dst, graph.by_src):
+        we = torch.empty(max(side.nnz_max, 1), dtype=torch.float32, device=dev)
+        check(lib.npi_entry_weights(ptr(side.eid), ptr(side.rowidx), ptr(side.rowptr), ptr(edge_weight),
+                                    ptr(loop_w), fill, N, side.nnz_max, ptr(we), s), "npi_entry_weights")
+        out.append(we)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # SAGEConv
 # ---------------------------------------------------------------------------------------------
 class _SageConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, graph: CSRGraph):
-        agg = segsum(graph, graph.by_dst, x, mean=True)                  # a2-a4: gather + scatter_mean
+    def forward(ctx, x, weight, bias, graph: CSRGraph, w_entry=None):
+        # a2-a4: gather + scatter_mean (w_entry: PyG's `edge_weight.view(-1, 1) * x_j`; the mean still divides by the count)
+        agg = segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True)
         out = linear_fwd(agg, weight, bias)                               # a5: agg @ W + b
         ctx.graph = graph
+        ctx.w_src = w_entry[1] if w_entry else None
         ctx.has_bias = bias is not None
         ctx.save_for_backward(agg, weight)
         return out
@@ -211,22 +241,24 @@ class _SageConvFn(torch.autograd.Function):
                 side.wait_stream(main)                               # dAgg is complete for the side stream
                 dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True)
                 with torch.cuda.stream(side):
-                    dx = segsum(graph, graph.by_src, dagg, mean=False)
+                    dx = segsum(graph, graph.by_src, dagg, w=ctx.w_src, mean=False)
                 dagg.record_stream(side)                             # allocated on main, read on side
                 dx.record_stream(main)                               # allocated on side, consumed on main
                 main.wait_stream(side)
             else:
-                dx = segsum(graph, graph.by_src, dagg, mean=False)
-        return dx, dw, db, None
+                dx = segsum(graph, graph.by_src, dagg, w=ctx.w_src, mean=False)
+        return dx, dw, db, None, None
 
 
 def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              normalize: bool = False) -> torch.Tensor:
+              normalize: bool = False, edge_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PyG 1.4.2 ``SAGEConv(normalize=False, concat=False).forward`` on MI355X
-    (call sites: reference ``src/classes.py:62,66,70``)."""
+    (call sites: reference ``src/classes.py:62,66,70``).  ``edge_weight [E]`` scales the messages
+    (no gradient flows to it, as in the reference's use of the layer)."""
     require_gpu(x, weight, bias)
     graph = as_graph(edge_index, x.size(0))
-    out = _SageConvFn.apply(x, weight, bias, graph)
+    w_entry = entry_weights(graph, edge_weight, 1.0) if edge_weight is not None else None
+    out = _SageConvFn.apply(x, weight, bias, graph, w_entry)
     if normalize:
         out = torch.nn.functional.normalize(out, p=2.0, dim=-1)
     return out
@@ -245,24 +277,7 @@ class GCNNorm:
         fill = 2.0 if improved else 1.0
         s = stream_ptr(dev)
         sides = (graph.by_dst, graph.by_src)
-        w_entry = [None, None]
-        if edge_weight is not None or improved:
-            loop_w = None
-            if edge_weight is not None:
-                require_gpu(edge_weight)
-                edge_weight = _f32c(edge_weight.detach(), "edge_weight")
-            # add_remaining_self_loops: an existing self loop's weight (GCNConv.norm passes ones when
-            # edge_weight is None) becomes that node's loop weight instead of `fill`
-            src, dst = graph._src, graph._dst
-            m = src == dst
-            if bool(m.any()):
-                loop_w = torch.full((N,), fill, dtype=torch.float32, device=dev)
-                loop_w[src[m]] = edge_weight[m] if edge_weight is not None else 1.0
-            for k, side in enumerate(sides):
-                we = torch.empty(max(side.nnz_max, 1), dtype=torch.float32, device=dev)
-                check(lib.npi_entry_weights(ptr(side.eid), ptr(side.rowidx), ptr(side.rowptr), ptr(edge_weight),
-                                            ptr(loop_w), fill, N, side.nnz_max, ptr(we), s), "npi_entry_weights")
-                w_entry[k] = we
+        w_entry = entry_weights(graph, edge_weight, fill) if (edge_weight is not None or improved) else [None, None]
         deg = None
         if w_entry[1] is not None:      # weighted degree over SOURCE rows
             deg = torch.empty(N, dtype=torch.float32, device=dev)

@@ -62,9 +62,9 @@ class SAGEConv(nn.Module):
         _uniform(self.weight.size(0), self.bias)
 
     def forward(self, x, edge_index, edge_weight=None, size=None):
-        if edge_weight is not None or size is not None:
-            raise NotImplementedError("SAGEConv: edge_weight / bipartite size are not used by NPI-GNN")
-        return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize)
+        if size is not None:
+            raise NotImplementedError("SAGEConv: the bipartite `size` form is not used by NPI-GNN")
+        return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize, edge_weight=edge_weight)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

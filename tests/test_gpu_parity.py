@@ -213,6 +213,37 @@ def test_sage_conv_fwd_bwd_matches_oracle(dev, N, E, Fi, Fo, sym):
     assert torch.allclose(bd.grad.cpu(), ref_db, atol=ATOL * N ** 0.5, rtol=1e-3)
 
 
+def test_sage_conv_edge_weight_matches_oracle(dev):
+    """`edge_weight.view(-1, 1) * x_j`, mean over the entry count; an existing self loop keeps its own weight as the
+    loop weight (add_remaining_self_loops), every other node's loop weighs 1."""
+    N, E, Fi, Fo = 700, 9000, 178, 128
+    g = torch.Generator().manual_seed(21)
+    ei = rand_edges(N, E, 21, hub=4)
+    same = ei[0] == ei[1]
+    ei[1, same] = (ei[1, same] + 1) % N                                        # no accidental (possibly duplicated) self loops
+    ei[:, :5] = torch.tensor([[3, 9, 9, 20, 50], [3, 9, 10, 20, 51]])          # explicit self loops (node 9 also a plain edge)
+    ew = torch.rand(E, generator=g) * 2.0
+    x = torch.randn(N, Fi, generator=g)
+    W, b, go = torch.randn(Fi, Fo, generator=g) / Fi ** 0.5, torch.randn(Fo, generator=g), torch.randn(N, Fo, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    ref = R.sage_conv(xr, ei, Wr, br, edge_weight=ew)
+    ref.backward(go)
+    conv = npi.SAGEConv(Fi, Fo).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(W)
+        conv.bias.copy_(b)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, ei.to(dev), edge_weight=ew.to(dev))
+    out.backward(go.to(dev))
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=ATOL, rtol=RTOL)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, atol=ATOL, rtol=RTOL)
+    assert torch.allclose(conv.weight.grad.cpu(), Wr.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(conv.bias.grad.cpu(), br.grad, atol=1e-3, rtol=1e-4)
+    # without weights the same module call is the reference's plain layer
+    plain = conv(x.to(dev), ei.to(dev)).detach().cpu()
+    assert torch.allclose(plain, R.sage_conv(x, ei, W, b).detach(), atol=ATOL, rtol=RTOL)
+
+
 def test_sage_direction_on_directed_toy(dev):
     x = torch.tensor([[1.0, 10.0], [3.0, 30.0], [5.0, 50.0]])
     ei = torch.tensor([[0, 0], [1, 2]])                      # 0->1, 0->2
