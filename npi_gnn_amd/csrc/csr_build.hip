@@ -233,11 +233,19 @@ fill_csr_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ v
         if (rowidx) rowidx[q] = (int32_t)k;
         return;
     }
+    // row r starts at the first sorted position with key >= r; its end is the next thread's start (one search per
+    // row, the workgroup's last thread searches once more)
+    __shared__ int64_t lb_s[257];
     int64_t r = (int64_t)(blockIdx.x - entry_blocks) * 256 + threadIdx.x;
-    if (r > N) return;
-    rowptr[r] = (int32_t)(first_key_at_least(keys, E, r) + (loops ? r : 0));
+    const bool have = r <= N;
+    const int64_t lb = have ? first_key_at_least(keys, E, r) : E;
+    lb_s[threadIdx.x] = lb;
+    if (threadIdx.x == 255) lb_s[256] = (r + 1 <= N) ? first_key_at_least(keys, E, r + 1) : E;
+    __syncthreads();
+    if (!have) return;
+    rowptr[r] = (int32_t)(lb + (loops ? r : 0));
     if (loops && r < N) {
-        int64_t q = first_key_at_least(keys, E, r + 1) + r;     // behind the last entry of row r
+        int64_t q = lb_s[threadIdx.x + 1] + r;                  // behind the last entry of row r
         col[q] = (int32_t)r + loop_col_offset;
         if (eid) eid[q] = -1;
         if (rowidx) rowidx[q] = (int32_t)r;
