@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- edges/sec per GNN layer (fwd+bwd) on the synthetic ncRNA-protein bipartite graph.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`), rank 0 prints ONE
-JSON line.  A "step" is one pass of the hot path over the whole graph: one SAGEConv layer
-(gather -> segmented mean -> MFMA projection) forward AND backward (dX, dW, db), the call pattern
-of reference src/classes.py:62 + src/train_with_twoDataset.PY:52-54, with x and the graph already
-resident in HBM.  Workload = BASELINE.json configs[3] ("C4"): N = 1M nodes, E = 20M directed edges,
-hidden = 256, fp32 -- it fits one GPU, so N=1 runs the full graph; N>1 shards the same graph by
-destination rows (strong scaling; npi_gnn_amd/dist.py).
+Contract: `python bench.py --gpus N --steps K --warmup W`; rank 0 prints ONE JSON line.  For N > 1 the
+driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; a plain
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts exactly that command itself as a
+child process BEFORE anything in this process touches the GPU, and exits with the child's code.
+
+A "step" is one pass of the hot path over the whole graph: one SAGEConv layer (gather -> segmented mean ->
+MFMA projection) forward AND backward (dX, dW, db), the call pattern of reference src/classes.py:62 +
+src/train_with_twoDataset.PY:52-54, with x and the graph already resident in HBM.  Workload =
+BASELINE.json configs[3] ("C4"): N = 1M nodes, E = 20M directed edges, hidden = 256, fp32 -- it fits one GPU,
+so N=1 runs the full graph; N>1 shards the same graph (strong scaling; npi_gnn_amd/dist.py, --partition).
+
+After the headline measurement (N=1 only) the line also carries
+  roofline.control_uniform  the same aggregation kernel on a 1M-node / 20M-edge graph whose sources are uniform
+                            over the whole 1 GB table (no cache-resident hub side): the un-assisted HBM fraction;
+  configs                   the other BASELINE.json configs on this GPU (C1-C3 with their parity error against
+                            committed oracle outputs, GCN / GAT at the C4 shape, C5 on one GPU).
 """
 from __future__ import annotations
 
@@ -16,6 +24,8 @@ import argparse
 import json
 import os
 import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,10 +34,13 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s is the guide's measured copy rate)
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -35,18 +48,51 @@ def parse():
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--hidden", type=int, default=256)
-    ap.add_argument("--conv", choices=["sage", "gcn"], default="sage")
+    ap.add_argument("--conv", choices=["sage", "gcn", "gat"], default="sage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=100_000, help="bounded CPU-baseline sample (1/10 scale)")
     ap.add_argument("--cpu-edges", type=int, default=2_000_000)
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (npi_gnn_amd.dist) even with one rank")
-    ap.add_argument("--partition", choices=["hubs", "rows"], default="hubs",
-                    help="N>1: replicate the protein side and exchange only hub rows (hubs), or a plain "
-                         "destination-row split with an all-gather of every row (rows)")
-    return ap.parse_args()
+    ap.add_argument("--partition", choices=["hubs", "rows", "edges"], default="hubs",
+                    help="N>1: replicate the protein side and exchange only hub rows (hubs); a plain destination-row "
+                         "split with an all-gather of every row (rows); or the north-star's baseline: a slice of the "
+                         "edge list per GPU, x replicated, all-reduce of the partial [N,F] sums (edges)")
+    ap.add_argument("--no-control", action="store_true", help="skip roofline.control_uniform")
+    ap.add_argument("--control-only", action="store_true",
+                    help="run only the uniform-source control launches (for a rocprofv3 --pmc pass)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config block")
+    ap.add_argument("--skip-c5", action="store_true", help="configs block without the 4M / 100M GAT stack")
+    ap.add_argument("--rank-check", action="store_true",
+                    help="every rank prints {rank, world} and exits before any GPU call (launcher test)")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int, argv) -> int:
+    """Start the N ranks as `python -m torch.distributed.run` -- a CHILD process; this process has made no GPU call
+    (importing torch does not initialise HIP) and makes none afterwards."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# byte / flop accounting
+# ---------------------------------------------------------------------------------------------------------
 def algorithmic_bytes(nnz_rows_edges: int, n_rows: int, F: int, s: int = 4) -> int:
     """SURVEY.md 8(d): B = E (F s + 4) + N (F s [self row] + F s [write] + 4 [rowptr]);
     the self loop is an ordinary CSR entry here, so its row read + index are the per-node terms."""
@@ -60,7 +106,20 @@ def parallelism(args, world):
     if args.partition == "hubs":
         return (f"vertex cut x{world}: ncRNA rows owned in strides, protein rows replicated; per direction one "
                 "all-gather of protein rows + one reduce-scatter of partial protein sums over RCCL")
+    if args.partition == "edges":
+        return (f"edge shards x{world} (contiguous slices of the target-sorted entry stream), x replicated; per "
+                "direction one RCCL all-reduce of the partial [N,F] sums (the north-star's baseline split)")
     return f"destination-row shards (strided ownership) x{world}, all-gather of every row over RCCL"
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor()
 
 
 def cpu_baseline(args):
@@ -95,28 +154,235 @@ def cpu_baseline(args):
                 break
         if time.time() > budget and best is not None:
             break
-    ts = [best] * runs
-    cpu_model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        cpu_model = platform.processor()
     return {"value": E / best, "unit": "edges/s", "cores": best_threads, "kind": "port",
             "sample": f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd, N={N} E={E} F={F} fp32 "
-                      f"(1/10-scale C4), best of {len(ts)} timed runs over 16/32/64 torch threads (1 warm-up each), os.cpu_count()={os.cpu_count()}, "
-                      f"cpu='{cpu_model}'"}
+                      f"(1/10-scale C4), best of {runs} timed runs over 16/32/64 torch threads (1 warm-up each), "
+                      f"os.cpu_count()={os.cpu_count()}, cpu='{cpu_model()}'"}
 
 
+def pmc_traffic():
+    """HBM-side bytes per aggregation launch from the OFFLINE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate
+    runs, gfx950 correction per the guide; tools/profile_bench.sh + tools/rocprof_summary.py write this file)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# roofline.control_uniform: the same kernel with no cache-resident hub table
+# ---------------------------------------------------------------------------------------------------------
+def control_uniform(dev, N, E, F, launches=10):
+    import npi_gnn_amd as npi
+    from npi_gnn_amd import functional as NF
+    g = torch.Generator(device=dev).manual_seed(20260311)
+    ei = torch.randint(0, N, (2, E), generator=g, device=dev)          # sources AND targets uniform over all rows
+    n_loops = int((ei[0] == ei[1]).sum())                              # dropped by add_remaining_self_loops
+    graph = npi.CSRGraph(ei, N)
+    del ei
+    x = torch.randn(N, F, generator=g, device=dev)
+    for _ in range(2):
+        NF.segsum(graph, graph.by_dst, x, mean=True)
+    ev = []
+    NF._PROFILE = ev
+    for _ in range(launches):
+        NF.segsum(graph, graph.by_dst, x, mean=True)
+    NF._PROFILE = None
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    alg = algorithmic_bytes(E - n_loops, N, F)
+    ach = alg / (ms * 1e-3) / 1e9
+    t = pmc_traffic()
+    traffic = t.get("control_uniform_bytes_per_launch")
+    res = {"workload": f"N={N} E={E} uniform random sources and targets (every row of the {N * F * 4 / 1e9:.2f} GB table "
+                       f"equally likely: no cache-resident hub side), F={F} fp32, aggregation launches only",
+           "avg_launch_ms": ms, "launches_timed": len(ev), "algorithmic_bytes_per_launch": alg,
+           "achieved": ach, "frac_algorithmic": ach / HBM_PEAK_GBS,
+           "traffic": traffic,
+           "frac_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+           "traffic_source": t.get("control_from")}
+    del graph, x
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# configs block: the other BASELINE.json configs on this GPU
+# ---------------------------------------------------------------------------------------------------------
+def _timeit(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def _stack_step(kind, weights, x, graph, dtype=torch.float32, norm=None, att=None):
+    """forward + backward through a stack of convs with relu between them (full batch)"""
+    import npi_gnn_amd as npi
+    from npi_gnn_amd import functional as NF
+    dev = x.device
+    params = [(W.to(dev).to(dtype).requires_grad_(True), b.to(dev).to(dtype).requires_grad_(True)) for W, b in weights]
+    atts = [a.to(dev).requires_grad_(True) for a in att] if att else None
+    xin = x.to(dtype).requires_grad_(True)
+
+    def step():
+        for W, b in params:
+            W.grad = b.grad = None
+        xin.grad = None
+        h = xin
+        for k, (W, b) in enumerate(params):
+            if kind == "sage":
+                h = npi.sage_conv(h, graph, W, b)
+            elif kind == "gcn":
+                h = NF.gcn_conv(h, None, W, b, norm=norm)
+            else:
+                h = npi.gat_conv(h, graph, W, atts[k], b, heads=1)
+            h = torch.relu(h)
+        h.float().pow(2).mean().backward()
+        return h
+    return step
+
+
+def _stack_forward(kind, weights, x, graph, dtype=torch.float32, norm=None):
+    import npi_gnn_amd as npi
+    from npi_gnn_amd import functional as NF
+    dev = x.device
+    with torch.no_grad():
+        h = x.to(dev).to(dtype)
+        for W, b in weights:
+            W, b = W.to(dev).to(dtype), b.to(dev).to(dtype)
+            h = torch.relu(npi.sage_conv(h, graph, W, b) if kind == "sage" else NF.gcn_conv(h, None, W, b, norm=norm))
+    return h.float().cpu()
+
+
+def run_configs(dev, args, c4):
+    """ms per full-batch step (fwd+bwd over the layer stack) and, for C1-C3, the max error against the oracle outputs
+    committed under tests/golden/ (made by tests/golden/make_golden.py / make_rpi7317.py from the CPU oracle)."""
+    import npi_gnn_amd as npi
+    from npi_gnn_amd import functional as NF
+    out = {}
+    G = os.path.join(ROOT, "tests", "golden")
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:                                  # the headline line must survive a failing extra
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
+
+    fx = torch.load(os.path.join(G, "npinter2_graph.pt"), map_location="cpu", weights_only=False)
+    x, ei = fx["x"], fx["edge_index"].long()
+    graph = npi.CSRGraph(ei.to(dev), x.size(0))
+    _ = graph.by_src
+    norm = NF.GCNNorm(graph)
+    rows = fx["rows"]
+    shape = f"NPInter2 graph N={x.size(0)} E={ei.size(1)}"
+
+    def c1():
+        h = _stack_forward("gcn", fx["gcn64"], x, graph, norm=norm)
+        return {"workload": f"{shape}, 2 x GCNConv 178->64->64 fp32, full batch",
+                "ms_per_step": _timeit(_stack_step("gcn", fx["gcn64"], x.to(dev), graph, norm=norm), 30, 5),
+                "parity_max_abs_err": float((h[rows] - fx["gcn64_out"]).abs().max()), "parity": "oracle (unpinned: GCNConv)"}
+
+    def c2():
+        h = _stack_forward("sage", fx["sage_weights"], x, graph, dtype=torch.bfloat16)
+        ref = fx["sage3_out"]
+        return {"workload": f"{shape}, 3 x SAGEConv 178->128->128->128, bf16 storage / f32 accumulate, full batch",
+                "ms_per_step": _timeit(_stack_step("sage", fx["sage_weights"], x.to(dev), graph, dtype=torch.bfloat16), 30, 5),
+                "ms_per_step_f32": _timeit(_stack_step("sage", fx["sage_weights"], x.to(dev), graph), 30, 5),
+                "parity_max_err_rel_to_max": float((h[rows] - ref).abs().max() / ref.abs().max()),
+                "parity": "fp32 oracle, bf16 tolerance"}
+
+    def c3():
+        p = os.path.join(G, "rpi7317_graph.pt")
+        f3 = torch.load(p, map_location="cpu", weights_only=False)
+        x3, ei3 = f3["x"], f3["edge_index"].long()
+        g3 = npi.CSRGraph(ei3.to(dev), x3.size(0))
+        _ = g3.by_src
+        n3 = NF.GCNNorm(g3)
+        h = _stack_forward("gcn", f3["gcn256"], x3, g3, norm=n3)
+        return {"workload": f"RPI7317 graph N={x3.size(0)} E={ei3.size(1)} (7,317 positives + 7,317 seeded negatives), "
+                            "3 x GCNConv 178->256->256->256 fp32, full batch",
+                "ms_per_step": _timeit(_stack_step("gcn", f3["gcn256"], x3.to(dev), g3, norm=n3), 30, 5),
+                "parity_max_abs_err": float((h[f3["rows"]] - f3["gcn256_out"]).abs().max()),
+                "parity": "oracle (unpinned: GCNConv)"}
+
+    guarded("C1", c1)
+    guarded("C2", c2)
+    guarded("C3", c3)
+    del graph, norm
+
+    # GCN / GAT layer at the C4 shape, on the headline graph
+    g4, x4, go4, F = c4["graph"], c4["x"], c4["go"], c4["F"]
+    E4 = c4["E"]
+    gen = torch.Generator().manual_seed(11)
+
+    def gcn_c4():
+        conv = npi.GCNConv(F, F).to(dev)
+        n4 = NF.GCNNorm(g4)
+        xx = x4.detach().requires_grad_(True)
+
+        def step():
+            conv.weight.grad = conv.bias.grad = xx.grad = None
+            NF.gcn_conv(xx, None, conv.weight, conv.bias, norm=n4).backward(go4)
+        ms = _timeit(step, 10, 3)
+        return {"workload": f"C4 graph, 1 x GCNConv {F}->{F} fp32 fwd+bwd", "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3}
+
+    def gat_c4():
+        conv = npi.GATConv(F, F, heads=1).to(dev)
+        xx = x4.detach().requires_grad_(True)
+
+        def step():
+            for p in conv.parameters():
+                p.grad = None
+            xx.grad = None
+            conv(xx, g4).backward(go4)
+        ms = _timeit(step, 10, 3)
+        return {"workload": f"C4 graph, 1 x GATConv {F}->{F} (1 head) fp32 fwd+bwd", "ms_per_step": ms,
+                "edges_per_s": E4 / ms * 1e3}
+
+    guarded("gcn_c4", gcn_c4)
+    guarded("gat_c4", gat_c4)
+
+    if not args.skip_c5:
+        def c5():
+            from npi_gnn_amd.synth import bipartite_edge_index
+            c4.clear()                                             # release the C4 graph and features first
+            torch.cuda.empty_cache()
+            N5, E5, F5 = 4_000_000, 100_000_000, 256
+            ei5 = bipartite_edge_index(N5, E5, seed=2).to(dev)
+            g5 = npi.CSRGraph(ei5, N5)
+            _ = g5.by_src
+            del ei5
+            weights = [((torch.randn(F5, F5, generator=gen) / 16), torch.zeros(F5)) for _ in range(3)]
+            att = [torch.randn(1, 1, 2 * F5, generator=gen) * 0.1 for _ in range(3)]
+            x5 = torch.randn(N5, F5, generator=gen).to(dev)
+            ms = _timeit(_stack_step("gat", weights, x5, g5, att=att), 3, 1)
+            return {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU",
+                    "ms_per_step": ms, "edge_layers_per_s": 3 * E5 / ms * 1e3}
+        guarded("C5_1gpu", c5)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rank_check:
+        print(json.dumps({"rank_check": True, "rank": rank, "world": world, "local_rank": local_rank,
+                          "cuda_initialized": torch.cuda.is_initialized()}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -131,6 +397,10 @@ def main():
     from npi_gnn_amd.synth import bipartite_edge_index
 
     N, E, F = args.nodes, args.edges, args.hidden
+    if args.control_only:
+        print(json.dumps({"control_uniform": control_uniform(dev, N, E, F)}), flush=True)
+        return
+    sharded = world > 1 or args.force_sharded
     ei = bipartite_edge_index(N, E, seed=20260310)
     g = torch.Generator().manual_seed(1)
     x_full = torch.randn(N, F, generator=g)
@@ -141,24 +411,26 @@ def main():
     seg_events = []                       # (start, end) HIP events around every npi_segsum launch
     gemm_events = []                      # (name, flops, start, end) around every projection GEMM
     NF._PROFILE = None
+    c4 = {}
 
-    if world == 1 and not args.force_sharded:
+    if not sharded:
         t0 = time.time()
         graph = npi.CSRGraph(ei.to(dev), N)
         _ = graph.by_src
         torch.cuda.synchronize()
         t_build = time.time() - t0
-        conv = (npi.SAGEConv if args.conv == "sage" else npi.GCNConv)(F, F).to(dev)
+        conv = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[args.conv](F, F).to(dev)
         with torch.no_grad():
             conv.weight.copy_(W)
             conv.bias.copy_(bias)
         x = x_full.to(dev).requires_grad_(True)
         go = go_full.to(dev)
         norm = NF.GCNNorm(graph) if args.conv == "gcn" else None
+        c4.update(graph=graph, x=x, go=go, F=F, E=E)
 
         def step():
-            conv.weight.grad = None
-            conv.bias.grad = None
+            for p in conv.parameters():
+                p.grad = None
             x.grad = None
             if norm is not None:
                 out = NF.gcn_conv(x, None, conv.weight, conv.bias, norm=norm)
@@ -168,24 +440,33 @@ def main():
         seg_launch_bytes = [algorithmic_bytes(E, N, F)]
     else:
         from npi_gnn_amd import dist as ND
-        t0 = time.time()
         from npi_gnn_amd.synth import protein_mask
-        sg = ND.ShardedGraph(ei, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None)
+        t0 = time.time()
+        if args.partition == "edges":
+            sg = ND.EdgeShardedGraph(ei, N, rank, world, dev)
+            layer = ND.EdgeShardedSAGELayer(sg, W.to(dev), bias.to(dev))
+            x = x_full.to(dev).requires_grad_(True)            # x is REPLICATED in this split
+            go = sg.shard(go_full).to(dev)
+            seg_launch_bytes = [algorithmic_bytes(sg.local_nnz, N, F)]
+        else:
+            sg = ND.ShardedGraph(ei, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None)
+            layer = {"sage": ND.ShardedSAGELayer, "gcn": ND.ShardedGCNLayer}[args.conv](sg, W.to(dev), bias.to(dev)) \
+                if args.conv != "gat" else ND.ShardedGATLayer(sg, W.to(dev), torch.randn(1, 1, 2 * F, generator=g).to(dev) * 0.1,
+                                                               bias.to(dev))
+            x = sg.shard(x_full).to(dev).requires_grad_(True)  # this rank's rows: its ncRNAs, then its proteins
+            go = sg.shard(go_full).to(dev)
+            # per direction this rank launches side A (its rows) and, with hubs, side B (partial hub sums)
+            seg_launch_bytes = [algorithmic_bytes(sg.A.nnz_max - sg.n_local, sg.n_local, F)]
+            if sg.B is not None:
+                seg_launch_bytes.append(algorithmic_bytes(sg.B.nnz_max, sg.part.hub_rows, F) - sg.part.hub_rows * F * 4)
         torch.cuda.synchronize()
         t_build = time.time() - t0
-        layer = ND.ShardedSAGELayer(sg, W.to(dev), bias.to(dev))
-        x = sg.shard(x_full).to(dev).requires_grad_(True)      # this rank's rows: its ncRNAs, then its proteins
-        go = sg.shard(go_full).to(dev)
 
         def step():
             layer.zero_grad()
             x.grad = None
             out = layer(x)
             out.backward(go)
-        # per direction this rank launches side A (its rows) and, with hubs, side B (partial hub sums)
-        seg_launch_bytes = [algorithmic_bytes(sg.A.nnz_max - sg.n_local, sg.n_local, F)]
-        if sg.B is not None:
-            seg_launch_bytes.append(algorithmic_bytes(sg.B.nnz_max, sg.part.hub_rows, F) - sg.part.hub_rows * F * 4)
 
     def barrier():
         if world > 1:
@@ -199,7 +480,7 @@ def main():
     NF._PROFILE = seg_events
     NF._PROFILE_GEMM = gemm_events
     comm_events = []                      # (tag, start, end) around every wait on a collective (sharded path only)
-    if world > 1 or args.force_sharded:
+    if sharded:
         from npi_gnn_amd import dist as ND_
         ND_._COMM_PROFILE = comm_events
     t0 = time.perf_counter()
@@ -209,7 +490,7 @@ def main():
     dt = time.perf_counter() - t0
     NF._PROFILE = None
     NF._PROFILE_GEMM = None
-    if world > 1 or args.force_sharded:
+    if sharded:
         ND_._COMM_PROFILE = None
     if world > 1:
         import torch.distributed as dist
@@ -225,13 +506,12 @@ def main():
     seg_avg_ms = sum(seg_ms) / max(len(seg_ms), 1)
     alg_bytes = sum(seg_launch_bytes) / len(seg_launch_bytes)          # average over the launches of one direction
     achieved = alg_bytes / (seg_avg_ms * 1e-3) / 1e9 if seg_ms else 0.0
+    pmc = pmc_traffic()
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and world == 1 and not args.force_sharded and (N, E, F) == (1_000_000, 20_000_000, 256):
-        try:
-            traffic = json.load(open(pmc_path)).get("segsum_kernel_bytes_per_launch")
-        except Exception:
-            traffic = None
+    if not sharded and args.conv == "sage" and (N, E, F) == (1_000_000, 20_000_000, 256):
+        traffic = pmc.get("segsum_kernel_bytes_per_launch")
+    frac_alg = achieved / HBM_PEAK_GBS
+    frac_traffic = (traffic / (seg_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and seg_ms) else None
 
     # aggregation-only rate beside the layer total, and the projection against the MFMA peak
     seg_total_ms = sum(seg_ms)
@@ -242,33 +522,60 @@ def main():
         g_[1] += e0.elapsed_time(e1)
         g_[2] += 1
     # the two GEMMs that run alone on the chip give the MFMA figure; dW is listed with the duration it has while it
-    # shares every CU with the backward aggregation (that sharing is the point of launching it one workgroup per CU)
+    # shares every CU with the backward aggregation
     solo = [v for k, v in gem.items() if k != "bwd_weight"]
     solo_flops, solo_ms = sum(v[0] for v in solo), sum(v[1] for v in solo)
+    solo_tf = (solo_flops / (solo_ms * 1e-3) / 1e12) if solo_ms else None
     # the communication that was NOT hidden -- how long a stream stood still at each wait on a collective
     exposed = {}
     for tag, e0, e1 in comm_events:
         exposed[tag] = exposed.get(tag, 0.0) + e0.elapsed_time(e1)
     exchange = None
-    if world > 1:
+    if sharded:
         exchange = {"exposed_ms_per_step": sum(exposed.values()) / args.steps,
                     "by_collective_ms_per_step": {k: v / args.steps for k, v in sorted(exposed.items())},
                     "note": "rank 0; stall of the waiting stream at each collective (HIP events around work.wait())"}
+    split_on = bool(int(npi.load().npi_gemm_mode(-1)))
     extra = {
         "exchange": exchange,
         "aggregation_only": {"edges_per_s": (E * args.steps / (seg_total_ms * 1e-3)) if seg_ms and world == 1 else None,
                              "ms_per_step": seg_total_ms / args.steps if seg_ms else None,
                              "note": "gather + segmented reduction, forward + transposed backward launches of one layer"},
-        "projection": {"bound": "mfma", "achieved": (solo_flops / (solo_ms * 1e-3) / 1e12) if solo_ms else None,
-                       "peak": 157.3, "unit": "TFLOP/s (f32-equivalent, against the f32 MFMA peak)",
-                       "frac": (solo_flops / (solo_ms * 1e-3) / 1e12 / 157.3) if solo_ms else None,
-                       "kernels": "fwd + bwd_data (gemm_split_ws_kernel: f32-accurate 3-way bf16 split on the bf16 matrix cores)",
-                       "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},
-                       "per_gemm_tflops": {k: v[0] / (v[1] * 1e-3) / 1e12 for k, v in gem.items() if v[1] > 0},
-                       "note": "bwd_weight (exact f32 MFMA, one workgroup per CU on a side stream) is timed while it shares "
-                               "the CUs with the backward aggregation; alone it takes 1.3 ms (100 TFLOP/s)"},
+        "projection": {
+            "bound": "mfma",
+            "kernels": "fwd + bwd_data: gemm_split_ws_kernel (f32 operands split 3-way into bf16, six "
+                       "v_mfma_f32_32x32x16_bf16 per f32 product, f32 accumulate)" if split_on else
+                       "fwd + bwd_data: exact-f32 v_mfma_f32_32x32x2_f32 kernels",
+            "achieved_f32_equivalent": solo_tf, "unit": "TFLOP/s",
+            # the pipe the kernel runs on: six bf16 MFMA flops are issued per f32-equivalent flop
+            "achieved": (6.0 * solo_tf) if (solo_tf and split_on) else solo_tf,
+            "peak": MFMA_BF16_PEAK_TF if split_on else MFMA_F32_PEAK_TF,
+            "frac": ((6.0 * solo_tf / MFMA_BF16_PEAK_TF) if split_on else (solo_tf / MFMA_F32_PEAK_TF)) if solo_tf else None,
+            "frac_note": "issued bf16-MFMA flops (6 x f32-equivalent) / dense bf16 MFMA peak" if split_on else
+                         "f32 flops / f32 MFMA peak",
+            "f32_equivalent_vs_f32_mfma_peak": (solo_tf / MFMA_F32_PEAK_TF) if solo_tf else None,
+            "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},
+            "per_gemm_tflops_f32_equivalent": {k: v[0] / (v[1] * 1e-3) / 1e12 for k, v in gem.items() if v[1] > 0},
+            "note": "bwd_weight is timed while it shares the CUs with the backward aggregation on a second stream"},
     }
+    res = None
     if rank == 0:
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # two fractions of the 8 TB/s HBM peak, both from the same live launch duration:
+                "frac_algorithmic": frac_alg,      # SURVEY 8(d) bytes (every gathered row counted, no cache credit) / time
+                "frac_traffic": frac_traffic,      # bytes that crossed the L2 <-> fabric boundary (PMC) / time
+                "frac": frac_traffic if frac_traffic is not None else min(frac_alg, 1.0),
+                "frac_basis": ("traffic: PMC bytes / live duration / peak -- the HBM-roofline fraction; frac_algorithmic "
+                               "exceeds it (and can exceed 1) because gathers of the 100k protein rows are served by the "
+                               "XCD L2s / Infinity Cache and never reach HBM") if frac_traffic is not None else
+                              "algorithmic (no PMC pass on file for this configuration), capped at 1",
+                "traffic": traffic,
+                "traffic_source": (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately; FETCH_SIZE x "
+                                   f"{pmc.get('fetch_scale')} gfx950 calibration), {pmc.get('from')} -- not measured in this run")
+                if traffic else None,
+                "kernel": "segsum_kernel (+ segsum_fixup_kernel), avg of fwd and bwd launches",
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": seg_avg_ms,
+                "launches_timed": len(seg_ms)}
         res = {
             "metric": "edges/sec per GNN layer (fwd+bwd)", "value": value, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -279,21 +586,31 @@ def main():
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
                        "parallelism": parallelism(args, world),
                        "csr_build_s": round(t_build, 4)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "segsum_kernel (+ segsum_fixup_kernel), avg of fwd and bwd launches",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": seg_avg_ms,
-                         "launches_timed": len(seg_ms)},
+            "roofline": roof,
         }
         res.update(extra)
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args)
-        elif not args.no_cpu_baseline:
-            res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+    # ---- extras after the timed region (one GPU only): control, per-config block, CPU baseline -------------
+    if world == 1 and not sharded:
+        del x_full, go_full, ei
+        if not args.no_control and args.conv == "sage":
+            try:
+                res["roofline"]["control_uniform"] = control_uniform(dev, N, E, F)
+            except Exception as e:
+                res["roofline"]["control_uniform"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_configs and args.conv == "sage":
+            del graph, x, go, step, conv
+            res["configs"] = run_configs(dev, args, c4)
+    if not args.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline(args)
+    elif not args.no_cpu_baseline:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -111,6 +111,15 @@ int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_ro
                const float* w, int64_t N, int64_t nnz_max,
                const void* x, int64_t ldx, void* out, int64_t ldo, int64_t F, int dtype,
                int mean, const float* bias, float* carry, void* stream);
+/* The same reduction over a TWO-PART feature table: an entry with col[p] < split reads row col[p] of x, any other
+ * entry row col[p] - split of x2 (same leading dimension and dtype).  One rank of the sharded layers
+ * (npi_gnn_amd/dist.py) gathers from [hub rows received from all ranks ; its own rows] without
+ * copying its own rows behind the received ones.  x2 == NULL: one table, as npi_segsum. */
+int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                  const float* w, int64_t N, int64_t nnz_max,
+                  const void* x, int64_t ldx, const void* x2, int64_t split,
+                  void* out, int64_t ldo, int64_t F, int dtype,
+                  int mean, const float* bias, float* carry, void* stream);
 
 /* GCNConv.norm (PyG 1.4.2): deg[j] = sum of weights of entries in row j of the BY-SOURCE CSR
  * (deg == NULL: unweighted, the row lengths of deg_rowptr are used);
@@ -218,6 +227,15 @@ int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       const float* g_dst, const float* g_src, const float* att,
                       const float* alpha, const int32_t* alpha_map,
                       float* carry, void* stream);
+/* npi_gat_aggregate over a two-part table (x2 / split as in npi_segsum_ex). */
+int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                         int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
+                         float* out, int64_t ldo,
+                         int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
+                         const float* s, float negative_slope, int by_source, const float* bias,
+                         const float* g_dst, const float* g_src, const float* att,
+                         const float* alpha, const int32_t* alpha_map,
+                         float* carry, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                    int64_t N, int64_t H, int64_t C, float* D, void* stream);
 int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
@@ -225,6 +243,16 @@ int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       const float* dout, int64_t ldd, int64_t H, int64_t C,
                       const float* a_dst, const float* a_src, const float* m, const float* s,
                       const float* D, float negative_slope, float* dz, float* alpha_out, void* stream);
+/* npi_gat_edge_grad with a two-part gathered table (hfeat2 / split) and, swap != 0, the roles of rows and columns
+ * exchanged -- the same dz seen from a by-SOURCE CSR: rows are source nodes (`dout` = their hfeat rows, a_src indexed
+ * by row), columns are target nodes (`hfeat` = the gathered dOut rows; a_dst, m, s, D indexed by column).  The sharded
+ * GAT backward uses it to sum dz by source without a transpose map between different ranks' entry sets. */
+int npi_gat_edge_grad_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                         int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
+                         const float* hfeat2, int64_t split,
+                         const float* dout, int64_t ldd, int64_t H, int64_t C,
+                         const float* a_dst, const float* a_src, const float* m, const float* s,
+                         const float* D, float negative_slope, int swap, float* dz, float* alpha_out, void* stream);
 int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
                    int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
                    void* stream);

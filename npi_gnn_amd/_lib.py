@@ -32,6 +32,7 @@ PROTOTYPES = {
     "npi_edge_positions": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "npi_segsum_carry_elems": (_I, [_I, _I]),
     "npi_segsum": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
+    "npi_segsum_ex": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
     "npi_row_weight_sum": (c_int, [_P, _P, _I, _P, _P]),
     "npi_gcn_norm": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_row_inv_count": (c_int, [_P, _I, _P, _P]),
@@ -53,8 +54,12 @@ PROTOTYPES = {
     "npi_gat_softmax_stats": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _I, _P]),
     "npi_gat_aggregate": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                   _P, _P, _P, _P, _P, _P, _P, _P]),
+    "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
+                                     _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "npi_gat_edge_grad": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "npi_gat_edge_grad_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float,
+                                     c_int, _P, _P, _P]),
     "npi_seg_rowsum": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_entry_transpose_map": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_gat_att_grad_workspace_elems": (_I, [_I, _I, _I]),

@@ -438,8 +438,14 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                      const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ dout, int64_t ldd,
                      int H, int C, const float* __restrict__ a_dst, const float* __restrict__ a_src,
                      const float* __restrict__ m, const float* __restrict__ s, const float* __restrict__ D,
-                     float slope, float* __restrict__ dz, float* __restrict__ alpha_out) {
+                     float slope, float* __restrict__ dz, float* __restrict__ alpha_out,
+                     const float* __restrict__ hfeat2, int split, int swap) {
+    // swap == 0: rows are TARGETS (dout rows, a_dst / m / s / D by row), columns SOURCES (hfeat gathered, a_src by column).
+    // swap != 0: the same edges seen from a by-source CSR -- rows are sources (`dout` holds their hfeat rows, a_src by
+    //            row), columns targets (`hfeat` holds the gathered dOut rows; a_dst / m / s / D by column).
+    // hfeat2 / split: two-part gathered table as in segsum (column >= split reads row column - split of hfeat2).
     constexpr int U = (NCH <= 2) ? 4 : 2;
+    const float* __restrict__ hf2 = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(hfeat2) - (uint64_t)split * (uint64_t)ldh * sizeof(float));
     const int lane = lane_id();
     const int item = uniform_i(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= n_items) return;
@@ -479,7 +485,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int cu = bcast_i(cv, min(j + u, nb - 1));
-                    hv8[u] = act[0] ? *reinterpret_cast<const float4*>(hfeat + (int64_t)cu * ldh + foff[0])
+                    hv8[u] = act[0] ? *reinterpret_cast<const float4*>((cu < split ? hfeat : hf2) + (int64_t)cu * ldh + foff[0])
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 float p[8];
@@ -515,7 +521,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                 const int cu = bcast_i(cv, min(j + u, nb - 1));
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
-                    hv[u][c] = act[c] ? *reinterpret_cast<const float4*>(hfeat + (int64_t)cu * ldh + foff[c])
+                    hv[u][c] = act[c] ? *reinterpret_cast<const float4*>((cu < split ? hfeat : hf2) + (int64_t)cu * ldh + foff[c])
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -540,8 +546,8 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                     if (staged) {
                         if (lane == 0) pb[(j + u) * H + h] = p;
                     } else if (lane == 0) {
-                        const int64_t ii = (int64_t)i * H + h;
-                        const float z = a_dst[ii] + a_src[(int64_t)cu * H + h];
+                        const int64_t ii = (int64_t)(swap ? cu : i) * H + h;
+                        const float z = a_dst[ii] + a_src[(int64_t)(swap ? i : cu) * H + h];
                         const float alpha = expf(lrelu_(z, slope) - m[ii]) / (s[ii] + 1e-16f);
                         const float de = alpha * (p - D[ii]);
                         dz[(int64_t)(kb + j + u) * H + h] = de * (z > 0.f ? 1.f : slope);
@@ -557,8 +563,8 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                 const int en = min(t / H, nb - 1), h = t - (t / H) * H;
                 const int i = __shfl(rv, en, WAVE), cu = __shfl(cv, en, WAVE);
                 if (t >= nb * H) continue;
-                const int64_t ii = (int64_t)i * H + h;
-                const float z = a_dst[ii] + a_src[(int64_t)cu * H + h];
+                const int64_t ii = (int64_t)(swap ? cu : i) * H + h;
+                const float z = a_dst[ii] + a_src[(int64_t)(swap ? i : cu) * H + h];
                 const float alpha = expf(lrelu_(z, slope) - m[ii]) / (s[ii] + 1e-16f);
                 const float de = alpha * (pb[t] - D[ii]);
                 dz[(int64_t)kb * H + t] = de * (z > 0.f ? 1.f : slope);
@@ -748,7 +754,20 @@ extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, cons
                                  const float* g_dst, const float* g_src, const float* att,
                                  const float* alpha, const int32_t* alpha_map,
                                  float* carry, void* stream_) {
+    return npi_gat_aggregate_ex(rowptr, col, item_row, N, nnz_max, x, ldx, nullptr, 0, out, ldo, H, C, a_dst, a_src, m, s,
+                                slope, by_source, bias, g_dst, g_src, att, alpha, alpha_map, carry, stream_);
+}
+
+extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                                    int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
+                                    float* out, int64_t ldo,
+                                    int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
+                                    const float* s, float slope, int by_source, const float* bias,
+                                    const float* g_dst, const float* g_src, const float* att,
+                                    const float* alpha, const int32_t* alpha_map,
+                                    float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_ex: bad split");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && H > 0 && C > 0, "npi_gat_aggregate: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && col && item_row && x && out && a_dst && a_src && m && s && carry, "npi_gat_aggregate: null pointer");
@@ -757,6 +776,7 @@ extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, cons
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
     P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
     P.x = x; P.ldx = ldx; P.out = out; P.ldo = ldo; P.F = (int)(H * C);
+    P.x2 = x2; P.split = (int)split;
     P.carry = carry; P.w = nullptr; P.bias = bias;
     P.H = (int)H; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.m = m; P.s = s; P.slope = slope;
     P.g_dst = g_dst; P.g_src = g_src; P.att = att;
@@ -773,7 +793,20 @@ extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, cons
                                  const float* dout, int64_t ldd, int64_t H, int64_t C,
                                  const float* a_dst, const float* a_src, const float* m, const float* s,
                                  const float* D, float slope, float* dz, float* alpha_out, void* stream_) {
+    return npi_gat_edge_grad_ex(rowptr, col, rowidx, N, nnz_max, hfeat, ldh, nullptr, 0, dout, ldd, H, C, a_dst, a_src, m, s, D,
+                                slope, 0, dz, alpha_out, stream_);
+}
+
+extern "C" int npi_gat_edge_grad_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                                    int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
+                                    const float* hfeat2, int64_t split,
+                                    const float* dout, int64_t ldd, int64_t H, int64_t C,
+                                    const float* a_dst, const float* a_src, const float* m, const float* s,
+                                    const float* D, float slope, int swap, float* dz, float* alpha_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(hfeat2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_edge_grad_ex: bad split");
+    if (hfeat2 == nullptr) { hfeat2 = hfeat; split = 0x7fffffff; }
+    NPI_REQUIRE((uintptr_t)hfeat2 % 16 == 0, "npi_gat_edge_grad_ex: hfeat2 must be 16-B aligned");
     NPI_REQUIRE(N >= 0 && nnz_max >= 0 && H > 0 && C > 0, "npi_gat_edge_grad: bad size");
     if (N == 0 || nnz_max == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && col && rowidx && hfeat && dout && a_dst && a_src && m && s && D && dz, "npi_gat_edge_grad: null pointer");
@@ -784,7 +817,7 @@ extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, cons
     const int n_items = (int)npi_num_items(nnz_max);
     const unsigned grid = (unsigned)ceil_div(n_items, 4);
     const int nch = (int)ceil_div(F, 256);
-#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, item_edges_for(nnz_max), hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz, alpha_out)
+#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, item_edges_for(nnz_max), hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz, alpha_out, hfeat2, (int)split, swap)
     if (nch == 1) NPI_EG(1); else if (nch == 2) NPI_EG(2); else if (nch == 3) NPI_EG(3); else NPI_EG(4);
 #undef NPI_EG
     return check_launch("npi_gat_edge_grad");

@@ -14,6 +14,8 @@ struct SegParams {
     int item;                // entries per item (item_edges_for(nnz_max)); filled in by segsum_run
     const float* x;
     int64_t ldx;
+    const float* x2;         // two-part table: entries with col >= split read row (col - split) of x2 (same ldx);
+    int split;               // segsum_run fills in x2 = x, split = INT_MAX when x2 is null (one table)
     float* out;
     int64_t ldo;
     int F;

@@ -165,6 +165,10 @@ segsum_kernel(SegParams P) {
     const int k1 = min(k0 + P.item, nnz);
     const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
+    // second part of the table, biased so that it is indexed by the column id itself (sharded layers: the gathered hub
+    // rows and the rank's own rows are two buffers; dist.py)
+    const T* __restrict__ x2T = reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(P.x2) - (uint64_t)P.split * (uint64_t)P.ldx * sizeof(T));
+    const int split = P.split;
 
     Lanes<VEC, NCH, WMODE, EXACT> L;
     L.init(P);
@@ -252,7 +256,7 @@ segsum_kernel(SegParams P) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cu = bcast_i(cv, j + u);
-                const T* src = xT + (int64_t)cu * P.ldx;
+                const T* src = (cu < split ? xT : x2T) + (int64_t)cu * P.ldx;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[u][c]);
@@ -288,7 +292,7 @@ segsum_kernel(SegParams P) {
             float v[NCH][VEC];
             float g0[NCH], g1[NCH], g2[NCH];
             const int cu = bcast_i(cv, j);
-            const T* src = xT + (int64_t)cu * P.ldx;
+            const T* src = (cu < split ? xT : x2T) + (int64_t)cu * P.ldx;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[c]);
@@ -350,6 +354,8 @@ segsum_group_kernel(SegParams P) {
     const int k1 = min(k0 + P.item, nnz);
     const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
+    const T* __restrict__ x2T = reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(P.x2) - (uint64_t)P.split * (uint64_t)P.ldx * sizeof(T));
+    const int split = P.split;
     const int grp = lane / LG;
     const int foff = (lane % LG) * VEC;
     const bool act = foff < F;
@@ -411,7 +417,7 @@ segsum_group_kernel(SegParams P) {
                 const int e = j + u * G + grp;             // this lane group's entry of wave instruction u
                 const int cu = __shfl(cv, min(e, nb - 1), WAVE);
                 we[u] = (WMODE == W_ARRAY) ? __shfl(wv, min(e, nb - 1), WAVE) : 1.f;
-                if (act && e < nb) load_row<VEC, T>(xT + (int64_t)cu * P.ldx + foff, v[u]);
+                if (act && e < nb) load_row<VEC, T>((cu < split ? xT : x2T) + (int64_t)cu * P.ldx + foff, v[u]);
                 else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) v[u][q] = 0.f;
@@ -659,13 +665,15 @@ int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hip
     const int64_t F = P.F;
     P.item = item_edges_for(nnz_max);
     const int es = (dtype == NPI_BF16) ? 2 : 4;              // bytes per stored element
+    if (P.x2 == nullptr) { P.x2 = P.x; P.split = 0x7fffffff; }
     const char* x = reinterpret_cast<const char*>(P.x);
+    const char* x2 = reinterpret_cast<const char*>(P.x2);
     char* out = reinterpret_cast<char*>(P.out);
     const char* bias = reinterpret_cast<const char*>(P.bias);
     // widest vector the row pitch and base alignment allow
     auto aligned = [&](int v) {
         return (F % v == 0) && (P.ldx % v == 0) && (P.ldo % v == 0) &&
-               (((uintptr_t)x % (es * v)) == 0) && (((uintptr_t)out % (es * v)) == 0) &&
+               (((uintptr_t)x % (es * v)) == 0) && (((uintptr_t)x2 % (es * v)) == 0) && (((uintptr_t)out % (es * v)) == 0) &&
                (((uintptr_t)P.carry % (4 * v)) == 0);
     };
     const int vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
@@ -682,6 +690,7 @@ int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hip
         SegParams Q = P;
         Q.F = (int)((F - f0 < span) ? (F - f0) : span);       // carry rows are Q.F wide for this column block
         Q.x = reinterpret_cast<const float*>(x + f0 * es);
+        Q.x2 = reinterpret_cast<const float*>(x2 + f0 * es);
         Q.out = reinterpret_cast<float*>(out + f0 * es);
         Q.bias = bias ? reinterpret_cast<const float*>(bias + f0 * es) : nullptr;
         if (dtype == NPI_BF16) {
@@ -710,7 +719,16 @@ extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32
                           const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
                           void* out_, int64_t ldo, int64_t F, int dtype, int mean, const float* bias,
                           float* carry, void* stream_) {
+    return npi_segsum_ex(rowptr, col, item_row, w, N, nnz_max, x_, ldx, nullptr, 0, out_, ldo, F, dtype, mean, bias,
+                         carry, stream_);
+}
+
+extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                             const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
+                             const void* x2_, int64_t split, void* out_, int64_t ldo, int64_t F, int dtype, int mean,
+                             const float* bias, float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(x2_ == nullptr || (split >= 0 && split < 0x7fffffff), "npi_segsum_ex: bad split");
     NPI_REQUIRE(N >= 0 && nnz_max >= 0 && F > 0, "npi_segsum: bad size");
     NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_segsum: dtype must be NPI_F32 or NPI_BF16");
     NPI_REQUIRE(ldx >= F && ldo >= F, "npi_segsum: leading dimension < F");
@@ -728,6 +746,7 @@ extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
     P.N = (int)N; P.n_items = (int)n_items;
     P.x = (const float*)x_; P.ldx = ldx; P.out = (float*)out_; P.ldo = ldo; P.F = (int)F;
+    P.x2 = (const float*)x2_; P.split = (int)split;
     P.carry = carry; P.w = w; P.bias = bias;
     P.H = 1; P.C = (int)F;
     return segsum_run(P, w ? W_ARRAY : W_NONE, mean, nnz_max, dtype, stream);

@@ -1,7 +1,7 @@
 """One conv layer across the GPUs of a node: one process per GPU, RCCL over xGMI.
 
 The reference is single-process (no distributed code); this is the build's own
-multi-GPU form of the same layer (BASELINE.json configs[3]).
+multi-GPU form of the same layers (BASELINE.json configs[3] and [4]).
 
 Partition: a vertex cut with REPLICATED HUBS.  Nodes are split into hubs H (on the ncRNA-protein
 graphs: the protein side, ~10x fewer and ~10x heavier nodes) and light nodes L (the ncRNAs).
@@ -20,18 +20,32 @@ direction).  With every node a hub (``hub_mask=None``) side B is empty and the s
 destination-row split with an all-gather of all rows; that is the fallback for graphs without a
 small hub side.
 
-Local row order on rank r: its light nodes first, then the hubs it owns.  Side A reads a table
-``[gathered hub rows (W * h_per, rank-major, padded) ; local light rows]`` that the all-gather
-fills in place; side B reads the rank's own rows directly, so it runs while the all-gather is in
-flight, and the reduce-scatter of its result overlaps side A and (backward) the weight-gradient GEMM:
+Local row order on rank r: its light nodes first, then the hubs it owns.  Side A gathers from a
+TWO-PART table ``[gathered hub rows (W * h_per, rank-major, padded) ; the rank's own rows]``: the
+all-gather fills the first part, the second part IS the layer input (``npi_segsum_ex``; nothing is
+copied behind the received rows).  Side B reads the rank's own rows only, so it runs while the
+all-gather is in flight, and the reduce-scatter of its result overlaps side A and (backward) the
+weight-gradient GEMM:
 
-  forward :  hubs  = all_gather(x_own[hub rows])                     | part = segsum(B, x_own)
-             hsum  = reduce_scatter(part)                            | agg  = segsum_mean(A, table)
-             agg[hub rows] = (agg * cnt_A + hsum) / cnt ;  out = agg @ W + b
-  backward:  dagg  = (dOut @ W^T) / cnt
-             hubs  = all_gather(dagg[hub rows])                      | part = segsum(B^T, dagg)
-             hsum  = reduce_scatter(part)                            | dW, db (+ all_reduce, 256 KiB)
-             dX    = segsum(A^T, table) ;  dX[hub rows] += hsum
+  SAGE forward :  hubs  = all_gather(x_own[hub rows])                 | part = segsum(B, x_own)
+                  hsum  = reduce_scatter(part)                        | agg  = segsum_mean(A, [hubs ; x_own])
+                  agg[hub rows] = (agg * cnt_A + hsum) / cnt ;  out = agg @ W + b
+  SAGE backward:  dagg  = (dOut @ W^T) / cnt
+                  hubs  = all_gather(dagg[hub rows])                  | part = segsum(B^T, dagg)
+                  hsum  = reduce_scatter(part)                        | dW, db (+ all_reduce, 256 KiB)
+                  dX    = segsum(A^T, [hubs ; dagg]) ;  dX[hub rows] += hsum
+
+GCNConv is the same exchange at width F_out with the symmetric normalisation as per-entry weights
+on both sides (the degrees are global, known to every rank).  GATConv needs the softmax of a hub
+row whose sources sit on every rank: each rank computes (max, sum exp) of its part, one small
+all-reduce(MAX) makes the row maxima global, the partial weighted sums and exp-sums are then taken
+relative to that maximum and simply ADD (reduce-scatter) -- see ``_ShardedGatFn``.
+
+``EdgeShardedGraph`` / ``EdgeShardedSAGELayer`` are the north-star's literal baseline: every GPU
+walks a contiguous slice of the target-sorted entry stream over a full replica of ``x`` and the
+partial ``[N, F]`` sums are all-reduced (2.04 GB through the ring per direction at C4, against 0.2 GB
+for the hub cut) -- kept selectable (``bench.py --partition edges``) so the difference is measured,
+not asserted.
 
 Sums of partials arrive in RCCL's order, so multi-GPU results match the single-GPU ones to fp32
 rounding (tests: 1e-5), not bit for bit.
@@ -47,6 +61,8 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 from torch import nn
+
+NEG = -3.0e38      # "no entry" row maximum (what the softmax-statistics kernels start from)
 
 
 def auto_hubs(edge_index: torch.Tensor, num_nodes: int, ratio: float = 2.0, max_fraction: float = 0.5):
@@ -106,6 +122,13 @@ class HubPartition:
         k = self.index[ids]
         return (k % self.W) * self.h_per + k // self.W
 
+    def hub_table_ids(self) -> torch.Tensor:
+        """global node id of every row of the hub table (-1 for the pad rows of short ranks)"""
+        ids = torch.full((self.hub_rows,), -1, dtype=torch.long, device=self.hub.device)
+        h = torch.nonzero(self.hub).flatten()
+        ids[self.hub_row(h)] = h
+        return ids
+
     def own_ids(self, rank: int) -> torch.Tensor:
         """global ids of the rows of rank ``rank`` in local order (light nodes, then hubs)"""
         ids = torch.arange(self.N, device=self.hub.device)
@@ -125,7 +148,8 @@ class HubPartition:
 def local_sides(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: int):
     """(key, val, n_rows, n_cols) of side A and side B of rank ``rank`` for messages ``src -> dst``
     (call with the two swapped for the transposed sides).  Global self loops are dropped and one
-    loop per local row is appended LAST, which is where add_remaining_self_loops puts it."""
+    loop per local row is appended LAST, which is where add_remaining_self_loops puts it.
+    Column ids of side A index the two-part table ``[hub table (hub_rows) ; own rows (nL + nH)]``."""
     dev = src.device
     keep = src != dst
     src, dst = src[keep], dst[keep]
@@ -134,13 +158,13 @@ def local_sides(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: 
         raise ValueError("HubPartition: an edge joins two light nodes; mark one endpoint as a hub (auto_hubs)")
     nL, nH = part.n_light(rank), part.n_hub(rank)
     mine_d = part.owner(dst) == rank
-    # side A: rows = local order; table = [hub table ; local light rows]
+    # side A: rows = local order; table = [hub table ; own rows]
     a = mine_d & hub_s                                             # (light or hub) <- hub
     key_a = torch.where(hub_d[a], nL + part.local(dst[a]), part.local(dst[a]))
     val_a = part.hub_row(src[a])
     rows = torch.arange(nL + nH, device=dev)
     loop_col = torch.cat([part.hub_rows + rows[:nL], rank * part.h_per + rows[:nH]])
-    side_a = (torch.cat([key_a, rows]), torch.cat([val_a, loop_col]), nL + nH, part.hub_rows + nL)
+    side_a = (torch.cat([key_a, rows]), torch.cat([val_a, loop_col]), nL + nH, part.hub_rows + nL + nH)
     # side B: rows = hub table rows; sources = this rank's light rows, read from its own block
     b = hub_d & ~hub_s & (part.owner(src) == rank)
     side_b = (part.hub_row(dst[b]), part.local(src[b]), part.hub_rows, nL + nH)
@@ -180,10 +204,16 @@ def _portable(group) -> bool:
     return dist.get_backend(group) != "nccl"
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 def all_gather_rows(block: torch.Tensor, out: torch.Tensor, world: int, group=None, async_op: bool = False):
     """block [h_per, F] of every rank -> out [W * h_per, F] (rank-major)"""
     if _solo(world):
-        out.copy_(block)
+        if out.data_ptr() != block.data_ptr():
+            out.copy_(block)
         return None
     if _portable(group):                                           # gloo (CPU tests, one-GPU test rigs)
         work = dist.all_gather(list(out.view(world, block.size(0), -1).unbind(0)), block, group=group,
@@ -193,16 +223,12 @@ def all_gather_rows(block: torch.Tensor, out: torch.Tensor, world: int, group=No
     return work if async_op else None
 
 
-class _Done:
-    def wait(self):
-        return True
-
-
 def reduce_scatter_rows(part_sums: torch.Tensor, out: torch.Tensor, rank: int, world: int, group=None,
                         async_op: bool = False):
     """part_sums [W * h_per, F] of every rank -> out [h_per, F] = sum over ranks of block ``rank``"""
     if _solo(world):
-        out.copy_(part_sums)
+        if out.data_ptr() != part_sums.data_ptr():
+            out.copy_(part_sums)
         return None
     if _portable(group):
         dist.all_reduce(part_sums, group=group)
@@ -212,6 +238,12 @@ def reduce_scatter_rows(part_sums: torch.Tensor, out: torch.Tensor, rank: int, w
     return work if async_op else None
 
 
+def _all_reduce(t: torch.Tensor, world: int, group=None, op=None, tag: str = "all_reduce") -> None:
+    if _solo(world):
+        return
+    _wait(dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group, async_op=True), tag, t)
+
+
 class HipBackend:
     """Local compute of one rank on its MI355X through the C ABI."""
 
@@ -219,9 +251,18 @@ class HipBackend:
         from .graph import build_side
         return build_side(key.contiguous(), val.contiguous(), n_rows, n_cols, False, 0, False)
 
-    def segsum(self, side, table, mean: bool = False):
+    def row_lengths(self, side):
+        return (side.rowptr[1:] - side.rowptr[:-1])
+
+    def row_of_entry(self, side):
+        return side.rowidx[: side.nnz_max].long()
+
+    def col_of_entry(self, side):
+        return side.col[: side.nnz_max].long()
+
+    def segsum(self, side, table, mean: bool = False, table2=None, w=None, bias=None):
         from . import functional as NF
-        return NF.segsum(None, side, table, mean=mean)
+        return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2)
 
     def linear_fwd(self, a, w, b):
         from . import functional as NF
@@ -235,12 +276,49 @@ class HipBackend:
         from . import functional as NF
         return NF.linear_bwd_weight(a, dc, want_bias, shared=shared)
 
+    def colsum(self, x):
+        from . import functional as NF
+        return NF.colsum(x)
+
     def side_stream(self, like):
         """second HIP stream for the weight-gradient GEMM, or None when the shard is too small to gain"""
         from . import functional as NF
         if not NF.OVERLAP_STREAMS or like.size(0) < NF.OVERLAP_MIN_ROWS:
             return None
         return NF._side_stream(like.device)
+
+    # ---- GATConv pieces (functional.py wraps the C ABI; index spaces: rows of the side / its table) ----
+    def gat_scores(self, h, att2, H, C):
+        from . import functional as NF
+        return NF.gat_scores(h, att2, H, C)
+
+    def gat_stats(self, side, a_row, a_col, H, slope):
+        from . import functional as NF
+        return NF.gat_softmax_stats(side, a_row, a_col, H, slope)
+
+    def gat_aggregate(self, side, table, table2, H, C, a_dst, a_src, m, s, slope, by_source, bias=None,
+                      g_dst=None, g_src=None, att=None):
+        from . import functional as NF
+        if side.nnz_max == 0:
+            return table.new_zeros((side.n_rows, H * C))
+        return NF._gat_aggregate(None, side, table, H, C, a_dst, a_src, m, s, slope, by_source, bias=bias, g_dst=g_dst,
+                                 g_src=g_src, att=att, x2=table2)
+
+    def gat_rowdot(self, a, b, bias, H, C):
+        from . import functional as NF
+        return NF.gat_rowdot(a, b, bias, H, C)
+
+    def gat_edge_grad(self, side, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap):
+        from . import functional as NF
+        return NF.gat_edge_grad(side, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap)
+
+    def seg_rowsum(self, side, vals, H):
+        from . import functional as NF
+        return NF.seg_rowsum(side, vals, H)
+
+    def gat_att_grad(self, h, g_dst, g_src, H, C):
+        from . import functional as NF
+        return NF.gat_att_grad(h, g_dst, g_src, H, C)
 
 
 class ShardedGraph:
@@ -264,33 +342,84 @@ class ShardedGraph:
         self.local_nnz = int(a[0].numel()) + int(b[0].numel())    # entries this rank walks per direction
         # 1 / (in-degree + 1) of the local rows; for hub rows also the share of it that side A holds
         keep = src != dst
-        cnt = torch.bincount(dst[keep], minlength=num_nodes).to(torch.float32) + 1.0
+        self._src, self._dst = src[keep], dst[keep]
+        cnt = torch.bincount(self._dst, minlength=num_nodes).to(torch.float32) + 1.0
         own = part.own_ids(rank)
         self.inv_cnt = (1.0 / cnt[own]).contiguous()
         self.cnt_a_hub = torch.bincount(a[0], minlength=self.n_local)[self.nL:].to(torch.float32).view(-1, 1)
         self.own = own
+        self.own_hub = slice(rank * part.h_per, rank * part.h_per + self.nH)       # this rank's rows of the hub table
+        self._gcn = None
+        self._b_empty = None
 
     def shard(self, x_full: torch.Tensor) -> torch.Tensor:
         return x_full[self.own.to(x_full.device)]
 
+    def gcn_norm(self):
+        """Per-entry symmetric normalisation (PyG 1.4.2 ``GCNConv.norm``: deg = out-degree incl. the self loop, over
+        the SOURCE rows) of sides A, B, At, Bt -- the degrees are global, every rank derives them from the edge list."""
+        if self._gcn is None:
+            part, be, N = self.part, self.backend, self.part.N
+            deg = torch.bincount(self._src, minlength=N).to(torch.float32) + 1.0
+            dinv = deg.pow(-0.5)
+            tid = part.hub_table_ids()
+            d_hub = torch.where(tid >= 0, dinv[tid.clamp(min=0)], torch.zeros((), device=dinv.device))
+            d_own = dinv[self.own]
+            d_tbl = torch.cat([d_hub, d_own])                     # index space of side A's columns
+            w = {}
+            for name, side in (("A", self.A), ("At", self.At)):
+                w[name] = (d_own[be.row_of_entry(side)] * d_tbl[be.col_of_entry(side)]).contiguous()
+            for name, side in (("B", self.B), ("Bt", self.Bt)):
+                w[name] = None if side is None else (d_hub[be.row_of_entry(side)] * d_own[be.col_of_entry(side)]).contiguous()
+            self._gcn = w
+        return self._gcn
 
-def _exchange_start(sg: ShardedGraph, rows: torch.Tensor, side_b):
-    """Launch the all-gather of the hub rows of ``rows`` and the reduce-scatter of side B's partial
-    hub sums.  Returns (table for side A, its pending work, reduced hub sums or None, its pending work)."""
-    part, be, W = sg.part, sg.backend, sg.world
-    F = rows.size(1)
-    table = rows.new_empty((part.hub_rows + sg.nL, F))
+    def b_empty(self):
+        """[hub_rows, 1] bool: hub-table rows to which this rank contributes no entry (side B)"""
+        if self._b_empty is None and self.B is not None:
+            self._b_empty = (self.backend.row_lengths(self.B) == 0).view(-1, 1)
+        return self._b_empty
+
+
+def _hub_block(sg: ShardedGraph, rows: torch.Tensor) -> torch.Tensor:
+    """this rank's hub rows of ``rows`` [n_local, K], zero-padded to h_per"""
     block = rows[sg.nL:]
-    if sg.nH != part.h_per:                                        # short rank: one zero pad row
-        block = rows.new_zeros((part.h_per, F))
+    if sg.nH != sg.part.h_per:                                     # short rank: one zero pad row
+        block = rows.new_zeros((sg.part.h_per,) + tuple(rows.shape[1:]))
         block[: sg.nH] = rows[sg.nL:]
-    g_work = all_gather_rows(block.contiguous(), table[: part.hub_rows], W, sg.group, async_op=not _solo(W))
-    table[part.hub_rows:] = rows[: sg.nL]
+    return block.contiguous()
+
+
+def gather_hub(sg: ShardedGraph, rows: torch.Tensor, async_op: bool = False):
+    """all-gather of the hub rows of ``rows`` [n_local, K] -> ([hub_rows, K] rank-major, pending work or None)"""
+    part, W = sg.part, sg.world
+    block = _hub_block(sg, rows)
+    if _solo(W):
+        return block, None                                         # one rank: the hub table IS its own hub block
+    table = rows.new_empty((part.hub_rows,) + tuple(rows.shape[1:]))
+    work = all_gather_rows(block, table, W, sg.group, async_op=async_op)
+    return table, work
+
+
+def scatter_hub_sums(sg: ShardedGraph, partial: torch.Tensor, async_op: bool = False):
+    """reduce-scatter of partial hub sums [hub_rows, K] -> ([h_per, K] for this rank's hubs, pending work or None)"""
+    W = sg.world
+    if _solo(W):
+        return partial, None
+    hsum = partial.new_empty((sg.part.h_per,) + tuple(partial.shape[1:]))
+    work = reduce_scatter_rows(partial, hsum, sg.rank, W, sg.group, async_op=async_op)
+    return hsum, work
+
+
+def _exchange_start(sg: ShardedGraph, rows: torch.Tensor, side_b, w_b=None):
+    """Launch the all-gather of the hub rows of ``rows`` and the reduce-scatter of side B's partial
+    hub sums.  Returns (hub table for side A, its pending work, reduced hub sums or None, its pending work)."""
+    be = sg.backend
+    table, g_work = gather_hub(sg, rows, async_op=True)
     hsum = r_work = None
     if sg.exchange_partials:
-        partial = be.segsum(side_b, rows)                          # no remote input: overlaps the all-gather
-        hsum = rows.new_empty((part.h_per, F))
-        r_work = reduce_scatter_rows(partial, hsum, sg.rank, W, sg.group, async_op=not _solo(W))
+        partial = be.segsum(side_b, rows, w=w_b)                   # no remote input: overlaps the all-gather
+        hsum, r_work = scatter_hub_sums(sg, partial, async_op=True)
     return table, g_work, hsum, r_work
 
 
@@ -301,7 +430,7 @@ class _ShardedSageFn(torch.autograd.Function):
         x_own = x_own.contiguous()
         table, g_work, hsum, r_work = _exchange_start(sg, x_own, sg.B)
         _wait(g_work, "fwd_all_gather", table)
-        agg = be.segsum(sg.A, table, mean=True)
+        agg = be.segsum(sg.A, table, mean=True, table2=x_own)
         if hsum is not None:
             _wait(r_work, "fwd_reduce_scatter", hsum)
             if sg.nH:
@@ -321,6 +450,7 @@ class _ShardedSageFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         dx = dw = db = None
         started = None
+        dagg = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0]:
             dagg = be.linear_bwd_data(grad_out, weight, sg.inv_cnt)
@@ -340,7 +470,7 @@ class _ShardedSageFn(torch.autograd.Function):
 
             def finish():
                 _wait(g_work, "bwd_all_gather", table)
-                out = be.segsum(sg.At, table)
+                out = be.segsum(sg.At, table, table2=dagg)
                 if hsum is not None:
                     _wait(r_work, "bwd_reduce_scatter", hsum)
                     if sg.nH:
@@ -349,30 +479,308 @@ class _ShardedSageFn(torch.autograd.Function):
             if side is not None:
                 with torch.cuda.stream(side):
                     dx = finish()
-                for t in (table, hsum):
+                for t in (table, hsum, dagg):
                     if t is not None:
                         t.record_stream(side)
                 dx.record_stream(main)
                 main.wait_stream(side)
             else:
                 dx = finish()
-        if want_w and not _solo(sg.world):
-            _wait(dist.all_reduce(dw, group=sg.group, async_op=True), "bwd_all_reduce_dw", dw)
+        if want_w:
+            _all_reduce(dw, sg.world, sg.group, tag="bwd_all_reduce_dw")
             if db is not None:
-                _wait(dist.all_reduce(db, group=sg.group, async_op=True), "bwd_all_reduce_db", db)
+                _all_reduce(db, sg.world, sg.group, tag="bwd_all_reduce_db")
         return dx, dw, db, None
 
 
-class ShardedSAGELayer(nn.Module):
-    """SAGEConv (PyG 1.4.2 semantics, mean over in-neighbours and self, then ``@ W + b``) on a sharded
-    graph.  Input and output are this rank's rows (``ShardedGraph.own``: light nodes, then hubs);
-    parameters are replicated and their gradients all-reduced, as data-parallel training expects."""
+class _ShardedGcnFn(torch.autograd.Function):
+    """GCNConv (PyG 1.4.2, normalize=True, unweighted): project first, then the hub exchange at width F_out with
+    ``norm_e = deg^-1/2[src] deg^-1/2[dst]`` as per-entry weights of every side."""
 
+    @staticmethod
+    def forward(ctx, x_own, weight, bias, sg: ShardedGraph):
+        be = sg.backend
+        nrm = sg.gcn_norm()
+        x_own = x_own.contiguous()
+        xw = be.linear_fwd(x_own, weight, None)
+        table, g_work, hsum, r_work = _exchange_start(sg, xw, sg.B, nrm["B"])
+        _wait(g_work, "fwd_all_gather", table)
+        out = be.segsum(sg.A, table, table2=xw, w=nrm["A"], bias=bias)
+        if hsum is not None:
+            _wait(r_work, "fwd_reduce_scatter", hsum)
+            if sg.nH:
+                out[sg.nL:] += hsum[: sg.nH]
+        ctx.sg = sg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x_own, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_own, weight = ctx.saved_tensors
+        sg: ShardedGraph = ctx.sg
+        be = sg.backend
+        nrm = sg.gcn_norm()
+        grad_out = grad_out.contiguous()
+        dx = dw = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = be.colsum(grad_out)
+            _all_reduce(db, sg.world, sg.group, tag="bwd_all_reduce_db")
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            table, g_work, hsum, r_work = _exchange_start(sg, grad_out, sg.Bt, nrm["Bt"])
+            _wait(g_work, "bwd_all_gather", table)
+            dxw = be.segsum(sg.At, table, table2=grad_out, w=nrm["At"])
+            if hsum is not None:
+                _wait(r_work, "bwd_reduce_scatter", hsum)
+                if sg.nH:
+                    dxw[sg.nL:] += hsum[: sg.nH]
+            if ctx.needs_input_grad[1]:
+                dw, _ = be.linear_bwd_weight(x_own, dxw, False)
+                _all_reduce(dw, sg.world, sg.group, tag="bwd_all_reduce_dw")
+            if ctx.needs_input_grad[0]:
+                dx = be.linear_bwd_data(dxw, weight, None)
+        return dx, dw, db, None
+
+
+class _ShardedGatFn(torch.autograd.Function):
+    """GATConv (PyG 1.4.2, dropout 0, concat) on the hub cut.  The softmax of a LIGHT target row is local (all its
+    sources are hub rows of the gathered table, plus itself).  A HUB target row has sources on every rank:
+
+      forward   rank r: (m_r, s_r) = (max, sum exp(. - m_r)) of ITS entries of the row      [side B; owner: side A]
+                M = all_reduce(MAX) of m_r                       one small collective, [hub_rows, H]
+                U_r = sum_p exp(e_p - M) h_j,  S_r = s_r exp(m_r - M)                       relative to the GLOBAL max
+                owner: out = (sum_r U_r) / (sum_r S_r + 1e-16)   reduce-scatter of U [hub_rows, F] and S [hub_rows, H]
+      backward  every rank needs (a_dst, M, S, D, dOut) of the hub TARGETS it holds entries of: all-gather of the hub
+                rows of dOut and of three scalars; dz is recomputed in the orientation it is summed in (by target for
+                g_dst, by source for g_src; npi_gat_edge_grad_ex swap), partial hub sums reduce-scattered.
+    """
+
+    @staticmethod
+    def forward(ctx, x_own, weight, att, bias, sg: ShardedGraph, heads: int, slope: float):
+        be, part, W = sg.backend, sg.part, sg.world
+        nL, nH = sg.nL, sg.nH
+        H = int(heads)
+        C = weight.size(1) // H
+        x_own = x_own.contiguous()
+        att2 = att.reshape(H, 2 * C).contiguous()
+        h = be.linear_fwd(x_own, weight, None)
+        a_dst, a_src = be.gat_scores(h, att2, H, C)                              # [n_local, H] each
+        tbl_h, g_work = gather_hub(sg, h, async_op=True)                          # big: hub rows of h
+        hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))              # small
+        hub_a_dst, hub_a_src = hub_sc[:, :H].contiguous(), hub_sc[:, H:].contiguous()
+        tbl_a_src = torch.cat([hub_a_src, a_src])                                 # index space of side A's columns
+        mA, sA = be.gat_stats(sg.A, a_dst, tbl_a_src, H, slope)                   # every row holds its self loop
+        own = sg.own_hub
+        if sg.exchange_partials:
+            mB, sB = be.gat_stats(sg.B, hub_a_dst, a_src, H, slope)
+            empty = sg.b_empty()
+            mB = torch.where(empty, torch.full_like(mB, NEG), mB)
+            M = mB.clone()
+        else:
+            M = torch.full((part.hub_rows, H), NEG, dtype=h.dtype, device=h.device)
+        M[own] = torch.maximum(M[own], mA[nL:])
+        _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
+        ones_h = torch.ones((nH, H), dtype=h.dtype, device=h.device)
+        m_own = torch.cat([mA[:nL], M[own]])
+        _wait(g_work, "fwd_all_gather", tbl_h)
+        # light rows: finished softmax; hub rows: weighted sum relative to M, not yet normalised
+        out = be.gat_aggregate(sg.A, tbl_h, h, H, C, a_dst, tbl_a_src, m_own, torch.cat([sA[:nL], ones_h]), slope,
+                               False, bias=bias)
+        S_tot = sA[nL:] * torch.exp(mA[nL:] - M[own])
+        U = out[nL:] - bias if bias is not None else out[nL:]
+        if sg.exchange_partials:
+            U_B = be.gat_aggregate(sg.B, h, None, H, C, hub_a_dst, a_src, M, torch.ones_like(M), slope, False)
+            S_B = torch.where(empty, torch.zeros_like(sB), sB * torch.exp(mB - M))
+            hU, wU = scatter_hub_sums(sg, U_B, async_op=True)
+            hS, wS = scatter_hub_sums(sg, S_B.contiguous(), async_op=True)
+            _wait(wU, "fwd_reduce_scatter", hU)
+            _wait(wS, "fwd_reduce_scatter_s", hS)
+            U = U + hU[:nH]
+            S_tot = S_tot + hS[:nH]
+        if nH:
+            res = (U.view(nH, H, C) / (S_tot.view(nH, H, 1) + 1e-16)).reshape(nH, H * C)
+            out[nL:] = res + bias if bias is not None else res
+        s_own = torch.cat([sA[:nL], S_tot])
+        hubS, _ = gather_hub(sg, s_own)                                           # the backward's per-target sums
+        ctx.sg, ctx.H, ctx.C, ctx.slope = sg, H, C, float(slope)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x_own, weight, att2, h, a_dst, a_src, tbl_h, hub_a_dst, hub_a_src, M, hubS, m_own, s_own,
+                              out, bias if bias is not None else h.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x_own, weight, att2, h, a_dst, a_src, tbl_h, hub_a_dst, hub_a_src, hubM, hubS, m_own, s_own, out,
+         bias) = ctx.saved_tensors
+        sg: ShardedGraph = ctx.sg
+        be, W = sg.backend, sg.world
+        nL, nH = sg.nL, sg.nH
+        H, C, slope = ctx.H, ctx.C, ctx.slope
+        dO = grad_out.contiguous()
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = be.colsum(dO)
+            _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
+        D = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, H, C)          # [n_local, H]
+        tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                        # big: hub rows of dOut
+        hubD, _ = gather_hub(sg, D)
+        # per-TARGET scalars in the index space of the two-part table [hub table ; own rows]
+        tbl_a_dst = torch.cat([hub_a_dst, a_dst])
+        tbl_m, tbl_s, tbl_D = torch.cat([hubM, m_own]), torch.cat([hubS, s_own]), torch.cat([hubD, D])
+        tbl_a_src = torch.cat([hub_a_src, a_src])
+        # g_dst[i] = sum over the entries whose TARGET is i
+        dz = be.gat_edge_grad(sg.A, tbl_h, h, dO, H, C, a_dst, tbl_a_src, m_own, s_own, D, slope, 0)
+        g_dst = be.seg_rowsum(sg.A, dz, H)
+        _wait(g_work, "bwd_all_gather", tbl_dO)
+        # g_src[j] = sum over the entries whose SOURCE is j: the same dz, recomputed on the by-source sides
+        dz = be.gat_edge_grad(sg.At, tbl_dO, dO, h, H, C, tbl_a_dst, a_src, tbl_m, tbl_s, tbl_D, slope, 1)
+        g_src = be.seg_rowsum(sg.At, dz, H)
+        if sg.exchange_partials:
+            dz = be.gat_edge_grad(sg.B, h, None, tbl_dO, H, C, hub_a_dst, a_src, hubM, hubS, hubD, slope, 0)
+            pg_dst = be.seg_rowsum(sg.B, dz, H)
+            dz = be.gat_edge_grad(sg.Bt, dO, None, tbl_h, H, C, a_dst, hub_a_src, m_own, s_own, D, slope, 1)
+            pg_src = be.seg_rowsum(sg.Bt, dz, H)
+            pg, wg = scatter_hub_sums(sg, torch.cat([pg_dst, pg_src], dim=1).contiguous(), async_op=True)
+            # partial d h of the hub rows from this rank's light targets, under the small reduce-scatter
+            pdh = be.gat_aggregate(sg.Bt, dO, None, H, C, a_dst, hub_a_src, m_own, s_own, slope, True)
+            hdh, wh = scatter_hub_sums(sg, pdh, async_op=True)
+            _wait(wg, "bwd_reduce_scatter_g", pg)
+            if nH:
+                g_dst[nL:] += pg[:nH, :H]
+                g_src[nL:] += pg[:nH, H:]
+        # d h_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
+        dh = be.gat_aggregate(sg.At, tbl_dO, dO, H, C, tbl_a_dst, a_src, tbl_m, tbl_s, slope, True,
+                              g_dst=g_dst, g_src=g_src, att=att2)
+        if sg.exchange_partials:
+            _wait(wh, "bwd_reduce_scatter", hdh)
+            if nH:
+                dh[nL:] += hdh[:nH]
+        datt = dw = dx = None
+        if ctx.needs_input_grad[2]:
+            datt = be.gat_att_grad(h, g_dst, g_src, H, C)
+            _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
+            datt = datt.view(1, H, 2 * C)
+        if ctx.needs_input_grad[1]:
+            dw, _ = be.linear_bwd_weight(x_own, dh, False)
+            _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
+        if ctx.needs_input_grad[0]:
+            dx = be.linear_bwd_data(dh, weight, None)
+        return dx, dw, datt, db, None, None, None
+
+
+class _ShardedLayer(nn.Module):
     def __init__(self, sg: ShardedGraph, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
         super().__init__()
         self.sg = sg
         self.weight = nn.Parameter(weight.clone())
         self.bias = nn.Parameter(bias.clone()) if bias is not None else None
 
+
+class ShardedSAGELayer(_ShardedLayer):
+    """SAGEConv (PyG 1.4.2 semantics, mean over in-neighbours and self, then ``@ W + b``) on a sharded
+    graph.  Input and output are this rank's rows (``ShardedGraph.own``: light nodes, then hubs);
+    parameters are replicated and their gradients all-reduced, as data-parallel training expects."""
+
     def forward(self, x_own: torch.Tensor) -> torch.Tensor:
         return _ShardedSageFn.apply(x_own, self.weight, self.bias, self.sg)
+
+
+class ShardedGCNLayer(_ShardedLayer):
+    """GCNConv (PyG 1.4.2: ``improved=False, normalize=True``, no edge weights) on a sharded graph."""
+
+    def forward(self, x_own: torch.Tensor) -> torch.Tensor:
+        return _ShardedGcnFn.apply(x_own, self.weight, self.bias, self.sg)
+
+
+class ShardedGATLayer(_ShardedLayer):
+    """GATConv (PyG 1.4.2: ``concat=True, dropout=0``) on a sharded graph; ``att`` is ``[1, heads, 2 * out]``."""
+
+    def __init__(self, sg: ShardedGraph, weight: torch.Tensor, att: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 heads: int = 1, negative_slope: float = 0.2):
+        super().__init__(sg, weight, bias)
+        self.att = nn.Parameter(att.clone())
+        self.heads, self.negative_slope = int(heads), float(negative_slope)
+
+    def forward(self, x_own: torch.Tensor) -> torch.Tensor:
+        return _ShardedGatFn.apply(x_own, self.weight, self.att, self.bias, self.sg, self.heads, self.negative_slope)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# the north-star's baseline split: edge shards over a replicated x, all-reduce of the partial [N, F] sums
+# -------------------------------------------------------------------------------------------------------------
+class EdgeShardedGraph:
+    """Rank r walks entries [r E'/W, (r+1) E'/W) of the target-sorted (forward) / source-sorted (backward) stream of
+    non-loop edges -- cut on the entry count, so a heavy row may straddle ranks -- plus the self loops of its block of
+    output rows.  ``x`` is replicated; outputs are the contiguous row block ``[lo, hi)`` of this rank."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, device, backend=None, group=None):
+        self.N, self.rank, self.world, self.group = int(num_nodes), rank, world, group
+        self.backend = be = backend or HipBackend()
+        ei = edge_index.to(device)
+        keep = ei[0] != ei[1]
+        src, dst = ei[0][keep], ei[1][keep]
+        E = int(src.numel())
+        self.per = (self.N + world - 1) // world                      # padded rows per rank
+        self.lo, self.hi = min(rank * self.per, self.N), min((rank + 1) * self.per, self.N)
+        blk = torch.arange(self.lo, self.hi, device=device)
+        e0, e1 = rank * E // world, (rank + 1) * E // world
+
+        def side(key, val):
+            order = torch.sort(key, stable=True)[1][e0:e1]
+            return be.make_side(torch.cat([key[order], blk]), torch.cat([val[order], blk]), self.N, self.N)
+        self.fwd, self.bwd = side(dst, src), side(src, dst)
+        self.local_nnz = e1 - e0
+        cnt = torch.bincount(dst, minlength=self.N).to(torch.float32) + 1.0
+        self.inv_cnt = (1.0 / cnt[self.lo:self.hi]).contiguous()
+
+    def shard(self, x_full: torch.Tensor) -> torch.Tensor:
+        return x_full[self.lo:self.hi]
+
+
+class _EdgeShardedSageFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_full, weight, bias, sg: EdgeShardedGraph):
+        be = sg.backend
+        part = be.segsum(sg.fwd, x_full.contiguous())                  # partial sums of ALL rows over this rank's entries
+        _all_reduce(part, sg.world, sg.group, tag="fwd_all_reduce")
+        agg = part[sg.lo:sg.hi] * sg.inv_cnt.view(-1, 1)
+        out = be.linear_fwd(agg.contiguous(), weight, bias)
+        ctx.sg = sg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(agg, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        agg, weight = ctx.saved_tensors
+        sg: EdgeShardedGraph = ctx.sg
+        be, W = sg.backend, sg.world
+        grad_out = grad_out.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
+            _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
+            if db is not None:
+                _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
+        if ctx.needs_input_grad[0]:
+            dagg = be.linear_bwd_data(grad_out, weight, sg.inv_cnt)     # this rank's row block
+            full = dagg.new_empty((W * sg.per, dagg.size(1)))
+            if _solo(W):
+                full[: dagg.size(0)] = dagg
+            else:
+                block = dagg
+                if dagg.size(0) != sg.per:                              # last rank(s): pad the block
+                    block = dagg.new_zeros((sg.per, dagg.size(1)))
+                    block[: dagg.size(0)] = dagg
+                _wait(all_gather_rows(block.contiguous(), full, W, sg.group, async_op=True), "bwd_all_gather", full)
+            dx = be.segsum(sg.bwd, full[: sg.N])                        # partial dX of ALL rows
+            _all_reduce(dx, W, sg.group, tag="bwd_all_reduce")          # x is replicated: its gradient is the sum
+        return dx, dw, db, None
+
+
+class EdgeShardedSAGELayer(_ShardedLayer):
+    """SAGEConv with the north-star's edge split: input = the full (replicated) ``x``, output = this rank's block of
+    rows; the gradient of ``x`` comes back complete on every rank."""
+
+    def forward(self, x_full: torch.Tensor) -> torch.Tensor:
+        return _EdgeShardedSageFn.apply(x_full, self.weight, self.bias, self.sg)

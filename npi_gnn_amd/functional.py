@@ -84,16 +84,26 @@ def _code(t: torch.Tensor) -> int:
 # ---------------------------------------------------------------------------------------------
 def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Tensor] = None,
            mean: bool = False, bias: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i] = scale_i * sum_{p in row i} w[p] * x[col[p]] (+ bias): fused gather + segmented
-    reduction (``npi_segsum``)."""
-    dev = require_gpu(x, w, bias)
+    reduction (``npi_segsum``).  ``x2``: second part of a two-part table -- entries with
+    ``col >= x.size(0)`` read ``x2[col - x.size(0)]`` (``npi_segsum_ex``; the sharded layers)."""
+    dev = require_gpu(x, w, bias, x2)
     x = _fc(x, "x")
     if bias is not None:
         bias = _fc(bias, "bias", x)
     N, F = side.n_rows, x.size(1)                  # `graph` may be None for a stand-alone (sharded) side
-    if x.size(0) != side.n_cols:
-        raise ValueError(f"x has {x.size(0)} rows, the adjacency indexes a table of {side.n_cols}")
+    split = x.size(0)
+    if x2 is not None:
+        x2 = _fc(x2, "x2", x)
+        if x2.size(1) != F:
+            raise ValueError("x2 must have the width of x")
+        if x2.stride(0) != x.stride(0):
+            x2 = x2.contiguous()
+            if x2.stride(0) != x.stride(0):
+                x = x.contiguous()
+    if side.n_cols > split + (x2.size(0) if x2 is not None else 0):
+        raise ValueError(f"the table has {split + (x2.size(0) if x2 is not None else 0)} rows, the adjacency indexes {side.n_cols}")
     if out is None:
         out = torch.empty((N, F), dtype=x.dtype, device=dev)
     carry = side.carry(F)
@@ -101,9 +111,9 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     if prof is not None:        # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(dev))
-    check(load().npi_segsum(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), ptr(w), N, side.nnz_max,
-                            ptr(x), x.stride(0), ptr(out), out.stride(0), F, _code(x), 1 if mean else 0,
-                            ptr(bias), ptr(carry), stream_ptr(dev)), "npi_segsum")
+    check(load().npi_segsum_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), ptr(w), N, side.nnz_max,
+                               ptr(x), x.stride(0), ptr(x2), split if x2 is not None else 0, ptr(out), out.stride(0), F,
+                               _code(x), 1 if mean else 0, ptr(bias), ptr(carry), stream_ptr(dev)), "npi_segsum")
     if prof is not None:
         ev1.record(torch.cuda.current_stream(dev))
         prof.append((ev0, ev1))
@@ -362,15 +372,103 @@ def _transpose_map(graph: CSRGraph) -> torch.Tensor:
 
 
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
-                   g_src=None, att=None, alpha=None, alpha_map=None):
+                   g_src=None, att=None, alpha=None, alpha_map=None, x2=None):
+    """``x2``: second part of a two-part table (see ``segsum``)."""
     dev = x.device
+    x = _f32c(x, "x")
+    if x2 is not None:
+        x2 = _f32c(x2, "x2")
+        if x2.stride(0) != x.stride(0):
+            raise ValueError("the two parts of the table must share the row pitch")
     out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
-    check(load().npi_gat_aggregate(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
-                                   ptr(x), x.stride(0), ptr(out), out.stride(0), H, C, ptr(a_dst), ptr(a_src),
-                                   ptr(m), ptr(s), float(slope), 1 if by_source else 0, ptr(bias), ptr(g_dst),
-                                   ptr(g_src), ptr(att), ptr(alpha), ptr(alpha_map), ptr(side.carry(H * C)),
-                                   stream_ptr(dev)), "npi_gat_aggregate")
+    check(load().npi_gat_aggregate_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
+                                      ptr(x), x.stride(0), ptr(x2), x.size(0) if x2 is not None else 0,
+                                      ptr(out), out.stride(0), H, C, ptr(a_dst), ptr(a_src),
+                                      ptr(m), ptr(s), float(slope), 1 if by_source else 0, ptr(bias), ptr(g_dst),
+                                      ptr(g_src), ptr(att), ptr(alpha), ptr(alpha_map), ptr(side.carry(H * C)),
+                                      stream_ptr(dev)), "npi_gat_aggregate")
     return out
+
+
+def gat_scores(hfeat, att2, H, C):
+    """a_dst[i,h] = <hfeat[i,h,:], att[h,:C]>, a_src[i,h] = <hfeat[i,h,:], att[h,C:]>"""
+    dev = hfeat.device
+    N = hfeat.size(0)
+    a_dst = torch.empty((N, H), dtype=torch.float32, device=dev)
+    a_src = torch.empty((N, H), dtype=torch.float32, device=dev)
+    check(load().npi_gat_scores(ptr(hfeat), hfeat.stride(0), ptr(att2), N, H, C, ptr(a_dst), ptr(a_src), stream_ptr(dev)),
+          "npi_gat_scores")
+    return a_dst, a_src
+
+
+def gat_softmax_stats(side: CSRSide, a_row, a_col, H, slope):
+    """(m, s) [n_rows, H]: row max and sum of exp(. - max) of leaky_relu(a_row[row] + a_col[col]) over the entries of
+    every row of ``side`` (an empty row gets m = 0, s = 0)."""
+    lib = load()
+    dev = a_row.device
+    m = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
+    s = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
+    n_hw = int(lib.npi_gat_heavy_workspace_elems(side.nnz_max, H))
+    hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
+    check(lib.npi_gat_softmax_stats(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), ptr(a_row), ptr(a_col),
+                                    side.n_rows, side.nnz_max, H, float(slope), ptr(m), ptr(s), ptr(hws), n_hw,
+                                    stream_ptr(dev)), "npi_gat_softmax_stats")
+    return m, s
+
+
+def gat_rowdot(a, b, bias, H, C):
+    """D[i,h] = <a[i,h,:], b[i,h,:] - bias[h,:]>"""
+    dev = a.device
+    N = a.size(0)
+    D = torch.empty((N, H), dtype=torch.float32, device=dev)
+    check(load().npi_gat_rowdot(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), N, H, C, ptr(D), stream_ptr(dev)),
+          "npi_gat_rowdot")
+    return D
+
+
+def gat_edge_grad(side: CSRSide, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap,
+                  alpha_out=None):
+    """dz per entry of ``side`` (``npi_gat_edge_grad_ex``).  swap = 0: rows are targets (row_feat = dOut rows; a_dst,
+    m, s, D by row; a_src by column; col_feat = gathered hfeat).  swap = 1: rows are sources (row_feat = their hfeat;
+    a_src by row; a_dst, m, s, D by column; col_feat = gathered dOut)."""
+    dev = row_feat.device
+    dz = torch.empty((max(side.nnz_max, 1), H), dtype=torch.float32, device=dev)
+    col_feat = _f32c(col_feat, "col_feat")
+    if col_feat2 is not None:
+        col_feat2 = _f32c(col_feat2, "col_feat2")
+        if col_feat2.stride(0) != col_feat.stride(0):
+            raise ValueError("the two parts of the table must share the row pitch")
+    check(load().npi_gat_edge_grad_ex(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), side.n_rows, side.nnz_max,
+                                      ptr(col_feat), col_feat.stride(0), ptr(col_feat2),
+                                      col_feat.size(0) if col_feat2 is not None else 0,
+                                      ptr(row_feat), row_feat.stride(0), H, C, ptr(a_dst), ptr(a_src), ptr(m), ptr(s),
+                                      ptr(D), float(slope), int(swap), ptr(dz), ptr(alpha_out), stream_ptr(dev)),
+          "npi_gat_edge_grad")
+    return dz
+
+
+def seg_rowsum(side: CSRSide, vals, H, map_=None):
+    """out[r, h] = sum over the entries p of row r of vals[map ? map[p] : p, h]"""
+    lib = load()
+    dev = vals.device
+    out = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
+    n_hw = int(lib.npi_gat_heavy_workspace_elems(side.nnz_max, H))
+    hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
+    check(lib.npi_seg_rowsum(ptr(side.rowptr), ptr(side.item_row), ptr(vals), ptr(map_), side.n_rows, side.nnz_max, H,
+                             ptr(out), ptr(hws), n_hw, stream_ptr(dev)), "npi_seg_rowsum")
+    return out
+
+
+def gat_att_grad(hfeat, g_dst, g_src, H, C):
+    lib = load()
+    dev = hfeat.device
+    N = hfeat.size(0)
+    n_ws = int(lib.npi_gat_att_grad_workspace_elems(N, H, C))
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+    datt = torch.empty((H, 2 * C), dtype=torch.float32, device=dev)
+    check(lib.npi_gat_att_grad(ptr(hfeat), hfeat.stride(0), ptr(g_dst), ptr(g_src), N, H, C, ptr(datt), ptr(ws), n_ws,
+                               stream_ptr(dev)), "npi_gat_att_grad")
+    return datt
 
 
 class _GatConvFn(torch.autograd.Function):
@@ -378,28 +476,18 @@ class _GatConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float):
-        lib = load()
-        dev = x.device
-        st = stream_ptr(dev)
-        N, H = graph.num_nodes, int(heads)
+        H = int(heads)
         C = weight.size(1) // H
         att2 = _f32c(att.reshape(H, 2 * C), "att")
         hfeat = linear_fwd(x, weight)                                        # x @ W
-        f32 = dict(dtype=torch.float32, device=dev)
-        a_dst, a_src = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
-        check(lib.npi_gat_scores(ptr(hfeat), hfeat.stride(0), ptr(att2), N, H, C, ptr(a_dst), ptr(a_src), st),
-              "npi_gat_scores")
-        m, s = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
+        a_dst, a_src = gat_scores(hfeat, att2, H, C)
         d = graph.by_dst
-        n_hw = int(lib.npi_gat_heavy_workspace_elems(d.nnz_max, H))
-        hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
-        check(lib.npi_gat_softmax_stats(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), ptr(a_dst), ptr(a_src), N,
-                                        d.nnz_max, H, float(slope), ptr(m), ptr(s), ptr(hws), n_hw, st), "npi_gat_softmax_stats")
+        m, s = gat_softmax_stats(d, a_dst, a_src, H, slope)
         out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, att2, hfeat, a_dst, a_src, m, s, out,
-                              bias if bias is not None else torch.empty(0, device=dev))
+                              bias if bias is not None else torch.empty(0, device=x.device))
         return out
 
     @staticmethod
@@ -407,44 +495,25 @@ class _GatConvFn(torch.autograd.Function):
         x, weight, att2, hfeat, a_dst, a_src, m, s, out, bias = ctx.saved_tensors
         graph: CSRGraph = ctx.graph
         H, C, slope = ctx.H, ctx.C, ctx.slope
-        lib = load()
         dev = x.device
-        st = stream_ptr(dev)
-        N = graph.num_nodes
         grad_out = _f32c(grad_out, "grad_out")
         d, sr = graph.by_dst, graph.by_src
-        f32 = dict(dtype=torch.float32, device=dev)
         db = colsum(grad_out) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
         # D_i = <dOut_i, out_i - b> = sum_p alpha_p dalpha_p  (softmax backward)
-        D = torch.empty((N, H), **f32)
-        check(lib.npi_gat_rowdot(ptr(grad_out), grad_out.stride(0), ptr(out), out.stride(0),
-                                 ptr(bias) if ctx.has_bias else 0, N, H, C, ptr(D), st), "npi_gat_rowdot")
-        # dz per by-target entry, then its row sums in both orientations
-        dz = torch.empty((max(d.nnz_max, 1), H), **f32)
+        D = gat_rowdot(grad_out, out, bias if ctx.has_bias else None, H, C)
+        # dz per by-target entry, then its row sums in both orientations;
         # one head: keep the alpha this kernel computes; the by-source pass reads it back through the transpose map
-        alpha = torch.empty((max(d.nnz_max, 1), H), **f32) if H == 1 else None
-        check(lib.npi_gat_edge_grad(ptr(d.rowptr), ptr(d.col), ptr(d.rowidx), N, d.nnz_max, ptr(hfeat), hfeat.stride(0),
-                                    ptr(grad_out), grad_out.stride(0), H, C, ptr(a_dst), ptr(a_src), ptr(m), ptr(s),
-                                    ptr(D), slope, ptr(dz), ptr(alpha), st), "npi_gat_edge_grad")
-        g_dst, g_src = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
-        n_hw = int(lib.npi_gat_heavy_workspace_elems(max(d.nnz_max, sr.nnz_max), H))
-        hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
-        check(lib.npi_seg_rowsum(ptr(d.rowptr), ptr(d.item_row), ptr(dz), 0, N, d.nnz_max, H, ptr(g_dst), ptr(hws), n_hw, st),
-              "npi_seg_rowsum")
-        check(lib.npi_seg_rowsum(ptr(sr.rowptr), ptr(sr.item_row), ptr(dz), ptr(_transpose_map(graph)), N, sr.nnz_max,
-                                 H, ptr(g_src), ptr(hws), n_hw, st), "npi_seg_rowsum")
+        alpha = torch.empty((max(d.nnz_max, 1), H), dtype=torch.float32, device=dev) if H == 1 else None
+        dz = gat_edge_grad(d, hfeat, None, grad_out, H, C, a_dst, a_src, m, s, D, slope, 0, alpha_out=alpha)
+        g_dst = seg_rowsum(d, dz, H)
+        g_src = seg_rowsum(sr, dz, H, map_=_transpose_map(graph))
         # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
         dh = _gat_aggregate(graph, sr, grad_out, H, C, a_dst, a_src, m, s, slope, True,
                             g_dst=g_dst, g_src=g_src, att=att2, alpha=alpha,
                             alpha_map=_transpose_map(graph) if alpha is not None else None)
         datt = None
         if ctx.needs_input_grad[2]:
-            n_ws = int(lib.npi_gat_att_grad_workspace_elems(N, H, C))
-            ws = torch.empty(n_ws, **f32)
-            datt = torch.empty((H, 2 * C), **f32)
-            check(lib.npi_gat_att_grad(ptr(hfeat), hfeat.stride(0), ptr(g_dst), ptr(g_src), N, H, C, ptr(datt),
-                                       ptr(ws), n_ws, st), "npi_gat_att_grad")
-            datt = datt.view(1, H, 2 * C)
+            datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
         dw = dx = None
         if ctx.needs_input_grad[1]:
             dw, _ = linear_bwd_weight(x, dh, want_bias=False)

@@ -8,33 +8,102 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import torch.nn.functional as F
 
 from npi_gnn_amd import dist as ND
 from oracle import ref_conv as R
 
 
 class TorchBackend:
-    """Stand-in for HipBackend: same contract, plain torch ops."""
+    """Stand-in for HipBackend: same contract, plain torch ops (a side is its COO entry list)."""
 
     def make_side(self, key, val, n_rows, n_cols):
         return key, val, n_rows, n_cols
 
-    def segsum(self, side, table, mean=False):
+    def row_lengths(self, side):
+        return torch.bincount(side[0], minlength=side[2])
+
+    def row_of_entry(self, side):
+        return side[0]
+
+    def col_of_entry(self, side):
+        return side[1]
+
+    @staticmethod
+    def _table(table, table2):
+        return table if table2 is None else torch.cat([table, table2])
+
+    def segsum(self, side, table, mean=False, table2=None, w=None, bias=None):
         key, val, n_rows, n_cols = side
-        assert table.size(0) == n_cols
-        out = torch.zeros(n_rows, table.size(1)).index_add_(0, key, table[val])
+        t = self._table(table, table2)
+        assert t.size(0) >= n_cols
+        msg = t[val] if w is None else t[val] * w.view(-1, 1)
+        out = torch.zeros(n_rows, t.size(1)).index_add_(0, key, msg)
         if mean:
             out = out / torch.bincount(key, minlength=n_rows).clamp(min=1).float().view(-1, 1)
-        return out
+        return out + bias if bias is not None else out
 
     def linear_fwd(self, a, w, b):
         return a @ w + (b if b is not None else 0)
 
     def linear_bwd_data(self, dc, w, rowscale):
-        return (dc @ w.t()) * rowscale.view(-1, 1)
+        out = dc @ w.t()
+        return out * rowscale.view(-1, 1) if rowscale is not None else out
 
-    def linear_bwd_weight(self, a, dc, want_bias):
+    def linear_bwd_weight(self, a, dc, want_bias, shared=False):
         return a.t() @ dc, (dc.sum(0) if want_bias else None)
+
+    def colsum(self, x):
+        return x.sum(0)
+
+    # ---- GATConv pieces, same index-space contract as HipBackend ----
+    def gat_scores(self, h, att2, H, C):
+        hv = h.view(-1, H, C)
+        return (hv * att2[:, :C]).sum(-1), (hv * att2[:, C:]).sum(-1)
+
+    def gat_stats(self, side, a_row, a_col, H, slope):
+        key, val, n_rows, _ = side
+        z = F.leaky_relu(a_row[key] + a_col[val], slope)
+        m = torch.full((n_rows, H), -3.0e38).scatter_reduce(0, key.view(-1, 1).expand(-1, H), z, "amax", include_self=True)
+        empty = torch.bincount(key, minlength=n_rows) == 0
+        m = torch.where(empty.view(-1, 1), torch.zeros_like(m), m)           # the kernel's answer for an empty row
+        s = torch.zeros(n_rows, H).index_add_(0, key, torch.exp(z - m[key]))
+        return m, s
+
+    def _alpha(self, side, a_dst, a_src, m, s, slope, by_source):
+        key, val = side[0], side[1]
+        tgt, src = (val, key) if by_source else (key, val)
+        z = a_dst[tgt] + a_src[src]
+        return torch.exp(F.leaky_relu(z, slope) - m[tgt]) / (s[tgt] + 1e-16), z, tgt
+
+    def gat_aggregate(self, side, table, table2, H, C, a_dst, a_src, m, s, slope, by_source, bias=None,
+                      g_dst=None, g_src=None, att=None):
+        key, val, n_rows, _ = side
+        t = self._table(table, table2)
+        alpha, _, _ = self._alpha(side, a_dst, a_src, m, s, slope, by_source)
+        msg = t[val].view(-1, H, C) * alpha.view(-1, H, 1)
+        out = torch.zeros(n_rows, H, C).index_add_(0, key, msg)
+        if g_dst is not None:
+            out = out + g_dst.view(-1, H, 1) * att[:, :C].view(1, H, C) + g_src.view(-1, H, 1) * att[:, C:].view(1, H, C)
+        out = out.reshape(n_rows, H * C)
+        return out + bias if bias is not None else out
+
+    def gat_rowdot(self, a, b, bias, H, C):
+        bb = b - bias if bias is not None else b
+        return (a.view(-1, H, C) * bb.view(-1, H, C)).sum(-1)
+
+    def gat_edge_grad(self, side, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap):
+        key, val = side[0], side[1]
+        alpha, z, tgt = self._alpha(side, a_dst, a_src, m, s, slope, bool(swap))
+        p = (row_feat[key].view(-1, H, C) * self._table(col_feat, col_feat2)[val].view(-1, H, C)).sum(-1)
+        return alpha * (p - D[tgt]) * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+
+    def seg_rowsum(self, side, vals, H):
+        return torch.zeros(side[2], H).index_add_(0, side[0], vals[: side[0].numel()])
+
+    def gat_att_grad(self, h, g_dst, g_src, H, C):
+        hv = h.view(-1, H, C)
+        return torch.cat([(g_dst.view(-1, H, 1) * hv).sum(0), (g_src.view(-1, H, 1) * hv).sum(0)], dim=1)
 
 
 def _case(N, E, F, kind, seed=0):
@@ -63,20 +132,39 @@ def _case(N, E, F, kind, seed=0):
     return ei, x, W, b, go, hub
 
 
-def _worker(rank, world, port, N, E, F, kind, q):
+def _att(Fd, H=1, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(1, H, 2 * (Fd // H), generator=g) * 0.3
+
+
+def _worker(rank, world, port, N, E, Fd, kind, layer_kind, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ei, x, W, b, go, hub = _case(N, E, F, kind)
-        sg = ND.ShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub)
-        layer = ND.ShardedSAGELayer(sg, W, b)
-        xl = sg.shard(x).clone().requires_grad_(True)
+        ei, x, W, b, go, hub = _case(N, E, Fd, kind)
+        extra = ()
+        if layer_kind == "edges":
+            sg = ND.EdgeShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend())
+            layer = ND.EdgeShardedSAGELayer(sg, W, b)
+            xl = x.clone().requires_grad_(True)                    # replicated input
+        else:
+            sg = ND.ShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub)
+            if layer_kind == "sage":
+                layer = ND.ShardedSAGELayer(sg, W, b)
+            elif layer_kind == "gcn":
+                layer = ND.ShardedGCNLayer(sg, W, b)
+            else:
+                H = int(layer_kind[3:])
+                layer = ND.ShardedGATLayer(sg, W, _att(Fd, H), b, heads=H)
+            xl = sg.shard(x).clone().requires_grad_(True)
         out = layer(xl)
         out.backward(sg.shard(go))
+        if layer_kind.startswith("gat"):
+            extra = (layer.att.grad,)
         # numpy arrays are pickled by value (torch tensors travel through shared-memory files that
         # vanish when this process exits)
-        q.put((rank,) + tuple(t.detach().numpy().copy() for t in (out, xl.grad, layer.weight.grad, layer.bias.grad)))
+        q.put((rank,) + tuple(t.detach().numpy().copy() for t in (out, xl.grad, layer.weight.grad, layer.bias.grad) + extra))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -90,34 +178,65 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,N,kind", [(2, 101, "any"), (3, 64, "any"), (2, 203, "bipartite"),
-                                          (3, 160, "bipartite"), (2, 120, "auto"), (8, 333, "bipartite"),
-                                          (4, 61, "any")])
-def test_sharded_layer_matches_single_process_oracle(world, N, kind):
-    E, F = 900, 16
+def _reference(layer_kind, ei, x, W, b, go, Fd):
+    if layer_kind in ("sage", "edges"):
+        return R.sage_layer_fwd_bwd(x, ei, W, b, go)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    if layer_kind == "gcn":
+        out = R.gcn_conv(xr, ei, Wr, br)
+        out.backward(go)
+        return out.detach(), xr.grad, Wr.grad, br.grad
+    H = int(layer_kind[3:])
+    att = _att(Fd, H).requires_grad_(True)
+    out = R.gat_conv(xr, ei, Wr, att, br, heads=H)
+    out.backward(go)
+    return out.detach(), xr.grad, Wr.grad, br.grad, att.grad
+
+
+@pytest.mark.parametrize("world,N,kind,layer_kind", [
+    (2, 101, "any", "sage"), (3, 64, "any", "sage"), (2, 203, "bipartite", "sage"), (3, 160, "bipartite", "sage"),
+    (2, 120, "auto", "sage"), (8, 333, "bipartite", "sage"), (4, 61, "any", "sage"),
+    (2, 203, "bipartite", "gcn"), (3, 64, "any", "gcn"), (8, 333, "bipartite", "gcn"),
+    (2, 203, "bipartite", "gat1"), (3, 160, "bipartite", "gat2"), (3, 64, "any", "gat1"), (8, 333, "bipartite", "gat1"),
+    (2, 120, "auto", "gat4"),
+    (2, 101, "any", "edges"), (3, 160, "bipartite", "edges"), (8, 333, "bipartite", "edges"),
+])
+def test_sharded_layer_matches_single_process_oracle(world, N, kind, layer_kind):
+    E, Fd = 900, 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, E, F, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, E, Fd, kind, layer_kind, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
     for _ in range(world):
-        r, out, dx, dw, db = q.get(timeout=180)
-        res[r] = tuple(torch.from_numpy(a) for a in (out, dx, dw, db))
+        got = q.get(timeout=180)
+        res[got[0]] = tuple(torch.from_numpy(a) for a in got[1:])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ei, x, W, b, go, hub = _case(N, E, F, kind)
-    ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(x, ei, W, b, go)
-    part = ND.HubPartition(N, world, hub)
-    out = part.unshard([res[r][0] for r in range(world)])
-    dx = part.unshard([res[r][1] for r in range(world)])
+    ei, x, W, b, go, hub = _case(N, E, Fd, kind)
+    ref = _reference(layer_kind, ei, x, W, b, go, Fd)
+    ref_out, ref_dx, ref_dw, ref_db = ref[:4]
+    if layer_kind == "edges":
+        per = (N + world - 1) // world
+        out = torch.cat([res[r][0] for r in range(world)])
+        assert out.shape == ref_out.shape and all(res[r][0].size(0) == min(per, max(N - r * per, 0)) for r in range(world))
+        for r in range(world):                              # x is replicated: every rank holds the complete dX
+            assert torch.allclose(res[r][1], ref_dx, atol=1e-5, rtol=1e-5)
+        dx = res[0][1]
+    else:
+        part = ND.HubPartition(N, world, hub)
+        out = part.unshard([res[r][0] for r in range(world)])
+        dx = part.unshard([res[r][1] for r in range(world)])
     assert torch.allclose(out, ref_out, atol=1e-5, rtol=1e-5)
     assert torch.allclose(dx, ref_dx, atol=1e-5, rtol=1e-5)
     for r in range(world):                                  # gradients are all-reduced: identical everywhere
         assert torch.allclose(res[r][2], ref_dw, atol=1e-4, rtol=1e-5)
         assert torch.allclose(res[r][3], ref_db, atol=1e-4, rtol=1e-5)
+        if layer_kind.startswith("gat"):
+            assert torch.allclose(res[r][4], ref[4], atol=1e-4, rtol=1e-5)
 
 
 def test_partition_maps():

@@ -32,7 +32,35 @@ def _case(N, E, F, kind, seed=0):
     return ei, x, W, b, go, hub
 
 
-def _worker(rank, world, port, N, E, F, kind, q):
+def _att(F, H=1):
+    return torch.randn(1, H, 2 * (F // H), generator=torch.Generator().manual_seed(9)) * 0.2
+
+
+def _make_layer(ND, layer_kind, sg, W, b, dev, F):
+    if layer_kind == "sage":
+        return ND.ShardedSAGELayer(sg, W.to(dev), b.to(dev))
+    if layer_kind == "gcn":
+        return ND.ShardedGCNLayer(sg, W.to(dev), b.to(dev))
+    H = int(layer_kind[3:])
+    return ND.ShardedGATLayer(sg, W.to(dev), _att(F, H).to(dev), b.to(dev), heads=H)
+
+
+def _reference(layer_kind, ei, x, W, b, go, F):
+    if layer_kind == "sage":
+        return R.sage_layer_fwd_bwd(x, ei, W, b, go)
+    xr, Wr, br = (t.double().clone().requires_grad_(True) for t in (x, W, b))      # fp64: hub rows are long
+    if layer_kind == "gcn":
+        out = R.gcn_conv(xr, ei, Wr, br)
+        out.backward(go.double())
+        return tuple(t.float() for t in (out.detach(), xr.grad, Wr.grad, br.grad))
+    H = int(layer_kind[3:])
+    att = _att(F, H).double().requires_grad_(True)
+    out = R.gat_conv(xr, ei, Wr, att, br, heads=H)
+    out.backward(go.double())
+    return tuple(t.float() for t in (out.detach(), xr.grad, Wr.grad, br.grad, att.grad))
+
+
+def _worker(rank, world, port, N, E, F, kind, layer_kind, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,14 +70,15 @@ def _worker(rank, world, port, N, E, F, kind, q):
         dev = torch.device("cuda:0")
         ei, x, W, b, go, hub = _case(N, E, F, kind)
         sg = ND.ShardedGraph(ei, N, rank, world, dev, hub_mask=hub)
-        layer = ND.ShardedSAGELayer(sg, W.to(dev), b.to(dev))
+        layer = _make_layer(ND, layer_kind, sg, W, b, dev, F)
         xl = sg.shard(x).to(dev).requires_grad_(True)
         out = layer(xl)
         out.backward(sg.shard(go).to(dev))
         torch.cuda.synchronize()
+        extra = (layer.att.grad,) if layer_kind.startswith("gat") else ()
         # numpy arrays are pickled by value (torch tensors travel through shared-memory files that
         # vanish when this process exits)
-        q.put((rank,) + tuple(t.detach().cpu().numpy().copy() for t in (out, xl.grad, layer.weight.grad, layer.bias.grad)))
+        q.put((rank,) + tuple(t.detach().cpu().numpy().copy() for t in (out, xl.grad, layer.weight.grad, layer.bias.grad) + extra))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -63,31 +92,131 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("kind,N,E", [("any", 4001, 30000), ("bipartite", 6003, 60000)])
-def test_two_ranks_one_gpu_hip_backend(dev, kind, N, E):
+@pytest.mark.parametrize("kind,N,E,layer_kind", [("any", 4001, 30000, "sage"), ("bipartite", 6003, 60000, "sage"),
+                                                 ("bipartite", 6003, 60000, "gcn"), ("any", 4001, 30000, "gcn"),
+                                                 ("bipartite", 6003, 60000, "gat1"), ("any", 4001, 30000, "gat1"),
+                                                 ("bipartite", 6003, 60000, "gat4")])
+def test_two_ranks_one_gpu_hip_backend(dev, kind, N, E, layer_kind):
     world, F = 2, 256
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, E, F, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, E, F, kind, layer_kind, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
     for _ in range(world):
-        r, out, dx, dw, db = q.get(timeout=300)
-        res[r] = tuple(torch.from_numpy(a) for a in (out, dx, dw, db))
+        got = q.get(timeout=300)
+        res[got[0]] = tuple(torch.from_numpy(a) for a in got[1:])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     from npi_gnn_amd import dist as ND
     ei, x, W, b, go, hub = _case(N, E, F, kind)
-    ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(x, ei, W, b, go)
+    ref = _reference(layer_kind, ei, x, W, b, go, F)
+    ref_out, ref_dx, ref_dw, ref_db = ref[:4]
     part = ND.HubPartition(N, world, hub)
     assert torch.allclose(part.unshard([res[r][0] for r in range(world)]), ref_out, atol=1e-4, rtol=1e-4)
     assert torch.allclose(part.unshard([res[r][1] for r in range(world)]), ref_dx, atol=1e-4, rtol=1e-4)
     for r in range(world):
         assert torch.allclose(res[r][2], ref_dw, atol=1e-2, rtol=1e-3)
         assert torch.allclose(res[r][3], ref_db, atol=1e-2, rtol=1e-3)
+        if layer_kind.startswith("gat"):
+            assert torch.allclose(res[r][4], ref[4], atol=1e-2, rtol=1e-3)
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+@pytest.mark.parametrize("layer_kind", ["gcn", "gat1", "gat2"])
+def test_virtual_ranks_gcn_gat_on_one_gpu(dev, world, layer_kind):
+    """SURVEY.md 8(e), one-GPU form: the W shards of a GCN / GAT layer run one after the other in ONE process, the
+    collectives replaced by an in-process exchange (a gloo-free stand-in that holds every rank's buffers), HIP backend."""
+    from npi_gnn_amd import dist as ND
+    from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
+    N, E, F = 5003, 60000, 128
+    ei = bipartite_edge_index(N, E, seed=21)
+    g = torch.Generator().manual_seed(4)
+    x, go = torch.randn(N, F, generator=g), torch.randn(N, F, generator=g)
+    W, b = torch.randn(F, F, generator=g) / F ** 0.5, torch.randn(F, generator=g)
+    ref = _reference(layer_kind, ei, x, W, b, go, F)
+    outs, dxs, dws = _run_virtual(ND, world, layer_kind, ei, N, F, x, go, W, b, protein_mask(N), dev)
+    part = ND.HubPartition(N, world, protein_mask(N))
+    assert torch.allclose(part.unshard(outs), ref[0], atol=1e-4, rtol=1e-4)
+    assert torch.allclose(part.unshard(dxs), ref[1], atol=1e-4, rtol=1e-4)
+    for dw in dws:
+        assert torch.allclose(dw, ref[2], atol=1e-2, rtol=1e-3)
+
+
+def _run_virtual(ND, world, layer_kind, ei, N, F, x, go, W, b, hub, dev):
+    """W ranks in ONE process without threads: the ranks run one after the other, pass after pass.  Collective number
+    k of a pass returns its true result once every rank's input to it is known from an earlier pass (inputs of
+    collective k depend only on the results of collectives < k, and the kernels are deterministic), a dummy before --
+    so pass p resolves collective p and the last pass is an exact lock-step execution."""
+    inputs, results = [], []            # per collective index: {rank: tensor}, resolved result (list per rank) or None
+    state = {"rank": 0, "k": 0, "valid": True}
+
+    class Work:
+        def wait(self):
+            return True
+
+    def collective(value, fn):
+        k, r = state["k"], state["rank"]
+        state["k"] += 1
+        while len(inputs) <= k:
+            inputs.append({})
+            results.append(None)
+        if results[k] is not None:
+            return results[k]
+        if state["valid"]:
+            inputs[k][r] = value.detach().clone()
+            if len(inputs[k]) == world:
+                results[k] = ("pending", fn)
+        state["valid"] = False
+        return None
+
+    def resolve():
+        for k, res in enumerate(results):
+            if isinstance(res, tuple) and res[0] == "pending":
+                results[k] = res[1]([inputs[k][r] for r in range(world)])
+
+    def all_gather_rows(block, out, w, group=None, async_op=False):
+        res = collective(block, lambda v: torch.cat(v))
+        out.copy_(res) if res is not None else out.zero_()
+        return Work() if async_op else None
+
+    def reduce_scatter_rows(part_sums, out, rank, w, group=None, async_op=False):
+        res = collective(part_sums, lambda v: torch.stack(v).sum(0))
+        out.copy_(res.view(w, out.size(0), -1)[rank].view_as(out)) if res is not None else out.zero_()
+        return Work() if async_op else None
+
+    def all_reduce(t, w, group=None, op=None, tag=""):
+        mx = op == dist.ReduceOp.MAX
+        res = collective(t, (lambda v: torch.stack(v).max(0)[0]) if mx else (lambda v: torch.stack(v).sum(0)))
+        if res is not None:
+            t.copy_(res)
+
+    saved = (ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo)
+    ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce = all_gather_rows, reduce_scatter_rows, all_reduce
+    ND._solo = lambda w: False
+    try:
+        sgs = [ND.ShardedGraph(ei, N, r, world, dev, hub_mask=hub) for r in range(world)]
+        for _ in range(64):
+            outs, dxs, dws = [], [], []
+            complete = True
+            for r, sg in enumerate(sgs):
+                state.update(rank=r, k=0, valid=True)
+                layer = _make_layer(ND, layer_kind, sg, W, b, dev, F)
+                xl = sg.shard(x).to(dev).requires_grad_(True)
+                out = layer(xl)
+                out.backward(sg.shard(go).to(dev))
+                torch.cuda.synchronize()
+                complete = complete and state["valid"]
+                outs.append(out.detach().cpu()), dxs.append(xl.grad.cpu()), dws.append(layer.weight.grad.cpu())
+            if complete:
+                return outs, dxs, dws
+            resolve()
+        raise AssertionError("virtual ranks did not converge")
+    finally:
+        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo = saved
 
 
 @pytest.mark.parametrize("hubs", [False, True])
@@ -162,6 +291,27 @@ def _rccl_solo_worker(port, q):
             errs.append((rel(out, ref[sg.own]), rel(xl.grad, xr.grad[sg.own]), rel(layer.weight.grad, conv.weight.grad)))
         tags = sorted({t for t, _, _ in comm})
         stall_ms = [e0.elapsed_time(e1) for _, e0, e1 in comm]
+        # GCN and GAT layers through the same real collectives (incl. the MAX all-reduce of the hub-row maxima)
+        sg = ND.ShardedGraph(ei, N, 0, 1, dev, hub_mask=protein_mask(N))
+        att = _att(F, 2).to(dev)
+        for kind in ("gcn", "gat"):
+            if kind == "gcn":
+                layer, conv = ND.ShardedGCNLayer(sg, W, b), npi.GCNConv(F, F).to(dev)
+            else:
+                layer, conv = ND.ShardedGATLayer(sg, W, att, b, heads=2), npi.GATConv(F, F // 2, heads=2).to(dev)
+                with torch.no_grad():
+                    conv.att.copy_(att)
+            with torch.no_grad():
+                conv.weight.copy_(W)
+                conv.bias.copy_(b)
+            xl = sg.shard(x).to(dev).requires_grad_(True)
+            out = layer(xl)
+            out.backward(sg.shard(go).to(dev))
+            xr = x.to(dev).requires_grad_(True)
+            ref = conv(xr, npi.CSRGraph(ei.to(dev), N))
+            ref.backward(go.to(dev))
+            torch.cuda.synchronize()
+            errs.append((rel(out, ref[sg.own]), rel(xl.grad, xr.grad[sg.own]), rel(layer.weight.grad, conv.weight.grad)))
         q.put((errs, tags, min(stall_ms), max(stall_ms)))
     finally:
         dist.destroy_process_group()
@@ -181,5 +331,35 @@ def test_collectives_through_rccl_with_one_rank(dev):
     assert tags == ["bwd_all_gather", "bwd_all_reduce_db", "bwd_all_reduce_dw", "bwd_reduce_scatter", "fwd_all_gather",
                     "fwd_reduce_scatter"]
     assert 0.0 <= stall_min <= stall_max < 1000.0
+    assert len(errs) == 4                   # SAGE (hubs, rows), GCN, GAT
     for e_out, e_dx, e_dw in errs:
         assert e_out < 1e-5 and e_dx < 1e-5 and e_dw < 1e-5
+
+
+def test_world_one_edge_sharded_baseline_equals_single_gpu_conv(dev):
+    """bench.py --partition edges --force-sharded: the north-star's baseline split with one rank."""
+    import npi_gnn_amd as npi
+    from npi_gnn_amd import dist as ND
+    from npi_gnn_amd.synth import bipartite_edge_index
+    N, E, F = 20000, 300000, 128
+    ei = bipartite_edge_index(N, E, seed=3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, F, generator=g)
+    W = (torch.randn(F, F, generator=g) / F ** 0.5).to(dev)
+    b = torch.randn(F, generator=g).to(dev)
+    go = torch.randn(N, F, generator=g).to(dev)
+    sg = ND.EdgeShardedGraph(ei, N, 0, 1, dev)
+    layer = ND.EdgeShardedSAGELayer(sg, W, b)
+    xl = x.to(dev).requires_grad_(True)
+    out = layer(xl)
+    out.backward(go)
+    conv = npi.SAGEConv(F, F).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(W)
+        conv.bias.copy_(b)
+    xr = x.to(dev).requires_grad_(True)
+    ref = conv(xr, npi.CSRGraph(ei.to(dev), N))
+    ref.backward(go)
+    assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(xl.grad, xr.grad, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(layer.weight.grad, conv.weight.grad, atol=1e-3, rtol=1e-4)

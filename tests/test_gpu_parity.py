@@ -329,8 +329,8 @@ def test_sharded_backend_virtual_ranks_on_one_gpu(dev, world, hubs):
         partial = [be.segsum(getattr(sg, side_b), own[r]) for r, sg in enumerate(sgs)] if sgs[0].exchange_partials else None
         outs = []
         for r, sg in enumerate(sgs):
-            table = torch.cat([hub_table, own[r][: sg.nL]])
-            agg = be.segsum(getattr(sg, side_a), table, mean=mean)
+            # two-part table: [gathered hub rows ; the rank's own rows] (npi_segsum_ex), nothing copied
+            agg = be.segsum(getattr(sg, side_a), hub_table, mean=mean, table2=own[r])
             if partial is not None and sg.nH:
                 hsum = sum(p[r * part.h_per: r * part.h_per + sg.nH] for p in partial)
                 if mean:
