@@ -27,6 +27,13 @@
 
 namespace npi {
 
+// A/B switch for measurements only (tools/build_variant.sh one_table -DNPI_SEG_ONE_TABLE=1): compiles the two-part
+// table select out of the gather
+#ifndef NPI_SEG_ONE_TABLE
+#define NPI_SEG_ONE_TABLE 0
+#endif
+constexpr bool TWO_PART = !NPI_SEG_ONE_TABLE;
+
 constexpr int SEG_THREADS = 256;
 constexpr int SEG_WAVES = SEG_THREADS / WAVE;
 
@@ -256,7 +263,7 @@ segsum_kernel(SegParams P) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cu = bcast_i(cv, j + u);
-                const T* src = (cu < split ? xT : x2T) + (int64_t)cu * P.ldx;
+                const T* src = ((TWO_PART && cu >= split) ? x2T : xT) + (int64_t)cu * P.ldx;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[u][c]);
@@ -292,7 +299,7 @@ segsum_kernel(SegParams P) {
             float v[NCH][VEC];
             float g0[NCH], g1[NCH], g2[NCH];
             const int cu = bcast_i(cv, j);
-            const T* src = (cu < split ? xT : x2T) + (int64_t)cu * P.ldx;
+            const T* src = ((TWO_PART && cu >= split) ? x2T : xT) + (int64_t)cu * P.ldx;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[c]);
@@ -417,7 +424,7 @@ segsum_group_kernel(SegParams P) {
                 const int e = j + u * G + grp;             // this lane group's entry of wave instruction u
                 const int cu = __shfl(cv, min(e, nb - 1), WAVE);
                 we[u] = (WMODE == W_ARRAY) ? __shfl(wv, min(e, nb - 1), WAVE) : 1.f;
-                if (act && e < nb) load_row<VEC, T>((cu < split ? xT : x2T) + (int64_t)cu * P.ldx + foff, v[u]);
+                if (act && e < nb) load_row<VEC, T>(((TWO_PART && cu >= split) ? x2T : xT) + (int64_t)cu * P.ldx + foff, v[u]);
                 else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) v[u][q] = 0.f;

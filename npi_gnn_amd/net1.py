@@ -1,0 +1,149 @@
+"""The caller of the conv hot path, mirrored: the reference's ``Net_1``
+(``src/classes.py:45-82``) built from this package's modules, the batch source that replaces its
+PyG ``DataLoader`` over pre-built subgraph files (``src/train_with_twoDataset.PY:142-143``) with
+device-side extraction from target pairs, and its training loop (``:46-57`` and ``:154-184``)
+followed statement by statement.  Parameter names and shapes equal the reference's, so
+``Net_1.load_state_dict(torch.load('result/<proj>/model_<k>_fold/<epoch>'))`` works unchanged.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import metrics as NM
+from . import pool as NP
+from .nn import SAGEConv
+from .subgraph import InteractionGraph
+
+
+class Net_1(torch.nn.Module):
+    """Reference ``src/classes.py:45-82``: three SAGEConv(., 128) + TopKPooling(128, 0.5) stages, the
+    ``[global_max_pool || global_mean_pool]`` readout after each summed, then the 256-128-64-2 MLP with
+    dropout 0.5 after ``lin1`` and ``log_softmax``."""
+
+    def __init__(self, num_node_features, num_of_classes=2):
+        super().__init__()
+        self.conv1 = SAGEConv(num_node_features, 128)
+        self.pool1 = NP.TopKPooling(128, ratio=0.5)
+        self.conv2 = SAGEConv(128, 128)
+        self.pool2 = NP.TopKPooling(128, ratio=0.5)
+        self.conv3 = SAGEConv(128, 128)
+        self.pool3 = NP.TopKPooling(128, ratio=0.5)
+        self.lin1 = torch.nn.Linear(256, 128)
+        self.lin2 = torch.nn.Linear(128, 64)
+        self.lin3 = torch.nn.Linear(64, num_of_classes)
+
+    def forward(self, data):
+        x, edge_index, batch = data.x, data.edge_index, data.batch
+        B = getattr(data, "num_graphs", None)
+        total = None
+        for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
+            x = F.relu(conv(x, edge_index))
+            x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
+            # torch.cat([gmp(x, batch), gap(x, batch)], dim=1) as ONE kernel (src/classes.py:64,68,72)
+            r = NP.global_max_mean_pool(x, batch, B)
+            total = r if total is None else total + r
+        x = F.relu(self.lin1(total))
+        x = F.dropout(x, p=0.5, training=self.training)
+        x = F.relu(self.lin2(x))
+        x = self.lin3(x)
+        return F.log_softmax(x, dim=-1)
+
+
+class Batch:
+    """What a PyG ``DataLoader`` yields, as far as ``Net_1``, ``train()`` and the metrics look at it."""
+
+    def __init__(self, x, edge_index, batch, y):
+        self.x, self.edge_index, self.batch, self.y = x, edge_index, batch, y
+        self.num_graphs = int(y.numel())
+
+    def to(self, device):
+        return self
+
+
+class KeyLoader:
+    """``DataLoader(dataset, batch_size=B)`` over a list of target pairs: every batch of enclosing subgraphs is
+    built on the device when it is asked for (``InteractionGraph.batch``) instead of being read from the files
+    the reference writes at dataset-build time.  ``shuffle()`` is ``dataset.shuffle()`` of
+    ``src/train_with_twoDataset.PY:78-79``: ONE random permutation of the samples; the loader itself never
+    shuffles (``:142`` passes no ``shuffle=``), so every epoch sees the same batches in the same order."""
+
+    def __init__(self, ig: InteractionGraph, keys: torch.Tensor, y: torch.Tensor, batch_size: int = 200):
+        self.ig, self.keys, self.y, self.batch_size = ig, keys, y, int(batch_size)
+        self.dataset = range(int(keys.size(0)))              # len(loader.dataset), as src/methods.py:85 uses it
+
+    def shuffle(self, generator: Optional[torch.Generator] = None) -> "KeyLoader":
+        perm = torch.randperm(self.keys.size(0), generator=generator).to(self.keys.device)
+        return KeyLoader(self.ig, self.keys[perm], self.y[perm], self.batch_size)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for i in range(0, len(self.dataset), self.batch_size):
+            k = self.keys[i:i + self.batch_size]
+            x, ei, b = self.ig.batch(k)
+            yield Batch(x, ei, b, self.y[i:i + self.batch_size])
+
+
+def train(model, train_loader, optimizer, device) -> float:
+    """``train()`` of ``src/train_with_twoDataset.PY:46-57``."""
+    model.train()
+    # `loss_all += data.num_graphs * loss.item()` with the running sum kept ON the device in float64 -- the same
+    # arithmetic (f32 loss widened exactly, product and sum in f64, same order) without a host sync per batch
+    loss_all = torch.zeros((), dtype=torch.float64, device=device)
+    for data in train_loader:
+        data = data.to(device)
+        optimizer.zero_grad()
+        output = model(data)
+        loss = F.nll_loss(output, data.y)
+        loss.backward()
+        loss_all += data.num_graphs * loss.detach().double()
+        optimizer.step()
+    return loss_all.item() / len(train_loader.dataset)
+
+
+def fit(model, train_loader, test_loader, device, num_of_epoch: int = 50, LR: float = 0.001,
+        L2_weight_decay: float = 0.001, log: Callable[[str], None] = print, eval_train: bool = True):
+    """The epoch loop of ``src/train_with_twoDataset.PY:130-184``: Adam(lr, weight_decay), ``ExponentialLR(0.95)``
+    stepped ONLY when the epoch loss rose (``:158-160``), train + test metrics every 5th epoch except the last
+    (``:163-172``) and once more at the end (``:186-193``), best test MCC tracked.  Returns a dict with the final
+    test metrics, the best-MCC epoch and the wall time."""
+    optimizer = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=L2_weight_decay)
+    scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=0.95)
+    fmt = '{}, {} dataset, Accuracy: {:.5f}, Precision: {:.5f}, Sensitivity: {:.5f}, Specificity: {:.5f}, MCC: {:.5f}'
+    start_time = time.time()
+    MCC_max, epoch_MCC_max, lr_steps = -1, 0, 0
+    loss_last = float('inf')
+    history = []
+    for epoch in range(num_of_epoch):
+        loss = train(model, train_loader, optimizer, device)
+        if loss > loss_last:
+            scheduler.step()
+            lr_steps += 1
+        loss_last = loss
+        history.append(loss)
+        if (epoch + 1) % 5 == 0 and epoch != num_of_epoch - 1:
+            if eval_train:
+                log(fmt.format('Epoch: {:03d}'.format(epoch + 1), 'training',
+                               *NM.Accuracy_Precision_Sensitivity_Specificity_MCC(model, train_loader, device)))
+            m = NM.Accuracy_Precision_Sensitivity_Specificity_MCC(model, test_loader, device)
+            log(fmt.format('Epoch: {:03d}'.format(epoch + 1), 'testing', *m))
+            if m[4] > MCC_max:
+                MCC_max, epoch_MCC_max = m[4], epoch + 1
+    train_m = NM.Accuracy_Precision_Sensitivity_Specificity_MCC(model, train_loader, device) if eval_train else None
+    if train_m:
+        log(fmt.format('result', 'training', *train_m))
+    test_m = NM.Accuracy_Precision_Sensitivity_Specificity_MCC(model, test_loader, device)
+    log(fmt.format('result', 'testing', *test_m))
+    if test_m[4] > MCC_max:
+        MCC_max, epoch_MCC_max = test_m[4], num_of_epoch
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    wall = time.time() - start_time
+    log('Time consuming: ' + str(wall))
+    return {"test": test_m, "train": train_m, "MCC_max": MCC_max, "epoch_MCC_max": epoch_MCC_max, "seconds": wall,
+            "loss": history, "lr_steps": lr_steps}

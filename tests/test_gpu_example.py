@@ -1,40 +1,48 @@
-"""The end-to-end training example (examples/train_rpi369.py): target pairs -> device-built batches -> Net_1 ->
-loss -> backward -> Adam, then evaluation through the confusion kernel, on the RPI369 vectors."""
+"""The end-to-end training flow (npi_gnn_amd.net1 + examples/): target pairs -> device-built batches -> Net_1 -> loss ->
+backward -> Adam, evaluation through the confusion kernel -- the reference's loop (src/train_with_twoDataset.PY:46-57,
+142-184) on the RPI369 vectors."""
 import importlib.util
 import os
 
 import pytest
 import torch
-import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_training_loop_learns_on_rpi369(dev):
-    spec = importlib.util.spec_from_file_location("train_rpi369", os.path.join(ROOT, "examples", "train_rpi369.py"))
+def _example(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
     ex = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ex)
+    return ex
+
+
+def test_training_loop_learns_on_rpi369(dev):
+    from npi_gnn_amd import net1
+    ex = _example("train_rpi369")
     torch.manual_seed(0)
     ig, train_keys, train_y, test_keys, test_y, F_in = ex.load_project(dev)
     assert train_keys.size(0) == 590 and test_keys.size(0) == 148 and F_in == 178
     assert int(test_y.sum()) == 74 and int(train_y.sum()) == 295
-    model = ex.Net_1(F_in).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
-    loader = ex.KeyLoader(ig, train_keys, train_y, 200, shuffle=True, seed=0)
-    losses = []
-    for epoch in range(12):
-        model.train()
-        tot = 0.0
-        for data in loader:
-            opt.zero_grad()
-            loss = F.nll_loss(model(data), data.y)
-            loss.backward()
-            opt.step()
-            tot += data.num_graphs * float(loss.detach())
-        losses.append(tot / train_keys.size(0))
+    g = torch.Generator().manual_seed(0)
+    train_loader = net1.KeyLoader(ig, train_keys, train_y, 200).shuffle(g)
+    test_loader = net1.KeyLoader(ig, test_keys, test_y, 200)
+    # the loader does not reshuffle: two passes yield the same batches (reference: DataLoader without shuffle=)
+    a = [b.y.clone() for b in train_loader]
+    b = [b.y.clone() for b in train_loader]
+    assert len(a) == 3 and all(torch.equal(u, v) for u, v in zip(a, b))
+    model = net1.Net_1(F_in).to(dev)
+    lines = []
+    res = net1.fit(model, train_loader, test_loader, dev, num_of_epoch=12, log=lines.append)
+    losses = res["loss"]
     assert all(l == l for l in losses)                       # no NaN
     assert losses[-1] < losses[0] - 0.03, losses             # it learns
-    from npi_gnn_amd import metrics as NM
-    m = NM.Accuracy_Precision_Sensitivity_Specificity_MCC(model, ex.KeyLoader(ig, test_keys, test_y, 200, shuffle=False), dev)
+    # the scheduler is stepped exactly in the epochs whose loss rose (src/train_with_twoDataset.PY:158-160)
+    assert res["lr_steps"] == sum(1 for i in range(1, len(losses)) if losses[i] > losses[i - 1])
+    # metrics every 5th epoch on both loaders, and once at the end (:163-172, :186-193)
+    assert [l.split(",")[0] + "," + l.split(",")[1] for l in lines if "dataset" in l] == [
+        "Epoch: 005, training dataset", "Epoch: 005, testing dataset", "Epoch: 010, training dataset",
+        "Epoch: 010, testing dataset", "result, training dataset", "result, testing dataset"]
+    m = res["test"]
     assert all(0.0 <= v <= 1.0 for v in m[:4]) and -1.0 <= m[4] <= 1.0

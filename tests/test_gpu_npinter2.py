@@ -1,0 +1,77 @@
+"""The reference's REAL workload on the MI355X: project 1223_1 (NPInter2) from
+tests/golden/npinter2_folds.pt -- made by tests/golden/make_npinter2_folds.py from the reference's data files after
+the CPU oracle had reproduced the same numbers.
+
+  fold 0  4,166 test keys -> device extraction -> Net_1 (reference checkpoint, loaded with load_state_dict) ->
+          confusion kernel  ==  TP 1994 / FN 89 / TN 1901 / FP 182 and the metric line of result/1223_1/log_0.txt
+  fold 1  all 2,083 per-sample P(positive) the reference logged for the fold's test negatives, <= 1e-5
+  train   a few epochs of the reference's loop on the 16,658 training pairs: the loss falls, accuracy is sane
+"""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ex():
+    spec = importlib.util.spec_from_file_location("train_npinter2", os.path.join(ROOT, "examples", "train_npinter2.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_whole_fold_kat_through_device_extraction(dev, ex):
+    from npi_gnn_amd import metrics as NM, net1
+    ig, train_keys, train_y, test_keys, test_y, F_in, fx = ex.load_fold(dev, 0)
+    assert (train_keys.size(0), test_keys.size(0), F_in) == (16658, 4166, 178)
+    model = net1.Net_1(F_in).to(dev)
+    model.load_state_dict(fx["fold0"]["state_dict"])          # the reference's checkpoint, unchanged (src/test.py:41)
+    model.eval()
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        for data in net1.KeyLoader(ig, test_keys, test_y, 200):
+            NM.confusion_update(model(data), data.y, counts)
+    assert counts.tolist() == fx["fold0"]["confusion_TP_FN_TN_FP"] == [1994, 89, 1901, 182]
+    m = NM.Accuracy_Precision_Sensitivity_Specificity_MCC(model, net1.KeyLoader(ig, test_keys, test_y, 200), dev)
+    assert ["%.5f" % v for v in m] == fx["fold0"]["logged_metrics"]
+    # batching does not change a sample's prediction: batch size 1 (the case-study scripts) on a slice, 64 on the rest
+    with torch.no_grad():
+        a = torch.cat([model(d) for d in net1.KeyLoader(ig, test_keys[:48], test_y[:48], 1)])
+        b = torch.cat([model(d) for d in net1.KeyLoader(ig, test_keys[:48], test_y[:48], 64)])
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+
+
+def test_all_case_study_probabilities_fold1(dev, ex):
+    from npi_gnn_amd import net1
+    ig, _, _, _, _, F_in, fx = ex.load_fold(dev, 1)
+    f1 = fx["fold1"]
+    keys = f1["test_neg"].long().to(dev)
+    model = net1.Net_1(F_in).to(dev)
+    model.load_state_dict(f1["state_dict"])
+    model.eval()
+    y = torch.zeros(keys.size(0), dtype=torch.long, device=dev)
+    with torch.no_grad():
+        logp = torch.cat([model(d) for d in net1.KeyLoader(ig, keys, y, 200)])
+    p = logp[:, 1].double().exp().cpu()
+    ref = f1["p_positive_logged"]
+    assert p.numel() == ref.numel() == 2083
+    assert float((p - ref).abs().max()) <= 1e-5              # observed on the CPU oracle: 6.7e-7
+
+
+def test_reference_training_loop_on_the_real_fold(dev, ex):
+    from npi_gnn_amd import net1
+    torch.manual_seed(0)
+    ig, train_keys, train_y, test_keys, test_y, F_in, fx = ex.load_fold(dev, 0)
+    g = torch.Generator().manual_seed(0)
+    train_loader = net1.KeyLoader(ig, train_keys, train_y, 200).shuffle(g)
+    test_loader = net1.KeyLoader(ig, test_keys, test_y, 200).shuffle(g)
+    assert len(train_loader) == 84                            # 84 batches per epoch
+    model = net1.Net_1(F_in).to(dev)
+    res = net1.fit(model, train_loader, test_loader, dev, num_of_epoch=3, log=lambda s: None, eval_train=False)
+    assert res["loss"][-1] < res["loss"][0]
+    assert res["test"][0] > 0.85                              # reference: 0.934 at epoch 5 (log_0.txt)
