@@ -1102,6 +1102,7 @@ static int64_t dw_workgroups(bool shared) {
             int dev = 0, cus = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) v = (3 * cus) / 4;
         }
+        if (v > 1024) v = 1024;                          // the workspace is sized for the 1,024-workgroup plan
         return (int64_t)(v > 0 ? v : 192);
     }();
     return ctas;
@@ -1342,19 +1343,26 @@ extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* d
     int splits, kchunk;
     int64_t m_main;
     bwd_weight_plan(M, K, N, g_dw_shared != 0, splits, kchunk, m_main);
-    const int nslab = splits + 1;
-    float* db_slabs = workspace + (int64_t)nslab * K * N;
+    // the slab of the < BK remainder exists only when there is a remainder (a node count that is a multiple of BK used to
+    // pay a zero-filling launch here, which queued behind the co-resident aggregation for 0.4-0.6 ms at C4)
+    const bool has_rem = M > m_main || m_main == 0;
+    const int nslab = (m_main > 0 ? splits : 0) + (has_rem ? 1 : 0);
+    float* db_slabs = workspace + (int64_t)(splits + 1) * K * N;
     const bool v4 = vec4_ok(A, lda, K, es) && vec4_ok(dC, lddc, N, es);
     // output rows = K (features of A), cols = N; A(m = feature, k = node) = A[node*lda + feature]
     // main part: nodes [0, m_main) in `splits` f32 slabs
-    GemmArgs a{fp(A), lda, fp(dC), lddc, workspace, N, (int)K, (int)N, (int)m_main, kchunk, 0, 0, K * N,
-               Epilogue{nullptr, nullptr, 0, db ? db_slabs : nullptr}};
-    (void)launch_gemm<1, 0>(v4, a, splits, stream, dtype, NPI_F32);          // AMODE 1 never takes the allocating path
-    // remainder: nodes [m_main, M) into slab `splits` (a zero slab when there is none)
-    GemmArgs r{fp(advance(A, m_main * lda, es)), lda, fp(advance(dC, m_main * lddc, es)), lddc,
-               workspace + (int64_t)splits * K * N, N, (int)K, (int)N, (int)(M - m_main), BK, 0, 0, K * N,
-               Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)splits * N : nullptr}};
-    (void)launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
+    if (m_main > 0) {
+        GemmArgs a{fp(A), lda, fp(dC), lddc, workspace, N, (int)K, (int)N, (int)m_main, kchunk, 0, 0, K * N,
+                   Epilogue{nullptr, nullptr, 0, db ? db_slabs : nullptr}};
+        (void)launch_gemm<1, 0>(v4, a, splits, stream, dtype, NPI_F32);          // AMODE 1 never takes the allocating path
+    }
+    // remainder: nodes [m_main, M) into slab `splits`
+    if (has_rem) {
+        GemmArgs r{fp(advance(A, m_main * lda, es)), lda, fp(advance(dC, m_main * lddc, es)), lddc,
+                   workspace + (int64_t)(m_main > 0 ? splits : 0) * K * N, N, (int)K, (int)N, (int)(M - m_main), BK, 0, 0, K * N,
+                   Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)(m_main > 0 ? splits : 0) * N : nullptr}};
+        (void)launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
+    }
     const unsigned gw = (unsigned)ceil_div(K * N, 256), gb = (unsigned)ceil_div(N, 256);
     if (dtype == NPI_BF16) {
         slab_reduce_kernel<bf16_t><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (bf16_t*)dW, lddw);

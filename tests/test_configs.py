@@ -75,9 +75,36 @@ def test_config2_sage_bf16_backward(dev, fx):
     assert close(bd.grad, ref_db, 2e-2)
 
 
+@pytest.fixture(scope="module")
+def fx3():
+    """BASELINE.json configs[2] on the graph SURVEY.md 8(d) names: RPI7317 (1,874 ncRNAs + 118 proteins, 7,317 positives
+    + 7,317 seeded negatives = 29,268 directed edges); tests/golden/make_rpi7317.py."""
+    d = torch.load(os.path.join(G, "rpi7317_graph.pt"), map_location="cpu", weights_only=False)
+    d["edge_index"] = d["edge_index"].long()
+    return d
+
+
+def test_config3_graph_is_rpi7317_and_oracle_reproduces_the_vectors(fx3):
+    assert fx3["x"].shape == (1992, 178) and fx3["edge_index"].shape == (2, 29268)
+    assert (fx3["num_rna"], fx3["num_protein"]) == (1874, 118)
+    ei = fx3["edge_index"]
+    assert not bool((ei[0] == ei[1]).any())
+    code = ei[0] * 1992 + ei[1]
+    assert torch.unique(code).numel() == 29268                      # no duplicate directed edge
+    half = ei[:, :14634]
+    assert torch.equal(ei[:, 14634:], half.flip(0))                 # both directions (src/classes.py:701-704)
+    assert bool((fx3["x"][:, 0] == 1).all()) and float(fx3["x"][:, 1:65].abs().max()) == 0.0   # label 1, no node2vec
+    h = fx3["x"]
+    with torch.no_grad():
+        for W, b in fx3["gcn256"]:
+            h = torch.relu(R.gcn_conv(h, ei, W, b))
+    assert torch.allclose(h[fx3["rows"]], fx3["gcn256_out"], atol=1e-6)
+
+
 @pytest.mark.gpu
-def test_config3_gcn3_hidden256_fp32(dev, fx):
+def test_config3_gcn3_hidden256_fp32_on_rpi7317(dev, fx3):
     import npi_gnn_amd as npi
+    fx = fx3
     ei = fx["edge_index"].to(dev)
     convs = []
     for W, b in fx["gcn256"]:

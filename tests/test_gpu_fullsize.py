@@ -244,3 +244,118 @@ def test_c5_gat_forward_rows_against_fp64_formula(c5):
             truth = torch.softmax(e, 0) @ h_nb + b.double()
             worst = max(worst, float((out[i].double() - truth).abs().max()))
         assert worst < 1e-5, worst
+
+
+def test_c5_gat_backward_against_fp64_formulas(c5):
+    """GATConv BACKWARD at the full C5 size: every output of the backward -- dX (all 4M rows), dW, datt,
+    db -- against the PyG-1.4.2 formulas evaluated in fp64 on the same GPU with plain torch ops over the 104M entries
+    (chunked: the per-entry gathers do not fit at once).  Covers edge_grad, both row-sum passes incl. the 2M-entry hub
+    rows, the alpha read-back through the transpose map, att-grad and the two GEMMs."""
+    ei, graph, x = c5
+    dev = x.device
+    g = torch.Generator().manual_seed(17)
+    W = ((torch.rand(F, F, generator=g) * 2 - 1) * (6.0 / (2 * F)) ** 0.5).to(dev).requires_grad_(True)
+    att = ((torch.rand(1, 1, 2 * F, generator=g) * 2 - 1) * (6.0 / (1 + 2 * F)) ** 0.5 * 3.0).to(dev).requires_grad_(True)
+    b = (torch.randn(F, generator=g) * 0.1).to(dev).requires_grad_(True)
+    xg = x.detach().requires_grad_(True)
+    go = torch.randn(N5, F, device=dev)
+    out = npi.gat_conv(xg, graph, W, att, b, heads=1)
+    out.backward(go)
+    got = {k: v.grad.detach() for k, v in (("dx", xg), ("dW", W), ("datt", att), ("db", b))}
+    out = out.detach()
+    xg.grad = None
+    with torch.no_grad():
+        side = graph.by_dst
+        nnz = int(side.rowptr[-1])
+        row, col = side.rowidx[:nnz].long(), side.col[:nnz].long()         # entry p = (target row[p] <- source col[p]), loops incl.
+        Wd = W.detach().double()
+        a_d, a_s = att.detach().double().view(-1)[:F], att.detach().double().view(-1)[F:]
+        h = x.double() @ Wd                                                 # [N5, F] fp64
+        s_dst, s_src = h @ a_d, h @ a_s
+        pre = s_dst[row] + s_src[col]
+        z = torch.nn.functional.leaky_relu(pre, 0.2)
+        m = torch.full((N5,), -1e300, dtype=torch.float64, device=dev).scatter_reduce(0, row, z, "amax")
+        ez = torch.exp(z - m[row])
+        ssum = torch.zeros(N5, dtype=torch.float64, device=dev).index_add_(0, row, ez)
+        alpha = ez / (ssum[row] + 1e-16)
+        del ez, z
+        # the forward first (all rows), then D_i = <dOut_i, out_i - b>
+        ref_out = torch.zeros(N5, F, dtype=torch.float64, device=dev)
+        dot = torch.empty(nnz, dtype=torch.float64, device=dev)             # <dOut_i, h_j> per entry
+        CH = 4_000_000
+        for p0 in range(0, nnz, CH):
+            sl = slice(p0, min(p0 + CH, nnz))
+            hj = h[col[sl]]
+            ref_out.index_add_(0, row[sl], alpha[sl, None] * hj)
+            dot[sl] = (go[row[sl]].double() * hj).sum(1)
+            del hj
+        ref_out += b.detach().double()
+        scale = float(ref_out.abs().max())
+        assert float((out.double() - ref_out).abs().max()) < 1e-5 * max(scale, 1.0)
+        D = (go.double() * (ref_out - b.detach().double())).sum(1)
+        del ref_out
+        dz = alpha * (dot - D[row]) * torch.where(pre > 0, 1.0, 0.2)
+        del dot, pre
+        g_dst = torch.zeros(N5, dtype=torch.float64, device=dev).index_add_(0, row, dz)
+        g_src = torch.zeros(N5, dtype=torch.float64, device=dev).index_add_(0, col, dz)
+        del dz
+        dh = g_dst[:, None] * a_d[None, :] + g_src[:, None] * a_s[None, :]
+        for p0 in range(0, nnz, CH):
+            sl = slice(p0, min(p0 + CH, nnz))
+            dh.index_add_(0, col[sl], alpha[sl, None] * go[row[sl]].double())
+        ref = {"datt": torch.cat([g_dst @ h, g_src @ h]).view(1, 1, 2 * F), "db": go.double().sum(0),
+               "dW": x.double().t() @ dh, "dx": dh @ Wd.t()}
+        del dh, h, alpha
+
+        def rel(a, r):
+            return float((a.double() - r).abs().max() / r.abs().max())
+        # fp32 sums over up to 2M (rows) / 4M (dW, datt, db) terms against fp64: relative to the largest entry
+        assert rel(got["db"], ref["db"]) < 1e-5
+        assert rel(got["datt"], ref["datt"]) < 1e-4
+        assert rel(got["dW"], ref["dW"]) < 1e-4
+        err = (got["dx"].double() - ref["dx"]).abs().amax(1)
+        rows_scale = ref["dx"].abs().amax(1).clamp(min=float(ref["dx"].abs().mean()))
+        assert float((err / rows_scale).max()) < 1e-4                        # every one of the 4M rows, hubs included
+        deg = side.rowptr[1:].long() - side.rowptr[:-1].long()
+        hubs = torch.topk(deg, 4).indices
+        assert int(deg[hubs].min()) > 1_000_000                              # the 2M-entry rows are among them
+        assert float((err[hubs] / rows_scale[hubs]).max()) < 1e-5
+
+
+def test_c5_three_layer_gat_stack_chained(c5):
+    """BASELINE.json configs[4] as a stack: 3 x GATConv(256, 256) with relu between, forward and backward on one GPU; the
+    LAST layer's rows against the fp64 formula evaluated on the tensor that actually entered it."""
+    ei, graph, x = c5
+    dev = x.device
+    g = torch.Generator().manual_seed(19)
+    convs = []
+    for _ in range(3):
+        c = npi.GATConv(F, F, heads=1).to(dev)
+        with torch.no_grad():
+            c.att.mul_(3.0)
+            c.bias.copy_((torch.randn(F, generator=g) * 0.1).to(dev))
+        convs.append(c)
+    xg = x.detach().requires_grad_(True)
+    h1 = torch.relu(convs[0](xg, graph))
+    h2 = torch.relu(convs[1](h1, graph))
+    out = convs[2](h2, graph)
+    out.pow(2).mean().backward()
+    assert bool(torch.isfinite(xg.grad).all()) and float(xg.grad.abs().max()) > 0
+    for c in convs:
+        assert all(bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0 for p in c.parameters())
+    with torch.no_grad():
+        side = graph.by_dst
+        rowptr, col = side.rowptr.long(), side.col.long()
+        in_deg = rowptr[1:] - rowptr[:-1]
+        rows = torch.cat([torch.randint(0, N5, (256,), generator=g).to(dev), torch.topk(in_deg, 2).indices])
+        Wd, bd = convs[2].weight.double(), convs[2].bias.double()
+        a_dst, a_src = convs[2].att.double().view(-1)[:F], convs[2].att.double().view(-1)[F:]
+        worst = 0.0
+        for i in rows.tolist():
+            nb = col[rowptr[i]:rowptr[i + 1]]
+            h_nb = h2[nb].double() @ Wd
+            h_i = h2[i].double() @ Wd
+            e = torch.nn.functional.leaky_relu((h_i * a_dst).sum() + h_nb @ a_src, 0.2)
+            truth = torch.softmax(e, 0) @ h_nb + bd
+            worst = max(worst, float((out[i].double() - truth).abs().max() / truth.abs().max().clamp(min=1.0)))
+        assert worst < 1e-5, worst
