@@ -11,7 +11,13 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer borrowed from the caller (PyTorch's caching allocator);
- *     the library never allocates, frees or retains device memory;
+ *     the library never frees or retains the caller's memory, and the *_ex entry points never allocate: every
+ *     scratch buffer is a caller workspace with a size query next to it.  (Two legacy GEMM entry points,
+ *     npi_linear_fwd[_t] and npi_linear_bwd_data[_t], have no workspace argument and take 6*K*N bytes for the
+ *     duration of the call from the stream-ordered allocator, hipMallocAsync / hipFreeAsync.)
+ *   - no entry point reads or writes process-wide state except the two documented legacy switches
+ *     (npi_gemm_mode, npi_dw_shared), which only the legacy GEMM entry points consult; calls on different
+ *     streams from different threads are independent;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     every call is asynchronous on it and performs no host synchronisation;
  *   - return value: 0 = ok, <0 = error (text via npi_last_error(), thread-local); no C++
@@ -179,6 +185,29 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
                           float* dW, int64_t lddw, float* db,
                           int64_t M, int64_t K, int64_t N,
                           float* workspace, int64_t workspace_elems, void* stream);
+
+/* Per-call forms (what npi_gnn_amd/functional.py binds): the arithmetic and the grid regime are ARGUMENTS, the
+ * scratch for the re-laid weight matrix is a caller workspace -- no process-wide switch is read, nothing is allocated.
+ *   flags     : 0 = follow npi_gemm_mode(); NPI_GEMM_EXACT_F32 / NPI_GEMM_SPLIT_BF16 force one arithmetic for this call
+ *   workspace : npi_linear_workspace_bytes(K, N) bytes, 16-byte aligned (NULL: stream-ordered allocation as the legacy
+ *               entry points do)
+ *   shared    : npi_linear_bwd_weight_ex: 1 = the GEMM shares the CUs with an HBM-bound kernel on another stream
+ *               (about 3 workgroups per 4 CUs), 0 = it has the GPU to itself (see npi_dw_shared) */
+#define NPI_GEMM_EXACT_F32 1
+#define NPI_GEMM_SPLIT_BF16 2
+int64_t npi_linear_workspace_bytes(int64_t K, int64_t N);
+int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                      const float* rowscale, void* C, int64_t ldc,
+                      int64_t M, int64_t K, int64_t N, int relu, int dtype, int flags,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+                           const float* rowscale, void* dA, int64_t ldda,
+                           int64_t M, int64_t K, int64_t N, int dtype, int flags,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
+                             void* dW, int64_t lddw, void* db,
+                             int64_t M, int64_t K, int64_t N,
+                             float* workspace, int64_t workspace_elems, int dtype, int shared, void* stream);
 
 /* The same three GEMMs with A / W / C / bias / dW / db stored as `dtype` (NPI_F32 or NPI_BF16; bf16
  * storage, f32 MFMA accumulation, f32 rowscale and workspace) -- BASELINE.json configs[1]. */

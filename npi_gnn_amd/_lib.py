@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("NPI_GNN_LIB") or os.path.join(HERE, "libnpi_gnn.so") 
 
 NPI_F32 = 0
 NPI_BF16 = 1
+NPI_GEMM_EXACT_F32 = 1      # flags of the npi_linear_*_ex entry points
+NPI_GEMM_SPLIT_BF16 = 2
 
 _P = c_void_p
 _I = c_int64
@@ -49,6 +51,10 @@ PROTOTYPES = {
     "npi_linear_fwd_t": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, _P]),
     "npi_linear_bwd_data_t": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, _P]),
     "npi_linear_bwd_weight_t": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, _P]),
+    "npi_linear_workspace_bytes": (_I, [_I, _I]),
+    "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
+    "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
+    "npi_linear_bwd_weight_ex": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, c_int, _P]),
     "npi_gat_scores": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "npi_gat_heavy_workspace_elems": (_I, [_I, _I]),
     "npi_gat_softmax_stats": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _I, _P]),

@@ -1118,7 +1118,11 @@ static int pick_splits(int64_t M, int64_t tiles, bool shared) {
 // two ragged strips.  `splits` slabs along the contraction; the fast path needs K % BK == 0.
 // dtype_in: storage of A and B; dtype_out: storage of C and bias.  bf16 runs the guarded kernel only.
 template <int AMODE, int BMODE>
-static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32) {
+// `mode`: 0 = exact-f32 MFMA kernels, 1 = bf16 matrix cores where the tile shape allows (3-way split for f32 storage).
+// `scratch`: caller memory for the re-laid weight matrix (npi_linear_workspace_bytes); null = take it from the
+// stream-ordered allocator (the legacy entry points).
+static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32,
+                       int mode = 1, void* scratch = nullptr) {
     const bool bf16_in = dtype_in == NPI_BF16 && dtype_out == NPI_F32;          // dW of the bf16 path: bf16 operands, f32 slabs
     const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && ((dtype_in == NPI_F32 && dtype_out == NPI_F32) || bf16_in);
     // 128 x 256 tile (one workgroup per CU): measured 3-10 % SLOWER than 128 x 128 at C4 (round 1:
@@ -1130,11 +1134,12 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     // bf16 storage: interior tiles on the bf16 MFMA pipeline (K % 64 == 0, 16-byte aligned rows); the rest guarded
     const bool bf16_ws = AMODE == 0 && splits == 1 && dtype_in == NPI_BF16 && dtype_out == NPI_BF16 && a.ep.colsum == nullptr &&
                          a.K % 64 == 0 && a.N % 128 == 0 && a.M >= 128 && (a.lda % 8 == 0) && (a.ldc % 4 == 0) &&
-                         ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.C % 8 == 0) && g_gemm_mode != 0;
+                         ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.C % 8 == 0) && mode != 0;
     if (bf16_ws) {
-        uint16_t* blocks = nullptr;
+        uint16_t* blocks = reinterpret_cast<uint16_t*>(scratch);
         const int64_t nel = (int64_t)a.N * a.K;
-        if (hipMallocAsync(reinterpret_cast<void**>(&blocks), (size_t)nel * 2, stream) != hipSuccess || blocks == nullptr) {
+        if (blocks == nullptr &&
+            (hipMallocAsync(reinterpret_cast<void**>(&blocks), (size_t)nel * 2, stream) != hipSuccess || blocks == nullptr)) {
             (void)hipGetLastError();
             set_error("gemm: hipMallocAsync of the bf16 weight blocks failed");
             return NPI_ERR_LAUNCH;
@@ -1149,7 +1154,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);
         if (wide_n) gemm_bf16_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(ba);
         else        gemm_bf16_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(ba);
-        (void)hipFreeAsync(blocks, stream);
+        if (scratch == nullptr) (void)hipFreeAsync(blocks, stream);
         // the ragged bottom strip (M % 128 rows) goes through the guarded kernel below
         const int tm_all = (int)ceil_div(a.M, 128), tn_all = (int)ceil_div(a.N, 128);
         if (tm_all > bfm) {
@@ -1161,13 +1166,14 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         }
         return NPI_OK;
     }
-    const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && g_gemm_mode != 0 && a.ep.colsum == nullptr &&
+    const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
                        ((uintptr_t)a.C % 16 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
     if (fm > 0 && fn > 0 && split) {
         // stream-ordered scratch for the three bf16 planes of B (W is small: 3 * 2 * K * N bytes)
-        uint16_t* planes = nullptr;
+        uint16_t* planes = reinterpret_cast<uint16_t*>(scratch);
         const int64_t nel = (int64_t)a.N * a.K;
-        if (hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)nel * 6, stream) != hipSuccess || planes == nullptr) {
+        if (planes == nullptr &&
+            (hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)nel * 6, stream) != hipSuccess || planes == nullptr)) {
             (void)hipGetLastError();
             set_error("gemm: hipMallocAsync of the split planes failed");
             return NPI_ERR_LAUNCH;
@@ -1180,7 +1186,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
         if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
         else        gemm_split_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(sa);
-        (void)hipFreeAsync(planes, stream);
+        if (scratch == nullptr) (void)hipFreeAsync(planes, stream);
     } else if (fm > 0 && fn > 0) {
         GemmArgs f = a;
         f.tm0 = 0; f.tn0 = 0;
@@ -1230,9 +1236,25 @@ extern "C" int npi_gemm_mode(int mode) {
     return prev;
 }
 
-extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
-                                const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
-                                int64_t N, int relu, int dtype, void* stream_) {
+// per-call arithmetic of the *_ex entry points -> launch_gemm's mode
+static int gemm_mode_of(int flags) {
+    if (flags & NPI_GEMM_EXACT_F32) return 0;
+    if (flags & NPI_GEMM_SPLIT_BF16) return 1;
+    return g_gemm_mode;
+}
+static bool scratch_ok(void* ws, int64_t ws_bytes, int64_t K, int64_t N) {
+    return ws == nullptr || (ws_bytes >= npi_linear_workspace_bytes(K, N) && ((uintptr_t)ws % 16) == 0);
+}
+
+extern "C" int64_t npi_linear_workspace_bytes(int64_t K, int64_t N) {
+    if (K <= 0 || N <= 0) return -1;
+    return 6 * K * N + 256;                                   // three bf16 planes of the weight matrix
+}
+
+extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                                 const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
+                                 int64_t N, int relu, int dtype, int flags, void* workspace, int64_t workspace_bytes,
+                                 void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_fwd: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_fwd: size > int32");
@@ -1240,11 +1262,21 @@ extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64
     if (M == 0) return NPI_OK;
     NPI_REQUIRE(A && W && C, "npi_linear_fwd: null pointer");
     NPI_REQUIRE(lda >= K && ldw >= N && ldc >= N, "npi_linear_fwd: leading dimension too small");
+    if (!scratch_ok(workspace, workspace_bytes, K, N)) {
+        set_error("npi_linear_fwd_ex: workspace too small or not 16-byte aligned");
+        return NPI_ERR_WORKSPACE;
+    }
     const int es = dtype == NPI_BF16 ? 2 : 4;
     GemmArgs a{fp(A), lda, fp(W), ldw, (float*)C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
                Epilogue{fp(bias), rowscale, relu, nullptr}};
-    const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, K, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
+    const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, K, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
+                                     gemm_mode_of(flags), workspace);
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd");
+}
+extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                                const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
+                                int64_t N, int relu, int dtype, void* stream_) {
+    return npi_linear_fwd_ex(A, lda, W, ldw, bias, rowscale, C, ldc, M, K, N, relu, dtype, 0, nullptr, 0, stream_);
 }
 extern "C" int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                               const float* rowscale, float* C, int64_t ldc, int64_t M, int64_t K,
@@ -1253,9 +1285,10 @@ extern "C" int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64
 }
 
 // dA[M,K] = rowscale * (dC[M,N] @ W[K,N]^T): GEMM with "K" = N (contracted), output width K
-extern "C" int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
-                                     const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
-                                     int64_t N, int dtype, void* stream_) {
+extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+                                      const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
+                                      int64_t N, int dtype, int flags, void* workspace, int64_t workspace_bytes,
+                                      void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_data: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_data: size > int32");
@@ -1263,12 +1296,22 @@ extern "C" int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W
     if (M == 0) return NPI_OK;
     NPI_REQUIRE(dC && W && dA, "npi_linear_bwd_data: null pointer");
     NPI_REQUIRE(lddc >= N && ldw >= N && ldda >= K, "npi_linear_bwd_data: leading dimension too small");
+    if (!scratch_ok(workspace, workspace_bytes, K, N)) {
+        set_error("npi_linear_bwd_data_ex: workspace too small or not 16-byte aligned");
+        return NPI_ERR_WORKSPACE;
+    }
     const int es = dtype == NPI_BF16 ? 2 : 4;
     // B(k = n_contract, n = k_out) = W[k_out * ldw + n_contract]  -> BMODE 1
     GemmArgs a{fp(dC), lddc, fp(W), ldw, (float*)dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
                Epilogue{nullptr, rowscale, 0, nullptr}};
-    const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype);
+    const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
+                                     gemm_mode_of(flags), workspace);
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data");
+}
+extern "C" int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+                                     const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
+                                     int64_t N, int dtype, void* stream_) {
+    return npi_linear_bwd_data_ex(dC, lddc, W, ldw, rowscale, dA, ldda, M, K, N, dtype, 0, nullptr, 0, stream_);
 }
 extern "C" int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
                                    const float* rowscale, float* dA, int64_t ldda, int64_t M, int64_t K,
@@ -1329,6 +1372,12 @@ extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, i
 extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t lddc,
                                        void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
                                        float* workspace, int64_t workspace_elems, int dtype, void* stream_) {
+    return npi_linear_bwd_weight_ex(A, lda, dC, lddc, dW, lddw, db, M, K, N, workspace, workspace_elems, dtype,
+                                    g_dw_shared != 0 ? 1 : 0, stream_);
+}
+extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
+                                        void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
+                                        float* workspace, int64_t workspace_elems, int dtype, int shared, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_weight: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_weight: size > int32");
@@ -1342,7 +1391,7 @@ extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* d
     const int es = dtype == NPI_BF16 ? 2 : 4;
     int splits, kchunk;
     int64_t m_main;
-    bwd_weight_plan(M, K, N, g_dw_shared != 0, splits, kchunk, m_main);
+    bwd_weight_plan(M, K, N, shared != 0, splits, kchunk, m_main);
     // the slab of the < BK remainder exists only when there is a remainder (a node count that is a multiple of BK used to
     // pay a zero-filling launch here, which queued behind the co-resident aggregation for 0.4-0.6 ms at C4)
     const bool has_rem = M > m_main || m_main == 0;

@@ -168,7 +168,8 @@ segsum_kernel(SegParams P) {
     const int N = P.N;
     const int nnz = P.rowptr[N];
     const int k0 = item * P.item;
-    if (k0 >= nnz) return;
+    // a CSR with capacity but no entry at all (every edge dropped): item 0 still runs and closes all N empty rows
+    if (k0 >= nnz && !(item == 0 && nnz == 0)) return;
     const int k1 = min(k0 + P.item, nnz);
     const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
@@ -357,7 +358,8 @@ segsum_group_kernel(SegParams P) {
     const int N = P.N;
     const int nnz = P.rowptr[N];
     const int k0 = item * P.item;
-    if (k0 >= nnz) return;
+    // a CSR with capacity but no entry at all (every edge dropped): item 0 still runs and closes all N empty rows
+    if (k0 >= nnz && !(item == 0 && nnz == 0)) return;
     const int k1 = min(k0 + P.item, nnz);
     const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);

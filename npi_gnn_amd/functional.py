@@ -120,8 +120,18 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     return out
 
 
+# Arithmetic of the f32 projection GEMMs, passed PER CALL (npi_linear_*_ex flags): 0 = the library default (3-way bf16
+# split on the bf16 matrix cores unless NPI_GEMM_SPLIT=0), NPI_GEMM_EXACT_F32, NPI_GEMM_SPLIT_BF16.
+GEMM_FLAGS = 0
+
+
+def _gemm_workspace(K: int, N: int, dev) -> torch.Tensor:
+    """caller-owned scratch for the re-laid weight matrix: the library allocates nothing"""
+    return torch.empty(int(load().npi_linear_workspace_bytes(K, N)), dtype=torch.uint8, device=dev)
+
+
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               rowscale: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+               rowscale: Optional[torch.Tensor] = None, relu: bool = False, flags: Optional[int] = None) -> torch.Tensor:
     dev = require_gpu(a, weight, bias, rowscale)
     a = _fc(a, "a")
     weight = _fc(weight, "weight", a)
@@ -130,30 +140,35 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     M, K = a.shape
     N = weight.size(1)
     out = torch.empty((M, N), dtype=a.dtype, device=dev)
+    ws = _gemm_workspace(K, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
-        check(load().npi_linear_fwd_t(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
-                                      ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a), stream_ptr(dev)),
+        check(load().npi_linear_fwd_ex(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
+                                       ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a),
+                                       GEMM_FLAGS if flags is None else flags, ptr(ws), ws.numel(), stream_ptr(dev)),
               "npi_linear_fwd")
     return out
 
 
 def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
-                    rowscale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    rowscale: Optional[torch.Tensor] = None, flags: Optional[int] = None) -> torch.Tensor:
     dev = require_gpu(dc, weight, rowscale)
     dc = _fc(dc, "dC")
     weight = _fc(weight, "weight", dc)
     M, N = dc.shape
     K = weight.size(0)
     da = torch.empty((M, K), dtype=dc.dtype, device=dev)
+    ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
-        check(load().npi_linear_bwd_data_t(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
-                                           ptr(da), da.stride(0), M, K, N, _code(dc), stream_ptr(dev)),
+        check(load().npi_linear_bwd_data_ex(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
+                                            ptr(da), da.stride(0), M, K, N, _code(dc),
+                                            GEMM_FLAGS if flags is None else flags, ptr(ws), ws.numel(), stream_ptr(dev)),
               "npi_linear_bwd_data")
     return da
 
 
 def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False):
-    """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid, see npi_dw_shared)."""
+    """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid; a per-call argument of
+    ``npi_linear_bwd_weight_ex``, no process-wide switch is touched)."""
     dev = require_gpu(a, dc)
     a = _fc(a, "a")
     dc = _fc(dc, "dC", a)
@@ -164,10 +179,10 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True,
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     dw = torch.empty((K, N), dtype=a.dtype, device=dev)
     db = torch.empty(N, dtype=a.dtype, device=dev) if want_bias else None
-    lib.npi_dw_shared(1 if shared else 0)
     with _gemm_events("bwd_weight", 2.0 * M * K * N, dev):
-        check(lib.npi_linear_bwd_weight_t(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
-                                          M, K, N, ptr(ws), n_ws, _code(a), stream_ptr(dev)), "npi_linear_bwd_weight")
+        check(lib.npi_linear_bwd_weight_ex(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
+                                           M, K, N, ptr(ws), n_ws, _code(a), 1 if shared else 0, stream_ptr(dev)),
+              "npi_linear_bwd_weight")
     return dw, db
 
 
@@ -326,10 +341,11 @@ class _GcnConvFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         norm: GCNNorm = ctx.norm
         graph = norm.graph
-        grad_out = _f32c(grad_out, "grad_out")
+        grad_out = _fc(grad_out, "grad_out", x)
         dx = dw = db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(grad_out)
+            # the column-sum kernel is f32: bf16 storage (BASELINE.json configs[1] style training) widens dOut for it
+            db = colsum(grad_out) if grad_out.dtype == torch.float32 else colsum(grad_out.float()).to(grad_out.dtype)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dxw = segsum(graph, graph.by_src, grad_out, w=norm.by_src)        # A_hat^T dOut
             if ctx.needs_input_grad[1]:

@@ -18,12 +18,44 @@ from ._lib import check, load, ptr, require_gpu, stream_ptr
 
 _DEBUG = False
 
+# Status words of graph builds that nobody has looked at yet.  A build never synchronises, so an out-of-range node id
+# (which the build DROPS, where PyG's index_select / scatter raise) is reported at the next point that reads from the
+# device anyway: TopKPooling's size read, InteractionGraph.batch, CSRGraph.nnz(), the metrics read -- or after
+# _PENDING_MAX unchecked builds (one extra device read per that many builds).  set_debug(True) checks every build at once.
+_PENDING = []
+_PENDING_MAX = 256
+
 
 def set_debug(flag: bool) -> None:
     """When on, every graph build synchronises and raises on out-of-range node ids
     (PyG/torch raise IndexError/RuntimeError there)."""
     global _DEBUG
     _DEBUG = bool(flag)
+
+
+def pending_status() -> list:
+    """Device status words not yet checked (callers that are about to read from the device append them to their read and
+    hand the values to ``raise_on_status``)."""
+    out = list(_PENDING)
+    _PENDING.clear()
+    return out
+
+
+def raise_on_status(values) -> None:
+    if any(int(v) & 1 for v in values):
+        raise IndexError("edge_index holds a node id outside [0, num_nodes): the edges were dropped by the graph build "
+                         "(PyG's index_select / scatter raise here)")
+
+
+def check_pending() -> None:
+    """Read and check every outstanding status word now (synchronises)."""
+    st = pending_status()
+    if st:
+        by_dev = {}
+        for t in st:
+            by_dev.setdefault(t.device, []).append(t)
+        for ts in by_dev.values():
+            raise_on_status(torch.cat(ts).tolist())
 
 
 @dataclass
@@ -85,8 +117,12 @@ def build_side(key: torch.Tensor, val: torch.Tensor, n_rows: int, n_cols: int, s
                                int(loop_col_offset), 1 if drop_equal else 0, ptr(rowptr), ptr(col), ptr(eid),
                                ptr(rowidx), ptr(item_row), ptr(status), ptr(ws), ws_bytes, stream_ptr(dev)),
           "npi_csr_build_ex")
-    if _DEBUG and int(status.item()) & 1:
-        raise IndexError("edge_index holds a node id outside [0, num_nodes)")
+    if _DEBUG:
+        raise_on_status([status.item()])
+    else:
+        _PENDING.append(status)
+        if len(_PENDING) > _PENDING_MAX:
+            check_pending()
     side = CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
     side.n_rows, side.n_cols = N, int(n_cols)
     return side
@@ -129,8 +165,10 @@ class CSRGraph:
         return side.carry(F)
 
     def nnz(self) -> int:
-        """Entries incl. self loops (device read; synchronises)."""
-        return int(self.by_dst.rowptr[-1].item())
+        """Entries incl. self loops (device read; synchronises -- and reports dropped out-of-range ids)."""
+        n = int(self.by_dst.rowptr[-1].item())
+        check_pending()
+        return n
 
 
 def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:

@@ -48,6 +48,8 @@ def Accuracy_Precision_Sensitivity_Specificity_MCC(model, loader, device):
             data = data.to(device)
             confusion_update(model(data).float(), data.y.to(torch.int64), counts)
     TP, FN, TN, FP = counts.tolist()
+    from .graph import check_pending
+    check_pending()                     # the evaluation's one device read: also the place dropped node ids surface
     print('TP: %d, FN: %d, TN: %d, FP: %d' % (TP, FN, TN, FP))
     return metrics_from_counts(TP, FN, TN, FP)
 

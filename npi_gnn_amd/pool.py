@@ -72,7 +72,12 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
           "npi_filter_adj")
     # sizes of the outputs are data dependent: ONE device read per pooling layer (PyG's own implementation has several)
-    n_out, flags, e_out = torch.cat([out_ptr[-1:], status, count]).tolist() if B else (0, 0, 0)
+    # (the same read also reports graph builds that dropped out-of-range node ids, graph.pending_status)
+    from . import graph as _graph
+    pend = [t for t in _graph.pending_status() if t.device == dev]
+    vals = torch.cat([out_ptr[-1:], status, count] + pend).tolist() if B else [0, 0, 0] + (torch.cat(pend).tolist() if pend else [])
+    n_out, flags, e_out = vals[:3]
+    _graph.raise_on_status(vals[3:])
     if flags & 2:
         raise NotImplementedError("TopKPooling: a graph has more than 16384 nodes")
     xo = torch.empty((n_out, F), dtype=torch.float32, device=dev)

@@ -79,12 +79,39 @@ def test_csr_build_flags_out_of_range_ids(dev):
     g = npi.CSRGraph(ei.to(dev), 3)
     assert int(g.by_dst.status.item()) == 1
     assert g.by_dst.rowptr.cpu().tolist() == [0, 1, 3, 5]      # bad column dropped
+    # a build never synchronises; the dropped id is reported at the next device read (PyG raises here)
+    with pytest.raises(IndexError):
+        g.nnz()
+    ok = npi.CSRGraph(torch.tensor([[0, 1], [1, 2]]).to(dev), 3)
+    assert ok.nnz() == 5                                       # the report is made once, later graphs are clean
     npi.set_debug(True)
     try:
         with pytest.raises(IndexError):
             npi.CSRGraph(ei.to(dev), 3)
     finally:
         npi.set_debug(False)
+
+
+def test_segsum_on_a_csr_whose_every_edge_was_dropped(dev):
+    """capacity nnz_max > 0 but rowptr[N] == 0 (self_loops=False and only self loops / bad ids in the edge
+    list): every output row must still be written (zero, or the bias)."""
+    N, F = 300, 256
+    ei = torch.arange(N).repeat(2, 1)                          # nothing but self loops
+    g = npi.CSRGraph(ei.to(dev), N, self_loops=False)
+    x = torch.randn(N, F, device=dev)
+    bias = torch.randn(F, device=dev)
+    for mean in (False, True):
+        out = torch.full((N, F), float("nan"), device=dev)
+        NF.segsum(g, g.by_dst, x, mean=mean, out=out)
+        assert bool((out == 0).all())
+        out = torch.full((N, F), float("nan"), device=dev)
+        NF.segsum(g, g.by_dst, x, mean=mean, bias=bias, out=out)
+        assert torch.equal(out, bias.expand(N, F))
+    xs = torch.randn(N, 64, device=dev)                        # the narrow-row kernel
+    out = torch.full((N, 64), float("nan"), device=dev)
+    NF.segsum(g, g.by_dst, xs, out=out)
+    assert bool((out == 0).all())
+    assert g.nnz() == 0
 
 
 def _segsum_oracle(ei, N, x, w_entry_fn=None, mean=False, loops=True):
@@ -375,21 +402,86 @@ def test_split_bf16_gemm_is_f32_accurate(dev, M, K, N):
     dC = torch.randn(M, N, generator=g).to(dev)
     ref_f = torch.relu(rs.double().view(-1, 1) * (A.double() @ W.double()) + b.double())
     ref_b = rs.double().view(-1, 1) * (dC.double() @ W.double().t())
-    prev = lib.npi_gemm_mode(-1)
-    try:
-        err = {}
-        for mode in (0, 1):
-            lib.npi_gemm_mode(mode)
-            cf = NF.linear_fwd(A, W, b, rowscale=rs, relu=True)
-            cb = NF.linear_bwd_data(dC, W, rs)
-            err[mode] = (float((cf.double() - ref_f).abs().max() / ref_f.abs().max()),
-                         float((cb.double() - ref_b).abs().max() / ref_b.abs().max()))
-            again = NF.linear_fwd(A, W, b, rowscale=rs, relu=True)
-            assert torch.equal(cf, again)                      # run-to-run bitwise reproducible
-        for e0, e1 in zip(err[0], err[1]):
-            assert e1 < 2e-6 and e1 < 3 * e0 + 1e-7, err
-    finally:
-        lib.npi_gemm_mode(prev)
+    from npi_gnn_amd._lib import NPI_GEMM_EXACT_F32, NPI_GEMM_SPLIT_BF16
+    before = lib.npi_gemm_mode(-1)
+    err = {}
+    for mode, flags in ((0, NPI_GEMM_EXACT_F32), (1, NPI_GEMM_SPLIT_BF16)):          # per-call: no process-wide switch
+        cf = NF.linear_fwd(A, W, b, rowscale=rs, relu=True, flags=flags)
+        cb = NF.linear_bwd_data(dC, W, rs, flags=flags)
+        err[mode] = (float((cf.double() - ref_f).abs().max() / ref_f.abs().max()),
+                     float((cb.double() - ref_b).abs().max() / ref_b.abs().max()))
+        again = NF.linear_fwd(A, W, b, rowscale=rs, relu=True, flags=flags)
+        assert torch.equal(cf, again)                      # run-to-run bitwise reproducible
+    for e0, e1 in zip(err[0], err[1]):
+        assert e1 < 2e-6 and e1 < 3 * e0 + 1e-7, err
+    assert lib.npi_gemm_mode(-1) == before                 # nothing global was touched
+
+
+def test_gemm_entry_points_are_independent_across_threads_and_streams(dev):
+    """the arithmetic and the dW grid regime are per-call arguments now.  Two threads, each on its own
+    HIP stream, hammer the three GEMMs with DIFFERENT settings at the same time; every result must be bit-identical to
+    the one the same call gives alone."""
+    import threading
+    from npi_gnn_amd._lib import NPI_GEMM_EXACT_F32, NPI_GEMM_SPLIT_BF16
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 4096, 256, 256
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(dev)
+    dC = torch.randn(M, N, generator=g).to(dev)
+    settings = [(NPI_GEMM_EXACT_F32, False), (NPI_GEMM_SPLIT_BF16, True)]
+
+    def run(flags, shared):
+        return (NF.linear_fwd(A, W, None, flags=flags), NF.linear_bwd_data(dC, W, None, flags=flags)) + \
+            NF.linear_bwd_weight(A, dC, True, shared=shared)
+    alone = [tuple(t.clone() for t in run(*s)) for s in settings]
+    torch.cuda.synchronize()
+    assert not torch.equal(alone[0][0], alone[1][0])          # the two arithmetics do differ in the last bits
+    bad = []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(40):
+                    got = run(*settings[k])
+                    st.synchronize()
+                    if not all(torch.equal(a, b) for a, b in zip(got, alone[k])):
+                        bad.append(k)
+        except Exception as e:                              # noqa: BLE001
+            bad.append(repr(e))
+    th = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
+
+
+def test_gcn_bf16_storage_trains(dev):
+    """GCNConv(...).to(bfloat16) backward (bf16 storage, f32 accumulation) against the fp32 oracle on
+    the bf16-rounded inputs."""
+    N, E, Fi, Fo = 3000, 24000, 128, 128
+    ei = rand_edges(N, E, seed=4, hub=5)
+    g = torch.Generator().manual_seed(6)
+    x, W, b, go = (torch.randn(N, Fi, generator=g), torch.randn(Fi, Fo, generator=g) / Fi ** 0.5,
+                   torch.randn(Fo, generator=g), torch.randn(N, Fo, generator=g))
+    xr, Wr, br, gor = (t.to(torch.bfloat16).float().requires_grad_(q) for t, q in ((x, True), (W, True), (b, True), (go, False)))
+    ref = R.gcn_conv(xr, ei, Wr, br)
+    ref.backward(gor)
+    conv = npi.GCNConv(Fi, Fo).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(W)
+        conv.bias.copy_(b)
+    conv = conv.to(torch.bfloat16)
+    xd = x.to(dev).to(torch.bfloat16).requires_grad_(True)
+    out = conv(xd, ei.to(dev))
+    out.backward(go.to(dev).to(torch.bfloat16))
+    assert out.dtype == torch.bfloat16 and conv.weight.grad.dtype == torch.bfloat16
+
+    def close(a, r, rel=2e-2):
+        return float((a.float().cpu() - r).abs().max()) <= rel * float(r.abs().max())
+    assert close(out.detach(), ref.detach()) and close(xd.grad, xr.grad) and close(conv.weight.grad, Wr.grad)
+    assert close(conv.bias.grad, br.grad)
 
 
 def test_training_step_is_hip_graph_capturable(dev):
