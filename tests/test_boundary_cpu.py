@@ -80,11 +80,21 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
                                                            8, N, 8, N),
         "npi_gat_edge_grad": lambda: lib.npi_gat_edge_grad(N, N, N, 4, 16, N, 4, N, 4, 0, 4, N, N, N, N, N, 0.2, N, N, N),
         "npi_seg_rowsum": lambda: lib.npi_seg_rowsum(N, N, N, N, -1, 0, 1, N, N, 0, N),
+        "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N),       # bad split
+        "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N),
+        "npi_linear_bwd_data_ex": lambda: lib.npi_linear_bwd_data_ex(N, 0, N, 0, N, N, 0, 8, 8, -3, 0, 0, N, 0, N),
+        "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 1, N),
+        "npi_gat_edge_grad_ex": lambda: lib.npi_gat_edge_grad_ex(N, N, N, 4, 16, N, 4, N, 0, N, 4, 0, 4, N, N, N, N, N, 0.2, 1, N, N, N),
     }
     for name, call in calls.items():
         assert call() == -1, name
         stem = name[:-3] if name.endswith("_ex") else name           # npi_csr_build_ex reports as npi_csr_build
         assert stem.encode() in lib.npi_last_error(), (name, lib.npi_last_error())
+    # a caller workspace that is too small is refused before anything is launched (status -3), and sized by a query
+    assert lib.npi_linear_workspace_bytes(256, 256) >= 6 * 256 * 256 and lib.npi_linear_workspace_bytes(0, 8) == -1
+    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 0, 16, 100, N) == -3
+    assert b"workspace" in lib.npi_last_error()
+    assert lib.npi_linear_bwd_data_ex(16, 256, 16, 256, N, 16, 256, 128, 256, 256, 0, 0, 24, 10 ** 9, N) == -3   # misaligned
     assert lib.npi_linear_bwd_weight_workspace_elems(-1, 8, 8) == -1
     assert lib.npi_gemm_mode(-1) in (0, 1)                      # query only
 

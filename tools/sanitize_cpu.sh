@@ -1,0 +1,25 @@
+#!/bin/bash
+# Host-side AddressSanitizer + UndefinedBehaviorSanitizer pass over the C ABI.  GPU sanitizers are
+# not available on this pool, so only the HOST half of every .hip file is instrumented (-fno-gpu-sanitize: argument validation,
+# size queries, launch planning, error reporting; the device code is compiled as usual and never launched) and the CPU boundary tests run
+# against that library with the ASan runtime preloaded into the (uninstrumented) python.
+#   tools/sanitize_cpu.sh            build + run tests/test_boundary_cpu.py
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/npi_gnn_amd/build/asan"
+mkdir -p "$OUT"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+objs=""
+for f in csr_build segsum gemm_f32 graph_ops gat pool subgraph; do
+  $HIPCC -O1 -g -fno-gpu-sanitize -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -fno-omit-frame-pointer \
+         -fsanitize=address,undefined -fno-sanitize-recover=undefined -shared-libasan \
+         -c "$ROOT/npi_gnn_amd/csrc/$f.hip" -o "$OUT/$f.o" &
+  objs="$objs $OUT/$f.o"
+done
+wait
+$HIPCC -shared -fPIC -fsanitize=address,undefined -shared-libasan -o "$OUT/libnpi_gnn_asan.so" $objs
+echo "built $OUT/libnpi_gnn_asan.so"
+cd "$ROOT"
+LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:verify_asan_link_order=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+  NPI_GNN_LIB="$OUT/libnpi_gnn_asan.so" python3 -m pytest tests/test_boundary_cpu.py -x -q -p no:cacheprovider "$@"
