@@ -250,7 +250,7 @@ def _stack_step(kind, weights, x, graph, dtype=torch.float32, norm=None, att=Non
 def _stack_forward(kind, weights, x, graph, dtype=torch.float32, norm=None):
     import npi_gnn_amd as npi
     from npi_gnn_amd import functional as NF
-    dev = x.device
+    dev = graph.device
     with torch.no_grad():
         h = x.to(dev).to(dtype)
         for W, b in weights:

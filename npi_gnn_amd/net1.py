@@ -71,13 +71,17 @@ class KeyLoader:
     ``src/train_with_twoDataset.PY:78-79``: ONE random permutation of the samples; the loader itself never
     shuffles (``:142`` passes no ``shuffle=``), so every epoch sees the same batches in the same order."""
 
-    def __init__(self, ig: InteractionGraph, keys: torch.Tensor, y: torch.Tensor, batch_size: int = 200):
+    def __init__(self, ig: InteractionGraph, keys: torch.Tensor, y: torch.Tensor, batch_size: int = 200, _sizes=None):
         self.ig, self.keys, self.y, self.batch_size = ig, keys, y, int(batch_size)
         self.dataset = range(int(keys.size(0)))              # len(loader.dataset), as src/methods.py:85 uses it
+        # a sample's size depends on its key only: ONE device read for the whole list, then every batch's totals are known
+        # on the host and building a batch needs no read-back (the reference knows them too: its samples are files)
+        self._nodes, self._pairs = _sizes if _sizes is not None else ig.sizes(keys)
 
     def shuffle(self, generator: Optional[torch.Generator] = None) -> "KeyLoader":
-        perm = torch.randperm(self.keys.size(0), generator=generator).to(self.keys.device)
-        return KeyLoader(self.ig, self.keys[perm], self.y[perm], self.batch_size)
+        perm = torch.randperm(self.keys.size(0), generator=generator)
+        dperm = perm.to(self.keys.device)
+        return KeyLoader(self.ig, self.keys[dperm], self.y[dperm], self.batch_size, (self._nodes[perm], self._pairs[perm]))
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -85,7 +89,8 @@ class KeyLoader:
     def __iter__(self):
         for i in range(0, len(self.dataset), self.batch_size):
             k = self.keys[i:i + self.batch_size]
-            x, ei, b = self.ig.batch(k)
+            x, ei, b = self.ig.batch(k, n_nodes=int(self._nodes[i:i + self.batch_size].sum()),
+                                     n_pairs=int(self._pairs[i:i + self.batch_size].sum()))
             yield Batch(x, ei, b, self.y[i:i + self.batch_size])
 
 

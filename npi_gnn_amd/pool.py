@@ -79,7 +79,23 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     n_out, flags, e_out = vals[:3]
     _graph.raise_on_status(vals[3:])
     if flags & 2:
-        raise NotImplementedError("TopKPooling: a graph has more than 16384 nodes")
+        # A graph with more than 16,384 nodes does not fit the LDS sort of npi_topk_select (one-hop subgraphs of the
+        # bundled datasets stay below 1,000 nodes).  Rare path: the same selection rule -- score descending, lower index
+        # first among equals, ceil(ratio n) per graph -- with device-wide torch sorts, then filter_adj again with the new map.
+        gpl = gp.long()
+        n_per = gpl[1:] - gpl[:-1]
+        k_per = torch.ceil(float(ratio) * n_per.double()).long()
+        order = torch.argsort(score, descending=True, stable=True)
+        order = order[torch.argsort(batch[order], stable=True)]
+        rank = torch.arange(N, device=dev) - gpl[:-1][batch[order]]
+        kept = order[rank < k_per[batch[order]]]
+        out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(k_per, 0)]).to(torch.int32)
+        perm = kept.to(torch.int32)
+        remap = torch.full((max(N, 1),), -1, **i32)
+        remap[kept] = torch.arange(kept.numel(), **i32)
+        check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
+              "npi_filter_adj")
+        n_out, e_out = int(kept.numel()), int(count.item())
     xo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
     batch_o = torch.empty(n_out, dtype=torch.int64, device=dev)
     score_o = torch.empty(n_out, dtype=torch.float32, device=dev)

@@ -58,8 +58,28 @@ class InteractionGraph:
         self.feat = feat.contiguous()
         self.device = dev
 
-    def batch(self, keys: torch.Tensor, return_node_id: bool = False):
-        """``keys [B, 2]`` (rna_serial, protein_serial) -> ``x, edge_index, batch`` of the B enclosing subgraphs."""
+    def sizes(self, keys: torch.Tensor):
+        """(nodes, pairs) per sample of ``keys [K, 2]`` as HOST int64 tensors -- one device read for the whole key list.
+        A loader that keeps them (``net1.KeyLoader``) can tell ``batch`` the size of every batch it asks for, and the
+        per-batch device read below disappears (sample sizes depend on the key only, not on the batch it is in)."""
+        lib = load()
+        dev = self.device
+        keys = keys.to(device=dev, dtype=torch.int32).contiguous()
+        K = keys.size(0)
+        i32 = dict(dtype=torch.int32, device=dev)
+        node_off, pair_off = torch.empty(K + 1, **i32), torch.empty(K + 1, **i32)
+        ws = torch.empty(max(2 * K, 1), **i32)
+        check(lib.npi_subgraph_sizes(ptr(self.ptr), ptr(self.nbr), ptr(self.ok), ptr(keys), K, ptr(node_off), ptr(pair_off),
+                                     ptr(ws), stream_ptr(dev)), "npi_subgraph_sizes")
+        # the workspace holds, per sample, the usable partners of its RNA and of its protein (the scan only reads them)
+        cnt = ws[: 2 * K].view(2, K).to(torch.int64).cpu() if K else torch.zeros((2, 0), dtype=torch.int64)
+        both = cnt[0] + cnt[1]
+        return both + 2, both + 1                               # nodes: the pair itself + partners; pairs: target + partners
+
+    def batch(self, keys: torch.Tensor, return_node_id: bool = False, n_nodes: Optional[int] = None,
+              n_pairs: Optional[int] = None):
+        """``keys [B, 2]`` (rna_serial, protein_serial) -> ``x, edge_index, batch`` of the B enclosing subgraphs.
+        ``n_nodes`` / ``n_pairs``: the batch's totals when the caller already knows them (``sizes``): no device read."""
         lib = load()
         dev = self.device
         keys = keys.to(device=dev, dtype=torch.int32).contiguous()
@@ -71,8 +91,11 @@ class InteractionGraph:
         ws = torch.empty(max(2 * B, 1), **i32)
         check(lib.npi_subgraph_sizes(ptr(self.ptr), ptr(self.nbr), ptr(self.ok), ptr(keys), B, ptr(node_off), ptr(pair_off),
                                      ptr(ws), st), "npi_subgraph_sizes")
-        # output sizes are data dependent: one device read per batch
-        n, npairs = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
+        # output sizes are data dependent: one device read per batch, unless the caller knows them
+        if n_nodes is not None and n_pairs is not None:
+            n, npairs = int(n_nodes), int(n_pairs)
+        else:
+            n, npairs = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
         if n < 0:
             raise OverflowError("InteractionGraph.batch: the batch has more than 2^31 - 1 rows; use fewer keys per call")
         Ff = self.feat.size(1)

@@ -76,6 +76,30 @@ def test_topk_large_graph_and_ties(dev):
     assert torch.allclose(gx.cpu(), xo, atol=1e-6, rtol=1e-6)
 
 
+def test_topk_graph_beyond_the_lds_sort_capacity(dev):
+    """a graph with more than 16,384 nodes (a hub protein's one-hop subgraph at the C4 / C5 scale) used to
+    raise NotImplementedError; it now takes the device-wide sort with the same selection rule, forward and backward."""
+    g = torch.Generator().manual_seed(2)
+    n1, n2 = 20000, 50
+    x = torch.randn(n1 + n2, 16, generator=g)
+    x[500:520] = x[500]                                      # ties: lower index first
+    batch = torch.cat([torch.zeros(n1, dtype=torch.long), torch.ones(n2, dtype=torch.long)])
+    ei = torch.randint(0, n1 + n2, (2, 60000), generator=g)
+    w = torch.randn(1, 16, generator=g)
+    xo, eo, bo, perm, sc = R.topk_pool(x, ei, batch, w, 0.5)
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    gx, ge, _, gb, gperm, gsc = NP.topk_pool(xd, ei.to(dev), batch.to(dev), wd, 0.5)
+    assert gperm.numel() == 10000 + 25
+    assert torch.equal(gperm.cpu(), perm) and torch.equal(ge.cpu(), eo) and torch.equal(gb.cpu(), bo)
+    assert torch.allclose(gx.detach().cpu(), xo, atol=1e-6, rtol=1e-6)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    R.topk_pool(xr, ei, batch, wr, 0.5)[0].pow(2).sum().backward()
+    gx.pow(2).sum().backward()
+    assert torch.allclose(xd.grad.cpu(), xr.grad, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(wd.grad.cpu(), wr.grad, atol=1e-3 * float(wr.grad.abs().max()), rtol=1e-3)
+
+
 def _run_net1(dev, fx, n_graphs):
     model = Net1(fx["x"].size(1)).to(dev)
     model.load_state_dict({k: v.to(dev) for k, v in fx["state_dict"].items()})      # reference checkpoint, unchanged

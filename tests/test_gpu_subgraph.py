@@ -78,3 +78,27 @@ def test_extraction_rejects_bad_graphs(dev):
         InteractionGraph(torch.tensor([[0, 3], [0, 3]], device=dev), ok, feat)          # duplicate pair
     with pytest.raises(ValueError):
         InteractionGraph(torch.tensor([[0, 3], [3, 4]], device=dev), ok, feat)          # 3 is rna and protein
+
+
+def test_per_key_sizes_replace_the_per_batch_device_read(dev):
+    """InteractionGraph.sizes: one read for a whole key list; a batch built with the totals it implies is identical to one
+    that reads its sizes back (net1.KeyLoader uses this: no host sync per batch)."""
+    from npi_gnn_amd import net1
+    fx = torch.load(os.path.join(G, "rpi369_extract.pt"), map_location="cpu", weights_only=False)
+    ig = InteractionGraph(fx["pairs"].long().to(dev), fx["usable"].to(dev), fx["feat"].to(dev))
+    keys = fx["keys"].long().to(dev)
+    nodes, pairs = ig.sizes(keys)
+    assert nodes.device.type == "cpu" and nodes.numel() == keys.size(0)
+    for lo, hi in ((0, 148), (10, 11), (40, 100)):
+        x0, e0, b0 = ig.batch(keys[lo:hi])
+        assert int(nodes[lo:hi].sum()) == x0.size(0) and 2 * int(pairs[lo:hi].sum()) == e0.size(1)
+        x1, e1, b1 = ig.batch(keys[lo:hi], n_nodes=int(nodes[lo:hi].sum()), n_pairs=int(pairs[lo:hi].sum()))
+        assert torch.equal(x0, x1) and torch.equal(e0, e1) and torch.equal(b0, b1)
+    y = torch.zeros(keys.size(0), dtype=torch.long, device=dev)
+    loader = net1.KeyLoader(ig, keys, y, 64).shuffle(torch.Generator().manual_seed(1))
+    seen = 0
+    for data in loader:
+        xs, es, bs = ig.batch(loader.keys[seen:seen + 64])
+        assert torch.equal(data.x, xs) and torch.equal(data.edge_index, es)
+        seen += data.num_graphs
+    assert seen == 148
