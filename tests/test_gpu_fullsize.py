@@ -247,10 +247,14 @@ def test_c5_gat_forward_rows_against_fp64_formula(c5):
 
 
 def test_c5_gat_backward_against_fp64_formulas(c5):
-    """GATConv BACKWARD at the full C5 size: every output of the backward -- dX (all 4M rows), dW, datt,
-    db -- against the PyG-1.4.2 formulas evaluated in fp64 on the same GPU with plain torch ops over the 104M entries
-    (chunked: the per-entry gathers do not fit at once).  Covers edge_grad, both row-sum passes incl. the 2M-entry hub
-    rows, the alpha read-back through the transpose map, att-grad and the two GEMMs."""
+    """GATConv BACKWARD at the full C5 size: datt, db, dW and dX against the PyG-1.4.2 formulas
+    evaluated on the same GPU with plain torch ops over all 104M entries -- per-entry scalars, softmax statistics, dz,
+    g_dst and g_src in fp64 through SEGMENT reductions over the sorted CSR (no atomics: fp32 / fp64 index_add over the
+    2M-entry hub rows takes ten minutes); d h for all rows in fp32 (screens every one of the 4M rows of dX, gives dW),
+    and in fp64 for sampled rows incl. the hubs and the rows around the 4,096-entry wave / workgroup split.
+    Covers edge_grad, both row-sum passes, the alpha read-back through the transpose map, att-grad and the two GEMMs.
+    leaky_relu is not differentiable at 0: an entry whose pre-activation is within fp32 rounding of 0 may take either
+    slope (about ten of the 104M entries do); the rows such an entry touches are left out of the comparison."""
     ei, graph, x = c5
     dev = x.device
     g = torch.Generator().manual_seed(17)
@@ -262,64 +266,98 @@ def test_c5_gat_backward_against_fp64_formulas(c5):
     out = npi.gat_conv(xg, graph, W, att, b, heads=1)
     out.backward(go)
     got = {k: v.grad.detach() for k, v in (("dx", xg), ("dW", W), ("datt", att), ("db", b))}
-    out = out.detach()
+    out = out.detach()                                   # the forward is held to the fp64 formula by the test above
     xg.grad = None
+    CH = 4_000_000
+
+    def seg(v, rowptr, op="sum"):
+        return torch.segment_reduce(v, op, offsets=rowptr, axis=0)
+
     with torch.no_grad():
-        side = graph.by_dst
-        nnz = int(side.rowptr[-1])
-        row, col = side.rowidx[:nnz].long(), side.col[:nnz].long()         # entry p = (target row[p] <- source col[p]), loops incl.
         Wd = W.detach().double()
         a_d, a_s = att.detach().double().view(-1)[:F], att.detach().double().view(-1)[F:]
-        h = x.double() @ Wd                                                 # [N5, F] fp64
-        s_dst, s_src = h @ a_d, h @ a_s
-        pre = s_dst[row] + s_src[col]
-        z = torch.nn.functional.leaky_relu(pre, 0.2)
-        m = torch.full((N5,), -1e300, dtype=torch.float64, device=dev).scatter_reduce(0, row, z, "amax")
-        ez = torch.exp(z - m[row])
-        ssum = torch.zeros(N5, dtype=torch.float64, device=dev).index_add_(0, row, ez)
-        alpha = ez / (ssum[row] + 1e-16)
-        del ez, z
-        # the forward first (all rows), then D_i = <dOut_i, out_i - b>
-        ref_out = torch.zeros(N5, F, dtype=torch.float64, device=dev)
-        dot = torch.empty(nnz, dtype=torch.float64, device=dev)             # <dOut_i, h_j> per entry
-        CH = 4_000_000
-        for p0 in range(0, nnz, CH):
-            sl = slice(p0, min(p0 + CH, nnz))
-            hj = h[col[sl]]
-            ref_out.index_add_(0, row[sl], alpha[sl, None] * hj)
-            dot[sl] = (go[row[sl]].double() * hj).sum(1)
-            del hj
-        ref_out += b.detach().double()
-        scale = float(ref_out.abs().max())
-        assert float((out.double() - ref_out).abs().max()) < 1e-5 * max(scale, 1.0)
-        D = (go.double() * (ref_out - b.detach().double())).sum(1)
-        del ref_out
-        dz = alpha * (dot - D[row]) * torch.where(pre > 0, 1.0, 0.2)
-        del dot, pre
-        g_dst = torch.zeros(N5, dtype=torch.float64, device=dev).index_add_(0, row, dz)
-        g_src = torch.zeros(N5, dtype=torch.float64, device=dev).index_add_(0, col, dz)
+        h = x @ W.detach()                                               # fp32 copy for the gathers
+        h64 = x.double() @ Wd
+        s_dst, s_src = h64 @ a_d, h64 @ a_s
+        D = (go.double() * (out.double() - b.detach().double())).sum(1)
+        ambiguous = []
+
+        def per_entry(side, swap):
+            """(alpha, dz) in fp64 for the entries of `side`: rows are targets (swap False) or sources (swap True)"""
+            nnz = int(side.rowptr[-1])
+            r, c = side.rowidx[:nnz].long(), side.col[:nnz].long()
+            tgt, src = (c, r) if swap else (r, c)
+            pre = s_dst[tgt] + s_src[src]
+            amb = pre.abs() < 1e-5 * (s_dst[tgt].abs() + s_src[src].abs())
+            ambiguous.append(torch.cat([tgt[amb], src[amb]]))
+            z = torch.nn.functional.leaky_relu(pre, 0.2)
+            if not swap:
+                stats["m"] = seg(z, side.rowptr.long(), "max")
+                stats["s"] = seg(torch.exp(z - stats["m"][tgt]), side.rowptr.long())
+            alpha = torch.exp(z - stats["m"][tgt]) / (stats["s"][tgt] + 1e-16)
+            dot = torch.empty(nnz, dtype=torch.float64, device=dev)
+            for p0 in range(0, nnz, CH):
+                sl = slice(p0, min(p0 + CH, nnz))
+                dot[sl] = (go[tgt[sl]].double() * h[src[sl]].double()).sum(1)
+            dz = alpha * (dot - D[tgt]) * torch.where(pre > 0, 1.0, 0.2)
+            return alpha, dz, tgt
+        stats = {}
+        d, sr = graph.by_dst, graph.by_src
+        _, dz, _ = per_entry(d, False)
+        g_dst = seg(dz, d.rowptr.long())
         del dz
-        dh = g_dst[:, None] * a_d[None, :] + g_src[:, None] * a_s[None, :]
-        for p0 in range(0, nnz, CH):
-            sl = slice(p0, min(p0 + CH, nnz))
-            dh.index_add_(0, col[sl], alpha[sl, None] * go[row[sl]].double())
-        ref = {"datt": torch.cat([g_dst @ h, g_src @ h]).view(1, 1, 2 * F), "db": go.double().sum(0),
-               "dW": x.double().t() @ dh, "dx": dh @ Wd.t()}
-        del dh, h, alpha
+        alpha_s, dz, tgt_s = per_entry(sr, True)                         # the same entries seen from their sources
+        g_src = seg(dz, sr.rowptr.long())
+        del dz
+        amb_rows = torch.unique(torch.cat(ambiguous))
+        assert amb_rows.numel() < 1000
+        ref = {"datt": torch.cat([g_dst @ h64, g_src @ h64]).view(1, 1, 2 * F), "db": go.double().sum(0)}
+        # d h_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:], all rows, fp32 segment sums over by-source rows
+        dh = (g_dst[:, None] * a_d[None, :] + g_src[:, None] * a_s[None, :]).float()
+        rp = sr.rowptr.long().cpu()
+        r0 = 0
+        while r0 < N5:
+            r1 = int(torch.searchsorted(rp, rp[r0] + CH, right=True)) - 1
+            r1 = min(max(r1, r0 + 1), N5)
+            e0, e1 = int(rp[r0]), int(rp[r1])
+            contrib = alpha_s[e0:e1, None].float() * go[tgt_s[e0:e1]]
+            dh[r0:r1] += torch.segment_reduce(contrib, "sum", lengths=(rp[r0 + 1:r1 + 1] - rp[r0:r1]).to(dev), axis=0)
+            del contrib
+            r0 = r1
+        ref["dW"] = x.double().t() @ dh.double()
+        ref_dx = dh @ W.detach().t()
 
         def rel(a, r):
             return float((a.double() - r).abs().max() / r.abs().max())
-        # fp32 sums over up to 2M (rows) / 4M (dW, datt, db) terms against fp64: relative to the largest entry
         assert rel(got["db"], ref["db"]) < 1e-5
         assert rel(got["datt"], ref["datt"]) < 1e-4
-        assert rel(got["dW"], ref["dW"]) < 1e-4
-        err = (got["dx"].double() - ref["dx"]).abs().amax(1)
-        rows_scale = ref["dx"].abs().amax(1).clamp(min=float(ref["dx"].abs().mean()))
-        assert float((err / rows_scale).max()) < 1e-4                        # every one of the 4M rows, hubs included
-        deg = side.rowptr[1:].long() - side.rowptr[:-1].long()
-        hubs = torch.topk(deg, 4).indices
-        assert int(deg[hubs].min()) > 1_000_000                              # the 2M-entry rows are among them
-        assert float((err[hubs] / rows_scale[hubs]).max()) < 1e-5
+        assert rel(got["dW"], ref["dW"]) < 1e-3                            # the fp32 d h reference sets this bar
+        err = (got["dx"] - ref_dx).abs().amax(1)
+        scale = ref_dx.abs().amax(1).clamp(min=float(ref_dx.abs().mean()))
+        ratio = err / scale
+        ratio[amb_rows] = 0
+        deg_s = (sr.rowptr[1:] - sr.rowptr[:-1]).long()
+        # every one of the 4M rows; on rows above 10^4 entries the fp32 reference (one serial sum per row) is the less
+        # accurate side -- those are held to fp64 below
+        assert float(ratio[deg_s < 10_000].max()) < 1e-3
+        assert float(ratio[deg_s >= 10_000].max()) < 3e-2
+        # sampled rows in fp64
+        near = torch.argsort((deg_s - 4096).abs())[:4]
+        hubs = torch.topk(deg_s, 4).indices
+        assert int(deg_s[hubs].min()) > 1_000_000                          # the 2M-entry rows are among them
+        rows = torch.cat([torch.randint(0, N5, (256,), generator=g).to(dev), hubs, near])
+        is_amb = torch.zeros(N5, dtype=torch.bool, device=dev)
+        is_amb[amb_rows] = True
+        worst = 0.0
+        for j in rows[~is_amb[rows]].tolist():
+            e0, e1 = int(rp[j]), int(rp[j + 1])
+            dh_j = g_dst[j] * a_d + g_src[j] * a_s
+            for p0 in range(e0, e1, CH):
+                p1 = min(p0 + CH, e1)
+                dh_j = dh_j + alpha_s[p0:p1] @ go[tgt_s[p0:p1]].double()
+            truth = dh_j @ Wd.t()
+            worst = max(worst, float((got["dx"][j].double() - truth).abs().max() / truth.abs().max()))
+        assert worst < 2e-5, worst
 
 
 def test_c5_three_layer_gat_stack_chained(c5):
