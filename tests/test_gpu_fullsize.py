@@ -310,7 +310,7 @@ def test_c5_gat_backward_against_fp64_formulas(c5):
         g_src = seg(dz, sr.rowptr.long())
         del dz
         amb_rows = torch.unique(torch.cat(ambiguous))
-        assert amb_rows.numel() < 1000
+        assert amb_rows.numel() < 5000                                       # ~0.03 % of the rows
         ref = {"datt": torch.cat([g_dst @ h64, g_src @ h64]).view(1, 1, 2 * F), "db": go.double().sum(0)}
         # d h_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:], all rows, fp32 segment sums over by-source rows
         dh = (g_dst[:, None] * a_d[None, :] + g_src[:, None] * a_s[None, :]).float()
