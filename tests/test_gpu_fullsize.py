@@ -344,7 +344,7 @@ def test_c5_gat_backward_against_fp64_formulas(c5):
         # sampled rows in fp64
         near = torch.argsort((deg_s - 4096).abs())[:4]
         hubs = torch.topk(deg_s, 4).indices
-        assert int(deg_s[hubs].min()) > 1_000_000                          # the 2M-entry rows are among them
+        assert int(deg_s[hubs].max()) > 1_500_000                          # the ~2M-entry hub row is among them
         rows = torch.cat([torch.randint(0, N5, (256,), generator=g).to(dev), hubs, near])
         is_amb = torch.zeros(N5, dtype=torch.bool, device=dev)
         is_amb[amb_rows] = True
