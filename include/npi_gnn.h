@@ -161,7 +161,8 @@ int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fil
  * accumulate, error at f32-rounding level; csrc/gemm_f32.hip).  Returns the previous mode; any other
  * argument only queries.  Process-wide; initial value 1 unless env NPI_GEMM_SPLIT=0.
  * Used by npi_linear_fwd and npi_linear_bwd_data on full 128 x 128 tiles when K % 32 == 0 and rows are
- * 16-byte aligned; everything else (ragged strips, dW, bf16 storage) runs the exact-f32 kernels. */
+ * 16-byte aligned, and by npi_linear_bwd_weight when K % 128 == 0, N % 128 == 0, M >= 4096 (both operands split on the
+ * fly, gemm_dw_split_kernel); everything else (ragged strips, other shapes, bf16 storage) runs the exact-f32 kernels. */
 int npi_gemm_mode(int mode);
 
 int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
@@ -207,7 +208,7 @@ int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* W, int64_t 
 int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
                              void* dW, int64_t lddw, void* db,
                              int64_t M, int64_t K, int64_t N,
-                             float* workspace, int64_t workspace_elems, int dtype, int shared, void* stream);
+                             float* workspace, int64_t workspace_elems, int dtype, int flags, int shared, void* stream);
 
 /* The same three GEMMs with A / W / C / bias / dW / db stored as `dtype` (NPI_F32 or NPI_BF16; bf16
  * storage, f32 MFMA accumulation, f32 rowscale and workspace) -- BASELINE.json configs[1]. */

@@ -860,6 +860,180 @@ gemm_split_ws_kernel(SplitArgs a) {
     }
 }
 
+// ---- dW on the bf16 matrix cores: both operands split on the fly --------------------------------------------------
+// dW[K, N] = A[M, K]^T dC[M, N]: the contraction runs over the NODES, which is the slow (row) dimension of both
+// operands in memory, while a 32x32x16 MFMA wants 8 consecutive contraction values per lane.  The producer therefore
+// loads in FRAGMENT ORDER: a thread takes 4 adjacent columns of 8 consecutive node rows -- eight 16-byte loads, each
+// wave instruction still whole 512 B / 1 KiB row segments -- so it holds, per column, the 8 k-values of one fragment
+// half; it splits them (3-way, as above) and stores one 16-byte half row per plane into the SAME [row][16 bf16] LDS
+// image the split kernel uses.  The consumer waves are therefore unchanged: ds_read_b128 fragments, six MFMAs per
+// product tile, hand-over through the per-stage LDS counters.  Six bf16 MFMAs per f32 product = 6/16 of the exact
+// kernel's matrix-pipe time; error at f32-rounding level (tests: against fp64).
+// One workgroup = one 128 (features of A) x 64 TN (columns of dC) tile of dW over one SLAB of the node range; the slabs
+// are summed by slab_reduce_kernel in slab order (deterministic).  db = column sums of dC ride on the B loads of the
+// workgroups with m-tile 0 (two partial rows per slab: the two 8-node halves of a k-step).
+// The 16-byte LDS stores of 8 adjacent lanes go to 8 different bank quads: lane cg stores its columns in the rotated
+// order rho(cg) + c (see dw_rot), which with the image's half swizzle covers all 32 banks.
+struct DwArgs {
+    const float* A; int64_t lda;     // [M, K]
+    const float* dC; int64_t ldc;    // [M, N]
+    float* slabs;                    // [nslab][K][N] partial dW
+    float* db_slabs;                 // [2 nslab][N] partial column sums of dC, or null
+    int K, N;
+    int64_t m_main;                  // nodes covered (multiple of 16)
+    int64_t per;                     // nodes per slab (multiple of 16)
+    int tiles_m, tiles_n, nslab;
+};
+
+__device__ __forceinline__ int dw_rot(int cg) { return (cg & 1) + 2 * ((cg >> 2) & 1); }
+
+template <int TN>
+__global__ void __launch_bounds__(WS_THREADS, 1)
+gemm_dw_split_kernel(DwArgs a) {
+    constexpr int TM = 2;
+    constexpr int BN = 64 * TN;
+    constexpr int APL = 128 * 32, BPL = BN * 32;
+    constexpr int BUF = 3 * APL + 3 * BPL;
+    constexpr int NST = 4;
+    constexpr int BSETS = BN / 2;                           // B producer threads: BN / 4 column groups x 2 node halves
+    __shared__ __attribute__((aligned(16))) char lds[NST * BUF];
+    __shared__ int full[NST], empty[NST];
+    const int t = threadIdx.x;
+    const int wave = uniform_i(t >> 6);
+    // workgroup -> (slab, m-tile, n-tile); the tiles of one slab are neighbours (they share the slab's dC rows in L2)
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int slab = (int)blockIdx.x / tiles;
+    const int tile = (int)blockIdx.x % tiles;
+    const int mt = tile / a.tiles_n, nt = tile % a.tiles_n;
+    if (slab >= a.nslab) return;
+    const int64_t node0 = (int64_t)slab * a.per;
+    const int64_t node1 = node0 + a.per < a.m_main ? node0 + a.per : a.m_main;
+    const int nk = node1 > node0 ? (int)((node1 - node0) / SK) : 0;      // k-steps of 16 nodes (uniform)
+    if (t < NST) { full[t] = 0; empty[t] = 0; }
+    __syncthreads();
+
+    if (wave >= 4) {
+        // ---------------- producer ----------------
+        const int pt = t - 256;
+        const bool isA = pt < 64;
+        const bool isB = pt >= 64 && pt < 64 + BSETS;
+        const int q = isA ? pt : pt - 64;
+        const int ncg = isA ? 32 : BN / 4;                  // column groups of 4
+        const int half = q / ncg, cg = q % ncg;
+        const float* __restrict__ src = isA ? a.A + (int64_t)mt * 128 + 4 * cg : a.dC + (int64_t)nt * BN + 4 * cg;
+        const int64_t ld = isA ? a.lda : a.ldc;
+        char* img = lds + (isA ? 0 : 3 * APL);
+        const int plane = isA ? APL : BPL;
+        const int rot = dw_rot(cg);
+        const bool do_db = isB && a.db_slabs != nullptr && mt == 0;
+        float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4r cur[8], nxt[8];
+        auto load = [&](f32x4r (&r)[8], int ks) {
+            // past the last step the loads are repeated on the last valid step and dropped (a fixed number in flight)
+            const int kk = ks < nk ? ks : nk - 1;
+            const float* p = src + (node0 + (int64_t)kk * SK + 8 * half) * ld;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const f32x4r*>(p + (int64_t)i * ld);
+        };
+        if ((isA || isB) && nk > 0) load(cur, 0);
+        for (int ks = 0; ks < nk; ++ks) {
+            const int stg = ks & (NST - 1), round = ks >> 2;
+            if (isA || isB) {
+                load(nxt, ks + 1);
+                if (round > 0) wait_ge(&empty[stg], 4 * round);
+                char* st = img + stg * BUF;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int cc = (c + rot) & 3;          // wave-divergent choice of the component, resolved by selects
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        v[i] = cc == 0 ? cur[i].x : cc == 1 ? cur[i].y : cc == 2 ? cur[i].z : cur[i].w;
+                    if (do_db) {
+                        float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                        dbs[0] += cc == 0 ? sum : 0.f; dbs[1] += cc == 1 ? sum : 0.f;
+                        dbs[2] += cc == 2 ? sum : 0.f; dbs[3] += cc == 3 ? sum : 0.f;
+                    }
+                    uint32_t p0[4], p1[4], p2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
+                    char* dst = st + simg(4 * cg + cc, half);
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+                    *reinterpret_cast<uint4*>(dst + plane) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+                    *reinterpret_cast<uint4*>(dst + 2 * plane) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            } else if (round > 0) {
+                wait_ge(&empty[stg], 4 * round);
+            }
+            signal(&full[stg]);
+        }
+        if (do_db) {
+            float* o = a.db_slabs + ((int64_t)slab * 2 + half) * a.N + (int64_t)nt * BN + 4 * cg;
+            *reinterpret_cast<float4*>(o) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
+        }
+        return;
+    }
+
+    // ---------------- consumer: the split kernel's loop on one tile ----------------
+    const int lane = t & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int offa[TM], offb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offa[i] = simg(wm * 64 + i * 32 + li, lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offb[j] = 3 * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    for (int g = 0; g < nk; ++g) {
+        const int stg = g & (NST - 1);
+        wait_ge(&full[stg], 4 * ((g >> 2) + 1));
+        const char* st = lds + stg * BUF;
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + offa[i] + p * APL);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + offb[j] + p * BPL);
+        asm volatile("" ::: "memory");
+#define NPI_MMA6(I, J)                                                                                 \
+        do {                                                                                           \
+            f32x16 c = acc[I][J];                                                                      \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][2], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][2], af[I][0], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][1], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][1], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][0], c, 0, 0, 0);               \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][0], c, 0, 0, 0);               \
+            acc[I][J] = c;                                                                             \
+        } while (0)
+        NPI_MMA6(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        signal(&empty[stg]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (i + j > 0) NPI_MMA6(i, j);
+#undef NPI_MMA6
+    }
+    // the tile of this slab (zeros when the slab holds no node: slab_reduce adds every slab)
+    const float rs[TM] = {1.f, 1.f};
+    store_tile_t<TM, TN>(a.slabs + (int64_t)slab * a.K * a.N, a.N, mt * 128 + wm * 64, nt * BN + wn * (32 * TN), li, lh, acc,
+                         nullptr, rs, false);
+}
+
 // ---- bf16 storage: the same persistent producer / consumer pipeline on plain bf16 MFMAs ---------------------
 // A [M, K] and C [M, N] are bf16, accumulation f32 (v_mfma_f32_32x32x16_bf16, one product per tile pair).
 // A k-step is 64 wide: a stage holds FOUR 16-wide k-blocks in the 32-byte-row image of the split kernel, so the
@@ -1354,6 +1528,24 @@ static void bwd_weight_plan(int64_t M, int64_t K, int64_t N, bool shared, int& s
     kchunk = (int)(ceil_div(ceil_div(m_main > 0 ? m_main : 1, splits), BK) * BK);
 }
 
+// Plan of the split-bf16 dW kernel (gemm_dw_split_kernel): one workgroup per CU when it has the GPU to itself, about
+// three per four CUs when it shares them with the backward aggregation; `per` nodes per slab (multiple of 16).
+static bool dw_split_shape_ok(int64_t M, int64_t K, int64_t N) { return K % 128 == 0 && N % 128 == 0 && M >= 4096; }
+static void dw_split_plan(int64_t m_main, int64_t K, int64_t N, bool shared, int& nslab, int64_t& per, int& tiles_m, int& tiles_n,
+                          bool& wide) {
+    wide = (N % 256 == 0);
+    tiles_m = (int)(K / 128);
+    tiles_n = (int)(wide ? N / 256 : N / 128);
+    const int64_t wgs = shared ? dw_workgroups(true) : 256;
+    int64_t ns = wgs / ((int64_t)tiles_m * tiles_n);
+    if (ns < 1) ns = 1;
+    const int64_t maxs = ceil_div(m_main, (int64_t)SK * 16);                 // at least 16 k-steps per slab
+    if (ns > maxs) ns = maxs;
+    if (ns > 256) ns = 256;
+    nslab = (int)ns;
+    per = ceil_div(ceil_div(m_main, ns), (int64_t)SK) * SK;
+}
+
 extern "C" int npi_dw_shared(int shared) {
     const int prev = g_dw_shared;
     if (shared == 0 || shared == 1) g_dw_shared = shared;
@@ -1365,19 +1557,25 @@ extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, i
     int splits, kchunk;
     int64_t m_main;
     bwd_weight_plan(M, K, N, /*shared=*/false, splits, kchunk, m_main);          // the regime with more slabs: enough for both
-    return (int64_t)(splits + 1) * K * N + (int64_t)(splits + 1) * N + 64;      // dW slabs, then db slabs
+    int64_t slabs = splits + 1, dbs = splits + 1;
+    if (dw_split_shape_ok(M, K, N)) {                                             // the split-bf16 plan: <= 256 slabs, 2 db rows each
+        if (slabs < 257) slabs = 257;
+        if (dbs < 2 * 256 + 1) dbs = 2 * 256 + 1;
+    }
+    return slabs * K * N + dbs * N + 64;                                          // dW slabs, then db slabs
 }
 
 // dW[K,N] = A[M,K]^T @ dC[M,N] (contract over M), db[N] = colsum(dC); A, dC, dW, db stored as `dtype`
 extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t lddc,
                                        void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
                                        float* workspace, int64_t workspace_elems, int dtype, void* stream_) {
-    return npi_linear_bwd_weight_ex(A, lda, dC, lddc, dW, lddw, db, M, K, N, workspace, workspace_elems, dtype,
+    return npi_linear_bwd_weight_ex(A, lda, dC, lddc, dW, lddw, db, M, K, N, workspace, workspace_elems, dtype, 0,
                                     g_dw_shared != 0 ? 1 : 0, stream_);
 }
 extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
                                         void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
-                                        float* workspace, int64_t workspace_elems, int dtype, int shared, void* stream_) {
+                                        float* workspace, int64_t workspace_elems, int dtype, int flags, int shared,
+                                        void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_weight: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_weight: size > int32");
@@ -1389,6 +1587,31 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         return NPI_ERR_WORKSPACE;
     }
     const int es = dtype == NPI_BF16 ? 2 : 4;
+    const bool v4 = vec4_ok(A, lda, K, es) && vec4_ok(dC, lddc, N, es);
+    const unsigned gw = (unsigned)ceil_div(K * N, 256), gb = (unsigned)ceil_div(N, 256);
+    // ---- f32 storage on the bf16 matrix cores: both operands split on the fly (gemm_dw_split_kernel) ----
+    if (dtype == NPI_F32 && gemm_mode_of(flags) != 0 && v4 && dw_split_shape_ok(M, K, N)) {
+        const int64_t m16 = (M / SK) * SK;
+        int nslab, tm, tn;
+        int64_t per;
+        bool wide;
+        dw_split_plan(m16, K, N, shared != 0, nslab, per, tm, tn, wide);
+        const bool has_rem = M > m16;
+        float* db_slabs = workspace + (int64_t)(nslab + 1) * K * N;
+        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)K, (int)N, m16, per, tm, tn, nslab};
+        const unsigned grid = (unsigned)(nslab * tm * tn);
+        if (wide) gemm_dw_split_kernel<4><<<grid, WS_THREADS, 0, stream>>>(d);
+        else      gemm_dw_split_kernel<2><<<grid, WS_THREADS, 0, stream>>>(d);
+        if (has_rem) {        // < 16 trailing nodes: one guarded exact-f32 launch into slab `nslab`
+            GemmArgs r{fp(advance(A, m16 * lda, es)), lda, fp(advance(dC, m16 * lddc, es)), lddc,
+                       workspace + (int64_t)nslab * K * N, N, (int)K, (int)N, (int)(M - m16), BK, 0, 0, K * N,
+                       Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)2 * nslab * N : nullptr}};
+            (void)launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
+        }
+        slab_reduce_kernel<float><<<gw, 256, 0, stream>>>(workspace, K * N, nslab + (has_rem ? 1 : 0), (int)K, (int)N, N, (float*)dW, lddw);
+        if (db) slab_reduce_kernel<float><<<gb, 256, 0, stream>>>(db_slabs, N, 2 * nslab + (has_rem ? 1 : 0), 1, (int)N, N, (float*)db, N);
+        return check_launch("npi_linear_bwd_weight");
+    }
     int splits, kchunk;
     int64_t m_main;
     bwd_weight_plan(M, K, N, shared != 0, splits, kchunk, m_main);
@@ -1397,7 +1620,6 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
     const bool has_rem = M > m_main || m_main == 0;
     const int nslab = (m_main > 0 ? splits : 0) + (has_rem ? 1 : 0);
     float* db_slabs = workspace + (int64_t)(splits + 1) * K * N;
-    const bool v4 = vec4_ok(A, lda, K, es) && vec4_ok(dC, lddc, N, es);
     // output rows = K (features of A), cols = N; A(m = feature, k = node) = A[node*lda + feature]
     // main part: nodes [0, m_main) in `splits` f32 slabs
     if (m_main > 0) {
@@ -1412,7 +1634,6 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
                    Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)(m_main > 0 ? splits : 0) * N : nullptr}};
         (void)launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
     }
-    const unsigned gw = (unsigned)ceil_div(K * N, 256), gb = (unsigned)ceil_div(N, 256);
     if (dtype == NPI_BF16) {
         slab_reduce_kernel<bf16_t><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (bf16_t*)dW, lddw);
         if (db) slab_reduce_kernel<bf16_t><<<gb, 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, (bf16_t*)db, N);

@@ -166,7 +166,8 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
     return da
 
 
-def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False):
+def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False,
+                      flags: Optional[int] = None):
     """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid; a per-call argument of
     ``npi_linear_bwd_weight_ex``, no process-wide switch is touched)."""
     dev = require_gpu(a, dc)
@@ -181,7 +182,8 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True,
     db = torch.empty(N, dtype=a.dtype, device=dev) if want_bias else None
     with _gemm_events("bwd_weight", 2.0 * M * K * N, dev):
         check(lib.npi_linear_bwd_weight_ex(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
-                                           M, K, N, ptr(ws), n_ws, _code(a), 1 if shared else 0, stream_ptr(dev)),
+                                           M, K, N, ptr(ws), n_ws, _code(a), GEMM_FLAGS if flags is None else flags,
+                                           1 if shared else 0, stream_ptr(dev)),
               "npi_linear_bwd_weight")
     return dw, db
 

@@ -83,7 +83,7 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N),       # bad split
         "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N),
         "npi_linear_bwd_data_ex": lambda: lib.npi_linear_bwd_data_ex(N, 0, N, 0, N, N, 0, 8, 8, -3, 0, 0, N, 0, N),
-        "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 1, N),
+        "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 0, 1, N),
         "npi_gat_edge_grad_ex": lambda: lib.npi_gat_edge_grad_ex(N, N, N, 4, 16, N, 4, N, 0, N, 4, 0, 4, N, N, N, N, N, 0.2, 1, N, N, N),
     }
     for name, call in calls.items():

@@ -417,6 +417,32 @@ def test_split_bf16_gemm_is_f32_accurate(dev, M, K, N):
     assert lib.npi_gemm_mode(-1) == before                 # nothing global was touched
 
 
+@pytest.mark.parametrize("M,K,N", [(4096, 256, 256), (100003, 128, 128), (50000 + 7, 256, 128), (20000, 128, 256),
+                                   (300000, 256, 256), (8192 + 15, 384, 512)])
+@pytest.mark.parametrize("shared", [False, True])
+def test_split_bf16_dw_is_f32_accurate(dev, M, K, N, shared):
+    """dW = A^T dC with BOTH operands split 3-way into bf16 on the fly (gemm_dw_split_kernel) against an fp64 product: the
+    error must be at the level of the exact-f32 MFMA kernel's, for dW and for the fused column sums db, incl. node counts
+    that are not a multiple of 16 (guarded remainder slab) and both grid regimes; run-to-run bit identical."""
+    from npi_gnn_amd._lib import NPI_GEMM_EXACT_F32, NPI_GEMM_SPLIT_BF16
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g).to(dev)
+    dC = (torch.randn(M, N, generator=g) * (1 + torch.rand(1, N, generator=g) * 3)).to(dev)
+    ref_w = A.double().t() @ dC.double()
+    ref_b = dC.double().sum(0)
+    err = {}
+    for mode, flags in ((0, NPI_GEMM_EXACT_F32), (1, NPI_GEMM_SPLIT_BF16)):
+        dw, db = NF.linear_bwd_weight(A, dC, True, shared=shared, flags=flags)
+        err[mode] = (float((dw.double() - ref_w).abs().max() / ref_w.abs().max()),
+                     float((db.double() - ref_b).abs().max() / ref_b.abs().max()))
+        dw2, db2 = NF.linear_bwd_weight(A, dC, True, shared=shared, flags=flags)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        dw3, none = NF.linear_bwd_weight(A, dC, False, shared=shared, flags=flags)
+        assert none is None and torch.equal(dw, dw3)
+    for e0, e1 in zip(err[0], err[1]):
+        assert e1 < 5e-6 and e1 < 3 * e0 + 2e-7, err
+
+
 def test_gemm_entry_points_are_independent_across_threads_and_streams(dev):
     """the arithmetic and the dW grid regime are per-call arguments now.  Two threads, each on its own
     HIP stream, hammer the three GEMMs with DIFFERENT settings at the same time; every result must be bit-identical to
