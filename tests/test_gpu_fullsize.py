@@ -349,6 +349,7 @@ def test_c5_gat_backward_against_fp64_formulas(c5):
         is_amb = torch.zeros(N5, dtype=torch.bool, device=dev)
         is_amb[amb_rows] = True
         worst = 0.0
+        floor = float(ref_dx.abs().mean())                                 # rows whose dX nearly cancels: absolute bar
         for j in rows[~is_amb[rows]].tolist():
             e0, e1 = int(rp[j]), int(rp[j + 1])
             dh_j = g_dst[j] * a_d + g_src[j] * a_s
@@ -356,7 +357,7 @@ def test_c5_gat_backward_against_fp64_formulas(c5):
                 p1 = min(p0 + CH, e1)
                 dh_j = dh_j + alpha_s[p0:p1] @ go[tgt_s[p0:p1]].double()
             truth = dh_j @ Wd.t()
-            worst = max(worst, float((got["dx"][j].double() - truth).abs().max() / truth.abs().max()))
+            worst = max(worst, float((got["dx"][j].double() - truth).abs().max() / truth.abs().max().clamp(min=floor)))
         assert worst < 2e-5, worst
 
 
