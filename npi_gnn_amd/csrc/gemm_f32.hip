@@ -901,9 +901,12 @@ gemm_dw_split_kernel(DwArgs a) {
     const int t = threadIdx.x;
     const int wave = uniform_i(t >> 6);
     // workgroup -> (slab, m-tile, n-tile); the tiles of one slab are neighbours (they share the slab's dC rows in L2)
+    // blockIdx -> XCD is round-robin (b % 8): the tiles of one slab take slots 8 apart, i.e. the SAME XCD, so the slab's
+    // dC rows (read by every m-tile) and A rows (read by every n-tile) are fetched into that XCD's L2 once
     const int tiles = a.tiles_m * a.tiles_n;
-    const int slab = (int)blockIdx.x / tiles;
-    const int tile = (int)blockIdx.x % tiles;
+    const int b = (int)blockIdx.x;
+    const int slab = (b / (8 * tiles)) * 8 + (b & 7);
+    const int tile = (b >> 3) % tiles;
     const int mt = tile / a.tiles_n, nt = tile % a.tiles_n;
     if (slab >= a.nslab) return;
     const int64_t node0 = (int64_t)slab * a.per;
@@ -920,55 +923,90 @@ gemm_dw_split_kernel(DwArgs a) {
         const int q = isA ? pt : pt - 64;
         const int ncg = isA ? 32 : BN / 4;                  // column groups of 4
         const int half = q / ncg, cg = q % ncg;
-        const float* __restrict__ src = isA ? a.A + (int64_t)mt * 128 + 4 * cg : a.dC + (int64_t)nt * BN + 4 * cg;
         const int64_t ld = isA ? a.lda : a.ldc;
         char* img = lds + (isA ? 0 : 3 * APL);
         const int plane = isA ? APL : BPL;
         const int rot = dw_rot(cg);
         const bool do_db = isB && a.db_slabs != nullptr && mt == 0;
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
-        f32x4r cur[8], nxt[8];
-        auto load = [&](f32x4r (&r)[8], int ks) {
-            // past the last step the loads are repeated on the last valid step and dropped (a fixed number in flight)
-            const int kk = ks < nk ? ks : nk - 1;
-            const float* p = src + (node0 + (int64_t)kk * SK + 8 * half) * ld;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const f32x4r*>(p + (int64_t)i * ld);
-        };
-        if ((isA || isB) && nk > 0) load(cur, 0);
-        for (int ks = 0; ks < nk; ++ks) {
+        // Three register sets: two k-steps of loads (16 x 16 B per thread) stay in flight while the third is split and
+        // stored -- with one set ahead the kernel was latency-bound (2.1 us per k-step, 2.9 TB/s).  As in the split kernel
+        // above the loads and their waits are written in assembly: hipcc's own vmcnt bookkeeping drains the ring at the
+        // hand-over spin loop and at the loop back-edge (it waited vmcnt(0..7) with 24 loads meant to be in flight).
+        // global_load dst, v_off, s[base]: wave-uniform row base (one per node row), fixed per-thread byte offset.
+        const char* srcb = reinterpret_cast<const char*>(isA ? a.A + (int64_t)mt * 128 : a.dC + (int64_t)nt * BN);
+        const int64_t ldb = ld * 4;                                   // row pitch in bytes
+        const uint32_t voff = (uint32_t)(((int64_t)8 * half * ld + 4 * cg) * 4);
+        const bool active = isA || isB;
+#define DW_GL(dst, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#define DW_DECL(S) f32x4r S##0, S##1, S##2, S##3, S##4, S##5, S##6, S##7
+#define DW_LOAD(S, KS)                                                                                 \
+    do {                                                                                               \
+        const int kk_ = (KS) < nk ? (KS) : nk - 1;   /* past the end: reload the last step, dropped */ \
+        const char* g_ = srcb + (node0 + (int64_t)kk_ * SK) * ldb;                                     \
+        DW_GL(S##0, uniform_ptr(g_));           DW_GL(S##1, uniform_ptr(g_ + ldb));                    \
+        DW_GL(S##2, uniform_ptr(g_ + 2 * ldb)); DW_GL(S##3, uniform_ptr(g_ + 3 * ldb));                \
+        DW_GL(S##4, uniform_ptr(g_ + 4 * ldb)); DW_GL(S##5, uniform_ptr(g_ + 5 * ldb));                \
+        DW_GL(S##6, uniform_ptr(g_ + 6 * ldb)); DW_GL(S##7, uniform_ptr(g_ + 7 * ldb));                \
+    } while (0)
+        // the set is an in/out operand of the wait, so that no use of it can be scheduled above the wait
+#define DW_WAIT16(S)                                                                                   \
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(S##0), "+v"(S##1), "+v"(S##2), "+v"(S##3), "+v"(S##4), "+v"(S##5), \
+                     "+v"(S##6), "+v"(S##7) : : "memory")
+        auto process = [&](int ks, f32x4r c0, f32x4r c1, f32x4r c2, f32x4r c3, f32x4r c4, f32x4r c5, f32x4r c6, f32x4r c7) {
             const int stg = ks & (NST - 1), round = ks >> 2;
-            if (isA || isB) {
-                load(nxt, ks + 1);
-                if (round > 0) wait_ge(&empty[stg], 4 * round);
-                char* st = img + stg * BUF;
+            if (round > 0) wait_ge(&empty[stg], 4 * round);
+            char* st = img + stg * BUF;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int cc = (c + rot) & 3;          // wave-divergent choice of the component, resolved by selects
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        v[i] = cc == 0 ? cur[i].x : cc == 1 ? cur[i].y : cc == 2 ? cur[i].z : cur[i].w;
-                    if (do_db) {
-                        float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                        dbs[0] += cc == 0 ? sum : 0.f; dbs[1] += cc == 1 ? sum : 0.f;
-                        dbs[2] += cc == 2 ? sum : 0.f; dbs[3] += cc == 3 ? sum : 0.f;
-                    }
-                    uint32_t p0[4], p1[4], p2[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
-                    char* dst = st + simg(4 * cg + cc, half);
-                    *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
-                    *reinterpret_cast<uint4*>(dst + plane) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
-                    *reinterpret_cast<uint4*>(dst + 2 * plane) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+            for (int c = 0; c < 4; ++c) {
+                const int cc = (c + rot) & 3;              // lane-dependent choice of the component, resolved by selects
+                auto pick = [&](const f32x4r& r) { return cc == 0 ? r.x : cc == 1 ? r.y : cc == 2 ? r.z : r.w; };
+                const float v[8] = {pick(c0), pick(c1), pick(c2), pick(c3), pick(c4), pick(c5), pick(c6), pick(c7)};
+                if (do_db) {
+                    float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    dbs[0] += cc == 0 ? sum : 0.f; dbs[1] += cc == 1 ? sum : 0.f;
+                    dbs[2] += cc == 2 ? sum : 0.f; dbs[3] += cc == 3 ? sum : 0.f;
                 }
+                uint32_t p0[4], p1[4], p2[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-            } else if (round > 0) {
-                wait_ge(&empty[stg], 4 * round);
+                for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
+                char* dst = st + simg(4 * cg + cc, half);
+                *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+                *reinterpret_cast<uint4*>(dst + plane) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+                *reinterpret_cast<uint4*>(dst + 2 * plane) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
             }
             signal(&full[stg]);
+        };
+        if (active && nk > 0) {                                // wave-uniform
+            DW_DECL(ra); DW_DECL(rb); DW_DECL(rc);
+            DW_LOAD(ra, 0);
+            DW_LOAD(rb, 1);
+            for (int ks = 0; ks < nk; ks += 3) {
+                DW_LOAD(rc, ks + 2);
+                DW_WAIT16(ra);
+                process(ks, ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7);
+                if (ks + 1 >= nk) break;
+                DW_LOAD(ra, ks + 3);
+                DW_WAIT16(rb);
+                process(ks + 1, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7);
+                if (ks + 2 >= nk) break;
+                DW_LOAD(rb, ks + 4);
+                DW_WAIT16(rc);
+                process(ks + 2, rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dropped tail loads land before the registers are reused
+        } else {
+            // a producer wave without a share of this tile shape only keeps the hand-over counters in step
+            for (int ks = 0; ks < nk; ++ks) {
+                const int stg = ks & (NST - 1), round = ks >> 2;
+                if (round > 0) wait_ge(&empty[stg], 4 * round);
+                signal(&full[stg]);
+            }
         }
+#undef DW_GL
+#undef DW_DECL
+#undef DW_LOAD
+#undef DW_WAIT16
         if (do_db) {
             float* o = a.db_slabs + ((int64_t)slab * 2 + half) * a.N + (int64_t)nt * BN + 4 * cg;
             *reinterpret_cast<float4*>(o) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
@@ -1599,7 +1637,7 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         const bool has_rem = M > m16;
         float* db_slabs = workspace + (int64_t)(nslab + 1) * K * N;
         DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)K, (int)N, m16, per, tm, tn, nslab};
-        const unsigned grid = (unsigned)(nslab * tm * tn);
+        const unsigned grid = (unsigned)(ceil_div(nslab, 8) * 8 * tm * tn);     // slots of 8 slabs (one per XCD) x tiles
         if (wide) gemm_dw_split_kernel<4><<<grid, WS_THREADS, 0, stream>>>(d);
         else      gemm_dw_split_kernel<2><<<grid, WS_THREADS, 0, stream>>>(d);
         if (has_rem) {        // < 16 trailing nodes: one guarded exact-f32 launch into slab `nslab`
