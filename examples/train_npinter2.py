@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fold", type=int, default=0, choices=[0, 1])
     ap.add_argument("--no-train-eval", action="store_true", help="skip the metrics on the training loader")
+    ap.add_argument("--capture", action="store_true",
+                    help="replay every batch's training step from a HIP graph after the first epoch (net1.GraphedEpoch)")
     ap.add_argument("--json", action="store_true", help="print a one-line JSON summary at the end")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -58,7 +60,8 @@ def main():
     print('number of samples in testing dataset：', len(test_loader.dataset), 'number of samples in training dataset：',
           len(train_loader.dataset))
     model = net1.Net_1(F_in, 2).to(dev)
-    res = net1.fit(model, train_loader, test_loader, dev, num_of_epoch=a.epochs, eval_train=not a.no_train_eval)
+    res = net1.fit(model, train_loader, test_loader, dev, num_of_epoch=a.epochs, eval_train=not a.no_train_eval,
+                   capture=a.capture)
     ref = fx["fold0"]
     lo, hi = min(ref["logged_test_acc_5fold_epoch50"]), max(ref["logged_test_acc_5fold_epoch50"])
     print(f"reference (result/1223_1/log_*.txt): {ref['logged_wall_seconds']:.1f} s for fold 0, test accuracy at epoch 50 "
@@ -66,7 +69,7 @@ def main():
           f"lr stepped {res['lr_steps']} times")
     if a.json:
         print(json.dumps({"seconds": res["seconds"], "test_acc": res["test"][0], "test_mcc": res["test"][4],
-                          "epochs": a.epochs, "lr_steps": res["lr_steps"], "reference_seconds": ref["logged_wall_seconds"],
+                          "epochs": a.epochs, "captured": a.capture, "lr_steps": res["lr_steps"], "reference_seconds": ref["logged_wall_seconds"],
                           "reference_acc_range": [lo, hi]}))
 
 

@@ -62,7 +62,8 @@ int npi_abi_version(void);
  *                                val = edge_index[0].  CSR-by-source (transpose, for backward):
  *                                swap them.
  *   Columns with key == val (existing self loops) and columns with an id outside [0,N) are
- *   dropped; the latter also set bit 0 of status[0].
+ *   dropped; the latter also set bit 0 of status[0] -- except the padding column (-1, -1) of
+ *   npi_filter_adj_ex, which is dropped silently.
  *   add_self_loops != 0 appends (i,i) as the LAST entry of every row.
  *
  *   rowptr[N+1]  : int32, rowptr[N] = nnz (device-side; nnz <= E + N)
@@ -316,6 +317,13 @@ int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64
 int64_t npi_filter_adj_workspace_elems(int64_t E);
 int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                    int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, void* stream);
+/* npi_filter_adj with the output kept at the INPUT's length: pad_tail != 0 fills out_src / out_dst[count .. E) with -1.
+ * A (-1, -1) column is padding everywhere downstream -- npi_csr_build drops it without raising the out-of-range flag,
+ * npi_filter_adj skips it -- so a caller that knows the node counts (TopKPooling keeps ceil(ratio n_g) per graph) never
+ * has to read the surviving-edge count back and the whole Net_1 step runs without a host synchronisation (and captures
+ * into a HIP graph).  Negative ids in src / dst are always treated as dropped.  Output arrays must not alias the input. */
+int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
+                      int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, int pad_tail, void* stream);
 int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
                          float* out, void* stream);
 

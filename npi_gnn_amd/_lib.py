@@ -76,6 +76,7 @@ PROTOTYPES = {
     "npi_topk_gather": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "npi_filter_adj_workspace_elems": (_I, [_I]),
     "npi_filter_adj": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "npi_filter_adj_ex": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, c_int, _P]),
     "npi_readout_max_mean": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_topk_gather_bwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "npi_topk_weight_grad_workspace_elems": (_I, [_I, _I]),

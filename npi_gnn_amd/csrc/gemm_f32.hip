@@ -934,20 +934,23 @@ gemm_dw_split_kernel(DwArgs a) {
         // above the loads and their waits are written in assembly: hipcc's own vmcnt bookkeeping drains the ring at the
         // hand-over spin loop and at the loop back-edge (it waited vmcnt(0..7) with 24 loads meant to be in flight).
         // global_load dst, v_off, s[base]: wave-uniform row base (one per node row), fixed per-thread byte offset.
-        const char* srcb = reinterpret_cast<const char*>(isA ? a.A + (int64_t)mt * 128 : a.dC + (int64_t)nt * BN);
-        const int64_t ldb = ld * 4;                                   // row pitch in bytes
+        // (wave-uniform values are forced into SGPRs, so that the row bases below are scalar arithmetic: a base produced
+        // by VALU + v_readfirstlane right in front of the load that reads it violates the VALU-writes-SGPR -> VMEM-reads
+        // hazard -- 5 wait states -- which hipcc does not pad for an inline-asm consumer: a memory fault in the first build)
+        const char* srcb = uniform_ptr(reinterpret_cast<const char*>(isA ? a.A + (int64_t)mt * 128 : a.dC + (int64_t)nt * BN));
+        const int64_t ldb = ((int64_t)uniform_i((int)(ld >> 32)) << 32 | (uint32_t)uniform_i((int)(ld & 0xffffffff))) * 4;   // row pitch in bytes
         const uint32_t voff = (uint32_t)(((int64_t)8 * half * ld + 4 * cg) * 4);
         const bool active = isA || isB;
-#define DW_GL(dst, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#define DW_GL(dst, base) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define DW_DECL(S) f32x4r S##0, S##1, S##2, S##3, S##4, S##5, S##6, S##7
 #define DW_LOAD(S, KS)                                                                                 \
     do {                                                                                               \
         const int kk_ = (KS) < nk ? (KS) : nk - 1;   /* past the end: reload the last step, dropped */ \
         const char* g_ = srcb + (node0 + (int64_t)kk_ * SK) * ldb;                                     \
-        DW_GL(S##0, uniform_ptr(g_));           DW_GL(S##1, uniform_ptr(g_ + ldb));                    \
-        DW_GL(S##2, uniform_ptr(g_ + 2 * ldb)); DW_GL(S##3, uniform_ptr(g_ + 3 * ldb));                \
-        DW_GL(S##4, uniform_ptr(g_ + 4 * ldb)); DW_GL(S##5, uniform_ptr(g_ + 5 * ldb));                \
-        DW_GL(S##6, uniform_ptr(g_ + 6 * ldb)); DW_GL(S##7, uniform_ptr(g_ + 7 * ldb));                \
+        DW_GL(S##0, g_);           DW_GL(S##1, g_ + ldb);                                              \
+        DW_GL(S##2, g_ + 2 * ldb); DW_GL(S##3, g_ + 3 * ldb);                                          \
+        DW_GL(S##4, g_ + 4 * ldb); DW_GL(S##5, g_ + 5 * ldb);                                          \
+        DW_GL(S##6, g_ + 6 * ldb); DW_GL(S##7, g_ + 7 * ldb);                                          \
     } while (0)
         // the set is an in/out operand of the wait, so that no use of it can be scheduled above the wait
 #define DW_WAIT16(S)                                                                                   \

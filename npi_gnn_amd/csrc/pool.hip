@@ -147,7 +147,8 @@ topk_gather_kernel(const float* __restrict__ x, int64_t ldx, const float* __rest
 constexpr int FA_TILE = 2048;      // edges per workgroup (256 threads x 8)
 __global__ void __launch_bounds__(256)
 filter_flag_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E,
-                   const int32_t* __restrict__ remap, int32_t* __restrict__ tile_counts) {
+                   const int32_t* __restrict__ remap, int32_t* __restrict__ tile_counts,
+                   int64_t* __restrict__ pad_src, int64_t* __restrict__ pad_dst) {
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
@@ -155,7 +156,11 @@ filter_flag_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ 
     const int64_t base = (int64_t)blockIdx.x * FA_TILE;
     for (int j = 0; j < 8; ++j) {
         const int64_t e = base + j * 256 + threadIdx.x;
-        if (e < E) c += (remap[src[e]] >= 0 && remap[dst[e]] >= 0) ? 1 : 0;
+        if (e < E) {
+            const int64_t s0 = src[e], d0 = dst[e];              // negative ids: padding columns of an earlier filter
+            c += (s0 >= 0 && d0 >= 0 && remap[s0] >= 0 && remap[d0] >= 0) ? 1 : 0;
+            if (pad_src != nullptr) { pad_src[e] = -1; pad_dst[e] = -1; }   // filter_write overwrites the first `count`
+        }
     }
     c = (int)wsum((float)c);          // <= 512 per wave: exact in f32
     if (lane_id() == 0) atomicAdd(&cnt, c);
@@ -200,9 +205,12 @@ filter_write_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__
         const int64_t e = wbase + j * 64 + lane;
         keep[j] = false;
         if (e < E) {
-            const int rs = remap[src[e]], rd = remap[dst[e]];
-            keep[j] = rs >= 0 && rd >= 0;
-            s[j] = rs; d[j] = rd;
+            const int64_t s0 = src[e], d0 = dst[e];
+            if (s0 >= 0 && d0 >= 0) {
+                const int rs = remap[s0], rd = remap[d0];
+                keep[j] = rs >= 0 && rd >= 0;
+                s[j] = rs; d[j] = rd;
+            }
         }
         c += __popcll(__ballot(keep[j]));
     }
@@ -566,13 +574,21 @@ extern "C" int64_t npi_filter_adj_workspace_elems(int64_t E) { return ceil_div(E
 extern "C" int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                               int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace,
                               void* stream_) {
+    return npi_filter_adj_ex(src, dst, E, remap, out_src, out_dst, count, workspace, 0, stream_);
+}
+
+extern "C" int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
+                                 int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace,
+                                 int pad_tail, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(E >= 0 && E < 0x7fffffff, "npi_filter_adj: bad size");
     NPI_REQUIRE(count && workspace, "npi_filter_adj: null pointer");
     if (E == 0) { (void)hipMemsetAsync(count, 0, sizeof(int32_t), stream); return check_launch("npi_filter_adj"); }
     NPI_REQUIRE(src && dst && remap && out_src && out_dst, "npi_filter_adj: null pointer");
+    NPI_REQUIRE(!pad_tail || (out_src != src && out_dst != dst), "npi_filter_adj_ex: pad_tail needs separate output arrays");
     const int ntiles = (int)ceil_div(E, FA_TILE);
-    filter_flag_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace);
+    filter_flag_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, pad_tail ? out_src : nullptr,
+                                                   pad_tail ? out_dst : nullptr);
     scan_small_kernel<<<1, 256, 0, stream>>>(workspace, ntiles, count);
     filter_write_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, out_src, out_dst);
     return check_launch("npi_filter_adj");

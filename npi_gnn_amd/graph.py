@@ -117,7 +117,9 @@ def build_side(key: torch.Tensor, val: torch.Tensor, n_rows: int, n_cols: int, s
                                int(loop_col_offset), 1 if drop_equal else 0, ptr(rowptr), ptr(col), ptr(eid),
                                ptr(rowidx), ptr(item_row), ptr(status), ptr(ws), ws_bytes, stream_ptr(dev)),
           "npi_csr_build_ex")
-    if _DEBUG:
+    if torch.cuda.is_current_stream_capturing():
+        pass                                  # inside a HIP-graph capture: no reads, and the word lives in the graph's pool
+    elif _DEBUG:
         raise_on_status([status.item()])
     else:
         _PENDING.append(status)

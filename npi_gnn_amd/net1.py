@@ -24,8 +24,9 @@ class Net_1(torch.nn.Module):
     ``[global_max_pool || global_mean_pool]`` readout after each summed, then the 256-128-64-2 MLP with
     dropout 0.5 after ``lin1`` and ``log_softmax``."""
 
-    def __init__(self, num_node_features, num_of_classes=2):
+    def __init__(self, num_node_features, num_of_classes=2, dropout: float = 0.5):
         super().__init__()
+        self.dropout = dropout                                # 0.5 in the reference (src/classes.py:76)
         self.conv1 = SAGEConv(num_node_features, 128)
         self.pool1 = NP.TopKPooling(128, ratio=0.5)
         self.conv2 = SAGEConv(128, 128)
@@ -47,7 +48,7 @@ class Net_1(torch.nn.Module):
             r = NP.global_max_mean_pool(x, batch, B)
             total = r if total is None else total + r
         x = F.relu(self.lin1(total))
-        x = F.dropout(x, p=0.5, training=self.training)
+        x = F.dropout(x, p=self.dropout, training=self.training)
         x = F.relu(self.lin2(x))
         x = self.lin3(x)
         return F.log_softmax(x, dim=-1)
@@ -89,8 +90,9 @@ class KeyLoader:
     def __iter__(self):
         for i in range(0, len(self.dataset), self.batch_size):
             k = self.keys[i:i + self.batch_size]
-            x, ei, b = self.ig.batch(k, n_nodes=int(self._nodes[i:i + self.batch_size].sum()),
-                                     n_pairs=int(self._pairs[i:i + self.batch_size].sum()))
+            nodes = self._nodes[i:i + self.batch_size]
+            x, ei, b = self.ig.batch(k, n_nodes=int(nodes.sum()), n_pairs=int(self._pairs[i:i + self.batch_size].sum()))
+            b._npi_sizes = nodes                          # host-known graph sizes: TopKPooling then needs no device read
             yield Batch(x, ei, b, self.y[i:i + self.batch_size])
 
 
@@ -111,13 +113,78 @@ def train(model, train_loader, optimizer, device) -> float:
     return loss_all.item() / len(train_loader.dataset)
 
 
+class GraphedEpoch:
+    """``train()`` with every batch's whole step -- forward, loss, backward, Adam -- captured into its own HIP graph.
+
+    Possible because (i) the reference's loader never reshuffles (``src/train_with_twoDataset.PY:142``), so epoch after
+    epoch the same 84 batches arrive in the same order: their input tensors are built ONCE and kept; (ii) with the graph
+    sizes known on the host no layer of ``Net_1`` reads anything back from the device (``pool.NO_SYNC``: padded edge
+    lists), so a step is a fixed sequence of ~190 kernels.  The first epoch runs eagerly (it also warms every lazy
+    initialisation up), the second captures each step and replays it at once, later epochs only replay: the host cost of
+    ~190 launches per step (the step is host-bound: 2.5 ms for 1.65 ms of kernels) is paid once per batch instead of
+    once per batch and epoch.  Numerically this is the same sequence of kernels as the eager loop.  The optimizer must be
+    ``Adam(..., capturable=True)`` with a tensor learning rate (``fit(capture=True)`` makes it so): a captured step
+    reads the current rate from that tensor, so the scheduler keeps working."""
+
+    def __init__(self, model, train_loader, optimizer, device, capture_after: int = 1):
+        self.model, self.optimizer, self.device = model, optimizer, device
+        self.capture_after = capture_after                            # eager epochs before the steps are captured
+        self.batches = [d.to(device) for d in train_loader]           # static inputs: fixed addresses for the captures
+        self.n = len(train_loader.dataset)
+        self.graphs = [None] * len(self.batches)
+        self.losses = [None] * len(self.batches)
+        self.pool = None
+        self.epochs_done = 0
+
+    def _eager(self, data):
+        self.optimizer.zero_grad()
+        loss = F.nll_loss(self.model(data), data.y)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _capture(self, i, data):
+        g = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g, pool=self.pool):
+            loss = F.nll_loss(self.model(data), data.y)
+            loss.backward()
+            self.optimizer.step()
+        if self.pool is None:
+            self.pool = g.pool()          # the graphs are replayed one after the other, always in this order: one pool
+        self.graphs[i], self.losses[i] = g, loss.detach()
+
+    def __call__(self) -> float:
+        self.model.train()
+        loss_all = torch.zeros((), dtype=torch.float64, device=self.device)
+        for i, data in enumerate(self.batches):
+            if self.epochs_done < self.capture_after:
+                loss = self._eager(data)
+            else:
+                if self.graphs[i] is None:
+                    self._capture(i, data)
+                self.graphs[i].replay()
+                loss = self.losses[i]
+            loss_all += data.num_graphs * loss.double()
+        self.epochs_done += 1
+        return loss_all.item() / self.n
+
+
 def fit(model, train_loader, test_loader, device, num_of_epoch: int = 50, LR: float = 0.001,
-        L2_weight_decay: float = 0.001, log: Callable[[str], None] = print, eval_train: bool = True):
+        L2_weight_decay: float = 0.001, log: Callable[[str], None] = print, eval_train: bool = True,
+        capture: bool = False):
     """The epoch loop of ``src/train_with_twoDataset.PY:130-184``: Adam(lr, weight_decay), ``ExponentialLR(0.95)``
     stepped ONLY when the epoch loss rose (``:158-160``), train + test metrics every 5th epoch except the last
     (``:163-172``) and once more at the end (``:186-193``), best test MCC tracked.  Returns a dict with the final
-    test metrics, the best-MCC epoch and the wall time."""
-    optimizer = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=L2_weight_decay)
+    test metrics, the best-MCC epoch and the wall time.  ``capture``: the same loop with every batch's step replayed from
+    a HIP graph after the first epoch (``GraphedEpoch``)."""
+    if capture:
+        optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(LR, device=device), weight_decay=L2_weight_decay,
+                                     capturable=True)
+        epoch_fn = GraphedEpoch(model, train_loader, optimizer, device)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=L2_weight_decay)
+        epoch_fn = None
     scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=0.95)
     fmt = '{}, {} dataset, Accuracy: {:.5f}, Precision: {:.5f}, Sensitivity: {:.5f}, Specificity: {:.5f}, MCC: {:.5f}'
     start_time = time.time()
@@ -125,7 +192,7 @@ def fit(model, train_loader, test_loader, device, num_of_epoch: int = 50, LR: fl
     loss_last = float('inf')
     history = []
     for epoch in range(num_of_epoch):
-        loss = train(model, train_loader, optimizer, device)
+        loss = epoch_fn() if epoch_fn is not None else train(model, train_loader, optimizer, device)
         if loss > loss_last:
             scheduler.step()
             lr_steps += 1

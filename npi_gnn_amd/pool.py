@@ -22,6 +22,11 @@ from torch.nn import Parameter
 from ._lib import check, load, ptr, require_gpu, stream_ptr
 
 
+# When the sizes of a batch's graphs are known on the host (batch._npi_sizes) TopKPooling makes no device read: see
+# _topk_pool_fwd.  The edge_index it returns is then PADDED to the input's length with (-1, -1) columns.
+NO_SYNC = True
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32, got {t.dtype}")
@@ -37,6 +42,9 @@ def graph_ptr(batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Te
     known = getattr(batch, "_npi_graph_ptr", None)          # left by topk_pool on the batch vector it produced
     if known is not None and (num_graphs is None or int(num_graphs) == known.numel() - 1):
         return known
+    sizes = getattr(batch, "_npi_sizes", None)             # host-known graph sizes (net1.KeyLoader): no device read
+    if num_graphs is None and sizes is not None:
+        num_graphs = int(sizes.numel())
     B = int(num_graphs) if num_graphs is not None else (int(batch[-1].item()) + 1 if N else 0)
     gp = torch.empty(B + 1, dtype=torch.int32, device=dev)
     check(load().npi_graph_bounds(ptr(batch.contiguous()), N, B, ptr(gp), stream_ptr(dev)), "npi_graph_bounds")
@@ -69,33 +77,43 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     out_ei = torch.empty((2, max(E, 1)), dtype=torch.int64, device=dev)
     count = torch.empty(1, **i32)
     ws = torch.empty(int(lib.npi_filter_adj_workspace_elems(E)), **i32)
-    check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
-          "npi_filter_adj")
-    # sizes of the outputs are data dependent: ONE device read per pooling layer (PyG's own implementation has several)
-    # (the same read also reports graph builds that dropped out-of-range node ids, graph.pending_status)
-    from . import graph as _graph
-    pend = [t for t in _graph.pending_status() if t.device == dev]
-    vals = torch.cat([out_ptr[-1:], status, count] + pend).tolist() if B else [0, 0, 0] + (torch.cat(pend).tolist() if pend else [])
-    n_out, flags, e_out = vals[:3]
-    _graph.raise_on_status(vals[3:])
-    if flags & 2:
-        # A graph with more than 16,384 nodes does not fit the LDS sort of npi_topk_select (one-hop subgraphs of the
-        # bundled datasets stay below 1,000 nodes).  Rare path: the same selection rule -- score descending, lower index
-        # first among equals, ceil(ratio n) per graph -- with device-wide torch sorts, then filter_adj again with the new map.
-        gpl = gp.long()
-        n_per = gpl[1:] - gpl[:-1]
-        k_per = torch.ceil(float(ratio) * n_per.double()).long()
-        order = torch.argsort(score, descending=True, stable=True)
-        order = order[torch.argsort(batch[order], stable=True)]
-        rank = torch.arange(N, device=dev) - gpl[:-1][batch[order]]
-        kept = order[rank < k_per[batch[order]]]
-        out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(k_per, 0)]).to(torch.int32)
-        perm = kept.to(torch.int32)
-        remap = torch.full((max(N, 1),), -1, **i32)
-        remap[kept] = torch.arange(kept.numel(), **i32)
-        check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
-              "npi_filter_adj")
-        n_out, e_out = int(kept.numel()), int(count.item())
+    # Host-known graph sizes (``batch._npi_sizes``, left by net1.KeyLoader or by the previous pooling layer): the kept
+    # node count is ceil(ratio n_g) per graph -- computable on the host -- and the surviving edges stay in an array of the
+    # input's length whose tail is (-1, -1) padding (npi_filter_adj_ex), which every consumer drops.  No device read at
+    # all: the layer, and with it the whole Net_1 step, runs without a host synchronisation and captures into a HIP graph.
+    kept = _kept_sizes(batch, ratio) if B > 0 else None
+    nosync = kept is not None and kept.numel() == B
+    check(lib.npi_filter_adj_ex(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws),
+                                1 if nosync else 0, st), "npi_filter_adj")
+    if nosync:
+        n_out, e_out = int(kept.sum()), E                # kept = ceil(ratio n_g) in the kernel's f32 arithmetic
+    else:
+        kept = None
+        # sizes of the outputs are data dependent: ONE device read per pooling layer (PyG's own implementation has several)
+        # (the same read also reports graph builds that dropped out-of-range node ids, graph.pending_status)
+        from . import graph as _graph
+        pend = [t for t in _graph.pending_status() if t.device == dev]
+        vals = torch.cat([out_ptr[-1:], status, count] + pend).tolist() if B else [0, 0, 0] + (torch.cat(pend).tolist() if pend else [])
+        n_out, flags, e_out = vals[:3]
+        _graph.raise_on_status(vals[3:])
+        if flags & 2:
+            # A graph with more than 16,384 nodes does not fit the LDS sort of npi_topk_select (one-hop subgraphs of the
+            # bundled datasets stay below 1,000 nodes).  Rare path: the same selection rule -- score descending, lower index
+            # first among equals, ceil(ratio n) per graph -- with device-wide torch sorts, then filter_adj again with the new map.
+            gpl = gp.long()
+            n_per = gpl[1:] - gpl[:-1]
+            k_per = torch.ceil(float(ratio) * n_per.double()).long()
+            order = torch.argsort(score, descending=True, stable=True)
+            order = order[torch.argsort(batch[order], stable=True)]
+            rank = torch.arange(N, device=dev) - gpl[:-1][batch[order]]
+            keep = order[rank < k_per[batch[order]]]
+            out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(k_per, 0)]).to(torch.int32)
+            perm = keep.to(torch.int32)
+            remap = torch.full((max(N, 1),), -1, **i32)
+            remap[keep] = torch.arange(keep.numel(), **i32)
+            check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
+                  "npi_filter_adj")
+            n_out, e_out = int(keep.numel()), int(count.item())
     xo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
     batch_o = torch.empty(n_out, dtype=torch.int64, device=dev)
     score_o = torch.empty(n_out, dtype=torch.float32, device=dev)
@@ -104,6 +122,8 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     # the kept-row offsets ARE the segment starts of the pooled batch vector: the readout and the next pooling
     # layer take them from here instead of searching `batch_o` again
     batch_o._npi_graph_ptr = out_ptr
+    if kept is not None:
+        batch_o._npi_sizes = kept                        # the next pooling layer knows its sizes as well
     return (xo, out_ei[:, :e_out], None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
 
 
@@ -112,8 +132,9 @@ class _TopKPoolFn(torch.autograd.Function):
     def forward(ctx, x, weight, edge_index, batch, ratio, num_graphs):
         (xo, ei_o, _, batch_o, perm, score_o), (score, perm32) = _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)
         ctx.save_for_backward(x.detach(), weight.detach(), score, perm32)
-        ctx.mark_non_differentiable(ei_o, batch_o, perm)
-        return xo, score_o, ei_o, batch_o, perm
+        out_ptr = batch_o._npi_graph_ptr
+        ctx.mark_non_differentiable(ei_o, batch_o, perm, out_ptr)
+        return xo, score_o, ei_o, batch_o, perm, out_ptr
 
     @staticmethod
     def backward(ctx, dxo, dscore_o, *_unused):
@@ -144,12 +165,24 @@ class _TopKPoolFn(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), dw, None, None, None, None
 
 
+def _kept_sizes(batch, ratio):
+    sizes = getattr(batch, "_npi_sizes", None)
+    if not NO_SYNC or sizes is None or sizes.numel() == 0 or int(sizes.max()) > 16384:
+        return None
+    return torch.ceil(torch.tensor(float(ratio), dtype=torch.float32) * sizes.to(torch.float32)).to(torch.int64)
+
+
 def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, weight: torch.Tensor,
               ratio: float = 0.5, num_graphs: Optional[int] = None):
     """``TopKPooling.forward`` -> ``(x', edge_index', None, batch', perm, score[perm])``; differentiable in
     ``x`` and ``weight``."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        xo, score_o, ei_o, batch_o, perm = _TopKPoolFn.apply(x, weight, edge_index, batch, ratio, num_graphs)
+        xo, score_o, ei_o, batch_o, perm, out_ptr = _TopKPoolFn.apply(x, weight, edge_index, batch, ratio, num_graphs)
+        # (the tensors an autograd Function hands back need not be the objects its forward created: re-attach)
+        batch_o._npi_graph_ptr = out_ptr
+        kept = _kept_sizes(batch, ratio)
+        if kept is not None:
+            batch_o._npi_sizes = kept
         return xo, ei_o, None, batch_o, perm, score_o
     return _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)[0]
 

@@ -46,3 +46,31 @@ def test_training_loop_learns_on_rpi369(dev):
         "Epoch: 010, testing dataset", "result, training dataset", "result, testing dataset"]
     m = res["test"]
     assert all(0.0 <= v <= 1.0 for v in m[:4]) and -1.0 <= m[4] <= 1.0
+
+
+def test_training_step_replayed_from_hip_graphs_equals_the_eager_loop(dev):
+    """net1.GraphedEpoch: every batch's whole step -- Net_1 forward with its three pooling layers, loss,
+    backward, Adam -- captured once and replayed; with dropout off the loss curve must be the eager loop's."""
+    from npi_gnn_amd import net1
+    ex = _example("train_rpi369")
+    ig, train_keys, train_y, test_keys, test_y, F_in = ex.load_project(dev)
+    g = torch.Generator().manual_seed(0)
+    loader = net1.KeyLoader(ig, train_keys, train_y, 200).shuffle(g)
+    curves = []
+    for capture_after in (1, 10 ** 9):
+        torch.manual_seed(0)
+        model = net1.Net_1(F_in, dropout=0.0).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-3, device=dev), weight_decay=1e-3, capturable=True)
+        epoch = net1.GraphedEpoch(model, loader, opt, dev, capture_after=capture_after)
+        curves.append([epoch() for _ in range(6)])
+        if capture_after == 1:
+            assert all(gr is not None for gr in epoch.graphs)
+    a, b = curves
+    assert all(abs(u - v) <= 1e-5 * max(1.0, abs(v)) for u, v in zip(a, b)), (a, b)
+    assert a[-1] < a[0]
+    # and through fit(): the reference's loop with captured steps, scheduler included
+    torch.manual_seed(0)
+    model = net1.Net_1(F_in).to(dev)
+    res = net1.fit(model, loader, net1.KeyLoader(ig, test_keys, test_y, 200), dev, num_of_epoch=8, log=lambda s: None,
+                   capture=True)
+    assert res["loss"][-1] < res["loss"][0] and all(l == l for l in res["loss"])
