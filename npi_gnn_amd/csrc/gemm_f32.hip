@@ -874,6 +874,11 @@ gemm_split_ws_kernel(SplitArgs a) {
 // workgroups with m-tile 0 (two partial rows per slab: the two 8-node halves of a k-step).
 // The 16-byte LDS stores of 8 adjacent lanes go to 8 different bank quads: lane cg stores its columns in the rotated
 // order rho(cg) + c (see dw_rot), which with the image's half swizzle covers all 32 banks.
+// measurement switches of gemm_dw_split_kernel (tools/build_variant.sh <name> -DNPI_DW_PROBE=<bits>): 1 = no start stagger,
+// 2 = cheap split (timing only, wrong numbers), 4 = one MFMA per product tile (timing only)
+#ifndef NPI_DW_PROBE
+#define NPI_DW_PROBE 0
+#endif
 struct DwArgs {
     const float* A; int64_t lda;     // [M, K]
     const float* dC; int64_t ldc;    // [M, N]
@@ -940,12 +945,16 @@ gemm_dw_split_kernel(DwArgs a) {
         const char* srcb = uniform_ptr(reinterpret_cast<const char*>(isA ? a.A + (int64_t)mt * 128 : a.dC + (int64_t)nt * BN));
         const int64_t ldb = ((int64_t)uniform_i((int)(ld >> 32)) << 32 | (uint32_t)uniform_i((int)(ld & 0xffffffff))) * 4;   // row pitch in bytes
         const uint32_t voff = (uint32_t)(((int64_t)8 * half * ld + 4 * cg) * 4);
+        // every slab walks its node range from a different starting step (and wraps): 256 workgroups that all start on a
+        // slab boundary -- addresses a multiple of 16 KiB apart -- otherwise sweep the memory channels in lockstep
+        const int phase = (NPI_DW_PROBE & 1) || nk < 2 ? 0 : (int)(((int64_t)slab * 37) % nk);
         const bool active = isA || isB;
 #define DW_GL(dst, base) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define DW_DECL(S) f32x4r S##0, S##1, S##2, S##3, S##4, S##5, S##6, S##7
 #define DW_LOAD(S, KS)                                                                                 \
     do {                                                                                               \
-        const int kk_ = (KS) < nk ? (KS) : nk - 1;   /* past the end: reload the last step, dropped */ \
+        const int kc_ = (KS) < nk ? (KS) : nk - 1;   /* past the end: reload the last step, dropped */ \
+        const int kk_ = kc_ + phase < nk ? kc_ + phase : kc_ + phase - nk;   /* staggered start, wraps */ \
         const char* g_ = srcb + (node0 + (int64_t)kk_ * SK) * ldb;                                     \
         DW_GL(S##0, g_);           DW_GL(S##1, g_ + ldb);                                              \
         DW_GL(S##2, g_ + 2 * ldb); DW_GL(S##3, g_ + 3 * ldb);                                          \
@@ -972,7 +981,10 @@ gemm_dw_split_kernel(DwArgs a) {
                 }
                 uint32_t p0[4], p1[4], p2[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
+                for (int i = 0; i < 4; ++i) {
+                    if (NPI_DW_PROBE & 2) { p0[i] = pack_bf16(v[2 * i], v[2 * i + 1]); p1[i] = p0[i]; p2[i] = p0[i]; }
+                    else split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
+                }
                 char* dst = st + simg(4 * cg + cc, half);
                 *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
                 *reinterpret_cast<uint4*>(dst + plane) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
@@ -1050,11 +1062,13 @@ gemm_dw_split_kernel(DwArgs a) {
 #define NPI_MMA6(I, J)                                                                                 \
         do {                                                                                           \
             f32x16 c = acc[I][J];                                                                      \
+            if (!(NPI_DW_PROBE & 4)) {                                                                 \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][2], c, 0, 0, 0);               \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][2], af[I][0], c, 0, 0, 0);               \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][1], c, 0, 0, 0);               \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][1], c, 0, 0, 0);               \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][0], c, 0, 0, 0);               \
+            }                                                                                          \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][0], c, 0, 0, 0);               \
             acc[I][J] = c;                                                                             \
         } while (0)
@@ -1577,7 +1591,10 @@ static void dw_split_plan(int64_t m_main, int64_t K, int64_t N, bool shared, int
     wide = (N % 256 == 0);
     tiles_m = (int)(K / 128);
     tiles_n = (int)(wide ? N / 256 : N / 128);
-    const int64_t wgs = shared ? dw_workgroups(true) : 256;
+    // shared regime: the 512-thread workgroup holds 2 x 208 VGPRs per SIMD and leaves the aggregation one wave slot there, so
+    // it is kept to about 3 of 8 CUs (step at C4 by workgroup count: 64: 7.86, 96: 7.11, 128: 7.15, 192: 7.25 ms)
+    static const bool ctas_env = getenv("NPI_DW_CTAS") != nullptr;
+    const int64_t wgs = shared ? (ctas_env ? dw_workgroups(true) : dw_workgroups(true) / 2) : 256;
     int64_t ns = wgs / ((int64_t)tiles_m * tiles_n);
     if (ns < 1) ns = 1;
     const int64_t maxs = ceil_div(m_main, (int64_t)SK * 16);                 // at least 16 k-steps per slab
