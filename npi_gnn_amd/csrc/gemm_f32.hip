@@ -527,6 +527,12 @@ typedef float f32x4r __attribute__((ext_vector_type(4)));      // native 128-bit
 typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
 constexpr int SK = 16;                             // k-step of the split kernel = one 32x32x16 MFMA block
+// Order of the 6 x TM x TN MFMAs of a k-step in the consumer waves.  0: tile by tile (six DEPENDENT MFMAs on one
+// accumulator back to back -- each waits for the previous one's result); 1: product by product over all tiles, so that
+// consecutive MFMAs are independent.  The per-accumulator order of the six products is the same: results are bit-identical.
+#ifndef NPI_MMA_INTERLEAVE
+#define NPI_MMA_INTERLEAVE 1
+#endif
 // LDS plane image: [row][16 bf16] = 32-byte rows, no padding; the two 16-byte halves of a row are swapped
 // on rows with bit 3 set, which makes the ds_read_b128 fragment reads (lane -> row, half lane>>5)
 // bank-conflict free for the 16-lane groups the hardware forms
@@ -835,6 +841,22 @@ gemm_split_ws_kernel(SplitArgs a) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][0], c, 0, 0, 0);               \
             acc[I][J] = c;                                                                             \
         } while (0)
+#if NPI_MMA_INTERLEAVE
+#define NPI_MMA1(BP, AP)                                                                               \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][BP], af[i][AP], acc[i][j], 0, 0, 0)
+        NPI_MMA1(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        signal(&empty[stg]);                                 // every fragment read has returned by now
+        __builtin_amdgcn_sched_barrier(0);
+        NPI_MMA1(2, 0);
+        NPI_MMA1(1, 1);
+        NPI_MMA1(0, 1);
+        NPI_MMA1(1, 0);
+        NPI_MMA1(0, 0);
+#undef NPI_MMA1
+#else
         NPI_MMA6(0, 0);
         __builtin_amdgcn_sched_barrier(0);
         signal(&empty[stg]);
@@ -844,6 +866,7 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 if (i + j > 0) NPI_MMA6(i, j);
+#endif
 #undef NPI_MMA6
         ++g;
         if (w.kt == nk - 1) {
@@ -1072,6 +1095,22 @@ gemm_dw_split_kernel(DwArgs a) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][0], c, 0, 0, 0);               \
             acc[I][J] = c;                                                                             \
         } while (0)
+#if NPI_MMA_INTERLEAVE
+#define NPI_MMA1(BP, AP)                                                                               \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][BP], af[i][AP], acc[i][j], 0, 0, 0)
+        NPI_MMA1(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        signal(&empty[stg]);                                 // every fragment read has returned by now
+        __builtin_amdgcn_sched_barrier(0);
+        NPI_MMA1(2, 0);
+        NPI_MMA1(1, 1);
+        NPI_MMA1(0, 1);
+        NPI_MMA1(1, 0);
+        NPI_MMA1(0, 0);
+#undef NPI_MMA1
+#else
         NPI_MMA6(0, 0);
         __builtin_amdgcn_sched_barrier(0);
         signal(&empty[stg]);
@@ -1081,6 +1120,7 @@ gemm_dw_split_kernel(DwArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 if (i + j > 0) NPI_MMA6(i, j);
+#endif
 #undef NPI_MMA6
     }
     // the tile of this slab (zeros when the slab holds no node: slab_reduce adds every slab)
