@@ -530,8 +530,10 @@ constexpr int SK = 16;                             // k-step of the split kernel
 // Order of the 6 x TM x TN MFMAs of a k-step in the consumer waves.  0: tile by tile (six DEPENDENT MFMAs on one
 // accumulator back to back -- each waits for the previous one's result); 1: product by product over all tiles, so that
 // consecutive MFMAs are independent.  The per-accumulator order of the six products is the same: results are bit-identical.
+// Measured neutral at 1M x 256 x 256 (tools/ab_mma.sh: fwd 0.96-0.98 / 0.94-0.96, bwd_data 0.88-0.89 / 0.89-0.90, dW
+// 1.02 / 1.01-1.02 ms): the dependent chain is not what holds the matrix pipe at ~50 %.  Default: the original order.
 #ifndef NPI_MMA_INTERLEAVE
-#define NPI_MMA_INTERLEAVE 1
+#define NPI_MMA_INTERLEAVE 0
 #endif
 // LDS plane image: [row][16 bf16] = 32-byte rows, no padding; the two 16-byte halves of a row are swapped
 // on rows with bit 3 set, which makes the ds_read_b128 fragment reads (lane -> row, half lane>>5)
