@@ -250,6 +250,8 @@ class _SageConvFn(torch.autograd.Function):
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
+        # symmetric edge list, no per-entry weights: A^T has the rows of A (graph.CSRGraph.symmetric) -- skip the second sort
+        tside = (lambda: graph.by_dst) if (graph.symmetric and ctx.w_src is None) else (lambda: graph.by_src)
         overlap = want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS
         if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)       # aggT dOut, colsum
@@ -268,12 +270,12 @@ class _SageConvFn(torch.autograd.Function):
                 side.wait_stream(main)                               # dAgg is complete for the side stream
                 dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True)
                 with torch.cuda.stream(side):
-                    dx = segsum(graph, graph.by_src, dagg, w=ctx.w_src, mean=False)
+                    dx = segsum(graph, tside(), dagg, w=ctx.w_src, mean=False)
                 dagg.record_stream(side)                             # allocated on main, read on side
                 dx.record_stream(main)                               # allocated on side, consumed on main
                 main.wait_stream(side)
             else:
-                dx = segsum(graph, graph.by_src, dagg, w=ctx.w_src, mean=False)
+                dx = segsum(graph, tside(), dagg, w=ctx.w_src, mean=False)
         return dx, dw, db, None, None
 
 

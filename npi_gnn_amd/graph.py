@@ -148,6 +148,11 @@ class CSRGraph:
         self.num_edges = int(edge_index.size(1))
         self.self_loops = bool(self_loops)
         self.device = edge_index.device
+        # The producer of the edge list may vouch that it holds every edge in both directions (edge_index._npi_symmetric:
+        # the device-side subgraph extraction emits both, src/classes.py:701-704, and filter_adj keeps the property).
+        # Then row j of the by-source CSR holds the same neighbours as row j of the by-target CSR -- in another order --
+        # and an UNWEIGHTED transposed aggregation can walk the by-target side: no second sort (functional._SageConvFn).
+        self.symmetric = bool(getattr(edge_index, "_npi_symmetric", False))
         # rows of a [2,E] tensor are contiguous when the tensor is; otherwise copy (index plumbing)
         self._src = edge_index[0].contiguous()
         self._dst = edge_index[1].contiguous()

@@ -124,7 +124,10 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     batch_o._npi_graph_ptr = out_ptr
     if kept is not None:
         batch_o._npi_sizes = kept                        # the next pooling layer knows its sizes as well
-    return (xo, out_ei[:, :e_out], None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
+    ei_out = out_ei[:, :e_out]
+    if getattr(edge_index, "_npi_symmetric", False):
+        ei_out._npi_symmetric = True                     # both directions of a pair survive or fall together
+    return (xo, ei_out, None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
 
 
 class _TopKPoolFn(torch.autograd.Function):
@@ -183,6 +186,8 @@ def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, we
         kept = _kept_sizes(batch, ratio)
         if kept is not None:
             batch_o._npi_sizes = kept
+        if getattr(edge_index, "_npi_symmetric", False):
+            ei_o._npi_symmetric = True
         return xo, ei_o, None, batch_o, perm, score_o
     return _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)[0]
 

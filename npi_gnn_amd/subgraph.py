@@ -107,6 +107,7 @@ class InteractionGraph:
                                     ptr(node_id), ptr(bvec), ptr(ei[0]), ptr(ei[1]), st), "npi_subgraph_fill")
         check(lib.npi_subgraph_features(ptr(self.feat), self.feat.stride(0), Ff, ptr(node_id), ptr(bvec), ptr(node_off), n,
                                         ptr(x), x.stride(0), st), "npi_subgraph_features")
+        ei._npi_symmetric = True          # every pair is emitted in both directions (graph.CSRGraph.symmetric)
         if return_node_id:
             return x, ei, bvec, node_id[:n]
         return x, ei, bvec

@@ -572,3 +572,29 @@ def test_bf16_mfma_gemm_matches_f32_reference(dev, M, K, N):
         assert float(err.mean()) < 2e-3 * max(1.0, float(ref.abs().mean()))
     again = NF.linear_fwd(A.to(dev), W.to(dev), b.to(dev), rowscale=rs.to(dev), relu=True)
     assert torch.equal(cf, again)
+
+
+def test_symmetric_edge_list_skips_the_second_sort(dev):
+    """An edge list whose producer vouches for both directions (edge_index._npi_symmetric: the device-side extraction,
+    filter_adj keeps it): the unweighted SAGE backward walks the by-target CSR -- the by-source one is never built -- and
+    gives the same dX up to the summation order."""
+    N, F = 3000, 128
+    half = rand_edges(N, 12000, seed=8, hub=4)
+    half = half[:, half[0] != half[1]]
+    ei = torch.cat([half, half.flip(0)], dim=1).to(dev)
+    x = torch.randn(N, F, generator=torch.Generator().manual_seed(1)).to(dev)
+    go = torch.randn(N, 64, generator=torch.Generator().manual_seed(2)).to(dev)
+    conv = npi.SAGEConv(F, 64).to(dev)
+    outs = []
+    for mark in (False, True):
+        e = ei.clone()
+        if mark:
+            e._npi_symmetric = True
+        g = npi.CSRGraph(e, N)
+        xg = x.clone().requires_grad_(True)
+        out = conv(xg, g)
+        out.backward(go)
+        outs.append((out.detach(), xg.grad.clone(), g._by_src is None))
+    assert outs[0][2] is False and outs[1][2] is True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-5, rtol=1e-5)
