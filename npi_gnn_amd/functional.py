@@ -285,6 +285,8 @@ def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[
     (call sites: reference ``src/classes.py:62,66,70``).  ``edge_weight [E]`` scales the messages
     (no gradient flows to it, as in the reference's use of the layer)."""
     require_gpu(x, weight, bias)
+    if edge_weight is not None and edge_weight.requires_grad:
+        raise NotImplementedError("gradients w.r.t. edge_weight are not implemented")      # as gcn_conv: never silently detached
     graph = as_graph(edge_index, x.size(0))
     w_entry = entry_weights(graph, edge_weight, 1.0) if edge_weight is not None else None
     out = _SageConvFn.apply(x, weight, bias, graph, w_entry)

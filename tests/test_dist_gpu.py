@@ -363,3 +363,40 @@ def test_world_one_edge_sharded_baseline_equals_single_gpu_conv(dev):
     assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
     assert torch.allclose(xl.grad, xr.grad, atol=1e-5, rtol=1e-5)
     assert torch.allclose(layer.weight.grad, conv.weight.grad, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("layer_kind", ["sage", "gat1"])
+def test_virtual_ranks_at_the_c4_size(dev, layer_kind):
+    """the sharded layers at the FULL C4 size (N = 1M, E = 20M, hidden 256) -- two virtual ranks on the
+    one GPU, hub cut, lock-step replay of the collectives -- against the single-GPU layer of the same kernels."""
+    import npi_gnn_amd as npi
+    from npi_gnn_amd import dist as ND
+    from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
+    N, E, F, world = 1_000_000, 20_000_000, 256, 2
+    ei = bipartite_edge_index(N, E, seed=20260310)
+    g = torch.Generator().manual_seed(6)
+    x, go = torch.randn(N, F, generator=g), torch.randn(N, F, generator=g)
+    W, b = torch.randn(F, F, generator=g) / F ** 0.5, torch.randn(F, generator=g) * 0.1
+    hub = protein_mask(N)
+    outs, dxs, dws = _run_virtual(ND, world, layer_kind, ei, N, F, x, go, W, b, hub, dev)
+    part = ND.HubPartition(N, world, hub)
+    out, dx = part.unshard(outs), part.unshard(dxs)
+    if layer_kind == "sage":
+        conv = npi.SAGEConv(F, F).to(dev)
+    else:
+        conv = npi.GATConv(F, F, heads=1).to(dev)
+        with torch.no_grad():
+            conv.att.copy_(_att(F, 1))
+    with torch.no_grad():
+        conv.weight.copy_(W)
+        conv.bias.copy_(b)
+    xr = x.to(dev).requires_grad_(True)
+    ref = conv(xr, npi.CSRGraph(ei.to(dev), N))
+    ref.backward(go.to(dev))
+
+    def rel(a, r):
+        return float((a - r.cpu()).abs().max() / r.abs().max())
+    assert rel(out, ref.detach()) < 1e-5
+    assert rel(dx, xr.grad) < 2e-5
+    for dw in dws:
+        assert rel(dw, conv.weight.grad) < 1e-4
