@@ -449,43 +449,42 @@ class _ShardedSageFn(torch.autograd.Function):
         be = sg.backend
         grad_out = grad_out.contiguous()
         dx = dw = db = None
-        started = None
         dagg = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        if ctx.needs_input_grad[0]:
+        want_x = ctx.needs_input_grad[0]
+        if want_x:
             dagg = be.linear_bwd_data(grad_out, weight, sg.inv_cnt)
-            started = _exchange_start(sg, dagg, sg.Bt)
-        # dW is independent of the dX chain.  On the GPU backend it is launched here, on this stream, so that it is
-        # resident before the aggregation -- sent to a second stream -- fills the CUs (see functional._SageConvFn);
-        # other backends run everything in line.
-        side = be.side_stream(grad_out) if (want_w and started is not None and hasattr(be, "side_stream")) else None
+        # dW is independent of the dX chain.  On the GPU backend it is launched FIRST, on this stream, so that it is resident
+        # before the aggregations -- BOTH sides, sent to a second stream -- fill the CUs (see functional._SageConvFn); with
+        # side B in front of dW, as in round 1, half of the aggregation ran alone and dW then outlasted the other half
+        # (W = 1: 7.99 ms per step).  Other backends run everything in line.
+        side = be.side_stream(grad_out) if (want_w and want_x and hasattr(be, "side_stream")) else None
         main = torch.cuda.current_stream(grad_out.device) if side is not None else None
         if side is not None:
             side.wait_stream(main)
         if want_w:
             dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias, shared=True) if side is not None else \
                 be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
-        if started is not None:
-            table, g_work, hsum, r_work = started
-
-            def finish():
+        if want_x:
+            def chain():
+                table, g_work, hsum, r_work = _exchange_start(sg, dagg, sg.Bt)
                 _wait(g_work, "bwd_all_gather", table)
                 out = be.segsum(sg.At, table, table2=dagg)
                 if hsum is not None:
                     _wait(r_work, "bwd_reduce_scatter", hsum)
                     if sg.nH:
                         out[sg.nL:] += hsum[: sg.nH]
-                return out
+                return out, (table, hsum)
             if side is not None:
                 with torch.cuda.stream(side):
-                    dx = finish()
-                for t in (table, hsum, dagg):
+                    dx, keep = chain()
+                for t in keep + (dagg,):
                     if t is not None:
                         t.record_stream(side)
                 dx.record_stream(main)
                 main.wait_stream(side)
             else:
-                dx = finish()
+                dx, _ = chain()
         if want_w:
             _all_reduce(dw, sg.world, sg.group, tag="bwd_all_reduce_dw")
             if db is not None:
