@@ -915,7 +915,11 @@ struct DwArgs {
     int tiles_m, tiles_n, nslab;
 };
 
-__device__ __forceinline__ int dw_rot(int cg) { return (cg & 1) + 2 * ((cg >> 2) & 1); }
+// LDS row of column 4 cg + c of the tile: inside every block of 32 columns the 8 x 4 (cg, c) grid is stored TRANSPOSED,
+// row 8 c + cg -- the lanes of a store instruction (fixed c, consecutive cg) then hit consecutive rows.  The consumer's
+// fragment of LDS row r therefore belongs to column dw_col(r); only the epilogue has to know (dw_store_tile).
+__device__ __forceinline__ int dw_row(int cg, int c) { return 32 * (cg >> 3) + 8 * c + (cg & 7); }
+__device__ __forceinline__ int dw_col(int r) { return (r & ~31) + 4 * (r & 7) + ((r >> 3) & 3); }
 
 template <int TN>
 __global__ void __launch_bounds__(WS_THREADS, 1)
@@ -951,12 +955,12 @@ gemm_dw_split_kernel(DwArgs a) {
         const bool isA = pt < 64;
         const bool isB = pt >= 64 && pt < 64 + BSETS;
         const int q = isA ? pt : pt - 64;
-        const int ncg = isA ? 32 : BN / 4;                  // column groups of 4
-        const int half = q / ncg, cg = q % ncg;
+        // adjacent lanes take the two 8-node halves of the same 4 columns: 8 consecutive lanes then store 4 consecutive LDS
+        // rows x 2 halves = 8 different 16-byte bank groups (see dw_row): conflict-free without any per-lane rotation
+        const int half = q & 1, cg = q >> 1;
         const int64_t ld = isA ? a.lda : a.ldc;
         char* img = lds + (isA ? 0 : 3 * APL);
         const int plane = isA ? APL : BPL;
-        const int rot = dw_rot(cg);
         const bool do_db = isB && a.db_slabs != nullptr && mt == 0;
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
         // Three register sets: two k-steps of loads (16 x 16 B per thread) stay in flight while the third is split and
@@ -996,21 +1000,15 @@ gemm_dw_split_kernel(DwArgs a) {
             char* st = img + stg * BUF;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int cc = (c + rot) & 3;              // lane-dependent choice of the component, resolved by selects
-                auto pick = [&](const f32x4r& r) { return cc == 0 ? r.x : cc == 1 ? r.y : cc == 2 ? r.z : r.w; };
-                const float v[8] = {pick(c0), pick(c1), pick(c2), pick(c3), pick(c4), pick(c5), pick(c6), pick(c7)};
-                if (do_db) {
-                    float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                    dbs[0] += cc == 0 ? sum : 0.f; dbs[1] += cc == 1 ? sum : 0.f;
-                    dbs[2] += cc == 2 ? sum : 0.f; dbs[3] += cc == 3 ? sum : 0.f;
-                }
+                const float v[8] = {c0[c], c1[c], c2[c], c3[c], c4[c], c5[c], c6[c], c7[c]};
+                if (do_db) dbs[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 uint32_t p0[4], p1[4], p2[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (NPI_DW_PROBE & 2) { p0[i] = pack_bf16(v[2 * i], v[2 * i + 1]); p1[i] = p0[i]; p2[i] = p0[i]; }
                     else split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
                 }
-                char* dst = st + simg(4 * cg + cc, half);
+                char* dst = st + simg(dw_row(cg, c), half);
                 *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
                 *reinterpret_cast<uint4*>(dst + plane) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
                 *reinterpret_cast<uint4*>(dst + 2 * plane) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
@@ -1126,9 +1124,20 @@ gemm_dw_split_kernel(DwArgs a) {
 #undef NPI_MMA6
     }
     // the tile of this slab (zeros when the slab holds no node: slab_reduce adds every slab)
-    const float rs[TM] = {1.f, 1.f};
-    store_tile_t<TM, TN>(a.slabs + (int64_t)slab * a.K * a.N, a.N, mt * 128 + wm * 64, nt * BN + wn * (32 * TN), li, lh, acc,
-                         nullptr, rs, false);
+    // Accumulator tile = C^T of the LDS-row grid: the lane owns LDS row li of the A image, its registers run along LDS rows
+    // 8 (q >> 2) + 4 lh + (q & 3) of the B image; both are permuted columns (dw_col).  128 KiB per workgroup, once: 4-byte stores.
+    float* __restrict__ C = a.slabs + (int64_t)slab * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = mt * 128 + dw_col(wm * 64 + i * 32 + li);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int col = nt * BN + dw_col(wn * (32 * TN) + j * 32 + 8 * (q >> 2) + 4 * lh + (q & 3));
+                C[(int64_t)row * a.N + col] = acc[i][j][q];
+            }
+    }
 }
 
 // ---- bf16 storage: the same persistent producer / consumer pipeline on plain bf16 MFMAs ---------------------
