@@ -557,7 +557,7 @@ def main():
             "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},
             "per_gemm_tflops_f32_equivalent": {k: v[0] / (v[1] * 1e-3) / 1e12 for k, v in gem.items() if v[1] > 0},
             "note": "bwd_weight (gemm_dw_split_kernel: both operands split on the fly) is timed while it shares the CUs "
-                    "with the backward aggregation on a second stream; alone it takes 1.02 ms"},
+                    "with the backward aggregation on a second stream; alone it takes 0.93 ms"},
     }
     res = None
     if rank == 0:
