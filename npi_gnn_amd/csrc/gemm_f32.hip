@@ -617,6 +617,23 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
     }
 }
 
+// A-operand staging of gemm_split_ws_kernel.  0: a thread takes 4 consecutive k of rows r and r + 64 (two float4) and stores
+// 8-byte pieces per plane (round 1; SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles).  1: a thread takes 8 consecutive k of ONE
+// row (two adjacent float4) and stores one 16-byte half row per plane; adjacent lanes hold the two halves of a row, so the 8
+// lanes of a ds_write_b128 group cover 4 consecutive rows x 2 halves = 8 different bank quads (conflict-free).
+#ifndef NPI_SPLIT_A16
+#define NPI_SPLIT_A16 1
+#endif
+__device__ __forceinline__ void split3_store16(f32x4r lo, f32x4r hi, char* img, int plane) {
+    uint32_t a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+    split3_pair(lo.x, lo.y, a0, a1, a2);
+    split3_pair(lo.z, lo.w, b0, b1, b2);
+    split3_pair(hi.x, hi.y, c0, c1, c2);
+    split3_pair(hi.z, hi.w, d0, d1, d2);
+    *reinterpret_cast<uint4*>(img) = make_uint4(a0, b0, c0, d0);
+    *reinterpret_cast<uint4*>(img + plane) = make_uint4(a1, b1, c1, d1);
+    *reinterpret_cast<uint4*>(img + 2 * plane) = make_uint4(a2, b2, c2, d2);
+}
 struct SplitArgs {
     const float* A; int64_t lda;
     const uint16_t* Bp;      // [3][K/16][N][16]
@@ -696,12 +713,23 @@ gemm_split_ws_kernel(SplitArgs a) {
         // 32-bit byte offset fixed for the whole kernel.
         // A: float4 #(pt & 3) of rows (pt >> 2) and (pt >> 2) + 64;  B: the NB consecutive 16-B chunks NB pt ... of each plane's tile
         const int64_t b_plane = (int64_t)a.N * a.K * 2;
+#if NPI_SPLIT_A16
+        const uint32_t oa0 = (uint32_t)(((int64_t)(pt >> 1) * a.lda + (pt & 1) * 8) * 4);     // row pt / 2, k half pt % 2
+        const uint32_t oa1 = oa0 + 16;
+#else
         const uint32_t oa0 = (uint32_t)(((int64_t)(pt >> 2) * a.lda + (pt & 3) * 4) * 4);
         const uint32_t oa1 = oa0 + (uint32_t)(a.lda * 64 * 4);
+#endif
         const uint32_t ob = (uint32_t)pt * (16 * NB);
         const int ar = pt >> 2, ac = pt & 3;
+#if NPI_SPLIT_A16
+        char* la0 = lds + simg(pt >> 1, pt & 1);
+        char* la1 = la0;
+        (void)ar; (void)ac;
+#else
         char* la0 = lds + simg(ar, ac >> 1) + (ac & 1) * 8;
         char* la1 = lds + simg(ar + 64, ac >> 1) + (ac & 1) * 8;
+#endif
         // chunk c -> row c / 2, half c % 2
         char* lb0 = lds + 3 * APL + (NB == 2 ? simg(pt, 0) : simg(pt >> 1, pt & 1));
         char* lb1 = lds + 3 * APL + simg(pt, 1);
@@ -741,8 +769,8 @@ gemm_split_ws_kernel(SplitArgs a) {
     } while (0)
 #define NPI_WSTORE(OFF, S)                                                                             \
     do {                                                                                               \
-        split3_store(S##a0, la0 + (OFF), APL);                                                         \
-        split3_store(S##a1, la1 + (OFF), APL);                                                         \
+        if constexpr (NPI_SPLIT_A16) { split3_store16(S##a0, S##a1, la0 + (OFF), APL); (void)la1; }    \
+        else { split3_store(S##a0, la0 + (OFF), APL); split3_store(S##a1, la1 + (OFF), APL); }         \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF)) = S##b0;                                               \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF) + BPL) = S##b1;                                         \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF) + 2 * BPL) = S##b2;                                     \
