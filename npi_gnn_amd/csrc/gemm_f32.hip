@@ -621,8 +621,10 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
 // 8-byte pieces per plane (round 1; SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles).  1: a thread takes 8 consecutive k of ONE
 // row (two adjacent float4) and stores one 16-byte half row per plane; adjacent lanes hold the two halves of a row, so the 8
 // lanes of a ds_write_b128 group cover 4 consecutive rows x 2 halves = 8 different bank quads (conflict-free).
+// Measured at 1M x 256 x 256 (tools/ab_split_a.sh): 1 is 3-4 % SLOWER (bwd_data 0.92 vs 0.88 ms, fwd min 0.95 vs 0.83):
+// the bank conflicts of the 8-byte stores are not what limits the kernel.  Default 0.
 #ifndef NPI_SPLIT_A16
-#define NPI_SPLIT_A16 1
+#define NPI_SPLIT_A16 0
 #endif
 __device__ __forceinline__ void split3_store16(f32x4r lo, f32x4r hi, char* img, int plane) {
     uint32_t a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
