@@ -267,6 +267,20 @@ int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_
                          const float* g_dst, const float* g_src, const float* att,
                          const float* alpha, const int32_t* alpha_map,
                          float* carry, void* stream);
+/* Fused backward pass (one head, C <= 256): over the by-SOURCE CSR, in ONE pass over the gathered dOut rows,
+ *     out[j, :] = sum_q alpha_q dout[col q, :]                                   (the aggregation half of d hfeat)
+ *     dz[q]     = alpha_q (<dout[col q], hfeat[j]> - D[col q]) leaky_relu'(a_dst[col q] + a_src[j])   (the SDDMM)
+ * with alpha read back from the FORWARD (npi_gat_aggregate with by_source == 0, alpha != NULL and alpha_map == NULL stores
+ * it in by-target entry order) through alpha_map = npi_entry_transpose_map.  Replaces npi_gat_edge_grad + the by-source
+ * npi_gat_aggregate: one gather pass over the entries instead of two.  The rank-1 terms g_dst att[:C] + g_src att[C:]
+ * are added afterwards by npi_gat_rank1_add (row sums of dz: npi_seg_rowsum over both orientations). */
+int npi_gat_backward_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                           int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* hfeat, int64_t ldh,
+                           float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src, const float* D,
+                           float negative_slope, const float* alpha, const int32_t* alpha_map, float* dz, float* carry,
+                           void* stream);
+int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
+                      int64_t N, int64_t H, int64_t C, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                    int64_t N, int64_t H, int64_t C, float* D, void* stream);
 int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,

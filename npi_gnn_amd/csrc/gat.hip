@@ -676,9 +676,61 @@ gat_att_grad_reduce_kernel(const float* __restrict__ part, int nchunks, int H, i
     }
 }
 
+// dh[i, h C + c] += g_dst[i, h] att[h, c] + g_src[i, h] att[h, C + c]: the rank-1 terms of the attention-score gradient,
+// added once g_dst / g_src are complete (the fused backward pass cannot apply them in its row epilogue)
+__global__ void __launch_bounds__(256)
+gat_rank1_add_kernel(float* __restrict__ dh, int64_t ld, const float* __restrict__ g_dst, const float* __restrict__ g_src,
+                     const float* __restrict__ att, int64_t N, int H, int C) {
+    const int F = H * C;
+    const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (idx >= N * F) return;
+    const int64_t i = idx / F;
+    const int f = (int)(idx - i * F);                  // F % 4 == 0 and C % 4 == 0: the four columns share a head
+    const int h = f / C, c = f - h * C;
+    const float gd = g_dst[i * H + h], gs = g_src[i * H + h];
+    const float4 ad = *reinterpret_cast<const float4*>(att + (int64_t)h * 2 * C + c);
+    const float4 as = *reinterpret_cast<const float4*>(att + (int64_t)h * 2 * C + C + c);
+    float4 v = *reinterpret_cast<float4*>(dh + i * ld + f);
+    v.x += gd * ad.x + gs * as.x; v.y += gd * ad.y + gs * as.y;
+    v.z += gd * ad.z + gs * as.z; v.w += gd * ad.w + gs * as.w;
+    *reinterpret_cast<float4*>(dh + i * ld + f) = v;
+}
+
 }  // namespace npi
 
 using namespace npi;
+
+extern "C" int npi_gat_backward_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                                      int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* hfeat, int64_t ldh,
+                                      float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src, const float* D,
+                                      float slope, const float* alpha, const int32_t* alpha_map, float* dz, float* carry,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_backward_fused: needs one head of <= 256 channels, C % 4 == 0");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && col && rowidx && item_row && dout && hfeat && out && a_dst && a_src && D && alpha && alpha_map && dz && carry,
+                "npi_gat_backward_fused: null pointer");
+    NPI_REQUIRE(ldd >= C && ldh >= C && ldo >= C && ldh % 4 == 0 && ((uintptr_t)hfeat % 16) == 0,
+                "npi_gat_backward_fused: leading dimension / alignment");
+    SegParams P{};
+    P.rowptr = rowptr; P.col = col; P.item_row = item_row;
+    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
+    P.x = dout; P.ldx = ldd; P.out = out; P.ldo = ldo; P.F = (int)C;
+    P.carry = carry; P.w = alpha; P.wmap = alpha_map; P.bias = nullptr;
+    P.H = 1; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.m = a_dst; P.s = a_dst; P.slope = slope;   // m, s unused in this mode
+    P.hrow = hfeat; P.ldh = ldh; P.Dt = D; P.rowidx = rowidx; P.dz_out = dz;
+    return segsum_run(P, W_GAT_SRC_FUSED, 0, nnz_max, NPI_F32, stream);
+}
+
+extern "C" int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
+                                 int64_t N, int64_t H, int64_t C, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && H > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0, "npi_gat_rank1_add: bad size (C % 4 == 0, ld % 4 == 0)");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(dh && g_dst && g_src && att && ((uintptr_t)dh % 16) == 0 && ((uintptr_t)att % 16) == 0, "npi_gat_rank1_add: null or misaligned pointer");
+    gat_rank1_add_kernel<<<(unsigned)ceil_div(N * H * C, 1024), 256, 0, stream>>>(dh, ld, g_dst, g_src, att, N, (int)H, (int)C);
+    return check_launch("npi_gat_rank1_add");
+}
 
 extern "C" int npi_gat_scores(const float* h, int64_t ldh, const float* att, int64_t N, int64_t H, int64_t C,
                               float* a_dst, float* a_src, void* stream_) {
@@ -780,7 +832,12 @@ extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, c
     P.carry = carry; P.w = nullptr; P.bias = bias;
     P.H = (int)H; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.m = m; P.s = s; P.slope = slope;
     P.g_dst = g_dst; P.g_src = g_src; P.att = att;
-    if (alpha != nullptr) {       // the weights of npi_gat_edge_grad, read back through the transpose map (one head, by source)
+    if (alpha != nullptr && !by_source) {     // forward, one head: also WRITE alpha of every entry (by-target order) for the backward
+        NPI_REQUIRE(H == 1 && alpha_map == nullptr, "npi_gat_aggregate: storing alpha needs one head (and no alpha_map)");
+        P.alpha_out = const_cast<float*>(alpha);
+        return segsum_run(P, W_GAT_DST, 0, nnz_max, NPI_F32, stream);
+    }
+    if (alpha != nullptr) {       // the weights of the forward / of npi_gat_edge_grad, read back through the transpose map (one head, by source)
         NPI_REQUIRE(by_source && H == 1 && alpha_map != nullptr, "npi_gat_aggregate: alpha needs by_source, one head and alpha_map");
         P.w = alpha; P.wmap = alpha_map;
         return segsum_run(P, W_GAT_SRC_PRE, 0, nnz_max, NPI_F32, stream);

@@ -4,7 +4,7 @@
 
 namespace npi {
 
-enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4 };
+enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4, W_GAT_SRC_FUSED = 5 };
 
 struct SegParams {
     const int32_t* rowptr;
@@ -34,6 +34,15 @@ struct SegParams {
     const float* g_dst;
     const float* g_src;
     const float* att;        // [H, 2C]
+    // W_GAT_DST, one head: alpha of every entry is also written here (by-target entry order) when not null
+    float* alpha_out;
+    // W_GAT_SRC_FUSED (one head, F <= 256): W_GAT_SRC_PRE plus, in the same pass over the gathered dOut rows, the
+    // score gradient dz[q] = alpha_q (<dOut_i, h_j> - D_i) leaky_relu'(a_dst[i] + a_src[j]) of every by-source entry q
+    const float* hrow;       // [N, F] features of the ROW nodes (h_j), leading dimension ldh
+    int64_t ldh;
+    const float* Dt;         // [N] D of the column (target) nodes
+    const int32_t* rowidx;   // row of every entry (the by-source CSR's rowidx)
+    float* dz_out;           // [nnz_max] by-source entry order
 };
 
 // x / out / bias are stored as `dtype` (NPI_F32 or NPI_BF16; the struct's float* are reinterpreted)

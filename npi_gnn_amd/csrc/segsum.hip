@@ -20,6 +20,8 @@
 //              = GATConv's softmax(alpha) * x_j on the by-target CSR, alpha never stored
 //   W_GAT_SRC_PRE  W_GAT_SRC with alpha read back (w[wmap[p]], one head) instead of recomputed: the per-entry
 //              exp / divide of W_GAT_SRC costs more VALU time than the row it weighs costs memory time
+//   W_GAT_SRC_FUSED  W_GAT_SRC_PRE that also computes the per-entry score gradient dz from the rows it gathers anyway
+//              (the SDDMM of the GATConv backward: no separate gather pass over the 104M entries)
 //   W_GAT_SRC  the same alpha seen from the by-source CSR (backward: d h_j = sum_i alpha_ij d out_i),
 //              plus the rank-1 terms of the attention-score gradient in the epilogue
 #include "segsum.h"
@@ -195,8 +197,14 @@ segsum_kernel(SegParams P) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
 
+    // W_GAT_SRC_FUSED: per-entry dot products of one 64-entry block are parked here, then all 64 lanes turn them into dz
+    __shared__ float seg_pb[SEG_WAVES][WAVE];
+    float* __restrict__ pb = seg_pb[threadIdx.x >> 6];
+    float hr[VEC];                       // W_GAT_SRC_FUSED: this lane's columns of the open row's own features (h_j)
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) hr[q] = 0.f;
     // per-row constants of the GAT weight (per lane: the head of its columns)
-    float rs_a[NCH], rs_m[NCH];
+    float rs_a[NCH], rs_m[NCH], rs_i[NCH];
     auto open_row = [&]() {
         if (WMODE == W_GAT_DST) {
 #pragma unroll
@@ -204,7 +212,10 @@ segsum_kernel(SegParams P) {
                 const int64_t i = (int64_t)min(r, N - 1) * P.H + L.hd[c];
                 rs_a[c] = P.a_dst[i];
                 rs_m[c] = P.m[i];
+                rs_i[c] = P.alpha_out ? 1.f / (P.s[i] + 1e-16f) : 0.f;
             }
+        } else if (WMODE == W_GAT_SRC_FUSED) {
+            if (L.act[0]) load_row<VEC, float>(P.hrow + (int64_t)min(r, N - 1) * P.ldh + L.foff[0], hr);
         } else if (WMODE == W_GAT_SRC) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -245,7 +256,7 @@ segsum_kernel(SegParams P) {
 
     // one gathered row (+ its weight) into the accumulators
     auto entry_weight = [&](int c, float g0, float g1, float g2, float ws) -> float {
-        if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE) return ws;
+        if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) return ws;
         if (WMODE == W_GAT_DST) return expf(lrelu(rs_a[c] + g0, P.slope) - rs_m[c]);
         if (WMODE == W_GAT_SRC) return expf(lrelu(g0 + rs_a[c], P.slope) - g1) * g2;
         return 1.f;
@@ -256,7 +267,7 @@ segsum_kernel(SegParams P) {
         const int cv = (lane < nb) ? P.col[kb + lane] : 0;
         float wv = 1.f;
         if (WMODE == W_ARRAY) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
-        if (WMODE == W_GAT_SRC_PRE) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
+        if (WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
         int j = 0;
         for (; j + U <= nb; j += U) {
             float v[U][NCH][VEC];
@@ -282,18 +293,40 @@ segsum_kernel(SegParams P) {
                     }
                 }
             }
+            float pd[U];                 // W_GAT_SRC_FUSED: this lane's share of <gathered row, open row's own features>
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int k = kb + j + u;
                 while (k == row_end) close_row();
-                const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE) ? bcast_f(wv, j + u) : 1.f;
+                const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) ? bcast_f(wv, j + u) : 1.f;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
+                    if (WMODE == W_GAT_DST && c == 0 && P.alpha_out != nullptr && lane == 0) P.alpha_out[k] = we * rs_i[0];
 #pragma unroll
                     for (int q = 0; q < VEC; ++q)
                         acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[u][c][q]) : fmaf(we, v[u][c][q], acc[c][q]);
                 }
+                pd[u] = 0.f;
+                if (WMODE == W_GAT_SRC_FUSED) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) pd[u] = fmaf(v[u][0][q], hr[q], pd[u]);
+                }
+            }
+            if (WMODE == W_GAT_SRC_FUSED && U == 8) {
+                // the 8 partial dots are reduce-SCATTERED: every xor step halves the entries a lane still carries
+                // (4 + 2 + 1 + 3 = 10 cross-lane steps), after which lane group l >> 3 holds the sum of entry (l >> 3)
+                const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+                float w4[4], w2[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w4[k] = (b5 ? pd[(k + 4) % U] : pd[k % U]) + __shfl_xor(b5 ? pd[k % U] : pd[(k + 4) % U], 32, WAVE);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) w2[k] = (b4 ? w4[k + 2] : w4[k]) + __shfl_xor(b4 ? w4[k] : w4[k + 2], 16, WAVE);
+                float y = (b3 ? w2[1] : w2[0]) + __shfl_xor(b3 ? w2[0] : w2[1], 8, WAVE);
+                y += __shfl_xor(y, 4, WAVE);
+                y += __shfl_xor(y, 2, WAVE);
+                y += __shfl_xor(y, 1, WAVE);
+                if ((lane & 7) == 0) pb[j + (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0)] = y;
             }
         }
         for (; j < nb; ++j) {       // ragged tail of the last item only
@@ -319,14 +352,33 @@ segsum_kernel(SegParams P) {
             }
             const int k = kb + j;
             while (k == row_end) close_row();
-            const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE) ? bcast_f(wv, j) : 1.f;
+            const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) ? bcast_f(wv, j) : 1.f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
+                if (WMODE == W_GAT_DST && c == 0 && P.alpha_out != nullptr && lane == 0) P.alpha_out[k] = we * rs_i[0];
 #pragma unroll
                 for (int q = 0; q < VEC; ++q)
                     acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[c][q]) : fmaf(we, v[c][q], acc[c][q]);
             }
+            if (WMODE == W_GAT_SRC_FUSED) {
+                float p = 0.f;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) p = fmaf(v[0][q], hr[q], p);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, WAVE);
+                if (lane == 0) pb[j] = p;
+            }
+        }
+        if (WMODE == W_GAT_SRC_FUSED) {
+            // all 64 lanes turn the block's dots into dz together: dz = alpha (dot - D_i) leaky_relu'(a_dst[i] + a_src[j])
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nb) {
+                const int jj = P.rowidx[kb + lane];
+                const float z = P.a_dst[cv] + P.a_src[jj];
+                P.dz_out[kb + lane] = wv * (pb[lane] - P.Dt[cv]) * (z > 0.f ? 1.f : P.slope);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     // entries exhausted at k1
@@ -642,6 +694,15 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, false, EXACT>(P, stream);
     } else if (wmode == W_GAT_SRC_PRE) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, false, EXACT>(P, stream);
+    } else if (wmode == W_GAT_SRC_FUSED) {
+        if constexpr (VEC == 4 && sizeof(T) == 4 && NCH == 1) {
+            dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
+            segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED, false, EXACT><<<grid, block, 0, stream>>>(P);
+            launch_fixup<T, VEC, NCH, W_GAT_SRC_PRE, false, EXACT>(P, stream);       // same row epilogue
+        } else {
+            set_error("npi_gat_backward_fused: needs heads * out_channels <= 256");
+            return NPI_ERR_ARG;
+        }
     } else {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC, false, EXACT>(P, stream);
     }

@@ -393,6 +393,27 @@ def _transpose_map(graph: CSRGraph) -> torch.Tensor:
     return tm
 
 
+def _inverse_transpose_map(graph: CSRGraph) -> torch.Tensor:
+    """by-source position of every by-target entry (inverse of ``_transpose_map``), cached; index work in torch, once per graph"""
+    inv = getattr(graph, "_tmap_inv", None)
+    if inv is None:
+        tm = _transpose_map(graph)
+        n = tm.numel()
+        idx = torch.arange(n, device=tm.device)
+        valid = idx < graph.by_src.rowptr[-1]                       # entries past nnz (dropped edges / padding) hold garbage
+        inv = torch.zeros(n + 1, dtype=torch.int32, device=tm.device)
+        inv.scatter_(0, torch.where(valid, tm.long(), torch.full_like(idx, n)), idx.to(torch.int32))
+        inv = inv[:n].contiguous()
+        graph._tmap_inv = inv
+    return inv
+
+
+# GATConv backward, one head of <= 256 channels: ONE gather pass over the by-source entries produces both the aggregation
+# half of d hfeat and the per-entry score gradient (npi_gat_backward_fused), with alpha stored by the forward -- instead of
+# npi_gat_edge_grad (a gather pass over the by-target entries) followed by the by-source aggregation.
+GAT_FUSED_BACKWARD = os.environ.get("NPI_GAT_FUSED", "1") != "0"
+
+
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
                    g_src=None, att=None, alpha=None, alpha_map=None, x2=None):
     """``x2``: second part of a two-part table (see ``segsum``)."""
@@ -505,16 +526,21 @@ class _GatConvFn(torch.autograd.Function):
         a_dst, a_src = gat_scores(hfeat, att2, H, C)
         d = graph.by_dst
         m, s = gat_softmax_stats(d, a_dst, a_src, H, slope)
-        out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias)
+        fused = GAT_FUSED_BACKWARD and H == 1 and C <= 256 and C % 4 == 0 and any(ctx.needs_input_grad[:4])
+        # one head: the forward also stores alpha of every entry (by-target order) -- the backward reads it back
+        alpha = torch.empty(max(d.nnz_max, 1), dtype=torch.float32, device=x.device) if fused else None
+        out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias, alpha=alpha)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
         ctx.has_bias = bias is not None
+        ctx.fused = fused
         ctx.save_for_backward(x, weight, att2, hfeat, a_dst, a_src, m, s, out,
-                              bias if bias is not None else torch.empty(0, device=x.device))
+                              bias if bias is not None else torch.empty(0, device=x.device),
+                              alpha if fused else torch.empty(0, device=x.device))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight, att2, hfeat, a_dst, a_src, m, s, out, bias = ctx.saved_tensors
+        x, weight, att2, hfeat, a_dst, a_src, m, s, out, bias, alpha_fwd = ctx.saved_tensors
         graph: CSRGraph = ctx.graph
         H, C, slope = ctx.H, ctx.C, ctx.slope
         dev = x.device
@@ -523,6 +549,25 @@ class _GatConvFn(torch.autograd.Function):
         db = colsum(grad_out) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
         # D_i = <dOut_i, out_i - b> = sum_p alpha_p dalpha_p  (softmax backward)
         D = gat_rowdot(grad_out, out, bias if ctx.has_bias else None, H, C)
+        if ctx.fused:
+            N = graph.num_nodes
+            tm = _transpose_map(graph)
+            dz = torch.empty(max(sr.nnz_max, 1), dtype=torch.float32, device=dev)
+            dh = torch.empty((N, C), dtype=torch.float32, device=dev)
+            check(load().npi_gat_backward_fused(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N, sr.nnz_max,
+                                                ptr(grad_out), grad_out.stride(0), ptr(hfeat), hfeat.stride(0), ptr(dh),
+                                                dh.stride(0), C, ptr(a_dst), ptr(a_src), ptr(D), slope, ptr(alpha_fwd), ptr(tm),
+                                                ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)), "npi_gat_backward_fused")
+            dz = dz.view(-1, 1)
+            g_src = seg_rowsum(sr, dz, 1)                                         # dz is in by-source entry order here
+            g_dst = seg_rowsum(d, dz, 1, map_=_inverse_transpose_map(graph))
+            # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
+            check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), N, 1, C, stream_ptr(dev)),
+                  "npi_gat_rank1_add")
+            datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C) if ctx.needs_input_grad[2] else None
+            dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+            dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
+            return dx, dw, datt, db, None, None, None
         # dz per by-target entry, then its row sums in both orientations;
         # one head: keep the alpha this kernel computes; the by-source pass reads it back through the transpose map
         alpha = torch.empty((max(d.nnz_max, 1), H), dtype=torch.float32, device=dev) if H == 1 else None
