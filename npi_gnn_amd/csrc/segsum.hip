@@ -268,6 +268,8 @@ segsum_kernel(SegParams P) {
         float wv = 1.f;
         if (WMODE == W_ARRAY) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
         if (WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
+        int avec = 0;                    // W_GAT_DST + alpha_out: alpha of entry kb + l collects in lane l, stored once per block
+        const bool keep_alpha = WMODE == W_GAT_DST && P.alpha_out != nullptr;
         int j = 0;
         for (; j + U <= nb; j += U) {
             float v[U][NCH][VEC];
@@ -302,7 +304,8 @@ segsum_kernel(SegParams P) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
-                    if (WMODE == W_GAT_DST && c == 0 && P.alpha_out != nullptr && lane == 0) P.alpha_out[k] = we * rs_i[0];
+                    if (keep_alpha && c == 0)       // one head: every lane holds the same weight
+                        avec = (lane == j + u) ? __float_as_int(we * rs_i[0]) : avec;
 #pragma unroll
                     for (int q = 0; q < VEC; ++q)
                         acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[u][c][q]) : fmaf(we, v[u][c][q], acc[c][q]);
@@ -356,7 +359,8 @@ segsum_kernel(SegParams P) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
-                if (WMODE == W_GAT_DST && c == 0 && P.alpha_out != nullptr && lane == 0) P.alpha_out[k] = we * rs_i[0];
+                if (keep_alpha && c == 0)
+                    avec = (lane == j) ? __float_as_int(we * rs_i[0]) : avec;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q)
                     acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[c][q]) : fmaf(we, v[c][q], acc[c][q]);
@@ -370,6 +374,7 @@ segsum_kernel(SegParams P) {
                 if (lane == 0) pb[j] = p;
             }
         }
+        if (keep_alpha && lane < nb) P.alpha_out[kb + lane] = __int_as_float(avec);      // one coalesced store per 64 entries
         if (WMODE == W_GAT_SRC_FUSED) {
             // all 64 lanes turn the block's dots into dz together: dz = alpha (dot - D_i) leaky_relu'(a_dst[i] + a_src[j])
             __builtin_amdgcn_wave_barrier();
