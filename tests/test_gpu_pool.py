@@ -313,3 +313,37 @@ def test_pooling_without_a_device_read_when_graph_sizes_are_known(dev):
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.equal(l0, l1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+def test_padded_edge_lists_edge_cases(dev):
+    """The no-read pooling path on degenerate inputs: single-node graphs, a batch whose every edge is dropped (the next conv
+    then sees nothing but padding and aggregates each node with itself), ratio 1.0, and an empty key list for the sizes query."""
+    from npi_gnn_amd.subgraph import InteractionGraph
+    g = torch.Generator().manual_seed(9)
+    sizes = torch.tensor([1, 2, 5, 1, 7])
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(5), sizes)
+    x = torch.randn(n, 12, generator=g)
+    # edges only between the two nodes of graph 1: with ratio 0.5 one of them is dropped -> no edge survives
+    ei = torch.tensor([[1, 2], [2, 1]])
+    w = torch.randn(1, 12, generator=g)
+    ref = R.topk_pool(x, ei, batch, w, 0.5)
+    b2 = batch.to(dev)
+    b2._npi_sizes = sizes
+    got = NP.topk_pool(x.to(dev), ei.to(dev), b2, w.to(dev), 0.5)
+    assert torch.equal(got[4].cpu(), ref[3]) and got[1].shape == (2, 2) and bool((got[1] == -1).all()) and ref[1].numel() == 0
+    assert torch.equal(got[3]._npi_sizes, torch.tensor([1, 1, 3, 1, 4]))
+    conv = npi.SAGEConv(12, 8).to(dev)
+    out = conv(got[0], got[1])                                   # only padding: every node aggregates itself
+    assert torch.allclose(out, got[0] @ conv.weight + conv.bias, atol=1e-5)
+    # second pooling layer on the padded list, ratio 1.0 keeps everything
+    got2 = NP.topk_pool(got[0], got[1], got[3], torch.randn(1, 12, generator=g).to(dev), 1.0)
+    assert got2[0].size(0) == got[0].size(0) and bool((got2[1] == -1).all())
+    # sizes of an empty key list; size hints for one key
+    ig = InteractionGraph(torch.tensor([[0, 3], [1, 3], [1, 4]]).to(dev), torch.tensor([True, True, True]).to(dev),
+                          torch.randn(5, 6, generator=g).to(dev))
+    nodes, pairs = ig.sizes(torch.zeros((0, 2), dtype=torch.long, device=dev))
+    assert nodes.numel() == 0 and pairs.numel() == 0
+    nodes, pairs = ig.sizes(torch.tensor([[1, 3]], device=dev))
+    xb, eb, bb = ig.batch(torch.tensor([[1, 3]], device=dev), n_nodes=int(nodes[0]), n_pairs=int(pairs[0]))
+    assert xb.size(0) == int(nodes[0]) == 4 and eb.size(1) == 2 * int(pairs[0]) == 6        # rna 1, protein 3, rna 0, protein 4
