@@ -361,6 +361,57 @@ class _GcnConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _GcnAggFirstFn(torch.autograd.Function):
+    """The same GCNConv evaluated as ``(A_hat x) W + b`` instead of ``A_hat (x W) + b`` -- identical up to fp32 rounding.
+    Aggregating FIRST (at width F_in <= F_out) gives the layer SAGEConv's schedule: the aggregate is saved, so the
+    weight gradient ``agg^T dOut`` (with ``db`` fused) no longer waits for the backward aggregation and runs on the matrix
+    cores UNDER it (second stream), and the aggregations run at the narrower width (C3's first layer: 178 instead of 256)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, norm: GCNNorm):
+        graph = norm.graph
+        agg = segsum(graph, graph.by_dst, x, w=norm.by_dst)                    # sum_e norm_e x[src]
+        out = linear_fwd(agg, weight, bias)
+        ctx.norm = norm
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(agg, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        agg, weight = ctx.saved_tensors
+        norm: GCNNorm = ctx.norm
+        graph = norm.graph
+        grad_out = _fc(grad_out, "grad_out", agg)
+        dx = dw = db = None
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        want_x = ctx.needs_input_grad[0]
+        overlap = want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS
+        if want_w and not overlap:
+            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
+        if want_x:
+            dagg = linear_bwd_data(grad_out, weight)
+            if overlap:                                                        # see _SageConvFn.backward
+                dev = grad_out.device
+                main = torch.cuda.current_stream(dev)
+                side = _side_stream(dev)
+                side.wait_stream(main)
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True)
+                with torch.cuda.stream(side):
+                    dx = segsum(graph, graph.by_src, dagg, w=norm.by_src)
+                dagg.record_stream(side)
+                dx.record_stream(main)
+                main.wait_stream(side)
+            else:
+                dx = segsum(graph, graph.by_src, dagg, w=norm.by_src)
+        return dx, dw, db, None
+
+
+# GCNConv: aggregate first when the input is not wider than the output (see _GcnAggFirstFn); NPI_GCN_AGG_FIRST=0 keeps PyG's
+# literal order (project, then aggregate) everywhere
+GCN_AGG_FIRST = os.environ.get("NPI_GCN_AGG_FIRST", "1") != "0"
+
+
 def gcn_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
              edge_weight: Optional[torch.Tensor] = None, improved: bool = False,
              norm: Optional[GCNNorm] = None) -> torch.Tensor:
@@ -370,6 +421,8 @@ def gcn_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[t
         raise NotImplementedError("gradients w.r.t. edge_weight are not implemented")
     if norm is None:
         norm = GCNNorm(as_graph(edge_index, x.size(0)), edge_weight, improved)
+    if GCN_AGG_FIRST and weight.size(0) <= weight.size(1):
+        return _GcnAggFirstFn.apply(x, weight, bias, norm)
     return _GcnConvFn.apply(x, weight, bias, norm)
 
 
