@@ -45,32 +45,43 @@ def main():
     ap.add_argument("--epochs", type=int, default=50)
     ap.add_argument("--batch", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--fold", type=int, default=0, choices=[0, 1])
+    ap.add_argument("--fold", default="0", choices=["0", "1", "2", "3", "4", "all"],
+                    help="fold of the reference's five-fold cross-validation; `all` runs the five one after the other")
     ap.add_argument("--no-train-eval", action="store_true", help="skip the metrics on the training loader")
     ap.add_argument("--capture", action="store_true",
                     help="replay every batch's training step from a HIP graph after the first epoch (net1.GraphedEpoch)")
     ap.add_argument("--json", action="store_true", help="print a one-line JSON summary at the end")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    torch.manual_seed(a.seed)
-    ig, train_keys, train_y, test_keys, test_y, F_in, fx = load_fold(dev, a.fold)
-    g = torch.Generator().manual_seed(a.seed)
-    train_loader = net1.KeyLoader(ig, train_keys, train_y, a.batch).shuffle(g)         # train_dataset.shuffle()
-    test_loader = net1.KeyLoader(ig, test_keys, test_y, a.batch).shuffle(g)            # test_dataset.shuffle()
-    print('number of samples in testing dataset：', len(test_loader.dataset), 'number of samples in training dataset：',
-          len(train_loader.dataset))
-    model = net1.Net_1(F_in, 2).to(dev)
-    res = net1.fit(model, train_loader, test_loader, dev, num_of_epoch=a.epochs, eval_train=not a.no_train_eval,
-                   capture=a.capture)
+    folds = range(5) if a.fold == "all" else [int(a.fold)]
+    summary = []
+    for fold in folds:
+        torch.manual_seed(a.seed + fold)
+        ig, train_keys, train_y, test_keys, test_y, F_in, fx = load_fold(dev, fold)
+        g = torch.Generator().manual_seed(a.seed + fold)
+        train_loader = net1.KeyLoader(ig, train_keys, train_y, a.batch).shuffle(g)         # train_dataset.shuffle()
+        test_loader = net1.KeyLoader(ig, test_keys, test_y, a.batch).shuffle(g)            # test_dataset.shuffle()
+        print(f'fold {fold}: number of samples in testing dataset：', len(test_loader.dataset),
+              'number of samples in training dataset：', len(train_loader.dataset))
+        model = net1.Net_1(F_in, 2).to(dev)
+        res = net1.fit(model, train_loader, test_loader, dev, num_of_epoch=a.epochs, eval_train=not a.no_train_eval,
+                       capture=a.capture)
+        logged = fx[f"fold{fold}"].get("logged_metrics")
+        summary.append({"fold": fold, "seconds": res["seconds"], "test_acc": res["test"][0], "test_mcc": res["test"][4],
+                        "lr_steps": res["lr_steps"], "reference_test_acc": float(logged[0]) if logged else None})
+        del model, ig, train_loader, test_loader
+        torch.cuda.empty_cache()
     ref = fx["fold0"]
     lo, hi = min(ref["logged_test_acc_5fold_epoch50"]), max(ref["logged_test_acc_5fold_epoch50"])
+    total = sum(s_["seconds"] for s_ in summary)
+    mean_acc = sum(s_["test_acc"] for s_ in summary) / len(summary)
     print(f"reference (result/1223_1/log_*.txt): {ref['logged_wall_seconds']:.1f} s for fold 0, test accuracy at epoch 50 "
-          f"{lo:.5f}-{hi:.5f} over the five folds; this run: {res['seconds']:.1f} s, test accuracy {res['test'][0]:.5f}, "
-          f"lr stepped {res['lr_steps']} times")
+          f"{lo:.5f}-{hi:.5f} over the five folds (mean {sum(ref['logged_test_acc_5fold_epoch50']) / 5:.5f}); this run: "
+          f"{total:.1f} s for {len(summary)} fold(s), test accuracy " + ", ".join(f"{s_['test_acc']:.5f}" for s_ in summary) +
+          f" (mean {mean_acc:.5f})")
     if a.json:
-        print(json.dumps({"seconds": res["seconds"], "test_acc": res["test"][0], "test_mcc": res["test"][4],
-                          "epochs": a.epochs, "captured": a.capture, "lr_steps": res["lr_steps"], "reference_seconds": ref["logged_wall_seconds"],
-                          "reference_acc_range": [lo, hi]}))
+        print(json.dumps({"seconds": total, "test_acc": mean_acc, "folds": summary, "epochs": a.epochs, "captured": a.capture,
+                          "reference_seconds": ref["logged_wall_seconds"], "reference_acc_range": [lo, hi]}))
 
 
 if __name__ == "__main__":

@@ -11,6 +11,8 @@ regime end to end:
   fold 1   node2vec block (training_1), test keys, checkpoint model_1_fold/15 and the 2,083 per-sample P(positive)
            the reference logged for the fold's test negatives
            (data/case_study/1223_1_fold_1_negativeSamples_threshold_0.99/logs, src/case_study_negativeSample.py:337-355)
+  folds 2-4  node2vec blocks, test keys and the logged epoch-50 test metrics (result/1223_1/log_k.txt): the inputs of the
+           reference's five-fold cross-validation, for examples/train_npinter2.py --fold all
 
 Before anything is written the CPU oracle (oracle/kat.py + oracle/ref_conv.py) must reproduce both: the confusion
 matrix exactly and every probability to 1e-5.  Only data is stored: no reference source text.
@@ -74,6 +76,14 @@ def main():
     f1 = fold_block(p1)
     f1.update(state_dict=sd1, p_positive_logged=p_ref, case=case)
     out["fold1"] = f1
+    # folds 2-4: inputs and the reference's logged epoch-50 test metrics only (five-fold cross-validation of the example)
+    for k in (2, 3, 4):
+        pk = kat.Project("NPInter2", "1223_1", k)
+        assert pk.pos == p0.pos and pk.neg == p0.neg
+        fk = fold_block(pk)
+        fk.update(logged_metrics=kat.logged_metrics("1223_1", k, 50))
+        out[f"fold{k}"] = fk
+    out["fold1"]["logged_metrics"] = kat.logged_metrics("1223_1", 1, 50)
     out["source"] = ("NPInter2.xlsx, data/set_allInteractionKey/1223_1, data/node2vec_result/1223_1/training_{0,1}, "
                      "data/lncRNA_3_mer + protein_2_mer; result/1223_1/model_0_fold/50, model_1_fold/15, log_*.txt; "
                      f"data/case_study/{case}/logs")

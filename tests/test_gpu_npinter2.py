@@ -75,3 +75,18 @@ def test_reference_training_loop_on_the_real_fold(dev, ex):
     res = net1.fit(model, train_loader, test_loader, dev, num_of_epoch=3, log=lambda s: None, eval_train=False)
     assert res["loss"][-1] < res["loss"][0]
     assert res["test"][0] > 0.85                              # reference: 0.934 at epoch 5 (log_0.txt)
+
+
+def test_every_fold_of_the_cross_validation_is_loadable(dev, ex):
+    """The fixture carries the inputs of all five folds (examples/train_npinter2.py --fold all): 4/5 of the 20,824 pairs train,
+    1/5 test, the test keys never usable as context (src/generate_dataset.py:296-299), logged reference accuracy per fold."""
+    seen = set()
+    for fold in range(5):
+        ig, train_keys, train_y, test_keys, test_y, F_in, fx = ex.load_fold(dev, fold)
+        assert F_in == 178 and train_keys.size(0) + test_keys.size(0) == 20824
+        assert test_keys.size(0) in (4166, 4164) and int(test_y.sum()) * 2 == test_keys.size(0)
+        codes = set((test_keys[:, 0] * 5085 + test_keys[:, 1]).tolist())
+        assert not (codes & seen)                                   # the folds' test sets are disjoint
+        seen |= codes
+        assert 0.92 < float(fx[f"fold{fold}"]["logged_metrics"][0]) < 0.95
+    assert len(seen) == 20824
