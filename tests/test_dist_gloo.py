@@ -200,6 +200,8 @@ def _reference(layer_kind, ei, x, W, b, go, Fd):
     (2, 203, "bipartite", "gat1"), (3, 160, "bipartite", "gat2"), (3, 64, "any", "gat1"), (8, 333, "bipartite", "gat1"),
     (2, 120, "auto", "gat4"),
     (2, 101, "any", "edges"), (3, 160, "bipartite", "edges"), (8, 333, "bipartite", "edges"),
+    # fewer hubs than ranks (5 proteins, 8 ranks: three ranks own no hub row at all)
+    (8, 40, "bipartite", "sage"), (8, 40, "bipartite", "gcn"), (8, 40, "bipartite", "gat1"),
 ])
 def test_sharded_layer_matches_single_process_oracle(world, N, kind, layer_kind):
     E, Fd = 900, 16
