@@ -424,20 +424,28 @@ def _exchange_start(sg: ShardedGraph, rows: torch.Tensor, side_b, w_b=None):
 
 
 class _ShardedSageFn(torch.autograd.Function):
+    """Aggregate, then project.  ``gcn = False``: SAGEConv (mean over in-neighbours and self).  ``gcn = True``: GCNConv in
+    the same order, ``(A_hat x) W + b`` with the symmetric normalisation as per-entry weights (see
+    functional._GcnAggFirstFn: identical to PyG's ``A_hat (x W) + b`` up to rounding, dW overlaps the backward aggregation)."""
+
     @staticmethod
-    def forward(ctx, x_own, weight, bias, sg: ShardedGraph):
+    def forward(ctx, x_own, weight, bias, sg: ShardedGraph, gcn: bool = False):
         be = sg.backend
         x_own = x_own.contiguous()
-        table, g_work, hsum, r_work = _exchange_start(sg, x_own, sg.B)
+        nrm = sg.gcn_norm() if gcn else {"A": None, "B": None}
+        table, g_work, hsum, r_work = _exchange_start(sg, x_own, sg.B, nrm["B"])
         _wait(g_work, "fwd_all_gather", table)
-        agg = be.segsum(sg.A, table, mean=True, table2=x_own)
+        agg = be.segsum(sg.A, table, mean=not gcn, table2=x_own, w=nrm["A"])
         if hsum is not None:
             _wait(r_work, "fwd_reduce_scatter", hsum)
-            if sg.nH:
+            if sg.nH and gcn:
+                agg[sg.nL:] += hsum[: sg.nH]
+            elif sg.nH:
                 inv = sg.inv_cnt[sg.nL:].view(-1, 1)
                 agg[sg.nL:] = (agg[sg.nL:] * sg.cnt_a_hub + hsum[: sg.nH]) * inv
         out = be.linear_fwd(agg, weight, bias)
         ctx.sg = sg
+        ctx.gcn = gcn
         ctx.has_bias = bias is not None
         ctx.save_for_backward(agg, weight)
         return out
@@ -452,8 +460,9 @@ class _ShardedSageFn(torch.autograd.Function):
         dagg = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
+        nrm = sg.gcn_norm() if ctx.gcn else {"At": None, "Bt": None}
         if want_x:
-            dagg = be.linear_bwd_data(grad_out, weight, sg.inv_cnt)
+            dagg = be.linear_bwd_data(grad_out, weight, None if ctx.gcn else sg.inv_cnt)
         # dW is independent of the dX chain.  On the GPU backend it is launched FIRST, on this stream, so that it is resident
         # before the aggregations -- BOTH sides, sent to a second stream -- fill the CUs (see functional._SageConvFn); with
         # side B in front of dW, as in round 1, half of the aggregation ran alone and dW then outlasted the other half
@@ -467,9 +476,9 @@ class _ShardedSageFn(torch.autograd.Function):
                 be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
         if want_x:
             def chain():
-                table, g_work, hsum, r_work = _exchange_start(sg, dagg, sg.Bt)
+                table, g_work, hsum, r_work = _exchange_start(sg, dagg, sg.Bt, nrm["Bt"])
                 _wait(g_work, "bwd_all_gather", table)
-                out = be.segsum(sg.At, table, table2=dagg)
+                out = be.segsum(sg.At, table, table2=dagg, w=nrm["At"])
                 if hsum is not None:
                     _wait(r_work, "bwd_reduce_scatter", hsum)
                     if sg.nH:
@@ -489,7 +498,7 @@ class _ShardedSageFn(torch.autograd.Function):
             _all_reduce(dw, sg.world, sg.group, tag="bwd_all_reduce_dw")
             if db is not None:
                 _all_reduce(db, sg.world, sg.group, tag="bwd_all_reduce_db")
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _ShardedGcnFn(torch.autograd.Function):
@@ -688,6 +697,8 @@ class ShardedGCNLayer(_ShardedLayer):
     """GCNConv (PyG 1.4.2: ``improved=False, normalize=True``, no edge weights) on a sharded graph."""
 
     def forward(self, x_own: torch.Tensor) -> torch.Tensor:
+        if self.weight.size(0) <= self.weight.size(1):          # aggregate first: dW overlaps the backward aggregation
+            return _ShardedSageFn.apply(x_own, self.weight, self.bias, self.sg, True)
         return _ShardedGcnFn.apply(x_own, self.weight, self.bias, self.sg)
 
 
