@@ -150,9 +150,11 @@ def _worker(rank, world, port, N, E, Fd, kind, layer_kind, q):
             xl = x.clone().requires_grad_(True)                    # replicated input
         else:
             sg = ND.ShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub)
+            if layer_kind == "gcnN":                            # F_in > F_out: PyG's literal order (project, then aggregate)
+                W, b, go = W[:, : Fd // 2].contiguous(), b[: Fd // 2].contiguous(), go[:, : Fd // 2].contiguous()
             if layer_kind == "sage":
                 layer = ND.ShardedSAGELayer(sg, W, b)
-            elif layer_kind == "gcn":
+            elif layer_kind in ("gcn", "gcnN"):
                 layer = ND.ShardedGCNLayer(sg, W, b)
             else:
                 H = int(layer_kind[3:])
@@ -181,8 +183,10 @@ def _free_port():
 def _reference(layer_kind, ei, x, W, b, go, Fd):
     if layer_kind in ("sage", "edges"):
         return R.sage_layer_fwd_bwd(x, ei, W, b, go)
+    if layer_kind == "gcnN":
+        W, b, go = W[:, : Fd // 2].contiguous(), b[: Fd // 2].contiguous(), go[:, : Fd // 2].contiguous()
     xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
-    if layer_kind == "gcn":
+    if layer_kind in ("gcn", "gcnN"):
         out = R.gcn_conv(xr, ei, Wr, br)
         out.backward(go)
         return out.detach(), xr.grad, Wr.grad, br.grad
@@ -202,6 +206,7 @@ def _reference(layer_kind, ei, x, W, b, go, Fd):
     (2, 101, "any", "edges"), (3, 160, "bipartite", "edges"), (8, 333, "bipartite", "edges"),
     # fewer hubs than ranks (5 proteins, 8 ranks: three ranks own no hub row at all)
     (8, 40, "bipartite", "sage"), (8, 40, "bipartite", "gcn"), (8, 40, "bipartite", "gat1"),
+    (3, 160, "bipartite", "gcnN"), (2, 101, "any", "gcnN"),
 ])
 def test_sharded_layer_matches_single_process_oracle(world, N, kind, layer_kind):
     E, Fd = 900, 16
