@@ -279,9 +279,10 @@ def test_sage_direction_on_directed_toy(dev):
     assert out.tolist() == [[1.0, 10.0], [2.0, 20.0], [3.0, 30.0]]
 
 
+@pytest.mark.parametrize("Fi,Fo", [(178, 256), (178, 64)])      # (A x) W when F_in <= F_out, A (x W) otherwise
 @pytest.mark.parametrize("weighted,improved", [(False, False), (True, False), (False, True)])
-def test_gcn_conv_fwd_bwd_matches_oracle(dev, weighted, improved):
-    N, E, Fi, Fo = 3000, 25000, 178, 256
+def test_gcn_conv_fwd_bwd_matches_oracle(dev, weighted, improved, Fi, Fo):
+    N, E = 3000, 25000
     ei, x, W, b, go = _layer_case(N, E, Fi, Fo, 9, symmetric=not weighted)
     ew = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(1)) + 0.1 if weighted else None
     xr = x.clone().requires_grad_(True)
