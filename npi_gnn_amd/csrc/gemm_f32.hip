@@ -591,29 +591,35 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
 template <int TM, int TN>
 __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
                                              const f32x16 (&acc)[TM][TN], const float* __restrict__ bias_lds /* this wave's
-                                             first column, or null */, const float (&rs)[TM], bool relu_on) {
+                                             first column (zeros without a bias) */, const float (&rs)[TM], float floor_) {
     // bias comes from an LDS copy made once per workgroup and the row scales were fetched at the start of the
-    // tile: a global load here would put a full memory round trip in front of every tile's stores
+    // tile: a global load here would put a full memory round trip in front of every tile's stores.  No branch in
+    // here (a missing bias is a row of zeros, no ReLU is a floor of -inf): with one, every 16-byte store waited for
+    // its own LDS read of the bias -- 32 round trips per tile.
+    float* __restrict__ crow[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        float* __restrict__ crow = C + (int64_t)(mw + i * 32 + li) * ldc + nw + 4 * lh;
+    for (int i = 0; i < TM; ++i) crow[i] = C + (int64_t)(mw + i * 32 + li) * ldc + nw + 4 * lh;
+    // one bias read per 16-byte column group, shared by the row blocks and issued one group ahead of its use
+    float4 b = *reinterpret_cast<const float4*>(bias_lds + 4 * lh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+    for (int jg = 0; jg < 4 * TN; ++jg) {
+        const int j = jg >> 2, g = jg & 3;
+        const int jn = (jg + 1) >> 2, gn = (jg + 1) & 3;
+        float4 bn = b;
+        if (jg + 1 < 4 * TN) bn = *reinterpret_cast<const float4*>(bias_lds + jn * 32 + 8 * gn + 4 * lh);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + j * 32 + 8 * g + 4 * lh)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 v;
-                v.x = fmaf(acc[i][j][4 * g + 0], rs[i], b.x);
-                v.y = fmaf(acc[i][j][4 * g + 1], rs[i], b.y);
-                v.z = fmaf(acc[i][j][4 * g + 2], rs[i], b.z);
-                v.w = fmaf(acc[i][j][4 * g + 3], rs[i], b.w);
-                if (relu_on) {                               // keeps NaN, like torch.relu
-                    v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
-                    v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
-                }
-                *reinterpret_cast<float4*>(crow + j * 32 + 8 * g) = v;       // (non-temporal stores: 13 % slower)
-            }
+        for (int i = 0; i < TM; ++i) {
+            float4 v;
+            v.x = fmaf(acc[i][j][4 * g + 0], rs[i], b.x);
+            v.y = fmaf(acc[i][j][4 * g + 1], rs[i], b.y);
+            v.z = fmaf(acc[i][j][4 * g + 2], rs[i], b.z);
+            v.w = fmaf(acc[i][j][4 * g + 3], rs[i], b.w);
+            // keeps NaN, like torch.relu
+            v.x = v.x < floor_ ? floor_ : v.x; v.y = v.y < floor_ ? floor_ : v.y;
+            v.z = v.z < floor_ ? floor_ : v.z; v.w = v.w < floor_ ? floor_ : v.w;
+            *reinterpret_cast<float4*>(crow[i] + j * 32 + 8 * g) = v;        // (non-temporal stores: 13 % slower)
+        }
+        b = bn;
     }
 }
 
@@ -636,6 +642,22 @@ __device__ __forceinline__ void split3_store16(f32x4r lo, f32x4r hi, char* img, 
     *reinterpret_cast<uint4*>(img + plane) = make_uint4(a1, b1, c1, d1);
     *reinterpret_cast<uint4*>(img + 2 * plane) = make_uint4(a2, b2, c2, d2);
 }
+// measurement switches of gemm_split_ws_kernel (tools/build_variant.sh <name> -DNPI_WS_PROBE=<bits>; timing only, wrong
+// numbers): 1 = one MFMA per tile pair instead of six, 2 = no split arithmetic in the producer (plain bf16 pack into all
+// three planes), 4 = no C stores, 8 = the producer stores nothing to LDS (hand-over only), 32 = no global loads of A,
+// 64 = no global loads of the weight planes (stale registers are stored)
+// 16 = cycle stamps: npi_ws_probe_read() returns, summed over the workgroups, the cycles producer wave 4 spent waiting for
+// an empty stage / for its loads / splitting + storing, its total, and consumer wave 0's wait for a full stage / epilogue /
+// total, and the k-steps counted
+#ifndef NPI_WS_PROBE
+#define NPI_WS_PROBE 0
+#endif
+#if NPI_WS_PROBE & 16
+__device__ unsigned long long npi_ws_probe_acc[8];
+#define NPI_STAMP() __builtin_readcyclecounter()
+#else
+#define NPI_STAMP() 0ull
+#endif
 struct SplitArgs {
     const float* A; int64_t lda;
     const uint16_t* Bp;      // [3][K/16][N][16]
@@ -681,6 +703,91 @@ __device__ __forceinline__ void wait_ge(int* flag, int target) {
 __device__ __forceinline__ void signal(int* flag) {      // one count per wave, after the wave's LDS traffic is complete
     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
     if (lane_id() == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One k-step of a consumer wave of the split kernels, software-pipelined by hand.  The six products of a 32 x 32 tile pair
+// are 192 matrix-pipe cycles, a k-step 48 MFMAs = 1,536; the fragment reads of the NEXT step are issued between the blocks
+// of this one, into the very registers the finished block just freed (no second fragment set: 128 accumulator + 72
+// fragment registers is what two waves per SIMD allow), so that their LDS round trip -- and the poll of the next stage's
+// counter -- runs under MFMAs instead of in front of them.  (Reads first, then 48 MFMAs, as hipcc schedules the plain loop:
+// 2,060 cycles per step, the matrix pipe idle for a quarter of it.)  Column block j's B fragments are dead after the
+// block; the A fragments of row block i after ITS six MFMAs of the last column block, so A(0) is refilled half a block
+// before the step ends and A(1) at its end -- the next step starts with the row-block-0 MFMAs, which need only A(0).
+// The six products of a tile pair keep their order (small terms first): results are bit-identical to the plain loop.
+//   entry: this step's fragments are in registers or in flight;  exit: the next step's (`more`), stage handed back.
+// The fragment reads and their waits are assembly: hipcc's own lgkmcnt bookkeeping joins the loop's state with the
+// tile-start path (scalar loads pending there) and falls back to lgkmcnt(0) in front of the first MFMA of every step,
+// i.e. waits for the reads issued a few cycles earlier.  LDS operations complete in order, so "at most n younger ones
+// outstanding" is exact.  Issue order per step: B(0) | B(1) | ... | A(0) | A(1), B(TN-1)  (three planes each).
+#define NPI_DSR(dst, addr, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory")
+template <int PL>
+__device__ __forceinline__ void ws_read3(bf16x8 (&f)[3], uint32_t addr) {
+    NPI_DSR(f[0], addr, 0); NPI_DSR(f[1], addr, PL); NPI_DSR(f[2], addr, 2 * PL);
+}
+// at most N fragment reads still outstanding; the fragments are in/out operands so that no use moves above the wait
+#define NPI_LGKM_WAIT(N, F) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : : "memory")
+
+template <int TM, int TN, int APL, int BPL, int BUF, int NST, bool ONE_MMA = false>
+__device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, int* empty, int g, bool more,
+                                                const int (&offa)[TM], const int (&offb)[TN], bf16x8 (&af)[TM][3],
+                                                bf16x8 (&bf)[TN][3], f32x16 (&acc)[TM][TN],
+                                                unsigned long long* t_wait = nullptr) {
+    static_assert(TM == 2, "the wait counts below assume two row blocks");
+    const int stg = g & (NST - 1), stn = (g + 1) & (NST - 1);
+    const uint32_t nx = lds_base + (uint32_t)(stn * BUF);
+    // the poll of the next stage's counter is issued here and looked at after the first column block: its LDS round trip
+    // (150-250 cycles behind the fragment reads of four waves) then runs under 12 MFMAs instead of stalling the pipe
+    int fullv;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(fullv) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)&full[stn]) : "memory");
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (j == 0 && i == 0) NPI_LGKM_WAIT(7, af[0]);        // younger: A(1) and B(TN-1) of this step, the poll
+            if (j == 0 && i == 1) NPI_LGKM_WAIT(4, af[1]);        // younger: B(TN-1), the poll
+            // B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t)
+            f32x16 c = acc[i][j];
+            if (!ONE_MMA) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][2], af[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][0], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][0], c, 0, 0, 0);
+            acc[i][j] = c;
+            __builtin_amdgcn_sched_barrier(0);           // row block by row block: the first one of a step needs only A(0)
+            if (j == TN - 1 && more) ws_read3<APL>(af[i], nx + (uint32_t)offa[i]);   // row block i is finished: refill its A
+        }
+        if (j == 0) {
+            // every read of this stage was issued during the previous step: this wait is free by now (it is also what
+            // makes B(1..TN-1) of this step safe to use, and the poll's value)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[TN - 1][0]), "+v"(bf[TN - 1][1]), "+v"(bf[TN - 1][2]), "+v"(fullv) : : "memory");
+            signal(&empty[stg]);
+            const unsigned long long t0_ = t_wait ? NPI_STAMP() : 0ull;
+            const int target = 4 * (((g + 1) >> 2) + 1);
+            if (more && __builtin_amdgcn_readfirstlane(fullv) < target) wait_ge(&full[stn], target);   // rare: the producer is behind
+            if (t_wait) *t_wait += NPI_STAMP() - t0_;
+            // (the acquire for the stage's data: wait_ge's atomic load on the slow path, program order after the poll's
+            // wait on the fast one -- LDS operations of a wave execute in order)
+        }
+        if (more) ws_read3<BPL>(bf[j], nx + (uint32_t)offb[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// first step's fragments (prologue of the pipeline above)
+template <int TM, int TN, int APL, int BPL>
+__device__ __forceinline__ void ws_consume_first(uint32_t st, const int (&offa)[TM], const int (&offb)[TN],
+                                                 bf16x8 (&af)[TM][3], bf16x8 (&bf)[TN][3]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ws_read3<BPL>(bf[j], st + (uint32_t)offb[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ws_read3<APL>(af[i], st + (uint32_t)offa[i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) NPI_LGKM_WAIT(0, bf[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) NPI_LGKM_WAIT(0, af[i]);
 }
 
 template <int TN>
@@ -752,10 +859,12 @@ gemm_split_ws_kernel(SplitArgs a) {
         const char* gb0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * a.N + wl.nt * BN) * (SK * 2));     \
         const char* gb1 = uniform_ptr(gb0 + b_plane);                                                  \
         const char* gb2 = uniform_ptr(gb0 + 2 * b_plane);                                              \
-        NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0);                                          \
+        if constexpr ((NPI_WS_PROBE & 32) == 0) { NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0); }                          \
+        if constexpr ((NPI_WS_PROBE & 64) == 0) {                                                      \
         NPI_GL(S##b0, ob, gb0, 0); NPI_GL(S##b1, ob, gb1, 0); NPI_GL(S##b2, ob, gb2, 0);               \
         if constexpr (NB == 2) {                                                                       \
             NPI_GL(S##b3, ob, gb0, 16); NPI_GL(S##b4, ob, gb1, 16); NPI_GL(S##b5, ob, gb2, 16);        \
+        }                                                                                              \
         }                                                                                              \
         wl.next();                                                                                     \
     } while (0)
@@ -772,6 +881,14 @@ gemm_split_ws_kernel(SplitArgs a) {
 #define NPI_WSTORE(OFF, S)                                                                             \
     do {                                                                                               \
         if constexpr (NPI_SPLIT_A16) { split3_store16(S##a0, S##a1, la0 + (OFF), APL); (void)la1; }    \
+        else if constexpr ((NPI_WS_PROBE & 2) != 0) {                                                  \
+            const uint2 q0_ = make_uint2(pack_bf16(S##a0.x, S##a0.y), pack_bf16(S##a0.z, S##a0.w));    \
+            const uint2 q1_ = make_uint2(pack_bf16(S##a1.x, S##a1.y), pack_bf16(S##a1.z, S##a1.w));    \
+            for (int p_ = 0; p_ < 3; ++p_) {                                                           \
+                *reinterpret_cast<uint2*>(la0 + (OFF) + p_ * APL) = q0_;                               \
+                *reinterpret_cast<uint2*>(la1 + (OFF) + p_ * APL) = q1_;                               \
+            }                                                                                          \
+        }                                                                                              \
         else { split3_store(S##a0, la0 + (OFF), APL); split3_store(S##a1, la1 + (OFF), APL); }         \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF)) = S##b0;                                               \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF) + BPL) = S##b1;                                         \
@@ -785,12 +902,19 @@ gemm_split_ws_kernel(SplitArgs a) {
         // one k-step: refill the set freed by the previous step, split + store set CUR
 #define NPI_WSTEP(ST, CUR, FREE)                                                                       \
         NPI_WLOAD(FREE);                                                                               \
+        pt0 = NPI_STAMP();                                                                             \
         if (round > 0) wait_ge(&empty[ST], 4 * round);       /* the consumers are done with this stage's previous use */ \
+        pt1 = NPI_STAMP();                                                                             \
         NPI_WWAIT(CUR);                                                                                \
-        NPI_WSTORE((ST) * BUF, CUR);                                                                   \
+        pt2 = NPI_STAMP();                                                                             \
+        if constexpr ((NPI_WS_PROBE & 8) == 0) NPI_WSTORE((ST) * BUF, CUR);                            \
         signal(&full[ST]);                                                                             \
+        pt3 = NPI_STAMP();                                                                             \
+        pa_empty += pt1 - pt0; pa_vm += pt2 - pt1; pa_store += pt3 - pt2; ++pa_steps;                  \
         w.next();                                                                                      \
         if (!w.valid()) break
+        unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pa_empty = 0, pa_vm = 0, pa_store = 0, pa_steps = 0;
+        const unsigned long long p_begin = NPI_STAMP();
         NPI_WLOAD(r0);
         NPI_WLOAD(r1);
         NPI_WLOAD(r2);
@@ -806,6 +930,14 @@ gemm_split_ws_kernel(SplitArgs a) {
 #undef NPI_GL
 #undef NPI_WLOAD
 #undef NPI_WSTORE
+#if NPI_WS_PROBE & 16
+        if (t == 256) {
+            atomicAdd(&npi_ws_probe_acc[0], pa_empty); atomicAdd(&npi_ws_probe_acc[1], pa_vm);
+            atomicAdd(&npi_ws_probe_acc[2], pa_store); atomicAdd(&npi_ws_probe_acc[3], NPI_STAMP() - p_begin);
+            atomicAdd(&npi_ws_probe_acc[7], pa_steps);
+        }
+#endif
+        (void)pt0; (void)pt1; (void)pt2; (void)pt3; (void)pa_empty; (void)pa_vm; (void)pa_store; (void)pa_steps; (void)p_begin;
         return;
     }
 
@@ -829,8 +961,14 @@ gemm_split_ws_kernel(SplitArgs a) {
     float rs[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) rs[i] = 1.f;
-    const bool relu_on = a.ep.relu != 0;
+    const float floor_ = a.ep.relu != 0 ? 0.f : -__builtin_huge_valf();
     int g = 0;                                              // k-steps consumed so far: stage g % NST, use g / NST
+    bf16x8 af[TM][3], bf[TN][3];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned long long ca_wait = 0, ca_epi = 0;
+    const unsigned long long c_begin = NPI_STAMP();
+    wait_ge(&full[0], 4);
+    ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);
     while (w.valid()) {
         if (w.kt == 0) {
             // start of a tile: the row scales of this lane's rows and the bias of this wave's columns (into the
@@ -839,71 +977,24 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) rs[i] = a.ep.rowscale[w.mt * 128 + wm * 64 + i * 32 + li];
             }
-            if (a.ep.bias && w.nt != bias_nt) {             // only when the column block changes (never, for N = 64 TN): the
+            if (w.nt != bias_nt) {                          // only when the column block changes (once, for N = 64 TN): the
                 tsel ^= 1;                                  // copy waits on vmcnt(0), i.e. also on the previous tile's stores
                 bias_nt = w.nt;
-                for (int c = lane; c < 32 * TN; c += WAVE) bias_s[wave][tsel][c] = a.ep.bias[w.nt * BN + wn * (32 * TN) + c];
+                for (int c = lane; c < 32 * TN; c += WAVE)
+                    bias_s[wave][tsel][c] = a.ep.bias ? a.ep.bias[w.nt * BN + wn * (32 * TN) + c] : 0.f;
             }
         }
-        const int stg = g & (NST - 1);
-        wait_ge(&full[stg], 4 * ((g >> 2) + 1));            // all four producer waves have filled the stage
-        const char* st = lds + stg * BUF;
-        bf16x8 af[TM][3], bf[TN][3];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + offa[i] + p * APL);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + offb[j] + p * BPL);
-        // All 18 reads are issued above this point (the empty asm is a compiler barrier for memory operations);
-        // the first tile's MFMAs start as soon as THEIR fragments arrive, and the stage is handed back -- which
-        // needs every read complete -- while those MFMAs execute.
-        asm volatile("" ::: "memory");
-#define NPI_MMA6(I, J)                                                                                 \
-        do {                                                                                           \
-            f32x16 c = acc[I][J];                                                                      \
-            /* B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t) */ \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][2], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][2], af[I][0], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][1], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][1], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][0], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][0], c, 0, 0, 0);               \
-            acc[I][J] = c;                                                                             \
-        } while (0)
-#if NPI_MMA_INTERLEAVE
-#define NPI_MMA1(BP, AP)                                                                               \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][BP], af[i][AP], acc[i][j], 0, 0, 0)
-        NPI_MMA1(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        signal(&empty[stg]);                                 // every fragment read has returned by now
-        __builtin_amdgcn_sched_barrier(0);
-        NPI_MMA1(2, 0);
-        NPI_MMA1(1, 1);
-        NPI_MMA1(0, 1);
-        NPI_MMA1(1, 0);
-        NPI_MMA1(0, 0);
-#undef NPI_MMA1
-#else
-        NPI_MMA6(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        signal(&empty[stg]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (i + j > 0) NPI_MMA6(i, j);
-#endif
-#undef NPI_MMA6
+        TileWalk wn_ = w;
+        wn_.next();
+        ws_consume_step<TM, TN, APL, BPL, BUF, NST, (NPI_WS_PROBE & 1) != 0>(lds_base, full, empty, g, wn_.valid(), offa, offb, af, bf, acc,
+                                                                             (NPI_WS_PROBE & 16) ? &ca_wait : nullptr);
         ++g;
         if (w.kt == nk - 1) {
+            const unsigned long long e0_ = NPI_STAMP();
+            if ((NPI_WS_PROBE & 4) == 0 || acc[0][0][0] == 12345.678f)
             store_tile_t<TM, TN>(a.C, a.ldc, w.mt * 128 + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
-                                 a.ep.bias ? bias_s[wave][tsel] : nullptr, rs, relu_on);
+                                 bias_s[wave][tsel], rs, floor_);
+            ca_epi += NPI_STAMP() - e0_;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -911,8 +1002,15 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
         }
-        w.next();
+        w = wn_;
     }
+#if NPI_WS_PROBE & 16
+    if (t == 0) {
+        atomicAdd(&npi_ws_probe_acc[4], ca_wait); atomicAdd(&npi_ws_probe_acc[5], ca_epi);
+        atomicAdd(&npi_ws_probe_acc[6], NPI_STAMP() - c_begin);
+    }
+#endif
+    (void)ca_wait; (void)ca_epi; (void)c_begin;
 }
 
 // ---- dW on the bf16 matrix cores: both operands split on the fly --------------------------------------------------
@@ -1098,60 +1196,13 @@ gemm_dw_split_kernel(DwArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    for (int g = 0; g < nk; ++g) {
-        const int stg = g & (NST - 1);
-        wait_ge(&full[stg], 4 * ((g >> 2) + 1));
-        const char* st = lds + stg * BUF;
+    if (nk > 0) {
         bf16x8 af[TM][3], bf[TN][3];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + offa[i] + p * APL);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + offb[j] + p * BPL);
-        asm volatile("" ::: "memory");
-#define NPI_MMA6(I, J)                                                                                 \
-        do {                                                                                           \
-            f32x16 c = acc[I][J];                                                                      \
-            if (!(NPI_DW_PROBE & 4)) {                                                                 \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][2], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][2], af[I][0], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][1], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][1], c, 0, 0, 0);               \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][1], af[I][0], c, 0, 0, 0);               \
-            }                                                                                          \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[J][0], af[I][0], c, 0, 0, 0);               \
-            acc[I][J] = c;                                                                             \
-        } while (0)
-#if NPI_MMA_INTERLEAVE
-#define NPI_MMA1(BP, AP)                                                                               \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][BP], af[i][AP], acc[i][j], 0, 0, 0)
-        NPI_MMA1(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        signal(&empty[stg]);                                 // every fragment read has returned by now
-        __builtin_amdgcn_sched_barrier(0);
-        NPI_MMA1(2, 0);
-        NPI_MMA1(1, 1);
-        NPI_MMA1(0, 1);
-        NPI_MMA1(1, 0);
-        NPI_MMA1(0, 0);
-#undef NPI_MMA1
-#else
-        NPI_MMA6(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        signal(&empty[stg]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (i + j > 0) NPI_MMA6(i, j);
-#endif
-#undef NPI_MMA6
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+        wait_ge(&full[0], 4);
+        ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);
+        for (int g = 0; g < nk; ++g)
+            ws_consume_step<TM, TN, APL, BPL, BUF, NST, (NPI_DW_PROBE & 4) != 0>(lds_base, full, empty, g, g + 1 < nk, offa, offb, af, bf, acc);
     }
     // the tile of this slab (zeros when the slab holds no node: slab_reduce adds every slab)
     // Accumulator tile = C^T of the LDS-row grid: the lane owns LDS row li of the A image, its registers run along LDS rows
@@ -1540,6 +1591,14 @@ using namespace npi;
 static inline const float* fp(const void* p) { return reinterpret_cast<const float*>(p); }
 static inline const void* advance(const void* p, int64_t elems, int es) { return reinterpret_cast<const char*>(p) + elems * es; }
 
+#if NPI_WS_PROBE & 16
+extern "C" int npi_ws_probe_read(unsigned long long* out8) {          // measurement builds only: read and reset the stamps
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(npi_ws_probe_acc), sizeof(z)) != hipSuccess) return NPI_ERR_LAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(npi_ws_probe_acc), z, sizeof(z)) != hipSuccess) return NPI_ERR_LAUNCH;
+    return NPI_OK;
+}
+#endif
 extern "C" int npi_gemm_mode(int mode) {
     const int prev = g_gemm_mode;
     if (mode == 0 || mode == 1) g_gemm_mode = mode;
