@@ -197,6 +197,10 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
  *               (about 3 workgroups per 4 CUs), 0 = it has the GPU to itself (see npi_dw_shared) */
 #define NPI_GEMM_EXACT_F32 1
 #define NPI_GEMM_SPLIT_BF16 2
+/* npi_linear_fwd_ex / npi_linear_bwd_weight_ex, f32: A is stored with lda >= Kp (K rounded up to a multiple of 128) and its
+ * columns K .. Kp-1 are ZERO (W and dW keep K rows): the matrix-core kernels then run on Kp instead of the guarded kernel on
+ * an odd K (178 features in the reference's first layer).  Workspaces are queried with Kp. */
+#define NPI_GEMM_A_ZERO_PADDED 4
 int64_t npi_linear_workspace_bytes(int64_t K, int64_t N);
 int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                       const float* rowscale, void* C, int64_t ldc,
@@ -328,6 +332,10 @@ int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int
 int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
                     const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
                     float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream);
+/* the same; perm64 (may be NULL) receives perm as int64 -- the LongTensor TopKPooling returns -- without a cast launch */
+int npi_topk_gather_ex(const float* x, int64_t ldx, const float* score, const int64_t* batch,
+                    const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
+                    float* xo, int64_t ldo, int64_t* batch_o, float* score_o, int64_t* perm64, void* stream);
 int64_t npi_filter_adj_workspace_elems(int64_t E);
 int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                    int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, void* stream);
@@ -354,6 +362,15 @@ int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* graph_ptr, 
 int npi_topk_gather_bwd(const float* x, int64_t ldx, const float* score, const float* w, const int32_t* perm,
                         int64_t n_out, int64_t F, const float* dxo, int64_t lddxo, const float* dscore_o,
                         float* dx, int64_t lddx, float* dzv, float* dzz, void* stream);
+/* The forms the training step uses: no fill launch in front of them.
+ *   npi_topk_gather_bwd_ex     : one wave per INPUT row i of the N; remap[i] = its kept position p or -1 (npi_topk_select);
+ *                                dropped rows are written as zeros, so dx may come in uninitialised.
+ *   npi_readout_max_mean_bwd_ex: N = rows of x; rows outside [graph_ptr[0], graph_ptr[B]) are written as zeros. */
+int npi_topk_gather_bwd_ex(const float* x, int64_t ldx, const float* score, const float* w, const int32_t* remap,
+                           int64_t N, int64_t F, const float* dxo, int64_t lddxo, const float* dscore_o,
+                           float* dx, int64_t lddx, float* dzv, float* dzz, void* stream);
+int npi_readout_max_mean_bwd_ex(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
+                                const float* out, const float* dout, float* dx, int64_t lddx, int64_t N, void* stream);
 int64_t npi_topk_weight_grad_workspace_elems(int64_t n_out, int64_t F);
 int npi_topk_weight_grad(const float* x, int64_t ldx, const int32_t* perm, const float* dzv, const float* dzz,
                          int64_t n_out, int64_t F, const float* w, float* dw, float* workspace,

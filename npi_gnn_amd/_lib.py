@@ -18,6 +18,7 @@ NPI_F32 = 0
 NPI_BF16 = 1
 NPI_GEMM_EXACT_F32 = 1      # flags of the npi_linear_*_ex entry points
 NPI_GEMM_SPLIT_BF16 = 2
+NPI_GEMM_A_ZERO_PADDED = 4   # A stored with zero pad columns up to a multiple of 128 (include/npi_gnn.h)
 
 _P = c_void_p
 _I = c_int64
@@ -76,14 +77,17 @@ PROTOTYPES = {
     "npi_graph_bounds": (c_int, [_P, _I, _I, _P, _P]),
     "npi_topk_select": (c_int, [_P, _P, _I, _I, c_float, _P, _P, _P, _P, _P]),
     "npi_topk_gather": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "npi_topk_gather_ex": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "npi_filter_adj_workspace_elems": (_I, [_I]),
     "npi_filter_adj": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "npi_filter_adj_ex": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, c_int, _P]),
     "npi_readout_max_mean": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_topk_gather_bwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "npi_topk_gather_bwd_ex": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "npi_topk_weight_grad_workspace_elems": (_I, [_I, _I]),
     "npi_topk_weight_grad": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "npi_readout_max_mean_bwd": (c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "npi_readout_max_mean_bwd_ex": (c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     "npi_confusion_update": (c_int, [_P, _I, _I, _P, _I, _P, _P]),
     "npi_subgraph_sizes": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "npi_subgraph_fill": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -460,6 +460,80 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int64_t slab
     st1(out + (int64_t)r * ldo + c, s);
 }
 
+// The f32 dW epilogue in ONE launch: dW[r, c] = sum_z slabs[z][r, c] (z ascending) + the < 32 trailing nodes the slab
+// kernels do not cover, sum_m A[m, r] dC[m, c] (plain f32 FMAs, node order), and db[c] = sum_z db_slabs[z][c] + sum_m dC[m, c].
+// (Separate launches for the remainder GEMM and the db reduction were 2 of the 4 launches of a small layer's dW.)
+// Blocks [0, ceil(rows cols / 256)) take dW, one element per thread; the blocks behind them db: 16 columns x 16 partial sums
+// over every 16th slab row, folded in a fixed order (up to 512 db rows: one thread per column would walk them serially).
+constexpr int DWF_COLS = 16;
+static unsigned dw_finish_grid(int64_t rows, int64_t cols, bool with_db) {
+    return (unsigned)(ceil_div(rows * cols, 256) + (with_db ? ceil_div(cols, DWF_COLS) : 0));
+}
+__global__ void __launch_bounds__(256)
+dw_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nslab, int rows, int cols,
+                 float* __restrict__ dW, int64_t lddw, const float* __restrict__ db_slabs, int n_db,
+                 float* __restrict__ db, const float* __restrict__ A_rem, int64_t lda,
+                 const float* __restrict__ dC_rem, int64_t lddc, int n_rem) {
+    const int64_t n_w = (int64_t)rows * cols;
+    const int nb_w = (int)((n_w + 255) / 256);
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x < nb_w) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + t;
+        if (i >= n_w) return;
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const float* __restrict__ p = slabs + (int64_t)r * cols + c;
+        float s = 0.f;
+        int z = 0;
+        for (; z + 8 <= nslab; z += 8) {                      // 8 loads in flight; added in slab order all the same
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(z + u) * slab_stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < nslab; ++z) s += p[(int64_t)z * slab_stride];
+        for (int m0 = 0; m0 < n_rem; m0 += 8) {               // likewise the trailing nodes
+            float av[8], cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = m0 + u < n_rem;
+                av[u] = ok ? A_rem[(int64_t)(m0 + u) * lda + r] : 0.f;
+                cv[u] = ok ? dC_rem[(int64_t)(m0 + u) * lddc + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(av[u], cv[u], s);
+        }
+        dW[(int64_t)r * lddw + c] = s;
+        return;
+    }
+    if (db == nullptr) return;
+    __shared__ float part[256 / DWF_COLS][DWF_COLS];
+    const int cl = t % DWF_COLS, zl = t / DWF_COLS;
+    const int c = ((int)blockIdx.x - nb_w) * DWF_COLS + cl;
+    float s = 0.f;
+    if (c < cols) {
+        constexpr int ZL = 256 / DWF_COLS;
+        int z = zl;
+        for (; z + 3 * ZL < n_db; z += 4 * ZL) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = db_slabs[(int64_t)(z + u * ZL) * cols + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; z < n_db; z += ZL) s += db_slabs[(int64_t)z * cols + c];
+    }
+    part[zl][cl] = s;
+    __syncthreads();
+    if (zl == 0 && c < cols) {
+        float r = 0.f;
+#pragma unroll
+        for (int q = 0; q < 256 / DWF_COLS; ++q) r += part[q][cl];
+        for (int m = 0; m < n_rem; ++m) r += dC_rem[(int64_t)m * lddc + c];
+        db[c] = r;
+    }
+}
+
 // partial column sums of X[M, N] over row chunks: part[chunk][c].  Lanes walk a row 16 B each
 // (a 256-column row is one 1 KiB wave instruction); the 4 waves of a workgroup take rows r, r+1, ...
 constexpr int COLSUM_ROWS = 2048;      // most rows per workgroup (and the chunking the documented minimum workspace implies)
@@ -569,11 +643,12 @@ __device__ __forceinline__ void split3_store(f32x4r v, char* img, int plane) {
 // k-step major: the BN x 16 tile of one k-step is BN * 32 contiguous bytes per plane, so the producer's
 // loads are whole cache lines.
 __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, int K, int N, int bmode,
-                                    uint16_t* __restrict__ planes) {
+                                    uint16_t* __restrict__ planes, int k_valid) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * K) return;
     const int n = (int)(i / K), k = (int)(i % K);
-    const float x = bmode == 0 ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k];
+    // k >= k_valid: the zero rows that go with the zero pad columns of A (NPI_GEMM_A_ZERO_PADDED)
+    const float x = k >= k_valid ? 0.f : (bmode == 0 ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k]);
     uint32_t p0, p1, p2;
     split3_pair(x, 0.f, p0, p1, p2);
     const int64_t o = ((int64_t)(k / SK) * N + n) * SK + (k % SK);
@@ -673,6 +748,10 @@ struct TileWalk {
     int q, kt;          // position: tile sequence number, k-step
     int mt, nt;
     int qend, G, nk, tiles_m, tiles_n;
+    int last_row0;      // first row of the LAST m-tile: M - 128 when M is not a multiple of 128 -- that tile then overlaps its
+                        // neighbour instead of hanging over the edge; the shared rows are computed twice from the same
+                        // inputs in the same order and stored twice with the same bits (no guarded strip launch)
+    __device__ __forceinline__ int row0() const { return mt == tiles_m - 1 ? last_row0 : mt * 128; }
     __device__ __forceinline__ void decode() {
         // q -> (m-tile, n-tile): q & 7 = XCD of the workgroup (round-robin dispatch), consecutive slots of an
         // XCD take the n-tiles of one m-tile (their A rows then hit that XCD's L2)
@@ -684,8 +763,9 @@ struct TileWalk {
             q += G;
         }
     }
-    __device__ __forceinline__ void init(int b, int G_, int nk_, int tm, int tn) {
+    __device__ __forceinline__ void init(int b, int G_, int nk_, int tm, int tn, int M = -1) {
         G = G_; nk = nk_; tiles_m = tm; tiles_n = tn;
+        last_row0 = M >= 128 ? M - 128 : (tm - 1) * 128;
         qend = ((tm + 7) / 8) * 8 * tn;
         q = b; kt = 0;
         decode();
@@ -810,7 +890,7 @@ gemm_split_ws_kernel(SplitArgs a) {
     const int wave = uniform_i(t >> 6);
     const int nk = a.K / SK;
     TileWalk w;
-    w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n);
+    w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n, a.M);
     if (!w.valid()) return;                                 // no tile for this workgroup (uniform)
     if (t < NST) { full[t] = 0; empty[t] = 0; }
     __syncthreads();
@@ -855,7 +935,7 @@ gemm_split_ws_kernel(SplitArgs a) {
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(off), "s"(base) : "memory")
 #define NPI_WLOAD(S)                                                                                   \
     do {                                                                                               \
-        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.mt * 128 * a.lda + wl.kt * SK) * 4);      \
+        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.row0() * a.lda + wl.kt * SK) * 4);        \
         const char* gb0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * a.N + wl.nt * BN) * (SK * 2));     \
         const char* gb1 = uniform_ptr(gb0 + b_plane);                                                  \
         const char* gb2 = uniform_ptr(gb0 + 2 * b_plane);                                              \
@@ -975,7 +1055,7 @@ gemm_split_ws_kernel(SplitArgs a) {
             // wave's own LDS slot: written and, 16 k-steps later, read by the same wave -- in order, no hand-over)
             if (a.ep.rowscale) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) rs[i] = a.ep.rowscale[w.mt * 128 + wm * 64 + i * 32 + li];
+                for (int i = 0; i < TM; ++i) rs[i] = a.ep.rowscale[w.row0() + wm * 64 + i * 32 + li];
             }
             if (w.nt != bias_nt) {                          // only when the column block changes (once, for N = 64 TN): the
                 tsel ^= 1;                                  // copy waits on vmcnt(0), i.e. also on the previous tile's stores
@@ -992,7 +1072,7 @@ gemm_split_ws_kernel(SplitArgs a) {
         if (w.kt == nk - 1) {
             const unsigned long long e0_ = NPI_STAMP();
             if ((NPI_WS_PROBE & 4) == 0 || acc[0][0][0] == 12345.678f)
-            store_tile_t<TM, TN>(a.C, a.ldc, w.mt * 128 + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
+            store_tile_t<TM, TN>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
                                  bias_s[wave][tsel], rs, floor_);
             ca_epi += NPI_STAMP() - e0_;
 #pragma unroll
@@ -1482,13 +1562,23 @@ template <int AMODE, int BMODE>
 // `mode`: 0 = exact-f32 MFMA kernels, 1 = bf16 matrix cores where the tile shape allows (3-way split for f32 storage).
 // `scratch`: caller memory for the re-laid weight matrix (npi_linear_workspace_bytes); null = take it from the
 // stream-ordered allocator (the legacy entry points).
+// `k_valid` > 0 (AMODE 0, f32): A has a.K columns of which only the first k_valid are data, the rest ZERO, and B has only
+// k_valid rows (NPI_GEMM_A_ZERO_PADDED): the split kernel runs on a.K with the weight planes zero-extended, everything
+// else (guarded strips, the exact kernels) on k_valid.
 static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32,
-                       int mode = 1, void* scratch = nullptr) {
+                       int mode = 1, void* scratch = nullptr, int k_valid = 0) {
     const bool bf16_in = dtype_in == NPI_BF16 && dtype_out == NPI_F32;          // dW of the bf16 path: bf16 operands, f32 slabs
-    const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && ((dtype_in == NPI_F32 && dtype_out == NPI_F32) || bf16_in);
     // 128 x 256 tile (one workgroup per CU): measured 3-10 % SLOWER than 128 x 128 at C4 (round 1:
     // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms), so it is opt-in (NPI_GEMM_WIDE=1)
     static const bool wide_enabled = [] { const char* e = getenv("NPI_GEMM_WIDE"); return e && e[0] == '1'; }();
+    const int kv = k_valid > 0 ? k_valid : a.K;
+    if (kv != a.K) {
+        const bool can_split = AMODE == 0 && v4 && (a.K % BK == 0) && dtype_in == NPI_F32 && dtype_out == NPI_F32 && splits == 1 &&
+                               mode != 0 && !wide_enabled && a.ep.colsum == nullptr && a.M >= 128 && a.N >= 128 && ((uintptr_t)a.C % 16 == 0) &&
+                               (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
+        if (!can_split) { a.K = kv; a.kchunk = (int)align_up(kv, BK); }          // the pad columns are zero: dropping them is exact
+    }
+    const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && ((dtype_in == NPI_F32 && dtype_out == NPI_F32) || bf16_in);
     const bool wide = wide_enabled && fast_ok && !bf16_in && a.N >= 256 && a.M >= 128;
     const int bm = 128, bn = wide ? 256 : 128;
     const int fm = fast_ok ? a.M / bm : 0, fn = fast_ok ? a.N / bn : 0;    // full tiles
@@ -1529,6 +1619,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     }
     const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
                        ((uintptr_t)a.C % 16 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
+    int split_tm = 0;                                        // m-tiles the split kernel covered (all of them, when it ran)
     if (fm > 0 && fn > 0 && split) {
         // stream-ordered scratch for the three bf16 planes of B (W is small: 3 * 2 * K * N bytes)
         uint16_t* planes = reinterpret_cast<uint16_t*>(scratch);
@@ -1539,11 +1630,12 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
             set_error("gemm: hipMallocAsync of the split planes failed");
             return NPI_ERR_LAUNCH;
         }
-        split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes);
+        split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes, kv);
         const bool wide_n = (a.N % 256 == 0);                // 128 x 256 tiles: each A element is split once
         const int tn = wide_n ? a.N / 256 : fn;
-        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, fm, tn};
-        const int64_t ntiles = (int64_t)fm * tn;
+        split_tm = (int)ceil_div(a.M, 128);                  // a ragged last m-tile overlaps its neighbour (TileWalk::row0)
+        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, split_tm, tn};
+        const int64_t ntiles = (int64_t)split_tm * tn;
         const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
         if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
         else        gemm_split_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(sa);
@@ -1557,12 +1649,13 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     }
     // edge strips in 128 x 128 tiles
     const int tm = (int)ceil_div(a.M, 128), tn = (int)ceil_div(a.N, 128);
-    const int em = (fm > 0 && fn > 0) ? fm * bm / 128 : 0;       // first edge tile row
+    const int em = split_tm > 0 ? split_tm : ((fm > 0 && fn > 0) ? fm * bm / 128 : 0);       // first edge tile row
     const int en = (fm > 0 && fn > 0) ? fn * bn / 128 : 0;       // first edge tile column
     auto edge = [&](int tm0, int tn0, int nm, int nn) {
         if (nm <= 0 || nn <= 0) return;
         GemmArgs e = a;
         e.tm0 = tm0; e.tn0 = tn0;
+        if (kv != a.K) { e.K = kv; e.kchunk = (int)align_up(kv, BK); }          // B has kv rows only
         const dim3 g(nn, nm, splits);
         if (dtype_in == NPI_BF16 && dtype_out == NPI_BF16) {
             if (v4) gemm_edge_kernel<AMODE, BMODE, true, bf16_t, bf16_t><<<g, GEMM_THREADS, 0, stream>>>(e);
@@ -1631,15 +1724,20 @@ extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int6
     if (M == 0) return NPI_OK;
     NPI_REQUIRE(A && W && C, "npi_linear_fwd: null pointer");
     NPI_REQUIRE(lda >= K && ldw >= N && ldc >= N, "npi_linear_fwd: leading dimension too small");
-    if (!scratch_ok(workspace, workspace_bytes, K, N)) {
+    // A stored with zero pad columns up to a multiple of 128 (a 178-wide aggregate kept 256 wide): the bf16 matrix-core
+    // kernel runs on the padded width with the weight planes zero-extended instead of the guarded kernel on 178
+    const bool padded = (flags & NPI_GEMM_A_ZERO_PADDED) != 0 && dtype == NPI_F32 && K % 128 != 0;
+    const int64_t Kp = padded ? align_up(K, 128) : K;
+    NPI_REQUIRE(lda >= Kp, "npi_linear_fwd: NPI_GEMM_A_ZERO_PADDED needs lda >= K rounded up to 128");
+    if (!scratch_ok(workspace, workspace_bytes, Kp, N)) {
         set_error("npi_linear_fwd_ex: workspace too small or not 16-byte aligned");
         return NPI_ERR_WORKSPACE;
     }
     const int es = dtype == NPI_BF16 ? 2 : 4;
-    GemmArgs a{fp(A), lda, fp(W), ldw, (float*)C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
+    GemmArgs a{fp(A), lda, fp(W), ldw, (float*)C, ldc, (int)M, (int)N, (int)Kp, (int)align_up(Kp, BK), 0, 0, 0,
                Epilogue{fp(bias), rowscale, relu, nullptr}};
-    const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, K, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
-                                     gemm_mode_of(flags), workspace);
+    const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, Kp, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
+                                     gemm_mode_of(flags), workspace, padded ? (int)K : 0);
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd");
 }
 extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
@@ -1785,38 +1883,40 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         return NPI_ERR_WORKSPACE;
     }
     const int es = dtype == NPI_BF16 ? 2 : 4;
-    const bool v4 = vec4_ok(A, lda, K, es) && vec4_ok(dC, lddc, N, es);
+    // A with zero pad columns up to a multiple of 128 (see npi_linear_fwd_ex): the split kernel runs on the padded width --
+    // the pad rows of its slabs are zero and never read -- instead of the guarded kernel on K
+    const bool padded = (flags & NPI_GEMM_A_ZERO_PADDED) != 0 && dtype == NPI_F32 && K % 128 != 0;
+    const int64_t Kp = padded ? align_up(K, 128) : K;
+    NPI_REQUIRE(lda >= Kp, "npi_linear_bwd_weight: NPI_GEMM_A_ZERO_PADDED needs lda >= K rounded up to 128");
+    if (padded && workspace_elems < npi_linear_bwd_weight_workspace_elems(M, Kp, N)) {
+        set_error("npi_linear_bwd_weight: workspace too small (query it with K rounded up to 128 for a zero-padded A)");
+        return NPI_ERR_WORKSPACE;
+    }
+    const bool v4 = vec4_ok(A, lda, Kp, es) && vec4_ok(dC, lddc, N, es);
     const unsigned gw = (unsigned)ceil_div(K * N, 256), gb = (unsigned)ceil_div(N, 256);
+    const unsigned gwb = dw_finish_grid(K, N, db != nullptr);
     // ---- f32 storage on the bf16 matrix cores: both operands split on the fly (gemm_dw_split_kernel) ----
-    if (dtype == NPI_F32 && gemm_mode_of(flags) != 0 && v4 && dw_split_shape_ok(M, K, N)) {
+    if (dtype == NPI_F32 && gemm_mode_of(flags) != 0 && v4 && dw_split_shape_ok(M, Kp, N)) {
         const int64_t m16 = (M / SK) * SK;
         int nslab, tm, tn;
         int64_t per;
         bool wide;
-        dw_split_plan(m16, K, N, shared != 0, nslab, per, tm, tn, wide);
-        const bool has_rem = M > m16;
-        float* db_slabs = workspace + (int64_t)(nslab + 1) * K * N;
-        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)K, (int)N, m16, per, tm, tn, nslab};
+        dw_split_plan(m16, Kp, N, shared != 0, nslab, per, tm, tn, wide);
+        float* db_slabs = workspace + (int64_t)(nslab + 1) * Kp * N;
+        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)Kp, (int)N, m16, per, tm, tn, nslab};
         const unsigned grid = (unsigned)(ceil_div(nslab, 8) * 8 * tm * tn);     // slots of 8 slabs (one per XCD) x tiles
         if (wide) gemm_dw_split_kernel<4><<<grid, WS_THREADS, 0, stream>>>(d);
         else      gemm_dw_split_kernel<2><<<grid, WS_THREADS, 0, stream>>>(d);
-        if (has_rem) {        // < 16 trailing nodes: one guarded exact-f32 launch into slab `nslab`
-            GemmArgs r{fp(advance(A, m16 * lda, es)), lda, fp(advance(dC, m16 * lddc, es)), lddc,
-                       workspace + (int64_t)nslab * K * N, N, (int)K, (int)N, (int)(M - m16), BK, 0, 0, K * N,
-                       Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)2 * nslab * N : nullptr}};
-            (void)launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
-        }
-        slab_reduce_kernel<float><<<gw, 256, 0, stream>>>(workspace, K * N, nslab + (has_rem ? 1 : 0), (int)K, (int)N, N, (float*)dW, lddw);
-        if (db) slab_reduce_kernel<float><<<gb, 256, 0, stream>>>(db_slabs, N, 2 * nslab + (has_rem ? 1 : 0), 1, (int)N, N, (float*)db, N);
+        // slabs in slab order, the < 16 trailing nodes and db in one launch
+        dw_finish_kernel<<<gwb, 256, 0, stream>>>(workspace, Kp * N, nslab, (int)K, (int)N, (float*)dW, lddw, db_slabs, 2 * nslab,
+                                                  (float*)db, fp(advance(A, m16 * lda, es)), lda, fp(advance(dC, m16 * lddc, es)), lddc,
+                                                  (int)(M - m16));
         return check_launch("npi_linear_bwd_weight");
     }
     int splits, kchunk;
     int64_t m_main;
     bwd_weight_plan(M, K, N, shared != 0, splits, kchunk, m_main);
-    // the slab of the < BK remainder exists only when there is a remainder (a node count that is a multiple of BK used to
-    // pay a zero-filling launch here, which queued behind the co-resident aggregation for 0.4-0.6 ms at C4)
     const bool has_rem = M > m_main || m_main == 0;
-    const int nslab = (m_main > 0 ? splits : 0) + (has_rem ? 1 : 0);
     float* db_slabs = workspace + (int64_t)(splits + 1) * K * N;
     // output rows = K (features of A), cols = N; A(m = feature, k = node) = A[node*lda + feature]
     // main part: nodes [0, m_main) in `splits` f32 slabs
@@ -1825,20 +1925,25 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
                    Epilogue{nullptr, nullptr, 0, db ? db_slabs : nullptr}};
         (void)launch_gemm<1, 0>(v4, a, splits, stream, dtype, NPI_F32);          // AMODE 1 never takes the allocating path
     }
-    // remainder: nodes [m_main, M) into slab `splits`
+    if (dtype == NPI_F32) {
+        // slabs in slab order, the < 32 trailing nodes and db in one launch (a node count that is a multiple of 32 used to
+        // pay a zero-filling launch here, a remainder its own guarded GEMM)
+        const int ns = m_main > 0 ? splits : 0;
+        dw_finish_kernel<<<gwb, 256, 0, stream>>>(workspace, K * N, ns, (int)K, (int)N, (float*)dW, lddw, db_slabs, ns, (float*)db,
+                                                  fp(advance(A, m_main * lda, es)), lda, fp(advance(dC, m_main * lddc, es)), lddc,
+                                                  (int)(M - m_main));
+        return check_launch("npi_linear_bwd_weight");
+    }
+    // bf16 storage: remainder nodes [m_main, M) into slab `splits`, then the two reductions
+    const int nslab = (m_main > 0 ? splits : 0) + (has_rem ? 1 : 0);
     if (has_rem) {
         GemmArgs r{fp(advance(A, m_main * lda, es)), lda, fp(advance(dC, m_main * lddc, es)), lddc,
                    workspace + (int64_t)(m_main > 0 ? splits : 0) * K * N, N, (int)K, (int)N, (int)(M - m_main), BK, 0, 0, K * N,
                    Epilogue{nullptr, nullptr, 0, db ? db_slabs + (int64_t)(m_main > 0 ? splits : 0) * N : nullptr}};
         (void)launch_gemm<1, 0>(false, r, 1, stream, dtype, NPI_F32);
     }
-    if (dtype == NPI_BF16) {
-        slab_reduce_kernel<bf16_t><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (bf16_t*)dW, lddw);
-        if (db) slab_reduce_kernel<bf16_t><<<gb, 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, (bf16_t*)db, N);
-    } else {
-        slab_reduce_kernel<float><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (float*)dW, lddw);
-        if (db) slab_reduce_kernel<float><<<gb, 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, (float*)db, N);
-    }
+    slab_reduce_kernel<bf16_t><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (bf16_t*)dW, lddw);
+    if (db) slab_reduce_kernel<bf16_t><<<gb, 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, (bf16_t*)db, N);
     return check_launch("npi_linear_bwd_weight");
 }
 extern "C" int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t lddc,

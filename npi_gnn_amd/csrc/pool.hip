@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256)
 topk_gather_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ score,
                    const int64_t* __restrict__ batch, const int32_t* __restrict__ perm,
                    const int32_t* __restrict__ out_ptr, int B, int F, float* __restrict__ xo, int64_t ldo,
-                   int64_t* __restrict__ batch_o, float* __restrict__ score_o) {
+                   int64_t* __restrict__ batch_o, float* __restrict__ score_o, int64_t* __restrict__ perm64) {
     const int lane = lane_id();
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= out_ptr[B]) return;
@@ -140,6 +140,7 @@ topk_gather_kernel(const float* __restrict__ x, int64_t ldx, const float* __rest
     if (lane == 0) {
         batch_o[q] = batch[i];
         score_o[q] = s;
+        if (perm64) perm64[q] = i;                         // the LongTensor PyG returns, without a cast launch
     }
 }
 
@@ -320,15 +321,10 @@ readout_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restri
 //   ds = <dxo[p], x[i]> (+ dscore_o[p]);  dz = ds (1 - s^2);  dx[i] = dxo[p] s + dz w / ||w||
 //   dzv[p] = dz,  dzz[p] = dz z  with z = <x[i], w> / ||w||   (inputs of the weight gradient)
 // rows that were not kept receive no gradient: dx must come in zero-filled.
-__global__ void __launch_bounds__(256)
-topk_gather_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ score,
-                       const float* __restrict__ w, const int32_t* __restrict__ perm, int n_out, int F,
-                       const float* __restrict__ dxo, int64_t lddxo, const float* __restrict__ dscore_o,
-                       float* __restrict__ dx, int64_t lddx, float* __restrict__ dzv, float* __restrict__ dzz) {
-    const int lane = lane_id();
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= n_out) return;
-    const int i = perm[p];
+__device__ __forceinline__ void topk_bwd_row(const float* __restrict__ x, int64_t ldx, const float* __restrict__ score,
+                                             const float* __restrict__ w, int F, const float* __restrict__ dxo, int64_t lddxo,
+                                             const float* __restrict__ dscore_o, float* __restrict__ dx, int64_t lddx,
+                                             float* __restrict__ dzv, float* __restrict__ dzz, int p, int i, int lane) {
     const float* __restrict__ xr = x + (int64_t)i * ldx;
     const float* __restrict__ gr = dxo + (int64_t)p * lddxo;
     float ds = 0.f, dot = 0.f, nn = 0.f;
@@ -351,6 +347,37 @@ topk_gather_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __
         dzv[p] = dz;
         dzz[p] = dz * dot * inv_norm;
     }
+}
+
+__global__ void __launch_bounds__(256)
+topk_gather_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ score,
+                       const float* __restrict__ w, const int32_t* __restrict__ perm, int n_out, int F,
+                       const float* __restrict__ dxo, int64_t lddxo, const float* __restrict__ dscore_o,
+                       float* __restrict__ dx, int64_t lddx, float* __restrict__ dzv, float* __restrict__ dzz) {
+    const int lane = lane_id();
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_out) return;
+    const int i = perm[p];
+    topk_bwd_row(x, ldx, score, w, F, dxo, lddxo, dscore_o, dx, lddx, dzv, dzz, p, i, lane);
+}
+
+// the same over ALL input rows (one wave per row i; remap[i] = its kept position or -1): dropped rows get their zeros here,
+// so dx needs no zero-filling launch in front
+__global__ void __launch_bounds__(256)
+topk_gather_bwd_all_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ score,
+                           const float* __restrict__ w, const int32_t* __restrict__ remap, int N, int F,
+                           const float* __restrict__ dxo, int64_t lddxo, const float* __restrict__ dscore_o,
+                           float* __restrict__ dx, int64_t lddx, float* __restrict__ dzv, float* __restrict__ dzz) {
+    const int lane = lane_id();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int p = remap[i];
+    if (p < 0) {
+        float* __restrict__ dr = dx + (int64_t)i * lddx;
+        for (int c = lane; c < F; c += WAVE) dr[c] = 0.f;
+        return;
+    }
+    topk_bwd_row(x, ldx, score, w, F, dxo, lddxo, dscore_o, dx, lddx, dzv, dzz, p, i, lane);
 }
 
 // dw partials over chunks of POOLW_ROWS kept nodes: part[chunk][f] = sum_p dzv[p] x[perm[p], f]; part[chunk][F] = sum_p dzz[p]
@@ -434,15 +461,23 @@ topk_weight_grad_reduce_kernel(const float* __restrict__ part, int nchunks, cons
 template <int VEC>
 __global__ void __launch_bounds__(POOL_THREADS)
 readout_bwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ graph_ptr, int B, int F, int cgb,
-                   const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dx, int64_t lddx) {
+                   const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dx, int64_t lddx, int N) {
     __shared__ int first_s[POOL_THREADS * VEC];
     const int g = blockIdx.x;
     const int lanes = POOL_THREADS / cgb;
     const int cgi = threadIdx.x % cgb, rl = threadIdx.x / cgb;
     const int c0 = (blockIdx.y * cgb + cgi) * VEC;
     const int b = graph_ptr[g], e = graph_ptr[g + 1];
-    if (e <= b) return;                                    // uniform over the workgroup
     const bool live = rl < lanes && c0 < F;
+    if (N >= 0 && live && (g == 0 || g == B - 1)) {
+        // rows outside every graph (none in a PyG batch) get no gradient: zeroed here instead of by a fill launch in front
+        float z[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) z[k] = 0.f;
+        if (g == 0) for (int i = rl; i < graph_ptr[0]; i += lanes) store_vec<VEC>(dx + (int64_t)i * lddx + c0, z);
+        if (g == B - 1) for (int i = graph_ptr[B] + rl; i < N; i += lanes) store_vec<VEC>(dx + (int64_t)i * lddx + c0, z);
+    }
+    if (e <= b) return;                                    // uniform over the workgroup
     float mx[VEC], dmx[VEC], dmean[VEC];
     int first[VEC];
 #pragma unroll
@@ -560,11 +595,16 @@ extern "C" int npi_topk_select(const float* score, const int32_t* graph_ptr, int
 extern "C" int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
                                const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
                                float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream_) {
+    return npi_topk_gather_ex(x, ldx, score, batch, perm, out_ptr, B, F, n_out_max, xo, ldo, batch_o, score_o, nullptr, stream_);
+}
+extern "C" int npi_topk_gather_ex(const float* x, int64_t ldx, const float* score, const int64_t* batch,
+                                  const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
+                                  float* xo, int64_t ldo, int64_t* batch_o, float* score_o, int64_t* perm64, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(B >= 0 && F > 0 && n_out_max >= 0, "npi_topk_gather: bad size");
     if (n_out_max == 0) return NPI_OK;
     NPI_REQUIRE(x && score && batch && perm && out_ptr && xo && batch_o && score_o, "npi_topk_gather: null pointer");
-    topk_gather_kernel<<<(unsigned)ceil_div(n_out_max, 4), 256, 0, stream>>>(x, ldx, score, batch, perm, out_ptr, (int)B, (int)F, xo, ldo, batch_o, score_o);
+    topk_gather_kernel<<<(unsigned)ceil_div(n_out_max, 4), 256, 0, stream>>>(x, ldx, score, batch, perm, out_ptr, (int)B, (int)F, xo, ldo, batch_o, score_o, perm64);
     return check_launch("npi_topk_gather");
 }
 
@@ -621,6 +661,18 @@ extern "C" int npi_topk_gather_bwd(const float* x, int64_t ldx, const float* sco
     return check_launch("npi_topk_gather_bwd");
 }
 
+extern "C" int npi_topk_gather_bwd_ex(const float* x, int64_t ldx, const float* score, const float* w, const int32_t* remap,
+                                      int64_t N, int64_t F, const float* dxo, int64_t lddxo, const float* dscore_o,
+                                      float* dx, int64_t lddx, float* dzv, float* dzz, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && F > 0 && N < 0x7fffffff, "npi_topk_gather_bwd_ex: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(x && score && w && remap && dxo && dx && dzv && dzz, "npi_topk_gather_bwd_ex: null pointer");
+    topk_gather_bwd_all_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(x, ldx, score, w, remap, (int)N, (int)F, dxo, lddxo,
+                                                                             dscore_o, dx, lddx, dzv, dzz);
+    return check_launch("npi_topk_gather_bwd_ex");
+}
+
 extern "C" int64_t npi_topk_weight_grad_workspace_elems(int64_t n_out, int64_t F) {
     return ceil_div(n_out > 0 ? n_out : 1, POOLW_ROWS) * (F + 1);
 }
@@ -651,19 +703,27 @@ extern "C" int npi_topk_weight_grad(const float* x, int64_t ldx, const int32_t* 
 
 extern "C" int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
                                         const float* out, const float* dout, float* dx, int64_t lddx, void* stream_) {
+    return npi_readout_max_mean_bwd_ex(x, ldx, graph_ptr, B, F, out, dout, dx, lddx, -1, stream_);
+}
+extern "C" int npi_readout_max_mean_bwd_ex(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
+                                           const float* out, const float* dout, float* dx, int64_t lddx, int64_t N,
+                                           void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(B >= 0 && F > 0, "npi_readout_max_mean_bwd: bad size");
-    if (B == 0) return NPI_OK;
+    NPI_REQUIRE(B >= 0 && F > 0 && N < 0x7fffffff, "npi_readout_max_mean_bwd: bad size");
+    if (B == 0) {
+        NPI_REQUIRE(N <= 0, "npi_readout_max_mean_bwd_ex: rows without a graph need B >= 1 (or zero dx yourself)");
+        return NPI_OK;
+    }
     NPI_REQUIRE(x && graph_ptr && out && dout && dx, "npi_readout_max_mean_bwd: null pointer");
     const int vec = pool_vec(2 * F, {ldx, lddx, F}, {x, dx, out, dout});
     const int cgb = pool_groups_per_block(F, vec);
     const dim3 grid((unsigned)B, (unsigned)ceil_div(ceil_div(F, vec), cgb));
     if (vec == 4)
-        readout_bwd_kernel<4><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx);
+        readout_bwd_kernel<4><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx, (int)N);
     else if (vec == 2)
-        readout_bwd_kernel<2><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx);
+        readout_bwd_kernel<2><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx, (int)N);
     else
-        readout_bwd_kernel<1><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx);
+        readout_bwd_kernel<1><<<grid, POOL_THREADS, 0, stream>>>(x, ldx, graph_ptr, (int)B, (int)F, cgb, out, dout, dx, lddx, (int)N);
     return check_launch("npi_readout_max_mean_bwd");
 }
 

@@ -120,7 +120,8 @@ subgraph_fill_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict_
     }
 }
 
-// x[row] = [structural label | feat[node_id[row]]]; label 0 for the two target nodes of a sample
+// x[row] = [structural label | feat[node_id[row]]]; label 0 for the two target nodes of a sample; columns Ff + 1 .. ldx - 1
+// (a row pitch padded for the GEMMs, NPI_GEMM_A_ZERO_PADDED) are set to zero
 __global__ void __launch_bounds__(256)
 subgraph_features_kernel(const float* __restrict__ feat, int64_t ldf, int Ff, const int32_t* __restrict__ node_id,
                          const int64_t* __restrict__ batch, const int32_t* __restrict__ node_off, int64_t n,
@@ -131,7 +132,7 @@ subgraph_features_kernel(const float* __restrict__ feat, int64_t ldf, int Ff, co
     const float* __restrict__ src = feat + (int64_t)node_id[row] * ldf;
     float* __restrict__ dst = x + row * ldx;
     if (lane == 0) dst[0] = (row - node_off[batch[row]] < 2) ? 0.f : 1.f;
-    for (int c = lane; c < Ff; c += WAVE) dst[1 + c] = src[c];
+    for (int c = lane; 1 + c < ldx; c += WAVE) dst[1 + c] = c < Ff ? src[c] : 0.f;
 }
 
 }  // namespace npi

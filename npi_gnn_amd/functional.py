@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import NPI_BF16, NPI_F32, check, load, ptr, require_gpu, stream_ptr
+from ._lib import NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, check, load, ptr, require_gpu, stream_ptr
 from .graph import CSRGraph, CSRSide, as_graph
 
 
@@ -130,21 +130,32 @@ def _gemm_workspace(K: int, N: int, dev) -> torch.Tensor:
     return torch.empty(int(load().npi_linear_workspace_bytes(K, N)), dtype=torch.uint8, device=dev)
 
 
+def _pad128(k: int) -> int:
+    return (int(k) + 127) // 128 * 128
+
+
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                rowscale: Optional[torch.Tensor] = None, relu: bool = False, flags: Optional[int] = None) -> torch.Tensor:
+    """``a @ weight + bias``.  ``a`` may be wider than ``weight`` has rows: ``[M, Kp]`` with Kp = K rounded up to 128 and
+    the columns K.. ZERO (``NPI_GEMM_A_ZERO_PADDED``: the matrix-core kernel on Kp instead of the guarded one on an odd K)."""
     dev = require_gpu(a, weight, bias, rowscale)
     a = _fc(a, "a")
     weight = _fc(weight, "weight", a)
     if bias is not None:
         bias = _fc(bias, "bias", a)
-    M, K = a.shape
-    N = weight.size(1)
+    M, Ka = a.shape
+    K, N = weight.shape
+    fl = GEMM_FLAGS if flags is None else flags
+    if Ka != K:
+        if Ka != _pad128(K) or a.dtype != torch.float32:
+            raise ValueError(f"a has {Ka} columns, weight {K} rows (a zero-padded a must be f32 and {_pad128(K)} wide)")
+        fl |= NPI_GEMM_A_ZERO_PADDED
     out = torch.empty((M, N), dtype=a.dtype, device=dev)
-    ws = _gemm_workspace(K, N, dev)
+    ws = _gemm_workspace(Ka, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
         check(load().npi_linear_fwd_ex(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
                                        ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a),
-                                       GEMM_FLAGS if flags is None else flags, ptr(ws), ws.numel(), stream_ptr(dev)),
+                                       fl, ptr(ws), ws.numel(), stream_ptr(dev)),
               "npi_linear_fwd")
     return out
 
@@ -167,22 +178,29 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
 
 
 def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False,
-                      flags: Optional[int] = None):
+                      flags: Optional[int] = None, k_valid: Optional[int] = None):
     """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid; a per-call argument of
-    ``npi_linear_bwd_weight_ex``, no process-wide switch is touched)."""
+    ``npi_linear_bwd_weight_ex``, no process-wide switch is touched).  ``k_valid``: ``a`` is ``[M, Kp]`` with only the
+    first ``k_valid`` columns data and the rest ZERO (see ``linear_fwd``); dW then has ``k_valid`` rows."""
     dev = require_gpu(a, dc)
     a = _fc(a, "a")
     dc = _fc(dc, "dC", a)
-    M, K = a.shape
+    M, Ka = a.shape
     N = dc.size(1)
+    K = Ka if k_valid is None else int(k_valid)
+    fl = GEMM_FLAGS if flags is None else flags
+    if K != Ka:
+        if Ka != _pad128(K) or a.dtype != torch.float32:
+            raise ValueError(f"a zero-padded a must be f32 and {_pad128(K)} wide (got {Ka})")
+        fl |= NPI_GEMM_A_ZERO_PADDED
     lib = load()
-    n_ws = int(lib.npi_linear_bwd_weight_workspace_elems(M, K, N))
+    n_ws = int(lib.npi_linear_bwd_weight_workspace_elems(M, Ka, N))
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     dw = torch.empty((K, N), dtype=a.dtype, device=dev)
     db = torch.empty(N, dtype=a.dtype, device=dev) if want_bias else None
     with _gemm_events("bwd_weight", 2.0 * M * K * N, dev):
         check(lib.npi_linear_bwd_weight_ex(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
-                                           M, K, N, ptr(ws), n_ws, _code(a), GEMM_FLAGS if flags is None else flags,
+                                           M, K, N, ptr(ws), n_ws, _code(a), fl,
                                            1 if shared else 0, stream_ptr(dev)),
               "npi_linear_bwd_weight")
     return dw, db
@@ -234,8 +252,11 @@ class _SageConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, graph: CSRGraph, w_entry=None):
         # a2-a4: gather + scatter_mean (w_entry: PyG's `edge_weight.view(-1, 1) * x_j`; the mean still divides by the count)
+        # x may be the zero-padded base of the caller's features (sage_conv): agg then keeps the padded width -- zero
+        # columns stay zero under a weighted mean -- and both GEMMs run on it (linear_fwd / linear_bwd_weight)
         agg = segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True)
         out = linear_fwd(agg, weight, bias)                               # a5: agg @ W + b
+        ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None
         ctx.graph = graph
         ctx.w_src = w_entry[1] if w_entry else None
         ctx.has_bias = bias is not None
@@ -254,7 +275,7 @@ class _SageConvFn(torch.autograd.Function):
         tside = (lambda: graph.by_dst) if (graph.symmetric and ctx.w_src is None) else (lambda: graph.by_src)
         overlap = want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS
         if want_w and not overlap:
-            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)       # aggT dOut, colsum
+            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)   # aggT dOut, colsum
         if want_x:
             # dAgg = dOut W^T, pre-divided by the in-count of its row (fused epilogue), then
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
@@ -289,6 +310,12 @@ def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[
         raise NotImplementedError("gradients w.r.t. edge_weight are not implemented")      # as gcn_conv: never silently detached
     graph = as_graph(edge_index, x.size(0))
     w_entry = entry_weights(graph, edge_weight, 1.0) if edge_weight is not None else None
+    # features that are a view of a wider buffer whose extra columns are zero (InteractionGraph.batch: 178 -> 256): the
+    # layer runs on the padded buffer, so that its GEMMs take the matrix-core kernels instead of the guarded ones
+    base = getattr(x, "_npi_pad_base", None)
+    if (base is not None and not x.requires_grad and x.dtype == torch.float32 and base.size(0) == x.size(0)
+            and base.size(1) == _pad128(x.size(1)) and weight.size(0) == x.size(1) and base.data_ptr() == x.data_ptr()):
+        x = base
     out = _SageConvFn.apply(x, weight, bias, graph, w_entry)
     if normalize:
         out = torch.nn.functional.normalize(out, p=2.0, dim=-1)

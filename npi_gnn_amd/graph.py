@@ -184,4 +184,17 @@ def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:
         if g.num_nodes != num_nodes:
             raise ValueError(f"CSRGraph was built for {g.num_nodes} nodes, x has {num_nodes}")
         return g
+    # an edge list that is used again and again (the static batches of net1.GraphedEpoch) may carry its CSR
+    g = getattr(edge_index_or_graph, "_npi_graph", None)
+    if isinstance(g, CSRGraph) and g.num_nodes == num_nodes and g.num_edges == edge_index_or_graph.size(1):
+        return g
     return CSRGraph(edge_index_or_graph, num_nodes)
+
+
+def attach_graph(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
+    """Build the CSR of ``edge_index`` once and leave it on the tensor: every later conv call on this very tensor reuses
+    it instead of sorting again.  For edge lists that do not change (a loader that replays the same batches); the caller
+    vouches that the tensor is not modified in place afterwards."""
+    g = CSRGraph(edge_index, num_nodes)
+    edge_index._npi_graph = g
+    return g

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import metrics as NM
 from . import pool as NP
+from .graph import attach_graph
 from .nn import SAGEConv
 from .subgraph import InteractionGraph
 
@@ -130,6 +131,12 @@ class GraphedEpoch:
         self.model, self.optimizer, self.device = model, optimizer, device
         self.capture_after = capture_after                            # eager epochs before the steps are captured
         self.batches = [d.to(device) for d in train_loader]           # static inputs: fixed addresses for the captures
+        for d in self.batches:
+            # the input graph of a batch never changes either: its CSR is built here, once, instead of inside every step
+            # (the reference's counterpart is the processed dataset file; the graphs AFTER each pooling layer depend on the
+            # weights and are rebuilt inside the step)
+            attach_graph(d.edge_index, d.x.size(0))
+            d.batch._npi_graph_ptr = NP.graph_ptr(d.batch, d.num_graphs)      # likewise the segment starts of its batch vector
         self.n = len(train_loader.dataset)
         self.graphs = [None] * len(self.batches)
         self.losses = [None] * len(self.batches)

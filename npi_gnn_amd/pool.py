@@ -117,8 +117,9 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     xo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
     batch_o = torch.empty(n_out, dtype=torch.int64, device=dev)
     score_o = torch.empty(n_out, dtype=torch.float32, device=dev)
-    check(lib.npi_topk_gather(ptr(x), x.stride(0), ptr(score), ptr(batch.contiguous()), ptr(perm), ptr(out_ptr), B, F,
-                              n_out, ptr(xo), xo.stride(0), ptr(batch_o), ptr(score_o), st), "npi_topk_gather")
+    perm64 = torch.empty(n_out, dtype=torch.int64, device=dev)           # the LongTensor PyG returns, written by the gather
+    check(lib.npi_topk_gather_ex(ptr(x), x.stride(0), ptr(score), ptr(batch.contiguous()), ptr(perm), ptr(out_ptr), B, F,
+                                 n_out, ptr(xo), xo.stride(0), ptr(batch_o), ptr(score_o), ptr(perm64), st), "npi_topk_gather")
     # the kept-row offsets ARE the segment starts of the pooled batch vector: the readout and the next pooling
     # layer take them from here instead of searching `batch_o` again
     batch_o._npi_graph_ptr = out_ptr
@@ -127,21 +128,24 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     ei_out = out_ei[:, :e_out]
     if getattr(edge_index, "_npi_symmetric", False):
         ei_out._npi_symmetric = True                     # both directions of a pair survive or fall together
-    return (xo, ei_out, None, batch_o, perm[:n_out].long(), score_o), (score, perm[:n_out])
+    return (xo, ei_out, None, batch_o, perm64, score_o), (score, perm[:n_out], remap)
 
 
 class _TopKPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, edge_index, batch, ratio, num_graphs):
-        (xo, ei_o, _, batch_o, perm, score_o), (score, perm32) = _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)
-        ctx.save_for_backward(x.detach(), weight.detach(), score, perm32)
+        (xo, ei_o, _, batch_o, perm, score_o), (score, perm32, remap) = _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)
+        ctx.save_for_backward(x.detach(), weight.detach(), score, perm32, remap)
         out_ptr = batch_o._npi_graph_ptr
         ctx.mark_non_differentiable(ei_o, batch_o, perm, out_ptr)
+        # no zero tensors for the gradients of outputs nobody used (score[perm], and autograd materialises them even for the
+        # four integer outputs: five fill launches per layer and step)
+        ctx.set_materialize_grads(False)
         return xo, score_o, ei_o, batch_o, perm, out_ptr
 
     @staticmethod
     def backward(ctx, dxo, dscore_o, *_unused):
-        x, weight, score, perm = ctx.saved_tensors
+        x, weight, score, perm, remap = ctx.saved_tensors
         lib = load()
         dev = x.device
         x = _f32(x)
@@ -149,13 +153,15 @@ class _TopKPoolFn(torch.autograd.Function):
         N, F = x.shape
         n_out = perm.numel()
         st = stream_ptr(dev)
+        if dxo is None and dscore_o is None:
+            return None, None, None, None, None, None
         dxo = _f32(dxo) if dxo is not None else torch.zeros((n_out, F), dtype=torch.float32, device=dev)
         dso = _f32(dscore_o) if dscore_o is not None else None
-        dx = torch.zeros((N, F), dtype=torch.float32, device=dev)          # dropped rows get no gradient
+        dx = torch.empty((N, F), dtype=torch.float32, device=dev)          # dropped rows: zeros written by the kernel
         dzv = torch.empty(max(n_out, 1), dtype=torch.float32, device=dev)
         dzz = torch.empty(max(n_out, 1), dtype=torch.float32, device=dev)
-        check(lib.npi_topk_gather_bwd(ptr(x), x.stride(0), ptr(score), ptr(w), ptr(perm), n_out, F, ptr(dxo),
-                                      dxo.stride(0), ptr(dso), ptr(dx), dx.stride(0), ptr(dzv), ptr(dzz), st),
+        check(lib.npi_topk_gather_bwd_ex(ptr(x), x.stride(0), ptr(score), ptr(w), ptr(remap), N, F, ptr(dxo),
+                                         dxo.stride(0), ptr(dso), ptr(dx), dx.stride(0), ptr(dzv), ptr(dzz), st),
               "npi_topk_gather_bwd")
         dw = None
         if ctx.needs_input_grad[1]:
@@ -216,9 +222,11 @@ class _ReadoutFn(torch.autograd.Function):
         dev = x.device
         dout = _f32(dout)
         B, F = gp.numel() - 1, x.size(1)
-        dx = torch.zeros_like(x)                                           # rows outside every graph (none in PyG batches)
-        check(load().npi_readout_max_mean_bwd(ptr(x), x.stride(0), ptr(gp), B, F, ptr(out), ptr(dout), ptr(dx),
-                                              dx.stride(0), stream_ptr(dev)), "npi_readout_max_mean_bwd")
+        if B == 0:
+            return torch.zeros_like(x), None, None
+        dx = torch.empty_like(x)                  # rows outside every graph (none in PyG batches): zeroed by the kernel
+        check(load().npi_readout_max_mean_bwd_ex(ptr(x), x.stride(0), ptr(gp), B, F, ptr(out), ptr(dout), ptr(dx),
+                                                 dx.stride(0), x.size(0), stream_ptr(dev)), "npi_readout_max_mean_bwd")
         return dx, None, None
 
 

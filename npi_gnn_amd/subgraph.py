@@ -12,12 +12,18 @@ Python-``set`` iteration order, which is a CPython hashing detail.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
 
 from ._lib import check, load, ptr, require_gpu, stream_ptr
 from .graph import build_side
+
+
+# Row pitch of the feature matrix a batch returns: padded to a multiple of 128 with zero columns (see batch()).
+PAD_FEATURES = os.environ.get("NPI_PAD_FEATURES", "1") != "0"
 
 
 class InteractionGraph:
@@ -102,11 +108,22 @@ class InteractionGraph:
         node_id = torch.empty(max(n, 1), **i32)
         bvec = torch.empty(n, dtype=torch.int64, device=dev)
         ei = torch.empty((2, 2 * npairs), dtype=torch.int64, device=dev)
-        x = torch.empty((n, 1 + Ff), dtype=torch.float32, device=dev)
+        # an odd feature width (178) is stored with a row pitch of the next multiple of 128 and ZERO pad columns when that
+        # costs less than half as much again: x is the [n, 1 + Ff] view, `_npi_pad_base` the buffer; sage_conv then runs its
+        # GEMMs on the padded width (matrix-core kernels instead of the guarded ones: functional.linear_fwd)
+        Fx = 1 + Ff
+        ld = (Fx + 127) // 128 * 128
+        if not PAD_FEATURES or 2 * ld > 3 * Fx:
+            ld = Fx
+        full = torch.empty((n, ld), dtype=torch.float32, device=dev)
         check(lib.npi_subgraph_fill(ptr(self.ptr), ptr(self.nbr), ptr(self.ok), ptr(keys), B, ptr(node_off), ptr(pair_off),
                                     ptr(node_id), ptr(bvec), ptr(ei[0]), ptr(ei[1]), st), "npi_subgraph_fill")
         check(lib.npi_subgraph_features(ptr(self.feat), self.feat.stride(0), Ff, ptr(node_id), ptr(bvec), ptr(node_off), n,
-                                        ptr(x), x.stride(0), st), "npi_subgraph_features")
+                                        ptr(full), full.stride(0), st), "npi_subgraph_features")
+        x = full
+        if ld != Fx:
+            x = full[:, :Fx]
+            x._npi_pad_base = full
         ei._npi_symmetric = True          # every pair is emitted in both directions (graph.CSRGraph.symmetric)
         if return_node_id:
             return x, ei, bvec, node_id[:n]

@@ -599,3 +599,59 @@ def test_symmetric_edge_list_skips_the_second_sort(dev):
     assert outs[0][2] is False and outs[1][2] is True
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.allclose(outs[0][1], outs[1][1], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M", [50, 128 * 3 + 17, 4096, 20000 + 9])
+@pytest.mark.parametrize("K,N", [(178, 128), (65, 256)])
+def test_zero_padded_operand_takes_the_matrix_core_kernels_with_the_same_result(dev, M, K, N):
+    """NPI_GEMM_A_ZERO_PADDED: A stored 128-aligned with zero pad columns, W / dW with K rows: fwd and dW equal the fp64
+    product at f32 accuracy (and so the unpadded call), for row counts on every path (guarded only, strips, dW slabs)."""
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    dc = torch.randn(M, N, generator=g)
+    Kp = (K + 127) // 128 * 128
+    ap = torch.zeros(M, Kp)
+    ap[:, :K] = a
+    apd, wd, bd, dcd = ap.to(dev), w.to(dev), b.to(dev), dc.to(dev)
+    out = NF.linear_fwd(apd, wd, bd).cpu()
+    ref = (a.double() @ w.double() + b.double())
+    assert out.shape == (M, N)
+    assert (out.double() - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max())) * (K ** 0.5)
+    plain = NF.linear_fwd(a.to(dev), wd, bd).cpu()
+    torch.testing.assert_close(out, plain, atol=1e-5, rtol=1e-5)
+    dw, db = NF.linear_bwd_weight(apd, dcd, k_valid=K)
+    dw_ref = a.double().t() @ dc.double()
+    assert dw.shape == (K, N)
+    assert (dw.cpu().double() - dw_ref).abs().max() <= 3e-6 * float(dw_ref.abs().max()) + 1e-5
+    torch.testing.assert_close(db.cpu().double(), dc.double().sum(0), atol=1e-3, rtol=1e-5)
+    # a width that is not K rounded up to 128 is refused, not guessed
+    with pytest.raises(ValueError):
+        NF.linear_fwd(torch.zeros(M, Kp + 128, device=dev), wd, bd)
+
+
+def test_sage_conv_on_zero_padded_features_equals_the_plain_layer(dev):
+    """features that are a view of a 128-aligned buffer with zero pad columns (what InteractionGraph.batch returns): the
+    layer runs on the buffer; output, dW and db equal the layer on a contiguous copy"""
+    g = torch.Generator().manual_seed(5)
+    N, E, Fi, Fo = 6000, 40000, 178, 128
+    ei = rand_edges(N, E, 11)
+    ei = torch.cat([ei, ei.flip(0)], 1).to(dev)
+    x = torch.randn(N, Fi, generator=g)
+    full = torch.zeros(N, 256)
+    full[:, :Fi] = x
+    full = full.to(dev)
+    xv = full[:, :Fi]
+    xv._npi_pad_base = full
+    go = torch.randn(N, Fo, generator=g).to(dev)
+    res = []
+    for inp in (xv, x.to(dev)):
+        torch.manual_seed(0)
+        conv = npi.SAGEConv(Fi, Fo).to(dev)
+        out = conv(inp, ei)
+        out.backward(go)
+        res.append((out.detach().cpu(), conv.weight.grad.cpu(), conv.bias.grad.cpu()))
+    for p, q in zip(*res):                                  # dW sums 6,000 products per element: different summation orders
+        torch.testing.assert_close(p, q, atol=2e-6 * float(q.abs().max()) + 1e-6, rtol=1e-5)
+    assert res[0][1].shape == (Fi, Fo)

@@ -102,3 +102,37 @@ def test_per_key_sizes_replace_the_per_batch_device_read(dev):
         assert torch.equal(data.x, xs) and torch.equal(data.edge_index, es)
         seen += data.num_graphs
     assert seen == 148
+
+
+def test_feature_rows_are_stored_128_aligned_with_zero_pad_columns(dev):
+    """an odd feature width is stored with a row pitch of the next multiple of 128: x is the [n, F] view (bit-exact, as the
+    tests above check), the pad columns of its buffer are zero, and Net_1's first layer equals the unpadded one"""
+    from npi_gnn_amd import subgraph as SG
+    fx = torch.load(os.path.join(G, "rpi369_extract.pt"), map_location="cpu", weights_only=False)
+    ig = InteractionGraph(fx["pairs"].long().to(dev), fx["usable"].to(dev), fx["feat"].to(dev))
+    keys = fx["keys"].long().to(dev)
+    x, ei, b = ig.batch(keys)
+    F = x.size(1)
+    base = getattr(x, "_npi_pad_base", None)
+    if F % 128 != 0 and 2 * ((F + 127) // 128 * 128) <= 3 * F:
+        assert base is not None and base.size(1) == (F + 127) // 128 * 128 and base.data_ptr() == x.data_ptr()
+        assert x.stride(0) == base.size(1) and not bool(base[:, F:].any())
+    old = SG.PAD_FEATURES
+    try:
+        SG.PAD_FEATURES = False
+        x0, e0, b0 = ig.batch(keys)
+    finally:
+        SG.PAD_FEATURES = old
+    assert x0.is_contiguous() and getattr(x0, "_npi_pad_base", None) is None
+    assert torch.equal(x, x0) and torch.equal(ei, e0)
+    torch.manual_seed(0)
+    conv = npi.SAGEConv(F, 128).to(dev)
+    go = torch.randn(x.size(0), 128, device=dev)
+    outs = []
+    for inp in (x, x0):
+        conv.zero_grad()
+        out = conv(inp, ei)
+        out.backward(go)
+        outs.append((out.detach().clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    for p, q in zip(*outs):
+        torch.testing.assert_close(p, q, atol=2e-6 * float(q.abs().max()) + 1e-6, rtol=1e-5)

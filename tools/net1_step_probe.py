@@ -83,6 +83,10 @@ def report(path, R):
     print(f"{'calls/step':>10} {'us/call':>8} {'us/step':>8}  kernel")
     for name, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         print(f"{c / R:10.2f} {t / c / 1e3:8.2f} {t / R / 1e3:8.1f}  {name}")
+    n = len(seg) // R
+    print(f"\n-- the last step in launch order ({n} kernels) --")
+    for r in seg[-n:]:
+        print(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.2f}  {short(r['Kernel_Name'])[:100]}")
 
 
 if __name__ == "__main__":
