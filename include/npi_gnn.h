@@ -406,6 +406,26 @@ int npi_subgraph_features(const float* feat, int64_t ldf, int64_t Ff, const int3
 int npi_confusion_update(const float* scores, int64_t lds, int64_t C, const int64_t* y, int64_t B, int64_t* counts,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The readout sum and MLP head of Net_1 (reference src/classes.py:74-80):
+ *     x = x1 + x2 + x3; relu(lin1) -> dropout -> relu(lin2) -> lin3 -> log_softmax
+ * as one forward and two backward launches (a 200-row batch: every library GEMM / element-wise kernel of the head is
+ * launch-latency bound).  Weights in torch.nn.Linear layout W [out, in], 16-byte aligned; D0 <= 1024, D1, D2 <= 256 (all
+ * multiples of 4), D3 <= 32.  r2 / r3 may be NULL (fewer readouts).  mask [B, D1] holds 0 / 1 (NULL: evaluation), scale =
+ * 1 / (1 - p).  Saved for the backward (may be NULL in evaluation): s = the summed input [B, D0], h1 = relu(lin1) before
+ * dropout [B, D1], h2 [B, D2].  npi_mlp_head_bwd: ds (may be NULL) is the gradient of EACH readout; dW* / db* are written,
+ * not accumulated; every sum over the batch runs in row order (deterministic).
+ * ------------------------------------------------------------------------------------------ */
+int npi_mlp_head_fwd(const float* r1, int64_t ld1, const float* r2, int64_t ld2, const float* r3, int64_t ld3,
+                     int64_t B, int64_t D0, const float* W1, const float* b1, int64_t D1, const float* W2, const float* b2,
+                     int64_t D2, const float* W3, const float* b3, int64_t D3, const float* mask, float scale,
+                     float* s, float* h1, float* h2, float* logp, void* stream);
+int64_t npi_mlp_head_workspace_elems(int64_t B, int64_t D1, int64_t D2, int64_t D3);
+int npi_mlp_head_bwd(int64_t B, int64_t D0, int64_t D1, int64_t D2, int64_t D3, const float* W1, const float* W2,
+                     const float* W3, const float* mask, float scale, const float* s, const float* h1, const float* h2,
+                     const float* logp, const float* dlogp, float* ds, float* dW1, float* db1, float* dW2, float* db2,
+                     float* dW3, float* db3, float* workspace, int64_t workspace_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

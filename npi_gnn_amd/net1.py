@@ -7,17 +7,23 @@ followed statement by statement.  Parameter names and shapes equal the reference
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Callable, Optional
 
 import torch
 import torch.nn.functional as F
 
+from . import head as NH
 from . import metrics as NM
 from . import pool as NP
 from .graph import attach_graph
 from .nn import SAGEConv
 from .subgraph import InteractionGraph
+
+
+# the MLP head through csrc/head.hip (three launches) instead of torch ops (about thirty); NPI_FUSED_HEAD=0: torch ops
+FUSED_HEAD = os.environ.get("NPI_FUSED_HEAD", "1") != "0"
 
 
 class Net_1(torch.nn.Module):
@@ -41,14 +47,18 @@ class Net_1(torch.nn.Module):
     def forward(self, data):
         x, edge_index, batch = data.x, data.edge_index, data.batch
         B = getattr(data, "num_graphs", None)
-        total = None
+        readouts = []
         for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
             x = F.relu(conv(x, edge_index))
             x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
             # torch.cat([gmp(x, batch), gap(x, batch)], dim=1) as ONE kernel (src/classes.py:64,68,72)
-            r = NP.global_max_mean_pool(x, batch, B)
-            total = r if total is None else total + r
-        x = F.relu(self.lin1(total))
+            readouts.append(NP.global_max_mean_pool(x, batch, B))
+        if FUSED_HEAD and NH.head_dims_ok(self.lin1.in_features, self.lin1.out_features, self.lin2.out_features,
+                                          self.lin3.out_features):
+            # x1 + x2 + x3 and the whole MLP head (src/classes.py:74-80) in one forward / two backward launches
+            return NH.mlp_head(readouts, self.lin1, self.lin2, self.lin3, self.dropout, self.training)
+        x = readouts[0] + readouts[1] + readouts[2]
+        x = F.relu(self.lin1(x))
         x = F.dropout(x, p=self.dropout, training=self.training)
         x = F.relu(self.lin2(x))
         x = self.lin3(x)
