@@ -329,6 +329,9 @@ int npi_topk_score(const float* x, int64_t ldx, const float* w, int64_t N, int64
 int npi_graph_bounds(const int64_t* batch, int64_t N, int64_t B, int32_t* graph_ptr, void* stream);
 int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
                     int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, void* stream);
+/* max_nodes: an upper bound of the largest graph of the batch, when the caller knows one (0 = unknown) */
+int npi_topk_select_ex(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
+                    int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, int64_t max_nodes, void* stream);
 int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
                     const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
                     float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream);

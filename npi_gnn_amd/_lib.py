@@ -76,6 +76,7 @@ PROTOTYPES = {
     "npi_topk_score": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_graph_bounds": (c_int, [_P, _I, _I, _P, _P]),
     "npi_topk_select": (c_int, [_P, _P, _I, _I, c_float, _P, _P, _P, _P, _P]),
+    "npi_topk_select_ex": (c_int, [_P, _P, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
     "npi_topk_gather": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "npi_topk_gather_ex": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "npi_filter_adj_workspace_elems": (_I, [_I]),

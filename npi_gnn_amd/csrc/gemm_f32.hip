@@ -799,9 +799,16 @@ __device__ __forceinline__ void signal(int* flag) {      // one count per wave, 
 // tile-start path (scalar loads pending there) and falls back to lgkmcnt(0) in front of the first MFMA of every step,
 // i.e. waits for the reads issued a few cycles earlier.  LDS operations complete in order, so "at most n younger ones
 // outstanding" is exact.  Issue order per step: B(0) | B(1) | ... | A(0) | A(1), B(TN-1)  (three planes each).
+// The fragments live in registers as four opaque dwords (frag_t) and become bf16x8 only as MFMA operands: kept as a vector of
+// eight bf16 across basic blocks, hipcc "re-packs" them between the asm read and the asm wait (v_lshrrev + v_perm pairs that
+// are the identity on arrived data) -- on registers whose LDS data is still in flight that mixes stale and new halves.  It
+// showed only under contention (the first overlapped backward, while the by-source CSR was being sorted on the other stream):
+// dW off by 3 %.  tests: test_split_gemms_are_exact_under_concurrent_load.
+typedef u32x4r frag_t;
+#define FRAG(x) __builtin_bit_cast(bf16x8, x)
 #define NPI_DSR(dst, addr, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory")
 template <int PL>
-__device__ __forceinline__ void ws_read3(bf16x8 (&f)[3], uint32_t addr) {
+__device__ __forceinline__ void ws_read3(frag_t (&f)[3], uint32_t addr) {
     NPI_DSR(f[0], addr, 0); NPI_DSR(f[1], addr, PL); NPI_DSR(f[2], addr, 2 * PL);
 }
 // at most N fragment reads still outstanding; the fragments are in/out operands so that no use moves above the wait
@@ -809,8 +816,8 @@ __device__ __forceinline__ void ws_read3(bf16x8 (&f)[3], uint32_t addr) {
 
 template <int TM, int TN, int APL, int BPL, int BUF, int NST, bool ONE_MMA = false>
 __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, int* empty, int g, bool more,
-                                                const int (&offa)[TM], const int (&offb)[TN], bf16x8 (&af)[TM][3],
-                                                bf16x8 (&bf)[TN][3], f32x16 (&acc)[TM][TN],
+                                                const int (&offa)[TM], const int (&offb)[TN], frag_t (&af)[TM][3],
+                                                frag_t (&bf)[TN][3], f32x16 (&acc)[TM][TN],
                                                 unsigned long long* t_wait = nullptr) {
     static_assert(TM == 2, "the wait counts below assume two row blocks");
     const int stg = g & (NST - 1), stn = (g + 1) & (NST - 1);
@@ -828,13 +835,13 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
             // B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t)
             f32x16 c = acc[i][j];
             if (!ONE_MMA) {
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][2], af[i][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][2]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][2]), FRAG(af[i][0]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][1]), FRAG(af[i][1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][1]), FRAG(af[i][0]), c, 0, 0, 0);
             }
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][0]), c, 0, 0, 0);
             acc[i][j] = c;
             __builtin_amdgcn_sched_barrier(0);           // row block by row block: the first one of a step needs only A(0)
             if (j == TN - 1 && more) ws_read3<APL>(af[i], nx + (uint32_t)offa[i]);   // row block i is finished: refill its A
@@ -859,7 +866,7 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
 // first step's fragments (prologue of the pipeline above)
 template <int TM, int TN, int APL, int BPL>
 __device__ __forceinline__ void ws_consume_first(uint32_t st, const int (&offa)[TM], const int (&offb)[TN],
-                                                 bf16x8 (&af)[TM][3], bf16x8 (&bf)[TN][3]) {
+                                                 frag_t (&af)[TM][3], frag_t (&bf)[TN][3]) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) ws_read3<BPL>(bf[j], st + (uint32_t)offb[j]);
 #pragma unroll
@@ -1043,7 +1050,7 @@ gemm_split_ws_kernel(SplitArgs a) {
     for (int i = 0; i < TM; ++i) rs[i] = 1.f;
     const float floor_ = a.ep.relu != 0 ? 0.f : -__builtin_huge_valf();
     int g = 0;                                              // k-steps consumed so far: stage g % NST, use g / NST
-    bf16x8 af[TM][3], bf[TN][3];
+    frag_t af[TM][3], bf[TN][3];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     unsigned long long ca_wait = 0, ca_epi = 0;
     const unsigned long long c_begin = NPI_STAMP();
@@ -1277,7 +1284,7 @@ gemm_dw_split_kernel(DwArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     if (nk > 0) {
-        bf16x8 af[TM][3], bf[TN][3];
+        frag_t af[TM][3], bf[TN][3];
         const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
         wait_ge(&full[0], 4);
         ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);

@@ -54,9 +54,17 @@ __global__ void graph_bounds_kernel(const int64_t* __restrict__ batch, int64_t N
     graph_ptr[g] = (int32_t)lo;
 }
 
-// out_ptr[g] = sum_{g' < g} ceil(ratio * n_g'); one workgroup, B is small (graphs per batch)
+// out_ptr[g] = sum_{g' < g} ceil(ratio * n_g'); one workgroup, B is small (graphs per batch).  The same launch clears the
+// status word and presets remap to -1 (blocks 1 ..: one element per thread) -- three launches in one.
 __global__ void __launch_bounds__(256)
-topk_counts_kernel(const int32_t* __restrict__ graph_ptr, int B, float ratio, int32_t* __restrict__ out_ptr) {
+topk_counts_kernel(const int32_t* __restrict__ graph_ptr, int B, float ratio, int32_t* __restrict__ out_ptr,
+                   int32_t* __restrict__ status, int32_t* __restrict__ remap, int64_t N) {
+    if (blockIdx.x > 0) {
+        const int64_t i = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x;
+        if (i < N) remap[i] = -1;
+        return;
+    }
+    if (threadIdx.x == 0) *status = 0;
     __shared__ int lds[256];
     int carry = 0;
     for (int base = 0; base < B; base += 256) {
@@ -579,15 +587,21 @@ extern "C" int npi_graph_bounds(const int64_t* batch, int64_t N, int64_t B, int3
 // status[0] bit 1 is set when a graph has more than 16384 nodes (unsupported)
 extern "C" int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
                                int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, void* stream_) {
+    return npi_topk_select_ex(score, graph_ptr, N, B, ratio, out_ptr, perm, remap, status, 0, stream_);
+}
+// max_nodes: an upper bound of the largest graph of the batch the CALLER knows (0 = unknown): at most 1,024 skips the launch
+// for graphs of 1,025 .. 16,384 nodes (it would find none)
+extern "C" int npi_topk_select_ex(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
+                                  int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, int64_t max_nodes,
+                                  void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && B >= 0 && ratio > 0.f && ratio <= 1.f, "npi_topk_select: bad argument");
+    NPI_REQUIRE(N >= 0 && B >= 0 && ratio > 0.f && ratio <= 1.f && max_nodes >= 0, "npi_topk_select: bad argument");
     NPI_REQUIRE(out_ptr && status && (N == 0 || (score && graph_ptr && perm && remap)), "npi_topk_select: null pointer");
-    (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
-    if (N > 0) fill_i32_pool_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(remap, N, -1);
-    topk_counts_kernel<<<1, 256, 0, stream>>>(graph_ptr, (int)B, ratio, out_ptr);
+    topk_counts_kernel<<<(unsigned)(1 + ceil_div(N, 256)), 256, 0, stream>>>(graph_ptr, (int)B, ratio, out_ptr, status, remap, N);
     if (B > 0) {
         topk_select_kernel<1024, -1><<<(unsigned)B, 256, 0, stream>>>(score, graph_ptr, out_ptr, (int)B, perm, remap, status);
-        topk_select_kernel<16384, 1024><<<(unsigned)B, 1024, 0, stream>>>(score, graph_ptr, out_ptr, (int)B, perm, remap, status);
+        if (max_nodes == 0 || max_nodes > 1024)
+            topk_select_kernel<16384, 1024><<<(unsigned)B, 1024, 0, stream>>>(score, graph_ptr, out_ptr, (int)B, perm, remap, status);
     }
     return check_launch("npi_topk_select");
 }

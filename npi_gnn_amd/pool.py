@@ -69,8 +69,10 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     perm = torch.empty(max(N, 1), **i32)
     remap = torch.empty(max(N, 1), **i32)
     status = torch.empty(1, **i32)
-    check(lib.npi_topk_select(ptr(score), ptr(gp), N, B, float(ratio), ptr(out_ptr), ptr(perm), ptr(remap),
-                              ptr(status), st), "npi_topk_select")
+    sizes = getattr(batch, "_npi_sizes", None)               # host-known graph sizes: the largest one picks the kernels
+    max_nodes = int(sizes.max()) if sizes is not None and sizes.numel() == B and B > 0 else 0
+    check(lib.npi_topk_select_ex(ptr(score), ptr(gp), N, B, float(ratio), ptr(out_ptr), ptr(perm), ptr(remap),
+                                 ptr(status), max_nodes, st), "npi_topk_select")
     # filter_adj needs only the old->new id map, so it runs before the sizes are known
     E = edge_index.size(1)
     src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()

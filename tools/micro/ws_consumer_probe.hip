@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(512, 1) probe(float* out, const float* rnd, in
     for (int j = 0; j < TN; ++j) offb[j] = 3 * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
     f32x16 acc[TM][TN];
     for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    bf16x8 af[TM][3], bf[TN][3];
+    frag_t af[TM][3], bf[TN][3];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);
     const unsigned long long t0 = __builtin_readcyclecounter();
