@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s is the guide's measured copy rate)
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
+MFMA_BF16_RANDOM_TF = 1850.0   # the same pipe on random operands (clock held under load; tools/micro/mfma_bf16_rate.hip: 1.59-1.90 PF/s)
 SETUP_STEPS = 8                # untimed steps before the warm-up (lazy initialisation; reported as config.setup_steps)
 
 
@@ -584,6 +585,10 @@ def main():
             "frac_note": "issued bf16-MFMA flops (6 x f32-equivalent) / dense bf16 MFMA peak" if split_on else
                          "f32 flops / f32 MFMA peak",
             "f32_equivalent_vs_f32_mfma_peak": (solo_tf / MFMA_F32_PEAK_TF) if solo_tf else None,
+            # what the bf16 pipe sustains on random operands (the chip lowers its clock under MFMA load): measured with a bare
+            # v_mfma_f32_32x32x16_bf16 loop, tools/micro/mfma_bf16_rate.hip, 1.59-1.90 PF/s box to box
+            "sustained_random_operands": {"peak": MFMA_BF16_RANDOM_TF, "unit": "TFLOP/s", "source": "offline micro-benchmark",
+                                          "frac": (6.0 * solo_tf / MFMA_BF16_RANDOM_TF) if (solo_tf and split_on) else None},
             "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},
             "per_gemm_tflops_f32_equivalent": {k: v[0] / (v[1] * 1e-3) / 1e12 for k, v in gem.items() if v[1] > 0},
             "note": "bwd_weight (gemm_dw_split_kernel: both operands split on the fly) is timed while it shares the CUs "

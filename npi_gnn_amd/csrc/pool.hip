@@ -110,11 +110,15 @@ topk_select_kernel(const float* __restrict__ score, const int32_t* __restrict__ 
     if (n > CAP) { if (CAP > 1024 && threadIdx.x == 0) atomicOr(too_big, 2); return; }
     if (n <= LO) return;                                  // the smaller instantiation handles it
     const int T = blockDim.x;
-    for (int i = threadIdx.x; i < CAP; i += T) keys[i] = (i < n) ? topk_key(score[nb + i], (uint32_t)i) : ~0ull;
+    // the network only spans the next power of two above THIS graph's size (a 140-node graph sorts 256 keys in 36 stages,
+    // not 1,024 in 55): the pooled layers' graphs are a half and a quarter of the first one's
+    int cap = 64;
+    while (cap < n) cap <<= 1;
+    for (int i = threadIdx.x; i < cap; i += T) keys[i] = (i < n) ? topk_key(score[nb + i], (uint32_t)i) : ~0ull;
     __syncthreads();
-    for (int k = 2; k <= CAP; k <<= 1) {
+    for (int k = 2; k <= cap; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < CAP; i += T) {
+            for (int i = threadIdx.x; i < cap; i += T) {
                 const int l = i ^ j;
                 if (l > i) {
                     const uint64_t a = keys[i], b = keys[l];
