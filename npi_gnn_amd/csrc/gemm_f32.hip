@@ -720,7 +720,8 @@ __device__ __forceinline__ void split3_store16(f32x4r lo, f32x4r hi, char* img, 
 // measurement switches of gemm_split_ws_kernel (tools/build_variant.sh <name> -DNPI_WS_PROBE=<bits>; timing only, wrong
 // numbers): 1 = one MFMA per tile pair instead of six, 2 = no split arithmetic in the producer (plain bf16 pack into all
 // three planes), 4 = no C stores, 8 = the producer stores nothing to LDS (hand-over only), 32 = no global loads of A,
-// 64 = no global loads of the weight planes (stale registers are stored)
+// 64 = no global loads of the weight planes (stale registers are stored), 128 = the MFMAs as v_mfma_f32_16x16x32_bf16 (twelve per
+// tile pair: the same flops and fragment traffic in the shape that holds a higher clock)
 // 16 = cycle stamps: npi_ws_probe_read() returns, summed over the workgroups, the cycles producer wave 4 spent waiting for
 // an empty stage / for its loads / splitting + storing, its total, and consumer wave 0's wait for a full stage / epilogue /
 // total, and the k-steps counted
@@ -834,6 +835,19 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
             if (j == 0 && i == 1) NPI_LGKM_WAIT(4, af[1]);        // younger: B(TN-1), the poll
             // B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t)
             f32x16 c = acc[i][j];
+#if NPI_WS_PROBE & 128
+            {   // timing only: the same flops as twelve v_mfma_f32_16x16x32_bf16 (the shape that holds a higher clock)
+                typedef float f32x4m __attribute__((ext_vector_type(4)));
+                f32x4m q0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), q1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+                f32x4m q2 = __builtin_shufflevector(c, c, 8, 9, 10, 11), q3 = __builtin_shufflevector(c, c, 12, 13, 14, 15);
+#define NPI_M16(Q, BP, AP) Q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FRAG(bf[j][BP]), FRAG(af[i][AP]), Q, 0, 0, 0)
+                NPI_M16(q0, 0, 2); NPI_M16(q1, 0, 2); NPI_M16(q2, 2, 0); NPI_M16(q3, 2, 0); NPI_M16(q0, 1, 1); NPI_M16(q1, 1, 1);
+                NPI_M16(q2, 0, 1); NPI_M16(q3, 0, 1); NPI_M16(q0, 1, 0); NPI_M16(q1, 1, 0); NPI_M16(q2, 0, 0); NPI_M16(q3, 0, 0);
+#undef NPI_M16
+                c = __builtin_shufflevector(__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                            __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            }
+#else
             if (!ONE_MMA) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][2]), c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][2]), FRAG(af[i][0]), c, 0, 0, 0);
@@ -842,6 +856,7 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][1]), FRAG(af[i][0]), c, 0, 0, 0);
             }
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][0]), c, 0, 0, 0);
+#endif
             acc[i][j] = c;
             __builtin_amdgcn_sched_barrier(0);           // row block by row block: the first one of a step needs only A(0)
             if (j == TN - 1 && more) ws_read3<APL>(af[i], nx + (uint32_t)offa[i]);   // row block i is finished: refill its A
