@@ -250,24 +250,27 @@ def entry_weights(graph: CSRGraph, edge_weight: Optional[torch.Tensor], fill: fl
 # ---------------------------------------------------------------------------------------------
 class _SageConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, graph: CSRGraph, w_entry=None):
+    def forward(ctx, x, weight, bias, graph: CSRGraph, w_entry=None, relu: bool = False):
         # a2-a4: gather + scatter_mean (w_entry: PyG's `edge_weight.view(-1, 1) * x_j`; the mean still divides by the count)
         # x may be the zero-padded base of the caller's features (sage_conv): agg then keeps the padded width -- zero
         # columns stay zero under a weighted mean -- and both GEMMs run on it (linear_fwd / linear_bwd_weight)
         agg = segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True)
-        out = linear_fwd(agg, weight, bias)                               # a5: agg @ W + b
+        out = linear_fwd(agg, weight, bias, relu=relu)                    # a5: agg @ W + b (ReLU in the epilogue on request)
         ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None
         ctx.graph = graph
         ctx.w_src = w_entry[1] if w_entry else None
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(agg, weight)
+        ctx.relu = relu
+        ctx.save_for_backward(agg, weight, *([out] if relu else []))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        agg, weight = ctx.saved_tensors
+        agg, weight = ctx.saved_tensors[:2]
         graph: CSRGraph = ctx.graph
         grad_out = _fc(grad_out, "grad_out", agg)
+        if ctx.relu:                                            # threshold_backward, as F.relu's autograd does it
+            grad_out = torch.ops.aten.threshold_backward(grad_out, ctx.saved_tensors[2], 0)
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
@@ -297,11 +300,11 @@ class _SageConvFn(torch.autograd.Function):
                 main.wait_stream(side)
             else:
                 dx = segsum(graph, tside(), dagg, w=ctx.w_src, mean=False)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              normalize: bool = False, edge_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+              normalize: bool = False, edge_weight: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     """PyG 1.4.2 ``SAGEConv(normalize=False, concat=False).forward`` on MI355X
     (call sites: reference ``src/classes.py:62,66,70``).  ``edge_weight [E]`` scales the messages
     (no gradient flows to it, as in the reference's use of the layer)."""
@@ -316,7 +319,9 @@ def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[
     if (base is not None and not x.requires_grad and x.dtype == torch.float32 and base.size(0) == x.size(0)
             and base.size(1) == _pad128(x.size(1)) and weight.size(0) == x.size(1) and base.data_ptr() == x.data_ptr()):
         x = base
-    out = _SageConvFn.apply(x, weight, bias, graph, w_entry)
+    if relu and normalize:
+        raise ValueError("sage_conv: relu=True applies to the projection's output; normalize=True comes after it in PyG")
+    out = _SageConvFn.apply(x, weight, bias, graph, w_entry, relu)
     if normalize:
         out = torch.nn.functional.normalize(out, p=2.0, dim=-1)
     return out

@@ -49,7 +49,7 @@ class Net_1(torch.nn.Module):
         B = getattr(data, "num_graphs", None)
         readouts = []
         for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
-            x = F.relu(conv(x, edge_index))
+            x = conv(x, edge_index, relu=True)               # F.relu(conv(x, edge_index)), the ReLU in the GEMM's epilogue
             x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
             # torch.cat([gmp(x, batch), gap(x, batch)], dim=1) as ONE kernel (src/classes.py:64,68,72)
             readouts.append(NP.global_max_mean_pool(x, batch, B))

@@ -61,10 +61,13 @@ class SAGEConv(nn.Module):
         _uniform(self.weight.size(0), self.weight)
         _uniform(self.weight.size(0), self.bias)
 
-    def forward(self, x, edge_index, edge_weight=None, size=None):
+    def forward(self, x, edge_index, edge_weight=None, size=None, *, relu: bool = False):
+        """``relu=True`` (an extension of the PyG signature): ``F.relu(conv(x, edge_index))`` with the ReLU applied in the
+        projection GEMM's epilogue -- the same values, one launch and one activation-sized tensor fewer."""
         if size is not None:
             raise NotImplementedError("SAGEConv: the bipartite `size` form is not used by NPI-GNN")
-        return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize, edge_weight=edge_weight)
+        return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize, edge_weight=edge_weight,
+                            relu=relu)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

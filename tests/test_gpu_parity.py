@@ -655,3 +655,37 @@ def test_sage_conv_on_zero_padded_features_equals_the_plain_layer(dev):
     for p, q in zip(*res):                                  # dW sums 6,000 products per element: different summation orders
         torch.testing.assert_close(p, q, atol=2e-6 * float(q.abs().max()) + 1e-6, rtol=1e-5)
     assert res[0][1].shape == (Fi, Fo)
+
+
+@pytest.mark.parametrize("Fi,padded", [(128, False), (178, True)])
+def test_sage_conv_relu_in_the_epilogue_equals_relu_after_the_layer(dev, Fi, padded):
+    """SAGEConv(..., relu=True) == F.relu(SAGEConv(...)): output bit-identical (the same GEMM, the clamp in its epilogue),
+    gradients equal (threshold_backward on the saved output), on plain and on zero-padded features"""
+    g = torch.Generator().manual_seed(3)
+    N, E, Fo = 5000, 30000, 128
+    ei = rand_edges(N, E, 21)
+    ei = torch.cat([ei, ei.flip(0)], 1).to(dev)
+    x = torch.randn(N, Fi, generator=g)
+    if padded:
+        full = torch.zeros(N, 256)
+        full[:, :Fi] = x
+        full = full.to(dev)
+        xd = full[:, :Fi]
+        xd._npi_pad_base = full
+    else:
+        xd = x.to(dev).requires_grad_(True)
+    go = torch.randn(N, Fo, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        conv = npi.SAGEConv(Fi, Fo).to(dev)
+        if not padded:
+            xd.grad = None
+        out = conv(xd, ei, relu=True) if fused else torch.relu(conv(xd, ei))
+        out.backward(go)
+        res.append((out.detach().clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), None if padded else xd.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert bool((res[0][0] == 0).any()) and bool((res[0][0] > 0).any())
+    for p, q in zip(res[0][1:], res[1][1:]):
+        if p is not None:
+            torch.testing.assert_close(p, q, atol=1e-6 * float(q.abs().max()) + 1e-7, rtol=1e-6)
