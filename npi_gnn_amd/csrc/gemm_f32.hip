@@ -756,17 +756,21 @@ struct TileWalk {
     __device__ __forceinline__ void decode() {
         // q -> (m-tile, n-tile): q & 7 = XCD of the workgroup (round-robin dispatch), consecutive slots of an
         // XCD take the n-tiles of one m-tile (their A rows then hit that XCD's L2)
+        // (mt, nt) only ever hold a VALID tile: the producers' loads run a few k-steps past the end of the walk and drop the
+        // data -- from a slot of the rounded-up grid beyond the last row tile they would read up to 7 x 128 rows past the end
+        // of A, which is a memory fault when A ends where its mapping ends
         for (;;) {
             if (q >= qend) return;
-            nt = (q >> 3) % tiles_n;
-            mt = ((q >> 3) / tiles_n) * 8 + (q & 7);
-            if (mt < tiles_m) return;
+            const int nt_ = (q >> 3) % tiles_n;
+            const int mt_ = ((q >> 3) / tiles_n) * 8 + (q & 7);
+            if (mt_ < tiles_m) { mt = mt_; nt = nt_; return; }
             q += G;
         }
     }
     __device__ __forceinline__ void init(int b, int G_, int nk_, int tm, int tn, int M = -1) {
         G = G_; nk = nk_; tiles_m = tm; tiles_n = tn;
         last_row0 = M >= 128 ? M - 128 : (tm - 1) * 128;
+        mt = 0; nt = 0;
         qend = ((tm + 7) / 8) * 8 * tn;
         q = b; kt = 0;
         decode();

@@ -689,3 +689,23 @@ def test_sage_conv_relu_in_the_epilogue_equals_relu_after_the_layer(dev, Fi, pad
     for p, q in zip(res[0][1:], res[1][1:]):
         if p is not None:
             torch.testing.assert_close(p, q, atol=1e-6 * float(q.abs().max()) + 1e-7, rtol=1e-6)
+
+
+def test_split_gemm_reads_nothing_past_the_end_of_its_operand(dev):
+    """The persistent split GEMM's producers run a few k-steps past the end of their tile walk and drop the data; those loads
+    must stay inside A.  A here fills its own allocator segment to the last byte (a multiple of 2 MiB, allocated after the
+    cache was emptied) and has a row-tile count that is not a multiple of the 8 XCD slots -- the shape in which a walk that
+    parked on a slot of the rounded-up grid read up to 7 x 128 rows past the end (a GPU memory fault when nothing is mapped
+    there: it took the whole test process down in a full-suite run)."""
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    M, K, N = 512 * 301, 1024, 128                          # 4 KiB rows: 301 x 2 MiB; 1,204 row tiles = 8 x 150 + 4
+    a = torch.empty((M, K), device=dev).normal_()
+    w = torch.randn(K, N, device=dev) * 0.03
+    out = NF.linear_fwd(a, w, None)
+    torch.cuda.synchronize()
+    rows = torch.tensor([0, 1, M // 2, M - 129, M - 128, M - 1], device=dev)
+    ref = a[rows].double() @ w.double()
+    assert float((out[rows].double() - ref).abs().max()) < 1e-4
+    del a, out
+    torch.cuda.empty_cache()
