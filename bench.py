@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s is the guide's m
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
 MFMA_BF16_RANDOM_TF = 1850.0   # the same pipe on random operands (clock held under load; tools/micro/mfma_bf16_rate.hip: 1.59-1.90 PF/s)
-SETUP_STEPS = 8                # untimed steps before the warm-up (lazy initialisation; reported as config.setup_steps)
+SETUP_STEPS = 40               # untimed steps before the warm-up (lazy initialisation, clock ramp: ~0.3 s of load; reported as config.setup_steps)
 
 
 def parse(argv=None):
