@@ -315,9 +315,46 @@ def run_configs(dev, args, c4):
                 "parity_max_abs_err": float((h[f3["rows"]] - f3["gcn256_out"]).abs().max()),
                 "parity": "oracle (unpinned: GCNConv)"}
 
+    def r_step():
+        # the reference's REAL regime (SURVEY 8(a) "R"): one Net_1 training step -- forward, nll_loss, backward, Adam -- on a
+        # batch of 200 enclosing subgraphs of NPInter2 fold 0, extracted on the device; eager and replayed from a HIP graph
+        import torch.nn.functional as F_
+        from npi_gnn_amd import net1
+        from npi_gnn_amd.subgraph import InteractionGraph
+        fz = torch.load(os.path.join(G, "npinter2_folds.pt"), map_location="cpu", weights_only=False)
+        fb = fz["fold0"]
+        pairs, label, Nn = fz["pairs"].long(), fz["label"].long(), fz["num_nodes"]
+        test = torch.cat([fb["test_pos"], fb["test_neg"]]).long()
+        usable = ~torch.isin(pairs[:, 0] * Nn + pairs[:, 1], test[:, 0] * Nn + test[:, 1])
+        feat = torch.cat([fb["node2vec"], fz["kmer"]], dim=1)
+        ig = InteractionGraph(pairs.to(dev), usable.to(dev), feat.to(dev), num_nodes=Nn)
+        keys, yk = pairs[usable][:800].to(dev), label[usable][:800].to(dev)
+        loader = net1.KeyLoader(ig, keys, yk, 200)
+        torch.manual_seed(0)
+        model = net1.Net_1(feat.size(1) + 1, 2).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-3, device=dev), weight_decay=1e-3, capturable=True, fused=True)
+        ep = net1.GraphedEpoch(model, loader, opt, dev)
+        ep()                                                    # eager epoch (4 batches)
+        d0 = ep.batches[0]
+
+        def eager():
+            opt.zero_grad()
+            F_.nll_loss(model(d0), d0.y).backward()
+            opt.step()
+        ms_eager = _timeit(eager, 100, 10)
+        ep()                                                    # captures every batch's step, replays it once
+        ms_replay = _timeit(ep.graphs[0].replay, 200, 10)
+        return {"workload": f"NPInter2 fold 0, first batch of 200 enclosing subgraphs ({d0.x.size(0)} nodes, "
+                            f"{d0.edge_index.size(1)} directed edges, F = {d0.x.size(1)}): one Net_1 training step "
+                            "(forward, nll_loss, backward, Adam), fp32",
+                "ms_per_step": ms_replay, "ms_per_step_eager": ms_eager,
+                "note": "ms_per_step: the step replayed from a HIP graph (net1.GraphedEpoch); the reference logs 1413.5 s for "
+                        "its 50-epoch fold = 4,200 such steps + evaluations (examples/train_npinter2.py: 5.2 s)"}
+
     guarded("C1", c1)
     guarded("C2", c2)
     guarded("C3", c3)
+    guarded("R_net1_step", r_step)
     del graph, norm
 
     # GCN / GAT layer at the C4 shape, on the headline graph
