@@ -349,6 +349,16 @@ int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int3
  * into a HIP graph).  Negative ids in src / dst are always treated as dropped.  Output arrays must not alias the input. */
 int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                       int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, int pad_tail, void* stream);
+int64_t npi_filter_adj_newpos_offset(int64_t E);   /* npi_filter_adj_ex: workspace[offset + e] = new position of input edge e, -1 if dropped */
+/* The by-target CSR of the POOLED graph from the CSR of its parent, without a sort: row perm[r'] of the parent with the
+ * entries whose source survived (remap[col] >= 0), in the parent's order, self loop last; eid through newpos
+ * (npi_filter_adj_ex's workspace tail).  Bit-identical to npi_csr_build on the filtered edge list.  nnz_max_out = capacity
+ * of col_o / eid_o / rowidx_o (>= the surviving entries; E_in + n_out is what a fresh build would use); workspace int32[n_out];
+ * n_out <= npi_csr_filter_max_rows(). */
+int64_t npi_csr_filter_max_rows(void);
+int npi_csr_filter(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const int32_t* perm, const int32_t* remap,
+                   const int32_t* newpos, int64_t n_out, int64_t nnz_max_out, int32_t* rowptr_o, int32_t* col_o,
+                   int32_t* eid_o, int32_t* rowidx_o, int32_t* item_row_o, int32_t* status_o, int32_t* workspace, void* stream);
 int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
                          float* out, void* stream);
 

@@ -206,7 +206,7 @@ scan_small_kernel(int32_t* __restrict__ v, int n, int32_t* __restrict__ total) {
 __global__ void __launch_bounds__(256)
 filter_write_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E,
                     const int32_t* __restrict__ remap, const int32_t* __restrict__ tile_off,
-                    int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst) {
+                    int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst, int32_t* __restrict__ newpos) {
     __shared__ int wcnt[4];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t wbase = (int64_t)blockIdx.x * FA_TILE + wave * 512;
@@ -234,11 +234,14 @@ filter_write_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint64_t m = __ballot(keep[j]);
+        const int64_t e = wbase + j * 64 + lane;
+        int pos = -1;
         if (keep[j]) {
-            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            pos = off + __popcll(m & ((1ull << lane) - 1ull));
             out_src[pos] = s[j];
             out_dst[pos] = d[j];
         }
+        if (newpos != nullptr && e < E) newpos[e] = pos;      // where the edge went (-1: dropped): npi_csr_filter's eid map
         off += __popcll(m);
     }
 }
@@ -626,7 +629,10 @@ extern "C" int npi_topk_gather_ex(const float* x, int64_t ldx, const float* scor
     return check_launch("npi_topk_gather");
 }
 
-extern "C" int64_t npi_filter_adj_workspace_elems(int64_t E) { return ceil_div(E > 0 ? E : 1, FA_TILE) + 2; }
+// tile counts (+ 2), then -- npi_filter_adj_ex only -- the new position of every input edge (-1: dropped), which
+// npi_csr_filter takes as its `newpos`
+extern "C" int64_t npi_filter_adj_workspace_elems(int64_t E) { return ceil_div(E > 0 ? E : 1, FA_TILE) + 2 + (E > 0 ? E : 0); }
+extern "C" int64_t npi_filter_adj_newpos_offset(int64_t E) { return ceil_div(E > 0 ? E : 1, FA_TILE) + 2; }
 
 // out_src/out_dst: capacity E; count[0] = number of surviving edges (device)
 extern "C" int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
@@ -648,7 +654,8 @@ extern "C" int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t
     filter_flag_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, pad_tail ? out_src : nullptr,
                                                    pad_tail ? out_dst : nullptr);
     scan_small_kernel<<<1, 256, 0, stream>>>(workspace, ntiles, count);
-    filter_write_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, out_src, out_dst);
+    filter_write_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, out_src, out_dst,
+                                                    workspace + npi_filter_adj_newpos_offset(E));
     return check_launch("npi_filter_adj");
 }
 

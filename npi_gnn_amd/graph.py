@@ -140,7 +140,8 @@ class CSRGraph:
     ``by_dst`` groups entries by target node (forward aggregation, PyG flow ``source_to_target``);
     ``by_src`` groups them by source node (backward: dX = A^T ...), built lazily."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, self_loops: bool = True):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, self_loops: bool = True, by_dst: Optional[CSRSide] = None):
+        """``by_dst``: a by-target side somebody already derived for this very edge list (``filtered_side``): not rebuilt."""
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be a LongTensor of shape [2, E]")
         require_gpu(edge_index)
@@ -156,7 +157,8 @@ class CSRGraph:
         # rows of a [2,E] tensor are contiguous when the tensor is; otherwise copy (index plumbing)
         self._src = edge_index[0].contiguous()
         self._dst = edge_index[1].contiguous()
-        self.by_dst = _build_side(self._dst, self._src, self.num_edges, self.num_nodes, self.self_loops)
+        self.by_dst = by_dst if by_dst is not None else \
+            _build_side(self._dst, self._src, self.num_edges, self.num_nodes, self.self_loops)
         self._by_src: Optional[CSRSide] = None
 
     @property
@@ -188,7 +190,50 @@ def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:
     g = getattr(edge_index_or_graph, "_npi_graph", None)
     if isinstance(g, CSRGraph) and g.num_nodes == num_nodes and g.num_edges == edge_index_or_graph.size(1):
         return g
-    return CSRGraph(edge_index_or_graph, num_nodes)
+    # the edge list TopKPooling returned: its CSR is the parent's, filtered (no sort)
+    src = getattr(edge_index_or_graph, "_npi_graph_from", None)
+    g = None
+    if src is not None and src[4] == num_nodes and src[5] == edge_index_or_graph.size(1):
+        side = filtered_side(*src)
+        if side is not None:
+            g = CSRGraph(edge_index_or_graph, num_nodes, by_dst=side)
+        edge_index_or_graph._npi_graph_from = None           # the parent's arrays are not kept alive any longer
+    if g is None:
+        g = CSRGraph(edge_index_or_graph, num_nodes)
+    if getattr(edge_index_or_graph, "_npi_symmetric", False):
+        # an edge list this package produced itself (device-side extraction, filter_adj) and nobody modifies in place: its
+        # CSR stays on it -- the pooling layer behind the conv derives the pooled graph's CSR from it (filtered_side)
+        edge_index_or_graph._npi_graph = g
+    return g
+
+
+def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newpos: torch.Tensor, n_out: int,
+                  num_edges_out: int) -> Optional[CSRSide]:
+    """By-target side of the graph TopKPooling leaves -- nodes ``perm`` (int32, new -> old) of the parent, renumbered by
+    ``remap``, edges filtered in order (``newpos``: where ``npi_filter_adj_ex`` put every input edge) -- derived from the
+    parent's side without a sort (``npi_csr_filter``).  Identical to ``build_side`` on the filtered edge list of length
+    ``num_edges_out`` (the padded length when the list is padded).  None when the shape is outside the kernel's range."""
+    lib = load()
+    dev = parent.rowptr.device
+    n_out = int(n_out)
+    if n_out > int(lib.npi_csr_filter_max_rows()) or parent.n_rows != parent.n_cols:
+        return None
+    nnz_max = int(num_edges_out) + n_out
+    n_items = int(lib.npi_num_items(nnz_max))
+    i32 = dict(dtype=torch.int32, device=dev)
+    rowptr = torch.empty(n_out + 1, **i32)
+    col = torch.empty(max(nnz_max, 1), **i32)
+    eid = torch.empty(max(nnz_max, 1), **i32)
+    rowidx = torch.empty(max(nnz_max, 1), **i32)
+    item_row = torch.empty(n_items + 1, **i32)
+    status = torch.empty(1, **i32)
+    ws = torch.empty(max(n_out, 1), **i32)
+    check(lib.npi_csr_filter(ptr(parent.rowptr), ptr(parent.col), ptr(parent.eid), ptr(perm), ptr(remap), ptr(newpos), n_out,
+                             nnz_max, ptr(rowptr), ptr(col), ptr(eid), ptr(rowidx), ptr(item_row), ptr(status), ptr(ws),
+                             stream_ptr(dev)), "npi_csr_filter")
+    side = CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
+    side.n_rows = side.n_cols = n_out
+    return side
 
 
 def attach_graph(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:

@@ -13,6 +13,7 @@ outputs.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -31,6 +32,10 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
+
+
+# the pooled graph's CSR by filtering the parent's instead of a fresh sort (NPI_DERIVE_CSR=0: always sort)
+DERIVE_CSR = os.environ.get("NPI_DERIVE_CSR", "1") != "0"
 
 
 def graph_ptr(batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Tensor:
@@ -130,13 +135,22 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     ei_out = out_ei[:, :e_out]
     if getattr(edge_index, "_npi_symmetric", False):
         ei_out._npi_symmetric = True                     # both directions of a pair survive or fall together
+    # The conv in front of this layer left the CSR of `edge_index` on it (graph.as_graph): the pooled graph's CSR is that
+    # one filtered -- four launches, no sort -- and rides on the edge list this layer returns, where the next conv finds it.
+    parent = getattr(edge_index, "_npi_graph", None)
+    if DERIVE_CSR and nosync and parent is not None and parent.num_nodes == N and parent.num_edges == E and parent.self_loops:
+        off = int(lib.npi_filter_adj_newpos_offset(E))
+        # derived when (and only if) a conv asks for it: the last pooling layer's graph feeds no conv at all
+        ei_out._npi_graph_from = (parent.by_dst, perm, remap, ws[off:off + E], n_out, e_out)
     return (xo, ei_out, None, batch_o, perm64, score_o), (score, perm[:n_out], remap)
 
 
 class _TopKPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, edge_index, batch, ratio, num_graphs):
+    def forward(ctx, x, weight, edge_index, batch, ratio, num_graphs, holder=None):
         (xo, ei_o, _, batch_o, perm, score_o), (score, perm32, remap) = _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)
+        if holder is not None:                     # attributes do not survive the way out of an autograd Function
+            holder["graph"] = getattr(ei_o, "_npi_graph_from", None)
         ctx.save_for_backward(x.detach(), weight.detach(), score, perm32, remap)
         out_ptr = batch_o._npi_graph_ptr
         ctx.mark_non_differentiable(ei_o, batch_o, perm, out_ptr)
@@ -156,7 +170,7 @@ class _TopKPoolFn(torch.autograd.Function):
         n_out = perm.numel()
         st = stream_ptr(dev)
         if dxo is None and dscore_o is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dxo = _f32(dxo) if dxo is not None else torch.zeros((n_out, F), dtype=torch.float32, device=dev)
         dso = _f32(dscore_o) if dscore_o is not None else None
         dx = torch.empty((N, F), dtype=torch.float32, device=dev)          # dropped rows: zeros written by the kernel
@@ -173,7 +187,7 @@ class _TopKPoolFn(torch.autograd.Function):
             check(lib.npi_topk_weight_grad(ptr(x), x.stride(0), ptr(perm), ptr(dzv), ptr(dzz), n_out, F, ptr(w), ptr(dw),
                                            ptr(ws), n_ws, st), "npi_topk_weight_grad")
             dw = dw.view_as(weight)
-        return (dx if ctx.needs_input_grad[0] else None), dw, None, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), dw, None, None, None, None, None
 
 
 def _kept_sizes(batch, ratio):
@@ -188,7 +202,8 @@ def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, we
     """``TopKPooling.forward`` -> ``(x', edge_index', None, batch', perm, score[perm])``; differentiable in
     ``x`` and ``weight``."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        xo, score_o, ei_o, batch_o, perm, out_ptr = _TopKPoolFn.apply(x, weight, edge_index, batch, ratio, num_graphs)
+        holder = {}
+        xo, score_o, ei_o, batch_o, perm, out_ptr = _TopKPoolFn.apply(x, weight, edge_index, batch, ratio, num_graphs, holder)
         # (the tensors an autograd Function hands back need not be the objects its forward created: re-attach)
         batch_o._npi_graph_ptr = out_ptr
         kept = _kept_sizes(batch, ratio)
@@ -196,6 +211,8 @@ def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, we
             batch_o._npi_sizes = kept
         if getattr(edge_index, "_npi_symmetric", False):
             ei_o._npi_symmetric = True
+        if holder.get("graph") is not None:
+            ei_o._npi_graph_from = holder["graph"]
         return xo, ei_o, None, batch_o, perm, score_o
     return _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)[0]
 

@@ -347,3 +347,36 @@ def test_padded_edge_lists_edge_cases(dev):
     nodes, pairs = ig.sizes(torch.tensor([[1, 3]], device=dev))
     xb, eb, bb = ig.batch(torch.tensor([[1, 3]], device=dev), n_nodes=int(nodes[0]), n_pairs=int(pairs[0]))
     assert xb.size(0) == int(nodes[0]) == 4 and eb.size(1) == 2 * int(pairs[0]) == 6        # rna 1, protein 3, rna 0, protein 4
+
+
+def test_pooled_csr_derived_from_the_parent_equals_a_fresh_build(dev):
+    """graph.filtered_side (npi_csr_filter): the by-target CSR of the pooled graph, derived from the parent's without a sort,
+    equals build_side on the filtered (padded) edge list entry for entry -- rowptr, col, eid, rowidx, item_row -- over two
+    pooling layers; and the conv that follows picks it up from the edge list instead of sorting."""
+    from npi_gnn_amd import graph as NG
+    fx = torch.load(os.path.join(G, "rpi369_extract.pt"), map_location="cpu", weights_only=False)
+    from npi_gnn_amd.subgraph import InteractionGraph
+    from npi_gnn_amd import net1
+    ig = InteractionGraph(fx["pairs"].long().to(dev), fx["usable"].to(dev), fx["feat"].to(dev))
+    keys = fx["keys"].long().to(dev)
+    loader = net1.KeyLoader(ig, keys, torch.zeros(keys.size(0), dtype=torch.long, device=dev), 64)
+    data = next(iter(loader))
+    x, ei, b = data.x, data.edge_index, data.batch
+    torch.manual_seed(0)
+    w = torch.randn(1, x.size(1), device=dev)
+    NG.as_graph(ei, x.size(0))                                   # what the conv in front of the pool does
+    assert getattr(ei, "_npi_graph", None) is not None
+    for layer in range(2):
+        xo, eo, _, bo, perm, _ = NP.topk_pool(x.clone().requires_grad_(layer == 1), ei, b, w, 0.5, num_graphs=64)
+        assert getattr(eo, "_npi_graph_from", None) is not None and getattr(eo, "_npi_graph", None) is None     # derived on demand
+        g = NG.as_graph(eo, xo.size(0))
+        assert g is getattr(eo, "_npi_graph", None) and g.num_nodes == xo.size(0) and g.symmetric
+        ref = NG.build_side(eo[1].contiguous(), eo[0].contiguous(), xo.size(0), xo.size(0))
+        nnz = int(ref.rowptr[-1])
+        assert g.by_dst.nnz_max == ref.nnz_max and g.by_dst.n_items == ref.n_items
+        assert torch.equal(g.by_dst.rowptr, ref.rowptr)
+        for a, r in ((g.by_dst.col, ref.col), (g.by_dst.eid, ref.eid), (g.by_dst.rowidx, ref.rowidx)):
+            assert torch.equal(a[:nnz], r[:nnz])
+        assert torch.equal(g.by_dst.item_row, ref.item_row)
+        assert NG.as_graph(eo, xo.size(0)) is g                  # the next conv sorts nothing
+        x, ei, b = xo.detach(), eo, bo
