@@ -353,9 +353,10 @@ int64_t npi_filter_adj_newpos_offset(int64_t E);   /* npi_filter_adj_ex: workspa
 /* The by-target CSR of the POOLED graph from the CSR of its parent, without a sort: row perm[r'] of the parent with the
  * entries whose source survived (remap[col] >= 0), in the parent's order, self loop last; eid through newpos
  * (npi_filter_adj_ex's workspace tail).  Bit-identical to npi_csr_build on the filtered edge list.  nnz_max_out = capacity
- * of col_o / eid_o / rowidx_o (>= the surviving entries; E_in + n_out is what a fresh build would use); workspace int32[n_out];
- * n_out <= npi_csr_filter_max_rows(). */
+ * of col_o / eid_o / rowidx_o (>= the surviving entries; E_in + n_out is what a fresh build would use); workspace int32
+ * [npi_csr_filter_workspace_elems(n_out)]; n_out <= npi_csr_filter_max_rows(). */
 int64_t npi_csr_filter_max_rows(void);
+int64_t npi_csr_filter_workspace_elems(int64_t n_out);
 int npi_csr_filter(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const int32_t* perm, const int32_t* remap,
                    const int32_t* newpos, int64_t n_out, int64_t nnz_max_out, int32_t* rowptr_o, int32_t* col_o,
                    int32_t* eid_o, int32_t* rowidx_o, int32_t* item_row_o, int32_t* status_o, int32_t* workspace, void* stream);

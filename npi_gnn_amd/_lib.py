@@ -84,6 +84,7 @@ PROTOTYPES = {
     "npi_filter_adj_ex": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, c_int, _P]),
     "npi_filter_adj_newpos_offset": (_I, [_I]),
     "npi_csr_filter_max_rows": (_I, []),
+    "npi_csr_filter_workspace_elems": (_I, [_I]),
     "npi_csr_filter": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_readout_max_mean": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_topk_gather_bwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),

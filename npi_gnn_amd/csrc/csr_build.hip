@@ -395,94 +395,124 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
 // TopKPooling keeps a subset of the nodes, renumbers them (perm: new -> old, remap: old -> new or -1) and filter_adj drops
 // every edge that lost an endpoint while keeping the edge order.  The by-target CSR of the result is therefore the parent's,
 // row perm[r'] for new row r', with the entries whose source survived, in the same order (the self loop still last):
-// count per new row, one-workgroup scan, ordered fill, item rows -- four launches instead of the eight of a fresh radix sort.
+// count per new row, ordered fill (offsets from per-tile totals), item rows -- three launches instead of the eight of a fresh radix sort.
 namespace npi {
+// Tiles of 256 new rows, one thread per row: the enclosing subgraphs are double stars, so almost every row has two or three
+// entries and a lane walks its own row; the few long rows (the two centres of a subgraph, hundreds of entries) are taken by
+// the whole wave, one after the other.  count: per-row counts and the tile's total.  fill: the tile's base is the sum of the
+// totals in front of it (a few hundred integers), the rows' offsets an exclusive scan inside the tile -- no scan launch.
+constexpr int CF_SHORT = 8;
+__device__ __forceinline__ int cf_wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
 __global__ void __launch_bounds__(256)
 csr_filter_count_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
-                        const int32_t* __restrict__ remap, int n_out, int32_t* __restrict__ cnt) {
-    const int lane = lane_id();
-    const int r2 = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r2 >= n_out) return;
-    const int r = perm[r2];
-    const int b = rowptr[r], e = rowptr[r + 1];
-    int c = 0;
-    for (int p = b + lane; p < e; p += WAVE) c += remap[col[p]] >= 0 ? 1 : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, WAVE);
-    if (lane == 0) cnt[r2] = c;
-}
-// rowptr_o[0 .. n] = exclusive scan of cnt[0 .. n), rowptr_o[n] = total.  One workgroup of 1,024 threads walks tiles of 4,096
-// elements: four consecutive elements per thread (coalesced), wave scan by shuffles, the 16 wave totals scanned by the first
-// wave -- three barriers per tile.  (A contiguous chunk per thread, read element by element, took 40-90 us for 57 k rows.)
-__global__ void __launch_bounds__(1024)
-csr_filter_scan_kernel(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ rowptr_o) {
-    __shared__ int wtot[16];
+                        const int32_t* __restrict__ remap, int n_out, int32_t* __restrict__ cnt, int32_t* __restrict__ tile_total) {
+    __shared__ int wtot[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int carry = 0;
-    for (int base = 0; base < n; base += 4096) {
-        const int i = base + 4 * t;
-        int v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (i + k < n) ? cnt[i + k] : 0;
-        const int s = v[0] + v[1] + v[2] + v[3];
-        int x = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(x, off, WAVE);
-            if (lane >= off) x += y;
-        }
-        if (lane == 63) wtot[wave] = x;
-        __syncthreads();
-        if (wave == 0) {
-            int w = lane < 16 ? wtot[lane] : 0;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const int y = __shfl_up(w, off, WAVE);
-                if (lane >= off) w += y;
-            }
-            if (lane < 16) wtot[lane] = w;
-        }
-        __syncthreads();
-        int run = carry + (wave > 0 ? wtot[wave - 1] : 0) + x - s;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i + k < n) rowptr_o[i + k] = run;
-            run += v[k];
-        }
-        carry += wtot[15];
-        __syncthreads();
+    const int r2 = blockIdx.x * 256 + t;
+    const bool valid = r2 < n_out;
+    const int r = valid ? perm[r2] : 0;
+    const int b = valid ? rowptr[r] : 0, e = valid ? rowptr[r + 1] : 0;
+    const bool is_long = e - b > CF_SHORT;
+    int c = 0;
+    if (!is_long) for (int p = b; p < e; ++p) c += remap[col[p]] >= 0 ? 1 : 0;
+    uint64_t m = __ballot(is_long);
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int bb = __shfl(b, l, WAVE), ee = __shfl(e, l, WAVE);
+        int cc = 0;
+        for (int p = bb + lane; p < ee; p += WAVE) cc += remap[col[p]] >= 0 ? 1 : 0;
+        cc = cf_wave_sum(cc);
+        if (lane == l) c = cc;
     }
-    if (t == 0) rowptr_o[n] = carry;
+    if (valid) cnt[r2] = c;
+    const int ws_ = cf_wave_sum(c);
+    if (lane == 0) wtot[wave] = ws_;
+    __syncthreads();
+    if (t == 0) tile_total[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
 }
 __global__ void __launch_bounds__(256)
 csr_filter_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
                        const int32_t* __restrict__ perm, const int32_t* __restrict__ remap, const int32_t* __restrict__ newpos,
-                       int n_out, const int32_t* __restrict__ rowptr_o, int32_t* __restrict__ col_o, int32_t* __restrict__ eid_o,
+                       int n_out, const int32_t* __restrict__ cnt, const int32_t* __restrict__ tile_total,
+                       int32_t* __restrict__ rowptr_o, int32_t* __restrict__ col_o, int32_t* __restrict__ eid_o,
                        int32_t* __restrict__ rowidx_o) {
-    const int lane = lane_id();
-    const int r2 = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r2 >= n_out) return;
-    const int r = perm[r2];
-    const int b = rowptr[r], e = rowptr[r + 1];
-    int out = rowptr_o[r2];
-    for (int base = b; base < e; base += WAVE) {
-        const int p = base + lane;
-        int c2 = -1;
-        if (p < e) c2 = remap[col[p]];
-        const uint64_t m = __ballot(c2 >= 0);
-        if (c2 >= 0) {
-            const int pos = out + __popcll(m & ((1ull << lane) - 1ull));
-            const int e0 = eid[p];
-            col_o[pos] = c2;
-            eid_o[pos] = e0 >= 0 ? newpos[e0] : -1;          // the self loop keeps -1
-            rowidx_o[pos] = r2;
+    __shared__ int wtot[4], base_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // entries in front of this tile
+    int s = 0;
+    for (int i = t; i < (int)blockIdx.x; i += 256) s += tile_total[i];
+    s = cf_wave_sum(s);
+    if (lane == 0) wtot[wave] = s;
+    __syncthreads();
+    if (t == 0) base_s = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+    const int base = base_s;
+    const int r2 = blockIdx.x * 256 + t;
+    const bool valid = r2 < n_out;
+    const int c = valid ? cnt[r2] : 0;
+    int x = c;                                               // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, WAVE);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    const int start = base + woff + x - c;
+    if (valid) {
+        rowptr_o[r2] = start;
+        if (r2 == n_out - 1) rowptr_o[n_out] = start + c;
+    }
+    const int r = valid ? perm[r2] : 0;
+    const int b = valid ? rowptr[r] : 0, e = valid ? rowptr[r + 1] : 0;
+    const bool is_long = e - b > CF_SHORT;
+    if (!is_long) {
+        int pos = start;
+        for (int p = b; p < e; ++p) {
+            const int c2 = remap[col[p]];
+            if (c2 >= 0) {
+                const int e0 = eid[p];
+                col_o[pos] = c2;
+                eid_o[pos] = e0 >= 0 ? newpos[e0] : -1;      // the self loop keeps -1
+                rowidx_o[pos] = r2;
+                ++pos;
+            }
         }
-        out += __popcll(m);
+    }
+    uint64_t m = __ballot(is_long);
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int bb = __shfl(b, l, WAVE), ee = __shfl(e, l, WAVE), rr = __shfl(r2, l, WAVE);
+        int out = __shfl(start, l, WAVE);
+        for (int pb = bb; pb < ee; pb += WAVE) {
+            const int p = pb + lane;
+            int c2 = -1;
+            if (p < ee) c2 = remap[col[p]];
+            const uint64_t k = __ballot(c2 >= 0);
+            if (c2 >= 0) {
+                const int pos = out + __popcll(k & ((1ull << lane) - 1ull));
+                const int e0 = eid[p];
+                col_o[pos] = c2;
+                eid_o[pos] = e0 >= 0 ? newpos[e0] : -1;
+                rowidx_o[pos] = rr;
+            }
+            out += __popcll(k);
+        }
     }
 }
 }  // namespace npi
 
-extern "C" int64_t npi_csr_filter_max_rows(void) { return (int64_t)1 << 20; }      // the one-workgroup scan: above this, sort afresh
+extern "C" int64_t npi_csr_filter_max_rows(void) { return (int64_t)1 << 24; }      // tile totals summed per tile: above this, sort afresh
+extern "C" int64_t npi_csr_filter_workspace_elems(int64_t n_out) { return n_out < 0 ? -1 : n_out + ceil_div(n_out > 0 ? n_out : 1, 256) + 1; }
 
 extern "C" int npi_csr_filter(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const int32_t* perm,
                               const int32_t* remap, const int32_t* newpos, int64_t n_out, int64_t nnz_max_out,
@@ -493,12 +523,16 @@ extern "C" int npi_csr_filter(const int32_t* rowptr, const int32_t* col, const i
     NPI_REQUIRE(rowptr_o && item_row_o && status_o && (n_out == 0 || (rowptr && col && eid && perm && remap && newpos && col_o &&
                 eid_o && rowidx_o && workspace)), "npi_csr_filter: null pointer");
     (void)hipMemsetAsync(status_o, 0, sizeof(int32_t), stream);            // ids were checked when the parent was built
-    if (n_out > 0)
-        csr_filter_count_kernel<<<(unsigned)ceil_div(n_out, 4), 256, 0, stream>>>(rowptr, col, perm, remap, (int)n_out, workspace);
-    csr_filter_scan_kernel<<<1, 1024, 0, stream>>>(workspace, (int)n_out, rowptr_o);
-    if (n_out > 0)
-        csr_filter_fill_kernel<<<(unsigned)ceil_div(n_out, 4), 256, 0, stream>>>(rowptr, col, eid, perm, remap, newpos, (int)n_out,
-                                                                                  rowptr_o, col_o, eid_o, rowidx_o);
+    if (n_out == 0) {
+        (void)hipMemsetAsync(rowptr_o, 0, sizeof(int32_t), stream);
+    } else {
+        const unsigned tiles = (unsigned)ceil_div(n_out, 256);
+        int32_t* cnt = workspace;
+        int32_t* tile_total = workspace + n_out;
+        csr_filter_count_kernel<<<tiles, 256, 0, stream>>>(rowptr, col, perm, remap, (int)n_out, cnt, tile_total);
+        csr_filter_fill_kernel<<<tiles, 256, 0, stream>>>(rowptr, col, eid, perm, remap, newpos, (int)n_out, cnt, tile_total,
+                                                          rowptr_o, col_o, eid_o, rowidx_o);
+    }
     const int64_t n_items = npi_num_items(nnz_max_out);
     item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr_o, n_out, n_items, item_edges_for(nnz_max_out), item_row_o);
     return check_launch("npi_csr_filter");

@@ -211,7 +211,7 @@ def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newp
                   num_edges_out: int) -> Optional[CSRSide]:
     """By-target side of the graph TopKPooling leaves -- nodes ``perm`` (int32, new -> old) of the parent, renumbered by
     ``remap``, edges filtered in order (``newpos``: where ``npi_filter_adj_ex`` put every input edge) -- derived from the
-    parent's side without a sort (``npi_csr_filter``).  Identical to ``build_side`` on the filtered edge list of length
+    parent's side without a sort (``npi_csr_filter``: three launches).  Identical to ``build_side`` on the filtered edge list of length
     ``num_edges_out`` (the padded length when the list is padded).  None when the shape is outside the kernel's range."""
     lib = load()
     dev = parent.rowptr.device
@@ -227,7 +227,7 @@ def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newp
     rowidx = torch.empty(max(nnz_max, 1), **i32)
     item_row = torch.empty(n_items + 1, **i32)
     status = torch.empty(1, **i32)
-    ws = torch.empty(max(n_out, 1), **i32)
+    ws = torch.empty(int(lib.npi_csr_filter_workspace_elems(n_out)), **i32)
     check(lib.npi_csr_filter(ptr(parent.rowptr), ptr(parent.col), ptr(parent.eid), ptr(perm), ptr(remap), ptr(newpos), n_out,
                              nnz_max, ptr(rowptr), ptr(col), ptr(eid), ptr(rowidx), ptr(item_row), ptr(status), ptr(ws),
                              stream_ptr(dev)), "npi_csr_filter")
