@@ -349,7 +349,7 @@ def run_configs(dev, args, c4):
                             "(forward, nll_loss, backward, Adam), fp32",
                 "ms_per_step": ms_replay, "ms_per_step_eager": ms_eager,
                 "note": "ms_per_step: the step replayed from a HIP graph (net1.GraphedEpoch); the reference logs 1413.5 s for "
-                        "its 50-epoch fold = 4,200 such steps + evaluations (examples/train_npinter2.py: 5.2 s)"}
+                        "its 50-epoch fold = 4,200 such steps + evaluations (examples/train_npinter2.py --capture: 4.8 s)"}
 
     guarded("C1", c1)
     guarded("C2", c2)
