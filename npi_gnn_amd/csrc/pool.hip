@@ -22,6 +22,11 @@ __device__ __forceinline__ float wsum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
     return v;
 }
+__device__ __forceinline__ int wsum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
 
 // score[i] = tanh(<x_i, w> / ||w||_2); one wave per node
 __global__ void __launch_bounds__(256)
@@ -206,7 +211,8 @@ scan_small_kernel(int32_t* __restrict__ v, int n, int32_t* __restrict__ total) {
 __global__ void __launch_bounds__(256)
 filter_write_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E,
                     const int32_t* __restrict__ remap, const int32_t* __restrict__ tile_off,
-                    int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst, int32_t* __restrict__ newpos) {
+                    int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst, int32_t* __restrict__ newpos,
+                    int32_t* __restrict__ total, int scanned) {
     __shared__ int wcnt[4];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t wbase = (int64_t)blockIdx.x * FA_TILE + wave * 512;
@@ -227,9 +233,27 @@ filter_write_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__
         }
         c += __popcll(__ballot(keep[j]));
     }
-    if (lane == 0) wcnt[wave] = c;
+    // the tile's offset = the counts of the tiles in front of it (a few hundred integers: no scan launch in between);
+    // the first workgroup also publishes the total
+    __shared__ int psum[4];
+    int pre = 0, all = 0;
+    if (scanned) pre = threadIdx.x == 0 ? tile_off[blockIdx.x] : 0;     // many tiles: the host ran scan_small_kernel in between
+    else for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        const int v = tile_off[i];
+        all += v;
+        if (i < (int)blockIdx.x) pre += v;
+    }
+    pre = wsum_i(pre);
+    if (lane == 0) { wcnt[wave] = c; psum[wave] = pre; }
+    if (blockIdx.x == 0 && total != nullptr && !scanned) {
+        __shared__ int asum[4];
+        all = wsum_i(all);
+        if (lane == 0) asum[wave] = all;
+        __syncthreads();
+        if (threadIdx.x == 0) *total = asum[0] + asum[1] + asum[2] + asum[3];
+    }
     __syncthreads();
-    int off = tile_off[blockIdx.x];
+    int off = psum[0] + psum[1] + psum[2] + psum[3];
     for (int w = 0; w < wave; ++w) off += wcnt[w];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -653,9 +677,11 @@ extern "C" int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t
     const int ntiles = (int)ceil_div(E, FA_TILE);
     filter_flag_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, pad_tail ? out_src : nullptr,
                                                    pad_tail ? out_dst : nullptr);
-    scan_small_kernel<<<1, 256, 0, stream>>>(workspace, ntiles, count);
+    // up to 2,048 tiles (4 M edges) the tile counts are summed inside the write kernel: two launches; above, a scan in between
+    const int scanned = ntiles > 2048 ? 1 : 0;
+    if (scanned) scan_small_kernel<<<1, 256, 0, stream>>>(workspace, ntiles, count);
     filter_write_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, out_src, out_dst,
-                                                    workspace + npi_filter_adj_newpos_offset(E));
+                                                    workspace + npi_filter_adj_newpos_offset(E), count, scanned);
     return check_launch("npi_filter_adj");
 }
 

@@ -380,3 +380,33 @@ def test_pooled_csr_derived_from_the_parent_equals_a_fresh_build(dev):
         assert torch.equal(g.by_dst.item_row, ref.item_row)
         assert NG.as_graph(eo, xo.size(0)) is g                  # the next conv sorts nothing
         x, ei, b = xo.detach(), eo, bo
+
+
+@pytest.mark.parametrize("E", [3000, 2048 * 2048, 2048 * 2048 + 5000])
+def test_filter_adj_keeps_the_edge_order_on_both_tile_paths(dev, E):
+    """npi_filter_adj(_ex): the surviving edges, renumbered, in their original order, and the position map in the workspace --
+    with the tile offsets summed inside the write kernel (up to 2,048 tiles of 2,048 edges) and with the scan launch in
+    between (above): against a torch mask / cumsum"""
+    import ctypes  # noqa: F401
+    from npi_gnn_amd._lib import check, load, ptr, stream_ptr
+    lib = load()
+    g = torch.Generator().manual_seed(E)
+    N = 50_000
+    src = torch.randint(0, N, (E,), generator=g).to(dev)
+    dst = torch.randint(0, N, (E,), generator=g).to(dev)
+    keep = (torch.rand(N, generator=g) < 0.6).to(dev)
+    remap = torch.where(keep, torch.cumsum(keep.int(), 0).int() - 1, torch.full((N,), -1, dtype=torch.int32, device=dev)).int()
+    out = torch.empty((2, E), dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.npi_filter_adj_workspace_elems(E)), dtype=torch.int32, device=dev)
+    check(lib.npi_filter_adj_ex(ptr(src), ptr(dst), E, ptr(remap), ptr(out[0]), ptr(out[1]), ptr(count), ptr(ws), 1,
+                                stream_ptr(dev)), "npi_filter_adj_ex")
+    m = keep[src] & keep[dst]
+    n = int(m.sum())
+    assert int(count.item()) == n
+    assert torch.equal(out[0, :n], remap[src[m]].long()) and torch.equal(out[1, :n], remap[dst[m]].long())
+    assert bool((out[:, n:] == -1).all())                                   # pad_tail
+    off = int(lib.npi_filter_adj_newpos_offset(E))
+    newpos = ws[off:off + E]
+    ref = torch.where(m, torch.cumsum(m.int(), 0).int() - 1, torch.full((E,), -1, dtype=torch.int32, device=dev)).int()
+    assert torch.equal(newpos, ref)
