@@ -339,6 +339,8 @@ int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64
 int npi_topk_gather_ex(const float* x, int64_t ldx, const float* score, const int64_t* batch,
                     const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
                     float* xo, int64_t ldo, int64_t* batch_o, float* score_o, int64_t* perm64, void* stream);
+/* int32 workspace of npi_filter_adj / _ex: one count per tile of 2,048 edges, two spare words, then E words that receive the
+ * new position of every input edge (-1: dropped) -- npi_filter_adj_newpos_offset(E) is where those start */
 int64_t npi_filter_adj_workspace_elems(int64_t E);
 int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                    int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, void* stream);

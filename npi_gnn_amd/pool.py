@@ -58,7 +58,8 @@ def graph_ptr(batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Te
 
 def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, weight: torch.Tensor,
                    ratio: float = 0.5, num_graphs: Optional[int] = None):
-    """forward kernels; returns the public tuple plus (score [N], perm int32 [n_out]) for the backward"""
+    """forward kernels; returns the public tuple plus (score [N], perm int32 [n_out], remap int32 [N]: old -> new id or -1)
+    for the backward"""
     lib = load()
     dev = require_gpu(x, edge_index, batch, weight)
     x = _f32(x.detach())
