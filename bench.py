@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--skip-c5", action="store_true", help="configs block without the 4M / 100M GAT stack")
     ap.add_argument("--capture", action="store_true",
                     help="N=1: capture the step (both streams) into one HIP graph and time replays of it")
+    ap.add_argument("--virtual-world", type=int, default=8,
+                    help="N=1: time every rank's local work of a W-rank run on this GPU (configs.C4_w<W>_virtual); 0 = skip")
     ap.add_argument("--rank-check", action="store_true",
                     help="every rank prints {rank, world} and exits before any GPU call (launcher test)")
     return ap.parse_args(argv)
@@ -410,6 +412,202 @@ def run_configs(dev, args, c4):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# N > 1: is the sharded layer RIGHT?  (a scaling number without this is a claim about speed only)
+# ---------------------------------------------------------------------------------------------------------
+def sharded_parity(dev, args, world, sg, layer, x, go, ei, x_full, go_full, W, bias, att=None, samples=256):
+    """After the timed region every rank runs the SINGLE-GPU layer (the plain conv of this package, itself held to the
+    oracle by the -m gpu tests) over the WHOLE graph on its own GPU and compares the rows it owns of the sharded output
+    and of dX, and the all-reduced dW / db; SAGEConv rows are also checked against the formula in fp64 torch ops on
+    ``samples`` of the rank's rows.  Errors are relative to the largest reference magnitude; MAX over ranks."""
+    import npi_gnn_amd as npi
+    N, F = args.nodes, args.hidden
+    kind = args.conv
+    conv = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[kind](F, F).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(W)
+        conv.bias.copy_(bias)
+        if att is not None:
+            conv.att.copy_(att)
+    ei_dev = ei.to(dev)
+    graph = npi.CSRGraph(ei_dev, N)
+    xr = x_full.to(dev).requires_grad_(True)
+    ref = conv(xr, graph)
+    ref.backward(go_full.to(dev))
+    layer.zero_grad()
+    x.grad = None
+    out = layer(x)
+    out.backward(go)
+    torch.cuda.synchronize()
+    if args.partition == "edges":
+        rows = torch.arange(sg.lo, sg.hi, device=dev)
+        dx_ref, dx = xr.grad, x.grad                               # x is replicated: its gradient is complete on every rank
+    else:
+        rows = sg.own
+        dx_ref, dx = xr.grad[rows], x.grad
+
+    def rel(a, b):
+        return float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp(min=1e-30))
+    err = {"out": rel(out, ref[rows]), "dX": rel(dx, dx_ref), "dW": rel(layer.weight.grad, conv.weight.grad),
+           "db": rel(layer.bias.grad, conv.bias.grad)}
+    if att is not None:
+        err["datt"] = rel(layer.att.grad, conv.att.grad)
+    if kind == "sage" and rows.numel():
+        g = torch.Generator(device=dev).manual_seed(7 + int(rows[0]))
+        pos = torch.randperm(rows.numel(), generator=g, device=dev)[:samples]      # positions in this rank's row order
+        pick, order = rows[pos].sort()
+        pos = pos[order]
+        src, dst = ei_dev[0], ei_dev[1]
+        sel = torch.isin(dst, pick) & (src != dst)
+        slot = torch.searchsorted(pick, dst[sel])
+        acc = xr.detach()[pick].double().index_add_(0, slot, xr.detach()[src[sel]].double())
+        cnt = torch.bincount(slot, minlength=pick.numel()).double() + 1.0
+        want = (acc / cnt.view(-1, 1)) @ W.to(dev).double() + bias.to(dev).double()
+        err["out_rows_fp64_formula"] = float((out.detach()[pos].double() - want).abs().max() / want.abs().max())
+    names = sorted(err)
+    v = torch.tensor([err[k] for k in names], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    err = {k: float(e) for k, e in zip(names, v.tolist())}
+    return {"parity_max_err": max(err.values()), "by_tensor": err,
+            "against": "the single-GPU layer of this package run over the whole graph on every rank's GPU (its rows of out and "
+                       "dX, the all-reduced dW / db), max over ranks, relative to the largest reference magnitude; "
+                       f"out_rows_fp64_formula: {samples} rows per rank against mean(x_j) @ W + b in fp64 torch ops"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# virtual world: the W shards of the multi-GPU path, one after the other on this ONE GPU
+# ---------------------------------------------------------------------------------------------------------
+def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
+    """SURVEY.md 8(e), what one GPU can measure of the W-GPU run: every rank's LOCAL work (its shard's kernels, host
+    launch work included) timed alone on this GPU with the collectives replaced by local copies of the same shapes, for
+    the three partitions (SAGEConv) and the sharded GATConv.  From it: the load balance, the compute-side ceiling of the
+    speed-up (T1 / max_r T_r: what W GPUs reach with free communication), the bytes every collective moves, the
+    communication time a >= 6x speed-up leaves (T1 / 6 - max_r T_r) and the bus bandwidth that implies."""
+    import npi_gnn_amd as npi
+    from npi_gnn_amd import dist as ND
+    from npi_gnn_amd.synth import protein_mask
+    N, E, F = args.nodes, args.edges, args.hidden
+    gen = torch.Generator().manual_seed(3)
+    Wm = ((torch.rand(F, F, generator=gen) * 2 - 1) / F ** 0.5).to(dev)
+    bias = ((torch.rand(F, generator=gen) * 2 - 1) / F ** 0.5).to(dev)
+    att = (torch.randn(1, 1, 2 * F, generator=gen) * 0.1).to(dev)
+    log = {}
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def note(kind, nbytes, wire):
+        e = log.setdefault(kind, {"calls": 0, "payload_bytes": 0, "wire_bytes_per_rank": 0})
+        e["calls"] += 1
+        e["payload_bytes"] += nbytes
+        e["wire_bytes_per_rank"] += wire
+
+    frac = (W - 1) / W
+
+    def ag(block, out, w, group=None, async_op=False):
+        nb = out.numel() * out.element_size()
+        note("all_gather", nb, nb * frac)
+        out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1))
+        return _Done() if async_op else None
+
+    def rs(part_sums, out, rank, w, group=None, async_op=False):
+        nb = part_sums.numel() * part_sums.element_size()
+        note("reduce_scatter", nb, nb * frac)
+        out.copy_(part_sums.view(w, -1)[rank].view_as(out))
+        return _Done() if async_op else None
+
+    def ar(t, w, group=None, op=None, tag="all_reduce"):
+        nb = t.numel() * t.element_size()
+        note("all_reduce", nb, 2 * nb * frac)
+
+    def time_rank(layer, x, go, steps=5, warm=3):
+        def step():
+            layer.zero_grad()
+            x.grad = None
+            layer(x).backward(go)
+        for _ in range(warm):
+            step()
+        log.clear()
+        step()                                                  # the collectives of ONE step, by kind
+        one = {k: dict(v) for k, v in log.items()}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, one
+
+    def summary(name, t1, per_rank, nnz, coll, note_):
+        worst = max(per_rank)
+        wire = sum(v["wire_bytes_per_rank"] for v in coll.values())
+        budget = t1 / 6.0 - worst
+        return {"what": note_, "world": W, "t1_ms": t1, "per_rank_ms": per_rank, "per_rank_entries": nnz,
+                "balance": sum(per_rank) / len(per_rank) / worst, "compute_ceiling": t1 / worst,
+                "bytes_per_collective": coll, "wire_bytes_per_rank_per_step": wire,
+                "exposed_budget_ms_for_6x": budget,
+                "implied_bus_GBps": {"all_communication_hidden_under_T1_over_6": wire / (t1 / 6.0 * 1e-3) / 1e9,
+                                     "no_overlap_inside_the_exposed_budget": (wire / (budget * 1e-3) / 1e9) if budget > 0 else None}}
+
+    # T1 of the plain GATConv on this graph (the SAGE T1 is the headline measurement)
+    conv = npi.GATConv(F, F, heads=1).to(dev)
+    xx = c4["x"].detach().requires_grad_(True)
+
+    def gat_step():
+        for p in conv.parameters():
+            p.grad = None
+        xx.grad = None
+        conv(xx, c4["graph"]).backward(c4["go"])
+    t1_gat = _timeit(gat_step, 5, 2)
+    del conv, xx
+
+    saved = (ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo)
+    ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce = ag, rs, ar
+    ND._solo = lambda w: False
+    out = {}
+    try:
+        hub = protein_mask(N).to(dev)
+        in_count = torch.bincount(ei_dev[1][ei_dev[0] != ei_dev[1]], minlength=N)
+        res = {k: ([], [], None) for k in ("hubs_sage", "hubs_gat", "rows_sage", "edges_sage")}
+        for r in range(W):
+            for partition in ("hubs", "rows", "edges"):
+                if partition == "edges":
+                    sg = ND.EdgeShardedGraph(ei_dev, N, r, W, dev, in_count=in_count)
+                    x = torch.randn(N, F, device=dev).requires_grad_(True)
+                    go = torch.randn(sg.hi - sg.lo, F, device=dev)
+                    layers = [("edges_sage", ND.EdgeShardedSAGELayer(sg, Wm, bias))]
+                else:
+                    sg = ND.ShardedGraph(ei_dev, N, r, W, dev, hub_mask=hub if partition == "hubs" else None)
+                    x = torch.randn(sg.n_local, F, device=dev).requires_grad_(True)
+                    go = torch.randn(sg.n_local, F, device=dev)
+                    layers = [(partition + "_sage", ND.ShardedSAGELayer(sg, Wm, bias))]
+                    if partition == "hubs":
+                        layers.append(("hubs_gat", ND.ShardedGATLayer(sg, Wm, att, bias)))
+                for key, layer in layers:
+                    ms, coll = time_rank(layer, x, go)
+                    res[key][0].append(ms)
+                    res[key][1].append(int(sg.local_nnz))
+                    if r == 0:
+                        res[key] = (res[key][0], res[key][1], coll)
+                del sg, x, go, layers, layer
+                torch.cuda.empty_cache()
+        notes = {"hubs_sage": "SAGEConv, protein rows replicated (vertex cut): all-gather + reduce-scatter of hub rows per direction",
+                 "rows_sage": "SAGEConv, destination-row shards: all-gather of every row per direction",
+                 "edges_sage": "SAGEConv, the north-star's literal split: a slice of the edge list per GPU, x replicated, "
+                               "all-reduce of the partial [N,F] sums per direction",
+                 "hubs_gat": "GATConv (1 head), vertex cut with the cross-rank softmax"}
+        for key, (ms, nnz, coll) in res.items():
+            out[key] = summary(key, t1_gat if key == "hubs_gat" else t1_sage_ms, ms, nnz, coll, notes[key])
+    finally:
+        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo = saved
+    out["note"] = ("one GPU, ranks run one after the other; collectives are local copies of the same shapes, so per_rank_ms "
+                   "is local compute + host launch work only; wire bytes: all-gather / reduce-scatter of S bytes move "
+                   "S (W-1)/W per rank, an all-reduce 2 S (W-1)/W; N > 1 itself is NOT measured here")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     world_env = os.environ.get("WORLD_SIZE")
@@ -483,17 +681,20 @@ def main():
         from npi_gnn_amd import dist as ND
         from npi_gnn_amd.synth import protein_mask
         t0 = time.time()
+        # every rank ships only ITS slice of the edge list to its GPU; the partitioner routes the edges (dist.route_edges)
+        ei_mine = ei[:, rank * E // world: (rank + 1) * E // world] if world > 1 else ei
         if args.partition == "edges":
-            sg = ND.EdgeShardedGraph(ei, N, rank, world, dev)
+            sg = ND.EdgeShardedGraph(ei_mine, N, rank, world, dev, sliced=world > 1)
             layer = ND.EdgeShardedSAGELayer(sg, W.to(dev), bias.to(dev))
             x = x_full.to(dev).requires_grad_(True)            # x is REPLICATED in this split
             go = sg.shard(go_full).to(dev)
             seg_launch_bytes = [algorithmic_bytes(sg.local_nnz, N, F)]
         else:
-            sg = ND.ShardedGraph(ei, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None)
+            sg = ND.ShardedGraph(ei_mine, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None,
+                                 sliced=world > 1)
+            att_full = torch.randn(1, 1, 2 * F, generator=g) * 0.1
             layer = {"sage": ND.ShardedSAGELayer, "gcn": ND.ShardedGCNLayer}[args.conv](sg, W.to(dev), bias.to(dev)) \
-                if args.conv != "gat" else ND.ShardedGATLayer(sg, W.to(dev), torch.randn(1, 1, 2 * F, generator=g).to(dev) * 0.1,
-                                                               bias.to(dev))
+                if args.conv != "gat" else ND.ShardedGATLayer(sg, W.to(dev), att_full.to(dev), bias.to(dev))
             x = sg.shard(x_full).to(dev).requires_grad_(True)  # this rank's rows: its ncRNAs, then its proteins
             go = sg.shard(go_full).to(dev)
             # per direction this rank launches side A (its rows) and, with hubs, side B (partial hub sums)
@@ -568,6 +769,13 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = E * args.steps / dt
+    parity = None
+    if sharded:
+        try:
+            parity = sharded_parity(dev, args, world, sg, layer, x, go, ei, x_full, go_full, W, bias,
+                                    att=att_full if args.conv == "gat" and args.partition != "edges" else None)
+        except Exception as e:                                  # on every rank alike (same code, same data)
+            parity = {"parity_max_err": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
     # dominant kernel: segsum (fwd + bwd launches have the same algorithmic bytes when F_in == F_out)
     seg_ms = [s.elapsed_time(e) for s, e in seg_events]
@@ -663,6 +871,9 @@ def main():
             "roofline": roof,
         }
         res.update(extra)
+        if parity is not None:
+            res["parity_max_err"] = parity["parity_max_err"]
+            res["parity"] = parity
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -671,15 +882,26 @@ def main():
         return
     # ---- extras after the timed region (one GPU only): control, per-config block, CPU baseline -------------
     if world == 1 and not sharded:
-        del x_full, go_full, ei
+        del x_full, go_full
         if not args.no_control and args.conv == "sage":
             try:
                 res["roofline"]["control_uniform"] = control_uniform(dev, N, E, F)
             except Exception as e:
                 res["roofline"]["control_uniform"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        vw = None
+        if args.virtual_world > 1 and args.conv == "sage":
+            try:
+                ei_dev = ei.to(dev)
+                vw = virtual_world(dev, args, ei_dev, c4, ms_per_step, args.virtual_world)
+                del ei_dev
+            except Exception as e:
+                vw = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
         if not args.no_configs and args.conv == "sage":
             del graph, x, go, step, conv
             res["configs"] = run_configs(dev, args, c4)
+        if vw is not None:
+            res.setdefault("configs", {})[f"C4_w{args.virtual_world}_virtual"] = vw
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(args)
     elif not args.no_cpu_baseline:

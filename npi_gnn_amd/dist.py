@@ -56,6 +56,7 @@ is ``HipBackend`` and there is no CPU fallback in this package.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -171,6 +172,90 @@ def local_sides(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: 
     return side_a, side_b
 
 
+def sides_from_routed(l1, l2, part: HubPartition, rank: int):
+    """Sides A, B, A^T, B^T of rank ``rank`` from the two routed edge lists (``route_edges``):
+    ``l1 = (src, dst)`` -- the non-loop edges with a HUB source whose TARGET this rank owns (sides A and B^T),
+    ``l2 = (src, dst)`` -- those with a HUB target whose SOURCE this rank owns (sides A^T and B), both in edge_index order.
+    Equal, entry for entry, to ``local_sides(src, dst)`` / ``local_sides(dst, src)`` on the full edge list."""
+    dev = part.hub.device
+    nL, nH = part.n_light(rank), part.n_hub(rank)
+    rows = torch.arange(nL + nH, device=dev)
+    loop_col = torch.cat([part.hub_rows + rows[:nL], rank * part.h_per + rows[:nH]])
+    n_tab = part.hub_rows + nL + nH
+
+    def pair(keys, vals):
+        """(own rows <- hub table) side with its loops, and the (hub table rows <- own light rows) partial side"""
+        hub_k = part.hub[keys]
+        key = torch.where(hub_k, nL + part.local(keys), part.local(keys))
+        full = (torch.cat([key, rows]), torch.cat([part.hub_row(vals), loop_col]), nL + nH, n_tab)
+        sel = ~hub_k
+        partial = (part.hub_row(vals[sel]), part.local(keys[sel]), part.hub_rows, nL + nH)
+        return full, partial
+
+    a, bt = pair(l1[1], l1[0])             # keyed by target
+    at, b = pair(l2[0], l2[1])             # keyed by source
+    return a, b, at, bt
+
+
+def _stable_buckets(dest: torch.Tensor, world: int, backend):
+    """(order, counts): ``order`` lists the positions of ``dest`` grouped by value 0..world-1, input order kept inside a
+    group (so that chunks concatenated in rank order reproduce edge_index order); ``counts[k]`` = size of group k."""
+    if hasattr(backend, "bucket"):
+        return backend.bucket(dest, world)
+    return torch.sort(dest, stable=True)[1], torch.bincount(dest, minlength=world)
+
+
+def _all_to_all_rows(rows: torch.Tensor, counts: torch.Tensor, world: int, group) -> torch.Tensor:
+    """rows [n, K] grouped by destination rank (``counts[k]`` rows for rank k) -> the rows every rank addressed to this
+    one, in rank order.  Set-up traffic (the routed edge list), not part of a step."""
+    recv_counts = torch.empty_like(counts)
+    host = _portable(group) and rows.is_cuda                      # gloo has no all-to-all on device tensors
+    if host:
+        cin, cout = counts.cpu(), recv_counts.cpu()
+        dist.all_to_all_single(cout, cin, group=group)
+        recv = cout.tolist()
+        out = torch.empty((sum(recv), rows.size(1)), dtype=rows.dtype)
+        dist.all_to_all_single(out, rows.cpu(), recv, cin.tolist(), group=group)
+        return out.to(rows.device)
+    dist.all_to_all_single(recv_counts, counts, group=group)
+    recv = recv_counts.tolist()
+    out = torch.empty((sum(recv), rows.size(1)), dtype=rows.dtype, device=rows.device)
+    dist.all_to_all_single(out, rows.contiguous(), recv, counts.tolist(), group=group)
+    return out
+
+
+def route_edges(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: int, world: int, group=None,
+                backend=None):
+    """The distributed partitioner: every rank holds only ITS SLICE ``(src, dst)`` of the edge list (columns
+    ``[r E / W, (r+1) E / W)`` of edge_index, already on its device) and sends each edge to the rank(s) that compute with
+    it -- the owner of the target when the source is a hub, the owner of the source when the target is a hub -- in one
+    all-to-all per list.  No rank ever holds the whole edge list; what it receives is its ~1/W share, in edge_index order
+    (slices travel in rank order and the bucketing is stable), so the CSRs built from it are the ones the full-list
+    masks (``local_sides``) give.  Also returns the global in- and out-degree (non-loop edges) of every node: one
+    all-reduce of an int64 [N] vector each -- node metadata, needed for the mean and for GCN's normalisation."""
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    hub_s, hub_d = part.hub[src], part.hub[dst]
+    bad = (~hub_s & ~hub_d).any().to(torch.int64).view(1)
+    in_cnt = torch.bincount(dst, minlength=part.N)
+    out_cnt = torch.bincount(src, minlength=part.N)
+    if world > 1:
+        stats = torch.cat([bad, in_cnt, out_cnt])
+        dist.all_reduce(stats, group=group)
+        bad, in_cnt, out_cnt = stats[:1], stats[1:1 + part.N], stats[1 + part.N:]
+    if int(bad) > 0:
+        raise ValueError("HubPartition: an edge joins two light nodes; mark one endpoint as a hub (auto_hubs)")
+    lists = []
+    for mask, owner_of in ((hub_s, dst), (hub_d, src)):
+        s, d = src[mask], dst[mask]
+        rows = torch.stack([s, d], dim=1)
+        if world > 1:
+            order, counts = _stable_buckets(part.owner(owner_of[mask]), world, backend)
+            rows = _all_to_all_rows(rows[order], counts, world, group)
+        lists.append((rows[:, 0].contiguous(), rows[:, 1].contiguous()))
+    return lists[0], lists[1], in_cnt, out_cnt
+
+
 # tests set this to push a world-size-1 run through RCCL as well (the one-GPU box's only way to
 # exercise the real collectives); normally a single rank just copies
 ALWAYS_COMMUNICATE = False
@@ -251,6 +336,15 @@ class HipBackend:
         from .graph import build_side
         return build_side(key.contiguous(), val.contiguous(), n_rows, n_cols, False, 0, False)
 
+    def bucket(self, dest, world: int):
+        """stable grouping of positions by destination rank: the CSR build with one row per rank (one radix pass)"""
+        from .graph import build_side
+        n = int(dest.numel())
+        if n == 0:
+            return dest.new_empty(0), torch.zeros(world, dtype=torch.long, device=dest.device)
+        side = build_side(dest.contiguous(), torch.arange(n, device=dest.device), world, n, False, 0, False)
+        return side.col[:n].long(), (side.rowptr[1:] - side.rowptr[:-1]).long()
+
     def row_lengths(self, side):
         return (side.rowptr[1:] - side.rowptr[:-1])
 
@@ -286,6 +380,13 @@ class HipBackend:
         if not NF.OVERLAP_STREAMS or like.size(0) < NF.OVERLAP_MIN_ROWS:
             return None
         return NF._side_stream(like.device)
+
+    def partial_stream(self, like):
+        """third HIP stream for the partial (side B) aggregation of a direction, or None for small shards"""
+        from . import functional as NF
+        if not NF.OVERLAP_STREAMS or like.size(0) < NF.OVERLAP_MIN_ROWS:
+            return None
+        return NF._side_stream(like.device, 1)
 
     # ---- GATConv pieces (functional.py wraps the C ABI; index spaces: rows of the side / its table) ----
     def gat_scores(self, h, att2, H, C):
@@ -325,28 +426,53 @@ class ShardedGraph:
     """This rank's shard of the (self-loop-augmented) graph: sides A, B and their transposes."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, device,
-                 backend=None, group=None, hub_mask: Optional[torch.Tensor] = None):
+                 backend=None, group=None, hub_mask: Optional[torch.Tensor] = None, sliced: bool = False):
+        """``sliced=True``: ``edge_index`` is THIS RANK'S slice of the edge list (the ranks' slices, in rank order, are
+        the whole list); ``sliced=False``: the complete list, the same on every rank -- the rank then keeps only columns
+        ``[rank E / W, (rank + 1) E / W)`` BEFORE anything moves to its GPU.  Either way the edges reach the ranks that
+        compute with them through ``route_edges`` (an all-to-all): no GPU ever holds the whole edge list.  Without an
+        initialised process group (W == 1; virtual ranks in one process) the complete list is required and the rank's
+        share is cut out of it with masks -- the same entries in the same order (tests/test_dist_gloo.py)."""
         self.part = part = HubPartition(num_nodes, world, hub_mask, device)
         self.rank, self.world, self.group = rank, world, group
         self.nL, self.nH = part.n_light(rank), part.n_hub(rank)
         self.n_local = self.nL + self.nH
         self.exchange_partials = part.nL > 0                      # same answer on every rank
         self.backend = be = backend or HipBackend()
-        ei = edge_index.to(device)
-        src, dst = ei[0], ei[1]
-        a, b = local_sides(src, dst, part, rank)
-        at, bt = local_sides(dst, src, part, rank)
+        routed = world > 1 and dist.is_available() and dist.is_initialized()
+        if routed:
+            if not sliced:
+                E = edge_index.size(1)
+                edge_index = edge_index[:, rank * E // world: (rank + 1) * E // world]
+            ei = edge_index.to(device)
+            l1, l2, in_cnt, out_cnt = route_edges(ei[0], ei[1], part, rank, world, group, be)
+            del ei
+        else:
+            if sliced and world > 1:
+                raise ValueError("ShardedGraph(sliced=True) needs an initialised process group to route the edges")
+            ei = edge_index.to(device)
+            keep = ei[0] != ei[1]
+            src, dst = ei[0][keep], ei[1][keep]
+            hub_s, hub_d = part.hub[src], part.hub[dst]
+            if bool((~hub_s & ~hub_d).any()):
+                raise ValueError("HubPartition: an edge joins two light nodes; mark one endpoint as a hub (auto_hubs)")
+            m1, m2 = hub_s & (part.owner(dst) == rank), hub_d & (part.owner(src) == rank)
+            l1, l2 = (src[m1], dst[m1]), (src[m2], dst[m2])
+            in_cnt, out_cnt = torch.bincount(dst, minlength=num_nodes), torch.bincount(src, minlength=num_nodes)
+            del ei, src, dst, hub_s, hub_d, m1, m2
+        a, b, at, bt = sides_from_routed(l1, l2, part, rank)
         self.A, self.At = be.make_side(*a), be.make_side(*at)
         self.B = be.make_side(*b) if self.exchange_partials else None
         self.Bt = be.make_side(*bt) if self.exchange_partials else None
         self.local_nnz = int(a[0].numel()) + int(b[0].numel())    # entries this rank walks per direction
         # 1 / (in-degree + 1) of the local rows; for hub rows also the share of it that side A holds
-        keep = src != dst
-        self._src, self._dst = src[keep], dst[keep]
-        cnt = torch.bincount(self._dst, minlength=num_nodes).to(torch.float32) + 1.0
         own = part.own_ids(rank)
-        self.inv_cnt = (1.0 / cnt[own]).contiguous()
+        self.inv_cnt = (1.0 / (in_cnt[own].to(torch.float32) + 1.0)).contiguous()
         self.cnt_a_hub = torch.bincount(a[0], minlength=self.n_local)[self.nL:].to(torch.float32).view(-1, 1)
+        # the hub rows' merge after the reduce-scatter, agg = agg (cnt_A / cnt) + hsum / cnt, as two per-row factors
+        self.hub_scale_a = (self.cnt_a_hub * self.inv_cnt[self.nL:].view(-1, 1)).contiguous()
+        self.hub_scale_b = self.inv_cnt[self.nL:].view(-1, 1).contiguous()
+        self._out_deg = out_cnt                                     # global, [N] (GCNConv's degree is over the SOURCE rows)
         self.own = own
         self.own_hub = slice(rank * part.h_per, rank * part.h_per + self.nH)       # this rank's rows of the hub table
         self._gcn = None
@@ -360,7 +486,7 @@ class ShardedGraph:
         the SOURCE rows) of sides A, B, At, Bt -- the degrees are global, every rank derives them from the edge list."""
         if self._gcn is None:
             part, be, N = self.part, self.backend, self.part.N
-            deg = torch.bincount(self._src, minlength=N).to(torch.float32) + 1.0
+            deg = self._out_deg.to(torch.float32) + 1.0
             dinv = deg.pow(-0.5)
             tid = part.hub_table_ids()
             d_hub = torch.where(tid >= 0, dinv[tid.clamp(min=0)], torch.zeros((), device=dinv.device))
@@ -411,16 +537,45 @@ def scatter_hub_sums(sg: ShardedGraph, partial: torch.Tensor, async_op: bool = F
     return hsum, work
 
 
-def _exchange_start(sg: ShardedGraph, rows: torch.Tensor, side_b, w_b=None):
-    """Launch the all-gather of the hub rows of ``rows`` and the reduce-scatter of side B's partial
-    hub sums.  Returns (hub table for side A, its pending work, reduced hub sums or None, its pending work)."""
+# Side B (partial hub sums from the rank's own rows) needs nothing from another rank, side A needs the all-gathered hub
+# table: with B on its own HIP stream the two aggregations of a direction share the CUs (W = 1: one launch's tail under the
+# other; W > 1: A starts the moment the table has arrived instead of behind B).  NPI_PARTIAL_STREAM=0: one stream, B first.
+PARTIAL_SIDE_STREAM = os.environ.get("NPI_PARTIAL_STREAM", "1") != "0"
+
+
+def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, w_part, mean: bool, tag: str, bias=None):
+    """One direction of the hub-cut aggregation of ``rows`` [n_local, F]:
+
+        table = all_gather(hub rows of ``rows``)                      | psum = segsum(partial side, rows)
+        out   = segsum(full side, [table ; rows])  (mean / bias fused) | hsum = reduce_scatter(psum)
+
+    Returns (out, hsum or None): the caller folds ``hsum[:nH]`` into ``out[nL:]`` (the rule differs: SAGE's mean
+    re-weights the two shares, sums just add).  ``tag``: prefix of the exposed-communication records ("fwd" / "bwd")."""
     be = sg.backend
-    table, g_work = gather_hub(sg, rows, async_op=True)
-    hsum = r_work = None
+    table, g_work = gather_hub(sg, rows, async_op=True)            # needs nothing but ``rows``: issued first
+    hsum = b_stream = r_work = None
     if sg.exchange_partials:
-        partial = be.segsum(side_b, rows, w=w_b)                   # no remote input: overlaps the all-gather
-        hsum, r_work = scatter_hub_sums(sg, partial, async_op=True)
-    return table, g_work, hsum, r_work
+        b_stream = be.partial_stream(rows) if (PARTIAL_SIDE_STREAM and hasattr(be, "partial_stream")) else None
+        if b_stream is None:
+            psum = be.segsum(partial, rows, w=w_part)              # no remote input: overlaps the all-gather
+            hsum, r_work = scatter_hub_sums(sg, psum, async_op=True)
+        else:
+            cur = torch.cuda.current_stream(rows.device)
+            b_stream.wait_stream(cur)                              # ``rows`` is complete for the partial side
+            with torch.cuda.stream(b_stream):
+                psum = be.segsum(partial, rows, w=w_part)
+                hsum, r_work = scatter_hub_sums(sg, psum, async_op=True)
+            for t in (rows, w_part):
+                if t is not None:
+                    t.record_stream(b_stream)                      # allocated on ``cur``, read on the partial stream
+    _wait(g_work, tag + "_all_gather", table)
+    out = be.segsum(full, table, mean=mean, table2=rows, w=w_full, bias=bias)
+    if hsum is not None:
+        _wait(r_work, tag + "_reduce_scatter", hsum)
+        if b_stream is not None:
+            cur.wait_stream(b_stream)                              # one rank: no collective to wait for
+            hsum.record_stream(cur)
+    return out, hsum, table
 
 
 class _ShardedSageFn(torch.autograd.Function):
@@ -433,16 +588,12 @@ class _ShardedSageFn(torch.autograd.Function):
         be = sg.backend
         x_own = x_own.contiguous()
         nrm = sg.gcn_norm() if gcn else {"A": None, "B": None}
-        table, g_work, hsum, r_work = _exchange_start(sg, x_own, sg.B, nrm["B"])
-        _wait(g_work, "fwd_all_gather", table)
-        agg = be.segsum(sg.A, table, mean=not gcn, table2=x_own, w=nrm["A"])
-        if hsum is not None:
-            _wait(r_work, "fwd_reduce_scatter", hsum)
-            if sg.nH and gcn:
+        agg, hsum, _ = _hub_aggregate(sg, x_own, sg.A, sg.B, nrm["A"], nrm["B"], not gcn, "fwd")
+        if hsum is not None and sg.nH:
+            if gcn:
                 agg[sg.nL:] += hsum[: sg.nH]
-            elif sg.nH:
-                inv = sg.inv_cnt[sg.nL:].view(-1, 1)
-                agg[sg.nL:] = (agg[sg.nL:] * sg.cnt_a_hub + hsum[: sg.nH]) * inv
+            else:                                                  # mean over both shares: (agg cnt_A + hsum) / cnt
+                agg[sg.nL:].mul_(sg.hub_scale_a).addcmul_(hsum[: sg.nH], sg.hub_scale_b)
         out = be.linear_fwd(agg, weight, bias)
         ctx.sg = sg
         ctx.gcn = gcn
@@ -476,13 +627,9 @@ class _ShardedSageFn(torch.autograd.Function):
                 be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
         if want_x:
             def chain():
-                table, g_work, hsum, r_work = _exchange_start(sg, dagg, sg.Bt, nrm["Bt"])
-                _wait(g_work, "bwd_all_gather", table)
-                out = be.segsum(sg.At, table, table2=dagg, w=nrm["At"])
-                if hsum is not None:
-                    _wait(r_work, "bwd_reduce_scatter", hsum)
-                    if sg.nH:
-                        out[sg.nL:] += hsum[: sg.nH]
+                out, hsum, table = _hub_aggregate(sg, dagg, sg.At, sg.Bt, nrm["At"], nrm["Bt"], False, "bwd")
+                if hsum is not None and sg.nH:
+                    out[sg.nL:] += hsum[: sg.nH]
                 return out, (table, hsum)
             if side is not None:
                 with torch.cuda.stream(side):
@@ -511,13 +658,9 @@ class _ShardedGcnFn(torch.autograd.Function):
         nrm = sg.gcn_norm()
         x_own = x_own.contiguous()
         xw = be.linear_fwd(x_own, weight, None)
-        table, g_work, hsum, r_work = _exchange_start(sg, xw, sg.B, nrm["B"])
-        _wait(g_work, "fwd_all_gather", table)
-        out = be.segsum(sg.A, table, table2=xw, w=nrm["A"], bias=bias)
-        if hsum is not None:
-            _wait(r_work, "fwd_reduce_scatter", hsum)
-            if sg.nH:
-                out[sg.nL:] += hsum[: sg.nH]
+        out, hsum, _ = _hub_aggregate(sg, xw, sg.A, sg.B, nrm["A"], nrm["B"], False, "fwd", bias=bias)
+        if hsum is not None and sg.nH:
+            out[sg.nL:] += hsum[: sg.nH]
         ctx.sg = sg
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x_own, weight)
@@ -535,13 +678,9 @@ class _ShardedGcnFn(torch.autograd.Function):
             db = be.colsum(grad_out)
             _all_reduce(db, sg.world, sg.group, tag="bwd_all_reduce_db")
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            table, g_work, hsum, r_work = _exchange_start(sg, grad_out, sg.Bt, nrm["Bt"])
-            _wait(g_work, "bwd_all_gather", table)
-            dxw = be.segsum(sg.At, table, table2=grad_out, w=nrm["At"])
-            if hsum is not None:
-                _wait(r_work, "bwd_reduce_scatter", hsum)
-                if sg.nH:
-                    dxw[sg.nL:] += hsum[: sg.nH]
+            dxw, hsum, _ = _hub_aggregate(sg, grad_out, sg.At, sg.Bt, nrm["At"], nrm["Bt"], False, "bwd")
+            if hsum is not None and sg.nH:
+                dxw[sg.nL:] += hsum[: sg.nH]
             if ctx.needs_input_grad[1]:
                 dw, _ = be.linear_bwd_weight(x_own, dxw, False)
                 _all_reduce(dw, sg.world, sg.group, tag="bwd_all_reduce_dw")
@@ -719,28 +858,35 @@ class ShardedGATLayer(_ShardedLayer):
 # the north-star's baseline split: edge shards over a replicated x, all-reduce of the partial [N, F] sums
 # -------------------------------------------------------------------------------------------------------------
 class EdgeShardedGraph:
-    """Rank r walks entries [r E'/W, (r+1) E'/W) of the target-sorted (forward) / source-sorted (backward) stream of
-    non-loop edges -- cut on the entry count, so a heavy row may straddle ranks -- plus the self loops of its block of
-    output rows.  ``x`` is replicated; outputs are the contiguous row block ``[lo, hi)`` of this rank."""
+    """"Shard the edge list": rank r walks ITS SLICE of edge_index -- columns [r E / W, (r + 1) E / W), as they come --
+    over a full replica of ``x``, plus the self loops of its block of output rows; the partial sums of ALL rows are
+    all-reduced.  Outputs are the contiguous row block ``[lo, hi)`` of this rank.  ``sliced=True``: ``edge_index``
+    already is the slice (no rank holds the whole list); the global in-degree comes from an all-reduce of the slices'
+    counts (``in_count``: supplied by the caller when there is no process group -- virtual ranks)."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, device, backend=None, group=None):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, device, backend=None, group=None,
+                 sliced: bool = False, in_count: Optional[torch.Tensor] = None):
         self.N, self.rank, self.world, self.group = int(num_nodes), rank, world, group
         self.backend = be = backend or HipBackend()
+        if not sliced:
+            E = edge_index.size(1)
+            edge_index = edge_index[:, rank * E // world: (rank + 1) * E // world]
         ei = edge_index.to(device)
         keep = ei[0] != ei[1]
         src, dst = ei[0][keep], ei[1][keep]
-        E = int(src.numel())
         self.per = (self.N + world - 1) // world                      # padded rows per rank
         self.lo, self.hi = min(rank * self.per, self.N), min((rank + 1) * self.per, self.N)
         blk = torch.arange(self.lo, self.hi, device=device)
-        e0, e1 = rank * E // world, (rank + 1) * E // world
-
-        def side(key, val):
-            order = torch.sort(key, stable=True)[1][e0:e1]
-            return be.make_side(torch.cat([key[order], blk]), torch.cat([val[order], blk]), self.N, self.N)
-        self.fwd, self.bwd = side(dst, src), side(src, dst)
-        self.local_nnz = e1 - e0
-        cnt = torch.bincount(dst, minlength=self.N).to(torch.float32) + 1.0
+        self.fwd = be.make_side(torch.cat([dst, blk]), torch.cat([src, blk]), self.N, self.N)
+        self.bwd = be.make_side(torch.cat([src, blk]), torch.cat([dst, blk]), self.N, self.N)
+        self.local_nnz = int(src.numel())
+        if in_count is None:
+            in_count = torch.bincount(dst, minlength=self.N)
+            if world > 1:
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise ValueError("EdgeShardedGraph: world > 1 needs a process group or the global in_count")
+                dist.all_reduce(in_count, group=group)
+        cnt = in_count.to(device=device, dtype=torch.float32) + 1.0
         self.inv_cnt = (1.0 / cnt[self.lo:self.hi]).contiguous()
 
     def shard(self, x_full: torch.Tensor) -> torch.Tensor:

@@ -52,11 +52,11 @@ OVERLAP_MIN_ROWS = 100_000
 _SIDE_STREAMS = {}
 
 
-def _side_stream(dev) -> "torch.cuda.Stream":
-    s = _SIDE_STREAMS.get(dev)
+def _side_stream(dev, k: int = 0) -> "torch.cuda.Stream":
+    s = _SIDE_STREAMS.get((dev, k))
     if s is None:
         s = torch.cuda.Stream(device=dev)          # (a high-priority stream made no difference)
-        _SIDE_STREAMS[dev] = s
+        _SIDE_STREAMS[(dev, k)] = s
     return s
 
 

@@ -274,3 +274,65 @@ def test_auto_hubs_falls_back_when_there_is_no_small_hub_side():
     g = torch.Generator().manual_seed(0)
     ei = torch.randint(0, 50, (2, 400), generator=g)
     assert ND.auto_hubs(ei, 50) is None
+
+
+def _route_worker(rank, world, port, N, E, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ei, _, _, _, _, hub = _case(N, E, 4, kind)
+        Et = ei.size(1)
+        mine = ei[:, rank * Et // world: (rank + 1) * Et // world]      # the rank never sees the other columns
+        sg = ND.ShardedGraph(mine, N, rank, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub, sliced=True)
+        es = ND.EdgeShardedGraph(mine, N, rank, world, torch.device("cpu"), backend=TorchBackend(), sliced=True)
+        sides = [sg.A, sg.At] + ([sg.B, sg.Bt] if sg.B is not None else [])
+        q.put((rank, [(s[0].numpy().copy(), s[1].numpy().copy(), s[2], s[3]) for s in sides],
+               sg.inv_cnt.numpy().copy(), sg.cnt_a_hub.numpy().copy(), sg._out_deg.numpy().copy(),
+               es.inv_cnt.numpy().copy(), int(es.local_nnz)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,kind", [(2, 203, "bipartite"), (3, 64, "any"), (8, 333, "bipartite"), (4, 120, "auto")])
+def test_routed_partition_equals_the_full_list_masks(world, N, kind):
+    """dist.route_edges (every rank holds a slice of the edge list; one all-to-all per routed list) gives every rank the
+    sides the full-list masks give: the same entries in the same (edge_index) order, the same degree vectors."""
+    E = 900
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_route_worker, args=(r, world, port, N, E, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        got = q.get(timeout=180)
+        res[got[0]] = got[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ei, _, _, _, _, hub = _case(N, E, 4, kind)
+    keep = ei[0] != ei[1]
+    in_deg = torch.bincount(ei[1][keep], minlength=N)
+    total_edges = 0
+    for r in range(world):
+        sides, inv_cnt, cnt_a_hub, out_deg, e_inv, e_nnz = res[r]
+        local = ND.ShardedGraph(ei, N, r, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub)   # no group: masks
+        part = local.part
+        a, b = ND.local_sides(ei[0], ei[1], part, r)
+        at, bt = ND.local_sides(ei[1], ei[0], part, r)
+        want = [a, at] + ([b, bt] if local.B is not None else [])
+        assert len(sides) == len(want)
+        for got_side, ref_side in zip(sides, want):
+            assert torch.equal(torch.from_numpy(got_side[0]), ref_side[0]) and torch.equal(torch.from_numpy(got_side[1]), ref_side[1])
+            assert got_side[2:] == tuple(ref_side[2:])
+        assert torch.equal(torch.from_numpy(inv_cnt), local.inv_cnt) and torch.equal(torch.from_numpy(cnt_a_hub), local.cnt_a_hub)
+        assert torch.equal(torch.from_numpy(out_deg), torch.bincount(ei[0][keep], minlength=N))
+        per = (N + world - 1) // world
+        assert torch.allclose(torch.from_numpy(e_inv), 1.0 / (in_deg[r * per: (r + 1) * per].float() + 1.0))
+        total_edges += e_nnz
+    assert total_edges == int(keep.sum())                    # the edge slices partition the non-loop edges
+    with pytest.raises(ValueError):                          # a slice without a process group cannot be routed
+        ND.ShardedGraph(ei[:, :10], N, 0, 2, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub, sliced=True)
