@@ -197,6 +197,32 @@ def sides_from_routed(l1, l2, part: HubPartition, rank: int):
     return a, b, at, bt
 
 
+def direct_sides_from_routed(l1, l2, part: HubPartition, rank: int):
+    """The sides for a cut WITHOUT hub-hub edges (every bipartite graph): a hub row then gets nothing but light sources
+    and its own self loop, so the loop joins the PARTIAL side of the owner -- its source row is local -- and the
+    reduce-scattered sums are the complete hub rows: they land in the output directly, no merge pass.
+
+      A  : rows = this rank's nL light rows  <- [hub table ; own rows] (the light rows' loops read the second part)
+      B  : rows = hub table                  <- own rows: light sources, plus the loops of the hubs this rank owns (LAST)
+    and the same two keyed by source (A^T, B^T).  Returns (a, b, at, bt) as (key, val, n_rows, n_cols)."""
+    dev = part.hub.device
+    nL, nH = part.n_light(rank), part.n_hub(rank)
+    light = torch.arange(nL, device=dev)
+    own_hub_tbl = rank * part.h_per + torch.arange(nH, device=dev)
+    own_hub_loc = nL + torch.arange(nH, device=dev)
+    n_tab = part.hub_rows + nL + nH
+
+    def pair(keys, vals):
+        full = (torch.cat([part.local(keys), light]), torch.cat([part.hub_row(vals), part.hub_rows + light]), nL, n_tab)
+        partial = (torch.cat([part.hub_row(vals), own_hub_tbl]), torch.cat([part.local(keys), own_hub_loc]),
+                   part.hub_rows, nL + nH)
+        return full, partial
+
+    a, bt = pair(l1[1], l1[0])             # keyed by (light) target
+    at, b = pair(l2[0], l2[1])             # keyed by (light) source
+    return a, b, at, bt
+
+
 def _stable_buckets(dest: torch.Tensor, world: int, backend):
     """(order, counts): ``order`` lists the positions of ``dest`` grouped by value 0..world-1, input order kept inside a
     group (so that chunks concatenated in rank order reproduce edge_index order); ``counts[k]`` = size of group k."""
@@ -232,17 +258,19 @@ def route_edges(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: 
     all-to-all per list.  No rank ever holds the whole edge list; what it receives is its ~1/W share, in edge_index order
     (slices travel in rank order and the bucketing is stable), so the CSRs built from it are the ones the full-list
     masks (``local_sides``) give.  Also returns the global in- and out-degree (non-loop edges) of every node: one
-    all-reduce of an int64 [N] vector each -- node metadata, needed for the mean and for GCN's normalisation."""
+    all-reduce of an int64 [N] vector each -- node metadata, needed for the mean and for GCN's normalisation -- and
+    whether any edge joins two hubs (none on a bipartite graph: the hub rows then need no merge pass, ``direct_sides``)."""
     keep = src != dst
     src, dst = src[keep], dst[keep]
     hub_s, hub_d = part.hub[src], part.hub[dst]
     bad = (~hub_s & ~hub_d).any().to(torch.int64).view(1)
+    hub_hub = (hub_s & hub_d).any().to(torch.int64).view(1)
     in_cnt = torch.bincount(dst, minlength=part.N)
     out_cnt = torch.bincount(src, minlength=part.N)
     if world > 1:
-        stats = torch.cat([bad, in_cnt, out_cnt])
+        stats = torch.cat([bad, hub_hub, in_cnt, out_cnt])
         dist.all_reduce(stats, group=group)
-        bad, in_cnt, out_cnt = stats[:1], stats[1:1 + part.N], stats[1 + part.N:]
+        bad, hub_hub, in_cnt, out_cnt = stats[:1], stats[1:2], stats[2:2 + part.N], stats[2 + part.N:]
     if int(bad) > 0:
         raise ValueError("HubPartition: an edge joins two light nodes; mark one endpoint as a hub (auto_hubs)")
     lists = []
@@ -253,8 +281,11 @@ def route_edges(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: 
             order, counts = _stable_buckets(part.owner(owner_of[mask]), world, backend)
             rows = _all_to_all_rows(rows[order], counts, world, group)
         lists.append((rows[:, 0].contiguous(), rows[:, 1].contiguous()))
-    return lists[0], lists[1], in_cnt, out_cnt
+    return lists[0], lists[1], in_cnt, out_cnt, int(hub_hub) > 0
 
+
+# cuts without hub-hub edges: reduce-scatter the complete hub rows straight into the output (no merge pass); 0 = classic layout
+DIRECT_HUB_ROWS = os.environ.get("NPI_DIRECT_HUB_ROWS", "1") != "0"
 
 # tests set this to push a world-size-1 run through RCCL as well (the one-GPU box's only way to
 # exercise the real collectives); normally a single rank just copies
@@ -354,9 +385,9 @@ class HipBackend:
     def col_of_entry(self, side):
         return side.col[: side.nnz_max].long()
 
-    def segsum(self, side, table, mean: bool = False, table2=None, w=None, bias=None):
+    def segsum(self, side, table, mean: bool = False, table2=None, w=None, bias=None, out=None):
         from . import functional as NF
-        return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2)
+        return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2, out=out)
 
     def linear_fwd(self, a, w, b):
         from . import functional as NF
@@ -445,7 +476,7 @@ class ShardedGraph:
                 E = edge_index.size(1)
                 edge_index = edge_index[:, rank * E // world: (rank + 1) * E // world]
             ei = edge_index.to(device)
-            l1, l2, in_cnt, out_cnt = route_edges(ei[0], ei[1], part, rank, world, group, be)
+            l1, l2, in_cnt, out_cnt, hub_hub = route_edges(ei[0], ei[1], part, rank, world, group, be)
             del ei
         else:
             if sliced and world > 1:
@@ -459,16 +490,20 @@ class ShardedGraph:
             m1, m2 = hub_s & (part.owner(dst) == rank), hub_d & (part.owner(src) == rank)
             l1, l2 = (src[m1], dst[m1]), (src[m2], dst[m2])
             in_cnt, out_cnt = torch.bincount(dst, minlength=num_nodes), torch.bincount(src, minlength=num_nodes)
+            hub_hub = bool((hub_s & hub_d).any())
             del ei, src, dst, hub_s, hub_d, m1, m2
-        a, b, at, bt = sides_from_routed(l1, l2, part, rank)
-        self.A, self.At = be.make_side(*a), be.make_side(*at)
-        self.B = be.make_side(*b) if self.exchange_partials else None
-        self.Bt = be.make_side(*bt) if self.exchange_partials else None
-        self.local_nnz = int(a[0].numel()) + int(b[0].numel())    # entries this rank walks per direction
+        self._l1, self._l2 = l1, l2                               # this rank's routed share of the edge list (~2 E / W edges)
+        # no hub-hub edge anywhere (bipartite graphs): SAGE / GCN use the direct layout (direct_sides_from_routed)
+        self.direct_ok = self.exchange_partials and not hub_hub and DIRECT_HUB_ROWS
+        self._classic = self._direct = None
+        n_b = int((~part.hub[l2[0]]).sum()) if self.exchange_partials else 0
+        self.local_nnz = int(l1[0].numel()) + self.n_local + n_b  # entries this rank walks per direction
         # 1 / (in-degree + 1) of the local rows; for hub rows also the share of it that side A holds
         own = part.own_ids(rank)
+        self._in_cnt = in_cnt
         self.inv_cnt = (1.0 / (in_cnt[own].to(torch.float32) + 1.0)).contiguous()
-        self.cnt_a_hub = torch.bincount(a[0], minlength=self.n_local)[self.nL:].to(torch.float32).view(-1, 1)
+        hub_keys = l1[1][part.hub[l1[1]]]
+        self.cnt_a_hub = (torch.bincount(part.local(hub_keys), minlength=self.nH)[: self.nH].to(torch.float32) + 1.0).view(-1, 1)
         # the hub rows' merge after the reduce-scatter, agg = agg (cnt_A / cnt) + hsum / cnt, as two per-row factors
         self.hub_scale_a = (self.cnt_a_hub * self.inv_cnt[self.nL:].view(-1, 1)).contiguous()
         self.hub_scale_b = self.inv_cnt[self.nL:].view(-1, 1).contiguous()
@@ -476,7 +511,56 @@ class ShardedGraph:
         self.own = own
         self.own_hub = slice(rank * part.h_per, rank * part.h_per + self.nH)       # this rank's rows of the hub table
         self._gcn = None
+        self._gcn_direct = None
         self._b_empty = None
+
+    # ---- classic layout: A holds every local row with its loop, B the partial hub sums from light sources (GATConv, and
+    #      SAGE / GCN on cuts with hub-hub edges); built on first use
+    def _classic_sides(self):
+        if self._classic is None:
+            be = self.backend
+            a, b, at, bt = sides_from_routed(self._l1, self._l2, self.part, self.rank)
+            x = self.exchange_partials
+            self._classic = (be.make_side(*a), be.make_side(*b) if x else None, be.make_side(*at),
+                             be.make_side(*bt) if x else None)
+        return self._classic
+
+    A = property(lambda self: self._classic_sides()[0])
+    B = property(lambda self: self._classic_sides()[1])
+    At = property(lambda self: self._classic_sides()[2])
+    Bt = property(lambda self: self._classic_sides()[3])
+
+    def direct(self):
+        """(A, B, At, Bt) of the direct layout (``direct_sides_from_routed``); only when ``direct_ok``"""
+        if self._direct is None:
+            be = self.backend
+            self._direct = tuple(be.make_side(*t) for t in direct_sides_from_routed(self._l1, self._l2, self.part, self.rank))
+        return self._direct
+
+    def direct_weights(self, gcn: bool):
+        """Per-entry weights of the direct layout's four sides.  SAGE: the partial sides carry ``1 / (in-degree + 1)`` of
+        their (hub) row -- global counts, so the partial sums of all ranks ADD to the mean; the full sides use the
+        kernel's own mean (a light row is complete on its owner).  GCN: the symmetric normalisation on every side."""
+        if self._gcn_direct is None:
+            self._gcn_direct = {}
+        if gcn not in self._gcn_direct:
+            part, be = self.part, self.backend
+            A, B, At, Bt = self.direct()
+            tid = part.hub_table_ids()
+            if gcn:
+                dinv = (self._out_deg.to(torch.float32) + 1.0).pow(-0.5)
+                d_hub = torch.where(tid >= 0, dinv[tid.clamp(min=0)], torch.zeros((), device=dinv.device))
+                d_own = dinv[self.own]
+                d_tbl = torch.cat([d_hub, d_own])
+                w = {n: (d_own[be.row_of_entry(sd)] * d_tbl[be.col_of_entry(sd)]).contiguous() for n, sd in (("A", A), ("At", At))}
+                w.update({n: (d_hub[be.row_of_entry(sd)] * d_own[be.col_of_entry(sd)]).contiguous() for n, sd in (("B", B), ("Bt", Bt))})
+            else:
+                inv_hub = torch.where(tid >= 0, 1.0 / (self._in_cnt[tid.clamp(min=0)].to(torch.float32) + 1.0),
+                                      torch.zeros((), device=tid.device))
+                # backward: dagg arrives pre-divided by the TARGET's count (the GEMM epilogue), so B^T adds plain sums
+                w = {"A": None, "At": None, "B": inv_hub[be.row_of_entry(B)].contiguous(), "Bt": None}
+            self._gcn_direct[gcn] = w
+        return self._gcn_direct[gcn]
 
     def shard(self, x_full: torch.Tensor) -> torch.Tensor:
         return x_full[self.own.to(x_full.device)]
@@ -543,38 +627,54 @@ def scatter_hub_sums(sg: ShardedGraph, partial: torch.Tensor, async_op: bool = F
 PARTIAL_SIDE_STREAM = os.environ.get("NPI_PARTIAL_STREAM", "1") != "0"
 
 
-def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, w_part, mean: bool, tag: str, bias=None):
+def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, w_part, mean: bool, tag: str, bias=None,
+                   direct: bool = False):
     """One direction of the hub-cut aggregation of ``rows`` [n_local, F]:
 
         table = all_gather(hub rows of ``rows``)                      | psum = segsum(partial side, rows)
         out   = segsum(full side, [table ; rows])  (mean / bias fused) | hsum = reduce_scatter(psum)
 
-    Returns (out, hsum or None): the caller folds ``hsum[:nH]`` into ``out[nL:]`` (the rule differs: SAGE's mean
-    re-weights the two shares, sums just add).  ``tag``: prefix of the exposed-communication records ("fwd" / "bwd")."""
-    be = sg.backend
+    Classic layout: returns (out [n_local, F], hsum or None, table) and the caller folds ``hsum[:nH]`` into ``out[nL:]``
+    (the rule differs: SAGE's mean re-weights the two shares, sums just add).  ``direct`` (sides of
+    ``ShardedGraph.direct()``): the full side covers the light rows only and the reduce-scatter delivers the COMPLETE hub
+    rows, so both write into one ``[nL + h_per, F]`` buffer and (out[:n_local], None, table) comes back -- nothing to fold.
+    ``tag``: prefix of the exposed-communication records ("fwd" / "bwd")."""
+    be, W = sg.backend, sg.world
     table, g_work = gather_hub(sg, rows, async_op=True)            # needs nothing but ``rows``: issued first
-    hsum = b_stream = r_work = None
+    hsum = b_stream = r_work = out_full = None
+    if direct:
+        out_full = rows.new_empty((sg.nL + sg.part.h_per, rows.size(1)))
     if sg.exchange_partials:
         b_stream = be.partial_stream(rows) if (PARTIAL_SIDE_STREAM and hasattr(be, "partial_stream")) else None
-        if b_stream is None:
+        cur = None
+
+        def partial_side():
+            if direct and _solo(W):                                # one rank: the hub table IS its block of the output
+                return be.segsum(partial, rows, w=w_part, out=out_full[sg.nL:]), None
             psum = be.segsum(partial, rows, w=w_part)              # no remote input: overlaps the all-gather
-            hsum, r_work = scatter_hub_sums(sg, psum, async_op=True)
+            if direct:
+                hub_out = out_full[sg.nL:]
+                return hub_out, reduce_scatter_rows(psum, hub_out, sg.rank, W, sg.group, async_op=True)
+            return scatter_hub_sums(sg, psum, async_op=True)
+        if b_stream is None:
+            hsum, r_work = partial_side()
         else:
             cur = torch.cuda.current_stream(rows.device)
             b_stream.wait_stream(cur)                              # ``rows`` is complete for the partial side
             with torch.cuda.stream(b_stream):
-                psum = be.segsum(partial, rows, w=w_part)
-                hsum, r_work = scatter_hub_sums(sg, psum, async_op=True)
-            for t in (rows, w_part):
+                hsum, r_work = partial_side()
+            for t in (rows, w_part, out_full):
                 if t is not None:
-                    t.record_stream(b_stream)                      # allocated on ``cur``, read on the partial stream
+                    t.record_stream(b_stream)                      # allocated on ``cur``, used on the partial stream
     _wait(g_work, tag + "_all_gather", table)
-    out = be.segsum(full, table, mean=mean, table2=rows, w=w_full, bias=bias)
+    out = be.segsum(full, table, mean=mean, table2=rows, w=w_full, bias=bias, out=out_full[: sg.nL] if direct else None)
     if hsum is not None:
         _wait(r_work, tag + "_reduce_scatter", hsum)
         if b_stream is not None:
             cur.wait_stream(b_stream)                              # one rank: no collective to wait for
             hsum.record_stream(cur)
+    if direct:
+        return out_full[: sg.n_local], None, table
     return out, hsum, table
 
 
@@ -587,8 +687,12 @@ class _ShardedSageFn(torch.autograd.Function):
     def forward(ctx, x_own, weight, bias, sg: ShardedGraph, gcn: bool = False):
         be = sg.backend
         x_own = x_own.contiguous()
-        nrm = sg.gcn_norm() if gcn else {"A": None, "B": None}
-        agg, hsum, _ = _hub_aggregate(sg, x_own, sg.A, sg.B, nrm["A"], nrm["B"], not gcn, "fwd")
+        nrm = {"A": None, "B": None} if (sg.direct_ok or not gcn) else sg.gcn_norm()
+        if sg.direct_ok:
+            d, w = sg.direct(), sg.direct_weights(gcn)
+            agg, hsum, _ = _hub_aggregate(sg, x_own, d[0], d[1], w["A"], w["B"], not gcn, "fwd", direct=True)
+        else:
+            agg, hsum, _ = _hub_aggregate(sg, x_own, sg.A, sg.B, nrm["A"], nrm["B"], not gcn, "fwd")
         if hsum is not None and sg.nH:
             if gcn:
                 agg[sg.nL:] += hsum[: sg.nH]
@@ -611,7 +715,7 @@ class _ShardedSageFn(torch.autograd.Function):
         dagg = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
-        nrm = sg.gcn_norm() if ctx.gcn else {"At": None, "Bt": None}
+        nrm = {"At": None, "Bt": None} if (sg.direct_ok or not ctx.gcn) else sg.gcn_norm()
         if want_x:
             dagg = be.linear_bwd_data(grad_out, weight, None if ctx.gcn else sg.inv_cnt)
         # dW is independent of the dX chain.  On the GPU backend it is launched FIRST, on this stream, so that it is resident
@@ -627,7 +731,11 @@ class _ShardedSageFn(torch.autograd.Function):
                 be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
         if want_x:
             def chain():
-                out, hsum, table = _hub_aggregate(sg, dagg, sg.At, sg.Bt, nrm["At"], nrm["Bt"], False, "bwd")
+                if sg.direct_ok:
+                    d, w = sg.direct(), sg.direct_weights(ctx.gcn)
+                    out, hsum, table = _hub_aggregate(sg, dagg, d[2], d[3], w["At"], w["Bt"], False, "bwd", direct=True)
+                else:
+                    out, hsum, table = _hub_aggregate(sg, dagg, sg.At, sg.Bt, nrm["At"], nrm["Bt"], False, "bwd")
                 if hsum is not None and sg.nH:
                     out[sg.nL:] += hsum[: sg.nH]
                 return out, (table, hsum)

@@ -33,15 +33,20 @@ class TorchBackend:
     def _table(table, table2):
         return table if table2 is None else torch.cat([table, table2])
 
-    def segsum(self, side, table, mean=False, table2=None, w=None, bias=None):
+    def segsum(self, side, table, mean=False, table2=None, w=None, bias=None, out=None):
         key, val, n_rows, n_cols = side
         t = self._table(table, table2)
         assert t.size(0) >= n_cols
         msg = t[val] if w is None else t[val] * w.view(-1, 1)
-        out = torch.zeros(n_rows, t.size(1)).index_add_(0, key, msg)
+        res = torch.zeros(n_rows, t.size(1)).index_add_(0, key, msg)
         if mean:
-            out = out / torch.bincount(key, minlength=n_rows).clamp(min=1).float().view(-1, 1)
-        return out + bias if bias is not None else out
+            res = res / torch.bincount(key, minlength=n_rows).clamp(min=1).float().view(-1, 1)
+        res = res + bias if bias is not None else res
+        if out is not None:
+            assert out.shape == res.shape
+            out.copy_(res)
+            return out
+        return res
 
     def linear_fwd(self, a, w, b):
         return a @ w + (b if b is not None else 0)

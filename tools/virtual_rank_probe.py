@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""One virtual rank of a W-rank run on this GPU (collectives = local copies): wall time per step, GPU time per step
+(events), and -- under `rocprofv3 --kernel-trace --stats` -- the kernels of a rank's step.
+usage: python tools/virtual_rank_probe.py [--world 8] [--rank 0] [--conv sage|gat] [--partition hubs] [--steps 20] [--capture]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--conv", default="sage")
+    ap.add_argument("--partition", default="hubs")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--nodes", type=int, default=1_000_000)
+    ap.add_argument("--edges", type=int, default=20_000_000)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--capture", action="store_true")
+    a = ap.parse_args()
+    from npi_gnn_amd import dist as ND
+    from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
+    dev = torch.device("cuda:0")
+    N, E, F, W, r = a.nodes, a.edges, a.hidden, a.world, a.rank
+
+    class Done:
+        def wait(self):
+            return True
+
+    def ag(block, out, w, group=None, async_op=False):
+        out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1))
+        return Done() if async_op else None
+
+    def rs(part_sums, out, rank, w, group=None, async_op=False):
+        out.copy_(part_sums.view(w, -1)[rank].view_as(out))
+        return Done() if async_op else None
+
+    ND.all_gather_rows, ND.reduce_scatter_rows = ag, rs
+    ND._all_reduce = lambda *x, **k: None
+    ND._solo = lambda w: False
+    ei = bipartite_edge_index(N, E, seed=20260310).to(dev)
+    g = torch.Generator().manual_seed(3)
+    Wm = ((torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
+    b = ((torch.rand(F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
+    sg = ND.ShardedGraph(ei, N, r, W, dev, hub_mask=protein_mask(N).to(dev) if a.partition == "hubs" else None)
+    del ei
+    if a.conv == "sage":
+        layer = ND.ShardedSAGELayer(sg, Wm, b)
+    elif a.conv == "gcn":
+        layer = ND.ShardedGCNLayer(sg, Wm, b)
+    else:
+        layer = ND.ShardedGATLayer(sg, Wm, (torch.randn(1, 1, 2 * F, generator=g) * 0.1).to(dev), b)
+    x = torch.randn(sg.n_local, F, device=dev).requires_grad_(True)
+    go = torch.randn(sg.n_local, F, device=dev)
+
+    def step():
+        layer.zero_grad()
+        x.grad = None
+        layer(x).backward(go)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    if a.capture:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            step()
+        run = gr.replay
+    else:
+        run = step
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        run()
+    e1.record()
+    t_host = (time.perf_counter() - t0) / a.steps * 1e3
+    torch.cuda.synchronize()
+    t_wall = (time.perf_counter() - t0) / a.steps * 1e3
+    print(f"world {W} rank {r} {a.partition} {a.conv}: n_local {sg.n_local} entries {sg.local_nnz}  wall {t_wall:.3f} ms/step, "
+          f"events {e0.elapsed_time(e1) / a.steps:.3f} ms/step, host issue {t_host:.3f} ms/step, capture={a.capture}")
+
+
+if __name__ == "__main__":
+    main()
