@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=100_000, help="bounded CPU-baseline sample (1/10 scale)")
     ap.add_argument("--cpu-edges", type=int, default=2_000_000)
+    ap.add_argument("--cpu-small", action="store_true", help="CPU baseline on the 1/10-scale sample only")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (npi_gnn_amd.dist) even with one rank")
     ap.add_argument("--partition", choices=["hubs", "rows", "edges"], default="hubs",
@@ -128,51 +129,109 @@ def cpu_model() -> str:
     return platform.processor()
 
 
-def cpu_baseline(args):
-    """The oracle (PyG-style torch CPU ops: index_select -> index_add_ -> / -> matmul, autograd
-    backward) timed on this box's host cores on a bounded 1/10-scale sample of the same workload."""
+def mem_available_gb() -> float:
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(args, ei_full=None):
+    """The oracle (PyG-style torch CPU ops: index_select -> index_add_ -> / -> matmul, autograd backward) timed on this
+    box's host cores.  The thread count is chosen on the 1/10-scale sample (the index ops stop scaling long before the
+    host's thread count); the reported figure is the metric's OWN configuration -- the full C4 graph, N = 1M, E = 20M --
+    whenever the host has the memory for its [E+N, F] message tensors (MemAvailable >= 128 GB), else the 1/10 sample."""
     from npi_gnn_amd.synth import bipartite_edge_index
     from oracle import ref_conv as R
-    N, E, F = args.cpu_nodes, args.cpu_edges, args.hidden
-    ei = bipartite_edge_index(N, E, seed=20260310)
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(N, F, generator=g)
-    W = (torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5
-    b = torch.zeros(F)
-    go = torch.randn(N, F, generator=g)
+    F = args.hidden
+
+    def data(N, E, ei=None):
+        if ei is None:
+            ei = bipartite_edge_index(N, E, seed=20260310)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(N, F, generator=g)
+        W = (torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5
+        go = torch.randn(N, F, generator=g)
+        return x, ei, W, torch.zeros(F), go
+
     # The index_add_/index_select ops of this path stop scaling long before the host's thread count
     # (2 x 64-core EPYC 9575F: 32 threads 1.9 M edges/s, 256 threads 0.27 M; tools/cpu_threads_sweep.py),
     # so the baseline is the best of a short sweep, not "all threads".
     ncpu = os.cpu_count() or 1
-    budget = time.time() + 25.0
+    Ns, Es = args.cpu_nodes, args.cpu_edges
+    small = data(Ns, Es)
+    budget = time.time() + 20.0
     best, best_threads, runs = None, 1, 0
     for nt in sorted({min(t, ncpu) for t in (16, 32, 64)}):
         torch.set_num_threads(nt)
-        for it in range(1 + 3):
+        for it in range(1 + 2):
             t0 = time.time()
-            R.sage_layer_fwd_bwd(x, ei, W, b, go)
+            R.sage_layer_fwd_bwd(*small)
             dt = time.time() - t0
             if it >= 1:
                 runs += 1
                 if best is None or dt < best:
                     best, best_threads = dt, nt
-            if time.time() > budget and best is not None:
-                break
-        if time.time() > budget and best is not None:
+        if time.time() > budget:
             break
-    return {"value": E / best, "unit": "edges/s", "cores": best_threads, "kind": "port",
-            "sample": f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd, N={N} E={E} F={F} fp32 "
-                      f"(1/10-scale C4), best of {runs} timed runs over 16/32/64 torch threads (1 warm-up each), "
-                      f"os.cpu_count()={os.cpu_count()}, cpu='{cpu_model()}'"}
+    del small
+    mem = mem_available_gb()
+    sample_small = (f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd, N={Ns} E={Es} F={F} fp32 (1/10-scale C4), best of "
+                    f"{runs} timed runs over 16/32/64 torch threads (1 warm-up each)")
+    res = {"value": Es / best, "unit": "edges/s", "cores": best_threads, "kind": "port", "sample": sample_small,
+           "ran": "1/10-scale sample", "mem_available_gb": round(mem, 1)}
+    full = (args.nodes, args.edges) == (1_000_000, 20_000_000) and not args.cpu_small
+    if full and mem >= 128.0:
+        try:
+            torch.set_num_threads(best_threads)
+            big = data(args.nodes, args.edges, ei_full)
+            times = []
+            for it in range(1 + 2):                             # 1 warm-up, best of 2
+                t0 = time.time()
+                R.sage_layer_fwd_bwd(*big)
+                times.append(time.time() - t0)
+            del big
+            res.update(value=args.edges / min(times[1:]), ran="full C4 configuration",
+                       small_sample_edges_per_s=Es / best,
+                       sample=f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd on the metric's own configuration: "
+                              f"N={args.nodes} E={args.edges} F={F} fp32 (the full C4 graph of the GPU line), best of 2 timed runs "
+                              f"after 1 warm-up ({', '.join(f'{t:.1f}' for t in times)} s) at {best_threads} torch threads -- the "
+                              f"best of 16/32/64 on the 1/10-scale sample ({Es / best / 1e6:.2f} M edges/s there)")
+        except Exception as e:                                  # e.g. the host ran out of memory after all
+            res["full_c4_error"] = f"{type(e).__name__}: {e}"[:200]
+    elif full:
+        res["ran"] = f"1/10-scale sample (MemAvailable {mem:.0f} GB < 128 GB needed for the full C4 message tensors)"
+    res["sample"] += f", os.cpu_count()={os.cpu_count()}, cpu='{cpu_model()}'"
+    return res
+
+
+def kernel_source_sha(files=("segsum.hip", "segsum.h", "gat.hip")) -> dict:
+    """sha256[:16] of the kernel sources a PMC constant belongs to (profiles/pmc_traffic.json stores the same)"""
+    import hashlib
+    out = {}
+    for f in files:
+        try:
+            out[f] = hashlib.sha256(open(os.path.join(ROOT, "npi_gnn_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+        except OSError:
+            out[f] = None
+    return out
 
 
 def pmc_traffic():
     """HBM-side bytes per aggregation launch from the OFFLINE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate
-    runs, gfx950 correction per the guide; tools/profile_bench.sh + tools/rocprof_summary.py write this file)."""
+    runs, gfx950 correction per the guide; tools/profile_bench.sh + tools/rocprof_summary.py write this file).  The file
+    records the sha of the kernel sources it was measured on: constants of another source are STALE and are not used."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return {}
+    now, then = kernel_source_sha(), t.get("source_sha16") or {}
+    t["stale"] = [f for f in ("segsum.hip", "segsum.h") if then.get(f) != now[f]]
+    t["stale_gat"] = t["stale"] + [f for f in ("gat.hip",) if then.get(f) != now[f]]
+    return t
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -199,14 +258,15 @@ def control_uniform(dev, N, E, F, launches=10):
     alg = algorithmic_bytes(E - n_loops, N, F)
     ach = alg / (ms * 1e-3) / 1e9
     t = pmc_traffic()
-    traffic = t.get("control_uniform_bytes_per_launch")
+    traffic = t.get("control_uniform_bytes_per_launch") if not t.get("stale") else None
     res = {"workload": f"N={N} E={E} uniform random sources and targets (every row of the {N * F * 4 / 1e9:.2f} GB table "
                        f"equally likely: no cache-resident hub side), F={F} fp32, aggregation launches only",
            "avg_launch_ms": ms, "launches_timed": len(ev), "algorithmic_bytes_per_launch": alg,
            "achieved": ach, "frac_algorithmic": ach / HBM_PEAK_GBS,
            "traffic": traffic,
            "frac_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-           "traffic_source": t.get("control_from")}
+           "traffic_source": t.get("control_from") if traffic else
+           (f"STALE: {t.get('control_from')} was measured on another {t.get('stale')}" if t.get("stale") else None)}
     del graph, x
     torch.cuda.empty_cache()
     return res
@@ -784,7 +844,7 @@ def main():
     achieved = alg_bytes / (seg_avg_ms * 1e-3) / 1e9 if seg_ms else 0.0
     pmc = pmc_traffic()
     traffic = None
-    if not sharded and args.conv == "sage" and (N, E, F) == (1_000_000, 20_000_000, 256):
+    if not sharded and args.conv == "sage" and (N, E, F) == (1_000_000, 20_000_000, 256) and not pmc.get("stale"):
         traffic = pmc.get("segsum_kernel_bytes_per_launch")
     frac_alg = achieved / HBM_PEAK_GBS
     frac_traffic = (traffic / (seg_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and seg_ms) else None
@@ -845,15 +905,18 @@ def main():
                 # two fractions of the 8 TB/s HBM peak, both from the same live launch duration:
                 "frac_algorithmic": frac_alg,      # SURVEY 8(d) bytes (every gathered row counted, no cache credit) / time
                 "frac_traffic": frac_traffic,      # bytes that crossed the L2 <-> fabric boundary (PMC) / time
-                "frac": frac_traffic if frac_traffic is not None else min(frac_alg, 1.0),
+                "frac": frac_traffic if frac_traffic is not None else frac_alg,
                 "frac_basis": ("traffic: PMC bytes / live duration / peak -- the HBM-roofline fraction; frac_algorithmic "
                                "exceeds it (and can exceed 1) because gathers of the 100k protein rows are served by the "
                                "XCD L2s / Infinity Cache and never reach HBM") if frac_traffic is not None else
-                              "algorithmic (no PMC pass on file for this configuration), capped at 1",
-                "traffic": traffic,
+                              "algorithmic bytes / live duration / peak (no current PMC pass on file for this configuration; "
+                              "this figure counts every gathered row as an HBM read and can exceed 1 when caches serve gathers)",
+                "traffic": traffic if traffic else ("stale" if pmc.get("stale") else None),
                 "traffic_source": (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately; FETCH_SIZE x "
-                                   f"{pmc.get('fetch_scale')} gfx950 calibration), {pmc.get('from')} -- not measured in this run")
-                if traffic else None,
+                                   f"{pmc.get('fetch_scale')} gfx950 calibration; main + fix-up kernel), {pmc.get('from')}, measured "
+                                   f"on this very source (sha {pmc.get('source_sha16')}) -- not measured in this run")
+                if traffic else (f"STALE: {pmc.get('from')} was measured on another {pmc.get('stale')}; frac falls back to "
+                                 "frac_algorithmic" if pmc.get("stale") else None),
                 "kernel": "segsum_kernel (+ segsum_fixup_kernel), avg of fwd and bwd launches",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": seg_avg_ms,
                 "launches_timed": len(seg_ms)}
@@ -903,7 +966,7 @@ def main():
         if vw is not None:
             res.setdefault("configs", {})[f"C4_w{args.virtual_world}_virtual"] = vw
     if not args.no_cpu_baseline and world == 1:
-        res["cpu_baseline"] = cpu_baseline(args)
+        res["cpu_baseline"] = cpu_baseline(args, ei)
     elif not args.no_cpu_baseline:
         res["cpu_baseline"] = None
     print(json.dumps(res), flush=True)

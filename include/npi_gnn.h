@@ -195,6 +195,19 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
  *               entry points do)
  *   shared    : npi_linear_bwd_weight_ex: 1 = the GEMM shares the CUs with an HBM-bound kernel on another stream
  *               (about 3 workgroups per 4 CUs), 0 = it has the GPU to itself (see npi_dw_shared) */
+ *
+ * NON-FINITE OPERANDS (what replaces torch.matmul at PyG 1.4.2 SAGEConv.update / its autograd):
+ *   NPI_GEMM_EXACT_F32  is an fp32 fmaf chain: an Inf operand gives +-Inf in the products it takes part in (NaN against a
+ *                       zero or an opposing Inf), exactly like torch.matmul.
+ *   NPI_GEMM_SPLIT_BF16 (the default for f32) writes every operand as x0 + x1 + x2 with x1 = bf16(x - x0): for x = +-Inf,
+ *                       and for finite |x| > 3.3895e38 (beyond the largest bf16, x0 rounds to Inf), x - x0 is NaN, so every
+ *                       output element that operand takes part in is NaN -- the whole output ROW for an element of A / dC,
+ *                       the whole output COLUMN for an element of W -- where fp32 matmul gives +-Inf (or, for a finite
+ *                       |x| > 3.3895e38 against small weights, a finite number).  NaN operands give
+ *                       NaN in both.  Finite results are unaffected (error <= 3 * 2^-24 |a||b| per product).  A model that
+ *                       has diverged therefore reads NaN instead of Inf; callers that test `isinf` on activations must
+ *                       test `!isfinite`, or pass NPI_GEMM_EXACT_F32 (npi_gemm_mode(0) / NPI_GEMM_SPLIT=0 process-wide).
+ *                       Pinned by tests/test_gpu_parity.py::test_non_finite_operands_of_the_projection_gemms. */
 #define NPI_GEMM_EXACT_F32 1
 #define NPI_GEMM_SPLIT_BF16 2
 /* npi_linear_fwd_ex / npi_linear_bwd_weight_ex, f32: A is stored with lda >= Kp (K rounded up to a multiple of 128) and its

@@ -292,7 +292,7 @@ class _SageConvFn(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 side = _side_stream(dev)
                 side.wait_stream(main)                               # dAgg is complete for the side stream
-                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True)
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True, k_valid=ctx.k_valid)
                 with torch.cuda.stream(side):
                     dx = segsum(graph, tside(), dagg, w=ctx.w_src, mean=False)
                 dagg.record_stream(side)                             # allocated on main, read on side

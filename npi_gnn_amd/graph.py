@@ -33,11 +33,15 @@ def set_debug(flag: bool) -> None:
     _DEBUG = bool(flag)
 
 
-def pending_status() -> list:
+def pending_status(device=None) -> list:
     """Device status words not yet checked (callers that are about to read from the device append them to their read and
-    hand the values to ``raise_on_status``)."""
-    out = list(_PENDING)
-    _PENDING.clear()
+    hand the values to ``raise_on_status``).  ``device``: only that GPU's words are taken; the others stay pending."""
+    if device is None:
+        out = list(_PENDING)
+        _PENDING.clear()
+        return out
+    out = [t for t in _PENDING if t.device == device]
+    _PENDING[:] = [t for t in _PENDING if t.device != device]
     return out
 
 
@@ -149,6 +153,10 @@ class CSRGraph:
         self.num_edges = int(edge_index.size(1))
         self.self_loops = bool(self_loops)
         self.device = edge_index.device
+        # what this CSR was built from: a cached graph is reused only for THIS tensor in THIS state (an in-place edit of the
+        # edge list bumps ``_version`` and the next conv call sorts again -- ``cached_graph``)
+        self._ei_version = edge_index._version
+        self._ei_ptr = edge_index.data_ptr()
         # The producer of the edge list may vouch that it holds every edge in both directions (edge_index._npi_symmetric:
         # the device-side subgraph extraction emits both, src/classes.py:701-704, and filter_adj keeps the property).
         # Then row j of the by-source CSR holds the same neighbours as row j of the by-target CSR -- in another order --
@@ -180,6 +188,17 @@ class CSRGraph:
         return n
 
 
+def cached_graph(edge_index: torch.Tensor, num_nodes: Optional[int] = None) -> Optional[CSRGraph]:
+    """The CSR an earlier call left on this edge list -- only if the tensor is still the one it was built from: same
+    storage, same shape and, above all, the same ``_version`` (every in-place write bumps it), so an edit of a cached edge
+    list is never answered from the stale CSR."""
+    g = getattr(edge_index, "_npi_graph", None)
+    if (isinstance(g, CSRGraph) and g.num_edges == edge_index.size(1) and g._ei_version == edge_index._version
+            and g._ei_ptr == edge_index.data_ptr() and (num_nodes is None or g.num_nodes == num_nodes)):
+        return g
+    return None
+
+
 def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:
     if isinstance(edge_index_or_graph, CSRGraph):
         g = edge_index_or_graph
@@ -187,14 +206,16 @@ def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:
             raise ValueError(f"CSRGraph was built for {g.num_nodes} nodes, x has {num_nodes}")
         return g
     # an edge list that is used again and again (the static batches of net1.GraphedEpoch) may carry its CSR
-    g = getattr(edge_index_or_graph, "_npi_graph", None)
-    if isinstance(g, CSRGraph) and g.num_nodes == num_nodes and g.num_edges == edge_index_or_graph.size(1):
+    g = cached_graph(edge_index_or_graph, num_nodes)
+    if g is not None:
         return g
-    # the edge list TopKPooling returned: its CSR is the parent's, filtered (no sort)
+    # the edge list TopKPooling returned: its CSR is the parent's, filtered (no sort) -- unless somebody wrote to it since
     src = getattr(edge_index_or_graph, "_npi_graph_from", None)
     g = None
+    if src is not None and len(src) == 7 and src[6] != edge_index_or_graph._version:
+        src = None
     if src is not None and src[4] == num_nodes and src[5] == edge_index_or_graph.size(1):
-        side = filtered_side(*src)
+        side = filtered_side(*src[:6])
         if side is not None:
             g = CSRGraph(edge_index_or_graph, num_nodes, by_dst=side)
         edge_index_or_graph._npi_graph_from = None           # the parent's arrays are not kept alive any longer

@@ -35,11 +35,11 @@ class Net_1(torch.nn.Module):
         super().__init__()
         self.dropout = dropout                                # 0.5 in the reference (src/classes.py:76)
         self.conv1 = SAGEConv(num_node_features, 128)
-        self.pool1 = NP.TopKPooling(128, ratio=0.5)
+        self.pool1 = NP.TopKPooling(128, ratio=0.5, padded_edges=True)
         self.conv2 = SAGEConv(128, 128)
-        self.pool2 = NP.TopKPooling(128, ratio=0.5)
+        self.pool2 = NP.TopKPooling(128, ratio=0.5, padded_edges=True)
         self.conv3 = SAGEConv(128, 128)
-        self.pool3 = NP.TopKPooling(128, ratio=0.5)
+        self.pool3 = NP.TopKPooling(128, ratio=0.5, padded_edges=True)
         self.lin1 = torch.nn.Linear(256, 128)
         self.lin2 = torch.nn.Linear(128, 64)
         self.lin3 = torch.nn.Linear(64, num_of_classes)

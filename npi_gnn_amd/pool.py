@@ -23,8 +23,9 @@ from torch.nn import Parameter
 from ._lib import check, load, ptr, require_gpu, stream_ptr
 
 
-# When the sizes of a batch's graphs are known on the host (batch._npi_sizes) TopKPooling makes no device read: see
-# _topk_pool_fwd.  The edge_index it returns is then PADDED to the input's length with (-1, -1) columns.
+# ``padded_edges=True`` (an explicit argument of topk_pool / TopKPooling; net1.Net_1 sets it) AND the sizes of the batch's
+# graphs known on the host (batch._npi_sizes): TopKPooling makes no device read, see _topk_pool_fwd.  The edge_index it
+# returns is then PADDED to the input's length with (-1, -1) columns -- NOT PyG's contract, which is why it is opt-in.
 NO_SYNC = True
 
 
@@ -57,7 +58,7 @@ def graph_ptr(batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Te
 
 
 def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, weight: torch.Tensor,
-                   ratio: float = 0.5, num_graphs: Optional[int] = None):
+                   ratio: float = 0.5, num_graphs: Optional[int] = None, padded_edges: bool = False):
     """forward kernels; returns the public tuple plus (score [N], perm int32 [n_out], remap int32 [N]: old -> new id or -1)
     for the backward"""
     lib = load()
@@ -89,7 +90,7 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     # node count is ceil(ratio n_g) per graph -- computable on the host -- and the surviving edges stay in an array of the
     # input's length whose tail is (-1, -1) padding (npi_filter_adj_ex), which every consumer drops.  No device read at
     # all: the layer, and with it the whole Net_1 step, runs without a host synchronisation and captures into a HIP graph.
-    kept = _kept_sizes(batch, ratio) if B > 0 else None
+    kept = _kept_sizes(batch, ratio) if (B > 0 and padded_edges) else None
     nosync = kept is not None and kept.numel() == B
     check(lib.npi_filter_adj_ex(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws),
                                 1 if nosync else 0, st), "npi_filter_adj")
@@ -100,7 +101,7 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
         # sizes of the outputs are data dependent: ONE device read per pooling layer (PyG's own implementation has several)
         # (the same read also reports graph builds that dropped out-of-range node ids, graph.pending_status)
         from . import graph as _graph
-        pend = [t for t in _graph.pending_status() if t.device == dev]
+        pend = _graph.pending_status(dev)                   # this device's words only; the others stay pending
         vals = torch.cat([out_ptr[-1:], status, count] + pend).tolist() if B else [0, 0, 0] + (torch.cat(pend).tolist() if pend else [])
         n_out, flags, e_out = vals[:3]
         _graph.raise_on_status(vals[3:])
@@ -138,18 +139,20 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
         ei_out._npi_symmetric = True                     # both directions of a pair survive or fall together
     # The conv in front of this layer left the CSR of `edge_index` on it (graph.as_graph): the pooled graph's CSR is that
     # one filtered -- four launches, no sort -- and rides on the edge list this layer returns, where the next conv finds it.
-    parent = getattr(edge_index, "_npi_graph", None)
-    if DERIVE_CSR and nosync and parent is not None and parent.num_nodes == N and parent.num_edges == E and parent.self_loops:
+    from .graph import cached_graph
+    parent = cached_graph(edge_index, N)                 # None if the edge list was written to since its CSR was built
+    if DERIVE_CSR and nosync and parent is not None and parent.self_loops:
         off = int(lib.npi_filter_adj_newpos_offset(E))
         # derived when (and only if) a conv asks for it: the last pooling layer's graph feeds no conv at all
-        ei_out._npi_graph_from = (parent.by_dst, perm, remap, ws[off:off + E], n_out, e_out)
+        ei_out._npi_graph_from = (parent.by_dst, perm, remap, ws[off:off + E], n_out, e_out, ei_out._version)
     return (xo, ei_out, None, batch_o, perm64, score_o), (score, perm[:n_out], remap)
 
 
 class _TopKPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, edge_index, batch, ratio, num_graphs, holder=None):
-        (xo, ei_o, _, batch_o, perm, score_o), (score, perm32, remap) = _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)
+    def forward(ctx, x, weight, edge_index, batch, ratio, num_graphs, holder=None, padded_edges=False):
+        (xo, ei_o, _, batch_o, perm, score_o), (score, perm32, remap) = _topk_pool_fwd(x, edge_index, batch, weight, ratio,
+                                                                                       num_graphs, padded_edges)
         if holder is not None:                     # attributes do not survive the way out of an autograd Function
             holder["graph"] = getattr(ei_o, "_npi_graph_from", None)
         ctx.save_for_backward(x.detach(), weight.detach(), score, perm32, remap)
@@ -171,7 +174,7 @@ class _TopKPoolFn(torch.autograd.Function):
         n_out = perm.numel()
         st = stream_ptr(dev)
         if dxo is None and dscore_o is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dxo = _f32(dxo) if dxo is not None else torch.zeros((n_out, F), dtype=torch.float32, device=dev)
         dso = _f32(dscore_o) if dscore_o is not None else None
         dx = torch.empty((N, F), dtype=torch.float32, device=dev)          # dropped rows: zeros written by the kernel
@@ -188,7 +191,7 @@ class _TopKPoolFn(torch.autograd.Function):
             check(lib.npi_topk_weight_grad(ptr(x), x.stride(0), ptr(perm), ptr(dzv), ptr(dzz), n_out, F, ptr(w), ptr(dw),
                                            ptr(ws), n_ws, st), "npi_topk_weight_grad")
             dw = dw.view_as(weight)
-        return (dx if ctx.needs_input_grad[0] else None), dw, None, None, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), dw, None, None, None, None, None, None
 
 
 def _kept_sizes(batch, ratio):
@@ -199,23 +202,31 @@ def _kept_sizes(batch, ratio):
 
 
 def topk_pool(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tensor, weight: torch.Tensor,
-              ratio: float = 0.5, num_graphs: Optional[int] = None):
+              ratio: float = 0.5, num_graphs: Optional[int] = None, padded_edges: bool = False):
     """``TopKPooling.forward`` -> ``(x', edge_index', None, batch', perm, score[perm])``; differentiable in
-    ``x`` and ``weight``."""
+    ``x`` and ``weight``.
+
+    ``padded_edges=False`` (default): PyG's contract -- ``edge_index'`` is exactly the surviving edges (one device read
+    per call for the two data-dependent sizes).  ``padded_edges=True`` and ``batch._npi_sizes`` present (the per-graph
+    node counts on the host, net1.KeyLoader): NO device read -- ``edge_index'`` then keeps the INPUT's length, the
+    surviving edges first, in order, and a tail of ``(-1, -1)`` columns.  Only this package's consumers (the convs' CSR
+    build, the next ``filter_adj``, ``entry_weights``) drop that tail; ``x[edge_index[0]]`` or ``edge_index.size(1)``
+    in foreign code would not -- hence opt-in."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         holder = {}
-        xo, score_o, ei_o, batch_o, perm, out_ptr = _TopKPoolFn.apply(x, weight, edge_index, batch, ratio, num_graphs, holder)
+        xo, score_o, ei_o, batch_o, perm, out_ptr = _TopKPoolFn.apply(x, weight, edge_index, batch, ratio, num_graphs, holder,
+                                                                      padded_edges)
         # (the tensors an autograd Function hands back need not be the objects its forward created: re-attach)
         batch_o._npi_graph_ptr = out_ptr
-        kept = _kept_sizes(batch, ratio)
+        kept = _kept_sizes(batch, ratio) if padded_edges else None
         if kept is not None:
             batch_o._npi_sizes = kept
         if getattr(edge_index, "_npi_symmetric", False):
             ei_o._npi_symmetric = True
         if holder.get("graph") is not None:
-            ei_o._npi_graph_from = holder["graph"]
+            ei_o._npi_graph_from = holder["graph"][:6] + (ei_o._version,)
         return xo, ei_o, None, batch_o, perm, score_o
-    return _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs)[0]
+    return _topk_pool_fwd(x, edge_index, batch, weight, ratio, num_graphs, padded_edges)[0]
 
 
 def _readout_fwd(x: torch.Tensor, batch: torch.Tensor, num_graphs: Optional[int]):
@@ -269,9 +280,11 @@ class TopKPooling(nn.Module):
     """``TopKPooling(in_channels, ratio=0.5)``: parameter ``weight [1, in_channels]`` (PyG 1.4.2 layout,
     so ``pool1.weight`` of the reference checkpoints loads unchanged)."""
 
-    def __init__(self, in_channels: int, ratio: float = 0.5, **kwargs):
+    def __init__(self, in_channels: int, ratio: float = 0.5, padded_edges: bool = False, **kwargs):
+        """``padded_edges``: see ``topk_pool`` -- with host-known graph sizes the layer reads nothing back and returns an
+        edge list of the input's length with a ``(-1, -1)`` tail (for pipelines made of this package's layers only)."""
         super().__init__()
-        self.in_channels, self.ratio = in_channels, ratio
+        self.in_channels, self.ratio, self.padded_edges = in_channels, ratio, bool(padded_edges)
         self.weight = Parameter(torch.empty(1, in_channels))
         self.reset_parameters()
 
@@ -284,7 +297,7 @@ class TopKPooling(nn.Module):
             raise NotImplementedError("TopKPooling: edge_attr is not used by NPI-GNN")
         if batch is None:
             batch = torch.zeros(x.size(0), dtype=torch.int64, device=x.device)
-        return topk_pool(x, edge_index, batch, self.weight, self.ratio)
+        return topk_pool(x, edge_index, batch, self.weight, self.ratio, padded_edges=self.padded_edges)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, ratio={self.ratio})"

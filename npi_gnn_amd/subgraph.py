@@ -63,6 +63,7 @@ class InteractionGraph:
             torch.zeros(1, dtype=torch.uint8, device=dev)
         self.feat = feat.contiguous()
         self.device = dev
+        self._totals_checked = False      # batch(n_nodes=, n_pairs=): host totals verified against the device once
 
     def sizes(self, keys: torch.Tensor):
         """(nodes, pairs) per sample of ``keys [K, 2]`` as HOST int64 tensors -- one device read for the whole key list.
@@ -100,6 +101,18 @@ class InteractionGraph:
         # output sizes are data dependent: one device read per batch, unless the caller knows them
         if n_nodes is not None and n_pairs is not None:
             n, npairs = int(n_nodes), int(n_pairs)
+            if n > 2 ** 31 - 1 or 2 * npairs > 2 ** 31 - 1:
+                raise OverflowError("InteractionGraph.batch: the batch has more than 2^31 - 1 rows; use fewer keys per call")
+            # The fill kernels write at the DEVICE-computed offsets: totals that belong to other keys would be an
+            # out-of-bounds write, not an error.  Checked against node_off[-1] / pair_off[-1] the first time a caller
+            # supplies totals for this graph, and on every call under graph.set_debug(True) (a device read each).
+            from . import graph as _graph
+            if (_graph._DEBUG or not self._totals_checked) and not torch.cuda.is_current_stream_capturing():
+                dn, dp = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
+                if (dn, dp) != (n, npairs):
+                    raise ValueError(f"InteractionGraph.batch: n_nodes / n_pairs = {n} / {npairs} do not belong to these keys "
+                                     f"(the device counts {dn} / {dp}); totals must come from sizes() of the same keys")
+                self._totals_checked = True
         else:
             n, npairs = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
         if n < 0:

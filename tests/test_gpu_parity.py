@@ -418,6 +418,56 @@ def test_split_bf16_gemm_is_f32_accurate(dev, M, K, N):
     assert lib.npi_gemm_mode(-1) == before                 # nothing global was touched
 
 
+def test_non_finite_operands_of_the_projection_gemms(dev):
+    """Pins the documented Inf / NaN behaviour of the two f32 arithmetics (include/npi_gnn.h at NPI_GEMM_*; reference:
+    torch.matmul in PyG 1.4.2 SAGEConv.update).  Exact f32: an Inf operand gives Inf where torch.matmul does.  3-way
+    bf16 split (the default): the same element gives NaN -- in the whole output row for an element of A, the whole output
+    column for an element of W -- and every row / column that holds no such operand is untouched."""
+    from npi_gnn_amd._lib import NPI_GEMM_EXACT_F32, NPI_GEMM_SPLIT_BF16
+    g = torch.Generator().manual_seed(77)
+    M, K, N = 1024, 256, 256
+    A = torch.randn(M, K, generator=g).abs()                 # positive operands: an Inf product cannot meet an opposing Inf
+    W = (torch.randn(K, N, generator=g).abs() / K ** 0.5)
+    A[5, 17] = float("inf")                                   # one element of A
+    A[9, 3] = 3.4e38                                          # finite in f32, beyond the largest bf16 (3.3895e38)
+    A[300, 40] = float("nan")
+    Ad, Wd = A.to(dev), W.to(dev)
+    ref = A @ W                                               # fp32 matmul on the host = the reference's behaviour
+    assert torch.isinf(ref[5]).all() and torch.isnan(ref[300]).all() and torch.isfinite(ref[9]).all()   # 3.4e38 * w, |w| << 1
+    clean = torch.ones(M, dtype=torch.bool)
+    clean[[5, 9, 300]] = False
+    exact = NF.linear_fwd(Ad, Wd, None, flags=NPI_GEMM_EXACT_F32).cpu()
+    split = NF.linear_fwd(Ad, Wd, None, flags=NPI_GEMM_SPLIT_BF16).cpu()
+    for out in (exact, split):                                # rows without a non-finite operand: the ordinary accuracy
+        assert torch.isfinite(out[clean]).all()
+        assert float((out[clean] - ref[clean]).abs().max() / ref[clean].abs().max()) < 2e-6
+    assert torch.isinf(exact[5]).all() and (exact[5] > 0).all()              # exact f32: Inf, like torch.matmul
+    assert torch.isnan(exact[300]).all()
+    assert float((exact[9] - ref[9]).abs().max() / ref[9].abs().max()) < 2e-6   # exact f32: finite, like torch.matmul
+    assert torch.isnan(split[5]).all()                                        # split: Inf - bf16(Inf) = NaN poisons the row
+    assert torch.isnan(split[9]).all()                                        # |x| beyond bf16's range behaves like Inf
+    assert torch.isnan(split[300]).all()
+    # an Inf in W: one output column
+    W2 = W.clone()
+    W2[11, 200] = float("inf")
+    A2 = torch.randn(M, K, generator=g).abs().to(dev)
+    e2 = NF.linear_fwd(A2, W2.to(dev), None, flags=NPI_GEMM_EXACT_F32).cpu()
+    s2 = NF.linear_fwd(A2, W2.to(dev), None, flags=NPI_GEMM_SPLIT_BF16).cpu()
+    cols = torch.ones(N, dtype=torch.bool)
+    cols[200] = False
+    assert torch.isinf(e2[:, 200]).all() and torch.isnan(s2[:, 200]).all()
+    assert torch.isfinite(e2[:, cols]).all() and torch.isfinite(s2[:, cols]).all()
+    # backward-data and dW follow the same rule (dC with an Inf element)
+    dC = torch.randn(M, N, generator=g).abs()
+    dC[7, 1] = float("inf")
+    for flags, bad in ((NPI_GEMM_EXACT_F32, torch.isinf), (NPI_GEMM_SPLIT_BF16, torch.isnan)):
+        da = NF.linear_bwd_data(dC.to(dev), Wd, None, flags=flags).cpu()
+        assert bad(da[7]).all() and torch.isfinite(da[torch.arange(M) != 7]).all()
+        dw, db = NF.linear_bwd_weight(A2, dC.to(dev), True, flags=flags)
+        assert bad(dw.cpu()[:, 1]).all() and torch.isfinite(dw.cpu()[:, 2:]).all()
+        assert torch.isinf(db.cpu()[1]) or torch.isnan(db.cpu()[1])
+
+
 @pytest.mark.parametrize("M,K,N", [(4096, 256, 256), (100003, 128, 128), (50000 + 7, 256, 128), (20000, 128, 256),
                                    (300000, 256, 256), (8192 + 15, 384, 512)])
 @pytest.mark.parametrize("shared", [False, True])

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 import npi_gnn_amd as npi
+from npi_gnn_amd import graph as NG
 from npi_gnn_amd import pool as NP
 from oracle import kat, ref_conv as R
 
@@ -285,7 +286,9 @@ def test_pooling_without_a_device_read_when_graph_sizes_are_known(dev):
     ref = NP.topk_pool(x, ei, batch, w, 0.5, num_graphs=B)
     b2 = batch.clone()
     b2._npi_sizes = sizes
-    got = NP.topk_pool(x, ei, b2, w, 0.5)
+    plain = NP.topk_pool(x, ei, b2, w, 0.5)                   # sizes known but not asked for: PyG's contract, compact list
+    assert plain[1].size(1) == ref[1].size(1) and torch.equal(plain[1], ref[1])
+    got = NP.topk_pool(x, ei, b2, w, 0.5, padded_edges=True)
     e = ref[1].size(1)
     assert got[1].size(1) == ei.size(1) and torch.equal(got[1][:, :e], ref[1]) and bool((got[1][:, e:] == -1).all())
     assert torch.equal(got[0], ref[0]) and torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4])
@@ -330,14 +333,14 @@ def test_padded_edge_lists_edge_cases(dev):
     ref = R.topk_pool(x, ei, batch, w, 0.5)
     b2 = batch.to(dev)
     b2._npi_sizes = sizes
-    got = NP.topk_pool(x.to(dev), ei.to(dev), b2, w.to(dev), 0.5)
+    got = NP.topk_pool(x.to(dev), ei.to(dev), b2, w.to(dev), 0.5, padded_edges=True)
     assert torch.equal(got[4].cpu(), ref[3]) and got[1].shape == (2, 2) and bool((got[1] == -1).all()) and ref[1].numel() == 0
     assert torch.equal(got[3]._npi_sizes, torch.tensor([1, 1, 3, 1, 4]))
     conv = npi.SAGEConv(12, 8).to(dev)
     out = conv(got[0], got[1])                                   # only padding: every node aggregates itself
     assert torch.allclose(out, got[0] @ conv.weight + conv.bias, atol=1e-5)
     # second pooling layer on the padded list, ratio 1.0 keeps everything
-    got2 = NP.topk_pool(got[0], got[1], got[3], torch.randn(1, 12, generator=g).to(dev), 1.0)
+    got2 = NP.topk_pool(got[0], got[1], got[3], torch.randn(1, 12, generator=g).to(dev), 1.0, padded_edges=True)
     assert got2[0].size(0) == got[0].size(0) and bool((got2[1] == -1).all())
     # sizes of an empty key list; size hints for one key
     ig = InteractionGraph(torch.tensor([[0, 3], [1, 3], [1, 4]]).to(dev), torch.tensor([True, True, True]).to(dev),
@@ -367,7 +370,8 @@ def test_pooled_csr_derived_from_the_parent_equals_a_fresh_build(dev):
     NG.as_graph(ei, x.size(0))                                   # what the conv in front of the pool does
     assert getattr(ei, "_npi_graph", None) is not None
     for layer in range(2):
-        xo, eo, _, bo, perm, _ = NP.topk_pool(x.clone().requires_grad_(layer == 1), ei, b, w, 0.5, num_graphs=64)
+        xo, eo, _, bo, perm, _ = NP.topk_pool(x.clone().requires_grad_(layer == 1), ei, b, w, 0.5, num_graphs=64,
+                                              padded_edges=True)
         assert getattr(eo, "_npi_graph_from", None) is not None and getattr(eo, "_npi_graph", None) is None     # derived on demand
         g = NG.as_graph(eo, xo.size(0))
         assert g is getattr(eo, "_npi_graph", None) and g.num_nodes == xo.size(0) and g.symmetric
@@ -410,3 +414,62 @@ def test_filter_adj_keeps_the_edge_order_on_both_tile_paths(dev, E):
     newpos = ws[off:off + E]
     ref = torch.where(m, torch.cumsum(m.int(), 0).int() - 1, torch.full((E,), -1, dtype=torch.int32, device=dev)).int()
     assert torch.equal(newpos, ref)
+
+
+def test_in_place_edit_of_a_cached_edge_list_is_never_answered_from_the_stale_csr(dev):
+    """a CSR cached on an edge list (graph.attach_graph, the convs on lists this package produced, the
+    recipe TopKPooling leaves) is keyed by the tensor's ``_version``: an in-place write to the list -- same shape, same
+    storage -- makes the next conv sort again instead of aggregating over the old adjacency."""
+    g = torch.Generator().manual_seed(4)
+    N, E, F = 300, 2000, 16
+    ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+    x = torch.randn(N, F, generator=g).to(dev)
+    conv = npi.SAGEConv(F, 8).to(dev)
+    g0 = NG.attach_graph(ei, N)
+    out1 = conv(x, ei)
+    assert NG.cached_graph(ei, N) is g0                        # reused while the tensor is untouched
+    ei[0, :500] = torch.randint(0, N, (500,), generator=g).to(dev)       # in-place: same shape, same storage
+    assert NG.cached_graph(ei, N) is None
+    out2 = conv(x, ei)
+    want = conv(x, ei.clone())                                 # a tensor nobody has cached anything on
+    assert torch.equal(out2, want) and not torch.equal(out1, out2)
+    # the recipe a pooling layer leaves on the list it returns is dropped the same way
+    fx = load("rpi369_fold0.pt")
+    x, e, batch, y = (fx[k].to(dev) for k in ("x", "edge_index", "batch", "y"))
+    b2 = batch.clone()
+    b2._npi_sizes = torch.bincount(fx["batch"], minlength=y.numel())
+    e._npi_symmetric = True
+    NG.as_graph(e, x.size(0))                                  # the conv in front of the pool
+    w = torch.randn(1, x.size(1), generator=g).to(dev)
+    xo, eo, _, bo, _, _ = NP.topk_pool(x, e, b2, w, 0.5, padded_edges=True)
+    assert getattr(eo, "_npi_graph_from", None) is not None
+    keep = eo[0] >= 0
+    eo[:, keep] = eo[:, keep].flip(0)                          # in-place edit (here: every edge reversed)
+    got = NG.as_graph(eo, xo.size(0))
+    ref = NG.build_side(eo[1].contiguous(), eo[0].contiguous(), xo.size(0), xo.size(0))
+    nnz = int(ref.rowptr[-1])
+    assert torch.equal(got.by_dst.rowptr, ref.rowptr) and torch.equal(got.by_dst.col[:nnz], ref.col[:nnz])
+
+
+def test_stale_batch_totals_are_an_error_not_an_out_of_bounds_write(dev):
+    """InteractionGraph.batch(n_nodes=, n_pairs=) sizes its outputs from the caller's totals while the kernels
+    write at device-computed offsets -- totals of OTHER keys must raise (first supplied totals of a graph, and every call
+    under graph.set_debug), and host totals beyond int32 keep the overflow check."""
+    from npi_gnn_amd.subgraph import InteractionGraph
+    g = torch.Generator().manual_seed(2)
+    pairs = torch.tensor([[0, 3], [1, 3], [1, 4], [2, 4], [0, 4]])
+    ig = InteractionGraph(pairs.to(dev), torch.ones(5, dtype=torch.bool).to(dev), torch.randn(5, 6, generator=g).to(dev))
+    keys = pairs[:3].to(dev)
+    nodes, npairs = ig.sizes(keys)
+    with pytest.raises(ValueError):
+        ig.batch(keys[:2], n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))        # totals of three keys, two keys
+    ok = ig.batch(keys, n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))
+    assert ok[0].size(0) == int(nodes.sum())
+    NG.set_debug(True)
+    try:
+        with pytest.raises(ValueError):
+            ig.batch(keys[:1], n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))
+    finally:
+        NG.set_debug(False)
+    with pytest.raises(OverflowError):
+        ig.batch(keys, n_nodes=2 ** 31, n_pairs=5)

@@ -10,6 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="sanitizer builds run on the CPU build host only, never in a process "
+                                                         "that can see a GPU (the pool refuses sanitizer runs on GPU boxes)")
 @pytest.mark.skipif(os.environ.get("NPI_GNN_LIB") is not None, reason="already running against a variant library")
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
 def test_boundary_tests_are_clean_under_asan_and_ubsan():

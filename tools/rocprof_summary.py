@@ -42,10 +42,20 @@ def main():
            "fetch_scale_segsum": scale, "kernels": summ}
     json.dump(res, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
     seg = [v for k, v in summ.items() if "segsum_kernel" in k]
+    fix = [v for k, v in summ.items() if "segsum_fixup_kernel" in k]
     if seg and scale:
+        # per aggregation launch = main kernel + its fix-up kernel (bench.py's avg_launch_ms brackets both), averaged over
+        # the forward and the backward instantiation
         b = sum((v["FETCH_SIZE_KB_raw"] * scale + v["WRITE_SIZE_KB"]) * 1024 for v in seg) / len(seg)
-        json.dump({"segsum_kernel_bytes_per_launch": b, "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json"},
-                  open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+        if fix:
+            b += sum((v["FETCH_SIZE_KB_raw"] * scale + v["WRITE_SIZE_KB"]) * 1024 for v in fix) / len(fix)
+        sys.path.insert(0, root)
+        from bench import kernel_source_sha
+        p = os.path.join(out, "pmc_traffic.json")
+        t = json.load(open(p)) if os.path.exists(p) else {}
+        t.update({"segsum_kernel_bytes_per_launch": b, "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json",
+                  "includes_fixup_kernel": bool(fix), "source_sha16": kernel_source_sha()})
+        json.dump(t, open(p, "w"), indent=1)
     print(json.dumps(res, indent=1)[:1500])
 
 
