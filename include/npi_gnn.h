@@ -194,7 +194,7 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
  *   workspace : npi_linear_workspace_bytes(K, N) bytes, 16-byte aligned (NULL: stream-ordered allocation as the legacy
  *               entry points do)
  *   shared    : npi_linear_bwd_weight_ex: 1 = the GEMM shares the CUs with an HBM-bound kernel on another stream
- *               (about 3 workgroups per 4 CUs), 0 = it has the GPU to itself (see npi_dw_shared) */
+ *               (about 3 workgroups per 4 CUs), 0 = it has the GPU to itself (see npi_dw_shared)
  *
  * NON-FINITE OPERANDS (what replaces torch.matmul at PyG 1.4.2 SAGEConv.update / its autograd):
  *   NPI_GEMM_EXACT_F32  is an fp32 fmaf chain: an Inf operand gives +-Inf in the products it takes part in (NaN against a

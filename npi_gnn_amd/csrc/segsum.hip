@@ -116,7 +116,7 @@ struct Lanes {
 };
 
 // scale, bias and epilogue of a finished row r, then the store
-template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, NCH, WMODE, EXACT>& L,
                                            const float (&acc)[NCH][VEC], int r, int row_len) {
     T* __restrict__ dst = reinterpret_cast<T*>(P.out) + (int64_t)r * P.ldo;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
     for (int c = 0; c < NCH; ++c) {
         if (!L.act[c]) continue;
         float sc = 1.f;
-        if (MEAN) sc = 1.f / (float)max(row_len, 1);
+        if (P.mean) sc = 1.f / (float)max(row_len, 1);       // scatter_mean's divisor (a launch argument, not a template one)
         if (WMODE == W_GAT_DST) sc = 1.f / (P.s[(int64_t)r * P.H + L.hd[c]] + 1e-16f);
         float t[VEC];
 #pragma unroll
@@ -160,7 +160,7 @@ __device__ __forceinline__ int item_block(int b, int nb) {
     return (b % NPI_SEG_WAYS) * per + b / NPI_SEG_WAYS;           // a bijection of [0, nb); blocks past the items exit
 }
 
-template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
 segsum_kernel(SegParams P) {
     constexpr int U = inflight<VEC, NCH>::value;
@@ -238,7 +238,7 @@ segsum_kernel(SegParams P) {
             write_carry(0);
             head = false;
         } else {
-            finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, row_end - row_start);
+            finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_end - row_start);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -403,7 +403,7 @@ segsum_kernel(SegParams P) {
 // Entries are still added in entry order (group 0, a possible row close, group 1, ...); at a row close
 // the G partials are folded across the lane groups (xor shuffles) and group 0 stores.  Same items, carry
 // format and fix-up kernel as the wide path; W_NONE / W_ARRAY only.
-template <typename T, int VEC, int G, int WMODE, bool MEAN>
+template <typename T, int VEC, int G, int WMODE>
 __global__ void __launch_bounds__(SEG_THREADS)
 segsum_group_kernel(SegParams P) {
     constexpr int LG = WAVE / G;                           // lanes per entry group
@@ -454,7 +454,7 @@ segsum_group_kernel(SegParams P) {
             head = false;
         } else if (act && grp == 0) {
             const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
-            const float sc = MEAN ? 1.f / (float)max(row_end - row_start, 1) : 1.f;
+            const float sc = P.mean ? 1.f / (float)max(row_end - row_start, 1) : 1.f;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) t[q] = fmaf(t[q], sc, bias ? to_f32(bias[foff + q]) : 0.f);
             store_row<VEC, T>(reinterpret_cast<T*>(P.out) + (int64_t)r * P.ldo + foff, t);
@@ -539,7 +539,7 @@ __device__ __forceinline__ bool fix_owner(const SegParams& P, int item, int nnz,
     return true;
 }
 
-template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
 segsum_fixup_kernel(SegParams P) {
     __shared__ int s_row[FIX_SPAN], s_rs[FIX_SPAN], s_re[FIX_SPAN], s_len[FIX_SPAN];
@@ -584,7 +584,7 @@ segsum_fixup_kernel(SegParams P) {
                 }
             }
         }
-        finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
+        finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
     }
     // long chains: the whole workgroup, one chain after the other (s_* are read-only from here on)
     for (int q = 0; q < FIX_SPAN; ++q) {
@@ -652,34 +652,34 @@ segsum_fixup_kernel(SegParams P) {
                 for (int c = 0; c < NCH; ++c)
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[c][k] += red[w][(c * VEC + k) * WAVE + lane];
-            finish_row<T, VEC, NCH, WMODE, MEAN, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
+            finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
         }
         __syncthreads();                                          // red is reused by the next long chain
     }
 }
 
-template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 static void launch_fixup(const SegParams& P, hipStream_t stream) {
-    segsum_fixup_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<dim3((unsigned)ceil_div(P.n_items, FIX_SPAN)), dim3(SEG_THREADS), 0, stream>>>(P);
+    segsum_fixup_kernel<T, VEC, NCH, WMODE, EXACT><<<dim3((unsigned)ceil_div(P.n_items, FIX_SPAN)), dim3(SEG_THREADS), 0, stream>>>(P);
 }
 
-template <typename T, int VEC, int NCH, int WMODE, bool MEAN, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 static void launch_one(const SegParams& P, hipStream_t stream) {
     dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
-    segsum_kernel<T, VEC, NCH, WMODE, MEAN, EXACT><<<grid, block, 0, stream>>>(P);
-    launch_fixup<T, VEC, NCH, WMODE, MEAN, EXACT>(P, stream);
+    segsum_kernel<T, VEC, NCH, WMODE, EXACT><<<grid, block, 0, stream>>>(P);
+    launch_fixup<T, VEC, NCH, WMODE, EXACT>(P, stream);
 }
 
-template <typename T, int VEC, int G, int WMODE, bool MEAN>
+template <typename T, int VEC, int G, int WMODE>
 static void launch_group(const SegParams& P, hipStream_t stream) {
     dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
-    segsum_group_kernel<T, VEC, G, WMODE, MEAN><<<grid, block, 0, stream>>>(P);
-    launch_fixup<T, VEC, 1, WMODE, MEAN, false>(P, stream);
+    segsum_group_kernel<T, VEC, G, WMODE><<<grid, block, 0, stream>>>(P);
+    launch_fixup<T, VEC, 1, WMODE, false>(P, stream);
 }
 template <typename T, int VEC, int G>
 static int launch_group_modes(const SegParams& P, int wmode, int mean, hipStream_t stream) {
-    if (wmode == W_NONE) { if (mean) launch_group<T, VEC, G, W_NONE, true>(P, stream); else launch_group<T, VEC, G, W_NONE, false>(P, stream); }
-    else                 { if (mean) launch_group<T, VEC, G, W_ARRAY, true>(P, stream); else launch_group<T, VEC, G, W_ARRAY, false>(P, stream); }
+    if (wmode == W_NONE) launch_group<T, VEC, G, W_NONE>(P, stream);
+    else                 launch_group<T, VEC, G, W_ARRAY>(P, stream);
     return check_launch("npi_segsum");
 }
 
@@ -693,23 +693,23 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
             if (P.F <= 32 * VEC) return launch_group_modes<T, VEC, 2>(P, wmode, mean, stream);
         }
     }
-    if (wmode == W_NONE) { if (mean) launch_one<T, VEC, NCH, W_NONE, true, EXACT>(P, stream); else launch_one<T, VEC, NCH, W_NONE, false, EXACT>(P, stream); }
-    else if (wmode == W_ARRAY) { if (mean) launch_one<T, VEC, NCH, W_ARRAY, true, EXACT>(P, stream); else launch_one<T, VEC, NCH, W_ARRAY, false, EXACT>(P, stream); }
+    if (wmode == W_NONE) launch_one<T, VEC, NCH, W_NONE, EXACT>(P, stream);
+    else if (wmode == W_ARRAY) launch_one<T, VEC, NCH, W_ARRAY, EXACT>(P, stream);
     else if (wmode == W_GAT_DST) {
-        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, false, EXACT>(P, stream);
+        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, EXACT>(P, stream);
     } else if (wmode == W_GAT_SRC_PRE) {
-        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, false, EXACT>(P, stream);
+        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);
     } else if (wmode == W_GAT_SRC_FUSED) {
         if constexpr (VEC == 4 && sizeof(T) == 4 && NCH == 1) {
             dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
-            segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED, false, EXACT><<<grid, block, 0, stream>>>(P);
-            launch_fixup<T, VEC, NCH, W_GAT_SRC_PRE, false, EXACT>(P, stream);       // same row epilogue
+            segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED, EXACT><<<grid, block, 0, stream>>>(P);
+            launch_fixup<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);       // same row epilogue
         } else {
             set_error("npi_gat_backward_fused: needs heads * out_channels <= 256");
             return NPI_ERR_ARG;
         }
     } else {
-        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC, false, EXACT>(P, stream);
+        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC, EXACT>(P, stream);
     }
     return check_launch("npi_segsum");
 }
@@ -718,11 +718,13 @@ template <typename T, int VEC>
 static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t stream) {
     const int per = WAVE * VEC;
     const int nch = (int)ceil_div(P.F, per);
-    const bool exact = (P.F % per) == 0;
+    // the unguarded (EXACT) variant exists for 16-byte lanes only -- hidden = 256 / 512 / 768 / 1024, the widths the HBM
+    // roofline is quoted on; narrower vectors (odd widths, unaligned rows) always take the guarded kernel
+    const bool exact = VEC == 4 && (P.F % per) == 0;
 #define NPI_SEG_CASE(NC)                                                                    \
     case NC:                                                                                \
-        return exact ? launch_segsum<T, VEC, NC, true>(P, wmode, mean, stream)              \
-                     : launch_segsum<T, VEC, NC, false>(P, wmode, mean, stream)
+        if constexpr (VEC == 4) { if (exact) return launch_segsum<T, VEC, NC, true>(P, wmode, mean, stream); } \
+        return launch_segsum<T, VEC, NC, false>(P, wmode, mean, stream)
     switch (nch) {
         NPI_SEG_CASE(1);
         NPI_SEG_CASE(2);
@@ -739,6 +741,7 @@ static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t str
 int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hipStream_t stream) {
     const int64_t F = P.F;
     P.item = item_edges_for(nnz_max);
+    P.mean = mean ? 1 : 0;
     const int es = (dtype == NPI_BF16) ? 2 : 4;              // bytes per stored element
     if (P.x2 == nullptr) { P.x2 = P.x; P.split = 0x7fffffff; }
     const char* x = reinterpret_cast<const char*>(P.x);
