@@ -463,9 +463,18 @@ def test_non_finite_operands_of_the_projection_gemms(dev):
     for flags, bad in ((NPI_GEMM_EXACT_F32, torch.isinf), (NPI_GEMM_SPLIT_BF16, torch.isnan)):
         da = NF.linear_bwd_data(dC.to(dev), Wd, None, flags=flags).cpu()
         assert bad(da[7]).all() and torch.isfinite(da[torch.arange(M) != 7]).all()
+        # dW: the split kernel serves large node counts only (this M takes the exact one under either flag), so the
+        # column is non-finite -- Inf or NaN -- and every other column is untouched
         dw, db = NF.linear_bwd_weight(A2, dC.to(dev), True, flags=flags)
-        assert bad(dw.cpu()[:, 1]).all() and torch.isfinite(dw.cpu()[:, 2:]).all()
-        assert torch.isinf(db.cpu()[1]) or torch.isnan(db.cpu()[1])
+        assert (~torch.isfinite(dw.cpu()[:, 1])).all() and torch.isfinite(dw.cpu()[:, 2:]).all() and torch.isfinite(dw.cpu()[:, 0]).all()
+        assert not torch.isfinite(db.cpu()[1])
+    Mb = 65536                                                    # large enough for gemm_dw_split_kernel
+    Ab, dCb = torch.randn(Mb, K, generator=g).abs().to(dev), torch.randn(Mb, N, generator=g).abs()
+    dCb[4097, 1] = float("inf")
+    dwe = NF.linear_bwd_weight(Ab, dCb.to(dev), False, flags=NPI_GEMM_EXACT_F32)[0].cpu()
+    dws = NF.linear_bwd_weight(Ab, dCb.to(dev), False, flags=NPI_GEMM_SPLIT_BF16)[0].cpu()
+    assert torch.isinf(dwe[:, 1]).all() and torch.isnan(dws[:, 1]).all()
+    assert torch.isfinite(dwe[:, 2:]).all() and torch.isfinite(dws[:, 2:]).all()
 
 
 @pytest.mark.parametrize("M,K,N", [(4096, 256, 256), (100003, 128, 128), (50000 + 7, 256, 128), (20000, 128, 256),
