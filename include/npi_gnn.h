@@ -296,6 +296,16 @@ int npi_gat_backward_fused(const int32_t* rowptr, const int32_t* col, const int3
                            float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src, const float* D,
                            float negative_slope, const float* alpha, const int32_t* alpha_map, float* dz, float* carry,
                            void* stream);
+/* npi_gat_backward_fused without the stored alpha and without the transpose map (round 3): the four per-TARGET scalars the
+ * pass needs -- a_dst, m, 1 / (s + 1e-16), D -- are packed into one float4 per node (npi_gat_pack_targets; [N, 4], 16 MB at
+ * N = 1M: cache resident), every entry makes ONE 16-byte gather of its target's pack and alpha is recomputed by the lane
+ * that owns the entry (one exp per entry).  Replaces a random 4-byte read of the 84 MB alpha array per entry. */
+int npi_gat_pack_targets(const float* a_dst, const float* m, const float* s, const float* D, int64_t N, float* tpack,
+                         void* stream);
+int npi_gat_backward_fused_packed(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                                  int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* hfeat, int64_t ldh,
+                                  float* out, int64_t ldo, int64_t C, const float* tpack, const float* a_src,
+                                  float negative_slope, float* dz, float* carry, void* stream);
 int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
                       int64_t N, int64_t H, int64_t C, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -315,6 +325,33 @@ int npi_gat_edge_grad_ex(const int32_t* rowptr, const int32_t* col, const int32_
                          const float* dout, int64_t ldd, int64_t H, int64_t C,
                          const float* a_dst, const float* a_src, const float* m, const float* s,
                          const float* D, float negative_slope, int swap, float* dz, float* alpha_out, void* stream);
+/* Round 3, item-parallel forms (npi_gnn_amd/csrc/segscan.hip): the ENTRIES are streamed -- a wavefront per 64 / 256
+ * consecutive entries, a segmented scan keyed by the CSR's rowidx, cut rows folded by a second launch in a fixed order --
+ * instead of a lane group walking each row.  Same results (sums in another association: deterministic, <= 1 ulp-level
+ * differences from the row-walking kernels), 5-10 x the throughput on the skewed graphs.
+ *   npi_seg_rowsum_ex        = npi_seg_rowsum, with rowidx (row of every entry) in place of item_row
+ *   npi_gat_softmax_stats_ex = npi_gat_softmax_stats; additionally writes the leaky_relu score e_p of every entry to
+ *                              scores [nnz_max, H] (may be NULL), which npi_gat_aggregate_scores reads back
+ *   npi_gat_aggregate_scores = npi_gat_aggregate_ex(by_source = 0), one head, with the per-entry scores of the statistics
+ *                              pass instead of two gathered per-node scalars per entry; alpha_out as there (may be NULL)
+ *   npi_gat_rowdot_colsum    = npi_gat_rowdot AND the column sums of `a` (GATConv's bias gradient; colsum may be NULL) in
+ *                              one pass over a and b; needs 16-byte aligned rows, C % 4 == 0, H C <= 1024
+ * workspace: npi_seg_scan_workspace_elems(nnz_max, H) / npi_gat_rowdot_colsum_workspace_elems(N, H, C) floats. */
+int64_t npi_seg_scan_workspace_elems(int64_t nnz_max, int64_t H);
+int npi_seg_rowsum_ex(const int32_t* rowptr, const int32_t* rowidx, const float* vals, const int32_t* map,
+                      int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
+                      void* stream);
+int npi_gat_softmax_stats_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const float* a_row,
+                             const float* a_col, int64_t N, int64_t nnz_max, int64_t H, float negative_slope, float* m,
+                             float* s, float* scores, float* workspace, int64_t workspace_elems, void* stream);
+int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                             int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
+                             float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
+                             const float* bias, float* alpha_out, float* carry, void* stream);
+int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C);
+int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                          int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* workspace,
+                          int64_t workspace_elems, void* stream);
 int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
                    int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
                    void* stream);

@@ -64,12 +64,20 @@ PROTOTYPES = {
     "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_gat_backward_fused": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
+    "npi_gat_pack_targets": (c_int, [_P, _P, _P, _P, _I, _P, _P]),
+    "npi_gat_backward_fused_packed": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, _P, _P]),
     "npi_gat_rank1_add": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "npi_gat_edge_grad": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "npi_gat_edge_grad_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float,
                                      c_int, _P, _P, _P]),
     "npi_seg_rowsum": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "npi_seg_scan_workspace_elems": (_I, [_I, _I]),
+    "npi_seg_rowsum_ex": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "npi_gat_softmax_stats_ex": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
+    "npi_gat_aggregate_scores": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "npi_gat_rowdot_colsum_workspace_elems": (_I, [_I, _I, _I]),
+    "npi_gat_rowdot_colsum": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "npi_entry_transpose_map": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_gat_att_grad_workspace_elems": (_I, [_I, _I, _I]),
     "npi_gat_att_grad": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P]),

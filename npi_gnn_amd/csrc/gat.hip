@@ -139,6 +139,99 @@ gat_rowdot_vec_kernel(const float* __restrict__ a, int64_t lda, const float* __r
     }
 }
 
+// D[i, h] = <a[i, h, :], b[i, h, :] - bias[h, :]> AND the column sums of a, in ONE pass over a (= dOut) and b (= out): the
+// backward's softmax term and GATConv's bias gradient used to stream dOut once each (gat_rowdot_vec + colsum_partial:
+// 3 GB at C4), this reads 2 GB.  A workgroup takes `rows` rows (its four waves interleave groups of ROWS_PER_WAVE rows),
+// lane l owns the float4 column groups l, l + 64, ... (Fw = H C <= 1024); column sums: registers -> LDS (fixed wave
+// order) -> part[block, Fw], summed over the blocks in block order by slab_reduce (deterministic, no atomics).
+constexpr int RDC_MAXCH = 4;
+template <int NCHK>
+__global__ void __launch_bounds__(256)
+gat_rowdot_colsum_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                         const float* __restrict__ bias, int N, int H, int C, int rows, float* __restrict__ D,
+                         float* __restrict__ part) {
+    __shared__ float red[4][NCHK * 256];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int Fw = H * C;
+    const int rbeg = blockIdx.x * rows, rend = min(N, rbeg + rows);
+    float4 cs[NCHK], bs[NCHK];
+    int hd[NCHK];
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) {
+        cs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = k * 256 + lane * 4;
+        const bool on = c < Fw;
+        hd[k] = on ? c / C : -1;
+        bs[k] = (on && bias) ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int r0 = rbeg + wave * ROWS_PER_WAVE; r0 < rend; r0 += 4 * ROWS_PER_WAVE) {
+        float4 va[ROWS_PER_WAVE][NCHK], vb[ROWS_PER_WAVE][NCHK];
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+            const int64_t i = min(r0 + r, N - 1);
+#pragma unroll
+            for (int k = 0; k < NCHK; ++k) {
+                if (hd[k] >= 0) {
+                    va[r][k] = *reinterpret_cast<const float4*>(a + i * lda + k * 256 + lane * 4);
+                    vb[r][k] = *reinterpret_cast<const float4*>(b + i * ldb + k * 256 + lane * 4);
+                } else {
+                    va[r][k] = vb[r][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+            const bool live = r0 + r < rend;
+            float pk[NCHK];
+#pragma unroll
+            for (int k = 0; k < NCHK; ++k) {
+                const float4 x = va[r][k], y = vb[r][k];
+                pk[k] = x.x * (y.x - bs[k].x) + x.y * (y.y - bs[k].y) + x.z * (y.z - bs[k].z) + x.w * (y.w - bs[k].w);
+                if (live) { cs[k].x += x.x; cs[k].y += x.y; cs[k].z += x.z; cs[k].w += x.w; }
+            }
+            for (int h = 0; h < H; ++h) {                          // (one head: a single wave reduction per row)
+                float p = 0.f;
+#pragma unroll
+                for (int k = 0; k < NCHK; ++k) p += (hd[k] == h) ? pk[k] : 0.f;
+                p = wave_sum(p);
+                if (lane == 0 && live) D[(int64_t)(r0 + r) * H + h] = p;
+            }
+        }
+    }
+    if (part == nullptr) return;
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) *reinterpret_cast<float4*>(&red[wave][k * 256 + lane * 4]) = cs[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < Fw; c += 256)
+        part[(int64_t)blockIdx.x * Fw + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// out[c] = sum over the blocks of part[k, c]: 64 columns per workgroup, its four waves take the block ranges
+// [0, n/4), [n/4, n/2), ... with four independent partial sums each (k mod 4), folded in a fixed order
+__global__ void __launch_bounds__(256)
+colsum_blocks_kernel(const float* __restrict__ part, int nblocks, int Fw, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (nblocks + 3) / 4;
+    const int kb = wave * per, ke = min(nblocks, kb + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < Fw) {
+        int k = kb;
+        for (; k + 4 <= ke; k += 4) {
+            s0 += part[(int64_t)k * Fw + c];
+            s1 += part[(int64_t)(k + 1) * Fw + c];
+            s2 += part[(int64_t)(k + 2) * Fw + c];
+            s3 += part[(int64_t)(k + 3) * Fw + c];
+        }
+        for (; k < ke; ++k) s0 += part[(int64_t)k * Fw + c];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && c < Fw) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 static bool rows16(const void* p, int64_t ld, int64_t C) { return C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p % 16) == 0; }
 
 // ---- segment softmax statistics: m[i,h] = max_p e_p, s[i,h] = sum_p exp(e_p - m) -------------------
@@ -722,6 +815,47 @@ extern "C" int npi_gat_backward_fused(const int32_t* rowptr, const int32_t* col,
     return segsum_run(P, W_GAT_SRC_FUSED, 0, nnz_max, NPI_F32, stream);
 }
 
+__global__ void __launch_bounds__(256)
+gat_pack_targets_kernel(const float* __restrict__ a_dst, const float* __restrict__ m, const float* __restrict__ s,
+                        const float* __restrict__ D, int N, float4* __restrict__ t) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) t[i] = make_float4(a_dst[i], m[i], 1.f / (s[i] + 1e-16f), D[i]);
+}
+
+extern "C" int npi_gat_pack_targets(const float* a_dst, const float* m, const float* s, const float* D, int64_t N,
+                                    float* tpack, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && N < 0x7fffffff, "npi_gat_pack_targets: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(a_dst && m && s && D && tpack && ((uintptr_t)tpack % 16) == 0, "npi_gat_pack_targets: null or misaligned pointer");
+    gat_pack_targets_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(a_dst, m, s, D, (int)N, reinterpret_cast<float4*>(tpack));
+    return check_launch("npi_gat_pack_targets");
+}
+
+extern "C" int npi_gat_backward_fused_packed(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                                             const int32_t* item_row, int64_t N, int64_t nnz_max, const float* dout, int64_t ldd,
+                                             const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t C,
+                                             const float* tpack, const float* a_src, float slope, float* dz, float* carry,
+                                             void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_backward_fused_packed: needs one head of <= 256 channels, C % 4 == 0");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && col && rowidx && item_row && dout && hfeat && out && tpack && a_src && dz && carry,
+                "npi_gat_backward_fused_packed: null pointer");
+    NPI_REQUIRE(ldd >= C && ldh >= C && ldo >= C && ldh % 4 == 0 && ((uintptr_t)hfeat % 16) == 0 && ((uintptr_t)tpack % 16) == 0,
+                "npi_gat_backward_fused_packed: leading dimension / alignment");
+    SegParams P{};
+    P.rowptr = rowptr; P.col = col; P.item_row = item_row;
+    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
+    P.x = dout; P.ldx = ldd; P.out = out; P.ldo = ldo; P.F = (int)C;
+    P.carry = carry; P.bias = nullptr;
+    P.H = 1; P.C = (int)C; P.a_src = a_src; P.slope = slope;
+    P.a_dst = a_src; P.m = a_src; P.s = a_src;                                 // unused in this mode
+    P.tpack = reinterpret_cast<const float4*>(tpack);
+    P.hrow = hfeat; P.ldh = ldh; P.rowidx = rowidx; P.dz_out = dz;
+    return segsum_run(P, W_GAT_SRC_FUSED, 0, nnz_max, NPI_F32, stream);
+}
+
 extern "C" int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
                                  int64_t N, int64_t H, int64_t C, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -756,6 +890,43 @@ extern "C" int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64
     else
         gat_rowdot_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, D);
     return check_launch("npi_gat_rowdot");
+}
+
+static int rdc_rows(int64_t N) { return N >= (1 << 18) ? 1024 : (N >= (1 << 14) ? 256 : 64); }
+
+extern "C" int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C) {
+    if (N < 0 || H <= 0 || C <= 0) return -1;
+    return ceil_div(N > 0 ? N : 1, (int64_t)rdc_rows(N)) * H * C;
+}
+
+extern "C" int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                                     int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* workspace,
+                                     int64_t workspace_elems, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && H > 0 && C > 0 && N < 0x7fffffff, "npi_gat_rowdot_colsum: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(a && b && D, "npi_gat_rowdot_colsum: null pointer");
+    const int64_t Fw = H * C;
+    if (!(rows16(a, lda, C) && rows16(b, ldb, C) && ((uintptr_t)bias % 16) == 0 && Fw <= RDC_MAXCH * 256)) {
+        set_error("npi_gat_rowdot_colsum: needs 16-byte aligned rows, out_channels %% 4 == 0 and heads * out_channels <= 1024 "
+                  "(use npi_gat_rowdot + npi_colsum otherwise)");
+        return NPI_ERR_ARG;
+    }
+    const int rows = rdc_rows(N);
+    const int64_t nblocks = ceil_div(N, (int64_t)rows);
+    if (colsum != nullptr && (workspace == nullptr || workspace_elems < nblocks * Fw)) {
+        set_error("npi_gat_rowdot_colsum: workspace too small");
+        return NPI_ERR_WORKSPACE;
+    }
+    float* part = colsum ? workspace : nullptr;
+    switch ((int)ceil_div(Fw, 256)) {
+#define NPI_RDC(K) case K: gat_rowdot_colsum_kernel<K><<<(unsigned)nblocks, 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, rows, D, part); break
+        NPI_RDC(1); NPI_RDC(2); NPI_RDC(3); default: NPI_RDC(4);
+#undef NPI_RDC
+    }
+    if (colsum != nullptr)
+        colsum_blocks_kernel<<<(unsigned)ceil_div(Fw, 64), 256, 0, stream>>>(workspace, (int)nblocks, (int)Fw, colsum);
+    return check_launch("npi_gat_rowdot_colsum");
 }
 
 extern "C" int64_t npi_gat_heavy_workspace_elems(int64_t nnz_max, int64_t H) {
@@ -843,6 +1014,26 @@ extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, c
         return segsum_run(P, W_GAT_SRC_PRE, 0, nnz_max, NPI_F32, stream);
     }
     return segsum_run(P, by_source ? W_GAT_SRC : W_GAT_DST, 0, nnz_max, NPI_F32, stream);
+}
+
+extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+                                        int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
+                                        float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
+                                        const float* bias, float* alpha_out, float* carry, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_scores: bad split");
+    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0, "npi_gat_aggregate_scores: bad size");
+    if (N == 0) return NPI_OK;
+    NPI_REQUIRE(rowptr && col && item_row && x && out && scores && m && s && carry, "npi_gat_aggregate_scores: null pointer");
+    NPI_REQUIRE(ldx >= C && ldo >= C, "npi_gat_aggregate_scores: leading dimension too small");
+    SegParams P{};
+    P.rowptr = rowptr; P.col = col; P.item_row = item_row;
+    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
+    P.x = x; P.ldx = ldx; P.out = out; P.ldo = ldo; P.F = (int)C;
+    P.x2 = x2; P.split = (int)split;
+    P.carry = carry; P.w = scores; P.bias = bias;
+    P.H = 1; P.C = (int)C; P.m = m; P.s = s; P.alpha_out = alpha_out;
+    return segsum_run(P, W_GAT_DST_PRE, 0, nnz_max, NPI_F32, stream);
 }
 
 extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,

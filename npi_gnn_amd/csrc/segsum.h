@@ -4,7 +4,7 @@
 
 namespace npi {
 
-enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4, W_GAT_SRC_FUSED = 5 };
+enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4, W_GAT_SRC_FUSED = 5, W_GAT_DST_PRE = 6 };
 
 struct SegParams {
     const int32_t* rowptr;
@@ -21,7 +21,8 @@ struct SegParams {
     int64_t ldo;
     int F;
     float* carry;
-    const float* w;          // W_ARRAY: one weight per entry; W_GAT_SRC_PRE: alpha per by-target entry
+    const float* w;          // W_ARRAY: one weight per entry; W_GAT_SRC_PRE: alpha per by-target entry;
+                             // W_GAT_DST_PRE (one head): the leaky_relu score e_p of every entry (npi_gat_softmax_stats_ex)
     const int32_t* wmap;     // W_GAT_SRC_PRE: entry p takes w[wmap[p]] (by-source entry -> by-target position)
     const float* bias;       // [F] or null, added after scaling
     // GAT: H heads of C channels (F == H * C), per-node per-head scalars [N, H]
@@ -44,6 +45,9 @@ struct SegParams {
     const float* Dt;         // [N] D of the column (target) nodes
     const int32_t* rowidx;   // row of every entry (the by-source CSR's rowidx)
     float* dz_out;           // [nnz_max] by-source entry order
+    // W_GAT_SRC_FUSED, packed form: (a_dst, m, 1 / (s + 1e-16), D) of every TARGET node as one float4 -- one 16-byte gather
+    // per entry replaces alpha through the transpose map (a random 4-byte read of an 84 MB array) + Dt + a_dst; w / wmap unused
+    const float4* tpack;
 };
 
 // x / out / bias are stored as `dtype` (NPI_F32 or NPI_BF16; the struct's float* are reinterpreted)

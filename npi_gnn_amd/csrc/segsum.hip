@@ -126,7 +126,7 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
         if (!L.act[c]) continue;
         float sc = 1.f;
         if (P.mean) sc = 1.f / (float)max(row_len, 1);       // scatter_mean's divisor (a launch argument, not a template one)
-        if (WMODE == W_GAT_DST) sc = 1.f / (P.s[(int64_t)r * P.H + L.hd[c]] + 1e-16f);
+        if (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) sc = 1.f / (P.s[(int64_t)r * P.H + L.hd[c]] + 1e-16f);
         float t[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
@@ -206,11 +206,11 @@ segsum_kernel(SegParams P) {
     // per-row constants of the GAT weight (per lane: the head of its columns)
     float rs_a[NCH], rs_m[NCH], rs_i[NCH];
     auto open_row = [&]() {
-        if (WMODE == W_GAT_DST) {
+        if (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int64_t i = (int64_t)min(r, N - 1) * P.H + L.hd[c];
-                rs_a[c] = P.a_dst[i];
+                rs_a[c] = (WMODE == W_GAT_DST) ? P.a_dst[i] : 0.f;
                 rs_m[c] = P.m[i];
                 rs_i[c] = P.alpha_out ? 1.f / (P.s[i] + 1e-16f) : 0.f;
             }
@@ -257,6 +257,7 @@ segsum_kernel(SegParams P) {
     // one gathered row (+ its weight) into the accumulators
     auto entry_weight = [&](int c, float g0, float g1, float g2, float ws) -> float {
         if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) return ws;
+        if (WMODE == W_GAT_DST_PRE) return expf(ws - rs_m[c]);          // ws = the entry's score, computed by the statistics pass
         if (WMODE == W_GAT_DST) return expf(lrelu(rs_a[c] + g0, P.slope) - rs_m[c]);
         if (WMODE == W_GAT_SRC) return expf(lrelu(g0 + rs_a[c], P.slope) - g1) * g2;
         return 1.f;
@@ -266,10 +267,22 @@ segsum_kernel(SegParams P) {
         const int nb = min(WAVE, k1 - kb);
         const int cv = (lane < nb) ? P.col[kb + lane] : 0;
         float wv = 1.f;
-        if (WMODE == W_ARRAY) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
-        if (WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
+        if (WMODE == W_ARRAY || WMODE == W_GAT_DST_PRE) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
+        float dz_d = 0.f, dz_g = 0.f;    // W_GAT_SRC_FUSED, packed: D of the entry's target and leaky_relu' of its score
+        if (WMODE == W_GAT_SRC_FUSED && P.tpack != nullptr) {
+            // alpha of entry kb + l is computed BY LANE l (one exp per entry, not per lane) from the packed target scalars
+            if (lane < nb) {
+                const float4 t = P.tpack[cv];
+                const float z = t.x + P.a_src[P.rowidx[kb + lane]];
+                wv = expf(lrelu(z, P.slope) - t.y) * t.z;
+                dz_d = t.w;
+                dz_g = z > 0.f ? 1.f : P.slope;
+            } else {
+                wv = 0.f;
+            }
+        } else if (WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
         int avec = 0;                    // W_GAT_DST + alpha_out: alpha of entry kb + l collects in lane l, stored once per block
-        const bool keep_alpha = WMODE == W_GAT_DST && P.alpha_out != nullptr;
+        const bool keep_alpha = (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) && P.alpha_out != nullptr;
         int j = 0;
         for (; j + U <= nb; j += U) {
             float v[U][NCH][VEC];
@@ -300,7 +313,7 @@ segsum_kernel(SegParams P) {
             for (int u = 0; u < U; ++u) {
                 const int k = kb + j + u;
                 while (k == row_end) close_row();
-                const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) ? bcast_f(wv, j + u) : 1.f;
+                const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j + u) : 1.f;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
@@ -355,7 +368,7 @@ segsum_kernel(SegParams P) {
             }
             const int k = kb + j;
             while (k == row_end) close_row();
-            const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) ? bcast_f(wv, j) : 1.f;
+            const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j) : 1.f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
@@ -379,9 +392,13 @@ segsum_kernel(SegParams P) {
             // all 64 lanes turn the block's dots into dz together: dz = alpha (dot - D_i) leaky_relu'(a_dst[i] + a_src[j])
             __builtin_amdgcn_wave_barrier();
             if (lane < nb) {
-                const int jj = P.rowidx[kb + lane];
-                const float z = P.a_dst[cv] + P.a_src[jj];
-                P.dz_out[kb + lane] = wv * (pb[lane] - P.Dt[cv]) * (z > 0.f ? 1.f : P.slope);
+                if (P.tpack != nullptr) {
+                    P.dz_out[kb + lane] = wv * (pb[lane] - dz_d) * dz_g;
+                } else {
+                    const int jj = P.rowidx[kb + lane];
+                    const float z = P.a_dst[cv] + P.a_src[jj];
+                    P.dz_out[kb + lane] = wv * (pb[lane] - P.Dt[cv]) * (z > 0.f ? 1.f : P.slope);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -697,6 +714,12 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
     else if (wmode == W_ARRAY) launch_one<T, VEC, NCH, W_ARRAY, EXACT>(P, stream);
     else if (wmode == W_GAT_DST) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, EXACT>(P, stream);
+    } else if (wmode == W_GAT_DST_PRE) {
+        if constexpr (VEC == 4 && sizeof(T) == 4) {
+            dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
+            segsum_kernel<T, VEC, NCH, W_GAT_DST_PRE, EXACT><<<grid, block, 0, stream>>>(P);
+            launch_fixup<T, VEC, NCH, W_GAT_DST, EXACT>(P, stream);           // same row epilogue (1 / (s + eps), bias)
+        }
     } else if (wmode == W_GAT_SRC_PRE) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);
     } else if (wmode == W_GAT_SRC_FUSED) {

@@ -497,6 +497,7 @@ def _inverse_transpose_map(graph: CSRGraph) -> torch.Tensor:
 # half of d hfeat and the per-entry score gradient (npi_gat_backward_fused), with alpha stored by the forward -- instead of
 # npi_gat_edge_grad (a gather pass over the by-target entries) followed by the by-source aggregation.
 GAT_FUSED_BACKWARD = os.environ.get("NPI_GAT_FUSED", "1") != "0"
+GAT_PACKED_BACKWARD = os.environ.get("NPI_GAT_PACKED", "1") != "0"
 
 
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
@@ -529,13 +530,27 @@ def gat_scores(hfeat, att2, H, C):
     return a_dst, a_src
 
 
-def gat_softmax_stats(side: CSRSide, a_row, a_col, H, slope):
+# Row reductions of per-entry scalars (softmax statistics, row sums of dz): stream the ENTRIES item by item with a segmented
+# scan (csrc/segscan.hip) instead of walking every row with a lane group; NPI_GAT_ITEMS=0 keeps the round-2 kernels.
+GAT_ITEM_SCANS = os.environ.get("NPI_GAT_ITEMS", "1") != "0"
+
+
+def gat_softmax_stats(side: CSRSide, a_row, a_col, H, slope, want_scores: bool = False):
     """(m, s) [n_rows, H]: row max and sum of exp(. - max) of leaky_relu(a_row[row] + a_col[col]) over the entries of
-    every row of ``side`` (an empty row gets m = 0, s = 0)."""
+    every row of ``side`` (an empty row gets m = 0, s = 0).  ``want_scores``: also the score of every entry
+    ``[nnz_max, H]`` (entry order), for ``npi_gat_aggregate_scores`` -- returns (m, s, scores)."""
     lib = load()
     dev = a_row.device
     m = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
     s = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
+    if GAT_ITEM_SCANS or want_scores:
+        n_ws = int(lib.npi_seg_scan_workspace_elems(side.nnz_max, H))
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        e = torch.empty((max(side.nnz_max, 1), H), dtype=torch.float32, device=dev) if want_scores else None
+        check(lib.npi_gat_softmax_stats_ex(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(a_row), ptr(a_col),
+                                           side.n_rows, side.nnz_max, H, float(slope), ptr(m), ptr(s), ptr(e), ptr(ws), n_ws,
+                                           stream_ptr(dev)), "npi_gat_softmax_stats_ex")
+        return (m, s, e) if want_scores else (m, s)
     n_hw = int(lib.npi_gat_heavy_workspace_elems(side.nnz_max, H))
     hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
     check(lib.npi_gat_softmax_stats(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), ptr(a_row), ptr(a_col),
@@ -552,6 +567,25 @@ def gat_rowdot(a, b, bias, H, C):
     check(load().npi_gat_rowdot(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), N, H, C, ptr(D), stream_ptr(dev)),
           "npi_gat_rowdot")
     return D
+
+
+def gat_rowdot_colsum(a, b, bias, H, C, want_colsum: bool = True):
+    """(D, colsum(a) or None): ``gat_rowdot`` and the bias gradient in one pass over ``a`` (= dOut) and ``b`` (= out);
+    falls back on the two separate kernels for unaligned rows or H C > 1024."""
+    lib = load()
+    dev = a.device
+    N = a.size(0)
+    ok = (C % 4 == 0 and H * C <= 1024 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
+          and b.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
+    if not ok or not GAT_ITEM_SCANS:
+        return gat_rowdot(a, b, bias, H, C), (colsum(a) if want_colsum else None)
+    D = torch.empty((N, H), dtype=torch.float32, device=dev)
+    cs = torch.empty(H * C, dtype=torch.float32, device=dev) if want_colsum else None
+    n_ws = int(lib.npi_gat_rowdot_colsum_workspace_elems(N, H, C)) if want_colsum else 0
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
+    check(lib.npi_gat_rowdot_colsum(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), N, H, C, ptr(D), ptr(cs), ptr(ws),
+                                    n_ws, stream_ptr(dev)), "npi_gat_rowdot_colsum")
+    return D, cs
 
 
 def gat_edge_grad(side: CSRSide, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap,
@@ -580,6 +614,12 @@ def seg_rowsum(side: CSRSide, vals, H, map_=None):
     lib = load()
     dev = vals.device
     out = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
+    if GAT_ITEM_SCANS:
+        n_ws = int(lib.npi_seg_scan_workspace_elems(side.nnz_max, H))
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        check(lib.npi_seg_rowsum_ex(ptr(side.rowptr), ptr(side.rowidx), ptr(vals), ptr(map_), side.n_rows, side.nnz_max, H,
+                                    ptr(out), ptr(ws), n_ws, stream_ptr(dev)), "npi_seg_rowsum_ex")
+        return out
     n_hw = int(lib.npi_gat_heavy_workspace_elems(side.nnz_max, H))
     hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
     check(lib.npi_seg_rowsum(ptr(side.rowptr), ptr(side.item_row), ptr(vals), ptr(map_), side.n_rows, side.nnz_max, H,
@@ -610,17 +650,29 @@ class _GatConvFn(torch.autograd.Function):
         hfeat = linear_fwd(x, weight)                                        # x @ W
         a_dst, a_src = gat_scores(hfeat, att2, H, C)
         d = graph.by_dst
-        m, s = gat_softmax_stats(d, a_dst, a_src, H, slope)
         fused = GAT_FUSED_BACKWARD and H == 1 and C <= 256 and C % 4 == 0 and any(ctx.needs_input_grad[:4])
-        # one head: the forward also stores alpha of every entry (by-target order) -- the backward reads it back
-        alpha = torch.empty(max(d.nnz_max, 1), dtype=torch.float32, device=x.device) if fused else None
-        out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias, alpha=alpha)
+        # one head, NPI_GAT_PACKED=0: the forward also stores alpha of every entry (by-target order) and the backward reads it
+        # back through the transpose map; default: the backward recomputes alpha from packed per-target scalars
+        alpha = torch.empty(max(d.nnz_max, 1), dtype=torch.float32, device=x.device) if (fused and not GAT_PACKED_BACKWARD) else None
+        if GAT_ITEM_SCANS and H == 1 and C % 4 == 0 and d.nnz_max > 0:
+            # the statistics pass leaves the score of every entry; the aggregation reads it back (one coalesced load per
+            # 64 entries) instead of gathering a_src[j] per entry and redoing the leaky_relu
+            m, s, scores = gat_softmax_stats(d, a_dst, a_src, H, slope, want_scores=True)
+            out = torch.empty((d.n_rows, C), dtype=torch.float32, device=x.device)
+            check(load().npi_gat_aggregate_scores(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), d.n_rows, d.nnz_max,
+                                                  ptr(hfeat), hfeat.stride(0), None, 0, ptr(out), out.stride(0), C,
+                                                  ptr(scores), ptr(m), ptr(s), ptr(bias), ptr(alpha), ptr(d.carry(C)),
+                                                  stream_ptr(x.device)), "npi_gat_aggregate_scores")
+            del scores
+        else:
+            m, s = gat_softmax_stats(d, a_dst, a_src, H, slope)
+            out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias, alpha=alpha)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
         ctx.has_bias = bias is not None
         ctx.fused = fused
         ctx.save_for_backward(x, weight, att2, hfeat, a_dst, a_src, m, s, out,
                               bias if bias is not None else torch.empty(0, device=x.device),
-                              alpha if fused else torch.empty(0, device=x.device))
+                              alpha if alpha is not None else torch.empty(0, device=x.device))
         return out
 
     @staticmethod
@@ -631,18 +683,29 @@ class _GatConvFn(torch.autograd.Function):
         dev = x.device
         grad_out = _f32c(grad_out, "grad_out")
         d, sr = graph.by_dst, graph.by_src
-        db = colsum(grad_out) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
-        # D_i = <dOut_i, out_i - b> = sum_p alpha_p dalpha_p  (softmax backward)
-        D = gat_rowdot(grad_out, out, bias if ctx.has_bias else None, H, C)
+        # D_i = <dOut_i, out_i - b> = sum_p alpha_p dalpha_p  (softmax backward) and db = column sums of dOut: one pass
+        D, db = gat_rowdot_colsum(grad_out, out, bias if ctx.has_bias else None, H, C,
+                                  want_colsum=ctx.has_bias and ctx.needs_input_grad[3])
         if ctx.fused:
             N = graph.num_nodes
-            tm = _transpose_map(graph)
             dz = torch.empty(max(sr.nnz_max, 1), dtype=torch.float32, device=dev)
             dh = torch.empty((N, C), dtype=torch.float32, device=dev)
-            check(load().npi_gat_backward_fused(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N, sr.nnz_max,
-                                                ptr(grad_out), grad_out.stride(0), ptr(hfeat), hfeat.stride(0), ptr(dh),
-                                                dh.stride(0), C, ptr(a_dst), ptr(a_src), ptr(D), slope, ptr(alpha_fwd), ptr(tm),
-                                                ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)), "npi_gat_backward_fused")
+            if alpha_fwd.numel() == 0:
+                # packed form: (a_dst, m, 1/s, D) of every target in one float4; alpha is recomputed per entry by one lane
+                tpack = torch.empty((N, 4), dtype=torch.float32, device=dev)
+                check(load().npi_gat_pack_targets(ptr(a_dst), ptr(m), ptr(s), ptr(D), N, ptr(tpack), stream_ptr(dev)),
+                      "npi_gat_pack_targets")
+                check(load().npi_gat_backward_fused_packed(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N,
+                                                           sr.nnz_max, ptr(grad_out), grad_out.stride(0), ptr(hfeat),
+                                                           hfeat.stride(0), ptr(dh), dh.stride(0), C, ptr(tpack), ptr(a_src),
+                                                           slope, ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)),
+                      "npi_gat_backward_fused_packed")
+            else:
+                tm = _transpose_map(graph)
+                check(load().npi_gat_backward_fused(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N, sr.nnz_max,
+                                                    ptr(grad_out), grad_out.stride(0), ptr(hfeat), hfeat.stride(0), ptr(dh),
+                                                    dh.stride(0), C, ptr(a_dst), ptr(a_src), ptr(D), slope, ptr(alpha_fwd), ptr(tm),
+                                                    ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)), "npi_gat_backward_fused")
             dz = dz.view(-1, 1)
             g_src = seg_rowsum(sr, dz, 1)                                         # dz is in by-source entry order here
             g_dst = seg_rowsum(d, dz, 1, map_=_inverse_transpose_map(graph))

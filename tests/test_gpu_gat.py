@@ -76,3 +76,76 @@ def test_gat_is_bitwise_reproducible(dev):
     a = npi.gat_conv(*args)
     c = npi.gat_conv(*args)
     assert torch.equal(a, c)
+
+
+def _sides(dev, n_rows, n_cols, E, seed, hub_rows=(3,), empty_from=None):
+    """a by-row CSR side over random entries (no self loops added): some rows very long, the tail rows empty"""
+    from npi_gnn_amd import graph as NG
+    g = torch.Generator().manual_seed(seed)
+    hi = empty_from if empty_from is not None else n_rows
+    key = torch.randint(0, hi, (E,), generator=g)
+    for k, r in enumerate(hub_rows):
+        key[k * (E // 4): k * (E // 4) + E // 5] = r
+    val = torch.randint(0, n_cols, (E,), generator=g)
+    side = NG.build_side(key.to(dev), val.to(dev), n_rows, n_cols, False, 0, False)
+    return side, key, val
+
+
+@pytest.mark.parametrize("n_rows,E,H", [(50, 300, 1), (5000, 90_000, 1), (3000, 40_000, 4), (9000, 1_200_000, 1),
+                                        (700, 1_100_000, 2), (10, 0, 1)])
+def test_item_parallel_row_reductions_match_torch(dev, n_rows, E, H):
+    """csrc/segscan.hip: npi_seg_rowsum_ex (plain and through a map) and npi_gat_softmax_stats_ex (+ per-entry scores)
+    against index_add_ / scatter_reduce in fp64 -- hub rows cut over thousands of items (64- and 256-entry items), rows
+    that end exactly on an item boundary, empty rows at the end and in between, several heads; run-to-run bit identical."""
+    from npi_gnn_amd import functional as NF
+    n_cols = n_rows + 17
+    side, _, _ = _sides(dev, n_rows, n_cols, E, seed=n_rows + E, hub_rows=(3, n_rows // 2) if E else (), empty_from=max(n_rows - 7, 1))
+    nnz = int(side.rowptr[-1])
+    row = side.rowidx[:nnz].long()
+    g = torch.Generator().manual_seed(5)
+    vals = torch.randn(max(side.nnz_max, 1), H, generator=g).to(dev)
+    want = torch.zeros(n_rows, H, dtype=torch.float64, device=dev).index_add_(0, row, vals[:nnz].double())
+    got = NF.seg_rowsum(side, vals, H)
+    scale = float(want.abs().max().clamp(min=1.0))
+    assert float((got.double() - want).abs().max()) < 2e-6 * scale * max(1.0, (E / max(n_rows, 1)) ** 0.5)
+    assert torch.equal(got, NF.seg_rowsum(side, vals, H))
+    perm = torch.randperm(max(side.nnz_max, 1), generator=g).to(dev).to(torch.int32)
+    got_m = NF.seg_rowsum(side, vals, H, map_=perm)
+    want_m = torch.zeros(n_rows, H, dtype=torch.float64, device=dev).index_add_(0, row, vals[perm[:nnz].long()].double())
+    assert float((got_m.double() - want_m).abs().max()) < 2e-6 * scale * max(1.0, (E / max(n_rows, 1)) ** 0.5)
+    # softmax statistics + scores
+    a_row = (torch.randn(n_rows, H, generator=g) * 3).to(dev)
+    a_col = (torch.randn(n_cols, H, generator=g) * 3).to(dev)
+    m, s, e = NF.gat_softmax_stats(side, a_row, a_col, H, 0.2, want_scores=True)
+    z = torch.nn.functional.leaky_relu(a_row[row] + a_col[side.col[:nnz].long()], 0.2)
+    assert torch.equal(e[:nnz], z)
+    m_ref = torch.full((n_rows, H), -3e38, device=dev).scatter_reduce(0, row.view(-1, 1).expand(-1, H), z, "amax")
+    has = torch.bincount(row, minlength=n_rows) > 0
+    m_ref = torch.where(has.view(-1, 1), m_ref, torch.zeros_like(m_ref))
+    s_ref = torch.zeros(n_rows, H, dtype=torch.float64, device=dev).index_add_(0, row, torch.exp((z - m_ref[row]).double()))
+    assert torch.equal(m, m_ref)
+    assert torch.allclose(s.double(), s_ref, rtol=2e-5, atol=1e-6)
+    NF.GAT_ITEM_SCANS = False                                  # the round-2 row-walking kernels agree
+    try:
+        if E:
+            m0, s0 = NF.gat_softmax_stats(side, a_row, a_col, H, 0.2)
+            assert torch.equal(m0, m) and torch.allclose(s0, s, rtol=2e-5, atol=1e-6)
+            assert torch.allclose(NF.seg_rowsum(side, vals, H), got, rtol=1e-4, atol=1e-4 * scale)
+    finally:
+        NF.GAT_ITEM_SCANS = True
+
+
+@pytest.mark.parametrize("N,H,C", [(1000, 1, 256), (4097, 4, 64), (300_000, 1, 256), (50, 1, 8), (2000, 2, 512), (777, 3, 100)])
+def test_rowdot_and_bias_gradient_in_one_pass(dev, N, H, C):
+    from npi_gnn_amd import functional as NF
+    g = torch.Generator().manual_seed(N)
+    a = torch.randn(N, H * C, generator=g).to(dev)
+    b = torch.randn(N, H * C, generator=g).to(dev)
+    bias = torch.randn(H * C, generator=g).to(dev)
+    D, cs = NF.gat_rowdot_colsum(a, b, bias, H, C)
+    want_D = (a.double().view(N, H, C) * (b.double() - bias.double()).view(N, H, C)).sum(-1)
+    assert torch.allclose(D.double(), want_D, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(cs.double(), a.double().sum(0), rtol=1e-5, atol=1e-3 * max(1.0, N ** 0.5 / 30))
+    D2, none = NF.gat_rowdot_colsum(a, b, None, H, C, want_colsum=False)
+    assert none is None and torch.allclose(D2.double(), (a.double().view(N, H, C) * b.double().view(N, H, C)).sum(-1), rtol=1e-5, atol=1e-4)
+    assert torch.equal(NF.gat_rowdot_colsum(a, b, bias, H, C)[1], cs)
