@@ -19,6 +19,29 @@ from .graph import CSRGraph, CSRSide, as_graph
 
 
 _PROFILE = None     # bench.py sets this to a list to collect (start, end) events per segsum launch
+_PROFILE_TAGS = None  # bench.py: dict tag -> list of (start, end) events around the GAT aggregation launches
+
+
+class _tag_events:
+    """HIP events on the launch stream around one aggregation launch, filed under ``tag`` (a no-op unless bench.py asked)"""
+
+    def __init__(self, tag, dev):
+        self.rec = _PROFILE_TAGS
+        if self.rec is not None:
+            self.tag, self.dev = tag, dev
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.e1.record(torch.cuda.current_stream(self.dev))
+            self.rec.setdefault(self.tag, []).append((self.e0, self.e1))
+        return False
+
 _PROFILE_GEMM = None  # likewise (name, flops, start, end) per projection GEMM, on the stream it is launched on
 
 
@@ -659,10 +682,11 @@ class _GatConvFn(torch.autograd.Function):
             # 64 entries) instead of gathering a_src[j] per entry and redoing the leaky_relu
             m, s, scores = gat_softmax_stats(d, a_dst, a_src, H, slope, want_scores=True)
             out = torch.empty((d.n_rows, C), dtype=torch.float32, device=x.device)
-            check(load().npi_gat_aggregate_scores(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), d.n_rows, d.nnz_max,
-                                                  ptr(hfeat), hfeat.stride(0), None, 0, ptr(out), out.stride(0), C,
-                                                  ptr(scores), ptr(m), ptr(s), ptr(bias), ptr(alpha), ptr(d.carry(C)),
-                                                  stream_ptr(x.device)), "npi_gat_aggregate_scores")
+            with _tag_events("gat_fwd_aggregate", x.device):
+                check(load().npi_gat_aggregate_scores(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), d.n_rows, d.nnz_max,
+                                                      ptr(hfeat), hfeat.stride(0), None, 0, ptr(out), out.stride(0), C,
+                                                      ptr(scores), ptr(m), ptr(s), ptr(bias), ptr(alpha), ptr(d.carry(C)),
+                                                      stream_ptr(x.device)), "npi_gat_aggregate_scores")
             del scores
         else:
             m, s = gat_softmax_stats(d, a_dst, a_src, H, slope)
@@ -695,11 +719,12 @@ class _GatConvFn(torch.autograd.Function):
                 tpack = torch.empty((N, 4), dtype=torch.float32, device=dev)
                 check(load().npi_gat_pack_targets(ptr(a_dst), ptr(m), ptr(s), ptr(D), N, ptr(tpack), stream_ptr(dev)),
                       "npi_gat_pack_targets")
-                check(load().npi_gat_backward_fused_packed(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N,
-                                                           sr.nnz_max, ptr(grad_out), grad_out.stride(0), ptr(hfeat),
-                                                           hfeat.stride(0), ptr(dh), dh.stride(0), C, ptr(tpack), ptr(a_src),
-                                                           slope, ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)),
-                      "npi_gat_backward_fused_packed")
+                with _tag_events("gat_bwd_fused", dev):
+                    check(load().npi_gat_backward_fused_packed(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N,
+                                                               sr.nnz_max, ptr(grad_out), grad_out.stride(0), ptr(hfeat),
+                                                               hfeat.stride(0), ptr(dh), dh.stride(0), C, ptr(tpack), ptr(a_src),
+                                                               slope, ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)),
+                          "npi_gat_backward_fused_packed")
             else:
                 tm = _transpose_map(graph)
                 check(load().npi_gat_backward_fused(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N, sr.nnz_max,

@@ -2,8 +2,10 @@
 """Condense rocprofv3 CSV output (tools/profile_bench.sh) into the files kept under profiles/:
   <tag>_kernel_stats.csv   the --kernel-trace --stats summary, as rocprofv3 wrote it
   <tag>_pmc_summary.json   per-kernel mean FETCH_SIZE / WRITE_SIZE (KB, raw) from the separate --pmc passes
-usage: tools/rocprof_summary.py gpurun_out/prof_<tag> <tag> [fetch_scale]
-fetch_scale = calibration factor for FETCH_SIZE in the segsum access pattern (tools/pmc_calibrate.py)."""
+usage: tools/rocprof_summary.py gpurun_out/prof_<tag> <tag> [fetch_scale] [sage|gat|gcn]
+fetch_scale = calibration factor for FETCH_SIZE in the segsum access pattern (tools/pmc_calibrate.py).
+The last argument says which constants of profiles/pmc_traffic.json the run provides: the headline SAGE launch (default),
+the two GATConv aggregation kernels (bench.py --conv gat), or GCNConv's weighted launch (--conv gcn)."""
 import collections
 import csv
 import json
@@ -24,6 +26,7 @@ def per_kernel(path):
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     scale = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    kind = sys.argv[4] if len(sys.argv) > 4 else "sage"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -41,20 +44,34 @@ def main():
                    "coalesced reads (MI355X_MICROARCH.md, HBM): multiply by fetch_scale for the segsum pattern",
            "fetch_scale_segsum": scale, "kernels": summ}
     json.dump(res, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
-    seg = [v for k, v in summ.items() if "segsum_kernel" in k]
-    fix = [v for k, v in summ.items() if "segsum_fixup_kernel" in k]
-    if seg and scale:
-        # per aggregation launch = main kernel + its fix-up kernel (bench.py's avg_launch_ms brackets both), averaged over
-        # the forward and the backward instantiation
-        b = sum((v["FETCH_SIZE_KB_raw"] * scale + v["WRITE_SIZE_KB"]) * 1024 for v in seg) / len(seg)
-        if fix:
-            b += sum((v["FETCH_SIZE_KB_raw"] * scale + v["WRITE_SIZE_KB"]) * 1024 for v in fix) / len(fix)
+    def kb(pred):
+        """bytes per launch of the kernels whose name satisfies pred, averaged over the instantiations that match"""
+        vs = [v for k, v in summ.items() if pred(k)]
+        return sum((v["FETCH_SIZE_KB_raw"] * scale + v["WRITE_SIZE_KB"]) * 1024 for v in vs) / len(vs) if vs else 0.0
+
+    def mode(k):      # WMODE of a segsum instantiation name "...segsum_kernel<float, 4, 1, <mode>, true>"
+        try:
+            return int(k.split("<")[1].split(",")[3])
+        except Exception:
+            return -1
+    if scale:
         sys.path.insert(0, root)
         from bench import kernel_source_sha
         p = os.path.join(out, "pmc_traffic.json")
         t = json.load(open(p)) if os.path.exists(p) else {}
-        t.update({"segsum_kernel_bytes_per_launch": b, "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json",
-                  "includes_fixup_kernel": bool(fix), "source_sha16": kernel_source_sha()})
+        main = lambda m: (lambda k: "segsum_kernel" in k and mode(k) == m)
+        fix = lambda m: (lambda k: "segsum_fixup_kernel" in k and mode(k) == m)
+        if kind == "sage":
+            # per aggregation launch = main kernel + its fix-up kernel (bench.py's avg_launch_ms brackets both), averaged
+            # over the forward and the backward launch
+            t.update({"segsum_kernel_bytes_per_launch": kb(main(0)) + kb(fix(0)), "fetch_scale": scale,
+                      "from": f"profiles/{tag}_pmc_summary.json", "includes_fixup_kernel": True})
+        elif kind == "gat":
+            t.update({"gat_fwd_aggregate_bytes_per_launch": kb(main(6)) + kb(fix(2)),
+                      "gat_bwd_fused_bytes_per_launch": kb(main(5)) + kb(fix(4)), "gat_from": f"profiles/{tag}_pmc_summary.json"})
+        elif kind == "gcn":
+            t.update({"gcn_segsum_bytes_per_launch": kb(main(1)) + kb(fix(1)), "gcn_from": f"profiles/{tag}_pmc_summary.json"})
+        t["source_sha16"] = kernel_source_sha()
         json.dump(t, open(p, "w"), indent=1)
     print(json.dumps(res, indent=1)[:1500])
 
