@@ -382,6 +382,15 @@ int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int
 /* max_nodes: an upper bound of the largest graph of the batch, when the caller knows one (0 = unknown) */
 int npi_topk_select_ex(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
                     int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, int64_t max_nodes, void* stream);
+/* The same selection for graphs of ANY size (npi_topk_select sorts a graph's scores in LDS: at most 16,384 nodes per graph,
+ * bit 1 of its status word otherwise): two stable radix sorts of the whole batch on the device -- by score, descending, ties
+ * by the lower node index; then by graph id -- and one pass that keeps the first ceil(ratio n_g) nodes of every graph.
+ * Same outputs (out_ptr [B+1], perm in graph-major, score-descending order, remap), no device read; `batch` is the PyG batch
+ * vector (int64, non-decreasing).  workspace: npi_topk_sorted_workspace_bytes(N) bytes. */
+int64_t npi_topk_sorted_workspace_bytes(int64_t N);
+int npi_topk_select_sorted(const float* score, const int64_t* batch, const int32_t* graph_ptr, int64_t N, int64_t B,
+                           float ratio, int32_t* out_ptr, int32_t* perm, int32_t* remap, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
                     const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
                     float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream);

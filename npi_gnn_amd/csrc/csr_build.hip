@@ -310,6 +310,78 @@ static SortLayout sort_layout(int64_t E, int64_t N) {
     return L;
 }
 
+// stable LSD radix sort of (key, val) pairs on the low `bits` bits of the key, 8 bits per pass; the sorted pairs end up in
+// (keys_a, vals_a) -- the pointers are swapped pass by pass
+static void radix_sort_pairs(uint32_t*& keys_a, uint32_t*& keys_b, int32_t*& vals_a, int32_t*& vals_b, int64_t n, int bits,
+                             const SortLayout& L, int32_t* counts, int32_t* tiles, hipStream_t stream) {
+    const int passes = (bits + 7) / 8;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        radix_hist_kernel<<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, n, shift, (int)L.nblocks, counts);
+        if (L.nblocks <= SMALL_SORT_TILES) {
+            radix_scatter_kernel<false><<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, n, shift, (int)L.nblocks, counts);
+        } else {
+            scan_tiles_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
+            scan_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(tiles, L.ntiles);
+            scan_add_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
+            radix_scatter_kernel<true><<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, n, shift, (int)L.nblocks, counts);
+        }
+        uint32_t* tk = keys_a; keys_a = keys_b; keys_b = tk;
+        int32_t* tv = vals_a; vals_a = vals_b; vals_b = tv;
+    }
+}
+
+// ---- TopKPooling selection for graphs of ANY size (pool.hip sorts a graph's scores in LDS: up to 16,384 nodes) -----------
+// Two stable radix sorts of the whole batch: by score (descending; the sort is stable over the node index, so equal scores
+// keep the lower index first -- torch.sort(descending=True, stable) order, as the LDS kernel), then by graph id: position
+// graph_ptr[g] + r of the result is the node of graph g with the r-th highest score.
+__global__ void topk_score_keys_kernel(const float* __restrict__ score, int64_t N, uint32_t* __restrict__ keys,
+                                       int32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float f = score[i];
+    uint32_t u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // ascending-orderable
+    keys[i] = (f != f) ? 0u : ~u;                       // descending; NaN first, as torch.sort treats it as the largest
+    vals[i] = (int32_t)i;
+}
+__global__ void topk_graph_keys_kernel(const int64_t* __restrict__ batch, const int32_t* __restrict__ vals, int64_t N,
+                                       uint32_t* __restrict__ keys) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < N) keys[q] = (uint32_t)batch[vals[q]];
+}
+// out_ptr[g] = sum_{g' < g} min(ceil(ratio n_g'), n_g') in the f32 arithmetic of pool.hip's topk_counts_kernel; one workgroup
+__global__ void __launch_bounds__(256)
+topk_kept_offsets_kernel(const int32_t* __restrict__ graph_ptr, int B, float ratio, int32_t* __restrict__ out_ptr) {
+    __shared__ int lds[256];
+    int carry = 0;
+    for (int base = 0; base < B; base += 256) {
+        const int g = base + threadIdx.x;
+        int k = 0;
+        if (g < B) {
+            const int n = graph_ptr[g + 1] - graph_ptr[g];
+            k = min((int)ceilf(ratio * (float)n), n);
+        }
+        int total;
+        const int excl = block_exclusive_scan(k, lds, &total);
+        if (g < B) out_ptr[g] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) out_ptr[B] = carry;
+}
+__global__ void topk_take_kernel(const uint32_t* __restrict__ graph_of, const int32_t* __restrict__ node_of, int64_t N,
+                                 const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ out_ptr,
+                                 int32_t* __restrict__ perm, int32_t* __restrict__ remap) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const int g = (int)graph_of[q], node = node_of[q];
+    const int rank = (int)(q - graph_ptr[g]);
+    const int k = out_ptr[g + 1] - out_ptr[g];
+    const int at = rank < k ? out_ptr[g] + rank : -1;
+    if (at >= 0) perm[at] = node;
+    remap[node] = at;                                    // every node occurs exactly once: kept -> new id, dropped -> -1
+}
+
 }  // namespace npi
 
 using namespace npi;
@@ -366,21 +438,7 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
         make_keys_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(key_nodes, val_nodes, E, N, n_cols, drop_equal, keys_a, vals_a, status);
         int bits = 1;
         while (((int64_t)1 << bits) <= N) ++bits;       // keys lie in [0, N]
-        int passes = (bits + 7) / 8;
-        for (int p = 0; p < passes; ++p) {
-            int shift = 8 * p;
-            radix_hist_kernel<<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, E, shift, (int)L.nblocks, counts);
-            if (L.nblocks <= SMALL_SORT_TILES) {
-                radix_scatter_kernel<false><<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, E, shift, (int)L.nblocks, counts);
-            } else {
-                scan_tiles_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
-                scan_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(tiles, L.ntiles);
-                scan_add_kernel<<<(unsigned)L.ntiles, SCAN_THREADS, 0, stream>>>(counts, L.counts_len, tiles);
-                radix_scatter_kernel<true><<<(unsigned)L.nblocks, SORT_THREADS, 0, stream>>>(keys_a, vals_a, keys_b, vals_b, E, shift, (int)L.nblocks, counts);
-            }
-            uint32_t* tk = keys_a; keys_a = keys_b; keys_b = tk;
-            int32_t* tv = vals_a; vals_a = vals_b; vals_b = tv;
-        }
+        radix_sort_pairs(keys_a, keys_b, vals_a, vals_b, E, bits, L, counts, tiles, stream);
     }
     const unsigned entry_blocks = (unsigned)ceil_div(E, 256);
     fill_csr_kernel<<<entry_blocks + (unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(
@@ -389,6 +447,42 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
     int64_t n_items = npi_num_items(nnz_max);
     item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, item_edges_for(nnz_max), item_row);
     return check_launch("npi_csr_build");
+}
+
+extern "C" int64_t npi_topk_sorted_workspace_bytes(int64_t N) {
+    if (N < 0) return -1;
+    return sort_layout(N, 0).total;
+}
+
+extern "C" int npi_topk_select_sorted(const float* score, const int64_t* batch, const int32_t* graph_ptr, int64_t N, int64_t B,
+                                      float ratio, int32_t* out_ptr, int32_t* perm, int32_t* remap, void* workspace,
+                                      int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && B >= 0 && N < (int64_t)0x7fffffff && ratio > 0.f && ratio <= 1.f, "npi_topk_select_sorted: bad argument");
+    NPI_REQUIRE(out_ptr && graph_ptr && (N == 0 || (score && batch && perm && remap && workspace)), "npi_topk_select_sorted: null pointer");
+    topk_kept_offsets_kernel<<<1, 256, 0, stream>>>(graph_ptr, (int)B, ratio, out_ptr);
+    if (N == 0 || B == 0) return check_launch("npi_topk_select_sorted");
+    SortLayout L = sort_layout(N, 0);
+    if (workspace_bytes < L.total) {
+        set_error("npi_topk_select_sorted: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.total);
+        return NPI_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    uint32_t* keys_a = (uint32_t*)(ws + L.off_keys_a);
+    uint32_t* keys_b = (uint32_t*)(ws + L.off_keys_b);
+    int32_t* vals_a = (int32_t*)(ws + L.off_vals_a);
+    int32_t* vals_b = (int32_t*)(ws + L.off_vals_b);
+    int32_t* counts = (int32_t*)(ws + L.off_counts);
+    int32_t* tiles = (int32_t*)(ws + L.off_tiles);
+    const unsigned nb = (unsigned)ceil_div(N, 256);
+    topk_score_keys_kernel<<<nb, 256, 0, stream>>>(score, N, keys_a, vals_a);
+    radix_sort_pairs(keys_a, keys_b, vals_a, vals_b, N, 32, L, counts, tiles, stream);
+    topk_graph_keys_kernel<<<nb, 256, 0, stream>>>(batch, vals_a, N, keys_a);
+    int bits = 1;
+    while (((int64_t)1 << bits) < B) ++bits;             // graph ids lie in [0, B)
+    radix_sort_pairs(keys_a, keys_b, vals_a, vals_b, N, bits, L, counts, tiles, stream);
+    topk_take_kernel<<<nb, 256, 0, stream>>>(keys_a, vals_a, N, graph_ptr, out_ptr, perm, remap);
+    return check_launch("npi_topk_select_sorted");
 }
 
 // ---- the CSR of a pooled graph from the CSR of its parent: no sort ------------------------------------------------------

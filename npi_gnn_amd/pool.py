@@ -27,6 +27,7 @@ from ._lib import check, load, ptr, require_gpu, stream_ptr
 # graphs known on the host (batch._npi_sizes): TopKPooling makes no device read, see _topk_pool_fwd.  The edge_index it
 # returns is then PADDED to the input's length with (-1, -1) columns -- NOT PyG's contract, which is why it is opt-in.
 NO_SYNC = True
+LDS_SORT_MAX_NODES = 16384       # npi_topk_select sorts one graph's (score, index) keys in LDS; larger graphs: radix selection
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -78,8 +79,19 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
     status = torch.empty(1, **i32)
     sizes = getattr(batch, "_npi_sizes", None)               # host-known graph sizes: the largest one picks the kernels
     max_nodes = int(sizes.max()) if sizes is not None and sizes.numel() == B and B > 0 else 0
-    check(lib.npi_topk_select_ex(ptr(score), ptr(gp), N, B, float(ratio), ptr(out_ptr), ptr(perm), ptr(remap),
-                                 ptr(status), max_nodes, st), "npi_topk_select")
+
+    def select_sorted():
+        """graphs above the LDS sort's 16,384 nodes: two device-wide stable radix sorts (npi_topk_select_sorted)"""
+        n_ws = int(lib.npi_topk_sorted_workspace_bytes(N))
+        wsb = torch.empty(n_ws, dtype=torch.uint8, device=dev)
+        check(lib.npi_topk_select_sorted(ptr(score), ptr(batch.contiguous()), ptr(gp), N, B, float(ratio), ptr(out_ptr),
+                                         ptr(perm), ptr(remap), ptr(wsb), n_ws, st), "npi_topk_select_sorted")
+    if max_nodes > LDS_SORT_MAX_NODES:                      # known on the host: straight to the radix selection
+        status.zero_()
+        select_sorted()
+    else:
+        check(lib.npi_topk_select_ex(ptr(score), ptr(gp), N, B, float(ratio), ptr(out_ptr), ptr(perm), ptr(remap),
+                                     ptr(status), max_nodes, st), "npi_topk_select")
     # filter_adj needs only the old->new id map, so it runs before the sizes are known
     E = edge_index.size(1)
     src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
@@ -106,23 +118,13 @@ def _topk_pool_fwd(x: torch.Tensor, edge_index: torch.Tensor, batch: torch.Tenso
         n_out, flags, e_out = vals[:3]
         _graph.raise_on_status(vals[3:])
         if flags & 2:
-            # A graph with more than 16,384 nodes does not fit the LDS sort of npi_topk_select (one-hop subgraphs of the
-            # bundled datasets stay below 1,000 nodes).  Rare path: the same selection rule -- score descending, lower index
-            # first among equals, ceil(ratio n) per graph -- with device-wide torch sorts, then filter_adj again with the new map.
-            gpl = gp.long()
-            n_per = gpl[1:] - gpl[:-1]
-            k_per = torch.ceil(float(ratio) * n_per.double()).long()
-            order = torch.argsort(score, descending=True, stable=True)
-            order = order[torch.argsort(batch[order], stable=True)]
-            rank = torch.arange(N, device=dev) - gpl[:-1][batch[order]]
-            keep = order[rank < k_per[batch[order]]]
-            out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(k_per, 0)]).to(torch.int32)
-            perm = keep.to(torch.int32)
-            remap = torch.full((max(N, 1),), -1, **i32)
-            remap[keep] = torch.arange(keep.numel(), **i32)
+            # A graph with more than 16,384 nodes does not fit the LDS sort of npi_topk_select and nobody told us its size
+            # beforehand: select again with the radix kernels (same rule: score descending, lower index first among equals,
+            # ceil(ratio n) per graph), then filter_adj again with the new map -- all on the device.
+            select_sorted()
             check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
                   "npi_filter_adj")
-            n_out, e_out = int(keep.numel()), int(count.item())
+            n_out, e_out = (int(v) for v in torch.cat([out_ptr[-1:], count]).tolist())
     xo = torch.empty((n_out, F), dtype=torch.float32, device=dev)
     batch_o = torch.empty(n_out, dtype=torch.int64, device=dev)
     score_o = torch.empty(n_out, dtype=torch.float32, device=dev)
@@ -196,7 +198,7 @@ class _TopKPoolFn(torch.autograd.Function):
 
 def _kept_sizes(batch, ratio):
     sizes = getattr(batch, "_npi_sizes", None)
-    if not NO_SYNC or sizes is None or sizes.numel() == 0 or int(sizes.max()) > 16384:
+    if not NO_SYNC or sizes is None or sizes.numel() == 0:
         return None
     return torch.ceil(torch.tensor(float(ratio), dtype=torch.float32) * sizes.to(torch.float32)).to(torch.int64)
 

@@ -105,6 +105,48 @@ def test_topk_graph_beyond_the_lds_sort_capacity(dev):
     assert torch.allclose(wd.grad.cpu(), wr.grad, atol=1e-3 * float(wr.grad.abs().max()), rtol=1e-3)
 
 
+@pytest.mark.parametrize("sizes", [[20000, 50], [7, 200_000, 1, 30_000, 16385, 16384, 3], [17000] * 5])
+@pytest.mark.parametrize("ratio", [0.5, 0.25])          # (binary fractions: the oracle's float64 ceil and the kernel's float32 ceil agree)
+def test_radix_selection_for_graphs_of_any_size(dev, sizes, ratio):
+    """graphs above the LDS sort's 16,384 nodes are selected ON THE DEVICE (npi_topk_select_sorted: two
+    stable radix sorts, by score and by graph id) -- no torch.argsort, no host read when the sizes are known.  The kept
+    nodes, their order (score descending, lower index first among equals), the pooled batch vector and the filtered edge
+    list equal the oracle's; the no-sync path (batch._npi_sizes + padded_edges) gives the same and makes no device read."""
+    g = torch.Generator().manual_seed(sum(sizes))
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    x = torch.randn(n, 8, generator=g) * 0.1
+    x[:, 0] = torch.linspace(-2.5, 2.5, n)[torch.randperm(n, generator=g)]        # scores far apart (see the test above)
+    for lo in range(100, n - 40, max(n // 7, 1)):
+        x[lo:lo + 20] = x[lo]                                                     # runs of exact ties inside every large graph
+    w = torch.zeros(1, 8)
+    w[0, 0] = 1.0
+    ei = torch.randint(0, n, (2, 3 * n), generator=g)
+    xo, eo, bo, perm, sc = R.topk_pool(x, ei, batch, w, ratio)
+    got = NP.topk_pool(x.to(dev), ei.to(dev), batch.to(dev), w.to(dev), ratio)                       # sizes unknown: one read
+    assert torch.equal(got[4].cpu(), perm) and torch.equal(got[3].cpu(), bo) and torch.equal(got[1].cpu(), eo)
+    assert torch.allclose(got[0].cpu(), xo, atol=1e-6, rtol=1e-6)
+    b2 = batch.to(dev)
+    b2._npi_sizes = torch.tensor(sizes)
+    xd, eid, wd = x.to(dev), ei.to(dev), w.to(dev)
+    NP.topk_pool(xd, eid, b2, wd, ratio, padded_edges=True)                                            # warm-up (lazy inits)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        ns = NP.topk_pool(xd, eid, b2, wd, ratio, padded_edges=True)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    e = eo.size(1)
+    assert torch.equal(ns[4].cpu(), perm) and torch.equal(ns[3].cpu(), bo)
+    assert ns[1].size(1) == ei.size(1) and torch.equal(ns[1][:, :e].cpu(), eo) and bool((ns[1][:, e:] == -1).all())
+    # a NaN score sorts first, as in torch.sort(descending=True)
+    x2 = x.clone()
+    x2[sizes[0] // 2] = float("nan")
+    ref2 = R.topk_pool(x2, ei, batch, w, ratio)
+    got2 = NP.topk_pool(x2.to(dev), eid, batch.to(dev), wd, ratio)
+    assert torch.equal(got2[4].cpu(), ref2[3])
+
+
 def _run_net1(dev, fx, n_graphs):
     model = Net1(fx["x"].size(1)).to(dev)
     model.load_state_dict({k: v.to(dev) for k, v in fx["state_dict"].items()})      # reference checkpoint, unchanged
