@@ -663,12 +663,16 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
         log.clear()
         step()                                                  # the collectives of ONE step, by kind
         one = {k: dict(v) for k, v in log.items()}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3, one
+        best = None
+        for _ in range(3):                                      # best of three regions (a shared box: see _timeit)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps * 1e3
+            best = dt if best is None or dt < best else best
+        return best, one
 
     def summary(name, t1, per_rank, nnz, coll, note_):
         worst = max(per_rank)
