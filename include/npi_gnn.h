@@ -306,6 +306,13 @@ int npi_gat_backward_fused_packed(const int32_t* rowptr, const int32_t* col, con
                                   int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* hfeat, int64_t ldh,
                                   float* out, int64_t ldo, int64_t C, const float* tpack, const float* a_src,
                                   float negative_slope, float* dz, float* carry, void* stream);
+/* the same with the gathered rows coming from a two-part table (dout2 / split as x2 / split of npi_segsum_ex); tpack is ONE
+ * array indexed by the column id over both parts (the sharded GATConv: received hub rows + the rank's own rows) */
+int npi_gat_backward_fused_packed_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                                     int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* dout2,
+                                     int64_t split, const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t C,
+                                     const float* tpack, const float* a_src, float negative_slope, float* dz, float* carry,
+                                     void* stream);
 int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
                       int64_t N, int64_t H, int64_t C, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,

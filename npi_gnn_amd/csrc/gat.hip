@@ -837,8 +837,18 @@ extern "C" int npi_gat_backward_fused_packed(const int32_t* rowptr, const int32_
                                              const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t C,
                                              const float* tpack, const float* a_src, float slope, float* dz, float* carry,
                                              void* stream_) {
+    return npi_gat_backward_fused_packed_ex(rowptr, col, rowidx, item_row, N, nnz_max, dout, ldd, nullptr, 0, hfeat, ldh, out, ldo,
+                                            C, tpack, a_src, slope, dz, carry, stream_);
+}
+
+extern "C" int npi_gat_backward_fused_packed_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                                                const int32_t* item_row, int64_t N, int64_t nnz_max, const float* dout,
+                                                int64_t ldd, const float* dout2, int64_t split, const float* hfeat, int64_t ldh,
+                                                float* out, int64_t ldo, int64_t C, const float* tpack, const float* a_src,
+                                                float slope, float* dz, float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_backward_fused_packed: needs one head of <= 256 channels, C % 4 == 0");
+    NPI_REQUIRE(dout2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_backward_fused_packed_ex: bad split");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && col && rowidx && item_row && dout && hfeat && out && tpack && a_src && dz && carry,
                 "npi_gat_backward_fused_packed: null pointer");
@@ -848,10 +858,11 @@ extern "C" int npi_gat_backward_fused_packed(const int32_t* rowptr, const int32_
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
     P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
     P.x = dout; P.ldx = ldd; P.out = out; P.ldo = ldo; P.F = (int)C;
+    P.x2 = dout2; P.split = (int)split;              // rows gathered from a two-part table (the sharded layers), as npi_segsum_ex
     P.carry = carry; P.bias = nullptr;
     P.H = 1; P.C = (int)C; P.a_src = a_src; P.slope = slope;
     P.a_dst = a_src; P.m = a_src; P.s = a_src;                                 // unused in this mode
-    P.tpack = reinterpret_cast<const float4*>(tpack);
+    P.tpack = reinterpret_cast<const float4*>(tpack);                          // indexed by the COLUMN id (both parts: one array)
     P.hrow = hfeat; P.ldh = ldh; P.rowidx = rowidx; P.dz_out = dz;
     return segsum_run(P, W_GAT_SRC_FUSED, 0, nnz_max, NPI_F32, stream);
 }

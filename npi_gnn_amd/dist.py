@@ -286,6 +286,8 @@ def route_edges(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: 
 
 # cuts without hub-hub edges: reduce-scatter the complete hub rows straight into the output (no merge pass); 0 = classic layout
 DIRECT_HUB_ROWS = os.environ.get("NPI_DIRECT_HUB_ROWS", "1") != "0"
+# one-head GATConv on the direct layout with the fused packed backward (_ShardedGatDirectFn); 0 = the classic layout always
+GAT_DIRECT = os.environ.get("NPI_GAT_DIRECT", "1") != "0"
 
 # tests set this to push a world-size-1 run through RCCL as well (the one-GPU box's only way to
 # exercise the real collectives); normally a single rank just copies
@@ -444,9 +446,34 @@ class HipBackend:
         from . import functional as NF
         return NF.gat_edge_grad(side, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap)
 
-    def seg_rowsum(self, side, vals, H):
+    def seg_rowsum(self, side, vals, H, map_=None):
         from . import functional as NF
-        return NF.seg_rowsum(side, vals, H)
+        return NF.seg_rowsum(side, vals, H, map_=map_)
+
+    # ---- one head on the direct layout (_ShardedGatDirectFn): the round-3 kernels of the single-GPU layer
+    def entry_source_index(self, side):
+        """for every entry of the side, its position in the (key, val) arrays the side was built from"""
+        return side.eid[: side.nnz_max].long()
+
+    def gat_stats_scores(self, side, a_row, a_col, slope):
+        from . import functional as NF
+        return NF.gat_softmax_stats(side, a_row.contiguous(), a_col.contiguous(), 1, slope, want_scores=True)
+
+    def gat_aggregate_scores(self, side, table, table2, C, scores, m, s, bias=None, out=None):
+        from . import functional as NF
+        return NF.gat_aggregate_scores(side, table, table2, C, scores, m.contiguous(), s.contiguous(), bias=bias, out=out)
+
+    def gat_pack(self, a_dst, m, s, D):
+        from . import functional as NF
+        return NF.gat_pack_targets(a_dst, m, s, D)
+
+    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None):
+        from . import functional as NF
+        return NF.gat_backward_fused_packed(side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=out)
+
+    def gat_rank1_add(self, dh, g_dst, g_src, att2, H, C):
+        from . import functional as NF
+        return NF.gat_rank1_add(dh, g_dst.contiguous(), g_src.contiguous(), att2, H, C)
 
     def gat_att_grad(self, h, g_dst, g_src, H, C):
         from . import functional as NF
@@ -512,6 +539,7 @@ class ShardedGraph:
         self.own_hub = slice(rank * part.h_per, rank * part.h_per + self.nH)       # this rank's rows of the hub table
         self._gcn = None
         self._gcn_direct = None
+        self._gat_maps = None
         self._b_empty = None
 
     # ---- classic layout: A holds every local row with its loop, B the partial hub sums from light sources (GATConv, and
@@ -561,6 +589,27 @@ class ShardedGraph:
                 w = {"A": None, "At": None, "B": inv_hub[be.row_of_entry(B)].contiguous(), "Bt": None}
             self._gcn_direct[gcn] = w
         return self._gcn_direct[gcn]
+
+    def gat_maps(self):
+        """Direct layout, GATConv backward: dz of every entry is computed ONCE, on the by-source sides (A^T: own light sources,
+        B^T: hub sources); the by-target row sums need it in the order of A / B.  A and B^T hold the same routed edges (list 1),
+        B and A^T likewise (list 2), the light rows' loops live in A and A^T, the own hubs' loops in B and B^T -- so the two maps
+        ``entry of A / of B -> position in cat[dz of B^T, dz of A^T]`` are local index plumbing, built once."""
+        if self._gat_maps is None:
+            be = self.backend
+            A, B, At, Bt = self.direct()
+            n1, n2 = int(self._l1[0].numel()), int(self._l2[0].numel())
+            dev = self.part.hub.device
+            eA, eB, eAt, eBt = (be.entry_source_index(sd) for sd in (A, B, At, Bt))
+            nBt, nAt = int(eBt.numel()), int(eAt.numel())
+            pos_bt = torch.zeros(n1 + self.nH + 1, dtype=torch.long, device=dev)
+            pos_bt[eBt] = torch.arange(nBt, device=dev)              # list-1 edge e / own hub loop n1 + k -> entry of B^T
+            pos_at = torch.zeros(n2 + self.nL + 1, dtype=torch.long, device=dev)
+            pos_at[eAt] = torch.arange(nAt, device=dev)              # list-2 edge e / light loop n2 + i -> entry of A^T
+            map_a = torch.where(eA < n1, pos_bt[eA.clamp(max=max(n1 - 1, 0))], nBt + pos_at[(n2 + eA - n1).clamp(min=0)])
+            map_b = torch.where(eB < n2, nBt + pos_at[eB.clamp(max=max(n2 - 1, 0))], pos_bt[(n1 + eB - n2).clamp(min=0)])
+            self._gat_maps = (map_a.to(torch.int32).contiguous(), map_b.to(torch.int32).contiguous(), nBt, nAt)
+        return self._gat_maps
 
     def shard(self, x_full: torch.Tensor) -> torch.Tensor:
         return x_full[self.own.to(x_full.device)]
@@ -924,6 +973,124 @@ class _ShardedGatFn(torch.autograd.Function):
         return dx, dw, datt, db, None, None, None
 
 
+class _ShardedGatDirectFn(torch.autograd.Function):
+    """GATConv, ONE head, on the direct layout (cuts without hub-hub edges) with the single-GPU layer's round-3 kernels: the
+    statistics pass leaves the per-entry scores, the aggregation reads them back, and the backward is ONE fused gather pass per
+    by-source side on packed per-target scalars -- every entry's SDDMM dot is computed once (the classic path computes it on
+    both orientations of both sides).  Per rank and direction: two aggregation-sized launches over its ~E/W entries.
+
+      forward   light rows : complete softmax on the owner (sources: the gathered hub table + the own self loop)
+                hub rows   : (m_r, s_r) and U_r = sum exp(e - M) h_j over the rank's light sources and, on the owner, the
+                             hub's own loop; M = all_reduce(MAX) of m_r; (U, S) reduce-scattered; out = U / S + b
+      backward  dz of an entry lives on the by-source side that holds it (A^T: own light sources, B^T: hub sources);
+                by-target row sums read it through ``ShardedGraph.gat_maps``; partial d h / g_src / g_dst of the hub rows are
+                reduce-scattered; everything else is the single-GPU layer's arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x_own, weight, att, bias, sg: ShardedGraph, slope: float):
+        be, part, W = sg.backend, sg.part, sg.world
+        nL, nH, hp = sg.nL, sg.nH, sg.part.h_per
+        C = weight.size(1)
+        x_own = x_own.contiguous()
+        att2 = att.reshape(1, 2 * C).contiguous()
+        A, B, _, _ = sg.direct()
+        h = be.linear_fwd(x_own, weight, None)
+        a_dst, a_src = be.gat_scores(h, att2, 1, C)                                # [n_local, 1] each
+        tbl_h, g_work = gather_hub(sg, h, async_op=True)                           # big: hub rows of h
+        hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))               # small
+        tbl_a_dst, tbl_a_src = hub_sc[:, :1].contiguous(), hub_sc[:, 1:].contiguous()
+        # hub rows: this rank's share -- its light sources and the loops of the hubs it owns; needs nothing of tbl_h
+        mB, sB, eB = be.gat_stats_scores(B, tbl_a_dst, a_src, slope)
+        empty = be.row_lengths(B).view(-1, 1) == 0
+        M = torch.where(empty, torch.full_like(mB, NEG), mB)
+        _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
+        U = be.gat_aggregate_scores(B, h, None, C, eB, M, torch.ones_like(M))      # sum exp(e - M) h_j, not normalised
+        S = torch.where(empty, torch.zeros_like(sB), sB * torch.exp(mB - M))
+        out_full = h.new_empty((nL + hp, C))
+        hU, wU = out_full[nL:], None                                               # the reduce-scatter lands in the output
+        if _solo(W):
+            hU.copy_(U)
+            s_own = S
+        else:
+            wU = reduce_scatter_rows(U, hU, sg.rank, W, sg.group, async_op=True)
+            s_own = S.new_empty((hp, 1))
+            _wait(reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.group, async_op=True), "fwd_reduce_scatter_s", s_own)
+        # light rows: the whole softmax is local once the hub table is here
+        tbl_a_src_full = torch.cat([tbl_a_src, a_src])                             # index space of A's columns
+        mA, sA, eA = be.gat_stats_scores(A, a_dst[:nL], tbl_a_src_full, slope)
+        _wait(g_work, "fwd_all_gather", tbl_h)
+        be.gat_aggregate_scores(A, tbl_h, h, C, eA, mA, sA, bias=bias, out=out_full[:nL])
+        _wait(wU, "fwd_reduce_scatter", hU)
+        if nH:
+            hub = hU[:nH] / (s_own[:nH] + 1e-16)
+            hU[:nH] = hub + bias if bias is not None else hub
+        out = out_full[: nL + nH]
+        m_own = torch.cat([mA, M[sg.own_hub]])
+        s_all = torch.cat([sA, s_own[:nH]])
+        tbl_S, _ = gather_hub(sg, s_all)                                           # every rank needs S of the hub targets it holds
+        ctx.sg, ctx.C, ctx.slope = sg, C, float(slope)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x_own, weight, att2, h, a_dst, a_src, tbl_h, tbl_a_dst, tbl_a_src, M, tbl_S, m_own, s_all, out,
+                              bias if bias is not None else h.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x_own, weight, att2, h, a_dst, a_src, tbl_h, tbl_a_dst, tbl_a_src, M, tbl_S, m_own, s_all, out, bias) = ctx.saved_tensors
+        sg: ShardedGraph = ctx.sg
+        be, W = sg.backend, sg.world
+        nL, nH, hp = sg.nL, sg.nH, sg.part.h_per
+        C, slope = ctx.C, ctx.slope
+        A, B, At, Bt = sg.direct()
+        map_a, map_b, n_bt, n_at = sg.gat_maps()
+        dO = grad_out.contiguous()
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = be.colsum(dO)
+            _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
+        D = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, 1, C)           # [n_local, 1]
+        tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                         # big: hub rows of dOut
+        tbl_D, _ = gather_hub(sg, D)
+        # packed per-TARGET scalars (a_dst, m, 1 / s, D): the own rows, and the hub table (targets of the light sources)
+        t_own = be.gat_pack(a_dst, m_own, s_all, D)
+        t_tbl = be.gat_pack(tbl_a_dst, M, tbl_S, tbl_D)
+        # hub SOURCES (rows of the hub table): targets = this rank's rows (its light rows; the own hubs' loops): nothing remote
+        pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope)
+        pg_src = be.seg_rowsum(Bt, dz_bt.view(-1, 1), 1)
+        # own light SOURCES: targets = the hub table (+ the own loop)
+        dh_full = h.new_empty((nL + hp, C))
+        _wait(g_work, "bwd_all_gather", tbl_dO)
+        _, dz_at = be.gat_backward_fused(At, tbl_dO, dO, h[:nL], C, torch.cat([t_tbl, t_own]), a_src[:nL], slope, out=dh_full[:nL])
+        g_src_l = be.seg_rowsum(At, dz_at.view(-1, 1), 1)
+        dz_cat = torch.cat([dz_bt[:n_bt], dz_at[:n_at]]).view(-1, 1)
+        g_dst_l = be.seg_rowsum(A, dz_cat, 1, map_=map_a)                          # light targets: complete
+        pg_dst = be.seg_rowsum(B, dz_cat, 1, map_=map_b)                           # hub targets: this rank's share
+        pg = torch.cat([pg_dst, pg_src], dim=1).contiguous()                       # [hub_rows, 2]
+        if _solo(W):
+            dh_full[nL:].copy_(pdh)
+            g_hub = pg
+        else:
+            wh = reduce_scatter_rows(pdh, dh_full[nL:], sg.rank, W, sg.group, async_op=True)
+            g_hub = pg.new_empty((hp, 2))
+            _wait(reduce_scatter_rows(pg, g_hub, sg.rank, W, sg.group, async_op=True), "bwd_reduce_scatter_g", g_hub)
+            _wait(wh, "bwd_reduce_scatter", dh_full)
+        dh = dh_full[: nL + nH]
+        g_dst = torch.cat([g_dst_l, g_hub[:nH, :1]])
+        g_src = torch.cat([g_src_l, g_hub[:nH, 1:]])
+        be.gat_rank1_add(dh, g_dst, g_src, att2, 1, C)                             # d h_j += g_dst[j] att[:C] + g_src[j] att[C:]
+        datt = dw = dx = None
+        if ctx.needs_input_grad[2]:
+            datt = be.gat_att_grad(h, g_dst.contiguous(), g_src.contiguous(), 1, C)
+            _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
+            datt = datt.view(1, 1, 2 * C)
+        if ctx.needs_input_grad[1]:
+            dw, _ = be.linear_bwd_weight(x_own, dh, False)
+            _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
+        if ctx.needs_input_grad[0]:
+            dx = be.linear_bwd_data(dh, weight, None)
+        return dx, dw, datt, db, None, None
+
+
 class _ShardedLayer(nn.Module):
     def __init__(self, sg: ShardedGraph, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
         super().__init__()
@@ -960,6 +1127,10 @@ class ShardedGATLayer(_ShardedLayer):
         self.heads, self.negative_slope = int(heads), float(negative_slope)
 
     def forward(self, x_own: torch.Tensor) -> torch.Tensor:
+        C = self.weight.size(1)
+        if (GAT_DIRECT and self.heads == 1 and self.sg.direct_ok and C <= 256 and C % 4 == 0
+                and hasattr(self.sg.backend, "gat_backward_fused")):
+            return _ShardedGatDirectFn.apply(x_own, self.weight, self.att, self.bias, self.sg, self.negative_slope)
         return _ShardedGatFn.apply(x_own, self.weight, self.att, self.bias, self.sg, self.heads, self.negative_slope)
 
 

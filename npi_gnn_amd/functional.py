@@ -611,6 +611,69 @@ def gat_rowdot_colsum(a, b, bias, H, C, want_colsum: bool = True):
     return D, cs
 
 
+def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=None, out=None):
+    """One head: out[r] = sum_p exp(scores[p] - m[r]) / (s[r] + 1e-16) table[col p] (+ bias) over the entries of row r, the
+    per-entry scores coming from ``gat_softmax_stats(..., want_scores=True)``; ``table2``: second part of a two-part table."""
+    dev = table.device
+    table = _f32c(table, "table")
+    if table2 is not None:
+        table2 = _f32c(table2, "table2")
+        if table2.stride(0) != table.stride(0):
+            raise ValueError("the two parts of the table must share the row pitch")
+    if out is None:
+        out = torch.empty((side.n_rows, C), dtype=torch.float32, device=dev)
+    if side.nnz_max == 0:
+        return out.zero_() if bias is None else out.copy_(bias.view(1, -1).expand_as(out))
+    with _tag_events("gat_fwd_aggregate", dev):
+        check(load().npi_gat_aggregate_scores(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
+                                              ptr(table), table.stride(0), ptr(table2), table.size(0) if table2 is not None else 0,
+                                              ptr(out), out.stride(0), C, ptr(scores), ptr(m), ptr(s), ptr(bias), None,
+                                              ptr(side.carry(C)), stream_ptr(dev)), "npi_gat_aggregate_scores")
+    return out
+
+
+def gat_pack_targets(a_dst, m, s, D):
+    """[n, 4] = (a_dst, m, 1 / (s + 1e-16), D) of every target node (one head): what ``gat_backward_fused_packed`` gathers"""
+    dev = a_dst.device
+    n = a_dst.numel()
+    t = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    check(load().npi_gat_pack_targets(ptr(a_dst.contiguous()), ptr(m.contiguous()), ptr(s.contiguous()), ptr(D.contiguous()), n,
+                                      ptr(t), stream_ptr(dev)), "npi_gat_pack_targets")
+    return t
+
+
+def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None):
+    """One head, by-SOURCE side: (out [n_rows, C] = sum_q alpha_q dout[col q], dz [nnz_max] per entry) in one gather pass;
+    ``dout2``: second part of the gathered table; ``tpack`` [n_cols, 4] indexed by the column id; ``hrow`` / ``a_src_rows``:
+    features and source score of the ROW nodes."""
+    dev = dout.device
+    dout = _f32c(dout, "dout")
+    if dout2 is not None:
+        dout2 = _f32c(dout2, "dout2")
+        if dout2.stride(0) != dout.stride(0):
+            raise ValueError("the two parts of the table must share the row pitch")
+    hrow = _f32c(hrow, "hrow")
+    if out is None:
+        out = torch.empty((side.n_rows, C), dtype=torch.float32, device=dev)
+    dz = torch.empty(max(side.nnz_max, 1), dtype=torch.float32, device=dev)
+    if side.nnz_max == 0:
+        return out.zero_(), dz
+    with _tag_events("gat_bwd_fused", dev):
+        check(load().npi_gat_backward_fused_packed_ex(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row),
+                                                      side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
+                                                      dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
+                                                      out.stride(0), C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
+                                                      ptr(side.carry(C)), stream_ptr(dev)), "npi_gat_backward_fused_packed_ex")
+    return out, dz
+
+
+def gat_rank1_add(dh, g_dst, g_src, att2, H, C):
+    """dh[j, h, :] += g_dst[j, h] att[h, :C] + g_src[j, h] att[h, C:] in place"""
+    check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), dh.size(0), H, C,
+                                   stream_ptr(dh.device)), "npi_gat_rank1_add")
+    return dh
+
+
 def gat_edge_grad(side: CSRSide, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap,
                   alpha_out=None):
     """dz per entry of ``side`` (``npi_gat_edge_grad_ex``).  swap = 0: rows are targets (row_feat = dOut rows; a_dst,

@@ -103,8 +103,51 @@ class TorchBackend:
         p = (row_feat[key].view(-1, H, C) * self._table(col_feat, col_feat2)[val].view(-1, H, C)).sum(-1)
         return alpha * (p - D[tgt]) * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
 
-    def seg_rowsum(self, side, vals, H):
-        return torch.zeros(side[2], H).index_add_(0, side[0], vals[: side[0].numel()])
+    def seg_rowsum(self, side, vals, H, map_=None):
+        n = side[0].numel()
+        v = vals[map_.long()[:n]] if map_ is not None else vals[:n]
+        return torch.zeros(side[2], H).index_add_(0, side[0], v)
+
+    # ---- one head on the direct layout (dist._ShardedGatDirectFn): stand-ins for the round-3 kernels
+    def entry_source_index(self, side):
+        return torch.arange(side[0].numel())
+
+    def gat_stats_scores(self, side, a_row, a_col, slope):
+        key, val = side[0], side[1]
+        m, s = self.gat_stats(side, a_row, a_col, 1, slope)
+        return m, s, F.leaky_relu(a_row[key] + a_col[val], slope)
+
+    def gat_aggregate_scores(self, side, table, table2, C, scores, m, s, bias=None, out=None):
+        key, val, n_rows, _ = side
+        t = self._table(table, table2)
+        w = torch.exp(scores - m[key]) / (s[key] + 1e-16)
+        res = torch.zeros(n_rows, C).index_add_(0, key, t[val] * w)
+        res = res + bias if bias is not None else res
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def gat_pack(self, a_dst, m, s, D):
+        return torch.cat([a_dst.view(-1, 1), m.view(-1, 1), 1.0 / (s.view(-1, 1) + 1e-16), D.view(-1, 1)], dim=1)
+
+    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None):
+        key, val, n_rows, _ = side                                    # key = source row j, val = target column i
+        t = self._table(dout, dout2)
+        tp = tpack[val]
+        z = tp[:, 0] + a_src_rows.view(-1)[key]
+        alpha = torch.exp(F.leaky_relu(z, slope) - tp[:, 1]) * tp[:, 2]
+        res = torch.zeros(n_rows, C).index_add_(0, key, t[val] * alpha.view(-1, 1))
+        dot = (t[val] * hrow[key]).sum(-1)
+        dz = alpha * (dot - tp[:, 3]) * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+        if out is not None:
+            out.copy_(res)
+            res = out
+        return res, dz
+
+    def gat_rank1_add(self, dh, g_dst, g_src, att2, H, C):
+        dh += g_dst.view(-1, 1) * att2[:, :C] + g_src.view(-1, 1) * att2[:, C:]
+        return dh
 
     def gat_att_grad(self, h, g_dst, g_src, H, C):
         hv = h.view(-1, H, C)
