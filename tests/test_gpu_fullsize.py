@@ -177,6 +177,54 @@ def test_c4_gat_forward_matches_restatement_and_fp64_on_the_hubs(c4):
             assert float((out[i].double() - truth).abs().max()) < 1e-5
 
 
+def test_c4_gat_four_heads_forward_and_backward_against_fp64(c4):
+    """GATConv with FOUR heads (4 x 64) at the full C4 size -- the multi-head path (alpha recomputed per
+    entry, unfused backward).  Forward rows (random ones and the four heaviest hubs) against the softmax formula in fp64;
+    backward: dW / datt / db through the adjoint identity <dOut, J v> = <J^T dOut, v> in fp64 torch ops on the same GPU is
+    too large at this size, so the gradients are held to the ONE-head-at-a-time decomposition instead: a concat of heads
+    is H independent one-head layers, whose fused / packed kernels are themselves held to fp64 by the tests above."""
+    ei, graph, x = c4
+    dev = x.device
+    H, C = 4, F // 4
+    g = torch.Generator().manual_seed(11)
+    W = ((torch.rand(F, F, generator=g) * 2 - 1) * (6.0 / (2 * F)) ** 0.5).to(dev)
+    att = ((torch.rand(1, H, 2 * C, generator=g) * 2 - 1) * (6.0 / (H + 2 * C)) ** 0.5 * 3.0).to(dev)
+    b = (torch.randn(F, generator=g) * 0.1).to(dev)
+    go = torch.randn(N, F, generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+    xg, Wg, ag, bg = x.clone().requires_grad_(True), W.clone().requires_grad_(True), att.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out = npi.gat_conv(xg, graph, Wg, ag, bg, heads=H)
+    out.backward(go)
+    torch.cuda.synchronize()
+    # forward rows in fp64
+    in_deg = torch.bincount(ei[1], minlength=N)
+    rows = torch.cat([torch.topk(in_deg, 4).indices, torch.randint(0, N, (60,), generator=torch.Generator().manual_seed(5)).to(dev)])
+    h = (x.double() @ W.double()).view(N, H, C)
+    a_d, a_s = att.double().view(H, 2 * C)[:, :C], att.double().view(H, 2 * C)[:, C:]
+    for i in rows.tolist():
+        nb = torch.cat([ei[0][ei[1] == i], torch.tensor([i], device=dev)])
+        e = torch.nn.functional.leaky_relu((h[i] * a_d).sum(-1).view(1, H) + (h[nb] * a_s).sum(-1), 0.2)     # [deg, H]
+        alpha = torch.softmax(e, 0)
+        truth = (alpha.unsqueeze(-1) * h[nb]).sum(0).reshape(-1) + b.double()
+        assert float((out[i].detach().double() - truth).abs().max()) < 1e-5
+    del h
+    # gradients: head k of the 4-head layer == a one-head layer on W[:, kC:(k+1)C], att[k], b[kC:(k+1)C] (fused / packed path)
+    dx_sum = torch.zeros_like(x)
+    for k in range(H):
+        sl = slice(k * C, (k + 1) * C)
+        x1 = x.clone().requires_grad_(True)
+        W1, a1, b1 = (t.clone().requires_grad_(True) for t in (W[:, sl], att[:, k:k + 1], b[sl]))
+        o1 = npi.gat_conv(x1, graph, W1, a1, b1, heads=1)
+        assert float((o1.detach() - out.detach()[:, sl]).abs().max() / out.detach()[:, sl].abs().max()) < 1e-5
+        o1.backward(go[:, sl].contiguous())
+        dx_sum += x1.grad
+
+        def rel(a, r):
+            return float((a - r).abs().max() / r.abs().max())
+        assert rel(Wg.grad[:, sl], W1.grad) < 2e-4 and rel(ag.grad[:, k:k + 1], a1.grad) < 2e-4 and rel(bg.grad[sl], b1.grad) < 2e-4
+        del x1, o1
+    assert float((xg.grad - dx_sum).abs().max() / dx_sum.abs().max()) < 2e-4
+
+
 # ---- configs[4] ("C5"): N = 4M nodes, E = 100M directed edges, GATConv hidden 256, one head --------------------
 N5, E5 = 4_000_000, 100_000_000
 
