@@ -337,7 +337,8 @@ def _stack_step(kind, weights, x, graph, dtype=torch.float32, norm=None, att=Non
             elif kind == "gcn":
                 h = NF.gcn_conv(h, None, W, b, norm=norm)
             else:
-                h = npi.gat_conv(h, graph, W, atts[k], b, heads=1)
+                h = npi.gat_conv(h, graph, W, atts[k], b, heads=1, relu=True)      # F.relu(conv(h)), fused
+                continue
             h = torch.relu(h)
         h.float().pow(2).mean().backward()
         return h

@@ -340,7 +340,8 @@ int npi_gat_edge_grad_ex(const int32_t* rowptr, const int32_t* col, const int32_
  *   npi_gat_softmax_stats_ex = npi_gat_softmax_stats; additionally writes the leaky_relu score e_p of every entry to
  *                              scores [nnz_max, H] (may be NULL), which npi_gat_aggregate_scores reads back
  *   npi_gat_aggregate_scores = npi_gat_aggregate_ex(by_source = 0), one head, with the per-entry scores of the statistics
- *                              pass instead of two gathered per-node scalars per entry; alpha_out as there (may be NULL)
+ *                              pass instead of two gathered per-node scalars per entry; alpha_out as there (may be NULL);
+ *                              relu != 0: max(., 0) in the row epilogue (the F.relu behind the layer)
  *   npi_gat_rowdot_colsum    = npi_gat_rowdot AND the column sums of `a` (GATConv's bias gradient; colsum may be NULL) in
  *                              one pass over a and b; needs 16-byte aligned rows, C % 4 == 0, H C <= 1024
  * workspace: npi_seg_scan_workspace_elems(nnz_max, H) / npi_gat_rowdot_colsum_workspace_elems(N, H, C) floats. */
@@ -354,11 +355,18 @@ int npi_gat_softmax_stats_ex(const int32_t* rowptr, const int32_t* col, const in
 int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
                              int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                              float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
-                             const float* bias, float* alpha_out, float* carry, void* stream);
+                             const float* bias, int relu, float* alpha_out, float* carry, void* stream);
 int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C);
 int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                           int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* workspace,
                           int64_t workspace_elems, void* stream);
+/* `F.relu(conv(x))` fused (npi_gat_aggregate_scores with relu != 0 applies the ReLU in the row epilogue): b is then the ReLU
+ * OUTPUT, and this form first masks the incoming gradient, a' = a where b > 0 else 0 (threshold_backward), uses a' for D and
+ * the column sums and writes it to a_masked [N, ldm] -- the gradient of the pre-activation the rest of the backward consumes.
+ * D is unchanged by the fusion: where b > 0 the pre-activation equals b, elsewhere a' = 0. */
+int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                               int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* a_masked, int64_t ldm,
+                               float* workspace, int64_t workspace_elems, void* stream);
 int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
                    int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
                    void* stream);

@@ -77,9 +77,10 @@ PROTOTYPES = {
     "npi_seg_scan_workspace_elems": (_I, [_I, _I]),
     "npi_seg_rowsum_ex": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_gat_softmax_stats_ex": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
-    "npi_gat_aggregate_scores": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "npi_gat_aggregate_scores": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "npi_gat_rowdot_colsum_workspace_elems": (_I, [_I, _I, _I]),
     "npi_gat_rowdot_colsum": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "npi_gat_rowdot_colsum_relu": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
     "npi_entry_transpose_map": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_gat_att_grad_workspace_elems": (_I, [_I, _I, _I]),
     "npi_gat_att_grad": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P]),

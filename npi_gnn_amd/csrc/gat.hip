@@ -149,7 +149,7 @@ template <int NCHK>
 __global__ void __launch_bounds__(256)
 gat_rowdot_colsum_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
                          const float* __restrict__ bias, int N, int H, int C, int rows, float* __restrict__ D,
-                         float* __restrict__ part) {
+                         float* __restrict__ part, float* __restrict__ a_masked, int64_t ldm) {
     __shared__ float red[4][NCHK * 256];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -186,7 +186,14 @@ gat_rowdot_colsum_kernel(const float* __restrict__ a, int64_t lda, const float* 
             float pk[NCHK];
 #pragma unroll
             for (int k = 0; k < NCHK; ++k) {
-                const float4 x = va[r][k], y = vb[r][k];
+                float4 x = va[r][k];
+                const float4 y = vb[r][k];
+                if (a_masked != nullptr) {
+                    // b is a ReLU OUTPUT: the gradient passes where it is positive (threshold_backward), and that masked
+                    // gradient is what the rest of the backward consumes -- written here, in the pass that reads both anyway
+                    x.x = y.x > 0.f ? x.x : 0.f; x.y = y.y > 0.f ? x.y : 0.f; x.z = y.z > 0.f ? x.z : 0.f; x.w = y.w > 0.f ? x.w : 0.f;
+                    if (live && hd[k] >= 0) *reinterpret_cast<float4*>(a_masked + (int64_t)(r0 + r) * ldm + k * 256 + lane * 4) = x;
+                }
                 pk[k] = x.x * (y.x - bs[k].x) + x.y * (y.y - bs[k].y) + x.z * (y.z - bs[k].z) + x.w * (y.w - bs[k].w);
                 if (live) { cs[k].x += x.x; cs[k].y += x.y; cs[k].z += x.z; cs[k].w += x.w; }
             }
@@ -913,11 +920,18 @@ extern "C" int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, i
 extern "C" int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                                      int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* workspace,
                                      int64_t workspace_elems, void* stream_) {
+    return npi_gat_rowdot_colsum_relu(a, lda, b, ldb, bias, N, H, C, D, colsum, nullptr, 0, workspace, workspace_elems, stream_);
+}
+
+extern "C" int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                                          int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* a_masked,
+                                          int64_t ldm, float* workspace, int64_t workspace_elems, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(N >= 0 && H > 0 && C > 0 && N < 0x7fffffff, "npi_gat_rowdot_colsum: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(a && b && D, "npi_gat_rowdot_colsum: null pointer");
     const int64_t Fw = H * C;
+    NPI_REQUIRE(a_masked == nullptr || (ldm >= Fw && ldm % 4 == 0 && ((uintptr_t)a_masked % 16) == 0), "npi_gat_rowdot_colsum_relu: a_masked pitch / alignment");
     if (!(rows16(a, lda, C) && rows16(b, ldb, C) && ((uintptr_t)bias % 16) == 0 && Fw <= RDC_MAXCH * 256)) {
         set_error("npi_gat_rowdot_colsum: needs 16-byte aligned rows, out_channels %% 4 == 0 and heads * out_channels <= 1024 "
                   "(use npi_gat_rowdot + npi_colsum otherwise)");
@@ -931,7 +945,7 @@ extern "C" int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b
     }
     float* part = colsum ? workspace : nullptr;
     switch ((int)ceil_div(Fw, 256)) {
-#define NPI_RDC(K) case K: gat_rowdot_colsum_kernel<K><<<(unsigned)nblocks, 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, rows, D, part); break
+#define NPI_RDC(K) case K: gat_rowdot_colsum_kernel<K><<<(unsigned)nblocks, 256, 0, stream>>>(a, lda, b, ldb, bias, (int)N, (int)H, (int)C, rows, D, part, a_masked, ldm); break
         NPI_RDC(1); NPI_RDC(2); NPI_RDC(3); default: NPI_RDC(4);
 #undef NPI_RDC
     }
@@ -1030,7 +1044,7 @@ extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, c
 extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
                                         int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                                         float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
-                                        const float* bias, float* alpha_out, float* carry, void* stream_) {
+                                        const float* bias, int relu, float* alpha_out, float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_scores: bad split");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0, "npi_gat_aggregate_scores: bad size");
@@ -1043,7 +1057,7 @@ extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* co
     P.x = x; P.ldx = ldx; P.out = out; P.ldo = ldo; P.F = (int)C;
     P.x2 = x2; P.split = (int)split;
     P.carry = carry; P.w = scores; P.bias = bias;
-    P.H = 1; P.C = (int)C; P.m = m; P.s = s; P.alpha_out = alpha_out;
+    P.H = 1; P.C = (int)C; P.m = m; P.s = s; P.alpha_out = alpha_out; P.relu = relu ? 1 : 0;
     return segsum_run(P, W_GAT_DST_PRE, 0, nnz_max, NPI_F32, stream);
 }
 

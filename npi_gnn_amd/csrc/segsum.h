@@ -11,6 +11,7 @@ struct SegParams {
     const int32_t* col;
     const int32_t* item_row;
     int N, n_items;
+    int relu;                // != 0: max(., 0) after scale and bias (the F.relu behind a GATConv, in the row epilogue; NaN kept)
     int mean;                // != 0: divide every row sum by its entry count (scatter_mean); filled in by segsum_run
     int item;                // entries per item (item_edges_for(nnz_max)); filled in by segsum_run
     const float* x;

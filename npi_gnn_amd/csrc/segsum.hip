@@ -131,6 +131,7 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             t[q] = fmaf(acc[c][q], sc, bias ? to_f32(bias[L.foff[c] + q]) : 0.f);
+            if (P.relu) t[q] = (t[q] < 0.f) ? 0.f : t[q];            // keeps NaN, like torch.relu
         }
         if ((WMODE == W_GAT_SRC || WMODE == W_GAT_SRC_PRE) && P.g_dst != nullptr) {
             const int h = L.hd[c];

@@ -592,26 +592,33 @@ def gat_rowdot(a, b, bias, H, C):
     return D
 
 
-def gat_rowdot_colsum(a, b, bias, H, C, want_colsum: bool = True):
+def gat_rowdot_colsum(a, b, bias, H, C, want_colsum: bool = True, relu_mask: bool = False):
     """(D, colsum(a) or None): ``gat_rowdot`` and the bias gradient in one pass over ``a`` (= dOut) and ``b`` (= out);
-    falls back on the two separate kernels for unaligned rows or H C > 1024."""
+    falls back on the two separate kernels for unaligned rows or H C > 1024.  ``relu_mask``: ``b`` is the output of a fused
+    ReLU -- the gradient is masked first (``a' = a`` where ``b > 0``), D and the column sums use ``a'``, and ``a'`` is returned
+    as a third value (the gradient of the pre-activation, which the rest of the backward consumes)."""
     lib = load()
     dev = a.device
     N = a.size(0)
     ok = (C % 4 == 0 and H * C <= 1024 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
           and b.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
     if not ok or not GAT_ITEM_SCANS:
-        return gat_rowdot(a, b, bias, H, C), (colsum(a) if want_colsum else None)
+        if relu_mask:
+            a = torch.ops.aten.threshold_backward(a, b, 0)
+        res = (gat_rowdot(a, b, bias, H, C), (colsum(a) if want_colsum else None))
+        return res + (a,) if relu_mask else res
     D = torch.empty((N, H), dtype=torch.float32, device=dev)
     cs = torch.empty(H * C, dtype=torch.float32, device=dev) if want_colsum else None
+    am = torch.empty((N, H * C), dtype=torch.float32, device=dev) if relu_mask else None
     n_ws = int(lib.npi_gat_rowdot_colsum_workspace_elems(N, H, C)) if want_colsum else 0
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
-    check(lib.npi_gat_rowdot_colsum(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), N, H, C, ptr(D), ptr(cs), ptr(ws),
-                                    n_ws, stream_ptr(dev)), "npi_gat_rowdot_colsum")
-    return D, cs
+    check(lib.npi_gat_rowdot_colsum_relu(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), N, H, C, ptr(D), ptr(cs), ptr(am),
+                                         am.stride(0) if am is not None else 0, ptr(ws), n_ws, stream_ptr(dev)),
+          "npi_gat_rowdot_colsum")
+    return (D, cs, am) if relu_mask else (D, cs)
 
 
-def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=None, out=None):
+def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=None, out=None, relu: bool = False):
     """One head: out[r] = sum_p exp(scores[p] - m[r]) / (s[r] + 1e-16) table[col p] (+ bias) over the entries of row r, the
     per-entry scores coming from ``gat_softmax_stats(..., want_scores=True)``; ``table2``: second part of a two-part table."""
     dev = table.device
@@ -623,12 +630,13 @@ def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=Non
     if out is None:
         out = torch.empty((side.n_rows, C), dtype=torch.float32, device=dev)
     if side.nnz_max == 0:
-        return out.zero_() if bias is None else out.copy_(bias.view(1, -1).expand_as(out))
+        out = out.zero_() if bias is None else out.copy_(bias.view(1, -1).expand_as(out))
+        return out.clamp_(min=0) if relu else out
     with _tag_events("gat_fwd_aggregate", dev):
         check(load().npi_gat_aggregate_scores(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
                                               ptr(table), table.stride(0), ptr(table2), table.size(0) if table2 is not None else 0,
-                                              ptr(out), out.stride(0), C, ptr(scores), ptr(m), ptr(s), ptr(bias), None,
-                                              ptr(side.carry(C)), stream_ptr(dev)), "npi_gat_aggregate_scores")
+                                              ptr(out), out.stride(0), C, ptr(scores), ptr(m), ptr(s), ptr(bias), 1 if relu else 0,
+                                              None, ptr(side.carry(C)), stream_ptr(dev)), "npi_gat_aggregate_scores")
     return out
 
 
@@ -729,7 +737,7 @@ class _GatConvFn(torch.autograd.Function):
     """Returns the concatenated heads [N, H*C] (bias fused when given)."""
 
     @staticmethod
-    def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float):
+    def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float, relu: bool = False):
         H = int(heads)
         C = weight.size(1) // H
         att2 = _f32c(att.reshape(H, 2 * C), "att")
@@ -748,12 +756,15 @@ class _GatConvFn(torch.autograd.Function):
             with _tag_events("gat_fwd_aggregate", x.device):
                 check(load().npi_gat_aggregate_scores(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), d.n_rows, d.nnz_max,
                                                       ptr(hfeat), hfeat.stride(0), None, 0, ptr(out), out.stride(0), C,
-                                                      ptr(scores), ptr(m), ptr(s), ptr(bias), ptr(alpha), ptr(d.carry(C)),
-                                                      stream_ptr(x.device)), "npi_gat_aggregate_scores")
+                                                      ptr(scores), ptr(m), ptr(s), ptr(bias), 1 if relu else 0, ptr(alpha),
+                                                      ptr(d.carry(C)), stream_ptr(x.device)), "npi_gat_aggregate_scores")
             del scores
         else:
             m, s = gat_softmax_stats(d, a_dst, a_src, H, slope)
             out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias, alpha=alpha)
+            if relu:                                     # several heads / odd widths: the ReLU as its own pass
+                out = torch.relu_(out)
+        ctx.relu = bool(relu)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
         ctx.has_bias = bias is not None
         ctx.fused = fused
@@ -771,8 +782,13 @@ class _GatConvFn(torch.autograd.Function):
         grad_out = _f32c(grad_out, "grad_out")
         d, sr = graph.by_dst, graph.by_src
         # D_i = <dOut_i, out_i - b> = sum_p alpha_p dalpha_p  (softmax backward) and db = column sums of dOut: one pass
-        D, db = gat_rowdot_colsum(grad_out, out, bias if ctx.has_bias else None, H, C,
-                                  want_colsum=ctx.has_bias and ctx.needs_input_grad[3])
+        # (a fused ReLU: the same pass masks the gradient first and hands the masked gradient on)
+        if ctx.relu:
+            D, db, grad_out = gat_rowdot_colsum(grad_out, out, bias if ctx.has_bias else None, H, C,
+                                                want_colsum=ctx.has_bias and ctx.needs_input_grad[3], relu_mask=True)
+        else:
+            D, db = gat_rowdot_colsum(grad_out, out, bias if ctx.has_bias else None, H, C,
+                                      want_colsum=ctx.has_bias and ctx.needs_input_grad[3])
         if ctx.fused:
             N = graph.num_nodes
             dz = torch.empty(max(sr.nnz_max, 1), dtype=torch.float32, device=dev)
@@ -803,7 +819,7 @@ class _GatConvFn(torch.autograd.Function):
             datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C) if ctx.needs_input_grad[2] else None
             dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
             dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
-            return dx, dw, datt, db, None, None, None
+            return dx, dw, datt, db, None, None, None, None
         # dz per by-target entry, then its row sums in both orientations;
         # one head: keep the alpha this kernel computes; the by-source pass reads it back through the transpose map
         alpha = torch.empty((max(d.nnz_max, 1), H), dtype=torch.float32, device=dev) if H == 1 else None
@@ -822,17 +838,20 @@ class _GatConvFn(torch.autograd.Function):
             dw, _ = linear_bwd_weight(x, dh, want_bias=False)
         if ctx.needs_input_grad[0]:
             dx = linear_bwd_data(dh, weight)
-        return dx, dw, datt, db, None, None, None
+        return dx, dw, datt, db, None, None, None, None
 
 
 def gat_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, att: torch.Tensor,
              bias: Optional[torch.Tensor] = None, heads: int = 1, concat: bool = True,
-             negative_slope: float = 0.2) -> torch.Tensor:
-    """PyG 1.4.2 ``GATConv.forward`` (dropout = 0) on MI355X; ``att`` is ``[1, H, 2C]``."""
+             negative_slope: float = 0.2, relu: bool = False) -> torch.Tensor:
+    """PyG 1.4.2 ``GATConv.forward`` (dropout = 0) on MI355X; ``att`` is ``[1, H, 2C]``.  ``relu=True`` (an extension, as in
+    ``sage_conv``): ``F.relu(conv(x, edge_index))`` with the ReLU in the aggregation's row epilogue and its backward mask in the
+    pass that computes the softmax term -- one head; other shapes apply it as a separate pass."""
     require_gpu(x, weight, att, bias)
     graph = as_graph(edge_index, x.size(0))
     if concat:
-        return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope)
-    out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope)
+        return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope, relu)
+    out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope, False)
     out = out.view(x.size(0), heads, -1).mean(dim=1)          # head average (concat=False)
-    return out + bias if bias is not None else out
+    out = out + bias if bias is not None else out
+    return torch.relu(out) if relu else out

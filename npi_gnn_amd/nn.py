@@ -100,11 +100,12 @@ class GATConv(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
-    def forward(self, x, edge_index, size=None):
+    def forward(self, x, edge_index, size=None, *, relu: bool = False):
+        """``relu=True`` (an extension of the PyG signature, as in ``SAGEConv``): ``F.relu(conv(x, edge_index))`` fused."""
         if size is not None:
             raise NotImplementedError("GATConv: bipartite `size` is not implemented")
         return F_.gat_conv(x, edge_index, self.weight, self.att, self.bias, self.heads, self.concat,
-                           self.negative_slope)
+                           self.negative_slope, relu=relu)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"

@@ -149,3 +149,23 @@ def test_rowdot_and_bias_gradient_in_one_pass(dev, N, H, C):
     D2, none = NF.gat_rowdot_colsum(a, b, None, H, C, want_colsum=False)
     assert none is None and torch.allclose(D2.double(), (a.double().view(N, H, C) * b.double().view(N, H, C)).sum(-1), rtol=1e-5, atol=1e-4)
     assert torch.equal(NF.gat_rowdot_colsum(a, b, bias, H, C)[1], cs)
+
+
+@pytest.mark.parametrize("H,C", [(1, 256), (1, 64), (2, 32), (1, 300)])
+def test_fused_relu_equals_relu_behind_the_layer(dev, H, C):
+    """gat_conv(..., relu=True) == F.relu(gat_conv(...)): output and every gradient (the ReLU in the aggregation's row
+    epilogue, its mask in the rowdot / bias-gradient pass; several heads and odd widths take a separate pass)."""
+    N, E, Fi = 3000, 40000, 64
+    ei, x, W, att, b, go = _case(N, E, Fi, H, C, seed=H * 100 + C)
+    res = []
+    for fused in (False, True):
+        xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+        out = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=H, relu=fused)
+        if not fused:
+            out = torch.relu(out)
+        out.backward(go.to(dev))
+        res.append((out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad))
+    assert bool((res[1][0] >= 0).all()) and float((res[1][0] == 0).float().mean()) > 0.2      # a real ReLU
+    assert torch.equal(res[0][0], res[1][0])
+    for a, c in zip(res[0][1:], res[1][1:]):
+        assert torch.allclose(a, c, rtol=1e-5, atol=1e-6 * float(a.abs().max()))
