@@ -384,3 +384,69 @@ def test_routed_partition_equals_the_full_list_masks(world, N, kind):
     assert total_edges == int(keep.sum())                    # the edge slices partition the non-loop edges
     with pytest.raises(ValueError):                          # a slice without a process group cannot be routed
         ND.ShardedGraph(ei[:, :10], N, 0, 2, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub, sliced=True)
+
+
+def _stack_worker(rank, world, port, N, E, Fd, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ei, x, W, b, go, hub = _case(N, E, Fd, "bipartite")
+        Et = ei.size(1)
+        sg = ND.ShardedGraph(ei[:, rank * Et // world: (rank + 1) * Et // world], N, rank, world, torch.device("cpu"),
+                             backend=TorchBackend(), hub_mask=hub, sliced=True)
+        g = torch.Generator().manual_seed(11)
+        Ws = [torch.randn(Fd, Fd, generator=g) / Fd ** 0.5 for _ in range(3)]
+        bs = [torch.randn(Fd, generator=g) * 0.1 for _ in range(3)]
+        if kind == "gat":
+            layers = [ND.ShardedGATLayer(sg, Ws[k], _att(Fd, 1, seed=20 + k), bs[k], heads=1) for k in range(3)]
+        else:
+            layers = [ND.ShardedSAGELayer(sg, Ws[k], bs[k]) for k in range(3)]
+        xl = sg.shard(x).clone().requires_grad_(True)
+        hcur = xl
+        for layer in layers:                                   # a rank's output rows ARE the next layer's input rows
+            hcur = torch.relu(layer(hcur))
+        hcur.backward(sg.shard(go))
+        q.put((rank, hcur.detach().numpy().copy(), xl.grad.numpy().copy(),
+               [l.weight.grad.numpy().copy() for l in layers]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "gat"), (4, "sage"), (8, "gat")])
+def test_three_sharded_layers_chain_like_the_single_process_stack(world, kind):
+    """BASELINE.json configs[4]'s 8-GPU form is a 3-layer GATConv stack: sharded layers compose directly (rows in = rows out,
+    nothing is re-partitioned between layers); forward and every gradient of the chain against the single-process oracle."""
+    N, E, Fd = 160, 900, 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stack_worker, args=(r, world, port, N, E, Fd, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        got = q.get(timeout=180)
+        res[got[0]] = got[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ei, x, W, b, go, hub = _case(N, E, Fd, "bipartite")
+    g = torch.Generator().manual_seed(11)
+    Ws = [torch.randn(Fd, Fd, generator=g).div(Fd ** 0.5).requires_grad_(True) for _ in range(3)]
+    bs = [torch.randn(Fd, generator=g) * 0.1 for _ in range(3)]
+    xr = x.clone().requires_grad_(True)
+    hcur = xr
+    for k in range(3):
+        hcur = torch.relu(R.gat_conv(hcur, ei, Ws[k], _att(Fd, 1, seed=20 + k), bs[k], heads=1) if kind == "gat"
+                          else R.sage_conv(hcur, ei, Ws[k], bs[k]))
+    hcur.backward(go)
+    part = ND.HubPartition(N, world, hub)
+    out = part.unshard([torch.from_numpy(res[r][0]) for r in range(world)])
+    dx = part.unshard([torch.from_numpy(res[r][1]) for r in range(world)])
+    assert torch.allclose(out, hcur.detach(), atol=1e-5, rtol=1e-4)
+    assert torch.allclose(dx, xr.grad, atol=1e-5, rtol=1e-4)
+    for r in range(world):
+        for k in range(3):
+            assert torch.allclose(torch.from_numpy(res[r][2][k]), Ws[k].grad, atol=1e-4, rtol=1e-4)
