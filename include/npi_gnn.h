@@ -41,7 +41,7 @@ extern "C" {
 
 /* edges of the self-loop-augmented CSR that one wavefront ("item") reduces */
 #ifndef NPI_ITEM_EDGES
-#define NPI_ITEM_EDGES 256    /* large graphs; CSRs with capacity nnz_max < 2^20 use 64 (npi_item_edges) */
+#define NPI_ITEM_EDGES 256    /* large graphs; CSRs with capacity nnz_max < 2^22 use 64 (npi_item_edges, npi_small_graph_entries) */
 #endif
 
 /* data types of feature matrices */
@@ -75,6 +75,10 @@ int npi_abi_version(void);
  * ------------------------------------------------------------------------------------------ */
 int64_t npi_csr_workspace_bytes(int64_t E, int64_t N);
 int64_t npi_item_edges(int64_t nnz_max);   /* entries per item for a CSR of capacity nnz_max: 64 or NPI_ITEM_EDGES */
+/* the capacity below which a CSR is cut into 64-entry items (default 2^22; NPI_SMALL_GRAPH_ENTRIES in the environment presets
+ * it): n > 0 sets it and returns the previous value, n <= 0 only returns it.  Process-wide; change it only between graph
+ * builds -- a CSR (item_row, carry) built under one value must be consumed under the same one. */
+int64_t npi_small_graph_entries(int64_t n);
 int64_t npi_num_items(int64_t nnz_max);
 int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
                   int add_self_loops,

@@ -29,6 +29,7 @@ PROTOTYPES = {
     "npi_abi_version": (c_int, []),
     "npi_csr_workspace_bytes": (_I, [_I, _I]),
     "npi_item_edges": (_I, [_I]),
+    "npi_small_graph_entries": (_I, [_I]),
     "npi_num_items": (_I, [_I]),
     "npi_csr_build": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "npi_csr_build_ex": (c_int, [_P, _P, _I, _I, _I, c_int, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

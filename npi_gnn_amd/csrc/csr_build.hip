@@ -20,6 +20,13 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int64_t g_small_graph_entries = [] {
+    const char* e = getenv("NPI_SMALL_GRAPH_ENTRIES");
+    const long long n = e ? atoll(e) : 0;
+    return n > 0 ? (int64_t)n : NPI_SMALL_GRAPH_ENTRIES;
+}();
+int64_t small_graph_entries() { return g_small_graph_entries; }
+
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;
 constexpr int SORT_ITEMS = 16;                       // keys per lane
@@ -395,6 +402,11 @@ extern "C" int64_t npi_csr_workspace_bytes(int64_t E, int64_t N) {
 }
 
 extern "C" int64_t npi_item_edges(int64_t nnz_max) { return npi::item_edges_for(nnz_max); }
+extern "C" int64_t npi_small_graph_entries(int64_t n) {
+    const int64_t prev = npi::g_small_graph_entries;
+    if (n > 0) npi::g_small_graph_entries = n;
+    return prev;
+}
 
 extern "C" int64_t npi_num_items(int64_t nnz_max) {
     return nnz_max <= 0 ? 0 : ceil_div(nnz_max, (int64_t)npi::item_edges_for(nnz_max));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/npi_gnn.h"
 
 namespace npi {
@@ -44,8 +45,14 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // (the reference's 200-subgraph batches, the bundled full graphs) get 64-entry items -- four times as many
 // wavefronts, a quarter of the serial chain each -- large ones NPI_ITEM_EDGES.  Every entry point derives it
 // from the same nnz_max, so item_row, carry and the kernels always agree.
-constexpr int64_t NPI_SMALL_GRAPH_ENTRIES = 1 << 20;
-__host__ __device__ inline int item_edges_for(int64_t nnz_max) { return nnz_max < NPI_SMALL_GRAPH_ENTRIES ? 64 : NPI_ITEM_EDGES; }
+// Host-side decision (every kernel receives the item size as an argument).  Round 3: the switch moved from 2^20 to 2^22
+// entries -- the per-rank sides of a sharded graph (1.2-2.6 M entries at C4 with 8 ranks) were launched as ~5 k wavefronts of
+// 256 entries, a fraction of one wave per SIMD slot: a rank's SAGE step 1.19 -> 1.15 ms, its GAT step 1.97 -> 1.80 ms with
+// 64-entry items; 2^24 changes nothing at 5 M entries and costs 4 % at 10 M.  One process-wide value (csr_build.hip):
+// npi_small_graph_entries(n) sets it (tests), NPI_SMALL_GRAPH_ENTRIES=<n> in the environment presets it.
+constexpr int64_t NPI_SMALL_GRAPH_ENTRIES = (int64_t)1 << 22;
+int64_t small_graph_entries();
+inline int item_edges_for(int64_t nnz_max) { return nnz_max < small_graph_entries() ? 64 : NPI_ITEM_EDGES; }
 
 }  // namespace npi
 

@@ -37,14 +37,18 @@ def test_size_queries_without_gpu():
     lib = _lib.load()
     assert lib.npi_abi_version() == 1
     assert lib.npi_num_items(0) == 0
-    # small CSRs (capacity < 2^20 entries) are cut into 64-entry items, large ones into 256-entry items
-    assert lib.npi_item_edges(1000) == 64 and lib.npi_item_edges((1 << 20) - 1) == 64
-    assert lib.npi_item_edges(1 << 20) == 256 and lib.npi_item_edges(21_000_000) == 256
+    # small CSRs (capacity < 2^22 entries by default) are cut into 64-entry items, large ones into 256-entry items
+    T = int(lib.npi_small_graph_entries(0))
+    assert T == 1 << 22
+    assert lib.npi_item_edges(1000) == 64 and lib.npi_item_edges(T - 1) == 64
+    assert lib.npi_item_edges(T) == 256 and lib.npi_item_edges(21_000_000) == 256
+    assert lib.npi_small_graph_entries(1 << 20) == T and lib.npi_item_edges(1 << 20) == 256      # settable (tests of 256-entry items)
+    assert lib.npi_small_graph_entries(T) == 1 << 20 and lib.npi_item_edges(1 << 20) == 64
     assert lib.npi_num_items(1) == 1
     assert lib.npi_num_items(64) == 1
     assert lib.npi_num_items(65) == 2
-    assert lib.npi_num_items(1 << 20) == (1 << 20) // 256
-    assert lib.npi_num_items((1 << 20) + 1) == (1 << 20) // 256 + 1
+    assert lib.npi_num_items(T) == T // 256
+    assert lib.npi_num_items(T + 1) == T // 256 + 1
     assert lib.npi_csr_workspace_bytes(1000, 10) > 16 * 1000
     assert lib.npi_segsum_carry_elems(1000, 256) == 2 * 16 * 256
     assert lib.npi_linear_bwd_weight_workspace_elems(1000, 256, 256) >= 256 * 256

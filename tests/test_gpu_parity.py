@@ -62,10 +62,10 @@ def test_csr_build_is_bit_exact(dev, N, E, loops):
         assert np.array_equal(side.col.cpu().numpy()[:nnz], col)
         assert np.array_equal(side.eid.cpu().numpy()[:nnz], eid)
         assert np.array_equal(side.rowidx.cpu().numpy()[:nnz], rowidx)
-        # item_row[i] = row holding entry item_edges * i (64-entry items below 2^20 entries of capacity, else 256)
+        # item_row[i] = row holding entry item_edges * i (64-entry items below npi_small_graph_entries of capacity, else 256)
         from npi_gnn_amd._lib import load as _load
         item_edges = int(_load().npi_item_edges(side.nnz_max))
-        assert item_edges == (64 if side.nnz_max < (1 << 20) else 256)
+        assert item_edges == (64 if side.nnz_max < int(_load().npi_small_graph_entries(0)) else 256)
         ir = side.item_row.cpu().numpy()
         for i in range(1, side.n_items):
             k = item_edges * i
