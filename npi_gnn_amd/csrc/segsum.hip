@@ -557,11 +557,18 @@ __device__ __forceinline__ bool fix_owner(const SegParams& P, int item, int nnz,
     return true;
 }
 
+// Waves per fix-up workgroup: the long chain of a hub row (1,600 partial rows at C4) is summed by ONE workgroup, every wave
+// a slice with FIX_U row loads in flight -- a latency chain.  With one 256-column chunk per lane the kernel needs < 64 VGPRs, so
+// the workgroup is 16 waves (1,024 threads) instead of 4: the hub chain's slices shrink from 400 to 100 partials (72 -> ~25 us
+// per launch at C4); wider rows keep 4 waves (their staging registers would not fit 1,024 threads).
+template <int NCH> struct fix_waves { static constexpr int value = NCH == 1 ? 16 : SEG_WAVES; };
+
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
-__global__ void __launch_bounds__(SEG_THREADS)
+__global__ void __launch_bounds__(fix_waves<NCH>::value * WAVE)
 segsum_fixup_kernel(SegParams P) {
+    constexpr int FW = fix_waves<NCH>::value;
     __shared__ int s_row[FIX_SPAN], s_rs[FIX_SPAN], s_re[FIX_SPAN], s_len[FIX_SPAN];
-    __shared__ float red[SEG_WAVES][NCH * VEC * WAVE];
+    __shared__ float red[FW][NCH * VEC * WAVE];
     const int lane = lane_id();
     const int wave = uniform_i(threadIdx.x >> 6);
     const int base = blockIdx.x * FIX_SPAN;
@@ -577,7 +584,7 @@ segsum_fixup_kernel(SegParams P) {
     Lanes<VEC, NCH, WMODE, EXACT> L;
     L.init(P);
     // short chains: one wave each
-    for (int q = wave; q < FIX_SPAN; q += SEG_WAVES) {
+    for (int q = wave; q < FIX_SPAN; q += FW) {
         const int r = s_row[q], len = s_len[q];
         if (r < 0 || len >= FIX_COOP_MIN) continue;              // wave-uniform
         const int item = base + q;
@@ -609,7 +616,7 @@ segsum_fixup_kernel(SegParams P) {
         const int r = s_row[q], len = s_len[q];
         if (r < 0 || len < FIX_COOP_MIN) continue;               // workgroup-uniform
         const int item = base + q;
-        const int per = (len + SEG_WAVES - 1) / SEG_WAVES;
+        const int per = (len + FW - 1) / FW;
         const int jb = item + 1 + wave * per;
         const int je = min(jb + per, item + len + 1);
         float acc[NCH][VEC];
@@ -665,7 +672,7 @@ segsum_fixup_kernel(SegParams P) {
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int w = 1; w < SEG_WAVES; ++w)
+            for (int w = 1; w < FW; ++w)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -678,7 +685,7 @@ segsum_fixup_kernel(SegParams P) {
 
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 static void launch_fixup(const SegParams& P, hipStream_t stream) {
-    segsum_fixup_kernel<T, VEC, NCH, WMODE, EXACT><<<dim3((unsigned)ceil_div(P.n_items, FIX_SPAN)), dim3(SEG_THREADS), 0, stream>>>(P);
+    segsum_fixup_kernel<T, VEC, NCH, WMODE, EXACT><<<dim3((unsigned)ceil_div(P.n_items, FIX_SPAN)), dim3(fix_waves<NCH>::value * WAVE), 0, stream>>>(P);
 }
 
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>

@@ -11,7 +11,8 @@ mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 objs=""
-for f in csr_build segsum gemm_f32 graph_ops gat pool subgraph head; do
+# the library's own source list (npi_gnn_amd/build.py), so that a new .hip file cannot be forgotten here
+for f in $(cd "$ROOT" && python3 -c "from npi_gnn_amd.build import SOURCES; print(' '.join(s[:-4] for s in SOURCES))"); do
   $HIPCC -O1 -g -fno-gpu-sanitize -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -fno-omit-frame-pointer \
          -fsanitize=address,undefined -fno-sanitize-recover=undefined -shared-libasan \
          -c "$ROOT/npi_gnn_amd/csrc/$f.hip" -o "$OUT/$f.o" &
