@@ -357,6 +357,35 @@ def _stack_forward(kind, weights, x, graph, dtype=torch.float32, norm=None):
     return h.float().cpu()
 
 
+def virtual_c5(dev, ei5, N5, F5, weights, att, t1_ms, W):
+    from npi_gnn_amd import dist as ND
+    from npi_gnn_amd.synth import protein_mask
+    hub = protein_mask(N5).to(dev)
+    per_rank, nnz, coll = [], [], None
+    with stub_collectives(W) as stub:
+        for r in range(W):
+            sg = ND.ShardedGraph(ei5, N5, r, W, dev, hub_mask=hub)
+            layers = [ND.ShardedGATLayer(sg, Wk.to(dev), att[k].to(dev), bk.to(dev)) for k, (Wk, bk) in enumerate(weights)]
+            x = torch.randn(sg.n_local, F5, device=dev).requires_grad_(True)
+
+            def step():
+                for l in layers:
+                    l.zero_grad()
+                x.grad = None
+                h = x
+                for l in layers:
+                    h = torch.relu(l(h))
+                h.pow(2).mean().backward()
+            ms, one = time_virtual_rank(step, stub, steps=2, warm=1)
+            per_rank.append(ms)
+            nnz.append(int(sg.local_nnz))
+            coll = coll or one
+            del sg, layers, x, step
+            torch.cuda.empty_cache()
+    return virtual_summary(W, t1_ms, per_rank, nnz, coll, "3 x GATConv 256 (1 head) on the hub cut, N=4M E=100M, per-rank step of the "
+                           f"{W}-rank run timed alone on this GPU (collectives = local copies); T1 = C5_1gpu")
+
+
 def run_configs(dev, args, c4):
     """ms per full-batch step (fwd+bwd over the layer stack) and, for C1-C3, the max error against the oracle outputs
     committed under tests/golden/ (made by tests/golden/make_golden.py / make_rpi7317.py from the CPU oracle)."""
@@ -523,7 +552,6 @@ def run_configs(dev, args, c4):
             ei5 = bipartite_edge_index(N5, E5, seed=2).to(dev)
             g5 = npi.CSRGraph(ei5, N5)
             _ = g5.by_src
-            del ei5
             weights = [((torch.randn(F5, F5, generator=gen) / 16), torch.zeros(F5)) for _ in range(3)]
             att = [torch.randn(1, 1, 2 * F5, generator=gen) * 0.1 for _ in range(3)]
             x5 = torch.randn(N5, F5, generator=gen).to(dev)
@@ -537,8 +565,19 @@ def run_configs(dev, args, c4):
             gb = gat_bytes(E5, N5, F5)
             roof = {tag: agg_roofline(tags.get(tag, []), gb[tag], None, "as configs.gat_c4.roofline, at the C5 size (3 launches, one "
                                       "per layer)", "no PMC pass at this size: algorithmic bytes only") for tag in gb}
-            return {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU",
+            res5 = {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU",
                     "ms_per_step": ms, "edge_layers_per_s": 3 * E5 / ms * 1e3, "roofline": roof}
+            del st, x5, g5
+            torch.cuda.empty_cache()
+            if args.virtual_world > 1:
+                # BASELINE.json configs[4] in its 8-GPU form, rank by rank on this GPU: the same 3-layer GATConv stack on the
+                # hub cut, a rank's output rows being the next layer's input rows (collectives = local copies, as C4_w8_virtual)
+                try:
+                    res5["w8_virtual"] = virtual_c5(dev, ei5, N5, F5, weights, att, ms, args.virtual_world)
+                except Exception as e:
+                    res5["w8_virtual"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            del ei5
+            return res5
         guarded("C5_1gpu", c5)
     return out
 
@@ -610,6 +649,86 @@ def sharded_parity(dev, args, world, sg, layer, x, go, ei, x_full, go_full, W, b
 # ---------------------------------------------------------------------------------------------------------
 # virtual world: the W shards of the multi-GPU path, one after the other on this ONE GPU
 # ---------------------------------------------------------------------------------------------------------
+class stub_collectives:
+    """Replace the collectives of npi_gnn_amd.dist by local copies of the same shapes (one GPU stands in for rank r of W) and
+    log what every call would move: payload bytes, and bytes on the wire per rank (an all-gather / reduce-scatter of S bytes
+    moves S (W-1)/W per rank, an all-reduce 2 S (W-1)/W)."""
+
+    def __init__(self, W):
+        self.W, self.log = W, {}
+
+    def note(self, kind, nbytes, wire):
+        e = self.log.setdefault(kind, {"calls": 0, "payload_bytes": 0, "wire_bytes_per_rank": 0})
+        e["calls"] += 1
+        e["payload_bytes"] += nbytes
+        e["wire_bytes_per_rank"] += wire
+
+    def __enter__(self):
+        from npi_gnn_amd import dist as ND
+        frac = (self.W - 1) / self.W
+        me = self
+
+        class _Done:
+            def wait(self):
+                return True
+
+        def ag(block, out, w, group=None, async_op=False):
+            nb = out.numel() * out.element_size()
+            me.note("all_gather", nb, nb * frac)
+            out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1))
+            return _Done() if async_op else None
+
+        def rs(part_sums, out, rank, w, group=None, async_op=False):
+            nb = part_sums.numel() * part_sums.element_size()
+            me.note("reduce_scatter", nb, nb * frac)
+            out.copy_(part_sums.view(w, -1)[rank].view_as(out))
+            return _Done() if async_op else None
+
+        def ar(t, w, group=None, op=None, tag="all_reduce"):
+            nb = t.numel() * t.element_size()
+            me.note("all_reduce", nb, 2 * nb * frac)
+
+        self.saved = (ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo)
+        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce = ag, rs, ar
+        ND._solo = lambda w: False
+        return self
+
+    def __exit__(self, *exc):
+        from npi_gnn_amd import dist as ND
+        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo = self.saved
+        return False
+
+
+def virtual_summary(W, t1, per_rank, nnz, coll, what):
+    worst = max(per_rank)
+    wire = sum(v["wire_bytes_per_rank"] for v in coll.values())
+    budget = t1 / 6.0 - worst
+    return {"what": what, "world": W, "t1_ms": t1, "per_rank_ms": per_rank, "per_rank_entries": nnz,
+            "balance": sum(per_rank) / len(per_rank) / worst, "compute_ceiling": t1 / worst,
+            "bytes_per_collective": coll, "wire_bytes_per_rank_per_step": wire,
+            "exposed_budget_ms_for_6x": budget,
+            "implied_bus_GBps": {"all_communication_hidden_under_T1_over_6": wire / (t1 / 6.0 * 1e-3) / 1e9,
+                                 "no_overlap_inside_the_exposed_budget": (wire / (budget * 1e-3) / 1e9) if budget > 0 else None}}
+
+
+def time_virtual_rank(step, stub, steps=5, warm=3):
+    for _ in range(warm):
+        step()
+    stub.log.clear()
+    step()                                                  # the collectives of ONE step, by kind
+    one = {k: dict(v) for k, v in stub.log.items()}
+    best = None
+    for _ in range(3):                                      # best of three regions (a shared box: see _timeit)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps * 1e3
+        best = dt if best is None or dt < best else best
+    return best, one
+
+
 def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
     """SURVEY.md 8(e), what one GPU can measure of the W-GPU run: every rank's LOCAL work (its shard's kernels, host
     launch work included) timed alone on this GPU with the collectives replaced by local copies of the same shapes, for
@@ -624,68 +743,6 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
     Wm = ((torch.rand(F, F, generator=gen) * 2 - 1) / F ** 0.5).to(dev)
     bias = ((torch.rand(F, generator=gen) * 2 - 1) / F ** 0.5).to(dev)
     att = (torch.randn(1, 1, 2 * F, generator=gen) * 0.1).to(dev)
-    log = {}
-
-    class _Done:
-        def wait(self):
-            return True
-
-    def note(kind, nbytes, wire):
-        e = log.setdefault(kind, {"calls": 0, "payload_bytes": 0, "wire_bytes_per_rank": 0})
-        e["calls"] += 1
-        e["payload_bytes"] += nbytes
-        e["wire_bytes_per_rank"] += wire
-
-    frac = (W - 1) / W
-
-    def ag(block, out, w, group=None, async_op=False):
-        nb = out.numel() * out.element_size()
-        note("all_gather", nb, nb * frac)
-        out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1))
-        return _Done() if async_op else None
-
-    def rs(part_sums, out, rank, w, group=None, async_op=False):
-        nb = part_sums.numel() * part_sums.element_size()
-        note("reduce_scatter", nb, nb * frac)
-        out.copy_(part_sums.view(w, -1)[rank].view_as(out))
-        return _Done() if async_op else None
-
-    def ar(t, w, group=None, op=None, tag="all_reduce"):
-        nb = t.numel() * t.element_size()
-        note("all_reduce", nb, 2 * nb * frac)
-
-    def time_rank(layer, x, go, steps=5, warm=3):
-        def step():
-            layer.zero_grad()
-            x.grad = None
-            layer(x).backward(go)
-        for _ in range(warm):
-            step()
-        log.clear()
-        step()                                                  # the collectives of ONE step, by kind
-        one = {k: dict(v) for k, v in log.items()}
-        best = None
-        for _ in range(3):                                      # best of three regions (a shared box: see _timeit)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps * 1e3
-            best = dt if best is None or dt < best else best
-        return best, one
-
-    def summary(name, t1, per_rank, nnz, coll, note_):
-        worst = max(per_rank)
-        wire = sum(v["wire_bytes_per_rank"] for v in coll.values())
-        budget = t1 / 6.0 - worst
-        return {"what": note_, "world": W, "t1_ms": t1, "per_rank_ms": per_rank, "per_rank_entries": nnz,
-                "balance": sum(per_rank) / len(per_rank) / worst, "compute_ceiling": t1 / worst,
-                "bytes_per_collective": coll, "wire_bytes_per_rank_per_step": wire,
-                "exposed_budget_ms_for_6x": budget,
-                "implied_bus_GBps": {"all_communication_hidden_under_T1_over_6": wire / (t1 / 6.0 * 1e-3) / 1e9,
-                                     "no_overlap_inside_the_exposed_budget": (wire / (budget * 1e-3) / 1e9) if budget > 0 else None}}
-
     # T1 of the plain GATConv on this graph (the SAGE T1 is the headline measurement)
     conv = npi.GATConv(F, F, heads=1).to(dev)
     xx = c4["x"].detach().requires_grad_(True)
@@ -698,11 +755,8 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
     t1_gat = _timeit(gat_step, 5, 2)
     del conv, xx
 
-    saved = (ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo)
-    ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce = ag, rs, ar
-    ND._solo = lambda w: False
     out = {}
-    try:
+    with stub_collectives(W) as stub:
         hub = protein_mask(N).to(dev)
         in_count = torch.bincount(ei_dev[1][ei_dev[0] != ei_dev[1]], minlength=N)
         res = {k: ([], [], None) for k in ("hubs_sage", "hubs_gat", "rows_sage", "edges_sage")}
@@ -721,7 +775,11 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
                     if partition == "hubs":
                         layers.append(("hubs_gat", ND.ShardedGATLayer(sg, Wm, att, bias)))
                 for key, layer in layers:
-                    ms, coll = time_rank(layer, x, go)
+                    def step(layer=layer, x=x, go=go):
+                        layer.zero_grad()
+                        x.grad = None
+                        layer(x).backward(go)
+                    ms, coll = time_virtual_rank(step, stub)
                     res[key][0].append(ms)
                     res[key][1].append(int(sg.local_nnz))
                     if r == 0:
@@ -734,9 +792,7 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
                                "all-reduce of the partial [N,F] sums per direction",
                  "hubs_gat": "GATConv (1 head), vertex cut with the cross-rank softmax"}
         for key, (ms, nnz, coll) in res.items():
-            out[key] = summary(key, t1_gat if key == "hubs_gat" else t1_sage_ms, ms, nnz, coll, notes[key])
-    finally:
-        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo = saved
+            out[key] = virtual_summary(W, t1_gat if key == "hubs_gat" else t1_sage_ms, ms, nnz, coll, notes[key])
     out["note"] = ("one GPU, ranks run one after the other; collectives are local copies of the same shapes, so per_rank_ms "
                    "is local compute + host launch work only; wire bytes: all-gather / reduce-scatter of S bytes move "
                    "S (W-1)/W per rank, an all-reduce 2 S (W-1)/W; N > 1 itself is NOT measured here")
