@@ -317,6 +317,14 @@ int npi_gat_backward_fused_packed_ex(const int32_t* rowptr, const int32_t* col, 
                                      int64_t split, const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t C,
                                      const float* tpack, const float* a_src, float negative_slope, float* dz, float* carry,
                                      void* stream);
+/* ... and for SEVERAL heads (H in {1, 2, 4, 8}; for H > 1: C in {32, 64, 128}, H C <= 256): tpack is [n_cols, H, 4]
+ * (npi_gat_pack_targets over the N H flattened scalars), a_src [n_rows, H], dz [nnz_max, H]; every entry's H dots are reduced
+ * inside the C / 4 lanes of their head, alpha of every (entry, head) is computed once, by the lane that owns the entry. */
+int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                                 int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* dout2, int64_t split,
+                                 const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C,
+                                 const float* tpack, const float* a_src, float negative_slope, float* dz, float* carry,
+                                 void* stream);
 int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
                       int64_t N, int64_t H, int64_t C, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "npi_gat_backward_fused_packed": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, _P, _P]),
     "npi_gat_backward_fused_packed_ex": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, _P,
                                                  _P]),
+    "npi_gat_backward_fused_heads": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P, _P,
+                                             _P]),
     "npi_gat_rank1_add": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "npi_gat_edge_grad": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),

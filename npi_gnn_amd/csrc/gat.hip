@@ -853,25 +853,38 @@ extern "C" int npi_gat_backward_fused_packed_ex(const int32_t* rowptr, const int
                                                 int64_t ldd, const float* dout2, int64_t split, const float* hfeat, int64_t ldh,
                                                 float* out, int64_t ldo, int64_t C, const float* tpack, const float* a_src,
                                                 float slope, float* dz, float* carry, void* stream_) {
+    return npi_gat_backward_fused_heads(rowptr, col, rowidx, item_row, N, nnz_max, dout, ldd, dout2, split, hfeat, ldh, out, ldo, 1, C,
+                                        tpack, a_src, slope, dz, carry, stream_);
+}
+
+extern "C" int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                                            const int32_t* item_row, int64_t N, int64_t nnz_max, const float* dout,
+                                            int64_t ldd, const float* dout2, int64_t split, const float* hfeat, int64_t ldh,
+                                            float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack, const float* a_src,
+                                            float slope, float* dz, float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_backward_fused_packed: needs one head of <= 256 channels, C % 4 == 0");
+    const int64_t F = H * C;
+    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C % 4 == 0 && F <= 256, "npi_gat_backward_fused: needs heads * out_channels <= 256, out_channels % 4 == 0");
+    NPI_REQUIRE(H == 1 || ((H == 2 || H == 4 || H == 8) && C >= 32 && (C & (C - 1)) == 0),
+                "npi_gat_backward_fused_heads: several heads need 2 / 4 / 8 heads of 32 / 64 / 128 channels");
     NPI_REQUIRE(dout2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_backward_fused_packed_ex: bad split");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && col && rowidx && item_row && dout && hfeat && out && tpack && a_src && dz && carry,
                 "npi_gat_backward_fused_packed: null pointer");
-    NPI_REQUIRE(ldd >= C && ldh >= C && ldo >= C && ldh % 4 == 0 && ((uintptr_t)hfeat % 16) == 0 && ((uintptr_t)tpack % 16) == 0,
+    NPI_REQUIRE(ldd >= F && ldh >= F && ldo >= F && ldh % 4 == 0 && ((uintptr_t)hfeat % 16) == 0 && ((uintptr_t)tpack % 16) == 0,
                 "npi_gat_backward_fused_packed: leading dimension / alignment");
     SegParams P{};
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
     P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
-    P.x = dout; P.ldx = ldd; P.out = out; P.ldo = ldo; P.F = (int)C;
+    P.x = dout; P.ldx = ldd; P.out = out; P.ldo = ldo; P.F = (int)F;
     P.x2 = dout2; P.split = (int)split;              // rows gathered from a two-part table (the sharded layers), as npi_segsum_ex
     P.carry = carry; P.bias = nullptr;
-    P.H = 1; P.C = (int)C; P.a_src = a_src; P.slope = slope;
+    P.H = (int)H; P.C = (int)C; P.a_src = a_src; P.slope = slope;
     P.a_dst = a_src; P.m = a_src; P.s = a_src;                                 // unused in this mode
-    P.tpack = reinterpret_cast<const float4*>(tpack);                          // indexed by the COLUMN id (both parts: one array)
-    P.hrow = hfeat; P.ldh = ldh; P.rowidx = rowidx; P.dz_out = dz;
-    return segsum_run(P, W_GAT_SRC_FUSED, 0, nnz_max, NPI_F32, stream);
+    P.tpack = reinterpret_cast<const float4*>(tpack);                          // [n_cols, H, 4], indexed by the COLUMN id over both parts
+    P.hrow = hfeat; P.ldh = ldh; P.rowidx = rowidx; P.dz_out = dz;            // dz: [nnz_max, H]
+    const int mode = H == 1 ? W_GAT_SRC_FUSED : H == 2 ? W_GAT_SRC_FUSED_H2 : H == 4 ? W_GAT_SRC_FUSED_H4 : W_GAT_SRC_FUSED_H8;
+    return segsum_run(P, mode, 0, nnz_max, NPI_F32, stream);
 }
 
 extern "C" int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,

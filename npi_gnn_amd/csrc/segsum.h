@@ -4,7 +4,11 @@
 
 namespace npi {
 
-enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4, W_GAT_SRC_FUSED = 5, W_GAT_DST_PRE = 6 };
+enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4, W_GAT_SRC_FUSED = 5, W_GAT_DST_PRE = 6,
+       // the fused backward for 2 / 4 / 8 heads (packed form only; H C <= 256, C a power of two >= 32): compile-time head counts
+       W_GAT_SRC_FUSED_H2 = 7, W_GAT_SRC_FUSED_H4 = 8, W_GAT_SRC_FUSED_H8 = 9 };
+constexpr bool is_fused_mode(int m) { return m == W_GAT_SRC_FUSED || m >= W_GAT_SRC_FUSED_H2; }
+constexpr int fused_heads(int m) { return m == W_GAT_SRC_FUSED_H2 ? 2 : m == W_GAT_SRC_FUSED_H4 ? 4 : m == W_GAT_SRC_FUSED_H8 ? 8 : 1; }
 
 struct SegParams {
     const int32_t* rowptr;
@@ -46,7 +50,7 @@ struct SegParams {
     const float* Dt;         // [N] D of the column (target) nodes
     const int32_t* rowidx;   // row of every entry (the by-source CSR's rowidx)
     float* dz_out;           // [nnz_max] by-source entry order
-    // W_GAT_SRC_FUSED, packed form: (a_dst, m, 1 / (s + 1e-16), D) of every TARGET node as one float4 -- one 16-byte gather
+    // W_GAT_SRC_FUSED*, packed form: (a_dst, m, 1 / (s + 1e-16), D) of every TARGET node AND HEAD as one float4 ([N, H, 4]) -- one 16-byte gather
     // per entry replaces alpha through the transpose map (a random 4-byte read of an 84 MB array) + Dt + a_dst; w / wmap unused
     const float4* tpack;
 };

@@ -199,7 +199,8 @@ segsum_kernel(SegParams P) {
         for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
 
     // W_GAT_SRC_FUSED: per-entry dot products of one 64-entry block are parked here, then all 64 lanes turn them into dz
-    __shared__ float seg_pb[SEG_WAVES][WAVE];
+    constexpr int HH = fused_heads(WMODE);           // heads of the fused GAT backward (1 in every other mode)
+    __shared__ float seg_pb[SEG_WAVES][WAVE * HH];
     float* __restrict__ pb = seg_pb[threadIdx.x >> 6];
     float hr[VEC];                       // W_GAT_SRC_FUSED: this lane's columns of the open row's own features (h_j)
 #pragma unroll
@@ -215,7 +216,7 @@ segsum_kernel(SegParams P) {
                 rs_m[c] = P.m[i];
                 rs_i[c] = P.alpha_out ? 1.f / (P.s[i] + 1e-16f) : 0.f;
             }
-        } else if (WMODE == W_GAT_SRC_FUSED) {
+        } else if (is_fused_mode(WMODE)) {
             if (L.act[0]) load_row<VEC, float>(P.hrow + (int64_t)min(r, N - 1) * P.ldh + L.foff[0], hr);
         } else if (WMODE == W_GAT_SRC) {
 #pragma unroll
@@ -257,7 +258,7 @@ segsum_kernel(SegParams P) {
 
     // one gathered row (+ its weight) into the accumulators
     auto entry_weight = [&](int c, float g0, float g1, float g2, float ws) -> float {
-        if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) return ws;
+        if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || is_fused_mode(WMODE)) return ws;
         if (WMODE == W_GAT_DST_PRE) return expf(ws - rs_m[c]);          // ws = the entry's score, computed by the statistics pass
         if (WMODE == W_GAT_DST) return expf(lrelu(rs_a[c] + g0, P.slope) - rs_m[c]);
         if (WMODE == W_GAT_SRC) return expf(lrelu(g0 + rs_a[c], P.slope) - g1) * g2;
@@ -270,7 +271,24 @@ segsum_kernel(SegParams P) {
         float wv = 1.f;
         if (WMODE == W_ARRAY || WMODE == W_GAT_DST_PRE) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
         float dz_d = 0.f, dz_g = 0.f;    // W_GAT_SRC_FUSED, packed: D of the entry's target and leaky_relu' of its score
-        if (WMODE == W_GAT_SRC_FUSED && P.tpack != nullptr) {
+        // several heads: lane l holds alpha / D / leaky_relu' of entry kb + l for EVERY head; the lane's own head picks its weight
+        float wvh[HH], dzdh[HH], dzgh[HH];
+        const int myhead = L.hd[0];
+        const int lph = (HH > 1) ? (P.C >> 2) : WAVE;            // lanes per head: a power of two >= 8 (the entry point checks)
+        if constexpr (HH > 1) {
+            const int rl = (lane < nb) ? P.rowidx[kb + lane] : 0;
+#pragma unroll
+            for (int h = 0; h < HH; ++h) {
+                wvh[h] = dzdh[h] = dzgh[h] = 0.f;
+                if (lane < nb) {
+                    const float4 t = P.tpack[(int64_t)cv * HH + h];
+                    const float z = t.x + P.a_src[(int64_t)rl * HH + h];
+                    wvh[h] = expf(lrelu(z, P.slope) - t.y) * t.z;
+                    dzdh[h] = t.w;
+                    dzgh[h] = z > 0.f ? 1.f : P.slope;
+                }
+            }
+        } else if (WMODE == W_GAT_SRC_FUSED && P.tpack != nullptr) {
             // alpha of entry kb + l is computed BY LANE l (one exp per entry, not per lane) from the packed target scalars
             if (lane < nb) {
                 const float4 t = P.tpack[cv];
@@ -282,6 +300,7 @@ segsum_kernel(SegParams P) {
                 wv = 0.f;
             }
         } else if (WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
+        (void)wvh; (void)dzdh; (void)dzgh; (void)myhead; (void)lph;
         int avec = 0;                    // W_GAT_DST + alpha_out: alpha of entry kb + l collects in lane l, stored once per block
         const bool keep_alpha = (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) && P.alpha_out != nullptr;
         int j = 0;
@@ -314,7 +333,15 @@ segsum_kernel(SegParams P) {
             for (int u = 0; u < U; ++u) {
                 const int k = kb + j + u;
                 while (k == row_end) close_row();
-                const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j + u) : 1.f;
+                float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j + u) : 1.f;
+                if constexpr (HH > 1) {                 // alpha of entry j + u for this lane's head (HH scalar reads, HH - 1 selects)
+                    ws = bcast_f(wvh[0], j + u);
+#pragma unroll
+                    for (int h = 1; h < HH; ++h) {
+                        const float t = bcast_f(wvh[h], j + u);
+                        ws = (myhead == h) ? t : ws;
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
@@ -325,10 +352,24 @@ segsum_kernel(SegParams P) {
                         acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[u][c][q]) : fmaf(we, v[u][c][q], acc[c][q]);
                 }
                 pd[u] = 0.f;
-                if (WMODE == W_GAT_SRC_FUSED) {
+                if (is_fused_mode(WMODE)) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) pd[u] = fmaf(v[u][0][q], hr[q], pd[u]);
                 }
+            }
+            if constexpr (HH > 1 && U == 8) {
+                // the same reduce-scatter INSIDE every head's group of lph lanes: the three top bits of the position in the
+                // group halve the 8 entries (xor lph/2, lph/4, lph/8), the remaining bits are plain sums
+                const bool bh = (lane & (lph >> 1)) != 0, bm = (lane & (lph >> 2)) != 0, bl = (lane & (lph >> 3)) != 0;
+                float w4[4], w2[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w4[k] = (bh ? pd[(k + 4) % U] : pd[k % U]) + __shfl_xor(bh ? pd[k % U] : pd[(k + 4) % U], lph >> 1, WAVE);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) w2[k] = (bm ? w4[k + 2] : w4[k]) + __shfl_xor(bm ? w4[k] : w4[k + 2], lph >> 2, WAVE);
+                float y = (bl ? w2[1] : w2[0]) + __shfl_xor(bl ? w2[0] : w2[1], lph >> 3, WAVE);
+                for (int d = lph >> 4; d > 0; d >>= 1) y += __shfl_xor(y, d, WAVE);
+                if ((lane & ((lph >> 3) - 1)) == 0 && L.act[0])
+                    pb[(j + (bh ? 4 : 0) + (bm ? 2 : 0) + (bl ? 1 : 0)) * HH + myhead] = y;
             }
             if (WMODE == W_GAT_SRC_FUSED && U == 8) {
                 // the 8 partial dots are reduce-SCATTERED: every xor step halves the entries a lane still carries
@@ -369,7 +410,15 @@ segsum_kernel(SegParams P) {
             }
             const int k = kb + j;
             while (k == row_end) close_row();
-            const float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j) : 1.f;
+            float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j) : 1.f;
+            if constexpr (HH > 1) {
+                ws = bcast_f(wvh[0], j);
+#pragma unroll
+                for (int h = 1; h < HH; ++h) {
+                    const float t = bcast_f(wvh[h], j);
+                    ws = (myhead == h) ? t : ws;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
@@ -378,6 +427,13 @@ segsum_kernel(SegParams P) {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q)
                     acc[c][q] = (WMODE == W_NONE) ? (acc[c][q] + v[c][q]) : fmaf(we, v[c][q], acc[c][q]);
+            }
+            if constexpr (HH > 1) {
+                float p = 0.f;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) p = fmaf(v[0][q], hr[q], p);
+                for (int off = lph >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off, WAVE);
+                if ((lane & (lph - 1)) == 0 && L.act[0]) pb[j * HH + myhead] = p;
             }
             if (WMODE == W_GAT_SRC_FUSED) {
                 float p = 0.f;
@@ -389,6 +445,15 @@ segsum_kernel(SegParams P) {
             }
         }
         if (keep_alpha && lane < nb) P.alpha_out[kb + lane] = __int_as_float(avec);      // one coalesced store per 64 entries
+        if constexpr (HH > 1) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nb) {
+#pragma unroll
+                for (int h = 0; h < HH; ++h)
+                    P.dz_out[(int64_t)(kb + lane) * HH + h] = wvh[h] * (pb[lane * HH + h] - dzdh[h]) * dzgh[h];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         if (WMODE == W_GAT_SRC_FUSED) {
             // all 64 lanes turn the block's dots into dz together: dz = alpha (dot - D_i) leaky_relu'(a_dst[i] + a_src[j])
             __builtin_amdgcn_wave_barrier();
@@ -730,10 +795,13 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
         }
     } else if (wmode == W_GAT_SRC_PRE) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);
-    } else if (wmode == W_GAT_SRC_FUSED) {
+    } else if (is_fused_mode(wmode)) {
         if constexpr (VEC == 4 && sizeof(T) == 4 && NCH == 1) {
             dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
-            segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED, EXACT><<<grid, block, 0, stream>>>(P);
+            if (wmode == W_GAT_SRC_FUSED) segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED, EXACT><<<grid, block, 0, stream>>>(P);
+            else if (wmode == W_GAT_SRC_FUSED_H2) segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED_H2, EXACT><<<grid, block, 0, stream>>>(P);
+            else if (wmode == W_GAT_SRC_FUSED_H4) segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED_H4, EXACT><<<grid, block, 0, stream>>>(P);
+            else segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED_H8, EXACT><<<grid, block, 0, stream>>>(P);
             launch_fixup<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);       // same row epilogue
         } else {
             set_error("npi_gat_backward_fused: needs heads * out_channels <= 256");

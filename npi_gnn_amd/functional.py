@@ -744,7 +744,9 @@ class _GatConvFn(torch.autograd.Function):
         hfeat = linear_fwd(x, weight)                                        # x @ W
         a_dst, a_src = gat_scores(hfeat, att2, H, C)
         d = graph.by_dst
-        fused = GAT_FUSED_BACKWARD and H == 1 and C <= 256 and C % 4 == 0 and any(ctx.needs_input_grad[:4])
+        # the fused backward: one head of <= 256 channels, or 2 / 4 / 8 heads of 32 / 64 / 128 channels with H C <= 256 (packed form)
+        fused = (GAT_FUSED_BACKWARD and C % 4 == 0 and H * C <= 256 and any(ctx.needs_input_grad[:4])
+                 and (H == 1 or (GAT_PACKED_BACKWARD and H in (2, 4, 8) and C in (32, 64, 128))))
         # one head, NPI_GAT_PACKED=0: the forward also stores alpha of every entry (by-target order) and the backward reads it
         # back through the transpose map; default: the backward recomputes alpha from packed per-target scalars
         alpha = torch.empty(max(d.nnz_max, 1), dtype=torch.float32, device=x.device) if (fused and not GAT_PACKED_BACKWARD) else None
@@ -791,30 +793,28 @@ class _GatConvFn(torch.autograd.Function):
                                       want_colsum=ctx.has_bias and ctx.needs_input_grad[3])
         if ctx.fused:
             N = graph.num_nodes
-            dz = torch.empty(max(sr.nnz_max, 1), dtype=torch.float32, device=dev)
-            dh = torch.empty((N, C), dtype=torch.float32, device=dev)
+            dz = torch.empty(max(sr.nnz_max, 1) * H, dtype=torch.float32, device=dev)
+            dh = torch.empty((N, H * C), dtype=torch.float32, device=dev)
             if alpha_fwd.numel() == 0:
-                # packed form: (a_dst, m, 1/s, D) of every target in one float4; alpha is recomputed per entry by one lane
-                tpack = torch.empty((N, 4), dtype=torch.float32, device=dev)
-                check(load().npi_gat_pack_targets(ptr(a_dst), ptr(m), ptr(s), ptr(D), N, ptr(tpack), stream_ptr(dev)),
-                      "npi_gat_pack_targets")
+                # packed form: (a_dst, m, 1/s, D) of every (target, head) in one float4; alpha is recomputed per entry by one lane
+                tpack = gat_pack_targets(a_dst, m, s, D)                       # [N H, 4]
                 with _tag_events("gat_bwd_fused", dev):
-                    check(load().npi_gat_backward_fused_packed(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N,
-                                                               sr.nnz_max, ptr(grad_out), grad_out.stride(0), ptr(hfeat),
-                                                               hfeat.stride(0), ptr(dh), dh.stride(0), C, ptr(tpack), ptr(a_src),
-                                                               slope, ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)),
-                          "npi_gat_backward_fused_packed")
+                    check(load().npi_gat_backward_fused_heads(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N,
+                                                              sr.nnz_max, ptr(grad_out), grad_out.stride(0), None, 0, ptr(hfeat),
+                                                              hfeat.stride(0), ptr(dh), dh.stride(0), H, C, ptr(tpack), ptr(a_src),
+                                                              slope, ptr(dz), ptr(sr.carry(H * C)), stream_ptr(dev)),
+                          "npi_gat_backward_fused_heads")
             else:
                 tm = _transpose_map(graph)
                 check(load().npi_gat_backward_fused(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N, sr.nnz_max,
                                                     ptr(grad_out), grad_out.stride(0), ptr(hfeat), hfeat.stride(0), ptr(dh),
                                                     dh.stride(0), C, ptr(a_dst), ptr(a_src), ptr(D), slope, ptr(alpha_fwd), ptr(tm),
                                                     ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)), "npi_gat_backward_fused")
-            dz = dz.view(-1, 1)
-            g_src = seg_rowsum(sr, dz, 1)                                         # dz is in by-source entry order here
-            g_dst = seg_rowsum(d, dz, 1, map_=_inverse_transpose_map(graph))
+            dz = dz.view(-1, H)
+            g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
+            g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
-            check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), N, 1, C, stream_ptr(dev)),
+            check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), N, H, C, stream_ptr(dev)),
                   "npi_gat_rank1_add")
             datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C) if ctx.needs_input_grad[2] else None
             dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
