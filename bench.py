@@ -537,8 +537,19 @@ def run_configs(dev, args, c4):
                           ("gat_bwd_fused", "segsum_kernel<f32, 4, 1, W_GAT_SRC_FUSED> (+ fix-up): by-source aggregation + SDDMM in one gather pass")):
             tr, src = pmc_of(tag + "_bytes_per_launch", "stale_gat")
             roof[tag] = agg_roofline(tags.get(tag, []), gb[tag], tr, kern, src)
+        by_heads = {}
+        for Hh in (2, 4, 8):                                   # the same layer width as 2 / 4 / 8 heads of 128 / 64 / 32 channels
+            cv = npi.GATConv(F, F // Hh, heads=Hh).to(dev)
+
+            def hstep(cv=cv):
+                for p in cv.parameters():
+                    p.grad = None
+                xx.grad = None
+                cv(xx, g4).backward(go4)
+            by_heads[str(Hh)] = _timeit(hstep, 5, 2)
+            del cv
         return {"workload": f"C4 graph, 1 x GATConv {F}->{F} (1 head) fp32 fwd+bwd", "ms_per_step": ms,
-                "edges_per_s": E4 / ms * 1e3, "roofline": roof}
+                "edges_per_s": E4 / ms * 1e3, "ms_per_step_by_heads": by_heads, "roofline": roof}
 
     guarded("gcn_c4", gcn_c4)
     guarded("gat_c4", gat_c4)

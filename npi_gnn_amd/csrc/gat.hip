@@ -103,6 +103,38 @@ gat_scores_vec_kernel(const float* __restrict__ h, int64_t ldh, const float* __r
     }
 }
 
+// several heads whose lane groups are powers of two (C / 4 in {8, 16, 32} lanes, H C <= 256): the whole row is ONE wave
+// instruction -- lane l owns columns 4 l .. 4 l + 3 of head (4 l) / C -- and the two dot products of a head are reduced inside
+// its group of lanes (the loop-over-heads kernel above keeps 16 of 64 lanes busy at C = 64)
+__global__ void __launch_bounds__(256)
+gat_scores_heads_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ att, int N, int H, int C,
+                        float* __restrict__ a_dst, float* __restrict__ a_src) {
+    const int lane = lane_id();
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE;
+    if (i0 >= N) return;
+    const int Fw = H * C, lph = C >> 2;
+    const bool on = lane * 4 < Fw;
+    const int hd = on ? (lane * 4) / C : 0, cin = lane * 4 - hd * C;
+    const float4 ad = on ? *reinterpret_cast<const float4*>(att + (int64_t)hd * 2 * C + cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 as = on ? *reinterpret_cast<const float4*>(att + (int64_t)hd * 2 * C + C + cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v[ROWS_PER_WAVE];
+#pragma unroll
+    for (int r = 0; r < ROWS_PER_WAVE; ++r)
+        v[r] = on ? *reinterpret_cast<const float4*>(h + (int64_t)min(i0 + r, N - 1) * ldh + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+        float d = dot4(v[r], ad), sc = dot4(v[r], as);
+        for (int off = lph >> 1; off > 0; off >>= 1) {
+            d += __shfl_xor(d, off, WAVE);
+            sc += __shfl_xor(sc, off, WAVE);
+        }
+        if (on && (lane & (lph - 1)) == 0 && i0 + r < N) {
+            a_dst[(int64_t)(i0 + r) * H + hd] = d;
+            a_src[(int64_t)(i0 + r) * H + hd] = sc;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 gat_rowdot_vec_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
                       const float* __restrict__ bias, int N, int H, int C, float* __restrict__ D) {
@@ -903,7 +935,10 @@ extern "C" int npi_gat_scores(const float* h, int64_t ldh, const float* att, int
     NPI_REQUIRE(N >= 0 && H > 0 && C > 0 && ldh >= H * C, "npi_gat_scores: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(h && att && a_dst && a_src, "npi_gat_scores: null pointer");
-    if (rows16(h, ldh, C) && ((uintptr_t)att % 16) == 0)
+    const int64_t lph = C / 4;
+    if (H > 1 && H * C <= 256 && rows16(h, ldh, C) && ((uintptr_t)att % 16) == 0 && lph >= 2 && (lph & (lph - 1)) == 0)
+        gat_scores_heads_kernel<<<(unsigned)ceil_div(N, 4 * ROWS_PER_WAVE), 256, 0, stream>>>(h, ldh, att, (int)N, (int)H, (int)C, a_dst, a_src);
+    else if (rows16(h, ldh, C) && ((uintptr_t)att % 16) == 0)
         gat_scores_vec_kernel<<<(unsigned)ceil_div(N, 4 * ROWS_PER_WAVE), 256, 0, stream>>>(h, ldh, att, (int)N, (int)H, (int)C, a_dst, a_src);
     else
         gat_scores_kernel<<<(unsigned)ceil_div(N, 4), 256, 0, stream>>>(h, ldh, att, (int)N, (int)H, (int)C, a_dst, a_src);

@@ -80,10 +80,12 @@ template <> __device__ __forceinline__ void write_row<SoftmaxOp>(const ScanArgs&
     A.out1[i] = v.s;
 }
 
-// NB = blocks of 64 entries per item (1 or 4).  All of an item's index and value loads are issued before the first scan, and
-// no row bound is ever gathered: "p is the last entry of its row" <=> the NEXT entry has another row id (one more coalesced
-// load), "the row began in an earlier item" <=> it is the row of entry k0 - 1 (one scalar load per item).
-template <class Op, int NB>
+// NB = blocks of 64 entries per item (1 or 4); HH = heads handled TOGETHER (1, 2, 4, 8: the H values of an entry are one
+// contiguous 4 HH-byte load and share the key shuffles of the scan; any other H runs the HH = 1 kernel head by head).  All of
+// an item's index and value loads are issued before the first scan, and no row bound is ever gathered: "p is the last entry of
+// its row" <=> the NEXT entry has another row id (one more coalesced load), "the row began in an earlier item" <=> it is the
+// row of entry k0 - 1 (one scalar load per item).
+template <class Op, int NB, int HH>
 __global__ void __launch_bounds__(256)
 seg_items_kernel(ScanArgs A) {
     using V = typename Op::V;
@@ -110,26 +112,31 @@ seg_items_kernel(ScanArgs A) {
         else src[b] = p < k1 ? (A.map ? A.map[p] : p) : 0;
     }
     int tail_r = -1;
-    for (int hd = 0; hd < H; ++hd) {
-        V v[NB];
+    for (int h0 = 0; h0 < H; h0 += HH) {                                       // (one trip when HH == H)
+        V v[NB][HH];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {                                        // every value load of the item in flight at once
             const int p = k0 + b * WAVE + lane;
-            v[b] = Op::identity();
-            if (p < k1) {
-                if constexpr (SOFTMAX) {
-                    const float z = A.a_row[(int64_t)key[b] * H + hd] + A.a_col[(int64_t)src[b] * H + hd];
-                    const float e = z > 0.f ? z : z * A.slope;
-                    if (A.e_out) A.e_out[(int64_t)p * H + hd] = e;
-                    v[b].m = e;
-                    v[b].s = 1.f;
-                } else {
-                    v[b].a = A.vals[(int64_t)src[b] * H + hd];
+#pragma unroll
+            for (int h = 0; h < HH; ++h) {
+                v[b][h] = Op::identity();
+                if (p < k1) {
+                    if constexpr (SOFTMAX) {
+                        const float z = A.a_row[(int64_t)key[b] * H + h0 + h] + A.a_col[(int64_t)src[b] * H + h0 + h];
+                        const float e = z > 0.f ? z : z * A.slope;
+                        if (A.e_out) A.e_out[(int64_t)p * H + h0 + h] = e;
+                        v[b][h].m = e;
+                        v[b][h].s = 1.f;
+                    } else {
+                        v[b][h].a = A.vals[(int64_t)src[b] * H + h0 + h];
+                    }
                 }
             }
         }
         int open_key = -1;                          // row whose entries ran up to the end of the previous block
-        V open_val = Op::identity();
+        V open_val[HH];
+#pragma unroll
+        for (int h = 0; h < HH; ++h) open_val[h] = Op::identity();
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int kb = k0 + b * WAVE;
@@ -137,15 +144,24 @@ seg_items_kernel(ScanArgs A) {
             const int p = kb + lane;
             const bool valid = p < k1;
             const int kk = key[b];
-            V x = v[b];
+            V x[HH];
+#pragma unroll
+            for (int h = 0; h < HH; ++h) x[h] = v[b][h];
             // segmented inclusive scan: keys are sorted, so "same key at distance d" means the whole span shares it
 #pragma unroll
             for (int d = 1; d < WAVE; d <<= 1) {
-                const V o = Op::shfl_up(x, d);
                 const int ko = __shfl_up(kk, d, WAVE);
-                if (lane >= d && ko == kk) x = Op::merge(o, x);
+                const bool same = lane >= d && ko == kk;
+#pragma unroll
+                for (int h = 0; h < HH; ++h) {
+                    const V o = Op::shfl_up(x[h], d);
+                    if (same) x[h] = Op::merge(o, x[h]);
+                }
             }
-            if (valid && kk == open_key) x = Op::merge(open_val, x);        // first run: the row was already open
+            if (valid && kk == open_key) {                                   // first run: the row was already open
+#pragma unroll
+                for (int h = 0; h < HH; ++h) x[h] = Op::merge(open_val[h], x[h]);
+            }
             // row id of entry p + 1: the next lane, the next block's first lane, or the first entry behind the item
             int key_next = __shfl_down(kk, 1, WAVE);
             const int first_of_next = (b + 1 < NB && kb + WAVE < k1) ? bcast_i(key[b + 1 < NB ? b + 1 : b], 0) : next_row;
@@ -155,8 +171,11 @@ seg_items_kernel(ScanArgs A) {
             bool cont = false;                                               // this lane's run continues past the block
             if (run_end) {
                 if (key_next != kk) {                                        // p is the row's last entry
-                    if (kk != prev_row) write_row<Op>(A, (int64_t)kk * H + hd, x);
-                    else store_v<Op>(A.head, (int64_t)item * H + hd, x);     // it began in an earlier item
+#pragma unroll
+                    for (int h = 0; h < HH; ++h) {
+                        if (kk != prev_row) write_row<Op>(A, (int64_t)kk * H + h0 + h, x[h]);
+                        else store_v<Op>(A.head, (int64_t)item * H + h0 + h, x[h]);     // it began in an earlier item
+                    }
                 } else {
                     cont = true;
                 }
@@ -165,18 +184,24 @@ seg_items_kernel(ScanArgs A) {
             if (cm) {
                 const int cl = __ffsll((unsigned long long)cm) - 1;          // (at most one: the last valid lane)
                 open_key = bcast_i(kk, cl);
-                open_val = Op::lane(x, cl);
+#pragma unroll
+                for (int h = 0; h < HH; ++h) open_val[h] = Op::lane(x[h], cl);
             } else {
                 open_key = -1;
-                open_val = Op::identity();
+#pragma unroll
+                for (int h = 0; h < HH; ++h) open_val[h] = Op::identity();
             }
         }
         if (open_key >= 0) {                                                  // a row runs past the end of the item
             if (open_key != prev_row) {
-                if (lane == 0) store_v<Op>(A.tail, (int64_t)item * H + hd, open_val);
+                if (lane == 0) {
+#pragma unroll
+                    for (int h = 0; h < HH; ++h) store_v<Op>(A.tail, (int64_t)item * H + h0 + h, open_val[h]);
+                }
                 tail_r = open_key;
             } else if (lane == 0) {
-                store_v<Op>(A.head, (int64_t)item * H + hd, open_val);       // the whole item lies inside one row
+#pragma unroll
+                for (int h = 0; h < HH; ++h) store_v<Op>(A.head, (int64_t)item * H + h0 + h, open_val[h]);   // the whole item lies inside one row
             }
         }
     }
@@ -224,8 +249,17 @@ int run_scan(ScanArgs A, int64_t nnz_max, float* workspace, int64_t workspace_el
     A.n_items = (int)n_items;
     A.item = item_edges_for(nnz_max);
     const unsigned grid = (unsigned)ceil_div(n_items, 4);
-    if (A.item == WAVE) seg_items_kernel<Op, 1><<<grid, 256, 0, stream>>>(A);
-    else                seg_items_kernel<Op, NPI_ITEM_EDGES / WAVE><<<grid, 256, 0, stream>>>(A);
+    constexpr int NBL = NPI_ITEM_EDGES / WAVE;
+    const bool small = A.item == WAVE;
+#define NPI_SCAN(HH_) do { if (small) seg_items_kernel<Op, 1, HH_><<<grid, 256, 0, stream>>>(A); \
+                           else       seg_items_kernel<Op, NBL, HH_><<<grid, 256, 0, stream>>>(A); } while (0)
+    switch (A.H) {                       // 2 / 4 / 8 heads travel together; any other count head by head
+        case 2: NPI_SCAN(2); break;
+        case 4: NPI_SCAN(4); break;
+        case 8: NPI_SCAN(8); break;
+        default: NPI_SCAN(1); break;
+    }
+#undef NPI_SCAN
     seg_chain_kernel<Op><<<grid, 256, 0, stream>>>(A);
     return check_launch(what);
 }
