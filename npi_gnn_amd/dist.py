@@ -431,12 +431,13 @@ class HipBackend:
         return NF.gat_softmax_stats(side, a_row, a_col, H, slope)
 
     def gat_aggregate(self, side, table, table2, H, C, a_dst, a_src, m, s, slope, by_source, bias=None,
-                      g_dst=None, g_src=None, att=None):
+                      g_dst=None, g_src=None, att=None, out=None):
         from . import functional as NF
         if side.nnz_max == 0:
-            return table.new_zeros((side.n_rows, H * C))
-        return NF._gat_aggregate(None, side, table, H, C, a_dst, a_src, m, s, slope, by_source, bias=bias, g_dst=g_dst,
-                                 g_src=g_src, att=att, x2=table2)
+            res = table.new_zeros((side.n_rows, H * C))
+            return res if out is None else out.copy_(res)
+        return NF._gat_aggregate(None, side, table, H, C, a_dst.contiguous(), a_src.contiguous(), m.contiguous(), s.contiguous(),
+                                 slope, by_source, bias=bias, g_dst=g_dst, g_src=g_src, att=att, x2=table2, out=out)
 
     def gat_rowdot(self, a, b, bias, H, C):
         from . import functional as NF
@@ -467,9 +468,9 @@ class HipBackend:
         from . import functional as NF
         return NF.gat_pack_targets(a_dst, m, s, D)
 
-    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None):
+    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H=1):
         from . import functional as NF
-        return NF.gat_backward_fused_packed(side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=out)
+        return NF.gat_backward_fused_packed(side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=out, H=H)
 
     def gat_rank1_add(self, dh, g_dst, g_src, att2, H, C):
         from . import functional as NF
@@ -974,7 +975,7 @@ class _ShardedGatFn(torch.autograd.Function):
 
 
 class _ShardedGatDirectFn(torch.autograd.Function):
-    """GATConv, ONE head, on the direct layout (cuts without hub-hub edges) with the single-GPU layer's round-3 kernels: the
+    """GATConv, 1 / 2 / 4 / 8 heads, on the direct layout (cuts without hub-hub edges) with the single-GPU layer's round-3 kernels: the
     statistics pass leaves the per-entry scores, the aggregation reads them back, and the backward is ONE fused gather pass per
     by-source side on packed per-target scalars -- every entry's SDDMM dot is computed once (the classic path computes it on
     both orientations of both sides).  Per rank and direction: two aggregation-sized launches over its ~E/W entries.
@@ -987,48 +988,63 @@ class _ShardedGatDirectFn(torch.autograd.Function):
                 reduce-scattered; everything else is the single-GPU layer's arithmetic."""
 
     @staticmethod
-    def forward(ctx, x_own, weight, att, bias, sg: ShardedGraph, slope: float):
+    def forward(ctx, x_own, weight, att, bias, sg: ShardedGraph, heads: int, slope: float):
         be, part, W = sg.backend, sg.part, sg.world
         nL, nH, hp = sg.nL, sg.nH, sg.part.h_per
-        C = weight.size(1)
+        H = int(heads)
+        C = weight.size(1) // H
+        F = H * C
         x_own = x_own.contiguous()
-        att2 = att.reshape(1, 2 * C).contiguous()
+        att2 = att.reshape(H, 2 * C).contiguous()
         A, B, _, _ = sg.direct()
         h = be.linear_fwd(x_own, weight, None)
-        a_dst, a_src = be.gat_scores(h, att2, 1, C)                                # [n_local, 1] each
+        a_dst, a_src = be.gat_scores(h, att2, H, C)                                # [n_local, H] each
         tbl_h, g_work = gather_hub(sg, h, async_op=True)                           # big: hub rows of h
         hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))               # small
-        tbl_a_dst, tbl_a_src = hub_sc[:, :1].contiguous(), hub_sc[:, 1:].contiguous()
+        tbl_a_dst, tbl_a_src = hub_sc[:, :H].contiguous(), hub_sc[:, H:].contiguous()
         # hub rows: this rank's share -- its light sources and the loops of the hubs it owns; needs nothing of tbl_h
-        mB, sB, eB = be.gat_stats_scores(B, tbl_a_dst, a_src, slope)
+        # (one head: the statistics pass leaves the per-entry scores and the aggregation reads them back)
+        if H == 1:
+            mB, sB, eB = be.gat_stats_scores(B, tbl_a_dst, a_src, slope)
+        else:
+            mB, sB = be.gat_stats(B, tbl_a_dst, a_src, H, slope)
         empty = be.row_lengths(B).view(-1, 1) == 0
         M = torch.where(empty, torch.full_like(mB, NEG), mB)
         _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
-        U = be.gat_aggregate_scores(B, h, None, C, eB, M, torch.ones_like(M))      # sum exp(e - M) h_j, not normalised
+        if H == 1:
+            U = be.gat_aggregate_scores(B, h, None, C, eB, M, torch.ones_like(M))  # sum exp(e - M) h_j, not normalised
+        else:
+            U = be.gat_aggregate(B, h, None, H, C, tbl_a_dst, a_src, M, torch.ones_like(M), slope, False)
         S = torch.where(empty, torch.zeros_like(sB), sB * torch.exp(mB - M))
-        out_full = h.new_empty((nL + hp, C))
+        out_full = h.new_empty((nL + hp, F))
         hU, wU = out_full[nL:], None                                               # the reduce-scatter lands in the output
         if _solo(W):
             hU.copy_(U)
             s_own = S
         else:
             wU = reduce_scatter_rows(U, hU, sg.rank, W, sg.group, async_op=True)
-            s_own = S.new_empty((hp, 1))
+            s_own = S.new_empty((hp, H))
             _wait(reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.group, async_op=True), "fwd_reduce_scatter_s", s_own)
         # light rows: the whole softmax is local once the hub table is here
         tbl_a_src_full = torch.cat([tbl_a_src, a_src])                             # index space of A's columns
-        mA, sA, eA = be.gat_stats_scores(A, a_dst[:nL], tbl_a_src_full, slope)
-        _wait(g_work, "fwd_all_gather", tbl_h)
-        be.gat_aggregate_scores(A, tbl_h, h, C, eA, mA, sA, bias=bias, out=out_full[:nL])
+        if H == 1:
+            mA, sA, eA = be.gat_stats_scores(A, a_dst[:nL], tbl_a_src_full, slope)
+            _wait(g_work, "fwd_all_gather", tbl_h)
+            be.gat_aggregate_scores(A, tbl_h, h, C, eA, mA, sA, bias=bias, out=out_full[:nL])
+        else:
+            mA, sA = be.gat_stats(A, a_dst[:nL].contiguous(), tbl_a_src_full, H, slope)
+            _wait(g_work, "fwd_all_gather", tbl_h)
+            be.gat_aggregate(A, tbl_h, h, H, C, a_dst[:nL].contiguous(), tbl_a_src_full, mA, sA, slope, False, bias=bias,
+                             out=out_full[:nL])
         _wait(wU, "fwd_reduce_scatter", hU)
         if nH:
-            hub = hU[:nH] / (s_own[:nH] + 1e-16)
+            hub = (hU[:nH].view(nH, H, C) / (s_own[:nH].view(nH, H, 1) + 1e-16)).reshape(nH, F)
             hU[:nH] = hub + bias if bias is not None else hub
         out = out_full[: nL + nH]
         m_own = torch.cat([mA, M[sg.own_hub]])
         s_all = torch.cat([sA, s_own[:nH]])
         tbl_S, _ = gather_hub(sg, s_all)                                           # every rank needs S of the hub targets it holds
-        ctx.sg, ctx.C, ctx.slope = sg, C, float(slope)
+        ctx.sg, ctx.H, ctx.C, ctx.slope = sg, H, C, float(slope)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x_own, weight, att2, h, a_dst, a_src, tbl_h, tbl_a_dst, tbl_a_src, M, tbl_S, m_own, s_all, out,
                               bias if bias is not None else h.new_empty(0))
@@ -1040,7 +1056,8 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         sg: ShardedGraph = ctx.sg
         be, W = sg.backend, sg.world
         nL, nH, hp = sg.nL, sg.nH, sg.part.h_per
-        C, slope = ctx.C, ctx.slope
+        H, C, slope = ctx.H, ctx.C, ctx.slope
+        F = H * C
         A, B, At, Bt = sg.direct()
         map_a, map_b, n_bt, n_at = sg.gat_maps()
         dO = grad_out.contiguous()
@@ -1048,47 +1065,50 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = be.colsum(dO)
             _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
-        D = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, 1, C)           # [n_local, 1]
+        D = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, H, C)           # [n_local, H]
         tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                         # big: hub rows of dOut
         tbl_D, _ = gather_hub(sg, D)
         # packed per-TARGET scalars (a_dst, m, 1 / s, D): the own rows, and the hub table (targets of the light sources)
         t_own = be.gat_pack(a_dst, m_own, s_all, D)
         t_tbl = be.gat_pack(tbl_a_dst, M, tbl_S, tbl_D)
         # hub SOURCES (rows of the hub table): targets = this rank's rows (its light rows; the own hubs' loops): nothing remote
-        pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope)
-        pg_src = be.seg_rowsum(Bt, dz_bt.view(-1, 1), 1)
+        pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope, H=H)
+        dz_bt = dz_bt.view(-1, H)
+        pg_src = be.seg_rowsum(Bt, dz_bt, H)
         # own light SOURCES: targets = the hub table (+ the own loop)
-        dh_full = h.new_empty((nL + hp, C))
+        dh_full = h.new_empty((nL + hp, F))
         _wait(g_work, "bwd_all_gather", tbl_dO)
-        _, dz_at = be.gat_backward_fused(At, tbl_dO, dO, h[:nL], C, torch.cat([t_tbl, t_own]), a_src[:nL], slope, out=dh_full[:nL])
-        g_src_l = be.seg_rowsum(At, dz_at.view(-1, 1), 1)
-        dz_cat = torch.cat([dz_bt[:n_bt], dz_at[:n_at]]).view(-1, 1)
-        g_dst_l = be.seg_rowsum(A, dz_cat, 1, map_=map_a)                          # light targets: complete
-        pg_dst = be.seg_rowsum(B, dz_cat, 1, map_=map_b)                           # hub targets: this rank's share
-        pg = torch.cat([pg_dst, pg_src], dim=1).contiguous()                       # [hub_rows, 2]
+        _, dz_at = be.gat_backward_fused(At, tbl_dO, dO, h[:nL], C, torch.cat([t_tbl, t_own]), a_src[:nL].contiguous(), slope,
+                                         out=dh_full[:nL], H=H)
+        dz_at = dz_at.view(-1, H)
+        g_src_l = be.seg_rowsum(At, dz_at, H)
+        dz_cat = torch.cat([dz_bt[:n_bt], dz_at[:n_at]])
+        g_dst_l = be.seg_rowsum(A, dz_cat, H, map_=map_a)                          # light targets: complete
+        pg_dst = be.seg_rowsum(B, dz_cat, H, map_=map_b)                           # hub targets: this rank's share
+        pg = torch.cat([pg_dst, pg_src], dim=1).contiguous()                       # [hub_rows, 2 H]
         if _solo(W):
             dh_full[nL:].copy_(pdh)
             g_hub = pg
         else:
             wh = reduce_scatter_rows(pdh, dh_full[nL:], sg.rank, W, sg.group, async_op=True)
-            g_hub = pg.new_empty((hp, 2))
+            g_hub = pg.new_empty((hp, 2 * H))
             _wait(reduce_scatter_rows(pg, g_hub, sg.rank, W, sg.group, async_op=True), "bwd_reduce_scatter_g", g_hub)
             _wait(wh, "bwd_reduce_scatter", dh_full)
         dh = dh_full[: nL + nH]
-        g_dst = torch.cat([g_dst_l, g_hub[:nH, :1]])
-        g_src = torch.cat([g_src_l, g_hub[:nH, 1:]])
-        be.gat_rank1_add(dh, g_dst, g_src, att2, 1, C)                             # d h_j += g_dst[j] att[:C] + g_src[j] att[C:]
+        g_dst = torch.cat([g_dst_l, g_hub[:nH, :H]])
+        g_src = torch.cat([g_src_l, g_hub[:nH, H:]])
+        be.gat_rank1_add(dh, g_dst, g_src, att2, H, C)                             # d h_j += g_dst[j] att[:C] + g_src[j] att[C:]
         datt = dw = dx = None
         if ctx.needs_input_grad[2]:
-            datt = be.gat_att_grad(h, g_dst.contiguous(), g_src.contiguous(), 1, C)
+            datt = be.gat_att_grad(h, g_dst.contiguous(), g_src.contiguous(), H, C)
             _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
-            datt = datt.view(1, 1, 2 * C)
+            datt = datt.view(1, H, 2 * C)
         if ctx.needs_input_grad[1]:
             dw, _ = be.linear_bwd_weight(x_own, dh, False)
             _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
         if ctx.needs_input_grad[0]:
             dx = be.linear_bwd_data(dh, weight, None)
-        return dx, dw, datt, db, None, None
+        return dx, dw, datt, db, None, None, None
 
 
 class _ShardedLayer(nn.Module):
@@ -1127,10 +1147,11 @@ class ShardedGATLayer(_ShardedLayer):
         self.heads, self.negative_slope = int(heads), float(negative_slope)
 
     def forward(self, x_own: torch.Tensor) -> torch.Tensor:
-        C = self.weight.size(1)
-        if (GAT_DIRECT and self.heads == 1 and self.sg.direct_ok and C <= 256 and C % 4 == 0
-                and hasattr(self.sg.backend, "gat_backward_fused")):
-            return _ShardedGatDirectFn.apply(x_own, self.weight, self.att, self.bias, self.sg, self.negative_slope)
+        H = self.heads
+        C = self.weight.size(1) // H
+        fused_ok = C % 4 == 0 and H * C <= 256 and (H == 1 or (H in (2, 4, 8) and C in (32, 64, 128)))
+        if GAT_DIRECT and fused_ok and self.sg.direct_ok and hasattr(self.sg.backend, "gat_backward_fused"):
+            return _ShardedGatDirectFn.apply(x_own, self.weight, self.att, self.bias, self.sg, H, self.negative_slope)
         return _ShardedGatFn.apply(x_own, self.weight, self.att, self.bias, self.sg, self.heads, self.negative_slope)
 
 

@@ -524,15 +524,16 @@ GAT_PACKED_BACKWARD = os.environ.get("NPI_GAT_PACKED", "1") != "0"
 
 
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
-                   g_src=None, att=None, alpha=None, alpha_map=None, x2=None):
-    """``x2``: second part of a two-part table (see ``segsum``)."""
+                   g_src=None, att=None, alpha=None, alpha_map=None, x2=None, out=None):
+    """``x2``: second part of a two-part table (see ``segsum``); ``out``: write into this ``[n_rows, H C]`` buffer."""
     dev = x.device
     x = _f32c(x, "x")
     if x2 is not None:
         x2 = _f32c(x2, "x2")
         if x2.stride(0) != x.stride(0):
             raise ValueError("the two parts of the table must share the row pitch")
-    out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
     check(load().npi_gat_aggregate_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
                                       ptr(x), x.stride(0), ptr(x2), x.size(0) if x2 is not None else 0,
                                       ptr(out), out.stride(0), H, C, ptr(a_dst), ptr(a_src),
@@ -650,10 +651,10 @@ def gat_pack_targets(a_dst, m, s, D):
     return t
 
 
-def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None):
-    """One head, by-SOURCE side: (out [n_rows, C] = sum_q alpha_q dout[col q], dz [nnz_max] per entry) in one gather pass;
-    ``dout2``: second part of the gathered table; ``tpack`` [n_cols, 4] indexed by the column id; ``hrow`` / ``a_src_rows``:
-    features and source score of the ROW nodes."""
+def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H: int = 1):
+    """By-SOURCE side: (out [n_rows, H C] = sum_q alpha_q dout[col q], dz [nnz_max, H] per entry and head) in one gather pass;
+    ``dout2``: second part of the gathered table; ``tpack`` [n_cols H, 4] indexed by (column id, head); ``hrow`` /
+    ``a_src_rows``: features and source scores of the ROW nodes.  H in {1, 2, 4, 8} (npi_gat_backward_fused_heads)."""
     dev = dout.device
     dout = _f32c(dout, "dout")
     if dout2 is not None:
@@ -662,16 +663,16 @@ def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_
             raise ValueError("the two parts of the table must share the row pitch")
     hrow = _f32c(hrow, "hrow")
     if out is None:
-        out = torch.empty((side.n_rows, C), dtype=torch.float32, device=dev)
-    dz = torch.empty(max(side.nnz_max, 1), dtype=torch.float32, device=dev)
+        out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
+    dz = torch.empty(max(side.nnz_max, 1) * H, dtype=torch.float32, device=dev)
     if side.nnz_max == 0:
         return out.zero_(), dz
     with _tag_events("gat_bwd_fused", dev):
-        check(load().npi_gat_backward_fused_packed_ex(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row),
-                                                      side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
-                                                      dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
-                                                      out.stride(0), C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
-                                                      ptr(side.carry(C)), stream_ptr(dev)), "npi_gat_backward_fused_packed_ex")
+        check(load().npi_gat_backward_fused_heads(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row),
+                                                  side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
+                                                  dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
+                                                  out.stride(0), H, C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
+                                                  ptr(side.carry(H * C)), stream_ptr(dev)), "npi_gat_backward_fused_heads")
     return out, dz
 
 

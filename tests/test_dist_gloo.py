@@ -82,16 +82,20 @@ class TorchBackend:
         return torch.exp(F.leaky_relu(z, slope) - m[tgt]) / (s[tgt] + 1e-16), z, tgt
 
     def gat_aggregate(self, side, table, table2, H, C, a_dst, a_src, m, s, slope, by_source, bias=None,
-                      g_dst=None, g_src=None, att=None):
+                      g_dst=None, g_src=None, att=None, out=None):
         key, val, n_rows, _ = side
         t = self._table(table, table2)
         alpha, _, _ = self._alpha(side, a_dst, a_src, m, s, slope, by_source)
         msg = t[val].view(-1, H, C) * alpha.view(-1, H, 1)
-        out = torch.zeros(n_rows, H, C).index_add_(0, key, msg)
+        out_ = torch.zeros(n_rows, H, C).index_add_(0, key, msg)
         if g_dst is not None:
-            out = out + g_dst.view(-1, H, 1) * att[:, :C].view(1, H, C) + g_src.view(-1, H, 1) * att[:, C:].view(1, H, C)
-        out = out.reshape(n_rows, H * C)
-        return out + bias if bias is not None else out
+            out_ = out_ + g_dst.view(-1, H, 1) * att[:, :C].view(1, H, C) + g_src.view(-1, H, 1) * att[:, C:].view(1, H, C)
+        res = out_.reshape(n_rows, H * C)
+        res = res + bias if bias is not None else res
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def gat_rowdot(self, a, b, bias, H, C):
         bb = b - bias if bias is not None else b
@@ -129,24 +133,24 @@ class TorchBackend:
         return res
 
     def gat_pack(self, a_dst, m, s, D):
-        return torch.cat([a_dst.view(-1, 1), m.view(-1, 1), 1.0 / (s.view(-1, 1) + 1e-16), D.view(-1, 1)], dim=1)
+        return torch.cat([a_dst.reshape(-1, 1), m.reshape(-1, 1), 1.0 / (s.reshape(-1, 1) + 1e-16), D.reshape(-1, 1)], dim=1)
 
-    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None):
+    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H=1):
         key, val, n_rows, _ = side                                    # key = source row j, val = target column i
-        t = self._table(dout, dout2)
-        tp = tpack[val]
-        z = tp[:, 0] + a_src_rows.view(-1)[key]
-        alpha = torch.exp(F.leaky_relu(z, slope) - tp[:, 1]) * tp[:, 2]
-        res = torch.zeros(n_rows, C).index_add_(0, key, t[val] * alpha.view(-1, 1))
-        dot = (t[val] * hrow[key]).sum(-1)
-        dz = alpha * (dot - tp[:, 3]) * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+        t = self._table(dout, dout2).view(-1, H, C)
+        tp = tpack.view(-1, H, 4)[val]                                # [nnz, H, 4]
+        z = tp[..., 0] + a_src_rows.view(-1, H)[key]
+        alpha = torch.exp(F.leaky_relu(z, slope) - tp[..., 1]) * tp[..., 2]
+        res = torch.zeros(n_rows, H, C).index_add_(0, key, t[val] * alpha.unsqueeze(-1)).reshape(n_rows, H * C)
+        dot = (t[val] * hrow.view(-1, H, C)[key]).sum(-1)
+        dz = alpha * (dot - tp[..., 3]) * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
         if out is not None:
             out.copy_(res)
             res = out
-        return res, dz
+        return res, dz.reshape(-1)
 
     def gat_rank1_add(self, dh, g_dst, g_src, att2, H, C):
-        dh += g_dst.view(-1, 1) * att2[:, :C] + g_src.view(-1, 1) * att2[:, C:]
+        dh += (g_dst.view(-1, H, 1) * att2[:, :C].view(1, H, C) + g_src.view(-1, H, 1) * att2[:, C:].view(1, H, C)).reshape(dh.shape)
         return dh
 
     def gat_att_grad(self, h, g_dst, g_src, H, C):
@@ -450,3 +454,40 @@ def test_three_sharded_layers_chain_like_the_single_process_stack(world, kind):
     for r in range(world):
         for k in range(3):
             assert torch.allclose(torch.from_numpy(res[r][2][k]), Ws[k].grad, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("world,H,Fd", [(2, 2, 64), (8, 4, 128), (3, 8, 256)])
+def test_sharded_gat_several_heads_on_the_direct_layout(world, H, Fd):
+    """2 / 4 / 8 heads of 32 channels: the shapes the fused multi-head backward serves, through dist._ShardedGatDirectFn
+    (hub softmax merged relative to the all-reduced maximum, per-head packed target scalars, dz [nnz, H] through the local
+    index maps) -- outputs and every gradient against the single-process oracle."""
+    N, E = 160, 900
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    kind = f"gat{H}"
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, E, Fd, "bipartite", kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        got = q.get(timeout=180)
+        res[got[0]] = tuple(torch.from_numpy(a) for a in got[1:])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ei, x, W, b, go, hub = _case(N, E, Fd, "bipartite")
+    ref = _reference(kind, ei, x, W, b, go, Fd)
+    part = ND.HubPartition(N, world, hub)
+    out = part.unshard([res[r][0] for r in range(world)])
+    dx = part.unshard([res[r][1] for r in range(world)])
+    assert torch.allclose(out, ref[0], atol=1e-5, rtol=1e-4)
+    assert torch.allclose(dx, ref[1], atol=1e-5, rtol=1e-4)
+    for r in range(world):
+        assert torch.allclose(res[r][2], ref[2], atol=1e-4, rtol=1e-4)
+        assert torch.allclose(res[r][3], ref[3], atol=1e-4, rtol=1e-4)
+        assert torch.allclose(res[r][4], ref[4], atol=1e-4, rtol=1e-4)
+    # ... and it is the direct path that ran: same graph, one process, the Function's name
+    sg = ND.ShardedGraph(ei, N, 0, 1, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub)
+    layer = ND.ShardedGATLayer(sg, W, _att(Fd, H), b, heads=H)
+    assert type(layer(sg.shard(x).clone().requires_grad_(True)).grad_fn).__name__ == "_ShardedGatDirectFnBackward"
