@@ -817,9 +817,26 @@ class _GatConvFn(torch.autograd.Function):
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
             check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), N, H, C, stream_ptr(dev)),
                   "npi_gat_rank1_add")
-            datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C) if ctx.needs_input_grad[2] else None
+            # datt streams hfeat once (HBM-bound) and depends only on g_dst / g_src; the two GEMMs that follow are MFMA-bound:
+            # on large graphs the attention gradient runs on the side stream UNDER them
+            overlap = (ctx.needs_input_grad[2] and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and OVERLAP_STREAMS
+                       and N >= OVERLAP_MIN_ROWS)
+            datt = None
+            if overlap:
+                main = torch.cuda.current_stream(dev)
+                side = _side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
+                for t in (hfeat, g_dst, g_src):
+                    t.record_stream(side)
+                datt.record_stream(main)
+            elif ctx.needs_input_grad[2]:
+                datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
             dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
             dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
+            if overlap:
+                main.wait_stream(side)
             return dx, dw, datt, db, None, None, None, None
         # dz per by-target entry, then its row sums in both orientations;
         # one head: keep the alpha this kernel computes; the by-source pass reads it back through the transpose map
