@@ -150,6 +150,10 @@ int npi_entry_weights(const int32_t* eid, const int32_t* rowidx, const int32_t* 
                       int64_t N, int64_t nnz_max, float* w_entry, void* stream);
 int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
                     void* stream);
+/* Backward of the ReLU that SAGEConv(..., relu=True) applies in its projection epilogue (autograd's threshold_backward):
+ * dz[r, c] = y[r, c] > 0 ? dy[r, c] : 0 over M rows of F floats, y = the layer's (post-ReLU) output. */
+int npi_relu_backward(const float* dy, int64_t ldd, const float* y, int64_t ldy, int64_t M, int64_t F, float* dz, int64_t ldz,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projection on the matrix cores -- replaces `torch.matmul(aggr_out, self.weight) + bias`

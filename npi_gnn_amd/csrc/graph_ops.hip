@@ -110,6 +110,41 @@ extern "C" int npi_row_inv_count(const int32_t* rowptr, int64_t N, float* inv_cn
     return check_launch("npi_row_inv_count");
 }
 
+// grad of the pre-activation behind SAGEConv(..., relu=True): dz = dy where y > 0 else 0 (threshold_backward); y is the
+// ReLU OUTPUT the layer saved.  Rows of F floats with pitches (the activations of a batch may be views); 16-byte lanes when
+// everything is aligned, 4 elements per thread otherwise.
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+relu_backward_kernel(const float* __restrict__ dy, int64_t ldd, const float* __restrict__ y, int64_t ldy, int64_t M, int64_t F,
+                     float* __restrict__ dz, int64_t ldz) {
+    const int64_t per = (F + 3) / 4;                                  // column groups of 4 per row
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * per) return;
+    const int64_t r = i / per, c = (i % per) * 4;
+    if (VEC4) {
+        const float4 g = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+        const float4 v = *reinterpret_cast<const float4*>(y + r * ldy + c);
+        *reinterpret_cast<float4*>(dz + r * ldz + c) = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f,
+                                                                    v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+    } else {
+        for (int q = 0; q < 4 && c + q < F; ++q) dz[r * ldz + c + q] = y[r * ldy + c + q] > 0.f ? dy[r * ldd + c + q] : 0.f;
+    }
+}
+
+extern "C" int npi_relu_backward(const float* dy, int64_t ldd, const float* y, int64_t ldy, int64_t M, int64_t F, float* dz,
+                                 int64_t ldz, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(M >= 0 && F > 0 && ldd >= F && ldy >= F && ldz >= F, "npi_relu_backward: bad size");
+    if (M == 0) return NPI_OK;
+    NPI_REQUIRE(dy && y && dz, "npi_relu_backward: null pointer");
+    const int64_t n = M * ((F + 3) / 4);
+    const bool v4 = F % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)dy % 16) == 0 &&
+                    ((uintptr_t)y % 16) == 0 && ((uintptr_t)dz % 16) == 0;
+    if (v4) relu_backward_kernel<true><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(dy, ldd, y, ldy, M, F, dz, ldz);
+    else    relu_backward_kernel<false><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(dy, ldd, y, ldy, M, F, dz, ldz);
+    return check_launch("npi_relu_backward");
+}
+
 extern "C" int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -229,6 +229,23 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True,
     return dw, db
 
 
+def relu_backward(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dz = dy where y > 0 else 0 (``y``: the output of a fused ReLU); f32 through ``npi_relu_backward``, other storage types
+    through the equivalent torch op"""
+    if dy.dtype != torch.float32 or y.dtype != torch.float32 or dy.dim() != 2:
+        return torch.ops.aten.threshold_backward(dy, y, 0)
+    dev = require_gpu(dy, y)
+    if dy.stride(1) != 1:
+        dy = dy.contiguous()
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    M, F = dy.shape
+    dz = torch.empty((M, F), dtype=torch.float32, device=dev)
+    check(load().npi_relu_backward(ptr(dy), dy.stride(0), ptr(y), y.stride(0), M, F, ptr(dz), dz.stride(0), stream_ptr(dev)),
+          "npi_relu_backward")
+    return dz
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     dev = require_gpu(x)
     x = _f32c(x, "x")
@@ -293,7 +310,7 @@ class _SageConvFn(torch.autograd.Function):
         graph: CSRGraph = ctx.graph
         grad_out = _fc(grad_out, "grad_out", agg)
         if ctx.relu:                                            # threshold_backward, as F.relu's autograd does it
-            grad_out = torch.ops.aten.threshold_backward(grad_out, ctx.saved_tensors[2], 0)
+            grad_out = relu_backward(grad_out, ctx.saved_tensors[2])
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
@@ -605,7 +622,7 @@ def gat_rowdot_colsum(a, b, bias, H, C, want_colsum: bool = True, relu_mask: boo
           and b.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
     if not ok or not GAT_ITEM_SCANS:
         if relu_mask:
-            a = torch.ops.aten.threshold_backward(a, b, 0)
+            a = relu_backward(a, b)
         res = (gat_rowdot(a, b, bias, H, C), (colsum(a) if want_colsum else None))
         return res + (a,) if relu_mask else res
     D = torch.empty((N, H), dtype=torch.float32, device=dev)

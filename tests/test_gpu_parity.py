@@ -768,3 +768,32 @@ def test_split_gemm_reads_nothing_past_the_end_of_its_operand(dev):
     assert float((out[rows].double() - ref).abs().max()) < 1e-4
     del a, out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("M,F", [(1000, 128), (4097, 178), (3, 1), (20000, 256)])
+def test_relu_backward_kernel_equals_threshold_backward(dev, M, F):
+    """npi_relu_backward (the mask of SAGEConv(..., relu=True) in the layer's own backward) == autograd's op, bit for bit,
+    on contiguous rows and on a view with a row pitch."""
+    g = torch.Generator().manual_seed(M + F)
+    dy = torch.randn(M, F, generator=g).to(dev)
+    y = torch.relu(torch.randn(M, F, generator=g)).to(dev)
+    assert torch.equal(NF.relu_backward(dy, y), torch.ops.aten.threshold_backward(dy, y, 0))
+    wide = torch.randn(M, F + 5, generator=g).to(dev)
+    assert torch.equal(NF.relu_backward(wide[:, :F], y), torch.ops.aten.threshold_backward(wide[:, :F], y, 0))
+    # through the layer: relu=True == F.relu(conv(x)), output and gradients
+    if F >= 64 and M >= 1000:
+        ei = rand_edges(M, 5 * M, seed=3).to(dev)
+        W = (torch.randn(F, 64, generator=g) / F ** 0.5).to(dev)
+        b = torch.randn(64, generator=g).to(dev)
+        x = torch.randn(M, F, generator=g).to(dev)
+        go = torch.randn(M, 64, generator=g).to(dev)
+        res = []
+        for fused in (True, False):
+            xd, Wd, bd = (t.clone().requires_grad_(True) for t in (x, W, b))
+            out = npi.sage_conv(xd, ei, Wd, bd, relu=fused)
+            out = out if fused else torch.relu(out)
+            out.backward(go)
+            res.append((out.detach(), xd.grad, Wd.grad, bd.grad))
+        assert torch.equal(res[0][0], res[1][0])
+        for a, c in zip(res[0][1:], res[1][1:]):
+            assert torch.allclose(a, c, rtol=1e-5, atol=1e-6 * float(c.abs().max()))
