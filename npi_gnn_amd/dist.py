@@ -443,6 +443,10 @@ class HipBackend:
         from . import functional as NF
         return NF.gat_rowdot(a, b, bias, H, C)
 
+    def gat_rowdot_colsum(self, a, b, bias, H, C, want_colsum=True):
+        from . import functional as NF
+        return NF.gat_rowdot_colsum(a, b, bias, H, C, want_colsum=want_colsum)
+
     def gat_edge_grad(self, side, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap):
         from . import functional as NF
         return NF.gat_edge_grad(side, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap)
@@ -974,6 +978,38 @@ class _ShardedGatFn(torch.autograd.Function):
         return dx, dw, datt, db, None, None, None
 
 
+class _fork:
+    """``with _fork(stream, inputs) as f: ...`` runs the block on ``stream`` (inline when it is None): the stream first waits
+    for the current one, ``inputs`` (allocated on the current stream) are recorded on it; ``f.join(*outputs)`` makes the
+    current stream wait for the block and records the outputs (allocated on ``stream``) on the current stream."""
+
+    def __init__(self, stream, inputs=()):
+        self.s, self.inputs = stream, [t for t in inputs if t is not None and t.is_cuda]
+        self.ctx = None
+
+    def __enter__(self):
+        if self.s is not None:
+            self.cur = torch.cuda.current_stream(self.s.device)
+            self.s.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.s)
+            self.ctx.__enter__()
+            for t in self.inputs:
+                t.record_stream(self.s)
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        if self.s is not None:
+            self.cur.wait_stream(self.s)
+            for t in outputs:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.cur)
+
+
 class _ShardedGatDirectFn(torch.autograd.Function):
     """GATConv, 1 / 2 / 4 / 8 heads, on the direct layout (cuts without hub-hub edges) with the single-GPU layer's round-3 kernels: the
     statistics pass leaves the per-entry scores, the aggregation reads them back, and the backward is ONE fused gather pass per
@@ -1002,29 +1038,32 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         tbl_h, g_work = gather_hub(sg, h, async_op=True)                           # big: hub rows of h
         hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))               # small
         tbl_a_dst, tbl_a_src = hub_sc[:, :H].contiguous(), hub_sc[:, H:].contiguous()
-        # hub rows: this rank's share -- its light sources and the loops of the hubs it owns; needs nothing of tbl_h
+        # hub rows: this rank's share -- its light sources and the loops of the hubs it owns; needs nothing of tbl_h, so the
+        # whole chain (statistics, MAX all-reduce, aggregation, reduce-scatters) runs on the partial stream beside the light rows
         # (one head: the statistics pass leaves the per-entry scores and the aggregation reads them back)
-        if H == 1:
-            mB, sB, eB = be.gat_stats_scores(B, tbl_a_dst, a_src, slope)
-        else:
-            mB, sB = be.gat_stats(B, tbl_a_dst, a_src, H, slope)
-        empty = be.row_lengths(B).view(-1, 1) == 0
-        M = torch.where(empty, torch.full_like(mB, NEG), mB)
-        _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
-        if H == 1:
-            U = be.gat_aggregate_scores(B, h, None, C, eB, M, torch.ones_like(M))  # sum exp(e - M) h_j, not normalised
-        else:
-            U = be.gat_aggregate(B, h, None, H, C, tbl_a_dst, a_src, M, torch.ones_like(M), slope, False)
-        S = torch.where(empty, torch.zeros_like(sB), sB * torch.exp(mB - M))
         out_full = h.new_empty((nL + hp, F))
         hU, wU = out_full[nL:], None                                               # the reduce-scatter lands in the output
-        if _solo(W):
-            hU.copy_(U)
-            s_own = S
-        else:
-            wU = reduce_scatter_rows(U, hU, sg.rank, W, sg.group, async_op=True)
-            s_own = S.new_empty((hp, H))
-            _wait(reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.group, async_op=True), "fwd_reduce_scatter_s", s_own)
+        bs = be.partial_stream(h) if (PARTIAL_SIDE_STREAM and not _solo(W) and hasattr(be, "partial_stream")) else None
+        with _fork(bs, (h, a_src, tbl_a_dst, out_full)) as fk:
+            if H == 1:
+                mB, sB, eB = be.gat_stats_scores(B, tbl_a_dst, a_src, slope)
+            else:
+                mB, sB = be.gat_stats(B, tbl_a_dst, a_src, H, slope)
+            empty = be.row_lengths(B).view(-1, 1) == 0
+            M = torch.where(empty, torch.full_like(mB, NEG), mB)
+            _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
+            if H == 1:
+                U = be.gat_aggregate_scores(B, h, None, C, eB, M, torch.ones_like(M))  # sum exp(e - M) h_j, not normalised
+            else:
+                U = be.gat_aggregate(B, h, None, H, C, tbl_a_dst, a_src, M, torch.ones_like(M), slope, False)
+            S = torch.where(empty, torch.zeros_like(sB), sB * torch.exp(mB - M))
+            if _solo(W):
+                hU.copy_(U)
+                s_own = S
+            else:
+                wU = reduce_scatter_rows(U, hU, sg.rank, W, sg.group, async_op=True)
+                s_own = S.new_empty((hp, H))
+                _wait(reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.group, async_op=True), "fwd_reduce_scatter_s", s_own)
         # light rows: the whole softmax is local once the hub table is here
         tbl_a_src_full = torch.cat([tbl_a_src, a_src])                             # index space of A's columns
         if H == 1:
@@ -1036,6 +1075,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
             _wait(g_work, "fwd_all_gather", tbl_h)
             be.gat_aggregate(A, tbl_h, h, H, C, a_dst[:nL].contiguous(), tbl_a_src_full, mA, sA, slope, False, bias=bias,
                              out=out_full[:nL])
+        fk.join(M, s_own)
         _wait(wU, "fwd_reduce_scatter", hU)
         if nH:
             hub = (hU[:nH].view(nH, H, C) / (s_own[:nH].view(nH, H, 1) + 1e-16)).reshape(nH, F)
@@ -1061,20 +1101,25 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         A, B, At, Bt = sg.direct()
         map_a, map_b, n_bt, n_at = sg.gat_maps()
         dO = grad_out.contiguous()
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[3]:
-            db = be.colsum(dO)
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        if hasattr(be, "gat_rowdot_colsum"):                                       # D and the bias gradient in one pass over dOut, out
+            D, db = be.gat_rowdot_colsum(dO, out, bias if ctx.has_bias else None, H, C, want_colsum=want_db)
+        else:
+            D, db = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, H, C), (be.colsum(dO) if want_db else None)
+        if db is not None:
             _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
-        D = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, H, C)           # [n_local, H]
         tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                         # big: hub rows of dOut
         tbl_D, _ = gather_hub(sg, D)
         # packed per-TARGET scalars (a_dst, m, 1 / s, D): the own rows, and the hub table (targets of the light sources)
         t_own = be.gat_pack(a_dst, m_own, s_all, D)
         t_tbl = be.gat_pack(tbl_a_dst, M, tbl_S, tbl_D)
-        # hub SOURCES (rows of the hub table): targets = this rank's rows (its light rows; the own hubs' loops): nothing remote
-        pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope, H=H)
-        dz_bt = dz_bt.view(-1, H)
-        pg_src = be.seg_rowsum(Bt, dz_bt, H)
+        # hub SOURCES (rows of the hub table): targets = this rank's rows (its light rows; the own hubs' loops): nothing remote,
+        # so this pass and its row sums run on the partial stream beside the light sources' pass
+        bs = be.partial_stream(h) if (PARTIAL_SIDE_STREAM and not _solo(W) and hasattr(be, "partial_stream")) else None
+        with _fork(bs, (dO, tbl_h, t_own, tbl_a_src)) as fk:
+            pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope, H=H)
+            dz_bt = dz_bt.view(-1, H)
+            pg_src = be.seg_rowsum(Bt, dz_bt, H)
         # own light SOURCES: targets = the hub table (+ the own loop)
         dh_full = h.new_empty((nL + hp, F))
         _wait(g_work, "bwd_all_gather", tbl_dO)
@@ -1082,6 +1127,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
                                          out=dh_full[:nL], H=H)
         dz_at = dz_at.view(-1, H)
         g_src_l = be.seg_rowsum(At, dz_at, H)
+        fk.join(pdh, dz_bt, pg_src)
         dz_cat = torch.cat([dz_bt[:n_bt], dz_at[:n_at]])
         g_dst_l = be.seg_rowsum(A, dz_cat, H, map_=map_a)                          # light targets: complete
         pg_dst = be.seg_rowsum(B, dz_cat, H, map_=map_b)                           # hub targets: this rank's share

@@ -101,6 +101,9 @@ class TorchBackend:
         bb = b - bias if bias is not None else b
         return (a.view(-1, H, C) * bb.view(-1, H, C)).sum(-1)
 
+    def gat_rowdot_colsum(self, a, b, bias, H, C, want_colsum=True):
+        return self.gat_rowdot(a, b, bias, H, C), (a.sum(0) if want_colsum else None)
+
     def gat_edge_grad(self, side, col_feat, col_feat2, row_feat, H, C, a_dst, a_src, m, s, D, slope, swap):
         key, val = side[0], side[1]
         alpha, z, tgt = self._alpha(side, a_dst, a_src, m, s, slope, bool(swap))
