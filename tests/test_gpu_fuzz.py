@@ -127,3 +127,16 @@ def test_random_pooling_batches(dev, seed):
     kept = torch.bincount(bo, minlength=n_graphs) > 0
     assert torch.allclose(ro[kept], ref[kept], atol=1e-5, rtol=1e-5)
     assert float(ro[~kept].abs().sum()) == 0.0               # a graph without nodes reads out zeros
+
+
+def test_gat_random_campaign(dev):
+    """tools/fuzz_gat.py, 60 cases: random graphs (hub rows, empty rows, self loops, duplicates), 1 / 2 / 4 / 8 heads, both
+    item sizes (256-entry items forced on small graphs through npi_small_graph_entries), fused ReLU on / off -- GATConv
+    forward and every gradient against the fp64 oracle (1,050 cases of the same generator ran clean in round 3)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gat.py"), "60", "11"], capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0 and "60 cases ok" in p.stdout, (p.stdout + p.stderr)[-2000:]
