@@ -70,12 +70,18 @@ def test_gat_module_concat_false_and_state_dict(dev):
     assert conv.att.grad is not None and torch.isfinite(conv.att.grad).all()
 
 
-def test_gat_is_bitwise_reproducible(dev):
-    ei, x, W, att, b, go = _case(4000, 60000, 64, 1, 256, seed=4)
-    args = [t.to(dev) for t in (x, ei, W, att, b)]
-    a = npi.gat_conv(*args)
-    c = npi.gat_conv(*args)
-    assert torch.equal(a, c)
+@pytest.mark.parametrize("H,C", [(1, 256), (4, 64), (8, 32)])
+def test_gat_is_bitwise_reproducible(dev, H, C):
+    """forward AND every gradient, run to run: no float atomics anywhere (item scans, fused backward, chain folds)"""
+    ei, x, W, att, b, go = _case(4000, 60000, 64, H, C, seed=4)
+    runs = []
+    for _ in range(2):
+        xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+        out = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=H)
+        out.backward(go.to(dev))
+        runs.append((out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad))
+    for a, c in zip(*runs):
+        assert torch.equal(a, c)
 
 
 def _sides(dev, n_rows, n_cols, E, seed, hub_rows=(3,), empty_from=None):
