@@ -7,9 +7,9 @@ Only what the path needs: ``csrc/`` (hand-written gfx950 kernels + the C ABI of
 be imported.
 """
 from ._lib import LIB_PATH, NpiError, load  # noqa: F401
-from .graph import CSRGraph, as_graph, set_debug  # noqa: F401
+from .graph import CSRGraph, GraphBatch, as_graph, set_debug  # noqa: F401
 from .functional import GCNNorm, gat_conv, gcn_conv, sage_conv, segsum  # noqa: F401
 from .nn import GATConv, GCNConv, SAGEConv  # noqa: F401
 
-__all__ = ["CSRGraph", "as_graph", "set_debug", "GCNNorm", "gat_conv", "gcn_conv", "sage_conv", "segsum",
+__all__ = ["CSRGraph", "GraphBatch", "as_graph", "set_debug", "GCNNorm", "gat_conv", "gcn_conv", "sage_conv", "segsum",
            "GATConv", "GCNConv", "SAGEConv", "NpiError", "load", "LIB_PATH"]

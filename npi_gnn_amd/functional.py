@@ -344,10 +344,12 @@ class _SageConvFn(torch.autograd.Function):
 
 
 def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              normalize: bool = False, edge_weight: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+              normalize: bool = False, edge_weight: Optional[torch.Tensor] = None, relu: bool = False,
+              pad_base: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PyG 1.4.2 ``SAGEConv(normalize=False, concat=False).forward`` on MI355X
     (call sites: reference ``src/classes.py:62,66,70``).  ``edge_weight [E]`` scales the messages
-    (no gradient flows to it, as in the reference's use of the layer)."""
+    (no gradient flows to it, as in the reference's use of the layer).  ``pad_base``: the wider buffer ``x`` is the leading
+    columns of, its other columns zero (``GraphBatch.pad_base``)."""
     require_gpu(x, weight, bias)
     if edge_weight is not None and edge_weight.requires_grad:
         raise NotImplementedError("gradients w.r.t. edge_weight are not implemented")      # as gcn_conv: never silently detached
@@ -355,7 +357,7 @@ def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[
     w_entry = entry_weights(graph, edge_weight, 1.0) if edge_weight is not None else None
     # features that are a view of a wider buffer whose extra columns are zero (InteractionGraph.batch: 178 -> 256): the
     # layer runs on the padded buffer, so that its GEMMs take the matrix-core kernels instead of the guarded ones
-    base = getattr(x, "_npi_pad_base", None)
+    base = pad_base
     if (base is not None and not x.requires_grad and x.dtype == torch.float32 and base.size(0) == x.size(0)
             and base.size(1) == _pad128(x.size(1)) and weight.size(0) == x.size(1) and base.data_ptr() == x.data_ptr()):
         x = base

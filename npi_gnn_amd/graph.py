@@ -144,8 +144,13 @@ class CSRGraph:
     ``by_dst`` groups entries by target node (forward aggregation, PyG flow ``source_to_target``);
     ``by_src`` groups them by source node (backward: dX = A^T ...), built lazily."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, self_loops: bool = True, by_dst: Optional[CSRSide] = None):
-        """``by_dst``: a by-target side somebody already derived for this very edge list (``filtered_side``): not rebuilt."""
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, self_loops: bool = True, by_dst: Optional[CSRSide] = None,
+                 symmetric: bool = False):
+        """``by_dst``: a by-target side somebody already derived for this very edge list (``filtered_side``): not rebuilt.
+        ``symmetric``: the producer of the edge list vouches that it holds every edge in both directions (the device-side
+        subgraph extraction emits both, src/classes.py:701-704, and filter_adj keeps the property; ``GraphBatch.symmetric``).
+        Then row j of the by-source CSR holds the same neighbours as row j of the by-target CSR -- in another order -- and an
+        UNWEIGHTED transposed aggregation can walk the by-target side: no second sort (functional._SageConvFn)."""
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be a LongTensor of shape [2, E]")
         require_gpu(edge_index)
@@ -153,15 +158,11 @@ class CSRGraph:
         self.num_edges = int(edge_index.size(1))
         self.self_loops = bool(self_loops)
         self.device = edge_index.device
-        # what this CSR was built from: a cached graph is reused only for THIS tensor in THIS state (an in-place edit of the
-        # edge list bumps ``_version`` and the next conv call sorts again -- ``cached_graph``)
+        # what this CSR was built from: a GraphBatch reuses it only for THIS tensor in THIS state (an in-place edit of the
+        # edge list bumps ``_version`` and the next conv call sorts again -- ``built_from``)
         self._ei_version = edge_index._version
         self._ei_ptr = edge_index.data_ptr()
-        # The producer of the edge list may vouch that it holds every edge in both directions (edge_index._npi_symmetric:
-        # the device-side subgraph extraction emits both, src/classes.py:701-704, and filter_adj keeps the property).
-        # Then row j of the by-source CSR holds the same neighbours as row j of the by-target CSR -- in another order --
-        # and an UNWEIGHTED transposed aggregation can walk the by-target side: no second sort (functional._SageConvFn).
-        self.symmetric = bool(getattr(edge_index, "_npi_symmetric", False))
+        self.symmetric = bool(symmetric)
         # rows of a [2,E] tensor are contiguous when the tensor is; otherwise copy (index plumbing)
         self._src = edge_index[0].contiguous()
         self._dst = edge_index[1].contiguous()
@@ -174,6 +175,12 @@ class CSRGraph:
         if self._by_src is None:
             self._by_src = _build_side(self._src, self._dst, self.num_edges, self.num_nodes, self.self_loops)
         return self._by_src
+
+    def built_from(self, edge_index: torch.Tensor, num_nodes: Optional[int] = None) -> bool:
+        """True while ``edge_index`` is still the tensor this CSR was built from: same storage, same shape and, above all,
+        the same ``_version`` (every in-place write bumps it)."""
+        return (self.num_edges == edge_index.size(1) and self._ei_version == edge_index._version
+                and self._ei_ptr == edge_index.data_ptr() and (num_nodes is None or self.num_nodes == int(num_nodes)))
 
     def inv_count(self, side: CSRSide) -> torch.Tensor:
         return side.inv_count()
@@ -188,44 +195,141 @@ class CSRGraph:
         return n
 
 
-def cached_graph(edge_index: torch.Tensor, num_nodes: Optional[int] = None) -> Optional[CSRGraph]:
-    """The CSR an earlier call left on this edge list -- only if the tensor is still the one it was built from: same
-    storage, same shape and, above all, the same ``_version`` (every in-place write bumps it), so an edit of a cached edge
-    list is never answered from the stale CSR."""
-    g = getattr(edge_index, "_npi_graph", None)
-    if (isinstance(g, CSRGraph) and g.num_edges == edge_index.size(1) and g._ei_version == edge_index._version
-            and g._ei_ptr == edge_index.data_ptr() and (num_nodes is None or g.num_nodes == num_nodes)):
+@dataclass
+class CSRRecipe:
+    """How to obtain the by-target CSR of the graph a pooling layer leaves WITHOUT sorting: the parent's side filtered by the
+    kept nodes (``filtered_side``).  Made by ``pool.topk_pool``, consumed -- at most once, and only if a conv asks -- by
+    ``GraphBatch.graph``."""
+    parent: CSRSide
+    perm: torch.Tensor            # int32 [n_out]  new -> old node id
+    remap: torch.Tensor           # int32 [N]      old -> new node id or -1
+    newpos: torch.Tensor          # int32 [E]      where filter_adj put every input edge
+    n_out: int
+    num_edges_out: int
+    ei_version: int               # ``edge_index._version`` of the pooled edge list when the recipe was written
+
+
+class GraphBatch:
+    """One batch of graphs as the layers of ``Net_1`` hand it to one another: the node features
+    and everything this package knows about the structure they live on, in ONE explicit object -- nothing rides on tensor
+    attributes.  ``SAGEConv`` / ``GCNConv`` / ``GATConv`` map a ``GraphBatch`` to a ``GraphBatch`` (new ``x``, same structure),
+    ``TopKPooling`` to the pooled one, ``global_max_mean_pool`` reads its segments.  The layers still take PyG's plain
+    ``(x, edge_index[, batch])`` tensors; what they then cannot know is exactly the optional part below.
+
+    x           [n, F] float32 node features
+    edge_index  [2, E] int64, PyG layout (row 0 = source, row 1 = target); may end in (-1, -1) padding columns when it comes
+                from ``TopKPooling(padded_edges=True)`` -- every consumer in this package drops them
+    batch       [n] int64 graph id per node, non-decreasing (None: one graph)
+    num_graphs  B (None: read from ``batch`` when needed)
+    sizes       host LongTensor [B], nodes per graph, when known WITHOUT a device read (``net1.KeyLoader``: a sample's
+                size depends on its key only; a pooling layer: ceil(ratio n_g)) -- lets TopKPooling run without a read-back
+    graph_ptr   device int32 [B+1] segment starts of ``batch`` (``segment_ptr()`` builds them on first use)
+    symmetric   the edge list holds every edge in both directions (``CSRGraph.symmetric``)
+    pad_base    ``x`` is the leading columns of this wider buffer whose other columns are zero (``InteractionGraph.batch``:
+                178 -> 256): the first conv runs its GEMMs on the padded width
+    The CSR of ``edge_index`` is built by ``graph()`` on first use and kept for as long as the tensor is unchanged
+    (``CSRGraph.built_from``: storage, shape and ``_version``); a pooled batch may carry a ``CSRRecipe`` instead."""
+
+    __slots__ = ("x", "edge_index", "batch", "num_graphs", "sizes", "graph_ptr", "symmetric", "pad_base", "_csr", "_recipe")
+
+    def __init__(self, x: torch.Tensor, edge_index: torch.Tensor, batch: Optional[torch.Tensor] = None,
+                 num_graphs: Optional[int] = None, *, sizes: Optional[torch.Tensor] = None,
+                 graph_ptr: Optional[torch.Tensor] = None, symmetric: bool = False, pad_base: Optional[torch.Tensor] = None,
+                 csr: Optional[CSRGraph] = None, recipe: Optional[CSRRecipe] = None):
+        if isinstance(edge_index, CSRGraph):
+            raise TypeError("GraphBatch: edge_index is the [2, E] tensor; pass a prebuilt CSRGraph as csr=")
+        self.x, self.edge_index, self.batch = x, edge_index, batch
+        if num_graphs is None and sizes is not None:
+            num_graphs = int(sizes.numel())
+        if num_graphs is None and graph_ptr is not None:
+            num_graphs = int(graph_ptr.numel()) - 1
+        if num_graphs is None and batch is None:
+            num_graphs = 1
+        self.num_graphs = None if num_graphs is None else int(num_graphs)
+        if sizes is not None and self.num_graphs is not None and int(sizes.numel()) != self.num_graphs:
+            raise ValueError(f"GraphBatch: sizes has {int(sizes.numel())} entries for {self.num_graphs} graphs")
+        self.sizes, self.graph_ptr = sizes, graph_ptr
+        self.symmetric, self.pad_base = bool(symmetric), pad_base
+        self._csr, self._recipe = csr, recipe
+
+    # ---- unpacking as PyG's (x, edge_index, batch) ----------------------------------------------------------------------------
+    def __iter__(self):
+        return iter((self.x, self.edge_index, self.batch))
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.x.size(0))
+
+    def to(self, device):
+        """Batches of this package are born on the device (``InteractionGraph.batch``); kept for the reference's
+        ``data = data.to(device)`` (src/train_with_twoDataset.PY:50)."""
+        return self
+
+    def with_x(self, x: torch.Tensor) -> "GraphBatch":
+        """The same graphs with other node features (what a conv returns); the structure, incl. a CSR already built, is shared."""
+        return GraphBatch(x, self.edge_index, self.batch, self.num_graphs, sizes=self.sizes, graph_ptr=self.graph_ptr,
+                          symmetric=self.symmetric, pad_base=None, csr=self._csr, recipe=self._recipe)
+
+    # ---- structure, built on demand ------------------------------------------------------------------------------------------------
+    def peek_graph(self) -> Optional[CSRGraph]:
+        """The CSR if one was built AND ``edge_index`` has not been written to since; never builds."""
+        g = self._csr
+        if g is not None and g.built_from(self.edge_index, self.num_nodes):
+            return g
+        return None
+
+    def graph(self) -> CSRGraph:
+        """CSR of ``edge_index`` (+ self loops).  Reused while the edge list is untouched; an in-place edit (``_version``)
+        makes the next call sort again, so a stale adjacency is never served."""
+        g = self.peek_graph()
+        if g is not None:
+            return g
+        n, ei = self.num_nodes, self.edge_index
+        r, self._recipe = self._recipe, None                   # consumed either way: the parent's arrays are not kept alive
+        g = None
+        if r is not None and r.ei_version == ei._version and r.n_out == n and r.num_edges_out == ei.size(1):
+            side = filtered_side(r.parent, r.perm, r.remap, r.newpos, r.n_out, r.num_edges_out)
+            if side is not None:
+                g = CSRGraph(ei, n, by_dst=side, symmetric=self.symmetric)
+        if g is None:
+            g = CSRGraph(ei, n, symmetric=self.symmetric)
+        self._csr = g
         return g
-    return None
+
+    def segment_ptr(self) -> torch.Tensor:
+        """int32 ``[B+1]`` segment starts of ``batch`` on the device (kept)."""
+        if self.graph_ptr is None:
+            dev = self.x.device
+            if self.batch is None:
+                self.graph_ptr = torch.tensor([0, self.num_nodes], dtype=torch.int32, device=dev)
+            else:
+                from .pool import graph_ptr as _graph_ptr
+                self.graph_ptr = _graph_ptr(self.batch, self.num_graphs)
+            if self.num_graphs is None:
+                self.num_graphs = int(self.graph_ptr.numel()) - 1
+        return self.graph_ptr
+
+    def batch_vector(self) -> torch.Tensor:
+        if self.batch is None:
+            self.batch = torch.zeros(self.num_nodes, dtype=torch.int64, device=self.x.device)
+        return self.batch
+
+    def __repr__(self):
+        return (f"GraphBatch(nodes={self.num_nodes}, edges={int(self.edge_index.size(1))}, graphs={self.num_graphs}, "
+                f"F={int(self.x.size(1)) if self.x.dim() == 2 else '?'})")
 
 
 def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:
+    """What the convs aggregate over: a prebuilt ``CSRGraph``, a ``GraphBatch`` (its cached / derived CSR) or a plain
+    ``edge_index`` tensor (sorted here, every call: a tensor carries no state)."""
+    if isinstance(edge_index_or_graph, GraphBatch):
+        edge_index_or_graph = edge_index_or_graph.graph()
     if isinstance(edge_index_or_graph, CSRGraph):
         g = edge_index_or_graph
         if g.num_nodes != num_nodes:
             raise ValueError(f"CSRGraph was built for {g.num_nodes} nodes, x has {num_nodes}")
         return g
-    # an edge list that is used again and again (the static batches of net1.GraphedEpoch) may carry its CSR
-    g = cached_graph(edge_index_or_graph, num_nodes)
-    if g is not None:
-        return g
-    # the edge list TopKPooling returned: its CSR is the parent's, filtered (no sort) -- unless somebody wrote to it since
-    src = getattr(edge_index_or_graph, "_npi_graph_from", None)
-    g = None
-    if src is not None and len(src) == 7 and src[6] != edge_index_or_graph._version:
-        src = None
-    if src is not None and src[4] == num_nodes and src[5] == edge_index_or_graph.size(1):
-        side = filtered_side(*src[:6])
-        if side is not None:
-            g = CSRGraph(edge_index_or_graph, num_nodes, by_dst=side)
-        edge_index_or_graph._npi_graph_from = None           # the parent's arrays are not kept alive any longer
-    if g is None:
-        g = CSRGraph(edge_index_or_graph, num_nodes)
-    if getattr(edge_index_or_graph, "_npi_symmetric", False):
-        # an edge list this package produced itself (device-side extraction, filter_adj) and nobody modifies in place: its
-        # CSR stays on it -- the pooling layer behind the conv derives the pooled graph's CSR from it (filtered_side)
-        edge_index_or_graph._npi_graph = g
-    return g
+    return CSRGraph(edge_index_or_graph, num_nodes)
 
 
 def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newpos: torch.Tensor, n_out: int,
@@ -255,12 +359,3 @@ def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newp
     side = CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
     side.n_rows = side.n_cols = n_out
     return side
-
-
-def attach_graph(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
-    """Build the CSR of ``edge_index`` once and leave it on the tensor: every later conv call on this very tensor reuses
-    it instead of sorting again.  For edge lists that do not change (a loader that replays the same batches); the caller
-    vouches that the tensor is not modified in place afterwards."""
-    g = CSRGraph(edge_index, num_nodes)
-    edge_index._npi_graph = g
-    return g

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import head as NH
 from . import metrics as NM
 from . import pool as NP
-from .graph import attach_graph
+from .graph import GraphBatch
 from .nn import SAGEConv
 from .subgraph import InteractionGraph
 
@@ -45,14 +45,16 @@ class Net_1(torch.nn.Module):
         self.lin3 = torch.nn.Linear(64, num_of_classes)
 
     def forward(self, data):
-        x, edge_index, batch = data.x, data.edge_index, data.batch
-        B = getattr(data, "num_graphs", None)
+        # one explicit object travels through the layers (graph.GraphBatch); a PyG-style batch (x, edge_index, batch,
+        # num_graphs attributes) is wrapped -- then without the optional knowledge (host sizes, symmetry, padded features)
+        gb = data if isinstance(data, GraphBatch) else \
+            GraphBatch(data.x, data.edge_index, data.batch, getattr(data, "num_graphs", None))
         readouts = []
         for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
-            x = conv(x, edge_index, relu=True)               # F.relu(conv(x, edge_index)), the ReLU in the GEMM's epilogue
-            x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
+            gb = conv(gb, relu=True)                         # F.relu(conv(x, edge_index)), the ReLU in the GEMM's epilogue
+            gb, _, _ = pool(gb)                              # x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
             # torch.cat([gmp(x, batch), gap(x, batch)], dim=1) as ONE kernel (src/classes.py:64,68,72)
-            readouts.append(NP.global_max_mean_pool(x, batch, B))
+            readouts.append(NP.global_max_mean_pool(gb))
         if FUSED_HEAD and NH.head_dims_ok(self.lin1.in_features, self.lin1.out_features, self.lin2.out_features,
                                           self.lin3.out_features):
             # x1 + x2 + x3 and the whole MLP head (src/classes.py:74-80) in one forward / two backward launches
@@ -65,15 +67,15 @@ class Net_1(torch.nn.Module):
         return F.log_softmax(x, dim=-1)
 
 
-class Batch:
-    """What a PyG ``DataLoader`` yields, as far as ``Net_1``, ``train()`` and the metrics look at it."""
+class Batch(GraphBatch):
+    """What a PyG ``DataLoader`` yields, as far as ``Net_1``, ``train()`` and the metrics look at it: a ``GraphBatch`` plus
+    the labels ``y``."""
+    __slots__ = ("y",)
 
-    def __init__(self, x, edge_index, batch, y):
-        self.x, self.edge_index, self.batch, self.y = x, edge_index, batch, y
-        self.num_graphs = int(y.numel())
-
-    def to(self, device):
-        return self
+    def __init__(self, gb: GraphBatch, y: torch.Tensor, sizes: Optional[torch.Tensor] = None):
+        super().__init__(gb.x, gb.edge_index, gb.batch, int(y.numel()), sizes=sizes if sizes is not None else gb.sizes,
+                         graph_ptr=gb.graph_ptr, symmetric=gb.symmetric, pad_base=gb.pad_base)
+        self.y = y
 
 
 class KeyLoader:
@@ -102,9 +104,9 @@ class KeyLoader:
         for i in range(0, len(self.dataset), self.batch_size):
             k = self.keys[i:i + self.batch_size]
             nodes = self._nodes[i:i + self.batch_size]
-            x, ei, b = self.ig.batch(k, n_nodes=int(nodes.sum()), n_pairs=int(self._pairs[i:i + self.batch_size].sum()))
-            b._npi_sizes = nodes                          # host-known graph sizes: TopKPooling then needs no device read
-            yield Batch(x, ei, b, self.y[i:i + self.batch_size])
+            gb = self.ig.batch(k, n_nodes=int(nodes.sum()), n_pairs=int(self._pairs[i:i + self.batch_size].sum()))
+            # sizes=: the graph sizes known on the host -- TopKPooling then needs no device read
+            yield Batch(gb, self.y[i:i + self.batch_size], sizes=nodes)
 
 
 def train(model, train_loader, optimizer, device) -> float:
@@ -145,8 +147,8 @@ class GraphedEpoch:
             # the input graph of a batch never changes either: its CSR is built here, once, instead of inside every step
             # (the reference's counterpart is the processed dataset file; the graphs AFTER each pooling layer depend on the
             # weights and are rebuilt inside the step)
-            attach_graph(d.edge_index, d.x.size(0))
-            d.batch._npi_graph_ptr = NP.graph_ptr(d.batch, d.num_graphs)      # likewise the segment starts of its batch vector
+            d.graph()
+            d.segment_ptr()                                                   # likewise the segment starts of its batch vector
         self.n = len(train_loader.dataset)
         self.graphs = [None] * len(self.batches)
         self.losses = [None] * len(self.batches)

@@ -7,7 +7,10 @@ NPI-GNN's ``Net_1`` (reference ``src/classes.py:45-82``) and its train loop
 ``state_dict`` keys are ``weight [in, out]`` (``x @ W`` orientation, not ``nn.Linear``'s) and
 ``bias [out]``, so the reference's checkpoints (``result/<proj>/model_<k>_fold/<epoch>``, loaded at
 ``src/test.py:41``) load as they are.  ``forward`` also accepts a prebuilt ``CSRGraph`` in place of
-``edge_index`` (static full-batch graphs: sort once).
+``edge_index`` (static full-batch graphs: sort once), and a ``GraphBatch`` in place of ``x`` -- then it
+returns the ``GraphBatch`` with the new features (``conv(gb)``: the CSR is built once per batch and shared
+with the pooling layer behind the conv).  Plain tensors carry no hidden state: ``conv(x, edge_index)``
+sorts the edge list on every call, as PyG's scatter walks it on every call.
 """
 from __future__ import annotations
 
@@ -19,7 +22,7 @@ from torch import nn
 from torch.nn import Parameter
 
 from . import functional as F_
-from .graph import CSRGraph, as_graph
+from .graph import CSRGraph, GraphBatch, as_graph
 
 
 def _uniform(size: int, tensor: Optional[torch.Tensor]) -> None:
@@ -34,6 +37,12 @@ def _glorot(tensor: Optional[torch.Tensor]) -> None:
     if tensor is not None:
         stdv = math.sqrt(6.0 / (tensor.size(-2) + tensor.size(-1)))
         tensor.data.uniform_(-stdv, stdv)
+
+
+def _only_batch(gb: GraphBatch, edge_index, who: str) -> GraphBatch:
+    if edge_index is not None:
+        raise TypeError(f"{who}: a GraphBatch carries its own edge_index")
+    return gb
 
 
 class SAGEConv(nn.Module):
@@ -61,11 +70,15 @@ class SAGEConv(nn.Module):
         _uniform(self.weight.size(0), self.weight)
         _uniform(self.weight.size(0), self.bias)
 
-    def forward(self, x, edge_index, edge_weight=None, size=None, *, relu: bool = False):
+    def forward(self, x, edge_index=None, edge_weight=None, size=None, *, relu: bool = False):
         """``relu=True`` (an extension of the PyG signature): ``F.relu(conv(x, edge_index))`` with the ReLU applied in the
         projection GEMM's epilogue -- the same values, one launch and one activation-sized tensor fewer."""
         if size is not None:
             raise NotImplementedError("SAGEConv: the bipartite `size` form is not used by NPI-GNN")
+        if isinstance(x, GraphBatch):
+            gb = _only_batch(x, edge_index, "SAGEConv")
+            return gb.with_x(F_.sage_conv(gb.x, gb.graph(), self.weight, self.bias, normalize=self.normalize,
+                                          edge_weight=edge_weight, relu=relu, pad_base=gb.pad_base))
         return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize, edge_weight=edge_weight,
                             relu=relu)
 
@@ -100,10 +113,14 @@ class GATConv(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
-    def forward(self, x, edge_index, size=None, *, relu: bool = False):
+    def forward(self, x, edge_index=None, size=None, *, relu: bool = False):
         """``relu=True`` (an extension of the PyG signature, as in ``SAGEConv``): ``F.relu(conv(x, edge_index))`` fused."""
         if size is not None:
             raise NotImplementedError("GATConv: bipartite `size` is not implemented")
+        if isinstance(x, GraphBatch):
+            gb = _only_batch(x, edge_index, "GATConv")
+            return gb.with_x(F_.gat_conv(gb.x, gb.graph(), self.weight, self.att, self.bias, self.heads, self.concat,
+                                         self.negative_slope, relu=relu))
         return F_.gat_conv(x, edge_index, self.weight, self.att, self.bias, self.heads, self.concat,
                            self.negative_slope, relu=relu)
 
@@ -139,7 +156,10 @@ class GCNConv(nn.Module):
         self.cached_result = None
         self.cached_num_edges = None
 
-    def forward(self, x, edge_index, edge_weight=None):
+    def forward(self, x, edge_index=None, edge_weight=None):
+        if isinstance(x, GraphBatch):
+            gb = _only_batch(x, edge_index, "GCNConv")
+            return gb.with_x(self.forward(gb.x, gb.graph(), edge_weight))
         norm = None
         if self.cached and self.cached_result is not None:
             E = edge_index.num_edges if isinstance(edge_index, CSRGraph) else edge_index.size(1)

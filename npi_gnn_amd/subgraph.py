@@ -19,7 +19,7 @@ from typing import Optional, Tuple
 import torch
 
 from ._lib import check, load, ptr, require_gpu, stream_ptr
-from .graph import build_side
+from .graph import GraphBatch, build_side
 
 
 # Row pitch of the feature matrix a batch returns: padded to a multiple of 128 with zero columns (see batch()).
@@ -85,7 +85,8 @@ class InteractionGraph:
 
     def batch(self, keys: torch.Tensor, return_node_id: bool = False, n_nodes: Optional[int] = None,
               n_pairs: Optional[int] = None):
-        """``keys [B, 2]`` (rna_serial, protein_serial) -> ``x, edge_index, batch`` of the B enclosing subgraphs.
+        """``keys [B, 2]`` (rna_serial, protein_serial) -> the ``GraphBatch`` of the B enclosing subgraphs (it unpacks as
+        ``x, edge_index, batch``; with ``return_node_id`` the pair ``(GraphBatch, node_id)``).
         ``n_nodes`` / ``n_pairs``: the batch's totals when the caller already knows them (``sizes``): no device read."""
         lib = load()
         dev = self.device
@@ -122,7 +123,7 @@ class InteractionGraph:
         bvec = torch.empty(n, dtype=torch.int64, device=dev)
         ei = torch.empty((2, 2 * npairs), dtype=torch.int64, device=dev)
         # an odd feature width (178) is stored with a row pitch of the next multiple of 128 and ZERO pad columns when that
-        # costs less than half as much again: x is the [n, 1 + Ff] view, `_npi_pad_base` the buffer; sage_conv then runs its
+        # costs less than half as much again: x is the [n, 1 + Ff] view, `GraphBatch.pad_base` the buffer; sage_conv then runs its
         # GEMMs on the padded width (matrix-core kernels instead of the guarded ones: functional.linear_fwd)
         Fx = 1 + Ff
         ld = (Fx + 127) // 128 * 128
@@ -133,11 +134,8 @@ class InteractionGraph:
                                     ptr(node_id), ptr(bvec), ptr(ei[0]), ptr(ei[1]), st), "npi_subgraph_fill")
         check(lib.npi_subgraph_features(ptr(self.feat), self.feat.stride(0), Ff, ptr(node_id), ptr(bvec), ptr(node_off), n,
                                         ptr(full), full.stride(0), st), "npi_subgraph_features")
-        x = full
-        if ld != Fx:
-            x = full[:, :Fx]
-            x._npi_pad_base = full
-        ei._npi_symmetric = True          # every pair is emitted in both directions (graph.CSRGraph.symmetric)
+        # every pair is emitted in both directions (symmetric: graph.CSRGraph.symmetric)
+        gb = GraphBatch(full if ld == Fx else full[:, :Fx], ei, bvec, B, symmetric=True, pad_base=None if ld == Fx else full)
         if return_node_id:
-            return x, ei, bvec, node_id[:n]
-        return x, ei, bvec
+            return gb, node_id[:n]
+        return gb

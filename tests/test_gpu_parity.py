@@ -635,7 +635,7 @@ def test_bf16_mfma_gemm_matches_f32_reference(dev, M, K, N):
 
 
 def test_symmetric_edge_list_skips_the_second_sort(dev):
-    """An edge list whose producer vouches for both directions (edge_index._npi_symmetric: the device-side extraction,
+    """An edge list whose producer vouches for both directions (GraphBatch.symmetric / CSRGraph(symmetric=True): the device-side extraction,
     filter_adj keeps it): the unweighted SAGE backward walks the by-target CSR -- the by-source one is never built -- and
     gives the same dX up to the summation order."""
     N, F = 3000, 128
@@ -647,10 +647,7 @@ def test_symmetric_edge_list_skips_the_second_sort(dev):
     conv = npi.SAGEConv(F, 64).to(dev)
     outs = []
     for mark in (False, True):
-        e = ei.clone()
-        if mark:
-            e._npi_symmetric = True
-        g = npi.CSRGraph(e, N)
+        g = npi.CSRGraph(ei.clone(), N, symmetric=mark)
         xg = x.clone().requires_grad_(True)
         out = conv(xg, g)
         out.backward(go)
@@ -701,14 +698,13 @@ def test_sage_conv_on_zero_padded_features_equals_the_plain_layer(dev):
     full = torch.zeros(N, 256)
     full[:, :Fi] = x
     full = full.to(dev)
-    xv = full[:, :Fi]
-    xv._npi_pad_base = full
+    xv = npi.GraphBatch(full[:, :Fi], ei, pad_base=full)
     go = torch.randn(N, Fo, generator=g).to(dev)
     res = []
     for inp in (xv, x.to(dev)):
         torch.manual_seed(0)
         conv = npi.SAGEConv(Fi, Fo).to(dev)
-        out = conv(inp, ei)
+        out = conv(inp).x if isinstance(inp, npi.GraphBatch) else conv(inp, ei)
         out.backward(go)
         res.append((out.detach().cpu(), conv.weight.grad.cpu(), conv.bias.grad.cpu()))
     for p, q in zip(*res):                                  # dW sums 6,000 products per element: different summation orders
@@ -730,7 +726,7 @@ def test_sage_conv_relu_in_the_epilogue_equals_relu_after_the_layer(dev, Fi, pad
         full[:, :Fi] = x
         full = full.to(dev)
         xd = full[:, :Fi]
-        xd._npi_pad_base = full
+        gbd = npi.GraphBatch(xd, ei, pad_base=full)
     else:
         xd = x.to(dev).requires_grad_(True)
     go = torch.randn(N, Fo, generator=g).to(dev)
@@ -740,7 +736,10 @@ def test_sage_conv_relu_in_the_epilogue_equals_relu_after_the_layer(dev, Fi, pad
         conv = npi.SAGEConv(Fi, Fo).to(dev)
         if not padded:
             xd.grad = None
-        out = conv(xd, ei, relu=True) if fused else torch.relu(conv(xd, ei))
+        if padded:
+            out = conv(gbd, relu=True).x if fused else torch.relu(conv(gbd).x)
+        else:
+            out = conv(xd, ei, relu=True) if fused else torch.relu(conv(xd, ei))
         out.backward(go)
         res.append((out.detach().clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), None if padded else xd.grad.clone()))
     assert torch.equal(res[0][0], res[1][0])

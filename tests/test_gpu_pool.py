@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _pool_tuple(gb, w, ratio, padded_edges=False):
+    """topk_pool_batch in the shape of PyG's 6-tuple (the tests below index it like the oracle's)"""
+    out, perm, score = NP.topk_pool_batch(gb, w, ratio, padded_edges=padded_edges)
+    return out.x, out.edge_index, None, out.batch, perm, score
+
+
 def load(name):
     return torch.load(os.path.join(G, name), map_location="cpu", weights_only=False)
 
@@ -111,7 +117,7 @@ def test_radix_selection_for_graphs_of_any_size(dev, sizes, ratio):
     """graphs above the LDS sort's 16,384 nodes are selected ON THE DEVICE (npi_topk_select_sorted: two
     stable radix sorts, by score and by graph id) -- no torch.argsort, no host read when the sizes are known.  The kept
     nodes, their order (score descending, lower index first among equals), the pooled batch vector and the filtered edge
-    list equal the oracle's; the no-sync path (batch._npi_sizes + padded_edges) gives the same and makes no device read."""
+    list equal the oracle's; the no-sync path (GraphBatch.sizes + padded_edges) gives the same and makes no device read."""
     g = torch.Generator().manual_seed(sum(sizes))
     n = sum(sizes)
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
@@ -126,14 +132,14 @@ def test_radix_selection_for_graphs_of_any_size(dev, sizes, ratio):
     got = NP.topk_pool(x.to(dev), ei.to(dev), batch.to(dev), w.to(dev), ratio)                       # sizes unknown: one read
     assert torch.equal(got[4].cpu(), perm) and torch.equal(got[3].cpu(), bo) and torch.equal(got[1].cpu(), eo)
     assert torch.allclose(got[0].cpu(), xo, atol=1e-6, rtol=1e-6)
-    b2 = batch.to(dev)
-    b2._npi_sizes = torch.tensor(sizes)
     xd, eid, wd = x.to(dev), ei.to(dev), w.to(dev)
-    NP.topk_pool(xd, eid, b2, wd, ratio, padded_edges=True)                                            # warm-up (lazy inits)
+    gb = NG.GraphBatch(xd, eid, batch.to(dev), sizes=torch.tensor(sizes))
+    _pool_tuple(gb, wd, ratio, padded_edges=True)                                                      # warm-up (lazy inits)
+    gb = NG.GraphBatch(xd, eid, batch.to(dev), sizes=torch.tensor(sizes))                            # (segment starts not kept)
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode("error")
     try:
-        ns = NP.topk_pool(xd, eid, b2, wd, ratio, padded_edges=True)
+        ns = _pool_tuple(gb, wd, ratio, padded_edges=True)
     finally:
         torch.cuda.set_sync_debug_mode("default")
     e = eo.size(1)
@@ -258,14 +264,15 @@ def test_readout_forward_backward_shapes(dev, sizes, F, view):
 
 
 def test_pooled_batch_carries_its_segment_starts(dev):
-    """topk_pool leaves the kept-row offsets on the batch vector it returns; they must equal a fresh search."""
+    """The pooled GraphBatch carries the kept-row offsets as its segment starts; they must equal a fresh search."""
     x, ei, batch, w = _batch_case(4, (7, 0, 30, 2, 65, 1), 128)
-    _, _, _, bo, _, _ = NP.topk_pool(x.to(dev), ei.to(dev), batch.to(dev), w.to(dev), 0.5, num_graphs=6)
-    carried = NP.graph_ptr(bo, 6)
-    fresh = NP.graph_ptr(bo.clone(), 6)
-    assert carried is getattr(bo, "_npi_graph_ptr")
-    assert torch.equal(carried.cpu(), fresh.cpu())
-    assert torch.equal(NP.graph_ptr(bo, 9).cpu()[:7], fresh.cpu())     # another graph count: searched again
+    out, _, _ = NP.topk_pool_batch(NG.GraphBatch(x.to(dev), ei.to(dev), batch.to(dev), 6), w.to(dev), 0.5)
+    assert out.graph_ptr is not None and out.segment_ptr() is out.graph_ptr and out.num_graphs == 6
+    fresh = NP.graph_ptr(out.batch, 6)
+    assert torch.equal(out.graph_ptr.cpu(), fresh.cpu())
+    assert torch.equal(NP.graph_ptr(out.batch, 9).cpu()[:7], fresh.cpu())     # another graph count: searched again
+    # the readout of the GraphBatch = the readout of its tensors
+    assert torch.equal(NP.global_max_mean_pool(out), NP.global_max_mean_pool(out.x, out.batch, 6))
 
 
 def test_readout_max_gradient_goes_to_the_first_of_tied_rows(dev):
@@ -315,7 +322,7 @@ def test_net1_training_step_gradients_match_oracle(dev):
 
 
 def test_pooling_without_a_device_read_when_graph_sizes_are_known(dev):
-    """with the per-graph node counts known on the host (batch._npi_sizes, what net1.KeyLoader attaches)
+    """with the per-graph node counts known on the host (GraphBatch.sizes, what net1.KeyLoader supplies)
     TopKPooling reads nothing back: the kept counts are ceil(ratio n_g), the surviving edges stay in an array of the
     input's length padded with (-1, -1) columns that the CSR build and the next filter_adj drop.  Same numbers as the
     path that reads its sizes, forward and backward, and torch's sync detector stays quiet over a whole Net_1 step."""
@@ -326,15 +333,14 @@ def test_pooling_without_a_device_read_when_graph_sizes_are_known(dev):
     sizes = torch.bincount(fx["batch"], minlength=B)
     w = torch.randn(1, x.size(1), generator=torch.Generator().manual_seed(3)).to(dev)
     ref = NP.topk_pool(x, ei, batch, w, 0.5, num_graphs=B)
-    b2 = batch.clone()
-    b2._npi_sizes = sizes
-    plain = NP.topk_pool(x, ei, b2, w, 0.5)                   # sizes known but not asked for: PyG's contract, compact list
+    plain = _pool_tuple(NG.GraphBatch(x, ei, batch, sizes=sizes), w, 0.5)   # sizes known but padding not asked for: PyG's contract
     assert plain[1].size(1) == ref[1].size(1) and torch.equal(plain[1], ref[1])
-    got = NP.topk_pool(x, ei, b2, w, 0.5, padded_edges=True)
+    pooled, perm, _ = NP.topk_pool_batch(NG.GraphBatch(x, ei, batch, sizes=sizes), w, 0.5, padded_edges=True)
+    got = (pooled.x, pooled.edge_index, None, pooled.batch, perm)
     e = ref[1].size(1)
     assert got[1].size(1) == ei.size(1) and torch.equal(got[1][:, :e], ref[1]) and bool((got[1][:, e:] == -1).all())
     assert torch.equal(got[0], ref[0]) and torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4])
-    assert torch.equal(got[3]._npi_sizes, torch.ceil(0.5 * sizes.float()).long())
+    assert torch.equal(pooled.sizes, torch.ceil(0.5 * sizes.float()).long())
     # a conv over the padded edge list = a conv over the compact one
     conv = npi.SAGEConv(x.size(1), 32).to(dev)
     assert torch.equal(conv(got[0], got[1]), conv(ref[0], ref[1]))
@@ -343,18 +349,18 @@ def test_pooling_without_a_device_read_when_graph_sizes_are_known(dev):
     model = net1.Net_1(x.size(1)).to(dev)
     model.eval()                                              # (dropout off: the two runs must be comparable)
 
-    def run(bvec):
+    def run(known):
         model.zero_grad(set_to_none=True)
-        data = net1.Batch(x, ei, bvec, y)
+        data = net1.Batch(NG.GraphBatch(x, ei, batch), y, sizes=known)
         loss = torch.nn.functional.nll_loss(model(data), y)
         loss.backward()
         return loss.detach().clone(), [p.grad.clone() for p in model.parameters()]
-    l0, g0 = run(batch)
-    run(b2)                                                   # warm-up: lazy initialisations may synchronise once
+    l0, g0 = run(None)
+    run(sizes)                                                # warm-up: lazy initialisations may synchronise once
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode("error")
     try:
-        l1, g1 = run(b2)
+        l1, g1 = run(sizes)
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.equal(l0, l1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
@@ -373,17 +379,17 @@ def test_padded_edge_lists_edge_cases(dev):
     ei = torch.tensor([[1, 2], [2, 1]])
     w = torch.randn(1, 12, generator=g)
     ref = R.topk_pool(x, ei, batch, w, 0.5)
-    b2 = batch.to(dev)
-    b2._npi_sizes = sizes
-    got = NP.topk_pool(x.to(dev), ei.to(dev), b2, w.to(dev), 0.5, padded_edges=True)
+    pooled, perm, _ = NP.topk_pool_batch(NG.GraphBatch(x.to(dev), ei.to(dev), batch.to(dev), sizes=sizes), w.to(dev), 0.5,
+                                         padded_edges=True)
+    got = (pooled.x, pooled.edge_index, None, pooled.batch, perm)
     assert torch.equal(got[4].cpu(), ref[3]) and got[1].shape == (2, 2) and bool((got[1] == -1).all()) and ref[1].numel() == 0
-    assert torch.equal(got[3]._npi_sizes, torch.tensor([1, 1, 3, 1, 4]))
+    assert torch.equal(pooled.sizes, torch.tensor([1, 1, 3, 1, 4]))
     conv = npi.SAGEConv(12, 8).to(dev)
     out = conv(got[0], got[1])                                   # only padding: every node aggregates itself
     assert torch.allclose(out, got[0] @ conv.weight + conv.bias, atol=1e-5)
     # second pooling layer on the padded list, ratio 1.0 keeps everything
-    got2 = NP.topk_pool(got[0], got[1], got[3], torch.randn(1, 12, generator=g).to(dev), 1.0, padded_edges=True)
-    assert got2[0].size(0) == got[0].size(0) and bool((got2[1] == -1).all())
+    got2, _, _ = NP.topk_pool_batch(pooled, torch.randn(1, 12, generator=g).to(dev), 1.0, padded_edges=True)
+    assert got2.x.size(0) == got[0].size(0) and bool((got2.edge_index == -1).all())
     # sizes of an empty key list; size hints for one key
     ig = InteractionGraph(torch.tensor([[0, 3], [1, 3], [1, 4]]).to(dev), torch.tensor([True, True, True]).to(dev),
                           torch.randn(5, 6, generator=g).to(dev))
@@ -397,7 +403,7 @@ def test_padded_edge_lists_edge_cases(dev):
 def test_pooled_csr_derived_from_the_parent_equals_a_fresh_build(dev):
     """graph.filtered_side (npi_csr_filter): the by-target CSR of the pooled graph, derived from the parent's without a sort,
     equals build_side on the filtered (padded) edge list entry for entry -- rowptr, col, eid, rowidx, item_row -- over two
-    pooling layers; and the conv that follows picks it up from the edge list instead of sorting."""
+    pooling layers; and the conv that follows finds it in the GraphBatch instead of sorting."""
     from npi_gnn_amd import graph as NG
     fx = torch.load(os.path.join(G, "rpi369_extract.pt"), map_location="cpu", weights_only=False)
     from npi_gnn_amd.subgraph import InteractionGraph
@@ -405,18 +411,18 @@ def test_pooled_csr_derived_from_the_parent_equals_a_fresh_build(dev):
     ig = InteractionGraph(fx["pairs"].long().to(dev), fx["usable"].to(dev), fx["feat"].to(dev))
     keys = fx["keys"].long().to(dev)
     loader = net1.KeyLoader(ig, keys, torch.zeros(keys.size(0), dtype=torch.long, device=dev), 64)
-    data = next(iter(loader))
-    x, ei, b = data.x, data.edge_index, data.batch
+    gb = next(iter(loader))
     torch.manual_seed(0)
-    w = torch.randn(1, x.size(1), device=dev)
-    NG.as_graph(ei, x.size(0))                                   # what the conv in front of the pool does
-    assert getattr(ei, "_npi_graph", None) is not None
+    w = torch.randn(1, gb.x.size(1), device=dev)
+    assert gb.peek_graph() is None
+    gb.graph()                                                   # what the conv in front of the pool does
+    assert gb.peek_graph() is not None and gb.symmetric and gb.sizes is not None
     for layer in range(2):
-        xo, eo, _, bo, perm, _ = NP.topk_pool(x.clone().requires_grad_(layer == 1), ei, b, w, 0.5, num_graphs=64,
-                                              padded_edges=True)
-        assert getattr(eo, "_npi_graph_from", None) is not None and getattr(eo, "_npi_graph", None) is None     # derived on demand
-        g = NG.as_graph(eo, xo.size(0))
-        assert g is getattr(eo, "_npi_graph", None) and g.num_nodes == xo.size(0) and g.symmetric
+        out, perm, _ = NP.topk_pool_batch(gb.with_x(gb.x.clone().requires_grad_(layer == 1)), w, 0.5, padded_edges=True)
+        xo, eo = out.x, out.edge_index
+        assert out._recipe is not None and out.peek_graph() is None          # derived on demand
+        g = NG.as_graph(out, xo.size(0))
+        assert g is out.peek_graph() and out._recipe is None and g.num_nodes == xo.size(0) and g.symmetric
         ref = NG.build_side(eo[1].contiguous(), eo[0].contiguous(), xo.size(0), xo.size(0))
         nnz = int(ref.rowptr[-1])
         assert g.by_dst.nnz_max == ref.nnz_max and g.by_dst.n_items == ref.n_items
@@ -424,8 +430,8 @@ def test_pooled_csr_derived_from_the_parent_equals_a_fresh_build(dev):
         for a, r in ((g.by_dst.col, ref.col), (g.by_dst.eid, ref.eid), (g.by_dst.rowidx, ref.rowidx)):
             assert torch.equal(a[:nnz], r[:nnz])
         assert torch.equal(g.by_dst.item_row, ref.item_row)
-        assert NG.as_graph(eo, xo.size(0)) is g                  # the next conv sorts nothing
-        x, ei, b = xo.detach(), eo, bo
+        assert out.graph() is g and out.with_x(xo.detach()).graph() is g      # the next conv (and the pool behind it) sort nothing
+        gb = out.with_x(xo.detach())
 
 
 @pytest.mark.parametrize("E", [3000, 2048 * 2048, 2048 * 2048 + 5000])
@@ -459,35 +465,38 @@ def test_filter_adj_keeps_the_edge_order_on_both_tile_paths(dev, E):
 
 
 def test_in_place_edit_of_a_cached_edge_list_is_never_answered_from_the_stale_csr(dev):
-    """a CSR cached on an edge list (graph.attach_graph, the convs on lists this package produced, the
-    recipe TopKPooling leaves) is keyed by the tensor's ``_version``: an in-place write to the list -- same shape, same
-    storage -- makes the next conv sort again instead of aggregating over the old adjacency."""
+    """the CSR a GraphBatch keeps for its edge list (and the recipe TopKPooling leaves in the pooled batch)
+    is keyed by the tensor's ``_version``: an in-place write to the list -- same shape, same storage -- makes the next conv
+    sort again instead of aggregating over the old adjacency.  Plain tensors carry no state at all."""
     g = torch.Generator().manual_seed(4)
     N, E, F = 300, 2000, 16
     ei = torch.randint(0, N, (2, E), generator=g).to(dev)
     x = torch.randn(N, F, generator=g).to(dev)
     conv = npi.SAGEConv(F, 8).to(dev)
-    g0 = NG.attach_graph(ei, N)
-    out1 = conv(x, ei)
-    assert NG.cached_graph(ei, N) is g0                        # reused while the tensor is untouched
+    gb = NG.GraphBatch(x, ei)
+    g0 = gb.graph()
+    out1 = conv(gb).x
+    assert gb.peek_graph() is g0 and gb.graph() is g0          # reused while the tensor is untouched
+    assert torch.equal(out1, conv(x, ei)) and not hasattr(ei, "_npi_graph")      # the tensor form: same numbers, no state
     ei[0, :500] = torch.randint(0, N, (500,), generator=g).to(dev)       # in-place: same shape, same storage
-    assert NG.cached_graph(ei, N) is None
-    out2 = conv(x, ei)
-    want = conv(x, ei.clone())                                 # a tensor nobody has cached anything on
+    assert gb.peek_graph() is None
+    out2 = conv(gb).x
+    assert gb.graph() is not g0
+    want = conv(x, ei.clone())
     assert torch.equal(out2, want) and not torch.equal(out1, out2)
     # the recipe a pooling layer leaves on the list it returns is dropped the same way
     fx = load("rpi369_fold0.pt")
     x, e, batch, y = (fx[k].to(dev) for k in ("x", "edge_index", "batch", "y"))
-    b2 = batch.clone()
-    b2._npi_sizes = torch.bincount(fx["batch"], minlength=y.numel())
-    e._npi_symmetric = True
-    NG.as_graph(e, x.size(0))                                  # the conv in front of the pool
+    gb = NG.GraphBatch(x, e, batch, sizes=torch.bincount(fx["batch"], minlength=y.numel()), symmetric=True)
+    gb.graph()                                                 # the conv in front of the pool
     w = torch.randn(1, x.size(1), generator=g).to(dev)
-    xo, eo, _, bo, _, _ = NP.topk_pool(x, e, b2, w, 0.5, padded_edges=True)
-    assert getattr(eo, "_npi_graph_from", None) is not None
+    out, _, _ = NP.topk_pool_batch(gb, w, 0.5, padded_edges=True)
+    xo, eo = out.x, out.edge_index
+    assert out._recipe is not None
     keep = eo[0] >= 0
     eo[:, keep] = eo[:, keep].flip(0)                          # in-place edit (here: every edge reversed)
-    got = NG.as_graph(eo, xo.size(0))
+    got = out.graph()
+    assert out._recipe is None
     ref = NG.build_side(eo[1].contiguous(), eo[0].contiguous(), xo.size(0), xo.size(0))
     nnz = int(ref.rowptr[-1])
     assert torch.equal(got.by_dst.rowptr, ref.rowptr) and torch.equal(got.by_dst.col[:nnz], ref.col[:nnz])
@@ -506,7 +515,7 @@ def test_stale_batch_totals_are_an_error_not_an_out_of_bounds_write(dev):
     with pytest.raises(ValueError):
         ig.batch(keys[:2], n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))        # totals of three keys, two keys
     ok = ig.batch(keys, n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))
-    assert ok[0].size(0) == int(nodes.sum())
+    assert ok.x.size(0) == int(nodes.sum())
     NG.set_debug(True)
     try:
         with pytest.raises(ValueError):

@@ -16,7 +16,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def _check(dev, pairs, usable, feat, keys):
     ig = InteractionGraph(pairs.to(dev), usable.to(dev), feat.to(dev))
-    x, ei, b, nid = ig.batch(keys.to(dev), return_node_id=True)
+    (x, ei, b), nid = ig.batch(keys.to(dev), return_node_id=True)
     ox, oe, ob, on = RS.enclosing_subgraph_batch(pairs, usable, feat, keys)
     assert torch.equal(nid.cpu().long(), on)
     assert torch.equal(b.cpu(), ob)
@@ -111,27 +111,30 @@ def test_feature_rows_are_stored_128_aligned_with_zero_pad_columns(dev):
     fx = torch.load(os.path.join(G, "rpi369_extract.pt"), map_location="cpu", weights_only=False)
     ig = InteractionGraph(fx["pairs"].long().to(dev), fx["usable"].to(dev), fx["feat"].to(dev))
     keys = fx["keys"].long().to(dev)
-    x, ei, b = ig.batch(keys)
+    gb = ig.batch(keys)
+    x, ei, b = gb
+    assert gb.symmetric and gb.num_graphs == keys.size(0)
     F = x.size(1)
-    base = getattr(x, "_npi_pad_base", None)
+    base = gb.pad_base
     if F % 128 != 0 and 2 * ((F + 127) // 128 * 128) <= 3 * F:
         assert base is not None and base.size(1) == (F + 127) // 128 * 128 and base.data_ptr() == x.data_ptr()
         assert x.stride(0) == base.size(1) and not bool(base[:, F:].any())
     old = SG.PAD_FEATURES
     try:
         SG.PAD_FEATURES = False
-        x0, e0, b0 = ig.batch(keys)
+        gb0 = ig.batch(keys)
+        x0, e0, b0 = gb0
     finally:
         SG.PAD_FEATURES = old
-    assert x0.is_contiguous() and getattr(x0, "_npi_pad_base", None) is None
+    assert x0.is_contiguous() and gb0.pad_base is None
     assert torch.equal(x, x0) and torch.equal(ei, e0)
     torch.manual_seed(0)
     conv = npi.SAGEConv(F, 128).to(dev)
     go = torch.randn(x.size(0), 128, device=dev)
     outs = []
-    for inp in (x, x0):
+    for inp in (gb, gb0):                                  # the padded batch runs its GEMMs on the 128-aligned buffer
         conv.zero_grad()
-        out = conv(inp, ei)
+        out = conv(inp).x
         out.backward(go)
         outs.append((out.detach().clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
     for p, q in zip(*outs):

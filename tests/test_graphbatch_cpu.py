@@ -1,0 +1,70 @@
+"""graph.GraphBatch, the one explicit object the layers of Net_1 hand to one another: the host-side
+logic that needs no GPU -- what it infers, what it shares, what it refuses."""
+import pytest
+import torch
+
+import npi_gnn_amd as npi
+from npi_gnn_amd import net1
+from npi_gnn_amd import pool as NP
+from npi_gnn_amd.graph import GraphBatch
+
+
+def _case():
+    x = torch.randn(7, 4)
+    ei = torch.tensor([[0, 1, 4, 5], [1, 0, 5, 4]])
+    batch = torch.tensor([0, 0, 0, 1, 1, 1, 1])
+    return x, ei, batch
+
+
+def test_unpacks_like_the_pyg_triple_and_infers_the_graph_count():
+    x, ei, batch = _case()
+    gb = GraphBatch(x, ei, batch, sizes=torch.tensor([3, 4]))
+    a, b, c = gb
+    assert a is x and b is ei and c is batch
+    assert gb.num_graphs == 2 and gb.num_nodes == 7 and gb.to("cuda:0") is gb
+    assert GraphBatch(x, ei).num_graphs == 1                              # no batch vector: one graph
+    assert GraphBatch(x, ei, batch).num_graphs is None                    # unknown until somebody needs it
+    assert GraphBatch(x, ei, batch, graph_ptr=torch.tensor([0, 3, 7], dtype=torch.int32)).num_graphs == 2
+    with pytest.raises(ValueError):
+        GraphBatch(x, ei, batch, 3, sizes=torch.tensor([3, 4]))
+    assert "nodes=7" in repr(gb)
+
+
+def test_with_x_shares_the_structure_and_drops_the_padded_buffer():
+    x, ei, batch = _case()
+    full = torch.zeros(7, 128)
+    gb = GraphBatch(full[:, :4], ei, batch, 2, sizes=torch.tensor([3, 4]), symmetric=True, pad_base=full)
+    y = torch.randn(7, 9)
+    out = gb.with_x(y)
+    assert out.x is y and out.edge_index is ei and out.batch is batch and out.sizes is gb.sizes
+    assert out.symmetric and out.num_graphs == 2 and out.pad_base is None and gb.pad_base is full
+    assert gb.peek_graph() is None and out.peek_graph() is None           # nothing built, nothing invented
+
+
+def test_layers_refuse_a_second_edge_list_next_to_a_graph_batch():
+    x, ei, batch = _case()
+    gb = GraphBatch(x, ei, batch, 2)
+    for layer in (npi.SAGEConv(4, 3), npi.GCNConv(4, 3), npi.GATConv(4, 3)):
+        with pytest.raises(TypeError):
+            layer(gb, ei)
+    with pytest.raises(TypeError):
+        NP.TopKPooling(4)(gb, ei)
+    with pytest.raises(TypeError):
+        GraphBatch(x, object.__new__(npi.CSRGraph))                      # a prebuilt CSR goes in as csr=, not as edge_index
+
+
+def test_loader_batch_is_a_graph_batch_with_labels():
+    x, ei, batch = _case()
+    y = torch.tensor([1, 0])
+    d = net1.Batch(GraphBatch(x, ei, batch, symmetric=True), y, sizes=torch.tensor([3, 4]))
+    assert isinstance(d, GraphBatch) and d.y is y and d.num_graphs == 2 and d.symmetric and d.to(None) is d
+    assert torch.equal(d.sizes, torch.tensor([3, 4]))
+
+
+def test_no_layer_reads_or_writes_tensor_attributes():
+    """the side channels of round 2 (``_npi_graph``, ``_npi_sizes`` ...) are gone from the package"""
+    import os
+    root = os.path.dirname(os.path.abspath(npi.__file__))
+    for name in os.listdir(root):
+        if name.endswith(".py"):
+            assert "_npi_" not in open(os.path.join(root, name)).read(), name
