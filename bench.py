@@ -50,6 +50,8 @@ def parse(argv=None):
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--graph-seed", type=int, default=20260310,
+                    help="seed of the synthetic bipartite graph (2 = the graph of configs.C5_1gpu: its PMC passes)")
     ap.add_argument("--conv", choices=["sage", "gcn", "gat"], default="sage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=100_000, help="bounded CPU-baseline sample (1/10 scale)")
@@ -175,7 +177,7 @@ def cpu_baseline(args, ei_full=None):
 
     def data(N, E, ei=None):
         if ei is None:
-            ei = bipartite_edge_index(N, E, seed=20260310)
+            ei = bipartite_edge_index(N, E, seed=args.graph_seed)
         g = torch.Generator().manual_seed(1)
         x = torch.randn(N, F, generator=g)
         W = (torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5
@@ -574,8 +576,15 @@ def run_configs(dev, args, c4):
             NF._PROFILE_TAGS = None
             torch.cuda.synchronize()
             gb = gat_bytes(E5, N5, F5)
-            roof = {tag: agg_roofline(tags.get(tag, []), gb[tag], None, "as configs.gat_c4.roofline, at the C5 size (3 launches, one "
-                                      "per layer)", "no PMC pass at this size: algorithmic bytes only") for tag in gb}
+            # HBM bytes of the two aggregation launches at THIS size, from their own PMC passes (tools/r03_pmc_c5.sh: bench.py
+            # --conv gat on this very graph); the algorithmic bytes count every gathered row, the hub rows served from L2 included
+            roof = {}
+            for tag in gb:
+                tr = None if pmc.get("stale_gat") else pmc.get("c5_" + tag + "_bytes_per_launch")
+                src = pmc.get("c5_from") if tr else (f"STALE: measured on another {pmc.get('stale_gat')}" if pmc.get("stale_gat")
+                                                     else "no PMC pass at this size: algorithmic bytes only")
+                roof[tag] = agg_roofline(tags.get(tag, []), gb[tag], tr, "as configs.gat_c4.roofline, at the C5 size (3 launches, "
+                                         "one per layer)", src)
             res5 = {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU",
                     "ms_per_step": ms, "edge_layers_per_s": 3 * E5 / ms * 1e3, "roofline": roof}
             del st, x5, g5
@@ -843,7 +852,7 @@ def main():
         print(json.dumps({"control_uniform": control_uniform(dev, N, E, F)}), flush=True)
         return
     sharded = world > 1 or args.force_sharded
-    ei = bipartite_edge_index(N, E, seed=20260310)
+    ei = bipartite_edge_index(N, E, seed=args.graph_seed)
     g = torch.Generator().manual_seed(1)
     x_full = torch.randn(N, F, generator=g)
     W = ((torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5)

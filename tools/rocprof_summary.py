@@ -2,7 +2,7 @@
 """Condense rocprofv3 CSV output (tools/profile_bench.sh) into the files kept under profiles/:
   <tag>_kernel_stats.csv   the --kernel-trace --stats summary, as rocprofv3 wrote it
   <tag>_pmc_summary.json   per-kernel mean FETCH_SIZE / WRITE_SIZE (KB, raw) from the separate --pmc passes
-usage: tools/rocprof_summary.py gpurun_out/prof_<tag> <tag> [fetch_scale] [sage|gat|gcn]
+usage: tools/rocprof_summary.py gpurun_out/prof_<tag> <tag> [fetch_scale] [sage|gat|gcn|c5gat]
 fetch_scale = calibration factor for FETCH_SIZE in the segsum access pattern (tools/pmc_calibrate.py).
 The last argument says which constants of profiles/pmc_traffic.json the run provides: the headline SAGE launch (default),
 the two GATConv aggregation kernels (bench.py --conv gat), or GCNConv's weighted launch (--conv gcn)."""
@@ -69,6 +69,9 @@ def main():
         elif kind == "gat":
             t.update({"gat_fwd_aggregate_bytes_per_launch": kb(main(6)) + kb(fix(2)),
                       "gat_bwd_fused_bytes_per_launch": kb(main(5)) + kb(fix(4)), "gat_from": f"profiles/{tag}_pmc_summary.json"})
+        elif kind == "c5gat":      # the same two kernels on the C5 graph (bench.py --conv gat --nodes 4000000 --edges 100000000 --graph-seed 2)
+            t.update({"c5_gat_fwd_aggregate_bytes_per_launch": kb(main(6)) + kb(fix(2)),
+                      "c5_gat_bwd_fused_bytes_per_launch": kb(main(5)) + kb(fix(4)), "c5_from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "gcn":
             t.update({"gcn_segsum_bytes_per_launch": kb(main(1)) + kb(fix(1)), "gcn_from": f"profiles/{tag}_pmc_summary.json"})
         t["source_sha16"] = kernel_source_sha()
