@@ -241,6 +241,17 @@ int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t
 int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                      const float* rowscale, void* C, int64_t ldc,
                      int64_t M, int64_t K, int64_t N, int relu, int dtype, void* stream);
+/* dA = dC W^T + row0 (x) col0 + row1 (x) col1 (f32; row* are [M], col* [K] vectors): npi_linear_bwd_data with a rank-2 term
+ * added in the store epilogue of the matrix-core kernel -- no read-modify-write pass over dA or dC.  GATConv backward
+ * (PyG 1.4.2 GATConv.message's `(x_i, x_j) * att` terms, reference call site src/classes.py:48-52 via BASELINE configs[4]): the
+ * attention terms g_dst (x) W att_dst + g_src (x) W att_src of dX.  Only shapes the kernel covers completely:
+ * npi_linear_bwd_data_rank2_supported(M, K, N) (M >= 128, K % 128 == 0, N % 32 == 0, default GEMM arithmetic); anything else
+ * returns NPI_ERR_ARG (the caller adds the terms to dC with npi_gat_rank1_add instead).  Operands 16-byte aligned, leading
+ * dimensions % 4 == 0; workspace as npi_linear_bwd_data_ex. */
+int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t N);
+int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0, const float* row1,
+                              const float* col0, const float* col1, float* dA, int64_t ldda, int64_t M, int64_t K, int64_t N,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
                           const float* rowscale, void* dA, int64_t ldda,
                           int64_t M, int64_t K, int64_t N, int dtype, void* stream);

@@ -41,6 +41,9 @@ struct Epilogue {
     const float* rowscale;   // [M] or null
     int relu;
     float* colsum;           // BMODE 0 only: per-split column sums of B, [splits][N], or null
+    // rank-2 update of the output, C += r2_row0 (x) r2_col0 + r2_row1 (x) r2_col1 ([M] and [N] vectors; all four or none):
+    // only the split kernel applies it, and only when it covers the whole output (npi_linear_bwd_data_rank2)
+    const float* r2_row0; const float* r2_row1; const float* r2_col0; const float* r2_col1;
 };
 
 // C[M,N] (+ split-K slabs) = A(m,k) * B(k,n) over the tile grid starting at (tm0, tn0)
@@ -663,10 +666,12 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
 // 16-byte stores.  (With the natural orientation a lane owns a column and every store is 4 bytes; a wave
 // may have 64 stores in flight, so the 1 GB of C then drains at 64 x 256 B per write round trip per wave --
 // measured 0.45 ms of a 0.9 ms kernel.)
-template <int TM, int TN>
+template <int TM, int TN, bool R2 = false>
 __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
                                              const f32x16 (&acc)[TM][TN], const float* __restrict__ bias_lds /* this wave's
-                                             first column (zeros without a bias) */, const float (&rs)[TM], float floor_) {
+                                             first column (zeros without a bias) */, const float (&rs)[TM], float floor_,
+                                             const float* __restrict__ u0_lds = nullptr, const float* __restrict__ u1_lds = nullptr,
+                                             const float (*g0)[TM] = nullptr, const float (*g1)[TM] = nullptr) {
     // bias comes from an LDS copy made once per workgroup and the row scales were fetched at the start of the
     // tile: a global load here would put a full memory round trip in front of every tile's stores.  No branch in
     // here (a missing bias is a row of zeros, no ReLU is a floor of -inf): with one, every 16-byte store waited for
@@ -682,6 +687,11 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
         const int jn = (jg + 1) >> 2, gn = (jg + 1) & 3;
         float4 bn = b;
         if (jg + 1 < 4 * TN) bn = *reinterpret_cast<const float4*>(bias_lds + jn * 32 + 8 * gn + 4 * lh);
+        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+        if constexpr (R2) {               // the column vectors of the rank-2 term, same LDS layout as the bias
+            u0 = *reinterpret_cast<const float4*>(u0_lds + j * 32 + 8 * g + 4 * lh);
+            u1 = *reinterpret_cast<const float4*>(u1_lds + j * 32 + 8 * g + 4 * lh);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float4 v;
@@ -689,6 +699,11 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
             v.y = fmaf(acc[i][j][4 * g + 1], rs[i], b.y);
             v.z = fmaf(acc[i][j][4 * g + 2], rs[i], b.z);
             v.w = fmaf(acc[i][j][4 * g + 3], rs[i], b.w);
+            if constexpr (R2) {
+                const float a0 = (*g0)[i], a1 = (*g1)[i];
+                v.x = fmaf(a1, u1.x, fmaf(a0, u0.x, v.x)); v.y = fmaf(a1, u1.y, fmaf(a0, u0.y, v.y));
+                v.z = fmaf(a1, u1.z, fmaf(a0, u0.z, v.z)); v.w = fmaf(a1, u1.w, fmaf(a0, u0.w, v.w));
+            }
             // keeps NaN, like torch.relu
             v.x = v.x < floor_ ? floor_ : v.x; v.y = v.y < floor_ ? floor_ : v.y;
             v.z = v.z < floor_ ? floor_ : v.z; v.w = v.w < floor_ ? floor_ : v.w;
@@ -896,7 +911,7 @@ __device__ __forceinline__ void ws_consume_first(uint32_t st, const int (&offa)[
     for (int i = 0; i < TM; ++i) NPI_LGKM_WAIT(0, af[i]);
 }
 
-template <int TN>
+template <int TN, bool R2 = false>
 __global__ void __launch_bounds__(WS_THREADS, 1)
 gemm_split_ws_kernel(SplitArgs a) {
     constexpr int TM = 2;
@@ -907,6 +922,8 @@ gemm_split_ws_kernel(SplitArgs a) {
     constexpr int NST = 4;                            // LDS stages (4 x 36 KiB at TN = 4)
     __shared__ __attribute__((aligned(16))) char lds[NST * BUF];
     __shared__ __attribute__((aligned(16))) float bias_s[4][2][32 * TN];   // per consumer wave: bias of its columns, by tile parity
+    // R2: the two column vectors of the rank-2 term, kept exactly like the bias
+    __shared__ __attribute__((aligned(16))) float r2_s[R2 ? 4 : 1][2][2][R2 ? 32 * TN : 4];
     // hand-over counters, one pair per stage, only ever incremented: the 4 producer waves add to full[s] when their
     // part of a k-step is in stage s, the 4 consumer waves add to empty[s] when their fragments are in registers.
     // No barrier in the main loop: the producer runs up to NST - 1 k-steps ahead, so a consumer epilogue (10 k
@@ -1064,9 +1081,9 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     int tsel = 1, bias_nt = -1;                             // bias_s half in use, and the n-tile whose bias it holds
-    float rs[TM];
+    float rs[TM], g0[TM], g1[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) rs[i] = 1.f;
+    for (int i = 0; i < TM; ++i) { rs[i] = 1.f; g0[i] = 0.f; g1[i] = 0.f; }
     const float floor_ = a.ep.relu != 0 ? 0.f : -__builtin_huge_valf();
     int g = 0;                                              // k-steps consumed so far: stage g % NST, use g / NST
     frag_t af[TM][3], bf[TN][3];
@@ -1083,11 +1100,23 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) rs[i] = a.ep.rowscale[w.row0() + wm * 64 + i * 32 + li];
             }
+            if constexpr (R2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    g0[i] = a.ep.r2_row0[w.row0() + wm * 64 + i * 32 + li];
+                    g1[i] = a.ep.r2_row1[w.row0() + wm * 64 + i * 32 + li];
+                }
+            }
             if (w.nt != bias_nt) {                          // only when the column block changes (once, for N = 64 TN): the
                 tsel ^= 1;                                  // copy waits on vmcnt(0), i.e. also on the previous tile's stores
                 bias_nt = w.nt;
-                for (int c = lane; c < 32 * TN; c += WAVE)
+                for (int c = lane; c < 32 * TN; c += WAVE) {
                     bias_s[wave][tsel][c] = a.ep.bias ? a.ep.bias[w.nt * BN + wn * (32 * TN) + c] : 0.f;
+                    if constexpr (R2) {
+                        r2_s[wave][tsel][0][c] = a.ep.r2_col0[w.nt * BN + wn * (32 * TN) + c];
+                        r2_s[wave][tsel][1][c] = a.ep.r2_col1[w.nt * BN + wn * (32 * TN) + c];
+                    }
+                }
             }
         }
         TileWalk wn_ = w;
@@ -1098,8 +1127,8 @@ gemm_split_ws_kernel(SplitArgs a) {
         if (w.kt == nk - 1) {
             const unsigned long long e0_ = NPI_STAMP();
             if ((NPI_WS_PROBE & 4) == 0 || acc[0][0][0] == 12345.678f)
-            store_tile_t<TM, TN>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
-                                 bias_s[wave][tsel], rs, floor_);
+            store_tile_t<TM, TN, R2>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
+                                     bias_s[wave][tsel], rs, floor_, r2_s[R2 ? wave : 0][tsel][0], r2_s[R2 ? wave : 0][tsel][1], &g0, &g1);
             ca_epi += NPI_STAMP() - e0_;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1646,6 +1675,10 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
                        ((uintptr_t)a.C % 16 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
     int split_tm = 0;                                        // m-tiles the split kernel covered (all of them, when it ran)
+    if (a.ep.r2_row0 != nullptr && !(fm > 0 && fn > 0 && split && a.N % 128 == 0 && kv == a.K)) {
+        set_error("gemm: the rank-2 epilogue needs the split kernel over the whole output (npi_linear_bwd_data_rank2_supported)");
+        return NPI_ERR_ARG;
+    }
     if (fm > 0 && fn > 0 && split) {
         // stream-ordered scratch for the three bf16 planes of B (W is small: 3 * 2 * K * N bytes)
         uint16_t* planes = reinterpret_cast<uint16_t*>(scratch);
@@ -1663,8 +1696,13 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, split_tm, tn};
         const int64_t ntiles = (int64_t)split_tm * tn;
         const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
-        if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
-        else        gemm_split_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(sa);
+        if (a.ep.r2_row0 != nullptr) {
+            if (wide_n) gemm_split_ws_kernel<4, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+            else        gemm_split_ws_kernel<2, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+        } else {
+            if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
+            else        gemm_split_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(sa);
+        }
         if (scratch == nullptr) (void)hipFreeAsync(planes, stream);
     } else if (fm > 0 && fn > 0) {
         GemmArgs f = a;
@@ -1800,6 +1838,33 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
     const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
                                      gemm_mode_of(flags), workspace);
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data");
+}
+// dA = dC W^T + row0 (x) col0 + row1 (x) col1, the rank-2 term added in the split kernel's store epilogue (GATConv backward:
+// the attention terms g_dst (x) W att_dst + g_src (x) W att_src of dX, without a read-modify-write pass over d hfeat)
+extern "C" int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t N) {
+    static const bool wide_enabled = [] { const char* e = getenv("NPI_GEMM_WIDE"); return e && e[0] == '1'; }();
+    return (g_gemm_mode != 0 && !wide_enabled && M >= 128 && M < 0x7fffffff && K >= 128 && K % 128 == 0 && N >= BK && N % BK == 0 &&
+            N % 4 == 0) ? 1 : 0;
+}
+extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
+                                         const float* row1, const float* col0, const float* col1, float* dA, int64_t ldda,
+                                         int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
+                                         void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(npi_linear_bwd_data_rank2_supported(M, K, N), "npi_linear_bwd_data_rank2: shape outside the split kernel's "
+                "full coverage (M >= 128, K % 128 == 0, N % 32 == 0, default GEMM mode)");
+    NPI_REQUIRE(dC && W && dA && row0 && row1 && col0 && col1, "npi_linear_bwd_data_rank2: null pointer");
+    NPI_REQUIRE(lddc >= N && ldw >= N && ldda >= K, "npi_linear_bwd_data_rank2: leading dimension too small");
+    NPI_REQUIRE(vec4_ok(dC, lddc, N, 4) && vec4_ok(W, ldw, N, 4) && ((uintptr_t)dA % 16 == 0) && (ldda % 4 == 0),
+                "npi_linear_bwd_data_rank2: operands must be 16-byte aligned with leading dimensions % 4 == 0");
+    if (!scratch_ok(workspace, workspace_bytes, K, N)) {
+        set_error("npi_linear_bwd_data_rank2: workspace too small or not 16-byte aligned");
+        return NPI_ERR_WORKSPACE;
+    }
+    GemmArgs a{dC, lddc, W, ldw, dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
+               Epilogue{nullptr, nullptr, 0, nullptr, row0, row1, col0, col1}};
+    const int rc = launch_gemm<0, 1>(true, a, 1, stream, NPI_F32, NPI_F32, g_gemm_mode, workspace);
+    return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data_rank2");
 }
 extern "C" int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
                                      const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,

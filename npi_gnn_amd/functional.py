@@ -200,6 +200,33 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
     return da
 
 
+def linear_bwd_data_rank2_ok(dc: torch.Tensor, weight: torch.Tensor) -> bool:
+    """can ``linear_bwd_data_rank2`` take these operands (f32, aligned, a shape the split kernel covers completely)?"""
+    M, N = dc.shape
+    return (dc.dtype == torch.float32 and weight.dtype == torch.float32 and dc.stride(1) == 1 and weight.stride(1) == 1
+            and dc.stride(0) % 4 == 0 and weight.stride(0) % 4 == 0 and dc.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
+            and GEMM_FLAGS == 0 and bool(load().npi_linear_bwd_data_rank2_supported(M, weight.size(0), N)))
+
+
+def linear_bwd_data_rank2(dc: torch.Tensor, weight: torch.Tensor, row0: torch.Tensor, row1: torch.Tensor,
+                          col0: torch.Tensor, col1: torch.Tensor) -> torch.Tensor:
+    """``dc @ weight.T + row0 (x) col0 + row1 (x) col1`` with the rank-2 term added in the GEMM's store epilogue
+    (``npi_linear_bwd_data_rank2``; ``row*`` are ``[M]``, ``col*`` ``[K]``)."""
+    dev = require_gpu(dc, weight, row0, row1, col0, col1)
+    M, N = dc.shape
+    K = weight.size(0)
+    if row0.numel() != M or row1.numel() != M or col0.numel() != K or col1.numel() != K:
+        raise ValueError("linear_bwd_data_rank2: row vectors must have M entries, column vectors K")
+    row0, row1, col0, col1 = (_f32c(t.reshape(-1), "rank-2 vector") for t in (row0, row1, col0, col1))
+    da = torch.empty((M, K), dtype=torch.float32, device=dev)
+    ws = _gemm_workspace(K, N, dev)
+    with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
+        check(load().npi_linear_bwd_data_rank2(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(row0), ptr(row1),
+                                               ptr(col0), ptr(col1), ptr(da), da.stride(0), M, K, N, ptr(ws), ws.numel(),
+                                               stream_ptr(dev)), "npi_linear_bwd_data_rank2")
+    return da
+
+
 def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False,
                       flags: Optional[int] = None, k_valid: Optional[int] = None):
     """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid; a per-call argument of
@@ -540,6 +567,10 @@ def _inverse_transpose_map(graph: CSRGraph) -> torch.Tensor:
 # npi_gat_edge_grad (a gather pass over the by-target entries) followed by the by-source aggregation.
 GAT_FUSED_BACKWARD = os.environ.get("NPI_GAT_FUSED", "1") != "0"
 GAT_PACKED_BACKWARD = os.environ.get("NPI_GAT_PACKED", "1") != "0"
+# one head: the attention terms of d hfeat, g_dst (x) att_dst + g_src (x) att_src, are never added to d hfeat (a read-modify-write
+# pass over [N, C]); dX takes them in the store epilogue of its GEMM (rank 2: g (x) W att), dW as an outer-product correction
+# built from x^T g -- the same pass over x that yields d att.  0: the separate npi_gat_rank1_add pass
+GAT_RANK2_EPILOGUE = os.environ.get("NPI_GAT_RANK2", "1") != "0"
 
 
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
@@ -833,6 +864,9 @@ class _GatConvFn(torch.autograd.Function):
             dz = dz.view(-1, H)
             g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
             g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
+            if (GAT_RANK2_EPILOGUE and H == 1 and ctx.needs_input_grad[0] and x.dtype == torch.float32 and weight.size(0) % 4 == 0
+                    and linear_bwd_data_rank2_ok(dh, weight)):
+                return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, g_dst, g_src, db, C)
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
             check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), N, H, C, stream_ptr(dev)),
                   "npi_gat_rank1_add")
@@ -875,6 +909,41 @@ class _GatConvFn(torch.autograd.Function):
             dw, _ = linear_bwd_weight(x, dh, want_bias=False)
         if ctx.needs_input_grad[0]:
             dx = linear_bwd_data(dh, weight)
+        return dx, dw, datt, db, None, None, None, None
+
+
+    @staticmethod
+    def _backward_rank2(ctx, x, weight, att2, dh, g_dst, g_src, db, C):
+        """The tail of the one-head backward without ever forming d hfeat' = dh + g_dst (x) a1 + g_src (x) a2 (a1 = att[:C],
+        a2 = att[C:]).  With P = [x^T g_dst; x^T g_src] ([2, K], ONE pass over x -- the pass that used to stream hfeat for d att):
+            dX   = dh W^T + g_dst (x) (W a1) + g_src (x) (W a2)      the rank-2 term in the GEMM's store epilogue
+            dW   = x^T dh + P^T [a1; a2]                              a [K, C] outer-product correction
+            datt = [P W]                                              since hfeat = x W
+        The pass over x and the [2, .] products run on the side stream under the two large GEMMs."""
+        dev = x.device
+        K = weight.size(0)
+        A = att2.view(2, C)                                                   # rows a1, a2
+        U = linear_bwd_data(A, weight)                                        # [2, K]: W a1, W a2 (exact f32: two rows)
+        main = torch.cuda.current_stream(dev)
+        overlap = OVERLAP_STREAMS and x.size(0) >= OVERLAP_MIN_ROWS
+        side = _side_stream(dev) if overlap else main
+        if overlap:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            P = gat_att_grad(x, g_dst, g_src, 1, K).view(2, K)                # x^T g_dst, x^T g_src
+            datt = linear_fwd(P, weight).view(1, 1, 2 * C) if ctx.needs_input_grad[2] else None
+            corr = linear_bwd_weight(P, A, want_bias=False)[0] if ctx.needs_input_grad[1] else None      # [K, C]
+        dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+        dx = linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
+        if overlap:
+            for t in (x, g_dst, g_src, weight, A):
+                t.record_stream(side)
+            for t in (P, datt, corr):
+                if t is not None:
+                    t.record_stream(main)
+            main.wait_stream(side)
+        if dw is not None:
+            dw += corr
         return dx, dw, datt, db, None, None, None, None
 
 

@@ -187,3 +187,28 @@ def test_fused_relu_equals_relu_behind_the_layer(dev, H, C):
     assert torch.equal(res[0][0], res[1][0])
     for a, c in zip(res[0][1:], res[1][1:]):
         assert torch.allclose(a, c, rtol=1e-5, atol=1e-6 * float(a.abs().max()))
+
+
+@pytest.mark.parametrize("N,E,Fi,C", [(3000, 40000, 128, 256), (5000, 60000, 256, 64), (130, 900, 128, 32)])
+def test_attention_terms_in_the_gemm_epilogue_equal_the_separate_pass(dev, N, E, Fi, C):
+    """One head: the terms g_dst (x) att_dst + g_src (x) att_src of d hfeat are never added to it -- dX takes them in the
+    store epilogue of its GEMM (rank 2), dW as an outer-product correction from x^T g, d att from the same pass over x
+    (functional._GatConvFn._backward_rank2).  Same gradients as with the read-modify-write pass (NPI_GAT_RANK2=0) up to
+    f32 rounding; the forward is untouched."""
+    from npi_gnn_amd import functional as NF
+    ei, x, W, att, b, go = _case(N, E, Fi, 1, C, seed=N + C)
+    res = []
+    old = NF.GAT_RANK2_EPILOGUE
+    try:
+        for flag in (False, True):
+            NF.GAT_RANK2_EPILOGUE = flag
+            xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+            out = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=1)
+            out.backward(go.to(dev))
+            res.append((out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad))
+    finally:
+        NF.GAT_RANK2_EPILOGUE = old
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][4], res[1][4])
+    for a, c in zip(res[0][1:4], res[1][1:4]):
+        assert torch.allclose(a, c, rtol=1e-4, atol=2e-6 * float(a.abs().max()) * max(1.0, N ** 0.5 / 30))
+    assert not torch.equal(res[0][1], res[1][1])          # (the two paths really are different arithmetic)

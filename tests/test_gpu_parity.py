@@ -796,3 +796,36 @@ def test_relu_backward_kernel_equals_threshold_backward(dev, M, F):
         assert torch.equal(res[0][0], res[1][0])
         for a, c in zip(res[0][1:], res[1][1:]):
             assert torch.allclose(a, c, rtol=1e-5, atol=1e-6 * float(c.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 128, 32), (128 * 3 + 17, 128, 64), (1000, 256, 256), (4096 + 5, 384, 256), (70000, 256, 128)])
+def test_bwd_data_with_rank2_epilogue_equals_the_product_plus_the_outer_products(dev, M, K, N):
+    """npi_linear_bwd_data_rank2: dC W^T + r0 (x) c0 + r1 (x) c1 with the rank-2 term added in the split kernel's store epilogue
+    (GATConv's attention terms of dX) against fp64, on one tile, ragged last row tiles (overlapping tiles store the same
+    bits twice), both tile widths and many tiles per workgroup; shapes the kernel does not cover completely are refused."""
+    g = torch.Generator().manual_seed(M + K + N)
+    dc = torch.randn(M, N, generator=g)
+    w = torch.randn(K, N, generator=g) * 0.1
+    r0, r1 = torch.randn(M, generator=g), torch.randn(M, generator=g)
+    c0, c1 = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    dcd, wd = dc.to(dev), w.to(dev)
+    assert NF.linear_bwd_data_rank2_ok(dcd, wd)
+    out = NF.linear_bwd_data_rank2(dcd, wd, r0.to(dev), r1.to(dev), c0.to(dev), c1.to(dev)).cpu()
+    ref = dc.double() @ w.double().t() + torch.outer(r0.double(), c0.double()) + torch.outer(r1.double(), c1.double())
+    assert out.shape == (M, K)
+    assert (out.double() - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max())) * (N ** 0.5)
+    # the plain product is untouched by the new template parameter, and adding the outer products afterwards agrees
+    plain = NF.linear_bwd_data(dcd, wd).cpu()
+    torch.testing.assert_close(out, plain + torch.outer(r0, c0) + torch.outer(r1, c1), atol=1e-5, rtol=1e-5)
+    again = NF.linear_bwd_data_rank2(dcd, wd, r0.to(dev), r1.to(dev), c0.to(dev), c1.to(dev)).cpu()
+    assert torch.equal(out, again)
+
+
+def test_rank2_epilogue_refuses_what_the_split_kernel_does_not_cover(dev):
+    for M, K, N in ((100, 128, 32), (512, 178, 64), (512, 128, 30), (512, 64, 32)):
+        dc, w = torch.zeros(M, N, device=dev), torch.zeros(K, N, device=dev)
+        assert not NF.linear_bwd_data_rank2_ok(dc, w)
+        if N % 4 == 0:
+            with pytest.raises(npi.NpiError):
+                NF.linear_bwd_data_rank2(dc, w, torch.zeros(M, device=dev), torch.zeros(M, device=dev),
+                                         torch.zeros(K, device=dev), torch.zeros(K, device=dev))
