@@ -20,7 +20,7 @@ for it in range(cases):
     H, C = [(1, 256), (1, 64), (1, 100), (2, 32), (2, 128), (4, 64), (4, 32), (8, 32), (2, 64), (1, 8)][int(rng.integers(0, 10))]
     N = int(rng.integers(2, 2500))
     E = int(rng.integers(0, 40000))
-    Fi = int(rng.choice([16, 33, 64, 128]))
+    Fi = int(rng.choice([16, 33, 64, 128, 128, 256]))       # (128 / 256 with one head: the rank-2 store epilogue of dX)
     big_items = bool(rng.random() < 0.5)
     lib.npi_small_graph_entries(1 if big_items else default_thr)       # 1: every CSR takes 256-entry items
     g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
