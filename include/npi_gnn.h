@@ -155,6 +155,16 @@ int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fil
 int npi_relu_backward(const float* dy, int64_t ldd, const float* y, int64_t ldy, int64_t M, int64_t F, float* dz, int64_t ldz,
                       void* stream);
 
+/* SAGEConv(normalize=True): y_i = x_i / max(||x_i||_2, eps) -- torch.nn.functional.normalize(out, p=2, dim=-1) at the end of
+ * PyG 1.4.2 SAGEConv.update (the reference constructs its layers with the default normalize=False, src/classes.py:48-52; the
+ * option is part of the layer's signature).  norm [M] receives ||x_i|| for the backward:
+ * dx_i = (dy_i - y_i <dy_i, y_i>) / ||x_i||, and dy_i / eps where the norm was clamped.  One wavefront per row, fixed
+ * reduction tree (bitwise reproducible); rows with pitches, 16-byte lanes when aligned. */
+int npi_l2_normalize_rows(const float* x, int64_t ldx, int64_t M, int64_t F, float eps, float* y, int64_t ldy, float* norm,
+                          void* stream);
+int npi_l2_normalize_rows_bwd(const float* dy, int64_t ldd, const float* y, int64_t ldy, const float* norm, int64_t M, int64_t F,
+                              float eps, float* dx, int64_t ldx, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense projection on the matrix cores -- replaces `torch.matmul(aggr_out, self.weight) + bias`
  * (SAGEConv.update / GCNConv.forward) and its autograd backward.  f32 in, f32 out, f32 accumulate on

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "npi_entry_weights": (c_int, [_P, _P, _P, _P, _P, c_float, _I, _I, _P, _P]),
     "npi_permute_f32": (c_int, [_P, _P, _I, c_float, _P, _P]),
     "npi_relu_backward": (c_int, [_P, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "npi_l2_normalize_rows": (c_int, [_P, _I, _I, _I, c_float, _P, _I, _P, _P]),
+    "npi_l2_normalize_rows_bwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, c_float, _P, _I, _P]),
     "npi_gemm_mode": (c_int, [c_int]),
     "npi_linear_fwd": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, _P]),
     "npi_linear_bwd_data": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

@@ -145,6 +145,110 @@ extern "C" int npi_relu_backward(const float* dy, int64_t ldd, const float* y, i
     return check_launch("npi_relu_backward");
 }
 
+// SAGEConv(normalize=True): y_i = x_i / max(||x_i||_2, eps)  (torch.nn.functional.normalize(p = 2, dim = -1), PyG 1.4.2
+// sage_conv.update).  One wavefront per row: lanes stride over the row in 16-byte pieces (or single floats when the row is not
+// 16-byte aligned), a fixed xor tree adds the squares -- the same order on every run.  The backward of y = x / n:
+// dx = (dy - y <dy, y>) / n where n > eps, dy / eps below it (the clamp is then the constant divisor), as torch's.
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+l2_normalize_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int F, float eps, float* __restrict__ y, int64_t ldy,
+                         float* __restrict__ nrm) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;                                               // wave-uniform
+    const int lane = lane_id();
+    const float* xr = x + r * ldx;
+    float ss = 0.f;
+    if (VEC4) {
+        for (int c = lane * 4; c < F; c += 4 * WAVE) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+        }
+    } else {
+        for (int c = lane; c < F; c += WAVE) ss = fmaf(xr[c], xr[c], ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float n = sqrtf(ss);
+    const float inv = 1.f / fmaxf(n, eps);
+    if (lane == 0) nrm[r] = n;
+    float* yr = y + r * ldy;
+    if (VEC4) {
+        for (int c = lane * 4; c < F; c += 4 * WAVE) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            *reinterpret_cast<float4*>(yr + c) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+        }
+    } else {
+        for (int c = lane; c < F; c += WAVE) yr[c] = xr[c] * inv;
+    }
+}
+
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+l2_normalize_rows_bwd_kernel(const float* __restrict__ dy, int64_t ldd, const float* __restrict__ y, int64_t ldy,
+                             const float* __restrict__ nrm, int64_t M, int F, float eps, float* __restrict__ dx, int64_t ldx) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int lane = lane_id();
+    const float* gr = dy + r * ldd;
+    const float* yr = y + r * ldy;
+    const float n = nrm[r];
+    const bool clamped = !(n > eps);                                  // the divisor was the constant eps: no projection term
+    float dot = 0.f;
+    if (!clamped) {
+        if (VEC4) {
+            for (int c = lane * 4; c < F; c += 4 * WAVE) {
+                const float4 g = *reinterpret_cast<const float4*>(gr + c);
+                const float4 v = *reinterpret_cast<const float4*>(yr + c);
+                dot = fmaf(g.x, v.x, dot); dot = fmaf(g.y, v.y, dot); dot = fmaf(g.z, v.z, dot); dot = fmaf(g.w, v.w, dot);
+            }
+        } else {
+            for (int c = lane; c < F; c += WAVE) dot = fmaf(gr[c], yr[c], dot);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    }
+    const float inv = 1.f / fmaxf(n, eps);
+    float* xr = dx + r * ldx;
+    if (VEC4) {
+        for (int c = lane * 4; c < F; c += 4 * WAVE) {
+            const float4 g = *reinterpret_cast<const float4*>(gr + c);
+            const float4 v = *reinterpret_cast<const float4*>(yr + c);
+            *reinterpret_cast<float4*>(xr + c) = make_float4((g.x - v.x * dot) * inv, (g.y - v.y * dot) * inv,
+                                                             (g.z - v.z * dot) * inv, (g.w - v.w * dot) * inv);
+        }
+    } else {
+        for (int c = lane; c < F; c += WAVE) xr[c] = (gr[c] - yr[c] * dot) * inv;
+    }
+}
+
+static bool rows_vec4(const void* p, int64_t ld, int64_t F) { return F % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p % 16) == 0; }
+
+extern "C" int npi_l2_normalize_rows(const float* x, int64_t ldx, int64_t M, int64_t F, float eps, float* y, int64_t ldy,
+                                     float* norm, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(M >= 0 && F > 0 && F < 0x7fffffff && ldx >= F && ldy >= F && eps > 0.f, "npi_l2_normalize_rows: bad size");
+    if (M == 0) return NPI_OK;
+    NPI_REQUIRE(x && y && norm, "npi_l2_normalize_rows: null pointer");
+    const unsigned grid = (unsigned)ceil_div(M, 4);
+    if (rows_vec4(x, ldx, F) && rows_vec4(y, ldy, F)) l2_normalize_rows_kernel<true><<<grid, 256, 0, stream>>>(x, ldx, M, (int)F, eps, y, ldy, norm);
+    else                                              l2_normalize_rows_kernel<false><<<grid, 256, 0, stream>>>(x, ldx, M, (int)F, eps, y, ldy, norm);
+    return check_launch("npi_l2_normalize_rows");
+}
+
+extern "C" int npi_l2_normalize_rows_bwd(const float* dy, int64_t ldd, const float* y, int64_t ldy, const float* norm, int64_t M,
+                                         int64_t F, float eps, float* dx, int64_t ldx, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(M >= 0 && F > 0 && F < 0x7fffffff && ldd >= F && ldy >= F && ldx >= F && eps > 0.f, "npi_l2_normalize_rows_bwd: bad size");
+    if (M == 0) return NPI_OK;
+    NPI_REQUIRE(dy && y && norm && dx, "npi_l2_normalize_rows_bwd: null pointer");
+    const unsigned grid = (unsigned)ceil_div(M, 4);
+    if (rows_vec4(dy, ldd, F) && rows_vec4(y, ldy, F) && rows_vec4(dx, ldx, F))
+        l2_normalize_rows_bwd_kernel<true><<<grid, 256, 0, stream>>>(dy, ldd, y, ldy, norm, M, (int)F, eps, dx, ldx);
+    else
+        l2_normalize_rows_bwd_kernel<false><<<grid, 256, 0, stream>>>(dy, ldd, y, ldy, norm, M, (int)F, eps, dx, ldx);
+    return check_launch("npi_l2_normalize_rows_bwd");
+}
+
 extern "C" int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -256,6 +256,42 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True,
     return dw, db
 
 
+class _L2NormalizeFn(torch.autograd.Function):
+    """``F.normalize(x, p=2, dim=-1)`` for f32 rows (``npi_l2_normalize_rows`` / ``_bwd``)"""
+
+    @staticmethod
+    def forward(ctx, x, eps: float):
+        dev = require_gpu(x)
+        x = _f32c(x, "x")
+        M, F = x.shape
+        y = torch.empty((M, F), dtype=torch.float32, device=dev)
+        nrm = torch.empty(M, dtype=torch.float32, device=dev)
+        check(load().npi_l2_normalize_rows(ptr(x), x.stride(0), M, F, float(eps), ptr(y), y.stride(0), ptr(nrm), stream_ptr(dev)),
+              "npi_l2_normalize_rows")
+        ctx.eps = float(eps)
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        dev = y.device
+        dy = _f32c(dy, "grad_out")
+        M, F = y.shape
+        dx = torch.empty((M, F), dtype=torch.float32, device=dev)
+        check(load().npi_l2_normalize_rows_bwd(ptr(dy), dy.stride(0), ptr(y), y.stride(0), ptr(nrm), M, F, ctx.eps, ptr(dx),
+                                               dx.stride(0), stream_ptr(dev)), "npi_l2_normalize_rows_bwd")
+        return dx, None
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """``torch.nn.functional.normalize(x, p=2.0, dim=-1)`` (what ``SAGEConv(normalize=True)`` ends with); f32 2-D through the
+    package's own kernels, other storage types through the torch op"""
+    if x.dtype != torch.float32 or x.dim() != 2:
+        return torch.nn.functional.normalize(x, p=2.0, dim=-1, eps=eps)
+    return _L2NormalizeFn.apply(x, eps)
+
+
 def relu_backward(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """dz = dy where y > 0 else 0 (``y``: the output of a fused ReLU); f32 through ``npi_relu_backward``, other storage types
     through the equivalent torch op"""
@@ -392,7 +428,7 @@ def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[
         raise ValueError("sage_conv: relu=True applies to the projection's output; normalize=True comes after it in PyG")
     out = _SageConvFn.apply(x, weight, bias, graph, w_entry, relu)
     if normalize:
-        out = torch.nn.functional.normalize(out, p=2.0, dim=-1)
+        out = l2_normalize(out)
     return out
 
 

@@ -829,3 +829,50 @@ def test_rank2_epilogue_refuses_what_the_split_kernel_does_not_cover(dev):
             with pytest.raises(npi.NpiError):
                 NF.linear_bwd_data_rank2(dc, w, torch.zeros(M, device=dev), torch.zeros(M, device=dev),
                                          torch.zeros(K, device=dev), torch.zeros(K, device=dev))
+
+
+@pytest.mark.parametrize("M,F", [(1, 1), (7, 3), (1000, 128), (5001, 178), (3000, 300)])
+def test_l2_normalize_rows_and_its_backward_match_torch(dev, M, F):
+    """functional.l2_normalize = torch.nn.functional.normalize(p=2, dim=-1), forward and backward, incl. all-zero rows (the
+    clamp: y = 0, dx = dy / eps) and tiny rows; bitwise reproducible.  SAGEConv(normalize=True) ends with it."""
+    g = torch.Generator().manual_seed(M * 31 + F)
+    x = torch.randn(M, F, generator=g)
+    if M > 5:
+        x[3] = 0.0                                     # an all-zero row: the clamped branch
+        x[4] *= 1e-20
+    go = torch.randn(M, F, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xr, p=2.0, dim=-1)
+    ref.backward(go.double())
+    xd = x.to(dev).requires_grad_(True)
+    out = NF.l2_normalize(xd)
+    out.backward(go.to(dev))
+    assert torch.allclose(out.detach().cpu().double(), ref.detach(), atol=1e-6, rtol=1e-5)
+    scale = float(xr.grad.abs().max())
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) <= 1e-5 * scale + 1e-6
+    xd2 = x.to(dev).requires_grad_(True)
+    out2 = NF.l2_normalize(xd2)
+    out2.backward(go.to(dev))
+    assert torch.equal(out, out2) and torch.equal(xd.grad, xd2.grad)
+    # a view with a row pitch (the unaligned lanes)
+    wide = torch.zeros(M, F + 3, device=dev)
+    wide[:, 1:F + 1] = x.to(dev)
+    assert torch.allclose(NF.l2_normalize(wide[:, 1:F + 1]), out.detach(), atol=1e-6, rtol=1e-6)
+
+
+def test_sage_conv_normalize_true_matches_the_oracle(dev):
+    N, E, Fi, Fo = 2000, 15000, 64, 32
+    ei = rand_edges(N, E, seed=5, hub=3)
+    g = torch.Generator().manual_seed(6)
+    x, go = torch.randn(N, Fi, generator=g), torch.randn(N, Fo, generator=g)
+    conv = npi.SAGEConv(Fi, Fo, normalize=True).to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, ei.to(dev))
+    out.backward(go.to(dev))
+    xr = x.clone().requires_grad_(True)
+    Wr, br = conv.weight.detach().cpu().clone().requires_grad_(True), conv.bias.detach().cpu().clone().requires_grad_(True)
+    ref = torch.nn.functional.normalize(R.sage_conv(xr, ei, Wr, br), p=2.0, dim=-1)
+    ref.backward(go)
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-4)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, atol=1e-5, rtol=1e-3)
+    assert torch.allclose(conv.weight.grad.cpu(), Wr.grad, atol=1e-4, rtol=1e-3)
