@@ -484,6 +484,14 @@ class HipBackend:
         from . import functional as NF
         return NF.gat_att_grad(h, g_dst, g_src, H, C)
 
+    def linear_bwd_data_rank2_ok(self, dc, w):
+        from . import functional as NF
+        return NF.GAT_RANK2_EPILOGUE and NF.linear_bwd_data_rank2_ok(dc, w)
+
+    def linear_bwd_data_rank2(self, dc, w, row0, row1, col0, col1):
+        from . import functional as NF
+        return NF.linear_bwd_data_rank2(dc, w, row0, row1, col0, col1)
+
 
 class ShardedGraph:
     """This rank's shard of the (self-loop-augmented) graph: sides A, B and their transposes."""
@@ -1143,8 +1151,28 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         dh = dh_full[: nL + nH]
         g_dst = torch.cat([g_dst_l, g_hub[:nH, :H]])
         g_src = torch.cat([g_src_l, g_hub[:nH, H:]])
-        be.gat_rank1_add(dh, g_dst, g_src, att2, H, C)                             # d h_j += g_dst[j] att[:C] + g_src[j] att[C:]
         datt = dw = dx = None
+        if (H == 1 and ctx.needs_input_grad[0] and weight.size(0) % 4 == 0 and hasattr(be, "linear_bwd_data_rank2")
+                and be.linear_bwd_data_rank2_ok(dh, weight)):
+            # one head: the attention terms are never added to d h -- dX takes them in its GEMM's store epilogue, dW as the
+            # outer-product correction P^T [a1; a2] with P = x_own^T [g_dst g_src] (this rank's share: dW and d att are
+            # all-reduced anyway), d att = P W (functional._GatConvFn._backward_rank2)
+            K = weight.size(0)
+            A2 = att2.view(2, C)
+            U = be.linear_bwd_data(A2, weight, None)                               # [2, K]: W a1, W a2
+            g_dst, g_src = g_dst.contiguous(), g_src.contiguous()
+            P = be.gat_att_grad(x_own, g_dst, g_src, 1, K).view(2, K)
+            if ctx.needs_input_grad[2]:
+                datt = be.linear_fwd(P, weight, None).reshape(1, 2 * C)
+                _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
+                datt = datt.view(1, 1, 2 * C)
+            if ctx.needs_input_grad[1]:
+                dw, _ = be.linear_bwd_weight(x_own, dh, False)
+                dw += be.linear_bwd_weight(P, A2, False)[0]
+                _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
+            dx = be.linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
+            return dx, dw, datt, db, None, None, None
+        be.gat_rank1_add(dh, g_dst, g_src, att2, H, C)                             # d h_j += g_dst[j] att[:C] + g_src[j] att[C:]
         if ctx.needs_input_grad[2]:
             datt = be.gat_att_grad(h, g_dst.contiguous(), g_src.contiguous(), H, C)
             _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
