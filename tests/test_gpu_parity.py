@@ -9,6 +9,7 @@ import torch
 
 import npi_gnn_amd as npi
 from npi_gnn_amd import functional as NF
+from npi_gnn_amd import graph as NG
 from oracle import ref_conv as R
 
 pytestmark = pytest.mark.gpu
@@ -876,3 +877,49 @@ def test_sage_conv_normalize_true_matches_the_oracle(dev):
     assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-4)
     assert torch.allclose(xd.grad.cpu(), xr.grad, atol=1e-5, rtol=1e-3)
     assert torch.allclose(conv.weight.grad.cpu(), Wr.grad, atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("item_entries", [64, 256])
+@pytest.mark.parametrize("F", [256, 64, 20, 300])
+def test_long_chains_of_partials_add_up_exactly(dev, item_entries, F):
+    """Rows cut over MANY items (a hub row: 7,800 partials at C5) through the carry + fix-up path.  Integer-valued features make
+    every order of addition exact in f32, so the result must EQUAL the reference bit for bit: rows starting / ending exactly on
+    multiples of 64 items, rows one entry short of that, an empty row in between, plus mean, per-entry weights and a repeat
+    run.  Both item sizes; one-chunk, narrow (group kernel) and two-chunk rows.  (Written for a variant that pre-summed spans of
+    64 partials in an extra launch -- measured slower everywhere and dropped; the test stays.)"""
+    from npi_gnn_amd._lib import load as _load
+    lib = _load()
+    prev = int(lib.npi_small_graph_entries(0))
+    span = 64 * item_entries                                           # entries of 64 items
+    lens = [5, span - 5,                                               # -> the next row starts exactly at entry `span`
+            3 * span,                                                  # starts on a boundary, ends on one
+            7, 2 * span + 11, 0, span - 1, 20 * span + 123, 1, 2 * span - 7, 5 * span]
+    g = torch.Generator().manual_seed(F + item_entries)
+    small = torch.randint(0, 40, (30000,), generator=g).tolist()
+    lens = lens + small
+    n_rows = len(lens)
+    nnz = sum(lens)
+    n_cols = 5000
+    key = torch.repeat_interleave(torch.arange(n_rows), torch.tensor(lens))
+    val = torch.randint(0, n_cols, (nnz,), generator=g)
+    x = torch.randint(-3, 4, (n_cols, F), generator=g).float()
+    w = torch.randint(-2, 3, (nnz,), generator=g).float()
+    try:
+        lib.npi_small_graph_entries(1 if item_entries == 256 else 1 << 40)        # force the item size
+        side = NG.build_side(key.to(dev), val.to(dev), n_rows, n_cols, self_loops=False, drop_equal=False)
+        xd = x.to(dev)
+        ref = torch.zeros(n_rows, F).index_add_(0, key, x[val])           # (small integers: exact in f32 in any order)
+        out = NF.segsum(None, side, xd)
+        assert torch.equal(out.cpu(), ref)
+        assert torch.equal(NF.segsum(None, side, xd), out)
+        # per-entry weights (entry order = edge order here: the keys are sorted and the build is stable)
+        we = torch.empty(side.nnz_max, device=dev)
+        we[:nnz] = w.to(dev)[side.eid[:nnz].long()]
+        refw = torch.zeros(n_rows, F).index_add_(0, key, x[val] * w.view(-1, 1))
+        assert torch.equal(NF.segsum(None, side, xd, w=we).cpu(), refw)
+        # mean: one division per row after the exact sum
+        cnt = torch.tensor(lens, dtype=torch.float64).clamp(min=1).view(-1, 1)
+        got = NF.segsum(None, side, xd, mean=True).cpu().double()
+        assert torch.allclose(got, ref.double() / cnt, rtol=1e-6, atol=0)
+    finally:
+        lib.npi_small_graph_entries(prev)
