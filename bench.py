@@ -749,12 +749,13 @@ def time_virtual_rank(step, stub, steps=5, warm=3):
     return best, one
 
 
-def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
+def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
     """SURVEY.md 8(e), what one GPU can measure of the W-GPU run: every rank's LOCAL work (its shard's kernels, host
     launch work included) timed alone on this GPU with the collectives replaced by local copies of the same shapes, for
     the three partitions (SAGEConv) and the sharded GATConv.  From it: the load balance, the compute-side ceiling of the
     speed-up (T1 / max_r T_r: what W GPUs reach with free communication), the bytes every collective moves, the
-    communication time a >= 6x speed-up leaves (T1 / 6 - max_r T_r) and the bus bandwidth that implies."""
+    communication time a >= 6x speed-up leaves (T1 / 6 - max_r T_r) and the bus bandwidth that implies.
+    ``only="hubs_sage"``: the SAGEConv vertex cut alone (the smaller worlds of the 1 / 2 / 4 / 8 curve)."""
     import npi_gnn_amd as npi
     from npi_gnn_amd import dist as ND
     from npi_gnn_amd.synth import protein_mask
@@ -772,16 +773,17 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
             p.grad = None
         xx.grad = None
         conv(xx, c4["graph"]).backward(c4["go"])
-    t1_gat = _timeit(gat_step, 5, 2)
+    t1_gat = _timeit(gat_step, 5, 2) if only is None else None
     del conv, xx
 
     out = {}
     with stub_collectives(W) as stub:
         hub = protein_mask(N).to(dev)
         in_count = torch.bincount(ei_dev[1][ei_dev[0] != ei_dev[1]], minlength=N)
-        res = {k: ([], [], None) for k in ("hubs_sage", "hubs_gat", "rows_sage", "edges_sage")}
+        kinds = ("hubs_sage", "hubs_gat", "rows_sage", "edges_sage") if only is None else (only,)
+        res = {k: ([], [], None) for k in kinds}
         for r in range(W):
-            for partition in ("hubs", "rows", "edges"):
+            for partition in (("hubs", "rows", "edges") if only is None else ("hubs",)):
                 if partition == "edges":
                     sg = ND.EdgeShardedGraph(ei_dev, N, r, W, dev, in_count=in_count)
                     x = torch.randn(N, F, device=dev).requires_grad_(True)
@@ -792,7 +794,7 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8):
                     x = torch.randn(sg.n_local, F, device=dev).requires_grad_(True)
                     go = torch.randn(sg.n_local, F, device=dev)
                     layers = [(partition + "_sage", ND.ShardedSAGELayer(sg, Wm, bias))]
-                    if partition == "hubs":
+                    if partition == "hubs" and only is None:
                         layers.append(("hubs_gat", ND.ShardedGATLayer(sg, Wm, att, bias)))
                 for key, layer in layers:
                     def step(layer=layer, x=x, go=go):
@@ -1108,6 +1110,17 @@ def main():
             try:
                 ei_dev = ei.to(dev)
                 vw = virtual_world(dev, args, ei_dev, c4, ms_per_step, args.virtual_world)
+                # the smaller worlds of the metric's 1 / 2 / 4 / 8 curve, vertex cut only: compute-side ceilings per world size
+                curve = {}
+                for w_ in (2, 4):
+                    if w_ < args.virtual_world:
+                        v_ = virtual_world(dev, args, ei_dev, c4, ms_per_step, w_, only="hubs_sage")["hubs_sage"]
+                        curve[str(w_)] = {k: v_[k] for k in ("per_rank_ms", "balance", "compute_ceiling", "wire_bytes_per_rank_per_step")
+                                          if k in v_}
+                if "hubs_sage" in vw:
+                    curve[str(args.virtual_world)] = {k: vw["hubs_sage"][k] for k in ("per_rank_ms", "balance", "compute_ceiling",
+                                                                                      "wire_bytes_per_rank_per_step") if k in vw["hubs_sage"]}
+                vw["hubs_sage_by_world"] = curve
                 del ei_dev
             except Exception as e:
                 vw = {"error": f"{type(e).__name__}: {e}"[:300]}
