@@ -391,9 +391,9 @@ class HipBackend:
         from . import functional as NF
         return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2, out=out)
 
-    def linear_fwd(self, a, w, b):
+    def linear_fwd(self, a, w, b, out=None):
         from . import functional as NF
-        return NF.linear_fwd(a, w, b)
+        return NF.linear_fwd(a, w, b, out=out)
 
     def linear_bwd_data(self, dc, w, rowscale):
         from . import functional as NF
@@ -687,10 +687,13 @@ def scatter_hub_sums(sg: ShardedGraph, partial: torch.Tensor, async_op: bool = F
 # table: with B on its own HIP stream the two aggregations of a direction share the CUs (W = 1: one launch's tail under the
 # other; W > 1: A starts the moment the table has arrived instead of behind B).  NPI_PARTIAL_STREAM=0: one stream, B first.
 PARTIAL_SIDE_STREAM = os.environ.get("NPI_PARTIAL_STREAM", "1") != "0"
+# direct layout, W > 1: the projection of the light rows (complete on the rank) is launched before the reduce-scattered hub rows
+# have arrived, the hub rows' projection after them; 0: one GEMM over all rows behind the reduce-scatter
+SPLIT_PROJECTION = os.environ.get("NPI_SPLIT_PROJECTION", "1") != "0"
 
 
 def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, w_part, mean: bool, tag: str, bias=None,
-                   direct: bool = False):
+                   direct: bool = False, defer: bool = False):
     """One direction of the hub-cut aggregation of ``rows`` [n_local, F]:
 
         table = all_gather(hub rows of ``rows``)                      | psum = segsum(partial side, rows)
@@ -700,6 +703,8 @@ def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, 
     (the rule differs: SAGE's mean re-weights the two shares, sums just add).  ``direct`` (sides of
     ``ShardedGraph.direct()``): the full side covers the light rows only and the reduce-scatter delivers the COMPLETE hub
     rows, so both write into one ``[nL + h_per, F]`` buffer and (out[:n_local], None, table) comes back -- nothing to fold.
+    ``defer`` (direct only): the light rows are returned BEFORE the hub rows have arrived -- the second item is then a
+    callable that waits for the reduce-scatter (and the partial stream); the caller may work on ``out[:nL]`` first.
     ``tag``: prefix of the exposed-communication records ("fwd" / "bwd")."""
     be, W = sg.backend, sg.world
     table, g_work = gather_hub(sg, rows, async_op=True)            # needs nothing but ``rows``: issued first
@@ -731,11 +736,16 @@ def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, 
                     t.record_stream(b_stream)                      # allocated on ``cur``, used on the partial stream
     _wait(g_work, tag + "_all_gather", table)
     out = be.segsum(full, table, mean=mean, table2=rows, w=w_full, bias=bias, out=out_full[: sg.nL] if direct else None)
-    if hsum is not None:
-        _wait(r_work, tag + "_reduce_scatter", hsum)
-        if b_stream is not None:
-            cur.wait_stream(b_stream)                              # one rank: no collective to wait for
-            hsum.record_stream(cur)
+
+    def hub_rows_arrived():
+        if hsum is not None:
+            _wait(r_work, tag + "_reduce_scatter", hsum)
+            if b_stream is not None:
+                cur.wait_stream(b_stream)                          # one rank: no collective to wait for
+                hsum.record_stream(cur)
+    if direct and defer:
+        return out_full[: sg.n_local], hub_rows_arrived, table
+    hub_rows_arrived()
     if direct:
         return out_full[: sg.n_local], None, table
     return out, hsum, table
@@ -753,15 +763,25 @@ class _ShardedSageFn(torch.autograd.Function):
         nrm = {"A": None, "B": None} if (sg.direct_ok or not gcn) else sg.gcn_norm()
         if sg.direct_ok:
             d, w = sg.direct(), sg.direct_weights(gcn)
-            agg, hsum, _ = _hub_aggregate(sg, x_own, d[0], d[1], w["A"], w["B"], not gcn, "fwd", direct=True)
+            split = SPLIT_PROJECTION and sg.nL > 0 and sg.nH > 0 and not _solo(sg.world)
+            agg, arrived, _ = _hub_aggregate(sg, x_own, d[0], d[1], w["A"], w["B"], not gcn, "fwd", direct=True, defer=split)
+            if split:
+                # the light rows are complete on this rank: their projection runs while the hub rows are still on the wire
+                # (row-wise independent: the same numbers as one GEMM over all rows)
+                out = agg.new_empty((sg.n_local, weight.size(1)))
+                be.linear_fwd(agg[: sg.nL], weight, bias, out=out[: sg.nL])
+                arrived()
+                be.linear_fwd(agg[sg.nL:], weight, bias, out=out[sg.nL:])
+            else:
+                out = be.linear_fwd(agg, weight, bias)
         else:
             agg, hsum, _ = _hub_aggregate(sg, x_own, sg.A, sg.B, nrm["A"], nrm["B"], not gcn, "fwd")
-        if hsum is not None and sg.nH:
-            if gcn:
-                agg[sg.nL:] += hsum[: sg.nH]
-            else:                                                  # mean over both shares: (agg cnt_A + hsum) / cnt
-                agg[sg.nL:].mul_(sg.hub_scale_a).addcmul_(hsum[: sg.nH], sg.hub_scale_b)
-        out = be.linear_fwd(agg, weight, bias)
+            if hsum is not None and sg.nH:
+                if gcn:
+                    agg[sg.nL:] += hsum[: sg.nH]
+                else:                                              # mean over both shares: (agg cnt_A + hsum) / cnt
+                    agg[sg.nL:].mul_(sg.hub_scale_a).addcmul_(hsum[: sg.nH], sg.hub_scale_b)
+            out = be.linear_fwd(agg, weight, bias)
         ctx.sg = sg
         ctx.gcn = gcn
         ctx.has_bias = bias is not None

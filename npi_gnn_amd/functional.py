@@ -158,9 +158,11 @@ def _pad128(k: int) -> int:
 
 
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               rowscale: Optional[torch.Tensor] = None, relu: bool = False, flags: Optional[int] = None) -> torch.Tensor:
+               rowscale: Optional[torch.Tensor] = None, relu: bool = False, flags: Optional[int] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``a @ weight + bias``.  ``a`` may be wider than ``weight`` has rows: ``[M, Kp]`` with Kp = K rounded up to 128 and
-    the columns K.. ZERO (``NPI_GEMM_A_ZERO_PADDED``: the matrix-core kernel on Kp instead of the guarded one on an odd K)."""
+    the columns K.. ZERO (``NPI_GEMM_A_ZERO_PADDED``: the matrix-core kernel on Kp instead of the guarded one on an odd K).
+    ``out``: write into this ``[M, N]`` tensor (rows may have a pitch; same dtype) instead of a new one."""
     dev = require_gpu(a, weight, bias, rowscale)
     a = _fc(a, "a")
     weight = _fc(weight, "weight", a)
@@ -173,7 +175,10 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         if Ka != _pad128(K) or a.dtype != torch.float32:
             raise ValueError(f"a has {Ka} columns, weight {K} rows (a zero-padded a must be f32 and {_pad128(K)} wide)")
         fl |= NPI_GEMM_A_ZERO_PADDED
-    out = torch.empty((M, N), dtype=a.dtype, device=dev)
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=dev)
+    elif out.shape != (M, N) or out.dtype != a.dtype or out.stride(1) != 1 or out.device != a.device:
+        raise ValueError(f"linear_fwd: out must be [{M}, {N}] {a.dtype} with unit column stride on the operands' device")
     ws = _gemm_workspace(Ka, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
         check(load().npi_linear_fwd_ex(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),

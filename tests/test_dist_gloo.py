@@ -48,8 +48,12 @@ class TorchBackend:
             return out
         return res
 
-    def linear_fwd(self, a, w, b):
-        return a @ w + (b if b is not None else 0)
+    def linear_fwd(self, a, w, b, out=None):
+        res = a @ w + (b if b is not None else 0)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def linear_bwd_data(self, dc, w, rowscale):
         out = dc @ w.t()
