@@ -553,8 +553,29 @@ def run_configs(dev, args, c4):
         return {"workload": f"C4 graph, 1 x GATConv {F}->{F} (1 head) fp32 fwd+bwd", "ms_per_step": ms,
                 "edges_per_s": E4 / ms * 1e3, "ms_per_step_by_heads": by_heads, "roofline": roof}
 
+    def c4_bf16():
+        """the headline layer with bf16 STORAGE (features, weights, gradients; f32 accumulation inside the kernels, as config C2):
+        information only -- the metric's precision is f32 and `value` is the f32 number"""
+        bf = torch.bfloat16
+        conv = npi.SAGEConv(F, F).to(dev)
+        ref = conv(x4, g4).detach()
+        convb = npi.SAGEConv(F, F).to(dev)
+        convb.load_state_dict(conv.state_dict())
+        convb = convb.to(bf)
+        xb = x4.detach().to(bf).requires_grad_(True)
+        gob = go4.to(bf)
+
+        def step():
+            convb.weight.grad = convb.bias.grad = xb.grad = None
+            convb(xb, g4).backward(gob)
+        ms = _timeit(step, 10, 3)
+        dev_rel = float((convb(xb, g4).detach().float() - ref).abs().max() / ref.abs().max())
+        return {"workload": f"C4 graph, 1 x SAGEConv {F}->{F} fwd+bwd, bf16 storage / f32 accumulate (NOT the metric's precision)",
+                "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3, "max_dev_from_f32_output_rel": dev_rel}
+
     guarded("gcn_c4", gcn_c4)
     guarded("gat_c4", gat_c4)
+    guarded("C4_bf16_storage", c4_bf16)
 
     if not args.skip_c5:
         def c5():
