@@ -524,3 +524,27 @@ def test_stale_batch_totals_are_an_error_not_an_out_of_bounds_write(dev):
         NG.set_debug(False)
     with pytest.raises(OverflowError):
         ig.batch(keys, n_nodes=2 ** 31, n_pairs=5)
+
+
+def test_net1_takes_a_pyg_style_batch_as_well_as_a_graph_batch(dev):
+    """Net_1.forward(data): ``data`` may be anything with ``x / edge_index / batch / num_graphs`` (what a PyG DataLoader
+    yields) -- it is wrapped into a GraphBatch WITHOUT the optional knowledge -- or a GraphBatch that carries it (host sizes,
+    symmetric edge list): the same log-probabilities up to the summation order, and gradients reach every parameter."""
+    import types
+    from npi_gnn_amd import net1
+    fx = load("rpi369_fold0.pt")
+    x, ei, batch, y = (fx[k].to(dev) for k in ("x", "edge_index", "batch", "y"))
+    B = y.numel()
+    torch.manual_seed(0)
+    model = net1.Net_1(x.size(1)).to(dev)
+    model.eval()
+    plain = types.SimpleNamespace(x=x, edge_index=ei, batch=batch, num_graphs=B, y=y)
+    rich = net1.Batch(NG.GraphBatch(x, ei, batch, symmetric=True), y, sizes=torch.bincount(fx["batch"], minlength=B))
+    a = model(plain)
+    b = model(rich)
+    assert a.shape == (B, 2) and torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    assert torch.equal(a.argmax(1), b.argmax(1))
+    model.train()
+    torch.nn.functional.nll_loss(model(plain), y).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    assert not hasattr(ei, "_npi_graph") and not hasattr(batch, "_npi_sizes")        # nothing was left on the caller's tensors
