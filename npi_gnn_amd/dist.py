@@ -1156,27 +1156,40 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         dz_at = dz_at.view(-1, H)
         g_src_l = be.seg_rowsum(At, dz_at, H)
         fk.join(pdh, dz_bt, pg_src)
+        dh = dh_full[: nL + nH]
+        # One head on a shape the split GEMM covers: the attention terms g_dst (x) a1 + g_src (x) a2 are never added to d h --
+        # dX takes them in its GEMM's store epilogue, dW as the outer-product correction P^T [a1; a2] with
+        # P = x_own^T [g_dst g_src] (this rank's share: dW and d att are all-reduced anyway), d att = P W
+        # (functional._GatConvFn._backward_rank2).  d h is then final as soon as its hub rows have been reduce-scattered, so
+        # that exchange is issued FIRST and the weight-gradient GEMM runs on the side stream under the row sums of dz below.
+        rank2 = (H == 1 and ctx.needs_input_grad[0] and weight.size(0) % 4 == 0 and hasattr(be, "linear_bwd_data_rank2")
+                 and be.linear_bwd_data_rank2_ok(dh, weight))
+        wh = dws = None
+        if not _solo(W):
+            wh = reduce_scatter_rows(pdh, dh_full[nL:], sg.rank, W, sg.group, async_op=True)
+        else:
+            dh_full[nL:].copy_(pdh)
+        dw = None
+        if rank2 and ctx.needs_input_grad[1]:
+            dws = be.side_stream(dh) if hasattr(be, "side_stream") else None
+            with _fork(dws, (x_own, dh_full, pdh)) as fw:
+                _wait(wh, "bwd_reduce_scatter", dh_full)
+                wh = None
+                dw, _ = be.linear_bwd_weight(x_own, dh, False)
         dz_cat = torch.cat([dz_bt[:n_bt], dz_at[:n_at]])
         g_dst_l = be.seg_rowsum(A, dz_cat, H, map_=map_a)                          # light targets: complete
         pg_dst = be.seg_rowsum(B, dz_cat, H, map_=map_b)                           # hub targets: this rank's share
         pg = torch.cat([pg_dst, pg_src], dim=1).contiguous()                       # [hub_rows, 2 H]
         if _solo(W):
-            dh_full[nL:].copy_(pdh)
             g_hub = pg
         else:
-            wh = reduce_scatter_rows(pdh, dh_full[nL:], sg.rank, W, sg.group, async_op=True)
             g_hub = pg.new_empty((hp, 2 * H))
             _wait(reduce_scatter_rows(pg, g_hub, sg.rank, W, sg.group, async_op=True), "bwd_reduce_scatter_g", g_hub)
             _wait(wh, "bwd_reduce_scatter", dh_full)
-        dh = dh_full[: nL + nH]
         g_dst = torch.cat([g_dst_l, g_hub[:nH, :H]])
         g_src = torch.cat([g_src_l, g_hub[:nH, H:]])
-        datt = dw = dx = None
-        if (H == 1 and ctx.needs_input_grad[0] and weight.size(0) % 4 == 0 and hasattr(be, "linear_bwd_data_rank2")
-                and be.linear_bwd_data_rank2_ok(dh, weight)):
-            # one head: the attention terms are never added to d h -- dX takes them in its GEMM's store epilogue, dW as the
-            # outer-product correction P^T [a1; a2] with P = x_own^T [g_dst g_src] (this rank's share: dW and d att are
-            # all-reduced anyway), d att = P W (functional._GatConvFn._backward_rank2)
+        datt = dx = None
+        if rank2:
             K = weight.size(0)
             A2 = att2.view(2, C)
             U = be.linear_bwd_data(A2, weight, None)                               # [2, K]: W a1, W a2
@@ -1187,8 +1200,9 @@ class _ShardedGatDirectFn(torch.autograd.Function):
                 _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
                 datt = datt.view(1, 1, 2 * C)
             if ctx.needs_input_grad[1]:
-                dw, _ = be.linear_bwd_weight(x_own, dh, False)
-                dw += be.linear_bwd_weight(P, A2, False)[0]
+                corr = be.linear_bwd_weight(P, A2, False)[0]
+                fw.join(dw)
+                dw += corr
                 _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
             dx = be.linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
             return dx, dw, datt, db, None, None, None
