@@ -468,9 +468,9 @@ class HipBackend:
         from . import functional as NF
         return NF.gat_aggregate_scores(side, table, table2, C, scores, m.contiguous(), s.contiguous(), bias=bias, out=out)
 
-    def gat_pack(self, a_dst, m, s, D):
+    def gat_pack(self, a_dst, m, s, D, out=None):
         from . import functional as NF
-        return NF.gat_pack_targets(a_dst, m, s, D)
+        return NF.gat_pack_targets(a_dst, m, s, D, out=out)
 
     def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H=1):
         from . import functional as NF
@@ -1139,8 +1139,11 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                         # big: hub rows of dOut
         tbl_D, _ = gather_hub(sg, D)
         # packed per-TARGET scalars (a_dst, m, 1 / s, D): the own rows, and the hub table (targets of the light sources)
-        t_own = be.gat_pack(a_dst, m_own, s_all, D)
-        t_tbl = be.gat_pack(tbl_a_dst, M, tbl_S, tbl_D)
+        # (one table [hub table ; own rows], the index space of A^T's columns; B^T's columns are the own rows)
+        n_tbl = tbl_a_dst.numel()
+        t_all = h.new_empty((n_tbl + a_dst.numel(), 4))
+        t_own = be.gat_pack(a_dst, m_own, s_all, D, out=t_all[n_tbl:])
+        be.gat_pack(tbl_a_dst, M, tbl_S, tbl_D, out=t_all[:n_tbl])
         # hub SOURCES (rows of the hub table): targets = this rank's rows (its light rows; the own hubs' loops): nothing remote,
         # so this pass and its row sums run on the partial stream beside the light sources' pass
         bs = be.partial_stream(h) if (PARTIAL_SIDE_STREAM and not _solo(W) and hasattr(be, "partial_stream")) else None
@@ -1151,7 +1154,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         # own light SOURCES: targets = the hub table (+ the own loop)
         dh_full = h.new_empty((nL + hp, F))
         _wait(g_work, "bwd_all_gather", tbl_dO)
-        _, dz_at = be.gat_backward_fused(At, tbl_dO, dO, h[:nL], C, torch.cat([t_tbl, t_own]), a_src[:nL].contiguous(), slope,
+        _, dz_at = be.gat_backward_fused(At, tbl_dO, dO, h[:nL], C, t_all, a_src[:nL].contiguous(), slope,
                                          out=dh_full[:nL], H=H)
         dz_at = dz_at.view(-1, H)
         g_src_l = be.seg_rowsum(At, dz_at, H)

@@ -732,11 +732,14 @@ def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=Non
     return out
 
 
-def gat_pack_targets(a_dst, m, s, D):
-    """[n, 4] = (a_dst, m, 1 / (s + 1e-16), D) of every target node (one head): what ``gat_backward_fused_packed`` gathers"""
+def gat_pack_targets(a_dst, m, s, D, out=None):
+    """[n, 4] = (a_dst, m, 1 / (s + 1e-16), D) of every target node (one head): what ``gat_backward_fused_packed`` gathers.
+    ``out``: a contiguous ``[n, 4]`` f32 tensor to fill (a slice of a larger table)."""
     dev = a_dst.device
     n = a_dst.numel()
-    t = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    if out is not None and (out.shape != (n, 4) or out.dtype != torch.float32 or not out.is_contiguous()):
+        raise ValueError(f"gat_pack_targets: out must be a contiguous [{n}, 4] float32 tensor")
+    t = out if out is not None else torch.empty((n, 4), dtype=torch.float32, device=dev)
     check(load().npi_gat_pack_targets(ptr(a_dst.contiguous()), ptr(m.contiguous()), ptr(s.contiguous()), ptr(D.contiguous()), n,
                                       ptr(t), stream_ptr(dev)), "npi_gat_pack_targets")
     return t

@@ -139,8 +139,12 @@ class TorchBackend:
             return out
         return res
 
-    def gat_pack(self, a_dst, m, s, D):
-        return torch.cat([a_dst.reshape(-1, 1), m.reshape(-1, 1), 1.0 / (s.reshape(-1, 1) + 1e-16), D.reshape(-1, 1)], dim=1)
+    def gat_pack(self, a_dst, m, s, D, out=None):
+        t = torch.cat([a_dst.reshape(-1, 1), m.reshape(-1, 1), 1.0 / (s.reshape(-1, 1) + 1e-16), D.reshape(-1, 1)], dim=1)
+        if out is not None:
+            out.copy_(t)
+            return out
+        return t
 
     def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H=1):
         key, val, n_rows, _ = side                                    # key = source row j, val = target column i
