@@ -612,6 +612,8 @@ GAT_PACKED_BACKWARD = os.environ.get("NPI_GAT_PACKED", "1") != "0"
 # pass over [N, C]); dX takes them in the store epilogue of its GEMM (rank 2: g (x) W att), dW as an outer-product correction
 # built from x^T g -- the same pass over x that yields d att.  0: the separate npi_gat_rank1_add pass
 GAT_RANK2_EPILOGUE = os.environ.get("NPI_GAT_RANK2", "1") != "0"
+# ... from this many rows on: below, the three [2, .] products it needs cost more than the pass over d hfeat they replace
+GAT_RANK2_MIN_ROWS = int(os.environ.get("NPI_GAT_RANK2_MIN_ROWS", "100000"))
 
 
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
@@ -908,8 +910,8 @@ class _GatConvFn(torch.autograd.Function):
             dz = dz.view(-1, H)
             g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
             g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
-            if (GAT_RANK2_EPILOGUE and H == 1 and ctx.needs_input_grad[0] and x.dtype == torch.float32 and weight.size(0) % 4 == 0
-                    and linear_bwd_data_rank2_ok(dh, weight)):
+            if (GAT_RANK2_EPILOGUE and H == 1 and N >= GAT_RANK2_MIN_ROWS and ctx.needs_input_grad[0] and x.dtype == torch.float32
+                    and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight)):
                 return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, g_dst, g_src, db, C)
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
             check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), N, H, C, stream_ptr(dev)),

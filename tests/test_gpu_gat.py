@@ -198,8 +198,9 @@ def test_attention_terms_in_the_gemm_epilogue_equal_the_separate_pass(dev, N, E,
     from npi_gnn_amd import functional as NF
     ei, x, W, att, b, go = _case(N, E, Fi, 1, C, seed=N + C)
     res = []
-    old = NF.GAT_RANK2_EPILOGUE
+    old, old_min = NF.GAT_RANK2_EPILOGUE, NF.GAT_RANK2_MIN_ROWS
     try:
+        NF.GAT_RANK2_MIN_ROWS = 0                       # (the product takes this path from 100,000 rows on)
         for flag in (False, True):
             NF.GAT_RANK2_EPILOGUE = flag
             xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
@@ -207,7 +208,7 @@ def test_attention_terms_in_the_gemm_epilogue_equal_the_separate_pass(dev, N, E,
             out.backward(go.to(dev))
             res.append((out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad))
     finally:
-        NF.GAT_RANK2_EPILOGUE = old
+        NF.GAT_RANK2_EPILOGUE, NF.GAT_RANK2_MIN_ROWS = old, old_min
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][4], res[1][4])
     for a, c in zip(res[0][1:4], res[1][1:4]):
         assert torch.allclose(a, c, rtol=1e-4, atol=2e-6 * float(a.abs().max()) * max(1.0, N ** 0.5 / 30))

@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import npi_gnn_amd as npi
 from npi_gnn_amd._lib import load
 from oracle import ref_conv as R
+from npi_gnn_amd import functional as _NF
+_NF.GAT_RANK2_MIN_ROWS = 0          # small graphs too: the rank-2 store epilogue of dX (the product takes it from 100,000 rows on)
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
