@@ -68,3 +68,17 @@ def test_no_layer_reads_or_writes_tensor_attributes():
     for name in os.listdir(root):
         if name.endswith(".py"):
             assert "_npi_" not in open(os.path.join(root, name)).read(), name
+
+
+def test_examples_and_tools_compile():
+    """every script under examples/ and tools/ is at least syntactically valid Python (they run on the GPU box only)"""
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 0
+    for sub in ("examples", "tools"):
+        for name in sorted(os.listdir(os.path.join(root, sub))):
+            if name.endswith(".py"):
+                py_compile.compile(os.path.join(root, sub, name), doraise=True, cfile=os.devnull)
+                n += 1
+    assert n >= 20
