@@ -73,12 +73,12 @@ def test_no_layer_reads_or_writes_tensor_attributes():
 def test_examples_and_tools_compile():
     """every script under examples/ and tools/ is at least syntactically valid Python (they run on the GPU box only)"""
     import os
-    import py_compile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     n = 0
     for sub in ("examples", "tools"):
         for name in sorted(os.listdir(os.path.join(root, sub))):
             if name.endswith(".py"):
-                py_compile.compile(os.path.join(root, sub, name), doraise=True, cfile=os.devnull)
+                with open(os.path.join(root, sub, name)) as f:
+                    compile(f.read(), name, "exec")               # (no .pyc written)
                 n += 1
     assert n >= 20
