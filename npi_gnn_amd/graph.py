@@ -261,9 +261,24 @@ class GraphBatch:
         return int(self.x.size(0))
 
     def to(self, device):
-        """Batches of this package are born on the device (``InteractionGraph.batch``); kept for the reference's
-        ``data = data.to(device)`` (src/train_with_twoDataset.PY:50)."""
-        return self
+        """The reference's ``data = data.to(device)`` (src/train_with_twoDataset.PY:50).  Batches of this package are born on
+        the device (``InteractionGraph.batch``): then this is the object itself.  Otherwise the tensors are moved; what was
+        built for the old device (CSR, recipe, padded buffer) is dropped, the host-side knowledge (``sizes``) stays."""
+        device = torch.device(device) if device is not None else self.x.device
+        if device.type == "cuda" and device.index is None and self.x.is_cuda:
+            device = self.x.device
+        if device == self.x.device:
+            return self
+        mv = lambda t: None if t is None else t.to(device)                      # noqa: E731
+        other = object.__new__(type(self))
+        GraphBatch.__init__(other, mv(self.x), mv(self.edge_index), mv(self.batch), self.num_graphs, sizes=self.sizes,
+                            graph_ptr=mv(self.graph_ptr), symmetric=self.symmetric)
+        for klass in type(self).__mro__:                                       # subclasses' own fields (net1.Batch.y)
+            for name in getattr(klass, "__slots__", ()):
+                if name not in GraphBatch.__slots__ and hasattr(self, name):
+                    v = getattr(self, name)
+                    setattr(other, name, v.to(device) if isinstance(v, torch.Tensor) else v)
+        return other
 
     def with_x(self, x: torch.Tensor) -> "GraphBatch":
         """The same graphs with other node features (what a conv returns); the structure, incl. a CSR already built, is shared."""

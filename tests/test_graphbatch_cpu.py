@@ -21,7 +21,10 @@ def test_unpacks_like_the_pyg_triple_and_infers_the_graph_count():
     gb = GraphBatch(x, ei, batch, sizes=torch.tensor([3, 4]))
     a, b, c = gb
     assert a is x and b is ei and c is batch
-    assert gb.num_graphs == 2 and gb.num_nodes == 7 and gb.to("cuda:0") is gb
+    assert gb.num_graphs == 2 and gb.num_nodes == 7 and gb.to("cpu") is gb and gb.to(None) is gb
+    moved = gb.to("meta")                                                 # another device: tensors move, host knowledge stays
+    assert moved is not gb and moved.x.device.type == "meta" and moved.edge_index.device.type == "meta"
+    assert moved.sizes is gb.sizes and moved.num_graphs == 2 and moved.peek_graph() is None
     assert GraphBatch(x, ei).num_graphs == 1                              # no batch vector: one graph
     assert GraphBatch(x, ei, batch).num_graphs is None                    # unknown until somebody needs it
     assert GraphBatch(x, ei, batch, graph_ptr=torch.tensor([0, 3, 7], dtype=torch.int32)).num_graphs == 2
@@ -58,6 +61,8 @@ def test_loader_batch_is_a_graph_batch_with_labels():
     y = torch.tensor([1, 0])
     d = net1.Batch(GraphBatch(x, ei, batch, symmetric=True), y, sizes=torch.tensor([3, 4]))
     assert isinstance(d, GraphBatch) and d.y is y and d.num_graphs == 2 and d.symmetric and d.to(None) is d
+    m = d.to("meta")
+    assert type(m) is net1.Batch and m.y.device.type == "meta" and m.symmetric and m.num_graphs == 2
     assert torch.equal(d.sizes, torch.tensor([3, 4]))
 
 
