@@ -262,6 +262,14 @@ int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t N);
 int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0, const float* row1,
                               const float* col0, const float* col1, float* dA, int64_t ldda, int64_t M, int64_t K, int64_t N,
                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The two-row products around that epilogue, one head (att = [att_dst ; att_src], [2, C]; W [K, C]; P = x^T [g_dst g_src], [2, K] from
+ * npi_gat_att_grad on x):  cols: U [2, K] = att W^T, the column vectors col0 / col1 above.  tail: dW [K, C] += P^T att (the
+ * outer-product correction of the weight gradient; null: skipped) and datt [2, C] = P W (null: skipped).  Fixed summation
+ * orders.  (GATConv.message's att terms, PyG 1.4.2 gat_conv.py; not on the reference's own path: BASELINE configs[4].) */
+int npi_gat_rank2_cols(const float* W, int64_t ldw, const float* att, int64_t K, int64_t C, float* U, void* stream);
+int npi_gat_rank2_tail(const float* P, const float* W, int64_t ldw, const float* att, int64_t K, int64_t C, float* dw, int64_t lddw,
+                       float* datt, void* stream);
 int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
                           const float* rowscale, void* dA, int64_t ldda,
                           int64_t M, int64_t K, int64_t N, int dtype, void* stream);

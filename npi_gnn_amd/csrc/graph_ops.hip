@@ -249,6 +249,68 @@ extern "C" int npi_l2_normalize_rows_bwd(const float* dy, int64_t ldd, const flo
     return check_launch("npi_l2_normalize_rows_bwd");
 }
 
+// The [2, .] products around GATConv's rank-2 store epilogue (npi_linear_bwd_data_rank2), one head, as two small launches
+// instead of three guarded GEMMs of two rows each (23 us apiece: a 128 x 128 tile walk for 2 x 256 outputs):
+//   cols:  U[r, k] = sum_c W[k, c] att[r, c]                 (r = 0: att_dst, 1: att_src)  -- the column vectors of the epilogue
+//   tail:  dW[k, c] += P[0, k] att[0, c] + P[1, k] att[1, c]   and   datt[r, c] = sum_k P[r, k] W[k, c]      (P = x^T [g_dst g_src])
+// Fixed summation orders (a lane strides over c / a thread walks k), so run-to-run identical.
+__global__ void __launch_bounds__(256)
+gat_rank2_cols_kernel(const float* __restrict__ W, int64_t ldw, const float* __restrict__ att, int K, int C, float* __restrict__ U) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);               // one wavefront per row of W
+    if (k >= K) return;
+    const int lane = lane_id();
+    float u0 = 0.f, u1 = 0.f;
+    for (int c = lane; c < C; c += WAVE) {
+        const float w = W[(int64_t)k * ldw + c];
+        u0 = fmaf(w, att[c], u0);
+        u1 = fmaf(w, att[C + c], u1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { u0 += __shfl_xor(u0, o); u1 += __shfl_xor(u1, o); }
+    if (lane == 0) { U[k] = u0; U[K + k] = u1; }
+}
+
+__global__ void __launch_bounds__(256)
+gat_rank2_tail_kernel(const float* __restrict__ P, const float* __restrict__ W, int64_t ldw, const float* __restrict__ att, int K, int C,
+                      float* __restrict__ dw, int64_t lddw, float* __restrict__ datt) {
+    const int cb = (C + 255) / 256;                                   // column blocks
+    if ((int)blockIdx.x < K * cb) {
+        if (dw == nullptr) return;
+        const int k = blockIdx.x / cb, c = (blockIdx.x % cb) * 256 + threadIdx.x;
+        if (c < C) dw[(int64_t)k * lddw + c] += fmaf(P[k], att[c], P[K + k] * att[C + c]);
+        return;
+    }
+    if (datt == nullptr) return;
+    const int c = ((int)blockIdx.x - K * cb) * 256 + threadIdx.x;
+    if (c >= C) return;
+    float d0 = 0.f, d1 = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float w = W[(int64_t)k * ldw + c];
+        d0 = fmaf(P[k], w, d0);
+        d1 = fmaf(P[K + k], w, d1);
+    }
+    datt[c] = d0;
+    datt[C + c] = d1;
+}
+
+extern "C" int npi_gat_rank2_cols(const float* W, int64_t ldw, const float* att, int64_t K, int64_t C, float* U, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(K > 0 && C > 0 && K < 0x7fffffff && C < 0x7fffffff && ldw >= C, "npi_gat_rank2_cols: bad size");
+    NPI_REQUIRE(W && att && U, "npi_gat_rank2_cols: null pointer");
+    gat_rank2_cols_kernel<<<(unsigned)ceil_div(K, 4), 256, 0, stream>>>(W, ldw, att, (int)K, (int)C, U);
+    return check_launch("npi_gat_rank2_cols");
+}
+
+extern "C" int npi_gat_rank2_tail(const float* P, const float* W, int64_t ldw, const float* att, int64_t K, int64_t C, float* dw,
+                                  int64_t lddw, float* datt, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(K > 0 && C > 0 && K < (1 << 20) && C < (1 << 20) && ldw >= C && (dw == nullptr || lddw >= C), "npi_gat_rank2_tail: bad size");
+    NPI_REQUIRE(P && W && att && (dw || datt), "npi_gat_rank2_tail: null pointer");
+    const int64_t cb = ceil_div(C, 256);
+    gat_rank2_tail_kernel<<<(unsigned)(K * cb + cb), 256, 0, stream>>>(P, W, ldw, att, (int)K, (int)C, dw, lddw, datt);
+    return check_launch("npi_gat_rank2_tail");
+}
+
 extern "C" int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

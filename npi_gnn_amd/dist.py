@@ -492,6 +492,14 @@ class HipBackend:
         from . import functional as NF
         return NF.linear_bwd_data_rank2(dc, w, row0, row1, col0, col1)
 
+    def gat_rank2_cols(self, w, att2):
+        from . import functional as NF
+        return NF.gat_rank2_cols(w, att2)
+
+    def gat_rank2_tail(self, P, w, att2, dw, want_datt):
+        from . import functional as NF
+        return NF.gat_rank2_tail(P, w, att2, dw, want_datt)
+
 
 class ShardedGraph:
     """This rank's shard of the (self-loop-augmented) graph: sides A, B and their transposes."""
@@ -1195,17 +1203,17 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         if rank2:
             K = weight.size(0)
             A2 = att2.view(2, C)
-            U = be.linear_bwd_data(A2, weight, None)                               # [2, K]: W a1, W a2
+            U = be.gat_rank2_cols(weight, A2)                                      # [2, K]: W a1, W a2
             g_dst, g_src = g_dst.contiguous(), g_src.contiguous()
             P = be.gat_att_grad(x_own, g_dst, g_src, 1, K).view(2, K)
-            if ctx.needs_input_grad[2]:
-                datt = be.linear_fwd(P, weight, None).reshape(1, 2 * C)
+            if ctx.needs_input_grad[1]:
+                fw.join(dw)
+            datt = be.gat_rank2_tail(P, weight, A2, dw, ctx.needs_input_grad[2])   # dW += P^T [a1; a2], d att = P W
+            if datt is not None:
+                datt = datt.reshape(1, 2 * C)
                 _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
                 datt = datt.view(1, 1, 2 * C)
-            if ctx.needs_input_grad[1]:
-                corr = be.linear_bwd_weight(P, A2, False)[0]
-                fw.join(dw)
-                dw += corr
+            if dw is not None:
                 _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
             dx = be.linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
             return dx, dw, datt, db, None, None, None

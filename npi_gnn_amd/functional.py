@@ -232,6 +232,33 @@ def linear_bwd_data_rank2(dc: torch.Tensor, weight: torch.Tensor, row0: torch.Te
     return da
 
 
+def gat_rank2_cols(weight: torch.Tensor, att2: torch.Tensor) -> torch.Tensor:
+    """``U [2, K] = [att_dst ; att_src] @ weight.T`` (one head; ``att2`` is ``[1, 2C]`` or ``[2, C]``): the column vectors of
+    ``linear_bwd_data_rank2`` (``npi_gat_rank2_cols``)"""
+    dev = require_gpu(weight, att2)
+    weight, att2 = _f32c(weight, "weight"), _f32c(att2.reshape(2, -1), "att")
+    K, C = weight.shape
+    U = torch.empty((2, K), dtype=torch.float32, device=dev)
+    check(load().npi_gat_rank2_cols(ptr(weight), weight.stride(0), ptr(att2), K, C, ptr(U), stream_ptr(dev)), "npi_gat_rank2_cols")
+    return U
+
+
+def gat_rank2_tail(P: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor, dw: Optional[torch.Tensor], want_datt: bool):
+    """``dw += P.T @ att`` in place (``dw`` None: skipped) and, when asked, ``datt [2, C] = P @ weight`` -- one launch
+    (``npi_gat_rank2_tail``); P is ``[2, K]`` = x^T [g_dst g_src]"""
+    dev = require_gpu(P, weight, att2, dw)
+    P, weight, att2 = _f32c(P, "P"), _f32c(weight, "weight"), _f32c(att2.reshape(2, -1), "att")
+    K, C = weight.shape
+    if dw is not None and (dw.shape != (K, C) or dw.dtype != torch.float32 or dw.stride(1) != 1):
+        raise ValueError("gat_rank2_tail: dw must be a [K, C] float32 tensor with unit column stride")
+    datt = torch.empty((2, C), dtype=torch.float32, device=dev) if want_datt else None
+    if dw is None and datt is None:
+        return None
+    check(load().npi_gat_rank2_tail(ptr(P), ptr(weight), weight.stride(0), ptr(att2), K, C, ptr(dw),
+                                    dw.stride(0) if dw is not None else 0, ptr(datt), stream_ptr(dev)), "npi_gat_rank2_tail")
+    return datt
+
+
 def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False,
                       flags: Optional[int] = None, k_valid: Optional[int] = None):
     """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid; a per-call argument of
@@ -965,11 +992,12 @@ class _GatConvFn(torch.autograd.Function):
             dX   = dh W^T + g_dst (x) (W a1) + g_src (x) (W a2)      the rank-2 term in the GEMM's store epilogue
             dW   = x^T dh + P^T [a1; a2]                              a [K, C] outer-product correction
             datt = [P W]                                              since hfeat = x W
-        The pass over x and the [2, .] products run on the side stream under the two large GEMMs."""
+        The pass over x runs on the side stream under the two large GEMMs; the [2, .] products are two small launches
+        (``npi_gat_rank2_cols`` in front, ``npi_gat_rank2_tail`` behind)."""
         dev = x.device
         K = weight.size(0)
         A = att2.view(2, C)                                                   # rows a1, a2
-        U = linear_bwd_data(A, weight)                                        # [2, K]: W a1, W a2 (exact f32: two rows)
+        U = gat_rank2_cols(weight, A)                                         # [2, K]: W a1, W a2
         main = torch.cuda.current_stream(dev)
         overlap = OVERLAP_STREAMS and x.size(0) >= OVERLAP_MIN_ROWS
         side = _side_stream(dev) if overlap else main
@@ -977,19 +1005,17 @@ class _GatConvFn(torch.autograd.Function):
             side.wait_stream(main)
         with torch.cuda.stream(side):
             P = gat_att_grad(x, g_dst, g_src, 1, K).view(2, K)                # x^T g_dst, x^T g_src
-            datt = linear_fwd(P, weight).view(1, 1, 2 * C) if ctx.needs_input_grad[2] else None
-            corr = linear_bwd_weight(P, A, want_bias=False)[0] if ctx.needs_input_grad[1] else None      # [K, C]
         dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
         dx = linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
         if overlap:
-            for t in (x, g_dst, g_src, weight, A):
+            for t in (x, g_dst, g_src):
                 t.record_stream(side)
-            for t in (P, datt, corr):
-                if t is not None:
-                    t.record_stream(main)
+            P.record_stream(main)
             main.wait_stream(side)
-        if dw is not None:
-            dw += corr
+        # dW += P^T [a1; a2] and d att = P W in one small launch behind the GEMMs
+        datt = gat_rank2_tail(P, weight, A, dw, ctx.needs_input_grad[2])
+        if datt is not None:
+            datt = datt.view(1, 1, 2 * C)
         return dx, dw, datt, db, None, None, None, None
 
 

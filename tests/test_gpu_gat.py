@@ -213,3 +213,25 @@ def test_attention_terms_in_the_gemm_epilogue_equal_the_separate_pass(dev, N, E,
     for a, c in zip(res[0][1:4], res[1][1:4]):
         assert torch.allclose(a, c, rtol=1e-4, atol=2e-6 * float(a.abs().max()) * max(1.0, N ** 0.5 / 30))
     assert not torch.equal(res[0][1], res[1][1])          # (the two paths really are different arithmetic)
+
+
+@pytest.mark.parametrize("K,C", [(128, 256), (256, 64), (178, 300), (4, 8)])
+def test_rank2_helper_products_match_torch(dev, K, C):
+    """npi_gat_rank2_cols (U = att W^T) and npi_gat_rank2_tail (dW += P^T att, datt = P W) against fp64 matmuls; the in-place
+    update leaves a dW with a row pitch intact outside its columns; either output may be skipped."""
+    from npi_gnn_amd import functional as NF
+    g = torch.Generator().manual_seed(K + C)
+    W, att, P = torch.randn(K, C, generator=g), torch.randn(2, C, generator=g), torch.randn(2, K, generator=g)
+    dw0 = torch.randn(K, C, generator=g)
+    U = NF.gat_rank2_cols(W.to(dev), att.to(dev)).cpu()
+    assert torch.allclose(U.double(), att.double() @ W.double().t(), atol=1e-5 * C ** 0.5, rtol=1e-5)
+    wide = torch.full((K, C + 5), 7.0, device=dev)
+    wide[:, :C] = dw0.to(dev)
+    dw = wide[:, :C]
+    datt = NF.gat_rank2_tail(P.to(dev), W.to(dev), att.to(dev), dw, True).cpu()
+    assert torch.allclose(datt.double(), P.double() @ W.double(), atol=1e-5 * K ** 0.5, rtol=1e-5)
+    assert torch.allclose(dw.cpu().double(), dw0.double() + P.double().t() @ att.double(), atol=1e-5, rtol=1e-5)
+    assert bool((wide[:, C:] == 7.0).all())
+    assert NF.gat_rank2_tail(P.to(dev), W.to(dev), att.to(dev), None, False) is None
+    only = NF.gat_rank2_tail(P.to(dev), W.to(dev), att.to(dev), None, True)
+    assert torch.equal(only.cpu(), datt)
