@@ -281,16 +281,19 @@ gat_rank2_tail_kernel(const float* __restrict__ P, const float* __restrict__ W, 
         return;
     }
     if (datt == nullptr) return;
-    const int c = ((int)blockIdx.x - K * cb) * 256 + threadIdx.x;
+    // one wavefront per column: lanes stride over k (W is small and cache resident), then a fixed xor tree
+    const int c = ((int)blockIdx.x - K * cb) * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
+    const int lane = lane_id();
     float d0 = 0.f, d1 = 0.f;
-    for (int k = 0; k < K; ++k) {
+    for (int k = lane; k < K; k += WAVE) {
         const float w = W[(int64_t)k * ldw + c];
         d0 = fmaf(P[k], w, d0);
         d1 = fmaf(P[K + k], w, d1);
     }
-    datt[c] = d0;
-    datt[C + c] = d1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+    if (lane == 0) { datt[c] = d0; datt[C + c] = d1; }
 }
 
 extern "C" int npi_gat_rank2_cols(const float* W, int64_t ldw, const float* att, int64_t K, int64_t C, float* U, void* stream_) {
@@ -307,7 +310,7 @@ extern "C" int npi_gat_rank2_tail(const float* P, const float* W, int64_t ldw, c
     NPI_REQUIRE(K > 0 && C > 0 && K < (1 << 20) && C < (1 << 20) && ldw >= C && (dw == nullptr || lddw >= C), "npi_gat_rank2_tail: bad size");
     NPI_REQUIRE(P && W && att && (dw || datt), "npi_gat_rank2_tail: null pointer");
     const int64_t cb = ceil_div(C, 256);
-    gat_rank2_tail_kernel<<<(unsigned)(K * cb + cb), 256, 0, stream>>>(P, W, ldw, att, (int)K, (int)C, dw, lddw, datt);
+    gat_rank2_tail_kernel<<<(unsigned)(K * cb + ceil_div(C, 4)), 256, 0, stream>>>(P, W, ldw, att, (int)K, (int)C, dw, lddw, datt);
     return check_launch("npi_gat_rank2_tail");
 }
 
