@@ -1085,14 +1085,22 @@ class _ShardedGatDirectFn(torch.autograd.Function):
                 mB, sB, eB = be.gat_stats_scores(B, tbl_a_dst, a_src, slope)
             else:
                 mB, sB = be.gat_stats(B, tbl_a_dst, a_src, H, slope)
-            empty = be.row_lengths(B).view(-1, 1) == 0
-            M = torch.where(empty, torch.full_like(mB, NEG), mB)
+            # constants of the graph, built once: which hub rows have no entry on this rank, and the fill values they take
+            const = sg._gat_const.get(H) if hasattr(sg, "_gat_const") else None
+            if const is None:
+                empty = be.row_lengths(B).view(-1, 1) == 0
+                const = (empty, torch.full_like(mB, NEG), torch.ones_like(mB), torch.zeros_like(sB))
+                if not hasattr(sg, "_gat_const"):
+                    sg._gat_const = {}
+                sg._gat_const[H] = const
+            empty, neg, ones, zeros = const
+            M = torch.where(empty, neg, mB)
             _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
             if H == 1:
-                U = be.gat_aggregate_scores(B, h, None, C, eB, M, torch.ones_like(M))  # sum exp(e - M) h_j, not normalised
+                U = be.gat_aggregate_scores(B, h, None, C, eB, M, ones)            # sum exp(e - M) h_j, not normalised
             else:
-                U = be.gat_aggregate(B, h, None, H, C, tbl_a_dst, a_src, M, torch.ones_like(M), slope, False)
-            S = torch.where(empty, torch.zeros_like(sB), sB * torch.exp(mB - M))
+                U = be.gat_aggregate(B, h, None, H, C, tbl_a_dst, a_src, M, ones, slope, False)
+            S = torch.where(empty, zeros, sB * torch.exp(mB - M))
             if _solo(W):
                 hU.copy_(U)
                 s_own = S
