@@ -875,6 +875,7 @@ def main():
         print(json.dumps({"control_uniform": control_uniform(dev, N, E, F)}), flush=True)
         return
     sharded = world > 1 or args.force_sharded
+    fallback = None                                             # set when the sharded pre-flight step fell back (below)
     ei = bipartite_edge_index(N, E, seed=args.graph_seed)
     g = torch.Generator().manual_seed(1)
     x_full = torch.randn(N, F, generator=g)
@@ -918,32 +919,58 @@ def main():
         t0 = time.time()
         # every rank ships only ITS slice of the edge list to its GPU; the partitioner routes the edges (dist.route_edges)
         ei_mine = ei[:, rank * E // world: (rank + 1) * E // world] if world > 1 else ei
-        if args.partition == "edges":
-            sg = ND.EdgeShardedGraph(ei_mine, N, rank, world, dev, sliced=world > 1)
-            layer = ND.EdgeShardedSAGELayer(sg, W.to(dev), bias.to(dev))
-            x = x_full.to(dev).requires_grad_(True)            # x is REPLICATED in this split
-            go = sg.shard(go_full).to(dev)
-            seg_launch_bytes = [algorithmic_bytes(sg.local_nnz, N, F)]
-        else:
-            sg = ND.ShardedGraph(ei_mine, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None,
-                                 sliced=world > 1)
-            att_full = torch.randn(1, 1, 2 * F, generator=g) * 0.1
-            layer = {"sage": ND.ShardedSAGELayer, "gcn": ND.ShardedGCNLayer}[args.conv](sg, W.to(dev), bias.to(dev)) \
-                if args.conv != "gat" else ND.ShardedGATLayer(sg, W.to(dev), att_full.to(dev), bias.to(dev))
-            x = sg.shard(x_full).to(dev).requires_grad_(True)  # this rank's rows: its ncRNAs, then its proteins
-            go = sg.shard(go_full).to(dev)
+        att_full = torch.randn(1, 1, 2 * F, generator=g) * 0.1
+
+        def build_sharded():
+            if args.partition == "edges":
+                sg_ = ND.EdgeShardedGraph(ei_mine, N, rank, world, dev, sliced=world > 1)
+                layer_ = ND.EdgeShardedSAGELayer(sg_, W.to(dev), bias.to(dev))
+                x_ = x_full.to(dev).requires_grad_(True)        # x is REPLICATED in this split
+                return sg_, layer_, x_, sg_.shard(go_full).to(dev), [algorithmic_bytes(sg_.local_nnz, N, F)]
+            sg_ = ND.ShardedGraph(ei_mine, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None,
+                                  sliced=world > 1)
+            layer_ = {"sage": ND.ShardedSAGELayer, "gcn": ND.ShardedGCNLayer}[args.conv](sg_, W.to(dev), bias.to(dev)) \
+                if args.conv != "gat" else ND.ShardedGATLayer(sg_, W.to(dev), att_full.to(dev), bias.to(dev))
+            x_ = sg_.shard(x_full).to(dev).requires_grad_(True)  # this rank's rows: its ncRNAs, then its proteins
             # per direction this rank launches side A (its rows) and, with hubs, side B (partial hub sums)
-            seg_launch_bytes = [algorithmic_bytes(sg.A.nnz_max - sg.n_local, sg.n_local, F)]
-            if sg.B is not None:
-                seg_launch_bytes.append(algorithmic_bytes(sg.B.nnz_max, sg.part.hub_rows, F) - sg.part.hub_rows * F * 4)
-        torch.cuda.synchronize()
-        t_build = time.time() - t0
+            nbytes = [algorithmic_bytes(sg_.A.nnz_max - sg_.n_local, sg_.n_local, F)]
+            if sg_.B is not None:
+                nbytes.append(algorithmic_bytes(sg_.B.nnz_max, sg_.part.hub_rows, F) - sg_.part.hub_rows * F * 4)
+            return sg_, layer_, x_, sg_.shard(go_full).to(dev), nbytes
+        sg, layer, x, go, seg_launch_bytes = build_sharded()
 
         def step():
             layer.zero_grad()
             x.grad = None
             out = layer(x)
             out.backward(go)
+
+        # Pre-flight: ONE step of the layer as configured.  If any rank raises (a code path that no test box could run: the
+        # schedule with the third stream, the merge-free hub layout, the split projection, the rank-2 store epilogue have only
+        # met RCCL through this bench), every rank falls back to the round-2 schedule -- classic layout, one extra stream, one
+        # GEMM per direction -- rebuilds its shard and says so in the line (`config.fallback`), instead of leaving the scaling
+        # run without a number.  The parity block below checks whichever schedule ran.
+        err = None
+        try:
+            if os.environ.get("NPI_BENCH_INJECT_FAILURE") == "1":
+                raise RuntimeError("injected pre-flight failure (NPI_BENCH_INJECT_FAILURE=1)")
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:                                  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad) != 0:
+            fallback = err or "another rank failed its pre-flight step"
+            ND.DIRECT_HUB_ROWS = ND.PARTIAL_SIDE_STREAM = ND.SPLIT_PROJECTION = ND.GAT_DIRECT = False
+            NF.GAT_RANK2_EPILOGUE = False
+            del sg, layer, x, go
+            torch.cuda.empty_cache()
+            sg, layer, x, go, seg_launch_bytes = build_sharded()
+        torch.cuda.synchronize()
+        t_build = time.time() - t0
 
     def barrier():
         if world > 1:
@@ -1105,7 +1132,7 @@ def main():
                                    f"(both directions, Zipf-skewed protein side), 1 {args.conv.upper()}Conv layer "
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
                        "parallelism": parallelism(args, world), "hip_graph_replay": captured, "setup_steps": SETUP_STEPS,
-                       "csr_build_s": round(t_build, 4)},
+                       "csr_build_s": round(t_build, 4), "fallback": fallback},
             "roofline": roof,
         }
         res.update(extra)

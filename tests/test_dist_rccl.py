@@ -150,3 +150,22 @@ def test_bench_parity_block_with_one_rank_through_the_sharded_code(dev):
         assert line["parity_max_err"] is not None and line["parity_max_err"] < 1e-5, line.get("parity")
         if conv == "sage":
             assert line["parity"]["by_tensor"]["out_rows_fp64_formula"] < 1e-5
+
+
+def test_bench_falls_back_to_the_conservative_schedule_when_its_preflight_step_fails(dev):
+    """bench.py's sharded path runs ONE pre-flight step; a failure (injected here) makes every rank rebuild its shard on the
+    round-2 schedule (classic hub layout, no third stream, one GEMM per direction) and say so in the line -- the numbers of the
+    fallback run still pass the in-bench parity check."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for inject in ("1", "0"):
+        env["NPI_BENCH_INJECT_FAILURE"] = inject
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--nodes", "200000", "--edges",
+                            "4000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        if inject == "1":
+            assert "injected pre-flight failure" in line["config"]["fallback"]
+        else:
+            assert line["config"]["fallback"] is None
+        assert line["parity_max_err"] is not None and line["parity_max_err"] < 1e-5, line.get("parity")
