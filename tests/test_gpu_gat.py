@@ -235,3 +235,37 @@ def test_rank2_helper_products_match_torch(dev, K, C):
     assert NF.gat_rank2_tail(P.to(dev), W.to(dev), att.to(dev), None, False) is None
     only = NF.gat_rank2_tail(P.to(dev), W.to(dev), att.to(dev), None, True)
     assert torch.equal(only.cpu(), datt)
+
+
+@pytest.mark.parametrize("freeze", [(), ("weight",), ("att",), ("weight", "att"), ("bias",)])
+def test_rank2_path_with_frozen_parameters(dev, freeze):
+    """GATConv at a size that takes the rank-2 store epilogue (>= 100,000 rows) with some parameters frozen: the gradients that
+    are asked for equal the ones of the separate-pass backward, the others stay None (no stray work for a frozen weight / att)."""
+    from npi_gnn_amd import functional as NF
+    from npi_gnn_amd.synth import bipartite_edge_index
+    N, E, F = 120_000, 1_200_000, 128
+    ei = bipartite_edge_index(N, E, seed=5).to(dev)
+    g = npi.CSRGraph(ei, N)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x0 = torch.randn(N, F, device=dev, generator=gen)
+    go = torch.randn(N, F, device=dev, generator=gen)
+
+    def run(rank2):
+        old = NF.GAT_RANK2_EPILOGUE
+        NF.GAT_RANK2_EPILOGUE = rank2
+        try:
+            torch.manual_seed(0)
+            conv = npi.GATConv(F, F).to(dev)
+            for name in freeze:
+                getattr(conv, name).requires_grad_(False)
+            x = x0.clone().requires_grad_(True)
+            conv(x, g).backward(go)
+            return x.grad, conv.weight.grad, conv.att.grad, conv.bias.grad
+        finally:
+            NF.GAT_RANK2_EPILOGUE = old
+    a, b = run(True), run(False)
+    for name, p, q in zip(("dx", "dW", "datt", "db"), a, b):
+        assert (p is None) == (q is None), name
+        if p is not None:
+            assert float((p - q).abs().max()) <= 1e-4 * float(q.abs().max()), name
+    assert a[1] is None if "weight" in freeze else a[1] is not None
