@@ -114,7 +114,7 @@ def gat_bytes(E: int, N: int, F: int, H: int = 1) -> dict:
     per-entry / per-node scalars of the attention.  nnz = E + N: the self loop is an ordinary entry.
       forward  (npi_gat_aggregate_scores): per entry a gathered h row 4F + col 4 + its score 4H; per node the output row
                4F + rowptr 4 + (m, s) 8H
-      backward (npi_gat_backward_fused_packed): per by-source entry a gathered dOut row 4F + col 4 + rowidx 4 + the target's
+      backward (npi_gat_backward_fused_heads): per by-source entry a gathered dOut row 4F + col 4 + rowidx 4 + the target's
                packed scalars 16 + dz written 4; per node its own h row 4F + the d h row written 4F + rowptr 4 + a_src 4"""
     nnz = E + N
     return {"gat_fwd_aggregate": nnz * (4 * F + 4 + 4 * H) + N * (4 * F + 4 + 8 * H),
@@ -359,12 +359,15 @@ def _stack_forward(kind, weights, x, graph, dtype=torch.float32, norm=None):
     return h.float().cpu()
 
 
-def virtual_c5(dev, ei5, N5, F5, weights, att, t1_ms, W):
+def virtual_c5(dev, ei5, N5, F5, weights, att, t1_ms, W, ref=None):
+    """configs[4] in its 8-GPU form on ONE GPU: every rank's 3-layer step timed alone (collectives = stand-in copies), and --
+    ``ref`` = (x, go, out, dX, per-layer parameter gradients) of the single-GPU stack -- the same 8 ranks run once more in
+    exact lock step (npi_gnn_amd.virtual.LockStep: true collective results) and compared with it: ``parity``."""
     from npi_gnn_amd import dist as ND
     from npi_gnn_amd.synth import protein_mask
     hub = protein_mask(N5).to(dev)
     per_rank, nnz, coll = [], [], None
-    with stub_collectives(W) as stub:
+    with stub_collectives(W, dev) as stub:
         for r in range(W):
             sg = ND.ShardedGraph(ei5, N5, r, W, dev, hub_mask=hub)
             layers = [ND.ShardedGATLayer(sg, Wk.to(dev), att[k].to(dev), bk.to(dev)) for k, (Wk, bk) in enumerate(weights)]
@@ -384,8 +387,26 @@ def virtual_c5(dev, ei5, N5, F5, weights, att, t1_ms, W):
             coll = coll or one
             del sg, layers, x, step
             torch.cuda.empty_cache()
-    return virtual_summary(W, t1_ms, per_rank, nnz, coll, "3 x GATConv 256 (1 head) on the hub cut, N=4M E=100M, per-rank step of the "
-                           f"{W}-rank run timed alone on this GPU (collectives = local copies); T1 = C5_1gpu")
+    res = virtual_summary(W, t1_ms, per_rank, nnz, coll, "3 x GATConv 256 (1 head) on the hub cut, N=4M E=100M, per-rank step of the "
+                          f"{W}-rank run timed alone on this GPU (collectives = local copies); T1 = C5_1gpu")
+    if ref is not None:
+        try:
+            from npi_gnn_amd.virtual import sharded_stack_errors
+            x5, go5, ref_out, ref_dx, ref_grads = ref
+            errs = sharded_stack_errors(
+                W, ei5, N5, hub, lambda sg: [ND.ShardedGATLayer(sg, Wk.to(dev), att[k].to(dev), bk.to(dev))
+                                             for k, (Wk, bk) in enumerate(weights)],
+                x5, go5, ref_out, ref_dx, ref_grads, dev)
+            passes = errs.pop("lockstep_passes")
+            res["parity"] = {"parity_max_err": max(errs.values()), "by_tensor": errs, "lockstep_passes": passes,
+                             "against": f"the single-GPU 3-layer stack on the whole graph; the {W} ranks in exact lock step on this "
+                                        "GPU (true all-gather / reduce-scatter / all-reduce results), every rank's rows of the "
+                                        "stack's output and of dX and every layer's all-reduced dW / d att / db, max over ranks, "
+                                        "relative to the largest reference magnitude"}
+            res["parity_max_err"] = res["parity"]["parity_max_err"]
+        except Exception as e:                                  # noqa: BLE001
+            res["parity"] = {"parity_max_err": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    return res
 
 
 def run_configs(dev, args, c4):
@@ -608,16 +629,31 @@ def run_configs(dev, args, c4):
                                          "one per layer)", src)
             res5 = {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU",
                     "ms_per_step": ms, "edge_layers_per_s": 3 * E5 / ms * 1e3, "roofline": roof}
-            del st, x5, g5
+            del st
+            ref = None
+            if args.virtual_world > 1:
+                # the reference of the 8-rank parity check: the single-GPU stack once more, with an explicit output gradient
+                go5 = torch.randn(N5, F5, generator=gen).to(dev)
+                ps = [(Wk.to(dev).requires_grad_(True), ak.to(dev).requires_grad_(True), bk.to(dev).requires_grad_(True))
+                      for (Wk, bk), ak in zip(weights, att)]
+                xin = x5.detach().requires_grad_(True)
+                h = xin
+                for Wk, ak, bk in ps:
+                    h = npi.gat_conv(h, g5, Wk, ak, bk, heads=1, relu=True)
+                h.backward(go5)
+                ref = (x5, go5, h.detach(), xin.grad, [{"weight": Wk.grad, "att": ak.grad, "bias": bk.grad} for Wk, ak, bk in ps])
+                del h, xin, ps
+            del x5, g5
             torch.cuda.empty_cache()
             if args.virtual_world > 1:
                 # BASELINE.json configs[4] in its 8-GPU form, rank by rank on this GPU: the same 3-layer GATConv stack on the
-                # hub cut, a rank's output rows being the next layer's input rows (collectives = local copies, as C4_w8_virtual)
+                # hub cut, a rank's output rows being the next layer's input rows (collectives = local copies, as C4_w8_virtual),
+                # then the same ranks in exact lock step against the single-GPU stack (parity)
                 try:
-                    res5["w8_virtual"] = virtual_c5(dev, ei5, N5, F5, weights, att, ms, args.virtual_world)
+                    res5["w8_virtual"] = virtual_c5(dev, ei5, N5, F5, weights, att, ms, args.virtual_world, ref=ref)
                 except Exception as e:
                     res5["w8_virtual"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            del ei5
+            del ei5, ref
             return res5
         guarded("C5_1gpu", c5)
     return out
@@ -690,54 +726,12 @@ def sharded_parity(dev, args, world, sg, layer, x, go, ei, x_full, go_full, W, b
 # ---------------------------------------------------------------------------------------------------------
 # virtual world: the W shards of the multi-GPU path, one after the other on this ONE GPU
 # ---------------------------------------------------------------------------------------------------------
-class stub_collectives:
-    """Replace the collectives of npi_gnn_amd.dist by local copies of the same shapes (one GPU stands in for rank r of W) and
-    log what every call would move: payload bytes, and bytes on the wire per rank (an all-gather / reduce-scatter of S bytes
-    moves S (W-1)/W per rank, an all-reduce 2 S (W-1)/W)."""
-
-    def __init__(self, W):
-        self.W, self.log = W, {}
-
-    def note(self, kind, nbytes, wire):
-        e = self.log.setdefault(kind, {"calls": 0, "payload_bytes": 0, "wire_bytes_per_rank": 0})
-        e["calls"] += 1
-        e["payload_bytes"] += nbytes
-        e["wire_bytes_per_rank"] += wire
-
-    def __enter__(self):
-        from npi_gnn_amd import dist as ND
-        frac = (self.W - 1) / self.W
-        me = self
-
-        class _Done:
-            def wait(self):
-                return True
-
-        def ag(block, out, w, group=None, async_op=False):
-            nb = out.numel() * out.element_size()
-            me.note("all_gather", nb, nb * frac)
-            out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1))
-            return _Done() if async_op else None
-
-        def rs(part_sums, out, rank, w, group=None, async_op=False):
-            nb = part_sums.numel() * part_sums.element_size()
-            me.note("reduce_scatter", nb, nb * frac)
-            out.copy_(part_sums.view(w, -1)[rank].view_as(out))
-            return _Done() if async_op else None
-
-        def ar(t, w, group=None, op=None, tag="all_reduce"):
-            nb = t.numel() * t.element_size()
-            me.note("all_reduce", nb, 2 * nb * frac)
-
-        self.saved = (ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo)
-        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce = ag, rs, ar
-        ND._solo = lambda w: False
-        return self
-
-    def __exit__(self, *exc):
-        from npi_gnn_amd import dist as ND
-        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo = self.saved
-        return False
+def stub_collectives(W, dev):
+    """npi_gnn_amd.virtual.StubCollectives with the stand-in copies on a stream of their own: a collective is issued when its
+    input is ready and the compute streams wait for it where they consume its result -- the dependency graph RCCL's stream
+    gives the real run (the partial side runs beside the all-gather stand-in, the projection beside the reduce-scatter one)."""
+    from npi_gnn_amd.virtual import StubCollectives
+    return StubCollectives(W, copy_stream=torch.cuda.Stream(device=dev))
 
 
 def virtual_summary(W, t1, per_rank, nnz, coll, what):
@@ -798,7 +792,7 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
     del conv, xx
 
     out = {}
-    with stub_collectives(W) as stub:
+    with stub_collectives(W, dev) as stub:
         hub = protein_mask(N).to(dev)
         in_count = torch.bincount(ei_dev[1][ei_dev[0] != ei_dev[1]], minlength=N)
         kinds = ("hubs_sage", "hubs_gat", "rows_sage", "edges_sage") if only is None else (only,)
@@ -836,8 +830,9 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
                  "hubs_gat": "GATConv (1 head), vertex cut with the cross-rank softmax"}
         for key, (ms, nnz, coll) in res.items():
             out[key] = virtual_summary(W, t1_gat if key == "hubs_gat" else t1_sage_ms, ms, nnz, coll, notes[key])
-    out["note"] = ("one GPU, ranks run one after the other; collectives are local copies of the same shapes, so per_rank_ms "
-                   "is local compute + host launch work only; wire bytes: all-gather / reduce-scatter of S bytes move "
+    out["note"] = ("one GPU, ranks run one after the other; collectives are local copies of the same shapes on a stream of their own "
+                   "(issued when their input is ready, waited for where their result is consumed: the real run's dependency graph), "
+                   "so per_rank_ms is local compute + host launch work only; wire bytes: all-gather / reduce-scatter of S bytes move "
                    "S (W-1)/W per rank, an all-reduce 2 S (W-1)/W; N > 1 itself is NOT measured here")
     return out
 
@@ -921,14 +916,14 @@ def main():
         ei_mine = ei[:, rank * E // world: (rank + 1) * E // world] if world > 1 else ei
         att_full = torch.randn(1, 1, 2 * F, generator=g) * 0.1
 
-        def build_sharded():
+        def build_sharded(schedule):
             if args.partition == "edges":
                 sg_ = ND.EdgeShardedGraph(ei_mine, N, rank, world, dev, sliced=world > 1)
                 layer_ = ND.EdgeShardedSAGELayer(sg_, W.to(dev), bias.to(dev))
                 x_ = x_full.to(dev).requires_grad_(True)        # x is REPLICATED in this split
                 return sg_, layer_, x_, sg_.shard(go_full).to(dev), [algorithmic_bytes(sg_.local_nnz, N, F)]
             sg_ = ND.ShardedGraph(ei_mine, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None,
-                                  sliced=world > 1)
+                                  sliced=world > 1, schedule=schedule)
             layer_ = {"sage": ND.ShardedSAGELayer, "gcn": ND.ShardedGCNLayer}[args.conv](sg_, W.to(dev), bias.to(dev)) \
                 if args.conv != "gat" else ND.ShardedGATLayer(sg_, W.to(dev), att_full.to(dev), bias.to(dev))
             x_ = sg_.shard(x_full).to(dev).requires_grad_(True)  # this rank's rows: its ncRNAs, then its proteins
@@ -937,7 +932,8 @@ def main():
             if sg_.B is not None:
                 nbytes.append(algorithmic_bytes(sg_.B.nnz_max, sg_.part.hub_rows, F) - sg_.part.hub_rows * F * 4)
             return sg_, layer_, x_, sg_.shard(go_full).to(dev), nbytes
-        sg, layer, x, go, seg_launch_bytes = build_sharded()
+        from npi_gnn_amd.schedule import CONSERVATIVE, DEFAULT
+        sg, layer, x, go, seg_launch_bytes = build_sharded(DEFAULT)
 
         def step():
             layer.zero_grad()
@@ -964,11 +960,9 @@ def main():
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if int(bad) != 0:
             fallback = err or "another rank failed its pre-flight step"
-            ND.DIRECT_HUB_ROWS = ND.PARTIAL_SIDE_STREAM = ND.SPLIT_PROJECTION = ND.GAT_DIRECT = False
-            NF.GAT_RANK2_EPILOGUE = False
             del sg, layer, x, go
             torch.cuda.empty_cache()
-            sg, layer, x, go, seg_launch_bytes = build_sharded()
+            sg, layer, x, go, seg_launch_bytes = build_sharded(CONSERVATIVE)      # an argument of the shard, no process-wide switch
         torch.cuda.synchronize()
         t_build = time.time() - t0
 
@@ -1178,10 +1172,10 @@ def main():
             res["configs"] = run_configs(dev, args, c4)
         if vw is not None:
             res.setdefault("configs", {})[f"C4_w{args.virtual_world}_virtual"] = vw
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline:
+        # rank 0, after the process group is gone (the other ranks have left): the N > 1 line carries the CPU path timed in the
+        # same run as well -- the same sample as the N = 1 line, so the two are comparable
         res["cpu_baseline"] = cpu_baseline(args, ei)
-    elif not args.no_cpu_baseline:
-        res["cpu_baseline"] = None
     print(json.dumps(res), flush=True)
 
 

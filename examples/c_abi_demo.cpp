@@ -47,7 +47,8 @@ int main() {
     int64_t* d_src = to_device(src);  int64_t* d_dst = to_device(dst);
     float* d_x = to_device(x);  float* d_W = to_device(W);  float* d_b = to_device(b);
     const int64_t nnz_max = E + N;                                   // edges + one self loop per node
-    const int64_t n_items = npi_num_items(nnz_max);
+    const int64_t item_edges = npi_item_edges(nnz_max);              // the recommended item size; this CSR keeps it from here on
+    const int64_t n_items = npi_num_items(nnz_max, item_edges);
     int32_t* rowptr = device_alloc<int32_t>(N + 1);
     int32_t* col = device_alloc<int32_t>(nnz_max);
     int32_t* eid = device_alloc<int32_t>(nnz_max);
@@ -58,12 +59,12 @@ int main() {
     void* ws = device_alloc<char>((size_t)ws_bytes);
     if (!d_src || !d_dst || !d_x || !d_W || !d_b || !rowptr || !col || !eid || !rowidx || !item_row || !status || !ws) return 2;
     // key = destination, value = source: rows are the targets, as scatter_mean(x_j, edge_index[1]) groups them
-    NPI_CALL(npi_csr_build(d_dst, d_src, E, N, /*add_self_loops=*/1, rowptr, col, eid, rowidx, item_row, status, ws, ws_bytes, stream));
+    NPI_CALL(npi_csr_build(d_dst, d_src, E, N, /*add_self_loops=*/1, rowptr, col, eid, rowidx, item_row, item_edges, status, ws, ws_bytes, stream));
     float* agg = device_alloc<float>(N * Fin);
-    float* carry = device_alloc<float>((size_t)npi_segsum_carry_elems(nnz_max, Fin));
+    float* carry = device_alloc<float>((size_t)npi_segsum_carry_elems(nnz_max, item_edges, Fin));
     float* out = device_alloc<float>(N * Fout);
     if (!agg || !carry || !out) return 2;
-    NPI_CALL(npi_segsum(rowptr, col, item_row, /*w=*/nullptr, N, nnz_max, d_x, Fin, agg, Fin, Fin, NPI_F32, /*mean=*/1, /*bias=*/nullptr, carry, stream));
+    NPI_CALL(npi_segsum(rowptr, col, item_row, item_edges, /*w=*/nullptr, N, nnz_max, d_x, Fin, agg, Fin, Fin, NPI_F32, /*mean=*/1, /*bias=*/nullptr, carry, stream));
     NPI_CALL(npi_linear_fwd(agg, Fin, d_W, Fout, d_b, /*rowscale=*/nullptr, out, Fout, N, Fin, Fout, /*relu=*/0, stream));
     std::vector<float> got(N * Fout);
     HIP_OK(hipMemcpyAsync(got.data(), out, got.size() * sizeof(float), hipMemcpyDeviceToHost, stream));

@@ -15,9 +15,11 @@
  *     scratch buffer is a caller workspace with a size query next to it.  (Two legacy GEMM entry points,
  *     npi_linear_fwd[_t] and npi_linear_bwd_data[_t], have no workspace argument and take 6*K*N bytes for the
  *     duration of the call from the stream-ordered allocator, hipMallocAsync / hipFreeAsync.)
- *   - no entry point reads or writes process-wide state except the two documented legacy switches
+ *   - no entry point's RESULT depends on process-wide state except through the two documented legacy switches
  *     (npi_gemm_mode, npi_dw_shared), which only the legacy GEMM entry points consult; calls on different
- *     streams from different threads are independent;
+ *     streams from different threads are independent.  The item size of a CSR is an explicit argument
+ *     (item_edges, next to item_row) of the build and of every consumer; npi_small_graph_entries only moves
+ *     the HINT npi_item_edges() returns to callers that have not decided yet;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     every call is asynchronous on it and performs no host synchronisation;
  *   - return value: 0 = ok, <0 = error (text via npi_last_error(), thread-local); no C++
@@ -39,9 +41,11 @@ extern "C" {
 #define NPI_ERR_LAUNCH (-2)   /* HIP launch / runtime error */
 #define NPI_ERR_WORKSPACE (-3)/* workspace too small */
 
-/* edges of the self-loop-augmented CSR that one wavefront ("item") reduces */
+/* entries of the self-loop-augmented CSR that one wavefront ("item") reduces: a property of each CSR, 64 or NPI_ITEM_EDGES,
+ * chosen by whoever builds it (npi_item_edges(nnz_max) = the recommended value) and passed as `item_edges` to the build and
+ * to every entry point that takes `item_row` */
 #ifndef NPI_ITEM_EDGES
-#define NPI_ITEM_EDGES 256    /* large graphs; CSRs with capacity nnz_max < 2^22 use 64 (npi_item_edges, npi_small_graph_entries) */
+#define NPI_ITEM_EDGES 256
 #endif
 
 /* data types of feature matrices */
@@ -70,20 +74,22 @@ int npi_abi_version(void);
  *   col[E+N]     : int32 neighbour (val) node per entry
  *   eid[E+N]     : int32 original column in edge_index, -1 for an appended self loop (may be NULL)
  *   rowidx[E+N]  : int32 key node per entry, i.e. the sorted COO row (may be NULL)
- *   item_row[npi_num_items(E+N)+1] : int32 first row of every NPI_ITEM_EDGES-entry item
+ *   item_row[npi_num_items(E+N, item_edges)+1] : int32 first row of every item of item_edges entries
+ *   item_edges   : 64 or NPI_ITEM_EDGES -- the item size of THIS CSR; hand the same value to every call that takes item_row
  *   status[1]    : int32 device word, bit 0 = out-of-range id seen
  * ------------------------------------------------------------------------------------------ */
 int64_t npi_csr_workspace_bytes(int64_t E, int64_t N);
-int64_t npi_item_edges(int64_t nnz_max);   /* entries per item for a CSR of capacity nnz_max: 64 or NPI_ITEM_EDGES */
-/* the capacity below which a CSR is cut into 64-entry items (default 2^22; NPI_SMALL_GRAPH_ENTRIES in the environment presets
- * it): n > 0 sets it and returns the previous value, n <= 0 only returns it.  Process-wide; change it only between graph
- * builds -- a CSR (item_row, carry) built under one value must be consumed under the same one. */
+/* recommended item size for a new CSR of capacity nnz_max: 64 below npi_small_graph_entries, NPI_ITEM_EDGES from there on.
+ * A hint only -- nothing that consumes a CSR calls it. */
+int64_t npi_item_edges(int64_t nnz_max);
+/* the capacity at which that hint switches (default 2^22; NPI_SMALL_GRAPH_ENTRIES in the environment presets it): n > 0 sets
+ * it and returns the previous value, n <= 0 only returns it.  Changing it never affects a CSR that already exists. */
 int64_t npi_small_graph_entries(int64_t n);
-int64_t npi_num_items(int64_t nnz_max);
+int64_t npi_num_items(int64_t nnz_max, int64_t item_edges);   /* ceil(nnz_max / item_edges); -1 for an item size that does not exist */
 int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
                   int add_self_loops,
                   int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* rowidx,
-                  int32_t* item_row, int32_t* status,
+                  int32_t* item_row, int64_t item_edges, int32_t* status,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Same build with separate row and column id spaces, for a destination-row SHARD of the graph on
@@ -94,7 +100,7 @@ int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E,
 int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
                      int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int drop_equal,
                      int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* rowidx,
-                     int32_t* item_row, int32_t* status,
+                     int32_t* item_row, int64_t item_edges, int32_t* status,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* inverse map for per-edge data that lives in one CSR's entry order and is needed in the other's:
@@ -114,11 +120,12 @@ int npi_edge_positions(const int32_t* eid, const int32_t* rowptr, int64_t N, int
  *   w == NULL  : all ones (SAGE);  otherwise one f32 per CSR entry (GCN norm / GAT alpha)
  *   x, out     : [N, F] row-major, leading dimension ldx / ldo (elements), dtype f32 or bf16
  *                (bf16 storage, f32 accumulation)
- *   carry      : f32 scratch, 2 * npi_num_items(nnz_max) * F elements, for rows cut by an
+ *   item_row, item_edges : as the CSR was built (npi_csr_build / npi_csr_filter)
+ *   carry      : f32 scratch, npi_segsum_carry_elems(nnz_max, item_edges, F) elements, for rows cut by an
  *                item boundary (combined in item order => bitwise reproducible)
  * ------------------------------------------------------------------------------------------ */
-int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t F);
-int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, int64_t F);
+int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                const float* w, int64_t N, int64_t nnz_max,
                const void* x, int64_t ldx, void* out, int64_t ldo, int64_t F, int dtype,
                int mean, const float* bias, float* carry, void* stream);
@@ -126,7 +133,7 @@ int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_ro
  * entry row col[p] - split of x2 (same leading dimension and dtype).  One rank of the sharded layers
  * (npi_gnn_amd/dist.py) gathers from [hub rows received from all ranks ; its own rows] without
  * copying its own rows behind the received ones.  x2 == NULL: one table, as npi_segsum. */
-int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                   const float* w, int64_t N, int64_t nnz_max,
                   const void* x, int64_t ldx, const void* x2, int64_t split,
                   void* out, int64_t ldo, int64_t F, int dtype,
@@ -282,30 +289,26 @@ int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t 
  * GATConv (PyG 1.4.2; absent from the reference tree, BASELINE.json configs[4]).  H heads of C
  * channels, hfeat = x @ W is [N, H*C]; att is [H, 2C] (first C multiply the TARGET's features).
  * The attention coefficient alpha of an entry is recomputed from four per-node, per-head scalars
- * [N, H] -- a_dst, a_src (npi_gat_scores), m, s (npi_gat_softmax_stats):
+ * [N, H] -- a_dst, a_src (npi_gat_scores), m, s (npi_gat_softmax_stats_ex):
  *     alpha(i <- j) = exp(leaky_relu(a_dst[i] + a_src[j]) - m[i]) / (s[i] + 1e-16)
  * The backward may keep the alpha that npi_gat_edge_grad computes anyway (alpha_out [nnz_max, H], by-target
  * entry order) and hand it to the by-source npi_gat_aggregate (alpha + alpha_map = npi_entry_transpose_map;
  * one head): reading a weight back is cheaper there than the exp and the divide per entry.  Both NULL: recompute.
  *
  *   npi_gat_scores        `(cat[x_i, x_j] * att).sum(-1)` split into its two dot products
- *   npi_gat_softmax_stats `utils.softmax`: scatter_max + scatter_add(exp) per target row
+ *   npi_gat_softmax_stats_ex `utils.softmax`: scatter_max + scatter_add(exp) per target row
  *   npi_gat_aggregate     by_source == 0: out[i] = sum_p alpha_p hfeat[col p] (+ bias)          (forward)
  *                         by_source != 0: out[j] = sum_q alpha_q x[col q] + g_dst[j] att[:C] + g_src[j] att[C:]
  *                                         over the by-source CSR                                (backward, d hfeat)
  *   npi_gat_rowdot        D[i,h] = <a[i,h,:], b[i,h,:] - bias[h,:]>      (= sum_p alpha_p dalpha_p)
  *   npi_gat_edge_grad     dz[p,h] = alpha_p (<dout_i, hfeat_j> - D_i) * leaky_relu'(z_p), by-target entry order
- *   npi_seg_rowsum        out[r,h] = sum_{p in row r} vals[map ? map[p] : p, h]
+ *   npi_seg_rowsum_ex     out[r,h] = sum_{p in row r} vals[map ? map[p] : p, h]
  *   npi_entry_transpose_map  map[q] = by-target position of by-source entry q
  *   npi_gat_att_grad      datt[h,:C] = sum_i g_dst[i,h] hfeat[i,h,:],  datt[h,C:] likewise with g_src
  * ------------------------------------------------------------------------------------------ */
 int npi_gat_scores(const float* hfeat, int64_t ldh, const float* att, int64_t N, int64_t H, int64_t C,
                    float* a_dst, float* a_src, void* stream);
-int64_t npi_gat_heavy_workspace_elems(int64_t nnz_max, int64_t H);   /* f32 scratch of npi_gat_softmax_stats / npi_seg_rowsum */
-int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
-                          const float* a_dst, const float* a_src, int64_t N, int64_t nnz_max, int64_t H,
-                          float slope, float* m, float* s, float* workspace, int64_t workspace_elems, void* stream);
-int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                       int64_t N, int64_t nnz_max, const float* x, int64_t ldx, float* out, int64_t ldo,
                       int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
                       const float* s, float negative_slope, int by_source, const float* bias,
@@ -313,7 +316,7 @@ int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       const float* alpha, const int32_t* alpha_map,
                       float* carry, void* stream);
 /* npi_gat_aggregate over a two-part table (x2 / split as in npi_segsum_ex). */
-int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                          int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                          float* out, int64_t ldo,
                          int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
@@ -321,41 +324,24 @@ int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_
                          const float* g_dst, const float* g_src, const float* att,
                          const float* alpha, const int32_t* alpha_map,
                          float* carry, void* stream);
-/* Fused backward pass (one head, C <= 256): over the by-SOURCE CSR, in ONE pass over the gathered dOut rows,
- *     out[j, :] = sum_q alpha_q dout[col q, :]                                   (the aggregation half of d hfeat)
- *     dz[q]     = alpha_q (<dout[col q], hfeat[j]> - D[col q]) leaky_relu'(a_dst[col q] + a_src[j])   (the SDDMM)
- * with alpha read back from the FORWARD (npi_gat_aggregate with by_source == 0, alpha != NULL and alpha_map == NULL stores
- * it in by-target entry order) through alpha_map = npi_entry_transpose_map.  Replaces npi_gat_edge_grad + the by-source
- * npi_gat_aggregate: one gather pass over the entries instead of two.  The rank-1 terms g_dst att[:C] + g_src att[C:]
- * are added afterwards by npi_gat_rank1_add (row sums of dz: npi_seg_rowsum over both orientations). */
-int npi_gat_backward_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                           int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* hfeat, int64_t ldh,
-                           float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src, const float* D,
-                           float negative_slope, const float* alpha, const int32_t* alpha_map, float* dz, float* carry,
-                           void* stream);
-/* npi_gat_backward_fused without the stored alpha and without the transpose map (round 3): the four per-TARGET scalars the
- * pass needs -- a_dst, m, 1 / (s + 1e-16), D -- are packed into one float4 per node (npi_gat_pack_targets; [N, 4], 16 MB at
- * N = 1M: cache resident), every entry makes ONE 16-byte gather of its target's pack and alpha is recomputed by the lane
- * that owns the entry (one exp per entry).  Replaces a random 4-byte read of the 84 MB alpha array per entry. */
+/* Fused backward pass over the by-SOURCE CSR, H in {1, 2, 4, 8} heads (H > 1: C in {32, 64, 128}), H C <= 256 -- in ONE pass over
+ * the gathered dOut rows
+ *     out[j, :]  = sum_q alpha_q dout[col q, :]                                   (the aggregation half of d hfeat)
+ *     dz[q, h]   = alpha_q (<dout[col q], hfeat[j]> - D[col q]) leaky_relu'(a_dst[col q] + a_src[j])   (the SDDMM)
+ * replaces npi_gat_edge_grad + the by-source npi_gat_aggregate: one gather pass over the entries instead of two.  The four
+ * per-TARGET scalars the pass needs -- a_dst, m, 1 / (s + 1e-16), D -- are packed into one float4 per node and head
+ * (npi_gat_pack_targets over the N H flattened scalars; tpack [n_cols, H, 4], 16 MB at N = 1M: cache resident): every entry
+ * makes ONE 16-byte gather per head and alpha is recomputed by the lane that owns the entry (one exp per entry and head).
+ * a_src [n_rows, H], dz [nnz_max, H]; every entry's H dots are reduced inside the C / 4 lanes of their head.  dout2 / split: the
+ * gathered rows come from a two-part table as in npi_segsum_ex (tpack is ONE array indexed by the column id over both parts:
+ * the sharded GATConv's received hub rows + the rank's own rows).  The attention terms g_dst att[:C] + g_src att[C:] of d hfeat
+ * are added afterwards by npi_gat_rank1_add, or never formed (npi_linear_bwd_data_rank2); g_dst / g_src are row sums of dz
+ * (npi_seg_rowsum_ex over both orientations). */
 int npi_gat_pack_targets(const float* a_dst, const float* m, const float* s, const float* D, int64_t N, float* tpack,
                          void* stream);
-int npi_gat_backward_fused_packed(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                                  int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* hfeat, int64_t ldh,
-                                  float* out, int64_t ldo, int64_t C, const float* tpack, const float* a_src,
-                                  float negative_slope, float* dz, float* carry, void* stream);
-/* the same with the gathered rows coming from a two-part table (dout2 / split as x2 / split of npi_segsum_ex); tpack is ONE
- * array indexed by the column id over both parts (the sharded GATConv: received hub rows + the rank's own rows) */
-int npi_gat_backward_fused_packed_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                                     int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* dout2,
-                                     int64_t split, const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t C,
-                                     const float* tpack, const float* a_src, float negative_slope, float* dz, float* carry,
-                                     void* stream);
-/* ... and for SEVERAL heads (H in {1, 2, 4, 8}; for H > 1: C in {32, 64, 128}, H C <= 256): tpack is [n_cols, H, 4]
- * (npi_gat_pack_targets over the N H flattened scalars), a_src [n_rows, H], dz [nnz_max, H]; every entry's H dots are reduced
- * inside the C / 4 lanes of their head, alpha of every (entry, head) is computed once, by the lane that owns the entry. */
 int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                                 int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* dout2, int64_t split,
-                                 const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C,
+                                 int64_t item_edges, int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* dout2,
+                                 int64_t split, const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C,
                                  const float* tpack, const float* a_src, float negative_slope, float* dz, float* carry,
                                  void* stream);
 int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
@@ -377,15 +363,15 @@ int npi_gat_edge_grad_ex(const int32_t* rowptr, const int32_t* col, const int32_
                          const float* dout, int64_t ldd, int64_t H, int64_t C,
                          const float* a_dst, const float* a_src, const float* m, const float* s,
                          const float* D, float negative_slope, int swap, float* dz, float* alpha_out, void* stream);
-/* Round 3, item-parallel forms (npi_gnn_amd/csrc/segscan.hip): the ENTRIES are streamed -- a wavefront per 64 / 256
- * consecutive entries, a segmented scan keyed by the CSR's rowidx, cut rows folded by a second launch in a fixed order --
- * instead of a lane group walking each row.  Same results (sums in another association: deterministic, <= 1 ulp-level
- * differences from the row-walking kernels), 5-10 x the throughput on the skewed graphs.
- *   npi_seg_rowsum_ex        = npi_seg_rowsum, with rowidx (row of every entry) in place of item_row
- *   npi_gat_softmax_stats_ex = npi_gat_softmax_stats; additionally writes the leaky_relu score e_p of every entry to
- *                              scores [nnz_max, H] (may be NULL), which npi_gat_aggregate_scores reads back
+/* Per-row reductions of per-ENTRY scalars (npi_gnn_amd/csrc/segscan.hip): the entries are streamed -- a wavefront per 64 / 256
+ * consecutive entries, a segmented scan keyed by the CSR's rowidx, cut rows folded by a second launch in a fixed order
+ * (deterministic, no atomics).  These calls keep no item state: they take no item_row and chunk the stream per call.
+ *   npi_seg_rowsum_ex        out[r, h] = sum over the entries p of row r of vals[map ? map[p] : p, h]; rows without an entry: 0
+ *   npi_gat_softmax_stats_ex (m, s)[r, h] = (max, sum exp(. - max)) of e_p = leaky_relu(a_row[r] + a_col[col p]) over row r (an empty
+ *                              row: m = 0, s = 0); additionally writes e_p of every entry to scores [nnz_max, H] (may be NULL),
+ *                              which npi_gat_aggregate_scores reads back
  *   npi_gat_aggregate_scores = npi_gat_aggregate_ex(by_source = 0), one head, with the per-entry scores of the statistics
- *                              pass instead of two gathered per-node scalars per entry; alpha_out as there (may be NULL);
+ *                              pass instead of two gathered per-node scalars per entry;
  *                              relu != 0: max(., 0) in the row epilogue (the F.relu behind the layer)
  *   npi_gat_rowdot_colsum    = npi_gat_rowdot AND the column sums of `a` (GATConv's bias gradient; colsum may be NULL) in
  *                              one pass over a and b; needs 16-byte aligned rows, C % 4 == 0, H C <= 1024
@@ -397,10 +383,10 @@ int npi_seg_rowsum_ex(const int32_t* rowptr, const int32_t* rowidx, const float*
 int npi_gat_softmax_stats_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const float* a_row,
                              const float* a_col, int64_t N, int64_t nnz_max, int64_t H, float negative_slope, float* m,
                              float* s, float* scores, float* workspace, int64_t workspace_elems, void* stream);
-int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                              int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                              float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
-                             const float* bias, int relu, float* alpha_out, float* carry, void* stream);
+                             const float* bias, int relu, float* carry, void* stream);
 int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C);
 int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                           int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* workspace,
@@ -412,9 +398,6 @@ int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t l
 int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                                int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* a_masked, int64_t ldm,
                                float* workspace, int64_t workspace_elems, void* stream);
-int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
-                   int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
-                   void* stream);
 int npi_entry_transpose_map(const int32_t* src_eid, const int32_t* src_rowidx, const int32_t* src_rowptr,
                             const int32_t* dst_rowptr, const int32_t* pos_dst_of_edge, int64_t N,
                             int64_t nnz_max, int32_t* map, void* stream);
@@ -474,13 +457,15 @@ int64_t npi_filter_adj_newpos_offset(int64_t E);   /* npi_filter_adj_ex: workspa
 /* The by-target CSR of the POOLED graph from the CSR of its parent, without a sort: row perm[r'] of the parent with the
  * entries whose source survived (remap[col] >= 0), in the parent's order, self loop last; eid through newpos
  * (npi_filter_adj_ex's workspace tail).  Bit-identical to npi_csr_build on the filtered edge list.  nnz_max_out = capacity
- * of col_o / eid_o / rowidx_o (>= the surviving entries; E_in + n_out is what a fresh build would use); workspace int32
- * [npi_csr_filter_workspace_elems(n_out)]; n_out <= npi_csr_filter_max_rows(). */
+ * of col_o / eid_o / rowidx_o (>= the surviving entries; E_in + n_out is what a fresh build would use); item_edges: the item
+ * size of the NEW CSR (independent of the parent's); workspace int32 [npi_csr_filter_workspace_elems(n_out)];
+ * n_out <= npi_csr_filter_max_rows(). */
 int64_t npi_csr_filter_max_rows(void);
 int64_t npi_csr_filter_workspace_elems(int64_t n_out);
 int npi_csr_filter(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const int32_t* perm, const int32_t* remap,
                    const int32_t* newpos, int64_t n_out, int64_t nnz_max_out, int32_t* rowptr_o, int32_t* col_o,
-                   int32_t* eid_o, int32_t* rowidx_o, int32_t* item_row_o, int32_t* status_o, int32_t* workspace, void* stream);
+                   int32_t* eid_o, int32_t* rowidx_o, int32_t* item_row_o, int64_t item_edges, int32_t* status_o, int32_t* workspace,
+                   void* stream);
 int npi_readout_max_mean(const float* x, int64_t ldx, const int32_t* graph_ptr, int64_t B, int64_t F,
                          float* out, void* stream);
 
@@ -523,16 +508,19 @@ int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_p
  * pairs: target first, then in that same order, each in both directions ((rna, protein) first).
  *   npi_subgraph_sizes   : node_off[B+1], pair_off[B+1] (exclusive prefix sums; directed edges = 2 pairs);
  *                          workspace int32[2B]; node_off[B] = pair_off[B] = -1 when the batch exceeds 2^31 - 1 rows
- *   npi_subgraph_fill    : node_id[n], batch[n] (int64), edge_src/edge_dst[2 * pairs] (int64, batch-global ids)
- *   npi_subgraph_features: x[row] = [row is a target ? 0 : 1 | feat[node_id[row]][0..Ff)]
+ *   npi_subgraph_fill    : node_id[n], batch[n] (int64), edge_src/edge_dst[2 * pairs] (int64, batch-global ids).  n_nodes /
+ *                          n_pairs: the totals the CALLER sized those arrays with; when they are not node_off[B] / pair_off[B]
+ *                          (totals computed for other keys) nothing is written and bit 2 (value 4) of status[0] is raised --
+ *                          an error the host reads at its next device read instead of an out-of-bounds write (status may be NULL)
+ *   npi_subgraph_features: x[row] = [row is a target ? 0 : 1 | feat[node_id[row]][0..Ff)]; writes nothing unless node_off[B] == n
  * ------------------------------------------------------------------------------------------ */
 int npi_subgraph_sizes(const int32_t* ptr, const int32_t* nbr, const uint8_t* ok, const int32_t* keys, int64_t B,
                        int32_t* node_off, int32_t* pair_off, int32_t* workspace, void* stream);
 int npi_subgraph_fill(const int32_t* ptr, const int32_t* nbr, const uint8_t* ok, const int32_t* keys, int64_t B,
                       const int32_t* node_off, const int32_t* pair_off, int32_t* node_id, int64_t* batch,
-                      int64_t* edge_src, int64_t* edge_dst, void* stream);
+                      int64_t* edge_src, int64_t* edge_dst, int64_t n_nodes, int64_t n_pairs, int32_t* status, void* stream);
 int npi_subgraph_features(const float* feat, int64_t ldf, int64_t Ff, const int32_t* node_id, const int64_t* batch,
-                          const int32_t* node_off, int64_t n, float* x, int64_t ldx, void* stream);
+                          const int32_t* node_off, int64_t B, int64_t n, float* x, int64_t ldx, void* stream);
 
 /* Evaluation loop (reference src/methods.py:87-105 compares one element per Python
  * iteration, one device sync each).  counts[4] += [TP, FN, TN, FP] for pred = first arg-max of scores[i, 0..C):

@@ -30,13 +30,13 @@ PROTOTYPES = {
     "npi_csr_workspace_bytes": (_I, [_I, _I]),
     "npi_item_edges": (_I, [_I]),
     "npi_small_graph_entries": (_I, [_I]),
-    "npi_num_items": (_I, [_I]),
-    "npi_csr_build": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "npi_csr_build_ex": (c_int, [_P, _P, _I, _I, _I, c_int, _I, c_int, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "npi_num_items": (_I, [_I, _I]),
+    "npi_csr_build": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "npi_csr_build_ex": (c_int, [_P, _P, _I, _I, _I, c_int, _I, c_int, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "npi_edge_positions": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
-    "npi_segsum_carry_elems": (_I, [_I, _I]),
-    "npi_segsum": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
-    "npi_segsum_ex": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
+    "npi_segsum_carry_elems": (_I, [_I, _I, _I]),
+    "npi_segsum": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
+    "npi_segsum_ex": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
     "npi_row_weight_sum": (c_int, [_P, _P, _I, _P, _P]),
     "npi_gcn_norm": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_row_inv_count": (c_int, [_P, _I, _P, _P]),
@@ -65,29 +65,22 @@ PROTOTYPES = {
     "npi_gat_rank2_tail": (c_int, [_P, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     "npi_linear_bwd_weight_ex": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, c_int, c_int, _P]),
     "npi_gat_scores": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
-    "npi_gat_heavy_workspace_elems": (_I, [_I, _I]),
-    "npi_gat_softmax_stats": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _I, _P]),
-    "npi_gat_aggregate": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
+    "npi_gat_aggregate": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                   _P, _P, _P, _P, _P, _P, _P, _P]),
-    "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
+    "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
-    "npi_gat_backward_fused": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "npi_gat_pack_targets": (c_int, [_P, _P, _P, _P, _I, _P, _P]),
-    "npi_gat_backward_fused_packed": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, _P, _P]),
-    "npi_gat_backward_fused_packed_ex": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, _P,
-                                                 _P]),
-    "npi_gat_backward_fused_heads": (c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P, _P,
-                                             _P]),
+    "npi_gat_backward_fused_heads": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P,
+                                             _P, _P]),
     "npi_gat_rank1_add": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "npi_gat_edge_grad": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "npi_gat_edge_grad_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float,
                                      c_int, _P, _P, _P]),
-    "npi_seg_rowsum": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_seg_scan_workspace_elems": (_I, [_I, _I]),
     "npi_seg_rowsum_ex": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_gat_softmax_stats_ex": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
-    "npi_gat_aggregate_scores": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "npi_gat_aggregate_scores": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, c_int, _P, _P]),
     "npi_gat_rowdot_colsum_workspace_elems": (_I, [_I, _I, _I]),
     "npi_gat_rowdot_colsum": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "npi_gat_rowdot_colsum_relu": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
@@ -108,7 +101,7 @@ PROTOTYPES = {
     "npi_filter_adj_newpos_offset": (_I, [_I]),
     "npi_csr_filter_max_rows": (_I, []),
     "npi_csr_filter_workspace_elems": (_I, [_I]),
-    "npi_csr_filter": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "npi_csr_filter": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "npi_readout_max_mean": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_topk_gather_bwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "npi_topk_gather_bwd_ex": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
@@ -123,8 +116,8 @@ PROTOTYPES = {
     "npi_mlp_head_bwd": (c_int, [_I, _I, _I, _I, _I, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  _P, _I, _P]),
     "npi_subgraph_sizes": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "npi_subgraph_fill": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "npi_subgraph_features": (c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "npi_subgraph_fill": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "npi_subgraph_features": (c_int, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P]),
 }
 
 _lib = None

@@ -394,7 +394,7 @@ __global__ void topk_take_kernel(const uint32_t* __restrict__ graph_of, const in
 using namespace npi;
 
 extern "C" const char* npi_last_error(void) { return npi::g_err; }
-extern "C" int npi_abi_version(void) { return 1; }
+extern "C" int npi_abi_version(void) { return 2; }
 
 extern "C" int64_t npi_csr_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return -1;
@@ -408,25 +408,27 @@ extern "C" int64_t npi_small_graph_entries(int64_t n) {
     return prev;
 }
 
-extern "C" int64_t npi_num_items(int64_t nnz_max) {
-    return nnz_max <= 0 ? 0 : ceil_div(nnz_max, (int64_t)npi::item_edges_for(nnz_max));
+extern "C" int64_t npi_num_items(int64_t nnz_max, int64_t item_edges) {
+    if (!npi::item_edges_ok(item_edges)) return -1;
+    return npi::num_items_of(nnz_max, item_edges);
 }
 
 extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
                              int add_self_loops, int32_t* rowptr, int32_t* col, int32_t* eid,
-                             int32_t* rowidx, int32_t* item_row, int32_t* status,
+                             int32_t* rowidx, int32_t* item_row, int64_t item_edges, int32_t* status,
                              void* workspace, int64_t workspace_bytes, void* stream_) {
     return npi_csr_build_ex(key_nodes, val_nodes, E, N, N, add_self_loops, 0, 1, rowptr, col, eid, rowidx,
-                            item_row, status, workspace, workspace_bytes, stream_);
+                            item_row, item_edges, status, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
                                 int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int drop_equal,
                                 int32_t* rowptr, int32_t* col, int32_t* eid,
-                                int32_t* rowidx, int32_t* item_row, int32_t* status,
+                                int32_t* rowidx, int32_t* item_row, int64_t item_edges, int32_t* status,
                                 void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(E >= 0 && N >= 0 && n_cols >= 0, "npi_csr_build: negative size");
+    NPI_REQUIRE(item_edges_ok(item_edges), "npi_csr_build: item_edges must be 64 or NPI_ITEM_EDGES (npi_item_edges gives the hint)");
     NPI_REQUIRE(E + N + 1 < (int64_t)0x7fffffff, "npi_csr_build: E + N does not fit int32");
     NPI_REQUIRE(n_cols < (int64_t)0x7fffffff && loop_col_offset >= 0 && loop_col_offset + N <= (n_cols > N ? n_cols : N),
                 "npi_csr_build: column range does not fit");
@@ -456,8 +458,8 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
     fill_csr_kernel<<<entry_blocks + (unsigned)ceil_div(N + 1, 256), 256, 0, stream>>>(
         keys_a, vals_a, val_nodes, E, N, add_self_loops, (int32_t)loop_col_offset, entry_blocks, rowptr, col, eid, rowidx);
     const int64_t nnz_max = E + (add_self_loops ? N : 0);
-    int64_t n_items = npi_num_items(nnz_max);
-    item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, item_edges_for(nnz_max), item_row);
+    int64_t n_items = num_items_of(nnz_max, item_edges);
+    item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr, N, n_items, (int)item_edges, item_row);
     return check_launch("npi_csr_build");
 }
 
@@ -623,9 +625,10 @@ extern "C" int64_t npi_csr_filter_workspace_elems(int64_t n_out) { return n_out 
 extern "C" int npi_csr_filter(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const int32_t* perm,
                               const int32_t* remap, const int32_t* newpos, int64_t n_out, int64_t nnz_max_out,
                               int32_t* rowptr_o, int32_t* col_o, int32_t* eid_o, int32_t* rowidx_o, int32_t* item_row_o,
-                              int32_t* status_o, int32_t* workspace, void* stream_) {
+                              int64_t item_edges, int32_t* status_o, int32_t* workspace, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(n_out >= 0 && n_out <= npi_csr_filter_max_rows() && nnz_max_out >= n_out, "npi_csr_filter: bad size");
+    NPI_REQUIRE(item_edges_ok(item_edges), "npi_csr_filter: item_edges must be 64 or NPI_ITEM_EDGES");
     NPI_REQUIRE(rowptr_o && item_row_o && status_o && (n_out == 0 || (rowptr && col && eid && perm && remap && newpos && col_o &&
                 eid_o && rowidx_o && workspace)), "npi_csr_filter: null pointer");
     (void)hipMemsetAsync(status_o, 0, sizeof(int32_t), stream);            // ids were checked when the parent was built
@@ -639,8 +642,8 @@ extern "C" int npi_csr_filter(const int32_t* rowptr, const int32_t* col, const i
         csr_filter_fill_kernel<<<tiles, 256, 0, stream>>>(rowptr, col, eid, perm, remap, newpos, (int)n_out, cnt, tile_total,
                                                           rowptr_o, col_o, eid_o, rowidx_o);
     }
-    const int64_t n_items = npi_num_items(nnz_max_out);
-    item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr_o, n_out, n_items, item_edges_for(nnz_max_out), item_row_o);
+    const int64_t n_items = num_items_of(nnz_max_out, item_edges);
+    item_rows_kernel<<<(unsigned)ceil_div(n_items + 1, 256), 256, 0, stream>>>(rowptr_o, n_out, n_items, (int)item_edges, item_row_o);
     return check_launch("npi_csr_filter");
 }
 

@@ -4,10 +4,11 @@
 // GATConv is absent from the reference tree ("parity unpinned"); the formulas are the
 // published PyG 1.4.2 ones.
 //
-// alpha is never stored: every kernel recomputes it from four per-node, per-head scalars
-// (a_dst, a_src, row max m, row sum s), so the same numbers serve the by-target CSR (forward) and
-// the by-source CSR (backward) and no per-edge array has to be permuted between the two.
-// The weighted aggregation itself is segsum.hip's kernel in W_GAT_DST / W_GAT_SRC mode.
+// alpha is never stored: every kernel recomputes it from per-node, per-head scalars (a_dst, a_src, row max m, row sum s),
+// so the same numbers serve the by-target CSR (forward) and the by-source CSR (backward) and no per-edge array has to be
+// permuted between the two.  This file holds the per-node dot products, the by-target SDDMM (npi_gat_edge_grad, shapes the
+// fused backward does not cover), the attention-gradient reductions and the entry points of the weighted aggregations, which
+// are segsum.hip's kernel in its W_GAT_* modes; the per-row statistics and row sums live in segscan.hip.
 #include "segsum.h"
 
 namespace npi {
@@ -15,11 +16,6 @@ namespace npi {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
     return v;
 }
 __device__ __forceinline__ float lrelu_(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -273,292 +269,6 @@ colsum_blocks_kernel(const float* __restrict__ part, int nblocks, int Fw, float*
 
 static bool rows16(const void* p, int64_t ld, int64_t C) { return C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p % 16) == 0; }
 
-// ---- segment softmax statistics: m[i,h] = max_p e_p, s[i,h] = sum_p exp(e_p - m) -------------------
-constexpr int GAT_HEAVY = 4096;      // rows longer than this go to the workgroup-per-row kernel
-
-// LG lanes per row, WAVE / LG rows per wave: the typical row of these graphs has ~20 entries (an ncRNA with its
-// partners and its self loop), a third of a wavefront.  Rows much longer than the group (a protein) are then taken
-// by the whole wave, one after the other; rows above GAT_HEAVY belong to the segment kernel.
-template <int LG> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = LG / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
-}
-template <int LG> __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int off = LG / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
-    return v;
-}
-constexpr int GROUP_WIDE = 8;        // a row longer than GROUP_WIDE * LG entries is worth the whole wave
-
-static int row_group_lanes(int64_t nnz_max, int64_t N) {
-    const int64_t avg = nnz_max / (N > 0 ? N : 1);
-    return avg <= 12 ? 8 : avg <= 24 ? 16 : avg <= 48 ? 32 : 64;
-}
-
-// (max, sum of exp(. - max)) of row i, head hd, over entries [b, e) with lanes gl, gl + LG, ...
-template <int LG>
-__device__ __forceinline__ void softmax_row(const int32_t* __restrict__ col, const float* __restrict__ a_src, int H, int hd,
-                                            float ad, int b, int e, int gl, float slope, float& mx, float& sum) {
-    // the lane's first entry stays in a register: rows that fit the group (most of them) gather a_src once, not twice
-    const bool has0 = b + gl < e;
-    const float z0 = has0 ? lrelu_(ad + a_src[(int64_t)col[b + gl] * H + hd], slope) : -3.0e38f;
-    mx = z0;
-    for (int p = b + gl + LG; p < e; p += LG) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
-    mx = group_max<LG>(mx);
-    if (e == b) mx = 0.f;
-    sum = has0 ? expf(z0 - mx) : 0.f;
-    for (int p = b + gl + LG; p < e; p += LG) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
-    sum = group_sum<LG>(sum);
-}
-
-template <int LG>
-__global__ void __launch_bounds__(256)
-gat_softmax_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                        const float* __restrict__ a_dst, const float* __restrict__ a_src, int N, int H,
-                        float slope, float* __restrict__ m, float* __restrict__ s) {
-    constexpr int G = WAVE / LG;
-    const int lane = lane_id();
-    const int grp = lane / LG, gl = lane % LG;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
-    if (row0 >= N) return;
-    const int i = row0 + grp;
-    const bool have = i < N;
-    const int b = have ? rowptr[i] : 0, e = have ? rowptr[i + 1] : 0;
-    const bool heavy = e - b > GAT_HEAVY;
-    const bool wide = LG < WAVE && !heavy && e - b > GROUP_WIDE * LG;
-    if (have && !heavy && !wide) {
-        for (int hd = 0; hd < H; ++hd) {
-            float mx, sum;
-            softmax_row<LG>(col, a_src, H, hd, a_dst[(int64_t)i * H + hd], b, e, gl, slope, mx, sum);
-            if (gl == 0) {
-                m[(int64_t)i * H + hd] = mx;
-                s[(int64_t)i * H + hd] = sum;
-            }
-        }
-    }
-    if (LG < WAVE) {
-        uint64_t todo = __ballot(wide && gl == 0);
-        while (todo) {                                     // wave-uniform
-            const int from = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const int wb = __shfl(b, from, WAVE), we = __shfl(e, from, WAVE), wi = __shfl(i, from, WAVE);
-            for (int hd = 0; hd < H; ++hd) {
-                float mx, sum;
-                softmax_row<WAVE>(col, a_src, H, hd, a_dst[(int64_t)wi * H + hd], wb, we, lane, slope, mx, sum);
-                if (lane == 0) {
-                    m[(int64_t)wi * H + hd] = mx;
-                    s[(int64_t)wi * H + hd] = sum;
-                }
-            }
-        }
-    }
-}
-
-// Heavy rows (hub proteins: 400k entries at C4, 2M at C5) are cut into SEGMENTS of HEAVY_SEG_ITEMS items, one
-// 1024-thread workgroup per segment, so a hub row is spread over dozens of CUs instead of serialising on one.
-// There is one workgroup per item; it takes (a) the first segment of the heavy row that STARTS in its item (at
-// most one: a heavy row is longer than an item) and (b) the continuing segment that starts at its first entry, if
-// the row passing through is heavy and (item - first_item(row)) is a multiple of HEAVY_SEG_ITEMS.  A segment's
-// partial goes to workspace slot 2 item + (0: first segment, 1: continuing); the workgroup that finishes LAST
-// (per-row counter, indexed by the row's first item) folds the partials in segment order -- a fixed order, so
-// the result does not depend on which workgroup that is.
-constexpr int HEAVY_THREADS = 1024;
-constexpr int HEAVY_WAVES = HEAVY_THREADS / WAVE;
-constexpr int HEAVY_SEG_ITEMS = 64;
-constexpr int HEAVY_GRID = 2048;     // workgroups walking the segment list (8 per CU)
-
-struct HeavySeg {
-    int row, b, e;      // row and entry range of the segment
-    int fi, k, nseg;    // first item of the row, index of this segment, segments of the row
-};
-
-// segments this workgroup (item) owns: returns a bit mask (1: first segment in seg[0], 2: continuing in seg[1])
-__device__ __forceinline__ int heavy_segments(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
-                                              int N, int n_items, int item, int IE, HeavySeg (&seg)[2]) {
-    const int nnz = rowptr[N];
-    const int64_t k0 = (int64_t)item * IE, k1 = k0 + IE;
-    int mask = 0;
-    if (k0 >= nnz) return 0;
-    const int span = HEAVY_SEG_ITEMS * IE;
-    // (b) the row that contains entry k0 and started before it
-    const int r0 = item_row[item];
-    const int b0 = rowptr[r0];
-    if (b0 < k0) {
-        const int e0 = rowptr[r0 + 1];
-        if (e0 - b0 > GAT_HEAVY) {
-            const int fi = b0 / IE;
-            if ((item - fi) % HEAVY_SEG_ITEMS == 0) {
-                seg[1].row = r0; seg[1].b = (int)k0; seg[1].e = (int)min((int64_t)e0, k0 + span);
-                seg[1].fi = fi; seg[1].k = (item - fi) / HEAVY_SEG_ITEMS;
-                seg[1].nseg = ((e0 - 1) / IE - fi) / HEAVY_SEG_ITEMS + 1;
-                mask |= 2;
-            }
-        }
-    }
-    // (a) the row that starts in this item and reaches past its end
-    if (k1 < nnz && item + 1 <= n_items) {
-        const int r1 = item_row[item + 1];                 // row holding entry k1
-        const int b1 = rowptr[r1];
-        if (b1 >= k0 && b1 < k1) {
-            const int e1 = rowptr[r1 + 1];
-            if (e1 - b1 > GAT_HEAVY) {
-                seg[0].row = r1; seg[0].b = b1; seg[0].e = (int)min((int64_t)e1, k0 + span);
-                seg[0].fi = item; seg[0].k = 0;
-                seg[0].nseg = ((e1 - 1) / IE - item) / HEAVY_SEG_ITEMS + 1;
-                mask |= 1;
-            }
-        }
-    }
-    return mask;
-}
-__device__ __forceinline__ int heavy_slot(const HeavySeg& g, int k) {          // workspace slot of segment k of g's row
-    return k == 0 ? 2 * g.fi : 2 * (g.fi + k * HEAVY_SEG_ITEMS) + 1;
-}
-
-// The heavy segments of a CSR are few (a row needs > GAT_HEAVY entries): a scout launch -- one THREAD per item --
-// lists them as item * 2 + q, and the 1024-thread kernels run over that list instead of over every item
-// (82 k mostly idle workgroups at C4 before: 0.3-0.5 ms per launch of pure dispatch).  The order of the list is
-// whatever the atomics make it; it does not matter: every segment writes its own slot and the fold order is fixed.
-__host__ __device__ inline int64_t heavy_list_capacity(int64_t nnz_max) {
-    const int64_t ie = item_edges_for(nnz_max);
-    const int64_t items = (nnz_max + ie - 1) / ie;
-    const int64_t bound = nnz_max / (HEAVY_SEG_ITEMS * ie) + 2 * (nnz_max / GAT_HEAVY) + 4;   // sum over heavy rows of (len / span + 2)
-    return bound < 2 * items ? bound : 2 * items;
-}
-__global__ void __launch_bounds__(256)
-heavy_list_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row, int N, int n_items, int item_edges,
-                  int capacity, int* __restrict__ cnt, int* __restrict__ count, int* __restrict__ list) {
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= n_items) return;
-    cnt[item] = 0;                                         // the per-row arrival counters (indexed by first item)
-    HeavySeg seg[2];
-    const int mask = heavy_segments(rowptr, item_row, N, n_items, item, item_edges, seg);
-    for (int q = 0; q < 2; ++q) {
-        if (!(mask & (1 << q))) continue;
-        const int at = atomicAdd(count, 1);
-        if (at < capacity) list[at] = item * 2 + q;
-    }
-}
-// the segment workgroup `w` of the list owns (workgroup-uniform); false: nothing to do
-__device__ __forceinline__ bool heavy_take(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row, int N,
-                                           int n_items, int item_edges, const int* __restrict__ count,
-                                           const int* __restrict__ list, int w, HeavySeg& g) {
-    if (w >= *count) return false;
-    const int code = list[w];
-    HeavySeg seg[2];
-    const int mask = heavy_segments(rowptr, item_row, N, n_items, code >> 1, item_edges, seg);
-    if (!(mask & (1 << (code & 1)))) return false;         // cannot happen: the scout saw the same CSR
-    g = seg[code & 1];
-    return true;
-}
-
-// fixed-order sum / max of one value per wave
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
-    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < HEAVY_WAVES; ++w) s += red[w];
-    __syncthreads();
-    return s;
-}
-__device__ __forceinline__ float block_max(float v, float* red) {
-    v = wave_max(v);
-    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = red[0];
-#pragma unroll
-    for (int w = 1; w < HEAVY_WAVES; ++w) s = fmaxf(s, red[w]);
-    __syncthreads();
-    return s;
-}
-// partials written by OTHER workgroups are read past this CU's L1
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// thread 0 publishes the segment's partial and learns whether its workgroup is the last one of the row
-__device__ __forceinline__ bool heavy_arrive(int* cnt, const HeavySeg& g, int* flag) {
-    if (threadIdx.x == 0) {
-        __threadfence();                                   // the partial is visible before the count
-        *flag = (atomicAdd(cnt + g.fi, 1) == g.nseg - 1);
-        __threadfence();
-    }
-    __syncthreads();
-    const bool last = *flag != 0;
-    __syncthreads();
-    return last;
-}
-
-// part[slot][H][2] = (max, sum of exp(. - max)) of a segment; the last workgroup merges them like an online softmax
-__global__ void __launch_bounds__(HEAVY_THREADS)
-gat_softmax_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                         const int32_t* __restrict__ item_row, const float* __restrict__ a_dst,
-                         const float* __restrict__ a_src, int N, int n_items, int H, float slope,
-                         float* __restrict__ m, float* __restrict__ s, int item_edges,
-                         float* __restrict__ part, int* __restrict__ cnt, const int* __restrict__ count,
-                         const int* __restrict__ list) {
-    __shared__ float red[HEAVY_WAVES];
-    __shared__ int flag;
-    const int t = threadIdx.x;
-    HeavySeg g;
-    for (int w = blockIdx.x; heavy_take(rowptr, item_row, N, n_items, item_edges, count, list, w, g); w += gridDim.x) {   // workgroup-uniform
-        const int i = g.row;
-        float* __restrict__ mine = part + (int64_t)heavy_slot(g, g.k) * H * 2;
-        for (int hd = 0; hd < H; ++hd) {
-            const float ad = a_dst[(int64_t)i * H + hd];
-            float mx = -3.0e38f;
-            for (int p = g.b + t; p < g.e; p += HEAVY_THREADS) mx = fmaxf(mx, lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope));
-            mx = block_max(mx, red);
-            float sum = 0.f;
-            for (int p = g.b + t; p < g.e; p += HEAVY_THREADS) sum += expf(lrelu_(ad + a_src[(int64_t)col[p] * H + hd], slope) - mx);
-            sum = block_sum(sum, red);
-            if (t == 0) { mine[hd * 2] = mx; mine[hd * 2 + 1] = sum; }
-        }
-        if (heavy_arrive(cnt, g, &flag) && t < H) {
-            float M = -3.0e38f;
-            for (int k = 0; k < g.nseg; ++k) M = fmaxf(M, ld_agent(part + ((int64_t)heavy_slot(g, k) * H + t) * 2));
-            float S = 0.f;
-            for (int k = 0; k < g.nseg; ++k) {
-                const float* pk = part + ((int64_t)heavy_slot(g, k) * H + t) * 2;
-                S += ld_agent(pk + 1) * expf(ld_agent(pk) - M);
-            }
-            m[(int64_t)i * H + t] = M;
-            s[(int64_t)i * H + t] = S;
-        }
-    }
-}
-
-// row sums of per-entry scalars for the heavy rows (see seg_rowsum_scalar_kernel below for the rest)
-__global__ void __launch_bounds__(HEAVY_THREADS)
-seg_rowsum_heavy_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ item_row,
-                        const float* __restrict__ vals, const int32_t* __restrict__ map, int N, int n_items, int H,
-                        float* __restrict__ out, int item_edges, float* __restrict__ part, int* __restrict__ cnt,
-                        const int* __restrict__ count, const int* __restrict__ list) {
-    __shared__ float red[HEAVY_WAVES];
-    __shared__ int flag;
-    const int t = threadIdx.x;
-    HeavySeg g;
-    for (int w = blockIdx.x; heavy_take(rowptr, item_row, N, n_items, item_edges, count, list, w, g); w += gridDim.x) {
-        float* __restrict__ mine = part + (int64_t)heavy_slot(g, g.k) * H;
-        for (int hd = 0; hd < H; ++hd) {
-            float sum = 0.f;
-            for (int p = g.b + t; p < g.e; p += HEAVY_THREADS) {
-                const int64_t idx = map ? map[p] : p;
-                sum += vals[idx * H + hd];
-            }
-            sum = block_sum(sum, red);
-            if (t == 0) mine[hd] = sum;
-        }
-        if (heavy_arrive(cnt, g, &flag) && t < H) {
-            float S = 0.f;
-            for (int k = 0; k < g.nseg; ++k) S += ld_agent(part + (int64_t)heavy_slot(g, k) * H + t);
-            out[(int64_t)g.row * H + t] = S;
-        }
-    }
-}
-
 // ---- backward: per-entry score gradient over the by-target CSR ------------------------------------------
 //   dalpha_p = <dout_i[h], hfeat_j[h]>;  de_p = alpha_p (dalpha_p - D_i);  dz_p = de_p * lrelu'(z_p)
 // one wave per 256-entry item; dout_i is reloaded when the row changes, hfeat_j gathered per entry
@@ -707,53 +417,6 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
     }
 }
 
-// out[r,h] = sum over the entries p of row r of vals[idx(p), h], idx = map ? map[p] : p; LG lanes per row like
-// gat_softmax_rows_kernel
-template <int LG>
-__device__ __forceinline__ float rowsum_row(const float* __restrict__ vals, const int32_t* __restrict__ map, int H, int hd,
-                                            int b, int e, int gl) {
-    float sum = 0.f;
-    for (int p = b + gl; p < e; p += LG) {
-        const int64_t q = map ? map[p] : p;
-        sum += vals[q * H + hd];
-    }
-    return group_sum<LG>(sum);
-}
-
-template <int LG>
-__global__ void __launch_bounds__(256)
-seg_rowsum_scalar_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals,
-                         const int32_t* __restrict__ map, int N, int H, float* __restrict__ out, int skip_heavy) {
-    constexpr int G = WAVE / LG;
-    const int lane = lane_id();
-    const int grp = lane / LG, gl = lane % LG;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
-    if (row0 >= N) return;
-    const int r = row0 + grp;
-    const bool have = r < N;
-    const int b = have ? rowptr[r] : 0, e = have ? rowptr[r + 1] : 0;
-    const bool heavy = skip_heavy && e - b > GAT_HEAVY;    // seg_rowsum_heavy_kernel owns it
-    const bool wide = LG < WAVE && !heavy && e - b > GROUP_WIDE * LG;
-    if (have && !heavy && !wide) {
-        for (int hd = 0; hd < H; ++hd) {
-            const float sum = rowsum_row<LG>(vals, map, H, hd, b, e, gl);
-            if (gl == 0) out[(int64_t)r * H + hd] = sum;
-        }
-    }
-    if (LG < WAVE) {
-        uint64_t todo = __ballot(wide && gl == 0);
-        while (todo) {
-            const int from = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const int wb = __shfl(b, from, WAVE), we = __shfl(e, from, WAVE), wr = __shfl(r, from, WAVE);
-            for (int hd = 0; hd < H; ++hd) {
-                const float sum = rowsum_row<WAVE>(vals, map, H, hd, wb, we, lane);
-                if (lane == 0) out[(int64_t)wr * H + hd] = sum;
-            }
-        }
-    }
-}
-
 // map[q] = position in the by-target CSR of by-source entry q (same directed edge; loops map to loops)
 __global__ void entry_transpose_map_kernel(const int32_t* __restrict__ src_eid, const int32_t* __restrict__ src_rowidx,
                                            const int32_t* __restrict__ src_rowptr, const int32_t* __restrict__ dst_rowptr,
@@ -832,28 +495,6 @@ gat_rank1_add_kernel(float* __restrict__ dh, int64_t ld, const float* __restrict
 
 using namespace npi;
 
-extern "C" int npi_gat_backward_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                                      int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* hfeat, int64_t ldh,
-                                      float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src, const float* D,
-                                      float slope, const float* alpha, const int32_t* alpha_map, float* dz, float* carry,
-                                      void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_backward_fused: needs one head of <= 256 channels, C % 4 == 0");
-    if (N == 0) return NPI_OK;
-    NPI_REQUIRE(rowptr && col && rowidx && item_row && dout && hfeat && out && a_dst && a_src && D && alpha && alpha_map && dz && carry,
-                "npi_gat_backward_fused: null pointer");
-    NPI_REQUIRE(ldd >= C && ldh >= C && ldo >= C && ldh % 4 == 0 && ((uintptr_t)hfeat % 16) == 0,
-                "npi_gat_backward_fused: leading dimension / alignment");
-    SegParams P{};
-    P.rowptr = rowptr; P.col = col; P.item_row = item_row;
-    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
-    P.x = dout; P.ldx = ldd; P.out = out; P.ldo = ldo; P.F = (int)C;
-    P.carry = carry; P.w = alpha; P.wmap = alpha_map; P.bias = nullptr;
-    P.H = 1; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.m = a_dst; P.s = a_dst; P.slope = slope;   // m, s unused in this mode
-    P.hrow = hfeat; P.ldh = ldh; P.Dt = D; P.rowidx = rowidx; P.dz_out = dz;
-    return segsum_run(P, W_GAT_SRC_FUSED, 0, nnz_max, NPI_F32, stream);
-}
-
 __global__ void __launch_bounds__(256)
 gat_pack_targets_kernel(const float* __restrict__ a_dst, const float* __restrict__ m, const float* __restrict__ s,
                         const float* __restrict__ D, int N, float4* __restrict__ t) {
@@ -871,43 +512,26 @@ extern "C" int npi_gat_pack_targets(const float* a_dst, const float* m, const fl
     return check_launch("npi_gat_pack_targets");
 }
 
-extern "C" int npi_gat_backward_fused_packed(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
-                                             const int32_t* item_row, int64_t N, int64_t nnz_max, const float* dout, int64_t ldd,
-                                             const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t C,
-                                             const float* tpack, const float* a_src, float slope, float* dz, float* carry,
-                                             void* stream_) {
-    return npi_gat_backward_fused_packed_ex(rowptr, col, rowidx, item_row, N, nnz_max, dout, ldd, nullptr, 0, hfeat, ldh, out, ldo,
-                                            C, tpack, a_src, slope, dz, carry, stream_);
-}
-
-extern "C" int npi_gat_backward_fused_packed_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
-                                                const int32_t* item_row, int64_t N, int64_t nnz_max, const float* dout,
-                                                int64_t ldd, const float* dout2, int64_t split, const float* hfeat, int64_t ldh,
-                                                float* out, int64_t ldo, int64_t C, const float* tpack, const float* a_src,
-                                                float slope, float* dz, float* carry, void* stream_) {
-    return npi_gat_backward_fused_heads(rowptr, col, rowidx, item_row, N, nnz_max, dout, ldd, dout2, split, hfeat, ldh, out, ldo, 1, C,
-                                        tpack, a_src, slope, dz, carry, stream_);
-}
-
 extern "C" int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
-                                            const int32_t* item_row, int64_t N, int64_t nnz_max, const float* dout,
+                                            const int32_t* item_row, int64_t item_edges, int64_t N, int64_t nnz_max, const float* dout,
                                             int64_t ldd, const float* dout2, int64_t split, const float* hfeat, int64_t ldh,
                                             float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack, const float* a_src,
                                             float slope, float* dz, float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t F = H * C;
-    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C % 4 == 0 && F <= 256, "npi_gat_backward_fused: needs heads * out_channels <= 256, out_channels % 4 == 0");
+    NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C % 4 == 0 && F <= 256, "npi_gat_backward_fused_heads: needs heads * out_channels <= 256, out_channels % 4 == 0");
     NPI_REQUIRE(H == 1 || ((H == 2 || H == 4 || H == 8) && C >= 32 && (C & (C - 1)) == 0),
                 "npi_gat_backward_fused_heads: several heads need 2 / 4 / 8 heads of 32 / 64 / 128 channels");
-    NPI_REQUIRE(dout2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_backward_fused_packed_ex: bad split");
+    NPI_REQUIRE(dout2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_backward_fused_heads: bad split");
+    NPI_REQUIRE(item_edges_ok(item_edges), "npi_gat_backward_fused_heads: item_edges must be 64 or NPI_ITEM_EDGES (the value the CSR was built with)");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && col && rowidx && item_row && dout && hfeat && out && tpack && a_src && dz && carry,
-                "npi_gat_backward_fused_packed: null pointer");
+                "npi_gat_backward_fused_heads: null pointer");
     NPI_REQUIRE(ldd >= F && ldh >= F && ldo >= F && ldh % 4 == 0 && ((uintptr_t)hfeat % 16) == 0 && ((uintptr_t)tpack % 16) == 0,
-                "npi_gat_backward_fused_packed: leading dimension / alignment");
+                "npi_gat_backward_fused_heads: leading dimension / alignment");
     SegParams P{};
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
-    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
+    P.N = (int)N; P.item = (int)item_edges;
     P.x = dout; P.ldx = ldd; P.out = out; P.ldo = ldo; P.F = (int)F;
     P.x2 = dout2; P.split = (int)split;              // rows gathered from a two-part table (the sharded layers), as npi_segsum_ex
     P.carry = carry; P.bias = nullptr;
@@ -1002,59 +626,18 @@ extern "C" int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const flo
     return check_launch("npi_gat_rowdot_colsum");
 }
 
-extern "C" int64_t npi_gat_heavy_workspace_elems(int64_t nnz_max, int64_t H) {
-    const int64_t items = npi_num_items(nnz_max);
-    // segment partials (2 slots x 2 values per item and head), row counters, segment count, segment list
-    return 4 * items * (H > 0 ? H : 1) + items + 1 + heavy_list_capacity(nnz_max) + 64;
-}
-
-extern "C" int npi_gat_softmax_stats(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
-                                     const float* a_dst, const float* a_src, int64_t N, int64_t nnz_max, int64_t H,
-                                     float slope, float* m, float* s, float* workspace, int64_t workspace_elems,
-                                     void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && H > 0 && H <= HEAVY_THREADS && nnz_max >= 0, "npi_gat_softmax_stats: bad size");
-    if (N == 0) return NPI_OK;
-    NPI_REQUIRE(rowptr && item_row && a_dst && a_src && m && s && workspace, "npi_gat_softmax_stats: null pointer");
-    if (workspace_elems < npi_gat_heavy_workspace_elems(nnz_max, H)) {
-        set_error("npi_gat_softmax_stats: workspace too small");
-        return NPI_ERR_WORKSPACE;
-    }
-    switch (row_group_lanes(nnz_max, N)) {
-#define NPI_ROWS(LG) gat_softmax_rows_kernel<LG><<<(unsigned)ceil_div(N, 4 * (WAVE / LG)), 256, 0, stream>>>(rowptr, col, a_dst, a_src, (int)N, (int)H, slope, m, s)
-        case 8: NPI_ROWS(8); break;
-        case 16: NPI_ROWS(16); break;
-        case 32: NPI_ROWS(32); break;
-        default: NPI_ROWS(64); break;
-#undef NPI_ROWS
-    }
-    const int64_t n_items = npi_num_items(nnz_max);
-    if (n_items > 0) {
-        int* cnt = reinterpret_cast<int*>(workspace + 4 * n_items * H);
-        int* count = cnt + n_items;
-        int* list = count + 1;
-        const int cap = (int)heavy_list_capacity(nnz_max);
-        const int ie = item_edges_for(nnz_max);
-        (void)hipMemsetAsync(count, 0, sizeof(int), stream);
-        heavy_list_kernel<<<(unsigned)ceil_div(n_items, 256), 256, 0, stream>>>(rowptr, item_row, (int)N, (int)n_items, ie, cap, cnt, count, list);
-        gat_softmax_heavy_kernel<<<(unsigned)(cap < HEAVY_GRID ? cap : HEAVY_GRID), HEAVY_THREADS, 0, stream>>>(rowptr, col, item_row, a_dst, a_src, (int)N, (int)n_items,
-                                                                             (int)H, slope, m, s, ie, workspace, cnt, count, list);
-    }
-    return check_launch("npi_gat_softmax_stats");
-}
-
-extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                                  int64_t N, int64_t nnz_max, const float* x, int64_t ldx, float* out, int64_t ldo,
                                  int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
                                  const float* s, float slope, int by_source, const float* bias,
                                  const float* g_dst, const float* g_src, const float* att,
                                  const float* alpha, const int32_t* alpha_map,
                                  float* carry, void* stream_) {
-    return npi_gat_aggregate_ex(rowptr, col, item_row, N, nnz_max, x, ldx, nullptr, 0, out, ldo, H, C, a_dst, a_src, m, s,
+    return npi_gat_aggregate_ex(rowptr, col, item_row, item_edges, N, nnz_max, x, ldx, nullptr, 0, out, ldo, H, C, a_dst, a_src, m, s,
                                 slope, by_source, bias, g_dst, g_src, att, alpha, alpha_map, carry, stream_);
 }
 
-extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                                     int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                                     float* out, int64_t ldo,
                                     int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
@@ -1064,13 +647,14 @@ extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, c
                                     float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_ex: bad split");
+    NPI_REQUIRE(item_edges_ok(item_edges), "npi_gat_aggregate: item_edges must be 64 or NPI_ITEM_EDGES (the value the CSR was built with)");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && H > 0 && C > 0, "npi_gat_aggregate: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && col && item_row && x && out && a_dst && a_src && m && s && carry, "npi_gat_aggregate: null pointer");
     NPI_REQUIRE(ldx >= H * C && ldo >= H * C, "npi_gat_aggregate: leading dimension too small");
     SegParams P{};
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
-    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
+    P.N = (int)N; P.item = (int)item_edges;
     P.x = x; P.ldx = ldx; P.out = out; P.ldo = ldo; P.F = (int)(H * C);
     P.x2 = x2; P.split = (int)split;
     P.carry = carry; P.w = nullptr; P.bias = bias;
@@ -1089,23 +673,24 @@ extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, c
     return segsum_run(P, by_source ? W_GAT_SRC : W_GAT_DST, 0, nnz_max, NPI_F32, stream);
 }
 
-extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                                         int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                                         float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
-                                        const float* bias, int relu, float* alpha_out, float* carry, void* stream_) {
+                                        const float* bias, int relu, float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_scores: bad split");
+    NPI_REQUIRE(item_edges_ok(item_edges), "npi_gat_aggregate_scores: item_edges must be 64 or NPI_ITEM_EDGES (the value the CSR was built with)");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0, "npi_gat_aggregate_scores: bad size");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && col && item_row && x && out && scores && m && s && carry, "npi_gat_aggregate_scores: null pointer");
     NPI_REQUIRE(ldx >= C && ldo >= C, "npi_gat_aggregate_scores: leading dimension too small");
     SegParams P{};
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
-    P.N = (int)N; P.n_items = (int)npi_num_items(nnz_max);
+    P.N = (int)N; P.item = (int)item_edges;
     P.x = x; P.ldx = ldx; P.out = out; P.ldo = ldo; P.F = (int)C;
     P.x2 = x2; P.split = (int)split;
     P.carry = carry; P.w = scores; P.bias = bias;
-    P.H = 1; P.C = (int)C; P.m = m; P.s = s; P.alpha_out = alpha_out; P.relu = relu ? 1 : 0;
+    P.H = 1; P.C = (int)C; P.m = m; P.s = s; P.relu = relu ? 1 : 0;
     return segsum_run(P, W_GAT_DST_PRE, 0, nnz_max, NPI_F32, stream);
 }
 
@@ -1135,51 +720,15 @@ extern "C" int npi_gat_edge_grad_ex(const int32_t* rowptr, const int32_t* col, c
     NPI_REQUIRE(F % 4 == 0 && C % 4 == 0 && ldh % 4 == 0 && ldd % 4 == 0 && F <= 1024 &&
                 ((uintptr_t)hfeat % 16 == 0) && ((uintptr_t)dout % 16 == 0),
                 "npi_gat_edge_grad: needs 16-B aligned rows, out_channels % 4 == 0, heads*out_channels <= 1024");
-    const int n_items = (int)npi_num_items(nnz_max);
+    // this kernel keeps no item state between calls (no item_row, no carry): its own chunking of the entry stream, per call
+    const int chunk = item_edges_for(nnz_max);
+    const int n_items = (int)num_items_of(nnz_max, chunk);
     const unsigned grid = (unsigned)ceil_div(n_items, 4);
     const int nch = (int)ceil_div(F, 256);
-#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, item_edges_for(nnz_max), hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz, alpha_out, hfeat2, (int)split, swap)
+#define NPI_EG(NC) gat_edge_grad_kernel<NC><<<grid, 256, 0, stream>>>(rowptr, col, rowidx, (int)N, n_items, chunk, hfeat, ldh, dout, ldd, (int)H, (int)C, a_dst, a_src, m, s, D, slope, dz, alpha_out, hfeat2, (int)split, swap)
     if (nch == 1) NPI_EG(1); else if (nch == 2) NPI_EG(2); else if (nch == 3) NPI_EG(3); else NPI_EG(4);
 #undef NPI_EG
     return check_launch("npi_gat_edge_grad");
-}
-
-extern "C" int npi_seg_rowsum(const int32_t* rowptr, const int32_t* item_row, const float* vals, const int32_t* map,
-                              int64_t N, int64_t nnz_max, int64_t H, float* out, float* workspace, int64_t workspace_elems,
-                              void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(N >= 0 && H > 0 && H <= HEAVY_THREADS && nnz_max >= 0, "npi_seg_rowsum: bad size");
-    if (N == 0) return NPI_OK;
-    NPI_REQUIRE(rowptr && vals && out, "npi_seg_rowsum: null pointer");
-    const int64_t n_items = item_row ? npi_num_items(nnz_max) : 0;
-    if (n_items > 0) {
-        NPI_REQUIRE(workspace != nullptr, "npi_seg_rowsum: null workspace");
-        if (workspace_elems < npi_gat_heavy_workspace_elems(nnz_max, H)) {
-            set_error("npi_seg_rowsum: workspace too small");
-            return NPI_ERR_WORKSPACE;
-        }
-    }
-    // rows up to 4096 entries: one wave each; longer ones: 1024-thread workgroups over 64-item segments
-    switch (row_group_lanes(nnz_max, N)) {
-#define NPI_ROWS(LG) seg_rowsum_scalar_kernel<LG><<<(unsigned)ceil_div(N, 4 * (WAVE / LG)), 256, 0, stream>>>(rowptr, vals, map, (int)N, (int)H, out, n_items > 0 ? 1 : 0)
-        case 8: NPI_ROWS(8); break;
-        case 16: NPI_ROWS(16); break;
-        case 32: NPI_ROWS(32); break;
-        default: NPI_ROWS(64); break;
-#undef NPI_ROWS
-    }
-    if (n_items > 0) {
-        int* cnt = reinterpret_cast<int*>(workspace + 4 * n_items * H);
-        int* count = cnt + n_items;
-        int* list = count + 1;
-        const int cap = (int)heavy_list_capacity(nnz_max);
-        const int ie = item_edges_for(nnz_max);
-        (void)hipMemsetAsync(count, 0, sizeof(int), stream);
-        heavy_list_kernel<<<(unsigned)ceil_div(n_items, 256), 256, 0, stream>>>(rowptr, item_row, (int)N, (int)n_items, ie, cap, cnt, count, list);
-        seg_rowsum_heavy_kernel<<<(unsigned)(cap < HEAVY_GRID ? cap : HEAVY_GRID), HEAVY_THREADS, 0, stream>>>(rowptr, item_row, vals, map, (int)N, (int)n_items, (int)H, out,
-                                                                            ie, workspace, cnt, count, list);
-    }
-    return check_launch("npi_seg_rowsum");
 }
 
 extern "C" int npi_entry_transpose_map(const int32_t* src_eid, const int32_t* src_rowidx, const int32_t* src_rowptr,

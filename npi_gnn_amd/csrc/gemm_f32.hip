@@ -1587,17 +1587,14 @@ static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4)
 //   shared  : about three workgroups per four CUs -- as a light resident it leaves room for the backward
 //             aggregation to co-run on every CU (functional.py, OVERLAP_STREAMS).  Step time at C4 by workgroup
 //             count: 128: 7.50, 160-224: 7.11-7.12, 256: 7.22, 384: 7.38, 512: 7.55 ms; alone that grid takes 1.77 ms.
-// The caller says which one applies (npi_dw_shared); NPI_DW_CTAS overrides the shared count.
+// The caller says which one applies (npi_linear_bwd_weight_ex's `shared`; npi_dw_shared for the legacy entry point).
 static int g_dw_shared = 0;
 static int64_t dw_workgroups(bool shared) {
     if (!shared) return 1024;
     static const int64_t ctas = [] {
-        const char* e = getenv("NPI_DW_CTAS");
-        long v = e ? atol(e) : 0;
-        if (v <= 0) {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) v = (3 * cus) / 4;
-        }
+        long v = 0;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) v = (3 * cus) / 4;
         if (v > 1024) v = 1024;                          // the workspace is sized for the 1,024-workgroup plan
         return (int64_t)(v > 0 ? v : 192);
     }();
@@ -1623,19 +1620,17 @@ template <int AMODE, int BMODE>
 static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32,
                        int mode = 1, void* scratch = nullptr, int k_valid = 0) {
     const bool bf16_in = dtype_in == NPI_BF16 && dtype_out == NPI_F32;          // dW of the bf16 path: bf16 operands, f32 slabs
-    // 128 x 256 tile (one workgroup per CU): measured 3-10 % SLOWER than 128 x 128 at C4 (round 1:
-    // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms), so it is opt-in (NPI_GEMM_WIDE=1)
-    static const bool wide_enabled = [] { const char* e = getenv("NPI_GEMM_WIDE"); return e && e[0] == '1'; }();
+    // (a 128 x 256 tile of the exact-f32 kernel, one workgroup per CU, measured 3-10 % SLOWER than 128 x 128 at C4 in round 1:
+    // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms -- not built)
     const int kv = k_valid > 0 ? k_valid : a.K;
     if (kv != a.K) {
         const bool can_split = AMODE == 0 && v4 && (a.K % BK == 0) && dtype_in == NPI_F32 && dtype_out == NPI_F32 && splits == 1 &&
-                               mode != 0 && !wide_enabled && a.ep.colsum == nullptr && a.M >= 128 && a.N >= 128 && ((uintptr_t)a.C % 16 == 0) &&
+                               mode != 0 && a.ep.colsum == nullptr && a.M >= 128 && a.N >= 128 && ((uintptr_t)a.C % 16 == 0) &&
                                (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
         if (!can_split) { a.K = kv; a.kchunk = (int)align_up(kv, BK); }          // the pad columns are zero: dropping them is exact
     }
     const bool fast_ok = v4 && (a.K % BK == 0) && (a.K > 0) && ((dtype_in == NPI_F32 && dtype_out == NPI_F32) || bf16_in);
-    const bool wide = wide_enabled && fast_ok && !bf16_in && a.N >= 256 && a.M >= 128;
-    const int bm = 128, bn = wide ? 256 : 128;
+    const int bm = 128, bn = 128;
     const int fm = fast_ok ? a.M / bm : 0, fn = fast_ok ? a.N / bn : 0;    // full tiles
     // bf16 storage: interior tiles on the bf16 MFMA pipeline (K % 64 == 0, 16-byte aligned rows); the rest guarded
     const bool bf16_ws = AMODE == 0 && splits == 1 && dtype_in == NPI_BF16 && dtype_out == NPI_BF16 && a.ep.colsum == nullptr &&
@@ -1672,7 +1667,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         }
         return NPI_OK;
     }
-    const bool split = fast_ok && !wide && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
+    const bool split = fast_ok && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
                        ((uintptr_t)a.C % 16 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
     int split_tm = 0;                                        // m-tiles the split kernel covered (all of them, when it ran)
     if (a.ep.r2_row0 != nullptr && !(fm > 0 && fn > 0 && split && a.N % 128 == 0 && kv == a.K)) {
@@ -1708,7 +1703,6 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         GemmArgs f = a;
         f.tm0 = 0; f.tn0 = 0;
         if (bf16_in)   gemm_fast_kernel<AMODE, BMODE, 2, 2, bf16_t><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
-        else if (wide) gemm_fast_kernel<AMODE, BMODE, 2, 4><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
         else           gemm_fast_kernel<AMODE, BMODE, 2, 2><<<dim3(fn, fm, splits), GEMM_THREADS, 0, stream>>>(f);
     }
     // edge strips in 128 x 128 tiles
@@ -1842,8 +1836,7 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
 // dA = dC W^T + row0 (x) col0 + row1 (x) col1, the rank-2 term added in the split kernel's store epilogue (GATConv backward:
 // the attention terms g_dst (x) W att_dst + g_src (x) W att_src of dX, without a read-modify-write pass over d hfeat)
 extern "C" int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t N) {
-    static const bool wide_enabled = [] { const char* e = getenv("NPI_GEMM_WIDE"); return e && e[0] == '1'; }();
-    return (g_gemm_mode != 0 && !wide_enabled && M >= 128 && M < 0x7fffffff && K >= 128 && K % 128 == 0 && N >= BK && N % BK == 0 &&
+    return (g_gemm_mode != 0 && M >= 128 && M < 0x7fffffff && K >= 128 && K % 128 == 0 && N >= BK && N % BK == 0 &&
             N % 4 == 0) ? 1 : 0;
 }
 extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
@@ -1922,8 +1915,7 @@ static void dw_split_plan(int64_t m_main, int64_t K, int64_t N, bool shared, int
     tiles_n = (int)(wide ? N / 256 : N / 128);
     // shared regime: the 512-thread workgroup holds 2 x 208 VGPRs per SIMD and leaves the aggregation one wave slot there, so
     // it is kept to about 3 of 8 CUs (step at C4 by workgroup count: 64: 7.86, 96: 7.11, 128: 7.15, 192: 7.25 ms)
-    static const bool ctas_env = getenv("NPI_DW_CTAS") != nullptr;
-    const int64_t wgs = shared ? (ctas_env ? dw_workgroups(true) : dw_workgroups(true) / 2) : 256;
+    const int64_t wgs = shared ? dw_workgroups(true) / 2 : 256;
     int64_t ns = wgs / ((int64_t)tiles_m * tiles_n);
     if (ns < 1) ns = 1;
     const int64_t maxs = ceil_div(m_main, (int64_t)SK * 16);                 // at least 16 k-steps per slab

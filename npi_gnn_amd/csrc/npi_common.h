@@ -41,18 +41,19 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
 
-// Entries per work item ("item" = what one wavefront reduces) as a function of the CSR's capacity: small graphs
-// (the reference's 200-subgraph batches, the bundled full graphs) get 64-entry items -- four times as many
-// wavefronts, a quarter of the serial chain each -- large ones NPI_ITEM_EDGES.  Every entry point derives it
-// from the same nnz_max, so item_row, carry and the kernels always agree.
-// Host-side decision (every kernel receives the item size as an argument).  Round 3: the switch moved from 2^20 to 2^22
-// entries -- the per-rank sides of a sharded graph (1.2-2.6 M entries at C4 with 8 ranks) were launched as ~5 k wavefronts of
-// 256 entries, a fraction of one wave per SIMD slot: a rank's SAGE step 1.19 -> 1.15 ms, its GAT step 1.97 -> 1.80 ms with
-// 64-entry items; 2^24 changes nothing at 5 M entries and costs 4 % at 10 M.  One process-wide value (csr_build.hip):
-// npi_small_graph_entries(n) sets it (tests), NPI_SMALL_GRAPH_ENTRIES=<n> in the environment presets it.
+// Entries per work item ("item" = what one wavefront reduces).  The item size is a PROPERTY OF THE CSR: npi_csr_build /
+// npi_csr_filter take it as an argument and cut item_row with it, and every consumer of item_row (npi_segsum*, npi_gat_*)
+// receives the same value from the caller, next to item_row -- no launch re-derives it from process state.  What remains
+// process-wide is only the HINT a caller may ask for when it builds a CSR (npi_item_edges(nnz_max)): 64-entry items for
+// capacities below npi_small_graph_entries (2^22 unless NPI_SMALL_GRAPH_ENTRIES presets it) -- the reference's 200-subgraph
+// batches, the bundled full graphs and the per-rank sides of a sharded graph, four times as many wavefronts with a quarter of
+// the serial chain each -- and NPI_ITEM_EDGES above.  Kernels that keep no item state between calls (segscan.hip,
+// gat_edge_grad) pick their own chunking per call from the same hint.
 constexpr int64_t NPI_SMALL_GRAPH_ENTRIES = (int64_t)1 << 22;
 int64_t small_graph_entries();
 inline int item_edges_for(int64_t nnz_max) { return nnz_max < small_graph_entries() ? 64 : NPI_ITEM_EDGES; }
+inline bool item_edges_ok(int64_t item) { return item == 64 || item == NPI_ITEM_EDGES; }
+inline int64_t num_items_of(int64_t nnz_max, int64_t item) { return nnz_max <= 0 ? 0 : ceil_div(nnz_max, item); }
 
 }  // namespace npi
 

@@ -235,7 +235,10 @@ seg_chain_kernel(ScanArgs A) {
 
 template <class Op>
 int run_scan(ScanArgs A, int64_t nnz_max, float* workspace, int64_t workspace_elems, hipStream_t stream, const char* what) {
-    const int64_t n_items = npi_num_items(nnz_max);
+    // no item state outlives the call (head / tail / tail_row are this call's scratch): the chunking is chosen here, and the
+    // workspace query below sizes for the finest one, so it fits whatever the hint is at call time
+    A.item = item_edges_for(nnz_max);
+    const int64_t n_items = num_items_of(nnz_max, A.item);
     const int64_t per = (int64_t)sizeof(typename Op::V) / 4 * A.H;
     if (n_items == 0) return NPI_OK;
     if (workspace == nullptr || workspace_elems < 2 * per * n_items + n_items + 2) {
@@ -247,7 +250,6 @@ int run_scan(ScanArgs A, int64_t nnz_max, float* workspace, int64_t workspace_el
     A.tail = ws + per * n_items;
     A.tail_row = reinterpret_cast<int32_t*>(A.tail + per * n_items);
     A.n_items = (int)n_items;
-    A.item = item_edges_for(nnz_max);
     const unsigned grid = (unsigned)ceil_div(n_items, 4);
     constexpr int NBL = NPI_ITEM_EDGES / WAVE;
     const bool small = A.item == WAVE;
@@ -272,7 +274,8 @@ using namespace npi;
 
 extern "C" int64_t npi_seg_scan_workspace_elems(int64_t nnz_max, int64_t H) {
     if (nnz_max < 0 || H <= 0) return -1;
-    return 4 * H * npi_num_items(nnz_max) + npi_num_items(nnz_max) + 4;
+    const int64_t items = num_items_of(nnz_max, WAVE);          // the finest chunking run_scan may choose
+    return 4 * H * items + items + 4;
 }
 
 extern "C" int npi_seg_rowsum_ex(const int32_t* rowptr, const int32_t* rowidx, const float* vals, const int32_t* map,

@@ -14,10 +14,10 @@ struct SegParams {
     const int32_t* rowptr;
     const int32_t* col;
     const int32_t* item_row;
-    int N, n_items;
+    int N, n_items;          // n_items: filled in by segsum_run from nnz_max and item
     int relu;                // != 0: max(., 0) after scale and bias (the F.relu behind a GATConv, in the row epilogue; NaN kept)
     int mean;                // != 0: divide every row sum by its entry count (scatter_mean); filled in by segsum_run
-    int item;                // entries per item (item_edges_for(nnz_max)); filled in by segsum_run
+    int item;                // entries per item: the CSR's own item size (what item_row was cut with), set by the entry point
     const float* x;
     int64_t ldx;
     const float* x2;         // two-part table: entries with col >= split read row (col - split) of x2 (same ldx);
@@ -43,15 +43,14 @@ struct SegParams {
     const float* att;        // [H, 2C]
     // W_GAT_DST, one head: alpha of every entry is also written here (by-target entry order) when not null
     float* alpha_out;
-    // W_GAT_SRC_FUSED (one head, F <= 256): W_GAT_SRC_PRE plus, in the same pass over the gathered dOut rows, the
-    // score gradient dz[q] = alpha_q (<dOut_i, h_j> - D_i) leaky_relu'(a_dst[i] + a_src[j]) of every by-source entry q
+    // W_GAT_SRC_FUSED* (F <= 256): the by-source aggregation plus, in the same pass over the gathered dOut rows, the score
+    // gradient dz[q, h] = alpha_q (<dOut_i, h_j> - D_i) leaky_relu'(a_dst[i] + a_src[j]) of every by-source entry q and head
     const float* hrow;       // [N, F] features of the ROW nodes (h_j), leading dimension ldh
     int64_t ldh;
-    const float* Dt;         // [N] D of the column (target) nodes
     const int32_t* rowidx;   // row of every entry (the by-source CSR's rowidx)
-    float* dz_out;           // [nnz_max] by-source entry order
-    // W_GAT_SRC_FUSED*, packed form: (a_dst, m, 1 / (s + 1e-16), D) of every TARGET node AND HEAD as one float4 ([N, H, 4]) -- one 16-byte gather
-    // per entry replaces alpha through the transpose map (a random 4-byte read of an 84 MB array) + Dt + a_dst; w / wmap unused
+    float* dz_out;           // [nnz_max, H] by-source entry order
+    // (a_dst, m, 1 / (s + 1e-16), D) of every TARGET node AND HEAD as one float4 ([n_cols, H, 4]): one 16-byte gather per entry
+    // and head, alpha recomputed by the lane that owns the entry
     const float4* tpack;
 };
 

@@ -18,10 +18,12 @@
 //   W_ARRAY    w[p]                                GCNConv norm, any per-entry weight
 //   W_GAT_DST  exp(lrelu(a_dst[row] + a_src[col]) - m[row]), row scale 1/(s[row] + 1e-16)
 //              = GATConv's softmax(alpha) * x_j on the by-target CSR, alpha never stored
+//   W_GAT_DST_PRE  W_GAT_DST, one head, with the entry's score read back from the statistics pass (w[p]) instead of gathered
 //   W_GAT_SRC_PRE  W_GAT_SRC with alpha read back (w[wmap[p]], one head) instead of recomputed: the per-entry
 //              exp / divide of W_GAT_SRC costs more VALU time than the row it weighs costs memory time
-//   W_GAT_SRC_FUSED  W_GAT_SRC_PRE that also computes the per-entry score gradient dz from the rows it gathers anyway
-//              (the SDDMM of the GATConv backward: no separate gather pass over the 104M entries)
+//   W_GAT_SRC_FUSED[_H2/4/8]  by-source aggregation that also computes the per-entry score gradient dz from the rows it
+//              gathers anyway (the SDDMM of the GATConv backward: no separate gather pass over the 104M entries); alpha is
+//              recomputed by the lane that owns the entry from ONE 16-byte gather of packed per-target scalars (tpack)
 //   W_GAT_SRC  the same alpha seen from the by-source CSR (backward: d h_j = sum_i alpha_ij d out_i),
 //              plus the rank-1 terms of the attention-score gradient in the epilogue
 #include "segsum.h"
@@ -29,12 +31,8 @@
 
 namespace npi {
 
-// A/B switch for measurements only (tools/build_variant.sh one_table -DNPI_SEG_ONE_TABLE=1): compiles the two-part
-// table select out of the gather
-#ifndef NPI_SEG_ONE_TABLE
-#define NPI_SEG_ONE_TABLE 0
-#endif
-constexpr bool TWO_PART = !NPI_SEG_ONE_TABLE;
+// the gather reads a two-part table (SegParams.x / x2, split): the select is free (2.479 vs 2.480 ms at C4 with it compiled out)
+constexpr bool TWO_PART = true;
 
 constexpr int SEG_THREADS = 256;
 constexpr int SEG_WAVES = SEG_THREADS / WAVE;
@@ -144,22 +142,11 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
     }
 }
 
-// Workgroup -> block of items.  NPI_SEG_WAYS > 1 deals the workgroups round-robin over that many contiguous parts of
-// the entry stream, so that parts with different access patterns (rows that gather cache-resident hub rows, rows
-// that gather from HBM) are in flight together instead of one after the other.  Measured at C4 (f32): 2 ways 2.43 / 2.46 ms
-// against 2.45 / 2.41 ms for fwd / bwd, 4 ways 2.56, 8 ways 3.02 ms -- the two phases do not overlap; the default stays 1.
-#ifndef NPI_SEG_WAYS
-#define NPI_SEG_WAYS 1
-#endif
-static unsigned seg_grid(int n_items) {
-    const int64_t nb = ceil_div(n_items, SEG_WAVES);
-    return (unsigned)(ceil_div(nb, NPI_SEG_WAYS) * NPI_SEG_WAYS);
-}
-__device__ __forceinline__ int item_block(int b, int nb) {
-    if (NPI_SEG_WAYS <= 1) return b;
-    const int per = nb / NPI_SEG_WAYS;                            // the grid is a multiple of NPI_SEG_WAYS (seg_grid)
-    return (b % NPI_SEG_WAYS) * per + b / NPI_SEG_WAYS;           // a bijection of [0, nb); blocks past the items exit
-}
+// Workgroup b takes items 4 b .. 4 b + 3, in stream order.  (Dealing the workgroups round-robin over 2 / 4 / 8 contiguous
+// parts of the entry stream, so that rows gathering cache-resident hub rows and rows gathering from HBM are in flight
+// together, was measured at C4: 2.43-2.46 / 2.56 / 3.02 ms against 2.41-2.45 -- the phases do not overlap; not kept.)
+static unsigned seg_grid(int n_items) { return (unsigned)ceil_div(n_items, SEG_WAVES); }
+__device__ __forceinline__ int item_block(int b, int) { return b; }
 
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS)
@@ -214,7 +201,7 @@ segsum_kernel(SegParams P) {
                 const int64_t i = (int64_t)min(r, N - 1) * P.H + L.hd[c];
                 rs_a[c] = (WMODE == W_GAT_DST) ? P.a_dst[i] : 0.f;
                 rs_m[c] = P.m[i];
-                rs_i[c] = P.alpha_out ? 1.f / (P.s[i] + 1e-16f) : 0.f;
+                rs_i[c] = (WMODE == W_GAT_DST && P.alpha_out) ? 1.f / (P.s[i] + 1e-16f) : 0.f;
             }
         } else if (is_fused_mode(WMODE)) {
             if (L.act[0]) load_row<VEC, float>(P.hrow + (int64_t)min(r, N - 1) * P.ldh + L.foff[0], hr);
@@ -288,7 +275,7 @@ segsum_kernel(SegParams P) {
                     dzgh[h] = z > 0.f ? 1.f : P.slope;
                 }
             }
-        } else if (WMODE == W_GAT_SRC_FUSED && P.tpack != nullptr) {
+        } else if (WMODE == W_GAT_SRC_FUSED) {
             // alpha of entry kb + l is computed BY LANE l (one exp per entry, not per lane) from the packed target scalars
             if (lane < nb) {
                 const float4 t = P.tpack[cv];
@@ -299,10 +286,10 @@ segsum_kernel(SegParams P) {
             } else {
                 wv = 0.f;
             }
-        } else if (WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
+        } else if (WMODE == W_GAT_SRC_PRE) wv = (lane < nb) ? P.w[P.wmap[kb + lane]] : 0.f;
         (void)wvh; (void)dzdh; (void)dzgh; (void)myhead; (void)lph;
         int avec = 0;                    // W_GAT_DST + alpha_out: alpha of entry kb + l collects in lane l, stored once per block
-        const bool keep_alpha = (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) && P.alpha_out != nullptr;
+        const bool keep_alpha = WMODE == W_GAT_DST && P.alpha_out != nullptr;
         int j = 0;
         for (; j + U <= nb; j += U) {
             float v[U][NCH][VEC];
@@ -457,15 +444,7 @@ segsum_kernel(SegParams P) {
         if (WMODE == W_GAT_SRC_FUSED) {
             // all 64 lanes turn the block's dots into dz together: dz = alpha (dot - D_i) leaky_relu'(a_dst[i] + a_src[j])
             __builtin_amdgcn_wave_barrier();
-            if (lane < nb) {
-                if (P.tpack != nullptr) {
-                    P.dz_out[kb + lane] = wv * (pb[lane] - dz_d) * dz_g;
-                } else {
-                    const int jj = P.rowidx[kb + lane];
-                    const float z = P.a_dst[cv] + P.a_src[jj];
-                    P.dz_out[kb + lane] = wv * (pb[lane] - P.Dt[cv]) * (z > 0.f ? 1.f : P.slope);
-                }
-            }
+            if (lane < nb) P.dz_out[kb + lane] = wv * (pb[lane] - dz_d) * dz_g;
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -776,9 +755,8 @@ static int launch_group_modes(const SegParams& P, int wmode, int mean, hipStream
 template <typename T, int VEC, int NCH, bool EXACT>
 static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t stream) {
     if constexpr (NCH == 1 && !EXACT) {
-        // narrow rows: several entries per wave instruction (NPI_SEG_NARROW=0 keeps the one-entry kernel)
-        static const bool narrow_on = [] { const char* e = getenv("NPI_SEG_NARROW"); return !(e && e[0] == '0'); }();
-        if (narrow_on && wmode <= W_ARRAY) {
+        // narrow rows: several entries per wave instruction
+        if (wmode <= W_ARRAY) {
             if (P.F <= 16 * VEC) return launch_group_modes<T, VEC, 4>(P, wmode, mean, stream);
             if (P.F <= 32 * VEC) return launch_group_modes<T, VEC, 2>(P, wmode, mean, stream);
         }
@@ -839,7 +817,11 @@ static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t str
 // shared by npi_segsum and npi_gat_aggregate (gat.hip)
 int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hipStream_t stream) {
     const int64_t F = P.F;
-    P.item = item_edges_for(nnz_max);
+    if (!item_edges_ok(P.item)) {                             // the CSR's own item size, handed over by the caller next to item_row
+        set_error("npi_segsum: item_edges must be 64 or %d (the value the CSR was built with)", NPI_ITEM_EDGES);
+        return NPI_ERR_ARG;
+    }
+    P.n_items = (int)num_items_of(nnz_max, P.item);
     P.mean = mean ? 1 : 0;
     const int es = (dtype == NPI_BF16) ? 2 : 4;              // bytes per stored element
     if (P.x2 == nullptr) { P.x2 = P.x; P.split = 0x7fffffff; }
@@ -887,20 +869,21 @@ int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hip
 
 using namespace npi;
 
-extern "C" int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t F) {
-    int64_t items = npi_num_items(nnz_max);
+extern "C" int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, int64_t F) {
+    if (!item_edges_ok(item_edges) || F <= 0) return -1;
+    int64_t items = num_items_of(nnz_max, item_edges);
     return items > 0 ? 2 * items * F : 1;
 }
 
-extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                           const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
                           void* out_, int64_t ldo, int64_t F, int dtype, int mean, const float* bias,
                           float* carry, void* stream_) {
-    return npi_segsum_ex(rowptr, col, item_row, w, N, nnz_max, x_, ldx, nullptr, 0, out_, ldo, F, dtype, mean, bias,
+    return npi_segsum_ex(rowptr, col, item_row, item_edges, w, N, nnz_max, x_, ldx, nullptr, 0, out_, ldo, F, dtype, mean, bias,
                          carry, stream_);
 }
 
-extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row,
+extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                              const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
                              const void* x2_, int64_t split, void* out_, int64_t ldo, int64_t F, int dtype, int mean,
                              const float* bias, float* carry, void* stream_) {
@@ -911,7 +894,8 @@ extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const in
     NPI_REQUIRE(ldx >= F && ldo >= F, "npi_segsum: leading dimension < F");
     if (N == 0) return NPI_OK;
     NPI_REQUIRE(rowptr && item_row && x_ && out_ && carry, "npi_segsum: null pointer");
-    const int64_t n_items = npi_num_items(nnz_max);
+    NPI_REQUIRE(item_edges_ok(item_edges), "npi_segsum: item_edges must be 64 or NPI_ITEM_EDGES (the value the CSR was built with)");
+    const int64_t n_items = num_items_of(nnz_max, item_edges);
     if (n_items == 0) {     // no entries at all: every row is empty
         NPI_REQUIRE(bias == nullptr, "npi_segsum: bias with an entry-free graph is not supported");
         const size_t es = (dtype == NPI_BF16) ? 2 : 4;
@@ -921,7 +905,7 @@ extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const in
     NPI_REQUIRE(col != nullptr, "npi_segsum: null col");
     SegParams P{};
     P.rowptr = rowptr; P.col = col; P.item_row = item_row;
-    P.N = (int)N; P.n_items = (int)n_items;
+    P.N = (int)N; P.item = (int)item_edges;
     P.x = (const float*)x_; P.ldx = ldx; P.out = (float*)out_; P.ldo = ldo; P.F = (int)F;
     P.x2 = (const float*)x2_; P.split = (int)split;
     P.carry = carry; P.w = w; P.bias = bias;

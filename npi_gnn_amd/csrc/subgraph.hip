@@ -80,10 +80,17 @@ __global__ void __launch_bounds__(256)
 subgraph_fill_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ nbr, const uint8_t* __restrict__ ok,
                      const int32_t* __restrict__ keys, int B, const int32_t* __restrict__ node_off,
                      const int32_t* __restrict__ pair_off, int32_t* __restrict__ node_id, int64_t* __restrict__ batch,
-                     int64_t* __restrict__ esrc, int64_t* __restrict__ edst) {
+                     int64_t* __restrict__ esrc, int64_t* __restrict__ edst, int n_nodes, int n_pairs,
+                     int32_t* __restrict__ status) {
     const int lane = lane_id();
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= B) return;
+    // the arrays were sized from the CALLER's totals; the offsets below are the device's.  Totals that belong to other keys
+    // would make every store below an out-of-bounds write: nothing is written and bit 2 of the status word is raised instead
+    if (node_off[B] != n_nodes || pair_off[B] != n_pairs) {
+        if (g == 0 && lane == 0 && status != nullptr) atomicOr(status, 4);
+        return;
+    }
     const int l = keys[2 * g], p = keys[2 * g + 1];
     const int64_t n0 = node_off[g];
     const int64_t e0 = 2 * (int64_t)pair_off[g];
@@ -124,11 +131,12 @@ subgraph_fill_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict_
 // (a row pitch padded for the GEMMs, NPI_GEMM_A_ZERO_PADDED) are set to zero
 __global__ void __launch_bounds__(256)
 subgraph_features_kernel(const float* __restrict__ feat, int64_t ldf, int Ff, const int32_t* __restrict__ node_id,
-                         const int64_t* __restrict__ batch, const int32_t* __restrict__ node_off, int64_t n,
+                         const int64_t* __restrict__ batch, const int32_t* __restrict__ node_off, int B, int64_t n,
                          float* __restrict__ x, int64_t ldx) {
     const int lane = lane_id();
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
+    if (node_off[B] != n) return;                          // npi_subgraph_fill wrote nothing (and raised the status bit): node_id is not valid
     const float* __restrict__ src = feat + (int64_t)node_id[row] * ldf;
     float* __restrict__ dst = x + row * ldx;
     if (lane == 0) dst[0] = (row - node_off[batch[row]] < 2) ? 0.f : 1.f;
@@ -154,24 +162,27 @@ extern "C" int npi_subgraph_sizes(const int32_t* ptr, const int32_t* nbr, const 
 
 extern "C" int npi_subgraph_fill(const int32_t* ptr, const int32_t* nbr, const uint8_t* ok, const int32_t* keys,
                                  int64_t B, const int32_t* node_off, const int32_t* pair_off, int32_t* node_id,
-                                 int64_t* batch, int64_t* edge_src, int64_t* edge_dst, void* stream_) {
+                                 int64_t* batch, int64_t* edge_src, int64_t* edge_dst, int64_t n_nodes, int64_t n_pairs,
+                                 int32_t* status, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(B >= 0 && B < 0x3fffffff, "npi_subgraph_fill: bad size");
+    NPI_REQUIRE(n_nodes >= 0 && n_pairs >= 0 && n_nodes <= 0x7fffffff && n_pairs <= 0x7fffffff, "npi_subgraph_fill: bad totals");
+    if (status != nullptr) (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
     if (B == 0) return NPI_OK;
     NPI_REQUIRE(ptr && nbr && ok && keys && node_off && pair_off && node_id && batch && edge_src && edge_dst,
                 "npi_subgraph_fill: null pointer");
     subgraph_fill_kernel<<<(unsigned)ceil_div(B, 4), 256, 0, stream>>>(ptr, nbr, ok, keys, (int)B, node_off, pair_off, node_id,
-                                                                       batch, edge_src, edge_dst);
+                                                                       batch, edge_src, edge_dst, (int)n_nodes, (int)n_pairs, status);
     return check_launch("npi_subgraph_fill");
 }
 
 extern "C" int npi_subgraph_features(const float* feat, int64_t ldf, int64_t Ff, const int32_t* node_id,
-                                     const int64_t* batch, const int32_t* node_off, int64_t n, float* x, int64_t ldx,
+                                     const int64_t* batch, const int32_t* node_off, int64_t B, int64_t n, float* x, int64_t ldx,
                                      void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(n >= 0 && Ff > 0 && ldf >= Ff && ldx >= Ff + 1, "npi_subgraph_features: bad size");
+    NPI_REQUIRE(n >= 0 && B >= 0 && B < 0x3fffffff && Ff > 0 && ldf >= Ff && ldx >= Ff + 1, "npi_subgraph_features: bad size");
     if (n == 0) return NPI_OK;
     NPI_REQUIRE(feat && node_id && batch && node_off && x, "npi_subgraph_features: null pointer");
-    subgraph_features_kernel<<<(unsigned)ceil_div(n, 4), 256, 0, stream>>>(feat, ldf, (int)Ff, node_id, batch, node_off, n, x, ldx);
+    subgraph_features_kernel<<<(unsigned)ceil_div(n, 4), 256, 0, stream>>>(feat, ldf, (int)Ff, node_id, batch, node_off, (int)B, n, x, ldx);
     return check_launch("npi_subgraph_features");
 }

@@ -56,12 +56,13 @@ is ``HipBackend`` and there is no CPU fallback in this package.
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
 import torch.distributed as dist
 from torch import nn
+
+from .schedule import DEFAULT, Schedule
 
 NEG = -3.0e38      # "no entry" row maximum (what the softmax-statistics kernels start from)
 
@@ -284,11 +285,6 @@ def route_edges(src: torch.Tensor, dst: torch.Tensor, part: HubPartition, rank: 
     return lists[0], lists[1], in_cnt, out_cnt, int(hub_hub) > 0
 
 
-# cuts without hub-hub edges: reduce-scatter the complete hub rows straight into the output (no merge pass); 0 = classic layout
-DIRECT_HUB_ROWS = os.environ.get("NPI_DIRECT_HUB_ROWS", "1") != "0"
-# one-head GATConv on the direct layout with the fused packed backward (_ShardedGatDirectFn); 0 = the classic layout always
-GAT_DIRECT = os.environ.get("NPI_GAT_DIRECT", "1") != "0"
-
 # tests set this to push a world-size-1 run through RCCL as well (the one-GPU box's only way to
 # exercise the real collectives); normally a single rank just copies
 ALWAYS_COMMUNICATE = False
@@ -407,17 +403,17 @@ class HipBackend:
         from . import functional as NF
         return NF.colsum(x)
 
-    def side_stream(self, like):
+    def side_stream(self, like, sch: Schedule = DEFAULT):
         """second HIP stream for the weight-gradient GEMM, or None when the shard is too small to gain"""
         from . import functional as NF
-        if not NF.OVERLAP_STREAMS or like.size(0) < NF.OVERLAP_MIN_ROWS:
+        if not NF._overlaps(sch, like.size(0)):
             return None
         return NF._side_stream(like.device)
 
-    def partial_stream(self, like):
+    def partial_stream(self, like, sch: Schedule = DEFAULT):
         """third HIP stream for the partial (side B) aggregation of a direction, or None for small shards"""
         from . import functional as NF
-        if not NF.OVERLAP_STREAMS or like.size(0) < NF.OVERLAP_MIN_ROWS:
+        if not (sch.partial_stream and NF._overlaps(sch, like.size(0))):
             return None
         return NF._side_stream(like.device, 1)
 
@@ -433,8 +429,8 @@ class HipBackend:
     def gat_aggregate(self, side, table, table2, H, C, a_dst, a_src, m, s, slope, by_source, bias=None,
                       g_dst=None, g_src=None, att=None, out=None):
         from . import functional as NF
-        if side.nnz_max == 0:
-            res = table.new_zeros((side.n_rows, H * C))
+        if side.nnz_max == 0:                      # a side without entries: every row is empty -- zeros, plus the bias (as gat_aggregate_scores)
+            res = table.new_zeros((side.n_rows, H * C)) if bias is None else bias.view(1, -1).expand(side.n_rows, -1).clone()
             return res if out is None else out.copy_(res)
         return NF._gat_aggregate(None, side, table, H, C, a_dst.contiguous(), a_src.contiguous(), m.contiguous(), s.contiguous(),
                                  slope, by_source, bias=bias, g_dst=g_dst, g_src=g_src, att=att, x2=table2, out=out)
@@ -484,9 +480,9 @@ class HipBackend:
         from . import functional as NF
         return NF.gat_att_grad(h, g_dst, g_src, H, C)
 
-    def linear_bwd_data_rank2_ok(self, dc, w):
+    def linear_bwd_data_rank2_ok(self, dc, w, sch: Schedule = DEFAULT):
         from . import functional as NF
-        return NF.GAT_RANK2_EPILOGUE and NF.linear_bwd_data_rank2_ok(dc, w)
+        return sch.gat_rank2_epilogue and NF.linear_bwd_data_rank2_ok(dc, w)
 
     def linear_bwd_data_rank2(self, dc, w, row0, row1, col0, col1):
         from . import functional as NF
@@ -505,8 +501,10 @@ class ShardedGraph:
     """This rank's shard of the (self-loop-augmented) graph: sides A, B and their transposes."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, device,
-                 backend=None, group=None, hub_mask: Optional[torch.Tensor] = None, sliced: bool = False):
-        """``sliced=True``: ``edge_index`` is THIS RANK'S slice of the edge list (the ranks' slices, in rank order, are
+                 backend=None, group=None, hub_mask: Optional[torch.Tensor] = None, sliced: bool = False,
+                 schedule: Schedule = DEFAULT):
+        """``schedule``: how the layers on this shard arrange their launches and collectives (``schedule.Schedule``: hub-row
+        layout, streams, split projection); the same on every rank.  ``sliced=True``: ``edge_index`` is THIS RANK'S slice of the edge list (the ranks' slices, in rank order, are
         the whole list); ``sliced=False``: the complete list, the same on every rank -- the rank then keeps only columns
         ``[rank E / W, (rank + 1) E / W)`` BEFORE anything moves to its GPU.  Either way the edges reach the ranks that
         compute with them through ``route_edges`` (an all-to-all): no GPU ever holds the whole edge list.  Without an
@@ -514,6 +512,7 @@ class ShardedGraph:
         share is cut out of it with masks -- the same entries in the same order (tests/test_dist_gloo.py)."""
         self.part = part = HubPartition(num_nodes, world, hub_mask, device)
         self.rank, self.world, self.group = rank, world, group
+        self.schedule = schedule
         self.nL, self.nH = part.n_light(rank), part.n_hub(rank)
         self.n_local = self.nL + self.nH
         self.exchange_partials = part.nL > 0                      # same answer on every rank
@@ -542,7 +541,7 @@ class ShardedGraph:
             del ei, src, dst, hub_s, hub_d, m1, m2
         self._l1, self._l2 = l1, l2                               # this rank's routed share of the edge list (~2 E / W edges)
         # no hub-hub edge anywhere (bipartite graphs): SAGE / GCN use the direct layout (direct_sides_from_routed)
-        self.direct_ok = self.exchange_partials and not hub_hub and DIRECT_HUB_ROWS
+        self.direct_ok = self.exchange_partials and not hub_hub and schedule.direct_hub_rows
         self._classic = self._direct = None
         n_b = int((~part.hub[l2[0]]).sum()) if self.exchange_partials else 0
         self.local_nnz = int(l1[0].numel()) + self.n_local + n_b  # entries this rank walks per direction
@@ -692,12 +691,10 @@ def scatter_hub_sums(sg: ShardedGraph, partial: torch.Tensor, async_op: bool = F
 
 
 # Side B (partial hub sums from the rank's own rows) needs nothing from another rank, side A needs the all-gathered hub
-# table: with B on its own HIP stream the two aggregations of a direction share the CUs (W = 1: one launch's tail under the
-# other; W > 1: A starts the moment the table has arrived instead of behind B).  NPI_PARTIAL_STREAM=0: one stream, B first.
-PARTIAL_SIDE_STREAM = os.environ.get("NPI_PARTIAL_STREAM", "1") != "0"
-# direct layout, W > 1: the projection of the light rows (complete on the rank) is launched before the reduce-scattered hub rows
-# have arrived, the hub rows' projection after them; 0: one GEMM over all rows behind the reduce-scatter
-SPLIT_PROJECTION = os.environ.get("NPI_SPLIT_PROJECTION", "1") != "0"
+# table: with B on its own HIP stream (Schedule.partial_stream) the two aggregations of a direction share the CUs (W > 1: A
+# starts the moment the table has arrived instead of behind B); otherwise one stream, B first.  Schedule.split_projection
+# (direct layout, W > 1): the projection of the light rows (complete on the rank) is launched before the reduce-scattered hub
+# rows have arrived, the hub rows' projection after them; otherwise one GEMM over all rows behind the reduce-scatter.
 
 
 def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, w_part, mean: bool, tag: str, bias=None,
@@ -721,7 +718,7 @@ def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, 
         out_full = rows.new_empty((sg.nL + sg.part.h_per, rows.size(1)))
     if sg.exchange_partials:
         # (one rank: nothing to overlap with -- the two launches of a direction share a stream, 7.30 vs 7.33 ms at C4)
-        b_stream = be.partial_stream(rows) if (PARTIAL_SIDE_STREAM and not _solo(W) and hasattr(be, "partial_stream")) else None
+        b_stream = be.partial_stream(rows, sg.schedule) if (not _solo(W) and hasattr(be, "partial_stream")) else None
         cur = None
 
         def partial_side():
@@ -771,7 +768,7 @@ class _ShardedSageFn(torch.autograd.Function):
         nrm = {"A": None, "B": None} if (sg.direct_ok or not gcn) else sg.gcn_norm()
         if sg.direct_ok:
             d, w = sg.direct(), sg.direct_weights(gcn)
-            split = SPLIT_PROJECTION and sg.nL > 0 and sg.nH > 0 and not _solo(sg.world)
+            split = sg.schedule.split_projection and sg.nL > 0 and sg.nH > 0 and not _solo(sg.world)
             agg, arrived, _ = _hub_aggregate(sg, x_own, d[0], d[1], w["A"], w["B"], not gcn, "fwd", direct=True, defer=split)
             if split:
                 # the light rows are complete on this rank: their projection runs while the hub rows are still on the wire
@@ -813,7 +810,7 @@ class _ShardedSageFn(torch.autograd.Function):
         # before the aggregations -- BOTH sides, sent to a second stream -- fill the CUs (see functional._SageConvFn); with
         # side B in front of dW, as in round 1, half of the aggregation ran alone and dW then outlasted the other half
         # (W = 1: 7.99 ms per step).  Other backends run everything in line.
-        side = be.side_stream(grad_out) if (want_w and want_x and hasattr(be, "side_stream")) else None
+        side = be.side_stream(grad_out, sg.schedule) if (want_w and want_x and hasattr(be, "side_stream")) else None
         main = torch.cuda.current_stream(grad_out.device) if side is not None else None
         if side is not None:
             side.wait_stream(main)
@@ -1079,7 +1076,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         # (one head: the statistics pass leaves the per-entry scores and the aggregation reads them back)
         out_full = h.new_empty((nL + hp, F))
         hU, wU = out_full[nL:], None                                               # the reduce-scatter lands in the output
-        bs = be.partial_stream(h) if (PARTIAL_SIDE_STREAM and not _solo(W) and hasattr(be, "partial_stream")) else None
+        bs = be.partial_stream(h, sg.schedule) if (not _solo(W) and hasattr(be, "partial_stream")) else None
         with _fork(bs, (h, a_src, tbl_a_dst, out_full)) as fk:
             if H == 1:
                 mB, sB, eB = be.gat_stats_scores(B, tbl_a_dst, a_src, slope)
@@ -1162,7 +1159,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         be.gat_pack(tbl_a_dst, M, tbl_S, tbl_D, out=t_all[:n_tbl])
         # hub SOURCES (rows of the hub table): targets = this rank's rows (its light rows; the own hubs' loops): nothing remote,
         # so this pass and its row sums run on the partial stream beside the light sources' pass
-        bs = be.partial_stream(h) if (PARTIAL_SIDE_STREAM and not _solo(W) and hasattr(be, "partial_stream")) else None
+        bs = be.partial_stream(h, sg.schedule) if (not _solo(W) and hasattr(be, "partial_stream")) else None
         with _fork(bs, (dO, tbl_h, t_own, tbl_a_src)) as fk:
             pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope, H=H)
             dz_bt = dz_bt.view(-1, H)
@@ -1182,7 +1179,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         # (functional._GatConvFn._backward_rank2).  d h is then final as soon as its hub rows have been reduce-scattered, so
         # that exchange is issued FIRST and the weight-gradient GEMM runs on the side stream under the row sums of dz below.
         rank2 = (H == 1 and ctx.needs_input_grad[0] and weight.size(0) % 4 == 0 and hasattr(be, "linear_bwd_data_rank2")
-                 and be.linear_bwd_data_rank2_ok(dh, weight))
+                 and be.linear_bwd_data_rank2_ok(dh, weight, sg.schedule))
         wh = dws = None
         if not _solo(W):
             wh = reduce_scatter_rows(pdh, dh_full[nL:], sg.rank, W, sg.group, async_op=True)
@@ -1190,7 +1187,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
             dh_full[nL:].copy_(pdh)
         dw = None
         if rank2 and ctx.needs_input_grad[1]:
-            dws = be.side_stream(dh) if hasattr(be, "side_stream") else None
+            dws = be.side_stream(dh, sg.schedule) if hasattr(be, "side_stream") else None
             with _fork(dws, (x_own, dh_full, pdh)) as fw:
                 _wait(wh, "bwd_reduce_scatter", dh_full)
                 wh = None
@@ -1277,7 +1274,7 @@ class ShardedGATLayer(_ShardedLayer):
         H = self.heads
         C = self.weight.size(1) // H
         fused_ok = C % 4 == 0 and H * C <= 256 and (H == 1 or (H in (2, 4, 8) and C in (32, 64, 128)))
-        if GAT_DIRECT and fused_ok and self.sg.direct_ok and hasattr(self.sg.backend, "gat_backward_fused"):
+        if self.sg.schedule.gat_direct and fused_ok and self.sg.direct_ok and hasattr(self.sg.backend, "gat_backward_fused"):
             return _ShardedGatDirectFn.apply(x_own, self.weight, self.att, self.bias, self.sg, H, self.negative_slope)
         return _ShardedGatFn.apply(x_own, self.weight, self.att, self.bias, self.sg, self.heads, self.negative_slope)
 

@@ -9,13 +9,13 @@ Formulas (PyG 1.4.2):
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
 
 from ._lib import NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, check, load, ptr, require_gpu, stream_ptr
 from .graph import CSRGraph, CSRSide, as_graph
+from .schedule import DEFAULT, Schedule
 
 
 _PROFILE = None     # bench.py sets this to a list to collect (start, end) events per segsum launch
@@ -69,10 +69,12 @@ class _gemm_events:
 # registers free) runs on a side stream under the dX chain, whose aggregation is HBM-bound: the two then
 # share every CU instead of queueing.  Measured at C4: 8.0 -> 7.1 ms per step.  (With the dW grid
 # filling the chip twice over, as before, the same overlap gained 1 %.)  Only for graphs large enough
-# for the kernels to outlast the stream bookkeeping; NPI_OVERLAP_STREAMS=0 turns it off.
-OVERLAP_STREAMS = os.environ.get("NPI_OVERLAP_STREAMS", "1") != "0"
-OVERLAP_MIN_ROWS = 100_000
+# for the kernels to outlast the stream bookkeeping (Schedule.overlap_streams / overlap_min_rows).
 _SIDE_STREAMS = {}
+
+
+def _overlaps(sch: Schedule, rows: int) -> bool:
+    return sch.overlap_streams and rows >= sch.overlap_min_rows
 
 
 def _side_stream(dev, k: int = 0) -> "torch.cuda.Stream":
@@ -102,6 +104,15 @@ def _code(t: torch.Tensor) -> int:
     return NPI_BF16 if t.dtype == torch.bfloat16 else NPI_F32
 
 
+def _check_out(out: torch.Tensor, rows: int, cols: int, like: torch.Tensor, what: str) -> None:
+    """``out=`` buffers go straight to a kernel that writes ``rows`` rows of ``cols`` elements: anything else would be an
+    out-of-bounds device write, so it is an error here (a slice of a larger buffer with a row pitch is fine)"""
+    if (out.dim() != 2 or out.size(0) != rows or out.size(1) != cols or out.dtype != like.dtype or out.stride(1) != 1
+            or out.device != like.device):
+        raise ValueError(f"{what}: out must be [{rows}, {cols}] {like.dtype} with unit column stride on {like.device} "
+                         f"(got {tuple(out.shape)} {out.dtype}, strides {tuple(out.stride())}, {out.device})")
+
+
 # ---------------------------------------------------------------------------------------------
 # raw ops
 # ---------------------------------------------------------------------------------------------
@@ -129,12 +140,14 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
         raise ValueError(f"the table has {split + (x2.size(0) if x2 is not None else 0)} rows, the adjacency indexes {side.n_cols}")
     if out is None:
         out = torch.empty((N, F), dtype=x.dtype, device=dev)
+    else:
+        _check_out(out, N, F, x, "segsum")
     carry = side.carry(F)
     prof = _PROFILE
     if prof is not None:        # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(dev))
-    check(load().npi_segsum_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), ptr(w), N, side.nnz_max,
+    check(load().npi_segsum_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.item, ptr(w), N, side.nnz_max,
                                ptr(x), x.stride(0), ptr(x2), split if x2 is not None else 0, ptr(out), out.stride(0), F,
                                _code(x), 1 if mean else 0, ptr(bias), ptr(carry), stream_ptr(dev)), "npi_segsum")
     if prof is not None:
@@ -385,7 +398,7 @@ def entry_weights(graph: CSRGraph, edge_weight: Optional[torch.Tensor], fill: fl
 # ---------------------------------------------------------------------------------------------
 class _SageConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, graph: CSRGraph, w_entry=None, relu: bool = False):
+    def forward(ctx, x, weight, bias, graph: CSRGraph, w_entry=None, relu: bool = False, sch: Schedule = DEFAULT):
         # a2-a4: gather + scatter_mean (w_entry: PyG's `edge_weight.view(-1, 1) * x_j`; the mean still divides by the count)
         # x may be the zero-padded base of the caller's features (sage_conv): agg then keeps the padded width -- zero
         # columns stay zero under a weighted mean -- and both GEMMs run on it (linear_fwd / linear_bwd_weight)
@@ -396,6 +409,7 @@ class _SageConvFn(torch.autograd.Function):
         ctx.w_src = w_entry[1] if w_entry else None
         ctx.has_bias = bias is not None
         ctx.relu = relu
+        ctx.sch = sch
         ctx.save_for_backward(agg, weight, *([out] if relu else []))
         return out
 
@@ -411,7 +425,7 @@ class _SageConvFn(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         # symmetric edge list, no per-entry weights: A^T has the rows of A (graph.CSRGraph.symmetric) -- skip the second sort
         tside = (lambda: graph.by_dst) if (graph.symmetric and ctx.w_src is None) else (lambda: graph.by_src)
-        overlap = want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS
+        overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
         if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)   # aggT dOut, colsum
         if want_x:
@@ -435,12 +449,12 @@ class _SageConvFn(torch.autograd.Function):
                 main.wait_stream(side)
             else:
                 dx = segsum(graph, tside(), dagg, w=ctx.w_src, mean=False)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
               normalize: bool = False, edge_weight: Optional[torch.Tensor] = None, relu: bool = False,
-              pad_base: Optional[torch.Tensor] = None) -> torch.Tensor:
+              pad_base: Optional[torch.Tensor] = None, schedule: Schedule = DEFAULT) -> torch.Tensor:
     """PyG 1.4.2 ``SAGEConv(normalize=False, concat=False).forward`` on MI355X
     (call sites: reference ``src/classes.py:62,66,70``).  ``edge_weight [E]`` scales the messages
     (no gradient flows to it, as in the reference's use of the layer).  ``pad_base``: the wider buffer ``x`` is the leading
@@ -458,7 +472,7 @@ def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[
         x = base
     if relu and normalize:
         raise ValueError("sage_conv: relu=True applies to the projection's output; normalize=True comes after it in PyG")
-    out = _SageConvFn.apply(x, weight, bias, graph, w_entry, relu)
+    out = _SageConvFn.apply(x, weight, bias, graph, w_entry, relu, schedule)
     if normalize:
         out = l2_normalize(out)
     return out
@@ -501,6 +515,8 @@ class GCNNorm:
 
 
 class _GcnConvFn(torch.autograd.Function):
+    """PyG's literal order: project, then aggregate at width F_out (used when F_in > F_out, e.g. C1's 178 -> 64)."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, norm: GCNNorm):
         graph = norm.graph
@@ -537,12 +553,13 @@ class _GcnAggFirstFn(torch.autograd.Function):
     cores UNDER it (second stream), and the aggregations run at the narrower width (C3's first layer: 178 instead of 256)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, norm: GCNNorm):
+    def forward(ctx, x, weight, bias, norm: GCNNorm, sch: Schedule = DEFAULT):
         graph = norm.graph
         agg = segsum(graph, graph.by_dst, x, w=norm.by_dst)                    # sum_e norm_e x[src]
         out = linear_fwd(agg, weight, bias)
         ctx.norm = norm
         ctx.has_bias = bias is not None
+        ctx.sch = sch
         ctx.save_for_backward(agg, weight)
         return out
 
@@ -555,7 +572,7 @@ class _GcnAggFirstFn(torch.autograd.Function):
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
-        overlap = want_w and want_x and OVERLAP_STREAMS and grad_out.size(0) >= OVERLAP_MIN_ROWS
+        overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
         if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
         if want_x:
@@ -573,25 +590,22 @@ class _GcnAggFirstFn(torch.autograd.Function):
                 main.wait_stream(side)
             else:
                 dx = segsum(graph, graph.by_src, dagg, w=norm.by_src)
-        return dx, dw, db, None
-
-
-# GCNConv: aggregate first when the input is not wider than the output (see _GcnAggFirstFn); NPI_GCN_AGG_FIRST=0 keeps PyG's
-# literal order (project, then aggregate) everywhere
-GCN_AGG_FIRST = os.environ.get("NPI_GCN_AGG_FIRST", "1") != "0"
+        return dx, dw, db, None, None
 
 
 def gcn_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
              edge_weight: Optional[torch.Tensor] = None, improved: bool = False,
-             norm: Optional[GCNNorm] = None) -> torch.Tensor:
-    """PyG 1.4.2 ``GCNConv.forward`` (normalize=True) on MI355X."""
+             norm: Optional[GCNNorm] = None, schedule: Schedule = DEFAULT) -> torch.Tensor:
+    """PyG 1.4.2 ``GCNConv.forward`` (normalize=True) on MI355X.  Evaluated as ``(A_hat x) W + b`` when the input is not wider
+    than the output (``_GcnAggFirstFn``: the aggregation at the narrower width, dW under the backward aggregation), in PyG's
+    literal order ``A_hat (x W) + b`` otherwise -- the same number up to fp32 rounding."""
     require_gpu(x, weight, bias)
     if edge_weight is not None and edge_weight.requires_grad:
         raise NotImplementedError("gradients w.r.t. edge_weight are not implemented")
     if norm is None:
         norm = GCNNorm(as_graph(edge_index, x.size(0)), edge_weight, improved)
-    if GCN_AGG_FIRST and weight.size(0) <= weight.size(1):
-        return _GcnAggFirstFn.apply(x, weight, bias, norm)
+    if weight.size(0) <= weight.size(1):
+        return _GcnAggFirstFn.apply(x, weight, bias, norm, schedule)
     return _GcnConvFn.apply(x, weight, bias, norm)
 
 
@@ -630,17 +644,12 @@ def _inverse_transpose_map(graph: CSRGraph) -> torch.Tensor:
     return inv
 
 
-# GATConv backward, one head of <= 256 channels: ONE gather pass over the by-source entries produces both the aggregation
-# half of d hfeat and the per-entry score gradient (npi_gat_backward_fused), with alpha stored by the forward -- instead of
-# npi_gat_edge_grad (a gather pass over the by-target entries) followed by the by-source aggregation.
-GAT_FUSED_BACKWARD = os.environ.get("NPI_GAT_FUSED", "1") != "0"
-GAT_PACKED_BACKWARD = os.environ.get("NPI_GAT_PACKED", "1") != "0"
-# one head: the attention terms of d hfeat, g_dst (x) att_dst + g_src (x) att_src, are never added to d hfeat (a read-modify-write
-# pass over [N, C]); dX takes them in the store epilogue of its GEMM (rank 2: g (x) W att), dW as an outer-product correction
-# built from x^T g -- the same pass over x that yields d att.  0: the separate npi_gat_rank1_add pass
-GAT_RANK2_EPILOGUE = os.environ.get("NPI_GAT_RANK2", "1") != "0"
-# ... from this many rows on: below, the three [2, .] products it needs cost more than the pass over d hfeat they replace
-GAT_RANK2_MIN_ROWS = int(os.environ.get("NPI_GAT_RANK2_MIN_ROWS", "100000"))
+def gat_fused_shape(H: int, C: int) -> bool:
+    """Shapes the fused backward serves (``npi_gat_backward_fused_heads``): ONE gather pass over the by-source entries yields
+    the aggregation half of d hfeat AND every entry's score gradient -- one head of <= 256 channels, or 2 / 4 / 8 heads of
+    32 / 64 / 128 channels with H C <= 256.  Everything else takes ``npi_gat_edge_grad`` (a gather pass over the by-target
+    entries) followed by the by-source aggregation."""
+    return C % 4 == 0 and H * C <= 256 and (H == 1 or (H in (2, 4, 8) and C in (32, 64, 128)))
 
 
 def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, bias=None, g_dst=None,
@@ -654,7 +663,9 @@ def _gat_aggregate(graph, side, x, H, C, a_dst, a_src, m, s, slope, by_source, b
             raise ValueError("the two parts of the table must share the row pitch")
     if out is None:
         out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
-    check(load().npi_gat_aggregate_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
+    else:
+        _check_out(out, side.n_rows, H * C, x, "gat_aggregate")
+    check(load().npi_gat_aggregate_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.item, side.n_rows, side.nnz_max,
                                       ptr(x), x.stride(0), ptr(x2), x.size(0) if x2 is not None else 0,
                                       ptr(out), out.stride(0), H, C, ptr(a_dst), ptr(a_src),
                                       ptr(m), ptr(s), float(slope), 1 if by_source else 0, ptr(bias), ptr(g_dst),
@@ -674,33 +685,22 @@ def gat_scores(hfeat, att2, H, C):
     return a_dst, a_src
 
 
-# Row reductions of per-entry scalars (softmax statistics, row sums of dz): stream the ENTRIES item by item with a segmented
-# scan (csrc/segscan.hip) instead of walking every row with a lane group; NPI_GAT_ITEMS=0 keeps the round-2 kernels.
-GAT_ITEM_SCANS = os.environ.get("NPI_GAT_ITEMS", "1") != "0"
-
-
 def gat_softmax_stats(side: CSRSide, a_row, a_col, H, slope, want_scores: bool = False):
     """(m, s) [n_rows, H]: row max and sum of exp(. - max) of leaky_relu(a_row[row] + a_col[col]) over the entries of
-    every row of ``side`` (an empty row gets m = 0, s = 0).  ``want_scores``: also the score of every entry
-    ``[nnz_max, H]`` (entry order), for ``npi_gat_aggregate_scores`` -- returns (m, s, scores)."""
+    every row of ``side`` (an empty row gets m = 0, s = 0); item-parallel segmented scan (``npi_gat_softmax_stats_ex``).
+    ``want_scores``: also the score of every entry ``[nnz_max, H]`` (entry order), for ``npi_gat_aggregate_scores`` --
+    returns (m, s, scores)."""
     lib = load()
     dev = a_row.device
     m = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
     s = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
-    if GAT_ITEM_SCANS or want_scores:
-        n_ws = int(lib.npi_seg_scan_workspace_elems(side.nnz_max, H))
-        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
-        e = torch.empty((max(side.nnz_max, 1), H), dtype=torch.float32, device=dev) if want_scores else None
-        check(lib.npi_gat_softmax_stats_ex(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(a_row), ptr(a_col),
-                                           side.n_rows, side.nnz_max, H, float(slope), ptr(m), ptr(s), ptr(e), ptr(ws), n_ws,
-                                           stream_ptr(dev)), "npi_gat_softmax_stats_ex")
-        return (m, s, e) if want_scores else (m, s)
-    n_hw = int(lib.npi_gat_heavy_workspace_elems(side.nnz_max, H))
-    hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
-    check(lib.npi_gat_softmax_stats(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), ptr(a_row), ptr(a_col),
-                                    side.n_rows, side.nnz_max, H, float(slope), ptr(m), ptr(s), ptr(hws), n_hw,
-                                    stream_ptr(dev)), "npi_gat_softmax_stats")
-    return m, s
+    n_ws = int(lib.npi_seg_scan_workspace_elems(side.nnz_max, H))
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+    e = torch.empty((max(side.nnz_max, 1), H), dtype=torch.float32, device=dev) if want_scores else None
+    check(lib.npi_gat_softmax_stats_ex(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(a_row), ptr(a_col),
+                                       side.n_rows, side.nnz_max, H, float(slope), ptr(m), ptr(s), ptr(e), ptr(ws), n_ws,
+                                       stream_ptr(dev)), "npi_gat_softmax_stats_ex")
+    return (m, s, e) if want_scores else (m, s)
 
 
 def gat_rowdot(a, b, bias, H, C):
@@ -723,7 +723,7 @@ def gat_rowdot_colsum(a, b, bias, H, C, want_colsum: bool = True, relu_mask: boo
     N = a.size(0)
     ok = (C % 4 == 0 and H * C <= 1024 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
           and b.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
-    if not ok or not GAT_ITEM_SCANS:
+    if not ok:
         if relu_mask:
             a = relu_backward(a, b)
         res = (gat_rowdot(a, b, bias, H, C), (colsum(a) if want_colsum else None))
@@ -750,14 +750,17 @@ def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=Non
             raise ValueError("the two parts of the table must share the row pitch")
     if out is None:
         out = torch.empty((side.n_rows, C), dtype=torch.float32, device=dev)
+    else:
+        _check_out(out, side.n_rows, C, table, "gat_aggregate_scores")
     if side.nnz_max == 0:
         out = out.zero_() if bias is None else out.copy_(bias.view(1, -1).expand_as(out))
         return out.clamp_(min=0) if relu else out
     with _tag_events("gat_fwd_aggregate", dev):
-        check(load().npi_gat_aggregate_scores(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.n_rows, side.nnz_max,
-                                              ptr(table), table.stride(0), ptr(table2), table.size(0) if table2 is not None else 0,
-                                              ptr(out), out.stride(0), C, ptr(scores), ptr(m), ptr(s), ptr(bias), 1 if relu else 0,
-                                              None, ptr(side.carry(C)), stream_ptr(dev)), "npi_gat_aggregate_scores")
+        check(load().npi_gat_aggregate_scores(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.item, side.n_rows,
+                                              side.nnz_max, ptr(table), table.stride(0), ptr(table2),
+                                              table.size(0) if table2 is not None else 0, ptr(out), out.stride(0), C, ptr(scores),
+                                              ptr(m), ptr(s), ptr(bias), 1 if relu else 0, ptr(side.carry(C)), stream_ptr(dev)),
+              "npi_gat_aggregate_scores")
     return out
 
 
@@ -787,11 +790,13 @@ def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_
     hrow = _f32c(hrow, "hrow")
     if out is None:
         out = torch.empty((side.n_rows, H * C), dtype=torch.float32, device=dev)
+    else:
+        _check_out(out, side.n_rows, H * C, dout, "gat_backward_fused_packed")
     dz = torch.empty(max(side.nnz_max, 1) * H, dtype=torch.float32, device=dev)
     if side.nnz_max == 0:
         return out.zero_(), dz
     with _tag_events("gat_bwd_fused", dev):
-        check(load().npi_gat_backward_fused_heads(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row),
+        check(load().npi_gat_backward_fused_heads(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
                                                   side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
                                                   dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
                                                   out.stride(0), H, C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
@@ -832,16 +837,10 @@ def seg_rowsum(side: CSRSide, vals, H, map_=None):
     lib = load()
     dev = vals.device
     out = torch.empty((side.n_rows, H), dtype=torch.float32, device=dev)
-    if GAT_ITEM_SCANS:
-        n_ws = int(lib.npi_seg_scan_workspace_elems(side.nnz_max, H))
-        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
-        check(lib.npi_seg_rowsum_ex(ptr(side.rowptr), ptr(side.rowidx), ptr(vals), ptr(map_), side.n_rows, side.nnz_max, H,
-                                    ptr(out), ptr(ws), n_ws, stream_ptr(dev)), "npi_seg_rowsum_ex")
-        return out
-    n_hw = int(lib.npi_gat_heavy_workspace_elems(side.nnz_max, H))
-    hws = torch.empty(n_hw, dtype=torch.float32, device=dev)
-    check(lib.npi_seg_rowsum(ptr(side.rowptr), ptr(side.item_row), ptr(vals), ptr(map_), side.n_rows, side.nnz_max, H,
-                             ptr(out), ptr(hws), n_hw, stream_ptr(dev)), "npi_seg_rowsum")
+    n_ws = int(lib.npi_seg_scan_workspace_elems(side.nnz_max, H))
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+    check(lib.npi_seg_rowsum_ex(ptr(side.rowptr), ptr(side.rowidx), ptr(vals), ptr(map_), side.n_rows, side.nnz_max, H,
+                                ptr(out), ptr(ws), n_ws, stream_ptr(dev)), "npi_seg_rowsum_ex")
     return out
 
 
@@ -861,52 +860,42 @@ class _GatConvFn(torch.autograd.Function):
     """Returns the concatenated heads [N, H*C] (bias fused when given)."""
 
     @staticmethod
-    def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float, relu: bool = False):
+    def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float, relu: bool = False,
+                sch: Schedule = DEFAULT):
         H = int(heads)
         C = weight.size(1) // H
         att2 = _f32c(att.reshape(H, 2 * C), "att")
         hfeat = linear_fwd(x, weight)                                        # x @ W
         a_dst, a_src = gat_scores(hfeat, att2, H, C)
         d = graph.by_dst
-        # the fused backward: one head of <= 256 channels, or 2 / 4 / 8 heads of 32 / 64 / 128 channels with H C <= 256 (packed form)
-        fused = (GAT_FUSED_BACKWARD and C % 4 == 0 and H * C <= 256 and any(ctx.needs_input_grad[:4])
-                 and (H == 1 or (GAT_PACKED_BACKWARD and H in (2, 4, 8) and C in (32, 64, 128))))
-        # one head, NPI_GAT_PACKED=0: the forward also stores alpha of every entry (by-target order) and the backward reads it
-        # back through the transpose map; default: the backward recomputes alpha from packed per-target scalars
-        alpha = torch.empty(max(d.nnz_max, 1), dtype=torch.float32, device=x.device) if (fused and not GAT_PACKED_BACKWARD) else None
-        if GAT_ITEM_SCANS and H == 1 and C % 4 == 0 and d.nnz_max > 0:
+        if H == 1 and C % 4 == 0 and d.nnz_max > 0:
             # the statistics pass leaves the score of every entry; the aggregation reads it back (one coalesced load per
             # 64 entries) instead of gathering a_src[j] per entry and redoing the leaky_relu
             m, s, scores = gat_softmax_stats(d, a_dst, a_src, H, slope, want_scores=True)
-            out = torch.empty((d.n_rows, C), dtype=torch.float32, device=x.device)
-            with _tag_events("gat_fwd_aggregate", x.device):
-                check(load().npi_gat_aggregate_scores(ptr(d.rowptr), ptr(d.col), ptr(d.item_row), d.n_rows, d.nnz_max,
-                                                      ptr(hfeat), hfeat.stride(0), None, 0, ptr(out), out.stride(0), C,
-                                                      ptr(scores), ptr(m), ptr(s), ptr(bias), 1 if relu else 0, ptr(alpha),
-                                                      ptr(d.carry(C)), stream_ptr(x.device)), "npi_gat_aggregate_scores")
+            out = gat_aggregate_scores(d, hfeat, None, C, scores, m, s, bias=bias, relu=relu)
             del scores
         else:
             m, s = gat_softmax_stats(d, a_dst, a_src, H, slope)
-            out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias, alpha=alpha)
+            out = _gat_aggregate(graph, d, hfeat, H, C, a_dst, a_src, m, s, slope, False, bias=bias)
             if relu:                                     # several heads / odd widths: the ReLU as its own pass
                 out = torch.relu_(out)
         ctx.relu = bool(relu)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
         ctx.has_bias = bias is not None
-        ctx.fused = fused
+        ctx.sch = sch
         ctx.save_for_backward(x, weight, att2, hfeat, a_dst, a_src, m, s, out,
-                              bias if bias is not None else torch.empty(0, device=x.device),
-                              alpha if alpha is not None else torch.empty(0, device=x.device))
+                              bias if bias is not None else torch.empty(0, device=x.device))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight, att2, hfeat, a_dst, a_src, m, s, out, bias, alpha_fwd = ctx.saved_tensors
+        x, weight, att2, hfeat, a_dst, a_src, m, s, out, bias = ctx.saved_tensors
         graph: CSRGraph = ctx.graph
-        H, C, slope = ctx.H, ctx.C, ctx.slope
+        H, C, slope, sch = ctx.H, ctx.C, ctx.slope, ctx.sch
         dev = x.device
         grad_out = _f32c(grad_out, "grad_out")
         d, sr = graph.by_dst, graph.by_src
+        N = graph.num_nodes
         # D_i = <dOut_i, out_i - b> = sum_p alpha_p dalpha_p  (softmax backward) and db = column sums of dOut: one pass
         # (a fused ReLU: the same pass masks the gradient first and hands the masked gradient on)
         if ctx.relu:
@@ -915,75 +904,48 @@ class _GatConvFn(torch.autograd.Function):
         else:
             D, db = gat_rowdot_colsum(grad_out, out, bias if ctx.has_bias else None, H, C,
                                       want_colsum=ctx.has_bias and ctx.needs_input_grad[3])
-        if ctx.fused:
-            N = graph.num_nodes
-            dz = torch.empty(max(sr.nnz_max, 1) * H, dtype=torch.float32, device=dev)
-            dh = torch.empty((N, H * C), dtype=torch.float32, device=dev)
-            if alpha_fwd.numel() == 0:
-                # packed form: (a_dst, m, 1/s, D) of every (target, head) in one float4; alpha is recomputed per entry by one lane
-                tpack = gat_pack_targets(a_dst, m, s, D)                       # [N H, 4]
-                with _tag_events("gat_bwd_fused", dev):
-                    check(load().npi_gat_backward_fused_heads(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N,
-                                                              sr.nnz_max, ptr(grad_out), grad_out.stride(0), None, 0, ptr(hfeat),
-                                                              hfeat.stride(0), ptr(dh), dh.stride(0), H, C, ptr(tpack), ptr(a_src),
-                                                              slope, ptr(dz), ptr(sr.carry(H * C)), stream_ptr(dev)),
-                          "npi_gat_backward_fused_heads")
-            else:
-                tm = _transpose_map(graph)
-                check(load().npi_gat_backward_fused(ptr(sr.rowptr), ptr(sr.col), ptr(sr.rowidx), ptr(sr.item_row), N, sr.nnz_max,
-                                                    ptr(grad_out), grad_out.stride(0), ptr(hfeat), hfeat.stride(0), ptr(dh),
-                                                    dh.stride(0), C, ptr(a_dst), ptr(a_src), ptr(D), slope, ptr(alpha_fwd), ptr(tm),
-                                                    ptr(dz), ptr(sr.carry(C)), stream_ptr(dev)), "npi_gat_backward_fused")
+        if gat_fused_shape(H, C):
+            # (a_dst, m, 1/s, D) of every (target, head) in one float4; alpha is recomputed per entry by the lane that owns it
+            tpack = gat_pack_targets(a_dst, m, s, D)                           # [N H, 4]
+            dh, dz = gat_backward_fused_packed(sr, grad_out, None, hfeat, C, tpack, a_src, slope, H=H)
             dz = dz.view(-1, H)
             g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
             g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
-            if (GAT_RANK2_EPILOGUE and H == 1 and N >= GAT_RANK2_MIN_ROWS and ctx.needs_input_grad[0] and x.dtype == torch.float32
-                    and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight)):
+            if (sch.gat_rank2_epilogue and H == 1 and N >= sch.gat_rank2_min_rows and ctx.needs_input_grad[0]
+                    and x.dtype == torch.float32 and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight)):
                 return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, g_dst, g_src, db, C)
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
-            check(load().npi_gat_rank1_add(ptr(dh), dh.stride(0), ptr(g_dst), ptr(g_src), ptr(att2), N, H, C, stream_ptr(dev)),
-                  "npi_gat_rank1_add")
-            # datt streams hfeat once (HBM-bound) and depends only on g_dst / g_src; the two GEMMs that follow are MFMA-bound:
-            # on large graphs the attention gradient runs on the side stream UNDER them
-            overlap = (ctx.needs_input_grad[2] and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and OVERLAP_STREAMS
-                       and N >= OVERLAP_MIN_ROWS)
-            datt = None
-            if overlap:
-                main = torch.cuda.current_stream(dev)
-                side = _side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
-                for t in (hfeat, g_dst, g_src):
-                    t.record_stream(side)
-                datt.record_stream(main)
-            elif ctx.needs_input_grad[2]:
-                datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
-            dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
-            dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
-            if overlap:
-                main.wait_stream(side)
-            return dx, dw, datt, db, None, None, None, None
-        # dz per by-target entry, then its row sums in both orientations;
-        # one head: keep the alpha this kernel computes; the by-source pass reads it back through the transpose map
-        alpha = torch.empty((max(d.nnz_max, 1), H), dtype=torch.float32, device=dev) if H == 1 else None
-        dz = gat_edge_grad(d, hfeat, None, grad_out, H, C, a_dst, a_src, m, s, D, slope, 0, alpha_out=alpha)
-        g_dst = seg_rowsum(d, dz, H)
-        g_src = seg_rowsum(sr, dz, H, map_=_transpose_map(graph))
-        # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
-        dh = _gat_aggregate(graph, sr, grad_out, H, C, a_dst, a_src, m, s, slope, True,
-                            g_dst=g_dst, g_src=g_src, att=att2, alpha=alpha,
-                            alpha_map=_transpose_map(graph) if alpha is not None else None)
+            gat_rank1_add(dh, g_dst, g_src, att2, H, C)
+        else:
+            # dz per by-target entry, then its row sums in both orientations;
+            # one head: keep the alpha this kernel computes; the by-source pass reads it back through the transpose map
+            alpha = torch.empty((max(d.nnz_max, 1), H), dtype=torch.float32, device=dev) if H == 1 else None
+            dz = gat_edge_grad(d, hfeat, None, grad_out, H, C, a_dst, a_src, m, s, D, slope, 0, alpha_out=alpha)
+            g_dst = seg_rowsum(d, dz, H)
+            g_src = seg_rowsum(sr, dz, H, map_=_transpose_map(graph))
+            dh = _gat_aggregate(graph, sr, grad_out, H, C, a_dst, a_src, m, s, slope, True,
+                                g_dst=g_dst, g_src=g_src, att=att2, alpha=alpha,
+                                alpha_map=_transpose_map(graph) if alpha is not None else None)
+        # datt streams hfeat once (HBM-bound) and depends only on g_dst / g_src; the two GEMMs that follow are MFMA-bound:
+        # on large graphs the attention gradient runs on the side stream UNDER them
+        overlap = (ctx.needs_input_grad[2] and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and _overlaps(sch, N))
         datt = None
-        if ctx.needs_input_grad[2]:
+        if overlap:
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
+            for t in (hfeat, g_dst, g_src):
+                t.record_stream(side)
+            datt.record_stream(main)
+        elif ctx.needs_input_grad[2]:
             datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
-        dw = dx = None
-        if ctx.needs_input_grad[1]:
-            dw, _ = linear_bwd_weight(x, dh, want_bias=False)
-        if ctx.needs_input_grad[0]:
-            dx = linear_bwd_data(dh, weight)
-        return dx, dw, datt, db, None, None, None, None
-
+        dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+        dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
+        if overlap:
+            main.wait_stream(side)
+        return dx, dw, datt, db, None, None, None, None, None
 
     @staticmethod
     def _backward_rank2(ctx, x, weight, att2, dh, g_dst, g_src, db, C):
@@ -999,7 +961,7 @@ class _GatConvFn(torch.autograd.Function):
         A = att2.view(2, C)                                                   # rows a1, a2
         U = gat_rank2_cols(weight, A)                                         # [2, K]: W a1, W a2
         main = torch.cuda.current_stream(dev)
-        overlap = OVERLAP_STREAMS and x.size(0) >= OVERLAP_MIN_ROWS
+        overlap = _overlaps(ctx.sch, x.size(0))
         side = _side_stream(dev) if overlap else main
         if overlap:
             side.wait_stream(main)
@@ -1016,20 +978,20 @@ class _GatConvFn(torch.autograd.Function):
         datt = gat_rank2_tail(P, weight, A, dw, ctx.needs_input_grad[2])
         if datt is not None:
             datt = datt.view(1, 1, 2 * C)
-        return dx, dw, datt, db, None, None, None, None
+        return dx, dw, datt, db, None, None, None, None, None
 
 
 def gat_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, att: torch.Tensor,
              bias: Optional[torch.Tensor] = None, heads: int = 1, concat: bool = True,
-             negative_slope: float = 0.2, relu: bool = False) -> torch.Tensor:
+             negative_slope: float = 0.2, relu: bool = False, schedule: Schedule = DEFAULT) -> torch.Tensor:
     """PyG 1.4.2 ``GATConv.forward`` (dropout = 0) on MI355X; ``att`` is ``[1, H, 2C]``.  ``relu=True`` (an extension, as in
     ``sage_conv``): ``F.relu(conv(x, edge_index))`` with the ReLU in the aggregation's row epilogue and its backward mask in the
     pass that computes the softmax term -- one head; other shapes apply it as a separate pass."""
     require_gpu(x, weight, att, bias)
     graph = as_graph(edge_index, x.size(0))
     if concat:
-        return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope, relu)
-    out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope, False)
+        return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope, relu, schedule)
+    out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope, False, schedule)
     out = out.view(x.size(0), heads, -1).mean(dim=1)          # head average (concat=False)
     out = out + bias if bias is not None else out
     return torch.relu(out) if relu else out

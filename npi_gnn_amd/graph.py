@@ -49,6 +49,23 @@ def raise_on_status(values) -> None:
     if any(int(v) & 1 for v in values):
         raise IndexError("edge_index holds a node id outside [0, num_nodes): the edges were dropped by the graph build "
                          "(PyG's index_select / scatter raise here)")
+    if any(int(v) & 4 for v in values):
+        raise ValueError("InteractionGraph.batch: the n_nodes / n_pairs it was given do not belong to its keys (the device counted "
+                         "other totals); nothing was written -- that batch's tensors are uninitialised.  Totals must come from "
+                         "sizes() of the same keys")
+
+
+def note_status(status: torch.Tensor) -> None:
+    """File a device status word: checked at once under ``set_debug(True)``, otherwise at the next device read of this package
+    (or after ``_PENDING_MAX`` unchecked words); never during a HIP-graph capture."""
+    if torch.cuda.is_current_stream_capturing():
+        return                                # no reads inside a capture, and the word lives in the graph's pool
+    if _DEBUG:
+        raise_on_status([status.item()])
+        return
+    _PENDING.append(status)
+    if len(_PENDING) > _PENDING_MAX:
+        check_pending()
 
 
 def check_pending() -> None:
@@ -65,7 +82,9 @@ def check_pending() -> None:
 @dataclass
 class CSRSide:
     """One orientation.  ``rowptr[N+1]``, ``col/eid/rowidx[nnz_max]`` int32 in entry order;
-    ``item_row`` maps every 256-entry item to its first row; ``rowptr[N]`` is nnz on device."""
+    ``item_row`` maps every item of ``item`` entries (64 or 256: fixed when the side is built, and handed to every kernel that
+    walks ``item_row`` -- no process-wide setting can change the meaning of an existing side) to its first row;
+    ``rowptr[N]`` is nnz on device."""
     rowptr: torch.Tensor
     col: torch.Tensor
     eid: torch.Tensor
@@ -78,6 +97,7 @@ class CSRSide:
     _carry: Dict[int, torch.Tensor] = field(default_factory=dict)
     n_rows: int = -1          # output rows (key id space)
     n_cols: int = -1          # rows of the feature table the entries index (== n_rows unless sharded)
+    item: int = 0             # entries per item this side was cut with
 
     def inv_count(self) -> torch.Tensor:
         """1 / max(row length, 1): the scatter_mean divisor (count includes the self loop)."""
@@ -93,21 +113,31 @@ class CSRSide:
         """f32 scratch for rows cut by an item boundary; reused across calls of the same width."""
         buf = self._carry.get(F)
         if buf is None:
-            n = int(load().npi_segsum_carry_elems(self.nnz_max, F))
+            n = int(load().npi_segsum_carry_elems(self.nnz_max, self.item, F))
             buf = torch.empty(n, dtype=torch.float32, device=self.rowptr.device)
             self._carry[F] = buf
         return buf
 
 
+def item_hint(nnz_max: int) -> int:
+    """Recommended item size for a new CSR of this capacity (``npi_item_edges``: 64 below ``npi_small_graph_entries``, else 256).
+    Asked ONCE, when a side is built; the side then carries its own value."""
+    return int(load().npi_item_edges(int(nnz_max)))
+
+
 def build_side(key: torch.Tensor, val: torch.Tensor, n_rows: int, n_cols: int, self_loops: bool = True,
-               loop_col_offset: int = 0, drop_equal: bool = True) -> CSRSide:
+               loop_col_offset: int = 0, drop_equal: bool = True, item: Optional[int] = None) -> CSRSide:
     """CSR over ``n_rows`` key rows whose entries index a table of ``n_cols`` rows
-    (``npi_csr_build_ex``); with ``n_cols == n_rows`` and the defaults this is the plain build."""
+    (``npi_csr_build_ex``); with ``n_cols == n_rows`` and the defaults this is the plain build.  ``item``: entries per
+    item (64 or 256; default: ``item_hint``)."""
     lib = load()
     dev = require_gpu(key, val)
     E, N = int(key.numel()), int(n_rows)
     nnz_max = E + (N if self_loops else 0)
-    n_items = int(lib.npi_num_items(nnz_max))
+    item = item_hint(nnz_max) if item is None else int(item)
+    n_items = int(lib.npi_num_items(nnz_max, item))
+    if n_items < 0:
+        raise ValueError(f"build_side: item must be 64 or 256 (got {item})")
     i32 = dict(dtype=torch.int32, device=dev)
     rowptr = torch.empty(N + 1, **i32)
     col = torch.empty(max(nnz_max, 1), **i32)
@@ -119,23 +149,16 @@ def build_side(key: torch.Tensor, val: torch.Tensor, n_rows: int, n_cols: int, s
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     check(lib.npi_csr_build_ex(ptr(key), ptr(val), E, N, int(n_cols), 1 if self_loops else 0,
                                int(loop_col_offset), 1 if drop_equal else 0, ptr(rowptr), ptr(col), ptr(eid),
-                               ptr(rowidx), ptr(item_row), ptr(status), ptr(ws), ws_bytes, stream_ptr(dev)),
+                               ptr(rowidx), ptr(item_row), item, ptr(status), ptr(ws), ws_bytes, stream_ptr(dev)),
           "npi_csr_build_ex")
-    if torch.cuda.is_current_stream_capturing():
-        pass                                  # inside a HIP-graph capture: no reads, and the word lives in the graph's pool
-    elif _DEBUG:
-        raise_on_status([status.item()])
-    else:
-        _PENDING.append(status)
-        if len(_PENDING) > _PENDING_MAX:
-            check_pending()
+    note_status(status)
     side = CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
-    side.n_rows, side.n_cols = N, int(n_cols)
+    side.n_rows, side.n_cols, side.item = N, int(n_cols), item
     return side
 
 
-def _build_side(key: torch.Tensor, val: torch.Tensor, E: int, N: int, self_loops: bool) -> CSRSide:
-    return build_side(key, val, N, N, self_loops)
+def _build_side(key: torch.Tensor, val: torch.Tensor, E: int, N: int, self_loops: bool, item: Optional[int] = None) -> CSRSide:
+    return build_side(key, val, N, N, self_loops, item=item)
 
 
 class CSRGraph:
@@ -145,8 +168,9 @@ class CSRGraph:
     ``by_src`` groups them by source node (backward: dX = A^T ...), built lazily."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, self_loops: bool = True, by_dst: Optional[CSRSide] = None,
-                 symmetric: bool = False):
-        """``by_dst``: a by-target side somebody already derived for this very edge list (``filtered_side``): not rebuilt.
+                 symmetric: bool = False, item: Optional[int] = None):
+        """``item``: entries per item of both sides (64 or 256; default: the hint for this capacity, ``item_hint``).
+        ``by_dst``: a by-target side somebody already derived for this very edge list (``filtered_side``): not rebuilt.
         ``symmetric``: the producer of the edge list vouches that it holds every edge in both directions (the device-side
         subgraph extraction emits both, src/classes.py:701-704, and filter_adj keeps the property; ``GraphBatch.symmetric``).
         Then row j of the by-source CSR holds the same neighbours as row j of the by-target CSR -- in another order -- and an
@@ -166,14 +190,15 @@ class CSRGraph:
         # rows of a [2,E] tensor are contiguous when the tensor is; otherwise copy (index plumbing)
         self._src = edge_index[0].contiguous()
         self._dst = edge_index[1].contiguous()
+        self._item = item if by_dst is None else by_dst.item
         self.by_dst = by_dst if by_dst is not None else \
-            _build_side(self._dst, self._src, self.num_edges, self.num_nodes, self.self_loops)
+            _build_side(self._dst, self._src, self.num_edges, self.num_nodes, self.self_loops, self._item)
         self._by_src: Optional[CSRSide] = None
 
     @property
     def by_src(self) -> CSRSide:
         if self._by_src is None:
-            self._by_src = _build_side(self._src, self._dst, self.num_edges, self.num_nodes, self.self_loops)
+            self._by_src = _build_side(self._src, self._dst, self.num_edges, self.num_nodes, self.self_loops, self.by_dst.item)
         return self._by_src
 
     def built_from(self, edge_index: torch.Tensor, num_nodes: Optional[int] = None) -> bool:
@@ -359,7 +384,8 @@ def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newp
     if n_out > int(lib.npi_csr_filter_max_rows()) or parent.n_rows != parent.n_cols:
         return None
     nnz_max = int(num_edges_out) + n_out
-    n_items = int(lib.npi_num_items(nnz_max))
+    item = item_hint(nnz_max)
+    n_items = int(lib.npi_num_items(nnz_max, item))
     i32 = dict(dtype=torch.int32, device=dev)
     rowptr = torch.empty(n_out + 1, **i32)
     col = torch.empty(max(nnz_max, 1), **i32)
@@ -369,8 +395,9 @@ def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newp
     status = torch.empty(1, **i32)
     ws = torch.empty(int(lib.npi_csr_filter_workspace_elems(n_out)), **i32)
     check(lib.npi_csr_filter(ptr(parent.rowptr), ptr(parent.col), ptr(parent.eid), ptr(perm), ptr(remap), ptr(newpos), n_out,
-                             nnz_max, ptr(rowptr), ptr(col), ptr(eid), ptr(rowidx), ptr(item_row), ptr(status), ptr(ws),
+                             nnz_max, ptr(rowptr), ptr(col), ptr(eid), ptr(rowidx), ptr(item_row), item, ptr(status), ptr(ws),
                              stream_ptr(dev)), "npi_csr_filter")
     side = CSRSide(rowptr, col, eid, rowidx, item_row, status, nnz_max, n_items)
     side.n_rows = side.n_cols = n_out
+    side.item = item
     return side

@@ -7,7 +7,6 @@ followed statement by statement.  Parameter names and shapes equal the reference
 """
 from __future__ import annotations
 
-import os
 import time
 from typing import Callable, Optional
 
@@ -20,10 +19,6 @@ from . import pool as NP
 from .graph import GraphBatch
 from .nn import SAGEConv
 from .subgraph import InteractionGraph
-
-
-# the MLP head through csrc/head.hip (three launches) instead of torch ops (about thirty); NPI_FUSED_HEAD=0: torch ops
-FUSED_HEAD = os.environ.get("NPI_FUSED_HEAD", "1") != "0"
 
 
 class Net_1(torch.nn.Module):
@@ -55,8 +50,7 @@ class Net_1(torch.nn.Module):
             gb, _, _ = pool(gb)                              # x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
             # torch.cat([gmp(x, batch), gap(x, batch)], dim=1) as ONE kernel (src/classes.py:64,68,72)
             readouts.append(NP.global_max_mean_pool(gb))
-        if FUSED_HEAD and NH.head_dims_ok(self.lin1.in_features, self.lin1.out_features, self.lin2.out_features,
-                                          self.lin3.out_features):
+        if NH.head_dims_ok(self.lin1.in_features, self.lin1.out_features, self.lin2.out_features, self.lin3.out_features):
             # x1 + x2 + x3 and the whole MLP head (src/classes.py:74-80) in one forward / two backward launches
             return NH.mlp_head(readouts, self.lin1, self.lin2, self.lin3, self.dropout, self.training)
         x = readouts[0] + readouts[1] + readouts[2]

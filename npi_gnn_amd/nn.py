@@ -23,6 +23,7 @@ from torch.nn import Parameter
 
 from . import functional as F_
 from .graph import CSRGraph, GraphBatch, as_graph
+from .schedule import DEFAULT, Schedule
 
 
 def _uniform(size: int, tensor: Optional[torch.Tensor]) -> None:
@@ -51,10 +52,11 @@ class SAGEConv(nn.Module):
     initialised U(+-1/sqrt(in_channels)) as in PyG 1.4.2."""
 
     def __init__(self, in_channels: int, out_channels: int, normalize: bool = False, concat: bool = False,
-                 bias: bool = True, **kwargs):
+                 bias: bool = True, schedule: Schedule = DEFAULT, **kwargs):
         super().__init__()
         if concat:
             raise NotImplementedError("SAGEConv(concat=True) is not used by NPI-GNN and not implemented")
+        self.schedule = schedule                  # how the launches are arranged (schedule.Schedule); never what they compute
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.normalize = normalize
@@ -78,9 +80,9 @@ class SAGEConv(nn.Module):
         if isinstance(x, GraphBatch):
             gb = _only_batch(x, edge_index, "SAGEConv")
             return gb.with_x(F_.sage_conv(gb.x, gb.graph(), self.weight, self.bias, normalize=self.normalize,
-                                          edge_weight=edge_weight, relu=relu, pad_base=gb.pad_base))
+                                          edge_weight=edge_weight, relu=relu, pad_base=gb.pad_base, schedule=self.schedule))
         return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize, edge_weight=edge_weight,
-                            relu=relu)
+                            relu=relu, schedule=self.schedule)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
@@ -93,10 +95,11 @@ class GATConv(nn.Module):
     (BASELINE.json configs[4] only)."""
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
-                 negative_slope: float = 0.2, dropout: float = 0.0, bias: bool = True, **kwargs):
+                 negative_slope: float = 0.2, dropout: float = 0.0, bias: bool = True, schedule: Schedule = DEFAULT, **kwargs):
         super().__init__()
         if dropout != 0:
             raise NotImplementedError("GATConv: attention dropout is not implemented")
+        self.schedule = schedule
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
         self.weight = Parameter(torch.empty(in_channels, heads * out_channels))
@@ -120,9 +123,9 @@ class GATConv(nn.Module):
         if isinstance(x, GraphBatch):
             gb = _only_batch(x, edge_index, "GATConv")
             return gb.with_x(F_.gat_conv(gb.x, gb.graph(), self.weight, self.att, self.bias, self.heads, self.concat,
-                                         self.negative_slope, relu=relu))
+                                         self.negative_slope, relu=relu, schedule=self.schedule))
         return F_.gat_conv(x, edge_index, self.weight, self.att, self.bias, self.heads, self.concat,
-                           self.negative_slope, relu=relu)
+                           self.negative_slope, relu=relu, schedule=self.schedule)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"
@@ -133,10 +136,11 @@ class GCNConv(nn.Module):
     normalize=True)``; ``weight`` glorot, ``bias`` zeros (PyG 1.4.2)."""
 
     def __init__(self, in_channels: int, out_channels: int, improved: bool = False, cached: bool = False,
-                 bias: bool = True, normalize: bool = True, **kwargs):
+                 bias: bool = True, normalize: bool = True, schedule: Schedule = DEFAULT, **kwargs):
         super().__init__()
         if not normalize:
             raise NotImplementedError("GCNConv(normalize=False) is not implemented")
+        self.schedule = schedule
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.improved = improved
@@ -175,7 +179,7 @@ class GCNConv(nn.Module):
             if self.cached:
                 self.cached_result = norm
                 self.cached_num_edges = graph.num_edges
-        return F_.gcn_conv(x, None, self.weight, self.bias, norm=norm)
+        return F_.gcn_conv(x, None, self.weight, self.bias, norm=norm, schedule=self.schedule)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

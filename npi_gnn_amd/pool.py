@@ -13,7 +13,6 @@ outputs.
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional
 
 import torch
@@ -35,10 +34,6 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
-
-
-# the pooled graph's CSR by filtering the parent's instead of a fresh sort (NPI_DERIVE_CSR=0: always sort)
-DERIVE_CSR = os.environ.get("NPI_DERIVE_CSR", "1") != "0"
 
 
 def graph_ptr(batch: torch.Tensor, num_graphs: Optional[int] = None) -> torch.Tensor:
@@ -147,7 +142,7 @@ def _select(gb: GraphBatch, weight: torch.Tensor, ratio: float, padded_edges: bo
     # conv asks for the pooled graph -- the last pooling layer's graph feeds no conv at all.
     sel.recipe = None
     parent = gb.peek_graph()                                # None if the edge list was written to since its CSR was built
-    if DERIVE_CSR and nosync and parent is not None and parent.self_loops:
+    if nosync and parent is not None and parent.self_loops:
         off = int(lib.npi_filter_adj_newpos_offset(E))
         sel.recipe = CSRRecipe(parent.by_dst, sel.perm, remap, ws[off:off + E], sel.n_out, int(e_out),
                                sel.edge_index._version)

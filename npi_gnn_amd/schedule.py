@@ -1,0 +1,44 @@
+"""How a layer ARRANGES its launches -- never what they compute.
+
+Every field selects between two arrangements of the same arithmetic (a second HIP stream or one, an epilogue or a separate
+pass, one layout of the hub rows or the other).  A ``Schedule`` is an explicit argument of the layers (``nn.SAGEConv(...,
+schedule=)``, ``functional.sage_conv(..., schedule=)``, ``dist.ShardedGraph(..., schedule=)``); nothing in the package reads
+a process-wide switch or an environment variable to pick a path.  Each alternative is exercised by a ``-m gpu`` test
+(``tests/test_gpu_schedule.py``) against the default.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+
+
+@dataclass(frozen=True)
+class Schedule:
+    # single-GPU layers -----------------------------------------------------------------------------------------------------
+    #: dW (MFMA-bound, launched as about one workgroup per CU) on the launch stream and the HBM-bound backward aggregation on a
+    #: second HIP stream, so that the two share every CU instead of queueing (C4: 8.0 -> 7.1 ms per step); also the small
+    #: HBM-bound passes of the GATConv backward under its GEMMs.  Only from ``overlap_min_rows`` rows on.
+    overlap_streams: bool = True
+    overlap_min_rows: int = 100_000
+    #: one-head GATConv: the attention terms of dX in the store epilogue of its GEMM (rank 2) instead of a read-modify-write pass
+    #: over d hfeat; from ``gat_rank2_min_rows`` rows on (below, the three [2, .] products cost more than the pass they replace)
+    gat_rank2_epilogue: bool = True
+    gat_rank2_min_rows: int = 100_000
+    # sharded layers (dist.py) --------------------------------------------------------------------------------------------------
+    #: cuts without hub-hub edges: the reduce-scatter delivers the COMPLETE hub rows straight into the output (no merge pass)
+    direct_hub_rows: bool = True
+    #: the partial (side B) aggregation on its own HIP stream, beside the all-gather and the full side
+    partial_stream: bool = True
+    #: the light rows' projection launched before the reduce-scattered hub rows have arrived
+    split_projection: bool = True
+    #: GATConv on the direct layout with the fused packed backward (needs ``direct_hub_rows``)
+    gat_direct: bool = True
+
+    def but(self, **changes) -> "Schedule":
+        return replace(self, **changes)
+
+
+DEFAULT = Schedule()
+#: the round-2 arrangement of the sharded layers: classic hub layout, one extra stream, one GEMM per direction, no store epilogue.
+#: ``bench.py --gpus N`` falls back on it when its pre-flight step fails on a configuration no box has run yet.
+CONSERVATIVE = Schedule(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
+                        gat_rank2_epilogue=False)

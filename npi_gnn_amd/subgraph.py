@@ -12,18 +12,12 @@ Python-``set`` iteration order, which is a CPython hashing detail.
 """
 from __future__ import annotations
 
-import os
-
 from typing import Optional, Tuple
 
 import torch
 
 from ._lib import check, load, ptr, require_gpu, stream_ptr
 from .graph import GraphBatch, build_side
-
-
-# Row pitch of the feature matrix a batch returns: padded to a multiple of 128 with zero columns (see batch()).
-PAD_FEATURES = os.environ.get("NPI_PAD_FEATURES", "1") != "0"
 
 
 class InteractionGraph:
@@ -63,7 +57,6 @@ class InteractionGraph:
             torch.zeros(1, dtype=torch.uint8, device=dev)
         self.feat = feat.contiguous()
         self.device = dev
-        self._totals_checked = False      # batch(n_nodes=, n_pairs=): host totals verified against the device once
 
     def sizes(self, keys: torch.Tensor):
         """(nodes, pairs) per sample of ``keys [K, 2]`` as HOST int64 tensors -- one device read for the whole key list.
@@ -84,10 +77,13 @@ class InteractionGraph:
         return both + 2, both + 1                               # nodes: the pair itself + partners; pairs: target + partners
 
     def batch(self, keys: torch.Tensor, return_node_id: bool = False, n_nodes: Optional[int] = None,
-              n_pairs: Optional[int] = None):
+              n_pairs: Optional[int] = None, pad_features: bool = True):
         """``keys [B, 2]`` (rna_serial, protein_serial) -> the ``GraphBatch`` of the B enclosing subgraphs (it unpacks as
         ``x, edge_index, batch``; with ``return_node_id`` the pair ``(GraphBatch, node_id)``).
-        ``n_nodes`` / ``n_pairs``: the batch's totals when the caller already knows them (``sizes``): no device read."""
+        ``n_nodes`` / ``n_pairs``: the batch's totals when the caller already knows them (``sizes``): no device read.  The fill
+        kernels compare them with the device's own totals: a mismatch (totals of other keys) writes NOTHING and raises a status
+        bit that the next device read of this package reports as a ``ValueError`` (``graph.check_pending``; at once under
+        ``graph.set_debug(True)``).  ``pad_features=False``: ``x`` with its natural row pitch (no zero pad columns)."""
         lib = load()
         dev = self.device
         keys = keys.to(device=dev, dtype=torch.int32).contiguous()
@@ -104,16 +100,7 @@ class InteractionGraph:
             n, npairs = int(n_nodes), int(n_pairs)
             if n > 2 ** 31 - 1 or 2 * npairs > 2 ** 31 - 1:
                 raise OverflowError("InteractionGraph.batch: the batch has more than 2^31 - 1 rows; use fewer keys per call")
-            # The fill kernels write at the DEVICE-computed offsets: totals that belong to other keys would be an
-            # out-of-bounds write, not an error.  Checked against node_off[-1] / pair_off[-1] the first time a caller
-            # supplies totals for this graph, and on every call under graph.set_debug(True) (a device read each).
-            from . import graph as _graph
-            if (_graph._DEBUG or not self._totals_checked) and not torch.cuda.is_current_stream_capturing():
-                dn, dp = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
-                if (dn, dp) != (n, npairs):
-                    raise ValueError(f"InteractionGraph.batch: n_nodes / n_pairs = {n} / {npairs} do not belong to these keys "
-                                     f"(the device counts {dn} / {dp}); totals must come from sizes() of the same keys")
-                self._totals_checked = True
+            # (the fill kernels check these totals against node_off[-1] / pair_off[-1] themselves: see the status word below)
         else:
             n, npairs = (int(v) for v in torch.stack([node_off[-1], pair_off[-1]]).tolist())
         if n < 0:
@@ -127,13 +114,18 @@ class InteractionGraph:
         # GEMMs on the padded width (matrix-core kernels instead of the guarded ones: functional.linear_fwd)
         Fx = 1 + Ff
         ld = (Fx + 127) // 128 * 128
-        if not PAD_FEATURES or 2 * ld > 3 * Fx:
+        if not pad_features or 2 * ld > 3 * Fx:
             ld = Fx
         full = torch.empty((n, ld), dtype=torch.float32, device=dev)
+        status = torch.empty(1, **i32)
         check(lib.npi_subgraph_fill(ptr(self.ptr), ptr(self.nbr), ptr(self.ok), ptr(keys), B, ptr(node_off), ptr(pair_off),
-                                    ptr(node_id), ptr(bvec), ptr(ei[0]), ptr(ei[1]), st), "npi_subgraph_fill")
-        check(lib.npi_subgraph_features(ptr(self.feat), self.feat.stride(0), Ff, ptr(node_id), ptr(bvec), ptr(node_off), n,
+                                    ptr(node_id), ptr(bvec), ptr(ei[0]), ptr(ei[1]), n, npairs, ptr(status), st),
+              "npi_subgraph_fill")
+        check(lib.npi_subgraph_features(ptr(self.feat), self.feat.stride(0), Ff, ptr(node_id), ptr(bvec), ptr(node_off), B, n,
                                         ptr(full), full.stride(0), st), "npi_subgraph_features")
+        if n_nodes is not None and n_pairs is not None:
+            from . import graph as _graph
+            _graph.note_status(status)                         # read now under set_debug, else at the next device read
         # every pair is emitted in both directions (symmetric: graph.CSRGraph.symmetric)
         gb = GraphBatch(full if ld == Fx else full[:, :Fx], ei, bvec, B, symmetric=True, pad_base=None if ld == Fx else full)
         if return_node_id:

@@ -20,9 +20,11 @@ def dev():
     return torch.device("cuda:0")
 
 
-# The capacity below which a CSR is cut into 64-entry items is 2^22 by default (npi_small_graph_entries).  The kernel test
-# modules below carry cases "just above 2^20 entries" that exist to exercise the 256-ENTRY items (row ends on item boundaries,
-# hub rows cut over many items): they run with the switch at 2^20, so that both item sizes stay covered at test-sized inputs.
+# A CSR carries its own item size (64 or 256 entries); npi_small_graph_entries only moves the HINT for new builds (default:
+# 64-entry items below 2^22 entries of capacity).  The kernel test modules below carry cases "just above 2^20 entries" that
+# exist to exercise the 256-ENTRY items (row ends on item boundaries, hub rows cut over many items): they run with the hint
+# switching at 2^20, so that both item sizes stay covered at test-sized inputs.  Changing the hint never affects a CSR that
+# already exists (tests/test_gpu_parity.py::test_a_csr_keeps_its_item_size_when_the_hint_moves).
 _ITEMS_AT_2P20 = ("test_gpu_fuzz", "test_gpu_parity", "test_gpu_gat")
 
 

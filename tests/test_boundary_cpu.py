@@ -33,30 +33,55 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert set(names) == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
 
 
+def test_ctypes_prototypes_have_the_headers_argument_lists():
+    """every ctypes prototype has as many arguments as the declaration in include/npi_gnn.h, pointers where it has pointers
+    and 64-bit / 32-bit / float scalars where it has those (a drifted prototype shifts every later argument silently)"""
+    text = open(os.path.join(ROOT, "include", "npi_gnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(npi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert set(decls) == set(_lib.PROTOTYPES)
+    for name, args in decls.items():
+        args = " ".join(args.split())
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        want = []
+        for a in params:
+            if "*" in a:
+                want.append(ctypes.c_void_p)
+            elif a.startswith("int64_t"):
+                want.append(ctypes.c_int64)
+            elif a.startswith("float"):
+                want.append(ctypes.c_float)
+            elif a.startswith("int "):
+                want.append(ctypes.c_int)
+            else:
+                raise AssertionError(f"{name}: cannot classify parameter {a!r}")
+        assert _lib.PROTOTYPES[name][1] == want, f"{name}: ctypes prototype differs from the header's argument list"
+
+
 def test_size_queries_without_gpu():
     lib = _lib.load()
-    assert lib.npi_abi_version() == 1
-    assert lib.npi_num_items(0) == 0
-    # small CSRs (capacity < 2^22 entries by default) are cut into 64-entry items, large ones into 256-entry items
+    assert lib.npi_abi_version() == 2
+    # the item size is an argument (a property of each CSR); npi_item_edges is only the HINT for a new CSR: 64-entry items
+    # below 2^22 entries of capacity by default, 256-entry items from there on
     T = int(lib.npi_small_graph_entries(0))
     assert T == 1 << 22
     assert lib.npi_item_edges(1000) == 64 and lib.npi_item_edges(T - 1) == 64
     assert lib.npi_item_edges(T) == 256 and lib.npi_item_edges(21_000_000) == 256
-    assert lib.npi_small_graph_entries(1 << 20) == T and lib.npi_item_edges(1 << 20) == 256      # settable (tests of 256-entry items)
+    assert lib.npi_small_graph_entries(1 << 20) == T and lib.npi_item_edges(1 << 20) == 256      # the hint moves ...
     assert lib.npi_small_graph_entries(T) == 1 << 20 and lib.npi_item_edges(1 << 20) == 64
-    assert lib.npi_num_items(1) == 1
-    assert lib.npi_num_items(64) == 1
-    assert lib.npi_num_items(65) == 2
-    assert lib.npi_num_items(T) == T // 256
-    assert lib.npi_num_items(T + 1) == T // 256 + 1
+    for item in (64, 256):                                                                         # ... the sizes do not
+        assert lib.npi_num_items(0, item) == 0 and lib.npi_num_items(1, item) == 1
+        assert lib.npi_num_items(item, item) == 1 and lib.npi_num_items(item + 1, item) == 2
+        assert lib.npi_num_items(T + 1, item) == T // item + 1
+    assert lib.npi_num_items(1000, 128) == -1 and lib.npi_segsum_carry_elems(1000, 100, 256) == -1   # no such item size
     assert lib.npi_csr_workspace_bytes(1000, 10) > 16 * 1000
-    assert lib.npi_segsum_carry_elems(1000, 256) == 2 * 16 * 256
+    assert lib.npi_segsum_carry_elems(1000, 64, 256) >= 2 * 16 * 256 and lib.npi_segsum_carry_elems(1000, 256, 256) >= 2 * 4 * 256
     assert lib.npi_linear_bwd_weight_workspace_elems(1000, 256, 256) >= 256 * 256
 
 
 def test_argument_errors_do_not_need_a_gpu():
     lib = _lib.load()
-    rc = lib.npi_segsum(None, None, None, None, -1, 0, None, 0, None, 0, 4, 0, 0, None, None, None)
+    rc = lib.npi_segsum(None, None, None, 64, None, -1, 0, None, 0, None, 0, 4, 0, 0, None, None, None)
     assert rc == -1
     assert b"npi_segsum" in lib.npi_last_error()
 
@@ -66,7 +91,14 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
     lib = _lib.load()
     N = None
     calls = {
-        "npi_csr_build_ex": lambda: lib.npi_csr_build_ex(N, N, -1, 4, 4, 1, 0, 1, N, N, N, N, N, N, N, 0, N),
+        "npi_csr_build_ex": lambda: lib.npi_csr_build_ex(N, N, -1, 4, 4, 1, 0, 1, N, N, N, N, N, 64, N, N, 0, N),
+        # an item size that does not exist is refused by the build and by every consumer of item_row
+        "npi_csr_build": lambda: lib.npi_csr_build(8, 8, 4, 4, 1, 8, 8, 8, 8, 8, 100, 8, 8, 1 << 20, N),
+        "npi_csr_filter": lambda: lib.npi_csr_filter(8, 8, 8, 8, 8, 8, 4, 8, 8, 8, 8, 8, 8, 0, 8, 8, N),
+        "npi_segsum": lambda: lib.npi_segsum(8, 8, 8, 128, N, 4, 16, 8, 4, 8, 4, 4, 0, 0, N, 8, N),
+        "npi_gat_aggregate_scores": lambda: lib.npi_gat_aggregate_scores(8, 8, 8, 65, 4, 16, 8, 4, N, 0, 8, 4, 4, 8, 8, 8, N, 0, 8, N),
+        "npi_gat_backward_fused_heads": lambda: lib.npi_gat_backward_fused_heads(8, 8, 8, 8, 0, 4, 16, 16, 4, N, 0, 16, 4, 16, 4, 1, 4, 16,
+                                                                                 16, 0.2, 16, 16, N),
         "npi_linear_fwd": lambda: lib.npi_linear_fwd(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, N),
         "npi_linear_bwd_data": lambda: lib.npi_linear_bwd_data(N, 0, N, 0, N, N, 0, 8, 8, -3, N),
         "npi_linear_bwd_weight": lambda: lib.npi_linear_bwd_weight(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, N),
@@ -76,15 +108,16 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_readout_max_mean": lambda: lib.npi_readout_max_mean(N, 0, N, 2, 0, N, N),
         "npi_topk_gather_bwd": lambda: lib.npi_topk_gather_bwd(N, 0, N, N, N, -1, 8, N, 0, N, N, 0, N, N, N),
         "npi_subgraph_sizes": lambda: lib.npi_subgraph_sizes(N, N, N, N, -1, N, N, N, N),
-        "npi_subgraph_features": lambda: lib.npi_subgraph_features(N, 0, 0, N, N, N, 4, N, 0, N),
+        "npi_subgraph_features": lambda: lib.npi_subgraph_features(N, 0, 0, N, N, N, 1, 4, N, 0, N),
+        "npi_subgraph_fill": lambda: lib.npi_subgraph_fill(N, N, N, N, 4, N, N, N, N, N, N, -1, 0, N, N),
         "npi_confusion_update": lambda: lib.npi_confusion_update(N, 0, 0, N, 4, N, N),
         # alpha read-back is a by-source, one-head, mapped mode: a forward call carrying it is refused (pointers are only
         # compared with NULL before that check, never dereferenced on the host)
-        "npi_gat_aggregate": lambda: lib.npi_gat_aggregate(8, 8, 8, 4, 16, 8, 4, 8, 4, 1, 4, 8, 8, 8, 8, 0.2, 0, N, N, N, N,
+        "npi_gat_aggregate": lambda: lib.npi_gat_aggregate(8, 8, 8, 64, 4, 16, 8, 4, 8, 4, 1, 4, 8, 8, 8, 8, 0.2, 0, N, N, N, N,
                                                            8, N, 8, N),
         "npi_gat_edge_grad": lambda: lib.npi_gat_edge_grad(N, N, N, 4, 16, N, 4, N, 4, 0, 4, N, N, N, N, N, 0.2, N, N, N),
-        "npi_seg_rowsum": lambda: lib.npi_seg_rowsum(N, N, N, N, -1, 0, 1, N, N, 0, N),
-        "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N),       # bad split
+        "npi_seg_rowsum_ex": lambda: lib.npi_seg_rowsum_ex(N, N, N, N, -1, 0, 1, N, N, 0, N),
+        "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, 64, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N),       # bad split
         "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N),
         "npi_linear_bwd_data_ex": lambda: lib.npi_linear_bwd_data_ex(N, 0, N, 0, N, N, 0, 8, 8, -3, 0, 0, N, 0, N),
         "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 0, 1, N),

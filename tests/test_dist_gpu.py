@@ -146,77 +146,24 @@ def test_virtual_ranks_gcn_gat_on_one_gpu(dev, world, layer_kind):
         assert torch.allclose(dw, ref[2], atol=1e-2, rtol=1e-3)
 
 
-def _run_virtual(ND, world, layer_kind, ei, N, F, x, go, W, b, hub, dev):
-    """W ranks in ONE process without threads: the ranks run one after the other, pass after pass.  Collective number
-    k of a pass returns its true result once every rank's input to it is known from an earlier pass (inputs of
-    collective k depend only on the results of collectives < k, and the kernels are deterministic), a dummy before --
-    so pass p resolves collective p and the last pass is an exact lock-step execution."""
-    inputs, results = [], []            # per collective index: {rank: tensor}, resolved result (list per rank) or None
-    state = {"rank": 0, "k": 0, "valid": True}
+def _run_virtual(ND, world, layer_kind, ei, N, F, x, go, W, b, hub, dev, schedule=None):
+    """W ranks in ONE process without threads, in exact lock step (npi_gnn_amd.virtual.LockStep: the ranks run one after the
+    other, pass after pass; collective number k returns its true result once every rank's input to it is known)."""
+    from npi_gnn_amd.schedule import DEFAULT
+    from npi_gnn_amd.virtual import LockStep
+    with LockStep(world, max_passes=64) as ls:
+        sgs = [ND.ShardedGraph(ei, N, r, world, dev, hub_mask=hub, schedule=schedule or DEFAULT) for r in range(world)]
 
-    class Work:
-        def wait(self):
-            return True
-
-    def collective(value, fn):
-        k, r = state["k"], state["rank"]
-        state["k"] += 1
-        while len(inputs) <= k:
-            inputs.append({})
-            results.append(None)
-        if results[k] is not None:
-            return results[k]
-        if state["valid"]:
-            inputs[k][r] = value.detach().clone()
-            if len(inputs[k]) == world:
-                results[k] = ("pending", fn)
-        state["valid"] = False
-        return None
-
-    def resolve():
-        for k, res in enumerate(results):
-            if isinstance(res, tuple) and res[0] == "pending":
-                results[k] = res[1]([inputs[k][r] for r in range(world)])
-
-    def all_gather_rows(block, out, w, group=None, async_op=False):
-        res = collective(block, lambda v: torch.cat(v))
-        out.copy_(res) if res is not None else out.zero_()
-        return Work() if async_op else None
-
-    def reduce_scatter_rows(part_sums, out, rank, w, group=None, async_op=False):
-        res = collective(part_sums, lambda v: torch.stack(v).sum(0))
-        out.copy_(res.view(w, out.size(0), -1)[rank].view_as(out)) if res is not None else out.zero_()
-        return Work() if async_op else None
-
-    def all_reduce(t, w, group=None, op=None, tag=""):
-        mx = op == dist.ReduceOp.MAX
-        res = collective(t, (lambda v: torch.stack(v).max(0)[0]) if mx else (lambda v: torch.stack(v).sum(0)))
-        if res is not None:
-            t.copy_(res)
-
-    saved = (ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo)
-    ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce = all_gather_rows, reduce_scatter_rows, all_reduce
-    ND._solo = lambda w: False
-    try:
-        sgs = [ND.ShardedGraph(ei, N, r, world, dev, hub_mask=hub) for r in range(world)]
-        for _ in range(64):
-            outs, dxs, dws = [], [], []
-            complete = True
-            for r, sg in enumerate(sgs):
-                state.update(rank=r, k=0, valid=True)
-                layer = _make_layer(ND, layer_kind, sg, W, b, dev, F)
-                xl = sg.shard(x).to(dev).requires_grad_(True)
-                out = layer(xl)
-                out.backward(sg.shard(go).to(dev))
-                torch.cuda.synchronize()
-                complete = complete and state["valid"]
-                outs.append(out.detach().cpu()), dxs.append(xl.grad.cpu()), dws.append(layer.weight.grad.cpu())
-            if complete:
-                return outs, dxs, dws
-            resolve()
-        raise AssertionError("virtual ranks did not converge")
-    finally:
-        ND.all_gather_rows, ND.reduce_scatter_rows, ND._all_reduce, ND._solo = saved
+        def run_rank(r):
+            sg = sgs[r]
+            layer = _make_layer(ND, layer_kind, sg, W, b, dev, F)
+            xl = sg.shard(x).to(dev).requires_grad_(True)
+            out = layer(xl)
+            out.backward(sg.shard(go).to(dev))
+            torch.cuda.synchronize()
+            return out.detach(), xl.grad, layer.weight.grad
+        res = ls.run(run_rank)
+    return [r[0].cpu() for r in res], [r[1].cpu() for r in res], [r[2].cpu() for r in res]
 
 
 @pytest.mark.parametrize("hubs", [False, True])

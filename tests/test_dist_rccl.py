@@ -7,6 +7,8 @@ single-GPU layer of this package over the whole graph on its own GPU and compare
 The rank processes are fresh children (spawn): none of them has touched a GPU before it picks its own."""
 import json
 import os
+import time
+import queue
 import socket
 import subprocess
 import sys
@@ -110,12 +112,30 @@ def test_sharded_layers_through_rccl(layer_kind):
     for p in procs:
         p.start()
     got = {}
-    for _ in range(world):
-        rank, errs, tags = q.get(timeout=600)
-        got[rank] = (errs, tags)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        # a rank that dies leaves the others blocked in a collective: poll the queue in short slices and watch the exit codes
+        # instead of waiting 600 s for a message that will never come
+        deadline = time.time() + 600
+        while len(got) < world:
+            try:
+                rank, errs, tags = q.get(timeout=2)
+                got[rank] = (errs, tags)
+            except queue.Empty:
+                dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+                assert not dead, f"rank(s) died (rank, exit code): {dead}"
+                assert time.time() < deadline, f"only ranks {sorted(got)} of {world} reported within 600 s"
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                       # whatever happened: no rank process (and no GPU it holds) outlives the test
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
     assert sorted(got) == list(range(world))
     for rank, (errs, tags) in got.items():
         for name, e in errs.items():

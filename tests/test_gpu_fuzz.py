@@ -133,7 +133,7 @@ def test_random_pooling_batches(dev, seed):
 
 def test_gat_random_campaign(dev):
     """tools/fuzz_gat.py, 60 cases: random graphs (hub rows, empty rows, self loops, duplicates), 1 / 2 / 4 / 8 heads, both
-    item sizes (256-entry items forced on small graphs through npi_small_graph_entries), fused ReLU on / off -- GATConv
+    item sizes (CSRGraph(item=)), fused ReLU on / off -- GATConv
     forward and every gradient against the fp64 oracle (1,050 cases of the same generator ran clean in round 3)."""
     import os
     import subprocess

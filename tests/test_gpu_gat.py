@@ -143,14 +143,8 @@ def test_item_parallel_row_reductions_match_torch(dev, n_rows, E, H):
     s_ref = torch.from_numpy(by_row(np.exp(zc.astype(np.float64) - m_ref.numpy().astype(np.float64)[row.cpu().numpy()]), np.add, 0.0))
     assert torch.equal(m.cpu(), m_ref)
     assert torch.allclose(s.cpu().double(), s_ref, rtol=2e-5, atol=1e-6)
-    NF.GAT_ITEM_SCANS = False                                  # the round-2 row-walking kernels agree
-    try:
-        if E:
-            m0, s0 = NF.gat_softmax_stats(side, a_row, a_col, H, 0.2)
-            assert torch.equal(m0, m) and torch.allclose(s0, s, rtol=2e-5, atol=1e-6)
-            assert torch.allclose(NF.seg_rowsum(side, vals, H), got, rtol=1e-4, atol=1e-4 * scale)
-    finally:
-        NF.GAT_ITEM_SCANS = True
+    m0, s0 = NF.gat_softmax_stats(side, a_row, a_col, H, 0.2)   # without the score output: the same statistics
+    assert torch.equal(m0, m) and torch.equal(s0, s)
 
 
 @pytest.mark.parametrize("N,H,C", [(1000, 1, 256), (4097, 4, 64), (300_000, 1, 256), (50, 1, 8), (2000, 2, 512), (777, 3, 100)])
@@ -193,22 +187,17 @@ def test_fused_relu_equals_relu_behind_the_layer(dev, H, C):
 def test_attention_terms_in_the_gemm_epilogue_equal_the_separate_pass(dev, N, E, Fi, C):
     """One head: the terms g_dst (x) att_dst + g_src (x) att_src of d hfeat are never added to it -- dX takes them in the
     store epilogue of its GEMM (rank 2), dW as an outer-product correction from x^T g, d att from the same pass over x
-    (functional._GatConvFn._backward_rank2).  Same gradients as with the read-modify-write pass (NPI_GAT_RANK2=0) up to
-    f32 rounding; the forward is untouched."""
-    from npi_gnn_amd import functional as NF
+    (functional._GatConvFn._backward_rank2).  Same gradients as with the read-modify-write pass
+    (Schedule.gat_rank2_epilogue = False) up to f32 rounding; the forward is untouched."""
+    from npi_gnn_amd.schedule import DEFAULT
     ei, x, W, att, b, go = _case(N, E, Fi, 1, C, seed=N + C)
     res = []
-    old, old_min = NF.GAT_RANK2_EPILOGUE, NF.GAT_RANK2_MIN_ROWS
-    try:
-        NF.GAT_RANK2_MIN_ROWS = 0                       # (the product takes this path from 100,000 rows on)
-        for flag in (False, True):
-            NF.GAT_RANK2_EPILOGUE = flag
-            xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
-            out = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=1)
-            out.backward(go.to(dev))
-            res.append((out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad))
-    finally:
-        NF.GAT_RANK2_EPILOGUE, NF.GAT_RANK2_MIN_ROWS = old, old_min
+    for flag in (False, True):                          # (min_rows = 0: the product takes this path from 100,000 rows on)
+        sch = DEFAULT.but(gat_rank2_epilogue=flag, gat_rank2_min_rows=0)
+        xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+        out = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=1, schedule=sch)
+        out.backward(go.to(dev))
+        res.append((out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][4], res[1][4])
     for a, c in zip(res[0][1:4], res[1][1:4]):
         assert torch.allclose(a, c, rtol=1e-4, atol=2e-6 * float(a.abs().max()) * max(1.0, N ** 0.5 / 30))
@@ -251,18 +240,14 @@ def test_rank2_path_with_frozen_parameters(dev, freeze):
     go = torch.randn(N, F, device=dev, generator=gen)
 
     def run(rank2):
-        old = NF.GAT_RANK2_EPILOGUE
-        NF.GAT_RANK2_EPILOGUE = rank2
-        try:
-            torch.manual_seed(0)
-            conv = npi.GATConv(F, F).to(dev)
-            for name in freeze:
-                getattr(conv, name).requires_grad_(False)
-            x = x0.clone().requires_grad_(True)
-            conv(x, g).backward(go)
-            return x.grad, conv.weight.grad, conv.att.grad, conv.bias.grad
-        finally:
-            NF.GAT_RANK2_EPILOGUE = old
+        from npi_gnn_amd.schedule import DEFAULT
+        torch.manual_seed(0)
+        conv = npi.GATConv(F, F, schedule=DEFAULT.but(gat_rank2_epilogue=rank2)).to(dev)
+        for name in freeze:
+            getattr(conv, name).requires_grad_(False)
+        x = x0.clone().requires_grad_(True)
+        conv(x, g).backward(go)
+        return x.grad, conv.weight.grad, conv.att.grad, conv.bias.grad
     a, b = run(True), run(False)
     for name, p, q in zip(("dx", "dW", "datt", "db"), a, b):
         assert (p is None) == (q is None), name

@@ -63,10 +63,12 @@ def test_csr_build_is_bit_exact(dev, N, E, loops):
         assert np.array_equal(side.col.cpu().numpy()[:nnz], col)
         assert np.array_equal(side.eid.cpu().numpy()[:nnz], eid)
         assert np.array_equal(side.rowidx.cpu().numpy()[:nnz], rowidx)
-        # item_row[i] = row holding entry item_edges * i (64-entry items below npi_small_graph_entries of capacity, else 256)
+        # item_row[i] = row holding entry item_edges * i; the side carries its item size (the hint at build time: 64-entry items
+        # below npi_small_graph_entries of capacity, else 256)
         from npi_gnn_amd._lib import load as _load
-        item_edges = int(_load().npi_item_edges(side.nnz_max))
+        item_edges = side.item
         assert item_edges == (64 if side.nnz_max < int(_load().npi_small_graph_entries(0)) else 256)
+        assert side.n_items == -(-side.nnz_max // item_edges)
         ir = side.item_row.cpu().numpy()
         for i in range(1, side.n_items):
             k = item_edges * i
@@ -887,9 +889,6 @@ def test_long_chains_of_partials_add_up_exactly(dev, item_entries, F):
     multiples of 64 items, rows one entry short of that, an empty row in between, plus mean, per-entry weights and a repeat
     run.  Both item sizes; one-chunk, narrow (group kernel) and two-chunk rows.  (Written for a variant that pre-summed spans of
     64 partials in an extra launch -- measured slower everywhere and dropped; the test stays.)"""
-    from npi_gnn_amd._lib import load as _load
-    lib = _load()
-    prev = int(lib.npi_small_graph_entries(0))
     span = 64 * item_entries                                           # entries of 64 items
     lens = [5, span - 5,                                               # -> the next row starts exactly at entry `span`
             3 * span,                                                  # starts on a boundary, ends on one
@@ -904,22 +903,68 @@ def test_long_chains_of_partials_add_up_exactly(dev, item_entries, F):
     val = torch.randint(0, n_cols, (nnz,), generator=g)
     x = torch.randint(-3, 4, (n_cols, F), generator=g).float()
     w = torch.randint(-2, 3, (nnz,), generator=g).float()
+    side = NG.build_side(key.to(dev), val.to(dev), n_rows, n_cols, self_loops=False, drop_equal=False, item=item_entries)
+    assert side.item == item_entries
+    xd = x.to(dev)
+    ref = torch.zeros(n_rows, F).index_add_(0, key, x[val])           # (small integers: exact in f32 in any order)
+    out = NF.segsum(None, side, xd)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(NF.segsum(None, side, xd), out)
+    # per-entry weights (entry order = edge order here: the keys are sorted and the build is stable)
+    we = torch.empty(side.nnz_max, device=dev)
+    we[:nnz] = w.to(dev)[side.eid[:nnz].long()]
+    refw = torch.zeros(n_rows, F).index_add_(0, key, x[val] * w.view(-1, 1))
+    assert torch.equal(NF.segsum(None, side, xd, w=we).cpu(), refw)
+    # mean: one division per row after the exact sum
+    cnt = torch.tensor(lens, dtype=torch.float64).clamp(min=1).view(-1, 1)
+    got = NF.segsum(None, side, xd, mean=True).cpu().double()
+    assert torch.allclose(got, ref.double() / cnt, rtol=1e-6, atol=0)
+
+
+def test_a_csr_keeps_its_item_size_when_the_hint_moves(dev):
+    """VERDICT r3 item 4 / ADVICE r3 (medium): the item size used to be re-derived at every LAUNCH from a process-wide
+    threshold, so a CSR with 2^20 <= capacity < 2^22 built before npi_small_graph_entries moved and aggregated after it was
+    walked with the wrong geometry (wrong sums, out-of-range carry writes).  Now the side carries it: build with 64-entry
+    items, move the hint so that a fresh build of this capacity would take 256, and every consumer of the OLD side -- SAGE
+    aggregation (plain, weighted, bf16), the GAT forward and fused backward, the whole layers -- still matches the oracle;
+    the same the other way round."""
+    from npi_gnn_amd._lib import load as _load
+    lib = _load()
+    prev = int(lib.npi_small_graph_entries(0))
+    N, E, F = 3000, 1_200_000, 64                     # capacity 2.4M entries: between the two thresholds used below
+    ei = rand_edges(N, E, seed=7)
+    x = torch.randn(N, F, generator=torch.Generator().manual_seed(1))
+    go = torch.randn(N, F, generator=torch.Generator().manual_seed(2))
     try:
-        lib.npi_small_graph_entries(1 if item_entries == 256 else 1 << 40)        # force the item size
-        side = NG.build_side(key.to(dev), val.to(dev), n_rows, n_cols, self_loops=False, drop_equal=False)
-        xd = x.to(dev)
-        ref = torch.zeros(n_rows, F).index_add_(0, key, x[val])           # (small integers: exact in f32 in any order)
-        out = NF.segsum(None, side, xd)
-        assert torch.equal(out.cpu(), ref)
-        assert torch.equal(NF.segsum(None, side, xd), out)
-        # per-entry weights (entry order = edge order here: the keys are sorted and the build is stable)
-        we = torch.empty(side.nnz_max, device=dev)
-        we[:nnz] = w.to(dev)[side.eid[:nnz].long()]
-        refw = torch.zeros(n_rows, F).index_add_(0, key, x[val] * w.view(-1, 1))
-        assert torch.equal(NF.segsum(None, side, xd, w=we).cpu(), refw)
-        # mean: one division per row after the exact sum
-        cnt = torch.tensor(lens, dtype=torch.float64).clamp(min=1).view(-1, 1)
-        got = NF.segsum(None, side, xd, mean=True).cpu().double()
-        assert torch.allclose(got, ref.double() / cnt, rtol=1e-6, atol=0)
+        for first, then in ((1 << 40, 1), (1, 1 << 40)):           # (every build takes 64) -> (every build takes 256), and back
+            lib.npi_small_graph_entries(first)
+            g = npi.CSRGraph(ei.to(dev), N)
+            item = g.by_dst.item
+            assert item == (64 if first > 1 else 256) and g.by_src.item == item
+            sage = npi.SAGEConv(F, F).to(dev)
+            gat = npi.GATConv(F, F).to(dev)
+            lib.npi_small_graph_entries(then)                         # a NEW side of this capacity would now get the other size
+            assert int(lib.npi_item_edges(g.by_dst.nnz_max)) != item and g.by_dst.item == item
+            xd = x.to(dev).requires_grad_(True)
+            out = sage(xd, g)
+            out.backward(go.to(dev))
+            r_out, r_dx, r_dw, r_db = R.sage_layer_fwd_bwd(x, ei, sage.weight.detach().cpu(), sage.bias.detach().cpu(), go)
+            assert float((out.detach().cpu() - r_out).abs().max()) <= 1e-4
+            assert float((xd.grad.cpu() - r_dx).abs().max()) <= 1e-4
+            assert float((sage.weight.grad.cpu() - r_dw).abs().max()) <= 2e-3 * float(r_dw.abs().max())
+            # bf16 storage and per-entry weights walk the same item_row / carry
+            agg16 = NF.segsum(g, g.by_dst, x.to(dev).bfloat16(), mean=True).float().cpu()
+            agg32 = NF.segsum(g, g.by_dst, x.to(dev), mean=True).cpu()
+            assert float((agg16 - agg32).abs().max()) <= 2e-2 * float(agg32.abs().max())
+            # GATConv: statistics, forward aggregation on the read-back scores, fused backward, both row sums
+            xg = x.to(dev).requires_grad_(True)
+            og = gat(xg, g)
+            og.backward(go.to(dev))
+            xr = x.clone().double().requires_grad_(True)
+            ref = R.gat_conv(xr, ei, gat.weight.detach().cpu().double(), gat.att.detach().cpu().double(),
+                             gat.bias.detach().cpu().double(), heads=1)
+            ref.backward(go.double())
+            assert float((og.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-4
+            assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-4 * max(1.0, float(xr.grad.abs().max()))
     finally:
         lib.npi_small_graph_entries(prev)

@@ -503,23 +503,36 @@ def test_in_place_edit_of_a_cached_edge_list_is_never_answered_from_the_stale_cs
 
 
 def test_stale_batch_totals_are_an_error_not_an_out_of_bounds_write(dev):
-    """ADVICE r2: InteractionGraph.batch(n_nodes=, n_pairs=) sizes its outputs from the caller's totals while the kernels
-    write at device-computed offsets -- totals of OTHER keys must raise (first supplied totals of a graph, and every call
-    under graph.set_debug), and host totals beyond int32 keep the overflow check."""
+    """ADVICE r2 / r3: InteractionGraph.batch(n_nodes=, n_pairs=) sizes its outputs from the caller's totals while the kernels
+    write at device-computed offsets.  The fill kernels compare the two THEMSELVES, on every call: totals of OTHER keys write
+    nothing and raise a status bit that the next device read reports (at once under graph.set_debug) -- no host sync on the
+    good path, no out-of-bounds write on the bad one; host totals beyond int32 keep the overflow check."""
     from npi_gnn_amd.subgraph import InteractionGraph
     g = torch.Generator().manual_seed(2)
     pairs = torch.tensor([[0, 3], [1, 3], [1, 4], [2, 4], [0, 4]])
     ig = InteractionGraph(pairs.to(dev), torch.ones(5, dtype=torch.bool).to(dev), torch.randn(5, 6, generator=g).to(dev))
     keys = pairs[:3].to(dev)
     nodes, npairs = ig.sizes(keys)
-    with pytest.raises(ValueError):
-        ig.batch(keys[:2], n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))        # totals of three keys, two keys
-    ok = ig.batch(keys, n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))
+    tot = dict(n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))
+    NG.check_pending()
+    ok = ig.batch(keys, **tot)
+    NG.check_pending()                                                  # the right totals: clean
     assert ok.x.size(0) == int(nodes.sum())
+    ref = ig.batch(keys)
+    assert torch.equal(ok.x, ref.x) and torch.equal(ok.edge_index, ref.edge_index)
+    for wrong in (keys[:2], keys[:1]):                                  # a LATER call is caught like the first one
+        with torch.cuda.device(dev):
+            guard = torch.full((4096,), 7.0, device=dev)                # a neighbour in the allocator's pool
+        bad = ig.batch(wrong, **tot)                                    # totals of three keys: nothing may be written
+        with pytest.raises(ValueError):
+            NG.check_pending()
+        assert bool((guard == 7.0).all()) and bad.x.size(0) == int(nodes.sum())
+        ig.batch(keys, **tot)
+        NG.check_pending()
     NG.set_debug(True)
     try:
         with pytest.raises(ValueError):
-            ig.batch(keys[:1], n_nodes=int(nodes.sum()), n_pairs=int(npairs.sum()))
+            ig.batch(keys[:1], **tot)
     finally:
         NG.set_debug(False)
     with pytest.raises(OverflowError):

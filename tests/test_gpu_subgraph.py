@@ -107,7 +107,6 @@ def test_per_key_sizes_replace_the_per_batch_device_read(dev):
 def test_feature_rows_are_stored_128_aligned_with_zero_pad_columns(dev):
     """an odd feature width is stored with a row pitch of the next multiple of 128: x is the [n, F] view (bit-exact, as the
     tests above check), the pad columns of its buffer are zero, and Net_1's first layer equals the unpadded one"""
-    from npi_gnn_amd import subgraph as SG
     fx = torch.load(os.path.join(G, "rpi369_extract.pt"), map_location="cpu", weights_only=False)
     ig = InteractionGraph(fx["pairs"].long().to(dev), fx["usable"].to(dev), fx["feat"].to(dev))
     keys = fx["keys"].long().to(dev)
@@ -119,13 +118,8 @@ def test_feature_rows_are_stored_128_aligned_with_zero_pad_columns(dev):
     if F % 128 != 0 and 2 * ((F + 127) // 128 * 128) <= 3 * F:
         assert base is not None and base.size(1) == (F + 127) // 128 * 128 and base.data_ptr() == x.data_ptr()
         assert x.stride(0) == base.size(1) and not bool(base[:, F:].any())
-    old = SG.PAD_FEATURES
-    try:
-        SG.PAD_FEATURES = False
-        gb0 = ig.batch(keys)
-        x0, e0, b0 = gb0
-    finally:
-        SG.PAD_FEATURES = old
+    gb0 = ig.batch(keys, pad_features=False)
+    x0, e0, b0 = gb0
     assert x0.is_contiguous() and gb0.pad_base is None
     assert torch.equal(x, x0) and torch.equal(ei, e0)
     torch.manual_seed(0)

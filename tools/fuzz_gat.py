@@ -1,22 +1,19 @@
 #!/usr/bin/env python3
-"""Randomised campaign for the round-3 GAT kernels against the CPU oracle (oracle/ref_conv.py): random graphs (hub rows, empty
-rows, self loops, duplicate edges), 1 / 2 / 4 / 8 heads, both item sizes (the 256-entry items are forced on small graphs by
-lowering npi_small_graph_entries), fused ReLU on / off.  usage: tools/fuzz_gat.py [cases] [seed]"""
+"""Randomised campaign for the GAT kernels against the CPU oracle (oracle/ref_conv.py): random graphs (hub rows, empty
+rows, self loops, duplicate edges), 1 / 2 / 4 / 8 heads, both item sizes (CSRGraph(item=)), fused ReLU on / off.
+usage: tools/fuzz_gat.py [cases] [seed]"""
 import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import npi_gnn_amd as npi
-from npi_gnn_amd._lib import load
+from npi_gnn_amd.schedule import DEFAULT
 from oracle import ref_conv as R
-from npi_gnn_amd import functional as _NF
-_NF.GAT_RANK2_MIN_ROWS = 0          # small graphs too: the rank-2 store epilogue of dX (the product takes it from 100,000 rows on)
+SCH = DEFAULT.but(gat_rank2_min_rows=0)   # small graphs too: the rank-2 store epilogue of dX (the product takes it from 100,000 rows on)
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
-lib = load()
-default_thr = int(lib.npi_small_graph_entries(0))
 worst = 0.0
 for it in range(cases):
     H, C = [(1, 256), (1, 64), (1, 100), (2, 32), (2, 128), (4, 64), (4, 32), (8, 32), (2, 64), (1, 8)][int(rng.integers(0, 10))]
@@ -24,7 +21,6 @@ for it in range(cases):
     E = int(rng.integers(0, 40000))
     Fi = int(rng.choice([16, 33, 64, 128, 128, 256]))       # (128 / 256 with one head: the rank-2 store epilogue of dX)
     big_items = bool(rng.random() < 0.5)
-    lib.npi_small_graph_entries(1 if big_items else default_thr)       # 1: every CSR takes 256-entry items
     g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
     ei = torch.randint(0, N, (2, E), generator=g)
     if E and rng.random() < 0.5:
@@ -38,7 +34,8 @@ for it in range(cases):
     b = torch.randn(H * C, generator=g) * 0.1
     go = torch.randn(N, H * C, generator=g)
     xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
-    out = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=H, relu=relu)
+    graph = npi.CSRGraph(ei.to(dev), N, item=256 if big_items else 64)
+    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCH)
     out.backward(go.to(dev))
     xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))
     ref = R.gat_conv(xr, ei, Wr, ar, br, heads=H)
@@ -61,21 +58,16 @@ for it in range(cases):
     worst = max(worst, m)
     if m > 2e-4:
         print(f"MISMATCH case {it}: H={H} C={C} N={N} E={E} Fi={Fi} big_items={big_items} relu={relu}: {errs}")
-        # bisect: the same inputs with single features switched off
-        from npi_gnn_amd import functional as NF
-        for flag in ("GAT_FUSED_BACKWARD", "GAT_ITEM_SCANS", "OVERLAP_STREAMS", None):
+        # bisect: the same inputs with single arrangements switched off
+        for name, sch in (("default", SCH), ("no rank-2 epilogue", SCH.but(gat_rank2_epilogue=False)),
+                          ("one stream", SCH.but(overlap_streams=False))):
             for use_relu in ((relu, False) if relu else (False,)):
-                if flag:
-                    setattr(NF, flag, False)
                 xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
-                o = npi.gat_conv(xd, ei.to(dev), Wd, ad, bd, heads=H, relu=use_relu)
+                o = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=use_relu, schedule=sch)
                 if relu and not use_relu:
                     o = torch.relu(o)
                 o.backward(go.to(dev))
                 e = float((xd.grad.cpu().double() - xr.grad).abs().max()) / max(float(xr.grad.abs().max()), 1e-3)
-                print(f"   {flag}=False fused_relu={use_relu}: dx err {e:.2e}")
-                if flag:
-                    setattr(NF, flag, True)
+                print(f"   {name}, fused_relu={use_relu}: dx err {e:.2e}")
         sys.exit(1)
-lib.npi_small_graph_entries(default_thr)
 print(f"{cases} cases ok, worst relative error {worst:.2e}")

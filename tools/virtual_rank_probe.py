@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One virtual rank of a W-rank run on this GPU (collectives = local copies): wall time per step, GPU time per step
+"""One virtual rank of a W-rank run on this GPU (collectives = local copies on a stream of their own, npi_gnn_amd.virtual): wall time per step, GPU time per step
 (events), and -- under `rocprofv3 --kernel-trace --stats` -- the kernels of a rank's step.
 usage: python tools/virtual_rank_probe.py [--world 8] [--rank 0] [--conv sage|gat] [--partition hubs] [--steps 20] [--capture]"""
 import argparse
@@ -23,27 +23,16 @@ def main():
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--capture", action="store_true")
+    ap.add_argument("--inline-copies", action="store_true", help="stand-in copies on the compute stream (default: their own stream)")
     a = ap.parse_args()
     from npi_gnn_amd import dist as ND
     from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
     dev = torch.device("cuda:0")
     N, E, F, W, r = a.nodes, a.edges, a.hidden, a.world, a.rank
 
-    class Done:
-        def wait(self):
-            return True
-
-    def ag(block, out, w, group=None, async_op=False):
-        out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1))
-        return Done() if async_op else None
-
-    def rs(part_sums, out, rank, w, group=None, async_op=False):
-        out.copy_(part_sums.view(w, -1)[rank].view_as(out))
-        return Done() if async_op else None
-
-    ND.all_gather_rows, ND.reduce_scatter_rows = ag, rs
-    ND._all_reduce = lambda *x, **k: None
-    ND._solo = lambda w: False
+    from npi_gnn_amd.virtual import StubCollectives
+    stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev))
+    stub.__enter__()                                       # for the life of the process
     ei = bipartite_edge_index(N, E, seed=20260310).to(dev)
     g = torch.Generator().manual_seed(3)
     Wm = ((torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
