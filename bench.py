@@ -391,18 +391,39 @@ def virtual_c5(dev, ei5, N5, F5, weights, att, t1_ms, W, ref=None):
                           f"{W}-rank run timed alone on this GPU (collectives = local copies); T1 = C5_1gpu")
     if ref is not None:
         try:
-            from npi_gnn_amd.virtual import sharded_stack_errors
-            x5, go5, ref_out, ref_dx, ref_grads = ref
-            errs = sharded_stack_errors(
-                W, ei5, N5, hub, lambda sg: [ND.ShardedGATLayer(sg, Wk.to(dev), att[k].to(dev), bk.to(dev))
-                                             for k, (Wk, bk) in enumerate(weights)],
-                x5, go5, ref_out, ref_dx, ref_grads, dev)
-            passes = errs.pop("lockstep_passes")
-            res["parity"] = {"parity_max_err": max(errs.values()), "by_tensor": errs, "lockstep_passes": passes,
-                             "against": f"the single-GPU 3-layer stack on the whole graph; the {W} ranks in exact lock step on this "
-                                        "GPU (true all-gather / reduce-scatter / all-reduce results), every rank's rows of the "
-                                        "stack's output and of dX and every layer's all-reduced dW / d att / db, max over ranks, "
-                                        "relative to the largest reference magnitude"}
+            from npi_gnn_amd.virtual import gat_stack_reference, sharded_stack_errors, stack_distance
+            x5, go5 = ref
+            params = [(Wk.to(dev), att[k].to(dev), bk.to(dev)) for k, (Wk, bk) in enumerate(weights)]
+
+            def layers_of(ps):
+                return lambda sg: [ND.ShardedGATLayer(sg, W_, a_, b_) for W_, a_, b_ in ps]
+            # ONE layer (well conditioned): strict
+            r1 = gat_stack_reference(ei5, N5, params[:1], x5, go5, relu=False)
+            e1 = sharded_stack_errors(W, ei5, N5, hub, layers_of(params[:1]), x5, go5, *r1, dev, relu_between=False)
+            p1 = e1.pop("lockstep_passes")
+            del r1
+            torch.cuda.empty_cache()
+            # the 3-layer stack of the timing, against the single-GPU stack AND against the stack's own fp32 noise floor
+            rs = gat_stack_reference(ei5, N5, params, x5, go5, relu=True)
+            fls = [stack_distance(gat_stack_reference(ei5, N5, params, x5, go5, relu=True, permute_seed=sd), rs) for sd in (5, 6)]
+            floor = {k: max(f[k] for f in fls) for k in fls[0]}
+            torch.cuda.empty_cache()
+            e3 = sharded_stack_errors(W, ei5, N5, hub, layers_of(params), x5, go5, *rs, dev, relu_between=True)
+            p3 = e3.pop("lockstep_passes")
+            del rs
+            ratio = {k: (v / floor[k] if floor[k] > 0 else None) for k, v in e3.items() if k.endswith(".l2") and not k.startswith("out")}
+            res["parity"] = {
+                "parity_max_err": max(list(e1.values()) + [e3["out"], e3["out.l2"]]),
+                "one_layer": {"by_tensor": e1, "lockstep_passes": p1},
+                "stack": {"by_tensor": e3, "fp32_noise_floor": floor, "err_over_floor": ratio,
+                          "max_err_over_floor": max(v for v in ratio.values() if v is not None), "lockstep_passes": p3},
+                "against": f"the single-GPU GATConv on the whole graph; the {W} ranks in exact lock step on this GPU (true all-gather / "
+                           "reduce-scatter / all-reduce results); every rank's rows of out and dX and the all-reduced dW / d att / db, max "
+                           "over ranks; <tensor>: max |diff| / max |reference|, <tensor>.l2: ||diff|| / ||reference||.  parity_max_err = "
+                           "every tensor of ONE layer and the output of the 3-layer stack.  The stack's GRADIENTS are reported against its "
+                           "own fp32 noise floor = the distance between two single-GPU runs that differ only in the order of the edge list (max of two "
+                           "such runs; err_over_floor on the L2 figures) "
+                           "(the backward of a deep random GAT stack is ill-conditioned: 1e-4 .. 1e-3 on this data whoever computes it)"}
             res["parity_max_err"] = res["parity"]["parity_max_err"]
         except Exception as e:                                  # noqa: BLE001
             res["parity"] = {"parity_max_err": None, "error": f"{type(e).__name__}: {e}"[:300]}
@@ -629,21 +650,9 @@ def run_configs(dev, args, c4):
                                          "one per layer)", src)
             res5 = {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU",
                     "ms_per_step": ms, "edge_layers_per_s": 3 * E5 / ms * 1e3, "roofline": roof}
-            del st
-            ref = None
-            if args.virtual_world > 1:
-                # the reference of the 8-rank parity check: the single-GPU stack once more, with an explicit output gradient
-                go5 = torch.randn(N5, F5, generator=gen).to(dev)
-                ps = [(Wk.to(dev).requires_grad_(True), ak.to(dev).requires_grad_(True), bk.to(dev).requires_grad_(True))
-                      for (Wk, bk), ak in zip(weights, att)]
-                xin = x5.detach().requires_grad_(True)
-                h = xin
-                for Wk, ak, bk in ps:
-                    h = npi.gat_conv(h, g5, Wk, ak, bk, heads=1, relu=True)
-                h.backward(go5)
-                ref = (x5, go5, h.detach(), xin.grad, [{"weight": Wk.grad, "att": ak.grad, "bias": bk.grad} for Wk, ak, bk in ps])
-                del h, xin, ps
-            del x5, g5
+            del st, g5
+            x5 = x5.detach()
+            ref = (x5, torch.randn(N5, F5, generator=gen).to(dev)) if args.virtual_world > 1 else None     # inputs of the parity check
             torch.cuda.empty_cache()
             if args.virtual_world > 1:
                 # BASELINE.json configs[4] in its 8-GPU form, rank by rank on this GPU: the same 3-layer GATConv stack on the
@@ -653,7 +662,7 @@ def run_configs(dev, args, c4):
                     res5["w8_virtual"] = virtual_c5(dev, ei5, N5, F5, weights, att, ms, args.virtual_world, ref=ref)
                 except Exception as e:
                     res5["w8_virtual"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            del ei5, ref
+            del ei5, ref, x5
             return res5
         guarded("C5_1gpu", c5)
     return out

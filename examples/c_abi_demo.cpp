@@ -64,6 +64,8 @@ int main() {
     float* carry = device_alloc<float>((size_t)npi_segsum_carry_elems(nnz_max, item_edges, Fin));
     float* out = device_alloc<float>(N * Fout);
     if (!agg || !carry || !out) return 2;
+    // the scratch holds arrival counters: zero it ONCE after allocating it (every launch leaves them at zero again)
+    HIP_OK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)npi_segsum_carry_elems(nnz_max, item_edges, Fin), stream));
     NPI_CALL(npi_segsum(rowptr, col, item_row, item_edges, /*w=*/nullptr, N, nnz_max, d_x, Fin, agg, Fin, Fin, NPI_F32, /*mean=*/1, /*bias=*/nullptr, carry, stream));
     NPI_CALL(npi_linear_fwd(agg, Fin, d_W, Fout, d_b, /*rowscale=*/nullptr, out, Fout, N, Fin, Fout, /*relu=*/0, stream));
     std::vector<float> got(N * Fout);

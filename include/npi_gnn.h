@@ -121,8 +121,12 @@ int npi_edge_positions(const int32_t* eid, const int32_t* rowptr, int64_t N, int
  *   x, out     : [N, F] row-major, leading dimension ldx / ldo (elements), dtype f32 or bf16
  *                (bf16 storage, f32 accumulation)
  *   item_row, item_edges : as the CSR was built (npi_csr_build / npi_csr_filter)
- *   carry      : f32 scratch, npi_segsum_carry_elems(nnz_max, item_edges, F) elements, for rows cut by an
- *                item boundary (combined in item order => bitwise reproducible)
+ *   carry      : f32 scratch, npi_segsum_carry_elems(nnz_max, item_edges, F) elements: the partial sums of rows cut by a
+ *                workgroup boundary and the agent-scope arrival counters through which the LAST workgroup to deliver a
+ *                partial of a row sums that row's chain inside the same launch (in a fixed order => bitwise reproducible;
+ *                no second launch).  ZERO IT ONCE after allocating it: every launch resets the counters it used, so the
+ *                buffer can be reused launch after launch (any width F' <= F, this CSR or another of no larger capacity);
+ *                two launches that may run CONCURRENTLY need two buffers.
  * ------------------------------------------------------------------------------------------ */
 int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, int64_t F);
 int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,

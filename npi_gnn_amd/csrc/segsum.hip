@@ -10,8 +10,9 @@
 // owns VEC consecutive feature columns of a row (F = 256 f32: one global_load_dwordx4 wave
 // instruction == one 1 KiB row), accumulates in registers, and a row is written when its last
 // entry has been added -- so a 540k-entry hub row and a 3-entry row cost the same per entry.
-// Rows cut by an item boundary leave f32 partial sums in `carry`; the item that holds the row's
-// first entry adds them up in item order (segsum_fixup_kernel) => bitwise reproducible.
+// Rows cut by an item boundary are finished INSIDE the launch: partials meet in LDS when the cut lies inside a workgroup
+// (4 items), in `carry` otherwise, where the last workgroup to deliver a row's partial adds the chain up in a fixed order
+// (see "rows cut by an item boundary" below) => one launch per aggregation, bitwise reproducible.
 //
 // The per-entry weight comes in four flavours (WMODE):
 //   W_NONE     1                                   SAGEConv (mean or sum)
@@ -148,28 +149,245 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
 static unsigned seg_grid(int n_items) { return (unsigned)ceil_div(n_items, SEG_WAVES); }
 __device__ __forceinline__ int item_block(int b, int) { return b; }
 
+
+// ---- rows cut by an item boundary: resolved INSIDE the launch ------------------------------------------------------------------
+// A wavefront that leaves a row unfinished (the row began in an earlier item: "head" partial; the row continues in the next
+// item: "tail" partial) parks the f32 partial in LDS.  The wavefront of the workgroup that finishes LAST (an LDS arrival
+// counter: no barrier, the other waves have left) walks the workgroup's SEG_WAVES items in order and
+//   * finishes every row that lies inside the workgroup (tail of item i + heads of the items behind it, in item order),
+//   * is left with at most two partials that concern OTHER workgroups: the head partial of a row that began before the
+//     workgroup's first entry and the tail partial of a row that runs past its last one.
+// Those go to `carry` in global memory, and the chain of a row's workgroup-level partials is summed by whichever workgroup
+// delivers the LAST of them -- an agent-scope arrival counter per row, kept at the row's FIRST workgroup.  A long chain (a hub
+// row: 400 workgroup partials at C4, 2,000 at C5) is summed in two levels: the heads that fall into one span of CHAIN_SPAN
+// workgroups by the last arriver of that span, the span sums (+ the tail) by the last arriver of the row.  Which workgroup
+// does a sum depends on timing; WHAT it adds in which order does not (item order inside a workgroup, workgroup order inside
+// a span, span order inside a row): the result is bitwise reproducible.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md, inter-workgroup visibility): the partial rows are
+// stored write-through (sc1), the storing wave drains its stores (s_waitcnt vmcnt(0)), ONE lane signals with an agent-scope
+// atomic add whose returned value tells the last arriver; that wave makes one agent-scope acquire and then loads.  Every
+// counter is reset by its last arriver, so the words are zero again when the launch ends: `carry` has to be zeroed ONCE, when
+// it is allocated (npi_segsum_carry_elems), not per launch.
+constexpr int CHAIN_SPAN = 64;       // workgroups per span of the two-level sum; chains up to this length are summed directly
+constexpr int CHAIN_U = 8;           // partial rows in flight while a chain is summed
+
+struct ItemMeta {                    // what a wavefront leaves behind for the resolver (LDS)
+    int head_row, head_rs, head_re, head_closed;     // head_row < 0: no head partial; closed: the row ended inside the item
+    int tail_row, tail_rs, tail_re;                   // tail_row < 0: no tail partial
+};
+
+struct CarryLayout {                 // global scratch of one launch (f32 words); n_wg = workgroups of the launch
+    int64_t n_wg, n_span;
+    __host__ __device__ CarryLayout(int64_t n_items) {
+        n_wg = (n_items + SEG_WAVES - 1) / SEG_WAVES;
+        n_span = (n_wg + CHAIN_SPAN - 1) / CHAIN_SPAN;
+    }
+    // [counters: n_wg row counters, 2 n_span span counters][pad to 64 words][2 n_wg rows of F][2 n_span rows of F]
+    __host__ __device__ int64_t counters() const { return ((n_wg + 2 * n_span + 63) / 64) * 64; }
+    __host__ __device__ int64_t elems(int64_t F) const { return counters() + (2 * n_wg + 2 * n_span) * F; }
+};
+
+// write-through (sc1) stores of a partial row: hipcc does not count an asm store, the caller drains with drain_stores()
+template <int VEC>
+__device__ __forceinline__ void store_row_sc1(float* p, const float (&d)[VEC]) {
+    if constexpr (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v = {d[0], d[1], d[2], d[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    } else if constexpr (VEC == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 v = {d[0], d[1]};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    } else {
+        asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d[0]) : "memory");
+    }
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// one lane adds 1 to an agent-scope counter; true in every lane of the wave iff this arrival was the `expected`-th.  The last
+// arriver resets the counter (nobody else touches it any more in this launch) and makes the acquire its loads need.
+__device__ __forceinline__ bool arrive_last(int* cnt, int expected) {
+    int old = 0;
+    if (lane_id() == 0) old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = uniform_i(old);
+    if (old != expected - 1) return false;
+    if (lane_id() == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+// acc += rows [j0, j1) of `base` (row stride `stride` floats), CHAIN_U rows in flight, in row order
+template <int VEC, int NCH, class Geo>
+__device__ __forceinline__ void add_rows(const Geo& L, float (&acc)[NCH][VEC], const float* base, int64_t stride, int j0, int j1) {
+    int j = j0;
+    for (; j + CHAIN_U <= j1; j += CHAIN_U) {
+        float v[CHAIN_U][NCH][VEC];
+#pragma unroll
+        for (int u = 0; u < CHAIN_U; ++u) {
+            const float* src = base + (int64_t)(j + u) * stride;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (L.act[c]) load_row<VEC, float>(src + L.foff[c], v[u][c]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) v[u][c][k] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CHAIN_U; ++u)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[c][k] += v[u][c][k];
+    }
+    for (; j < j1; ++j) {
+        const float* src = base + (int64_t)j * stride;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float v[VEC];
+            if (L.act[c]) {
+                load_row<VEC, float>(src + L.foff[c], v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[c][k] += v[k];
+            }
+        }
+    }
+}
+
+// The resolver wave hands over a workgroup-level partial of row r = entries [rs, re): `slot` 0 = head (the row began before
+// this workgroup), 1 = tail (the row began in it).  Whoever delivers the last partial of the row sums the chain and finishes it.
+template <int VEC, int NCH, class Geo, class Fin>
+__device__ __forceinline__ void emit_partial(const SegParams& P, const Geo& L, const Fin& finish, float (&acc)[NCH][VEC],
+                                             int slot, int r, int rs, int re) {
+    const int F = P.F;
+    const int S = P.item * SEG_WAVES;                                  // entries per workgroup
+    const CarryLayout lay(P.n_items);
+    int* cnt_row = reinterpret_cast<int*>(P.carry);
+    int* cnt_span = cnt_row + lay.n_wg;
+    float* rows = P.carry + lay.counters();                             // [2 n_wg, F]
+    float* span_rows = rows + 2 * lay.n_wg * (int64_t)F;                // [2 n_span, F]
+    const int b = blockIdx.x;
+    const int fi = rs / S, li = (re - 1) / S, len = li - fi;            // workgroups of the row: fi .. li (len >= 1)
+    float* mine = rows + ((int64_t)b * 2 + slot) * F;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (L.act[c]) store_row_sc1<VEC>(mine + L.foff[c], acc[c]);
+    drain_stores();
+    auto load_tail = [&]() {                                            // the row's first partial: the tail of workgroup fi
+        const float* t = rows + ((int64_t)fi * 2 + 1) * F;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (L.act[c]) load_row<VEC, float>(t + L.foff[c], acc[c]);
+            else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[c][k] = 0.f;
+            }
+        }
+    };
+    if (len <= CHAIN_SPAN) {                                            // tail + len heads: summed directly
+        if (!arrive_last(cnt_row + fi, len + 1)) return;
+        load_tail();
+        add_rows<VEC, NCH>(L, acc, rows + (int64_t)(fi + 1) * 2 * F, 2 * (int64_t)F, 0, len);      // heads of fi + 1 .. li
+        finish(acc, r, re - rs);
+        return;
+    }
+    const int g0 = (fi + 1) / CHAIN_SPAN, g1 = li / CHAIN_SPAN;          // spans that hold heads of this row
+    if (slot == 0) {
+        const int g = b / CHAIN_SPAN;
+        const int s = fi >= g * CHAIN_SPAN ? 1 : 0;                      // the row began inside this span / before it
+        const int lo = max(fi + 1, g * CHAIN_SPAN), hi = min(li, g * CHAIN_SPAN + CHAIN_SPAN - 1);
+        if (!arrive_last(cnt_span + 2 * g + s, hi - lo + 1)) return;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[c][k] = 0.f;
+        add_rows<VEC, NCH>(L, acc, rows + (int64_t)lo * 2 * F, 2 * (int64_t)F, 0, hi - lo + 1);
+        float* sp = span_rows + ((int64_t)2 * g + s) * F;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (L.act[c]) store_row_sc1<VEC>(sp + L.foff[c], acc[c]);
+        drain_stores();
+    }
+    if (!arrive_last(cnt_row + fi, 1 + (g1 - g0 + 1))) return;           // the tail + one arrival per span
+    load_tail();
+    // span g0 holds the row in its slot 1 when the row began inside it, in slot 0 otherwise; every later span in slot 0
+    add_rows<VEC, NCH>(L, acc, span_rows + ((int64_t)2 * g0 + (fi >= g0 * CHAIN_SPAN ? 1 : 0)) * F, 0, 0, 1);
+    if (g1 > g0) add_rows<VEC, NCH>(L, acc, span_rows + (int64_t)2 * (g0 + 1) * F, 2 * (int64_t)F, 0, g1 - g0);
+    finish(acc, r, re - rs);
+}
+
+// Every wave calls this when its item is done (inactive waves too).  `part`: [SEG_WAVES][2][ROWF] LDS rows, `meta`: [SEG_WAVES],
+// both filled in by the waves themselves (lane 0 writes the meta words at the moment they are known).
+template <int VEC, int NCH, int ROWF, class Geo, class Fin>
+__device__ __forceinline__ void resolve_block(const SegParams& P, const Geo& L, const Fin& finish, float (*part)[2][ROWF],
+                                              ItemMeta* meta, int* arrived) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                // the wave's partial rows and meta (LDS) before its arrival
+    int old = 0;
+    if (lane_id() == 0) old = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = uniform_i(old);
+    if (old != SEG_WAVES - 1) return;                                   // not the last wave of the workgroup
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float acc[NCH][VEC];
+    bool open = false, wg_head = false;
+    int orow = 0, ors = 0, ore = 0;
+    auto load_part = [&](int w, int slot, bool add) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float v[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+            if (L.act[c]) load_row<VEC, float>(&part[w][slot][L.foff[c]], v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[c][k] = add ? acc[c][k] + v[k] : v[k];
+        }
+    };
+    for (int w = 0; w < SEG_WAVES; ++w) {                               // (wave-uniform control flow: meta is read by every lane)
+        const int m_head_row = meta[w].head_row, m_tail_row = meta[w].tail_row;
+        if (m_head_row >= 0) {
+            if (!open) {                                                // the row began before this workgroup
+                load_part(w, 0, false);
+                open = true; wg_head = true; orow = m_head_row; ors = meta[w].head_rs;
+            } else {
+                load_part(w, 0, true);                                  // the open row runs on through this item
+            }
+            ore = meta[w].head_re;
+            if (meta[w].head_closed) {
+                if (wg_head) emit_partial<VEC, NCH>(P, L, finish, acc, 0, orow, ors, ore);
+                else finish(acc, orow, ore - ors);                      // began and ended inside the workgroup
+                open = false;
+            }
+        }
+        if (m_tail_row >= 0) {
+            load_part(w, 1, false);
+            open = true; wg_head = false; orow = m_tail_row; ors = meta[w].tail_rs; ore = meta[w].tail_re;
+        }
+    }
+    if (open) {
+        // wg_head: the whole workgroup lies inside one row
+        emit_partial<VEC, NCH>(P, L, finish, acc, wg_head ? 0 : 1, orow, ors, ore);
+    }
+}
+
+// one item: `part` = this wave's two LDS rows ([2][NCH VEC WAVE]: head partial, tail partial), `M` = what it leaves behind
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
-__global__ void __launch_bounds__(SEG_THREADS)
-segsum_kernel(SegParams P) {
+__device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC, NCH, WMODE, EXACT>& L, const int item,
+                                            float* __restrict__ part, ItemMeta* __restrict__ M) {
     constexpr int U = inflight<VEC, NCH>::value;
+    constexpr int ROWF = NCH * VEC * WAVE;
     const int lane = lane_id();
-    const int item = uniform_i(item_block(blockIdx.x, gridDim.x) * SEG_WAVES + (threadIdx.x >> 6));
-    if (item >= P.n_items) return;
     const int N = P.N;
     const int nnz = P.rowptr[N];
     const int k0 = item * P.item;
     // a CSR with capacity but no entry at all (every edge dropped): item 0 still runs and closes all N empty rows
     if (k0 >= nnz && !(item == 0 && nnz == 0)) return;
     const int k1 = min(k0 + P.item, nnz);
-    const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
     // second part of the table, biased so that it is indexed by the column id itself (sharded layers: the gathered hub
     // rows and the rank's own rows are two buffers; dist.py)
     const T* __restrict__ x2T = reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(P.x2) - (uint64_t)P.split * (uint64_t)P.ldx * sizeof(T));
     const int split = P.split;
-
-    Lanes<VEC, NCH, WMODE, EXACT> L;
-    L.init(P);
 
     int r = uniform_i(P.item_row[item]);
     int row_start = uniform_i(P.rowptr[r]);
@@ -215,8 +433,8 @@ segsum_kernel(SegParams P) {
     };
     open_row();
 
-    auto write_carry = [&](int slot) {
-        float* __restrict__ dst = P.carry + ((int64_t)item * 2 + slot) * F;
+    auto write_carry = [&](int slot) {                                   // to LDS: resolve_block takes it from there
+        float* __restrict__ dst = part + slot * ROWF;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
             if (L.act[c]) store_row<VEC, float>(dst + L.foff[c], acc[c]);
@@ -225,6 +443,7 @@ segsum_kernel(SegParams P) {
     auto close_row = [&]() {
         if (head) {
             write_carry(0);
+            if (lane == 0) { M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 1; }
             head = false;
         } else {
             finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_end - row_start);
@@ -454,26 +673,51 @@ segsum_kernel(SegParams P) {
         while (r < N && row_end == k1) close_row();      // empty rows behind it (out = bias)
     } else if (head) {
         write_carry(0);                                  // one row spans the whole item
+        if (lane == 0) { M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 0; }
     } else {
         write_carry(1);                                  // row continues in the next item
+        if (lane == 0) { M->tail_row = r; M->tail_rs = row_start; M->tail_re = row_end; }
     }
+}
+
+// the HBM-bound kernels of the headline (one 16-byte chunk per lane, no GAT weights) must keep 8 waves per SIMD: <= 64 VGPRs
+template <int VEC, int NCH, int WMODE, bool EXACT> struct seg_min_waves { static constexpr int value = (NCH == 1 && WMODE <= W_ARRAY && EXACT) ? 8 : 1; };
+
+template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
+__global__ void __launch_bounds__(SEG_THREADS, (seg_min_waves<VEC, NCH, WMODE, EXACT>::value))
+segsum_kernel(SegParams P) {
+    constexpr int ROWF = NCH * VEC * WAVE;
+    __shared__ __attribute__((aligned(16))) float s_part[SEG_WAVES][2][ROWF];
+    __shared__ ItemMeta s_meta[SEG_WAVES];
+    __shared__ int s_arrived;
+    if (threadIdx.x == 0) s_arrived = 0;
+    if (threadIdx.x < SEG_WAVES) { s_meta[threadIdx.x].head_row = -1; s_meta[threadIdx.x].tail_row = -1; }   // "no partial"
+    __syncthreads();
+    const int wave = uniform_i(threadIdx.x >> 6);           // wave-uniform: LDS addresses derived from it stay in SGPRs
+    const int item = uniform_i(item_block(blockIdx.x, gridDim.x) * SEG_WAVES + wave);
+    Lanes<VEC, NCH, WMODE, EXACT> L;
+    L.init(P);
+    if (item < P.n_items) segsum_item<T, VEC, NCH, WMODE, EXACT>(P, L, item, &s_part[wave][0][0], s_meta + wave);
+    auto finish = [&](const float (&acc)[NCH][VEC], int r, int row_len) { finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_len); };
+    resolve_block<VEC, NCH, ROWF>(P, L, finish, s_part, s_meta, &s_arrived);
 }
 
 // Narrow rows (F <= 32 VEC: hidden = 128 or 64 in f32, the reference's own model width): one row is only
 // half / a quarter of a wave instruction, so G = 2 or 4 ENTRIES are gathered per instruction -- lane group
 // g = lane / (64 / G) fetches entry G j + g -- and every group keeps its own partial sum of the open row.
 // Entries are still added in entry order (group 0, a possible row close, group 1, ...); at a row close
-// the G partials are folded across the lane groups (xor shuffles) and group 0 stores.  Same items, carry
-// format and fix-up kernel as the wide path; W_NONE / W_ARRAY only.
+// the G partials are folded across the lane groups (xor shuffles) and group 0 stores.  Same items and the same in-launch
+// resolution of cut rows as the wide path (the lanes of group 0 own the columns); W_NONE / W_ARRAY only.
+template <int VEC> struct GroupLanes { bool act[1]; int foff[1]; };
+
 template <typename T, int VEC, int G, int WMODE>
-__global__ void __launch_bounds__(SEG_THREADS)
-segsum_group_kernel(SegParams P) {
+__device__ __forceinline__ void segsum_group_item(const SegParams& P, const int item, float* __restrict__ part,
+                                                  ItemMeta* __restrict__ M) {
     constexpr int LG = WAVE / G;                           // lanes per entry group
+    constexpr int ROWF = LG * VEC;
     constexpr int U = 8 / G < 2 ? 2 : 8 / G;               // wave instructions in flight: U * G = 8 rows (16 or 32 rows: no gain at
                                                            // 58k edges, -3 % / -40 % at 20M)
     const int lane = lane_id();
-    const int item = uniform_i(item_block(blockIdx.x, gridDim.x) * SEG_WAVES + (threadIdx.x >> 6));
-    if (item >= P.n_items) return;
     const int N = P.N;
     const int nnz = P.rowptr[N];
     const int k0 = item * P.item;
@@ -512,7 +756,8 @@ segsum_group_kernel(SegParams P) {
         float t[VEC];
         fold(t);
         if (head) {
-            if (act && grp == 0) store_row<VEC, float>(P.carry + ((int64_t)item * 2 + 0) * F + foff, t);
+            if (act && grp == 0) store_row<VEC, float>(part + foff, t);
+            if (lane == 0) { M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 1; }
             head = false;
         } else if (act && grp == 0) {
             const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
@@ -573,177 +818,54 @@ segsum_group_kernel(SegParams P) {
     } else {
         float t[VEC];
         fold(t);
-        if (act && grp == 0) store_row<VEC, float>(P.carry + ((int64_t)item * 2 + (head ? 0 : 1)) * F + foff, t);
+        if (act && grp == 0) store_row<VEC, float>(part + (head ? 0 : ROWF) + foff, t);
+        if (lane == 0) {
+            if (head) { M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 0; }   // one row spans the whole item
+            else { M->tail_row = r; M->tail_rs = row_start; M->tail_re = row_end; }                            // row continues in the next item
+        }
     }
 }
 
-// Fix-up: the item holding a cut row's FIRST entry (the "owner") sums that row's partials in item order.
-// A workgroup takes FIX_SPAN items.  One thread per item finds out whether it owns a cut row and how long its
-// chain of partials is (three dependent index loads -- paid once per span, not once per workgroup as with a
-// workgroup per item); then each wave walks its share of the span's owners and adds up the SHORT chains (the
-// common case: tail of item i + head of item i + 1); finally the whole workgroup takes the span's LONG
-// chains (a hub row: ~1,600 partials at C4) one by one: 4 contiguous slices, one per wave with 8 loads in
-// flight, slice sums added in slice order.  Every order of addition is fixed by the data, never by
-// scheduling => bitwise reproducible.
-constexpr int FIX_COOP_MIN = 16;     // chain length from which the whole workgroup cooperates
-constexpr int FIX_U = 8;
-constexpr int FIX_SPAN = 64;         // items per workgroup (16 / 32: same time -- the hub row's chain sets it: ~40 us at C4)
-
-// (owner?, row, first entry, end entry, chain length) of `item`
-__device__ __forceinline__ bool fix_owner(const SegParams& P, int item, int nnz, int& r, int& rs, int& re, int& len) {
-    const int k0 = item * P.item, k1 = k0 + P.item;
-    if (item >= P.n_items || k1 >= nnz) return false;            // last item: nothing continues
-    r = P.item_row[item + 1];                                     // row holding entry k1
-    rs = P.rowptr[r];
-    if (rs >= k1 || rs < k0) return false;                        // not cut here / owned by an earlier item
-    re = P.rowptr[r + 1];
-    len = (re - 1) / P.item - item;                                 // head partials to add (>= 1)
-    return true;
-}
-
-// Waves per fix-up workgroup: the long chain of a hub row (1,600 partial rows at C4) is summed by ONE workgroup, every wave
-// a slice with FIX_U row loads in flight -- a latency chain.  With one 256-column chunk per lane the kernel needs < 64 VGPRs, so
-// the workgroup is 16 waves (1,024 threads) instead of 4: the hub chain's slices shrink from 400 to 100 partials (72 -> ~25 us
-// per launch at C4); wider rows keep 4 waves (their staging registers would not fit 1,024 threads).
-template <int NCH> struct fix_waves { static constexpr int value = NCH == 1 ? 16 : SEG_WAVES; };
-
-template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
-__global__ void __launch_bounds__(fix_waves<NCH>::value * WAVE)
-segsum_fixup_kernel(SegParams P) {
-    constexpr int FW = fix_waves<NCH>::value;
-    __shared__ int s_row[FIX_SPAN], s_rs[FIX_SPAN], s_re[FIX_SPAN], s_len[FIX_SPAN];
-    __shared__ float red[FW][NCH * VEC * WAVE];
-    const int lane = lane_id();
-    const int wave = uniform_i(threadIdx.x >> 6);
-    const int base = blockIdx.x * FIX_SPAN;
-    const int N = P.N, F = P.F;
-    const int nnz = P.rowptr[N];
-    if (threadIdx.x < FIX_SPAN) {
-        int r = -1, rs = 0, re = 0, len = 0;
-        const bool own = fix_owner(P, base + threadIdx.x, nnz, r, rs, re, len);
-        s_row[threadIdx.x] = own ? r : -1;
-        s_rs[threadIdx.x] = rs; s_re[threadIdx.x] = re; s_len[threadIdx.x] = own ? len : 0;
-    }
+template <typename T, int VEC, int G, int WMODE>
+__global__ void __launch_bounds__(SEG_THREADS, 8)            // 8 waves per SIMD: <= 64 VGPRs, <= 96 SGPRs
+segsum_group_kernel(SegParams P) {
+    constexpr int LG = WAVE / G;
+    constexpr int ROWF = LG * VEC;
+    __shared__ __attribute__((aligned(16))) float s_part[SEG_WAVES][2][ROWF];
+    __shared__ ItemMeta s_meta[SEG_WAVES];
+    __shared__ int s_arrived;
+    if (threadIdx.x == 0) s_arrived = 0;
+    if (threadIdx.x < SEG_WAVES) { s_meta[threadIdx.x].head_row = -1; s_meta[threadIdx.x].tail_row = -1; }   // "no partial"
     __syncthreads();
-    Lanes<VEC, NCH, WMODE, EXACT> L;
-    L.init(P);
-    // short chains: one wave each
-    for (int q = wave; q < FIX_SPAN; q += FW) {
-        const int r = s_row[q], len = s_len[q];
-        if (r < 0 || len >= FIX_COOP_MIN) continue;              // wave-uniform
-        const int item = base + q;
-        float acc[NCH][VEC];
+    const int wave = uniform_i(threadIdx.x >> 6);           // wave-uniform: LDS addresses derived from it stay in SGPRs
+    const int lane = lane_id();
+    const int item = uniform_i(item_block(blockIdx.x, gridDim.x) * SEG_WAVES + wave);
+    if (item < P.n_items) segsum_group_item<T, VEC, G, WMODE>(P, item, &s_part[wave][0][0], s_meta + wave);
+    GroupLanes<VEC> L;
+    L.foff[0] = (lane % LG) * VEC;
+    L.act[0] = lane < LG && L.foff[0] < P.F;                 // the lanes of group 0 own the columns
+    auto finish = [&](const float (&acc)[1][VEC], int r, int row_len) {
+        if (!L.act[0]) return;
+        const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
+        const float sc = P.mean ? 1.f / (float)max(row_len, 1) : 1.f;
+        float t[VEC];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (L.act[c]) load_row<VEC, float>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);   // the owner's tail partial
-            else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
-            }
-        }
-        for (int j = 1; j <= len; ++j) {
-            const float* src = P.carry + ((int64_t)(item + j) * 2 + 0) * F;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                float v[VEC];
-                if (L.act[c]) {
-                    load_row<VEC, float>(src + L.foff[c], v);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[c][k] += v[k];
-                }
-            }
-        }
-        finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
-    }
-    // long chains: the whole workgroup, one chain after the other (s_* are read-only from here on)
-    for (int q = 0; q < FIX_SPAN; ++q) {
-        const int r = s_row[q], len = s_len[q];
-        if (r < 0 || len < FIX_COOP_MIN) continue;               // workgroup-uniform
-        const int item = base + q;
-        const int per = (len + FW - 1) / FW;
-        const int jb = item + 1 + wave * per;
-        const int je = min(jb + per, item + len + 1);
-        float acc[NCH][VEC];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            // wave 0 starts from the owner's tail partial, the other slices from zero
-            if (L.act[c] && wave == 0) load_row<VEC, float>(P.carry + ((int64_t)item * 2 + 1) * F + L.foff[c], acc[c]);
-            else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
-            }
-        }
-        int j = jb;
-        for (; j + FIX_U <= je; j += FIX_U) {
-            float v[FIX_U][NCH][VEC];
-#pragma unroll
-            for (int u = 0; u < FIX_U; ++u) {
-                const float* src = P.carry + ((int64_t)(j + u) * 2 + 0) * F;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (L.act[c]) load_row<VEC, float>(src + L.foff[c], v[u][c]);
-                    else {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) v[u][c][k] = 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < FIX_U; ++u)
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[c][k] += v[u][c][k];
-        }
-        for (; j < je; ++j) {
-            const float* src = P.carry + ((int64_t)j * 2 + 0) * F;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                float v[VEC];
-                if (L.act[c]) {
-                    load_row<VEC, float>(src + L.foff[c], v);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[c][k] += v[k];
-                }
-            }
-        }
-        if (wave != 0) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) red[wave][(c * VEC + k) * WAVE + lane] = acc[c][k];
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int w = 1; w < FW; ++w)
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[c][k] += red[w][(c * VEC + k) * WAVE + lane];
-            finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, s_re[q] - s_rs[q]);
-        }
-        __syncthreads();                                          // red is reused by the next long chain
-    }
-}
-
-template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
-static void launch_fixup(const SegParams& P, hipStream_t stream) {
-    segsum_fixup_kernel<T, VEC, NCH, WMODE, EXACT><<<dim3((unsigned)ceil_div(P.n_items, FIX_SPAN)), dim3(fix_waves<NCH>::value * WAVE), 0, stream>>>(P);
+        for (int q = 0; q < VEC; ++q) t[q] = fmaf(acc[0][q], sc, bias ? to_f32(bias[L.foff[0] + q]) : 0.f);
+        store_row<VEC, T>(reinterpret_cast<T*>(P.out) + (int64_t)r * P.ldo + L.foff[0], t);
+    };
+    resolve_block<VEC, 1, ROWF>(P, L, finish, s_part, s_meta, &s_arrived);
 }
 
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 static void launch_one(const SegParams& P, hipStream_t stream) {
     dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
     segsum_kernel<T, VEC, NCH, WMODE, EXACT><<<grid, block, 0, stream>>>(P);
-    launch_fixup<T, VEC, NCH, WMODE, EXACT>(P, stream);
 }
 
 template <typename T, int VEC, int G, int WMODE>
 static void launch_group(const SegParams& P, hipStream_t stream) {
     dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
     segsum_group_kernel<T, VEC, G, WMODE><<<grid, block, 0, stream>>>(P);
-    launch_fixup<T, VEC, 1, WMODE, false>(P, stream);
 }
 template <typename T, int VEC, int G>
 static int launch_group_modes(const SegParams& P, int wmode, int mean, hipStream_t stream) {
@@ -766,11 +888,7 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
     else if (wmode == W_GAT_DST) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, EXACT>(P, stream);
     } else if (wmode == W_GAT_DST_PRE) {
-        if constexpr (VEC == 4 && sizeof(T) == 4) {
-            dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
-            segsum_kernel<T, VEC, NCH, W_GAT_DST_PRE, EXACT><<<grid, block, 0, stream>>>(P);
-            launch_fixup<T, VEC, NCH, W_GAT_DST, EXACT>(P, stream);           // same row epilogue (1 / (s + eps), bias)
-        }
+        if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST_PRE, EXACT>(P, stream);
     } else if (wmode == W_GAT_SRC_PRE) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);
     } else if (is_fused_mode(wmode)) {
@@ -780,7 +898,6 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
             else if (wmode == W_GAT_SRC_FUSED_H2) segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED_H2, EXACT><<<grid, block, 0, stream>>>(P);
             else if (wmode == W_GAT_SRC_FUSED_H4) segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED_H4, EXACT><<<grid, block, 0, stream>>>(P);
             else segsum_kernel<T, VEC, NCH, W_GAT_SRC_FUSED_H8, EXACT><<<grid, block, 0, stream>>>(P);
-            launch_fixup<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);       // same row epilogue
         } else {
             set_error("npi_gat_backward_fused: needs heads * out_channels <= 256");
             return NPI_ERR_ARG;
@@ -871,8 +988,11 @@ using namespace npi;
 
 extern "C" int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, int64_t F) {
     if (!item_edges_ok(item_edges) || F <= 0) return -1;
-    int64_t items = num_items_of(nnz_max, item_edges);
-    return items > 0 ? 2 * items * F : 1;
+    const int64_t items = num_items_of(nnz_max, item_edges);
+    if (items == 0) return 64;
+    // one launch handles at most 1,024 columns (wider rows: several launches over column blocks, one after the other on the
+    // stream, reusing the scratch): arrival counters + two partial rows per workgroup + two span rows per CHAIN_SPAN workgroups
+    return CarryLayout(items).elems(F < 1024 ? F : 1024);
 }
 
 extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,

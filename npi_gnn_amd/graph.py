@@ -110,11 +110,14 @@ class CSRSide:
         return self._inv_cnt
 
     def carry(self, F: int) -> torch.Tensor:
-        """f32 scratch for rows cut by an item boundary; reused across calls of the same width."""
+        """f32 scratch of the aggregation launches (partial sums of rows cut by a workgroup boundary + their arrival
+        counters); reused across calls of the same width.  ZEROED once, here: every launch leaves its counters at zero again
+        (``npi_segsum_carry_elems``).  One buffer per (side, width): launches that may run CONCURRENTLY on two streams must not
+        share a side at the same width."""
         buf = self._carry.get(F)
         if buf is None:
             n = int(load().npi_segsum_carry_elems(self.nnz_max, self.item, F))
-            buf = torch.empty(n, dtype=torch.float32, device=self.rowptr.device)
+            buf = torch.zeros(n, dtype=torch.float32, device=self.rowptr.device)
             self._carry[F] = buf
         return buf
 

@@ -112,6 +112,11 @@ class LockStep(_Patched):
             for r in range(self.W):
                 self.state.update(rank=r, k=0, valid=True)
                 out.append(run_rank(r))
+                # a rank's step uses several HIP streams (partial side, weight gradient); the inputs it left for the collectives
+                # were cloned on whichever stream issued them: everything has to have landed before the next rank / the resolution
+                # (on the default stream) reads them
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 complete = complete and self.state["valid"]
             if complete:
                 return out
@@ -190,14 +195,23 @@ def sharded_stack_errors(world: int, edge_index: torch.Tensor, num_nodes: int, h
     whole graph (normally this package's single-GPU layers, themselves checked by the ``-m gpu`` parity tests).
 
     ``make_layers(sg)`` -> the rank's list of ``dist.Sharded*Layer`` (same parameters on every rank); a rank's output rows
-    are the next layer's input rows (``torch.relu`` in between when ``relu_between``); the last output is driven backward
-    with ``go_full[sg.own]``.  ``ref_out`` / ``ref_dx`` ``[N, F]``: the reference's output and input gradient;
+    are the next layer's input rows (``torch.relu`` behind every layer when ``relu_between``); the last output is driven
+    backward with ``go_full[sg.own]``.  ``ref_out`` / ``ref_dx`` ``[N, F]``: the reference's output and input gradient;
     ``ref_grads[k]``: dict parameter name -> gradient of layer k (already summed over all nodes, as the all-reduce leaves it).
-    Returns the MAX over ranks of |value - reference| / max |reference| for ``out``, ``dX`` and every ``layer<k>.<name>``."""
+
+    Returns, as the MAX over ranks, for ``out``, ``dX`` and every ``layer<k>.<name>``: ``<name>`` = max |value - reference| /
+    max |reference| and ``<name>.l2`` = ||value - reference|| / ||reference|| over the rank's rows (``out`` / ``dX``: the two
+    norms are summed over the ranks first, i.e. the figure is the whole tensor's).  With ReLUs in the stack the max-abs figure
+    of the GRADIENTS is not a rounding measure: an activation whose pre-activation is within rounding of zero may have either
+    sign in two correct fp32 evaluations, and one flipped mask bit moves single gradient elements by their full size -- the L2
+    figure and the no-ReLU stack are the ones to hold to a rounding-level bar."""
     from .schedule import DEFAULT
 
     def rel(a, r):
         return (a.detach() - r).abs().max() / r.abs().max().clamp(min=1e-30)
+
+    def sq(a):
+        return a.detach().double().pow(2).sum()
 
     with LockStep(world) as ls:
         sgs = [ND.ShardedGraph(edge_index, num_nodes, r, world, dev, hub_mask=hub_mask, schedule=schedule or DEFAULT)
@@ -207,21 +221,67 @@ def sharded_stack_errors(world: int, edge_index: torch.Tensor, num_nodes: int, h
             sg = sgs[r]
             layers = make_layers(sg)
             own = sg.own.to(x_full.device)
-            x = x_full[own].to(dev).requires_grad_(True)
+            x = x_full.detach()[own].to(dev).clone().requires_grad_(True)          # a fresh leaf, whatever x_full is
             h = x
-            for k, layer in enumerate(layers):
+            for layer in layers:
                 h = layer(h)
                 if relu_between:
                     h = torch.relu(h)
-            h.backward(go_full[own].to(dev))
-            errs = {"out": rel(h, ref_out[own].to(dev)), "dX": rel(x.grad, ref_dx[own].to(dev))}
+            h.backward(go_full.detach()[own].to(dev))
+            ro, rx = ref_out[own].to(dev), ref_dx[own].to(dev)
+            errs = {"out": rel(h, ro), "dX": rel(x.grad, rx)}
+            norms = {"out": (sq(h - ro), sq(ro)), "dX": (sq(x.grad - rx), sq(rx))}
             for k, layer in enumerate(layers):
                 for name, g in ref_grads[k].items():
-                    errs[f"layer{k}.{name}"] = rel(getattr(layer, name).grad.reshape(g.shape), g.to(dev))
-            return errs
+                    got = getattr(layer, name).grad.reshape(g.shape)
+                    errs[f"layer{k}.{name}"] = rel(got, g.to(dev))
+                    errs[f"layer{k}.{name}.l2"] = (sq(got - g.to(dev)) / sq(g.to(dev)).clamp(min=1e-300)).sqrt()
+            return errs, norms
         per_rank = ls.run(run_rank)
         passes = ls.passes
-    names = sorted(per_rank[0])
-    out = {n: max(float(e[n]) for e in per_rank) for n in names}
+    names = sorted(per_rank[0][0])
+    out = {n: max(float(e[n]) for e, _ in per_rank) for n in names}
+    for n in ("out", "dX"):
+        num = sum(float(nm[n][0]) for _, nm in per_rank)
+        den = sum(float(nm[n][1]) for _, nm in per_rank)
+        out[n + ".l2"] = (num / max(den, 1e-300)) ** 0.5
     out["lockstep_passes"] = passes
+    return out
+
+
+def gat_stack_reference(edge_index: torch.Tensor, num_nodes: int, params, x: torch.Tensor, go: torch.Tensor, relu: bool,
+                        permute_seed=None):
+    """The single-GPU GATConv stack (one head) on the whole graph: ``params`` = [(weight, att, bias), ...] on the device.
+    Returns (out, dX, [{"weight", "att", "bias"} gradients per layer]).  ``permute_seed``: the same stack on the same graph
+    with the COLUMNS OF THE EDGE LIST IN ANOTHER ORDER -- the same mathematics, other summation orders inside every row: the
+    distance between two such runs is the fp32 noise floor of the stack on this data (a deep stack of random GAT layers is
+    ill-conditioned in its backward: the score gradient alpha (<dOut_i, h_j> - D_i) cancels once the features are smooth)."""
+    from .functional import gat_conv
+    from .graph import CSRGraph
+    ei = edge_index
+    if permute_seed is not None:
+        g = torch.Generator(device=ei.device).manual_seed(int(permute_seed))
+        ei = ei[:, torch.randperm(ei.size(1), generator=g, device=ei.device)].contiguous()
+    graph = CSRGraph(ei, num_nodes)
+    ps = [tuple(t.detach().clone().requires_grad_(True) for t in p) for p in params]
+    xin = x.detach().clone().requires_grad_(True)
+    h = xin
+    for W, a, b in ps:
+        h = gat_conv(h, graph, W, a, b, heads=1, relu=relu)
+    h.backward(go)
+    return h.detach(), xin.grad, [{"weight": W.grad, "att": a.grad, "bias": b.grad} for W, a, b in ps]
+
+
+def stack_distance(a, b) -> dict:
+    """the figures of ``sharded_stack_errors`` between two whole-graph results ``(out, dX, grads)``"""
+    def rel(p, r):
+        return float((p - r).abs().max() / r.abs().max().clamp(min=1e-30))
+
+    def l2(p, r):
+        return float((p - r).double().norm() / r.double().norm().clamp(min=1e-300))
+    out = {"out": rel(a[0], b[0]), "out.l2": l2(a[0], b[0]), "dX": rel(a[1], b[1]), "dX.l2": l2(a[1], b[1])}
+    for k, (ga, gb) in enumerate(zip(a[2], b[2])):
+        for n in gb:
+            out[f"layer{k}.{n}"] = rel(ga[n], gb[n])
+            out[f"layer{k}.{n}.l2"] = l2(ga[n], gb[n])
     return out

@@ -75,7 +75,9 @@ def test_size_queries_without_gpu():
         assert lib.npi_num_items(T + 1, item) == T // item + 1
     assert lib.npi_num_items(1000, 128) == -1 and lib.npi_segsum_carry_elems(1000, 100, 256) == -1   # no such item size
     assert lib.npi_csr_workspace_bytes(1000, 10) > 16 * 1000
-    assert lib.npi_segsum_carry_elems(1000, 64, 256) >= 2 * 16 * 256 and lib.npi_segsum_carry_elems(1000, 256, 256) >= 2 * 4 * 256
+    # two partial rows per WORKGROUP (4 items) + two span rows per 64 workgroups + the arrival counters
+    assert lib.npi_segsum_carry_elems(1000, 64, 256) >= (2 * 4 + 2) * 256 + 4 and lib.npi_segsum_carry_elems(1000, 256, 256) >= (2 + 2) * 256
+    assert lib.npi_segsum_carry_elems(21_000_000, 256, 256) < 2 * 82032 * 256       # a quarter of the per-item scratch it replaces
     assert lib.npi_linear_bwd_weight_workspace_elems(1000, 256, 256) >= 256 * 256
 
 

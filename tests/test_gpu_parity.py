@@ -921,6 +921,49 @@ def test_long_chains_of_partials_add_up_exactly(dev, item_entries, F):
     assert torch.allclose(got, ref.double() / cnt, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("item_entries", [64, 256])
+def test_in_launch_chain_resolution_under_load_and_reuse(dev, item_entries):
+    """Rows cut by a workgroup boundary are summed INSIDE the aggregation launch by whichever workgroup delivers a row's last
+    partial (write-through stores, agent-scope arrival counters, one acquire: segsum.hip).  What would break such a hand-off
+    shows only under reuse and uneven load (cdna_hip_programming.md Guideline 16, pitfalls 3 / 10): so the SAME scratch buffer
+    serves 60 launches that alternate between two inputs -- a partial read stale from the previous launch belongs to the other
+    input and changes the (integer-valued, hence exact) sums -- while a second stream keeps the chip busy with another
+    aggregation of changing size, and the sums are compared bit for bit every time.  Long chains (two-level sums), chains that
+    end on span boundaries, short chains and thousands of two-partial rows."""
+    span = 4 * 64 * item_entries                                       # entries of 64 workgroups (one span of the two-level sum)
+    lens = [3, span + 17, 2 * span, 5, 64 * item_entries - 1, 7 * span + 3, 1, 4 * item_entries, 4 * item_entries + 1, 9]
+    g = torch.Generator().manual_seed(item_entries)
+    lens = lens + torch.randint(0, 3 * item_entries, (4000,), generator=g).tolist()
+    n_rows, nnz, n_cols, F = len(lens), sum(lens), 3000, 256
+    key = torch.repeat_interleave(torch.arange(n_rows), torch.tensor(lens))
+    val = torch.randint(0, n_cols, (nnz,), generator=g)
+    side = NG.build_side(key.to(dev), val.to(dev), n_rows, n_cols, self_loops=False, drop_equal=False, item=item_entries)
+    xs = [torch.randint(-3, 4, (n_cols, F), generator=g).float() for _ in range(2)]
+    refs = [torch.zeros(n_rows, F).index_add_(0, key, x[val]).to(dev) for x in xs]
+    xd = [x.to(dev) for x in xs]
+    # the load on the other stream: aggregations over another side (its own scratch), sizes changing from launch to launch
+    lk = torch.randint(0, 2000, (300_000,), generator=g)
+    lv = torch.randint(0, n_cols, (300_000,), generator=g)
+    noise = [NG.build_side(lk[:n].to(dev), lv[:n].to(dev), 2000, n_cols, self_loops=False, drop_equal=False)
+             for n in (300_000, 40_000, 150_000)]
+    other = torch.cuda.Stream(device=dev)
+    out = torch.empty(n_rows, F, device=dev)
+    bad = 0
+    for it in range(60):
+        with torch.cuda.stream(other):
+            NF.segsum(None, noise[it % 3], xd[it % 2])
+        k = (it * 7 + it // 3) % 2
+        NF.segsum(None, side, xd[k], out=out)
+        bad += int((out != refs[k]).any())
+    torch.cuda.synchronize()
+    assert bad == 0
+    # the scratch is left reusable: every arrival counter is back at zero
+    n_items = side.n_items
+    n_wg = -(-n_items // 4)
+    counters = side.carry(F)[: n_wg + 2 * (-(-n_wg // 64))].view(torch.int32)
+    assert int(counters.abs().sum()) == 0
+
+
 def test_a_csr_keeps_its_item_size_when_the_hint_moves(dev):
     """VERDICT r3 item 4 / ADVICE r3 (medium): the item size used to be re-derived at every LAUNCH from a process-wide
     threshold, so a CSR with 2^20 <= capacity < 2^22 built before npi_small_graph_entries moved and aggregated after it was
