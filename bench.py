@@ -556,7 +556,7 @@ def run_configs(dev, args, c4):
         alg = algorithmic_bytes(E4, N4, F) + (E4 + N4) * 4
         tr, src = pmc_of("gcn_segsum_bytes_per_launch")
         return {"workload": f"C4 graph, 1 x GCNConv {F}->{F} fp32 fwd+bwd", "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3,
-                "roofline": agg_roofline(ev, alg, tr, "segsum_kernel<f32, 4, 1, W_ARRAY> (+ fix-up), avg of the forward and the "
+                "roofline": agg_roofline(ev, alg, tr, "segsum_kernel<f32, 4, 1, W_ARRAY> (one launch: cut rows are finished inside it), avg of the forward and the "
                                                       "backward launch (the latter co-resident with dW)", src)}
 
     def gat_c4():
@@ -577,8 +577,8 @@ def run_configs(dev, args, c4):
         torch.cuda.synchronize()
         gb = gat_bytes(E4, N4, F)
         roof = {}
-        for tag, kern in (("gat_fwd_aggregate", "segsum_kernel<f32, 4, 1, W_GAT_DST_PRE> (+ fix-up): weighted aggregation, scores read back"),
-                          ("gat_bwd_fused", "segsum_kernel<f32, 4, 1, W_GAT_SRC_FUSED> (+ fix-up): by-source aggregation + SDDMM in one gather pass")):
+        for tag, kern in (("gat_fwd_aggregate", "segsum_kernel<f32, 4, 1, W_GAT_DST_PRE>: weighted aggregation, scores read back"),
+                          ("gat_bwd_fused", "segsum_kernel<f32, 4, 1, W_GAT_SRC_FUSED>: by-source aggregation + SDDMM in one gather pass")):
             tr, src = pmc_of(tag + "_bytes_per_launch", "stale_gat")
             roof[tag] = agg_roofline(tags.get(tag, []), gb[tag], tr, kern, src)
         by_heads = {}
@@ -611,9 +611,20 @@ def run_configs(dev, args, c4):
             convb.weight.grad = convb.bias.grad = xb.grad = None
             convb(xb, g4).backward(gob)
         ms = _timeit(step, 10, 3)
+        ev = []
+        NF._PROFILE = ev
+        for _ in range(5):
+            step()
+        NF._PROFILE = None
+        torch.cuda.synchronize()
         dev_rel = float((convb(xb, g4).detach().float() - ref).abs().max() / ref.abs().max())
+        # SURVEY 8(d) with s = 2 bytes per stored element: per edge F s + 4 = 516 B, per node 2 F s + 4 = 1,028 B
+        alg = algorithmic_bytes(E4, N4, F, s=2)
         return {"workload": f"C4 graph, 1 x SAGEConv {F}->{F} fwd+bwd, bf16 storage / f32 accumulate (NOT the metric's precision)",
-                "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3, "max_dev_from_f32_output_rel": dev_rel}
+                "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3, "max_dev_from_f32_output_rel": dev_rel,
+                "roofline": agg_roofline(ev, alg, None, "segsum_kernel<bf16, 4, 1, W_NONE>, avg of the forward and the backward "
+                                         "launch (the latter co-resident with dW); NOT the metric's precision", "no PMC pass "
+                                         "for the bf16 kernels: algorithmic bytes (516 B per edge, 1,028 B per node) only")}
 
     guarded("gcn_c4", gcn_c4)
     guarded("gat_c4", gat_c4)
@@ -1118,11 +1129,11 @@ def main():
                               "this figure counts every gathered row as an HBM read and can exceed 1 when caches serve gathers)",
                 "traffic": traffic if traffic else ("stale" if pmc.get("stale") else None),
                 "traffic_source": (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately; FETCH_SIZE x "
-                                   f"{pmc.get('fetch_scale')} gfx950 calibration; main + fix-up kernel), {pmc.get('from')}, measured "
+                                   f"{pmc.get('fetch_scale')} gfx950 calibration), {pmc.get('from')}, measured "
                                    f"on this very source (sha {pmc.get('source_sha16')}) -- not measured in this run")
                 if traffic else (f"STALE: {pmc.get('from')} was measured on another {pmc.get('stale')}; frac falls back to "
                                  "frac_algorithmic" if pmc.get("stale") else None),
-                "kernel": "segsum_kernel (+ segsum_fixup_kernel), avg of fwd and bwd launches",
+                "kernel": "segsum_kernel (one launch per aggregation: rows cut by an item boundary are finished inside it), avg of fwd and bwd launches",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": seg_avg_ms,
                 "launches_timed": len(seg_ms)}
         res = {

@@ -26,7 +26,7 @@ def main():
     f = per_kernel(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"))
     w = per_kernel(os.path.join(src, "pmc_write", "write_counter_collection.csv"))
     seg = [k for k in f if "segsum_kernel" in k]
-    fix = [k for k in f if "segsum_fixup_kernel" in k]
+    fix = []                                     # (rounds 1-3 had a second, fix-up launch)
     res = {"note": "bench.py --control-only under rocprofv3, FETCH_SIZE and WRITE_SIZE in separate --pmc runs (KB, raw); "
                    "FETCH_SIZE x fetch_scale = gfx950 calibration of tools/pmc_calibrate.py",
            "fetch_scale": scale, "kernels": {k: {"launches": f[k][0], "FETCH_SIZE_KB_raw": f[k][1], "WRITE_SIZE_KB": w.get(k, (0, 0))[1]}

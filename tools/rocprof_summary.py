@@ -60,20 +60,18 @@ def main():
         p = os.path.join(out, "pmc_traffic.json")
         t = json.load(open(p)) if os.path.exists(p) else {}
         main = lambda m: (lambda k: "segsum_kernel" in k and mode(k) == m)
-        fix = lambda m: (lambda k: "segsum_fixup_kernel" in k and mode(k) == m)
+        t.pop("includes_fixup_kernel", None)        # (rounds 1-3: a second launch; cut rows are finished inside the launch now)
         if kind == "sage":
-            # per aggregation launch = main kernel + its fix-up kernel (bench.py's avg_launch_ms brackets both), averaged
-            # over the forward and the backward launch
-            t.update({"segsum_kernel_bytes_per_launch": kb(main(0)) + kb(fix(0)), "fetch_scale": scale,
-                      "from": f"profiles/{tag}_pmc_summary.json", "includes_fixup_kernel": True})
+            # per aggregation launch (ONE kernel), averaged over the forward and the backward launch
+            t.update({"segsum_kernel_bytes_per_launch": kb(main(0)), "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "gat":
-            t.update({"gat_fwd_aggregate_bytes_per_launch": kb(main(6)) + kb(fix(2)),
-                      "gat_bwd_fused_bytes_per_launch": kb(main(5)) + kb(fix(4)), "gat_from": f"profiles/{tag}_pmc_summary.json"})
+            t.update({"gat_fwd_aggregate_bytes_per_launch": kb(main(6)), "gat_bwd_fused_bytes_per_launch": kb(main(5)),
+                      "gat_from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "c5gat":      # the same two kernels on the C5 graph (bench.py --conv gat --nodes 4000000 --edges 100000000 --graph-seed 2)
-            t.update({"c5_gat_fwd_aggregate_bytes_per_launch": kb(main(6)) + kb(fix(2)),
-                      "c5_gat_bwd_fused_bytes_per_launch": kb(main(5)) + kb(fix(4)), "c5_from": f"profiles/{tag}_pmc_summary.json"})
+            t.update({"c5_gat_fwd_aggregate_bytes_per_launch": kb(main(6)), "c5_gat_bwd_fused_bytes_per_launch": kb(main(5)),
+                      "c5_from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "gcn":
-            t.update({"gcn_segsum_bytes_per_launch": kb(main(1)) + kb(fix(1)), "gcn_from": f"profiles/{tag}_pmc_summary.json"})
+            t.update({"gcn_segsum_bytes_per_launch": kb(main(1)), "gcn_from": f"profiles/{tag}_pmc_summary.json"})
         t["source_sha16"] = kernel_source_sha()
         json.dump(t, open(p, "w"), indent=1)
     print(json.dumps(res, indent=1)[:1500])
