@@ -185,7 +185,7 @@ def cpu_baseline(args, ei_full=None):
         return x, ei, W, torch.zeros(F), go
 
     # The index_add_/index_select ops of this path stop scaling long before the host's thread count
-    # (2 x 64-core EPYC 9575F: 32 threads 1.9 M edges/s, 256 threads 0.27 M; tools/cpu_threads_sweep.py),
+    # (2 x 64-core EPYC 9575F: 32 threads 1.9 M edges/s, 256 threads 0.27 M; a sweep of round 1, EXPERIMENTS.md),
     # so the baseline is the best of a short sweep, not "all threads".
     ncpu = os.cpu_count() or 1
     Ns, Es = args.cpu_nodes, args.cpu_edges
@@ -650,7 +650,7 @@ def run_configs(dev, args, c4):
             NF._PROFILE_TAGS = None
             torch.cuda.synchronize()
             gb = gat_bytes(E5, N5, F5)
-            # HBM bytes of the two aggregation launches at THIS size, from their own PMC passes (tools/r03_pmc_c5.sh: bench.py
+            # HBM bytes of the two aggregation launches at THIS size, from their own PMC passes (tools/profile_all.sh: bench.py
             # --conv gat on this very graph); the algorithmic bytes count every gathered row, the hub rows served from L2 included
             roof = {}
             for tag in gb:

@@ -607,7 +607,7 @@ constexpr int SK = 16;                             // k-step of the split kernel
 // Order of the 6 x TM x TN MFMAs of a k-step in the consumer waves.  0: tile by tile (six DEPENDENT MFMAs on one
 // accumulator back to back -- each waits for the previous one's result); 1: product by product over all tiles, so that
 // consecutive MFMAs are independent.  The per-accumulator order of the six products is the same: results are bit-identical.
-// Measured neutral at 1M x 256 x 256 (tools/ab_mma.sh: fwd 0.96-0.98 / 0.94-0.96, bwd_data 0.88-0.89 / 0.89-0.90, dW
+// Measured neutral at 1M x 256 x 256 (same-box A/B builds, round 2: fwd 0.96-0.98 / 0.94-0.96, bwd_data 0.88-0.89 / 0.89-0.90, dW
 // 1.02 / 1.01-1.02 ms): the dependent chain is not what holds the matrix pipe at ~50 %.  Default: the original order.
 #ifndef NPI_MMA_INTERLEAVE
 #define NPI_MMA_INTERLEAVE 0
@@ -717,7 +717,7 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
 // 8-byte pieces per plane (round 1; SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles).  1: a thread takes 8 consecutive k of ONE
 // row (two adjacent float4) and stores one 16-byte half row per plane; adjacent lanes hold the two halves of a row, so the 8
 // lanes of a ds_write_b128 group cover 4 consecutive rows x 2 halves = 8 different bank quads (conflict-free).
-// Measured at 1M x 256 x 256 (tools/ab_split_a.sh): 1 is 3-4 % SLOWER (bwd_data 0.92 vs 0.88 ms, fwd min 0.95 vs 0.83):
+// Measured at 1M x 256 x 256 (same-box A/B builds, round 2): 1 is 3-4 % SLOWER (bwd_data 0.92 vs 0.88 ms, fwd min 0.95 vs 0.83):
 // the bank conflicts of the 8-byte stores are not what limits the kernel.  Default 0.
 #ifndef NPI_SPLIT_A16
 #define NPI_SPLIT_A16 0
@@ -732,7 +732,7 @@ __device__ __forceinline__ void split3_store16(f32x4r lo, f32x4r hi, char* img, 
     *reinterpret_cast<uint4*>(img + plane) = make_uint4(a1, b1, c1, d1);
     *reinterpret_cast<uint4*>(img + 2 * plane) = make_uint4(a2, b2, c2, d2);
 }
-// measurement switches of gemm_split_ws_kernel (tools/build_variant.sh <name> -DNPI_WS_PROBE=<bits>; timing only, wrong
+// measurement switches of gemm_split_ws_kernel (compile segsum-independent variant libraries with -DNPI_WS_PROBE=<bits> and load them through NPI_GNN_LIB; timing only, wrong
 // numbers): 1 = one MFMA per tile pair instead of six, 2 = no split arithmetic in the producer (plain bf16 pack into all
 // three planes), 4 = no C stores, 8 = the producer stores nothing to LDS (hand-over only), 32 = no global loads of A,
 // 64 = no global loads of the weight planes (stale registers are stored), 128 = the MFMAs as v_mfma_f32_16x16x32_bf16 (twelve per
@@ -1162,7 +1162,7 @@ gemm_split_ws_kernel(SplitArgs a) {
 // workgroups with m-tile 0 (two partial rows per slab: the two 8-node halves of a k-step).
 // The 16-byte LDS stores of 8 adjacent lanes go to 8 different bank quads: lane cg stores its columns in the rotated
 // order rho(cg) + c (see dw_rot), which with the image's half swizzle covers all 32 banks.
-// measurement switches of gemm_dw_split_kernel (tools/build_variant.sh <name> -DNPI_DW_PROBE=<bits>): 1 = no start stagger,
+// measurement switches of gemm_dw_split_kernel (variant library with -DNPI_DW_PROBE=<bits>, loaded through NPI_GNN_LIB): 1 = no start stagger,
 // 2 = cheap split (timing only, wrong numbers), 4 = one MFMA per product tile (timing only)
 #ifndef NPI_DW_PROBE
 #define NPI_DW_PROBE 0

@@ -575,7 +575,7 @@ def test_gcn_bf16_storage_trains(dev):
 
 def test_training_step_is_hip_graph_capturable(dev):
     """No kernel on the path synchronises, allocates outside the stream order or reads sizes back: a full-batch
-    fwd + bwd on a fixed graph captures into one HIP graph and replays bit-identically (tools/graph_capture_bench.py)."""
+    fwd + bwd on a fixed graph captures into one HIP graph and replays bit-identically."""
     N, E, F = 3000, 20000, 128
     ei = rand_edges(N, E, seed=9, hub=3).to(dev)
     graph = npi.CSRGraph(ei, N)
