@@ -909,11 +909,11 @@ class _GatConvFn(torch.autograd.Function):
             tpack = gat_pack_targets(a_dst, m, s, D)                           # [N H, 4]
             dh, dz = gat_backward_fused_packed(sr, grad_out, None, hfeat, C, tpack, a_src, slope, H=H)
             dz = dz.view(-1, H)
-            g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
-            g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
             if (sch.gat_rank2_epilogue and H == 1 and N >= sch.gat_rank2_min_rows and ctx.needs_input_grad[0]
                     and x.dtype == torch.float32 and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight)):
-                return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, g_dst, g_src, db, C)
+                return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, dz, db, C)
+            g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
+            g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
             gat_rank1_add(dh, g_dst, g_src, att2, H, C)
         else:
@@ -948,31 +948,48 @@ class _GatConvFn(torch.autograd.Function):
         return dx, dw, datt, db, None, None, None, None, None
 
     @staticmethod
-    def _backward_rank2(ctx, x, weight, att2, dh, g_dst, g_src, db, C):
+    def _backward_rank2(ctx, x, weight, att2, dh, dz, db, C):
         """The tail of the one-head backward without ever forming d hfeat' = dh + g_dst (x) a1 + g_src (x) a2 (a1 = att[:C],
-        a2 = att[C:]).  With P = [x^T g_dst; x^T g_src] ([2, K], ONE pass over x -- the pass that used to stream hfeat for d att):
+        a2 = att[C:]; g_dst / g_src = row sums of dz by target / by source).  With P = [x^T g_dst; x^T g_src] ([2, K], ONE
+        pass over x):
             dX   = dh W^T + g_dst (x) (W a1) + g_src (x) (W a2)      the rank-2 term in the GEMM's store epilogue
             dW   = x^T dh + P^T [a1; a2]                              a [K, C] outer-product correction
             datt = [P W]                                              since hfeat = x W
-        The pass over x runs on the side stream under the two large GEMMs; the [2, .] products are two small launches
-        (``npi_gat_rank2_cols`` in front, ``npi_gat_rank2_tail`` behind)."""
+        Only dX needs g_dst / g_src; dW = x^T dh needs neither.  So the MFMA-bound dW GEMM goes on the launch stream and the
+        HBM-bound passes -- the by-target row sum of dz (a gather through the transpose map) and the pass over x -- run on
+        the side stream beside it (both fit next to a dW workgroup on a CU: <= 70 VGPRs, <= 8 KB LDS); dX waits for the row
+        sums only.  The [2, .] products
+        are two small launches (``npi_gat_rank2_cols`` in front, ``npi_gat_rank2_tail`` behind)."""
         dev = x.device
+        graph: CSRGraph = ctx.graph
         K = weight.size(0)
         A = att2.view(2, C)                                                   # rows a1, a2
         U = gat_rank2_cols(weight, A)                                         # [2, K]: W a1, W a2
         main = torch.cuda.current_stream(dev)
         overlap = _overlaps(ctx.sch, x.size(0))
         side = _side_stream(dev) if overlap else main
+        tmap = _inverse_transpose_map(graph)                                  # cached; built on the launch stream
+        # dz is in by-source entry order: its by-source row sum is a coalesced, latency-bound pass (0.09 ms alone, 0.31 ms
+        # with one wave per SIMD beside a dW workgroup), so it stays in front of dW
+        g_src = seg_rowsum(graph.by_src, dz, 1)
         if overlap:
             side.wait_stream(main)
+            # resident before the side stream's passes ask for wave slots
+            dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
         with torch.cuda.stream(side):
+            g_dst = seg_rowsum(graph.by_dst, dz, 1, map_=tmap)                # 128-byte lines of a 4-byte permutation
+            have_g = torch.cuda.Event()
+            have_g.record(side)
             P = gat_att_grad(x, g_dst, g_src, 1, K).view(2, K)                # x^T g_dst, x^T g_src
-        dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+        if not overlap:
+            dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+        main.wait_event(have_g)
         dx = linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
         if overlap:
-            for t in (x, g_dst, g_src):
+            for t in (x, dz, tmap, g_src):
                 t.record_stream(side)
-            P.record_stream(main)
+            for t in (P, g_dst):
+                t.record_stream(main)
             main.wait_stream(side)
         # dW += P^T [a1; a2] and d att = P W in one small launch behind the GEMMs
         datt = gat_rank2_tail(P, weight, A, dw, ctx.needs_input_grad[2])
