@@ -262,6 +262,18 @@ int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t
 int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                      const float* rowscale, void* C, int64_t ldc,
                      int64_t M, int64_t K, int64_t N, int relu, int dtype, void* stream);
+/* C = A W (f32, no bias) and, from the accumulators on their way to C, the row dots sc0[m] = <C[m, :], att[:N]>,
+ * sc1[m] = <C[m, :], att[N:]> (att: [2 N]; sc0 / sc1: [M]): GATConv's `x = torch.mm(x, self.weight)` together with the two
+ * halves of `(torch.cat([x_i, x_j], dim=-1) * self.att).sum(dim=-1)` per NODE (PyG 1.4.2 gat_conv.py forward / message, one
+ * head; not on the reference's own path: BASELINE configs[4]) -- the pass over h that npi_gat_scores makes is gone.  Only
+ * shapes where one column tile of the matrix-core kernel covers N: npi_linear_fwd_scores_supported(M, K, N) (M >= 128,
+ * K % 32 == 0, N = 128 or 256, default GEMM arithmetic); anything else returns NPI_ERR_ARG (the caller runs npi_linear_fwd_ex
+ * + npi_gat_scores).  Operands 16-byte aligned, leading dimensions % 4 == 0; workspace as npi_linear_fwd_ex.  Fixed
+ * summation order (bitwise reproducible). */
+int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N);
+int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C, int64_t ldc,
+                          float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
+                          void* stream);
 /* dA = dC W^T + row0 (x) col0 + row1 (x) col1 (f32; row* are [M], col* [K] vectors): npi_linear_bwd_data with a rank-2 term
  * added in the store epilogue of the matrix-core kernel -- no read-modify-write pass over dA or dC.  GATConv backward
  * (PyG 1.4.2 GATConv.message's `(x_i, x_j) * att` terms, reference call site src/classes.py:48-52 via BASELINE configs[4]): the

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "npi_linear_workspace_bytes": (_I, [_I, _I]),
     "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
     "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
+    "npi_linear_fwd_scores_supported": (c_int, [_I, _I, _I]),
+    "npi_linear_fwd_scores": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "npi_linear_bwd_data_rank2_supported": (c_int, [_I, _I, _I]),
     "npi_linear_bwd_data_rank2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "npi_gat_rank2_cols": (c_int, [_P, _I, _P, _I, _I, _P, _P]),

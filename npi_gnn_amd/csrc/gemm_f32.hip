@@ -44,6 +44,9 @@ struct Epilogue {
     // rank-2 update of the output, C += r2_row0 (x) r2_col0 + r2_row1 (x) r2_col1 ([M] and [N] vectors; all four or none):
     // only the split kernel applies it, and only when it covers the whole output (npi_linear_bwd_data_rank2)
     const float* r2_row0; const float* r2_row1; const float* r2_col0; const float* r2_col1;
+    // row dots of the STORED output with two column vectors, sc0[m] = <C[m, :], r2_col0>, sc1[m] = <C[m, :], r2_col1> ([M] outputs;
+    // both or none; excludes the rank-2 term): only the split kernel when ONE column tile covers N (npi_linear_fwd_scores)
+    float* sc0; float* sc1;
 };
 
 // C[M,N] (+ split-K slabs) = A(m,k) * B(k,n) over the tile grid starting at (tm0, tn0)
@@ -666,12 +669,19 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
 // 16-byte stores.  (With the natural orientation a lane owns a column and every store is 4 bytes; a wave
 // may have 64 stores in flight, so the 1 GB of C then drains at 64 x 256 B per write round trip per wave --
 // measured 0.45 ms of a 0.9 ms kernel.)
-template <int TM, int TN, bool R2 = false>
+// EPI: 0 plain, 1 (R2) the rank-2 term, 2 (SC) this lane's share of the row dots of the stored values with two column
+// vectors (same LDS layout as the bias), returned in (*g0)[i] / (*g1)[i]
+template <int TM, int TN, int EPI = 0>
 __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
                                              const f32x16 (&acc)[TM][TN], const float* __restrict__ bias_lds /* this wave's
                                              first column (zeros without a bias) */, const float (&rs)[TM], float floor_,
                                              const float* __restrict__ u0_lds = nullptr, const float* __restrict__ u1_lds = nullptr,
-                                             const float (*g0)[TM] = nullptr, const float (*g1)[TM] = nullptr) {
+                                             float (*g0)[TM] = nullptr, float (*g1)[TM] = nullptr) {
+    constexpr bool R2 = EPI == 1, SC = EPI == 2;
+    if constexpr (SC) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { (*g0)[i] = 0.f; (*g1)[i] = 0.f; }
+    }
     // bias comes from an LDS copy made once per workgroup and the row scales were fetched at the start of the
     // tile: a global load here would put a full memory round trip in front of every tile's stores.  No branch in
     // here (a missing bias is a row of zeros, no ReLU is a floor of -inf): with one, every 16-byte store waited for
@@ -680,21 +690,30 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
 #pragma unroll
     for (int i = 0; i < TM; ++i) crow[i] = C + (int64_t)(mw + i * 32 + li) * ldc + nw + 4 * lh;
     // one bias read per 16-byte column group, shared by the row blocks and issued one group ahead of its use
-    float4 b = *reinterpret_cast<const float4*>(bias_lds + 4 * lh);
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!SC) b = *reinterpret_cast<const float4*>(bias_lds + 4 * lh);
 #pragma unroll
     for (int jg = 0; jg < 4 * TN; ++jg) {
         const int j = jg >> 2, g = jg & 3;
         const int jn = (jg + 1) >> 2, gn = (jg + 1) & 3;
         float4 bn = b;
-        if (jg + 1 < 4 * TN) bn = *reinterpret_cast<const float4*>(bias_lds + jn * 32 + 8 * gn + 4 * lh);
+        if constexpr (!SC)
+            if (jg + 1 < 4 * TN) bn = *reinterpret_cast<const float4*>(bias_lds + jn * 32 + 8 * gn + 4 * lh);
         float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
-        if constexpr (R2) {               // the column vectors of the rank-2 term, same LDS layout as the bias
+        if constexpr (R2 || SC) {         // the column vectors of the rank-2 term / the row dots, same LDS layout as the bias
             u0 = *reinterpret_cast<const float4*>(u0_lds + j * 32 + 8 * g + 4 * lh);
             u1 = *reinterpret_cast<const float4*>(u1_lds + j * 32 + 8 * g + 4 * lh);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float4 v;
+            if constexpr (SC) {           // plain C = A B (no bias, row scale or ReLU: npi_linear_fwd_scores): the registers go to the dots
+                v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                (*g0)[i] = fmaf(v.w, u0.w, fmaf(v.z, u0.z, fmaf(v.y, u0.y, fmaf(v.x, u0.x, (*g0)[i]))));
+                (*g1)[i] = fmaf(v.w, u1.w, fmaf(v.z, u1.z, fmaf(v.y, u1.y, fmaf(v.x, u1.x, (*g1)[i]))));
+                *reinterpret_cast<float4*>(crow[i] + j * 32 + 8 * g) = v;
+                continue;
+            }
             v.x = fmaf(acc[i][j][4 * g + 0], rs[i], b.x);
             v.y = fmaf(acc[i][j][4 * g + 1], rs[i], b.y);
             v.z = fmaf(acc[i][j][4 * g + 2], rs[i], b.z);
@@ -911,9 +930,11 @@ __device__ __forceinline__ void ws_consume_first(uint32_t st, const int (&offa)[
     for (int i = 0; i < TM; ++i) NPI_LGKM_WAIT(0, af[i]);
 }
 
-template <int TN, bool R2 = false>
+template <int TN, int EPI = 0>
 __global__ void __launch_bounds__(WS_THREADS, 1)
 gemm_split_ws_kernel(SplitArgs a) {
+    constexpr bool R2 = EPI == 1, SC = EPI == 2;
+    constexpr bool UV = R2 || SC;                     // two column vectors kept in LDS beside the bias
     constexpr int TM = 2;
     constexpr int BN = 64 * TN;                       // 128 or 256 output columns per tile
     constexpr int APL = 128 * 32, BPL = BN * 32;      // bytes of one A / B plane image
@@ -923,7 +944,13 @@ gemm_split_ws_kernel(SplitArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[NST * BUF];
     __shared__ __attribute__((aligned(16))) float bias_s[4][2][32 * TN];   // per consumer wave: bias of its columns, by tile parity
     // R2: the two column vectors of the rank-2 term, kept exactly like the bias
-    __shared__ __attribute__((aligned(16))) float r2_s[R2 ? 4 : 1][2][2][R2 ? 32 * TN : 4];
+    __shared__ __attribute__((aligned(16))) float r2_s[UV ? 4 : 1][2][2][UV ? 32 * TN : 4];
+    // SC: the two consumer waves that share a row block (wn = 0 / 1: the two halves of the columns) meet here -- wave wn = 1
+    // parks its half of the 64 rows' dots and counts up sc_flag[wm]; wave wn = 0 waits for the count of ITS tile, adds its own
+    // half (fixed order: columns low + high) and stores the rows' two scalars.  By tile parity: wave 1 can be at most NST
+    // k-steps ahead of wave 0, never a whole tile.
+    __shared__ __attribute__((aligned(8))) float sc_s[SC ? 2 : 1][2][SC ? 64 : 1][2];
+    __shared__ int sc_flag[2];
     // hand-over counters, one pair per stage, only ever incremented: the 4 producer waves add to full[s] when their
     // part of a k-step is in stage s, the 4 consumer waves add to empty[s] when their fragments are in registers.
     // No barrier in the main loop: the producer runs up to NST - 1 k-steps ahead, so a consumer epilogue (10 k
@@ -936,6 +963,7 @@ gemm_split_ws_kernel(SplitArgs a) {
     w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n, a.M);
     if (!w.valid()) return;                                 // no tile for this workgroup (uniform)
     if (t < NST) { full[t] = 0; empty[t] = 0; }
+    if (t < 2) sc_flag[t] = 0;
     __syncthreads();
 
     if (wave >= 4) {
@@ -1086,6 +1114,8 @@ gemm_split_ws_kernel(SplitArgs a) {
     for (int i = 0; i < TM; ++i) { rs[i] = 1.f; g0[i] = 0.f; g1[i] = 0.f; }
     const float floor_ = a.ep.relu != 0 ? 0.f : -__builtin_huge_valf();
     int g = 0;                                              // k-steps consumed so far: stage g % NST, use g / NST
+    int tq = 0;                                             // SC: tiles this workgroup has finished
+    (void)tq;
     frag_t af[TM][3], bf[TN][3];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     unsigned long long ca_wait = 0, ca_epi = 0;
@@ -1112,7 +1142,7 @@ gemm_split_ws_kernel(SplitArgs a) {
                 bias_nt = w.nt;
                 for (int c = lane; c < 32 * TN; c += WAVE) {
                     bias_s[wave][tsel][c] = a.ep.bias ? a.ep.bias[w.nt * BN + wn * (32 * TN) + c] : 0.f;
-                    if constexpr (R2) {
+                    if constexpr (UV) {
                         r2_s[wave][tsel][0][c] = a.ep.r2_col0[w.nt * BN + wn * (32 * TN) + c];
                         r2_s[wave][tsel][1][c] = a.ep.r2_col1[w.nt * BN + wn * (32 * TN) + c];
                     }
@@ -1127,8 +1157,36 @@ gemm_split_ws_kernel(SplitArgs a) {
         if (w.kt == nk - 1) {
             const unsigned long long e0_ = NPI_STAMP();
             if ((NPI_WS_PROBE & 4) == 0 || acc[0][0][0] == 12345.678f)
-            store_tile_t<TM, TN, R2>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
-                                     bias_s[wave][tsel], rs, floor_, r2_s[R2 ? wave : 0][tsel][0], r2_s[R2 ? wave : 0][tsel][1], &g0, &g1);
+            store_tile_t<TM, TN, EPI>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
+                                      bias_s[wave][tsel], rs, floor_, r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1);
+            if constexpr (SC) {
+                const int par = tq & 1;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {              // the other 16 of every 32 columns sit in lane ^ 32
+                    g0[i] += __shfl_xor(g0[i], 32, WAVE);
+                    g1[i] += __shfl_xor(g1[i], 32, WAVE);
+                }
+                if (wn == 1) {
+                    if (lh == 0) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            *reinterpret_cast<float2*>(&sc_s[wm][par][i * 32 + li][0]) = make_float2(g0[i], g1[i]);
+                    }
+                    signal(&sc_flag[wm]);
+                } else {
+                    wait_ge(&sc_flag[wm], tq + 1);
+                    if (lh == 0) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const float2 o = *reinterpret_cast<const float2*>(&sc_s[wm][par][i * 32 + li][0]);
+                            const int row = w.row0() + wm * 64 + i * 32 + li;
+                            a.ep.sc0[row] = g0[i] + o.x;
+                            a.ep.sc1[row] = g1[i] + o.y;
+                        }
+                    }
+                }
+                ++tq;
+            }
             ca_epi += NPI_STAMP() - e0_;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1674,6 +1732,10 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         set_error("gemm: the rank-2 epilogue needs the split kernel over the whole output (npi_linear_bwd_data_rank2_supported)");
         return NPI_ERR_ARG;
     }
+    if (a.ep.sc0 != nullptr && !(fm > 0 && fn > 0 && split && (a.N == 128 || a.N == 256) && kv == a.K && a.ep.r2_row0 == nullptr)) {
+        set_error("gemm: the row-dot epilogue needs the split kernel with one column tile (npi_linear_fwd_scores_supported)");
+        return NPI_ERR_ARG;
+    }
     if (fm > 0 && fn > 0 && split) {
         // stream-ordered scratch for the three bf16 planes of B (W is small: 3 * 2 * K * N bytes)
         uint16_t* planes = reinterpret_cast<uint16_t*>(scratch);
@@ -1692,8 +1754,11 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         const int64_t ntiles = (int64_t)split_tm * tn;
         const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
         if (a.ep.r2_row0 != nullptr) {
-            if (wide_n) gemm_split_ws_kernel<4, true><<<grid, WS_THREADS, 0, stream>>>(sa);
-            else        gemm_split_ws_kernel<2, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+            if (wide_n) gemm_split_ws_kernel<4, 1><<<grid, WS_THREADS, 0, stream>>>(sa);
+            else        gemm_split_ws_kernel<2, 1><<<grid, WS_THREADS, 0, stream>>>(sa);
+        } else if (a.ep.sc0 != nullptr) {
+            if (wide_n) gemm_split_ws_kernel<4, 2><<<grid, WS_THREADS, 0, stream>>>(sa);
+            else        gemm_split_ws_kernel<2, 2><<<grid, WS_THREADS, 0, stream>>>(sa);
         } else {
             if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
             else        gemm_split_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(sa);
@@ -1832,6 +1897,30 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
     const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
                                      gemm_mode_of(flags), workspace);
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data");
+}
+// C = A W and, from the accumulators on their way out, sc0[m] = <C[m, :], att[:N]>, sc1[m] = <C[m, :], att[N:]>: GATConv's
+// h = x W with the two attention scores of every node in the GEMM's store epilogue (one head) instead of a pass over h
+extern "C" int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N) {
+    return (g_gemm_mode != 0 && M >= 128 && M < 0x7fffffff && K >= BK && K % BK == 0 && (N == 128 || N == 256)) ? 1 : 0;
+}
+extern "C" int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C,
+                                     int64_t ldc, float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace,
+                                     int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(npi_linear_fwd_scores_supported(M, K, N), "npi_linear_fwd_scores: shape outside the split kernel's one-column-"
+                "tile coverage (M >= 128, K % 32 == 0, N = 128 or 256, default GEMM mode)");
+    NPI_REQUIRE(A && W && att && C && sc0 && sc1, "npi_linear_fwd_scores: null pointer");
+    NPI_REQUIRE(lda >= K && ldw >= N && ldc >= N, "npi_linear_fwd_scores: leading dimension too small");
+    NPI_REQUIRE(vec4_ok(A, lda, K, 4) && vec4_ok(W, ldw, N, 4) && ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0),
+                "npi_linear_fwd_scores: operands must be 16-byte aligned with leading dimensions % 4 == 0");
+    if (!scratch_ok(workspace, workspace_bytes, K, N)) {
+        set_error("npi_linear_fwd_scores: workspace too small or not 16-byte aligned");
+        return NPI_ERR_WORKSPACE;
+    }
+    GemmArgs a{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
+               Epilogue{nullptr, nullptr, 0, nullptr, nullptr, nullptr, att, att + N, sc0, sc1}};
+    const int rc = launch_gemm<0, 0>(true, a, 1, stream, NPI_F32, NPI_F32, g_gemm_mode, workspace);
+    return rc != NPI_OK ? rc : check_launch("npi_linear_fwd_scores");
 }
 // dA = dC W^T + row0 (x) col0 + row1 (x) col1, the rank-2 term added in the split kernel's store epilogue (GATConv backward:
 // the attention terms g_dst (x) W att_dst + g_src (x) W att_src of dX, without a read-modify-write pass over d hfeat)

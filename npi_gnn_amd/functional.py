@@ -218,6 +218,34 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
     return da
 
 
+def linear_fwd_scores_ok(a: torch.Tensor, weight: torch.Tensor) -> bool:
+    """can ``linear_fwd_scores`` take these operands (f32, aligned, one column tile of the split kernel covers the output)?"""
+    return (a.dtype == torch.float32 and weight.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
+            and weight.stride(1) == 1 and a.stride(0) % 4 == 0 and weight.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
+            and weight.data_ptr() % 16 == 0 and GEMM_FLAGS == 0
+            and bool(load().npi_linear_fwd_scores_supported(a.size(0), weight.size(0), weight.size(1))))
+
+
+def linear_fwd_scores(a: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor):
+    """``(h, a_dst, a_src)``: ``h = a @ weight`` and the row dots ``h @ att[:N]``, ``h @ att[N:]`` taken from the accumulators in
+    the GEMM's store epilogue (``npi_linear_fwd_scores``; one head, ``att2`` holds ``2 N`` values)."""
+    dev = require_gpu(a, weight, att2)
+    M, K = a.shape
+    N = weight.size(1)
+    att2 = _f32c(att2.reshape(-1), "att")
+    if att2.numel() != 2 * N:
+        raise ValueError("linear_fwd_scores: att must hold 2 N values")
+    h = torch.empty((M, N), dtype=torch.float32, device=dev)
+    a_dst = torch.empty((M, 1), dtype=torch.float32, device=dev)
+    a_src = torch.empty((M, 1), dtype=torch.float32, device=dev)
+    ws = _gemm_workspace(K, N, dev)
+    with _gemm_events("fwd", 2.0 * M * K * N, dev):
+        check(load().npi_linear_fwd_scores(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(att2), ptr(h), h.stride(0),
+                                           ptr(a_dst), ptr(a_src), M, K, N, ptr(ws), ws.numel(), stream_ptr(dev)),
+              "npi_linear_fwd_scores")
+    return h, a_dst, a_src
+
+
 def linear_bwd_data_rank2_ok(dc: torch.Tensor, weight: torch.Tensor) -> bool:
     """can ``linear_bwd_data_rank2`` take these operands (f32, aligned, a shape the split kernel covers completely)?"""
     M, N = dc.shape
@@ -865,8 +893,11 @@ class _GatConvFn(torch.autograd.Function):
         H = int(heads)
         C = weight.size(1) // H
         att2 = _f32c(att.reshape(H, 2 * C), "att")
-        hfeat = linear_fwd(x, weight)                                        # x @ W
-        a_dst, a_src = gat_scores(hfeat, att2, H, C)
+        if H == 1 and sch.gat_scores_epilogue and linear_fwd_scores_ok(x, weight):
+            hfeat, a_dst, a_src = linear_fwd_scores(x, weight, att2)        # x @ W, both scores in its store epilogue
+        else:
+            hfeat = linear_fwd(x, weight)                                    # x @ W
+            a_dst, a_src = gat_scores(hfeat, att2, H, C)
         d = graph.by_dst
         if H == 1 and C % 4 == 0 and d.nnz_max > 0:
             # the statistics pass leaves the score of every entry; the aggregation reads it back (one coalesced load per

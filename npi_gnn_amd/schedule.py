@@ -23,6 +23,9 @@ class Schedule:
     #: over d hfeat; from ``gat_rank2_min_rows`` rows on (below, the three [2, .] products cost more than the pass they replace)
     gat_rank2_epilogue: bool = True
     gat_rank2_min_rows: int = 100_000
+    #: one-head GATConv forward: a_dst / a_src of every node from the accumulators of h = x W in the GEMM's store epilogue
+    #: instead of a pass over h (shapes one column tile covers: 128 or 256 output channels)
+    gat_scores_epilogue: bool = True
     # sharded layers (dist.py) --------------------------------------------------------------------------------------------------
     #: cuts without hub-hub edges: the reduce-scatter delivers the COMPLETE hub rows straight into the output (no merge pass)
     direct_hub_rows: bool = True

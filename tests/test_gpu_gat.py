@@ -254,3 +254,29 @@ def test_rank2_path_with_frozen_parameters(dev, freeze):
         if p is not None:
             assert float((p - q).abs().max()) <= 1e-4 * float(q.abs().max()), name
     assert a[1] is None if "weight" in freeze else a[1] is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(128, 32, 128), (1000, 256, 256), (130_001, 128, 256), (70_000, 160, 128)])
+def test_scores_in_the_gemm_epilogue_equal_the_pass_over_h(dev, M, K, N):
+    """npi_linear_fwd_scores: h = x W bit-equal to npi_linear_fwd, and both row dots within fp32 rounding of npi_gat_scores on
+    that h (ragged last row tile, both tile widths, several tiles per workgroup); bitwise reproducible."""
+    from npi_gnn_amd import functional as NF
+    g = torch.Generator(device=dev).manual_seed(M + K)
+    x = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(K, N, device=dev, generator=g) / K ** 0.5
+    att = torch.randn(1, 2 * N, device=dev, generator=g)
+    assert NF.linear_fwd_scores_ok(x, W)
+    h, a_dst, a_src = NF.linear_fwd_scores(x, W, att)
+    h_ref = NF.linear_fwd(x, W)
+    d_ref, s_ref = NF.gat_scores(h_ref, att.view(1, 2 * N), 1, N)
+    assert torch.equal(h, h_ref)
+    ref64 = h_ref.double() @ att.view(2, N).double().t()
+    scale = float(ref64.abs().max())
+    assert float((a_dst.double().view(-1) - ref64[:, 0]).abs().max()) <= 2e-6 * scale
+    assert float((a_src.double().view(-1) - ref64[:, 1]).abs().max()) <= 2e-6 * scale
+    assert float((a_dst - d_ref).abs().max()) <= 4e-6 * scale and float((a_src - s_ref).abs().max()) <= 4e-6 * scale
+    for _ in range(3):
+        h2, d2, s2 = NF.linear_fwd_scores(x, W, att)
+        assert torch.equal(h2, h) and torch.equal(d2, a_dst) and torch.equal(s2, a_src)
+    assert not NF.linear_fwd_scores_ok(x, torch.randn(K, 192, device=dev))      # two column tiles: not served

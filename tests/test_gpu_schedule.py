@@ -29,8 +29,8 @@ def test_no_environment_switch_selects_a_path():
                 seen |= set(re.findall(r"""(?:environ(?:\.get)?\s*[\[(]\s*|getenv\s*\(\s*)["'](NPI_[A-Z0-9_]+)["']""", src))
     assert seen <= allowed, seen - allowed
     fields = set(Schedule.__dataclass_fields__)
-    assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "direct_hub_rows",
-                      "partial_stream", "split_projection", "gat_direct"}
+    assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "gat_scores_epilogue",
+                      "direct_hub_rows", "partial_stream", "split_projection", "gat_direct"}
     assert CONSERVATIVE == DEFAULT.but(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
                                        gat_rank2_epilogue=False)
 
@@ -57,6 +57,7 @@ def _run(make, graph, x, go):
     ("sage", dict(overlap_streams=False)), ("sage", dict(overlap_min_rows=10 ** 9)),
     ("gcn", dict(overlap_streams=False)),
     ("gat", dict(overlap_streams=False)), ("gat", dict(gat_rank2_epilogue=False)), ("gat", dict(gat_rank2_min_rows=10 ** 9)),
+    ("gat", dict(gat_scores_epilogue=False)),
 ])
 def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     ei, graph, x, go = _graph(dev)
@@ -64,7 +65,10 @@ def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     cls = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[kind]
     ref = _run(lambda: cls(F, F), graph, x, go)
     got = _run(lambda: cls(F, F, schedule=DEFAULT.but(**alt)), graph, x, go)
-    assert torch.equal(got[0], ref[0])                                   # the forward is the same launches
+    if "gat_scores_epilogue" in alt:                                     # the scores' 128-term dots in another association
+        assert float((got[0] - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
+    else:
+        assert torch.equal(got[0], ref[0])                               # the forward is the same launches
     # the backward: the same sums in another association at most (the weight gradient's slab count follows the grid regime,
     # the rank-2 epilogue moves the attention terms into the GEMM's store)
     for a, r in zip(got[1:], ref[1:]):

@@ -49,8 +49,10 @@ def test_hot_kernels_keep_the_occupancy_the_design_assumes(built):
     for n, m in hot.items():
         assert m["vgpr"] <= 64 and m["agpr"] == 0, (n, m)     # 8 waves / SIMD (512 VGPRs / 64)
     gemm = _pretty(built["gemm_f32.hip"][0])
-    # (<4, true>: the same kernel with the rank-2 store epilogue of GATConv's dX -- 22 registers and 8 KB of LDS more)
-    for fam in ("gemm_split_ws_kernel<4, false>", "gemm_split_ws_kernel<4, true>", "gemm_dw_split_kernel<4>", "gemm_bf16_ws_kernel<4>"):
+    # (<4, 1>: the same kernel with the rank-2 store epilogue of GATConv's dX -- 22 registers and 8 KB of LDS more; <4, 2>: with
+    # the row dots of GATConv's scores in the store epilogue -- 10 KB of LDS more)
+    for fam in ("gemm_split_ws_kernel<4, 0>", "gemm_split_ws_kernel<4, 1>", "gemm_split_ws_kernel<4, 2>", "gemm_dw_split_kernel<4>",
+                "gemm_bf16_ws_kernel<4>"):
         ks = {n: m for n, m in gemm.items() if fam in n}
         assert len(ks) == 1, fam
         for n, m in ks.items():
@@ -69,7 +71,7 @@ def test_asm_gemms_hold_no_flat_access_no_sgpr_hazard_and_touch_no_in_flight_lds
             assert G.find_flat(instrs) == [], (sym, G.find_flat(instrs)[:3])
             assert any(i.startswith("global_load_dwordx4") for i in instrs), sym     # the asm loads are there at all
             assert any(i.startswith("ds_read_b128") for i in instrs) and any("v_mfma_f32_32x32x16_bf16" in i for i in instrs), sym
-    assert checked == 8                                       # <4> and <2> of each family, the split kernel also with the rank-2 epilogue
+    assert checked == 10                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue
     for src, (_, code) in built.items():
         for sym, instrs in code.items():
             hz = G.find_sgpr_hazards(instrs)
