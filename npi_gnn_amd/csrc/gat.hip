@@ -287,7 +287,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
     //            row), columns targets (`hfeat` holds the gathered dOut rows; a_dst / m / s / D by column).
     // hfeat2 / split: two-part gathered table as in segsum (column >= split reads row column - split of hfeat2).
     constexpr int U = (NCH <= 2) ? 4 : 2;
-    const float* __restrict__ hf2 = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(hfeat2) - (uint64_t)split * (uint64_t)ldh * sizeof(float));
+    const float* __restrict__ hf2 = hfeat2;           // (a pointer biased through integer arithmetic turns every gather into a FLAT load)
     const int lane = lane_id();
     const int item = uniform_i(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= n_items) return;
@@ -327,7 +327,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int cu = bcast_i(cv, min(j + u, nb - 1));
-                    hv8[u] = act[0] ? *reinterpret_cast<const float4*>((cu < split ? hfeat : hf2) + (int64_t)cu * ldh + foff[0])
+                    hv8[u] = act[0] ? *reinterpret_cast<const float4*>((cu < split ? hfeat + (int64_t)cu * ldh : hf2 + (int64_t)(cu - split) * ldh) + foff[0])
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 float p[8];
@@ -363,7 +363,7 @@ gat_edge_grad_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restri
                 const int cu = bcast_i(cv, min(j + u, nb - 1));
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
-                    hv[u][c] = act[c] ? *reinterpret_cast<const float4*>((cu < split ? hfeat : hf2) + (int64_t)cu * ldh + foff[c])
+                    hv[u][c] = act[c] ? *reinterpret_cast<const float4*>((cu < split ? hfeat + (int64_t)cu * ldh : hf2 + (int64_t)(cu - split) * ldh) + foff[c])
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll

@@ -119,6 +119,11 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = __builtin_bit_cast(bf16_t, (__bf16)v); }
+__device__ __forceinline__ float elem_f32(float v) { return v; }
+__device__ __forceinline__ float elem_f32(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+template <typename T> __device__ __forceinline__ T elem_from_f32(float v);
+template <> __device__ __forceinline__ float elem_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t elem_from_f32<bf16_t>(float v) { return __builtin_bit_cast(bf16_t, (__bf16)v); }
 
 // guarded load of staging slot p (EDGE kernel): rows beyond rmax / k beyond kmax read as zero
 template <int MODE_KCONTIG, int ROWS, bool VEC4, typename T>
@@ -475,11 +480,13 @@ constexpr int DWF_COLS = 16;
 static unsigned dw_finish_grid(int64_t rows, int64_t cols, bool with_db) {
     return (unsigned)(ceil_div(rows * cols, 256) + (with_db ? ceil_div(cols, DWF_COLS) : 0));
 }
+// TS: storage of A / dC (the trailing nodes) and of dW / db: float, or bf16 (widened on load, rounded once on store)
+template <typename TS>
 __global__ void __launch_bounds__(256)
 dw_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nslab, int rows, int cols,
-                 float* __restrict__ dW, int64_t lddw, const float* __restrict__ db_slabs, int n_db,
-                 float* __restrict__ db, const float* __restrict__ A_rem, int64_t lda,
-                 const float* __restrict__ dC_rem, int64_t lddc, int n_rem) {
+                 TS* __restrict__ dW, int64_t lddw, const float* __restrict__ db_slabs, int n_db,
+                 TS* __restrict__ db, const TS* __restrict__ A_rem, int64_t lda,
+                 const TS* __restrict__ dC_rem, int64_t lddc, int n_rem) {
     const int64_t n_w = (int64_t)rows * cols;
     const int nb_w = (int)((n_w + 255) / 256);
     const int t = threadIdx.x;
@@ -503,13 +510,13 @@ dw_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nslab
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const bool ok = m0 + u < n_rem;
-                av[u] = ok ? A_rem[(int64_t)(m0 + u) * lda + r] : 0.f;
-                cv[u] = ok ? dC_rem[(int64_t)(m0 + u) * lddc + c] : 0.f;
+                av[u] = ok ? elem_f32(A_rem[(int64_t)(m0 + u) * lda + r]) : 0.f;
+                cv[u] = ok ? elem_f32(dC_rem[(int64_t)(m0 + u) * lddc + c]) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) s = fmaf(av[u], cv[u], s);
         }
-        dW[(int64_t)r * lddw + c] = s;
+        dW[(int64_t)r * lddw + c] = elem_from_f32<TS>(s);
         return;
     }
     if (db == nullptr) return;
@@ -535,8 +542,8 @@ dw_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nslab
         float r = 0.f;
 #pragma unroll
         for (int q = 0; q < 256 / DWF_COLS; ++q) r += part[q][cl];
-        for (int m = 0; m < n_rem; ++m) r += dC_rem[(int64_t)m * lddc + c];
-        db[c] = r;
+        for (int m = 0; m < n_rem; ++m) r += elem_f32(dC_rem[(int64_t)m * lddc + c]);
+        db[c] = elem_from_f32<TS>(r);
     }
 }
 
@@ -1461,7 +1468,7 @@ gemm_bf16_ws_kernel(Bf16Args a) {
     const int wave = uniform_i(t >> 6);
     const int nk = a.K / (SK * KB);
     TileWalk w;
-    w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n);
+    w.init((int)blockIdx.x, (int)gridDim.x, nk, a.tiles_m, a.tiles_n, a.M);    // a ragged last row tile overlaps its neighbour (TileWalk::row0)
     if (!w.valid()) return;
     if (t < NST) { full[t] = 0; empty[t] = 0; }
     __syncthreads();
@@ -1485,7 +1492,7 @@ gemm_bf16_ws_kernel(Bf16Args a) {
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(off), "s"(base) : "memory")
 #define NPI_BLOAD(S)                                                                                   \
     do {                                                                                               \
-        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.mt * 128 * a.lda + wl.kt * (SK * KB)) * 2);   \
+        const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.row0() * a.lda + wl.kt * (SK * KB)) * 2);   \
         const char* g0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * KB * a.N + wl.nt * BN) * (SK * 2));     \
         const char* g1 = uniform_ptr(g0 + b_blk);                                                      \
         const char* g2 = uniform_ptr(g0 + 2 * b_blk);                                                  \
@@ -1573,7 +1580,7 @@ gemm_bf16_ws_kernel(Bf16Args a) {
         if (w.kt == 0) {
             if (a.rowscale) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) rs[i] = a.rowscale[w.mt * 128 + wm * 64 + i * 32 + li];
+                for (int i = 0; i < TM; ++i) rs[i] = a.rowscale[w.row0() + wm * 64 + i * 32 + li];
             }
             if (a.bias && w.nt != bias_nt) {
                 tsel ^= 1;
@@ -1608,7 +1615,7 @@ gemm_bf16_ws_kernel(Bf16Args a) {
             const float* __restrict__ bl = a.bias ? bias_s[wave][tsel] : nullptr;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                uint16_t* __restrict__ crow = a.C + (int64_t)(w.mt * 128 + wm * 64 + i * 32 + li) * a.ldc + w.nt * BN + wn * (32 * TN) + 4 * lh;
+                uint16_t* __restrict__ crow = a.C + (int64_t)(w.row0() + wm * 64 + i * 32 + li) * a.ldc + w.nt * BN + wn * (32 * TN) + 4 * lh;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1704,7 +1711,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
             return NPI_ERR_LAUNCH;
         }
         bf16_blocks_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(reinterpret_cast<const uint16_t*>(a.B), a.ldb, a.K, a.N, BMODE, blocks);
-        const int bfm = a.M / 128;
+        const int bfm = (int)ceil_div(a.M, 128);             // the last row tile starts at M - 128: no guarded strip launch
         const bool wide_n = (a.N % 256 == 0);
         const int btn = wide_n ? a.N / 256 : a.N / 128;
         Bf16Args ba{reinterpret_cast<const uint16_t*>(a.A), a.lda, blocks, reinterpret_cast<uint16_t*>(a.C), a.ldc, a.M, a.N, a.K,
@@ -1714,15 +1721,6 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         if (wide_n) gemm_bf16_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(ba);
         else        gemm_bf16_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(ba);
         if (scratch == nullptr) (void)hipFreeAsync(blocks, stream);
-        // the ragged bottom strip (M % 128 rows) goes through the guarded kernel below
-        const int tm_all = (int)ceil_div(a.M, 128), tn_all = (int)ceil_div(a.N, 128);
-        if (tm_all > bfm) {
-            GemmArgs e = a;
-            e.tm0 = bfm; e.tn0 = 0;
-            const dim3 g(tn_all, tm_all - bfm, 1);
-            if (v4) gemm_edge_kernel<AMODE, BMODE, true, bf16_t, bf16_t><<<g, GEMM_THREADS, 0, stream>>>(e);
-            else    gemm_edge_kernel<AMODE, BMODE, false, bf16_t, bf16_t><<<g, GEMM_THREADS, 0, stream>>>(e);
-        }
         return NPI_OK;
     }
     const bool split = fast_ok && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
@@ -2080,7 +2078,7 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         if (wide) gemm_dw_split_kernel<4><<<grid, WS_THREADS, 0, stream>>>(d);
         else      gemm_dw_split_kernel<2><<<grid, WS_THREADS, 0, stream>>>(d);
         // slabs in slab order, the < 16 trailing nodes and db in one launch
-        dw_finish_kernel<<<gwb, 256, 0, stream>>>(workspace, Kp * N, nslab, (int)K, (int)N, (float*)dW, lddw, db_slabs, 2 * nslab,
+        dw_finish_kernel<float><<<gwb, 256, 0, stream>>>(workspace, Kp * N, nslab, (int)K, (int)N, (float*)dW, lddw, db_slabs, 2 * nslab,
                                                   (float*)db, fp(advance(A, m16 * lda, es)), lda, fp(advance(dC, m16 * lddc, es)), lddc,
                                                   (int)(M - m16));
         return check_launch("npi_linear_bwd_weight");
@@ -2101,9 +2099,18 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         // slabs in slab order, the < 32 trailing nodes and db in one launch (a node count that is a multiple of 32 used to
         // pay a zero-filling launch here, a remainder its own guarded GEMM)
         const int ns = m_main > 0 ? splits : 0;
-        dw_finish_kernel<<<gwb, 256, 0, stream>>>(workspace, K * N, ns, (int)K, (int)N, (float*)dW, lddw, db_slabs, ns, (float*)db,
+        dw_finish_kernel<float><<<gwb, 256, 0, stream>>>(workspace, K * N, ns, (int)K, (int)N, (float*)dW, lddw, db_slabs, ns, (float*)db,
                                                   fp(advance(A, m_main * lda, es)), lda, fp(advance(dC, m_main * lddc, es)), lddc,
                                                   (int)(M - m_main));
+        return check_launch("npi_linear_bwd_weight");
+    }
+    if (M - m_main < 32 && m_main > 0) {
+        // bf16 storage, the usual case: the < 32 trailing nodes, the slab sums, db and the rounding to bf16 in the one finishing
+        // launch (rounds 1-3: a guarded GEMM for the trailing nodes and two reductions -- 4 launches per dW against 2 for f32)
+        dw_finish_kernel<bf16_t><<<gwb, 256, 0, stream>>>(workspace, K * N, splits, (int)K, (int)N, (bf16_t*)dW, lddw, db_slabs, splits,
+                                                         (bf16_t*)db, reinterpret_cast<const bf16_t*>(advance(A, m_main * lda, es)), lda,
+                                                         reinterpret_cast<const bf16_t*>(advance(dC, m_main * lddc, es)), lddc,
+                                                         (int)(M - m_main));
         return check_launch("npi_linear_bwd_weight");
     }
     // bf16 storage: remainder nodes [m_main, M) into slab `splits`, then the two reductions

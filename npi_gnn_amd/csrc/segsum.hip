@@ -56,6 +56,29 @@ template <> struct vec_of<bf16_t, 1> { using type = uint16_t; };
 template <> struct vec_of<bf16_t, 2> { using type = uint32_t; };
 template <> struct vec_of<bf16_t, 4> { using type = uint2; };
 
+// A gather in two halves: the raw load (may sit in an exec-masked block of the guarded kernels) and the widening to f32.
+// With both in one masked block (round 1-3) hipcc waited vmcnt(0) behind EVERY bf16 load to convert it inside the block --
+// 16 serialised round trips per batch of 8 entries (C2's F = 178 aggregation: 45 us against 24 us in f32).
+template <typename V> __device__ __forceinline__ V zero_of() { V z; __builtin_memset(&z, 0, sizeof(V)); return z; }
+template <int VEC, typename T>
+__device__ __forceinline__ typename vec_of<T, VEC>::type load_raw(const T* __restrict__ p) {
+    return *reinterpret_cast<const typename vec_of<T, VEC>::type*>(p);
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void unpack_row(const typename vec_of<T, VEC>::type& v, float (&d)[VEC]) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (VEC == 1) { d[0] = v; }
+        if constexpr (VEC == 2) { d[0] = v.x; d[1] = v.y; }
+        if constexpr (VEC == 4) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    } else {
+        if constexpr (VEC == 1) { d[0] = to_f32((bf16_t)v); }
+        if constexpr (VEC == 2) { d[0] = __uint_as_float(v << 16); d[1] = __uint_as_float(v & 0xffff0000u); }
+        if constexpr (VEC == 4) {
+            d[0] = __uint_as_float(v.x << 16); d[1] = __uint_as_float(v.x & 0xffff0000u);
+            d[2] = __uint_as_float(v.y << 16); d[3] = __uint_as_float(v.y & 0xffff0000u);
+        }
+    }
+}
 template <int VEC, typename T>
 __device__ __forceinline__ void load_row(const T* __restrict__ p, float (&d)[VEC]) {
     using V = typename vec_of<T, VEC>::type;
@@ -386,7 +409,8 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
     // second part of the table, biased so that it is indexed by the column id itself (sharded layers: the gathered hub
     // rows and the rank's own rows are two buffers; dist.py)
-    const T* __restrict__ x2T = reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(P.x2) - (uint64_t)P.split * (uint64_t)P.ldx * sizeof(T));
+    // (a pointer biased by -split rows through integer arithmetic loses its address space: every gather became a FLAT load)
+    const T* __restrict__ x2T = reinterpret_cast<const T*>(P.x2);
     const int split = P.split;
 
     int r = uniform_i(P.item_row[item]);
@@ -512,18 +536,16 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
         int j = 0;
         for (; j + U <= nb; j += U) {
             float v[U][NCH][VEC];
+            typename vec_of<T, VEC>::type raw[U][NCH];
             float g0[U][NCH], g1[U][NCH], g2[U][NCH];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cu = bcast_i(cv, j + u);
-                const T* src = ((TWO_PART && cu >= split) ? x2T : xT) + (int64_t)cu * P.ldx;
+                const T* src = (TWO_PART && cu >= split) ? x2T + (int64_t)(cu - split) * P.ldx : xT + (int64_t)cu * P.ldx;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[u][c]);
-                    else {
-#pragma unroll
-                        for (int q = 0; q < VEC; ++q) v[u][c][q] = 0.f;
-                    }
+                    raw[u][c] = zero_of<typename vec_of<T, VEC>::type>();
+                    if (L.act[c]) raw[u][c] = load_raw<VEC, T>(src + L.foff[c]);
                     g0[u][c] = g1[u][c] = g2[u][c] = 0.f;
                     if (WMODE == W_GAT_DST) g0[u][c] = P.a_src[(int64_t)cu * P.H + L.hd[c]];
                     if (WMODE == W_GAT_SRC) {
@@ -539,6 +561,8 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
             for (int u = 0; u < U; ++u) {
                 const int k = kb + j + u;
                 while (k == row_end) close_row();
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) unpack_row<VEC, T>(raw[u][c], v[u][c]);    // first use: all U NCH loads are in flight
                 float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j + u) : 1.f;
                 if constexpr (HH > 1) {                 // alpha of entry j + u for this lane's head (HH scalar reads, HH - 1 selects)
                     ws = bcast_f(wvh[0], j + u);
@@ -597,7 +621,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
             float v[NCH][VEC];
             float g0[NCH], g1[NCH], g2[NCH];
             const int cu = bcast_i(cv, j);
-            const T* src = ((TWO_PART && cu >= split) ? x2T : xT) + (int64_t)cu * P.ldx;
+            const T* src = (TWO_PART && cu >= split) ? x2T + (int64_t)(cu - split) * P.ldx : xT + (int64_t)cu * P.ldx;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (L.act[c]) load_row<VEC, T>(src + L.foff[c], v[c]);
@@ -726,7 +750,8 @@ __device__ __forceinline__ void segsum_group_item(const SegParams& P, const int 
     const int k1 = min(k0 + P.item, nnz);
     const int F = P.F;
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
-    const T* __restrict__ x2T = reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(P.x2) - (uint64_t)P.split * (uint64_t)P.ldx * sizeof(T));
+    // (a pointer biased by -split rows through integer arithmetic loses its address space: every gather became a FLAT load)
+    const T* __restrict__ x2T = reinterpret_cast<const T*>(P.x2);
     const int split = P.split;
     const int grp = lane / LG;
     const int foff = (lane % LG) * VEC;
@@ -784,18 +809,18 @@ __device__ __forceinline__ void segsum_group_item(const SegParams& P, const int 
         if (WMODE == W_ARRAY) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
         for (int j = 0; j < nb; j += U * G) {
             float v[U][VEC];
+            typename vec_of<T, VEC>::type raw[U];
             float we[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = j + u * G + grp;             // this lane group's entry of wave instruction u
                 const int cu = __shfl(cv, min(e, nb - 1), WAVE);
                 we[u] = (WMODE == W_ARRAY) ? __shfl(wv, min(e, nb - 1), WAVE) : 1.f;
-                if (act && e < nb) load_row<VEC, T>(((TWO_PART && cu >= split) ? x2T : xT) + (int64_t)cu * P.ldx + foff, v[u]);
-                else {
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.f;
-                }
+                raw[u] = zero_of<typename vec_of<T, VEC>::type>();
+                if (act && e < nb) raw[u] = load_raw<VEC, T>(((TWO_PART && cu >= split) ? x2T + (int64_t)(cu - split) * P.ldx : xT + (int64_t)cu * P.ldx) + foff);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) unpack_row<VEC, T>(raw[u], v[u]);       // behind the last load: all U are in flight
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll

@@ -72,6 +72,12 @@ def test_asm_gemms_hold_no_flat_access_no_sgpr_hazard_and_touch_no_in_flight_lds
             assert any(i.startswith("global_load_dwordx4") for i in instrs), sym     # the asm loads are there at all
             assert any(i.startswith("ds_read_b128") for i in instrs) and any("v_mfma_f32_32x32x16_bf16" in i for i in instrs), sym
     assert checked == 10                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue
+    # no FLAT memory instruction anywhere: a flat access counts on lgkmcnt as well as vmcnt (every LDS / scalar-load wait then
+    # drains the gathers too) -- round 4 found all 128 aggregation kernels gathering through flat_load because the second
+    # part of the table was addressed through a pointer biased with integer arithmetic
+    for src, (_, code) in built.items():
+        for sym, instrs in code.items():
+            assert G.find_flat(instrs) == [], (src, sym, G.find_flat(instrs)[:3])
     for src, (_, code) in built.items():
         for sym, instrs in code.items():
             hz = G.find_sgpr_hazards(instrs)
