@@ -418,6 +418,13 @@ class HipBackend:
         return NF._side_stream(like.device, 1)
 
     # ---- GATConv pieces (functional.py wraps the C ABI; index spaces: rows of the side / its table) ----
+    def linear_fwd_scores(self, a, w, att2, sch: Schedule = DEFAULT):
+        """(h, a_dst, a_src) with the scores from the GEMM's store epilogue (one head), or None when the shape is not served"""
+        from . import functional as NF
+        if sch.gat_scores_epilogue and NF.linear_fwd_scores_ok(a, w):
+            return NF.linear_fwd_scores(a, w, att2)
+        return None
+
     def gat_scores(self, h, att2, H, C):
         from . import functional as NF
         return NF.gat_scores(h, att2, H, C)
@@ -1066,8 +1073,12 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         x_own = x_own.contiguous()
         att2 = att.reshape(H, 2 * C).contiguous()
         A, B, _, _ = sg.direct()
-        h = be.linear_fwd(x_own, weight, None)
-        a_dst, a_src = be.gat_scores(h, att2, H, C)                                # [n_local, H] each
+        hs = be.linear_fwd_scores(x_own, weight, att2, sg.schedule) if (H == 1 and hasattr(be, "linear_fwd_scores")) else None
+        if hs is not None:
+            h, a_dst, a_src = hs                                                   # both scores in the GEMM's store epilogue
+        else:
+            h = be.linear_fwd(x_own, weight, None)
+            a_dst, a_src = be.gat_scores(h, att2, H, C)                            # [n_local, H] each
         tbl_h, g_work = gather_hub(sg, h, async_op=True)                           # big: hub rows of h
         hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))               # small
         tbl_a_dst, tbl_a_src = hub_sc[:, :H].contiguous(), hub_sc[:, H:].contiguous()
