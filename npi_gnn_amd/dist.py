@@ -391,9 +391,11 @@ class HipBackend:
         from . import functional as NF
         return NF.linear_fwd(a, w, b, out=out)
 
-    def linear_bwd_data(self, dc, w, rowscale):
+    bwd_data_into = True                              # linear_bwd_data takes ``out=`` (a row block of a larger buffer)
+
+    def linear_bwd_data(self, dc, w, rowscale, out=None):
         from . import functional as NF
-        return NF.linear_bwd_data(dc, w, rowscale)
+        return NF.linear_bwd_data(dc, w, rowscale, out=out)
 
     def linear_bwd_weight(self, a, dc, want_bias, shared=False):
         from . import functional as NF
@@ -705,7 +707,7 @@ def scatter_hub_sums(sg: ShardedGraph, partial: torch.Tensor, async_op: bool = F
 
 
 def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, w_part, mean: bool, tag: str, bias=None,
-                   direct: bool = False, defer: bool = False):
+                   direct: bool = False, defer: bool = False, gathered=None):
     """One direction of the hub-cut aggregation of ``rows`` [n_local, F]:
 
         table = all_gather(hub rows of ``rows``)                      | psum = segsum(partial side, rows)
@@ -717,9 +719,11 @@ def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, 
     rows, so both write into one ``[nL + h_per, F]`` buffer and (out[:n_local], None, table) comes back -- nothing to fold.
     ``defer`` (direct only): the light rows are returned BEFORE the hub rows have arrived -- the second item is then a
     callable that waits for the reduce-scatter (and the partial stream); the caller may work on ``out[:nL]`` first.
-    ``tag``: prefix of the exposed-communication records ("fwd" / "bwd")."""
+    ``gathered``: ``gather_hub(sg, rows, async_op=True)`` already issued by the caller (the backward starts it as soon as
+    the hub rows of ``rows`` exist).  ``tag``: prefix of the exposed-communication records ("fwd" / "bwd")."""
     be, W = sg.backend, sg.world
-    table, g_work = gather_hub(sg, rows, async_op=True)            # needs nothing but ``rows``: issued first
+    # needs nothing but the hub rows of ``rows``: issued first
+    table, g_work = gathered if gathered is not None else gather_hub(sg, rows, async_op=True)
     hsum = b_stream = r_work = out_full = None
     if direct:
         out_full = rows.new_empty((sg.nL + sg.part.h_per, rows.size(1)))
@@ -811,8 +815,20 @@ class _ShardedSageFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
         nrm = {"At": None, "Bt": None} if (sg.direct_ok or not ctx.gcn) else sg.gcn_norm()
+        gathered = None
         if want_x:
-            dagg = be.linear_bwd_data(grad_out, weight, None if ctx.gcn else sg.inv_cnt)
+            rs = None if ctx.gcn else sg.inv_cnt
+            nL = sg.nL
+            if (sg.direct_ok and sg.schedule.split_projection and nL > 0 and sg.nH > 0 and not _solo(sg.world)
+                    and getattr(be, "bwd_data_into", False)):
+                # the hub rows of dAgg first (a one-round GEMM): their all-gather is on the wire while the light rows -- nine
+                # tenths of the GEMM -- are computed (row-wise independent: the same numbers as one GEMM over all rows)
+                dagg = grad_out.new_empty((sg.n_local, weight.size(0)))
+                be.linear_bwd_data(grad_out[nL:], weight, None if rs is None else rs[nL:], out=dagg[nL:])
+                gathered = gather_hub(sg, dagg, async_op=True)
+                be.linear_bwd_data(grad_out[:nL], weight, None if rs is None else rs[:nL], out=dagg[:nL])
+            else:
+                dagg = be.linear_bwd_data(grad_out, weight, rs)
         # dW is independent of the dX chain.  On the GPU backend it is launched FIRST, on this stream, so that it is resident
         # before the aggregations -- BOTH sides, sent to a second stream -- fill the CUs (see functional._SageConvFn); with
         # side B in front of dW, as in round 1, half of the aggregation ran alone and dW then outlasted the other half
@@ -828,7 +844,8 @@ class _ShardedSageFn(torch.autograd.Function):
             def chain():
                 if sg.direct_ok:
                     d, w = sg.direct(), sg.direct_weights(ctx.gcn)
-                    out, hsum, table = _hub_aggregate(sg, dagg, d[2], d[3], w["At"], w["Bt"], False, "bwd", direct=True)
+                    out, hsum, table = _hub_aggregate(sg, dagg, d[2], d[3], w["At"], w["Bt"], False, "bwd", direct=True,
+                                                      gathered=gathered)
                 else:
                     out, hsum, table = _hub_aggregate(sg, dagg, sg.At, sg.Bt, nrm["At"], nrm["Bt"], False, "bwd")
                 if hsum is not None and sg.nH:

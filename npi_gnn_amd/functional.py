@@ -202,13 +202,20 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
 
 
 def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
-                    rowscale: Optional[torch.Tensor] = None, flags: Optional[int] = None) -> torch.Tensor:
+                    rowscale: Optional[torch.Tensor] = None, flags: Optional[int] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``rowscale * (dc @ weight.T)``; ``out``: write into this ``[M, K]`` tensor (a row block of a larger buffer)."""
     dev = require_gpu(dc, weight, rowscale)
     dc = _fc(dc, "dC")
     weight = _fc(weight, "weight", dc)
     M, N = dc.shape
     K = weight.size(0)
-    da = torch.empty((M, K), dtype=dc.dtype, device=dev)
+    if out is None:
+        da = torch.empty((M, K), dtype=dc.dtype, device=dev)
+    else:
+        if out.shape != (M, K) or out.dtype != dc.dtype or out.stride(1) != 1 or out.device != dc.device:
+            raise ValueError(f"linear_bwd_data: out must be [{M}, {K}] {dc.dtype} with unit column stride on the operands' device")
+        da = out
     ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
         check(load().npi_linear_bwd_data_ex(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),

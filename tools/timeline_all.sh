@@ -20,4 +20,5 @@ W=${2:-vsage,vgat,gat1}
 [[ $W == *c5* ]] && run c5 60 python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-control --virtual-world 0 --conv gat --nodes 4000000 --edges 100000000 --graph-seed 2
 [[ $W == *c2b* ]] && run c2b 70 python3 "$ROOT/tools/c2_probe.py" bf16
 [[ $W == *c2f* ]] && run c2f 70 python3 "$ROOT/tools/c2_probe.py" f32
+[[ $W == *c5s* ]] && run c5s 130 python3 "$ROOT/tools/c5_stack_probe.py" 2
 true
