@@ -280,3 +280,29 @@ def test_scores_in_the_gemm_epilogue_equal_the_pass_over_h(dev, M, K, N):
         h2, d2, s2 = NF.linear_fwd_scores(x, W, att)
         assert torch.equal(h2, h) and torch.equal(d2, a_dst) and torch.equal(s2, a_src)
     assert not NF.linear_fwd_scores_ok(x, torch.randn(K, 192, device=dev))      # two column tiles: not served
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,C", [(100, 1, 256), (70_001, 1, 256), (5_000, 1, 128), (33_333, 1, 512), (9_000, 1, 1024), (4_097, 4, 64),
+                                   (12_345, 2, 32), (3_000, 1, 64), (2_000, 1, 257), (2_000, 3, 20), (600_000, 1, 256)])
+def test_att_grad_pass_matches_the_definition(dev, N, H, C):
+    """npi_gat_att_grad: datt[h, :C] = sum_i g_dst[i, h] hfeat[i, h, :], datt[h, C:] likewise with g_src -- the 16-byte kernel
+    (one head and wide rows: per-row scalars broadcast with v_readlane; several heads / narrow rows: per-lane scalars), its
+    full 64-row blocks and ragged tails, the 4-byte fallback (odd widths), against fp64; bitwise reproducible."""
+    from npi_gnn_amd import functional as NF
+    g = torch.Generator(device=dev).manual_seed(N + 7 * H + C)
+    h = torch.randn(N, H * C, device=dev, generator=g)
+    gd = torch.randn(N, H, device=dev, generator=g)
+    gs = torch.randn(N, H, device=dev, generator=g)
+    got = NF.gat_att_grad(h, gd, gs, H, C)
+    h64 = h.double().view(N, H, C)
+    ref = torch.cat([(gd.double().unsqueeze(-1) * h64).sum(0), (gs.double().unsqueeze(-1) * h64).sum(0)], dim=1)      # [H, 2C]
+    scale = float(ref.abs().max())
+    assert got.shape == (H, 2 * C)
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * scale + 1e-6 * N ** 0.5
+    assert torch.equal(NF.gat_att_grad(h, gd, gs, H, C), got)
+    # a row pitch wider than the row (a view of a larger buffer)
+    wide = torch.zeros(N, H * C + 12, device=dev)
+    wide[:, : H * C] = h
+    assert torch.equal(NF.gat_att_grad(wide[:, : H * C], gd, gs, H, C), got) or \
+        float((NF.gat_att_grad(wide[:, : H * C], gd, gs, H, C) - got).abs().max()) <= 1e-5 * scale
