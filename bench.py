@@ -899,6 +899,24 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
                  "hubs_gat": "GATConv (1 head), vertex cut with the cross-rank softmax"}
         for key, (ms, nnz, coll) in res.items():
             out[key] = virtual_summary(W, t1_gat if key == "hubs_gat" else t1_sage_ms, ms, nnz, coll, notes[key])
+    if "hubs_gat" in out and W == 8 and (N, E, F) == (1_000_000, 20_000_000, 256):
+        # the GATConv rank step is ~110 launches of a few us: eager it is bounded by the HOST and moves with the box's CPU
+        # (1.7-2.2 ms).  Its GPU time: rank 0's step replayed from a HIP graph, stand-in copies on the compute stream (capture with
+        # the copy stream's nested forks takes the HIP runtime down at capture_end, hence a CHILD process; None if it fails)
+        rep = None
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "virtual_rank_probe.py"),
+                                 "--conv", "gat", "--capture", "--inline-copies", "--steps", "50"], capture_output=True, text=True,
+                                timeout=240)
+            m = [l for l in cp.stdout.splitlines() if "events" in l and "capture=True" in l]
+            if m:
+                rep = float(m[-1].split("events")[1].split("ms/step")[0])
+        except Exception as e:                                  # noqa: BLE001 -- a side measurement
+            sys.stderr.write(f"graph replay of a GATConv rank step failed: {type(e).__name__}: {e}\n")
+        out["hubs_gat"]["rank0_ms_graph_replay"] = rep
+        out["hubs_gat"]["compute_ceiling_graph_replay"] = (t1_gat / rep) if rep else None
+        out["hubs_gat"]["graph_replay_note"] = ("rank 0's step replayed from a HIP graph (stand-in copies on the compute stream): the "
+                                                "GPU's time; per_rank_ms is the eager step, which the host bounds at this size")
     out["note"] = ("one GPU, ranks run one after the other; collectives are local copies of the same shapes on a stream of their own "
                    "(issued when their input is ready, waited for where their result is consumed: the real run's dependency graph), "
                    "so per_rank_ms is local compute + host launch work only; wire bytes: all-gather / reduce-scatter of S bytes move "

@@ -70,6 +70,8 @@ val = {
     "VR": rng(v["hubs_sage"]["per_rank_ms"]), "VBAL": f2(v["hubs_sage"]["balance"]), "VC": f2(v["hubs_sage"]["compute_ceiling"]),
     "V2": f2(v["hubs_sage_by_world"]["2"]["compute_ceiling"]), "V4": f2(v["hubs_sage_by_world"]["4"]["compute_ceiling"]),
     "VG": rng(v["hubs_gat"]["per_rank_ms"]), "VGC": f2(v["hubs_gat"]["compute_ceiling"]),
+    "VGR": f2(v["hubs_gat"]["rank0_ms_graph_replay"]) if v["hubs_gat"].get("rank0_ms_graph_replay") else "n/a",
+    "VGRC": f2(v["hubs_gat"]["compute_ceiling_graph_replay"]) if v["hubs_gat"].get("compute_ceiling_graph_replay") else "n/a",
     "VROWS": rng(v["rows_sage"]["per_rank_ms"]), "VROWSC": f2(v["rows_sage"]["compute_ceiling"]),
     "VEDG": rng(v["edges_sage"]["per_rank_ms"]), "VEDGC": f2(v["edges_sage"]["compute_ceiling"]),
     "V5": "%.1f–%.1f" % (min(c["C5_1gpu"]["w8_virtual"]["per_rank_ms"]), max(c["C5_1gpu"]["w8_virtual"]["per_rank_ms"])),

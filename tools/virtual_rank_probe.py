@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--capture", action="store_true")
     ap.add_argument("--inline-copies", action="store_true", help="stand-in copies on the compute stream (default: their own stream)")
+    ap.add_argument("--sched", default="", help="Schedule overrides, e.g. 'split_projection=False,partial_stream=False'")
     a = ap.parse_args()
     from npi_gnn_amd import dist as ND
     from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
@@ -37,7 +38,9 @@ def main():
     g = torch.Generator().manual_seed(3)
     Wm = ((torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
     b = ((torch.rand(F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
-    sg = ND.ShardedGraph(ei, N, r, W, dev, hub_mask=protein_mask(N).to(dev) if a.partition == "hubs" else None)
+    from npi_gnn_amd.schedule import DEFAULT
+    sch = DEFAULT.but(**eval("dict(" + a.sched + ")"))
+    sg = ND.ShardedGraph(ei, N, r, W, dev, hub_mask=protein_mask(N).to(dev) if a.partition == "hubs" else None, schedule=sch)
     del ei
     if a.conv == "sage":
         layer = ND.ShardedSAGELayer(sg, Wm, b)
