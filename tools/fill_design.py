@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """DESIGN.md = tools/doc/DESIGN.in.md with every @KEY@ replaced by the number of ONE bench line
 (profiles/<tag>_bench.json) and its rocprofv3 kernel stats: one current number per claim, no hand-copied figures.
-usage: python tools/fill_design.py r04a"""
+usage: python tools/fill_design.py r04a [tag of the rocprofv3 kernel stats, default the same]"""
 import csv, json, os, re, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-P = lambda n: os.path.join(root, "profiles", f"{tag}_{n}")
+stats_tag = sys.argv[2] if len(sys.argv) > 2 else tag
+P = lambda n: os.path.join(root, "profiles", f"{stats_tag if n.endswith('.csv') else tag}_{n}")
 b = json.load(open(P("bench.json")))
 c, r = b["configs"], b["roofline"]
 
