@@ -1011,3 +1011,24 @@ def test_a_csr_keeps_its_item_size_when_the_hint_moves(dev):
             assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-4 * max(1.0, float(xr.grad.abs().max()))
     finally:
         lib.npi_small_graph_entries(prev)
+
+
+@pytest.mark.parametrize("M,K,N", [(5085, 128, 128), (4096, 178, 128), (70_003, 256, 256), (20, 64, 64), (33, 96, 130), (1024, 128, 64)])
+@pytest.mark.parametrize("want_bias", [True, False])
+def test_bf16_dw_matches_f32_reference(dev, M, K, N, want_bias):
+    """bf16 storage: dW = A^T dC and db = colsum(dC) (f32 slabs on the matrix cores, then ONE finishing launch that adds the
+    slabs, the < 32 trailing nodes and db and rounds to bf16 -- dw_finish_kernel<bf16>; fewer than 32 nodes: the guarded path)
+    against an f32 product of the same bf16-rounded inputs; bitwise reproducible."""
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    dC = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    ref_w = A.float().t() @ dC.float()
+    ref_b = dC.float().sum(0)
+    dw, db = NF.linear_bwd_weight(A.to(dev), dC.to(dev), want_bias)
+    assert dw.dtype == torch.bfloat16 and dw.shape == (K, N) and (db is None) == (not want_bias)
+    scale = float(ref_w.abs().max())
+    assert float((dw.float().cpu() - ref_w).abs().max()) <= 2.0 ** -7 * scale            # one bf16 rounding of the result
+    if want_bias:
+        assert float((db.float().cpu() - ref_b).abs().max()) <= 2.0 ** -7 * float(ref_b.abs().max())
+    dw2, db2 = NF.linear_bwd_weight(A.to(dev), dC.to(dev), want_bias)
+    assert torch.equal(dw, dw2) and (db is None or torch.equal(db, db2))
