@@ -9,7 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import npi_gnn_amd as npi
 from npi_gnn_amd.schedule import DEFAULT
 from oracle import ref_conv as R
-SCH = DEFAULT.but(gat_rank2_min_rows=0)   # small graphs too: the rank-2 store epilogue of dX (the product takes it from 100,000 rows on)
+# small graphs too: the rank-2 store epilogue of dX and the second-stream schedule of the backward (the product takes both from
+# 100,000 rows on); every other case keeps the one-stream arrangement
+SCHS = [DEFAULT.but(gat_rank2_min_rows=0), DEFAULT.but(gat_rank2_min_rows=0, overlap_min_rows=0)]
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -35,7 +37,7 @@ for it in range(cases):
     go = torch.randn(N, H * C, generator=g)
     xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
     graph = npi.CSRGraph(ei.to(dev), N, item=256 if big_items else 64)
-    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCH)
+    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCHS[it & 1])
     out.backward(go.to(dev))
     xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))
     ref = R.gat_conv(xr, ei, Wr, ar, br, heads=H)
@@ -59,8 +61,9 @@ for it in range(cases):
     if m > 2e-4:
         print(f"MISMATCH case {it}: H={H} C={C} N={N} E={E} Fi={Fi} big_items={big_items} relu={relu}: {errs}")
         # bisect: the same inputs with single arrangements switched off
-        for name, sch in (("default", SCH), ("no rank-2 epilogue", SCH.but(gat_rank2_epilogue=False)),
-                          ("one stream", SCH.but(overlap_streams=False))):
+        SCH = SCHS[it & 1]
+        for name, sch in (("as run", SCH), ("no rank-2 epilogue", SCH.but(gat_rank2_epilogue=False)),
+                          ("no scores epilogue", SCH.but(gat_scores_epilogue=False)), ("one stream", SCH.but(overlap_streams=False))):
             for use_relu in ((relu, False) if relu else (False,)):
                 xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
                 o = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=use_relu, schedule=sch)
