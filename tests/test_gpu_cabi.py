@@ -23,3 +23,29 @@ def test_c_abi_from_a_cxx_host(dev, tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
     assert "max |err|" in run.stdout
+
+
+@pytest.mark.gpu
+def test_the_library_this_box_runs_is_the_guarded_build():
+    """the ISA guard (tests/test_isa_guard.py) runs where the library is BUILT.  On the GPU box nothing is
+    rebuilt -- the prebuilt .so travels with its objects -- so the same guard is run here on those very objects (the box has the
+    same llvm tools), and the .so must be the one linked from them: not stale against any source, newer than every object."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_guard as G
+    from npi_gnn_amd.build import HERE, LIB, SOURCES, _stale
+    assert os.path.exists(LIB) and not _stale(), "the shipped library is older than its sources: it would be rebuilt on this box"
+    t_lib = os.path.getmtime(LIB)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        for src in SOURCES:
+            obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+            assert os.path.exists(obj) and os.path.getmtime(obj) <= t_lib + 1.0, obj
+            meta, code = G.analyse(obj, tmp)
+            for name, m in meta.items():
+                assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (src, name, m)
+            for sym, instrs in code.items():
+                assert G.find_flat(instrs) == [], (src, sym)
+                assert G.find_sgpr_hazards(instrs) == [], (src, sym)
+                assert G.find_inflight_touch_linear(instrs) == [], (src, sym)
