@@ -15,7 +15,7 @@ run() { # name n_kernels cmd...
 }
 W=${2:-vsage,vgat,gat1}
 [[ $W == *vsage* ]] && run vsage 60 python3 "$ROOT/tools/virtual_rank_probe.py" --conv sage --steps 6
-[[ $W == *vgat* ]] && run vgat 120 python3 "$ROOT/tools/virtual_rank_probe.py" --conv gat --steps 6
+[[ $W == *vgat* ]] && run vgat 260 python3 "$ROOT/tools/virtual_rank_probe.py" --conv gat --steps 6
 [[ $W == *gat1* ]] && run gat1 60 python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-control --virtual-world 0 --conv gat
 [[ $W == *c5* ]] && run c5 60 python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-control --virtual-world 0 --conv gat --nodes 4000000 --edges 100000000 --graph-seed 2
 [[ $W == *c2b* ]] && run c2b 70 python3 "$ROOT/tools/c2_probe.py" bf16
