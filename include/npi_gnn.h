@@ -243,7 +243,19 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
  * columns K .. Kp-1 are ZERO (W and dW keep K rows): the matrix-core kernels then run on Kp instead of the guarded kernel on
  * an odd K (178 features in the reference's first layer).  Workspaces are queried with Kp. */
 #define NPI_GEMM_A_ZERO_PADDED 4
+/* npi_linear_fwd_ex / npi_linear_bwd_data_ex: `workspace` already holds the re-laid copy of THIS weight matrix that the call
+ * would otherwise prepare in a launch of its own -- written by npi_linear_prepare (set 0 for fwd, set 1 for bwd_data) from the
+ * same W / ldw / K / N / dtype, W unchanged since.  A layer prepares both copies in one launch and runs its forward GEMM,
+ * its backward GEMM and any row-block split of them (dist.py: light rows / hub rows) without a preparation launch each.  Not
+ * together with NPI_GEMM_A_ZERO_PADDED.  A call whose shape does not take the matrix-core kernels ignores the workspace. */
+#define NPI_GEMM_WORKSPACE_PREPARED 8
 int64_t npi_linear_workspace_bytes(int64_t K, int64_t N);
+/* The re-laid copies of W [K, N] (the `weight` of PyG's `torch.matmul(aggr_out, self.weight)`, reference call sites
+ * src/classes.py:62,66,70) for the matrix-core kernels, in ONE launch: which = 1: the copy npi_linear_fwd_ex uses, 2: the one
+ * npi_linear_bwd_data_ex uses, 3: both, the second npi_linear_workspace_bytes(K, N) bytes behind the first.  K and N
+ * multiples of 16; workspace 16-byte aligned, npi_linear_workspace_bytes(K, N) bytes per copy. */
+int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t N, int which, int dtype, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                       const float* rowscale, void* C, int64_t ldc,
                       int64_t M, int64_t K, int64_t N, int relu, int dtype, int flags,

@@ -19,6 +19,7 @@ NPI_BF16 = 1
 NPI_GEMM_EXACT_F32 = 1      # flags of the npi_linear_*_ex entry points
 NPI_GEMM_SPLIT_BF16 = 2
 NPI_GEMM_A_ZERO_PADDED = 4   # A stored with zero pad columns up to a multiple of 128 (include/npi_gnn.h)
+NPI_GEMM_WORKSPACE_PREPARED = 8   # the workspace already holds npi_linear_prepare's copy of this weight matrix
 
 _P = c_void_p
 _I = c_int64
@@ -59,6 +60,7 @@ PROTOTYPES = {
     "npi_linear_workspace_bytes": (_I, [_I, _I]),
     "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
     "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
+    "npi_linear_prepare": (c_int, [_P, _I, _I, _I, c_int, c_int, _P, _I, _P]),
     "npi_linear_fwd_scores_supported": (c_int, [_I, _I, _I]),
     "npi_linear_fwd_scores": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "npi_linear_bwd_data_rank2_supported": (c_int, [_I, _I, _I]),

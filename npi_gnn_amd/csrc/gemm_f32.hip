@@ -1683,7 +1683,9 @@ template <int AMODE, int BMODE>
 // k_valid rows (NPI_GEMM_A_ZERO_PADDED): the split kernel runs on a.K with the weight planes zero-extended, everything
 // else (guarded strips, the exact kernels) on k_valid.
 static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32,
-                       int mode = 1, void* scratch = nullptr, int k_valid = 0) {
+                       int mode = 1, void* scratch = nullptr, int k_valid = 0, bool prepared = false) {
+    // `prepared`: `scratch` already holds the re-laid weight matrix of THIS B / K / N / BMODE (npi_linear_prepare): no
+    // preparation launch in front of the GEMM
     const bool bf16_in = dtype_in == NPI_BF16 && dtype_out == NPI_F32;          // dW of the bf16 path: bf16 operands, f32 slabs
     // (a 128 x 256 tile of the exact-f32 kernel, one workgroup per CU, measured 3-10 % SLOWER than 128 x 128 at C4 in round 1:
     // 1.49 / 1.32 / 1.67 ms vs 1.41 / 1.28 / 1.52 ms -- not built)
@@ -1710,7 +1712,8 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
             set_error("gemm: hipMallocAsync of the bf16 weight blocks failed");
             return NPI_ERR_LAUNCH;
         }
-        bf16_blocks_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(reinterpret_cast<const uint16_t*>(a.B), a.ldb, a.K, a.N, BMODE, blocks);
+        if (!(prepared && scratch != nullptr))
+            bf16_blocks_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(reinterpret_cast<const uint16_t*>(a.B), a.ldb, a.K, a.N, BMODE, blocks);
         const int bfm = (int)ceil_div(a.M, 128);             // the last row tile starts at M - 128: no guarded strip launch
         const bool wide_n = (a.N % 256 == 0);
         const int btn = wide_n ? a.N / 256 : a.N / 128;
@@ -1744,7 +1747,8 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
             set_error("gemm: hipMallocAsync of the split planes failed");
             return NPI_ERR_LAUNCH;
         }
-        split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes, kv);
+        if (!(prepared && scratch != nullptr))
+            split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes, kv);
         const bool wide_n = (a.N % 256 == 0);                // 128 x 256 tiles: each A element is split once
         const int tn = wide_n ? a.N / 256 : fn;
         split_tm = (int)ceil_div(a.M, 128);                  // a ragged last m-tile overlaps its neighbour (TileWalk::row0)
@@ -1834,6 +1838,55 @@ extern "C" int64_t npi_linear_workspace_bytes(int64_t K, int64_t N) {
     return 6 * K * N + 256;                                   // three bf16 planes of the weight matrix
 }
 
+// Both re-laid copies of a weight matrix W [K, N] in ONE launch: set 0 = what npi_linear_fwd_ex prepares (B = W), set 1 = what
+// npi_linear_bwd_data_ex prepares (B = W^T); blockIdx.y walks the requested sets.  f32: three bf16 planes each; bf16: one
+// k-block-major copy each.
+template <typename T>
+__global__ void prepare_weight_kernel(const T* __restrict__ W, int64_t ldw, int K, int N, int first_set, char* __restrict__ ws,
+                                      int64_t set_bytes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int set = first_set + (int)blockIdx.y;                  // 0: contraction over K (rows of W), 1: over N (columns of W)
+    const int Kg = set == 0 ? K : N, Ng = set == 0 ? N : K;
+    const int n = (int)(i / Kg), k = (int)(i % Kg);
+    const T x = set == 0 ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k];
+    uint16_t* __restrict__ out = reinterpret_cast<uint16_t*>(ws + (int64_t)blockIdx.y * set_bytes);
+    const int64_t o = ((int64_t)(k / SK) * Ng + n) * SK + (k % SK);
+    if constexpr (sizeof(T) == 4) {
+        uint32_t p0, p1, p2;
+        split3_pair(x, 0.f, p0, p1, p2);
+        out[o] = (uint16_t)p0;
+        out[(int64_t)N * K + o] = (uint16_t)p1;
+        out[2 * (int64_t)N * K + o] = (uint16_t)p2;
+    } else {
+        out[o] = x;
+    }
+}
+
+extern "C" int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t N, int which, int dtype, void* workspace,
+                                  int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(K > 0 && N > 0 && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_prepare: bad size");
+    NPI_REQUIRE(which >= 1 && which <= 3, "npi_linear_prepare: which must be 1 (forward), 2 (backward) or 3 (both)");
+    NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_prepare: bad dtype");
+    NPI_REQUIRE(W && workspace && ldw >= N, "npi_linear_prepare: null pointer or leading dimension too small");
+    NPI_REQUIRE(K % SK == 0 && N % SK == 0, "npi_linear_prepare: K and N must be multiples of 16 (the matrix-core kernels' k-step)");
+    const int64_t one = npi_linear_workspace_bytes(K, N);
+    const int sets = which == 3 ? 2 : 1;
+    if (workspace_bytes < sets * one || ((uintptr_t)workspace % 16) != 0) {
+        set_error("npi_linear_prepare: workspace too small (npi_linear_workspace_bytes per set) or not 16-byte aligned");
+        return NPI_ERR_WORKSPACE;
+    }
+    const dim3 grid((unsigned)ceil_div(K * N, 256), (unsigned)sets);
+    const int first = which == 2 ? 1 : 0;
+    if (dtype == NPI_F32)
+        prepare_weight_kernel<float><<<grid, 256, 0, stream>>>(fp(W), ldw, (int)K, (int)N, first, (char*)workspace, one);
+    else
+        prepare_weight_kernel<uint16_t><<<grid, 256, 0, stream>>>(reinterpret_cast<const uint16_t*>(W), ldw, (int)K, (int)N, first,
+                                                                  (char*)workspace, one);
+    return check_launch("npi_linear_prepare");
+}
+
 extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                                  const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
                                  int64_t N, int relu, int dtype, int flags, void* workspace, int64_t workspace_bytes,
@@ -1857,8 +1910,11 @@ extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int6
     const int es = dtype == NPI_BF16 ? 2 : 4;
     GemmArgs a{fp(A), lda, fp(W), ldw, (float*)C, ldc, (int)M, (int)N, (int)Kp, (int)align_up(Kp, BK), 0, 0, 0,
                Epilogue{fp(bias), rowscale, relu, nullptr}};
+    const bool prepared = (flags & NPI_GEMM_WORKSPACE_PREPARED) != 0;
+    NPI_REQUIRE(!prepared || (workspace != nullptr && !padded), "npi_linear_fwd_ex: NPI_GEMM_WORKSPACE_PREPARED needs the workspace "
+                "npi_linear_prepare filled and excludes NPI_GEMM_A_ZERO_PADDED");
     const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, Kp, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
-                                     gemm_mode_of(flags), workspace, padded ? (int)K : 0);
+                                     gemm_mode_of(flags), workspace, padded ? (int)K : 0, prepared);
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd");
 }
 extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
@@ -1892,8 +1948,11 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
     // B(k = n_contract, n = k_out) = W[k_out * ldw + n_contract]  -> BMODE 1
     GemmArgs a{fp(dC), lddc, fp(W), ldw, (float*)dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
                Epilogue{nullptr, rowscale, 0, nullptr}};
+    const bool prepared = (flags & NPI_GEMM_WORKSPACE_PREPARED) != 0;
+    NPI_REQUIRE(!prepared || workspace != nullptr, "npi_linear_bwd_data_ex: NPI_GEMM_WORKSPACE_PREPARED needs the workspace "
+                "npi_linear_prepare filled");
     const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
-                                     gemm_mode_of(flags), workspace);
+                                     gemm_mode_of(flags), workspace, 0, prepared);
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data");
 }
 // C = A W and, from the accumulators on their way out, sc0[m] = <C[m, :], att[:N]>, sc1[m] = <C[m, :], att[N:]>: GATConv's

@@ -387,15 +387,20 @@ class HipBackend:
         from . import functional as NF
         return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2, out=out)
 
-    def linear_fwd(self, a, w, b, out=None):
+    def linear_fwd(self, a, w, b, out=None, ws=None):
         from . import functional as NF
-        return NF.linear_fwd(a, w, b, out=out)
+        return NF.linear_fwd(a, w, b, out=out, ws=ws)
+
+    def prepare_weight(self, w, backward=True):
+        """(ws_fwd, ws_bwd) for linear_fwd(..., ws=) / linear_bwd_data(..., ws=): both re-laid copies of ``w`` in one launch"""
+        from . import functional as NF
+        return NF.prepare_weight(w, backward)
 
     bwd_data_into = True                              # linear_bwd_data takes ``out=`` (a row block of a larger buffer)
 
-    def linear_bwd_data(self, dc, w, rowscale, out=None):
+    def linear_bwd_data(self, dc, w, rowscale, out=None, ws=None):
         from . import functional as NF
-        return NF.linear_bwd_data(dc, w, rowscale, out=out)
+        return NF.linear_bwd_data(dc, w, rowscale, out=out, ws=ws)
 
     def linear_bwd_weight(self, a, dc, want_bias, shared=False):
         from . import functional as NF
@@ -781,15 +786,18 @@ class _ShardedSageFn(torch.autograd.Function):
             d, w = sg.direct(), sg.direct_weights(gcn)
             split = sg.schedule.split_projection and sg.nL > 0 and sg.nH > 0 and not _solo(sg.world)
             agg, arrived, _ = _hub_aggregate(sg, x_own, d[0], d[1], w["A"], w["B"], not gcn, "fwd", direct=True, defer=split)
+            # both re-laid copies of W (this direction's GEMMs and the backward's) in one launch
+            wsf, ws_bwd = be.prepare_weight(weight, ctx.needs_input_grad[0]) if hasattr(be, "prepare_weight") else (None, None)
+            kw = {"ws": wsf} if wsf is not None else {}
             if split:
                 # the light rows are complete on this rank: their projection runs while the hub rows are still on the wire
                 # (row-wise independent: the same numbers as one GEMM over all rows)
                 out = agg.new_empty((sg.n_local, weight.size(1)))
-                be.linear_fwd(agg[: sg.nL], weight, bias, out=out[: sg.nL])
+                be.linear_fwd(agg[: sg.nL], weight, bias, out=out[: sg.nL], **kw)
                 arrived()
-                be.linear_fwd(agg[sg.nL:], weight, bias, out=out[sg.nL:])
+                be.linear_fwd(agg[sg.nL:], weight, bias, out=out[sg.nL:], **kw)
             else:
-                out = be.linear_fwd(agg, weight, bias)
+                out = be.linear_fwd(agg, weight, bias, **kw)
         else:
             agg, hsum, _ = _hub_aggregate(sg, x_own, sg.A, sg.B, nrm["A"], nrm["B"], not gcn, "fwd")
             if hsum is not None and sg.nH:
@@ -798,6 +806,8 @@ class _ShardedSageFn(torch.autograd.Function):
                 else:                                              # mean over both shares: (agg cnt_A + hsum) / cnt
                     agg[sg.nL:].mul_(sg.hub_scale_a).addcmul_(hsum[: sg.nH], sg.hub_scale_b)
             out = be.linear_fwd(agg, weight, bias)
+            ws_bwd = None
+        ctx.ws_bwd = ws_bwd
         ctx.sg = sg
         ctx.gcn = gcn
         ctx.has_bias = bias is not None
@@ -823,10 +833,13 @@ class _ShardedSageFn(torch.autograd.Function):
                     and getattr(be, "bwd_data_into", False)):
                 # the hub rows of dAgg first (a one-round GEMM): their all-gather is on the wire while the light rows -- nine
                 # tenths of the GEMM -- are computed (row-wise independent: the same numbers as one GEMM over all rows)
+                kw = {"ws": ctx.ws_bwd} if ctx.ws_bwd is not None else {}
                 dagg = grad_out.new_empty((sg.n_local, weight.size(0)))
-                be.linear_bwd_data(grad_out[nL:], weight, None if rs is None else rs[nL:], out=dagg[nL:])
+                be.linear_bwd_data(grad_out[nL:], weight, None if rs is None else rs[nL:], out=dagg[nL:], **kw)
                 gathered = gather_hub(sg, dagg, async_op=True)
-                be.linear_bwd_data(grad_out[:nL], weight, None if rs is None else rs[:nL], out=dagg[:nL])
+                be.linear_bwd_data(grad_out[:nL], weight, None if rs is None else rs[:nL], out=dagg[:nL], **kw)
+            elif ctx.ws_bwd is not None:
+                dagg = be.linear_bwd_data(grad_out, weight, rs, ws=ctx.ws_bwd)
             else:
                 dagg = be.linear_bwd_data(grad_out, weight, rs)
         # dW is independent of the dX chain.  On the GPU backend it is launched FIRST, on this stream, so that it is resident

@@ -13,7 +13,8 @@ from typing import Optional
 
 import torch
 
-from ._lib import NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, check, load, ptr, require_gpu, stream_ptr
+from ._lib import (NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, NPI_GEMM_WORKSPACE_PREPARED, check, load, ptr, require_gpu,
+                   stream_ptr)
 from .graph import CSRGraph, CSRSide, as_graph
 from .schedule import DEFAULT, Schedule
 
@@ -170,12 +171,31 @@ def _pad128(k: int) -> int:
     return (int(k) + 127) // 128 * 128
 
 
+def prepare_weight(weight: torch.Tensor, backward: bool = True):
+    """The re-laid copies of ``weight [K, N]`` the matrix-core GEMMs read (three bf16 planes for f32, a k-block-major copy for
+    bf16) for ``linear_fwd(..., ws=)`` and -- ``backward`` -- ``linear_bwd_data(..., ws=)``, written by ONE launch
+    (``npi_linear_prepare``) instead of one in front of every GEMM: ``(ws_fwd, ws_bwd or None)``, or ``(None, None)`` when the
+    shape does not take those kernels anyway.  Valid while ``weight`` is unchanged (a layer's forward and its backward)."""
+    K, N = weight.shape
+    if (weight.dtype not in (torch.float32, torch.bfloat16) or K % 32 or N % 32 or weight.stride(1) != 1 or GEMM_FLAGS != 0
+            or not weight.is_cuda):
+        return None, None
+    lib = load()
+    dev = weight.device
+    one = int(lib.npi_linear_workspace_bytes(K, N))
+    ws = torch.empty(one * (2 if backward else 1), dtype=torch.uint8, device=dev)
+    check(lib.npi_linear_prepare(ptr(weight), weight.stride(0), K, N, 3 if backward else 1, _code(weight), ptr(ws), ws.numel(),
+                                 stream_ptr(dev)), "npi_linear_prepare")
+    return ws[:one], (ws[one:] if backward else None)
+
+
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                rowscale: Optional[torch.Tensor] = None, relu: bool = False, flags: Optional[int] = None,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``a @ weight + bias``.  ``a`` may be wider than ``weight`` has rows: ``[M, Kp]`` with Kp = K rounded up to 128 and
     the columns K.. ZERO (``NPI_GEMM_A_ZERO_PADDED``: the matrix-core kernel on Kp instead of the guarded one on an odd K).
-    ``out``: write into this ``[M, N]`` tensor (rows may have a pitch; same dtype) instead of a new one."""
+    ``out``: write into this ``[M, N]`` tensor (rows may have a pitch; same dtype) instead of a new one.  ``ws``: the forward
+    copy of ``prepare_weight(weight)`` -- no preparation launch in front of the GEMM."""
     dev = require_gpu(a, weight, bias, rowscale)
     a = _fc(a, "a")
     weight = _fc(weight, "weight", a)
@@ -192,7 +212,10 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         out = torch.empty((M, N), dtype=a.dtype, device=dev)
     elif out.shape != (M, N) or out.dtype != a.dtype or out.stride(1) != 1 or out.device != a.device:
         raise ValueError(f"linear_fwd: out must be [{M}, {N}] {a.dtype} with unit column stride on the operands' device")
-    ws = _gemm_workspace(Ka, N, dev)
+    if ws is not None and Ka == K:
+        fl |= NPI_GEMM_WORKSPACE_PREPARED
+    else:
+        ws = _gemm_workspace(Ka, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
         check(load().npi_linear_fwd_ex(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
                                        ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a),
@@ -203,8 +226,9 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
 
 def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
                     rowscale: Optional[torch.Tensor] = None, flags: Optional[int] = None,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``rowscale * (dc @ weight.T)``; ``out``: write into this ``[M, K]`` tensor (a row block of a larger buffer)."""
+                    out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``rowscale * (dc @ weight.T)``; ``out``: write into this ``[M, K]`` tensor (a row block of a larger buffer); ``ws``: the
+    backward copy of ``prepare_weight(weight)``."""
     dev = require_gpu(dc, weight, rowscale)
     dc = _fc(dc, "dC")
     weight = _fc(weight, "weight", dc)
@@ -216,11 +240,15 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
         if out.shape != (M, K) or out.dtype != dc.dtype or out.stride(1) != 1 or out.device != dc.device:
             raise ValueError(f"linear_bwd_data: out must be [{M}, {K}] {dc.dtype} with unit column stride on the operands' device")
         da = out
-    ws = _gemm_workspace(K, N, dev)
+    fl = GEMM_FLAGS if flags is None else flags
+    if ws is not None:
+        fl |= NPI_GEMM_WORKSPACE_PREPARED
+    else:
+        ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
         check(load().npi_linear_bwd_data_ex(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
                                             ptr(da), da.stride(0), M, K, N, _code(dc),
-                                            GEMM_FLAGS if flags is None else flags, ptr(ws), ws.numel(), stream_ptr(dev)),
+                                            fl, ptr(ws), ws.numel(), stream_ptr(dev)),
               "npi_linear_bwd_data")
     return da
 
@@ -438,7 +466,10 @@ class _SageConvFn(torch.autograd.Function):
         # x may be the zero-padded base of the caller's features (sage_conv): agg then keeps the padded width -- zero
         # columns stay zero under a weighted mean -- and both GEMMs run on it (linear_fwd / linear_bwd_weight)
         agg = segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True)
-        out = linear_fwd(agg, weight, bias, relu=relu)                    # a5: agg @ W + b (ReLU in the epilogue on request)
+        # both re-laid copies of W (for this GEMM and for dAgg = dOut W^T of the backward) in one launch
+        wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0]) if (
+            agg.size(1) == weight.size(0) and agg.dtype == weight.dtype) else (None, None)
+        out = linear_fwd(agg, weight, bias, relu=relu, ws=wsf)            # a5: agg @ W + b (ReLU in the epilogue on request)
         ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None
         ctx.graph = graph
         ctx.w_src = w_entry[1] if w_entry else None
@@ -466,7 +497,7 @@ class _SageConvFn(torch.autograd.Function):
         if want_x:
             # dAgg = dOut W^T, pre-divided by the in-count of its row (fused epilogue), then
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
-            dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst))
+            dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst), ws=ctx.ws_bwd)
             if overlap:
                 # dW is independent of the dX chain.  It is launched on THIS stream right behind dAgg's GEMM, one
                 # workgroup per CU, so that it is resident everywhere before the aggregation -- sent to a second HIP
@@ -591,7 +622,8 @@ class _GcnAggFirstFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, norm: GCNNorm, sch: Schedule = DEFAULT):
         graph = norm.graph
         agg = segsum(graph, graph.by_dst, x, w=norm.by_dst)                    # sum_e norm_e x[src]
-        out = linear_fwd(agg, weight, bias)
+        wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0]) if agg.dtype == weight.dtype else (None, None)
+        out = linear_fwd(agg, weight, bias, ws=wsf)
         ctx.norm = norm
         ctx.has_bias = bias is not None
         ctx.sch = sch
@@ -611,7 +643,7 @@ class _GcnAggFirstFn(torch.autograd.Function):
         if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
         if want_x:
-            dagg = linear_bwd_data(grad_out, weight)
+            dagg = linear_bwd_data(grad_out, weight, ws=ctx.ws_bwd)
             if overlap:                                                        # see _SageConvFn.backward
                 dev = grad_out.device
                 main = torch.cuda.current_stream(dev)

@@ -1032,3 +1032,36 @@ def test_bf16_dw_matches_f32_reference(dev, M, K, N, want_bias):
         assert float((db.float().cpu() - ref_b).abs().max()) <= 2.0 ** -7 * float(ref_b.abs().max())
     dw2, db2 = NF.linear_bwd_weight(A.to(dev), dC.to(dev), want_bias)
     assert torch.equal(dw, dw2) and (db is None or torch.equal(db, db2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(1000, 256, 256), (5085, 128, 128), (300, 64, 192), (130, 160, 128)])
+def test_prepared_weight_copies_give_the_same_bits(dev, dtype, M, K, N):
+    """npi_linear_prepare writes both re-laid copies of W in one launch; a GEMM told NPI_GEMM_WORKSPACE_PREPARED reads them
+    instead of preparing its own: forward and bwd_data bit-equal to the plain calls, also on row blocks (the sharded layers'
+    light / hub split), f32 and bf16 storage."""
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(dtype).to(dev)
+    b = torch.randn(N, generator=g).to(dtype).to(dev)
+    dC = torch.randn(M, N, generator=g).to(dtype).to(dev)
+    rs = torch.rand(M, generator=g).to(dev)
+    wsf, wsb = NF.prepare_weight(W)
+    assert wsf is not None and wsb is not None
+    ref_f, ref_b = NF.linear_fwd(A, W, b, relu=True), NF.linear_bwd_data(dC, W, rs)
+    assert torch.equal(NF.linear_fwd(A, W, b, relu=True, ws=wsf), ref_f)
+    assert torch.equal(NF.linear_bwd_data(dC, W, rs, ws=wsb), ref_b)
+    only_f, none = NF.prepare_weight(W, backward=False)
+    assert none is None and torch.equal(NF.linear_fwd(A, W, b, relu=True, ws=only_f), ref_f)
+    assert NF.prepare_weight(W[:, : N - 8].contiguous()) == (None, None)             # a width the matrix-core kernels do not take
+    h = M // 3
+    if h < 128:                          # a block of < 128 rows takes the guarded exact-f32 kernel: other arithmetic either way
+        return
+    out = torch.empty_like(ref_f)
+    NF.linear_fwd(A[:h], W, b, relu=True, out=out[:h], ws=wsf)
+    NF.linear_fwd(A[h:], W, b, relu=True, out=out[h:], ws=wsf)
+    assert torch.equal(out, ref_f)
+    da = torch.empty_like(ref_b)
+    NF.linear_bwd_data(dC[h:], W, rs[h:], out=da[h:], ws=wsb)
+    NF.linear_bwd_data(dC[:h], W, rs[:h], out=da[:h], ws=wsb)
+    assert torch.equal(da, ref_b)
