@@ -18,6 +18,8 @@ struct SegParams {
     int relu;                // != 0: max(., 0) after scale and bias (the F.relu behind a GATConv, in the row epilogue; NaN kept)
     int mean;                // != 0: divide every row sum by its entry count (scatter_mean); filled in by segsum_run
     int item;                // entries per item: the CSR's own item size (what item_row was cut with), set by the entry point
+    int nt_out;              // != 0: finished rows leave with non-temporal stores (filled in by segsum_run: outputs of >= 64 MB,
+                             // which no cache would hold until their next use -- they only displace gathered rows)
     const float* x;
     int64_t ldx;
     const float* x2;         // two-part table: entries with col >= split read row (col - split) of x2 (same ldx);

@@ -162,6 +162,16 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
 #pragma unroll
             for (int q = 0; q < VEC; ++q) t[q] += gd * at[q] + gs * at[P.C + q];
         }
+        if constexpr (VEC == 4 && sizeof(T) == 4) {
+            // a large output is written once and read again after gigabytes of gathers: streamed past the caches it does not
+            // displace gathered rows (same-box A/B at C4: 2.618 -> 2.592 ms per launch, step 6.80 -> 6.75 ms)
+            if (P.nt_out) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f v = {t[0], t[1], t[2], t[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst + L.foff[c]));
+                continue;
+            }
+        }
         store_row<VEC, T>(dst + L.foff[c], t);
     }
 }
@@ -965,6 +975,7 @@ int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hip
     }
     P.n_items = (int)num_items_of(nnz_max, P.item);
     P.mean = mean ? 1 : 0;
+    P.nt_out = ((int64_t)P.N * F * ((dtype == NPI_BF16) ? 2 : 4) >= ((int64_t)64 << 20)) ? 1 : 0;
     const int es = (dtype == NPI_BF16) ? 2 : 4;              // bytes per stored element
     if (P.x2 == nullptr) { P.x2 = P.x; P.split = 0x7fffffff; }
     const char* x = reinterpret_cast<const char*>(P.x);
