@@ -1306,7 +1306,10 @@ gemm_dw_split_kernel(DwArgs a) {
         // slab boundary -- addresses a multiple of 16 KiB apart -- otherwise sweep the memory channels in lockstep
         const int phase = (NPI_DW_PROBE & 1) || nk < 2 ? 0 : (int)(((int64_t)slab * 37) % nk);
         const bool active = isA || isB;
-#define DW_GL(dst, base) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+// The operands of dW are read ONCE (1 GB each at C4) while the backward aggregation beside it lives off what the caches hold of
+// its gathered rows: non-temporal loads (same-box A/B builds at C4, twice: step 6.753 / 6.764 -> 6.692 / 6.681 ms; the same hint
+// on the A loads of the forward / bwd_data kernel, whose rows the aggregation has just written or will just read: +0.05 ms)
+#define DW_GL(dst, base) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define DW_DECL(S) f32x4r S##0, S##1, S##2, S##3, S##4, S##5, S##6, S##7
 #define DW_LOAD(S, KS)                                                                                 \
     do {                                                                                               \
