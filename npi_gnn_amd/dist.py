@@ -829,8 +829,8 @@ class _ShardedSageFn(torch.autograd.Function):
         if want_x:
             rs = None if ctx.gcn else sg.inv_cnt
             nL = sg.nL
-            if (sg.direct_ok and sg.schedule.split_projection and nL > 0 and sg.nH > 0 and not _solo(sg.world)
-                    and getattr(be, "bwd_data_into", False)):
+            if (sg.direct_ok and sg.schedule.split_projection and sg.schedule.early_hub_gather and nL > 0 and sg.nH > 0
+                    and not _solo(sg.world) and getattr(be, "bwd_data_into", False)):
                 # the hub rows of dAgg first (a one-round GEMM): their all-gather is on the wire while the light rows -- nine
                 # tenths of the GEMM -- are computed (row-wise independent: the same numbers as one GEMM over all rows)
                 kw = {"ws": ctx.ws_bwd} if ctx.ws_bwd is not None else {}

@@ -33,6 +33,11 @@ class Schedule:
     partial_stream: bool = True
     #: the light rows' projection launched before the reduce-scattered hub rows have arrived
     split_projection: bool = True
+    #: backward of the sharded SAGE / GCN layers (with ``split_projection``): the hub rows of dAgg are projected first and their
+    #: all-gather is issued before the light rows' GEMM.  OFF by default: on one GPU it costs a rank 3.5 % (an extra one-round GEMM;
+    #: the stand-in copy shares HBM with the light rows' GEMM), and on a node the collective's workgroups find no registers on a
+    #: CU while the persistent GEMM workgroup (8 x 230 VGPRs) is resident, so the head start is not theirs to use (EXPERIMENTS A9)
+    early_hub_gather: bool = False
     #: GATConv on the direct layout with the fused packed backward (needs ``direct_hub_rows``)
     gat_direct: bool = True
 
