@@ -101,6 +101,16 @@ def _fc(t: torch.Tensor, name: str, like: Optional[torch.Tensor] = None) -> torc
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _fcp(t: torch.Tensor, name: str) -> torch.Tensor:
+    """as ``_fc``, but a 2-D operand may keep a row pitch (a column block of a wider buffer): the kernels take a leading
+    dimension"""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.size(1):
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"{name} must be float32 or bfloat16 (got {t.dtype})")
+        return t
+    return _fc(t, name)
+
+
 def _code(t: torch.Tensor) -> int:
     return NPI_BF16 if t.dtype == torch.bfloat16 else NPI_F32
 
@@ -124,7 +134,7 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     reduction (``npi_segsum``).  ``x2``: second part of a two-part table -- entries with
     ``col >= x.size(0)`` read ``x2[col - x.size(0)]`` (``npi_segsum_ex``; the sharded layers)."""
     dev = require_gpu(x, w, bias, x2)
-    x = _fc(x, "x")
+    x = _fcp(x, "x")
     if bias is not None:
         bias = _fc(bias, "bias", x)
     N, F = side.n_rows, x.size(1)                  # `graph` may be None for a stand-alone (sharded) side
@@ -169,6 +179,19 @@ def _gemm_workspace(K: int, N: int, dev) -> torch.Tensor:
 
 def _pad128(k: int) -> int:
     return (int(k) + 127) // 128 * 128
+
+
+def padded_aggregate_buffer(x: torch.Tensor, K: int, rows: int, bf16_ok: bool = False):
+    """A zeroed ``[rows, Kp]`` f32 buffer (Kp = K rounded up to 128) whose first K columns the aggregation fills, or None.
+    The reference's feature width is 178: with the aggregate kept 256 wide and its pad columns zero, the layer's forward GEMM and
+    its weight-gradient GEMM take the matrix-core kernels (``NPI_GEMM_A_ZERO_PADDED``) instead of the guarded ones -- what
+    ``InteractionGraph.batch`` does for extracted batches, here for features the caller hands over 178 wide.  Only when the
+    padding costs less than half as much again (178 -> 256 yes, 65 -> 128 no).  (bf16 storage has no padded-operand flag: the
+    layer pads its weight matrix with zero rows instead, ``_SageConvFn``.)"""
+    if (x.dtype not in ((torch.float32, torch.bfloat16) if bf16_ok else (torch.float32,)) or x.size(1) != K or K % 128 == 0
+            or 2 * _pad128(K) > 3 * K or rows < 128 or GEMM_FLAGS != 0):
+        return None
+    return torch.zeros((rows, _pad128(K)), dtype=x.dtype, device=x.device)
 
 
 def prepare_weight(weight: torch.Tensor, backward: bool = True):
@@ -465,7 +488,17 @@ class _SageConvFn(torch.autograd.Function):
         # a2-a4: gather + scatter_mean (w_entry: PyG's `edge_weight.view(-1, 1) * x_j`; the mean still divides by the count)
         # x may be the zero-padded base of the caller's features (sage_conv): agg then keeps the padded width -- zero
         # columns stay zero under a weighted mean -- and both GEMMs run on it (linear_fwd / linear_bwd_weight)
-        agg = segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True)
+        agg = padded_aggregate_buffer(x, weight.size(0), graph.by_dst.n_rows, bf16_ok=True)
+        if agg is None:
+            agg = segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True)
+        else:
+            segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True, out=agg[:, : x.size(1)])
+        ctx.k_rows = None
+        if agg.size(1) != weight.size(0) and agg.dtype == torch.bfloat16:
+            # bf16 storage, zero-padded aggregate: W gets zero ROWS to match (one small launch) and all three GEMMs of the layer
+            # run the aligned bf16 matrix-core kernels; dAgg and dW are computed padded and cut back to the true width
+            ctx.k_rows = weight.size(0)
+            weight = torch.nn.functional.pad(weight.detach(), (0, 0, 0, agg.size(1) - weight.size(0)))
         # both re-laid copies of W (for this GEMM and for dAgg = dOut W^T of the backward) in one launch
         wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0]) if (
             agg.size(1) == weight.size(0) and agg.dtype == weight.dtype) else (None, None)
@@ -498,6 +531,8 @@ class _SageConvFn(torch.autograd.Function):
             # dAgg = dOut W^T, pre-divided by the in-count of its row (fused epilogue), then
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
             dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst), ws=ctx.ws_bwd)
+            if ctx.k_rows is not None:
+                dagg = dagg[:, : ctx.k_rows]                                 # (the pad columns of dAgg: dOut times zero rows)
             if overlap:
                 # dW is independent of the dX chain.  It is launched on THIS stream right behind dAgg's GEMM, one
                 # workgroup per CU, so that it is resident everywhere before the aggregation -- sent to a second HIP
@@ -515,6 +550,8 @@ class _SageConvFn(torch.autograd.Function):
                 main.wait_stream(side)
             else:
                 dx = segsum(graph, tside(), dagg, w=ctx.w_src, mean=False)
+        if dw is not None and ctx.k_rows is not None:
+            dw = dw[: ctx.k_rows]                                             # the gradient of the zero rows is not W's
         return dx, dw, db, None, None, None, None
 
 
@@ -621,9 +658,15 @@ class _GcnAggFirstFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, norm: GCNNorm, sch: Schedule = DEFAULT):
         graph = norm.graph
-        agg = segsum(graph, graph.by_dst, x, w=norm.by_dst)                    # sum_e norm_e x[src]
-        wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0]) if agg.dtype == weight.dtype else (None, None)
+        agg = padded_aggregate_buffer(x, weight.size(0), graph.by_dst.n_rows)
+        if agg is None:
+            agg = segsum(graph, graph.by_dst, x, w=norm.by_dst)                # sum_e norm_e x[src]
+        else:
+            segsum(graph, graph.by_dst, x, w=norm.by_dst, out=agg[:, : x.size(1)])
+        wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0]) if (
+            agg.size(1) == weight.size(0) and agg.dtype == weight.dtype) else (None, None)
         out = linear_fwd(agg, weight, bias, ws=wsf)
+        ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None
         ctx.norm = norm
         ctx.has_bias = bias is not None
         ctx.sch = sch
@@ -641,7 +684,7 @@ class _GcnAggFirstFn(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
         if want_w and not overlap:
-            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias)
+            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)
         if want_x:
             dagg = linear_bwd_data(grad_out, weight, ws=ctx.ws_bwd)
             if overlap:                                                        # see _SageConvFn.backward
@@ -649,7 +692,7 @@ class _GcnAggFirstFn(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 side = _side_stream(dev)
                 side.wait_stream(main)
-                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True)
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True, k_valid=ctx.k_valid)
                 with torch.cuda.stream(side):
                     dx = segsum(graph, graph.by_src, dagg, w=norm.by_src)
                 dagg.record_stream(side)

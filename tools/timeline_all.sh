@@ -22,4 +22,6 @@ W=${2:-vsage,vgat,gat1}
 [[ $W == *c2f* ]] && run c2f 70 python3 "$ROOT/tools/c2_probe.py" f32
 [[ $W == *c5s* ]] && run c5s 130 python3 "$ROOT/tools/c5_stack_probe.py" 2
 [[ $W == *net1* ]] && run net1 100 python3 "$ROOT/tools/net1_step_probe.py" 20
+[[ $W == *c3g* ]] && run c3g 60 python3 "$ROOT/tools/c13_probe.py" c3
+[[ $W == *c1g* ]] && run c1g 50 python3 "$ROOT/tools/c13_probe.py" c1
 true
