@@ -123,6 +123,9 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N),
         "npi_linear_bwd_data_ex": lambda: lib.npi_linear_bwd_data_ex(N, 0, N, 0, N, N, 0, 8, 8, -3, 0, 0, N, 0, N),
         "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 0, 1, N),
+        # round 4: the row-dot epilogue serves one column tile (N = 128 / 256) only; the preparation launch wants K, N % 16 == 0
+        "npi_linear_fwd_scores": lambda: lib.npi_linear_fwd_scores(16, 256, 16, 192, 16, 16, 192, 16, 16, 1000, 256, 192, N, 0, N),
+        "npi_linear_prepare": lambda: lib.npi_linear_prepare(16, 256, 178, 128, 3, 0, 16, 1 << 20, N),
         "npi_gat_edge_grad_ex": lambda: lib.npi_gat_edge_grad_ex(N, N, N, 4, 16, N, 4, N, 0, N, 4, 0, 4, N, N, N, N, N, 0.2, 1, N, N, N),
     }
     for name, call in calls.items():
@@ -134,6 +137,10 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
     assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 0, 16, 100, N) == -3
     assert b"workspace" in lib.npi_last_error()
     assert lib.npi_linear_bwd_data_ex(16, 256, 16, 256, N, 16, 256, 128, 256, 256, 0, 0, 24, 10 ** 9, N) == -3   # misaligned
+    assert lib.npi_linear_prepare(16, 256, 256, 256, 3, 0, 16, lib.npi_linear_workspace_bytes(256, 256), N) == -3     # both copies: 2 x
+    assert lib.npi_linear_fwd_scores_supported(1000, 256, 256) == 1 and lib.npi_linear_fwd_scores_supported(1000, 256, 192) == 0
+    # NPI_GEMM_WORKSPACE_PREPARED (8) without a workspace is an argument error
+    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 8, N, 0, N) == -1
     assert lib.npi_linear_bwd_weight_workspace_elems(-1, 8, 8) == -1
     assert lib.npi_gemm_mode(-1) in (0, 1)                      # query only
 

@@ -24,4 +24,6 @@ W=${2:-vsage,vgat,gat1}
 [[ $W == *net1* ]] && run net1 100 python3 "$ROOT/tools/net1_step_probe.py" 20
 [[ $W == *c3g* ]] && run c3g 60 python3 "$ROOT/tools/c13_probe.py" c3
 [[ $W == *c1g* ]] && run c1g 50 python3 "$ROOT/tools/c13_probe.py" c1
+[[ $W == *gath8* ]] && run gath8 40 python3 "$ROOT/tools/gat_heads_probe.py" 8 3
+[[ $W == *gath2* ]] && run gath2 40 python3 "$ROOT/tools/gat_heads_probe.py" 2 3
 true
