@@ -1065,3 +1065,33 @@ def test_prepared_weight_copies_give_the_same_bits(dev, dtype, M, K, N):
     NF.linear_bwd_data(dC[h:], W, rs[h:], out=da[h:], ws=wsb)
     NF.linear_bwd_data(dC[:h], W, rs[:h], out=da[:h], ws=wsb)
     assert torch.equal(da, ref_b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,K,Fo", [(5000, 178, 128), (700, 90, 64), (3000, 200, 256), (1500, 300, 128), (2000, 65, 128), (120, 178, 128),
+                                    (4000, 100, 160)])
+def test_sage_layer_with_odd_input_width_matches_the_oracle(dev, dtype, N, K, Fo):
+    """SAGEConv fwd + bwd at input widths that are not a multiple of 128: from 128 rows on and when the padding costs < 1.5 x the
+    aggregate is kept 128-aligned with zero pad columns (f32: NPI_GEMM_A_ZERO_PADDED; bf16: W padded with zero rows, dAgg / dW
+    cut back) -- 178 -> 256, 90 / 100 -> 128, 200 -> 256, 300 -> 384 padded; 65 and the 120-row graph not -- against the CPU
+    oracle on the same (bf16-rounded) inputs."""
+    g = torch.Generator().manual_seed(N + K)
+    E = 8 * N
+    ei = torch.randint(0, N, (2, E), generator=g)
+    x = torch.randn(N, K, generator=g)
+    W = torch.randn(K, Fo, generator=g) / K ** 0.5
+    b = torch.randn(Fo, generator=g) * 0.1
+    go = torch.randn(N, Fo, generator=g)
+    if dtype == torch.bfloat16:
+        x, W, b, go = (t.to(dtype).float() for t in (x, W, b, go))
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    ref = R.sage_conv(xr, ei, Wr, br)
+    ref.backward(go)
+    xd, Wd, bd = (t.to(dev).to(dtype).requires_grad_(True) for t in (x, W, b))
+    out = npi.sage_conv(xd, npi.CSRGraph(ei.to(dev), N), Wd, bd)
+    out.backward(go.to(dev).to(dtype))
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    for name, got, want in (("out", out, ref), ("dx", xd.grad, xr.grad), ("dW", Wd.grad, Wr.grad), ("db", bd.grad, br.grad)):
+        assert got.shape == want.shape and got.dtype == dtype, name
+        err = float((got.detach().float().cpu() - want.detach()).abs().max() / (want.detach().abs().max() + 1e-12))
+        assert err <= tol, (name, err)
