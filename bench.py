@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--control-only", action="store_true",
                     help="run only the uniform-source control launches (for a rocprofv3 --pmc pass)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config block")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="N > 1: keep the default Schedule instead of timing its alternatives during set-up")
     ap.add_argument("--skip-c5", action="store_true", help="configs block without the 4M / 100M GAT stack")
     ap.add_argument("--capture", action="store_true",
                     help="N=1: capture the step (both streams) into one HIP graph and time replays of it")
@@ -1052,6 +1054,50 @@ def main():
             sg, layer, x, go, seg_launch_bytes = build_sharded(CONSERVATIVE)      # an argument of the shard, no process-wide switch
         torch.cuda.synchronize()
         t_build = time.time() - t0
+        # Set-up, N > 1 only: two arrangements whose worth depends on what RCCL's kernels do beside ours -- nothing one GPU can
+        # tell (EXPERIMENTS A9, A16): the projection GEMMs on 16 CUs fewer (a persistent GEMM whose workgroup finds its CU held
+        # by a collective starts late with its full share of tiles) and the hub rows of dAgg projected first.  Each candidate
+        # is built, run 5 + 2 x 8 steps between barriers (MAX over ranks), and the fastest becomes THE schedule of the timed region;
+        # every rank takes the same decision from the same all-reduced numbers.  `config.autotune` lists what was measured.
+        autotune = None
+        if fallback is None and args.partition == "hubs" and args.conv in ("sage", "gcn") and not args.no_autotune and (
+                world > 1 or os.environ.get("NPI_BENCH_AUTOTUNE_SOLO") == "1"):
+            cands = {"default": DEFAULT, "gemm_reserve_cus=16": DEFAULT.but(gemm_reserve_cus=16),
+                     "early_hub_gather": DEFAULT.but(early_hub_gather=True),
+                     "gemm_reserve_cus=16,early_hub_gather": DEFAULT.but(gemm_reserve_cus=16, early_hub_gather=True)}
+            autotune, best = {}, ("default", None)
+            try:
+                for name, sch in cands.items():
+                    if name != "default":
+                        del sg, layer, x, go
+                        torch.cuda.empty_cache()
+                        sg, layer, x, go, seg_launch_bytes = build_sharded(sch)
+                    for _ in range(5):
+                        step()
+                    regions = []
+                    for _ in range(2):                          # the better of two regions: the first one after a rebuild is noisy
+                        if world > 1:
+                            dist.barrier()
+                        torch.cuda.synchronize()
+                        a0 = time.perf_counter()
+                        for _ in range(8):
+                            step()
+                        torch.cuda.synchronize()
+                        tt = torch.tensor([(time.perf_counter() - a0) / 8 * 1e3], dtype=torch.float64, device=dev)
+                        if world > 1:
+                            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        regions.append(float(tt.item()))
+                    autotune[name] = min(regions)
+                    if best[1] is None or autotune[name] < best[1]:
+                        best = (name, autotune[name])
+                if best[0] != list(cands)[-1]:                       # the last candidate is the one that is built right now
+                    del sg, layer, x, go
+                    torch.cuda.empty_cache()
+                    sg, layer, x, go, seg_launch_bytes = build_sharded(cands[best[0]])
+                autotune = {"ms_per_step": autotune, "chosen": best[0]}
+            except Exception as e:                              # noqa: BLE001 -- keep the default, say why
+                autotune = {"error": f"{type(e).__name__}: {e}"[:300], "chosen": "default"}
+                sg, layer, x, go, seg_launch_bytes = build_sharded(DEFAULT)
 
     def barrier():
         if world > 1:
@@ -1213,7 +1259,8 @@ def main():
                                    f"(both directions, Zipf-skewed protein side), 1 {args.conv.upper()}Conv layer "
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
                        "parallelism": parallelism(args, world), "hip_graph_replay": captured, "setup_steps": SETUP_STEPS,
-                       "csr_build_s": round(t_build, 4), "fallback": fallback},
+                       "csr_build_s": round(t_build, 4), "fallback": fallback,
+                       "autotune": autotune if sharded else None},
             "roofline": roof,
         }
         res.update(extra)

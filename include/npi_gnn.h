@@ -249,6 +249,13 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
  * its backward GEMM and any row-block split of them (dist.py: light rows / hub rows) without a preparation launch each.  Not
  * together with NPI_GEMM_A_ZERO_PADDED.  A call whose shape does not take the matrix-core kernels ignores the workspace. */
 #define NPI_GEMM_WORKSPACE_PREPARED 8
+/* npi_linear_fwd_ex / npi_linear_bwd_data_ex: the persistent matrix-core kernels (one workgroup per CU, a static walk over the
+ * tiles) take n workgroups fewer than the chip has CUs (n a multiple of 8, at most 128).  For a GEMM launched while another
+ * kernel holds CUs -- a collective's workgroups on a multi-GPU node: a workgroup that finds its CU taken starts late and
+ * still owns its share of the tiles, so the launch ends when the other kernel does (measured with a stand-in that holds 16
+ * CUs: 0.107 -> 0.15 ms for 125 k rows).  Costs n / 256 more tiles per workgroup when nothing else runs. */
+#define NPI_GEMM_RESERVE_CUS(n) ((((n) / 8) & 0xff) << 8)
+#define NPI_GEMM_RESERVED_CUS_OF(flags) ((((flags) >> 8) & 0xff) * 8)
 int64_t npi_linear_workspace_bytes(int64_t K, int64_t N);
 /* The re-laid copies of W [K, N] (the `weight` of PyG's `torch.matmul(aggr_out, self.weight)`, reference call sites
  * src/classes.py:62,66,70) for the matrix-core kernels, in ONE launch: which = 1: the copy npi_linear_fwd_ex uses, 2: the one

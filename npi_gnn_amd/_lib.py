@@ -21,6 +21,11 @@ NPI_GEMM_SPLIT_BF16 = 2
 NPI_GEMM_A_ZERO_PADDED = 4   # A stored with zero pad columns up to a multiple of 128 (include/npi_gnn.h)
 NPI_GEMM_WORKSPACE_PREPARED = 8   # the workspace already holds npi_linear_prepare's copy of this weight matrix
 
+
+def NPI_GEMM_RESERVE_CUS(n: int) -> int:
+    """flag bits of npi_linear_fwd_ex / npi_linear_bwd_data_ex: leave ``n`` CUs (a multiple of 8) to a kernel running beside the GEMM"""
+    return ((int(n) // 8) & 0xff) << 8
+
 _P = c_void_p
 _I = c_int64
 

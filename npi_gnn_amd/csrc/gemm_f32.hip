@@ -1694,7 +1694,10 @@ template <int AMODE, int BMODE>
 // k_valid rows (NPI_GEMM_A_ZERO_PADDED): the split kernel runs on a.K with the weight planes zero-extended, everything
 // else (guarded strips, the exact kernels) on k_valid.
 static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32,
-                       int mode = 1, void* scratch = nullptr, int k_valid = 0, bool prepared = false) {
+                       int mode = 1, void* scratch = nullptr, int k_valid = 0, bool prepared = false, int reserve_cus = 0) {
+    // `reserve_cus`: the persistent kernels take that many workgroups fewer than CUs (a multiple of 8: one per XCD), so that a
+    // kernel resident beside them -- a collective's -- holds CUs they do not wait for (NPI_GEMM_RESERVE_CUS)
+    const int cu_slots = 256 - ((reserve_cus < 0 ? 0 : reserve_cus > 128 ? 128 : reserve_cus) / 8) * 8;
     // `prepared`: `scratch` already holds the re-laid weight matrix of THIS B / K / N / BMODE (npi_linear_prepare): no
     // preparation launch in front of the GEMM
     const bool bf16_in = dtype_in == NPI_BF16 && dtype_out == NPI_F32;          // dW of the bf16 path: bf16 operands, f32 slabs
@@ -1731,7 +1734,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         Bf16Args ba{reinterpret_cast<const uint16_t*>(a.A), a.lda, blocks, reinterpret_cast<uint16_t*>(a.C), a.ldc, a.M, a.N, a.K,
                     reinterpret_cast<const uint16_t*>(a.ep.bias), a.ep.rowscale, a.ep.relu, bfm, btn};
         const int64_t ntiles = (int64_t)bfm * btn;
-        const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);
+        const int grid = (int)(ntiles < cu_slots ? ((ntiles + 7) / 8) * 8 : cu_slots);
         if (wide_n) gemm_bf16_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(ba);
         else        gemm_bf16_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(ba);
         if (scratch == nullptr) (void)hipFreeAsync(blocks, stream);
@@ -1765,7 +1768,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         split_tm = (int)ceil_div(a.M, 128);                  // a ragged last m-tile overlaps its neighbour (TileWalk::row0)
         SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, split_tm, tn};
         const int64_t ntiles = (int64_t)split_tm * tn;
-        const int grid = (int)(ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256);      // one workgroup per CU, multiple of 8 (XCDs)
+        const int grid = (int)(ntiles < cu_slots ? ((ntiles + 7) / 8) * 8 : cu_slots);      // one workgroup per CU, multiple of 8 (XCDs)
         if (a.ep.r2_row0 != nullptr) {
             if (wide_n) gemm_split_ws_kernel<4, 1><<<grid, WS_THREADS, 0, stream>>>(sa);
             else        gemm_split_ws_kernel<2, 1><<<grid, WS_THREADS, 0, stream>>>(sa);
@@ -1932,7 +1935,7 @@ extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int6
     NPI_REQUIRE(!prepared || (workspace != nullptr && !padded), "npi_linear_fwd_ex: NPI_GEMM_WORKSPACE_PREPARED needs the workspace "
                 "npi_linear_prepare filled and excludes NPI_GEMM_A_ZERO_PADDED");
     const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, Kp, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
-                                     gemm_mode_of(flags), workspace, padded ? (int)K : 0, prepared);
+                                     gemm_mode_of(flags), workspace, padded ? (int)K : 0, prepared, NPI_GEMM_RESERVED_CUS_OF(flags));
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd");
 }
 extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
@@ -1970,7 +1973,7 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
     NPI_REQUIRE(!prepared || workspace != nullptr, "npi_linear_bwd_data_ex: NPI_GEMM_WORKSPACE_PREPARED needs the workspace "
                 "npi_linear_prepare filled");
     const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
-                                     gemm_mode_of(flags), workspace, 0, prepared);
+                                     gemm_mode_of(flags), workspace, 0, prepared, NPI_GEMM_RESERVED_CUS_OF(flags));
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data");
 }
 // C = A W and, from the accumulators on their way out, sc0[m] = <C[m, :], att[:N]>, sc1[m] = <C[m, :], att[N:]>: GATConv's

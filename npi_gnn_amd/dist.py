@@ -387,9 +387,9 @@ class HipBackend:
         from . import functional as NF
         return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2, out=out)
 
-    def linear_fwd(self, a, w, b, out=None, ws=None):
+    def linear_fwd(self, a, w, b, out=None, ws=None, reserve_cus=0):
         from . import functional as NF
-        return NF.linear_fwd(a, w, b, out=out, ws=ws)
+        return NF.linear_fwd(a, w, b, out=out, ws=ws, reserve_cus=reserve_cus)
 
     def prepare_weight(self, w, backward=True):
         """(ws_fwd, ws_bwd) for linear_fwd(..., ws=) / linear_bwd_data(..., ws=): both re-laid copies of ``w`` in one launch"""
@@ -398,9 +398,9 @@ class HipBackend:
 
     bwd_data_into = True                              # linear_bwd_data takes ``out=`` (a row block of a larger buffer)
 
-    def linear_bwd_data(self, dc, w, rowscale, out=None, ws=None):
+    def linear_bwd_data(self, dc, w, rowscale, out=None, ws=None, reserve_cus=0):
         from . import functional as NF
-        return NF.linear_bwd_data(dc, w, rowscale, out=out, ws=ws)
+        return NF.linear_bwd_data(dc, w, rowscale, out=out, ws=ws, reserve_cus=reserve_cus)
 
     def linear_bwd_weight(self, a, dc, want_bias, shared=False):
         from . import functional as NF
@@ -789,6 +789,8 @@ class _ShardedSageFn(torch.autograd.Function):
             # both re-laid copies of W (this direction's GEMMs and the backward's) in one launch
             wsf, ws_bwd = be.prepare_weight(weight, ctx.needs_input_grad[0]) if hasattr(be, "prepare_weight") else (None, None)
             kw = {"ws": wsf} if wsf is not None else {}
+            if hasattr(be, "prepare_weight") and not _solo(sg.world) and sg.schedule.gemm_reserve_cus:
+                kw["reserve_cus"] = sg.schedule.gemm_reserve_cus           # a collective may be resident beside these GEMMs
             if split:
                 # the light rows are complete on this rank: their projection runs while the hub rows are still on the wire
                 # (row-wise independent: the same numbers as one GEMM over all rows)
@@ -834,12 +836,15 @@ class _ShardedSageFn(torch.autograd.Function):
                 # the hub rows of dAgg first (a one-round GEMM): their all-gather is on the wire while the light rows -- nine
                 # tenths of the GEMM -- are computed (row-wise independent: the same numbers as one GEMM over all rows)
                 kw = {"ws": ctx.ws_bwd} if ctx.ws_bwd is not None else {}
+                if sg.schedule.gemm_reserve_cus:
+                    kw["reserve_cus"] = sg.schedule.gemm_reserve_cus
                 dagg = grad_out.new_empty((sg.n_local, weight.size(0)))
                 be.linear_bwd_data(grad_out[nL:], weight, None if rs is None else rs[nL:], out=dagg[nL:], **kw)
                 gathered = gather_hub(sg, dagg, async_op=True)
                 be.linear_bwd_data(grad_out[:nL], weight, None if rs is None else rs[:nL], out=dagg[:nL], **kw)
             elif ctx.ws_bwd is not None:
-                dagg = be.linear_bwd_data(grad_out, weight, rs, ws=ctx.ws_bwd)
+                dagg = be.linear_bwd_data(grad_out, weight, rs, ws=ctx.ws_bwd,
+                                          reserve_cus=0 if _solo(sg.world) else sg.schedule.gemm_reserve_cus)
             else:
                 dagg = be.linear_bwd_data(grad_out, weight, rs)
         # dW is independent of the dX chain.  On the GPU backend it is launched FIRST, on this stream, so that it is resident

@@ -13,8 +13,8 @@ from typing import Optional
 
 import torch
 
-from ._lib import (NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, NPI_GEMM_WORKSPACE_PREPARED, check, load, ptr, require_gpu,
-                   stream_ptr)
+from ._lib import (NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, NPI_GEMM_RESERVE_CUS, NPI_GEMM_WORKSPACE_PREPARED, check, load, ptr,
+                   require_gpu, stream_ptr)
 from .graph import CSRGraph, CSRSide, as_graph
 from .schedule import DEFAULT, Schedule
 
@@ -214,11 +214,12 @@ def prepare_weight(weight: torch.Tensor, backward: bool = True):
 
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                rowscale: Optional[torch.Tensor] = None, relu: bool = False, flags: Optional[int] = None,
-               out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, reserve_cus: int = 0) -> torch.Tensor:
     """``a @ weight + bias``.  ``a`` may be wider than ``weight`` has rows: ``[M, Kp]`` with Kp = K rounded up to 128 and
     the columns K.. ZERO (``NPI_GEMM_A_ZERO_PADDED``: the matrix-core kernel on Kp instead of the guarded one on an odd K).
     ``out``: write into this ``[M, N]`` tensor (rows may have a pitch; same dtype) instead of a new one.  ``ws``: the forward
-    copy of ``prepare_weight(weight)`` -- no preparation launch in front of the GEMM."""
+    copy of ``prepare_weight(weight)`` -- no preparation launch in front of the GEMM.  ``reserve_cus``: leave that many CUs (a
+    multiple of 8) to a kernel that runs beside the GEMM (``NPI_GEMM_RESERVE_CUS``; the sharded layers, ``Schedule.gemm_reserve_cus``)."""
     dev = require_gpu(a, weight, bias, rowscale)
     a = _fc(a, "a")
     weight = _fc(weight, "weight", a)
@@ -226,7 +227,7 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         bias = _fc(bias, "bias", a)
     M, Ka = a.shape
     K, N = weight.shape
-    fl = GEMM_FLAGS if flags is None else flags
+    fl = (GEMM_FLAGS if flags is None else flags) | NPI_GEMM_RESERVE_CUS(reserve_cus)
     if Ka != K:
         if Ka != _pad128(K) or a.dtype != torch.float32:
             raise ValueError(f"a has {Ka} columns, weight {K} rows (a zero-padded a must be f32 and {_pad128(K)} wide)")
@@ -249,7 +250,7 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
 
 def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
                     rowscale: Optional[torch.Tensor] = None, flags: Optional[int] = None,
-                    out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, reserve_cus: int = 0) -> torch.Tensor:
     """``rowscale * (dc @ weight.T)``; ``out``: write into this ``[M, K]`` tensor (a row block of a larger buffer); ``ws``: the
     backward copy of ``prepare_weight(weight)``."""
     dev = require_gpu(dc, weight, rowscale)
@@ -263,7 +264,7 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
         if out.shape != (M, K) or out.dtype != dc.dtype or out.stride(1) != 1 or out.device != dc.device:
             raise ValueError(f"linear_bwd_data: out must be [{M}, {K}] {dc.dtype} with unit column stride on the operands' device")
         da = out
-    fl = GEMM_FLAGS if flags is None else flags
+    fl = (GEMM_FLAGS if flags is None else flags) | NPI_GEMM_RESERVE_CUS(reserve_cus)
     if ws is not None:
         fl |= NPI_GEMM_WORKSPACE_PREPARED
     else:

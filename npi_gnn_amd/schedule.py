@@ -38,6 +38,11 @@ class Schedule:
     #: the stand-in copy shares HBM with the light rows' GEMM), and on a node the collective's workgroups find no registers on a
     #: CU while the persistent GEMM workgroup (8 x 230 VGPRs) is resident, so the head start is not theirs to use (EXPERIMENTS A9)
     early_hub_gather: bool = False
+    #: CUs (a multiple of 8) the projection GEMMs of the sharded SAGE / GCN layers leave free when W > 1: a persistent GEMM whose
+    #: workgroup finds its CU held by a collective's kernel starts late with its full share of the tiles (a stand-in that holds 16
+    #: CUs: 0.107 -> 0.15 ms for a rank's 125 k rows; EXPERIMENTS A16).  0 until a node trace shows the collision: on one GPU,
+    #: where nothing holds a CU, 16 cost 16 / 256 more tiles per workgroup
+    gemm_reserve_cus: int = 0
     #: GATConv on the direct layout with the fused packed backward (needs ``direct_hub_rows``)
     gat_direct: bool = True
 
