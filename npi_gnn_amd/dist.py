@@ -795,7 +795,10 @@ class _ShardedSageFn(torch.autograd.Function):
                 # the light rows are complete on this rank: their projection runs while the hub rows are still on the wire
                 # (row-wise independent: the same numbers as one GEMM over all rows)
                 out = agg.new_empty((sg.n_local, weight.size(1)))
-                be.linear_fwd(agg[: sg.nL], weight, bias, out=out[: sg.nL], **kw)
+                kw_light = dict(kw)
+                if hasattr(be, "prepare_weight"):                  # this GEMM shares the chip with the reduce-scatter's kernel
+                    kw_light["reserve_cus"] = max(kw.get("reserve_cus", 0), sg.schedule.split_projection_reserve_cus)
+                be.linear_fwd(agg[: sg.nL], weight, bias, out=out[: sg.nL], **kw_light)
                 arrived()
                 be.linear_fwd(agg[sg.nL:], weight, bias, out=out[sg.nL:], **kw)
             else:

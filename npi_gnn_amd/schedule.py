@@ -43,6 +43,10 @@ class Schedule:
     #: CUs: 0.107 -> 0.15 ms for a rank's 125 k rows; EXPERIMENTS A16).  0 until a node trace shows the collision: on one GPU,
     #: where nothing holds a CU, 16 cost 16 / 256 more tiles per workgroup
     gemm_reserve_cus: int = 0
+    #: the light rows' projection of ``split_projection`` runs beside the reduce-scatter BY DESIGN, so it leaves this many CUs to
+    #: the collective's kernel whatever ``gemm_reserve_cus`` says (at W = 8 and C4 its 879 tiles are four rounds on 240 workgroups
+    #: as on 256: free on one GPU)
+    split_projection_reserve_cus: int = 16
     #: GATConv on the direct layout with the fused packed backward (needs ``direct_hub_rows``)
     gat_direct: bool = True
 

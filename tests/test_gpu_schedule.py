@@ -30,7 +30,8 @@ def test_no_environment_switch_selects_a_path():
     assert seen <= allowed, seen - allowed
     fields = set(Schedule.__dataclass_fields__)
     assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "gat_scores_epilogue",
-                      "direct_hub_rows", "partial_stream", "split_projection", "gat_direct", "early_hub_gather", "gemm_reserve_cus"}
+                      "direct_hub_rows", "partial_stream", "split_projection", "gat_direct", "early_hub_gather", "gemm_reserve_cus",
+                      "split_projection_reserve_cus"}
     assert CONSERVATIVE == DEFAULT.but(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
                                        gat_rank2_epilogue=False)
 
@@ -75,7 +76,7 @@ def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
         assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max())
 
 
-_ALTS = [dict(direct_hub_rows=False), dict(partial_stream=False), dict(split_projection=False), dict(early_hub_gather=True), dict(gemm_reserve_cus=16),
+_ALTS = [dict(direct_hub_rows=False), dict(partial_stream=False), dict(split_projection=False), dict(early_hub_gather=True), dict(gemm_reserve_cus=16), dict(split_projection_reserve_cus=0),
          dict(gat_direct=False),
          dict(overlap_streams=False), dict(gat_rank2_epilogue=False), "conservative"]
 _SHARDED_CASES = [(k, a) for k in ("sage", "gat1") for a in _ALTS] + [("gcn", "conservative"), ("gcn", dict(direct_hub_rows=False)),
