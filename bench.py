@@ -901,6 +901,28 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
                  "hubs_gat": "GATConv (1 head), vertex cut with the cross-rank softmax"}
         for key, (ms, nnz, coll) in res.items():
             out[key] = virtual_summary(W, t1_gat if key == "hubs_gat" else t1_sage_ms, ms, nnz, coll, notes[key])
+    if "hubs_sage" in out and only is None:
+        # The same rank step with the exchanges EMULATED: in front of every stand-in copy a kernel that computes nothing holds 16
+        # CUs (64 KB of LDS each, as a collective's resident workgroups hold theirs) for 20 us + wire bytes per rank / B -- an
+        # estimate of the W-GPU step under two stated assumptions (the rate B a GPU sustains over its xGMI links for these
+        # exchanges; the CUs RCCL's kernel sits on), NOT a measurement of xGMI.  Rank 0 only (the ranks are balanced to 1 %).
+        # (in a CHILD process: this one has created a dozen HIP streams by now, more than the hardware has queues, and a stand-in
+        # that holds its queue for hundreds of us then also holds whatever compute stream shares that queue)
+        emu = {"assumptions": {"latency_us_per_exchange": 20.0, "held_cus": 16, "what": "duration = latency + wire bytes per rank / B; "
+                               "a no-op kernel holds 16 CUs for it on the collective's stream"}, "by_wire_GBps": {}}
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "virtual_rank_probe.py"),
+                                 "--conv", "sage", "--steps", "30", "--wire-sweep", "800,400,200"], capture_output=True, text=True,
+                                timeout=300)
+            for l in cp.stdout.splitlines():
+                if l.startswith("emulated wire"):
+                    bw, ms = l.split()[2], float(l.split(":")[1].split("ms/step")[0])
+                    emu["by_wire_GBps"][bw] = {"rank0_ms": ms, "speedup_estimate": t1_sage_ms / ms}
+                elif " events " in l:
+                    emu["rank0_ms_no_wire"] = float(l.split("events")[1].split("ms/step")[0])
+        except Exception as e:                                  # noqa: BLE001 -- a side measurement
+            emu["error"] = f"{type(e).__name__}: {e}"[:300]
+        out["hubs_sage"]["emulated_wire"] = emu
     if "hubs_gat" in out and W == 8 and (N, E, F) == (1_000_000, 20_000_000, 256):
         # the GATConv rank step is ~110 launches of a few us: eager it is bounded by the HOST and moves with the box's CPU
         # (1.7-2.2 ms).  Its GPU time: rank 0's step replayed from a HIP graph, stand-in copies on the compute stream (capture with

@@ -323,3 +323,29 @@ extern "C" int npi_permute_f32(const float* src, const int32_t* index, int64_t n
     permute_f32_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(src, index, n, fill, dst);
     return check_launch("npi_permute_f32");
 }
+
+// ---- measurement support: a stand-in for a collective's RESIDENT kernel ----------------------------------------------------
+// `workgroups` workgroups that each hold 64 KB of a CU's LDS (no 152 KB GEMM workgroup fits beside one) for `nanoseconds` of
+// wall-clock time (wall_clock64: 100 MHz).  npi_gnn_amd.virtual.StubCollectives launches it on its copy stream to give a
+// one-GPU run of a rank's step the duration of an exchange over xGMI and the CUs RCCL's kernel would sit on (bench.py,
+// C4_w8_virtual.hubs_sage.emulated_wire); tools/occupy_probe.py times a GEMM beside it.  Computes nothing.
+namespace npi {
+__global__ void __launch_bounds__(256) hold_cus_kernel(long long ticks) {
+    __shared__ int hold[16384];
+    volatile int* h = hold;                            // volatile: the 64 KB stay allocated although nothing is computed with them
+    h[threadIdx.x] = (int)threadIdx.x;
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    h[16383 - threadIdx.x] = h[(threadIdx.x * 7) & 255];
+}
+}  // namespace npi
+extern "C" int npi_hold_cus(int workgroups, int64_t nanoseconds, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(workgroups >= 0 && workgroups <= 256 && nanoseconds >= 0 && nanoseconds <= 100000000,
+                "npi_hold_cus: 0..256 workgroups, at most 100 ms");
+    if (workgroups == 0 || nanoseconds == 0) return NPI_OK;
+    npi::hold_cus_kernel<<<(unsigned)workgroups, 256, 0, stream>>>((long long)(nanoseconds / 10));
+    return check_launch("npi_hold_cus");
+}
+

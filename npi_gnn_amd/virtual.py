@@ -130,10 +130,22 @@ class StubCollectives(_Patched):
     on the wire per rank (an all-gather / reduce-scatter of S bytes moves S (W-1)/W per rank, an all-reduce 2 S (W-1)/W).
     ``copy_stream``: run the stand-in copies on that HIP stream with event edges where RCCL's own stream would sit (the
     collective is issued when its input is ready on the compute stream, ``wait()`` makes the compute stream wait for it) --
-    the dependency graph of the real run; None: plain copies on the compute stream."""
+    the dependency graph of the real run; None: plain copies on the compute stream.
+    ``wire_gbps``: EMULATE the exchange's duration and footprint as well -- in front of every stand-in copy a kernel that
+    computes nothing holds ``held_cus`` CUs (``npi_hold_cus``: 64 KB of LDS each, as a collective's resident workgroups hold
+    theirs) for ``latency_us`` + wire bytes per rank / ``wire_gbps``.  What comes out is an estimate under those two stated
+    assumptions, not a measurement of xGMI."""
 
-    def __init__(self, W: int, copy_stream: "torch.cuda.Stream | None" = None):
+    def __init__(self, W: int, copy_stream: "torch.cuda.Stream | None" = None, wire_gbps: "float | None" = None,
+                 held_cus: int = 16, latency_us: float = 20.0):
         self.W, self.log, self.copy_stream = int(W), {}, copy_stream
+        self.wire_gbps, self.held_cus, self.latency_us = wire_gbps, int(held_cus), float(latency_us)
+
+    def _hold(self, wire_bytes: float, dev) -> None:
+        if self.wire_gbps:
+            from ._lib import check, load, stream_ptr
+            ns = int(self.latency_us * 1e3 + wire_bytes / self.wire_gbps)          # bytes / (GB/s) = ns
+            check(load().npi_hold_cus(self.held_cus, ns, stream_ptr(dev)), "npi_hold_cus")
 
     def note(self, kind, nbytes, wire):
         e = self.log.setdefault(kind, {"calls": 0, "payload_bytes": 0, "wire_bytes_per_rank": 0})
@@ -141,15 +153,17 @@ class StubCollectives(_Patched):
         e["payload_bytes"] += nbytes
         e["wire_bytes_per_rank"] += wire
 
-    def _issue(self, fn, tensors, async_op):
+    def _issue(self, fn, tensors, async_op, wire_bytes: float = 0.0):
         """run ``fn`` (the stand-in copy) where the collective would run"""
         cs = self.copy_stream
         if cs is None:
+            self._hold(wire_bytes, tensors[0].device)
             fn()
             return _Done() if async_op else None
         cur = torch.cuda.current_stream(cs.device)
         cs.wait_stream(cur)                               # inputs are ready on the issuing stream
         with torch.cuda.stream(cs):
+            self._hold(wire_bytes, cs.device)
             fn()
         for t in tensors:
             t.record_stream(cs)
@@ -173,12 +187,12 @@ class StubCollectives(_Patched):
         def ag(block, out, w, group=None, async_op=False):
             nb = out.numel() * out.element_size()
             me.note("all_gather", nb, nb * frac)
-            return me._issue(lambda: out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1)), (block, out), async_op)
+            return me._issue(lambda: out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1)), (block, out), async_op, nb * frac)
 
         def rs(part_sums, out, rank, w, group=None, async_op=False):
             nb = part_sums.numel() * part_sums.element_size()
             me.note("reduce_scatter", nb, nb * frac)
-            return me._issue(lambda: out.copy_(part_sums.view(w, -1)[rank].view_as(out)), (part_sums, out), async_op)
+            return me._issue(lambda: out.copy_(part_sums.view(w, -1)[rank].view_as(out)), (part_sums, out), async_op, nb * frac)
 
         def ar(t, w, group=None, op=None, tag="all_reduce"):
             nb = t.numel() * t.element_size()

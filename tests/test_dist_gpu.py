@@ -383,3 +383,43 @@ def test_eight_virtual_ranks_at_a_quarter_of_c4_match_the_single_gpu_layer(dev, 
     assert float((part.unshard(dxs) - ref_dx).abs().max()) <= 1e-5 * sx
     for dw in dws:
         assert float((dw - ref_dw).abs().max()) <= 1e-4 * float(ref_dw.abs().max())
+
+
+@pytest.mark.gpu
+def test_emulated_wire_holds_cus_for_the_stated_time_and_changes_no_result(dev):
+    """StubCollectives(wire_gbps=): every stand-in exchange is preceded by a no-op kernel that holds CUs for latency + wire bytes /
+    rate (npi_hold_cus) -- the layer's numbers are those of the plain stand-ins, a rank's step gets longer by about the wire time
+    that is not hidden, and npi_hold_cus itself lasts what it is asked to."""
+    import time
+    from npi_gnn_amd import dist as ND
+    from npi_gnn_amd._lib import check, load, stream_ptr
+    from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
+    from npi_gnn_amd.virtual import StubCollectives
+    check(load().npi_hold_cus(16, 1_000, stream_ptr(dev)), "npi_hold_cus")             # (the first launch uploads the kernel)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); check(load().npi_hold_cus(16, 300_000, stream_ptr(dev)), "npi_hold_cus"); e1.record()
+    torch.cuda.synchronize()
+    assert 0.29 <= e0.elapsed_time(e1) <= 0.6
+    N, E, F, W = 200_000, 4_000_000, 128, 4
+    ei = bipartite_edge_index(N, E, seed=5).to(dev)
+    g = torch.Generator().manual_seed(1)
+    Wm, b = (torch.randn(F, F, generator=g) / F ** 0.5).to(dev), torch.randn(F, generator=g).to(dev)
+    res = {}
+    for bw in (None, 50.0):
+        with StubCollectives(W, copy_stream=torch.cuda.Stream(device=dev), wire_gbps=bw) as stub:
+            sg = ND.ShardedGraph(ei, N, 1, W, dev, hub_mask=protein_mask(N).to(dev))
+            layer = ND.ShardedSAGELayer(sg, Wm, b)
+            x = torch.randn(sg.n_local, F, device=dev, generator=torch.Generator(device=dev).manual_seed(2)).requires_grad_(True)
+            go = torch.ones(sg.n_local, F, device=dev)
+            for _ in range(3):
+                layer.zero_grad(); x.grad = None
+                out = layer(x); out.backward(go)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5):
+                layer.zero_grad(); x.grad = None
+                out = layer(x); out.backward(go)
+            torch.cuda.synchronize()
+            res[bw] = (out.detach().clone(), x.grad.clone(), (time.perf_counter() - t0) / 5)
+    assert torch.equal(res[None][0], res[50.0][0]) and torch.equal(res[None][1], res[50.0][1])
+    assert res[50.0][2] > res[None][2] + 1e-4                      # four exchanges of ~7.7 MB at 50 GB/s + latency: >= 0.3 ms more

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--capture", action="store_true")
     ap.add_argument("--inline-copies", action="store_true", help="stand-in copies on the compute stream (default: their own stream)")
+    ap.add_argument("--wire-gbps", type=float, default=0.0, help="emulate the exchanges: hold CUs for latency + wire bytes / this rate")
+    ap.add_argument("--held-cus", type=int, default=16)
+    ap.add_argument("--wire-sweep", default="", help="comma-separated rates: after the plain run, one emulated run per rate (one line each)")
     ap.add_argument("--sched", default="", help="Schedule overrides, e.g. 'split_projection=False,partial_stream=False'")
     a = ap.parse_args()
     from npi_gnn_amd import dist as ND
@@ -32,7 +35,8 @@ def main():
     N, E, F, W, r = a.nodes, a.edges, a.hidden, a.world, a.rank
 
     from npi_gnn_amd.virtual import StubCollectives
-    stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev))
+    stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev),
+                           wire_gbps=a.wire_gbps or None, held_cus=a.held_cus)
     stub.__enter__()                                       # for the life of the process
     ei = bipartite_edge_index(N, E, seed=20260310).to(dev)
     g = torch.Generator().manual_seed(3)
@@ -78,6 +82,16 @@ def main():
     t_wall = (time.perf_counter() - t0) / a.steps * 1e3
     print(f"world {W} rank {r} {a.partition} {a.conv}: n_local {sg.n_local} entries {sg.local_nnz}  wall {t_wall:.3f} ms/step, "
           f"events {e0.elapsed_time(e1) / a.steps:.3f} ms/step, host issue {t_host:.3f} ms/step, capture={a.capture}")
+    for bw in [float(v) for v in a.wire_sweep.split(",") if v]:
+        stub.wire_gbps = bw
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        torch.cuda.synchronize()
+        print(f"emulated wire {bw:g} GB/s, {a.held_cus} CUs held: {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms/step")
 
 
 if __name__ == "__main__":
