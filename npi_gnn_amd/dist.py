@@ -1117,8 +1117,10 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         else:
             h = be.linear_fwd(x_own, weight, None)
             a_dst, a_src = be.gat_scores(h, att2, H, C)                            # [n_local, H] each
-        tbl_h, g_work = gather_hub(sg, h, async_op=True)                           # big: hub rows of h
+        # the small exchange FIRST: collectives of one communicator run in issue order, and behind the 0.4 GB table of hub rows
+        # this one -- which the partial chain below starts from -- would wait for all of it
         hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))               # small
+        tbl_h, g_work = gather_hub(sg, h, async_op=True)                           # big: hub rows of h
         tbl_a_dst, tbl_a_src = hub_sc[:, :H].contiguous(), hub_sc[:, H:].contiguous()
         # hub rows: this rank's share -- its light sources and the loops of the hubs it owns; needs nothing of tbl_h, so the
         # whole chain (statistics, MAX all-reduce, aggregation, reduce-scatters) runs on the partial stream beside the light rows
@@ -1142,18 +1144,22 @@ class _ShardedGatDirectFn(torch.autograd.Function):
             empty, neg, ones, zeros = const
             M = torch.where(empty, neg, mB)
             _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
+            # the partial denominators go on the wire BEFORE the aggregation is even launched: small, and not behind the 0.4 GB of U
+            S = torch.where(empty, zeros, sB * torch.exp(mB - M))
+            wS = None
+            if not _solo(W):
+                s_own = S.new_empty((hp, H))
+                wS = reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.group, async_op=True)
             if H == 1:
                 U = be.gat_aggregate_scores(B, h, None, C, eB, M, ones)            # sum exp(e - M) h_j, not normalised
             else:
                 U = be.gat_aggregate(B, h, None, H, C, tbl_a_dst, a_src, M, ones, slope, False)
-            S = torch.where(empty, zeros, sB * torch.exp(mB - M))
             if _solo(W):
                 hU.copy_(U)
                 s_own = S
             else:
                 wU = reduce_scatter_rows(U, hU, sg.rank, W, sg.group, async_op=True)
-                s_own = S.new_empty((hp, H))
-                _wait(reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.group, async_op=True), "fwd_reduce_scatter_s", s_own)
+                _wait(wS, "fwd_reduce_scatter_s", s_own)
         # light rows: the whole softmax is local once the hub table is here
         tbl_a_src_full = torch.cat([tbl_a_src, a_src])                             # index space of A's columns
         if H == 1:
@@ -1198,8 +1204,8 @@ class _ShardedGatDirectFn(torch.autograd.Function):
             D, db = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, H, C), (be.colsum(dO) if want_db else None)
         if db is not None:
             _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
+        tbl_D, _ = gather_hub(sg, D)                                               # small, first (see forward)
         tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                         # big: hub rows of dOut
-        tbl_D, _ = gather_hub(sg, D)
         # packed per-TARGET scalars (a_dst, m, 1 / s, D): the own rows, and the hub table (targets of the light sources)
         # (one table [hub table ; own rows], the index space of A^T's columns; B^T's columns are the own rows)
         n_tbl = tbl_a_dst.numel()
