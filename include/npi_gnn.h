@@ -165,8 +165,10 @@ int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fil
  * dz[r, c] = y[r, c] > 0 ? dy[r, c] : 0 over M rows of F floats, y = the layer's (post-ReLU) output. */
 /* Measurement support (no reference counterpart): `workgroups` workgroups that each hold 64 KB of a CU's LDS for `nanoseconds` --
  * a stand-in for the resident kernel of a collective, launched by npi_gnn_amd.virtual.StubCollectives beside a rank's step so
- * that a one-GPU run has the duration of an exchange and the CUs it sits on.  Computes nothing; <= 256 workgroups, <= 100 ms. */
-int npi_hold_cus(int workgroups, int64_t nanoseconds, void* stream);
+ * that a one-GPU run has the duration of an exchange and the CUs it sits on.  `start_word` (device memory, ZERO before the
+ * launch; may be null): the time runs from the moment the first workgroup got a CU -- one that waited for a wave slot leaves
+ * with the others; null: every workgroup times its own start.  Computes nothing; <= 256 workgroups, <= 100 ms. */
+int npi_hold_cus(int workgroups, int64_t nanoseconds, uint64_t* start_word, void* stream);
 int npi_relu_backward(const float* dy, int64_t ldd, const float* y, int64_t ldy, int64_t M, int64_t F, float* dz, int64_t ldz,
                       void* stream);
 

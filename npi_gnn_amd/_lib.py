@@ -66,7 +66,7 @@ PROTOTYPES = {
     "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
     "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
     "npi_linear_prepare": (c_int, [_P, _I, _I, _I, c_int, c_int, _P, _I, _P]),
-    "npi_hold_cus": (c_int, [c_int, _I, _P]),
+    "npi_hold_cus": (c_int, [c_int, _I, _P, _P]),
     "npi_linear_fwd_scores_supported": (c_int, [_I, _I, _I]),
     "npi_linear_fwd_scores": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "npi_linear_bwd_data_rank2_supported": (c_int, [_I, _I, _I]),

@@ -330,22 +330,33 @@ extern "C" int npi_permute_f32(const float* src, const int32_t* index, int64_t n
 // one-GPU run of a rank's step the duration of an exchange over xGMI and the CUs RCCL's kernel would sit on (bench.py,
 // C4_w8_virtual.hubs_sage.emulated_wire); tools/occupy_probe.py times a GEMM beside it.  Computes nothing.
 namespace npi {
-__global__ void __launch_bounds__(256) hold_cus_kernel(long long ticks) {
-    __shared__ int hold[16384];
-    volatile int* h = hold;                            // volatile: the 64 KB stay allocated although nothing is computed with them
+__global__ void __launch_bounds__(256) hold_cus_kernel(long long ticks, unsigned long long* __restrict__ start_word) {
+    __shared__ int h[16384];                           // 64 KB that nothing is computed with (kept alive by the asm at the end)
+    __shared__ long long t0_s;
     h[threadIdx.x] = (int)threadIdx.x;
+    if (threadIdx.x == 0) {
+        long long t0 = wall_clock64();
+        if (start_word != nullptr) {
+            // the exchange lasts `ticks` from the moment its FIRST workgroup got a CU: a workgroup that had to wait for a wave
+            // slot joins late and leaves with the others (each timing its own start would stretch the kernel by the wait)
+            const unsigned long long old = atomicCAS(start_word, 0ull, (unsigned long long)t0);
+            if (old != 0ull) t0 = (long long)old;
+        }
+        t0_s = t0;
+    }
     __syncthreads();
-    const long long t0 = wall_clock64();
+    const long long t0 = t0_s;
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
-    h[16383 - threadIdx.x] = h[(threadIdx.x * 7) & 255];
+    asm volatile("; keep %0" :: "v"(h[(threadIdx.x * 7) & 255]));
 }
 }  // namespace npi
-extern "C" int npi_hold_cus(int workgroups, int64_t nanoseconds, void* stream_) {
+extern "C" int npi_hold_cus(int workgroups, int64_t nanoseconds, uint64_t* start_word, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(workgroups >= 0 && workgroups <= 256 && nanoseconds >= 0 && nanoseconds <= 100000000,
                 "npi_hold_cus: 0..256 workgroups, at most 100 ms");
     if (workgroups == 0 || nanoseconds == 0) return NPI_OK;
-    npi::hold_cus_kernel<<<(unsigned)workgroups, 256, 0, stream>>>((long long)(nanoseconds / 10));
+    npi::hold_cus_kernel<<<(unsigned)workgroups, 256, 0, stream>>>((long long)(nanoseconds / 10),
+                                                                  reinterpret_cast<unsigned long long*>(start_word));
     return check_launch("npi_hold_cus");
 }
 

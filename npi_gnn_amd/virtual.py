@@ -145,7 +145,12 @@ class StubCollectives(_Patched):
         if self.wire_gbps:
             from ._lib import check, load, stream_ptr
             ns = int(self.latency_us * 1e3 + wire_bytes / self.wire_gbps)          # bytes / (GB/s) = ns
-            check(load().npi_hold_cus(self.held_cus, ns, stream_ptr(dev)), "npi_hold_cus")
+            words = getattr(self, "_words", None)
+            if words is None or self._next >= words.numel():
+                words = self._words = torch.zeros(1 << 16, dtype=torch.int64, device=dev)   # one zeroed start word per exchange
+                self._next = 0
+            check(load().npi_hold_cus(self.held_cus, ns, words.data_ptr() + 8 * self._next, stream_ptr(dev)), "npi_hold_cus")
+            self._next += 1
 
     def note(self, kind, nbytes, wire):
         e = self.log.setdefault(kind, {"calls": 0, "payload_bytes": 0, "wire_bytes_per_rank": 0})
@@ -197,6 +202,8 @@ class StubCollectives(_Patched):
         def ar(t, w, group=None, op=None, tag="all_reduce"):
             nb = t.numel() * t.element_size()
             me.note("all_reduce", nb, 2 * nb * frac)
+            if me.wire_gbps:                              # emulated wire: it takes its turn on the collectives' stream and the caller waits
+                me._issue(lambda: None, (t,), False, 2 * nb * frac)
 
         self._install(ag, rs, ar)
         return self

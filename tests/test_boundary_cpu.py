@@ -126,7 +126,7 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         # round 4: the row-dot epilogue serves one column tile (N = 128 / 256) only; the preparation launch wants K, N % 16 == 0
         "npi_linear_fwd_scores": lambda: lib.npi_linear_fwd_scores(16, 256, 16, 192, 16, 16, 192, 16, 16, 1000, 256, 192, N, 0, N),
         "npi_linear_prepare": lambda: lib.npi_linear_prepare(16, 256, 178, 128, 3, 0, 16, 1 << 20, N),
-        "npi_hold_cus": lambda: lib.npi_hold_cus(1000, 10, N),
+        "npi_hold_cus": lambda: lib.npi_hold_cus(1000, 10, N, N),
         "npi_gat_edge_grad_ex": lambda: lib.npi_gat_edge_grad_ex(N, N, N, 4, 16, N, 4, N, 0, N, 4, 0, 4, N, N, N, N, N, 0.2, 1, N, N, N),
     }
     for name, call in calls.items():

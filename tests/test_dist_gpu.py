@@ -395,10 +395,10 @@ def test_emulated_wire_holds_cus_for_the_stated_time_and_changes_no_result(dev):
     from npi_gnn_amd._lib import check, load, stream_ptr
     from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
     from npi_gnn_amd.virtual import StubCollectives
-    check(load().npi_hold_cus(16, 1_000, stream_ptr(dev)), "npi_hold_cus")             # (the first launch uploads the kernel)
+    check(load().npi_hold_cus(16, 1_000, None, stream_ptr(dev)), "npi_hold_cus")             # (the first launch uploads the kernel)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); check(load().npi_hold_cus(16, 300_000, stream_ptr(dev)), "npi_hold_cus"); e1.record()
+    e0.record(); check(load().npi_hold_cus(16, 300_000, None, stream_ptr(dev)), "npi_hold_cus"); e1.record()
     torch.cuda.synchronize()
     assert 0.29 <= e0.elapsed_time(e1) <= 0.6
     N, E, F, W = 200_000, 4_000_000, 128, 4

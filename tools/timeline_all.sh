@@ -26,4 +26,5 @@ W=${2:-vsage,vgat,gat1}
 [[ $W == *c1g* ]] && run c1g 50 python3 "$ROOT/tools/c13_probe.py" c1
 [[ $W == *gath8* ]] && run gath8 40 python3 "$ROOT/tools/gat_heads_probe.py" 8 3
 [[ $W == *gath2* ]] && run gath2 40 python3 "$ROOT/tools/gat_heads_probe.py" 2 3
+[[ $W == *vsw4* ]] && run vsw4 70 python3 "$ROOT/tools/virtual_rank_probe.py" --conv sage --steps 6 --wire-gbps 400
 true
