@@ -392,6 +392,30 @@ def _stack_forward(kind, weights, x, graph, dtype=torch.float32, norm=None):
     return h.float().cpu()
 
 
+def emulated_wire(probe_args, t1_ms, timeout=300):
+    """tools/virtual_rank_probe.py in a CHILD process: rank 0's step of one sharded layer with the exchanges emulated at 800 /
+    400 / 200 GB/s (see virtual.StubCollectives(wire_gbps=)); the small exchanges on their own lane (ShardedGraph(small_group=)),
+    as the N > 1 run of this file has them"""
+    emu = {"assumptions": {"latency_us_per_exchange": 20.0, "held_cus": 16, "what": "duration = latency + wire bytes per rank / B; "
+                           "a no-op kernel holds 16 CUs for it on the communicator's stream; two communicators (small exchanges "
+                           "on their own)"}, "by_wire_GBps": {}}
+    try:
+        cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "virtual_rank_probe.py")]
+                            + list(probe_args) + ["--two-lanes", "--wire-sweep", "800,400,200"], capture_output=True, text=True,
+                            timeout=timeout)
+        for l in cp.stdout.splitlines():
+            if l.startswith("emulated wire"):
+                bw, ms = l.split()[2], float(l.split(":")[1].split("ms/step")[0])
+                emu["by_wire_GBps"][bw] = {"rank0_ms": ms, "speedup_estimate": t1_ms / ms}
+            elif " events " in l:
+                emu["rank0_ms_no_wire"] = float(l.split("events")[1].split("ms/step")[0])
+        if not emu["by_wire_GBps"]:
+            emu["error"] = (cp.stderr or cp.stdout)[-300:]
+    except Exception as e:                                  # noqa: BLE001 -- a side measurement
+        emu["error"] = f"{type(e).__name__}: {e}"[:300]
+    return emu
+
+
 def virtual_c5(dev, ei5, N5, F5, weights, att, t1_ms, W, ref=None):
     """configs[4] in its 8-GPU form on ONE GPU: every rank's 3-layer step timed alone (collectives = stand-in copies), and --
     ``ref`` = (x, go, out, dX, per-layer parameter gradients) of the single-GPU stack -- the same 8 ranks run once more in
@@ -725,6 +749,12 @@ def run_configs(dev, args, c4):
                 except Exception as e:
                     res5["w8_virtual"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             del ei5, ref, x5
+            torch.cuda.empty_cache()
+            if args.virtual_world == 8 and "error" not in res5.get("w8_virtual", {"error": 1}):
+                # ONE GATConv layer of this size on rank 0 of 8 with the exchanges emulated (the child builds its own graph of the
+                # same shape); the single-GPU figure beside it is a third of the 3-layer step
+                res5["w8_virtual"]["emulated_wire_one_layer"] = emulated_wire(
+                    ["--conv", "gat", "--nodes", str(N5), "--edges", str(E5), "--steps", "10"], ms / 3, timeout=600)
             return res5
         guarded("C5_1gpu", c5)
     return out
@@ -908,21 +938,7 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
         # exchanges; the CUs RCCL's kernel sits on), NOT a measurement of xGMI.  Rank 0 only (the ranks are balanced to 1 %).
         # (in a CHILD process: this one has created a dozen HIP streams by now, more than the hardware has queues, and a stand-in
         # that holds its queue for hundreds of us then also holds whatever compute stream shares that queue)
-        emu = {"assumptions": {"latency_us_per_exchange": 20.0, "held_cus": 16, "what": "duration = latency + wire bytes per rank / B; "
-                               "a no-op kernel holds 16 CUs for it on the collective's stream"}, "by_wire_GBps": {}}
-        try:
-            cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "virtual_rank_probe.py"),
-                                 "--conv", "sage", "--steps", "30", "--wire-sweep", "800,400,200"], capture_output=True, text=True,
-                                timeout=300)
-            for l in cp.stdout.splitlines():
-                if l.startswith("emulated wire"):
-                    bw, ms = l.split()[2], float(l.split(":")[1].split("ms/step")[0])
-                    emu["by_wire_GBps"][bw] = {"rank0_ms": ms, "speedup_estimate": t1_sage_ms / ms}
-                elif " events " in l:
-                    emu["rank0_ms_no_wire"] = float(l.split("events")[1].split("ms/step")[0])
-        except Exception as e:                                  # noqa: BLE001 -- a side measurement
-            emu["error"] = f"{type(e).__name__}: {e}"[:300]
-        out["hubs_sage"]["emulated_wire"] = emu
+        out["hubs_sage"]["emulated_wire"] = emulated_wire(["--conv", "sage", "--steps", "30"], t1_sage_ms)
     if "hubs_gat" in out and W == 8 and (N, E, F) == (1_000_000, 20_000_000, 256):
         # the GATConv rank step is ~110 launches of a few us: eager it is bounded by the HOST and moves with the box's CPU
         # (1.7-2.2 ms).  Its GPU time: rank 0's step replayed from a HIP graph, stand-in copies on the compute stream (capture with
@@ -1021,11 +1037,18 @@ def main():
         seg_launch_bytes = [algorithmic_bytes(E, N, F)]
     else:
         from npi_gnn_amd import dist as ND
+        from npi_gnn_amd.schedule import CONSERVATIVE, DEFAULT
         from npi_gnn_amd.synth import protein_mask
         t0 = time.time()
         # every rank ships only ITS slice of the edge list to its GPU; the partitioner routes the edges (dist.route_edges)
         ei_mine = ei[:, rank * E // world: (rank + 1) * E // world] if world > 1 else ei
         att_full = torch.randn(1, 1, 2 * F, generator=g) * 0.1
+        # a second communicator for the small exchanges (per-row scalars, the softmax's MAX, parameter-gradient sums): on the main
+        # one they would queue behind the hub-row tables issued before them (ShardedGraph(small_group=))
+        small_group = None
+        if world > 1:
+            import torch.distributed as dist
+            small_group = dist.new_group()
 
         def build_sharded(schedule):
             if args.partition == "edges":
@@ -1034,7 +1057,8 @@ def main():
                 x_ = x_full.to(dev).requires_grad_(True)        # x is REPLICATED in this split
                 return sg_, layer_, x_, sg_.shard(go_full).to(dev), [algorithmic_bytes(sg_.local_nnz, N, F)]
             sg_ = ND.ShardedGraph(ei_mine, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None,
-                                  sliced=world > 1, schedule=schedule)
+                                  sliced=world > 1, schedule=schedule,
+                                  small_group=None if schedule is CONSERVATIVE else small_group)
             layer_ = {"sage": ND.ShardedSAGELayer, "gcn": ND.ShardedGCNLayer}[args.conv](sg_, W.to(dev), bias.to(dev)) \
                 if args.conv != "gat" else ND.ShardedGATLayer(sg_, W.to(dev), att_full.to(dev), bias.to(dev))
             x_ = sg_.shard(x_full).to(dev).requires_grad_(True)  # this rank's rows: its ncRNAs, then its proteins
@@ -1043,7 +1067,6 @@ def main():
             if sg_.B is not None:
                 nbytes.append(algorithmic_bytes(sg_.B.nnz_max, sg_.part.hub_rows, F) - sg_.part.hub_rows * F * 4)
             return sg_, layer_, x_, sg_.shard(go_full).to(dev), nbytes
-        from npi_gnn_amd.schedule import CONSERVATIVE, DEFAULT
         sg, layer, x, go, seg_launch_bytes = build_sharded(DEFAULT)
 
         def step():
@@ -1282,7 +1305,8 @@ def main():
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
                        "parallelism": parallelism(args, world), "hip_graph_replay": captured, "setup_steps": SETUP_STEPS,
                        "csr_build_s": round(t_build, 4), "fallback": fallback,
-                       "autotune": autotune if sharded else None},
+                       "autotune": autotune if sharded else None,
+                       "communicators": (2 if getattr(sg, "small_group", None) is not getattr(sg, "group", None) else 1) if sharded else None},
             "roofline": roof,
         }
         res.update(extra)

@@ -352,10 +352,15 @@ def reduce_scatter_rows(part_sums: torch.Tensor, out: torch.Tensor, rank: int, w
     return work if async_op else None
 
 
-def _all_reduce(t: torch.Tensor, world: int, group=None, op=None, tag: str = "all_reduce") -> None:
+def _all_reduce(t: torch.Tensor, world: int, group=None, op=None, tag: str = "all_reduce", async_op: bool = False):
+    """in place; ``async_op``: returns the pending work (None for one rank) -- the caller ``_wait``s before it reads ``t``"""
     if _solo(world):
-        return
-    _wait(dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group, async_op=True), tag, t)
+        return None
+    work = dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group, async_op=True)
+    if async_op:
+        return work
+    _wait(work, tag, t)
+    return None
 
 
 class HipBackend:
@@ -516,8 +521,11 @@ class ShardedGraph:
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, device,
                  backend=None, group=None, hub_mask: Optional[torch.Tensor] = None, sliced: bool = False,
-                 schedule: Schedule = DEFAULT):
-        """``schedule``: how the layers on this shard arrange their launches and collectives (``schedule.Schedule``: hub-row
+                 schedule: Schedule = DEFAULT, small_group=None):
+        """``small_group``: a SECOND communicator over the same ranks (``dist.new_group()``) for the step's small exchanges --
+        per-row scalars of the hub rows, the MAX of the softmax, parameter-gradient sums.  Collectives of one communicator
+        run in issue order, so on ``group`` alone a 4-byte-per-row gather waits behind the 512-byte-per-row one issued before
+        it; None: everything on ``group``.  ``schedule``: how the layers on this shard arrange their launches and collectives (``schedule.Schedule``: hub-row
         layout, streams, split projection); the same on every rank.  ``sliced=True``: ``edge_index`` is THIS RANK'S slice of the edge list (the ranks' slices, in rank order, are
         the whole list); ``sliced=False``: the complete list, the same on every rank -- the rank then keeps only columns
         ``[rank E / W, (rank + 1) E / W)`` BEFORE anything moves to its GPU.  Either way the edges reach the ranks that
@@ -526,6 +534,7 @@ class ShardedGraph:
         share is cut out of it with masks -- the same entries in the same order (tests/test_dist_gloo.py)."""
         self.part = part = HubPartition(num_nodes, world, hub_mask, device)
         self.rank, self.world, self.group = rank, world, group
+        self.small_group = small_group if small_group is not None else group
         self.schedule = schedule
         self.nL, self.nH = part.n_light(rank), part.n_hub(rank)
         self.n_local = self.nL + self.nH
@@ -683,14 +692,15 @@ def _hub_block(sg: ShardedGraph, rows: torch.Tensor) -> torch.Tensor:
     return block.contiguous()
 
 
-def gather_hub(sg: ShardedGraph, rows: torch.Tensor, async_op: bool = False):
-    """all-gather of the hub rows of ``rows`` [n_local, K] -> ([hub_rows, K] rank-major, pending work or None)"""
+def gather_hub(sg: ShardedGraph, rows: torch.Tensor, async_op: bool = False, small: bool = False):
+    """all-gather of the hub rows of ``rows`` [n_local, K] -> ([hub_rows, K] rank-major, pending work or None); ``small``: on the
+    communicator of the small exchanges (``ShardedGraph.small_group``)"""
     part, W = sg.part, sg.world
     block = _hub_block(sg, rows)
     if _solo(W):
         return block, None                                         # one rank: the hub table IS its own hub block
     table = rows.new_empty((part.hub_rows,) + tuple(rows.shape[1:]))
-    work = all_gather_rows(block, table, W, sg.group, async_op=async_op)
+    work = all_gather_rows(block, table, W, sg.small_group if small else sg.group, async_op=async_op)
     return table, work
 
 
@@ -883,9 +893,9 @@ class _ShardedSageFn(torch.autograd.Function):
             else:
                 dx, _ = chain()
         if want_w:
-            _all_reduce(dw, sg.world, sg.group, tag="bwd_all_reduce_dw")
+            _all_reduce(dw, sg.world, sg.small_group, tag="bwd_all_reduce_dw")
             if db is not None:
-                _all_reduce(db, sg.world, sg.group, tag="bwd_all_reduce_db")
+                _all_reduce(db, sg.world, sg.small_group, tag="bwd_all_reduce_db")
         return dx, dw, db, None, None
 
 
@@ -917,14 +927,14 @@ class _ShardedGcnFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = be.colsum(grad_out)
-            _all_reduce(db, sg.world, sg.group, tag="bwd_all_reduce_db")
+            _all_reduce(db, sg.world, sg.small_group, tag="bwd_all_reduce_db")
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dxw, hsum, _ = _hub_aggregate(sg, grad_out, sg.At, sg.Bt, nrm["At"], nrm["Bt"], False, "bwd")
             if hsum is not None and sg.nH:
                 dxw[sg.nL:] += hsum[: sg.nH]
             if ctx.needs_input_grad[1]:
                 dw, _ = be.linear_bwd_weight(x_own, dxw, False)
-                _all_reduce(dw, sg.world, sg.group, tag="bwd_all_reduce_dw")
+                _all_reduce(dw, sg.world, sg.small_group, tag="bwd_all_reduce_dw")
             if ctx.needs_input_grad[0]:
                 dx = be.linear_bwd_data(dxw, weight, None)
         return dx, dw, db, None
@@ -954,7 +964,7 @@ class _ShardedGatFn(torch.autograd.Function):
         h = be.linear_fwd(x_own, weight, None)
         a_dst, a_src = be.gat_scores(h, att2, H, C)                              # [n_local, H] each
         tbl_h, g_work = gather_hub(sg, h, async_op=True)                          # big: hub rows of h
-        hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))              # small
+        hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1), small=True)              # small
         hub_a_dst, hub_a_src = hub_sc[:, :H].contiguous(), hub_sc[:, H:].contiguous()
         tbl_a_src = torch.cat([hub_a_src, a_src])                                 # index space of side A's columns
         mA, sA = be.gat_stats(sg.A, a_dst, tbl_a_src, H, slope)                   # every row holds its self loop
@@ -967,7 +977,7 @@ class _ShardedGatFn(torch.autograd.Function):
         else:
             M = torch.full((part.hub_rows, H), NEG, dtype=h.dtype, device=h.device)
         M[own] = torch.maximum(M[own], mA[nL:])
-        _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
+        _all_reduce(M, W, sg.small_group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
         ones_h = torch.ones((nH, H), dtype=h.dtype, device=h.device)
         m_own = torch.cat([mA[:nL], M[own]])
         _wait(g_work, "fwd_all_gather", tbl_h)
@@ -989,7 +999,7 @@ class _ShardedGatFn(torch.autograd.Function):
             res = (U.view(nH, H, C) / (S_tot.view(nH, H, 1) + 1e-16)).reshape(nH, H * C)
             out[nL:] = res + bias if bias is not None else res
         s_own = torch.cat([sA[:nL], S_tot])
-        hubS, _ = gather_hub(sg, s_own)                                           # the backward's per-target sums
+        hubS, _ = gather_hub(sg, s_own, small=True)                                           # the backward's per-target sums
         ctx.sg, ctx.H, ctx.C, ctx.slope = sg, H, C, float(slope)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x_own, weight, att2, h, a_dst, a_src, tbl_h, hub_a_dst, hub_a_src, M, hubS, m_own, s_own,
@@ -1008,10 +1018,10 @@ class _ShardedGatFn(torch.autograd.Function):
         db = None
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = be.colsum(dO)
-            _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
+            _all_reduce(db, W, sg.small_group, tag="bwd_all_reduce_db")
         D = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, H, C)          # [n_local, H]
         tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                        # big: hub rows of dOut
-        hubD, _ = gather_hub(sg, D)
+        hubD, _ = gather_hub(sg, D, small=True)
         # per-TARGET scalars in the index space of the two-part table [hub table ; own rows]
         tbl_a_dst = torch.cat([hub_a_dst, a_dst])
         tbl_m, tbl_s, tbl_D = torch.cat([hubM, m_own]), torch.cat([hubS, s_own]), torch.cat([hubD, D])
@@ -1046,11 +1056,11 @@ class _ShardedGatFn(torch.autograd.Function):
         datt = dw = dx = None
         if ctx.needs_input_grad[2]:
             datt = be.gat_att_grad(h, g_dst, g_src, H, C)
-            _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
+            _all_reduce(datt, W, sg.small_group, tag="bwd_all_reduce_datt")
             datt = datt.view(1, H, 2 * C)
         if ctx.needs_input_grad[1]:
             dw, _ = be.linear_bwd_weight(x_own, dh, False)
-            _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
+            _all_reduce(dw, W, sg.small_group, tag="bwd_all_reduce_dw")
         if ctx.needs_input_grad[0]:
             dx = be.linear_bwd_data(dh, weight, None)
         return dx, dw, datt, db, None, None, None
@@ -1119,7 +1129,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
             a_dst, a_src = be.gat_scores(h, att2, H, C)                            # [n_local, H] each
         # the small exchange FIRST: collectives of one communicator run in issue order, and behind the 0.4 GB table of hub rows
         # this one -- which the partial chain below starts from -- would wait for all of it
-        hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1))               # small
+        hub_sc, _ = gather_hub(sg, torch.cat([a_dst, a_src], dim=1), small=True)               # small
         tbl_h, g_work = gather_hub(sg, h, async_op=True)                           # big: hub rows of h
         tbl_a_dst, tbl_a_src = hub_sc[:, :H].contiguous(), hub_sc[:, H:].contiguous()
         # hub rows: this rank's share -- its light sources and the loops of the hubs it owns; needs nothing of tbl_h, so the
@@ -1143,13 +1153,13 @@ class _ShardedGatDirectFn(torch.autograd.Function):
                 sg._gat_const[H] = const
             empty, neg, ones, zeros = const
             M = torch.where(empty, neg, mB)
-            _all_reduce(M, W, sg.group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
+            _all_reduce(M, W, sg.small_group, op=dist.ReduceOp.MAX, tag="fwd_all_reduce_max")
             # the partial denominators go on the wire BEFORE the aggregation is even launched: small, and not behind the 0.4 GB of U
             S = torch.where(empty, zeros, sB * torch.exp(mB - M))
             wS = None
             if not _solo(W):
                 s_own = S.new_empty((hp, H))
-                wS = reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.group, async_op=True)
+                wS = reduce_scatter_rows(S.contiguous(), s_own, sg.rank, W, sg.small_group, async_op=True)
             if H == 1:
                 U = be.gat_aggregate_scores(B, h, None, C, eB, M, ones)            # sum exp(e - M) h_j, not normalised
             else:
@@ -1179,7 +1189,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         out = out_full[: nL + nH]
         m_own = torch.cat([mA, M[sg.own_hub]])
         s_all = torch.cat([sA, s_own[:nH]])
-        tbl_S, _ = gather_hub(sg, s_all)                                           # every rank needs S of the hub targets it holds
+        tbl_S, _ = gather_hub(sg, s_all, small=True)                                           # every rank needs S of the hub targets it holds
         ctx.sg, ctx.H, ctx.C, ctx.slope = sg, H, C, float(slope)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x_own, weight, att2, h, a_dst, a_src, tbl_h, tbl_a_dst, tbl_a_src, M, tbl_S, m_own, s_all, out,
@@ -1203,8 +1213,8 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         else:
             D, db = be.gat_rowdot(dO, out, bias if ctx.has_bias else None, H, C), (be.colsum(dO) if want_db else None)
         if db is not None:
-            _all_reduce(db, W, sg.group, tag="bwd_all_reduce_db")
-        tbl_D, _ = gather_hub(sg, D)                                               # small, first (see forward)
+            _all_reduce(db, W, sg.small_group, tag="bwd_all_reduce_db")
+        tbl_D, _ = gather_hub(sg, D, small=True)                                               # small, first (see forward)
         tbl_dO, g_work = gather_hub(sg, dO, async_op=True)                         # big: hub rows of dOut
         # packed per-TARGET scalars (a_dst, m, 1 / s, D): the own rows, and the hub table (targets of the light sources)
         # (one table [hub table ; own rows], the index space of A^T's columns; B^T's columns are the own rows)
@@ -1255,7 +1265,7 @@ class _ShardedGatDirectFn(torch.autograd.Function):
             g_hub = pg
         else:
             g_hub = pg.new_empty((hp, 2 * H))
-            _wait(reduce_scatter_rows(pg, g_hub, sg.rank, W, sg.group, async_op=True), "bwd_reduce_scatter_g", g_hub)
+            _wait(reduce_scatter_rows(pg, g_hub, sg.rank, W, sg.small_group, async_op=True), "bwd_reduce_scatter_g", g_hub)
             _wait(wh, "bwd_reduce_scatter", dh_full)
         g_dst = torch.cat([g_dst_l, g_hub[:nH, :H]])
         g_src = torch.cat([g_src_l, g_hub[:nH, H:]])
@@ -1269,22 +1279,27 @@ class _ShardedGatDirectFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 fw.join(dw)
             datt = be.gat_rank2_tail(P, weight, A2, dw, ctx.needs_input_grad[2])   # dW += P^T [a1; a2], d att = P W
+            # the parameter-gradient sums are on the wire while the dX GEMM runs
+            w_att = w_dw = None
             if datt is not None:
                 datt = datt.reshape(1, 2 * C)
-                _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
-                datt = datt.view(1, 1, 2 * C)
+                w_att = _all_reduce(datt, W, sg.small_group, tag="bwd_all_reduce_datt", async_op=True)
             if dw is not None:
-                _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
+                w_dw = _all_reduce(dw, W, sg.small_group, tag="bwd_all_reduce_dw", async_op=True)
             dx = be.linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
+            _wait(w_att, "bwd_all_reduce_datt", datt)
+            _wait(w_dw, "bwd_all_reduce_dw", dw)
+            if datt is not None:
+                datt = datt.view(1, 1, 2 * C)
             return dx, dw, datt, db, None, None, None
         be.gat_rank1_add(dh, g_dst, g_src, att2, H, C)                             # d h_j += g_dst[j] att[:C] + g_src[j] att[C:]
         if ctx.needs_input_grad[2]:
             datt = be.gat_att_grad(h, g_dst.contiguous(), g_src.contiguous(), H, C)
-            _all_reduce(datt, W, sg.group, tag="bwd_all_reduce_datt")
+            _all_reduce(datt, W, sg.small_group, tag="bwd_all_reduce_datt")
             datt = datt.view(1, H, 2 * C)
         if ctx.needs_input_grad[1]:
             dw, _ = be.linear_bwd_weight(x_own, dh, False)
-            _all_reduce(dw, W, sg.group, tag="bwd_all_reduce_dw")
+            _all_reduce(dw, W, sg.small_group, tag="bwd_all_reduce_dw")
         if ctx.needs_input_grad[0]:
             dx = be.linear_bwd_data(dh, weight, None)
         return dx, dw, datt, db, None, None, None

@@ -28,6 +28,11 @@ class _Done:
         return True
 
 
+# stands for ``ShardedGraph(small_group=)`` in a virtual world: ``StubCollectives`` runs the collectives issued on it on its
+# second stream (``copy_stream2``), as a second communicator runs its own in their own order
+SMALL_LANE = "small-lane"
+
+
 class _Patched:
     """swap dist's collective entry points while active; ``_solo`` is forced False so that a rank of a virtual world takes the
     same code path as a rank of a real one"""
@@ -96,11 +101,12 @@ class LockStep(_Patched):
             out.copy_(res.view(w, out.size(0), -1)[rank].view_as(out)) if res is not None else out.zero_()
             return _Done() if async_op else None
 
-        def all_reduce(t, w, group=None, op=None, tag=""):
+        def all_reduce(t, w, group=None, op=None, tag="", async_op=False):
             mx = op == tdist.ReduceOp.MAX
             res = me._collective(t, (lambda v: torch.stack(v).max(0)[0]) if mx else (lambda v: torch.stack(v).sum(0)))
             if res is not None:
                 t.copy_(res)
+            return _Done() if async_op else None
 
         self._install(all_gather_rows, reduce_scatter_rows, all_reduce)
         return self
@@ -137,8 +143,9 @@ class StubCollectives(_Patched):
     assumptions, not a measurement of xGMI."""
 
     def __init__(self, W: int, copy_stream: "torch.cuda.Stream | None" = None, wire_gbps: "float | None" = None,
-                 held_cus: int = 16, latency_us: float = 20.0):
+                 held_cus: int = 16, latency_us: float = 20.0, copy_stream2: "torch.cuda.Stream | None" = None):
         self.W, self.log, self.copy_stream = int(W), {}, copy_stream
+        self.copy_stream2 = copy_stream2                  # collectives issued on SMALL_LANE (None: the same stream as the rest)
         self.wire_gbps, self.held_cus, self.latency_us = wire_gbps, int(held_cus), float(latency_us)
 
     def _hold(self, wire_bytes: float, dev) -> None:
@@ -158,9 +165,9 @@ class StubCollectives(_Patched):
         e["payload_bytes"] += nbytes
         e["wire_bytes_per_rank"] += wire
 
-    def _issue(self, fn, tensors, async_op, wire_bytes: float = 0.0):
+    def _issue(self, fn, tensors, async_op, wire_bytes: float = 0.0, group=None):
         """run ``fn`` (the stand-in copy) where the collective would run"""
-        cs = self.copy_stream
+        cs = self.copy_stream2 if (group is SMALL_LANE and self.copy_stream2 is not None) else self.copy_stream
         if cs is None:
             self._hold(wire_bytes, tensors[0].device)
             fn()
@@ -192,18 +199,19 @@ class StubCollectives(_Patched):
         def ag(block, out, w, group=None, async_op=False):
             nb = out.numel() * out.element_size()
             me.note("all_gather", nb, nb * frac)
-            return me._issue(lambda: out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1)), (block, out), async_op, nb * frac)
+            return me._issue(lambda: out.view(w, -1).copy_(block.reshape(1, -1).expand(w, -1)), (block, out), async_op, nb * frac, group)
 
         def rs(part_sums, out, rank, w, group=None, async_op=False):
             nb = part_sums.numel() * part_sums.element_size()
             me.note("reduce_scatter", nb, nb * frac)
-            return me._issue(lambda: out.copy_(part_sums.view(w, -1)[rank].view_as(out)), (part_sums, out), async_op, nb * frac)
+            return me._issue(lambda: out.copy_(part_sums.view(w, -1)[rank].view_as(out)), (part_sums, out), async_op, nb * frac, group)
 
-        def ar(t, w, group=None, op=None, tag="all_reduce"):
+        def ar(t, w, group=None, op=None, tag="all_reduce", async_op=False):
             nb = t.numel() * t.element_size()
             me.note("all_reduce", nb, 2 * nb * frac)
-            if me.wire_gbps:                              # emulated wire: it takes its turn on the collectives' stream and the caller waits
-                me._issue(lambda: None, (t,), False, 2 * nb * frac)
+            if me.wire_gbps:                              # emulated wire: it takes its turn on its communicator's stream
+                return me._issue(lambda: None, (t,), async_op, 2 * nb * frac, group)
+            return _Done() if async_op else None
 
         self._install(ag, rs, ar)
         return self

@@ -207,12 +207,15 @@ def _worker(rank, world, port, N, E, Fd, kind, layer_kind, q):
     try:
         ei, x, W, b, go, hub = _case(N, E, Fd, kind)
         extra = ()
+        two = layer_kind.endswith("+2c")                        # the small exchanges on a communicator of their own
+        layer_kind = layer_kind[:-3] if two else layer_kind
         if layer_kind == "edges":
             sg = ND.EdgeShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend())
             layer = ND.EdgeShardedSAGELayer(sg, W, b)
             xl = x.clone().requires_grad_(True)                    # replicated input
         else:
-            sg = ND.ShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub)
+            sg = ND.ShardedGraph(ei, N, rank, world, torch.device("cpu"), backend=TorchBackend(), hub_mask=hub,
+                                 small_group=dist.new_group() if two else None)
             if layer_kind == "gcnN":                            # F_in > F_out: PyG's literal order (project, then aggregate)
                 W, b, go = W[:, : Fd // 2].contiguous(), b[: Fd // 2].contiguous(), go[:, : Fd // 2].contiguous()
             if layer_kind == "sage":
@@ -270,6 +273,8 @@ def _reference(layer_kind, ei, x, W, b, go, Fd):
     # fewer hubs than ranks (5 proteins, 8 ranks: three ranks own no hub row at all)
     (8, 40, "bipartite", "sage"), (8, 40, "bipartite", "gcn"), (8, 40, "bipartite", "gat1"),
     (3, 160, "bipartite", "gcnN"), (2, 101, "any", "gcnN"),
+    # ShardedGraph(small_group=): per-row scalars, the softmax's MAX and the parameter-gradient sums on a second communicator
+    (2, 203, "bipartite", "sage+2c"), (3, 160, "bipartite", "gat1+2c"), (2, 120, "auto", "gat4+2c"), (2, 203, "bipartite", "gcn+2c"),
 ])
 def test_sharded_layer_matches_single_process_oracle(world, N, kind, layer_kind):
     E, Fd = 900, 16
@@ -286,6 +291,7 @@ def test_sharded_layer_matches_single_process_oracle(world, N, kind, layer_kind)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    layer_kind = layer_kind[:-3] if layer_kind.endswith("+2c") else layer_kind
     ei, x, W, b, go, hub = _case(N, E, Fd, kind)
     ref = _reference(layer_kind, ei, x, W, b, go, Fd)
     ref_out, ref_dx, ref_dw, ref_db = ref[:4]

@@ -239,7 +239,9 @@ def _rccl_solo_worker(port, q):
         tags = sorted({t for t, _, _ in comm})
         stall_ms = [e0.elapsed_time(e1) for _, e0, e1 in comm]
         # GCN and GAT layers through the same real collectives (incl. the MAX all-reduce of the hub-row maxima)
-        sg = ND.ShardedGraph(ei, N, 0, 1, dev, hub_mask=protein_mask(N))
+        # ... with the small exchanges on a SECOND RCCL communicator (ShardedGraph(small_group=), as bench.py's N > 1 run)
+        sg = ND.ShardedGraph(ei, N, 0, 1, dev, hub_mask=protein_mask(N), small_group=dist.new_group())
+        assert sg.small_group is not sg.group
         att = _att(F, 2).to(dev)
         for kind in ("gcn", "gat"):
             if kind == "gcn":
@@ -422,4 +424,21 @@ def test_emulated_wire_holds_cus_for_the_stated_time_and_changes_no_result(dev):
             torch.cuda.synchronize()
             res[bw] = (out.detach().clone(), x.grad.clone(), (time.perf_counter() - t0) / 5)
     assert torch.equal(res[None][0], res[50.0][0]) and torch.equal(res[None][1], res[50.0][1])
+    # a GATConv rank step with its small exchanges on their own lane: the same numbers as on one lane, emulated wire or not
+    from npi_gnn_amd.virtual import SMALL_LANE
+    att = (torch.randn(1, 1, 2 * F, generator=g) * 0.1).to(dev)
+    gat = {}
+    for lanes, bw in ((1, None), (2, None), (2, 50.0)):
+        with StubCollectives(W, copy_stream=torch.cuda.Stream(device=dev), wire_gbps=bw,
+                             copy_stream2=torch.cuda.Stream(device=dev) if lanes == 2 else None):
+            sg = ND.ShardedGraph(ei, N, 1, W, dev, hub_mask=protein_mask(N).to(dev), small_group=SMALL_LANE if lanes == 2 else None)
+            layer = ND.ShardedGATLayer(sg, Wm, att, b)
+            x = torch.randn(sg.n_local, F, device=dev, generator=torch.Generator(device=dev).manual_seed(2)).requires_grad_(True)
+            for _ in range(2):
+                layer.zero_grad(); x.grad = None
+                out = layer(x); out.backward(torch.ones_like(out))
+            torch.cuda.synchronize()
+            gat[(lanes, bw)] = (out.detach().clone(), x.grad.clone(), layer.weight.grad.clone(), layer.att.grad.clone())
+    for key in ((2, None), (2, 50.0)):
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(gat[(1, None)], gat[key])), key
     assert res[50.0][2] > res[None][2] + 1e-4                      # four exchanges of ~7.7 MB at 50 GB/s + latency: >= 0.3 ms more

@@ -60,7 +60,8 @@ def _worker(rank, world, port, layer_kind, N, E, F, q):
             conv = npi.SAGEConv(F, F)
         else:
             hub = None if layer_kind == "rows" else protein_mask(N)
-            sg = ND.ShardedGraph(mine, N, rank, world, dev, hub_mask=hub, sliced=True)
+            sg = ND.ShardedGraph(mine, N, rank, world, dev, hub_mask=hub, sliced=True,
+                                 small_group=dist.new_group() if layer_kind in ("sage", "gat1") else None)   # two communicators, as bench.py
             rows = sg.own
             xl = sg.shard(x).to(dev).requires_grad_(True)
             if layer_kind in ("sage", "rows"):

@@ -80,11 +80,12 @@ val = {
     "V5C": f2(c["C5_1gpu"]["w8_virtual"]["compute_ceiling"]),
     "TAG": tag,
 }
-emu = v["hubs_sage"].get("emulated_wire", {}).get("by_wire_GBps", {})
-for bw in ("800", "400", "200"):
-    e = emu.get(bw) or emu.get(bw + ".0") or {}
-    val["E" + bw] = f2(e["rank0_ms"]) if e else "n/a"
-    val["E" + bw + "S"] = "%.1f" % e["speedup_estimate"] if e else "n/a"
+for key, emu in (("E", v["hubs_sage"].get("emulated_wire", {}).get("by_wire_GBps", {})),
+                 ("G", c["C5_1gpu"]["w8_virtual"].get("emulated_wire_one_layer", {}).get("by_wire_GBps", {}))):
+    for bw in ("800", "400", "200"):
+        e = emu.get(bw) or emu.get(bw + ".0") or {}
+        val[key + bw] = f2(e["rank0_ms"]) if e else "n/a"
+        val[key + bw + "S"] = "%.1f" % e["speedup_estimate"] if e else "n/a"
 src = open(os.path.join(root, "tools", "doc", "DESIGN.in.md")).read()
 missing = sorted(set(re.findall(r"@([A-Z0-9]+)@", src)) - set(val))
 if missing:

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--wire-gbps", type=float, default=0.0, help="emulate the exchanges: hold CUs for latency + wire bytes / this rate")
     ap.add_argument("--held-cus", type=int, default=16)
     ap.add_argument("--wire-sweep", default="", help="comma-separated rates: after the plain run, one emulated run per rate (one line each)")
+    ap.add_argument("--two-lanes", action="store_true", help="the small exchanges on a second communicator (ShardedGraph(small_group=))")
     ap.add_argument("--sched", default="", help="Schedule overrides, e.g. 'split_projection=False,partial_stream=False'")
     a = ap.parse_args()
     from npi_gnn_amd import dist as ND
@@ -34,9 +35,10 @@ def main():
     dev = torch.device("cuda:0")
     N, E, F, W, r = a.nodes, a.edges, a.hidden, a.world, a.rank
 
-    from npi_gnn_amd.virtual import StubCollectives
+    from npi_gnn_amd.virtual import SMALL_LANE, StubCollectives
     stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev),
-                           wire_gbps=a.wire_gbps or None, held_cus=a.held_cus)
+                           wire_gbps=a.wire_gbps or None, held_cus=a.held_cus,
+                           copy_stream2=torch.cuda.Stream(device=dev) if (a.two_lanes and not a.inline_copies) else None)
     stub.__enter__()                                       # for the life of the process
     ei = bipartite_edge_index(N, E, seed=20260310).to(dev)
     g = torch.Generator().manual_seed(3)
@@ -44,7 +46,8 @@ def main():
     b = ((torch.rand(F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
     from npi_gnn_amd.schedule import DEFAULT
     sch = DEFAULT.but(**eval("dict(" + a.sched + ")"))
-    sg = ND.ShardedGraph(ei, N, r, W, dev, hub_mask=protein_mask(N).to(dev) if a.partition == "hubs" else None, schedule=sch)
+    sg = ND.ShardedGraph(ei, N, r, W, dev, hub_mask=protein_mask(N).to(dev) if a.partition == "hubs" else None, schedule=sch,
+                         small_group=SMALL_LANE if a.two_lanes else None)
     del ei
     if a.conv == "sage":
         layer = ND.ShardedSAGELayer(sg, Wm, b)
