@@ -814,7 +814,7 @@ def sharded_parity(dev, args, world, sg, layer, x, go, ei, x_full, go_full, W, b
         err["out_rows_fp64_formula"] = float((out.detach()[pos].double() - want).abs().max() / want.abs().max())
     names = sorted(err)
     v = torch.tensor([err[k] for k in names], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or dist_is_up():
         import torch.distributed as dist
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
     err = {k: float(e) for k, e in zip(names, v.tolist())}
@@ -965,6 +965,11 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def dist_is_up() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def main():
     args = parse()
     world_env = os.environ.get("WORLD_SIZE")
@@ -983,10 +988,21 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NPI_BENCH_RCCL_SOLO=1 (with --force-sharded): a world of ONE through everything the N > 1 run goes through -- a real RCCL
+    # process group and the second communicator, every collective of the layer (dist.ALWAYS_COMMUNICATE), the set-up's
+    # candidates, the all-reduced timings -- the one-GPU box's rehearsal of the node run (tests/test_dist_rccl.py)
+    rccl = world > 1 or (args.force_sharded and os.environ.get("NPI_BENCH_RCCL_SOLO") == "1")
+    if rccl:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            from npi_gnn_amd import dist as _ND
+            _ND.ALWAYS_COMMUNICATE = True
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import npi_gnn_amd as npi
     from npi_gnn_amd import functional as NF
@@ -1046,11 +1062,11 @@ def main():
         # a second communicator for the small exchanges (per-row scalars, the softmax's MAX, parameter-gradient sums): on the main
         # one they would queue behind the hub-row tables issued before them (ShardedGraph(small_group=))
         small_group = None
-        if world > 1:
+        if rccl:
             import torch.distributed as dist
             small_group = dist.new_group()
 
-        def build_sharded(schedule):
+        def build_sharded(schedule, one_communicator=False):
             if args.partition == "edges":
                 sg_ = ND.EdgeShardedGraph(ei_mine, N, rank, world, dev, sliced=world > 1)
                 layer_ = ND.EdgeShardedSAGELayer(sg_, W.to(dev), bias.to(dev))
@@ -1058,7 +1074,7 @@ def main():
                 return sg_, layer_, x_, sg_.shard(go_full).to(dev), [algorithmic_bytes(sg_.local_nnz, N, F)]
             sg_ = ND.ShardedGraph(ei_mine, N, rank, world, dev, hub_mask=protein_mask(N) if args.partition == "hubs" else None,
                                   sliced=world > 1, schedule=schedule,
-                                  small_group=None if schedule is CONSERVATIVE else small_group)
+                                  small_group=None if (schedule is CONSERVATIVE or one_communicator) else small_group)
             layer_ = {"sage": ND.ShardedSAGELayer, "gcn": ND.ShardedGCNLayer}[args.conv](sg_, W.to(dev), bias.to(dev)) \
                 if args.conv != "gat" else ND.ShardedGATLayer(sg_, W.to(dev), att_full.to(dev), bias.to(dev))
             x_ = sg_.shard(x_full).to(dev).requires_grad_(True)  # this rank's rows: its ncRNAs, then its proteins
@@ -1089,7 +1105,7 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
         bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
-        if world > 1:
+        if rccl:
             import torch.distributed as dist
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if int(bad) != 0:
@@ -1099,29 +1115,30 @@ def main():
             sg, layer, x, go, seg_launch_bytes = build_sharded(CONSERVATIVE)      # an argument of the shard, no process-wide switch
         torch.cuda.synchronize()
         t_build = time.time() - t0
-        # Set-up, N > 1 only: two arrangements whose worth depends on what RCCL's kernels do beside ours -- nothing one GPU can
+        # Set-up, N > 1 only: three arrangements whose worth depends on what RCCL's kernels do beside ours -- nothing one GPU can
         # tell (EXPERIMENTS A9, A16): the projection GEMMs on 16 CUs fewer (a persistent GEMM whose workgroup finds its CU held
-        # by a collective starts late with its full share of tiles) and the hub rows of dAgg projected first.  Each candidate
+        # by a collective starts late with its full share of tiles) the hub rows of dAgg projected first, and every exchange on ONE communicator.  Each candidate
         # is built, run 5 + 2 x 8 steps between barriers (MAX over ranks), and the fastest becomes THE schedule of the timed region;
         # every rank takes the same decision from the same all-reduced numbers.  `config.autotune` lists what was measured.
         autotune = None
         if fallback is None and args.partition == "hubs" and args.conv in ("sage", "gcn") and not args.no_autotune and (
-                world > 1 or os.environ.get("NPI_BENCH_AUTOTUNE_SOLO") == "1"):
+                rccl or os.environ.get("NPI_BENCH_AUTOTUNE_SOLO") == "1"):
             cands = {"default": DEFAULT, "gemm_reserve_cus=16": DEFAULT.but(gemm_reserve_cus=16),
                      "early_hub_gather": DEFAULT.but(early_hub_gather=True),
-                     "gemm_reserve_cus=16,early_hub_gather": DEFAULT.but(gemm_reserve_cus=16, early_hub_gather=True)}
+                     "gemm_reserve_cus=16,early_hub_gather": DEFAULT.but(gemm_reserve_cus=16, early_hub_gather=True),
+                     "one communicator": DEFAULT}                   # (the default has the small exchanges on a second one)
             autotune, best = {}, ("default", None)
             try:
                 for name, sch in cands.items():
                     if name != "default":
                         del sg, layer, x, go
                         torch.cuda.empty_cache()
-                        sg, layer, x, go, seg_launch_bytes = build_sharded(sch)
+                        sg, layer, x, go, seg_launch_bytes = build_sharded(sch, name == "one communicator")
                     for _ in range(5):
                         step()
                     regions = []
                     for _ in range(2):                          # the better of two regions: the first one after a rebuild is noisy
-                        if world > 1:
+                        if rccl:
                             dist.barrier()
                         torch.cuda.synchronize()
                         a0 = time.perf_counter()
@@ -1129,7 +1146,7 @@ def main():
                             step()
                         torch.cuda.synchronize()
                         tt = torch.tensor([(time.perf_counter() - a0) / 8 * 1e3], dtype=torch.float64, device=dev)
-                        if world > 1:
+                        if rccl:
                             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                         regions.append(float(tt.item()))
                     autotune[name] = min(regions)
@@ -1138,14 +1155,14 @@ def main():
                 if best[0] != list(cands)[-1]:                       # the last candidate is the one that is built right now
                     del sg, layer, x, go
                     torch.cuda.empty_cache()
-                    sg, layer, x, go, seg_launch_bytes = build_sharded(cands[best[0]])
+                    sg, layer, x, go, seg_launch_bytes = build_sharded(cands[best[0]], best[0] == "one communicator")
                 autotune = {"ms_per_step": autotune, "chosen": best[0]}
             except Exception as e:                              # noqa: BLE001 -- keep the default, say why
                 autotune = {"error": f"{type(e).__name__}: {e}"[:300], "chosen": "default"}
                 sg, layer, x, go, seg_launch_bytes = build_sharded(DEFAULT)
 
     def barrier():
-        if world > 1:
+        if rccl:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -1195,7 +1212,7 @@ def main():
                 step()
             barrier()
             repeats.append((time.perf_counter() - r0) / args.steps * 1e3)
-    if world > 1:
+    if rccl:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1313,7 +1330,7 @@ def main():
         if parity is not None:
             res["parity_max_err"] = parity["parity_max_err"]
             res["parity"] = parity
-    if world > 1:
+    if rccl:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

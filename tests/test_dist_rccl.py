@@ -173,6 +173,29 @@ def test_bench_parity_block_with_one_rank_through_the_sharded_code(dev):
             assert line["parity"]["by_tensor"]["out_rows_fp64_formula"] < 1e-5
 
 
+def test_bench_rehearsal_of_the_node_run_on_one_gpu(dev):
+    """NPI_BENCH_RCCL_SOLO=1: a world of one through what `bench.py --gpus N` goes through -- a real RCCL process group and the
+    second communicator for the small exchanges, every collective of the layer, the set-up that times the schedule
+    candidates, the all-reduced timings, the parity block."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NPI_BENCH_RCCL_SOLO"] = "1"
+    for conv in ("sage", "gat"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--steps", "2", "--warmup", "1",
+                            "--nodes", "200000", "--edges", "4000000", "--conv", conv, "--no-cpu-baseline"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        chosen = (line["config"]["autotune"] or {}).get("chosen")            # (GATConv: no candidates, the default runs)
+        assert line["config"]["fallback"] is None, line["config"]
+        assert line["config"]["communicators"] == (1 if chosen == "one communicator" else 2), line["config"]
+        assert line["parity_max_err"] is not None and line["parity_max_err"] < 1e-5, line.get("parity")
+        if conv == "sage":
+            tuned = line["config"]["autotune"]
+            assert "error" not in tuned and set(tuned["ms_per_step"]) >= {"default", "gemm_reserve_cus=16", "early_hub_gather",
+                                                                          "one communicator"}, tuned
+            assert line["exchange"]["by_collective_ms_per_step"], line["exchange"]     # waits on real collectives were timed
+
+
 def test_bench_falls_back_to_the_conservative_schedule_when_its_preflight_step_fails(dev):
     """bench.py's sharded path runs ONE pre-flight step; a failure (injected here) makes every rank rebuild its shard on the
     round-2 schedule (classic hub layout, no third stream, one GEMM per direction) and say so in the line -- the numbers of the
