@@ -277,8 +277,8 @@ def test_collectives_through_rccl_with_one_rank(dev):
     p.join(timeout=120)
     assert p.exitcode == 0
     # every wait on a collective is bracketed by HIP events on the waiting stream (hubs: gather + reduce-scatter per direction)
-    assert tags == ["bwd_all_gather", "bwd_all_reduce_db", "bwd_all_reduce_dw", "bwd_reduce_scatter", "fwd_all_gather",
-                    "fwd_reduce_scatter"]
+    # (dW and db are summed in ONE exchange)
+    assert tags == ["bwd_all_gather", "bwd_all_reduce_params", "bwd_reduce_scatter", "fwd_all_gather", "fwd_reduce_scatter"]
     assert 0.0 <= stall_min <= stall_max < 1000.0
     assert len(errs) == 4                   # SAGE (hubs, rows), GCN, GAT
     for e_out, e_dx, e_dw in errs:
