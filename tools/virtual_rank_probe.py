@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--wire-gbps", type=float, default=0.0, help="emulate the exchanges: hold CUs for latency + wire bytes / this rate")
     ap.add_argument("--held-cus", type=int, default=16)
     ap.add_argument("--wire-sweep", default="", help="comma-separated rates: after the plain run, one emulated run per rate (one line each)")
+    ap.add_argument("--hp-copies", action="store_true", help="the stand-in collectives on HIGH-priority streams")
     ap.add_argument("--two-lanes", action="store_true", help="the small exchanges on a second communicator (ShardedGraph(small_group=))")
     ap.add_argument("--sched", default="", help="Schedule overrides, e.g. 'split_projection=False,partial_stream=False'")
     a = ap.parse_args()
@@ -36,9 +37,10 @@ def main():
     N, E, F, W, r = a.nodes, a.edges, a.hidden, a.world, a.rank
 
     from npi_gnn_amd.virtual import SMALL_LANE, StubCollectives
-    stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev),
+    prio = -1 if a.hp_copies else 0
+    stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev, priority=prio),
                            wire_gbps=a.wire_gbps or None, held_cus=a.held_cus,
-                           copy_stream2=torch.cuda.Stream(device=dev) if (a.two_lanes and not a.inline_copies) else None)
+                           copy_stream2=torch.cuda.Stream(device=dev, priority=prio) if (a.two_lanes and not a.inline_copies) else None)
     stub.__enter__()                                       # for the life of the process
     ei = bipartite_edge_index(N, E, seed=20260310).to(dev)
     g = torch.Generator().manual_seed(3)
