@@ -1085,12 +1085,16 @@ class _GatConvFn(torch.autograd.Function):
         tmap = _inverse_transpose_map(graph)                                  # cached; built on the launch stream
         # dz is in by-source entry order: its by-source row sum is a coalesced, latency-bound pass (0.09 ms alone, 0.31 ms
         # with one wave per SIMD beside a dW workgroup), so it stays in front of dW
-        g_src = seg_rowsum(graph.by_src, dz, 1)
+        src_beside = overlap and ctx.sch.gat_src_rowsum_beside_dw
+        if not src_beside:
+            g_src = seg_rowsum(graph.by_src, dz, 1)
         if overlap:
             side.wait_stream(main)
             # resident before the side stream's passes ask for wave slots
             dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
         with torch.cuda.stream(side):
+            if src_beside:
+                g_src = seg_rowsum(graph.by_src, dz, 1)
             g_dst = seg_rowsum(graph.by_dst, dz, 1, map_=tmap)                # 128-byte lines of a 4-byte permutation
             have_g = torch.cuda.Event()
             have_g.record(side)
@@ -1102,7 +1106,7 @@ class _GatConvFn(torch.autograd.Function):
         if overlap:
             for t in (x, dz, tmap, g_src):
                 t.record_stream(side)
-            for t in (P, g_dst):
+            for t in (P, g_dst) + ((g_src,) if src_beside else ()):
                 t.record_stream(main)
             main.wait_stream(side)
         # dW += P^T [a1; a2] and d att = P W in one small launch behind the GEMMs

@@ -26,6 +26,9 @@ class Schedule:
     #: one-head GATConv forward: a_dst / a_src of every node from the accumulators of h = x W in the GEMM's store epilogue
     #: instead of a pass over h (shapes one column tile covers: 128 or 256 output channels)
     gat_scores_epilogue: bool = True
+    #: one-head GATConv backward (rank-2 path, two streams): the by-source row sum of dz on the side stream, in front of the
+    #: by-target one and beside the dW GEMM, instead of on the launch stream in front of dW
+    gat_src_rowsum_beside_dw: bool = False
     # sharded layers (dist.py) --------------------------------------------------------------------------------------------------
     #: cuts without hub-hub edges: the reduce-scatter delivers the COMPLETE hub rows straight into the output (no merge pass)
     direct_hub_rows: bool = True

@@ -58,7 +58,7 @@ def _run(make, graph, x, go):
     ("sage", dict(overlap_streams=False)), ("sage", dict(overlap_min_rows=10 ** 9)),
     ("gcn", dict(overlap_streams=False)),
     ("gat", dict(overlap_streams=False)), ("gat", dict(gat_rank2_epilogue=False)), ("gat", dict(gat_rank2_min_rows=10 ** 9)),
-    ("gat", dict(gat_scores_epilogue=False)),
+    ("gat", dict(gat_scores_epilogue=False)), ("gat", dict(gat_src_rowsum_beside_dw=True)),
 ])
 def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     ei, graph, x, go = _graph(dev)
