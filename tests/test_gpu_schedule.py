@@ -31,7 +31,7 @@ def test_no_environment_switch_selects_a_path():
     fields = set(Schedule.__dataclass_fields__)
     assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "gat_scores_epilogue",
                       "direct_hub_rows", "partial_stream", "split_projection", "gat_direct", "early_hub_gather", "gemm_reserve_cus",
-                      "split_projection_reserve_cus"}
+                      "split_projection_reserve_cus", "gat_src_rowsum_beside_dw"}
     assert CONSERVATIVE == DEFAULT.but(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
                                        gat_rank2_epilogue=False)
 
