@@ -1064,7 +1064,10 @@ def main():
         small_group = None
         if rccl:
             import torch.distributed as dist
-            small_group = dist.new_group()
+            try:
+                small_group = dist.new_group()
+            except Exception as e:                              # noqa: BLE001 -- one communicator then (config.communicators says so)
+                sys.stderr.write(f"rank {rank}: no second communicator ({type(e).__name__}: {e}); every exchange on the first\n")
 
         def build_sharded(schedule, one_communicator=False):
             if args.partition == "edges":
