@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--control-only", action="store_true",
                     help="run only the uniform-source control launches (for a rocprofv3 --pmc pass)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config block")
+    ap.add_argument("--plain-csr", action="store_true",
+                    help="build the graphs with every row's entries in edge-list order (default: in column order, CSRGraph(sort_columns=True))")
     ap.add_argument("--no-autotune", action="store_true",
                     help="N > 1: keep the default Schedule instead of timing its alternatives during set-up")
     ap.add_argument("--skip-c5", action="store_true", help="configs block without the 4M / 100M GAT stack")
@@ -706,7 +708,7 @@ def run_configs(dev, args, c4):
             torch.cuda.empty_cache()
             N5, E5, F5 = 4_000_000, 100_000_000, 256
             ei5 = bipartite_edge_index(N5, E5, seed=2).to(dev)
-            g5 = npi.CSRGraph(ei5, N5)
+            g5 = npi.CSRGraph(ei5, N5, sort_columns=not args.plain_csr)
             _ = g5.by_src
             weights = [((torch.randn(F5, F5, generator=gen) / 16), torch.zeros(F5)) for _ in range(3)]
             att = [torch.randn(1, 1, 2 * F5, generator=gen) * 0.1 for _ in range(3)]
@@ -1028,7 +1030,9 @@ def main():
 
     if not sharded:
         t0 = time.time()
-        graph = npi.CSRGraph(ei.to(dev), N)
+        # every row's entries in column order (CSRGraph(sort_columns=): a second key for the build's sort, once per graph;
+        # nothing for this SAGEConv line, 0.8-1.2 % for the GATConv configs -- EXPERIMENTS A22); --plain-csr: list order
+        graph = npi.CSRGraph(ei.to(dev), N, sort_columns=not args.plain_csr)
         _ = graph.by_src
         torch.cuda.synchronize()
         t_build = time.time() - t0
@@ -1324,7 +1328,8 @@ def main():
                                    f"(both directions, Zipf-skewed protein side), 1 {args.conv.upper()}Conv layer "
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
                        "parallelism": parallelism(args, world), "hip_graph_replay": captured, "setup_steps": SETUP_STEPS,
-                       "csr_build_s": round(t_build, 4), "fallback": fallback,
+                       "csr_build_s": round(t_build, 4), "csr_sorted_columns": (not args.plain_csr) if not sharded else False,
+                       "fallback": fallback,
                        "autotune": autotune if sharded else None,
                        "communicators": (2 if getattr(sg, "small_group", None) is not getattr(sg, "group", None) else 1) if sharded else None},
             "roofline": roof,

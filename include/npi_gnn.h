@@ -95,10 +95,15 @@ int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E,
 /* Same build with separate row and column id spaces, for a destination-row SHARD of the graph on
  * one GPU: keys are local row ids in [0, N), values index a feature table of
  * n_cols rows (e.g. the all-gathered x of every rank); the appended self loop of row r gets
- * column r + loop_col_offset; drop_equal == 0 keeps key == val columns (the caller has already
- * removed the global self loops). */
+ * column r + loop_col_offset.  build_flags: NPI_CSR_DROP_EQUAL drops key == val columns (0: the caller has
+ * already removed the global self loops); NPI_CSR_SORT_COLUMNS orders the entries of a row by column
+ * (ties: list order) instead of list order -- a second key for the build's sort, for graphs whose rows are
+ * long: the 4-byte gathers of per-node scalars (GATConv) then walk ascending addresses.  The SUMS are the
+ * same in another association. */
+#define NPI_CSR_DROP_EQUAL 1
+#define NPI_CSR_SORT_COLUMNS 2
 int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
-                     int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int drop_equal,
+                     int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int build_flags,
                      int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* rowidx,
                      int32_t* item_row, int64_t item_edges, int32_t* status,
                      void* workspace, int64_t workspace_bytes, void* stream);

@@ -57,6 +57,31 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ key_nodes,
     vals[e] = (int32_t)e;
 }
 
+// NPI_CSR_SORT_COLUMNS, first sort: key = the column node (out-of-range columns: n_cols, behind everything; make_keys_kernel's
+// rules decide later what becomes of them), val = the entry's position in the caller's list
+__global__ void col_keys_kernel(const int64_t* __restrict__ val_nodes, int64_t E, int64_t n_cols,
+                                uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t v = val_nodes[e];
+    keys[e] = (v < 0 || v >= n_cols) ? (uint32_t)n_cols : (uint32_t)v;
+    vals[e] = (int32_t)e;
+}
+
+// ... second sort's keys: make_keys_kernel's rule for the entry that the column sort left at position i
+__global__ void rekey_kernel(const int64_t* __restrict__ key_nodes, const int64_t* __restrict__ val_nodes,
+                             const int32_t* __restrict__ vals, int64_t E, int64_t N, int64_t n_cols, int drop_equal,
+                             uint32_t* __restrict__ keys, int32_t* __restrict__ status) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const int64_t e = vals[i];
+    const int64_t k = key_nodes[e], v = val_nodes[e];
+    const bool pad = (k == -1) & (v == -1);
+    const bool bad = !pad & ((k < 0) | (k >= N) | (v < 0) | (v >= n_cols));
+    if (bad) atomicOr(status, 1);
+    keys[i] = (pad || bad || (drop_equal && k == v)) ? (uint32_t)N : (uint32_t)k;
+}
+
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks,
                   int32_t* __restrict__ counts) {
@@ -422,12 +447,13 @@ extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes,
 }
 
 extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
-                                int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int drop_equal,
+                                int64_t n_cols, int add_self_loops, int64_t loop_col_offset, int build_flags,
                                 int32_t* rowptr, int32_t* col, int32_t* eid,
                                 int32_t* rowidx, int32_t* item_row, int64_t item_edges, int32_t* status,
                                 void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(E >= 0 && N >= 0 && n_cols >= 0, "npi_csr_build: negative size");
+    NPI_REQUIRE((build_flags & ~(NPI_CSR_DROP_EQUAL | NPI_CSR_SORT_COLUMNS)) == 0, "npi_csr_build: unknown build flag");
     NPI_REQUIRE(item_edges_ok(item_edges), "npi_csr_build: item_edges must be 64 or NPI_ITEM_EDGES (npi_item_edges gives the hint)");
     NPI_REQUIRE(E + N + 1 < (int64_t)0x7fffffff, "npi_csr_build: E + N does not fit int32");
     NPI_REQUIRE(n_cols < (int64_t)0x7fffffff && loop_col_offset >= 0 && loop_col_offset + N <= (n_cols > N ? n_cols : N),
@@ -448,8 +474,19 @@ extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nod
     int32_t* tiles = (int32_t*)(ws + L.off_tiles);
 
     (void)hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+    const int drop_equal = build_flags & NPI_CSR_DROP_EQUAL;
     if (E > 0) {
-        make_keys_kernel<<<(unsigned)ceil_div(E, 256), 256, 0, stream>>>(key_nodes, val_nodes, E, N, n_cols, drop_equal, keys_a, vals_a, status);
+        const unsigned eb = (unsigned)ceil_div(E, 256);
+        if (build_flags & NPI_CSR_SORT_COLUMNS) {
+            // LSD over the pair (row, column): the stable sort by column first, then the stable sort by row keeps it inside a row
+            col_keys_kernel<<<eb, 256, 0, stream>>>(val_nodes, E, n_cols, keys_a, vals_a);
+            int cbits = 1;
+            while (((int64_t)1 << cbits) <= n_cols) ++cbits;
+            radix_sort_pairs(keys_a, keys_b, vals_a, vals_b, E, cbits, L, counts, tiles, stream);
+            rekey_kernel<<<eb, 256, 0, stream>>>(key_nodes, val_nodes, vals_a, E, N, n_cols, drop_equal, keys_a, status);
+        } else {
+            make_keys_kernel<<<eb, 256, 0, stream>>>(key_nodes, val_nodes, E, N, n_cols, drop_equal, keys_a, vals_a, status);
+        }
         int bits = 1;
         while (((int64_t)1 << bits) <= N) ++bits;       // keys lie in [0, N]
         radix_sort_pairs(keys_a, keys_b, vals_a, vals_b, E, bits, L, counts, tiles, stream);

@@ -94,6 +94,8 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
     N = None
     calls = {
         "npi_csr_build_ex": lambda: lib.npi_csr_build_ex(N, N, -1, 4, 4, 1, 0, 1, N, N, N, N, N, 64, N, N, 0, N),
+        # build flags: NPI_CSR_DROP_EQUAL | NPI_CSR_SORT_COLUMNS, nothing else
+        "npi_csr_build_ex (flags)": lambda: lib.npi_csr_build_ex(8, 8, 4, 4, 4, 1, 0, 4, 8, 8, 8, 8, 8, 64, 8, 8, 1 << 20, N),
         # an item size that does not exist is refused by the build and by every consumer of item_row
         "npi_csr_build": lambda: lib.npi_csr_build(8, 8, 4, 4, 1, 8, 8, 8, 8, 8, 100, 8, 8, 1 << 20, N),
         "npi_csr_filter": lambda: lib.npi_csr_filter(8, 8, 8, 8, 8, 8, 4, 8, 8, 8, 8, 8, 8, 0, 8, 8, N),
@@ -131,6 +133,7 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
     }
     for name, call in calls.items():
         assert call() == -1, name
+        name = name.split()[0]
         stem = name[:-3] if name.endswith("_ex") else name           # npi_csr_build_ex reports as npi_csr_build
         assert stem.encode() in lib.npi_last_error(), (name, lib.npi_last_error())
     # a caller workspace that is too small is refused before anything is launched (status -3), and sized by a query

@@ -27,12 +27,13 @@ def rand_edges(N, E, seed, hub=None):
     return ei
 
 
-def csr_reference(key, val, N, loops=True):
-    """numpy restatement of the build contract: drop key==val, stable sort by key, loop last."""
+def csr_reference(key, val, N, loops=True, sort_columns=False):
+    """numpy restatement of the build contract: drop key==val, stable sort by key (``sort_columns``: by (key, column), ties in
+    list order), loop last."""
     key, val = key.numpy(), val.numpy()
     keep = key != val
     eids = np.nonzero(keep)[0]
-    order = np.argsort(key[keep], kind="stable")
+    order = np.lexsort((val[keep], key[keep])) if sort_columns else np.argsort(key[keep], kind="stable")
     k_s, v_s, e_s = key[keep][order], val[keep][order], eids[order]
     rows_col, rows_eid, rows_idx, rowptr = [], [], [], [0]
     bounds = np.searchsorted(k_s, np.arange(N + 1))
@@ -75,6 +76,35 @@ def test_csr_build_is_bit_exact(dev, N, E, loops):
             if k < nnz:
                 assert rowptr[ir[i]] <= k < rowptr[ir[i] + 1]
         assert int(side.status.item()) == 0
+
+
+@pytest.mark.parametrize("N,E,loops", [(7, 20, True), (300, 5000, False), (5000, 200000, True), (3000, 1_100_000, True)])
+def test_csr_build_with_sorted_columns_is_bit_exact(dev, N, E, loops):
+    """NPI_CSR_SORT_COLUMNS: the same rows, every row's entries in column order (duplicate edges: list order), eid still the
+    entry's position in the caller's list; an aggregation over it gives the sums of the plain build in another association"""
+    ei = rand_edges(N, E, seed=N + E, hub=N // 2)               # a third of the edges share one target: long rows, duplicates
+    g = npi.CSRGraph(ei.to(dev), N, self_loops=loops, sort_columns=True)
+    for side, key, val in ((g.by_dst, ei[1], ei[0]), (g.by_src, ei[0], ei[1])):
+        rowptr, col, eid, rowidx = csr_reference(key, val, N, loops, sort_columns=True)
+        nnz = int(rowptr[-1])
+        assert np.array_equal(side.rowptr.cpu().numpy(), rowptr)
+        assert np.array_equal(side.col.cpu().numpy()[:nnz], col)
+        assert np.array_equal(side.eid.cpu().numpy()[:nnz], eid)
+        assert np.array_equal(side.rowidx.cpu().numpy()[:nnz], rowidx)
+        assert int(side.status.item()) == 0
+    plain = npi.CSRGraph(ei.to(dev), N, self_loops=loops)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(N, 64, generator=gen).to(dev)
+    # (unweighted: with several self loops on one node in the list, WHICH of their weights becomes the node's loop weight is
+    # as unspecified here as it is in PyG's add_remaining_self_loops on a GPU)
+    a, b = (npi.sage_conv(x, gr, torch.eye(64, device=dev), None) for gr in (g, plain))
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    # out-of-range ids are flagged and dropped exactly as by the plain build
+    bad = torch.tensor([[0, 1, 9, 2], [1, 2, 0, -5]])
+    gb = npi.CSRGraph(bad.to(dev), 3, sort_columns=True)
+    assert int(gb.by_dst.status.item()) == 1 and gb.by_dst.rowptr.cpu().tolist() == [0, 1, 3, 5]
+    with pytest.raises(IndexError):                              # ... and reported at the next device read
+        gb.nnz()
 
 
 def test_csr_build_flags_out_of_range_ids(dev):
