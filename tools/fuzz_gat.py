@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised campaign for the GAT kernels against the CPU oracle (oracle/ref_conv.py): random graphs (hub rows, empty
-rows, self loops, duplicate edges), 1 / 2 / 4 / 8 heads, both item sizes (CSRGraph(item=)), fused ReLU on / off.
-usage: tools/fuzz_gat.py [cases] [seed]"""
+rows, self loops, duplicate edges), 1 / 2 / 4 / 8 heads, both item sizes (CSRGraph(item=)), rows in list or in column order
+(CSRGraph(sort_columns=)), fused ReLU on / off.
+usage: tools/fuzz_gat.py [cases] [seed [only_case [sort_columns 0|1]]]"""
 import os, sys
 import numpy as np
 import torch
@@ -15,8 +16,12 @@ SCHS = [DEFAULT.but(gat_rank2_min_rows=0), DEFAULT.but(gat_rank2_min_rows=0, ove
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # re-run ONE case of the campaign ...
+force_sort = {"0": False, "1": True}.get(sys.argv[4]) if len(sys.argv) > 4 else None     # ... with the row order forced
+force_item = int(sys.argv[5]) if len(sys.argv) > 5 else None                            # ... and the item size
 dev = torch.device("cuda:0")
 worst = 0.0
+flips = 0          # cases set aside: the fp32 ORACLE is as far from the fp64 one as the kernels are
 for it in range(cases):
     H, C = [(1, 256), (1, 64), (1, 100), (2, 32), (2, 128), (4, 64), (4, 32), (8, 32), (2, 64), (1, 8)][int(rng.integers(0, 10))]
     N = int(rng.integers(2, 2500))
@@ -36,7 +41,14 @@ for it in range(cases):
     b = torch.randn(H * C, generator=g) * 0.1
     go = torch.randn(N, H * C, generator=g)
     xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
-    graph = npi.CSRGraph(ei.to(dev), N, item=256 if big_items else 64)
+    sort_columns = bool(rng.random() < 0.5)
+    if only is not None and it != only:
+        continue
+    if force_sort is not None:
+        sort_columns = force_sort
+    if force_item is not None:
+        big_items = force_item == 256
+    graph = npi.CSRGraph(ei.to(dev), N, item=256 if big_items else 64, sort_columns=sort_columns)
     out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCHS[it & 1])
     out.backward(go.to(dev))
     xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))
@@ -57,9 +69,27 @@ for it in range(cases):
         e = float((a.cpu().double() - r).abs().max()) / scale
         errs.append((name, e, float(r.abs().max())))
     m = max(e for _, e, _ in errs)
-    worst = max(worst, m)
+    if m <= 2e-4:
+        worst = max(worst, m)
     if m > 2e-4:
-        print(f"MISMATCH case {it}: H={H} C={C} N={N} E={E} Fi={Fi} big_items={big_items} relu={relu}: {errs}")
+        print(f"MISMATCH case {it}: sort_columns={sort_columns} H={H} C={C} N={N} E={E} Fi={Fi} big_items={big_items} relu={relu}: {errs}")
+        # is it the data?  the ORACLE evaluated in fp32 against itself in fp64: what rounding alone does to this case
+        x32, W32, a32, b32 = (t.clone().float().requires_grad_(True) for t in (x, W, att, b))
+        r32 = R.gat_conv(x32, ei, W32, a32, b32, heads=H)
+        if relu:
+            r32 = r32 * (out.detach().cpu() > 0).float()
+        r32.backward(go.float())
+        floor = {n: float((a_.double() - r_).abs().max()) / max(float(r_.abs().max()), 1e-3) for n, a_, r_ in (
+            ("dx", x32.grad, xr.grad), ("dW", W32.grad, Wr.grad), ("datt", a32.grad, ar.grad))}
+        print(f"   the oracle in fp32 against the oracle in fp64: {floor}")
+        if all(e <= 2.0 * floor.get(n, 0.0) + 2e-4 for n, e, _ in errs):
+            # a leaky_relu argument within rounding of zero has either sign in fp32 and in fp64, and its slope jumps from 1 to
+            # 0.2: EVERY fp32 evaluation is that far from the fp64 one (seed 23, case 107: the oracle in fp32 is off by the same
+            # 5.4e-3 to six digits) -- the data, not the kernels
+            print("   -> the fp32 oracle is as far from the fp64 one: a discontinuity of the data (leaky_relu at a rounding-level "
+                  "argument), not counted")
+            flips += 1
+            continue
         # bisect: the same inputs with single arrangements switched off
         SCH = SCHS[it & 1]
         for name, sch in (("as run", SCH), ("no rank-2 epilogue", SCH.but(gat_rank2_epilogue=False)),
@@ -73,4 +103,4 @@ for it in range(cases):
                 e = float((xd.grad.cpu().double() - xr.grad).abs().max()) / max(float(xr.grad.abs().max()), 1e-3)
                 print(f"   {name}, fused_relu={use_relu}: dx err {e:.2e}")
         sys.exit(1)
-print(f"{cases} cases ok, worst relative error {worst:.2e}")
+print(f"{cases} cases ok, worst relative error {worst:.2e} ({flips} case(s) set aside: fp32 oracle equally far from fp64)")
