@@ -28,6 +28,19 @@ class _Done:
         return True
 
 
+class _EventWork:
+    """the pending stand-in collective: ``wait()`` makes the CURRENT stream wait for its event (what ``Work.wait()`` of an RCCL
+    collective does)"""
+    __slots__ = ("ev", "dev")
+
+    def __init__(self, ev, dev):
+        self.ev, self.dev = ev, dev
+
+    def wait(self):
+        torch.cuda.current_stream(self.dev).wait_event(self.ev)
+        return True
+
+
 # stands for ``ShardedGraph(small_group=)`` in a virtual world: ``StubCollectives`` runs the collectives issued on it on its
 # second stream (``copy_stream2``), as a second communicator runs its own in their own order
 SMALL_LANE = "small-lane"
@@ -181,12 +194,7 @@ class StubCollectives(_Patched):
             t.record_stream(cs)
         ev = torch.cuda.Event()
         ev.record(cs)
-
-        class _Work:
-            def wait(self_inner):
-                torch.cuda.current_stream(cs.device).wait_event(ev)
-                return True
-        w = _Work()
+        w = _EventWork(ev, cs.device)
         if not async_op:
             w.wait()
             return None
