@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- edges/sec per GNN layer (fwd+bwd) on the synthetic ncRNA-protein bipartite graph.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; rank 0 prints ONE JSON line.  For N > 1 the
-driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; a plain
-`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts exactly that command itself as a
-child process BEFORE anything in this process touches the GPU, and exits with the child's code.
+Contract: `python bench.py --gpus N --steps K --warmup W`; rank 0's LAST stdout line is ONE compact strict-JSON object
+(< 8 KB: metric, value, roofline, cpu_baseline, parity, one number per side config); everything longer -- per-tensor tables,
+per-rank arrays, prose -- goes to `bench_detail.json` in the working directory.  For N > 1 the driver launches
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; a plain `python bench.py --gpus N` (no
+WORLD_SIZE in the environment) starts exactly that command itself as a child process BEFORE anything in this process touches
+the GPU, and exits with the child's code.
 
-A "step" is one pass of the hot path over the whole graph: one SAGEConv layer (gather -> segmented mean ->
-MFMA projection) forward AND backward (dX, dW, db), the call pattern of reference src/classes.py:62 +
-src/train_with_twoDataset.PY:52-54, with x and the graph already resident in HBM.  Workload =
-BASELINE.json configs[3] ("C4"): N = 1M nodes, E = 20M directed edges, hidden = 256, fp32 -- it fits one GPU,
-so N=1 runs the full graph; N>1 shards the same graph (strong scaling; npi_gnn_amd/dist.py, --partition).
+A "step" is one pass of the hot path over the whole graph: one SAGEConv layer (gather -> segmented mean -> MFMA projection)
+forward AND backward (dX, dW, db), the call pattern of reference src/classes.py:62 + src/train_with_twoDataset.PY:52-54, with x
+and the graph already resident in HBM.  Workload = BASELINE.json configs[3] ("C4"): N = 1M nodes, E = 20M directed edges,
+hidden = 256, fp32 -- it fits one GPU, so N=1 runs the full graph; N>1 shards the same graph (strong scaling;
+npi_gnn_amd/dist.py, --partition).
 
-After the headline measurement (N=1 only) the line also carries
-  roofline.control_uniform  the same aggregation kernel on a 1M-node / 20M-edge graph whose sources are uniform
-                            over the whole 1 GB table (no cache-resident hub side): the un-assisted HBM fraction;
-  configs                   the other BASELINE.json configs on this GPU (C1-C3 with their parity error against
-                            committed oracle outputs, GCN / GAT at the C4 shape, C5 on one GPU).
+The default N=1 run: graph build, 40 + W + K steps, the roofline block (live HIP-event durations of the aggregation launches),
+the parity of exactly what was timed (every row of out / dX and dW, db against the formulas in fp64 torch ops), the
+cache-hostile control, one number per other BASELINE config inside a wall-clock budget, and the CPU path on the host cores.
+`--extras` adds the lab harness (tools/bench_extras.py: per-head sweeps, the virtual worlds of every partition, the emulated
+wire, the C5 stack in its 8-rank form with its parity) -- detail file only.
+
+N > 1: every rank launched by torch.distributed.run is a SUPERVISOR that never touches the GPU; it starts the rank's worker as
+a child process.  A worker that fails (or a pre-flight phase that does not finish in time) fails the whole attempt: every
+supervisor ends its own worker and starts a FRESH one on the conservative schedule (`config.fallback` says so) -- no in-process
+recovery after a HIP fault, no collective that a failed rank would have to join.
 """
 from __future__ import annotations
 
@@ -38,8 +45,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s is the guide's measured copy rate)
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
-MFMA_BF16_RANDOM_TF = 1850.0   # the same pipe on random operands (clock held under load; tools/micro/mfma_bf16_rate.hip: 1.59-1.90 PF/s)
 SETUP_STEPS = 40               # untimed steps before the warm-up (lazy initialisation, clock ramp: ~0.3 s of load; reported as config.setup_steps)
+LINE_CAP = 8192                # hard cap of the final stdout line (the driver's parser lost a 20.9 KB line in round 4)
+DETAIL_FILE = "bench_detail.json"
 
 
 def parse(argv=None):
@@ -51,7 +59,7 @@ def parse(argv=None):
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--graph-seed", type=int, default=20260310,
-                    help="seed of the synthetic bipartite graph (2 = the graph of configs.C5_1gpu: its PMC passes)")
+                    help="seed of the synthetic bipartite graph (2 = the C5 graph: its PMC passes)")
     ap.add_argument("--conv", choices=["sage", "gcn", "gat"], default="sage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=100_000, help="bounded CPU-baseline sample (1/10 scale)")
@@ -66,23 +74,30 @@ def parse(argv=None):
     ap.add_argument("--no-control", action="store_true", help="skip roofline.control_uniform")
     ap.add_argument("--control-only", action="store_true",
                     help="run only the uniform-source control launches (for a rocprofv3 --pmc pass)")
-    ap.add_argument("--no-configs", action="store_true", help="skip the per-config block")
+    ap.add_argument("--no-configs", action="store_true", help="skip the one-number-per-config summary")
+    ap.add_argument("--no-parity", action="store_true", help="N=1: skip the fp64 check of the timed configuration")
+    ap.add_argument("--configs-budget", type=float, default=45.0,
+                    help="wall-clock seconds the default run may spend on the per-config summary (entries that no longer fit are skipped)")
+    ap.add_argument("--extras", action="store_true",
+                    help="the lab harness (tools/bench_extras.py) without a budget: per-head sweeps, every partition's virtual "
+                         "world, emulated wire, the C5 stack on the host-generated graph with its 8-rank parity")
     ap.add_argument("--plain-csr", action="store_true",
                     help="build the graphs with every row's entries in edge-list order (default: in column order, CSRGraph(sort_columns=True))")
     ap.add_argument("--no-autotune", action="store_true",
                     help="N > 1: keep the default Schedule instead of timing its alternatives during set-up")
-    ap.add_argument("--skip-c5", action="store_true", help="configs block without the 4M / 100M GAT stack")
+    ap.add_argument("--conservative", action="store_true", help="N > 1: the round-2 schedule (what a second attempt runs)")
+    ap.add_argument("--skip-c5", action="store_true", help="configs summary without the 4M / 100M GAT stack")
     ap.add_argument("--capture", action="store_true",
                     help="N=1: capture the step (both streams) into one HIP graph and time replays of it")
     ap.add_argument("--virtual-world", type=int, default=8,
-                    help="N=1: time every rank's local work of a W-rank run on this GPU (configs.C4_w<W>_virtual); 0 = skip")
+                    help="N=1: time every rank's local work of a W-rank run on this GPU (configs.w<W>_hubs_sage_*); 0 = skip")
     ap.add_argument("--rank-check", action="store_true",
                     help="every rank prints {rank, world} and exits before any GPU call (launcher test)")
     return ap.parse_args(argv)
 
 
 # ---------------------------------------------------------------------------------------------------------
-# launcher
+# launcher and supervisor (neither touches the GPU)
 # ---------------------------------------------------------------------------------------------------------
 def _free_port() -> int:
     s = socket.socket()
@@ -103,6 +118,108 @@ def self_launch(n: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def rendezvous_dir(world: int = 0) -> str:
+    """One directory per LAUNCH, the same for every rank of it.  NPI_BENCH_RDV when set (a worker gets it from its supervisor;
+    a test may name one).  Otherwise, world > 1: the ranks are siblings started by one torch.distributed.run agent, so the
+    agent's pid + its start time (a pid can be reused, the pair cannot) + MASTER_PORT name the launch; world == 1: a fresh
+    temporary directory."""
+    d = os.environ.get("NPI_BENCH_RDV")
+    if not d:
+        tmp = os.environ.get("TMPDIR", "/tmp")
+        if world <= 1:
+            import tempfile
+            d = tempfile.mkdtemp(prefix="npi_bench_", dir=tmp)
+        else:
+            ppid = os.getppid()
+            try:
+                born = open(f"/proc/{ppid}/stat").read().rsplit(")", 1)[1].split()[19]      # field 22: starttime
+            except (OSError, IndexError):
+                born = "0"
+            d = os.path.join(tmp, f"npi_bench_{ppid}_{born}_{os.environ.get('MASTER_PORT', '0')}")
+        os.environ["NPI_BENCH_RDV"] = d
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def supervise(argv, rank: int, world: int) -> int:
+    """The process torch.distributed.run started for this rank: it makes NO GPU call.  It runs the rank's worker (this file with
+    NPI_BENCH_WORKER=1) as a child and watches the launch's rendezvous directory: attempt a has FAILED for everybody as soon as
+    any rank's worker exits non-zero (its supervisor drops `fail_<a>_<rank>`) or a worker does not report the end of its set-up
+    phase (`ok_<a>_<rank>`: pre-flight step + schedule candidates done) within NPI_BENCH_PREFLIGHT_TIMEOUT seconds.  Then every
+    supervisor ends ITS OWN worker (exact pid) and starts attempt 1: a fresh process on the conservative schedule, rendezvous
+    through a fresh file store.  A second failure is final (exit code 1)."""
+    rdv = rendezvous_dir(world)
+    limit = float(os.environ.get("NPI_BENCH_PREFLIGHT_TIMEOUT", "900"))
+    for attempt in (0, 1):
+        env = dict(os.environ, NPI_BENCH_WORKER="1", NPI_BENCH_ATTEMPT=str(attempt), NPI_BENCH_RDV=rdv)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env)
+        t0 = time.time()
+        failed = None
+        while True:
+            rc = p.poll()
+            if rc == 0:
+                if world <= 1:
+                    import shutil
+                    shutil.rmtree(rdv, ignore_errors=True)
+                return 0
+            if rc is not None:
+                failed = f"rank {rank}: worker exit code {rc}"
+            elif any(f.startswith(f"fail_{attempt}_") for f in os.listdir(rdv)):
+                failed = "another rank's worker failed"
+            elif not os.path.exists(os.path.join(rdv, f"ok_{attempt}_{rank}")) and time.time() - t0 > limit:
+                failed = f"rank {rank}: set-up phase not finished after {limit:.0f} s"
+            if failed:
+                break
+            time.sleep(0.2)
+        why = failed
+        errf = os.path.join(rdv, f"err_{attempt}_{rank}")
+        if os.path.exists(errf):
+            why += ": " + open(errf).read()[:300]
+        with open(os.path.join(rdv, f"fail_{attempt}_{rank}"), "w") as f:
+            f.write(why)
+        if p.poll() is None:                                    # this rank's worker, by pid: it may sit in a collective for ever
+            p.kill()
+            p.wait()
+        sys.stderr.write(f"[bench supervisor] attempt {attempt} failed ({why})"
+                         + ("; starting a fresh worker on the conservative schedule\n" if attempt == 0 else "; giving up\n"))
+    return 1
+
+
+def worker_note(kind: str, text: str = "") -> None:
+    """ok_<attempt>_<rank> / err_<attempt>_<rank> in the rendezvous directory (a worker under a supervisor only)"""
+    if os.environ.get("NPI_BENCH_WORKER") != "1":
+        return
+    a, r = os.environ.get("NPI_BENCH_ATTEMPT", "0"), os.environ.get("RANK", "0")
+    with open(os.path.join(rendezvous_dir(), f"{kind}_{a}_{r}"), "w") as f:
+        f.write(text)
+
+
+def first_attempt_failure():
+    """why attempt 0 failed, for `config.fallback` of the second attempt's line"""
+    rdv = rendezvous_dir()
+    why = [open(os.path.join(rdv, f)).read()[:300] for f in sorted(os.listdir(rdv)) if f.startswith("fail_0_")]
+    first_hand = [w for w in why if not w.startswith("another rank")]       # the rank that failed, not the ones that followed
+    return (first_hand or why or ["attempt 0 failed"])[0]
+
+
+def fake_worker(rank: int, world: int) -> int:
+    """NPI_BENCH_FAKE_WORKER=fail0 (tests/test_bench_launcher.py, no GPU): attempt 0 -- the last rank fails its pre-flight, the
+    others report ok and then sit in a 'collective' for ever; attempt 1 -- every rank finishes, rank 0 prints a line."""
+    attempt = int(os.environ.get("NPI_BENCH_ATTEMPT", "0"))
+    if attempt == 0:
+        if rank == world - 1:
+            worker_note("err", "RuntimeError: injected pre-flight failure")
+            return 3
+        worker_note("ok")
+        time.sleep(600)
+        return 0
+    worker_note("ok")
+    if rank == 0:
+        print(json.dumps({"fake": True, "attempt": attempt, "fallback": first_attempt_failure()}), flush=True)
+    return 0
+
+
 # ---------------------------------------------------------------------------------------------------------
 # byte / flop accounting
 # ---------------------------------------------------------------------------------------------------------
@@ -115,7 +232,7 @@ def algorithmic_bytes(nnz_rows_edges: int, n_rows: int, F: int, s: int = 4) -> i
 
 def gat_bytes(E: int, N: int, F: int, H: int = 1) -> dict:
     """Algorithmic bytes per launch of the two GATConv aggregation kernels (one head, f32, int32 CSR), SURVEY.md 8(d) plus the
-    per-entry / per-node scalars of the attention (DESIGN 3.2b).  nnz = E + N: the self loop is an ordinary entry.
+    per-entry / per-node scalars of the attention (DESIGN 3.4).  nnz = E + N: the self loop is an ordinary entry.
       forward  (npi_gat_aggregate_scores): per entry a gathered h row 4F + col 4 + its score 4H; per node the output row
                4F + rowptr 4 + (m, s) 8H
       backward (npi_gat_backward_fused_heads): per by-source entry a gathered dOut row 4F + col 4 + rowidx 4 + the target's
@@ -172,9 +289,10 @@ def mem_available_gb() -> float:
 
 def cpu_baseline(args, ei_full=None):
     """The oracle (PyG-style torch CPU ops: index_select -> index_add_ -> / -> matmul, autograd backward) timed on this
-    box's host cores.  The thread count is chosen on the 1/10-scale sample (the index ops stop scaling long before the
-    host's thread count); the reported figure is the metric's OWN configuration -- the full C4 graph, N = 1M, E = 20M --
-    whenever the host has the memory for its [E+N, F] message tensors (MemAvailable >= 128 GB), else the 1/10 sample."""
+    box's host cores: a bounded sample of about 30 s.  The thread count is chosen on the 1/10-scale sample (the index ops stop
+    scaling long before the host's thread count: 2 x 64-core EPYC 9575F, 32 threads 1.9 M edges/s, 256 threads 0.27 M -- a sweep
+    of round 1, EXPERIMENTS.md); the reported figure is the metric's OWN configuration -- the full C4 graph, one warm-up and one
+    timed run -- whenever the host has the memory for its [E+N, F] message tensors (MemAvailable >= 128 GB), else the sample."""
     from npi_gnn_amd.synth import bipartite_edge_index
     from oracle import ref_conv as R
     F = args.hidden
@@ -188,17 +306,14 @@ def cpu_baseline(args, ei_full=None):
         go = torch.randn(N, F, generator=g)
         return x, ei, W, torch.zeros(F), go
 
-    # The index_add_/index_select ops of this path stop scaling long before the host's thread count
-    # (2 x 64-core EPYC 9575F: 32 threads 1.9 M edges/s, 256 threads 0.27 M; a sweep of round 1, EXPERIMENTS.md),
-    # so the baseline is the best of a short sweep, not "all threads".
     ncpu = os.cpu_count() or 1
     Ns, Es = args.cpu_nodes, args.cpu_edges
     small = data(Ns, Es)
-    budget = time.time() + 20.0
+    budget = time.time() + 8.0
     best, best_threads, runs = None, 1, 0
     for nt in sorted({min(t, ncpu) for t in (16, 32, 64)}):
         torch.set_num_threads(nt)
-        for it in range(1 + 2):
+        for it in range(2):                                     # one warm-up, one timed
             t0 = time.time()
             R.sage_layer_fwd_bwd(*small)
             dt = time.time() - t0
@@ -210,9 +325,10 @@ def cpu_baseline(args, ei_full=None):
             break
     del small
     mem = mem_available_gb()
-    sample_small = (f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd, N={Ns} E={Es} F={F} fp32 (1/10-scale C4), best of "
-                    f"{runs} timed runs over 16/32/64 torch threads (1 warm-up each)")
-    res = {"value": Es / best, "unit": "edges/s", "cores": best_threads, "kind": "port", "sample": sample_small,
+    where = f"os.cpu_count()={os.cpu_count()}, cpu='{cpu_model()}'"
+    res = {"value": Es / best, "unit": "edges/s", "cores": best_threads, "kind": "port",
+           "sample": f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd, N={Ns} E={Es} F={F} fp32 (1/10-scale C4), best of "
+                     f"{runs} timed runs over 16/32/64 torch threads; {where}",
            "ran": "1/10-scale sample", "mem_available_gb": round(mem, 1)}
     full = (args.nodes, args.edges) == (1_000_000, 20_000_000) and not args.cpu_small
     if full and mem >= 128.0:
@@ -220,22 +336,20 @@ def cpu_baseline(args, ei_full=None):
             torch.set_num_threads(best_threads)
             big = data(args.nodes, args.edges, ei_full)
             times = []
-            for it in range(1 + 2):                             # 1 warm-up, best of 2
+            for it in range(2):                                 # one warm-up, one timed
                 t0 = time.time()
                 R.sage_layer_fwd_bwd(*big)
                 times.append(time.time() - t0)
             del big
-            res.update(value=args.edges / min(times[1:]), ran="full C4 configuration",
-                       small_sample_edges_per_s=Es / best,
-                       sample=f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd on the metric's own configuration: "
-                              f"N={args.nodes} E={args.edges} F={F} fp32 (the full C4 graph of the GPU line), best of 2 timed runs "
-                              f"after 1 warm-up ({', '.join(f'{t:.1f}' for t in times)} s) at {best_threads} torch threads -- the "
-                              f"best of 16/32/64 on the 1/10-scale sample ({Es / best / 1e6:.2f} M edges/s there)")
+            res.update(value=args.edges / times[1], ran="full C4 configuration", small_sample_edges_per_s=Es / best,
+                       sample=f"oracle/ref_conv.sage_layer_fwd_bwd, 1 SAGE layer fwd+bwd on the metric's own configuration "
+                              f"(N={args.nodes} E={args.edges} F={F} fp32, the graph of the GPU line): one timed run after one "
+                              f"warm-up ({times[0]:.1f} / {times[1]:.1f} s) at {best_threads} torch threads = the best of 16/32/64 "
+                              f"on a 1/10-scale sample; {where}")
         except Exception as e:                                  # e.g. the host ran out of memory after all
             res["full_c4_error"] = f"{type(e).__name__}: {e}"[:200]
     elif full:
         res["ran"] = f"1/10-scale sample (MemAvailable {mem:.0f} GB < 128 GB needed for the full C4 message tensors)"
-    res["sample"] += f", os.cpu_count()={os.cpu_count()}, cpu='{cpu_model()}'"
     return res
 
 
@@ -304,467 +418,46 @@ def control_uniform(dev, N, E, F, launches=10):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# configs block: the other BASELINE.json configs on this GPU
+# is what was timed RIGHT?
 # ---------------------------------------------------------------------------------------------------------
-def _timeit(fn, n, warm, rounds=3):
-    """ms per call: the best of `rounds` timed regions of n calls each (the configs block is a set of side measurements on a
-    box that other jobs may share: one region of one run measured 74 ms per step between regions of 6.9)"""
-    for _ in range(warm):
-        fn()
-    best = None
-    for _ in range(rounds):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n * 1e3
-        best = dt if best is None or dt < best else best
-    return best
+def timed_config_parity(ei_dev, N, x, go, conv, out, chunk=2_000_000):
+    """N = 1: the tensors of the LAST timed step (the conv on the very CSR the timed region walked: column-sorted unless
+    --plain-csr) against the SAGEConv formulas of SURVEY.md Appendix B evaluated in fp64 by plain torch ops on the GPU --
+    index_add_ over the ORIGINAL edge list in chunks, fp64 matmuls; nothing of this package.  Every row of out and dX, all of dW
+    and db.  Errors are max |diff| / max |reference|."""
+    W64, b64 = conv.weight.detach().double(), conv.bias.detach().double()
+    src, dst = ei_dev[0], ei_dev[1]
+    keep = src != dst                                           # add_remaining_self_loops drops existing loops first
+    cnt = (torch.bincount(dst[keep], minlength=N) + 1).double().view(-1, 1)
+    x64 = x.detach().double()
+
+    def spread(table, frm, to):                                # acc[to[e]] += table[frm[e]] over the kept edges, + the self loop
+        acc = table.clone()
+        for lo in range(0, src.numel(), chunk):
+            k = keep[lo: lo + chunk]
+            acc.index_add_(0, to[lo: lo + chunk][k], table[frm[lo: lo + chunk][k]])
+        return acc
+    agg = spread(x64, src, dst) / cnt
+    go64 = go.double()
+    want_out = agg @ W64 + b64
+    want_dw = agg.t() @ go64
+    del agg
+    want_db = go64.sum(0)
+    dagg = (go64 @ W64.t()) / cnt
+    del go64
+    want_dx = spread(dagg, dst, src)
+    del dagg
+
+    def rel(a, b):
+        return float((a.detach().double() - b).abs().max() / b.abs().max().clamp(min=1e-300))
+    err = {"out": rel(out, want_out), "dX": rel(x.grad, want_dx), "dW": rel(conv.weight.grad, want_dw),
+           "db": rel(conv.bias.grad, want_db)}
+    return {"parity_max_err": max(err.values()), "by_tensor": err,
+            "against": f"every row of out / dX and dW, db of the last timed step (the conv on the CSR the timed region used) against "
+                       "mean-aggregate @ W + b and its transpose evaluated in fp64 torch ops over the original edge list; max |diff| / "
+                       "max |reference|"}
 
 
-def _graph_replay_ms(step, n=200, warm=10):
-    """ms per replay of `step` captured in a HIP graph: the GPU's own time for the step's launches.  At the sizes of configs
-    1-3 an eager step is bounded by the HOST (about 40 launches of 5-25 us of GPU work each behind ~12 us of Python per
-    launch), so the eager figure moves with the host's load from region to region; the replayed one does not.  None when the
-    step cannot be captured."""
-    try:
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(s):
-            step()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
-                step()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        return _timeit(g.replay, n, warm)
-    except Exception as e:                                      # noqa: BLE001 -- a side measurement
-        sys.stderr.write(f"graph capture of a config step failed: {type(e).__name__}: {e}\n")
-        torch.cuda.synchronize()
-        return None
-
-
-def _stack_step(kind, weights, x, graph, dtype=torch.float32, norm=None, att=None, go=None):
-    """forward + backward through a stack of convs with relu between them (full batch).  ``go``: the gradient of the stack's
-    output, handed to ``backward`` as the headline's step does; None: a mean-square loss on the output drives it (configs 1-3;
-    at the C5 size that loss alone is 8 ms of elementwise kernels over [4M, 256] per step)."""
-    import npi_gnn_amd as npi
-    from npi_gnn_amd import functional as NF
-    dev = x.device
-    params = [(W.to(dev).to(dtype).requires_grad_(True), b.to(dev).to(dtype).requires_grad_(True)) for W, b in weights]
-    atts = [a.to(dev).requires_grad_(True) for a in att] if att else None
-    xin = x.to(dtype).requires_grad_(True)
-
-    def step():
-        for W, b in params:
-            W.grad = b.grad = None
-        xin.grad = None
-        h = xin
-        for k, (W, b) in enumerate(params):
-            if kind == "sage":
-                h = npi.sage_conv(h, graph, W, b)
-            elif kind == "gcn":
-                h = NF.gcn_conv(h, None, W, b, norm=norm)
-            else:
-                h = npi.gat_conv(h, graph, W, atts[k], b, heads=1, relu=True)      # F.relu(conv(h)), fused
-                continue
-            h = torch.relu(h)
-        if go is None:
-            h.float().pow(2).mean().backward()
-        else:
-            h.backward(go)
-        return h
-    return step
-
-
-def _stack_forward(kind, weights, x, graph, dtype=torch.float32, norm=None):
-    import npi_gnn_amd as npi
-    from npi_gnn_amd import functional as NF
-    dev = graph.device
-    with torch.no_grad():
-        h = x.to(dev).to(dtype)
-        for W, b in weights:
-            W, b = W.to(dev).to(dtype), b.to(dev).to(dtype)
-            h = torch.relu(npi.sage_conv(h, graph, W, b) if kind == "sage" else NF.gcn_conv(h, None, W, b, norm=norm))
-    return h.float().cpu()
-
-
-def emulated_wire(probe_args, t1_ms, timeout=300):
-    """tools/virtual_rank_probe.py in a CHILD process: rank 0's step of one sharded layer with the exchanges emulated at 800 /
-    400 / 200 GB/s (see virtual.StubCollectives(wire_gbps=)); the small exchanges on their own lane (ShardedGraph(small_group=)),
-    as the N > 1 run of this file has them"""
-    emu = {"assumptions": {"latency_us_per_exchange": 20.0, "held_cus": 16, "what": "duration = latency + wire bytes per rank / B; "
-                           "a no-op kernel holds 16 CUs for it on the communicator's stream; two communicators (small exchanges "
-                           "on their own)"}, "by_wire_GBps": {}}
-    try:
-        cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "virtual_rank_probe.py")]
-                            + list(probe_args) + ["--two-lanes", "--wire-sweep", "800,400,200"], capture_output=True, text=True,
-                            timeout=timeout)
-        for l in cp.stdout.splitlines():
-            if l.startswith("emulated wire"):
-                bw, ms = l.split()[2], float(l.split(":")[1].split("ms/step")[0])
-                emu["by_wire_GBps"][bw] = {"rank0_ms": ms, "speedup_estimate": t1_ms / ms}
-            elif " events " in l:
-                emu["rank0_ms_no_wire"] = float(l.split("events")[1].split("ms/step")[0])
-        if not emu["by_wire_GBps"]:
-            emu["error"] = (cp.stderr or cp.stdout)[-300:]
-    except Exception as e:                                  # noqa: BLE001 -- a side measurement
-        emu["error"] = f"{type(e).__name__}: {e}"[:300]
-    return emu
-
-
-def virtual_c5(dev, ei5, N5, F5, weights, att, t1_ms, W, ref=None):
-    """configs[4] in its 8-GPU form on ONE GPU: every rank's 3-layer step timed alone (collectives = stand-in copies), and --
-    ``ref`` = (x, go, out, dX, per-layer parameter gradients) of the single-GPU stack -- the same 8 ranks run once more in
-    exact lock step (npi_gnn_amd.virtual.LockStep: true collective results) and compared with it: ``parity``."""
-    from npi_gnn_amd import dist as ND
-    from npi_gnn_amd.synth import protein_mask
-    hub = protein_mask(N5).to(dev)
-    per_rank, nnz, coll = [], [], None
-    with stub_collectives(W, dev) as stub:
-        for r in range(W):
-            sg = ND.ShardedGraph(ei5, N5, r, W, dev, hub_mask=hub)
-            layers = [ND.ShardedGATLayer(sg, Wk.to(dev), att[k].to(dev), bk.to(dev)) for k, (Wk, bk) in enumerate(weights)]
-            x = torch.randn(sg.n_local, F5, device=dev).requires_grad_(True)
-            go = torch.randn(sg.n_local, F5, device=dev)
-
-            def step():                                         # from a given output gradient, as T1 (C5_1gpu.ms_per_step)
-                for l in layers:
-                    l.zero_grad()
-                x.grad = None
-                h = x
-                for l in layers:
-                    h = torch.relu(l(h))
-                h.backward(go)
-            ms, one = time_virtual_rank(step, stub, steps=2, warm=1)
-            per_rank.append(ms)
-            nnz.append(int(sg.local_nnz))
-            coll = coll or one
-            del sg, layers, x, go, step
-            torch.cuda.empty_cache()
-    res = virtual_summary(W, t1_ms, per_rank, nnz, coll, "3 x GATConv 256 (1 head) on the hub cut, N=4M E=100M, per-rank step of the "
-                          f"{W}-rank run timed alone on this GPU (collectives = local copies); T1 = C5_1gpu")
-    if ref is not None:
-        try:
-            from npi_gnn_amd.virtual import gat_stack_reference, sharded_stack_errors, stack_distance
-            x5, go5 = ref
-            params = [(Wk.to(dev), att[k].to(dev), bk.to(dev)) for k, (Wk, bk) in enumerate(weights)]
-
-            def layers_of(ps):
-                return lambda sg: [ND.ShardedGATLayer(sg, W_, a_, b_) for W_, a_, b_ in ps]
-            # ONE layer (well conditioned): strict
-            r1 = gat_stack_reference(ei5, N5, params[:1], x5, go5, relu=False)
-            e1 = sharded_stack_errors(W, ei5, N5, hub, layers_of(params[:1]), x5, go5, *r1, dev, relu_between=False)
-            p1 = e1.pop("lockstep_passes")
-            del r1
-            torch.cuda.empty_cache()
-            # the 3-layer stack of the timing, against the single-GPU stack AND against the stack's own fp32 noise floor
-            rs = gat_stack_reference(ei5, N5, params, x5, go5, relu=True)
-            fls = [stack_distance(gat_stack_reference(ei5, N5, params, x5, go5, relu=True, permute_seed=sd), rs) for sd in (5, 6)]
-            floor = {k: max(f[k] for f in fls) for k in fls[0]}
-            torch.cuda.empty_cache()
-            e3 = sharded_stack_errors(W, ei5, N5, hub, layers_of(params), x5, go5, *rs, dev, relu_between=True)
-            p3 = e3.pop("lockstep_passes")
-            del rs
-            ratio = {k: (v / floor[k] if floor[k] > 0 else None) for k, v in e3.items() if k.endswith(".l2") and not k.startswith("out")}
-            res["parity"] = {
-                "parity_max_err": max(list(e1.values()) + [e3["out"], e3["out.l2"]]),
-                "one_layer": {"by_tensor": e1, "lockstep_passes": p1},
-                "stack": {"by_tensor": e3, "fp32_noise_floor": floor, "err_over_floor": ratio,
-                          "max_err_over_floor": max(v for v in ratio.values() if v is not None), "lockstep_passes": p3},
-                "against": f"the single-GPU GATConv on the whole graph; the {W} ranks in exact lock step on this GPU (true all-gather / "
-                           "reduce-scatter / all-reduce results); every rank's rows of out and dX and the all-reduced dW / d att / db, max "
-                           "over ranks; <tensor>: max |diff| / max |reference|, <tensor>.l2: ||diff|| / ||reference||.  parity_max_err = "
-                           "every tensor of ONE layer and the output of the 3-layer stack.  The stack's GRADIENTS are reported against its "
-                           "own fp32 noise floor = the distance between two single-GPU runs that differ only in the order of the edge list (max of two "
-                           "such runs; err_over_floor on the L2 figures) "
-                           "(the backward of a deep random GAT stack is ill-conditioned: 1e-4 .. 1e-3 on this data whoever computes it)"}
-            res["parity_max_err"] = res["parity"]["parity_max_err"]
-        except Exception as e:                                  # noqa: BLE001
-            res["parity"] = {"parity_max_err": None, "error": f"{type(e).__name__}: {e}"[:300]}
-    return res
-
-
-def run_configs(dev, args, c4):
-    """ms per full-batch step (fwd+bwd over the layer stack) and, for C1-C3, the max error against the oracle outputs
-    committed under tests/golden/ (made by tests/golden/make_golden.py / make_rpi7317.py from the CPU oracle)."""
-    import npi_gnn_amd as npi
-    from npi_gnn_amd import functional as NF
-    out = {}
-    G = os.path.join(ROOT, "tests", "golden")
-
-    def guarded(name, fn):
-        try:
-            out[name] = fn()
-        except Exception as e:                                  # the headline line must survive a failing extra
-            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        torch.cuda.empty_cache()
-
-    fx = torch.load(os.path.join(G, "npinter2_graph.pt"), map_location="cpu", weights_only=False)
-    x, ei = fx["x"], fx["edge_index"].long()
-    graph = npi.CSRGraph(ei.to(dev), x.size(0))
-    _ = graph.by_src
-    norm = NF.GCNNorm(graph)
-    rows = fx["rows"]
-    shape = f"NPInter2 graph N={x.size(0)} E={ei.size(1)}"
-
-    def c1():
-        h = _stack_forward("gcn", fx["gcn64"], x, graph, norm=norm)
-        return {"workload": f"{shape}, 2 x GCNConv 178->64->64 fp32, full batch",
-                "ms_per_step": _timeit(_stack_step("gcn", fx["gcn64"], x.to(dev), graph, norm=norm), 30, 5),
-                "ms_per_step_graph": _graph_replay_ms(_stack_step("gcn", fx["gcn64"], x.to(dev), graph, norm=norm)),
-                "parity_max_abs_err": float((h[rows] - fx["gcn64_out"]).abs().max()), "parity": "oracle (unpinned: GCNConv)"}
-
-    def c2():
-        h = _stack_forward("sage", fx["sage_weights"], x, graph, dtype=torch.bfloat16)
-        ref = fx["sage3_out"]
-        sb = _stack_step("sage", fx["sage_weights"], x.to(dev), graph, dtype=torch.bfloat16)
-        sf = _stack_step("sage", fx["sage_weights"], x.to(dev), graph)
-        # eager: host-bound at this size (see _graph_replay_ms) -- the two storage types are timed alternately, best region each
-        eb = ef = None
-        for _ in range(3):
-            tb, tf = _timeit(sb, 50, 5, rounds=1), _timeit(sf, 50, 5, rounds=1)
-            eb, ef = (tb if eb is None else min(eb, tb)), (tf if ef is None else min(ef, tf))
-        return {"workload": f"{shape}, 3 x SAGEConv 178->128->128->128, bf16 storage / f32 accumulate, full batch",
-                "ms_per_step": eb, "ms_per_step_f32": ef,
-                "ms_per_step_graph": _graph_replay_ms(sb), "ms_per_step_graph_f32": _graph_replay_ms(sf),
-                "note": "ms_per_step*: eager (host-bound: ~40 launches per step); ms_per_step_graph*: the same step replayed from "
-                        "a HIP graph = the GPU's time",
-                "parity_max_err_rel_to_max": float((h[rows] - ref).abs().max() / ref.abs().max()),
-                "parity": "fp32 oracle, bf16 tolerance"}
-
-    def c3():
-        p = os.path.join(G, "rpi7317_graph.pt")
-        f3 = torch.load(p, map_location="cpu", weights_only=False)
-        x3, ei3 = f3["x"], f3["edge_index"].long()
-        g3 = npi.CSRGraph(ei3.to(dev), x3.size(0))
-        _ = g3.by_src
-        n3 = NF.GCNNorm(g3)
-        h = _stack_forward("gcn", f3["gcn256"], x3, g3, norm=n3)
-        return {"workload": f"RPI7317 graph N={x3.size(0)} E={ei3.size(1)} (7,317 positives + 7,317 seeded negatives), "
-                            "3 x GCNConv 178->256->256->256 fp32, full batch",
-                "ms_per_step": _timeit(_stack_step("gcn", f3["gcn256"], x3.to(dev), g3, norm=n3), 30, 5),
-                "ms_per_step_graph": _graph_replay_ms(_stack_step("gcn", f3["gcn256"], x3.to(dev), g3, norm=n3)),
-                "parity_max_abs_err": float((h[f3["rows"]] - f3["gcn256_out"]).abs().max()),
-                "parity": "oracle (unpinned: GCNConv)"}
-
-    def r_step():
-        # the reference's REAL regime (SURVEY 8(a) "R"): one Net_1 training step -- forward, nll_loss, backward, Adam -- on a
-        # batch of 200 enclosing subgraphs of NPInter2 fold 0, extracted on the device; eager and replayed from a HIP graph
-        import torch.nn.functional as F_
-        from npi_gnn_amd import net1
-        from npi_gnn_amd.subgraph import InteractionGraph
-        fz = torch.load(os.path.join(G, "npinter2_folds.pt"), map_location="cpu", weights_only=False)
-        fb = fz["fold0"]
-        pairs, label, Nn = fz["pairs"].long(), fz["label"].long(), fz["num_nodes"]
-        test = torch.cat([fb["test_pos"], fb["test_neg"]]).long()
-        usable = ~torch.isin(pairs[:, 0] * Nn + pairs[:, 1], test[:, 0] * Nn + test[:, 1])
-        feat = torch.cat([fb["node2vec"], fz["kmer"]], dim=1)
-        ig = InteractionGraph(pairs.to(dev), usable.to(dev), feat.to(dev), num_nodes=Nn)
-        keys, yk = pairs[usable][:800].to(dev), label[usable][:800].to(dev)
-        loader = net1.KeyLoader(ig, keys, yk, 200)
-        torch.manual_seed(0)
-        model = net1.Net_1(feat.size(1) + 1, 2).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-3, device=dev), weight_decay=1e-3, capturable=True, fused=True)
-        ep = net1.GraphedEpoch(model, loader, opt, dev)
-        ep()                                                    # eager epoch (4 batches)
-        d0 = ep.batches[0]
-
-        def eager():
-            opt.zero_grad()
-            F_.nll_loss(model(d0), d0.y).backward()
-            opt.step()
-        ms_eager = _timeit(eager, 100, 10)
-        ep()                                                    # captures every batch's step, replays it once
-        ms_replay = _timeit(ep.graphs[0].replay, 200, 10)
-        return {"workload": f"NPInter2 fold 0, first batch of 200 enclosing subgraphs ({d0.x.size(0)} nodes, "
-                            f"{d0.edge_index.size(1)} directed edges, F = {d0.x.size(1)}): one Net_1 training step "
-                            "(forward, nll_loss, backward, Adam), fp32",
-                "ms_per_step": ms_replay, "ms_per_step_eager": ms_eager,
-                "note": "ms_per_step: the step replayed from a HIP graph (net1.GraphedEpoch); the reference logs 1413.5 s for "
-                        "its 50-epoch fold = 4,200 such steps + evaluations (examples/train_npinter2.py --capture: 4.8 s)"}
-
-    guarded("C1", c1)
-    guarded("C2", c2)
-    guarded("C3", c3)
-    guarded("R_net1_step", r_step)
-    del graph, norm
-
-    # GCN / GAT layer at the C4 shape, on the headline graph
-    g4, x4, go4, F = c4["graph"], c4["x"], c4["go"], c4["F"]
-    E4 = c4["E"]
-    gen = torch.Generator().manual_seed(11)
-
-    pmc = pmc_traffic()
-    N4 = x4.size(0)
-
-    def pmc_of(key, stale_key="stale"):
-        if pmc.get(stale_key):
-            return None, f"STALE: measured on another {pmc.get(stale_key)}"
-        return pmc.get(key), (pmc.get("gat_from") if key.startswith("gat") else pmc.get("gcn_from"))
-
-    def gcn_c4():
-        conv = npi.GCNConv(F, F).to(dev)
-        n4 = NF.GCNNorm(g4)
-        xx = x4.detach().requires_grad_(True)
-
-        def step():
-            conv.weight.grad = conv.bias.grad = xx.grad = None
-            NF.gcn_conv(xx, None, conv.weight, conv.bias, norm=n4).backward(go4)
-        ms = _timeit(step, 10, 3)
-        ev = []
-        NF._PROFILE = ev
-        for _ in range(5):
-            step()
-        NF._PROFILE = None
-        torch.cuda.synchronize()
-        # SURVEY 8(d) + one f32 weight (the symmetric normalisation) per entry, self loops included
-        alg = algorithmic_bytes(E4, N4, F) + (E4 + N4) * 4
-        tr, src = pmc_of("gcn_segsum_bytes_per_launch")
-        return {"workload": f"C4 graph, 1 x GCNConv {F}->{F} fp32 fwd+bwd", "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3,
-                "roofline": agg_roofline(ev, alg, tr, "segsum_kernel<f32, 4, 1, W_ARRAY> (one launch: cut rows are finished inside it), avg of the forward and the "
-                                                      "backward launch (the latter co-resident with dW)", src)}
-
-    def gat_c4():
-        conv = npi.GATConv(F, F, heads=1).to(dev)
-        xx = x4.detach().requires_grad_(True)
-
-        def step():
-            for p in conv.parameters():
-                p.grad = None
-            xx.grad = None
-            conv(xx, g4).backward(go4)
-        ms = _timeit(step, 10, 3)
-        tags = {}
-        NF._PROFILE_TAGS = tags
-        for _ in range(5):
-            step()
-        NF._PROFILE_TAGS = None
-        torch.cuda.synchronize()
-        gb = gat_bytes(E4, N4, F)
-        roof = {}
-        for tag, kern in (("gat_fwd_aggregate", "segsum_kernel<f32, 4, 1, W_GAT_DST_PRE>: weighted aggregation, scores read back"),
-                          ("gat_bwd_fused", "segsum_kernel<f32, 4, 1, W_GAT_SRC_FUSED>: by-source aggregation + SDDMM in one gather pass")):
-            tr, src = pmc_of(tag + "_bytes_per_launch", "stale_gat")
-            roof[tag] = agg_roofline(tags.get(tag, []), gb[tag], tr, kern, src)
-        by_heads = {}
-        for Hh in (2, 4, 8):                                   # the same layer width as 2 / 4 / 8 heads of 128 / 64 / 32 channels
-            cv = npi.GATConv(F, F // Hh, heads=Hh).to(dev)
-
-            def hstep(cv=cv):
-                for p in cv.parameters():
-                    p.grad = None
-                xx.grad = None
-                cv(xx, g4).backward(go4)
-            by_heads[str(Hh)] = _timeit(hstep, 5, 2)
-            del cv
-        return {"workload": f"C4 graph, 1 x GATConv {F}->{F} (1 head) fp32 fwd+bwd", "ms_per_step": ms,
-                "edges_per_s": E4 / ms * 1e3, "ms_per_step_by_heads": by_heads, "roofline": roof}
-
-    def c4_bf16():
-        """the headline layer with bf16 STORAGE (features, weights, gradients; f32 accumulation inside the kernels, as config C2):
-        information only -- the metric's precision is f32 and `value` is the f32 number"""
-        bf = torch.bfloat16
-        conv = npi.SAGEConv(F, F).to(dev)
-        ref = conv(x4, g4).detach()
-        convb = npi.SAGEConv(F, F).to(dev)
-        convb.load_state_dict(conv.state_dict())
-        convb = convb.to(bf)
-        xb = x4.detach().to(bf).requires_grad_(True)
-        gob = go4.to(bf)
-
-        def step():
-            convb.weight.grad = convb.bias.grad = xb.grad = None
-            convb(xb, g4).backward(gob)
-        ms = _timeit(step, 10, 3)
-        ev = []
-        NF._PROFILE = ev
-        for _ in range(5):
-            step()
-        NF._PROFILE = None
-        torch.cuda.synchronize()
-        dev_rel = float((convb(xb, g4).detach().float() - ref).abs().max() / ref.abs().max())
-        # SURVEY 8(d) with s = 2 bytes per stored element: per edge F s + 4 = 516 B, per node 2 F s + 4 = 1,028 B
-        alg = algorithmic_bytes(E4, N4, F, s=2)
-        return {"workload": f"C4 graph, 1 x SAGEConv {F}->{F} fwd+bwd, bf16 storage / f32 accumulate (NOT the metric's precision)",
-                "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3, "max_dev_from_f32_output_rel": dev_rel,
-                "roofline": agg_roofline(ev, alg, None, "segsum_kernel<bf16, 4, 1, W_NONE>, avg of the forward and the backward "
-                                         "launch (the latter co-resident with dW); NOT the metric's precision", "no PMC pass "
-                                         "for the bf16 kernels: algorithmic bytes (516 B per edge, 1,028 B per node) only")}
-
-    guarded("gcn_c4", gcn_c4)
-    guarded("gat_c4", gat_c4)
-    guarded("C4_bf16_storage", c4_bf16)
-
-    if not args.skip_c5:
-        def c5():
-            from npi_gnn_amd.synth import bipartite_edge_index
-            c4.clear()                                             # release the C4 graph and features first
-            torch.cuda.empty_cache()
-            N5, E5, F5 = 4_000_000, 100_000_000, 256
-            ei5 = bipartite_edge_index(N5, E5, seed=2).to(dev)
-            g5 = npi.CSRGraph(ei5, N5, sort_columns=not args.plain_csr)
-            _ = g5.by_src
-            weights = [((torch.randn(F5, F5, generator=gen) / 16), torch.zeros(F5)) for _ in range(3)]
-            att = [torch.randn(1, 1, 2 * F5, generator=gen) * 0.1 for _ in range(3)]
-            x5 = torch.randn(N5, F5, generator=gen).to(dev)
-            go5 = torch.randn(N5, F5, generator=gen).to(dev)
-            ms_loss = _timeit(_stack_step("gat", weights, x5, g5, att=att), 3, 1, rounds=2)      # as rounds 1-3 measured it
-            st = _stack_step("gat", weights, x5, g5, att=att, go=go5)
-            ms = _timeit(st, 3, 1, rounds=2)
-            tags = {}
-            NF._PROFILE_TAGS = tags
-            st()
-            NF._PROFILE_TAGS = None
-            torch.cuda.synchronize()
-            gb = gat_bytes(E5, N5, F5)
-            # HBM bytes of the two aggregation launches at THIS size, from their own PMC passes (tools/profile_all.sh: bench.py
-            # --conv gat on this very graph); the algorithmic bytes count every gathered row, the hub rows served from L2 included
-            roof = {}
-            for tag in gb:
-                tr = None if pmc.get("stale_gat") else pmc.get("c5_" + tag + "_bytes_per_launch")
-                src = pmc.get("c5_from") if tr else (f"STALE: measured on another {pmc.get('stale_gat')}" if pmc.get("stale_gat")
-                                                     else "no PMC pass at this size: algorithmic bytes only")
-                roof[tag] = agg_roofline(tags.get(tag, []), gb[tag], tr, "as configs.gat_c4.roofline, at the C5 size (3 launches, "
-                                         "one per layer)", src)
-            res5 = {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU",
-                    "ms_per_step": ms, "edge_layers_per_s": 3 * E5 / ms * 1e3, "ms_per_step_with_mse_loss": ms_loss,
-                    "step": "forward + backward of the three layers from a given output gradient, as the headline's step "
-                            "(ms_per_step_with_mse_loss: with output.pow(2).mean() driving the backward -- 8 ms of elementwise "
-                            "kernels over [4M, 256] -- which is how rounds 1-3 timed this config)",
-                    "roofline": roof}
-            del st, g5, go5
-            x5 = x5.detach()
-            ref = (x5, torch.randn(N5, F5, generator=gen).to(dev)) if args.virtual_world > 1 else None     # inputs of the parity check
-            torch.cuda.empty_cache()
-            if args.virtual_world > 1:
-                # BASELINE.json configs[4] in its 8-GPU form, rank by rank on this GPU: the same 3-layer GATConv stack on the
-                # hub cut, a rank's output rows being the next layer's input rows (collectives = local copies, as C4_w8_virtual),
-                # then the same ranks in exact lock step against the single-GPU stack (parity)
-                try:
-                    res5["w8_virtual"] = virtual_c5(dev, ei5, N5, F5, weights, att, ms, args.virtual_world, ref=ref)
-                except Exception as e:
-                    res5["w8_virtual"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            del ei5, ref, x5
-            torch.cuda.empty_cache()
-            if args.virtual_world == 8 and "error" not in res5.get("w8_virtual", {"error": 1}):
-                # ONE GATConv layer of this size on rank 0 of 8 with the exchanges emulated (the child builds its own graph of the
-                # same shape); the single-GPU figure beside it is a third of the 3-layer step
-                res5["w8_virtual"]["emulated_wire_one_layer"] = emulated_wire(
-                    ["--conv", "gat", "--nodes", str(N5), "--edges", str(E5), "--steps", "10"], ms / 3, timeout=600)
-            return res5
-        guarded("C5_1gpu", c5)
-    return out
-
-
-# ---------------------------------------------------------------------------------------------------------
-# N > 1: is the sharded layer RIGHT?  (a scaling number without this is a claim about speed only)
-# ---------------------------------------------------------------------------------------------------------
 def sharded_parity(dev, args, world, sg, layer, x, go, ei, x_full, go_full, W, bias, att=None, samples=256):
     """After the timed region every rank runs the SINGLE-GPU layer (the plain conv of this package, itself held to the
     oracle by the -m gpu tests) over the WHOLE graph on its own GPU and compares the rows it owns of the sharded output
@@ -826,153 +519,151 @@ def sharded_parity(dev, args, world, sg, layer, x, go, ei, x_full, go_full, W, b
                        f"out_rows_fp64_formula: {samples} rows per rank against mean(x_j) @ W + b in fp64 torch ops"}
 
 
-# ---------------------------------------------------------------------------------------------------------
-# virtual world: the W shards of the multi-GPU path, one after the other on this ONE GPU
-# ---------------------------------------------------------------------------------------------------------
-def stub_collectives(W, dev):
-    """npi_gnn_amd.virtual.StubCollectives with the stand-in copies on a stream of their own: a collective is issued when its
-    input is ready and the compute streams wait for it where they consume its result -- the dependency graph RCCL's stream
-    gives the real run (the partial side runs beside the all-gather stand-in, the projection beside the reduce-scatter one)."""
-    from npi_gnn_amd.virtual import StubCollectives
-    return StubCollectives(W, copy_stream=torch.cuda.Stream(device=dev))
-
-
-def virtual_summary(W, t1, per_rank, nnz, coll, what):
-    worst = max(per_rank)
-    wire = sum(v["wire_bytes_per_rank"] for v in coll.values())
-    budget = t1 / 6.0 - worst
-    return {"what": what, "world": W, "t1_ms": t1, "per_rank_ms": per_rank, "per_rank_entries": nnz,
-            "balance": sum(per_rank) / len(per_rank) / worst, "compute_ceiling": t1 / worst,
-            "bytes_per_collective": coll, "wire_bytes_per_rank_per_step": wire,
-            "exposed_budget_ms_for_6x": budget,
-            "implied_bus_GBps": {"all_communication_hidden_under_T1_over_6": wire / (t1 / 6.0 * 1e-3) / 1e9,
-                                 "no_overlap_inside_the_exposed_budget": (wire / (budget * 1e-3) / 1e9) if budget > 0 else None}}
-
-
-def time_virtual_rank(step, stub, steps=5, warm=3):
-    for _ in range(warm):
-        step()
-    stub.log.clear()
-    step()                                                  # the collectives of ONE step, by kind
-    one = {k: dict(v) for k, v in stub.log.items()}
-    best = None
-    for _ in range(3):                                      # best of three regions (a shared box: see _timeit)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps * 1e3
-        best = dt if best is None or dt < best else best
-    return best, one
-
-
-def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
-    """SURVEY.md 8(e), what one GPU can measure of the W-GPU run: every rank's LOCAL work (its shard's kernels, host
-    launch work included) timed alone on this GPU with the collectives replaced by local copies of the same shapes, for
-    the three partitions (SAGEConv) and the sharded GATConv.  From it: the load balance, the compute-side ceiling of the
-    speed-up (T1 / max_r T_r: what W GPUs reach with free communication), the bytes every collective moves, the
-    communication time a >= 6x speed-up leaves (T1 / 6 - max_r T_r) and the bus bandwidth that implies.
-    ``only="hubs_sage"``: the SAGEConv vertex cut alone (the smaller worlds of the 1 / 2 / 4 / 8 curve)."""
-    import npi_gnn_amd as npi
-    from npi_gnn_amd import dist as ND
-    from npi_gnn_amd.synth import protein_mask
-    N, E, F = args.nodes, args.edges, args.hidden
-    gen = torch.Generator().manual_seed(3)
-    Wm = ((torch.rand(F, F, generator=gen) * 2 - 1) / F ** 0.5).to(dev)
-    bias = ((torch.rand(F, generator=gen) * 2 - 1) / F ** 0.5).to(dev)
-    att = (torch.randn(1, 1, 2 * F, generator=gen) * 0.1).to(dev)
-    # T1 of the plain GATConv on this graph (the SAGE T1 is the headline measurement)
-    conv = npi.GATConv(F, F, heads=1).to(dev)
-    xx = c4["x"].detach().requires_grad_(True)
-
-    def gat_step():
-        for p in conv.parameters():
-            p.grad = None
-        xx.grad = None
-        conv(xx, c4["graph"]).backward(c4["go"])
-    t1_gat = _timeit(gat_step, 5, 2) if only is None else None
-    del conv, xx
-
-    out = {}
-    with stub_collectives(W, dev) as stub:
-        hub = protein_mask(N).to(dev)
-        in_count = torch.bincount(ei_dev[1][ei_dev[0] != ei_dev[1]], minlength=N)
-        kinds = ("hubs_sage", "hubs_gat", "rows_sage", "edges_sage") if only is None else (only,)
-        res = {k: ([], [], None) for k in kinds}
-        for r in range(W):
-            for partition in (("hubs", "rows", "edges") if only is None else ("hubs",)):
-                if partition == "edges":
-                    sg = ND.EdgeShardedGraph(ei_dev, N, r, W, dev, in_count=in_count)
-                    x = torch.randn(N, F, device=dev).requires_grad_(True)
-                    go = torch.randn(sg.hi - sg.lo, F, device=dev)
-                    layers = [("edges_sage", ND.EdgeShardedSAGELayer(sg, Wm, bias))]
-                else:
-                    sg = ND.ShardedGraph(ei_dev, N, r, W, dev, hub_mask=hub if partition == "hubs" else None)
-                    x = torch.randn(sg.n_local, F, device=dev).requires_grad_(True)
-                    go = torch.randn(sg.n_local, F, device=dev)
-                    layers = [(partition + "_sage", ND.ShardedSAGELayer(sg, Wm, bias))]
-                    if partition == "hubs" and only is None:
-                        layers.append(("hubs_gat", ND.ShardedGATLayer(sg, Wm, att, bias)))
-                for key, layer in layers:
-                    def step(layer=layer, x=x, go=go):
-                        layer.zero_grad()
-                        x.grad = None
-                        layer(x).backward(go)
-                    ms, coll = time_virtual_rank(step, stub)
-                    res[key][0].append(ms)
-                    res[key][1].append(int(sg.local_nnz))
-                    if r == 0:
-                        res[key] = (res[key][0], res[key][1], coll)
-                del sg, x, go, layers, layer
-                torch.cuda.empty_cache()
-        notes = {"hubs_sage": "SAGEConv, protein rows replicated (vertex cut): all-gather + reduce-scatter of hub rows per direction",
-                 "rows_sage": "SAGEConv, destination-row shards: all-gather of every row per direction",
-                 "edges_sage": "SAGEConv, the north-star's literal split: a slice of the edge list per GPU, x replicated, "
-                               "all-reduce of the partial [N,F] sums per direction",
-                 "hubs_gat": "GATConv (1 head), vertex cut with the cross-rank softmax"}
-        for key, (ms, nnz, coll) in res.items():
-            out[key] = virtual_summary(W, t1_gat if key == "hubs_gat" else t1_sage_ms, ms, nnz, coll, notes[key])
-    if "hubs_sage" in out and only is None:
-        # The same rank step with the exchanges EMULATED: in front of every stand-in copy a kernel that computes nothing holds 16
-        # CUs (64 KB of LDS each, as a collective's resident workgroups hold theirs) for 20 us + wire bytes per rank / B -- an
-        # estimate of the W-GPU step under two stated assumptions (the rate B a GPU sustains over its xGMI links for these
-        # exchanges; the CUs RCCL's kernel sits on), NOT a measurement of xGMI.  Rank 0 only (the ranks are balanced to 1 %).
-        # (in a CHILD process: this one has created a dozen HIP streams by now, more than the hardware has queues, and a stand-in
-        # that holds its queue for hundreds of us then also holds whatever compute stream shares that queue)
-        out["hubs_sage"]["emulated_wire"] = emulated_wire(["--conv", "sage", "--steps", "30"], t1_sage_ms)
-    if "hubs_gat" in out and W == 8 and (N, E, F) == (1_000_000, 20_000_000, 256):
-        # the GATConv rank step is ~110 launches of a few us: eager it is bounded by the HOST and moves with the box's CPU
-        # (1.7-2.2 ms).  Its GPU time: rank 0's step replayed from a HIP graph, stand-in copies on the compute stream (capture with
-        # the copy stream's nested forks takes the HIP runtime down at capture_end, hence a CHILD process; None if it fails)
-        rep = None
-        try:
-            cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "virtual_rank_probe.py"),
-                                 "--conv", "gat", "--capture", "--inline-copies", "--steps", "50"], capture_output=True, text=True,
-                                timeout=240)
-            m = [l for l in cp.stdout.splitlines() if "events" in l and "capture=True" in l]
-            if m:
-                rep = float(m[-1].split("events")[1].split("ms/step")[0])
-        except Exception as e:                                  # noqa: BLE001 -- a side measurement
-            sys.stderr.write(f"graph replay of a GATConv rank step failed: {type(e).__name__}: {e}\n")
-        out["hubs_gat"]["rank0_ms_graph_replay"] = rep
-        out["hubs_gat"]["compute_ceiling_graph_replay"] = (t1_gat / rep) if rep else None
-        out["hubs_gat"]["graph_replay_note"] = ("rank 0's step replayed from a HIP graph (stand-in copies on the compute stream): the "
-                                                "GPU's time; per_rank_ms is the eager step, which the host bounds at this size")
-    out["note"] = ("one GPU, ranks run one after the other; collectives are local copies of the same shapes on a stream of their own "
-                   "(issued when their input is ready, waited for where their result is consumed: the real run's dependency graph), "
-                   "so per_rank_ms is local compute + host launch work only; wire bytes: all-gather / reduce-scatter of S bytes move "
-                   "S (W-1)/W per rank, an all-reduce 2 S (W-1)/W; N > 1 itself is NOT measured here")
-    return out
-
-
-# ---------------------------------------------------------------------------------------------------------
 def dist_is_up() -> bool:
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()
 
 
+# ---------------------------------------------------------------------------------------------------------
+# the final line
+# ---------------------------------------------------------------------------------------------------------
+def _num(v, nd=6):
+    """a JSON-safe number with a bounded mantissa (strict JSON: no NaN / Infinity)"""
+    if v is None or isinstance(v, (bool, int, str)):
+        return v
+    v = float(v)
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    return float(f"{v:.{nd}g}")
+
+
+def _short(s, n=160):
+    return s if (s is None or len(s) <= n) else s[: n - 3] + "..."
+
+
+def configs_summary(cfg: dict) -> dict:
+    """one number per side config for the compact line (ms per step unless the key says otherwise)"""
+    out = {}
+
+    def ms(name, key="ms_per_step"):
+        v = cfg.get(name)
+        if not isinstance(v, dict):
+            return None
+        if "error" in v:
+            return "error"
+        if "skipped" in v:
+            return "skipped"
+        return _num(v.get(key), 4)
+    for name in ("C1", "C3"):
+        if name in cfg:
+            out[name] = ms(name, "ms_per_step_graph") or ms(name)
+            out[name + "_eager"] = ms(name)
+    if "C2" in cfg:
+        out["C2"] = ms("C2", "ms_per_step_graph") or ms("C2")
+        out["C2_eager"] = ms("C2")
+        out["C2_f32"] = ms("C2", "ms_per_step_graph_f32")
+    if "R_net1_step" in cfg:
+        out["R_net1_step"] = ms("R_net1_step")
+        out["R_net1_step_eager"] = ms("R_net1_step", "ms_per_step_eager")
+    for name in ("gcn_c4", "gat_c4", "C4_bf16_storage", "C5_1gpu"):
+        if name in cfg:
+            out[name] = ms(name)
+    for k, v in cfg.items():
+        if k.startswith("C4_w") and isinstance(v, dict):
+            hs = v.get("hubs_sage")
+            W = k[4:].split("_")[0]
+            if isinstance(hs, dict) and "per_rank_ms" in hs:
+                out[f"w{W}_hubs_sage_rank_ms_max"] = _num(max(hs["per_rank_ms"]), 4)
+                out[f"w{W}_hubs_sage_ceiling"] = _num(hs.get("compute_ceiling"), 4)
+            for w_, c in (v.get("hubs_sage_by_world") or {}).items():
+                if w_ != W and isinstance(c, dict):
+                    out[f"w{w_}_hubs_sage_ceiling"] = _num(c.get("compute_ceiling"), 4)
+            hg = v.get("hubs_gat")
+            if isinstance(hg, dict) and "per_rank_ms" in hg:
+                out[f"w{W}_hubs_gat_rank_ms_max"] = _num(max(hg["per_rank_ms"]), 4)
+            if "error" in v:
+                out[f"w{W}_virtual"] = "error"
+    return out
+
+
+def compact_line(res: dict) -> str:
+    """The LAST stdout line: strict JSON, target <= 4 KB, never above LINE_CAP.  `res` is the full record (written to
+    bench_detail.json); this keeps the contract's keys, the roofline and cpu_baseline blocks and one number per side config."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: _num(res.get(k), 7) for k in keep}
+    line["ms_per_step_repeats"] = [_num(v, 5) for v in res.get("ms_per_step_repeats") or []]
+    cfg = dict(res.get("config") or {})
+    at = cfg.get("autotune")
+    if isinstance(at, dict):
+        cfg["autotune"] = {"chosen": at.get("chosen"), "error": _short(at.get("error"), 120),
+                           "ms_per_step": {k: _num(v, 4) for k, v in (at.get("ms_per_step") or {}).items()}}
+    cfg["fallback"] = _short(cfg.get("fallback"), 200)
+    line["config"] = cfg
+    if "parity_max_err" in res:
+        line["parity_max_err"] = _num(res["parity_max_err"], 3)
+        p = res.get("parity") or {}
+        line["parity"] = {"by_tensor": {k: _num(v, 3) for k, v in (p.get("by_tensor") or {}).items()},
+                          "against": _short(p.get("against"), 260), "error": _short(p.get("error"), 200)}
+    r = res.get("roofline") or {}
+    roof = {k: _num(r.get(k), 6) for k in ("bound", "kernel", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
+                                           "achieved", "peak", "unit", "frac", "frac_algorithmic", "frac_traffic", "traffic")}
+    roof["kernel"] = _short(roof.get("kernel"), 120)
+    roof["traffic_source"] = _short(r.get("traffic_source"), 230)
+    cu = r.get("control_uniform")
+    if isinstance(cu, dict):
+        roof["control_uniform"] = ({"error": _short(cu["error"], 120)} if "error" in cu else
+                                   {"avg_launch_ms": _num(cu.get("avg_launch_ms"), 5), "frac_algorithmic": _num(cu.get("frac_algorithmic"), 4),
+                                    "frac_traffic": _num(cu.get("frac_traffic"), 4),
+                                    "frac": _num(cu.get("frac_traffic") or cu.get("frac_algorithmic"), 4),
+                                    "what": "same kernel, sources and targets uniform over all rows (nothing cache-resident)"})
+    line["roofline"] = roof
+    pj = res.get("projection")
+    if isinstance(pj, dict):
+        line["projection"] = {"bound": "mfma", "achieved": _num(pj.get("achieved"), 5), "peak": pj.get("peak"), "unit": "TFLOP/s",
+                              "frac": _num(pj.get("frac"), 4), "achieved_f32_equivalent": _num(pj.get("achieved_f32_equivalent"), 5),
+                              "per_gemm_ms": {k: _num(v, 4) for k, v in (pj.get("per_gemm_ms") or {}).items()},
+                              "what": _short(pj.get("frac_note"), 100)}
+    ex = res.get("exchange")
+    if isinstance(ex, dict):
+        line["exchange"] = {"exposed_ms_per_step": _num(ex.get("exposed_ms_per_step"), 4),
+                            "by_collective_ms_per_step": {k: _num(v, 4) for k, v in (ex.get("by_collective_ms_per_step") or {}).items()}}
+    ao = res.get("aggregation_only")
+    if isinstance(ao, dict):
+        line["aggregation_only"] = {"edges_per_s": _num(ao.get("edges_per_s"), 5), "ms_per_step": _num(ao.get("ms_per_step"), 5)}
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": _num(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": _short(cb.get("sample"), 420), "ran": _short(cb.get("ran"), 120)}
+    if isinstance(res.get("configs"), dict):
+        line["configs"] = configs_summary(res["configs"])
+    line["detail"] = res.get("detail")
+    line["wall_s"] = res.get("wall_s")
+    s = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(s) > LINE_CAP:                                       # never expected; drop the optional blocks rather than lose the line
+        for k in ("configs", "exchange", "projection", "aggregation_only", "parity"):
+            line.pop(k, None)
+            s = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(s) <= LINE_CAP:
+                break
+    return s
+
+
+def emit(res: dict) -> None:
+    """detail file first (best effort), then the compact line as the last thing on stdout"""
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            json.dump(res, f, indent=1, default=str)
+        res["detail"] = DETAIL_FILE
+    except OSError as e:
+        res["detail"] = f"not written: {e}"[:120]
+    sys.stdout.flush()
+    print(compact_line(res), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
+    t_start = time.time()
     args = parse()
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
@@ -986,6 +677,13 @@ def main():
         print(json.dumps({"rank_check": True, "rank": rank, "world": world, "local_rank": local_rank,
                           "cuda_initialized": torch.cuda.is_initialized()}), flush=True)
         return
+    sharded = world > 1 or args.force_sharded
+    is_worker = os.environ.get("NPI_BENCH_WORKER") == "1"
+    if sharded and not is_worker and not args.control_only:
+        raise SystemExit(supervise(sys.argv[1:], rank, world))
+    if is_worker and os.environ.get("NPI_BENCH_FAKE_WORKER"):
+        raise SystemExit(fake_worker(rank, world))
+    attempt = int(os.environ.get("NPI_BENCH_ATTEMPT", "0")) if is_worker else 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -996,15 +694,13 @@ def main():
     rccl = world > 1 or (args.force_sharded and os.environ.get("NPI_BENCH_RCCL_SOLO") == "1")
     if rccl:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a FRESH file store per attempt: nothing of a failed attempt (keys in the launcher's store, half-open sockets) is met again
+        store = f"file://{os.path.join(rendezvous_dir(), f'store_{attempt}')}"
+        dist.init_process_group("nccl", init_method=store, rank=rank, world_size=world, device_id=dev)
         if world == 1:
-            os.environ.setdefault("MASTER_PORT", str(_free_port()))
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
             from npi_gnn_amd import dist as _ND
             _ND.ALWAYS_COMMUNICATE = True
-        else:
-            dist.init_process_group("nccl", device_id=dev)
 
     import npi_gnn_amd as npi
     from npi_gnn_amd import functional as NF
@@ -1014,8 +710,7 @@ def main():
     if args.control_only:
         print(json.dumps({"control_uniform": control_uniform(dev, N, E, F)}), flush=True)
         return
-    sharded = world > 1 or args.force_sharded
-    fallback = None                                             # set when the sharded pre-flight step fell back (below)
+    fallback = None
     ei = bipartite_edge_index(N, E, seed=args.graph_seed)
     g = torch.Generator().manual_seed(1)
     x_full = torch.randn(N, F, generator=g)
@@ -1027,12 +722,15 @@ def main():
     gemm_events = []                      # (name, flops, start, end) around every projection GEMM
     NF._PROFILE = None
     c4 = {}
+    autotune = None
+    last = {}                             # the output of the most recent step (N = 1: the parity check reads it)
 
     if not sharded:
         t0 = time.time()
+        ei_dev = ei.to(dev)
         # every row's entries in column order (CSRGraph(sort_columns=): a second key for the build's sort, once per graph;
         # nothing for this SAGEConv line, 0.8-1.2 % for the GATConv configs -- EXPERIMENTS A22); --plain-csr: list order
-        graph = npi.CSRGraph(ei.to(dev), N, sort_columns=not args.plain_csr)
+        graph = npi.CSRGraph(ei_dev, N, sort_columns=not args.plain_csr)
         _ = graph.by_src
         torch.cuda.synchronize()
         t_build = time.time() - t0
@@ -1054,24 +752,25 @@ def main():
             else:
                 out = conv(x, graph)
             out.backward(go)
+            last["out"] = out
         seg_launch_bytes = [algorithmic_bytes(E, N, F)]
     else:
         from npi_gnn_amd import dist as ND
         from npi_gnn_amd.schedule import CONSERVATIVE, DEFAULT
         from npi_gnn_amd.synth import protein_mask
         t0 = time.time()
+        conservative = args.conservative or attempt > 0
+        if attempt > 0:
+            fallback = "second attempt on the conservative schedule after: " + first_attempt_failure()
         # every rank ships only ITS slice of the edge list to its GPU; the partitioner routes the edges (dist.route_edges)
         ei_mine = ei[:, rank * E // world: (rank + 1) * E // world] if world > 1 else ei
         att_full = torch.randn(1, 1, 2 * F, generator=g) * 0.1
         # a second communicator for the small exchanges (per-row scalars, the softmax's MAX, parameter-gradient sums): on the main
         # one they would queue behind the hub-row tables issued before them (ShardedGraph(small_group=))
         small_group = None
-        if rccl:
+        if rccl and not conservative:
             import torch.distributed as dist
-            try:
-                small_group = dist.new_group()
-            except Exception as e:                              # noqa: BLE001 -- one communicator then (config.communicators says so)
-                sys.stderr.write(f"rank {rank}: no second communicator ({type(e).__name__}: {e}); every exchange on the first\n")
+            small_group = dist.new_group()
 
         def build_sharded(schedule, one_communicator=False):
             if args.partition == "edges":
@@ -1090,7 +789,6 @@ def main():
             if sg_.B is not None:
                 nbytes.append(algorithmic_bytes(sg_.B.nnz_max, sg_.part.hub_rows, F) - sg_.part.hub_rows * F * 4)
             return sg_, layer_, x_, sg_.shard(go_full).to(dev), nbytes
-        sg, layer, x, go, seg_launch_bytes = build_sharded(DEFAULT)
 
         def step():
             layer.zero_grad()
@@ -1098,44 +796,27 @@ def main():
             out = layer(x)
             out.backward(go)
 
-        # Pre-flight: ONE step of the layer as configured.  If any rank raises (a code path that no test box could run: the
-        # schedule with the third stream, the merge-free hub layout, the split projection, the rank-2 store epilogue have only
-        # met RCCL through this bench), every rank falls back to the round-2 schedule -- classic layout, one extra stream, one
-        # GEMM per direction -- rebuilds its shard and says so in the line (`config.fallback`), instead of leaving the scaling
-        # run without a number.  The parity block below checks whichever schedule ran.
-        err = None
+        # Set-up phase.  Anything that raises here ends THIS process with a non-zero code (the error in err_<attempt>_<rank>): the
+        # supervisors then end every rank's worker and start fresh ones on the conservative schedule.  No rank tries to recover
+        # in-process (a HIP fault is sticky) and no collective is needed to agree on the failure.
         try:
-            if os.environ.get("NPI_BENCH_INJECT_FAILURE") == "1":
+            sg, layer, x, go, seg_launch_bytes = build_sharded(CONSERVATIVE if conservative else DEFAULT)
+            if os.environ.get("NPI_BENCH_INJECT_FAILURE") == "1" and attempt == 0:
                 raise RuntimeError("injected pre-flight failure (NPI_BENCH_INJECT_FAILURE=1)")
-            step()
+            step()                                              # pre-flight: ONE step of the layer as configured
             torch.cuda.synchronize()
-        except Exception as e:                                  # noqa: BLE001
-            err = f"{type(e).__name__}: {e}"[:300]
-        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
-        if rccl:
-            import torch.distributed as dist
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad) != 0:
-            fallback = err or "another rank failed its pre-flight step"
-            del sg, layer, x, go
-            torch.cuda.empty_cache()
-            sg, layer, x, go, seg_launch_bytes = build_sharded(CONSERVATIVE)      # an argument of the shard, no process-wide switch
-        torch.cuda.synchronize()
-        t_build = time.time() - t0
-        # Set-up, N > 1 only: three arrangements whose worth depends on what RCCL's kernels do beside ours -- nothing one GPU can
-        # tell (EXPERIMENTS A9, A16): the projection GEMMs on 16 CUs fewer (a persistent GEMM whose workgroup finds its CU held
-        # by a collective starts late with its full share of tiles) the hub rows of dAgg projected first, and every exchange on ONE communicator.  Each candidate
-        # is built, run 5 + 2 x 8 steps between barriers (MAX over ranks), and the fastest becomes THE schedule of the timed region;
-        # every rank takes the same decision from the same all-reduced numbers.  `config.autotune` lists what was measured.
-        autotune = None
-        if fallback is None and args.partition == "hubs" and args.conv in ("sage", "gcn") and not args.no_autotune and (
-                rccl or os.environ.get("NPI_BENCH_AUTOTUNE_SOLO") == "1"):
-            cands = {"default": DEFAULT, "gemm_reserve_cus=16": DEFAULT.but(gemm_reserve_cus=16),
-                     "early_hub_gather": DEFAULT.but(early_hub_gather=True),
-                     "gemm_reserve_cus=16,early_hub_gather": DEFAULT.but(gemm_reserve_cus=16, early_hub_gather=True),
-                     "one communicator": DEFAULT}                   # (the default has the small exchanges on a second one)
-            autotune, best = {}, ("default", None)
-            try:
+            t_build = time.time() - t0
+            # N > 1 only: three arrangements whose worth depends on what RCCL's kernels do beside ours -- nothing one GPU can tell
+            # (EXPERIMENTS A9, A16): the projection GEMMs on 16 CUs fewer, the hub rows of dAgg projected first, and every exchange
+            # on ONE communicator.  Each candidate is built, run 5 + 2 x 8 steps between barriers (MAX over ranks), and the fastest
+            # becomes THE schedule of the timed region; every rank takes the same decision from the same all-reduced numbers.
+            if (not conservative and args.partition == "hubs" and args.conv in ("sage", "gcn") and not args.no_autotune
+                    and (rccl or os.environ.get("NPI_BENCH_AUTOTUNE_SOLO") == "1")):
+                cands = {"default": DEFAULT, "gemm_reserve_cus=16": DEFAULT.but(gemm_reserve_cus=16),
+                         "early_hub_gather": DEFAULT.but(early_hub_gather=True),
+                         "gemm_reserve_cus=16,early_hub_gather": DEFAULT.but(gemm_reserve_cus=16, early_hub_gather=True),
+                         "one communicator": DEFAULT}                   # (the default has the small exchanges on a second one)
+                tuned, best = {}, ("default", None)
                 for name, sch in cands.items():
                     if name != "default":
                         del sg, layer, x, go
@@ -1156,17 +837,25 @@ def main():
                         if rccl:
                             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                         regions.append(float(tt.item()))
-                    autotune[name] = min(regions)
-                    if best[1] is None or autotune[name] < best[1]:
-                        best = (name, autotune[name])
+                    tuned[name] = min(regions)
+                    if best[1] is None or tuned[name] < best[1]:
+                        best = (name, tuned[name])
                 if best[0] != list(cands)[-1]:                       # the last candidate is the one that is built right now
                     del sg, layer, x, go
                     torch.cuda.empty_cache()
                     sg, layer, x, go, seg_launch_bytes = build_sharded(cands[best[0]], best[0] == "one communicator")
-                autotune = {"ms_per_step": autotune, "chosen": best[0]}
-            except Exception as e:                              # noqa: BLE001 -- keep the default, say why
-                autotune = {"error": f"{type(e).__name__}: {e}"[:300], "chosen": "default"}
-                sg, layer, x, go, seg_launch_bytes = build_sharded(DEFAULT)
+                autotune = {"ms_per_step": tuned, "chosen": best[0]}
+            if rccl:
+                dist.barrier()                                  # every rank is through its set-up
+            torch.cuda.synchronize()
+        except Exception as e:                                  # noqa: BLE001 -- fatal for the attempt, by design
+            worker_note("err", f"{type(e).__name__}: {e}"[:300])
+            if is_worker:
+                sys.stderr.write(f"rank {rank}: set-up phase failed: {type(e).__name__}: {e}\n")
+                sys.stderr.flush()
+                os._exit(3)                                     # no destructors, no collective: the supervisors take over
+            raise
+        worker_note("ok")
 
     def barrier():
         if rccl:
@@ -1183,9 +872,9 @@ def main():
         step()
     barrier()
     captured = False
+    eager_step = step
     if args.capture and not sharded:
         # the same kernels on the same two streams, recorded once: the replayed step does not depend on the host's pace
-        eager_step = step
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
             eager_step()
@@ -1234,6 +923,15 @@ def main():
                                     att=att_full if args.conv == "gat" and args.partition != "edges" else None)
         except Exception as e:                                  # on every rank alike (same code, same data)
             parity = {"parity_max_err": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    elif args.conv == "sage" and not args.no_parity:
+        try:
+            if captured:
+                eager_step()                                    # the tensors of a replay live in the graph's pool: one eager step
+            torch.cuda.synchronize()
+            parity = timed_config_parity(ei_dev, N, x, go, conv, last["out"])
+        except Exception as e:                                  # noqa: BLE001 -- reported, never hidden
+            parity = {"parity_max_err": None, "error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
 
     # dominant kernel: segsum (fwd + bwd launches have the same algorithmic bytes when F_in == F_out)
     seg_ms = [s.elapsed_time(e) for s, e in seg_events]
@@ -1269,34 +967,7 @@ def main():
         exchange = {"exposed_ms_per_step": sum(exposed.values()) / args.steps,
                     "by_collective_ms_per_step": {k: v / args.steps for k, v in sorted(exposed.items())},
                     "note": "rank 0; stall of the waiting stream at each collective (HIP events around work.wait())"}
-    split_on = bool(int(npi.load().npi_gemm_mode(-1)))
-    extra = {
-        "exchange": exchange,
-        "aggregation_only": {"edges_per_s": (E * args.steps / (seg_total_ms * 1e-3)) if seg_ms and world == 1 else None,
-                             "ms_per_step": seg_total_ms / args.steps if seg_ms else None,
-                             "note": "gather + segmented reduction, forward + transposed backward launches of one layer"},
-        "projection": {
-            "bound": "mfma",
-            "kernels": "fwd + bwd_data: gemm_split_ws_kernel (f32 operands split 3-way into bf16, six "
-                       "v_mfma_f32_32x32x16_bf16 per f32 product, f32 accumulate)" if split_on else
-                       "fwd + bwd_data: exact-f32 v_mfma_f32_32x32x2_f32 kernels",
-            "achieved_f32_equivalent": solo_tf, "unit": "TFLOP/s",
-            # the pipe the kernel runs on: six bf16 MFMA flops are issued per f32-equivalent flop
-            "achieved": (6.0 * solo_tf) if (solo_tf and split_on) else solo_tf,
-            "peak": MFMA_BF16_PEAK_TF if split_on else MFMA_F32_PEAK_TF,
-            "frac": ((6.0 * solo_tf / MFMA_BF16_PEAK_TF) if split_on else (solo_tf / MFMA_F32_PEAK_TF)) if solo_tf else None,
-            "frac_note": "issued bf16-MFMA flops (6 x f32-equivalent) / dense bf16 MFMA peak" if split_on else
-                         "f32 flops / f32 MFMA peak",
-            "f32_equivalent_vs_f32_mfma_peak": (solo_tf / MFMA_F32_PEAK_TF) if solo_tf else None,
-            # what the bf16 pipe sustains on random operands (the chip lowers its clock under MFMA load): measured with a bare
-            # v_mfma_f32_32x32x16_bf16 loop, tools/micro/mfma_bf16_rate.hip, 1.59-1.90 PF/s box to box
-            "sustained_random_operands": {"peak": MFMA_BF16_RANDOM_TF, "unit": "TFLOP/s", "source": "offline micro-benchmark",
-                                          "frac": (6.0 * solo_tf / MFMA_BF16_RANDOM_TF) if (solo_tf and split_on) else None},
-            "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},
-            "per_gemm_tflops_f32_equivalent": {k: v[0] / (v[1] * 1e-3) / 1e12 for k, v in gem.items() if v[1] > 0},
-            "note": "bwd_weight (gemm_dw_split_kernel: both operands split on the fly) is timed while it shares the CUs "
-                    "with the backward aggregation on a second stream; alone it takes 0.93 ms"},
-    }
+    split_on = NF.GEMM_FLAGS == 0 and os.environ.get("NPI_GEMM_SPLIT", "1") != "0"
     res = None
     if rank == 0:
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1310,12 +981,11 @@ def main():
                               "algorithmic bytes / live duration / peak (no current PMC pass on file for this configuration; "
                               "this figure counts every gathered row as an HBM read and can exceed 1 when caches serve gathers)",
                 "traffic": traffic if traffic else ("stale" if pmc.get("stale") else None),
-                "traffic_source": (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately; FETCH_SIZE x "
-                                   f"{pmc.get('fetch_scale')} gfx950 calibration), {pmc.get('from')}, measured "
-                                   f"on this very source (sha {pmc.get('source_sha16')}) -- not measured in this run")
+                "traffic_source": (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE x {pmc.get('fetch_scale')} gfx950 calibration + WRITE_SIZE, "
+                                   f"separate runs), {pmc.get('from')}, on this very kernel source (sha checked); durations are live")
                 if traffic else (f"STALE: {pmc.get('from')} was measured on another {pmc.get('stale')}; frac falls back to "
                                  "frac_algorithmic" if pmc.get("stale") else None),
-                "kernel": "segsum_kernel (one launch per aggregation: rows cut by an item boundary are finished inside it), avg of fwd and bwd launches",
+                "kernel": "segsum_kernel (one launch per aggregation, cut rows finished inside it), avg of fwd and bwd launches",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": seg_avg_ms,
                 "launches_timed": len(seg_ms)}
         res = {
@@ -1333,8 +1003,27 @@ def main():
                        "autotune": autotune if sharded else None,
                        "communicators": (2 if getattr(sg, "small_group", None) is not getattr(sg, "group", None) else 1) if sharded else None},
             "roofline": roof,
+            "exchange": exchange,
+            "aggregation_only": {"edges_per_s": (E * args.steps / (seg_total_ms * 1e-3)) if seg_ms and world == 1 else None,
+                                 "ms_per_step": seg_total_ms / args.steps if seg_ms else None,
+                                 "note": "gather + segmented reduction, forward + transposed backward launches of one layer"},
+            "projection": {
+                "bound": "mfma",
+                "kernels": "fwd + bwd_data: gemm_split_ws_kernel (f32 operands split 3-way into bf16, six "
+                           "v_mfma_f32_32x32x16_bf16 per f32 product, f32 accumulate)" if split_on else
+                           "fwd + bwd_data: exact-f32 v_mfma_f32_32x32x2_f32 kernels",
+                "achieved_f32_equivalent": solo_tf, "unit": "TFLOP/s",
+                # the pipe the kernel runs on: six bf16 MFMA flops are issued per f32-equivalent flop
+                "achieved": (6.0 * solo_tf) if (solo_tf and split_on) else solo_tf,
+                "peak": MFMA_BF16_PEAK_TF if split_on else MFMA_F32_PEAK_TF,
+                "frac": ((6.0 * solo_tf / MFMA_BF16_PEAK_TF) if split_on else (solo_tf / MFMA_F32_PEAK_TF)) if solo_tf else None,
+                "frac_note": "issued bf16-MFMA flops (6 x f32-equivalent) / dense bf16 MFMA peak" if split_on else
+                             "f32 flops / f32 MFMA peak",
+                "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},
+                "per_gemm_tflops_f32_equivalent": {k: v[0] / (v[1] * 1e-3) / 1e12 for k, v in gem.items() if v[1] > 0},
+                "note": "bwd_weight (gemm_dw_split_kernel: both operands split on the fly) is timed while it shares the CUs "
+                        "with the backward aggregation on a second stream; alone it takes 0.93 ms"},
         }
-        res.update(extra)
         if parity is not None:
             res["parity_max_err"] = parity["parity_max_err"]
             res["parity"] = parity
@@ -1344,7 +1033,7 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
-    # ---- extras after the timed region (one GPU only): control, per-config block, CPU baseline -------------
+    # ---- after the timed region (one GPU only): control, per-config summary, CPU baseline -----------------
     if world == 1 and not sharded:
         del x_full, go_full
         if not args.no_control and args.conv == "sage":
@@ -1352,36 +1041,48 @@ def main():
                 res["roofline"]["control_uniform"] = control_uniform(dev, N, E, F)
             except Exception as e:
                 res["roofline"]["control_uniform"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        vw = None
-        if args.virtual_world > 1 and args.conv == "sage":
-            try:
-                ei_dev = ei.to(dev)
-                vw = virtual_world(dev, args, ei_dev, c4, ms_per_step, args.virtual_world)
-                # the smaller worlds of the metric's 1 / 2 / 4 / 8 curve, vertex cut only: compute-side ceilings per world size
-                curve = {}
-                for w_ in (2, 4):
-                    if w_ < args.virtual_world:
-                        v_ = virtual_world(dev, args, ei_dev, c4, ms_per_step, w_, only="hubs_sage")["hubs_sage"]
-                        curve[str(w_)] = {k: v_[k] for k in ("per_rank_ms", "balance", "compute_ceiling", "wire_bytes_per_rank_per_step")
-                                          if k in v_}
-                if "hubs_sage" in vw:
-                    curve[str(args.virtual_world)] = {k: vw["hubs_sage"][k] for k in ("per_rank_ms", "balance", "compute_ceiling",
-                                                                                      "wire_bytes_per_rank_per_step") if k in vw["hubs_sage"]}
-                vw["hubs_sage_by_world"] = curve
-                del ei_dev
-            except Exception as e:
-                vw = {"error": f"{type(e).__name__}: {e}"[:300]}
-            torch.cuda.empty_cache()
         if not args.no_configs and args.conv == "sage":
-            del graph, x, go, step, conv
-            res["configs"] = run_configs(dev, args, c4)
-        if vw is not None:
-            res.setdefault("configs", {})[f"C4_w{args.virtual_world}_virtual"] = vw
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_extras as X
+            quick = not args.extras
+            deadline = (time.time() + args.configs_budget) if quick else None
+            vw = None
+            if args.virtual_world > 1:
+                # what one GPU can measure of the W-GPU run: every rank's step timed alone, collectives = local copies.
+                # default run: the vertex cut of SAGEConv at W ranks; --extras: every partition, GATConv, 2 / 4 ranks, emulated wire
+                try:
+                    Wv = args.virtual_world
+                    if quick:
+                        vw = X.virtual_world(dev, args, ei_dev, c4, ms_per_step, Wv, only="hubs_sage")
+                        curve = {}
+                        for w_ in (2, 4):                       # the smaller worlds of the metric's 1 / 2 / 4 / 8 curve (ceilings)
+                            if w_ < Wv and time.time() + 6 < deadline - 20:
+                                v_ = X.virtual_world(dev, args, ei_dev, c4, ms_per_step, w_, only="hubs_sage")["hubs_sage"]
+                                curve[str(w_)] = {k: v_[k] for k in ("per_rank_ms", "balance", "compute_ceiling") if k in v_}
+                        vw["hubs_sage_by_world"] = curve
+                    else:
+                        vw = X.virtual_world(dev, args, ei_dev, c4, ms_per_step, Wv)
+                        curve = {}
+                        for w_ in (2, 4):
+                            if w_ < Wv:
+                                v_ = X.virtual_world(dev, args, ei_dev, c4, ms_per_step, w_, only="hubs_sage")["hubs_sage"]
+                                curve[str(w_)] = {k: v_[k] for k in ("per_rank_ms", "balance", "compute_ceiling",
+                                                                     "wire_bytes_per_rank_per_step") if k in v_}
+                        vw["hubs_sage_by_world"] = curve
+                except Exception as e:
+                    vw = {"error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
+            del ei_dev, graph, x, go, step, eager_step, conv
+            last.clear()
+            res["configs"] = X.run_configs(dev, args, c4, quick=quick, deadline=deadline)
+            if vw is not None:
+                res["configs"][f"C4_w{args.virtual_world}_virtual"] = vw
     if not args.no_cpu_baseline:
         # rank 0, after the process group is gone (the other ranks have left): the N > 1 line carries the CPU path timed in the
         # same run as well -- the same sample as the N = 1 line, so the two are comparable
         res["cpu_baseline"] = cpu_baseline(args, ei)
-    print(json.dumps(res), flush=True)
+    res["wall_s"] = round(time.time() - t_start, 1)
+    emit(res)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from _util import GRAD_REL, rel_max
 from oracle import ref_conv as R
 
 pytestmark = pytest.mark.gpu
@@ -45,19 +46,23 @@ def _make_layer(ND, layer_kind, sg, W, b, dev, F):
     return ND.ShardedGATLayer(sg, W.to(dev), _att(F, H).to(dev), b.to(dev), heads=H)
 
 
-def _reference(layer_kind, ei, x, W, b, go, F):
+def _reference(layer_kind, ei, x, W, b, go, F, fp64=False):
+    """the oracle's layer; ``fp64``: evaluated (and returned) in double -- the reference of the parameter-gradient bars"""
+    keep = (lambda t: t) if fp64 else (lambda t: t.float())
     if layer_kind == "sage":
+        if fp64:
+            return R.sage_layer_fwd_bwd(x.double(), ei, W.double(), b.double(), go.double())
         return R.sage_layer_fwd_bwd(x, ei, W, b, go)
     xr, Wr, br = (t.double().clone().requires_grad_(True) for t in (x, W, b))      # fp64: hub rows are long
     if layer_kind == "gcn":
         out = R.gcn_conv(xr, ei, Wr, br)
         out.backward(go.double())
-        return tuple(t.float() for t in (out.detach(), xr.grad, Wr.grad, br.grad))
+        return tuple(keep(t) for t in (out.detach(), xr.grad, Wr.grad, br.grad))
     H = int(layer_kind[3:])
     att = _att(F, H).double().requires_grad_(True)
     out = R.gat_conv(xr, ei, Wr, att, br, heads=H)
     out.backward(go.double())
-    return tuple(t.float() for t in (out.detach(), xr.grad, Wr.grad, br.grad, att.grad))
+    return tuple(keep(t) for t in (out.detach(), xr.grad, Wr.grad, br.grad, att.grad))
 
 
 def _worker(rank, world, port, N, E, F, kind, layer_kind, q):
@@ -118,11 +123,11 @@ def test_two_ranks_one_gpu_hip_backend(dev, kind, N, E, layer_kind):
     part = ND.HubPartition(N, world, hub)
     assert torch.allclose(part.unshard([res[r][0] for r in range(world)]), ref_out, atol=1e-4, rtol=1e-4)
     assert torch.allclose(part.unshard([res[r][1] for r in range(world)]), ref_dx, atol=1e-4, rtol=1e-4)
+    ref64 = _reference(layer_kind, ei, x, W, b, go, F, fp64=True)          # parameter gradients: 1e-5 of max against fp64
     for r in range(world):
-        assert torch.allclose(res[r][2], ref_dw, atol=1e-2, rtol=1e-3)
-        assert torch.allclose(res[r][3], ref_db, atol=1e-2, rtol=1e-3)
+        assert rel_max(res[r][2], ref64[2]) <= GRAD_REL and rel_max(res[r][3], ref64[3]) <= GRAD_REL
         if layer_kind.startswith("gat"):
-            assert torch.allclose(res[r][4], ref[4], atol=1e-2, rtol=1e-3)
+            assert rel_max(res[r][4], ref64[4]) <= GRAD_REL
 
 
 @pytest.mark.parametrize("world", [1, 3, 8])
@@ -142,8 +147,9 @@ def test_virtual_ranks_gcn_gat_on_one_gpu(dev, world, layer_kind):
     part = ND.HubPartition(N, world, protein_mask(N))
     assert torch.allclose(part.unshard(outs), ref[0], atol=1e-4, rtol=1e-4)
     assert torch.allclose(part.unshard(dxs), ref[1], atol=1e-4, rtol=1e-4)
+    dw64 = _reference(layer_kind, ei, x, W, b, go, F, fp64=True)[2]
     for dw in dws:
-        assert torch.allclose(dw, ref[2], atol=1e-2, rtol=1e-3)
+        assert rel_max(dw, dw64) <= GRAD_REL
 
 
 def _run_virtual(ND, world, layer_kind, ei, N, F, x, go, W, b, hub, dev, schedule=None):
@@ -194,8 +200,7 @@ def test_world_one_sharded_path_equals_single_gpu_conv(dev, hubs):
     own = sg.own
     assert torch.allclose(out, ref[own], atol=1e-5, rtol=1e-5)
     assert torch.allclose(xl.grad, xr.grad[own], atol=1e-5, rtol=1e-5)
-    assert torch.allclose(layer.weight.grad, conv.weight.grad, atol=1e-3, rtol=1e-4)
-    assert torch.allclose(layer.bias.grad, conv.bias.grad, atol=1e-3, rtol=1e-4)
+    assert rel_max(layer.weight.grad, conv.weight.grad) <= GRAD_REL and rel_max(layer.bias.grad, conv.bias.grad) <= GRAD_REL
 
 
 def _rccl_solo_worker(port, q):
@@ -311,7 +316,7 @@ def test_world_one_edge_sharded_baseline_equals_single_gpu_conv(dev):
     ref.backward(go)
     assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
     assert torch.allclose(xl.grad, xr.grad, atol=1e-5, rtol=1e-5)
-    assert torch.allclose(layer.weight.grad, conv.weight.grad, atol=1e-3, rtol=1e-4)
+    assert rel_max(layer.weight.grad, conv.weight.grad) <= GRAD_REL
 
 
 @pytest.mark.parametrize("layer_kind", ["sage", "gat1"])
@@ -408,7 +413,7 @@ def test_emulated_wire_holds_cus_for_the_stated_time_and_changes_no_result(dev):
     g = torch.Generator().manual_seed(1)
     Wm, b = (torch.randn(F, F, generator=g) / F ** 0.5).to(dev), torch.randn(F, generator=g).to(dev)
     res = {}
-    for bw in (None, 50.0):
+    for bw in (None, 5.0):
         with StubCollectives(W, copy_stream=torch.cuda.Stream(device=dev), wire_gbps=bw) as stub:
             sg = ND.ShardedGraph(ei, N, 1, W, dev, hub_mask=protein_mask(N).to(dev))
             layer = ND.ShardedSAGELayer(sg, Wm, b)
@@ -423,7 +428,7 @@ def test_emulated_wire_holds_cus_for_the_stated_time_and_changes_no_result(dev):
                 out = layer(x); out.backward(go)
             torch.cuda.synchronize()
             res[bw] = (out.detach().clone(), x.grad.clone(), (time.perf_counter() - t0) / 5)
-    assert torch.equal(res[None][0], res[50.0][0]) and torch.equal(res[None][1], res[50.0][1])
+    assert torch.equal(res[None][0], res[5.0][0]) and torch.equal(res[None][1], res[5.0][1])
     # a GATConv rank step with its small exchanges on their own lane: the same numbers as on one lane, emulated wire or not
     from npi_gnn_amd.virtual import SMALL_LANE
     att = (torch.randn(1, 1, 2 * F, generator=g) * 0.1).to(dev)
@@ -441,4 +446,6 @@ def test_emulated_wire_holds_cus_for_the_stated_time_and_changes_no_result(dev):
             gat[(lanes, bw)] = (out.detach().clone(), x.grad.clone(), layer.weight.grad.clone(), layer.att.grad.clone())
     for key in ((2, None), (2, 50.0)):
         assert all(torch.equal(a_, b_) for a_, b_ in zip(gat[(1, None)], gat[key])), key
-    assert res[50.0][2] > res[None][2] + 1e-4                      # four exchanges of ~7.7 MB at 50 GB/s + latency: >= 0.3 ms more
+    # four exchanges of ~7.7 MB at 5 GB/s = 6 ms of wire time per step, far above what the host's launch pace can hide (at
+    # 50 GB/s the 0.7 ms disappeared behind a 0.96 ms host-bound step on a slower box: round 5)
+    assert res[5.0][2] > res[None][2] + 1e-3

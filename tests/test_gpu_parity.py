@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 ATOL = 1e-4
 RTOL = 1e-4
+from _util import GRAD_REL, rel_max  # noqa: E402
 
 
 def rand_edges(N, E, seed, hub=None):
@@ -269,8 +270,9 @@ def test_sage_conv_fwd_bwd_matches_oracle(dev, N, E, Fi, Fo, sym):
     out.backward(go.to(dev))
     assert torch.allclose(out.detach().cpu(), ref_out, atol=ATOL, rtol=RTOL)
     assert torch.allclose(xd.grad.cpu(), ref_dx, atol=ATOL, rtol=RTOL)
-    assert torch.allclose(Wd.grad.cpu(), ref_dw, atol=ATOL * N ** 0.5, rtol=1e-3)
-    assert torch.allclose(bd.grad.cpu(), ref_db, atol=ATOL * N ** 0.5, rtol=1e-3)
+    # parameter gradients (sums over all N rows): max |diff| / max |ref| <= 1e-5 against the oracle evaluated in fp64
+    _, _, dw64, db64 = R.sage_layer_fwd_bwd(x.double(), ei, W.double(), b.double(), go.double())
+    assert rel_max(Wd.grad, dw64) <= GRAD_REL and rel_max(bd.grad, db64) <= GRAD_REL
 
 
 def test_sage_conv_edge_weight_matches_oracle(dev):
@@ -297,8 +299,9 @@ def test_sage_conv_edge_weight_matches_oracle(dev):
     out.backward(go.to(dev))
     assert torch.allclose(out.detach().cpu(), ref.detach(), atol=ATOL, rtol=RTOL)
     assert torch.allclose(xd.grad.cpu(), xr.grad, atol=ATOL, rtol=RTOL)
-    assert torch.allclose(conv.weight.grad.cpu(), Wr.grad, atol=1e-3, rtol=1e-4)
-    assert torch.allclose(conv.bias.grad.cpu(), br.grad, atol=1e-3, rtol=1e-4)
+    x6, W6, b6 = (t.double().clone().requires_grad_(True) for t in (x, W, b))
+    R.sage_conv(x6, ei, W6, b6, edge_weight=ew.double()).backward(go.double())
+    assert rel_max(conv.weight.grad, W6.grad) <= GRAD_REL and rel_max(conv.bias.grad, b6.grad) <= GRAD_REL
     # without weights the same module call is the reference's plain layer
     plain = conv(x.to(dev), ei.to(dev)).detach().cpu()
     assert torch.allclose(plain, R.sage_conv(x, ei, W, b).detach(), atol=ATOL, rtol=RTOL)
@@ -330,8 +333,9 @@ def test_gcn_conv_fwd_bwd_matches_oracle(dev, weighted, improved, Fi, Fo):
     out.backward(go.to(dev))
     assert torch.allclose(out.detach().cpu(), ref.detach(), atol=ATOL, rtol=RTOL)
     assert torch.allclose(xd.grad.cpu(), xr.grad, atol=ATOL, rtol=RTOL)
-    assert torch.allclose(Wd.grad.cpu(), Wr.grad, atol=ATOL * N ** 0.5, rtol=1e-3)
-    assert torch.allclose(bd.grad.cpu(), br.grad, atol=ATOL * N ** 0.5, rtol=1e-3)
+    x6, W6, b6 = (t.double().clone().requires_grad_(True) for t in (x, W, b))
+    R.gcn_conv(x6, ei, W6, b6, None if ew is None else ew.double(), improved).backward(go.double())
+    assert rel_max(Wd.grad, W6.grad) <= GRAD_REL and rel_max(bd.grad, b6.grad) <= GRAD_REL
 
 
 def test_modules_drop_into_a_net1_style_stack(dev):
@@ -417,8 +421,8 @@ def test_sharded_layer_world1_matches_single_gpu_layer(dev):
     ref_out, ref_dx, ref_dw, ref_db = R.sage_layer_fwd_bwd(x, ei, W, b, go)
     assert torch.allclose(out.detach().cpu(), ref_out, atol=ATOL, rtol=RTOL)
     assert torch.allclose(xl.grad.cpu(), ref_dx, atol=ATOL, rtol=RTOL)
-    assert torch.allclose(layer.weight.grad.cpu(), ref_dw, atol=ATOL * 60, rtol=1e-3)
-    assert torch.allclose(layer.bias.grad.cpu(), ref_db, atol=ATOL * 60, rtol=1e-3)
+    _, _, dw64, db64 = R.sage_layer_fwd_bwd(x.double(), ei, W.double(), b.double(), go.double())
+    assert rel_max(layer.weight.grad, dw64) <= GRAD_REL and rel_max(layer.bias.grad, db64) <= GRAD_REL
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 256, 256), (128 * 5 + 3, 128, 384), (4096, 64, 128), (130, 256, 128)])
@@ -908,7 +912,9 @@ def test_sage_conv_normalize_true_matches_the_oracle(dev):
     ref.backward(go)
     assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-4)
     assert torch.allclose(xd.grad.cpu(), xr.grad, atol=1e-5, rtol=1e-3)
-    assert torch.allclose(conv.weight.grad.cpu(), Wr.grad, atol=1e-4, rtol=1e-3)
+    x6, W6, b6 = (t.double().clone().requires_grad_(True) for t in (x, Wr.detach(), br.detach()))
+    torch.nn.functional.normalize(R.sage_conv(x6, ei, W6, b6), p=2.0, dim=-1).backward(go.double())
+    assert rel_max(conv.weight.grad, W6.grad) <= GRAD_REL and rel_max(conv.bias.grad, b6.grad) <= GRAD_REL
 
 
 @pytest.mark.parametrize("item_entries", [64, 256])
