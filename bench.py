@@ -141,6 +141,14 @@ def rendezvous_dir(world: int = 0) -> str:
     return d
 
 
+def _write_atomic(path: str, text: str) -> None:
+    """a marker file appears with its content (another rank may read it the moment it exists)"""
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
 def supervise(argv, rank: int, world: int) -> int:
     """The process torch.distributed.run started for this rank: it makes NO GPU call.  It runs the rank's worker (this file with
     NPI_BENCH_WORKER=1) as a child and watches the launch's rendezvous directory: attempt a has FAILED for everybody as soon as
@@ -165,7 +173,7 @@ def supervise(argv, rank: int, world: int) -> int:
                 return 0
             if rc is not None:
                 failed = f"rank {rank}: worker exit code {rc}"
-            elif any(f.startswith(f"fail_{attempt}_") for f in os.listdir(rdv)):
+            elif any(f.startswith(f"fail_{attempt}_") and ".tmp" not in f for f in os.listdir(rdv)):
                 failed = "another rank's worker failed"
             elif not os.path.exists(os.path.join(rdv, f"ok_{attempt}_{rank}")) and time.time() - t0 > limit:
                 failed = f"rank {rank}: set-up phase not finished after {limit:.0f} s"
@@ -176,8 +184,7 @@ def supervise(argv, rank: int, world: int) -> int:
         errf = os.path.join(rdv, f"err_{attempt}_{rank}")
         if os.path.exists(errf):
             why += ": " + open(errf).read()[:300]
-        with open(os.path.join(rdv, f"fail_{attempt}_{rank}"), "w") as f:
-            f.write(why)
+        _write_atomic(os.path.join(rdv, f"fail_{attempt}_{rank}"), why)
         if p.poll() is None:                                    # this rank's worker, by pid: it may sit in a collective for ever
             p.kill()
             p.wait()
@@ -191,15 +198,14 @@ def worker_note(kind: str, text: str = "") -> None:
     if os.environ.get("NPI_BENCH_WORKER") != "1":
         return
     a, r = os.environ.get("NPI_BENCH_ATTEMPT", "0"), os.environ.get("RANK", "0")
-    with open(os.path.join(rendezvous_dir(), f"{kind}_{a}_{r}"), "w") as f:
-        f.write(text)
+    _write_atomic(os.path.join(rendezvous_dir(), f"{kind}_{a}_{r}"), text)
 
 
 def first_attempt_failure():
     """why attempt 0 failed, for `config.fallback` of the second attempt's line"""
     rdv = rendezvous_dir()
-    why = [open(os.path.join(rdv, f)).read()[:300] for f in sorted(os.listdir(rdv)) if f.startswith("fail_0_")]
-    first_hand = [w for w in why if not w.startswith("another rank")]       # the rank that failed, not the ones that followed
+    why = [open(os.path.join(rdv, f)).read()[:300] for f in sorted(os.listdir(rdv)) if f.startswith("fail_0_") and ".tmp" not in f]
+    first_hand = [w for w in why if w and not w.startswith("another rank")]  # the rank that failed, not the ones that followed
     return (first_hand or why or ["attempt 0 failed"])[0]
 
 

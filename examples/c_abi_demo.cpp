@@ -1,7 +1,8 @@
 // Plain C++ host (no Python, no torch) driving the C ABI of include/npi_gnn.h: one SAGEConv forward
 //   out = mean_{j in N(i) U {i}} x_j  @ W + b            (PyG 1.4.2 SAGEConv, reference src/classes.py:62)
 // on a small random graph, checked against a CPU loop.  Shows what a non-Python caller binds:
-//   npi_csr_workspace_bytes / npi_csr_build  ->  npi_segsum_carry_elems / npi_segsum  ->  npi_linear_fwd
+//   npi_csr_workspace_bytes / npi_csr_build_ex  ->  npi_segsum_carry_elems / npi_segsum_ex  ->  npi_linear_workspace_bytes /
+//   npi_linear_fwd_ex  (ABI 3: every scratch buffer is the caller's; the library allocates nothing and keeps no state)
 // build:  hipcc --offload-arch=gfx950 -I include examples/c_abi_demo.cpp -L npi_gnn_amd -lnpi_gnn -Wl,-rpath,$PWD/npi_gnn_amd -o /tmp/c_abi_demo
 #include <hip/hip_runtime.h>
 
@@ -59,15 +60,20 @@ int main() {
     void* ws = device_alloc<char>((size_t)ws_bytes);
     if (!d_src || !d_dst || !d_x || !d_W || !d_b || !rowptr || !col || !eid || !rowidx || !item_row || !status || !ws) return 2;
     // key = destination, value = source: rows are the targets, as scatter_mean(x_j, edge_index[1]) groups them
-    NPI_CALL(npi_csr_build(d_dst, d_src, E, N, /*add_self_loops=*/1, rowptr, col, eid, rowidx, item_row, item_edges, status, ws, ws_bytes, stream));
+    NPI_CALL(npi_csr_build_ex(d_dst, d_src, E, N, /*n_cols=*/N, /*add_self_loops=*/1, /*loop_col_offset=*/0, NPI_CSR_DROP_EQUAL, rowptr, col, eid,
+                              rowidx, item_row, item_edges, status, ws, ws_bytes, stream));
     float* agg = device_alloc<float>(N * Fin);
     float* carry = device_alloc<float>((size_t)npi_segsum_carry_elems(nnz_max, item_edges, Fin));
     float* out = device_alloc<float>(N * Fout);
-    if (!agg || !carry || !out) return 2;
+    const int64_t gemm_ws_bytes = npi_linear_workspace_bytes(Fin, Fout);          // the re-laid weight matrix lives in caller memory
+    void* gemm_ws = device_alloc<char>((size_t)gemm_ws_bytes);
+    if (!agg || !carry || !out || !gemm_ws) return 2;
     // the scratch holds arrival counters: zero it ONCE after allocating it (every launch leaves them at zero again)
     HIP_OK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)npi_segsum_carry_elems(nnz_max, item_edges, Fin), stream));
-    NPI_CALL(npi_segsum(rowptr, col, item_row, item_edges, /*w=*/nullptr, N, nnz_max, d_x, Fin, agg, Fin, Fin, NPI_F32, /*mean=*/1, /*bias=*/nullptr, carry, stream));
-    NPI_CALL(npi_linear_fwd(agg, Fin, d_W, Fout, d_b, /*rowscale=*/nullptr, out, Fout, N, Fin, Fout, /*relu=*/0, stream));
+    NPI_CALL(npi_segsum_ex(rowptr, col, item_row, item_edges, /*w=*/nullptr, N, nnz_max, d_x, Fin, /*x2=*/nullptr, /*split=*/0, agg, Fin, Fin, NPI_F32,
+                           /*mean=*/1, /*bias=*/nullptr, carry, stream));
+    NPI_CALL(npi_linear_fwd_ex(agg, Fin, d_W, Fout, d_b, /*rowscale=*/nullptr, out, Fout, N, Fin, Fout, /*relu=*/0, NPI_F32, /*flags=*/0, gemm_ws,
+                               gemm_ws_bytes, stream));
     std::vector<float> got(N * Fout);
     HIP_OK(hipMemcpyAsync(got.data(), out, got.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));

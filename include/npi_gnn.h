@@ -11,15 +11,12 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer borrowed from the caller (PyTorch's caching allocator);
- *     the library never frees or retains the caller's memory, and the *_ex entry points never allocate: every
- *     scratch buffer is a caller workspace with a size query next to it.  (Two legacy GEMM entry points,
- *     npi_linear_fwd[_t] and npi_linear_bwd_data[_t], have no workspace argument and take 6*K*N bytes for the
- *     duration of the call from the stream-ordered allocator, hipMallocAsync / hipFreeAsync.)
- *   - no entry point's RESULT depends on process-wide state except through the two documented legacy switches
- *     (npi_gemm_mode, npi_dw_shared), which only the legacy GEMM entry points consult; calls on different
- *     streams from different threads are independent.  The item size of a CSR is an explicit argument
- *     (item_edges, next to item_row) of the build and of every consumer; npi_small_graph_entries only moves
- *     the HINT npi_item_edges() returns to callers that have not decided yet;
+ *     the library never frees or retains the caller's memory and NO entry point allocates (ABI 3: the library
+ *     imports no hipMalloc* / hipFree*): every scratch buffer is a caller workspace with a size query next to it;
+ *   - the library keeps NO process-wide state and reads no environment variable (ABI 3: the setters npi_gemm_mode,
+ *     npi_dw_shared, npi_small_graph_entries of ABI 2 and the entry points that consulted them are gone): the GEMM
+ *     arithmetic, the dW grid regime and the item size of a CSR are arguments of the calls they concern; calls on
+ *     different streams from different threads are independent.  npi_item_edges() is a pure function of its argument;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     every call is asynchronous on it and performs no host synchronisation;
  *   - return value: 0 = ok, <0 = error (text via npi_last_error(), thread-local); no C++
@@ -79,18 +76,10 @@ int npi_abi_version(void);
  *   status[1]    : int32 device word, bit 0 = out-of-range id seen
  * ------------------------------------------------------------------------------------------ */
 int64_t npi_csr_workspace_bytes(int64_t E, int64_t N);
-/* recommended item size for a new CSR of capacity nnz_max: 64 below npi_small_graph_entries, NPI_ITEM_EDGES from there on.
- * A hint only -- nothing that consumes a CSR calls it. */
+/* recommended item size for a new CSR of capacity nnz_max: 64 below 2^22 entries, NPI_ITEM_EDGES from there on.  A pure
+ * function and a hint only -- nothing that consumes a CSR calls it; a caller that wants the other size passes it. */
 int64_t npi_item_edges(int64_t nnz_max);
-/* the capacity at which that hint switches (default 2^22; NPI_SMALL_GRAPH_ENTRIES in the environment presets it): n > 0 sets
- * it and returns the previous value, n <= 0 only returns it.  Changing it never affects a CSR that already exists. */
-int64_t npi_small_graph_entries(int64_t n);
 int64_t npi_num_items(int64_t nnz_max, int64_t item_edges);   /* ceil(nnz_max / item_edges); -1 for an item size that does not exist */
-int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
-                  int add_self_loops,
-                  int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* rowidx,
-                  int32_t* item_row, int64_t item_edges, int32_t* status,
-                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Same build with separate row and column id spaces, for a destination-row SHARD of the graph on
  * one GPU: keys are local row ids in [0, N), values index a feature table of
@@ -125,7 +114,7 @@ int npi_edge_positions(const int32_t* eid, const int32_t* rowptr, int64_t N, int
  *   w == NULL  : all ones (SAGE);  otherwise one f32 per CSR entry (GCN norm / GAT alpha)
  *   x, out     : [N, F] row-major, leading dimension ldx / ldo (elements), dtype f32 or bf16
  *                (bf16 storage, f32 accumulation)
- *   item_row, item_edges : as the CSR was built (npi_csr_build / npi_csr_filter)
+ *   item_row, item_edges : as the CSR was built (npi_csr_build_ex / npi_csr_filter)
  *   carry      : f32 scratch, npi_segsum_carry_elems(nnz_max, item_edges, F) elements: the partial sums of rows cut by a
  *                workgroup boundary and the agent-scope arrival counters through which the LAST workgroup to deliver a
  *                partial of a row sums that row's chain inside the same launch (in a fixed order => bitwise reproducible;
@@ -134,14 +123,10 @@ int npi_edge_positions(const int32_t* eid, const int32_t* rowptr, int64_t N, int
  *                two launches that may run CONCURRENTLY need two buffers.
  * ------------------------------------------------------------------------------------------ */
 int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, int64_t F);
-int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
-               const float* w, int64_t N, int64_t nnz_max,
-               const void* x, int64_t ldx, void* out, int64_t ldo, int64_t F, int dtype,
-               int mean, const float* bias, float* carry, void* stream);
-/* The same reduction over a TWO-PART feature table: an entry with col[p] < split reads row col[p] of x, any other
- * entry row col[p] - split of x2 (same leading dimension and dtype).  One rank of the sharded layers
- * (npi_gnn_amd/dist.py) gathers from [hub rows received from all ranks ; its own rows] without
- * copying its own rows behind the received ones.  x2 == NULL: one table, as npi_segsum. */
+/* x2 != NULL: a TWO-PART feature table -- an entry with col[p] < split reads row col[p] of x, any other entry row
+ * col[p] - split of x2 (same leading dimension and dtype).  One rank of the sharded layers (npi_gnn_amd/dist.py, SURVEY.md
+ * 8(e)) gathers from [hub rows received from all ranks ; its own rows] without copying its own rows behind the received
+ * ones.  x2 == NULL (split ignored): one table. */
 int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                   const float* w, int64_t N, int64_t nnz_max,
                   const void* x, int64_t ldx, const void* x2, int64_t split,
@@ -164,8 +149,6 @@ int npi_row_inv_count(const int32_t* rowptr, int64_t N, float* inv_cnt, void* st
 int npi_entry_weights(const int32_t* eid, const int32_t* rowidx, const int32_t* rowptr,
                       const float* edge_w, const float* loop_w_node, float fill,
                       int64_t N, int64_t nnz_max, float* w_entry, void* stream);
-int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
-                    void* stream);
 /* Backward of the ReLU that SAGEConv(..., relu=True) applies in its projection epilogue (autograd's threshold_backward):
  * dz[r, c] = y[r, c] > 0 ? dy[r, c] : 0 over M rows of F floats, y = the layer's (post-ReLU) output. */
 /* Measurement support (no reference counterpart): `workgroups` workgroups that each hold 64 KB of a CU's LDS for `nanoseconds` --
@@ -190,51 +173,34 @@ int npi_l2_normalize_rows_bwd(const float* dy, int64_t ldd, const float* y, int6
 /* ------------------------------------------------------------------------------------------
  * Dense projection on the matrix cores -- replaces `torch.matmul(aggr_out, self.weight) + bias`
  * (SAGEConv.update / GCNConv.forward) and its autograd backward.  f32 in, f32 out, f32 accumulate on
- * the matrix cores, error at f32-rounding level in both arithmetics (see npi_gemm_mode).
+ * the matrix cores, error at f32-rounding level in both arithmetics (the `flags` of the entry points below).
  *
- *   npi_linear_fwd      : C[M,N]  = act( rowscale_m * (A[M,K] @ W[K,N]) + bias[N] )
- *   npi_linear_bwd_data : dA[M,K] = rowscale_m * (dC[M,N] @ W[K,N]^T)
- *   npi_linear_bwd_weight: dW[K,N] = A[M,K]^T @ dC[M,N],  db[N] = colsum(dC)   (db may be NULL)
- *                          deterministic split over M; workspace f32
+ *   npi_linear_fwd_ex       : C[M,N]  = act( rowscale_m * (A[M,K] @ W[K,N]) + bias[N] )
+ *   npi_linear_bwd_data_ex  : dA[M,K] = rowscale_m * (dC[M,N] @ W[K,N]^T)
+ *   npi_linear_bwd_weight_ex: dW[K,N] = A[M,K]^T @ dC[M,N],  db[N] = colsum(dC)   (db may be NULL)
+ *                             deterministic split over M; workspace f32
+ * GEMM arithmetic of f32 storage: the default (flags 0) is the 3-way bf16 split of both operands on the bf16 matrix cores (six
+ * v_mfma_f32_32x32x16_bf16 per product tile, f32 accumulate, error at f32-rounding level; csrc/gemm_f32.hip) -- used by
+ * fwd / bwd_data on full 128 x 128 tiles when K % 32 == 0 and rows are 16-byte aligned, and by bwd_weight when K % 128 == 0,
+ * N % 128 == 0, M >= 4096 (both operands split on the fly, gemm_dw_split_kernel); everything else (ragged strips, other
+ * shapes) and every call with NPI_GEMM_EXACT_F32 runs the exact-f32 kernels (v_mfma_f32_32x32x2_f32).
  * ------------------------------------------------------------------------------------------ */
-/* GEMM arithmetic of the f32 entry points: 0 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 3-way bf16
- * split of both operands on the bf16 matrix cores (six v_mfma_f32_32x32x16_bf16 per product tile, f32
- * accumulate, error at f32-rounding level; csrc/gemm_f32.hip).  Returns the previous mode; any other
- * argument only queries.  Process-wide; initial value 1 unless env NPI_GEMM_SPLIT=0.
- * Used by npi_linear_fwd and npi_linear_bwd_data on full 128 x 128 tiles when K % 32 == 0 and rows are
- * 16-byte aligned, and by npi_linear_bwd_weight when K % 128 == 0, N % 128 == 0, M >= 4096 (both operands split on the
- * fly, gemm_dw_split_kernel); everything else (ragged strips, other shapes, bf16 storage) runs the exact-f32 kernels. */
-int npi_gemm_mode(int mode);
 
-int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                   const float* rowscale, float* C, int64_t ldc,
-                   int64_t M, int64_t K, int64_t N, int relu, void* stream);
-int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
-                        const float* rowscale, float* dA, int64_t ldda,
-                        int64_t M, int64_t K, int64_t N, void* stream);
 /* out[N] = column sums of X[M,N] (GCNConv / GATConv bias gradient).  workspace f32: npi_colsum_workspace_elems(M, N)
  * elements for the finest row chunking; ceil(M/2048)*N is the minimum that is accepted (coarser chunks, slower on
  * small M). */
 int64_t npi_colsum_workspace_elems(int64_t M, int64_t N);
 int npi_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, float* workspace,
                int64_t workspace_elems, void* stream);
-/* Grid regime of npi_linear_bwd_weight: 0 (default) = the kernel has the GPU to itself (~4 workgroups per CU),
- * 1 = it shares the CUs with an HBM-bound kernel on another stream (about 3 workgroups per 4 CUs).
- * Returns the previous value; any other argument only queries.  Process-wide. */
-int npi_dw_shared(int shared);
 int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, int64_t N);
-int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t lddc,
-                          float* dW, int64_t lddw, float* db,
-                          int64_t M, int64_t K, int64_t N,
-                          float* workspace, int64_t workspace_elems, void* stream);
 
-/* Per-call forms (what npi_gnn_amd/functional.py binds): the arithmetic and the grid regime are ARGUMENTS, the
- * scratch for the re-laid weight matrix is a caller workspace -- no process-wide switch is read, nothing is allocated.
- *   flags     : 0 = follow npi_gemm_mode(); NPI_GEMM_EXACT_F32 / NPI_GEMM_SPLIT_BF16 force one arithmetic for this call
- *   workspace : npi_linear_workspace_bytes(K, N) bytes, 16-byte aligned (NULL: stream-ordered allocation as the legacy
- *               entry points do)
+/* The arithmetic and the grid regime are ARGUMENTS, the scratch for the re-laid weight matrix is a caller workspace -- no
+ * process-wide switch exists, nothing is allocated.
+ *   flags     : 0 = the default arithmetic (3-way bf16 split for f32 storage); NPI_GEMM_EXACT_F32 forces the exact-f32 kernels
+ *               for this call (NPI_GEMM_SPLIT_BF16 names the default explicitly)
+ *   workspace : npi_linear_workspace_bytes(K, N) bytes, 16-byte aligned, REQUIRED (NPI_ERR_WORKSPACE otherwise)
  *   shared    : npi_linear_bwd_weight_ex: 1 = the GEMM shares the CUs with an HBM-bound kernel on another stream
- *               (about 3 workgroups per 4 CUs), 0 = it has the GPU to itself (see npi_dw_shared)
+ *               (about 3 workgroups per 4 CUs), 0 = it has the GPU to itself (~4 workgroups per CU)
  *
  * NON-FINITE OPERANDS (what replaces torch.matmul at PyG 1.4.2 SAGEConv.update / its autograd):
  *   NPI_GEMM_EXACT_F32  is an fp32 fmaf chain: an Inf operand gives +-Inf in the products it takes part in (NaN against a
@@ -246,7 +212,7 @@ int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t 
  *                       |x| > 3.3895e38 against small weights, a finite number).  NaN operands give
  *                       NaN in both.  Finite results are unaffected (error <= 3 * 2^-24 |a||b| per product).  A model that
  *                       has diverged therefore reads NaN instead of Inf; callers that test `isinf` on activations must
- *                       test `!isfinite`, or pass NPI_GEMM_EXACT_F32 (npi_gemm_mode(0) / NPI_GEMM_SPLIT=0 process-wide).
+ *                       test `!isfinite`, or pass NPI_GEMM_EXACT_F32.
  *                       Pinned by tests/test_gpu_parity.py::test_non_finite_operands_of_the_projection_gemms. */
 #define NPI_GEMM_EXACT_F32 1
 #define NPI_GEMM_SPLIT_BF16 2
@@ -289,9 +255,6 @@ int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t
 
 /* The same three GEMMs with A / W / C / bias / dW / db stored as `dtype` (NPI_F32 or NPI_BF16; bf16
  * storage, f32 MFMA accumulation, f32 rowscale and workspace) -- BASELINE.json configs[1]. */
-int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
-                     const float* rowscale, void* C, int64_t ldc,
-                     int64_t M, int64_t K, int64_t N, int relu, int dtype, void* stream);
 /* C = A W (f32, no bias) and, from the accumulators on their way to C, the row dots sc0[m] = <C[m, :], att[:N]>,
  * sc1[m] = <C[m, :], att[N:]> (att: [2 N]; sc0 / sc1: [M]): GATConv's `x = torch.mm(x, self.weight)` together with the two
  * halves of `(torch.cat([x_i, x_j], dim=-1) * self.att).sum(dim=-1)` per NODE (PyG 1.4.2 gat_conv.py forward / message, one
@@ -304,7 +267,7 @@ int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N);
 int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C, int64_t ldc,
                           float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
                           void* stream);
-/* dA = dC W^T + row0 (x) col0 + row1 (x) col1 (f32; row* are [M], col* [K] vectors): npi_linear_bwd_data with a rank-2 term
+/* dA = dC W^T + row0 (x) col0 + row1 (x) col1 (f32; row* are [M], col* [K] vectors): npi_linear_bwd_data_ex with a rank-2 term
  * added in the store epilogue of the matrix-core kernel -- no read-modify-write pass over dA or dC.  GATConv backward
  * (PyG 1.4.2 GATConv.message's `(x_i, x_j) * att` terms, reference call site src/classes.py:48-52 via BASELINE configs[4]): the
  * attention terms g_dst (x) W att_dst + g_src (x) W att_src of dX.  Only shapes the kernel covers completely:
@@ -323,13 +286,6 @@ int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int
 int npi_gat_rank2_cols(const float* W, int64_t ldw, const float* att, int64_t K, int64_t C, float* U, void* stream);
 int npi_gat_rank2_tail(const float* P, const float* W, int64_t ldw, const float* att, int64_t K, int64_t C, float* dw, int64_t lddw,
                        float* datt, void* stream);
-int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
-                          const float* rowscale, void* dA, int64_t ldda,
-                          int64_t M, int64_t K, int64_t N, int dtype, void* stream);
-int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t lddc,
-                            void* dW, int64_t lddw, void* db,
-                            int64_t M, int64_t K, int64_t N,
-                            float* workspace, int64_t workspace_elems, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GATConv (PyG 1.4.2; absent from the reference tree, BASELINE.json configs[4]).  H heads of C
@@ -354,13 +310,6 @@ int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t 
  * ------------------------------------------------------------------------------------------ */
 int npi_gat_scores(const float* hfeat, int64_t ldh, const float* att, int64_t N, int64_t H, int64_t C,
                    float* a_dst, float* a_src, void* stream);
-int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
-                      int64_t N, int64_t nnz_max, const float* x, int64_t ldx, float* out, int64_t ldo,
-                      int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
-                      const float* s, float negative_slope, int by_source, const float* bias,
-                      const float* g_dst, const float* g_src, const float* att,
-                      const float* alpha, const int32_t* alpha_map,
-                      float* carry, void* stream);
 /* npi_gat_aggregate over a two-part table (x2 / split as in npi_segsum_ex). */
 int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                          int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
@@ -394,11 +343,6 @@ int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_
                       int64_t N, int64_t H, int64_t C, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                    int64_t N, int64_t H, int64_t C, float* D, void* stream);
-int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
-                      int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
-                      const float* dout, int64_t ldd, int64_t H, int64_t C,
-                      const float* a_dst, const float* a_src, const float* m, const float* s,
-                      const float* D, float negative_slope, float* dz, float* alpha_out, void* stream);
 /* npi_gat_edge_grad with a two-part gathered table (hfeat2 / split) and, swap != 0, the roles of rows and columns
  * exchanged -- the same dz seen from a by-SOURCE CSR: rows are source nodes (`dout` = their hfeat rows, a_src indexed
  * by row), columns are target nodes (`hfeat` = the gathered dOut rows; a_dst, m, s, D indexed by column).  The sharded
@@ -434,9 +378,6 @@ int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const in
                              float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
                              const float* bias, int relu, float* carry, void* stream);
 int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C);
-int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
-                          int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* workspace,
-                          int64_t workspace_elems, void* stream);
 /* `F.relu(conv(x))` fused (npi_gat_aggregate_scores with relu != 0 applies the ReLU in the row epilogue): b is then the ReLU
  * OUTPUT, and this form first masks the incoming gradient, a' = a where b > 0 else 0 (threshold_backward), uses a' for D and
  * the column sums and writes it to a_masked [N, ldm] -- the gradient of the pre-activation the rest of the backward consumes.
@@ -493,7 +434,7 @@ int64_t npi_filter_adj_workspace_elems(int64_t E);
 int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                    int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, void* stream);
 /* npi_filter_adj with the output kept at the INPUT's length: pad_tail != 0 fills out_src / out_dst[count .. E) with -1.
- * A (-1, -1) column is padding everywhere downstream -- npi_csr_build drops it without raising the out-of-range flag,
+ * A (-1, -1) column is padding everywhere downstream -- npi_csr_build_ex drops it without raising the out-of-range flag,
  * npi_filter_adj skips it -- so a caller that knows the node counts (TopKPooling keeps ceil(ratio n_g) per graph) never
  * has to read the surviving-edge count back and the whole Net_1 step runs without a host synchronisation (and captures
  * into a HIP graph).  Negative ids in src / dst are always treated as dropped.  Output arrays must not alias the input. */
@@ -502,7 +443,7 @@ int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t E, const i
 int64_t npi_filter_adj_newpos_offset(int64_t E);   /* npi_filter_adj_ex: workspace[offset + e] = new position of input edge e, -1 if dropped */
 /* The by-target CSR of the POOLED graph from the CSR of its parent, without a sort: row perm[r'] of the parent with the
  * entries whose source survived (remap[col] >= 0), in the parent's order, self loop last; eid through newpos
- * (npi_filter_adj_ex's workspace tail).  Bit-identical to npi_csr_build on the filtered edge list.  nnz_max_out = capacity
+ * (npi_filter_adj_ex's workspace tail).  Bit-identical to npi_csr_build_ex on the filtered edge list.  nnz_max_out = capacity
  * of col_o / eid_o / rowidx_o (>= the surviving entries; E_in + n_out is what a fresh build would use); item_edges: the item
  * size of the NEW CSR (independent of the parent's); workspace int32 [npi_csr_filter_workspace_elems(n_out)];
  * n_out <= npi_csr_filter_max_rows(). */
@@ -548,7 +489,7 @@ int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_p
  * One-hop enclosing-subgraph extraction + PyG Batch collate.  Replaces the
  * per-sample Python loops of local_subgraph_generation (reference src/classes.py:652-733) and the
  * DataLoader collate in front of Net_1.  Interaction graph = CSR over node serial numbers:
- * ptr[N+1], nbr[nnz] partners in interaction_list order (npi_csr_build keeps it), ok[nnz] = pair usable
+ * ptr[N+1], nbr[nnz] partners in interaction_list order (npi_csr_build_ex keeps it), ok[nnz] = pair usable
  * (not in set_allInteractionKey_cannotUse, src/generate_dataset.py:296-299).  keys[B][2] = (rna, protein)
  * targets.  Local node order of a sample: rna, protein, usable partners of the rna, then of the protein;
  * pairs: target first, then in that same order, each in both directions ((rna, protein) first).
@@ -556,9 +497,11 @@ int npi_readout_max_mean_bwd(const float* x, int64_t ldx, const int32_t* graph_p
  *                          workspace int32[2B]; node_off[B] = pair_off[B] = -1 when the batch exceeds 2^31 - 1 rows
  *   npi_subgraph_fill    : node_id[n], batch[n] (int64), edge_src/edge_dst[2 * pairs] (int64, batch-global ids).  n_nodes /
  *                          n_pairs: the totals the CALLER sized those arrays with; when they are not node_off[B] / pair_off[B]
- *                          (totals computed for other keys) nothing is written and bit 2 (value 4) of status[0] is raised --
- *                          an error the host reads at its next device read instead of an out-of-bounds write (status may be NULL)
- *   npi_subgraph_features: x[row] = [row is a target ? 0 : 1 | feat[node_id[row]][0..Ff)]; writes nothing unless node_off[B] == n
+ *                          (totals computed for other keys) bit 2 (value 4) of status[0] is raised -- an error the host reads at its
+ *                          next device read instead of an out-of-bounds write (status may be NULL) -- and the arrays are filled,
+ *                          within the caller's sizes, with values every consumer is safe on until then: node 0 / graph 0 for
+ *                          every row, the (-1, -1) padding column for every edge
+ *   npi_subgraph_features: x[row] = [row is a target ? 0 : 1 | feat[node_id[row]][0..Ff)]; zero rows unless node_off[B] == n
  * ------------------------------------------------------------------------------------------ */
 int npi_subgraph_sizes(const int32_t* ptr, const int32_t* nbr, const uint8_t* ok, const int32_t* keys, int64_t B,
                        int32_t* node_off, int32_t* pair_off, int32_t* workspace, void* stream);

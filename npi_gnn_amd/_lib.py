@@ -23,8 +23,12 @@ NPI_GEMM_WORKSPACE_PREPARED = 8   # the workspace already holds npi_linear_prepa
 
 
 def NPI_GEMM_RESERVE_CUS(n: int) -> int:
-    """flag bits of npi_linear_fwd_ex / npi_linear_bwd_data_ex: leave ``n`` CUs (a multiple of 8) to a kernel running beside the GEMM"""
-    return ((int(n) // 8) & 0xff) << 8
+    """flag bits of npi_linear_fwd_ex / npi_linear_bwd_data_ex: leave ``n`` CUs (a multiple of 8, at most 128) to a kernel running
+    beside the GEMM"""
+    n = int(n)
+    if n < 0 or n > 128 or n % 8:
+        raise ValueError(f"NPI_GEMM_RESERVE_CUS: a multiple of 8 in [0, 128], got {n}")
+    return (n // 8) << 8
 
 _P = c_void_p
 _I = c_int64
@@ -35,33 +39,21 @@ PROTOTYPES = {
     "npi_abi_version": (c_int, []),
     "npi_csr_workspace_bytes": (_I, [_I, _I]),
     "npi_item_edges": (_I, [_I]),
-    "npi_small_graph_entries": (_I, [_I]),
     "npi_num_items": (_I, [_I, _I]),
-    "npi_csr_build": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "npi_csr_build_ex": (c_int, [_P, _P, _I, _I, _I, c_int, _I, c_int, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "npi_edge_positions": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "npi_segsum_carry_elems": (_I, [_I, _I, _I]),
-    "npi_segsum": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
     "npi_segsum_ex": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
     "npi_row_weight_sum": (c_int, [_P, _P, _I, _P, _P]),
     "npi_gcn_norm": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_row_inv_count": (c_int, [_P, _I, _P, _P]),
     "npi_entry_weights": (c_int, [_P, _P, _P, _P, _P, c_float, _I, _I, _P, _P]),
-    "npi_permute_f32": (c_int, [_P, _P, _I, c_float, _P, _P]),
     "npi_relu_backward": (c_int, [_P, _I, _P, _I, _I, _I, _P, _I, _P]),
     "npi_l2_normalize_rows": (c_int, [_P, _I, _I, _I, c_float, _P, _I, _P, _P]),
     "npi_l2_normalize_rows_bwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, c_float, _P, _I, _P]),
-    "npi_gemm_mode": (c_int, [c_int]),
-    "npi_linear_fwd": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, _P]),
-    "npi_linear_bwd_data": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "npi_colsum_workspace_elems": (_I, [_I, _I]),
     "npi_colsum": (c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
-    "npi_dw_shared": (c_int, [c_int]),
     "npi_linear_bwd_weight_workspace_elems": (_I, [_I, _I, _I]),
-    "npi_linear_bwd_weight": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P]),
-    "npi_linear_fwd_t": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, _P]),
-    "npi_linear_bwd_data_t": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, _P]),
-    "npi_linear_bwd_weight_t": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, _P]),
     "npi_linear_workspace_bytes": (_I, [_I, _I]),
     "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
     "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
@@ -75,8 +67,6 @@ PROTOTYPES = {
     "npi_gat_rank2_tail": (c_int, [_P, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     "npi_linear_bwd_weight_ex": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, c_int, c_int, _P]),
     "npi_gat_scores": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
-    "npi_gat_aggregate": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
-                                  _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_gat_pack_targets": (c_int, [_P, _P, _P, _P, _I, _P, _P]),
@@ -84,7 +74,6 @@ PROTOTYPES = {
                                              _P, _P]),
     "npi_gat_rank1_add": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
-    "npi_gat_edge_grad": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "npi_gat_edge_grad_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float,
                                      c_int, _P, _P, _P]),
     "npi_seg_scan_workspace_elems": (_I, [_I, _I]),
@@ -92,7 +81,6 @@ PROTOTYPES = {
     "npi_gat_softmax_stats_ex": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
     "npi_gat_aggregate_scores": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, c_int, _P, _P]),
     "npi_gat_rowdot_colsum_workspace_elems": (_I, [_I, _I, _I]),
-    "npi_gat_rowdot_colsum": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "npi_gat_rowdot_colsum_relu": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
     "npi_entry_transpose_map": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_gat_att_grad_workspace_elems": (_I, [_I, _I, _I]),

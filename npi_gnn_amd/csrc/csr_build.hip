@@ -20,13 +20,6 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static int64_t g_small_graph_entries = [] {
-    const char* e = getenv("NPI_SMALL_GRAPH_ENTRIES");
-    const long long n = e ? atoll(e) : 0;
-    return n > 0 ? (int64_t)n : NPI_SMALL_GRAPH_ENTRIES;
-}();
-int64_t small_graph_entries() { return g_small_graph_entries; }
-
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;
 constexpr int SORT_ITEMS = 16;                       // keys per lane
@@ -419,7 +412,7 @@ __global__ void topk_take_kernel(const uint32_t* __restrict__ graph_of, const in
 using namespace npi;
 
 extern "C" const char* npi_last_error(void) { return npi::g_err; }
-extern "C" int npi_abi_version(void) { return 2; }
+extern "C" int npi_abi_version(void) { return 3; }
 
 extern "C" int64_t npi_csr_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return -1;
@@ -427,23 +420,10 @@ extern "C" int64_t npi_csr_workspace_bytes(int64_t E, int64_t N) {
 }
 
 extern "C" int64_t npi_item_edges(int64_t nnz_max) { return npi::item_edges_for(nnz_max); }
-extern "C" int64_t npi_small_graph_entries(int64_t n) {
-    const int64_t prev = npi::g_small_graph_entries;
-    if (n > 0) npi::g_small_graph_entries = n;
-    return prev;
-}
 
 extern "C" int64_t npi_num_items(int64_t nnz_max, int64_t item_edges) {
     if (!npi::item_edges_ok(item_edges)) return -1;
     return npi::num_items_of(nnz_max, item_edges);
-}
-
-extern "C" int npi_csr_build(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,
-                             int add_self_loops, int32_t* rowptr, int32_t* col, int32_t* eid,
-                             int32_t* rowidx, int32_t* item_row, int64_t item_edges, int32_t* status,
-                             void* workspace, int64_t workspace_bytes, void* stream_) {
-    return npi_csr_build_ex(key_nodes, val_nodes, E, N, N, add_self_loops, 0, 1, rowptr, col, eid, rowidx,
-                            item_row, item_edges, status, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int npi_csr_build_ex(const int64_t* key_nodes, const int64_t* val_nodes, int64_t E, int64_t N,

@@ -655,12 +655,6 @@ extern "C" int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, i
     return ceil_div(N > 0 ? N : 1, (int64_t)rdc_rows(N)) * H * C;
 }
 
-extern "C" int npi_gat_rowdot_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
-                                     int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* workspace,
-                                     int64_t workspace_elems, void* stream_) {
-    return npi_gat_rowdot_colsum_relu(a, lda, b, ldb, bias, N, H, C, D, colsum, nullptr, 0, workspace, workspace_elems, stream_);
-}
-
 extern "C" int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                                           int64_t N, int64_t H, int64_t C, float* D, float* colsum, float* a_masked,
                                           int64_t ldm, float* workspace, int64_t workspace_elems, void* stream_) {
@@ -690,17 +684,6 @@ extern "C" int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const flo
     if (colsum != nullptr)
         colsum_blocks_kernel<<<(unsigned)ceil_div(Fw, 64), 256, 0, stream>>>(workspace, (int)nblocks, (int)Fw, colsum);
     return check_launch("npi_gat_rowdot_colsum");
-}
-
-extern "C" int npi_gat_aggregate(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
-                                 int64_t N, int64_t nnz_max, const float* x, int64_t ldx, float* out, int64_t ldo,
-                                 int64_t H, int64_t C, const float* a_dst, const float* a_src, const float* m,
-                                 const float* s, float slope, int by_source, const float* bias,
-                                 const float* g_dst, const float* g_src, const float* att,
-                                 const float* alpha, const int32_t* alpha_map,
-                                 float* carry, void* stream_) {
-    return npi_gat_aggregate_ex(rowptr, col, item_row, item_edges, N, nnz_max, x, ldx, nullptr, 0, out, ldo, H, C, a_dst, a_src, m, s,
-                                slope, by_source, bias, g_dst, g_src, att, alpha, alpha_map, carry, stream_);
 }
 
 extern "C" int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
@@ -758,15 +741,6 @@ extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* co
     P.carry = carry; P.w = scores; P.bias = bias;
     P.H = 1; P.C = (int)C; P.m = m; P.s = s; P.relu = relu ? 1 : 0;
     return segsum_run(P, W_GAT_DST_PRE, 0, nnz_max, NPI_F32, stream);
-}
-
-extern "C" int npi_gat_edge_grad(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
-                                 int64_t N, int64_t nnz_max, const float* hfeat, int64_t ldh,
-                                 const float* dout, int64_t ldd, int64_t H, int64_t C,
-                                 const float* a_dst, const float* a_src, const float* m, const float* s,
-                                 const float* D, float slope, float* dz, float* alpha_out, void* stream_) {
-    return npi_gat_edge_grad_ex(rowptr, col, rowidx, N, nnz_max, hfeat, ldh, nullptr, 0, dout, ldd, H, C, a_dst, a_src, m, s, D,
-                                slope, 0, dz, alpha_out, stream_);
 }
 
 extern "C" int npi_gat_edge_grad_ex(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,

@@ -1651,9 +1651,6 @@ gemm_bf16_ws_kernel(Bf16Args a) {
     }
 }
 
-// 0 = exact f32 MFMA, 1 = 3-way bf16 split (fwd / bwd_data interior tiles; the default, NPI_GEMM_SPLIT=0 turns it off)
-static int g_gemm_mode = [] { const char* e = getenv("NPI_GEMM_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
-
 static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4) {
     return ((uintptr_t)p % (4 * es) == 0) && (ld % 4 == 0) && (inner_extent % 4 == 0);
 }
@@ -1663,8 +1660,17 @@ static bool vec4_ok(const void* p, int64_t ld, int64_t inner_extent, int es = 4)
 //   shared  : about three workgroups per four CUs -- as a light resident it leaves room for the backward
 //             aggregation to co-run on every CU (functional.py, OVERLAP_STREAMS).  Step time at C4 by workgroup
 //             count: 128: 7.50, 160-224: 7.11-7.12, 256: 7.22, 384: 7.38, 512: 7.55 ms; alone that grid takes 1.77 ms.
-// The caller says which one applies (npi_linear_bwd_weight_ex's `shared`; npi_dw_shared for the legacy entry point).
-static int g_dw_shared = 0;
+// The caller says which one applies (npi_linear_bwd_weight_ex's `shared`).
+// CUs of the current device (256 on MI355X), asked once: the persistent kernels launch one workgroup per CU
+static int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+            n = 256;
+        return (n / 8) * 8;
+    }();
+    return cus;
+}
 static int64_t dw_workgroups(bool shared) {
     if (!shared) return 1024;
     static const int64_t ctas = [] {
@@ -1688,8 +1694,8 @@ static int pick_splits(int64_t M, int64_t tiles, bool shared) {
 // dtype_in: storage of A and B; dtype_out: storage of C and bias.  bf16 runs the guarded kernel only.
 template <int AMODE, int BMODE>
 // `mode`: 0 = exact-f32 MFMA kernels, 1 = bf16 matrix cores where the tile shape allows (3-way split for f32 storage).
-// `scratch`: caller memory for the re-laid weight matrix (npi_linear_workspace_bytes); null = take it from the
-// stream-ordered allocator (the legacy entry points).
+// `scratch`: caller memory for the re-laid weight matrix (npi_linear_workspace_bytes).  Nothing is allocated here: a shape that
+// takes the matrix-core kernels without it is an error (ABI 3; the entry points require the workspace).
 // `k_valid` > 0 (AMODE 0, f32): A has a.K columns of which only the first k_valid are data, the rest ZERO, and B has only
 // k_valid rows (NPI_GEMM_A_ZERO_PADDED): the split kernel runs on a.K with the weight planes zero-extended, everything
 // else (guarded strips, the exact kernels) on k_valid.
@@ -1697,7 +1703,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
                        int mode = 1, void* scratch = nullptr, int k_valid = 0, bool prepared = false, int reserve_cus = 0) {
     // `reserve_cus`: the persistent kernels take that many workgroups fewer than CUs (a multiple of 8: one per XCD), so that a
     // kernel resident beside them -- a collective's -- holds CUs they do not wait for (NPI_GEMM_RESERVE_CUS)
-    const int cu_slots = 256 - ((reserve_cus < 0 ? 0 : reserve_cus > 128 ? 128 : reserve_cus) / 8) * 8;
+    const int cu_slots = device_cus() - ((reserve_cus < 0 ? 0 : reserve_cus > 128 ? 128 : reserve_cus) / 8) * 8;
     // `prepared`: `scratch` already holds the re-laid weight matrix of THIS B / K / N / BMODE (npi_linear_prepare): no
     // preparation launch in front of the GEMM
     const bool bf16_in = dtype_in == NPI_BF16 && dtype_out == NPI_F32;          // dW of the bf16 path: bf16 operands, f32 slabs
@@ -1720,11 +1726,9 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     if (bf16_ws) {
         uint16_t* blocks = reinterpret_cast<uint16_t*>(scratch);
         const int64_t nel = (int64_t)a.N * a.K;
-        if (blocks == nullptr &&
-            (hipMallocAsync(reinterpret_cast<void**>(&blocks), (size_t)nel * 2, stream) != hipSuccess || blocks == nullptr)) {
-            (void)hipGetLastError();
-            set_error("gemm: hipMallocAsync of the bf16 weight blocks failed");
-            return NPI_ERR_LAUNCH;
+        if (blocks == nullptr) {
+            set_error("gemm: the bf16 matrix-core kernel needs the caller's workspace (npi_linear_workspace_bytes)");
+            return NPI_ERR_WORKSPACE;
         }
         if (!(prepared && scratch != nullptr))
             bf16_blocks_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(reinterpret_cast<const uint16_t*>(a.B), a.ldb, a.K, a.N, BMODE, blocks);
@@ -1737,7 +1741,6 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         const int grid = (int)(ntiles < cu_slots ? ((ntiles + 7) / 8) * 8 : cu_slots);
         if (wide_n) gemm_bf16_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(ba);
         else        gemm_bf16_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(ba);
-        if (scratch == nullptr) (void)hipFreeAsync(blocks, stream);
         return NPI_OK;
     }
     const bool split = fast_ok && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
@@ -1752,14 +1755,12 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
         return NPI_ERR_ARG;
     }
     if (fm > 0 && fn > 0 && split) {
-        // stream-ordered scratch for the three bf16 planes of B (W is small: 3 * 2 * K * N bytes)
+        // the three bf16 planes of B live in the caller's workspace (W is small: 3 * 2 * K * N bytes)
         uint16_t* planes = reinterpret_cast<uint16_t*>(scratch);
         const int64_t nel = (int64_t)a.N * a.K;
-        if (planes == nullptr &&
-            (hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)nel * 6, stream) != hipSuccess || planes == nullptr)) {
-            (void)hipGetLastError();
-            set_error("gemm: hipMallocAsync of the split planes failed");
-            return NPI_ERR_LAUNCH;
+        if (planes == nullptr) {
+            set_error("gemm: the split kernel needs the caller's workspace (npi_linear_workspace_bytes)");
+            return NPI_ERR_WORKSPACE;
         }
         if (!(prepared && scratch != nullptr))
             split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes, kv);
@@ -1779,7 +1780,6 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
             if (wide_n) gemm_split_ws_kernel<4><<<grid, WS_THREADS, 0, stream>>>(sa);
             else        gemm_split_ws_kernel<2><<<grid, WS_THREADS, 0, stream>>>(sa);
         }
-        if (scratch == nullptr) (void)hipFreeAsync(planes, stream);
     }
     // edge strips in 128 x 128 tiles
     const int tm = (int)ceil_div(a.M, 128), tn = (int)ceil_div(a.N, 128);
@@ -1838,20 +1838,12 @@ extern "C" int npi_ws_probe_read(unsigned long long* out8) {          // measure
     return NPI_OK;
 }
 #endif
-extern "C" int npi_gemm_mode(int mode) {
-    const int prev = g_gemm_mode;
-    if (mode == 0 || mode == 1) g_gemm_mode = mode;
-    return prev;
-}
 
 // per-call arithmetic of the *_ex entry points -> launch_gemm's mode
-static int gemm_mode_of(int flags) {
-    if (flags & NPI_GEMM_EXACT_F32) return 0;
-    if (flags & NPI_GEMM_SPLIT_BF16) return 1;
-    return g_gemm_mode;
-}
+// (no process-wide default any more: 0 = the 3-way bf16 split wherever the shape takes it, NPI_GEMM_EXACT_F32 = the f32 MFMA kernels)
+static int gemm_mode_of(int flags) { return (flags & NPI_GEMM_EXACT_F32) ? 0 : 1; }
 static bool scratch_ok(void* ws, int64_t ws_bytes, int64_t K, int64_t N) {
-    return ws == nullptr || (ws_bytes >= npi_linear_workspace_bytes(K, N) && ((uintptr_t)ws % 16) == 0);
+    return ws != nullptr && ws_bytes >= npi_linear_workspace_bytes(K, N) && ((uintptr_t)ws % 16) == 0;
 }
 
 extern "C" int64_t npi_linear_workspace_bytes(int64_t K, int64_t N) {
@@ -1938,16 +1930,6 @@ extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int6
                                      gemm_mode_of(flags), workspace, padded ? (int)K : 0, prepared, NPI_GEMM_RESERVED_CUS_OF(flags));
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd");
 }
-extern "C" int npi_linear_fwd_t(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
-                                const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
-                                int64_t N, int relu, int dtype, void* stream_) {
-    return npi_linear_fwd_ex(A, lda, W, ldw, bias, rowscale, C, ldc, M, K, N, relu, dtype, 0, nullptr, 0, stream_);
-}
-extern "C" int npi_linear_fwd(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                              const float* rowscale, float* C, int64_t ldc, int64_t M, int64_t K,
-                              int64_t N, int relu, void* stream_) {
-    return npi_linear_fwd_t(A, lda, W, ldw, bias, rowscale, C, ldc, M, K, N, relu, NPI_F32, stream_);
-}
 
 // dA[M,K] = rowscale * (dC[M,N] @ W[K,N]^T): GEMM with "K" = N (contracted), output width K
 extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* W, int64_t ldw,
@@ -1979,14 +1961,16 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
 // C = A W and, from the accumulators on their way out, sc0[m] = <C[m, :], att[:N]>, sc1[m] = <C[m, :], att[N:]>: GATConv's
 // h = x W with the two attention scores of every node in the GEMM's store epilogue (one head) instead of a pass over h
 extern "C" int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N) {
-    return (g_gemm_mode != 0 && M >= 128 && M < 0x7fffffff && K >= BK && K % BK == 0 && (N == 128 || N == 256)) ? 1 : 0;
+    // K >= 64: the row-dot epilogue double-buffers its LDS exchange by tile parity, which holds only when a tile has at least
+    // NST = 4 k-steps of 16 (with 2 k-steps wave wn = 1 could be a whole tile ahead of wave wn = 0 and overwrite its slot)
+    return (M >= 128 && M < 0x7fffffff && K >= 2 * BK && K % BK == 0 && (N == 128 || N == 256)) ? 1 : 0;
 }
 extern "C" int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C,
                                      int64_t ldc, float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace,
                                      int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(npi_linear_fwd_scores_supported(M, K, N), "npi_linear_fwd_scores: shape outside the split kernel's one-column-"
-                "tile coverage (M >= 128, K % 32 == 0, N = 128 or 256, default GEMM mode)");
+                "tile coverage (M >= 128, K >= 64, K % 32 == 0, N = 128 or 256)");
     NPI_REQUIRE(A && W && att && C && sc0 && sc1, "npi_linear_fwd_scores: null pointer");
     NPI_REQUIRE(lda >= K && ldw >= N && ldc >= N, "npi_linear_fwd_scores: leading dimension too small");
     NPI_REQUIRE(vec4_ok(A, lda, K, 4) && vec4_ok(W, ldw, N, 4) && ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0),
@@ -1997,13 +1981,13 @@ extern "C" int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W
     }
     GemmArgs a{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
                Epilogue{nullptr, nullptr, 0, nullptr, nullptr, nullptr, att, att + N, sc0, sc1}};
-    const int rc = launch_gemm<0, 0>(true, a, 1, stream, NPI_F32, NPI_F32, g_gemm_mode, workspace);
+    const int rc = launch_gemm<0, 0>(true, a, 1, stream, NPI_F32, NPI_F32, 1, workspace);
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd_scores");
 }
 // dA = dC W^T + row0 (x) col0 + row1 (x) col1, the rank-2 term added in the split kernel's store epilogue (GATConv backward:
 // the attention terms g_dst (x) W att_dst + g_src (x) W att_src of dX, without a read-modify-write pass over d hfeat)
 extern "C" int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t N) {
-    return (g_gemm_mode != 0 && M >= 128 && M < 0x7fffffff && K >= 128 && K % 128 == 0 && N >= BK && N % BK == 0 &&
+    return (M >= 128 && M < 0x7fffffff && K >= 128 && K % 128 == 0 && N >= BK && N % BK == 0 &&
             N % 4 == 0) ? 1 : 0;
 }
 extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
@@ -2012,7 +1996,7 @@ extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const fl
                                          void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(npi_linear_bwd_data_rank2_supported(M, K, N), "npi_linear_bwd_data_rank2: shape outside the split kernel's "
-                "full coverage (M >= 128, K % 128 == 0, N % 32 == 0, default GEMM mode)");
+                "full coverage (M >= 128, K % 128 == 0, N % 32 == 0)");
     NPI_REQUIRE(dC && W && dA && row0 && row1 && col0 && col1, "npi_linear_bwd_data_rank2: null pointer");
     NPI_REQUIRE(lddc >= N && ldw >= N && ldda >= K, "npi_linear_bwd_data_rank2: leading dimension too small");
     NPI_REQUIRE(vec4_ok(dC, lddc, N, 4) && vec4_ok(W, ldw, N, 4) && ((uintptr_t)dA % 16 == 0) && (ldda % 4 == 0),
@@ -2023,18 +2007,8 @@ extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const fl
     }
     GemmArgs a{dC, lddc, W, ldw, dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
                Epilogue{nullptr, nullptr, 0, nullptr, row0, row1, col0, col1}};
-    const int rc = launch_gemm<0, 1>(true, a, 1, stream, NPI_F32, NPI_F32, g_gemm_mode, workspace);
+    const int rc = launch_gemm<0, 1>(true, a, 1, stream, NPI_F32, NPI_F32, 1, workspace);
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data_rank2");
-}
-extern "C" int npi_linear_bwd_data_t(const void* dC, int64_t lddc, const void* W, int64_t ldw,
-                                     const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
-                                     int64_t N, int dtype, void* stream_) {
-    return npi_linear_bwd_data_ex(dC, lddc, W, ldw, rowscale, dA, ldda, M, K, N, dtype, 0, nullptr, 0, stream_);
-}
-extern "C" int npi_linear_bwd_data(const float* dC, int64_t lddc, const float* W, int64_t ldw,
-                                   const float* rowscale, float* dA, int64_t ldda, int64_t M, int64_t K,
-                                   int64_t N, void* stream_) {
-    return npi_linear_bwd_data_t(dC, lddc, W, ldw, rowscale, dA, ldda, M, K, N, NPI_F32, stream_);
 }
 
 extern "C" int64_t npi_colsum_workspace_elems(int64_t M, int64_t N) {
@@ -2092,12 +2066,6 @@ static void dw_split_plan(int64_t m_main, int64_t K, int64_t N, bool shared, int
     per = ceil_div(ceil_div(m_main, ns), (int64_t)SK) * SK;
 }
 
-extern "C" int npi_dw_shared(int shared) {
-    const int prev = g_dw_shared;
-    if (shared == 0 || shared == 1) g_dw_shared = shared;
-    return prev;
-}
-
 extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, int64_t N) {
     if (M < 0 || K <= 0 || N <= 0) return -1;
     int splits, kchunk;
@@ -2112,12 +2080,6 @@ extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, i
 }
 
 // dW[K,N] = A[M,K]^T @ dC[M,N] (contract over M), db[N] = colsum(dC); A, dC, dW, db stored as `dtype`
-extern "C" int npi_linear_bwd_weight_t(const void* A, int64_t lda, const void* dC, int64_t lddc,
-                                       void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
-                                       float* workspace, int64_t workspace_elems, int dtype, void* stream_) {
-    return npi_linear_bwd_weight_ex(A, lda, dC, lddc, dW, lddw, db, M, K, N, workspace, workspace_elems, dtype, 0,
-                                    g_dw_shared != 0 ? 1 : 0, stream_);
-}
 extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
                                         void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
                                         float* workspace, int64_t workspace_elems, int dtype, int flags, int shared,
@@ -2204,9 +2166,4 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
     slab_reduce_kernel<bf16_t><<<gw, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, N, (bf16_t*)dW, lddw);
     if (db) slab_reduce_kernel<bf16_t><<<gb, 256, 0, stream>>>(db_slabs, N, nslab, 1, (int)N, N, (bf16_t*)db, N);
     return check_launch("npi_linear_bwd_weight");
-}
-extern "C" int npi_linear_bwd_weight(const float* A, int64_t lda, const float* dC, int64_t lddc,
-                                     float* dW, int64_t lddw, float* db, int64_t M, int64_t K, int64_t N,
-                                     float* workspace, int64_t workspace_elems, void* stream_) {
-    return npi_linear_bwd_weight_t(A, lda, dC, lddc, dW, lddw, db, M, K, N, workspace, workspace_elems, NPI_F32, stream_);
 }

@@ -314,16 +314,6 @@ extern "C" int npi_gat_rank2_tail(const float* P, const float* W, int64_t ldw, c
     return check_launch("npi_gat_rank2_tail");
 }
 
-extern "C" int npi_permute_f32(const float* src, const int32_t* index, int64_t n, float fill, float* dst,
-                               void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    NPI_REQUIRE(n >= 0, "npi_permute_f32: bad size");
-    if (n == 0) return NPI_OK;
-    NPI_REQUIRE(src && index && dst, "npi_permute_f32: null pointer");
-    permute_f32_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(src, index, n, fill, dst);
-    return check_launch("npi_permute_f32");
-}
-
 // ---- measurement support: a stand-in for a collective's RESIDENT kernel ----------------------------------------------------
 // `workgroups` workgroups that each hold 64 KB of a CU's LDS (no 152 KB GEMM workgroup fits beside one) for `nanoseconds` of
 // wall-clock time (wall_clock64: 100 MHz).  npi_gnn_amd.virtual.StubCollectives launches it on its copy stream to give a

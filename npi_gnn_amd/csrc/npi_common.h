@@ -43,15 +43,14 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 
 // Entries per work item ("item" = what one wavefront reduces).  The item size is a PROPERTY OF THE CSR: npi_csr_build /
 // npi_csr_filter take it as an argument and cut item_row with it, and every consumer of item_row (npi_segsum*, npi_gat_*)
-// receives the same value from the caller, next to item_row -- no launch re-derives it from process state.  What remains
-// process-wide is only the HINT a caller may ask for when it builds a CSR (npi_item_edges(nnz_max)): 64-entry items for
-// capacities below npi_small_graph_entries (2^22 unless NPI_SMALL_GRAPH_ENTRIES presets it) -- the reference's 200-subgraph
-// batches, the bundled full graphs and the per-rank sides of a sharded graph, four times as many wavefronts with a quarter of
-// the serial chain each -- and NPI_ITEM_EDGES above.  Kernels that keep no item state between calls (segscan.hip,
-// gat_edge_grad) pick their own chunking per call from the same hint.
+// receives the same value from the caller, next to item_row -- no launch re-derives it, and the library keeps NO process-wide
+// state (ABI 3).  npi_item_edges(nnz_max) is a pure HINT for a caller that builds a CSR: 64-entry items for capacities below
+// 2^22 entries -- the reference's 200-subgraph batches, the bundled full graphs and the per-rank sides of a sharded graph, four
+// times as many wavefronts with a quarter of the serial chain each -- and NPI_ITEM_EDGES above; a caller that wants the other
+// size passes it.  Kernels that keep no item state between calls (segscan.hip, gat_edge_grad) pick their own chunking per call
+// by the same rule.
 constexpr int64_t NPI_SMALL_GRAPH_ENTRIES = (int64_t)1 << 22;
-int64_t small_graph_entries();
-inline int item_edges_for(int64_t nnz_max) { return nnz_max < small_graph_entries() ? 64 : NPI_ITEM_EDGES; }
+inline int item_edges_for(int64_t nnz_max) { return nnz_max < NPI_SMALL_GRAPH_ENTRIES ? 64 : NPI_ITEM_EDGES; }
 inline bool item_edges_ok(int64_t item) { return item == 64 || item == NPI_ITEM_EDGES; }
 inline int64_t num_items_of(int64_t nnz_max, int64_t item) { return nnz_max <= 0 ? 0 : ceil_div(nnz_max, item); }
 

@@ -1031,14 +1031,6 @@ extern "C" int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, i
     return CarryLayout(items).elems(F < 1024 ? F : 1024);
 }
 
-extern "C" int npi_segsum(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
-                          const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
-                          void* out_, int64_t ldo, int64_t F, int dtype, int mean, const float* bias,
-                          float* carry, void* stream_) {
-    return npi_segsum_ex(rowptr, col, item_row, item_edges, w, N, nnz_max, x_, ldx, nullptr, 0, out_, ldo, F, dtype, mean, bias,
-                         carry, stream_);
-}
-
 extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                              const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
                              const void* x2_, int64_t split, void* out_, int64_t ldo, int64_t F, int dtype, int mean,

@@ -84,13 +84,18 @@ subgraph_fill_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict_
                      int32_t* __restrict__ status) {
     const int lane = lane_id();
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= B) return;
     // the arrays were sized from the CALLER's totals; the offsets below are the device's.  Totals that belong to other keys
-    // would make every store below an out-of-bounds write: nothing is written and bit 2 of the status word is raised instead
+    // would make every store below an out-of-bounds write: bit 2 of the status word is raised instead, and the arrays are
+    // filled -- within the caller's sizes -- with values every consumer is safe on until the status is read (which may be many
+    // launches later and never inside a capture): graph 0 / node 0 for every row, the (-1, -1) padding column for every edge
     if (node_off[B] != n_nodes || pair_off[B] != n_pairs) {
         if (g == 0 && lane == 0 && status != nullptr) atomicOr(status, 4);
+        const int64_t nt = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += nt) { node_id[i] = 0; batch[i] = 0; }
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * (int64_t)n_pairs; i += nt) { esrc[i] = -1; edst[i] = -1; }
         return;
     }
+    if (g >= B) return;
     const int l = keys[2 * g], p = keys[2 * g + 1];
     const int64_t n0 = node_off[g];
     const int64_t e0 = 2 * (int64_t)pair_off[g];
@@ -136,7 +141,10 @@ subgraph_features_kernel(const float* __restrict__ feat, int64_t ldf, int Ff, co
     const int lane = lane_id();
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
-    if (node_off[B] != n) return;                          // npi_subgraph_fill wrote nothing (and raised the status bit): node_id is not valid
+    if (node_off[B] != n) {                                // npi_subgraph_fill raised the status bit: node_id is a sentinel -- zero rows
+        for (int c = lane; c < ldx; c += WAVE) x[row * ldx + c] = 0.f;
+        return;
+    }
     const float* __restrict__ src = feat + (int64_t)node_id[row] * ldf;
     float* __restrict__ dst = x + row * ldx;
     if (lane == 0) dst[0] = (row - node_off[batch[row]] < 2) ? 0.f : 1.f;

@@ -167,8 +167,8 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     return out
 
 
-# Arithmetic of the f32 projection GEMMs, passed PER CALL (npi_linear_*_ex flags): 0 = the library default (3-way bf16
-# split on the bf16 matrix cores unless NPI_GEMM_SPLIT=0), NPI_GEMM_EXACT_F32, NPI_GEMM_SPLIT_BF16.
+# Arithmetic of the f32 projection GEMMs, passed PER CALL (npi_linear_*_ex flags): 0 = the default (3-way bf16 split on the bf16
+# matrix cores), NPI_GEMM_EXACT_F32 = the exact-f32 MFMA kernels.  The library has no process-wide switch (ABI 3).
 GEMM_FLAGS = 0
 
 

@@ -51,8 +51,8 @@ def raise_on_status(values) -> None:
                          "(PyG's index_select / scatter raise here)")
     if any(int(v) & 4 for v in values):
         raise ValueError("InteractionGraph.batch: the n_nodes / n_pairs it was given do not belong to its keys (the device counted "
-                         "other totals); nothing was written -- that batch's tensors are uninitialised.  Totals must come from "
-                         "sizes() of the same keys")
+                         "other totals); that batch holds placeholders only (node 0 / graph 0 rows, padding edges, zero features).  "
+                         "Totals must come from sizes() of the same keys")
 
 
 def note_status(status: torch.Tensor) -> None:
@@ -94,7 +94,7 @@ class CSRSide:
     nnz_max: int
     n_items: int
     _inv_cnt: Optional[torch.Tensor] = None
-    _carry: Dict[int, torch.Tensor] = field(default_factory=dict)
+    _carry: Dict[tuple, torch.Tensor] = field(default_factory=dict)
     n_rows: int = -1          # output rows (key id space)
     n_cols: int = -1          # rows of the feature table the entries index (== n_rows unless sharded)
     item: int = 0             # entries per item this side was cut with
@@ -111,20 +111,46 @@ class CSRSide:
 
     def carry(self, F: int) -> torch.Tensor:
         """f32 scratch of the aggregation launches (partial sums of rows cut by a workgroup boundary + their arrival
-        counters); reused across calls of the same width.  ZEROED once, here: every launch leaves its counters at zero again
-        (``npi_segsum_carry_elems``).  One buffer per (side, width): launches that may run CONCURRENTLY on two streams must not
-        share a side at the same width."""
-        buf = self._carry.get(F)
+        counters); reused across calls of the same width ON THE SAME STREAM.  ZEROED once, here: every launch leaves its
+        counters at zero again (``npi_segsum_carry_elems``).  One buffer per (side, width, current stream): launches of one
+        stream are ordered, so they may share it; two modules that walk the same side at the same width on two streams
+        (possibly concurrently) get a buffer each.  ``reset_carry()`` after a launch that did not run to its end."""
+        dev = self.rowptr.device
+        key = (F, _lib.stream_ptr(dev))
+        buf = self._carry.get(key)
         if buf is None:
             n = int(load().npi_segsum_carry_elems(self.nnz_max, self.item, F))
-            buf = torch.zeros(n, dtype=torch.float32, device=self.rowptr.device)
-            self._carry[F] = buf
+            buf = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._carry[key] = buf
+        elif _DEBUG and not torch.cuda.is_current_stream_capturing():
+            self._check_counters(buf)
         return buf
+
+    def _check_counters(self, buf: torch.Tensor) -> None:
+        """``set_debug(True)``: the arrival counters at the head of ``buf`` must be zero between launches (synchronises)"""
+        n_wg = -(-self.n_items // 4)
+        n = n_wg + 2 * (-(-n_wg // 64))
+        if n and int(buf[:n].view(torch.int32).abs().max()) != 0:
+            raise _lib.NpiError("aggregation scratch: an arrival counter is not zero between launches -- two launches shared the "
+                                "buffer concurrently or one was aborted; call reset_carry() on this side")
+
+    def reset_carry(self) -> None:
+        """Drop every scratch buffer of this side (after an aborted launch or a failed ``check()``): the next launch of each
+        (width, stream) gets a freshly zeroed one."""
+        self._carry.clear()
+
+
+#: capacity (entries) from which a NEW side gets 256-entry items when the caller names no item size; None = the library's rule
+#: (``npi_item_edges``: 2^22).  The library keeps no such state (ABI 3); tests lower this to reach the 256-entry items at
+#: test-sized inputs.  It never affects a side that exists.
+ITEM_SWITCH_ENTRIES: Optional[int] = None
 
 
 def item_hint(nnz_max: int) -> int:
-    """Recommended item size for a new CSR of this capacity (``npi_item_edges``: 64 below ``npi_small_graph_entries``, else 256).
+    """Recommended item size for a new CSR of this capacity (``npi_item_edges``: 64 below 2^22 entries, else 256).
     Asked ONCE, when a side is built; the side then carries its own value."""
+    if ITEM_SWITCH_ENTRIES is not None:
+        return 64 if int(nnz_max) < ITEM_SWITCH_ENTRIES else 256
     return int(load().npi_item_edges(int(nnz_max)))
 
 

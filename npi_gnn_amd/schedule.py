@@ -53,6 +53,13 @@ class Schedule:
     #: GATConv on the direct layout with the fused packed backward (needs ``direct_hub_rows``)
     gat_direct: bool = True
 
+    def __post_init__(self):
+        # the flag carries n / 8 in eight bits and the launch clamps at 128: say so here instead of rounding silently
+        for name in ("gemm_reserve_cus", "split_projection_reserve_cus"):
+            n = getattr(self, name)
+            if not isinstance(n, int) or n < 0 or n > 128 or n % 8:
+                raise ValueError(f"Schedule.{name} must be a multiple of 8 in [0, 128] (one CU per XCD at a time), got {n!r}")
+
     def but(self, **changes) -> "Schedule":
         return replace(self, **changes)
 

@@ -20,8 +20,8 @@ def dev():
     return torch.device("cuda:0")
 
 
-# A CSR carries its own item size (64 or 256 entries); npi_small_graph_entries only moves the HINT for new builds (default:
-# 64-entry items below 2^22 entries of capacity).  The kernel test modules below carry cases "just above 2^20 entries" that
+# A CSR carries its own item size (64 or 256 entries); graph.ITEM_SWITCH_ENTRIES only moves the HINT for new builds (default:
+# 64-entry items below 2^22 entries of capacity; the library itself keeps no such state since ABI 3).  The kernel test modules below carry cases "just above 2^20 entries" that
 # exist to exercise the 256-ENTRY items (row ends on item boundaries, hub rows cut over many items): they run with the hint
 # switching at 2^20, so that both item sizes stay covered at test-sized inputs.  Changing the hint never affects a CSR that
 # already exists (tests/test_gpu_parity.py::test_a_csr_keeps_its_item_size_when_the_hint_moves).
@@ -34,8 +34,7 @@ def _item_size_switch(request):
     if name not in _ITEMS_AT_2P20:
         yield
         return
-    from npi_gnn_amd._lib import load
-    lib = load()
-    prev = int(lib.npi_small_graph_entries(1 << 20))
+    from npi_gnn_amd import graph as NG
+    prev, NG.ITEM_SWITCH_ENTRIES = NG.ITEM_SWITCH_ENTRIES, 1 << 20
     yield
-    lib.npi_small_graph_entries(prev)
+    NG.ITEM_SWITCH_ENTRIES = prev

@@ -60,16 +60,13 @@ def test_ctypes_prototypes_have_the_headers_argument_lists():
 
 def test_size_queries_without_gpu():
     lib = _lib.load()
-    assert lib.npi_abi_version() == 2
-    # the item size is an argument (a property of each CSR); npi_item_edges is only the HINT for a new CSR: 64-entry items
-    # below 2^22 entries of capacity by default, 256-entry items from there on
-    T = int(lib.npi_small_graph_entries(0))
-    assert T == 1 << 22
+    assert lib.npi_abi_version() == 3
+    # the item size is an argument (a property of each CSR); npi_item_edges is only the HINT for a new CSR, a pure function:
+    # 64-entry items below 2^22 entries of capacity, 256-entry items from there on
+    T = 1 << 22
     assert lib.npi_item_edges(1000) == 64 and lib.npi_item_edges(T - 1) == 64
     assert lib.npi_item_edges(T) == 256 and lib.npi_item_edges(21_000_000) == 256
-    assert lib.npi_small_graph_entries(1 << 20) == T and lib.npi_item_edges(1 << 20) == 256      # the hint moves ...
-    assert lib.npi_small_graph_entries(T) == 1 << 20 and lib.npi_item_edges(1 << 20) == 64
-    for item in (64, 256):                                                                         # ... the sizes do not
+    for item in (64, 256):
         assert lib.npi_num_items(0, item) == 0 and lib.npi_num_items(1, item) == 1
         assert lib.npi_num_items(item, item) == 1 and lib.npi_num_items(item + 1, item) == 2
         assert lib.npi_num_items(T + 1, item) == T // item + 1
@@ -83,7 +80,7 @@ def test_size_queries_without_gpu():
 
 def test_argument_errors_do_not_need_a_gpu():
     lib = _lib.load()
-    rc = lib.npi_segsum(None, None, None, 64, None, -1, 0, None, 0, None, 0, 4, 0, 0, None, None, None)
+    rc = lib.npi_segsum_ex(None, None, None, 64, None, -1, 0, None, 0, None, 0, None, 0, 4, 0, 0, None, None, None)
     assert rc == -1
     assert b"npi_segsum" in lib.npi_last_error()
 
@@ -97,15 +94,12 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         # build flags: NPI_CSR_DROP_EQUAL | NPI_CSR_SORT_COLUMNS, nothing else
         "npi_csr_build_ex (flags)": lambda: lib.npi_csr_build_ex(8, 8, 4, 4, 4, 1, 0, 4, 8, 8, 8, 8, 8, 64, 8, 8, 1 << 20, N),
         # an item size that does not exist is refused by the build and by every consumer of item_row
-        "npi_csr_build": lambda: lib.npi_csr_build(8, 8, 4, 4, 1, 8, 8, 8, 8, 8, 100, 8, 8, 1 << 20, N),
+        "npi_csr_build_ex (item)": lambda: lib.npi_csr_build_ex(8, 8, 4, 4, 4, 1, 0, 1, 8, 8, 8, 8, 8, 100, 8, 8, 1 << 20, N),
         "npi_csr_filter": lambda: lib.npi_csr_filter(8, 8, 8, 8, 8, 8, 4, 8, 8, 8, 8, 8, 8, 0, 8, 8, N),
-        "npi_segsum": lambda: lib.npi_segsum(8, 8, 8, 128, N, 4, 16, 8, 4, 8, 4, 4, 0, 0, N, 8, N),
+        "npi_segsum_ex (item)": lambda: lib.npi_segsum_ex(8, 8, 8, 128, N, 4, 16, 8, 4, N, 0, 8, 4, 4, 0, 0, N, 8, N),
         "npi_gat_aggregate_scores": lambda: lib.npi_gat_aggregate_scores(8, 8, 8, 65, 4, 16, 8, 4, N, 0, 8, 4, 4, 8, 8, 8, N, 0, 8, N),
         "npi_gat_backward_fused_heads": lambda: lib.npi_gat_backward_fused_heads(8, 8, 8, 8, 0, 4, 16, 16, 4, N, 0, 16, 4, 16, 4, 1, 4, 16,
                                                                                  16, 0.2, 16, 16, N),
-        "npi_linear_fwd": lambda: lib.npi_linear_fwd(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, N),
-        "npi_linear_bwd_data": lambda: lib.npi_linear_bwd_data(N, 0, N, 0, N, N, 0, 8, 8, -3, N),
-        "npi_linear_bwd_weight": lambda: lib.npi_linear_bwd_weight(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, N),
         "npi_colsum": lambda: lib.npi_colsum(N, 0, -1, 8, N, N, 0, N),
         "npi_gat_scores": lambda: lib.npi_gat_scores(N, 0, N, 8, 0, 4, N, N, N),
         "npi_topk_score": lambda: lib.npi_topk_score(N, 0, N, 8, 0, N, N),
@@ -117,9 +111,8 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_confusion_update": lambda: lib.npi_confusion_update(N, 0, 0, N, 4, N, N),
         # alpha read-back is a by-source, one-head, mapped mode: a forward call carrying it is refused (pointers are only
         # compared with NULL before that check, never dereferenced on the host)
-        "npi_gat_aggregate": lambda: lib.npi_gat_aggregate(8, 8, 8, 64, 4, 16, 8, 4, 8, 4, 1, 4, 8, 8, 8, 8, 0.2, 0, N, N, N, N,
-                                                           8, N, 8, N),
-        "npi_gat_edge_grad": lambda: lib.npi_gat_edge_grad(N, N, N, 4, 16, N, 4, N, 4, 0, 4, N, N, N, N, N, 0.2, N, N, N),
+        "npi_gat_aggregate_ex": lambda: lib.npi_gat_aggregate_ex(8, 8, 8, 64, 4, 16, 8, 4, N, 0, 8, 4, 1, 4, 8, 8, 8, 8, 0.2, 0, N, N, N,
+                                                                 N, 8, N, 8, N),
         "npi_seg_rowsum_ex": lambda: lib.npi_seg_rowsum_ex(N, N, N, N, -1, 0, 1, N, N, 0, N),
         "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, 64, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N),       # bad split
         "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N),
@@ -143,10 +136,32 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
     assert lib.npi_linear_bwd_data_ex(16, 256, 16, 256, N, 16, 256, 128, 256, 256, 0, 0, 24, 10 ** 9, N) == -3   # misaligned
     assert lib.npi_linear_prepare(16, 256, 256, 256, 3, 0, 16, lib.npi_linear_workspace_bytes(256, 256), N) == -3     # both copies: 2 x
     assert lib.npi_linear_fwd_scores_supported(1000, 256, 256) == 1 and lib.npi_linear_fwd_scores_supported(1000, 256, 192) == 0
-    # NPI_GEMM_WORKSPACE_PREPARED (8) without a workspace is an argument error
-    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 8, N, 0, N) == -1
+    # NPI_GEMM_WORKSPACE_PREPARED (8) without a workspace: refused like every call without one (ABI 3)
+    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 8, N, 0, N) == -3
     assert lib.npi_linear_bwd_weight_workspace_elems(-1, 8, 8) == -1
-    assert lib.npi_gemm_mode(-1) in (0, 1)                      # query only
+    # ABI 3: the workspace is REQUIRED (nothing is allocated inside a call); a null one is refused with the workspace status
+    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 0, N, 0, N) == -3
+    # the row-dot epilogue needs >= 4 k-steps per tile: K = 32 is refused, K = 64 is served
+    assert lib.npi_linear_fwd_scores_supported(1000, 32, 128) == 0 and lib.npi_linear_fwd_scores_supported(1000, 64, 128) == 1
+
+
+def test_the_library_allocates_nothing_and_keeps_no_state():
+    """ABI 3: no hipMalloc* / hipFree* among the library's undefined symbols, no getenv, and neither the
+    header nor the export list carries a process-wide setter or a legacy GEMM entry point."""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "-u", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for bad in ("hipMalloc", "hipFree", "hipHostMalloc", "getenv"):
+        assert bad not in und, [l for l in und.splitlines() if bad in l]
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {l.split()[-1] for l in exported.splitlines() if " T " in l and l.split()[-1].startswith("npi_")}
+    header = open(os.path.join(ROOT, "include", "npi_gnn.h")).read()
+    gone = ("npi_gemm_mode", "npi_dw_shared", "npi_small_graph_entries", "npi_linear_fwd", "npi_linear_bwd_data", "npi_linear_bwd_weight",
+            "npi_linear_fwd_t", "npi_linear_bwd_data_t", "npi_linear_bwd_weight_t", "npi_csr_build", "npi_segsum", "npi_gat_aggregate",
+            "npi_gat_edge_grad", "npi_gat_rowdot_colsum", "npi_permute_f32")
+    declared = set(_declared_symbols())
+    for name in gone:
+        assert name not in names and name not in declared, name
+    assert declared == names == set(_lib.PROTOTYPES), (declared ^ names, names ^ set(_lib.PROTOTYPES))
 
 
 def test_modules_mirror_pyg_parameter_layout():

@@ -103,6 +103,8 @@ def test_bench_byte_models_are_the_ones_the_documents_state():
     assert round(gb["gat_fwd_aggregate"] / 1e9, 2) == 22.71 and round(gb["gat_bwd_fused"] / 1e9, 2) == 24.15
     coll = {"all_gather": {"calls": 2, "payload_bytes": 200, "wire_bytes_per_rank": 175.0},
             "reduce_scatter": {"calls": 2, "payload_bytes": 200, "wire_bytes_per_rank": 175.0}}
-    v = bench.virtual_summary(8, 8.0, [1.0, 1.25, 1.0, 1.0], [10, 12, 10, 10], coll, "x")
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench_extras                                   # the lab harness behind `bench.py --extras` (and the per-config summary)
+    v = bench_extras.virtual_summary(8, 8.0, [1.0, 1.25, 1.0, 1.0], [10, 12, 10, 10], coll, "x")
     assert v["compute_ceiling"] == 8.0 / 1.25 and abs(v["balance"] - (4.25 / 4) / 1.25) < 1e-12
     assert v["wire_bytes_per_rank_per_step"] == 350.0 and abs(v["exposed_budget_ms_for_6x"] - (8.0 / 6 - 1.25)) < 1e-12

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Error of the two f32 GEMM arithmetics (npi_gemm_mode 0 = exact f32 MFMA, 1 = 3-way bf16 split)
+"""Error of the two f32 GEMM arithmetics (mode 0 = NPI_GEMM_EXACT_F32, 1 = the default 3-way bf16 split; functional.GEMM_FLAGS, per call)
 against an fp64 product, and their speed, on one MI355X.
 usage: python tools/gemm_accuracy.py [--rows M] [--hidden F]"""
 import argparse
@@ -55,7 +55,7 @@ def main():
         ref_b = A.double() @ W.double().t()
         print(f"--- {name}: A [{M},{F}] W [{F},{F}]   (max err / max|ref|,  ||err|| / ||ref||)")
         for mode in (0, 1):
-            lib.npi_gemm_mode(mode)
+            NF.GEMM_FLAGS = 1 if mode == 0 else 0          # NPI_GEMM_EXACT_F32 / default
             cf = NF.linear_fwd(A, W, b)
             cb = NF.linear_bwd_data(A, W, None)
             torch.cuda.synchronize()
@@ -71,7 +71,7 @@ def main():
     rs = torch.rand(Mb, generator=g).to(dev)
     fl = 2.0 * Mb * F * F
     for mode in (0, 1):
-        lib.npi_gemm_mode(mode)
+        NF.GEMM_FLAGS = 1 if mode == 0 else 0
         t1 = timeit(lambda: NF.linear_fwd(A, W, b))
         t2 = timeit(lambda: NF.linear_bwd_data(A, W, rs))
         t3 = timeit(lambda: NF.linear_bwd_weight(A, A, True))
