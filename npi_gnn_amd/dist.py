@@ -436,9 +436,15 @@ class HipBackend:
         return NF._side_stream(like.device)
 
     def partial_stream(self, like, sch: Schedule = DEFAULT):
-        """third HIP stream for the partial (side B) aggregation of a direction, or None for small shards"""
+        """third HIP stream for the partial (side B) aggregation of a direction, or None for small shards.  None as well while
+        the current stream is being CAPTURED into a HIP graph: in the backward this stream is forked from the side stream, itself
+        forked from the launch stream, and ending a capture with that nested fork takes the HIP runtime down (a segmentation
+        fault inside hipStreamEndCapture, ROCm 7.2: EXPERIMENTS Part B, sharded capture) -- the partial side then runs in line
+        on the stream that asked, which is the ``partial_stream=False`` arrangement: the same kernels and the same numbers."""
         from . import functional as NF
         if not (sch.partial_stream and NF._overlaps(sch, like.size(0))):
+            return None
+        if torch.cuda.is_current_stream_capturing():
             return None
         return NF._side_stream(like.device, 1)
 

@@ -449,3 +449,26 @@ def test_emulated_wire_holds_cus_for_the_stated_time_and_changes_no_result(dev):
     # four exchanges of ~7.7 MB at 5 GB/s = 6 ms of wire time per step, far above what the host's launch pace can hide (at
     # 50 GB/s the 0.7 ms disappeared behind a 0.96 ms host-bound step on a slower box: round 5)
     assert res[5.0][2] > res[None][2] + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["8 virtual ranks", "world 1 through RCCL"])
+def test_the_default_sharded_sage_step_captures_into_a_hip_graph_and_replays_bit_equal(dev, how):
+    """capturing the DEFAULT sharded SAGEConv schedule took the process down in capture_end (the partial
+    stream forked from the side stream forked from the launch stream).  While a capture is on, the layer now runs its partial
+    side in line (HipBackend.partial_stream) -- the same kernels, the same numbers: a captured step replays bit-equal to the
+    eager one, for rank 1 of 8 with stand-in collectives and for a world of one through a real RCCL process group.  In a
+    CHILD process: a crash of the HIP runtime must fail this test, not end the session."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "virtual_rank_probe.py"), "--conv", "sage", "--capture", "--check-replay",
+           "--steps", "5", "--hidden", "128"]
+    if how.startswith("8"):
+        cmd += ["--world", "8", "--rank", "1", "--nodes", "1000000", "--edges", "8000000", "--inline-copies"]
+    else:
+        cmd += ["--rccl", "--nodes", "200000", "--edges", "4000000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    assert "replay == eager" in p.stdout and "capture=True" in p.stdout, p.stdout[-1500:]

@@ -608,6 +608,20 @@ def virtual_world(dev, args, ei_dev, c4, t1_sage_ms, W=8, only=None):
         # (in a CHILD process: this one has created a dozen HIP streams by now, more than the hardware has queues, and a stand-in
         # that holds its queue for hundreds of us then also holds whatever compute stream shares that queue)
         out["hubs_sage"]["emulated_wire"] = emulated_wire(["--conv", "sage", "--steps", "30"], t1_sage_ms)
+    if "hubs_sage" in out and only is None and W == 8 and (N, E, F) == (1_000_000, 20_000_000, 256):
+        # rank 0's SAGEConv step replayed from a HIP graph (the default schedule captures since round 5: the partial side runs in
+        # line while a capture is on): the GPU's time for the rank's launches, without the host's ~25 dependent launches
+        rep = None
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "virtual_rank_probe.py"), "--conv", "sage", "--capture",
+                                 "--inline-copies", "--steps", "50"], capture_output=True, text=True, timeout=240)
+            m = [l for l in cp.stdout.splitlines() if "events" in l and "capture=True" in l]
+            if m:
+                rep = float(m[-1].split("events")[1].split("ms/step")[0])
+        except Exception as e:                                  # noqa: BLE001 -- a side measurement
+            sys.stderr.write(f"graph replay of a SAGEConv rank step failed: {type(e).__name__}: {e}\n")
+        out["hubs_sage"]["rank0_ms_graph_replay"] = rep
+        out["hubs_sage"]["compute_ceiling_graph_replay"] = (t1_sage_ms / rep) if rep else None
     if "hubs_gat" in out and W == 8 and (N, E, F) == (1_000_000, 20_000_000, 256):
         # the GATConv rank step is ~110 launches of a few us: eager it is bounded by the HOST and moves with the box's CPU
         # (1.7-2.2 ms).  Its GPU time: rank 0's step replayed from a HIP graph, stand-in copies on the compute stream (capture with

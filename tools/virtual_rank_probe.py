@@ -30,6 +30,11 @@ def main():
     ap.add_argument("--hp-copies", action="store_true", help="the stand-in collectives on HIGH-priority streams")
     ap.add_argument("--two-lanes", action="store_true", help="the small exchanges on a second communicator (ShardedGraph(small_group=))")
     ap.add_argument("--sched", default="", help="Schedule overrides, e.g. 'split_projection=False,partial_stream=False'")
+    ap.add_argument("--check-replay", action="store_true",
+                    help="with --capture: the replayed step's out / dX / dW must be BIT-equal to the eager step's (prints 'replay == eager')")
+    ap.add_argument("--rccl", action="store_true",
+                    help="a world of ONE through a real RCCL process group (every collective of the layer issued: dist.ALWAYS_COMMUNICATE) "
+                         "instead of the stand-in collectives")
     a = ap.parse_args()
     from npi_gnn_amd import dist as ND
     from npi_gnn_amd.synth import bipartite_edge_index, protein_mask
@@ -38,10 +43,20 @@ def main():
 
     from npi_gnn_amd.virtual import SMALL_LANE, StubCollectives
     prio = -1 if a.hp_copies else 0
-    stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev, priority=prio),
-                           wire_gbps=a.wire_gbps or None, held_cus=a.held_cus,
-                           copy_stream2=torch.cuda.Stream(device=dev, priority=prio) if (a.two_lanes and not a.inline_copies) else None)
-    stub.__enter__()                                       # for the life of the process
+    if a.rccl:
+        import tempfile
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="npi_probe_store_"), rank=0, world_size=1,
+                                device_id=dev)
+        ND.ALWAYS_COMMUNICATE = True
+        W, r = 1, 0
+        stub = None
+    else:
+        stub = StubCollectives(W, copy_stream=None if a.inline_copies else torch.cuda.Stream(device=dev, priority=prio),
+                               wire_gbps=a.wire_gbps or None, held_cus=a.held_cus,
+                               copy_stream2=torch.cuda.Stream(device=dev, priority=prio) if (a.two_lanes and not a.inline_copies) else None)
+        stub.__enter__()                                   # for the life of the process
     ei = bipartite_edge_index(N, E, seed=20260310).to(dev)
     g = torch.Generator().manual_seed(3)
     Wm = ((torch.rand(F, F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
@@ -60,18 +75,29 @@ def main():
     x = torch.randn(sg.n_local, F, device=dev).requires_grad_(True)
     go = torch.randn(sg.n_local, F, device=dev)
 
+    keep = {}
+
     def step():
         layer.zero_grad()
         x.grad = None
-        layer(x).backward(go)
+        out = layer(x)
+        out.backward(go)
+        keep.update(out=out, dx=x.grad, dw=layer.weight.grad)
     for _ in range(5):
         step()
     torch.cuda.synchronize()
+    eager = {k: v.detach().clone() for k, v in keep.items()}
     if a.capture:
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
             step()
         run = gr.replay
+        if a.check_replay:
+            for _ in range(2):
+                gr.replay()
+            torch.cuda.synchronize()
+            bad = [k for k, v in keep.items() if not torch.equal(v, eager[k])]
+            print("replay == eager" if not bad else f"replay != eager: {bad}", flush=True)
     else:
         run = step
     run()
@@ -87,7 +113,7 @@ def main():
     t_wall = (time.perf_counter() - t0) / a.steps * 1e3
     print(f"world {W} rank {r} {a.partition} {a.conv}: n_local {sg.n_local} entries {sg.local_nnz}  wall {t_wall:.3f} ms/step, "
           f"events {e0.elapsed_time(e1) / a.steps:.3f} ms/step, host issue {t_host:.3f} ms/step, capture={a.capture}")
-    for bw in [float(v) for v in a.wire_sweep.split(",") if v]:
+    for bw in [float(v) for v in a.wire_sweep.split(",") if v and stub is not None]:
         stub.wire_gbps = bw
         for _ in range(3):
             run()
