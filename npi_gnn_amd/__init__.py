@@ -11,6 +11,7 @@ from .graph import CSRGraph, GraphBatch, as_graph, set_debug  # noqa: F401
 from .functional import GCNNorm, gat_conv, gcn_conv, sage_conv, segsum  # noqa: F401
 from .nn import GATConv, GCNConv, SAGEConv  # noqa: F401
 from .schedule import Schedule  # noqa: F401
+from .graphed import GraphedStack  # noqa: F401
 
 __all__ = ["CSRGraph", "GraphBatch", "as_graph", "set_debug", "GCNNorm", "gat_conv", "gcn_conv", "sage_conv", "segsum",
-           "GATConv", "GCNConv", "SAGEConv", "Schedule", "NpiError", "load", "LIB_PATH"]
+           "GATConv", "GCNConv", "SAGEConv", "Schedule", "GraphedStack", "NpiError", "load", "LIB_PATH"]

@@ -16,9 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_no_environment_switch_selects_a_path():
-    """the only environment variables the product reads: the library path (variant builds, the sanitizer pass), the legacy
-    GEMM-arithmetic default and the item-size HINT -- none of them selects a code path of a layer"""
-    allowed = {"NPI_GNN_LIB", "NPI_GEMM_SPLIT", "NPI_SMALL_GRAPH_ENTRIES"}
+    """the only environment variable the product reads: the library path (variant builds, the sanitizer pass); since ABI 3 the
+    library itself reads none (the GEMM-arithmetic default and the item-size hint of ABI 2 are gone)"""
+    allowed = {"NPI_GNN_LIB"}
     seen = set()
     for dirpath, _, files in os.walk(os.path.join(ROOT, "npi_gnn_amd")):
         if "build" in dirpath.split(os.sep):
@@ -105,3 +105,54 @@ def test_sharded_layer_under_every_alternative_schedule(dev, kind, alt):
     for name, rs, gs in zip(("out", "dX", "dW"), _REF[kind], got):
         for r, a in zip(rs, gs):
             assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max().clamp(min=1e-6)), (name, alt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,dtype", [("sage", torch.float32), ("sage", torch.bfloat16), ("gcn", torch.float32), ("gat", torch.float32)])
+def test_graphed_stack_replays_the_eager_step_bit_for_bit(dev, kind, dtype):
+    """npi.GraphedStack: a static full-batch stack captured into one HIP graph.  A replay IS the eager step
+    -- the same kernels in the same order -- so outputs and every gradient are bit-equal; new inputs go through the static
+    buffers; an optimizer that sets .grad to None between calls still finds the gradients."""
+    import os as _os
+    fx = torch.load(_os.path.join(ROOT, "tests", "golden", "npinter2_graph.pt"), map_location="cpu", weights_only=False)
+    x, ei = fx["x"].to(dev).to(dtype), fx["edge_index"].long().to(dev)
+    N = x.size(0)
+    graph = npi.CSRGraph(ei, N)
+    torch.manual_seed(3)
+    make = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[kind]
+    convs = [make(178, 128).to(dev).to(dtype), make(128, 128).to(dev).to(dtype), make(128, 128).to(dev).to(dtype)]
+    go = torch.randn(N, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(dtype)
+    stack = npi.GraphedStack(convs, graph, x, grad_out=go)
+    assert stack._graph is not None
+
+    def snapshot():
+        torch.cuda.synchronize()
+        return [stack.out.detach().clone(), stack.x.grad.clone()] + [p.grad.clone() for c in convs for p in c.parameters()]
+    stack.replay()
+    a = snapshot()
+    stack.eager()
+    b = snapshot()
+    assert all(torch.equal(u, v) for u, v in zip(a, b)), [float((u.float() - v.float()).abs().max()) for u, v in zip(a, b)]
+    # the plain modules, one call at a time (the reference's call pattern, F.relu behind every conv): the same numbers
+    xr = x.clone().requires_grad_(True)
+    for c in convs:
+        for p in c.parameters():
+            p.grad = None
+    h = xr
+    for c in convs:
+        h = torch.relu(c(h, graph))
+    h.backward(go)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(h.detach().float(), a[0].float(), **tol) and torch.allclose(xr.grad.float(), a[1].float(), **tol)
+    # new inputs through the static buffers; gradients survive an optimizer's zero_grad(set_to_none=True)
+    x2 = (x.float() * 0.5 + 0.1).to(dtype)
+    for c in convs:
+        for p in c.parameters():
+            p.grad = None
+    out2 = stack(x2, go * 2)
+    torch.cuda.synchronize()
+    assert all(p.grad is not None for c in convs for p in c.parameters())
+    ref = stack.__class__(convs, graph, x2, grad_out=go * 2, capture=False)
+    ref.eager()
+    torch.cuda.synchronize()
+    assert torch.equal(ref.out.detach(), out2.detach()) and torch.equal(ref.x.grad, stack.x.grad)

@@ -95,6 +95,21 @@ def _stack_step(kind, weights, x, graph, dtype=torch.float32, norm=None, att=Non
     return step
 
 
+def _graphed(kind, weights, x, graph, dtype=torch.float32):
+    """npi.GraphedStack over modules carrying ``weights`` = [(W, b), ...]: the mean-square loss of ``_stack_step`` drives the
+    backward; ``.replay`` = the captured step, ``.eager`` = the same step launched kernel by kernel"""
+    import npi_gnn_amd as npi
+    dev = graph.device
+    convs = []
+    for W, b in weights:
+        conv = (npi.SAGEConv if kind == "sage" else npi.GCNConv)(W.size(0), W.size(1)).to(dev)
+        with torch.no_grad():
+            conv.weight.copy_(W)
+            conv.bias.copy_(b)
+        convs.append(conv.to(dtype))
+    return npi.GraphedStack(convs, graph, x.to(dev).to(dtype), loss=lambda h: h.float().pow(2).mean())
+
+
 def _stack_forward(kind, weights, x, graph, dtype=torch.float32, norm=None):
     import npi_gnn_amd as npi
     from npi_gnn_amd import functional as NF
@@ -240,16 +255,17 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
 
     def c1():
         h = _stack_forward("gcn", fx["gcn64"], x, graph, norm=norm)
+        st = _graphed("gcn", fx["gcn64"], x, graph)
         return {"workload": f"{shape}, 2 x GCNConv 178->64->64 fp32, full batch",
-                "ms_per_step": _timeit(_stack_step("gcn", fx["gcn64"], x.to(dev), graph, norm=norm), 30, 5),
-                "ms_per_step_graph": _graph_replay_ms(_stack_step("gcn", fx["gcn64"], x.to(dev), graph, norm=norm)),
+                "ms_per_step": _timeit(st.eager, 30, 5), "ms_per_step_graph": _timeit(st.replay, 200, 10),
+                "note": "ms_per_step_graph: npi.GraphedStack (the step replayed from a HIP graph); ms_per_step: the same step eager",
                 "parity_max_abs_err": float((h[rows] - fx["gcn64_out"]).abs().max()), "parity": "oracle (unpinned: GCNConv)"}
 
     def c2():
         h = _stack_forward("sage", fx["sage_weights"], x, graph, dtype=torch.bfloat16)
         ref = fx["sage3_out"]
-        sb = _stack_step("sage", fx["sage_weights"], x.to(dev), graph, dtype=torch.bfloat16)
-        sf = _stack_step("sage", fx["sage_weights"], x.to(dev), graph)
+        gb_, gf_ = _graphed("sage", fx["sage_weights"], x, graph, torch.bfloat16), _graphed("sage", fx["sage_weights"], x, graph)
+        sb, sf = gb_.eager, gf_.eager
         # eager: host-bound at this size (see _graph_replay_ms) -- the two storage types are timed alternately, best region each
         eb = ef = None
         for _ in range(1 if quick else 3):
@@ -257,9 +273,9 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
             eb, ef = (tb if eb is None else min(eb, tb)), (tf if ef is None else min(ef, tf))
         return {"workload": f"{shape}, 3 x SAGEConv 178->128->128->128, bf16 storage / f32 accumulate, full batch",
                 "ms_per_step": eb, "ms_per_step_f32": ef,
-                "ms_per_step_graph": _graph_replay_ms(sb), "ms_per_step_graph_f32": _graph_replay_ms(sf),
-                "note": "ms_per_step*: eager (host-bound: ~40 launches per step); ms_per_step_graph*: the same step replayed from "
-                        "a HIP graph = the GPU's time",
+                "ms_per_step_graph": _timeit(gb_.replay, 200, 10), "ms_per_step_graph_f32": _timeit(gf_.replay, 200, 10),
+                "note": "ms_per_step*: eager (host-bound: ~40 launches per step); ms_per_step_graph*: npi.GraphedStack, the same "
+                        "step replayed from a HIP graph = the GPU's time",
                 "parity_max_err_rel_to_max": float((h[rows] - ref).abs().max() / ref.abs().max()),
                 "parity": "fp32 oracle, bf16 tolerance"}
 
@@ -271,10 +287,10 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
         _ = g3.by_src
         n3 = NF.GCNNorm(g3)
         h = _stack_forward("gcn", f3["gcn256"], x3, g3, norm=n3)
+        st = _graphed("gcn", f3["gcn256"], x3, g3)
         return {"workload": f"RPI7317 graph N={x3.size(0)} E={ei3.size(1)} (7,317 positives + 7,317 seeded negatives), "
                             "3 x GCNConv 178->256->256->256 fp32, full batch",
-                "ms_per_step": _timeit(_stack_step("gcn", f3["gcn256"], x3.to(dev), g3, norm=n3), 30, 5),
-                "ms_per_step_graph": _graph_replay_ms(_stack_step("gcn", f3["gcn256"], x3.to(dev), g3, norm=n3)),
+                "ms_per_step": _timeit(st.eager, 30, 5), "ms_per_step_graph": _timeit(st.replay, 200, 10),
                 "parity_max_abs_err": float((h[f3["rows"]] - f3["gcn256_out"]).abs().max()),
                 "parity": "oracle (unpinned: GCNConv)"}
 
