@@ -288,6 +288,35 @@ int npi_gat_rank2_tail(const float* P, const float* W, int64_t ldw, const float*
                        float* datt, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One conv LAYER CALL as one entry point -- replaces `SAGEConv.forward` as the reference calls it (`self.convK(x, edge_index)`,
+ * src/classes.py:62,66,70) and its autograd backward (src/train_with_twoDataset.PY:54); also GCNConv evaluated as (A_hat x) W + b.
+ * They issue, in order on `stream`, exactly the launches of the per-op entry points above and add no kernel of their own; what
+ * they save is the HOST's cost of eight separate calls per layer and direction, which bounds the step at the reference's real
+ * sizes (batches of 200 enclosing subgraphs, the bundled full graphs).  Large graphs keep the per-op calls (their backward is
+ * arranged on two streams by the caller).  Every buffer is the caller's, as everywhere.
+ *
+ *   npi_conv_fwd : agg[:, :F] = segsum(CSR by target, x)  (mean / per-entry weights w_entry as npi_segsum_ex; columns F .. of a
+ *                  wider agg must be ZERO: NPI_GEMM_A_ZERO_PADDED in gemm_flags);  out = act(agg @ W[K, Nout] + bias).
+ *                  prepare_which: 0 = the GEMM lays W out itself (ws: npi_linear_workspace_bytes(K rounded up to 128 if padded,
+ *                  Nout)), 1 = npi_linear_prepare of the forward copy first, 3 = both copies (ws: two of them; the second one is
+ *                  what npi_conv_bwd takes as ws_bwd with ws_prepared = 1).
+ *   npi_conv_bwd : g = out_relu ? dout masked by out_relu > 0 (into dz; f32) : dout;
+ *                  dW != NULL: dW[K, Nout] = agg^T g, db = colsum(g) (db may be NULL; dw_ws: npi_linear_bwd_weight_workspace_elems);
+ *                  dx != NULL: dagg = rowscale * (g @ W^T), dx = segsum(transposed CSR t_*, dagg) (sum; weights t_w or NULL).
+ * ------------------------------------------------------------------------------------------ */
+int npi_conv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
+                 const float* w_entry, int64_t N, int64_t nnz_max, const void* x, int64_t ldx, int64_t F, int mean,
+                 void* agg, int64_t ldagg, float* carry, const void* W, int64_t ldw, const void* bias, void* out,
+                 int64_t ldo, int64_t K, int64_t Nout, int relu, int dtype, int gemm_flags, int prepare_which,
+                 void* ws, int64_t ws_bytes, void* stream);
+int npi_conv_bwd(const void* dout, int64_t lddo, const float* out_relu, int64_t ldor, float* dz, int64_t lddz, int64_t N,
+                 int64_t K, int64_t Nout, int dtype, int gemm_flags, const void* agg, int64_t ldagg, void* dW, int64_t lddw,
+                 void* db, float* dw_ws, int64_t dw_ws_elems, const void* W, int64_t ldw, const float* rowscale,
+                 void* dagg, int64_t lddagg, void* ws_bwd, int64_t ws_bwd_bytes, int ws_prepared,
+                 const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_item_row, int64_t t_item_edges,
+                 const float* t_w, int64_t t_nnz_max, void* dx, int64_t lddx, float* t_carry, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * GATConv (PyG 1.4.2; absent from the reference tree, BASELINE.json configs[4]).  H heads of C
  * channels, hfeat = x @ W is [N, H*C]; att is [H, 2C] (first C multiply the TARGET's features).
  * The attention coefficient alpha of an entry is recomputed from four per-node, per-head scalars

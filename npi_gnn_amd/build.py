@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnpi_gnn.so")
 SOURCES = ["csr_build.hip", "segsum.hip", "gemm_f32.hip", "graph_ops.hip", "gat.hip", "segscan.hip", "pool.hip", "subgraph.hip",
-           "head.hip"]
+           "head.hip", "layer.hip"]
 ARCH = "gfx950"
 
 
