@@ -758,7 +758,7 @@ def main():
             else:
                 out = conv(x, graph)
             out.backward(go)
-            last["out"] = out
+            last["out"] = out.detach()                          # (detached: the step's autograd graph must not outlive the step)
         seg_launch_bytes = [algorithmic_bytes(E, N, F)]
     else:
         from npi_gnn_amd import dist as ND

@@ -17,6 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnpi_gnn.so")
 SOURCES = ["csr_build.hip", "segsum.hip", "gemm_f32.hip", "graph_ops.hip", "gat.hip", "segscan.hip", "pool.hip", "subgraph.hip",
            "head.hip", "layer.hip"]
+HOST_ONLY = {"layer.hip"}      # translation units without a kernel of their own (sequences of the other entry points)
 ARCH = "gfx950"
 
 

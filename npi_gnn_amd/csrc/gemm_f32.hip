@@ -1257,10 +1257,16 @@ struct DwArgs {
 __device__ __forceinline__ int dw_row(int cg, int c) { return 32 * (cg >> 3) + 8 * c + (cg & 7); }
 __device__ __forceinline__ int dw_col(int r) { return (r & ~31) + 4 * (r & 7) + ((r >> 3) & 3); }
 
-template <int TN>
+// BF16IN (round 5): A and dC are stored as bf16.  Their values ARE bf16, so there is nothing to split: the producer loads 8 bytes
+// per row (the same 4 columns x 8 node rows per thread), re-pairs the halves into the fragment order and stores ONE plane; the
+// consumer issues one MFMA per product tile (it still reads the three plane slots of a fragment -- the hand-tuned wait counts
+// of ws_consume_step assume them -- and ignores two).  Half the loader's bytes and a sixth of the matrix work: the kernel is
+// HBM-bound.  (Rounds 1-4 ran bf16 dW on the exact-f32 tile kernel: 1.8 ms at C4 against 0.93 for f32 storage.)
+template <int TN, bool BF16IN = false>
 __global__ void __launch_bounds__(WS_THREADS, 1)
 gemm_dw_split_kernel(DwArgs a) {
     constexpr int TM = 2;
+    constexpr int ES = BF16IN ? 2 : 4;                      // bytes per stored operand element
     constexpr int BN = 64 * TN;
     constexpr int APL = 128 * 32, BPL = BN * 32;
     constexpr int BUF = 3 * APL + 3 * BPL;
@@ -1307,13 +1313,87 @@ gemm_dw_split_kernel(DwArgs a) {
         // (wave-uniform values are forced into SGPRs, so that the row bases below are scalar arithmetic: a base produced
         // by VALU + v_readfirstlane right in front of the load that reads it violates the VALU-writes-SGPR -> VMEM-reads
         // hazard -- 5 wait states -- which hipcc does not pad for an inline-asm consumer: a memory fault in the first build)
-        const char* srcb = uniform_ptr(reinterpret_cast<const char*>(isA ? a.A + (int64_t)mt * 128 : a.dC + (int64_t)nt * BN));
-        const int64_t ldb = ((int64_t)uniform_i((int)(ld >> 32)) << 32 | (uint32_t)uniform_i((int)(ld & 0xffffffff))) * 4;   // row pitch in bytes
-        const uint32_t voff = (uint32_t)(((int64_t)8 * half * ld + 4 * cg) * 4);
+        const char* srcb = uniform_ptr(isA ? reinterpret_cast<const char*>(a.A) + (int64_t)mt * 128 * ES
+                                           : reinterpret_cast<const char*>(a.dC) + (int64_t)nt * BN * ES);
+        const int64_t ldb = ((int64_t)uniform_i((int)(ld >> 32)) << 32 | (uint32_t)uniform_i((int)(ld & 0xffffffff))) * ES;   // row pitch in bytes
+        const uint32_t voff = (uint32_t)(((int64_t)8 * half * ld + 4 * cg) * ES);
         // every slab walks its node range from a different starting step (and wraps): 256 workgroups that all start on a
         // slab boundary -- addresses a multiple of 16 KiB apart -- otherwise sweep the memory channels in lockstep
         const int phase = (NPI_DW_PROBE & 1) || nk < 2 ? 0 : (int)(((int64_t)slab * 37) % nk);
         const bool active = isA || isB;
+        if constexpr (BF16IN) {
+            // ---- bf16 operands: dwordx2 loads (4 bf16 columns of one node row), one plane, no split ----
+            typedef uint32_t u32x2r __attribute__((ext_vector_type(2)));
+#define DWB_GL(dst, base) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#define DWB_DECL(S) u32x2r S##0, S##1, S##2, S##3, S##4, S##5, S##6, S##7
+#define DWB_LOAD(S, KS)                                                                                \
+    do {                                                                                               \
+        const int kc_ = (KS) < nk ? (KS) : nk - 1;   /* past the end: reload the last step, dropped */ \
+        const int kk_ = kc_ + phase < nk ? kc_ + phase : kc_ + phase - nk;   /* staggered start, wraps */ \
+        const char* g_ = srcb + (node0 + (int64_t)kk_ * SK) * ldb;                                     \
+        DWB_GL(S##0, g_);           DWB_GL(S##1, g_ + ldb);                                            \
+        DWB_GL(S##2, g_ + 2 * ldb); DWB_GL(S##3, g_ + 3 * ldb);                                        \
+        DWB_GL(S##4, g_ + 4 * ldb); DWB_GL(S##5, g_ + 5 * ldb);                                        \
+        DWB_GL(S##6, g_ + 6 * ldb); DWB_GL(S##7, g_ + 7 * ldb);                                        \
+    } while (0)
+#define DWB_WAIT16(S)                                                                                  \
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(S##0), "+v"(S##1), "+v"(S##2), "+v"(S##3), "+v"(S##4), "+v"(S##5), \
+                     "+v"(S##6), "+v"(S##7) : : "memory")
+            auto process_b = [&](int ks, u32x2r c0, u32x2r c1, u32x2r c2, u32x2r c3, u32x2r c4, u32x2r c5, u32x2r c6, u32x2r c7) {
+                const int stg = ks & (NST - 1), round = ks >> 2;
+                if (round > 0) wait_ge(&empty[stg], 4 * round);
+                char* st = img + stg * BUF;
+                const u32x2r rows[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // column c of the thread's 4: the low (c even) or high (c odd) half of word c / 2 of every node row
+                    uint32_t w[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) w[r] = rows[r][c >> 1];
+                    uint32_t p0[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)                 // node rows 2 i and 2 i + 1 -> one dword of the fragment half
+                        p0[i] = (c & 1) ? ((w[2 * i] >> 16) | (w[2 * i + 1] & 0xffff0000u)) : ((w[2 * i] & 0xffffu) | (w[2 * i + 1] << 16));
+                    if (do_db) {
+                        float f[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) f[r] = __uint_as_float((c & 1) ? (w[r] & 0xffff0000u) : (w[r] << 16));
+                        dbs[c] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                    }
+                    *reinterpret_cast<uint4*>(st + simg(dw_row(cg, c), half)) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+                }
+                signal(&full[stg]);
+            };
+            if (active && nk > 0) {                            // wave-uniform
+                DWB_DECL(ra); DWB_DECL(rb); DWB_DECL(rc);
+                DWB_LOAD(ra, 0);
+                DWB_LOAD(rb, 1);
+                for (int ks = 0; ks < nk; ks += 3) {
+                    DWB_LOAD(rc, ks + 2);
+                    DWB_WAIT16(ra);
+                    process_b(ks, ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7);
+                    if (ks + 1 >= nk) break;
+                    DWB_LOAD(ra, ks + 3);
+                    DWB_WAIT16(rb);
+                    process_b(ks + 1, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7);
+                    if (ks + 2 >= nk) break;
+                    DWB_LOAD(rb, ks + 4);
+                    DWB_WAIT16(rc);
+                    process_b(ks + 2, rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                for (int ks = 0; ks < nk; ++ks) {
+                    const int stg = ks & (NST - 1), round = ks >> 2;
+                    if (round > 0) wait_ge(&empty[stg], 4 * round);
+                    signal(&full[stg]);
+                }
+            }
+#undef DWB_GL
+#undef DWB_DECL
+#undef DWB_LOAD
+#undef DWB_WAIT16
+        } else {
 // The operands of dW are read ONCE (1 GB each at C4) while the backward aggregation beside it lives off what the caches hold of
 // its gathered rows: non-temporal loads (same-box A/B builds at C4, twice: step 6.753 / 6.764 -> 6.692 / 6.681 ms; the same hint
 // on the A loads of the forward / bwd_data kernel, whose rows the aggregation has just written or will just read: +0.05 ms)
@@ -1384,6 +1464,7 @@ gemm_dw_split_kernel(DwArgs a) {
 #undef DW_DECL
 #undef DW_LOAD
 #undef DW_WAIT16
+        }   // f32 operands
         if (do_db) {
             float* o = a.db_slabs + ((int64_t)slab * 2 + half) * a.N + (int64_t)nt * BN + 4 * cg;
             *reinterpret_cast<float4*>(o) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
@@ -1413,7 +1494,7 @@ gemm_dw_split_kernel(DwArgs a) {
         wait_ge(&full[0], 4);
         ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);
         for (int g = 0; g < nk; ++g)
-            ws_consume_step<TM, TN, APL, BPL, BUF, NST, (NPI_DW_PROBE & 4) != 0>(lds_base, full, empty, g, g + 1 < nk, offa, offb, af, bf, acc);
+            ws_consume_step<TM, TN, APL, BPL, BUF, NST, BF16IN || (NPI_DW_PROBE & 4) != 0>(lds_base, full, empty, g, g + 1 < nk, offa, offb, af, bf, acc);
     }
     // the tile of this slab (zeros when the slab holds no node: slab_reduce adds every slab)
     // Accumulator tile = C^T of the LDS-row grid: the lane owns LDS row li of the A image, its registers run along LDS rows
@@ -2123,6 +2204,23 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         dw_finish_kernel<float><<<gwb, 256, 0, stream>>>(workspace, Kp * N, nslab, (int)K, (int)N, (float*)dW, lddw, db_slabs, 2 * nslab,
                                                   (float*)db, fp(advance(A, m16 * lda, es)), lda, fp(advance(dC, m16 * lddc, es)), lddc,
                                                   (int)(M - m16));
+        return check_launch("npi_linear_bwd_weight");
+    }
+    // ---- bf16 storage: the same kernel without the split (one plane, one MFMA per product tile); slabs and the finish in f32 ----
+    if (dtype == NPI_BF16 && gemm_mode_of(flags) != 0 && v4 && dw_split_shape_ok(M, K, N)) {
+        const int64_t m16 = (M / SK) * SK;
+        int nslab, tm, tn;
+        int64_t per;
+        bool wide;
+        dw_split_plan(m16, K, N, shared != 0, nslab, per, tm, tn, wide);
+        float* db_slabs = workspace + (int64_t)(nslab + 1) * K * N;
+        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)K, (int)N, m16, per, tm, tn, nslab};
+        const unsigned grid = (unsigned)(ceil_div(nslab, 8) * 8 * tm * tn);
+        if (wide) gemm_dw_split_kernel<4, true><<<grid, WS_THREADS, 0, stream>>>(d);
+        else      gemm_dw_split_kernel<2, true><<<grid, WS_THREADS, 0, stream>>>(d);
+        dw_finish_kernel<bf16_t><<<gwb, 256, 0, stream>>>(workspace, K * N, nslab, (int)K, (int)N, (bf16_t*)dW, lddw, db_slabs, 2 * nslab,
+                                                         (bf16_t*)db, reinterpret_cast<const bf16_t*>(advance(A, m16 * lda, es)), lda,
+                                                         reinterpret_cast<const bf16_t*>(advance(dC, m16 * lddc, es)), lddc, (int)(M - m16));
         return check_launch("npi_linear_bwd_weight");
     }
     int splits, kchunk;

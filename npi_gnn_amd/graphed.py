@@ -55,16 +55,18 @@ class GraphedStack:
         self.out = None
         self._graph = None
         self._params = [p for c in self.convs for p in c.parameters()]
-        # one eager step tells the output's shape (and warms every lazy initialisation up)
+        self._warmup = max(int(warmup), 1)
+        # one forward tells the output's shape (and warms every lazy initialisation up)
         if loss is None:
             with torch.no_grad():
                 probe = self._forward(self.x.detach())
             self.grad_out = (torch.ones_like(probe) if grad_out is None else grad_out.detach().clone())
             del probe
-        for _ in range(max(int(warmup), 1)):
-            self.eager()
         if capture:
             self.capture()
+        else:
+            for _ in range(self._warmup):
+                self.eager()
 
     # ---- the step ------------------------------------------------------------------------------------------------------------
     def _forward(self, h: torch.Tensor) -> torch.Tensor:
@@ -89,8 +91,10 @@ class GraphedStack:
             out.backward(self.grad_out)
         if self.optimizer is not None:
             self.optimizer.step()
-        self.out = out
-        return out
+        # detached: holding the output WITH its autograd graph would keep this step's AccumulateGrad nodes alive into the next
+        # one -- nodes bound to the stream they were created on, which breaks a capture on another stream (capture_end faults)
+        self.out = out.detach()
+        return self.out
 
     def capture(self) -> None:
         """record the step once (on a side stream, as ``torch.cuda.graph`` requires; the layers' own second stream is forked
@@ -99,7 +103,10 @@ class GraphedStack:
         s = torch.cuda.Stream(device=self.x.device)
         s.wait_stream(torch.cuda.current_stream(self.x.device))
         with torch.cuda.stream(s):
-            self.eager()                                            # this stream's own scratch buffers exist before the capture
+            # the warm-up runs on the CAPTURE stream: its scratch buffers (keyed by stream) and autograd's per-leaf accumulation
+            # nodes (bound to the stream of their first use) then belong to the stream that is captured
+            for _ in range(self._warmup):
+                self.eager()
             torch.cuda.synchronize(self.x.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):

@@ -21,11 +21,13 @@ LDS_BYTES_PER_CU = 160 * 1024
 @pytest.fixture(scope="module")
 def built():
     """{object name: (metadata, code)} of the library's objects (rebuilt first if a source is newer)"""
-    from npi_gnn_amd.build import HERE, SOURCES, build_library
+    from npi_gnn_amd.build import HERE, HOST_ONLY, SOURCES, build_library
     build_library()
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for src in SOURCES:
+            if src in HOST_ONLY:                              # no device code: nothing to guard
+                continue
             out[src] = G.analyse(os.path.join(HERE, "build", src.replace(".hip", ".o")), tmp)
     return out
 
@@ -51,7 +53,8 @@ def test_hot_kernels_keep_the_occupancy_the_design_assumes(built):
     gemm = _pretty(built["gemm_f32.hip"][0])
     # (<4, 1>: the same kernel with the rank-2 store epilogue of GATConv's dX -- 22 registers and 8 KB of LDS more; <4, 2>: with
     # the row dots of GATConv's scores in the store epilogue -- 10 KB of LDS more)
-    for fam in ("gemm_split_ws_kernel<4, 0>", "gemm_split_ws_kernel<4, 1>", "gemm_split_ws_kernel<4, 2>", "gemm_dw_split_kernel<4>",
+    for fam in ("gemm_split_ws_kernel<4, 0>", "gemm_split_ws_kernel<4, 1>", "gemm_split_ws_kernel<4, 2>", "gemm_dw_split_kernel<4, false>",
+                "gemm_dw_split_kernel<4, true>",
                 "gemm_bf16_ws_kernel<4>"):
         ks = {n: m for n, m in gemm.items() if fam in n}
         assert len(ks) == 1, fam
@@ -69,9 +72,10 @@ def test_asm_gemms_hold_no_flat_access_no_sgpr_hazard_and_touch_no_in_flight_lds
         if any(k in sym for k in ("gemm_split_ws_kernel", "gemm_dw_split_kernel", "gemm_bf16_ws_kernel")):
             checked += 1
             assert G.find_flat(instrs) == [], (sym, G.find_flat(instrs)[:3])
-            assert any(i.startswith("global_load_dwordx4") for i in instrs), sym     # the asm loads are there at all
+            wide = "global_load_dwordx2" if "gemm_dw_split_kernelILi4ELb1" in sym or "gemm_dw_split_kernelILi2ELb1" in sym else "global_load_dwordx4"
+            assert any(i.startswith(wide) for i in instrs), sym                     # the asm loads are there at all (bf16 dW: 8 bytes)
             assert any(i.startswith("ds_read_b128") for i in instrs) and any("v_mfma_f32_32x32x16_bf16" in i for i in instrs), sym
-    assert checked == 10                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue
+    assert checked == 12                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue, dW also for bf16 operands
     # no FLAT memory instruction anywhere: a flat access counts on lgkmcnt as well as vmcnt (every LDS / scalar-load wait then
     # drains the gathers too) -- round 4 found all 128 aggregation kernels gathering through flat_load because the second
     # part of the table was addressed through a pointer biased with integer arithmetic

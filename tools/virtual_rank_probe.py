@@ -82,7 +82,7 @@ def main():
         x.grad = None
         out = layer(x)
         out.backward(go)
-        keep.update(out=out, dx=x.grad, dw=layer.weight.grad)
+        keep.update(out=out.detach(), dx=x.grad, dw=layer.weight.grad)     # (detached: the graph must not outlive the step)
     for _ in range(5):
         step()
     torch.cuda.synchronize()
