@@ -429,9 +429,14 @@ class HipBackend:
         return NF.colsum(x)
 
     def side_stream(self, like, sch: Schedule = DEFAULT):
-        """second HIP stream for the weight-gradient GEMM, or None when the shard is too small to gain"""
+        """second HIP stream for the weight-gradient GEMM, or None when the shard is too small to gain -- or while the step is
+        being CAPTURED with a real process group up: the communicator issues its collectives on a stream of its own, forked
+        from whichever stream calls it; called from the side stream that is a fork of a fork, and ending such a capture takes
+        the HIP runtime down (see ``partial_stream``).  The chain then stays on the launch stream: same kernels, same numbers."""
         from . import functional as NF
         if not NF._overlaps(sch, like.size(0)):
+            return None
+        if torch.cuda.is_current_stream_capturing() and dist.is_available() and dist.is_initialized():
             return None
         return NF._side_stream(like.device)
 

@@ -651,9 +651,45 @@ class _SageConvFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _SageConcatFn(torch.autograd.Function):
+    """``SAGEConv(concat=True)`` (PyG 1.4.2): ``out = [x | mean_{j -> i} x_j] @ W[2F, Fo] + b`` over the edge list AS IT IS (no
+    self loop appended).  The mean is written straight into the right half of the ``[N, 2F]`` operand of ONE projection GEMM
+    (K = 2F); the backward splits ``dOut W^T`` into its two halves: the left one is x's own share, the right one -- divided by
+    the in-count -- goes through the transposed aggregation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, graph: CSRGraph, w_entry=None):
+        N, F = x.shape
+        cat = torch.empty((N, 2 * F), dtype=x.dtype, device=x.device)
+        cat[:, :F].copy_(x)
+        segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True, out=cat[:, F:])
+        out = linear_fwd(cat, weight, bias)
+        ctx.graph, ctx.F = graph, F
+        ctx.w_src = w_entry[1] if w_entry else None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(cat, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        cat, weight = ctx.saved_tensors
+        graph: CSRGraph = ctx.graph
+        F = ctx.F
+        grad_out = _fc(grad_out, "grad_out", cat)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = linear_bwd_weight(cat, grad_out, want_bias=ctx.has_bias)
+        if ctx.needs_input_grad[0]:
+            dcat = linear_bwd_data(grad_out, weight)                              # [N, 2F]
+            dagg = dcat[:, F:] * graph.inv_count(graph.by_dst).view(-1, 1).to(dcat.dtype)     # scatter_mean's divisor, per TARGET
+            dx = segsum(graph, graph.by_src, dagg.contiguous(), w=ctx.w_src, mean=False)
+            dx += dcat[:, :F]
+        return dx, dw, db, None, None
+
+
 def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
               normalize: bool = False, edge_weight: Optional[torch.Tensor] = None, relu: bool = False,
-              pad_base: Optional[torch.Tensor] = None, schedule: Schedule = DEFAULT) -> torch.Tensor:
+              pad_base: Optional[torch.Tensor] = None, schedule: Schedule = DEFAULT, concat: bool = False) -> torch.Tensor:
     """PyG 1.4.2 ``SAGEConv(normalize=False, concat=False).forward`` on MI355X
     (call sites: reference ``src/classes.py:62,66,70``).  ``edge_weight [E]`` scales the messages
     (no gradient flows to it, as in the reference's use of the layer).  ``pad_base``: the wider buffer ``x`` is the leading
@@ -661,6 +697,25 @@ def sage_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[
     require_gpu(x, weight, bias)
     if edge_weight is not None and edge_weight.requires_grad:
         raise NotImplementedError("gradients w.r.t. edge_weight are not implemented")      # as gcn_conv: never silently detached
+    if concat:
+        # PyG 1.4.2: ``concat=True`` skips add_remaining_self_loops -- the edge list as it is, weight [2 F_in, F_out]
+        if isinstance(edge_index, CSRGraph):
+            graph = edge_index
+            if graph.self_loops or not graph.keep_equal:
+                raise ValueError("sage_conv(concat=True) aggregates over the edge list as it is: build the graph with "
+                                 "CSRGraph(edge_index, N, self_loops=False, keep_equal=True)")
+            if graph.num_nodes != x.size(0):
+                raise ValueError(f"CSRGraph was built for {graph.num_nodes} nodes, x has {x.size(0)}")
+        else:
+            ei = edge_index.edge_index if hasattr(edge_index, "edge_index") else edge_index      # a GraphBatch or the [2, E] tensor
+            graph = CSRGraph(ei, x.size(0), self_loops=False, keep_equal=True)
+        if weight.size(0) != 2 * x.size(1):
+            raise ValueError(f"sage_conv(concat=True): weight must have {2 * x.size(1)} rows (got {weight.size(0)})")
+        w_entry = entry_weights(graph, edge_weight, 1.0) if edge_weight is not None else None
+        out = _SageConcatFn.apply(x, weight, bias, graph, w_entry)
+        if relu:
+            out = torch.relu(out)
+        return l2_normalize(out) if normalize else out
     graph = as_graph(edge_index, x.size(0))
     w_entry = entry_weights(graph, edge_weight, 1.0) if edge_weight is not None else None
     # features that are a view of a wider buffer whose extra columns are zero (InteractionGraph.batch: 178 -> 256): the
@@ -1080,12 +1135,12 @@ class _GatConvFn(torch.autograd.Function):
         H = int(heads)
         C = weight.size(1) // H
         att2 = _f32c(att.reshape(H, 2 * C), "att")
+        d = graph.by_dst
         if H == 1 and sch.gat_scores_epilogue and linear_fwd_scores_ok(x, weight):
             hfeat, a_dst, a_src = linear_fwd_scores(x, weight, att2)        # x @ W, both scores in its store epilogue
         else:
             hfeat = linear_fwd(x, weight)                                    # x @ W
             a_dst, a_src = gat_scores(hfeat, att2, H, C)
-        d = graph.by_dst
         if H == 1 and C % 4 == 0 and d.nnz_max > 0:
             # the statistics pass leaves the score of every entry; the aggregation reads it back (one coalesced load per
             # 64 entries) instead of gathering a_src[j] per entry and redoing the leaky_relu

@@ -200,11 +200,14 @@ class CSRGraph:
     ``by_src`` groups them by source node (backward: dX = A^T ...), built lazily."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, self_loops: bool = True, by_dst: Optional[CSRSide] = None,
-                 symmetric: bool = False, item: Optional[int] = None, sort_columns: bool = False):
+                 symmetric: bool = False, item: Optional[int] = None, sort_columns: bool = False, keep_equal: bool = False):
         """``item``: entries per item of both sides (64 or 256; default: the hint for this capacity, ``item_hint``).
         ``sort_columns``: both sides with every row's entries in column order (a second key for the build's sort: at 4M nodes /
         100M edges 3 ms more per side, once, for 1.2 % of every GATConv layer step and 0.6 % of every SAGEConv one -- the
         4-byte gathers of per-node scalars walk ascending addresses; EXPERIMENTS A22).  The sums are the same in another order.
+        ``self_loops=False, keep_equal=True``: the edge list exactly as it is -- no loop appended, existing ``(i, i)`` columns kept
+        as ordinary entries (what PyG's ``SAGEConv(concat=True)`` aggregates over; the default drops them first, as
+        ``add_remaining_self_loops`` does).
         ``by_dst``: a by-target side somebody already derived for this very edge list (``filtered_side``): not rebuilt.
         ``symmetric``: the producer of the edge list vouches that it holds every edge in both directions (the device-side
         subgraph extraction emits both, src/classes.py:701-704, and filter_adj keeps the property; ``GraphBatch.symmetric``).
@@ -227,15 +230,19 @@ class CSRGraph:
         self._dst = edge_index[1].contiguous()
         self._item = item if by_dst is None else by_dst.item
         self.sort_columns = bool(sort_columns)
+        self.keep_equal = bool(keep_equal)
+        if self.keep_equal and self.self_loops:
+            raise ValueError("CSRGraph: keep_equal=True (existing self loops stay ordinary entries) needs self_loops=False")
         self.by_dst = by_dst if by_dst is not None else \
-            _build_side(self._dst, self._src, self.num_edges, self.num_nodes, self.self_loops, self._item, self.sort_columns)
+            build_side(self._dst, self._src, self.num_nodes, self.num_nodes, self.self_loops, drop_equal=not self.keep_equal,
+                       item=self._item, sort_columns=self.sort_columns)
         self._by_src: Optional[CSRSide] = None
 
     @property
     def by_src(self) -> CSRSide:
         if self._by_src is None:
-            self._by_src = _build_side(self._src, self._dst, self.num_edges, self.num_nodes, self.self_loops, self.by_dst.item,
-                                       self.sort_columns)
+            self._by_src = build_side(self._src, self._dst, self.num_nodes, self.num_nodes, self.self_loops,
+                                      drop_equal=not self.keep_equal, item=self.by_dst.item, sort_columns=self.sort_columns)
         return self._by_src
 
     def built_from(self, edge_index: torch.Tensor, num_nodes: Optional[int] = None) -> bool:

@@ -115,6 +115,7 @@ class GraphedStack:
         self._graph = g
         self._grads = [p.grad for p in self._params]                # the tensors every replay rewrites
         self._xgrad = self.x.grad
+        self._out = self.out
 
     # ---- use -----------------------------------------------------------------------------------------------------------------
     def replay(self) -> torch.Tensor:
@@ -126,6 +127,7 @@ class GraphedStack:
                 p.grad = g
         if self.x.grad is not self._xgrad:
             self.x.grad = self._xgrad
+        self.out = self._out                                         # (an eager() in between left its own output here)
         return self.out
 
     def __call__(self, x: Optional[torch.Tensor] = None, grad_out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -49,19 +49,19 @@ def _only_batch(gb: GraphBatch, edge_index, who: str) -> GraphBatch:
 class SAGEConv(nn.Module):
     """``SAGEConv(in_channels, out_channels, normalize=False, concat=False, bias=True)`` --
     mean over in-neighbours and the node itself, then ``@ weight + bias``.  Both parameters are
-    initialised U(+-1/sqrt(in_channels)) as in PyG 1.4.2."""
+    initialised U(+-1/sqrt(weight.size(0))) as in PyG 1.4.2.  ``concat=True``: no self loop is added, the mean over the
+    in-neighbours is concatenated behind the node's own features and ``weight`` is ``[2 in, out]``."""
 
     def __init__(self, in_channels: int, out_channels: int, normalize: bool = False, concat: bool = False,
                  bias: bool = True, schedule: Schedule = DEFAULT, **kwargs):
         super().__init__()
-        if concat:
-            raise NotImplementedError("SAGEConv(concat=True) is not used by NPI-GNN and not implemented")
         self.schedule = schedule                  # how the launches are arranged (schedule.Schedule); never what they compute
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.normalize = normalize
         self.concat = concat
-        self.weight = Parameter(torch.empty(in_channels, out_channels))
+        # concat=True (PyG 1.4.2; not what the reference constructs): [x_i | mean_j x_j] @ weight[2 in, out], no self loops added
+        self.weight = Parameter(torch.empty(2 * in_channels if concat else in_channels, out_channels))
         if bias:
             self.bias = Parameter(torch.empty(out_channels))
         else:
@@ -79,10 +79,11 @@ class SAGEConv(nn.Module):
             raise NotImplementedError("SAGEConv: the bipartite `size` form is not used by NPI-GNN")
         if isinstance(x, GraphBatch):
             gb = _only_batch(x, edge_index, "SAGEConv")
-            return gb.with_x(F_.sage_conv(gb.x, gb.graph(), self.weight, self.bias, normalize=self.normalize,
-                                          edge_weight=edge_weight, relu=relu, pad_base=gb.pad_base, schedule=self.schedule))
+            return gb.with_x(F_.sage_conv(gb.x, gb if self.concat else gb.graph(), self.weight, self.bias, normalize=self.normalize,
+                                          edge_weight=edge_weight, relu=relu, pad_base=gb.pad_base, schedule=self.schedule,
+                                          concat=self.concat))
         return F_.sage_conv(x, edge_index, self.weight, self.bias, normalize=self.normalize, edge_weight=edge_weight,
-                            relu=relu, schedule=self.schedule)
+                            relu=relu, schedule=self.schedule, concat=self.concat)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

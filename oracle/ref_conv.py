@@ -130,6 +130,26 @@ def sage_conv(x: Tensor, edge_index: Tensor, weight: Tensor, bias: Optional[Tens
     return out
 
 
+def sage_conv_concat(x: Tensor, edge_index: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
+                     edge_weight: Optional[Tensor] = None, normalize: bool = False) -> Tensor:
+    """PyG 1.4.2 ``SAGEConv(in, out, concat=True).forward``: NO self loops are added (``add_remaining_self_loops`` runs only
+    ``if not self.concat``; the edge list is used as it is, existing self loops included), the mean over the in-neighbours
+    (``scatter_mean``: 0 for a node without one) is CONCATENATED behind the node's own features, and ``weight`` is
+    ``[2 * in, out]``: ``out = cat([x, mean_j x_j]) @ W + b``.  Parity unpinned: the reference constructs its layers with the
+    default ``concat=False`` (``src/classes.py:48-52``)."""
+    N = x.size(0)
+    x_j = x.index_select(0, edge_index[0])
+    if edge_weight is not None:
+        x_j = edge_weight.view(-1, 1) * x_j
+    aggr = scatter_mean(x_j, edge_index[1], N)
+    out = torch.matmul(torch.cat([x, aggr], dim=-1), weight)
+    if bias is not None:
+        out = out + bias
+    if normalize:
+        out = F.normalize(out, p=2.0, dim=-1)
+    return out
+
+
 def gcn_norm(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tensor] = None,
              improved: bool = False, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
     """PyG 1.4.2 ``GCNConv.norm`` -- NOTE the degree is scatter-added over ``row`` (= source)."""

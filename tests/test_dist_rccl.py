@@ -191,7 +191,7 @@ def test_bench_rehearsal_of_the_node_run_on_one_gpu(dev):
         assert line["parity_max_err"] is not None and line["parity_max_err"] < 1e-5, line.get("parity")
         if conv == "sage":
             tuned = line["config"]["autotune"]
-            assert "error" not in tuned and set(tuned["ms_per_step"]) >= {"default", "gemm_reserve_cus=16", "early_hub_gather",
+            assert not tuned.get("error") and set(tuned["ms_per_step"]) >= {"default", "gemm_reserve_cus=16", "early_hub_gather",
                                                                           "one communicator"}, tuned
             assert line["exchange"]["by_collective_ms_per_step"], line["exchange"]     # waits on real collectives were timed
 

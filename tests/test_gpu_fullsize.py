@@ -258,7 +258,8 @@ def test_split_gemms_are_exact_under_concurrent_load(c4):
     res = {}
     for mode in ("overlap_fresh_graph", "overlap_fresh_graph", "overlap", "serial"):
         sch = DEFAULT.but(overlap_streams=mode != "serial")
-        graph = npi.CSRGraph(ei, N) if mode == "overlap_fresh_graph" else graph0     # fresh: by_src is built inside the backward
+        # fresh: by_src is built inside the backward (the same CSR form as the fixture's: the sums are compared bit for bit)
+        graph = npi.CSRGraph(ei, N, sort_columns=graph0.sort_columns) if mode == "overlap_fresh_graph" else graph0
         torch.manual_seed(0)
         conv = npi.SAGEConv(F, F, schedule=sch).to(dev)
         xr = x.clone().requires_grad_(True)

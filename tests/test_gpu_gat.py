@@ -260,7 +260,7 @@ def test_rank2_path_with_frozen_parameters(dev, freeze):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,N", [(128, 32, 128), (1000, 256, 256), (130_001, 128, 256), (70_000, 160, 128)])
+@pytest.mark.parametrize("M,K,N", [(128, 64, 128), (40_000, 64, 256), (1000, 256, 256), (130_001, 128, 256), (70_000, 160, 128)])
 def test_scores_in_the_gemm_epilogue_equal_the_pass_over_h(dev, M, K, N):
     """npi_linear_fwd_scores: h = x W bit-equal to npi_linear_fwd, and both row dots within fp32 rounding of npi_gat_scores on
     that h (ragged last row tile, both tile widths, several tiles per workgroup); bitwise reproducible."""
@@ -283,6 +283,9 @@ def test_scores_in_the_gemm_epilogue_equal_the_pass_over_h(dev, M, K, N):
         h2, d2, s2 = NF.linear_fwd_scores(x, W, att)
         assert torch.equal(h2, h) and torch.equal(d2, a_dst) and torch.equal(s2, a_src)
     assert not NF.linear_fwd_scores_ok(x, torch.randn(K, 192, device=dev))      # two column tiles: not served
+    # K = 32 is two k-steps per tile: the epilogue's parity double buffer needs four -- refused, the layer then
+    # takes the pass over h
+    assert not NF.linear_fwd_scores_ok(x[:, :32].contiguous(), torch.randn(32, N, device=dev))
 
 
 @pytest.mark.gpu

@@ -243,6 +243,32 @@ def test_linear_bwd_weight_large_m_split(dev):
     assert float(err) < 1e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(200_003, 256, 256), (5085, 128, 128), (70_000, 128, 256), (4096 + 7, 256, 128)])
+@pytest.mark.parametrize("shared", [False, True])
+def test_bf16_dw_matches_f32_reference(dev, M, K, N, shared):
+    """bf16 STORAGE (BASELINE.json configs[1]): dW = a^T dC and db on the matrix-core dW kernel with a native bf16 producer (one
+    plane, no split: the operands are bf16 values).  Reference: the fp64 product of the SAME bf16-rounded operands -- every
+    product is exact in f32, so what is checked is the f32 accumulation over M rows plus the ONE rounding of the result to
+    bf16 (2^-9 relative); run-to-run bitwise reproducible; both grid regimes."""
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    dc = torch.randn(M, N, generator=g).bfloat16()
+    dw, db = NF.linear_bwd_weight(a.to(dev), dc.to(dev), shared=shared)
+    assert dw.dtype == torch.bfloat16 and db.dtype == torch.bfloat16
+    ref_w = a.double().t() @ dc.double()
+    ref_b = dc.double().sum(0)
+    for got, ref in ((dw, ref_w), (db, ref_b)):
+        got = got.double().cpu()
+        # every element within one bf16 rounding (2^-9 relative; 2^-8 allowed) of the fp64 value, + f32 accumulation noise
+        assert bool(((got - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-5 * float(ref.abs().max())).all())
+    dw2, db2 = NF.linear_bwd_weight(a.to(dev), dc.to(dev), shared=shared)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # the f32 path on the widened operands agrees to bf16 rounding: the two kernels compute the same sums
+    dwf, dbf = NF.linear_bwd_weight(a.to(dev).float(), dc.to(dev).float(), shared=shared)
+    assert float((dwf.double().cpu() - ref_w).abs().max() / ref_w.abs().max()) <= 1e-5
+    assert torch.equal(dwf.bfloat16(), dw) or float((dwf.bfloat16().float() - dw.float()).abs().max() / dwf.abs().max()) <= 2.0 ** -7
+
+
 def _layer_case(N, E, Fi, Fo, seed, symmetric):
     ei = rand_edges(N, E, seed, hub=3)
     if symmetric:
@@ -910,6 +936,38 @@ def test_sage_conv_normalize_true_matches_the_oracle(dev):
     x6, W6, b6 = (t.double().clone().requires_grad_(True) for t in (x, Wr.detach(), br.detach()))
     torch.nn.functional.normalize(R.sage_conv(x6, ei, W6, b6), p=2.0, dim=-1).backward(go.double())
     assert rel_max(conv.weight.grad, W6.grad) <= GRAD_REL and rel_max(conv.bias.grad, b6.grad) <= GRAD_REL
+
+
+@pytest.mark.parametrize("N,E,Fi,Fo,weighted", [(2000, 15000, 64, 32, False), (3000, 40000, 128, 128, False), (900, 7000, 178, 128, True)])
+def test_sage_conv_concat_true_matches_the_oracle(dev, N, E, Fi, Fo, weighted):
+    """``SAGEConv(concat=True)`` (PyG 1.4.2): no self loop is added -- existing (i, i) columns stay ordinary
+    entries, a node without an in-edge aggregates to zero -- and ``[x_i | mean_j x_j] @ W[2 F, Fo] + b``.  Parity unpinned (the
+    reference constructs concat=False): the oracle restates the published forward, gradients by autograd."""
+    ei = rand_edges(N, E, seed=11, hub=3)
+    ei[:, :3] = torch.tensor([[5, 9, 9], [5, 9, 9]])                         # explicit self loops, one of them twice
+    ei[1][ei[1] == 7] = 8                                                    # node 7 has no in-edge
+    g = torch.Generator().manual_seed(12)
+    x, go = torch.randn(N, Fi, generator=g), torch.randn(N, Fo, generator=g)
+    ew = torch.rand(ei.size(1), generator=g) * 2.0 if weighted else None
+    conv = npi.SAGEConv(Fi, Fo, concat=True).to(dev)
+    assert tuple(conv.weight.shape) == (2 * Fi, Fo)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, ei.to(dev), edge_weight=None if ew is None else ew.to(dev))
+    out.backward(go.to(dev))
+    x6, W6, b6 = (t.detach().cpu().double().clone().requires_grad_(True) for t in (x, conv.weight, conv.bias))
+    ref = R.sage_conv_concat(x6, ei, W6, b6, edge_weight=None if ew is None else ew.double())
+    ref.backward(go.double())
+    assert torch.allclose(out.detach().cpu().double(), ref.detach(), atol=ATOL, rtol=RTOL)
+    assert torch.allclose(xd.grad.cpu().double(), x6.grad, atol=ATOL, rtol=RTOL)
+    assert rel_max(conv.weight.grad, W6.grad) <= GRAD_REL and rel_max(conv.bias.grad, b6.grad) <= GRAD_REL
+    assert float(out.detach()[7].cpu().double().sub(x6.detach()[7] @ W6.detach()[:Fi] + b6.detach()).abs().max()) <= 1e-5   # no in-edge: own features only
+    # a prebuilt graph must be the edge list as it is
+    with pytest.raises(ValueError):
+        conv(xd, npi.CSRGraph(ei.to(dev), N))
+    gg = npi.CSRGraph(ei.to(dev), N, self_loops=False, keep_equal=True)
+    assert int(gg.by_dst.rowptr[-1]) == ei.size(1)                           # nothing dropped, nothing appended
+    if not weighted:
+        assert torch.equal(conv(x.to(dev), gg).detach(), out.detach())
 
 
 @pytest.mark.parametrize("item_entries", [64, 256])

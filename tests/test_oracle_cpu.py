@@ -89,3 +89,19 @@ def test_metrics_formula_matches_reference_log_line():
     # Sensitivity: 0.95727, Specificity: 0.91263, MCC: 0.87077"  <- TP 1994 FN 89 TN 1901 FP 182
     got = ["%.5f" % v for v in R.metrics_from_confusion(1994, 89, 1901, 182)]
     assert got == ["0.93495", "0.91636", "0.95727", "0.91263", "0.87077"]
+
+
+def test_sage_conv_concat_restatement_by_hand_and_gradcheck():
+    """oracle.sage_conv_concat (PyG 1.4.2 SAGEConv(concat=True)): no self loop added, existing ones are ordinary messages, an
+    isolated target aggregates to zero; weight [2 F, Fo]"""
+    x = torch.tensor([[1.0, 2.0], [3.0, 5.0], [7.0, 11.0]], dtype=torch.float64)
+    ei = torch.tensor([[0, 1, 1], [1, 1, 0]])                       # 0 -> 1, 1 -> 1 (a self loop), 1 -> 0; node 2 has no in-edge
+    W = torch.arange(8, dtype=torch.float64).view(4, 2) / 10
+    b = torch.tensor([0.5, -0.5], dtype=torch.float64)
+    agg = torch.stack([x[1], (x[0] + x[1]) / 2, torch.zeros(2, dtype=torch.float64)])
+    want = torch.cat([x, agg], dim=1) @ W + b
+    assert torch.allclose(R.sage_conv_concat(x, ei, W, b), want)
+    g = torch.Generator().manual_seed(0)
+    ei2 = torch.randint(0, 9, (2, 30), generator=g)
+    xs, Ws, bs = (torch.randn(*s, dtype=torch.float64, generator=g, requires_grad=True) for s in ((9, 5), (10, 3), (3,)))
+    assert torch.autograd.gradcheck(lambda a, w, c: R.sage_conv_concat(a, ei2, w, c), (xs, Ws, bs))
