@@ -61,6 +61,9 @@ def parse(argv=None):
     ap.add_argument("--graph-seed", type=int, default=20260310,
                     help="seed of the synthetic bipartite graph (2 = the C5 graph: its PMC passes)")
     ap.add_argument("--conv", choices=["sage", "gcn", "gat"], default="sage")
+    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
+                    help="N=1: bf16 = features, weights and gradients stored as bf16 (f32 accumulation inside the kernels, as "
+                         "BASELINE configs[1]) -- NOT the metric's precision: for the rocprofv3 passes of the bf16 kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=100_000, help="bounded CPU-baseline sample (1/10 scale)")
     ap.add_argument("--cpu-edges", type=int, default=2_000_000)
@@ -91,6 +94,10 @@ def parse(argv=None):
                     help="N=1: capture the step (both streams) into one HIP graph and time replays of it")
     ap.add_argument("--virtual-world", type=int, default=8,
                     help="N=1: time every rank's local work of a W-rank run on this GPU (configs.w<W>_hubs_sage_*); 0 = skip")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N=1: do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure the aggregation "
+                         "kernel's HBM-side bytes in THIS run; roofline.traffic then comes from profiles/pmc_traffic.json (offline)")
+    ap.add_argument("--setup-steps", type=int, default=SETUP_STEPS, help="untimed steps before the warm-up")
     ap.add_argument("--rank-check", action="store_true",
                     help="every rank prints {rank, world} and exits before any GPU call (launcher test)")
     return ap.parse_args(argv)
@@ -383,6 +390,56 @@ def pmc_traffic():
     t["stale"] = [f for f in ("segsum.hip", "segsum.h") if then.get(f) != now[f]]
     t["stale_gat"] = t["stale"] + [f for f in ("gat.hip",) if then.get(f) != now[f]]
     return t
+
+
+FETCH_SCALE = 1.992            # gfx950: FETCH_SIZE under-reports the gathers' wide coalesced reads by this factor (the guide's HBM section;
+                               # calibrated in round 1, tools/pmc_calibrate.py, and confirmed by the uniform control: PMC = 1.00 x algorithmic)
+
+
+def live_pmc(args, timeout_s: float = 300.0):
+    """HBM-side bytes per launch of the headline aggregation kernel measured IN THIS RUN: two child processes, each this very
+    file under `rocprofv3 --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in passes of their own, nothing else traced, as the guide
+    prescribes), on a short run of the same workload; started BEFORE this process touches the GPU.  Returns
+    {"bytes_per_launch", "fetch_KB_raw", "write_KB", "launches", "source"} or {"error": ...} (the offline constants of
+    profiles/pmc_traffic.json then stand in, and the line says so)."""
+    import csv
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="npi_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--setup-steps", "2", "--no-cpu-baseline",
+             "--no-configs", "--no-control", "--virtual-world", "0", "--no-parity", "--no-live-pmc", "--nodes", str(args.nodes),
+             "--edges", str(args.edges), "--hidden", str(args.hidden), "--graph-seed", str(args.graph_seed)]
+    if args.plain_csr:
+        child.append("--plain-csr")
+    env = dict(os.environ, TMPDIR="/tmp")
+    means, t0 = {}, time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cp = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child, cwd="/tmp",
+                                env=env, capture_output=True, text=True, timeout=max(30.0, timeout_s - (time.time() - t0)))
+            rows = []
+            for root_, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        rows += list(csv.DictReader(open(os.path.join(root_, f))))
+            vals = [float(r["Counter_Value"]) for r in rows
+                    if r.get("Counter_Name", counter) == counter and "segsum_kernel<float, 4, 1, 0" in r.get("Kernel_Name", "")]
+            if not vals:
+                return {"error": f"no {counter} rows for the aggregation kernel (rc {cp.returncode}): {(cp.stderr or cp.stdout)[-200:]}"}
+            means[counter] = (sum(vals) / len(vals), len(vals))
+    except Exception as e:                                      # noqa: BLE001 -- a side measurement: the offline constants stand in
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kb, write_kb = means["FETCH_SIZE"][0], means["WRITE_SIZE"][0]
+    return {"bytes_per_launch": (fetch_kb * FETCH_SCALE + write_kb) * 1024.0, "fetch_KB_raw": fetch_kb, "write_KB": write_kb,
+            "launches": means["FETCH_SIZE"][1], "wall_s": round(time.time() - t0, 1),
+            "source": f"LIVE: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this run (separate passes, avg over "
+                      f"{means['FETCH_SIZE'][1]} fwd+bwd aggregation launches; FETCH_SIZE x {FETCH_SCALE} gfx950 calibration + WRITE_SIZE)"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -690,6 +747,10 @@ def main():
     if is_worker and os.environ.get("NPI_BENCH_FAKE_WORKER"):
         raise SystemExit(fake_worker(rank, world))
     attempt = int(os.environ.get("NPI_BENCH_ATTEMPT", "0")) if is_worker else 0
+    pmc_live = None
+    if (not sharded and not args.no_live_pmc and not args.control_only and args.conv == "sage" and args.storage == "f32"
+            and not args.capture):
+        pmc_live = live_pmc(args)                               # child processes; this one has made no GPU call yet
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -744,8 +805,10 @@ def main():
         with torch.no_grad():
             conv.weight.copy_(W)
             conv.bias.copy_(bias)
-        x = x_full.to(dev).requires_grad_(True)
-        go = go_full.to(dev)
+        st = torch.bfloat16 if args.storage == "bf16" else torch.float32
+        conv = conv.to(st)
+        x = x_full.to(dev).to(st).requires_grad_(True)
+        go = go_full.to(dev).to(st)
         norm = NF.GCNNorm(graph) if args.conv == "gcn" else None
         c4.update(graph=graph, x=x, go=go, F=F, E=E)
 
@@ -759,7 +822,7 @@ def main():
                 out = conv(x, graph)
             out.backward(go)
             last["out"] = out.detach()                          # (detached: the step's autograd graph must not outlive the step)
-        seg_launch_bytes = [algorithmic_bytes(E, N, F)]
+        seg_launch_bytes = [algorithmic_bytes(E, N, F, s=2 if args.storage == "bf16" else 4)]
     else:
         from npi_gnn_amd import dist as ND
         from npi_gnn_amd.schedule import CONSERVATIVE, DEFAULT
@@ -872,7 +935,7 @@ def main():
     # steady state first: the first launches of a process pay lazy initialisation (kernel code upload, allocator growth, clock
     # ramp) that W = 3 warm-up steps do not always cover -- the first timed region measured 0.07-0.1 ms per step above the
     # following ones.  SETUP_STEPS untimed steps belong to the set-up, then the contract's W warm-up steps and K timed ones.
-    for _ in range(SETUP_STEPS):
+    for _ in range(max(args.setup_steps, 0)):
         step()
     for _ in range(args.warmup):
         step()
@@ -929,7 +992,7 @@ def main():
                                     att=att_full if args.conv == "gat" and args.partition != "edges" else None)
         except Exception as e:                                  # on every rank alike (same code, same data)
             parity = {"parity_max_err": None, "error": f"{type(e).__name__}: {e}"[:300]}
-    elif args.conv == "sage" and not args.no_parity:
+    elif args.conv == "sage" and not args.no_parity and args.storage == "f32":
         try:
             if captured:
                 eager_step()                                    # the tensors of a replay live in the graph's pool: one eager step
@@ -946,8 +1009,11 @@ def main():
     achieved = alg_bytes / (seg_avg_ms * 1e-3) / 1e9 if seg_ms else 0.0
     pmc = pmc_traffic()
     traffic = None
-    if not sharded and args.conv == "sage" and (N, E, F) == (1_000_000, 20_000_000, 256) and not pmc.get("stale"):
-        traffic = pmc.get("segsum_kernel_bytes_per_launch")
+    traffic_live = bool(pmc_live and pmc_live.get("bytes_per_launch"))
+    if traffic_live:
+        traffic = pmc_live["bytes_per_launch"]
+    elif not sharded and args.conv == "sage" and (N, E, F) == (1_000_000, 20_000_000, 256) and not pmc.get("stale"):
+        traffic = pmc.get("segsum_kernel_bytes_per_launch" if args.storage == "f32" else "bf16_segsum_bytes_per_launch")
     frac_alg = achieved / HBM_PEAK_GBS
     frac_traffic = (traffic / (seg_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and seg_ms) else None
 
@@ -987,23 +1053,27 @@ def main():
                               "algorithmic bytes / live duration / peak (no current PMC pass on file for this configuration; "
                               "this figure counts every gathered row as an HBM read and can exceed 1 when caches serve gathers)",
                 "traffic": traffic if traffic else ("stale" if pmc.get("stale") else None),
-                "traffic_source": (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE x {pmc.get('fetch_scale')} gfx950 calibration + WRITE_SIZE, "
-                                   f"separate runs), {pmc.get('from')}, on this very kernel source (sha checked); durations are live")
+                "traffic_source": (pmc_live["source"] + "; durations are live too") if traffic_live else
+                (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE x {pmc.get('fetch_scale')} gfx950 calibration + WRITE_SIZE, "
+                 f"separate runs), {pmc.get('from')}, on this very kernel source (sha checked); durations are live"
+                 + (f"; the live passes failed: {pmc_live.get('error')}" if pmc_live else ""))
                 if traffic else (f"STALE: {pmc.get('from')} was measured on another {pmc.get('stale')}; frac falls back to "
                                  "frac_algorithmic" if pmc.get("stale") else None),
                 "kernel": "segsum_kernel (one launch per aggregation, cut rows finished inside it), avg of fwd and bwd launches",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": seg_avg_ms,
-                "launches_timed": len(seg_ms)}
+                "launches_timed": len(seg_ms), "live_pmc": pmc_live,
+                "offline_pmc_bytes_per_launch": None if pmc.get("stale") else pmc.get("segsum_kernel_bytes_per_launch")}
         res = {
             "metric": "edges/sec per GNN layer (fwd+bwd)", "value": value, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "ms_per_step_repeats": repeats,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.storage == "f32" else "bf16 storage / f32 accumulate (NOT the metric's precision)",
             "data": "synthetic",
             "config": {"workload": f"C4 synthetic ncRNA-protein bipartite graph, N={N} nodes, E={E} directed edges "
                                    f"(both directions, Zipf-skewed protein side), 1 {args.conv.upper()}Conv layer "
                                    f"{F}->{F} fp32, fwd+bwd incl. dX/dW/db, graph+features resident in HBM",
-                       "parallelism": parallelism(args, world), "hip_graph_replay": captured, "setup_steps": SETUP_STEPS,
+                       "parallelism": parallelism(args, world), "hip_graph_replay": captured, "setup_steps": args.setup_steps,
                        "csr_build_s": round(t_build, 4), "csr_sorted_columns": (not args.plain_csr) if not sharded else False,
                        "fallback": fallback,
                        "autotune": autotune if sharded else None,
@@ -1042,12 +1112,12 @@ def main():
     # ---- after the timed region (one GPU only): control, per-config summary, CPU baseline -----------------
     if world == 1 and not sharded:
         del x_full, go_full
-        if not args.no_control and args.conv == "sage":
+        if not args.no_control and args.conv == "sage" and args.storage == "f32":
             try:
                 res["roofline"]["control_uniform"] = control_uniform(dev, N, E, F)
             except Exception as e:
                 res["roofline"]["control_uniform"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if not args.no_configs and args.conv == "sage":
+        if not args.no_configs and args.conv == "sage" and args.storage == "f32":
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_extras as X
             quick = not args.extras

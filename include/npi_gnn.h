@@ -556,14 +556,19 @@ int npi_confusion_update(const float* scores, int64_t lds, int64_t C, const int6
  * 1 / (1 - p).  Saved for the backward (may be NULL in evaluation): s = the summed input [B, D0], h1 = relu(lin1) before
  * dropout [B, D1], h2 [B, D2].  npi_mlp_head_bwd: ds (may be NULL) is the gradient of EACH readout; dW* / db* are written,
  * not accumulated; every sum over the batch runs in row order (deterministic).
+ * activation: what follows lin3 -- NPI_HEAD_LOG_SOFTMAX (Net_1) or NPI_HEAD_SIGMOID (the one-output variant,
+ * src/train_with_twoDataset_modelOnlyOneOutput.py:45-82: lin3 is 64 -> 1, `torch.sigmoid`, trained with binary cross entropy);
+ * `logp` / `dlogp` are then the sigmoid's output and its gradient.
  * ------------------------------------------------------------------------------------------ */
+#define NPI_HEAD_LOG_SOFTMAX 0
+#define NPI_HEAD_SIGMOID 1
 int npi_mlp_head_fwd(const float* r1, int64_t ld1, const float* r2, int64_t ld2, const float* r3, int64_t ld3,
                      int64_t B, int64_t D0, const float* W1, const float* b1, int64_t D1, const float* W2, const float* b2,
-                     int64_t D2, const float* W3, const float* b3, int64_t D3, const float* mask, float scale,
+                     int64_t D2, const float* W3, const float* b3, int64_t D3, const float* mask, float scale, int activation,
                      float* s, float* h1, float* h2, float* logp, void* stream);
 int64_t npi_mlp_head_workspace_elems(int64_t B, int64_t D1, int64_t D2, int64_t D3);
 int npi_mlp_head_bwd(int64_t B, int64_t D0, int64_t D1, int64_t D2, int64_t D3, const float* W1, const float* W2,
-                     const float* W3, const float* mask, float scale, const float* s, const float* h1, const float* h2,
+                     const float* W3, const float* mask, float scale, int activation, const float* s, const float* h1, const float* h2,
                      const float* logp, const float* dlogp, float* ds, float* dW1, float* db1, float* dW2, float* db2,
                      float* dW3, float* db3, float* workspace, int64_t workspace_elems, void* stream);
 

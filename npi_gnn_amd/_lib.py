@@ -112,10 +112,10 @@ PROTOTYPES = {
     "npi_readout_max_mean_bwd": (c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P]),
     "npi_readout_max_mean_bwd_ex": (c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     "npi_confusion_update": (c_int, [_P, _I, _I, _P, _I, _P, _P]),
-    "npi_mlp_head_fwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, c_float,
+    "npi_mlp_head_fwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, c_float, c_int,
                                  _P, _P, _P, _P, _P]),
     "npi_mlp_head_workspace_elems": (_I, [_I, _I, _I, _I]),
-    "npi_mlp_head_bwd": (c_int, [_I, _I, _I, _I, _I, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "npi_mlp_head_bwd": (c_int, [_I, _I, _I, _I, _I, _P, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  _P, _I, _P]),
     "npi_subgraph_sizes": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "npi_subgraph_fill": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),

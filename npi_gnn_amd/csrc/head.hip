@@ -24,6 +24,7 @@ struct HeadArgs {
     const float* mask;                               // [B, D1] of 0 / 1, or null (evaluation)
     float scale;                                     // 1 / (1 - p)
     float *s, *h1, *h2, *logp;                       // saved for the backward: [B, D0], [B, D1] (ReLU output, before dropout), [B, D2]; out [B, D3]
+    int act;                                         // NPI_HEAD_LOG_SOFTMAX (Net_1) or NPI_HEAD_SIGMOID (Net_1_onlyOneOutput): what follows lin3
 };
 
 // out[r][j] = sum_k in[r][k] W[j][k] for the HEAD_R rows in LDS; thread -> column j = t % Dout, row group t / Dout
@@ -131,7 +132,10 @@ head_fwd_kernel(HeadArgs a) {
         }
     }
     __syncthreads();
-    if (t < HEAD_R && row0 + t < a.B) {                    // log_softmax of one row (D3 = 2 in the reference)
+    if (t < HEAD_R && row0 + t < a.B && a.act == NPI_HEAD_SIGMOID) {      // torch.sigmoid(lin3(x)): the one-output variant
+        // (reference src/train_with_twoDataset_modelOnlyOneOutput.py:80-81)
+        for (int c = 0; c < a.D3; ++c) a.logp[(int64_t)(row0 + t) * a.D3 + c] = 1.f / (1.f + expf(-z3[t * a.D3 + c]));
+    } else if (t < HEAD_R && row0 + t < a.B) {             // log_softmax of one row (D3 = 2 in the reference)
         const float* z = z3 + t * a.D3;
         float m = z[0];
         for (int c = 1; c < a.D3; ++c) m = fmaxf(m, z[c]);
@@ -150,6 +154,7 @@ struct HeadBwdArgs {
     float *dz1, *dz2, *dz3;          // [B, D1], [B, D2], [B, D3]
     float* ds;                       // [B, D0] or null
     float *dW1, *db1, *dW2, *db2, *dW3, *db3;
+    int act;                         // as HeadArgs.act (`logp` then holds the sigmoid's output)
 };
 
 // rows: dz3 = dlogp - softmax * sum(dlogp);  dz2 = (dz3 W3) [h2 > 0];  dz1 = (dz2 W2) mask scale [h1 > 0];  ds = dz1 W1
@@ -167,7 +172,8 @@ head_bwd_rows_kernel(HeadBwdArgs a) {
         for (int c = 0; c < a.D3; ++c) {
             float v = 0.f;
             if (row < a.B) {
-                v = a.dlogp[(int64_t)row * a.D3 + c] - expf(a.logp[(int64_t)row * a.D3 + c]) * sum;
+                const float o = a.logp[(int64_t)row * a.D3 + c], d = a.dlogp[(int64_t)row * a.D3 + c];
+                v = a.act == NPI_HEAD_SIGMOID ? d * o * (1.f - o) : d - expf(o) * sum;      // sigmoid' = y (1 - y)
                 a.dz3[(int64_t)row * a.D3 + c] = v;
             }
             z3s[t * a.D3 + c] = v;
@@ -285,15 +291,16 @@ using namespace npi;
 extern "C" int npi_mlp_head_fwd(const float* r1, int64_t ld1, const float* r2, int64_t ld2, const float* r3, int64_t ld3,
                                 int64_t B, int64_t D0, const float* W1, const float* b1, int64_t D1, const float* W2,
                                 const float* b2, int64_t D2, const float* W3, const float* b3, int64_t D3, const float* mask,
-                                float scale, float* s, float* h1, float* h2, float* logp, void* stream_) {
+                                float scale, int activation, float* s, float* h1, float* h2, float* logp, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(head_dims_ok(B, D0, D1, D2, D3), "npi_mlp_head_fwd: bad size (D0 <= 1024, D1, D2 <= 256, D3 <= 32, widths multiples of 4)");
     if (B == 0) return NPI_OK;
+    NPI_REQUIRE(activation == NPI_HEAD_LOG_SOFTMAX || activation == NPI_HEAD_SIGMOID, "npi_mlp_head_fwd: unknown activation");
     NPI_REQUIRE(r1 && W1 && b1 && W2 && b2 && W3 && b3 && logp, "npi_mlp_head_fwd: null pointer");
     NPI_REQUIRE(ld1 >= D0 && (!r2 || ld2 >= D0) && (!r3 || ld3 >= D0) && (r2 || !r3), "npi_mlp_head_fwd: bad readout arguments");
     NPI_REQUIRE(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)W3) % 16 == 0, "npi_mlp_head_fwd: weights must be 16-byte aligned");
     HeadArgs a{{r1, r2, r3}, {ld1, ld2, ld3}, r3 ? 3 : (r2 ? 2 : 1), (int)B, (int)D0, (int)D1, (int)D2, (int)D3,
-               W1, b1, W2, b2, W3, b3, mask, scale, s, h1, h2, logp};
+               W1, b1, W2, b2, W3, b3, mask, scale, s, h1, h2, logp, activation};
     head_fwd_kernel<<<(unsigned)ceil_div(B, HEAD_R), HEAD_T, 0, stream>>>(a);
     return check_launch("npi_mlp_head_fwd");
 }
@@ -303,12 +310,13 @@ extern "C" int64_t npi_mlp_head_workspace_elems(int64_t B, int64_t D1, int64_t D
 }
 
 extern "C" int npi_mlp_head_bwd(int64_t B, int64_t D0, int64_t D1, int64_t D2, int64_t D3, const float* W1, const float* W2,
-                                const float* W3, const float* mask, float scale, const float* s, const float* h1,
+                                const float* W3, const float* mask, float scale, int activation, const float* s, const float* h1,
                                 const float* h2, const float* logp, const float* dlogp, float* ds, float* dW1, float* db1,
                                 float* dW2, float* db2, float* dW3, float* db3, float* workspace, int64_t workspace_elems,
                                 void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(head_dims_ok(B, D0, D1, D2, D3), "npi_mlp_head_bwd: bad size");
+    NPI_REQUIRE(activation == NPI_HEAD_LOG_SOFTMAX || activation == NPI_HEAD_SIGMOID, "npi_mlp_head_bwd: unknown activation");
     NPI_REQUIRE(W1 && W2 && W3 && s && h1 && h2 && logp && dlogp && dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace,
                 "npi_mlp_head_bwd: null pointer");
     if (workspace_elems < npi_mlp_head_workspace_elems(B, D1, D2, D3)) {
@@ -316,7 +324,7 @@ extern "C" int npi_mlp_head_bwd(int64_t B, int64_t D0, int64_t D1, int64_t D2, i
         return NPI_ERR_WORKSPACE;
     }
     HeadBwdArgs a{(int)B, (int)D0, (int)D1, (int)D2, (int)D3, W1, W2, W3, mask, scale, s, h1, h2, logp, dlogp,
-                  workspace, workspace + B * D1, workspace + B * (D1 + D2), ds, dW1, db1, dW2, db2, dW3, db3};
+                  workspace, workspace + B * D1, workspace + B * (D1 + D2), ds, dW1, db1, dW2, db2, dW3, db3, activation};
     if (B > 0) head_bwd_rows_kernel<<<(unsigned)ceil_div(B, HEAD_R), HEAD_T, 0, stream>>>(a);
     const unsigned nb = (unsigned)(D1 * head_jblocks((int)D0) + D2 * head_jblocks((int)D1) + D3 * head_jblocks((int)D2) +
                                    head_jblocks((int)D1) + head_jblocks((int)D2) + head_jblocks((int)D3));

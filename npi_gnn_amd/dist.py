@@ -440,6 +440,12 @@ class HipBackend:
             return None
         return NF._side_stream(like.device)
 
+    def overlap_wanted(self, like, sch: Schedule = DEFAULT) -> bool:
+        """would ``side_stream`` hand out a stream if no capture were on?  (the weight-gradient GEMM keeps the grid regime -- and
+        with it the slab count and the order of its sums -- of the eager step, so a captured step replays the same NUMBERS)"""
+        from . import functional as NF
+        return NF._overlaps(sch, like.size(0))
+
     def partial_stream(self, like, sch: Schedule = DEFAULT):
         """third HIP stream for the partial (side B) aggregation of a direction, or None for small shards.  None as well while
         the current stream is being CAPTURED into a HIP graph: in the backward this stream is forked from the side stream, itself
@@ -893,7 +899,8 @@ class _ShardedSageFn(torch.autograd.Function):
         if side is not None:
             side.wait_stream(main)
         if want_w:
-            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias, shared=True) if side is not None else \
+            shared = side is not None or (want_x and hasattr(be, "overlap_wanted") and be.overlap_wanted(grad_out, sg.schedule))
+            dw, db = be.linear_bwd_weight(agg, grad_out, ctx.has_bias, shared=True) if shared else \
                 be.linear_bwd_weight(agg, grad_out, ctx.has_bias)
         if want_x:
             def chain():

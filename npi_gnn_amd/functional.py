@@ -768,6 +768,24 @@ class GCNNorm:
         return self.norm[1]
 
 
+class PlainWeights:
+    """``GCNConv(normalize=False)`` (PyG 1.4.2: ``norm = edge_weight``): the per-entry weights of both orientations over the edge
+    list AS IT IS -- no self loop appended, existing ones ordinary entries -- in the shape the GCN functions take (``.graph``,
+    ``.by_dst``, ``.by_src``; None = unweighted)."""
+
+    def __init__(self, edge_index, num_nodes: int, edge_weight: Optional[torch.Tensor] = None):
+        if isinstance(edge_index, CSRGraph):
+            if edge_index.self_loops or not edge_index.keep_equal:
+                raise ValueError("GCNConv(normalize=False) aggregates over the edge list as it is: build the graph with "
+                                 "CSRGraph(edge_index, N, self_loops=False, keep_equal=True)")
+            self.graph = edge_index
+        else:
+            ei = edge_index.edge_index if hasattr(edge_index, "edge_index") else edge_index
+            self.graph = CSRGraph(ei, num_nodes, self_loops=False, keep_equal=True)
+        w = entry_weights(self.graph, edge_weight, 1.0) if edge_weight is not None else [None, None]
+        self.by_dst, self.by_src = w
+
+
 class _GcnConvFn(torch.autograd.Function):
     """PyG's literal order: project, then aggregate at width F_out (used when F_in > F_out, e.g. C1's 178 -> 64)."""
 
@@ -865,7 +883,7 @@ class _GcnAggFirstFn(torch.autograd.Function):
 
 def gcn_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
              edge_weight: Optional[torch.Tensor] = None, improved: bool = False,
-             norm: Optional[GCNNorm] = None, schedule: Schedule = DEFAULT) -> torch.Tensor:
+             norm: Optional[GCNNorm] = None, schedule: Schedule = DEFAULT, normalize: bool = True) -> torch.Tensor:
     """PyG 1.4.2 ``GCNConv.forward`` (normalize=True) on MI355X.  Evaluated as ``(A_hat x) W + b`` when the input is not wider
     than the output (``_GcnAggFirstFn``: the aggregation at the narrower width, dW under the backward aggregation), in PyG's
     literal order ``A_hat (x W) + b`` otherwise -- the same number up to fp32 rounding."""
@@ -873,7 +891,8 @@ def gcn_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, bias: Optional[t
     if edge_weight is not None and edge_weight.requires_grad:
         raise NotImplementedError("gradients w.r.t. edge_weight are not implemented")
     if norm is None:
-        norm = GCNNorm(as_graph(edge_index, x.size(0)), edge_weight, improved)
+        norm = GCNNorm(as_graph(edge_index, x.size(0)), edge_weight, improved) if normalize else \
+            PlainWeights(edge_index, x.size(0), edge_weight)            # normalize=False: norm = edge_weight, no self loops
     if weight.size(0) <= weight.size(1):
         return _GcnAggFirstFn.apply(x, weight, bias, norm, schedule)
     return _GcnConvFn.apply(x, weight, bias, norm)

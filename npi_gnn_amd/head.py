@@ -30,7 +30,7 @@ def head_dims_ok(D0: int, D1: int, D2: int, D3: int) -> bool:
 
 class _HeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mask, scale, n_r, *args):
+    def forward(ctx, mask, scale, n_r, act, *args):
         rs, (W1, b1, W2, b2, W3, b3) = args[:n_r], args[n_r:]
         dev = require_gpu(*rs, W1, b1, W2, b2, W3, b3, mask)
         for r in rs:
@@ -54,9 +54,9 @@ class _HeadFn(torch.autograd.Function):
                 raise ValueError("MLP head: the dropout mask must be [B, D1]")
         pr = [(ptr(r), r.stride(0)) for r in rs] + [(None, 0)] * (3 - len(rs))
         check(load().npi_mlp_head_fwd(pr[0][0], pr[0][1], pr[1][0], pr[1][1], pr[2][0], pr[2][1], B, D0, ptr(W1), ptr(b1), D1,
-                                      ptr(W2), ptr(b2), D2, ptr(W3), ptr(b3), D3, ptr(mask), float(scale), ptr(s), ptr(h1),
+                                      ptr(W2), ptr(b2), D2, ptr(W3), ptr(b3), D3, ptr(mask), float(scale), int(act), ptr(s), ptr(h1),
                                       ptr(h2), ptr(logp), stream_ptr(dev)), "npi_mlp_head_fwd")
-        ctx.n_r, ctx.scale = n_r, float(scale)
+        ctx.n_r, ctx.scale, ctx.act = n_r, float(scale), int(act)
         ctx.has_mask = mask is not None
         if keep:
             ctx.save_for_backward(W1, W2, W3, s, h1, h2, logp, *([mask] if mask is not None else []))
@@ -71,7 +71,7 @@ class _HeadFn(torch.autograd.Function):
         B, D0 = s.shape
         D1, D2, D3 = W1.size(0), W2.size(0), W3.size(0)
         f32 = dict(dtype=torch.float32, device=dev)
-        want_x = any(ctx.needs_input_grad[3:3 + ctx.n_r])
+        want_x = any(ctx.needs_input_grad[4:4 + ctx.n_r])
         ds = torch.empty((B, D0), **f32) if want_x else None
         dW1, db1 = torch.empty_like(W1), torch.empty(D1, **f32)
         dW2, db2 = torch.empty_like(W2), torch.empty(D2, **f32)
@@ -79,17 +79,25 @@ class _HeadFn(torch.autograd.Function):
         lib = load()
         n_ws = int(lib.npi_mlp_head_workspace_elems(B, D1, D2, D3))
         ws = torch.empty(n_ws, **f32)
-        check(lib.npi_mlp_head_bwd(B, D0, D1, D2, D3, ptr(W1), ptr(W2), ptr(W3), ptr(mask), ctx.scale, ptr(s), ptr(h1), ptr(h2),
+        check(lib.npi_mlp_head_bwd(B, D0, D1, D2, D3, ptr(W1), ptr(W2), ptr(W3), ptr(mask), ctx.scale, ctx.act, ptr(s), ptr(h1), ptr(h2),
                                    ptr(logp), ptr(dlogp), ptr(ds), ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(dW3), ptr(db3),
                                    ptr(ws), n_ws, stream_ptr(dev)), "npi_mlp_head_bwd")
-        grads_r = [ds if ctx.needs_input_grad[3 + i] else None for i in range(ctx.n_r)]
-        return (None, None, None, *grads_r, dW1, db1, dW2, db2, dW3, db3)
+        grads_r = [ds if ctx.needs_input_grad[4 + i] else None for i in range(ctx.n_r)]
+        return (None, None, None, None, *grads_r, dW1, db1, dW2, db2, dW3, db3)
+
+
+ACTIVATIONS = {"log_softmax": 0, "sigmoid": 1}           # NPI_HEAD_LOG_SOFTMAX / NPI_HEAD_SIGMOID
 
 
 def mlp_head(readouts: Sequence[torch.Tensor], lin1: torch.nn.Linear, lin2: torch.nn.Linear, lin3: torch.nn.Linear,
-             p: float = 0.5, training: bool = False, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+             p: float = 0.5, training: bool = False, mask: Optional[torch.Tensor] = None,
+             activation: str = "log_softmax") -> torch.Tensor:
     """``log_softmax(lin3(relu(lin2(dropout(relu(lin1(sum(readouts))), p)))))``; up to three readouts ``[B, D0]``.
-    ``mask`` (``[B, D1]`` of 0 / 1): the dropout mask to use instead of a fresh one (tests)."""
+    ``mask`` (``[B, D1]`` of 0 / 1): the dropout mask to use instead of a fresh one (tests).
+    ``activation="sigmoid"``: ``torch.sigmoid(lin3(...))`` instead of the log-softmax -- the head of the reference's one-output
+    variant (``src/train_with_twoDataset_modelOnlyOneOutput.py:45-82``; ``lin3`` is 64 -> 1, the loss binary cross entropy)."""
+    if activation not in ACTIVATIONS:
+        raise ValueError(f"mlp_head: activation must be one of {sorted(ACTIVATIONS)}")
     readouts = list(readouts)
     if not 1 <= len(readouts) <= 3:
         raise ValueError("mlp_head takes one to three readouts")
@@ -105,5 +113,5 @@ def mlp_head(readouts: Sequence[torch.Tensor], lin1: torch.nn.Linear, lin2: torc
         scale = 1.0 / (1.0 - p)
     else:
         mask = None
-    return _HeadFn.apply(mask, scale, len(readouts), *readouts, lin1.weight, lin1.bias, lin2.weight, lin2.bias,
-                         lin3.weight, lin3.bias)
+    return _HeadFn.apply(mask, scale, len(readouts), ACTIVATIONS[activation], *readouts, lin1.weight, lin1.bias, lin2.weight,
+                         lin2.bias, lin3.weight, lin3.bias)

@@ -26,6 +26,9 @@ class Net_1(torch.nn.Module):
     ``[global_max_pool || global_mean_pool]`` readout after each summed, then the 256-128-64-2 MLP with
     dropout 0.5 after ``lin1`` and ``log_softmax``."""
 
+    #: what follows lin3 (head.mlp_head's ``activation``); the one-output variant below overrides it
+    head_activation = "log_softmax"
+
     def __init__(self, num_node_features, num_of_classes=2, dropout: float = 0.5):
         super().__init__()
         self.dropout = dropout                                # 0.5 in the reference (src/classes.py:76)
@@ -52,13 +55,25 @@ class Net_1(torch.nn.Module):
             readouts.append(NP.global_max_mean_pool(gb))
         if NH.head_dims_ok(self.lin1.in_features, self.lin1.out_features, self.lin2.out_features, self.lin3.out_features):
             # x1 + x2 + x3 and the whole MLP head (src/classes.py:74-80) in one forward / two backward launches
-            return NH.mlp_head(readouts, self.lin1, self.lin2, self.lin3, self.dropout, self.training)
+            return NH.mlp_head(readouts, self.lin1, self.lin2, self.lin3, self.dropout, self.training,
+                               activation=self.head_activation)
         x = readouts[0] + readouts[1] + readouts[2]
         x = F.relu(self.lin1(x))
         x = F.dropout(x, p=self.dropout, training=self.training)
         x = F.relu(self.lin2(x))
         x = self.lin3(x)
-        return F.log_softmax(x, dim=-1)
+        return torch.sigmoid(x) if self.head_activation == "sigmoid" else F.log_softmax(x, dim=-1)
+
+
+class Net_1_onlyOneOutput(Net_1):
+    """The reference's one-output variant (``src/train_with_twoDataset_modelOnlyOneOutput.py:45-82``): the same three conv /
+    pooling stages and readouts, ``lin3`` 64 -> 1 and ``torch.sigmoid`` instead of the two-class log-softmax; trained with
+    ``F.binary_cross_entropy(output, y.float().view(-1, 1))`` (``:89-98``).  The head -- readout sum, MLP and the sigmoid --
+    is the same fused forward / backward pair (``head.mlp_head(..., activation="sigmoid")``)."""
+    head_activation = "sigmoid"
+
+    def __init__(self, num_node_features, num_of_classes=2, dropout: float = 0.5):
+        super().__init__(num_node_features, 1, dropout)       # (the reference ignores num_of_classes too: lin3 = Linear(64, 1))
 
 
 class Batch(GraphBatch):

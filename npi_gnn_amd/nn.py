@@ -98,8 +98,8 @@ class GATConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
                  negative_slope: float = 0.2, dropout: float = 0.0, bias: bool = True, schedule: Schedule = DEFAULT, **kwargs):
         super().__init__()
-        if dropout != 0:
-            raise NotImplementedError("GATConv: attention dropout is not implemented")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError("GATConv: dropout must be in [0, 1)")
         self.schedule = schedule
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
@@ -121,6 +121,11 @@ class GATConv(nn.Module):
         """``relu=True`` (an extension of the PyG signature, as in ``SAGEConv``): ``F.relu(conv(x, edge_index))`` fused."""
         if size is not None:
             raise NotImplementedError("GATConv: bipartite `size` is not implemented")
+        if self.dropout > 0 and self.training:
+            # F.dropout(alpha, p, training=True) draws a fresh mask per edge and head: the kernels never hold alpha (it is
+            # recomputed per entry in both directions), so a TRAINING step with attention dropout is not served; in evaluation
+            # (model.eval(), the reference's test loop) dropout is the identity and the layer runs as usual
+            raise NotImplementedError("GATConv: attention dropout in training mode is not implemented (evaluation is)")
         if isinstance(x, GraphBatch):
             gb = _only_batch(x, edge_index, "GATConv")
             return gb.with_x(F_.gat_conv(gb.x, gb.graph(), self.weight, self.att, self.bias, self.heads, self.concat,
@@ -139,8 +144,6 @@ class GCNConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, improved: bool = False, cached: bool = False,
                  bias: bool = True, normalize: bool = True, schedule: Schedule = DEFAULT, **kwargs):
         super().__init__()
-        if not normalize:
-            raise NotImplementedError("GCNConv(normalize=False) is not implemented")
         self.schedule = schedule
         self.in_channels = in_channels
         self.out_channels = out_channels
@@ -164,7 +167,7 @@ class GCNConv(nn.Module):
     def forward(self, x, edge_index=None, edge_weight=None):
         if isinstance(x, GraphBatch):
             gb = _only_batch(x, edge_index, "GCNConv")
-            return gb.with_x(self.forward(gb.x, gb.graph(), edge_weight))
+            return gb.with_x(self.forward(gb.x, gb.graph() if self.normalize else gb.edge_index, edge_weight))
         norm = None
         if self.cached and self.cached_result is not None:
             E = edge_index.num_edges if isinstance(edge_index, CSRGraph) else edge_index.size(1)
@@ -175,11 +178,13 @@ class GCNConv(nn.Module):
                     "constructor.")
             norm = self.cached_result
         if norm is None:
-            graph = as_graph(edge_index, x.size(0))
-            norm = F_.GCNNorm(graph, edge_weight, self.improved)
+            if self.normalize:
+                norm = F_.GCNNorm(as_graph(edge_index, x.size(0)), edge_weight, self.improved)
+            else:                                      # PyG 1.4.2: norm = edge_weight on the edge list as it is (no self loops)
+                norm = F_.PlainWeights(edge_index, x.size(0), edge_weight)
             if self.cached:
                 self.cached_result = norm
-                self.cached_num_edges = graph.num_edges
+                self.cached_num_edges = norm.graph.num_edges
         return F_.gcn_conv(x, None, self.weight, self.bias, norm=norm, schedule=self.schedule)
 
     def __repr__(self):

@@ -165,12 +165,16 @@ def gcn_norm(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tensor] =
 
 
 def gcn_conv(x: Tensor, edge_index: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
-             edge_weight: Optional[Tensor] = None, improved: bool = False) -> Tensor:
-    """PyG 1.4.2 ``GCNConv.forward`` (normalize=True): project FIRST, then
-    ``out[i] = sum_e norm_e * (xW)[src e] + b``.  Parity unpinned (module docstring)."""
+             edge_weight: Optional[Tensor] = None, improved: bool = False, normalize: bool = True) -> Tensor:
+    """PyG 1.4.2 ``GCNConv.forward``: project FIRST, then ``out[i] = sum_e norm_e * (xW)[src e] + b``.  ``normalize=False``:
+    ``norm = edge_weight`` on the edge list AS IT IS (no self loop added; ``message`` multiplies only when a norm is given).
+    Parity unpinned (module docstring)."""
     N = x.size(0)
     xw = torch.matmul(x, weight)
-    ei, norm = gcn_norm(edge_index, N, edge_weight, improved, x.dtype)
+    if normalize:
+        ei, norm = gcn_norm(edge_index, N, edge_weight, improved, x.dtype)
+    else:
+        ei, norm = edge_index, (edge_weight if edge_weight is not None else torch.ones(edge_index.size(1), dtype=x.dtype))
     msg = norm.view(-1, 1) * xw.index_select(0, ei[0])
     out = scatter_add(msg, ei[1], N)
     if bias is not None:

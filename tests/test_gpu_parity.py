@@ -363,6 +363,46 @@ def test_gcn_conv_fwd_bwd_matches_oracle(dev, weighted, improved, Fi, Fo):
     assert rel_max(Wd.grad, W6.grad) <= GRAD_REL and rel_max(bd.grad, b6.grad) <= GRAD_REL
 
 
+@pytest.mark.parametrize("Fi,Fo,weighted", [(64, 128, True), (178, 64, True), (128, 128, False)])
+def test_gcn_conv_normalize_false_matches_oracle(dev, Fi, Fo, weighted):
+    """``GCNConv(normalize=False)`` (PyG 1.4.2): ``norm = edge_weight`` over the edge list as it is -- no self loop is added,
+    existing (i, i) columns are ordinary messages; both evaluation orders.  Parity unpinned (the reference never constructs a
+    GCNConv)."""
+    N, E = 2500, 20000
+    ei = rand_edges(N, E, seed=13, hub=3)
+    ei[:, :2] = torch.tensor([[4, 9], [4, 9]])
+    g = torch.Generator().manual_seed(14)
+    x, go = torch.randn(N, Fi, generator=g), torch.randn(N, Fo, generator=g)
+    ew = torch.rand(E, generator=g) + 0.1 if weighted else None
+    conv = npi.GCNConv(Fi, Fo, normalize=False).to(dev)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.5, 0.5)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, ei.to(dev), None if ew is None else ew.to(dev))
+    out.backward(go.to(dev))
+    x6, W6, b6 = (t.detach().cpu().double().clone().requires_grad_(True) for t in (x, conv.weight, conv.bias))
+    ref = R.gcn_conv(x6, ei, W6, b6, None if ew is None else ew.double(), normalize=False)
+    ref.backward(go.double())
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= ATOL * scale
+    assert float((xd.grad.cpu().double() - x6.grad).abs().max()) <= ATOL * max(1.0, float(x6.grad.abs().max()))
+    assert rel_max(conv.weight.grad, W6.grad) <= GRAD_REL and rel_max(conv.bias.grad, b6.grad) <= GRAD_REL
+
+
+def test_gat_conv_with_dropout_runs_in_evaluation_mode_only(dev):
+    """attention dropout is the identity in evaluation (the reference's test loop calls model.eval()): the layer then equals the
+    dropout-free one; a TRAINING step with dropout > 0 is refused, never silently computed without the mask"""
+    ei = rand_edges(300, 2000, seed=3).to(dev)
+    x = torch.randn(300, 32, device=dev)
+    a, b = npi.GATConv(32, 16, heads=2, dropout=0.6).to(dev), npi.GATConv(32, 16, heads=2).to(dev)
+    b.load_state_dict(a.state_dict())
+    a.eval()
+    assert torch.equal(a(x, ei), b(x, ei))
+    a.train()
+    with pytest.raises(NotImplementedError):
+        a(x, ei)
+
+
 def test_modules_drop_into_a_net1_style_stack(dev):
     """conv -> relu -> conv, loss.backward(), optimizer.step(): the reference's call pattern
     (src/classes.py:62-70, src/train_with_twoDataset.PY:46-57) with the module interface."""

@@ -432,11 +432,13 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
         dev_rel = float((convb(xb, g4).detach().float() - ref).abs().max() / ref.abs().max())
         # SURVEY 8(d) with s = 2 bytes per stored element: per edge F s + 4 = 516 B, per node 2 F s + 4 = 1,028 B
         alg = algorithmic_bytes(E4, N4, F, s=2)
+        tr = None if pmc.get("stale") else pmc.get("bf16_segsum_bytes_per_launch")
         return {"workload": f"C4 graph, 1 x SAGEConv {F}->{F} fwd+bwd, bf16 storage / f32 accumulate (NOT the metric's precision)",
                 "ms_per_step": ms, "edges_per_s": E4 / ms * 1e3, "max_dev_from_f32_output_rel": dev_rel,
-                "roofline": agg_roofline(ev, alg, None, "segsum_kernel<bf16, 4, 1, W_NONE>, avg of the forward and the backward "
-                                         "launch (the latter co-resident with dW); NOT the metric's precision", "no PMC pass "
-                                         "for the bf16 kernels: algorithmic bytes (516 B per edge, 1,028 B per node) only")}
+                "roofline": agg_roofline(ev, alg, tr, "segsum_kernel<bf16, 4, 1, W_NONE>, avg of the forward and the backward "
+                                         "launch (the latter co-resident with dW); NOT the metric's precision",
+                                         pmc.get("bf16_from") if tr else "no current PMC pass for the bf16 kernels: algorithmic "
+                                         "bytes (516 B per edge, 1,028 B per node) only")}
 
     guarded("gcn_c4", gcn_c4, 2)
     guarded("gat_c4", gat_c4, 2)

@@ -2,7 +2,7 @@
 """Condense rocprofv3 CSV output (tools/profile_bench.sh) into the files kept under profiles/:
   <tag>_kernel_stats.csv   the --kernel-trace --stats summary, as rocprofv3 wrote it
   <tag>_pmc_summary.json   per-kernel mean FETCH_SIZE / WRITE_SIZE (KB, raw) from the separate --pmc passes
-usage: tools/rocprof_summary.py gpurun_out/prof_<tag> <tag> [fetch_scale] [sage|gat|gcn|c5gat]
+usage: tools/rocprof_summary.py gpurun_out/prof_<tag> <tag> [fetch_scale] [sage|gat|gcn|c5gat|bf16]
 fetch_scale = calibration factor for FETCH_SIZE in the segsum access pattern (tools/pmc_calibrate.py).
 The last argument says which constants of profiles/pmc_traffic.json the run provides: the headline SAGE launch (default),
 the two GATConv aggregation kernels (bench.py --conv gat), or GCNConv's weighted launch (--conv gcn)."""
@@ -59,7 +59,7 @@ def main():
         from bench import kernel_source_sha
         p = os.path.join(out, "pmc_traffic.json")
         t = json.load(open(p)) if os.path.exists(p) else {}
-        main = lambda m: (lambda k: "segsum_kernel" in k and mode(k) == m)
+        main = lambda m: (lambda k: "segsum_kernel<float" in k and mode(k) == m)
         t.pop("includes_fixup_kernel", None)        # (rounds 1-3: a second launch; cut rows are finished inside the launch now)
         if kind == "sage":
             # per aggregation launch (ONE kernel), averaged over the forward and the backward launch
@@ -72,6 +72,9 @@ def main():
                       "c5_from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "gcn":
             t.update({"gcn_segsum_bytes_per_launch": kb(main(1)), "gcn_from": f"profiles/{tag}_pmc_summary.json"})
+        elif kind == "bf16":       # the headline layer with bf16 storage (bench.py --storage bf16): segsum_kernel<unsigned short, 4, 1, 0, true>
+            bf = lambda k: "segsum_kernel<unsigned short" in k and mode(k) == 0
+            t.update({"bf16_segsum_bytes_per_launch": kb(bf), "bf16_from": f"profiles/{tag}_pmc_summary.json"})
         t["source_sha16"] = kernel_source_sha()
         json.dump(t, open(p, "w"), indent=1)
     print(json.dumps(res, indent=1)[:1500])
