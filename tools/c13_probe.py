@@ -4,7 +4,8 @@ kernels of a step.  usage: tools/c13_probe.py [c1|c3]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench as B
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_extras as B
 import npi_gnn_amd as npi
 from npi_gnn_amd import functional as NF
 dev = torch.device("cuda:0")

@@ -4,7 +4,8 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench as B
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_extras as B
 import npi_gnn_amd as npi
 from npi_gnn_amd.synth import bipartite_edge_index
 dev = torch.device("cuda:0")

@@ -56,7 +56,10 @@ val = {
     "GATH": " / ".join(f2(x) for x in c["gat_c4"]["ms_per_step_by_heads"].values()),
     "C5": "%.1f" % c["C5_1gpu"]["ms_per_step"], "C5R": "%.2f" % (c["C5_1gpu"]["edge_layers_per_s"] / 1e9),
     "C5L": "%.1f" % c["C5_1gpu"].get("ms_per_step_with_mse_loss", float("nan")),
-    "C1": f2(c["C1"]["ms_per_step"]), "C2": f2(c["C2"]["ms_per_step"]), "C2F": f2(c["C2"]["ms_per_step_f32"]),
+    "C1": f2(c["C1"]["ms_per_step"]), "C1G": "%.3f" % (c["C1"].get("ms_per_step_graph") or float("nan")),
+    "C3G": "%.3f" % (c["C3"].get("ms_per_step_graph") or float("nan")),
+    "PAR": "%.1e" % b["parity_max_err"] if b.get("parity_max_err") is not None else "n/a",
+    "VSR": f2(v["hubs_sage"]["rank0_ms_graph_replay"]) if v["hubs_sage"].get("rank0_ms_graph_replay") else "n/a", "C2": f2(c["C2"]["ms_per_step"]), "C2F": f2(c["C2"]["ms_per_step_f32"]),
     "C2G": "%.3f" % (c["C2"].get("ms_per_step_graph") or float("nan")), "C2GF": "%.3f" % (c["C2"].get("ms_per_step_graph_f32") or float("nan")),
     "C3": f2(c["C3"]["ms_per_step"]), "C4B": f2(c["C4_bf16_storage"]["ms_per_step"]),
     "R": f2(c["R_net1_step"]["ms_per_step"]), "RE": f2(c["R_net1_step"]["ms_per_step_eager"]),
