@@ -16,10 +16,8 @@ run() { # name n_kernels cmd...
 W=${2:-vsage,vgat,gat1}
 [[ $W == *vsage* ]] && run vsage 60 python3 "$ROOT/tools/virtual_rank_probe.py" --conv sage --steps 6
 [[ $W == *vgat* ]] && run vgat 260 python3 "$ROOT/tools/virtual_rank_probe.py" --conv gat --steps 6
-[[ $W == *gat1* ]] && run gat1 60 python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-control --virtual-world 0 --conv gat
-[[ $W == *c5* ]] && run c5 60 python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-control --virtual-world 0 --conv gat --nodes 4000000 --edges 100000000 --graph-seed 2
-[[ $W == *c2b* ]] && run c2b 70 python3 "$ROOT/tools/c2_probe.py" bf16
-[[ $W == *c2f* ]] && run c2f 70 python3 "$ROOT/tools/c2_probe.py" f32
+[[ $W == *gat1* ]] && run gat1 60 python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-control --no-live-pmc --virtual-world 0 --conv gat
+[[ $W == *c5* ]] && run c5 60 python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-control --no-live-pmc --virtual-world 0 --conv gat --nodes 4000000 --edges 100000000 --graph-seed 2
 [[ $W == *c5s* ]] && run c5s 130 python3 "$ROOT/tools/c5_stack_probe.py" 2
 [[ $W == *net1* ]] && run net1 100 python3 "$ROOT/tools/net1_step_probe.py" 20
 [[ $W == *c3g* ]] && run c3g 60 python3 "$ROOT/tools/c13_probe.py" c3
