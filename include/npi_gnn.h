@@ -406,6 +406,15 @@ int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const in
                              int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                              float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
                              const float* bias, int relu, float* carry, void* stream);
+/* The same forward aggregation WITHOUT the statistics pass in front of it (one head of at most 256 channels): every item computes
+ * the scores e_p = leaky_relu(a_dst[row p] + a_src[col p]) of its own entries, weights a row against the maximum of its entries
+ * (exactly as above for a row that lies inside one item; the parts of a row cut by an item boundary are merged with
+ * exp(m_part - m_row) where cut rows are resolved, in a fixed order), and writes m[N], s[N] -- the row maximum and the row sum of
+ * exp(e - m) that npi_gat_pack_targets / the backward need -- beside out.  rowidx: the by-target CSR's row of every entry. */
+int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                            int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
+                            int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src,
+                            float slope, const float* bias, int relu, float* m, float* s, float* carry, void* stream);
 int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C);
 /* `F.relu(conv(x))` fused (npi_gat_aggregate_scores with relu != 0 applies the ReLU in the row epilogue): b is then the ReLU
  * OUTPUT, and this form first masks the incoming gradient, a' = a where b > 0 else 0 (threshold_backward), uses a' for D and

@@ -70,6 +70,7 @@ PROTOTYPES = {
                              c_int, _P, _I, _P]),
     "npi_conv_bwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I,
                              c_int, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P]),
+    "npi_gat_aggregate_fused": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, c_int, _P, _P, _P, _P]),
     "npi_gat_scores": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),

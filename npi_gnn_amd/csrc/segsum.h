@@ -6,8 +6,14 @@ namespace npi {
 
 enum { W_NONE = 0, W_ARRAY = 1, W_GAT_DST = 2, W_GAT_SRC = 3, W_GAT_SRC_PRE = 4, W_GAT_SRC_FUSED = 5, W_GAT_DST_PRE = 6,
        // the fused backward for 2 / 4 / 8 heads (packed form only; H C <= 256, C a power of two >= 32): compile-time head counts
-       W_GAT_SRC_FUSED_H2 = 7, W_GAT_SRC_FUSED_H4 = 8, W_GAT_SRC_FUSED_H8 = 9 };
-constexpr bool is_fused_mode(int m) { return m == W_GAT_SRC_FUSED || m >= W_GAT_SRC_FUSED_H2; }
+       W_GAT_SRC_FUSED_H2 = 7, W_GAT_SRC_FUSED_H4 = 8, W_GAT_SRC_FUSED_H8 = 9,
+       // round 5, one head, F <= 256: the FORWARD aggregation that also computes every entry's score and the softmax statistics of
+       // every row -- no separate statistics pass, no per-entry score array.  An item first computes the scores of its entries
+       // (lane-parallel, parked in LDS); a row that lies inside the item is weighted against its exact maximum, exactly as with the
+       // statistics pass in front; the parts of a row that is cut by item / workgroup boundaries carry their own (max, sum exp) and
+       // are merged with the usual rescaling exp(m_part - m_row) where the cut rows are resolved (segsum.hip)
+       W_GAT_DST_FUSED = 10 };
+constexpr bool is_fused_mode(int m) { return m == W_GAT_SRC_FUSED || (m >= W_GAT_SRC_FUSED_H2 && m <= W_GAT_SRC_FUSED_H8); }
 constexpr int fused_heads(int m) { return m == W_GAT_SRC_FUSED_H2 ? 2 : m == W_GAT_SRC_FUSED_H4 ? 4 : m == W_GAT_SRC_FUSED_H8 ? 8 : 1; }
 
 struct SegParams {
@@ -54,6 +60,10 @@ struct SegParams {
     // (a_dst, m, 1 / (s + 1e-16), D) of every TARGET node AND HEAD as one float4 ([n_cols, H, 4]): one 16-byte gather per entry
     // and head, alpha recomputed by the lane that owns the entry
     const float4* tpack;
+    // W_GAT_DST_FUSED: the statistics it computes, [N] each (one head): row max of the scores, row sum of exp(score - max);
+    // `rowidx` above is then the by-TARGET CSR's row of every entry, a_dst / a_src the per-node scores, slope the leaky_relu's
+    float* m_out;
+    float* s_out;
 };
 
 // x / out / bias are stored as `dtype` (NPI_F32 or NPI_BF16; the struct's float* are reinterpreted)

@@ -27,6 +27,10 @@
 //              recomputed by the lane that owns the entry from ONE 16-byte gather of packed per-target scalars (tpack)
 //   W_GAT_SRC  the same alpha seen from the by-source CSR (backward: d h_j = sum_i alpha_ij d out_i),
 //              plus the rank-1 terms of the attention-score gradient in the epilogue
+//   W_GAT_DST_FUSED  (round 5; one head, F <= 256) W_GAT_DST_PRE without the statistics pass in front of it: the item computes
+//              the scores of its own entries, every row part is weighted against the maximum of ITS entries and carries
+//              (max, sum exp) next to its partial row; parts of a cut row are merged with exp(m_part - m_row) where cut rows
+//              are resolved, and the row's (m, s) come out beside the output for the backward
 #include "segsum.h"
 #include <stdlib.h>
 
@@ -138,17 +142,25 @@ struct Lanes {
 };
 
 // scale, bias and epilogue of a finished row r, then the store
+// (m_val, s_val: W_GAT_DST_FUSED only -- the row's softmax statistics, complete; every other mode passes zeros)
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, NCH, WMODE, EXACT>& L,
-                                           const float (&acc)[NCH][VEC], int r, int row_len) {
+                                           const float (&acc)[NCH][VEC], int r, int row_len, float m_val = 0.f, float s_val = 0.f) {
     T* __restrict__ dst = reinterpret_cast<T*>(P.out) + (int64_t)r * P.ldo;
     const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
+    if constexpr (WMODE == W_GAT_DST_FUSED) {
+        if (lane_id() == 0) {                                // an empty row: m = 0, s = 0, as the statistics pass leaves it
+            P.m_out[r] = row_len > 0 ? m_val : 0.f;
+            P.s_out[r] = row_len > 0 ? s_val : 0.f;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (!L.act[c]) continue;
         float sc = 1.f;
         if (P.mean) sc = 1.f / (float)max(row_len, 1);       // scatter_mean's divisor (a launch argument, not a template one)
         if (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) sc = 1.f / (P.s[(int64_t)r * P.H + L.hd[c]] + 1e-16f);
+        if (WMODE == W_GAT_DST_FUSED) sc = 1.f / ((row_len > 0 ? s_val : 0.f) + 1e-16f);
         float t[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
@@ -208,6 +220,7 @@ constexpr int CHAIN_U = 8;           // partial rows in flight while a chain is 
 struct ItemMeta {                    // what a wavefront leaves behind for the resolver (LDS)
     int head_row, head_rs, head_re, head_closed;     // head_row < 0: no head partial; closed: the row ended inside the item
     int tail_row, tail_rs, tail_re;                   // tail_row < 0: no tail partial
+    float head_m, head_s, tail_m, tail_s;             // W_GAT_DST_FUSED: (max, sum exp(. - max)) of the part's entries
 };
 
 struct CarryLayout {                 // global scratch of one launch (f32 words); n_wg = workgroups of the launch
@@ -216,9 +229,13 @@ struct CarryLayout {                 // global scratch of one launch (f32 words)
         n_wg = (n_items + SEG_WAVES - 1) / SEG_WAVES;
         n_span = (n_wg + CHAIN_SPAN - 1) / CHAIN_SPAN;
     }
-    // [counters: n_wg row counters, 2 n_span span counters][pad to 64 words][2 n_wg rows of F][2 n_span rows of F]
+    // [counters: n_wg row counters, 2 n_span span counters][pad to 64 words]
+    // [ms: (max, sum exp) of every partial row below, 2 floats each: W_GAT_DST_FUSED][pad to 64 words]
+    // [2 n_wg rows of F][2 n_span rows of F]
     __host__ __device__ int64_t counters() const { return ((n_wg + 2 * n_span + 63) / 64) * 64; }
-    __host__ __device__ int64_t elems(int64_t F) const { return counters() + (2 * n_wg + 2 * n_span) * F; }
+    __host__ __device__ int64_t ms_words() const { return ((2 * (2 * n_wg + 2 * n_span) + 63) / 64) * 64; }
+    __host__ __device__ int64_t rows_off() const { return counters() + ms_words(); }
+    __host__ __device__ int64_t elems(int64_t F) const { return rows_off() + (2 * n_wg + 2 * n_span) * F; }
 };
 
 // write-through (sc1) stores of a partial row: hipcc does not count an asm store, the caller drains with drain_stores()
@@ -299,7 +316,7 @@ __device__ __forceinline__ void emit_partial(const SegParams& P, const Geo& L, c
     const CarryLayout lay(P.n_items);
     int* cnt_row = reinterpret_cast<int*>(P.carry);
     int* cnt_span = cnt_row + lay.n_wg;
-    float* rows = P.carry + lay.counters();                             // [2 n_wg, F]
+    float* rows = P.carry + lay.rows_off();                             // [2 n_wg, F]
     float* span_rows = rows + 2 * lay.n_wg * (int64_t)F;                // [2 n_span, F]
     const int b = blockIdx.x;
     const int fi = rs / S, li = (re - 1) / S, len = li - fi;            // workgroups of the row: fi .. li (len >= 1)
@@ -323,7 +340,7 @@ __device__ __forceinline__ void emit_partial(const SegParams& P, const Geo& L, c
         if (!arrive_last(cnt_row + fi, len + 1)) return;
         load_tail();
         add_rows<VEC, NCH>(L, acc, rows + (int64_t)(fi + 1) * 2 * F, 2 * (int64_t)F, 0, len);      // heads of fi + 1 .. li
-        finish(acc, r, re - rs);
+        finish(acc, r, re - rs, 0.f, 0.f);
         return;
     }
     const int g0 = (fi + 1) / CHAIN_SPAN, g1 = li / CHAIN_SPAN;          // spans that hold heads of this row
@@ -348,12 +365,159 @@ __device__ __forceinline__ void emit_partial(const SegParams& P, const Geo& L, c
     // span g0 holds the row in its slot 1 when the row began inside it, in slot 0 otherwise; every later span in slot 0
     add_rows<VEC, NCH>(L, acc, span_rows + ((int64_t)2 * g0 + (fi >= g0 * CHAIN_SPAN ? 1 : 0)) * F, 0, 0, 1);
     if (g1 > g0) add_rows<VEC, NCH>(L, acc, span_rows + (int64_t)2 * (g0 + 1) * F, 2 * (int64_t)F, 0, g1 - g0);
-    finish(acc, r, re - rs);
+    finish(acc, r, re - rs, 0.f, 0.f);
+}
+
+// ---- W_GAT_DST_FUSED: the same resolution for partial rows that carry softmax statistics -------------------------------------
+// A partial of a row = (acc = sum_p exp(e_p - m) x[col p], m = max_p e_p, s = sum_p exp(e_p - m)) over the part's entries.  Two
+// parts merge as  M = max(m1, m2),  acc = acc1 exp(m1 - M) + acc2 exp(m2 - M),  s likewise (the online softmax).  A chain is
+// merged against ITS maximum: first the (m, s) pairs of the chain (lane-parallel, a wave-wide max), then the rows in chain
+// order, each scaled by exp(m_k - M) -- the same fixed order as the plain sums above, so the result stays bitwise reproducible.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, WAVE));
+    return v;
+}
+// max of the m of n (m, s) pairs, `stride` floats apart
+__device__ __forceinline__ float chain_max(const float* ms, int64_t stride, int n) {
+    float m = -3.0e38f;
+    for (int j = lane_id(); j < n; j += WAVE) m = fmaxf(m, ms[(int64_t)j * stride]);
+    return wave_max(m);
+}
+// acc += sum_j exp(m_j - M) row_j,  s_acc += sum_j exp(m_j - M) s_j  over rows [0, n) of `base` (row stride `stride` floats),
+// their (m, s) pairs `ms_stride` floats apart; in row order, CHAIN_U rows in flight
+constexpr int SM_U = 4;             // partial rows in flight while a chain with statistics is merged
+template <int VEC, int NCH, class Geo>
+__device__ __forceinline__ void add_rows_scaled(const Geo& L, float (&acc)[NCH][VEC], float& s_acc, const float* base, int64_t stride,
+                                                const float* ms, int64_t ms_stride, int n, float M) {
+    const int lane = lane_id();
+    for (int j0 = 0; j0 < n; j0 += WAVE) {
+        const int nb = min(WAVE, n - j0);
+        float f = 0.f, sv = 0.f;
+        if (lane < nb) {
+            const float2 t = *reinterpret_cast<const float2*>(ms + (int64_t)(j0 + lane) * ms_stride);
+            f = expf(t.x - M);
+            sv = t.y * f;
+        }
+        for (int j = 0; j < nb; j += SM_U) {
+            float v[SM_U][NCH][VEC];
+#pragma unroll
+            for (int u = 0; u < SM_U; ++u) {
+                const float* src = base + (int64_t)(j0 + min(j + u, nb - 1)) * stride;       // past the end: the last row again, dropped
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (L.act[c]) load_row<VEC, float>(src + L.foff[c], v[u][c]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) v[u][c][k] = 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SM_U; ++u) {
+                if (j + u < nb) {                                // wave-uniform
+                    const float fj = bcast_f(f, j + u);
+                    s_acc += bcast_f(sv, j + u);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[c][k] = fmaf(fj, v[u][c][k], acc[c][k]);
+                }
+            }
+        }
+    }
+}
+
+template <int VEC, int NCH, class Geo, class Fin>
+__device__ __forceinline__ void emit_partial_sm(const SegParams& P, const Geo& L, const Fin& finish, float (&acc)[NCH][VEC],
+                                                int slot, int r, int rs, int re, float pm, float ps) {
+    const int F = P.F;
+    const int S = P.item * SEG_WAVES;
+    const CarryLayout lay(P.n_items);
+    int* cnt_row = reinterpret_cast<int*>(P.carry);
+    int* cnt_span = cnt_row + lay.n_wg;
+    float* msb = P.carry + lay.counters();                              // [2 n_wg + 2 n_span][2]: (m, s) of every partial row
+    float* span_ms = msb + 2 * (2 * lay.n_wg);
+    float* rows = P.carry + lay.rows_off();
+    float* span_rows = rows + 2 * lay.n_wg * (int64_t)F;
+    const int b = blockIdx.x;
+    const int fi = rs / S, li = (re - 1) / S, len = li - fi;
+    float* mine = rows + ((int64_t)b * 2 + slot) * F;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (L.act[c]) store_row_sc1<VEC>(mine + L.foff[c], acc[c]);
+    if (lane_id() == 0) {
+        const float t2[2] = {pm, ps};
+        store_row_sc1<2>(msb + ((int64_t)b * 2 + slot) * 2, t2);
+    }
+    drain_stores();
+    float s_tot = 0.f;
+    // the row's first partial (the tail of workgroup fi) scaled into acc / s_tot against the chain's maximum M
+    auto take_tail = [&](float M) {
+        const float* t = rows + ((int64_t)fi * 2 + 1) * F;
+        const float2 tms = *reinterpret_cast<const float2*>(msb + ((int64_t)fi * 2 + 1) * 2);
+        const float ft = expf(tms.x - M);
+        s_tot = tms.y * ft;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float v[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+            if (L.act[c]) load_row<VEC, float>(t + L.foff[c], v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[c][k] = v[k] * ft;
+        }
+    };
+    const float* tail_m = msb + ((int64_t)fi * 2 + 1) * 2;
+    if (len <= CHAIN_SPAN) {
+        if (!arrive_last(cnt_row + fi, len + 1)) return;
+        const float* hms = msb + (int64_t)(fi + 1) * 2 * 2;              // heads of fi + 1 .. li: slot 0 of consecutive workgroups
+        const float M = fmaxf(chain_max(hms, 4, len), *tail_m);
+        take_tail(M);
+        add_rows_scaled<VEC, NCH>(L, acc, s_tot, rows + (int64_t)(fi + 1) * 2 * F, 2 * (int64_t)F, hms, 4, len, M);
+        finish(acc, r, re - rs, M, s_tot);
+        return;
+    }
+    const int g0 = (fi + 1) / CHAIN_SPAN, g1 = li / CHAIN_SPAN;
+    if (slot == 0) {
+        const int g = b / CHAIN_SPAN;
+        const int sl = fi >= g * CHAIN_SPAN ? 1 : 0;
+        const int lo = max(fi + 1, g * CHAIN_SPAN), hi = min(li, g * CHAIN_SPAN + CHAIN_SPAN - 1);
+        if (!arrive_last(cnt_span + 2 * g + sl, hi - lo + 1)) return;
+        const float* hms = msb + (int64_t)lo * 2 * 2;
+        const float Mg = chain_max(hms, 4, hi - lo + 1);
+        float sg = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[c][k] = 0.f;
+        add_rows_scaled<VEC, NCH>(L, acc, sg, rows + (int64_t)lo * 2 * F, 2 * (int64_t)F, hms, 4, hi - lo + 1, Mg);
+        float* sp = span_rows + ((int64_t)2 * g + sl) * F;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (L.act[c]) store_row_sc1<VEC>(sp + L.foff[c], acc[c]);
+        if (lane_id() == 0) {
+            const float t2[2] = {Mg, sg};
+            store_row_sc1<2>(span_ms + ((int64_t)2 * g + sl) * 2, t2);
+        }
+        drain_stores();
+    }
+    if (!arrive_last(cnt_row + fi, 1 + (g1 - g0 + 1))) return;
+    // span g0 holds the row in its slot 1 when the row began inside it, in slot 0 otherwise; every later span in slot 0
+    const int64_t first = (int64_t)2 * g0 + (fi >= g0 * CHAIN_SPAN ? 1 : 0);
+    const float* later_ms = span_ms + (int64_t)2 * (g0 + 1) * 2;
+    float M = fmaxf(*tail_m, span_ms[first * 2]);
+    if (g1 > g0) M = fmaxf(M, chain_max(later_ms, 4, g1 - g0));
+    take_tail(M);
+    add_rows_scaled<VEC, NCH>(L, acc, s_tot, span_rows + first * F, 0, span_ms + first * 2, 0, 1, M);
+    if (g1 > g0) add_rows_scaled<VEC, NCH>(L, acc, s_tot, span_rows + (int64_t)2 * (g0 + 1) * F, 2 * (int64_t)F, later_ms, 4, g1 - g0, M);
+    finish(acc, r, re - rs, M, s_tot);
 }
 
 // Every wave calls this when its item is done (inactive waves too).  `part`: [SEG_WAVES][2][ROWF] LDS rows, `meta`: [SEG_WAVES],
 // both filled in by the waves themselves (lane 0 writes the meta words at the moment they are known).
-template <int VEC, int NCH, int ROWF, class Geo, class Fin>
+// SM: the partial rows carry softmax statistics (W_GAT_DST_FUSED): merged with rescaling instead of added
+template <int VEC, int NCH, int ROWF, bool SM = false, class Geo, class Fin>
 __device__ __forceinline__ void resolve_block(const SegParams& P, const Geo& L, const Fin& finish, float (*part)[2][ROWF],
                                               ItemMeta* meta, int* arrived) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                // the wave's partial rows and meta (LDS) before its arrival
@@ -365,7 +529,22 @@ __device__ __forceinline__ void resolve_block(const SegParams& P, const Geo& L, 
     float acc[NCH][VEC];
     bool open = false, wg_head = false;
     int orow = 0, ors = 0, ore = 0;
+    float om = 0.f, os = 0.f;                                           // SM: (max, sum exp) of the open row so far
     auto load_part = [&](int w, int slot, bool add) {
+        float f1 = 1.f, f2 = 1.f;
+        if constexpr (SM) {
+            const float pm = slot ? meta[w].tail_m : meta[w].head_m, ps = slot ? meta[w].tail_s : meta[w].head_s;
+            if (add) {
+                const float M = fmaxf(om, pm);
+                f1 = expf(om - M);
+                f2 = expf(pm - M);
+                os = os * f1 + ps * f2;
+                om = M;
+            } else {
+                om = pm;
+                os = ps;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             float v[VEC];
@@ -373,8 +552,15 @@ __device__ __forceinline__ void resolve_block(const SegParams& P, const Geo& L, 
             for (int k = 0; k < VEC; ++k) v[k] = 0.f;
             if (L.act[c]) load_row<VEC, float>(&part[w][slot][L.foff[c]], v);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[c][k] = add ? acc[c][k] + v[k] : v[k];
+            for (int k = 0; k < VEC; ++k) {
+                if constexpr (SM) acc[c][k] = add ? fmaf(acc[c][k], f1, v[k] * f2) : v[k];
+                else acc[c][k] = add ? acc[c][k] + v[k] : v[k];
+            }
         }
+    };
+    auto emit = [&](int slot) {
+        if constexpr (SM) emit_partial_sm<VEC, NCH>(P, L, finish, acc, slot, orow, ors, ore, om, os);
+        else emit_partial<VEC, NCH>(P, L, finish, acc, slot, orow, ors, ore);
     };
     for (int w = 0; w < SEG_WAVES; ++w) {                               // (wave-uniform control flow: meta is read by every lane)
         const int m_head_row = meta[w].head_row, m_tail_row = meta[w].tail_row;
@@ -387,8 +573,8 @@ __device__ __forceinline__ void resolve_block(const SegParams& P, const Geo& L, 
             }
             ore = meta[w].head_re;
             if (meta[w].head_closed) {
-                if (wg_head) emit_partial<VEC, NCH>(P, L, finish, acc, 0, orow, ors, ore);
-                else finish(acc, orow, ore - ors);                      // began and ended inside the workgroup
+                if (wg_head) emit(0);
+                else finish(acc, orow, ore - ors, om, os);              // began and ended inside the workgroup
                 open = false;
             }
         }
@@ -399,7 +585,7 @@ __device__ __forceinline__ void resolve_block(const SegParams& P, const Geo& L, 
     }
     if (open) {
         // wg_head: the whole workgroup lies inside one row
-        emit_partial<VEC, NCH>(P, L, finish, acc, wg_head ? 0 : 1, orow, ors, ore);
+        emit(wg_head ? 0 : 1);
     }
 }
 
@@ -441,12 +627,44 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     constexpr int HH = fused_heads(WMODE);           // heads of the fused GAT backward (1 in every other mode)
     __shared__ float seg_pb[SEG_WAVES][WAVE * HH];
     float* __restrict__ pb = seg_pb[threadIdx.x >> 6];
+    // W_GAT_DST_FUSED: the score e_p = leaky_relu(a_dst[row p] + a_src[col p]) of every entry of the item, computed lane-parallel
+    // up front and parked in LDS (one 64-entry block per wave instruction); the gather loop below reads a block's scores back as
+    // the other modes read their per-entry weights, and a row's maximum is a masked wave-wide max over the blocks it touches
+    constexpr bool SMX = WMODE == W_GAT_DST_FUSED;
+    __shared__ float seg_sc[SEG_WAVES][SMX ? NPI_ITEM_EDGES : 1];
+    float* __restrict__ sc_w = seg_sc[threadIdx.x >> 6];
+    float m_loc = 0.f, s_run = 0.f;      // the open row's part in this item: max of its scores, running sum of exp(. - max)
+    if constexpr (SMX) {
+        for (int kb = k0; kb < k1; kb += WAVE) {
+            const int p = kb + lane;
+            if (p < k1) {
+                const float z = P.a_dst[P.rowidx[p]] + P.a_src[P.col[p]];
+                sc_w[p - k0] = z > 0.f ? z : z * P.slope;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    (void)sc_w; (void)m_loc; (void)s_run;
     float hr[VEC];                       // W_GAT_SRC_FUSED: this lane's columns of the open row's own features (h_j)
 #pragma unroll
     for (int q = 0; q < VEC; ++q) hr[q] = 0.f;
     // per-row constants of the GAT weight (per lane: the head of its columns)
     float rs_a[NCH], rs_m[NCH], rs_i[NCH];
     auto open_row = [&]() {
+        if constexpr (SMX) {
+            // maximum of the scores of row r's entries that lie in this item: [max(row_start, k0), min(row_end, k1))
+            const int lo = max(row_start, k0), hi = min(row_end, k1);
+            float mx = -3.0e38f;
+            for (int kb = k0 + ((lo - k0) & ~(WAVE - 1)); kb < hi; kb += WAVE) {
+                const int p = kb + lane;
+                mx = fmaxf(mx, (p >= lo && p < hi) ? sc_w[p - k0] : -3.0e38f);
+            }
+            m_loc = wave_max(mx);
+            s_run = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { rs_a[c] = 0.f; rs_m[c] = m_loc; rs_i[c] = 0.f; }
+            return;
+        }
         if (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -477,10 +695,13 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     auto close_row = [&]() {
         if (head) {
             write_carry(0);
-            if (lane == 0) { M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 1; }
+            if (lane == 0) {
+                M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 1;
+                if constexpr (SMX) { M->head_m = m_loc; M->head_s = s_run; }
+            }
             head = false;
         } else {
-            finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_end - row_start);
+            finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_end - row_start, m_loc, s_run);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -499,7 +720,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     // one gathered row (+ its weight) into the accumulators
     auto entry_weight = [&](int c, float g0, float g1, float g2, float ws) -> float {
         if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || is_fused_mode(WMODE)) return ws;
-        if (WMODE == W_GAT_DST_PRE) return expf(ws - rs_m[c]);          // ws = the entry's score, computed by the statistics pass
+        if (WMODE == W_GAT_DST_PRE || WMODE == W_GAT_DST_FUSED) return expf(ws - rs_m[c]);   // ws = the entry's score (statistics pass / this item's LDS)
         if (WMODE == W_GAT_DST) return expf(lrelu(rs_a[c] + g0, P.slope) - rs_m[c]);
         if (WMODE == W_GAT_SRC) return expf(lrelu(g0 + rs_a[c], P.slope) - g1) * g2;
         return 1.f;
@@ -510,6 +731,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
         const int cv = (lane < nb) ? P.col[kb + lane] : 0;
         float wv = 1.f;
         if (WMODE == W_ARRAY || WMODE == W_GAT_DST_PRE) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
+        if constexpr (SMX) wv = (lane < nb) ? sc_w[kb - k0 + lane] : 0.f;
         float dz_d = 0.f, dz_g = 0.f;    // W_GAT_SRC_FUSED, packed: D of the entry's target and leaky_relu' of its score
         // several heads: lane l holds alpha / D / leaky_relu' of entry kb + l for EVERY head; the lane's own head picks its weight
         float wvh[HH], dzdh[HH], dzgh[HH];
@@ -573,7 +795,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
                 while (k == row_end) close_row();
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) unpack_row<VEC, T>(raw[u][c], v[u][c]);    // first use: all U NCH loads are in flight
-                float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j + u) : 1.f;
+                float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE || SMX) ? bcast_f(wv, j + u) : 1.f;
                 if constexpr (HH > 1) {                 // alpha of entry j + u for this lane's head (HH scalar reads, HH - 1 selects)
                     ws = bcast_f(wvh[0], j + u);
 #pragma unroll
@@ -585,6 +807,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
+                    if (SMX && c == 0) s_run += we;     // (the same value in every lane)
                     if (keep_alpha && c == 0)       // one head: every lane holds the same weight
                         avec = (lane == j + u) ? __float_as_int(we * rs_i[0]) : avec;
 #pragma unroll
@@ -650,7 +873,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
             }
             const int k = kb + j;
             while (k == row_end) close_row();
-            float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j) : 1.f;
+            float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE || SMX) ? bcast_f(wv, j) : 1.f;
             if constexpr (HH > 1) {
                 ws = bcast_f(wvh[0], j);
 #pragma unroll
@@ -662,6 +885,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
+                if (SMX && c == 0) s_run += we;
                 if (keep_alpha && c == 0)
                     avec = (lane == j) ? __float_as_int(we * rs_i[0]) : avec;
 #pragma unroll
@@ -707,15 +931,24 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
         while (r < N && row_end == k1) close_row();      // empty rows behind it (out = bias)
     } else if (head) {
         write_carry(0);                                  // one row spans the whole item
-        if (lane == 0) { M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 0; }
+        if (lane == 0) {
+            M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 0;
+            if constexpr (SMX) { M->head_m = m_loc; M->head_s = s_run; }
+        }
     } else {
         write_carry(1);                                  // row continues in the next item
-        if (lane == 0) { M->tail_row = r; M->tail_rs = row_start; M->tail_re = row_end; }
+        if (lane == 0) {
+            M->tail_row = r; M->tail_rs = row_start; M->tail_re = row_end;
+            if constexpr (SMX) { M->tail_m = m_loc; M->tail_s = s_run; }
+        }
     }
 }
 
 // the HBM-bound kernels of the headline (one 16-byte chunk per lane, no GAT weights) must keep 8 waves per SIMD: <= 64 VGPRs
-template <int VEC, int NCH, int WMODE, bool EXACT> struct seg_min_waves { static constexpr int value = (NCH == 1 && WMODE <= W_ARRAY && EXACT) ? 8 : 1; };
+// (W_GAT_DST_FUSED: 6 waves per SIMD -- 80 VGPRs; left alone the allocator takes 93 for the chain resolution's sake, 5 waves)
+template <int VEC, int NCH, int WMODE, bool EXACT> struct seg_min_waves {
+    static constexpr int value = (NCH == 1 && WMODE <= W_ARRAY && EXACT) ? 8 : (NCH == 1 && WMODE == W_GAT_DST_FUSED) ? 6 : 1;
+};
 
 template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
 __global__ void __launch_bounds__(SEG_THREADS, (seg_min_waves<VEC, NCH, WMODE, EXACT>::value))
@@ -732,8 +965,10 @@ segsum_kernel(SegParams P) {
     Lanes<VEC, NCH, WMODE, EXACT> L;
     L.init(P);
     if (item < P.n_items) segsum_item<T, VEC, NCH, WMODE, EXACT>(P, L, item, &s_part[wave][0][0], s_meta + wave);
-    auto finish = [&](const float (&acc)[NCH][VEC], int r, int row_len) { finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_len); };
-    resolve_block<VEC, NCH, ROWF>(P, L, finish, s_part, s_meta, &s_arrived);
+    auto finish = [&](const float (&acc)[NCH][VEC], int r, int row_len, float m_, float s_) {
+        finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_len, m_, s_);
+    };
+    resolve_block<VEC, NCH, ROWF, WMODE == W_GAT_DST_FUSED>(P, L, finish, s_part, s_meta, &s_arrived);
 }
 
 // Narrow rows (F <= 32 VEC: hidden = 128 or 64 in f32, the reference's own model width): one row is only
@@ -879,7 +1114,7 @@ segsum_group_kernel(SegParams P) {
     GroupLanes<VEC> L;
     L.foff[0] = (lane % LG) * VEC;
     L.act[0] = lane < LG && L.foff[0] < P.F;                 // the lanes of group 0 own the columns
-    auto finish = [&](const float (&acc)[1][VEC], int r, int row_len) {
+    auto finish = [&](const float (&acc)[1][VEC], int r, int row_len, float, float) {
         if (!L.act[0]) return;
         const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
         const float sc = P.mean ? 1.f / (float)max(row_len, 1) : 1.f;
@@ -924,6 +1159,12 @@ static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t st
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST, EXACT>(P, stream);
     } else if (wmode == W_GAT_DST_PRE) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_DST_PRE, EXACT>(P, stream);
+    } else if (wmode == W_GAT_DST_FUSED) {
+        if constexpr (VEC == 4 && sizeof(T) == 4 && NCH == 1) launch_one<T, VEC, NCH, W_GAT_DST_FUSED, EXACT>(P, stream);
+        else {
+            set_error("npi_gat_aggregate_fused: needs one head of at most 256 channels");
+            return NPI_ERR_ARG;
+        }
     } else if (wmode == W_GAT_SRC_PRE) {
         if constexpr (VEC == 4 && sizeof(T) == 4) launch_one<T, VEC, NCH, W_GAT_SRC_PRE, EXACT>(P, stream);
     } else if (is_fused_mode(wmode)) {

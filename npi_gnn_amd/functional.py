@@ -1053,6 +1053,32 @@ def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=Non
     return out
 
 
+def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, a_src, slope, bias=None, out=None, relu: bool = False):
+    """One head of at most 256 channels: ``(out, m, s)`` -- the forward aggregation together with the softmax statistics of every
+    row, in ONE launch (``npi_gat_aggregate_fused``): no statistics pass, no per-entry score array.  ``a_dst`` ``[n_rows]``,
+    ``a_src`` ``[n_cols]``; ``table2``: second part of a two-part table."""
+    dev = table.device
+    table = _f32c(table, "table")
+    if table2 is not None:
+        table2 = _f32c(table2, "table2")
+        if table2.stride(0) != table.stride(0):
+            raise ValueError("the two parts of the table must share the row pitch")
+    if out is None:
+        out = torch.empty((side.n_rows, C), dtype=torch.float32, device=dev)
+    else:
+        _check_out(out, side.n_rows, C, table, "gat_aggregate_fused")
+    m = torch.empty((side.n_rows, 1), dtype=torch.float32, device=dev)
+    s = torch.empty((side.n_rows, 1), dtype=torch.float32, device=dev)
+    with _tag_events("gat_fwd_aggregate", dev):
+        check(load().npi_gat_aggregate_fused(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
+                                             side.n_rows, side.nnz_max, ptr(table), table.stride(0), ptr(table2),
+                                             table.size(0) if table2 is not None else 0, ptr(out), out.stride(0), C,
+                                             ptr(a_dst.contiguous()), ptr(a_src.contiguous()), float(slope), ptr(bias),
+                                             1 if relu else 0, ptr(m), ptr(s), ptr(side.carry(C)), stream_ptr(dev)),
+              "npi_gat_aggregate_fused")
+    return out, m, s
+
+
 def gat_pack_targets(a_dst, m, s, D, out=None):
     """[n, 4] = (a_dst, m, 1 / (s + 1e-16), D) of every target node (one head): what ``gat_backward_fused_packed`` gathers.
     ``out``: a contiguous ``[n, 4]`` f32 tensor to fill (a slice of a larger table)."""
@@ -1160,7 +1186,11 @@ class _GatConvFn(torch.autograd.Function):
         else:
             hfeat = linear_fwd(x, weight)                                    # x @ W
             a_dst, a_src = gat_scores(hfeat, att2, H, C)
-        if H == 1 and C % 4 == 0 and d.nnz_max > 0:
+        if H == 1 and C % 4 == 0 and C <= 256 and d.nnz_max > 0 and sch.gat_fused_stats:
+            # the statistics inside the aggregation launch: every item computes its entries' scores, rows cut by an item boundary
+            # merge their parts' (max, sum exp) where cut rows are resolved (round 5: one pass over col / rowidx and a launch less)
+            out, m, s = gat_aggregate_fused(d, hfeat, None, C, a_dst, a_src, slope, bias=bias, relu=relu)
+        elif H == 1 and C % 4 == 0 and d.nnz_max > 0:
             # the statistics pass leaves the score of every entry; the aggregation reads it back (one coalesced load per
             # 64 entries) instead of gathering a_src[j] per entry and redoing the leaky_relu
             m, s, scores = gat_softmax_stats(d, a_dst, a_src, H, slope, want_scores=True)

@@ -26,6 +26,10 @@ class Schedule:
     #: one-head GATConv forward: a_dst / a_src of every node from the accumulators of h = x W in the GEMM's store epilogue
     #: instead of a pass over h (shapes one column tile covers: 128 or 256 output channels)
     gat_scores_epilogue: bool = True
+    #: one-head GATConv forward (<= 256 channels): the softmax statistics INSIDE the aggregation launch (every item computes its
+    #: entries' scores; parts of cut rows are merged with rescaling: ``npi_gat_aggregate_fused``) instead of a statistics pass
+    #: that leaves every entry's score for the aggregation to read back
+    gat_fused_stats: bool = True
     #: one-head GATConv backward (rank-2 path, two streams): the by-source row sum of dz on the side stream, in front of the
     #: by-target one and beside the dW GEMM, instead of on the launch stream in front of dW
     gat_src_rowsum_beside_dw: bool = False

@@ -312,3 +312,81 @@ def test_att_grad_pass_matches_the_definition(dev, N, H, C):
     wide[:, : H * C] = h
     assert torch.equal(NF.gat_att_grad(wide[:, : H * C], gd, gs, H, C), got) or \
         float((NF.gat_att_grad(wide[:, : H * C], gd, gs, H, C) - got).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("item", [64, 256])
+@pytest.mark.parametrize("N,E,C,hub", [(3000, 40_000, 256, 0), (20_000, 600_000, 128, 300_000), (5_000, 150_000, 64, 70_000),
+                                       (900, 9_000, 36, 0)])
+def test_fused_forward_statistics_equal_the_statistics_pass(dev, N, E, C, hub, item):
+    """npi_gat_aggregate_fused (round 5): the forward aggregation that computes the scores and the softmax statistics itself
+    against the two-launch path (npi_gat_softmax_stats_ex + npi_gat_aggregate_scores): the row maxima EXACTLY, the row sums and the
+    output to fp32 rounding (the parts of a cut row are merged with exp(m_part - m_row) in a fixed order) -- with a hub row cut
+    over hundreds of workgroups (the two-level chain), both item sizes, scores that spread over +-20 (every merge rescales),
+    bias + ReLU; the hub row against the formula in fp64; bitwise reproducible."""
+    from npi_gnn_amd import functional as NF
+    g = torch.Generator().manual_seed(N + C + item)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    if hub:
+        ei[1, :hub] = 7                                             # one target with `hub` in-edges: its row spans many workgroups
+    graph = npi.CSRGraph(ei.to(dev), N, item=item)
+    d = graph.by_dst
+    h = torch.randn(N, C, generator=g).to(dev)
+    a_dst = (torch.randn(N, 1, generator=g) * 4).to(dev)
+    a_src = (torch.randn(N, 1, generator=g) * 6).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    m0, s0, sc = NF.gat_softmax_stats(d, a_dst, a_src, 1, 0.2, want_scores=True)
+    ref = NF.gat_aggregate_scores(d, h, None, C, sc, m0, s0, bias=bias, relu=True)
+    out, m, s = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(m, m0)
+    assert float(((s - s0).abs() / s0.abs().clamp(min=1e-30)).max()) <= 2e-5
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 2e-5 * max(scale, 1.0)
+    for _ in range(2):
+        o2, m2, s2 = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias, relu=True)
+        assert torch.equal(o2, out) and torch.equal(m2, m) and torch.equal(s2, s)
+    # the heaviest row against the definition in fp64 (self loop included: add_self_loops after remove_self_loops)
+    i = 7 if hub else int(torch.bincount(ei[1], minlength=N).argmax())
+    src = ei[0][(ei[1] == i) & (ei[0] != i)].to(dev)
+    src = torch.cat([src, torch.tensor([i], device=dev)])
+    z = (a_dst[i, 0] + a_src[src, 0]).double()
+    e = torch.where(z > 0, z, 0.2 * z)
+    w = torch.softmax(e, 0)
+    want = torch.relu((w.view(-1, 1) * h[src].double()).sum(0) + bias.double())
+    assert float((out[i].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert abs(float(m[i, 0]) - float(e.max())) <= 1e-6 * max(1.0, abs(float(e.max())))
+    assert abs(float(s[i, 0]) - float((e - e.max()).exp().sum())) <= 1e-5 * float((e - e.max()).exp().sum())
+
+
+@pytest.mark.gpu
+def test_fused_forward_on_an_edge_list_with_empty_rows_and_under_load(dev):
+    """rows without any entry (a graph built without self loops) come out as bias with m = s = 0, as the statistics pass leaves
+    them; 40 launches through one scratch buffer beside a second stream's load stay bit-identical (the arrival counters and the
+    (m, s) slots of the partial rows are reused launch after launch)"""
+    from npi_gnn_amd import functional as NF
+    g = torch.Generator().manual_seed(5)
+    N, E, C = 50_000, 1_500_000, 256
+    ei = torch.randint(0, N // 2, (2, E), generator=g)              # the upper half of the nodes has no edge at all
+    ei[1, :400_000] = 11
+    graph = npi.CSRGraph(ei.to(dev), N, self_loops=False, keep_equal=True)
+    d = graph.by_dst
+    h = torch.randn(N, C, generator=g).to(dev)
+    a_dst, a_src = (torch.randn(N, 1, generator=g) * 3).to(dev), (torch.randn(N, 1, generator=g) * 3).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    out, m, s = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias)
+    m0, s0, sc = NF.gat_softmax_stats(d, a_dst, a_src, 1, 0.2, want_scores=True)
+    ref = NF.gat_aggregate_scores(d, h, None, C, sc, m0, s0, bias=bias)
+    assert torch.equal(m, m0) and float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    empty = torch.bincount(ei[1], minlength=N).to(dev) == 0
+    assert bool(empty.any()) and torch.equal(out[empty], bias.expand(int(empty.sum()), C))
+    assert float(m[empty].abs().max()) == 0.0 and float(s[empty].abs().max()) == 0.0
+    side = torch.cuda.Stream(device=dev)
+    big = torch.randn(64_000_000, device=dev)
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big.mul_(1.0001)
+    for k in range(40):
+        o2, m2, s2 = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias)
+        assert torch.equal(o2, out) and torch.equal(s2, s), k
+    torch.cuda.synchronize()

@@ -31,7 +31,7 @@ def test_no_environment_switch_selects_a_path():
     fields = set(Schedule.__dataclass_fields__)
     assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "gat_scores_epilogue",
                       "direct_hub_rows", "partial_stream", "split_projection", "gat_direct", "early_hub_gather", "gemm_reserve_cus",
-                      "split_projection_reserve_cus", "gat_src_rowsum_beside_dw"}
+                      "split_projection_reserve_cus", "gat_src_rowsum_beside_dw", "gat_fused_stats"}
     assert CONSERVATIVE == DEFAULT.but(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
                                        gat_rank2_epilogue=False)
 
@@ -58,7 +58,7 @@ def _run(make, graph, x, go):
     ("sage", dict(overlap_streams=False)), ("sage", dict(overlap_min_rows=10 ** 9)),
     ("gcn", dict(overlap_streams=False)),
     ("gat", dict(overlap_streams=False)), ("gat", dict(gat_rank2_epilogue=False)), ("gat", dict(gat_rank2_min_rows=10 ** 9)),
-    ("gat", dict(gat_scores_epilogue=False)), ("gat", dict(gat_src_rowsum_beside_dw=True)),
+    ("gat", dict(gat_scores_epilogue=False)), ("gat", dict(gat_src_rowsum_beside_dw=True)), ("gat", dict(gat_fused_stats=False)),
 ])
 def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     ei, graph, x, go = _graph(dev)
@@ -66,7 +66,7 @@ def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     cls = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[kind]
     ref = _run(lambda: cls(F, F), graph, x, go)
     got = _run(lambda: cls(F, F, schedule=DEFAULT.but(**alt)), graph, x, go)
-    if "gat_scores_epilogue" in alt:                                     # the scores' 128-term dots in another association
+    if "gat_scores_epilogue" in alt or "gat_fused_stats" in alt:         # the scores' dots / the parts of cut rows in another association
         assert float((got[0] - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
     else:
         assert torch.equal(got[0], ref[0])                               # the forward is the same launches
