@@ -246,12 +246,12 @@ def algorithmic_bytes(nnz_rows_edges: int, n_rows: int, F: int, s: int = 4) -> i
 def gat_bytes(E: int, N: int, F: int, H: int = 1) -> dict:
     """Algorithmic bytes per launch of the two GATConv aggregation kernels (one head, f32, int32 CSR), SURVEY.md 8(d) plus the
     per-entry / per-node scalars of the attention.  nnz = E + N: the self loop is an ordinary entry.
-      forward  (npi_gat_aggregate_scores): per entry a gathered h row 4F + col 4 + its score 4H; per node the output row
-               4F + rowptr 4 + (m, s) 8H
+      forward  (npi_gat_aggregate_fused, round 5: the statistics inside the launch, the scores recomputed from the gathered
+               rows): per entry a gathered h row 4F + col 4; per node the output row 4F + rowptr 4 + a_dst 4 + (m, s) written 8H
       backward (npi_gat_backward_fused_heads): per by-source entry a gathered dOut row 4F + col 4 + rowidx 4 + the target's
                packed scalars 16 + dz written 4; per node its own h row 4F + the d h row written 4F + rowptr 4 + a_src 4"""
     nnz = E + N
-    return {"gat_fwd_aggregate": nnz * (4 * F + 4 + 4 * H) + N * (4 * F + 4 + 8 * H),
+    return {"gat_fwd_aggregate": nnz * (4 * F + 4) + N * (4 * F + 4 + 4 + 8 * H),
             "gat_bwd_fused": nnz * (4 * F + 4 + 4 + 16 + 4) + N * (8 * F + 8)}
 
 

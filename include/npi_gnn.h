@@ -406,14 +406,17 @@ int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const in
                              int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2, int64_t split,
                              float* out, int64_t ldo, int64_t C, const float* scores, const float* m, const float* s,
                              const float* bias, int relu, float* carry, void* stream);
-/* The same forward aggregation WITHOUT the statistics pass in front of it (one head of at most 256 channels): every item computes
- * the scores e_p = leaky_relu(a_dst[row p] + a_src[col p]) of its own entries, weights a row against the maximum of its entries
- * (exactly as above for a row that lies inside one item; the parts of a row cut by an item boundary are merged with
- * exp(m_part - m_row) where cut rows are resolved, in a fixed order), and writes m[N], s[N] -- the row maximum and the row sum of
- * exp(e - m) that npi_gat_pack_targets / the backward need -- beside out.  rowidx: the by-target CSR's row of every entry. */
+/* The same forward aggregation WITHOUT the statistics pass in front of it (one head of at most 256 channels): an online softmax
+ * inside the launch.  The score of an entry is e_p = leaky_relu(a_dst[row] + <x[col p], att[C:]>) -- the source's half recomputed
+ * from the row that is gathered anyway (att: the layer's [2 C] attention vector, PyG layout: target half first), so no per-entry
+ * score array and no 4-byte gather per entry exist; the open row keeps (max so far, sum of exp(e - max)) and rescales its
+ * accumulators when the maximum moves; the parts of a row cut by an item boundary carry their (max, sum) and are merged with
+ * exp(m_part - m_row) where cut rows are resolved, in a fixed order (bitwise reproducible).  Writes m[N], s[N] -- the row
+ * maximum and the row sum of exp(e - m) that npi_gat_pack_targets / the backward need -- beside out.  (rowidx: unused, may be
+ * NULL.)  The scores differ from npi_gat_scores' by the rounding of another summation order (1e-6 relative). */
 int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
                             int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
-                            int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src,
+                            int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
                             float slope, const float* bias, int relu, float* m, float* s, float* carry, void* stream);
 int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C);
 /* `F.relu(conv(x))` fused (npi_gat_aggregate_scores with relu != 0 applies the ReLU in the row epilogue): b is then the ReLU

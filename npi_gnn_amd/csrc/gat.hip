@@ -744,17 +744,19 @@ extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* co
 }
 
 // One head, C <= 256: the forward aggregation WITH the softmax statistics (W_GAT_DST_FUSED): out, m, s in one launch; no
-// statistics pass, no per-entry score array (npi_gat_softmax_stats_ex + npi_gat_aggregate_scores do the same in two)
+// statistics pass, no per-entry score array, no gather of the sources' scores (npi_gat_softmax_stats_ex +
+// npi_gat_aggregate_scores do the same in two): the source half of every score is recomputed from the gathered row
 extern "C" int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
                                        int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
-                                       int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* a_src,
+                                       int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
                                        float slope, const float* bias, int relu, float* m, float* s, float* carry, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_fused: bad split");
     NPI_REQUIRE(item_edges_ok(item_edges), "npi_gat_aggregate_fused: item_edges must be 64 or NPI_ITEM_EDGES (the value the CSR was built with)");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_aggregate_fused: bad size (one head of at most 256 channels, a multiple of 4)");
     if (N == 0) return NPI_OK;
-    NPI_REQUIRE(rowptr && col && rowidx && item_row && x && out && a_dst && a_src && m && s && carry, "npi_gat_aggregate_fused: null pointer");
+    NPI_REQUIRE(rowptr && col && item_row && x && out && a_dst && att && m && s && carry, "npi_gat_aggregate_fused: null pointer");
+    NPI_REQUIRE((uintptr_t)att % 16 == 0, "npi_gat_aggregate_fused: att must be 16-byte aligned");
     NPI_REQUIRE(ldx >= C && ldo >= C, "npi_gat_aggregate_fused: leading dimension too small");
     SegParams P{};
     P.rowptr = rowptr; P.col = col; P.item_row = item_row; P.rowidx = rowidx;
@@ -762,7 +764,7 @@ extern "C" int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col
     P.x = x; P.ldx = ldx; P.out = out; P.ldo = ldo; P.F = (int)C;
     P.x2 = x2; P.split = (int)split;
     P.carry = carry; P.bias = bias;
-    P.H = 1; P.C = (int)C; P.a_dst = a_dst; P.a_src = a_src; P.slope = slope; P.m_out = m; P.s_out = s; P.relu = relu ? 1 : 0;
+    P.H = 1; P.C = (int)C; P.a_dst = a_dst; P.att = att; P.slope = slope; P.m_out = m; P.s_out = s; P.relu = relu ? 1 : 0;
     return segsum_run(P, W_GAT_DST_FUSED, 0, nnz_max, NPI_F32, stream);
 }
 

@@ -373,10 +373,34 @@ __device__ __forceinline__ void emit_partial(const SegParams& P, const Geo& L, c
 // parts merge as  M = max(m1, m2),  acc = acc1 exp(m1 - M) + acc2 exp(m2 - M),  s likewise (the online softmax).  A chain is
 // merged against ITS maximum: first the (m, s) pairs of the chain (lane-parallel, a wave-wide max), then the rows in chain
 // order, each scaled by exp(m_k - M) -- the same fixed order as the plain sums above, so the result stays bitwise reproducible.
+// wave-wide max, the same value in every lane.  DPP, not __shfl_xor: six VALU instructions instead of six ds_bpermute round trips
+// (the fused GATConv forward takes one per row it opens: with the shuffles a 256-entry item of 11-entry rows spent ~7 us in them).
+// row_shr:1/2/4/8 = an inclusive max-scan inside every row of 16 lanes; row_bcast:15 folds row 0 into row 1 and row 2 into row 3,
+// row_bcast:31 rows 0-1 into rows 2-3: lane 63 then holds the maximum of all 64 (every lane must be active: wave-uniform callers).
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, WAVE));
-    return v;
+    const int ident = __float_as_int(-3.0e38f);
+#define NPI_DPP_MAX(CTRL, ROWS) \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ident, __float_as_int(v), CTRL, ROWS, 0xf, false)))
+    NPI_DPP_MAX(0x111, 0xf);
+    NPI_DPP_MAX(0x112, 0xf);
+    NPI_DPP_MAX(0x114, 0xf);
+    NPI_DPP_MAX(0x118, 0xf);
+    NPI_DPP_MAX(0x142, 0xa);
+    NPI_DPP_MAX(0x143, 0xc);
+#undef NPI_DPP_MAX
+    return bcast_f(v, WAVE - 1);
+}
+// wave-wide sum in the same fixed DPP order (deterministic): the partial dots of the fused GATConv forward's scores
+__device__ __forceinline__ float wave_sum(float v) {
+#define NPI_DPP_ADD(CTRL, ROWS) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false))
+    NPI_DPP_ADD(0x111, 0xf);
+    NPI_DPP_ADD(0x112, 0xf);
+    NPI_DPP_ADD(0x114, 0xf);
+    NPI_DPP_ADD(0x118, 0xf);
+    NPI_DPP_ADD(0x142, 0xa);
+    NPI_DPP_ADD(0x143, 0xc);
+#undef NPI_DPP_ADD
+    return bcast_f(v, WAVE - 1);
 }
 // max of the m of n (m, s) pairs, `stride` floats apart
 __device__ __forceinline__ float chain_max(const float* ms, int64_t stride, int n) {
@@ -627,24 +651,22 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     constexpr int HH = fused_heads(WMODE);           // heads of the fused GAT backward (1 in every other mode)
     __shared__ float seg_pb[SEG_WAVES][WAVE * HH];
     float* __restrict__ pb = seg_pb[threadIdx.x >> 6];
-    // W_GAT_DST_FUSED: the score e_p = leaky_relu(a_dst[row p] + a_src[col p]) of every entry of the item, computed lane-parallel
-    // up front and parked in LDS (one 64-entry block per wave instruction); the gather loop below reads a block's scores back as
-    // the other modes read their per-entry weights, and a row's maximum is a masked wave-wide max over the blocks it touches
+    // W_GAT_DST_FUSED: an ONLINE softmax.  The score of an entry is e_p = leaky_relu(a_dst[row] + <h_j, att_src>): the source's
+    // half is recomputed from the row h_j that is gathered anyway -- this lane's 4 columns against its 4 values of att_src, a DPP
+    // sum over the wave -- instead of gathering a_src[col p] (a 4-byte gather per entry costs the memory pipeline a line request
+    // of its own, 64 per wave instruction against the 16 of a row gather: the first version of this mode, with the scores
+    // gathered and parked in LDS, ran the launch 6-7 % slower and gave back what the statistics pass had cost).  The open row
+    // keeps (m_run, s_run) = (max so far, sum of exp(e - m_run)); a new maximum rescales the accumulators (rare after a row's
+    // first few entries: a wave-uniform branch).
     constexpr bool SMX = WMODE == W_GAT_DST_FUSED;
-    __shared__ float seg_sc[SEG_WAVES][SMX ? NPI_ITEM_EDGES : 1];
-    float* __restrict__ sc_w = seg_sc[threadIdx.x >> 6];
-    float m_loc = 0.f, s_run = 0.f;      // the open row's part in this item: max of its scores, running sum of exp(. - max)
+    float m_run = -3.0e38f, s_run = 0.f;
+    float at_src[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) at_src[q] = 0.f;
     if constexpr (SMX) {
-        for (int kb = k0; kb < k1; kb += WAVE) {
-            const int p = kb + lane;
-            if (p < k1) {
-                const float z = P.a_dst[P.rowidx[p]] + P.a_src[P.col[p]];
-                sc_w[p - k0] = z > 0.f ? z : z * P.slope;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        if (L.act[0]) load_row<VEC, float>(P.att + P.C + L.foff[0], at_src);
     }
-    (void)sc_w; (void)m_loc; (void)s_run;
+    (void)m_run; (void)s_run; (void)at_src;
     float hr[VEC];                       // W_GAT_SRC_FUSED: this lane's columns of the open row's own features (h_j)
 #pragma unroll
     for (int q = 0; q < VEC; ++q) hr[q] = 0.f;
@@ -652,17 +674,10 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     float rs_a[NCH], rs_m[NCH], rs_i[NCH];
     auto open_row = [&]() {
         if constexpr (SMX) {
-            // maximum of the scores of row r's entries that lie in this item: [max(row_start, k0), min(row_end, k1))
-            const int lo = max(row_start, k0), hi = min(row_end, k1);
-            float mx = -3.0e38f;
-            for (int kb = k0 + ((lo - k0) & ~(WAVE - 1)); kb < hi; kb += WAVE) {
-                const int p = kb + lane;
-                mx = fmaxf(mx, (p >= lo && p < hi) ? sc_w[p - k0] : -3.0e38f);
-            }
-            m_loc = wave_max(mx);
+            m_run = -3.0e38f;
             s_run = 0.f;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { rs_a[c] = 0.f; rs_m[c] = m_loc; rs_i[c] = 0.f; }
+            for (int c = 0; c < NCH; ++c) { rs_a[c] = P.a_dst[min(r, N - 1)]; rs_m[c] = 0.f; rs_i[c] = 0.f; }
             return;
         }
         if (WMODE == W_GAT_DST || WMODE == W_GAT_DST_PRE) {
@@ -697,11 +712,11 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
             write_carry(0);
             if (lane == 0) {
                 M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 1;
-                if constexpr (SMX) { M->head_m = m_loc; M->head_s = s_run; }
+                if constexpr (SMX) { M->head_m = m_run; M->head_s = s_run; }
             }
             head = false;
         } else {
-            finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_end - row_start, m_loc, s_run);
+            finish_row<T, VEC, NCH, WMODE, EXACT>(P, L, acc, r, row_end - row_start, m_run, s_run);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -720,7 +735,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     // one gathered row (+ its weight) into the accumulators
     auto entry_weight = [&](int c, float g0, float g1, float g2, float ws) -> float {
         if (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || is_fused_mode(WMODE)) return ws;
-        if (WMODE == W_GAT_DST_PRE || WMODE == W_GAT_DST_FUSED) return expf(ws - rs_m[c]);   // ws = the entry's score (statistics pass / this item's LDS)
+        if (WMODE == W_GAT_DST_PRE) return expf(ws - rs_m[c]);          // ws = the entry's score, computed by the statistics pass
         if (WMODE == W_GAT_DST) return expf(lrelu(rs_a[c] + g0, P.slope) - rs_m[c]);
         if (WMODE == W_GAT_SRC) return expf(lrelu(g0 + rs_a[c], P.slope) - g1) * g2;
         return 1.f;
@@ -731,7 +746,6 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
         const int cv = (lane < nb) ? P.col[kb + lane] : 0;
         float wv = 1.f;
         if (WMODE == W_ARRAY || WMODE == W_GAT_DST_PRE) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
-        if constexpr (SMX) wv = (lane < nb) ? sc_w[kb - k0 + lane] : 0.f;
         float dz_d = 0.f, dz_g = 0.f;    // W_GAT_SRC_FUSED, packed: D of the entry's target and leaky_relu' of its score
         // several heads: lane l holds alpha / D / leaky_relu' of entry kb + l for EVERY head; the lane's own head picks its weight
         float wvh[HH], dzdh[HH], dzgh[HH];
@@ -788,6 +802,38 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
                     }
                 }
             }
+            if constexpr (SMX) {
+                // scores of the U entries from their gathered rows, then the entries in order: row ends, online max, accumulate
+                float dt[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    unpack_row<VEC, T>(raw[u][0], v[u][0]);
+                    dt[u] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) dt[u] = fmaf(v[u][0][q], at_src[q], dt[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) dt[u] = wave_sum(dt[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = kb + j + u;
+                    while (k == row_end) close_row();
+                    const float z = rs_a[0] + dt[u];
+                    const float e = z > 0.f ? z : z * P.slope;
+                    if (e > m_run) {                      // wave-uniform: every lane holds the same e and m_run
+                        const float rsc = expf(m_run - e);
+                        s_run *= rsc;
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) acc[0][q] *= rsc;
+                        m_run = e;
+                    }
+                    const float we = expf(e - m_run);
+                    s_run += we;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc[0][q] = fmaf(we, v[u][0][q], acc[0][q]);
+                }
+                continue;
+            }
             float pd[U];                 // W_GAT_SRC_FUSED: this lane's share of <gathered row, open row's own features>
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -795,7 +841,7 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
                 while (k == row_end) close_row();
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) unpack_row<VEC, T>(raw[u][c], v[u][c]);    // first use: all U NCH loads are in flight
-                float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE || SMX) ? bcast_f(wv, j + u) : 1.f;
+                float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j + u) : 1.f;
                 if constexpr (HH > 1) {                 // alpha of entry j + u for this lane's head (HH scalar reads, HH - 1 selects)
                     ws = bcast_f(wvh[0], j + u);
 #pragma unroll
@@ -807,7 +853,6 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float we = entry_weight(c, g0[u][c], g1[u][c], g2[u][c], ws);
-                    if (SMX && c == 0) s_run += we;     // (the same value in every lane)
                     if (keep_alpha && c == 0)       // one head: every lane holds the same weight
                         avec = (lane == j + u) ? __float_as_int(we * rs_i[0]) : avec;
 #pragma unroll
@@ -873,7 +918,27 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
             }
             const int k = kb + j;
             while (k == row_end) close_row();
-            float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE || SMX) ? bcast_f(wv, j) : 1.f;
+            if constexpr (SMX) {
+                float dt = 0.f;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) dt = fmaf(v[0][q], at_src[q], dt);
+                dt = wave_sum(dt);
+                const float z = rs_a[0] + dt;
+                const float e = z > 0.f ? z : z * P.slope;
+                if (e > m_run) {
+                    const float rsc = expf(m_run - e);
+                    s_run *= rsc;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc[0][q] *= rsc;
+                    m_run = e;
+                }
+                const float we = expf(e - m_run);
+                s_run += we;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[0][q] = fmaf(we, v[0][q], acc[0][q]);
+                continue;
+            }
+            float ws = (WMODE == W_ARRAY || WMODE == W_GAT_SRC_PRE || WMODE == W_GAT_SRC_FUSED || WMODE == W_GAT_DST_PRE) ? bcast_f(wv, j) : 1.f;
             if constexpr (HH > 1) {
                 ws = bcast_f(wvh[0], j);
 #pragma unroll
@@ -885,7 +950,6 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float we = entry_weight(c, g0[c], g1[c], g2[c], ws);
-                if (SMX && c == 0) s_run += we;
                 if (keep_alpha && c == 0)
                     avec = (lane == j) ? __float_as_int(we * rs_i[0]) : avec;
 #pragma unroll
@@ -933,13 +997,13 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
         write_carry(0);                                  // one row spans the whole item
         if (lane == 0) {
             M->head_row = r; M->head_rs = row_start; M->head_re = row_end; M->head_closed = 0;
-            if constexpr (SMX) { M->head_m = m_loc; M->head_s = s_run; }
+            if constexpr (SMX) { M->head_m = m_run; M->head_s = s_run; }
         }
     } else {
         write_carry(1);                                  // row continues in the next item
         if (lane == 0) {
             M->tail_row = r; M->tail_rs = row_start; M->tail_re = row_end;
-            if constexpr (SMX) { M->tail_m = m_loc; M->tail_s = s_run; }
+            if constexpr (SMX) { M->tail_m = m_run; M->tail_s = s_run; }
         }
     }
 }

@@ -1053,10 +1053,11 @@ def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=Non
     return out
 
 
-def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, a_src, slope, bias=None, out=None, relu: bool = False):
+def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, att2, slope, bias=None, out=None, relu: bool = False):
     """One head of at most 256 channels: ``(out, m, s)`` -- the forward aggregation together with the softmax statistics of every
-    row, in ONE launch (``npi_gat_aggregate_fused``): no statistics pass, no per-entry score array.  ``a_dst`` ``[n_rows]``,
-    ``a_src`` ``[n_cols]``; ``table2``: second part of a two-part table."""
+    row, in ONE launch (``npi_gat_aggregate_fused``): an online softmax whose scores' source half is recomputed from the gathered
+    rows (``att2``: the layer's ``[1, 2C]`` attention vector) -- no statistics pass, no per-entry score array, no gather of
+    ``a_src``.  ``a_dst`` ``[n_rows]``; ``table2``: second part of a two-part table."""
     dev = table.device
     table = _f32c(table, "table")
     if table2 is not None:
@@ -1073,7 +1074,7 @@ def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, a_src, slope, bi
         check(load().npi_gat_aggregate_fused(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
                                              side.n_rows, side.nnz_max, ptr(table), table.stride(0), ptr(table2),
                                              table.size(0) if table2 is not None else 0, ptr(out), out.stride(0), C,
-                                             ptr(a_dst.contiguous()), ptr(a_src.contiguous()), float(slope), ptr(bias),
+                                             ptr(a_dst.contiguous()), ptr(_f32c(att2.reshape(-1), "att")), float(slope), ptr(bias),
                                              1 if relu else 0, ptr(m), ptr(s), ptr(side.carry(C)), stream_ptr(dev)),
               "npi_gat_aggregate_fused")
     return out, m, s
@@ -1189,7 +1190,7 @@ class _GatConvFn(torch.autograd.Function):
         if H == 1 and C % 4 == 0 and C <= 256 and d.nnz_max > 0 and sch.gat_fused_stats:
             # the statistics inside the aggregation launch: every item computes its entries' scores, rows cut by an item boundary
             # merge their parts' (max, sum exp) where cut rows are resolved (round 5: one pass over col / rowidx and a launch less)
-            out, m, s = gat_aggregate_fused(d, hfeat, None, C, a_dst, a_src, slope, bias=bias, relu=relu)
+            out, m, s = gat_aggregate_fused(d, hfeat, None, C, a_dst, att2, slope, bias=bias, relu=relu)
         elif H == 1 and C % 4 == 0 and d.nnz_max > 0:
             # the statistics pass leaves the score of every entry; the aggregation reads it back (one coalesced load per
             # 64 entries) instead of gathering a_src[j] per entry and redoing the leaky_relu

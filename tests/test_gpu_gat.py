@@ -332,19 +332,22 @@ def test_fused_forward_statistics_equal_the_statistics_pass(dev, N, E, C, hub, i
     graph = npi.CSRGraph(ei.to(dev), N, item=item)
     d = graph.by_dst
     h = torch.randn(N, C, generator=g).to(dev)
-    a_dst = (torch.randn(N, 1, generator=g) * 4).to(dev)
-    a_src = (torch.randn(N, 1, generator=g) * 6).to(dev)
+    att = (torch.randn(1, 2 * C, generator=g) * (6.0 / C ** 0.5)).to(dev)            # scores spread over about +-20
+    a_dst, a_src = NF.gat_scores(h, att, 1, C)                        # <h_i, att[:C]>, <h_i, att[C:]> per node
     bias = torch.randn(C, generator=g).to(dev)
     m0, s0, sc = NF.gat_softmax_stats(d, a_dst, a_src, 1, 0.2, want_scores=True)
     ref = NF.gat_aggregate_scores(d, h, None, C, sc, m0, s0, bias=bias, relu=True)
-    out, m, s = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias, relu=True)
+    out, m, s = NF.gat_aggregate_fused(d, h, None, C, a_dst, att, 0.2, bias=bias, relu=True)
     torch.cuda.synchronize()
-    assert torch.equal(m, m0)
-    assert float(((s - s0).abs() / s0.abs().clamp(min=1e-30)).max()) <= 2e-5
+    # the fused launch recomputes the source half of every score from the gathered row: another summation order of the same
+    # C-term dot, so maxima and sums agree to that rounding (relative to the scores' scale), not bit for bit
+    tol = 4e-6 * max(1.0, float(sc.abs().max()))
+    assert float((m - m0).abs().max()) <= tol
+    assert float(((s - s0).abs() / s0.abs().clamp(min=1e-30)).max()) <= 10 * tol + 2e-5
     scale = float(ref.abs().max())
-    assert float((out - ref).abs().max()) <= 2e-5 * max(scale, 1.0)
+    assert float((out - ref).abs().max()) <= 5e-5 * max(scale, 1.0)
     for _ in range(2):
-        o2, m2, s2 = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias, relu=True)
+        o2, m2, s2 = NF.gat_aggregate_fused(d, h, None, C, a_dst, att, 0.2, bias=bias, relu=True)
         assert torch.equal(o2, out) and torch.equal(m2, m) and torch.equal(s2, s)
     # the heaviest row against the definition in fp64 (self loop included: add_self_loops after remove_self_loops)
     i = 7 if hub else int(torch.bincount(ei[1], minlength=N).argmax())
@@ -355,8 +358,8 @@ def test_fused_forward_statistics_equal_the_statistics_pass(dev, N, E, C, hub, i
     w = torch.softmax(e, 0)
     want = torch.relu((w.view(-1, 1) * h[src].double()).sum(0) + bias.double())
     assert float((out[i].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
-    assert abs(float(m[i, 0]) - float(e.max())) <= 1e-6 * max(1.0, abs(float(e.max())))
-    assert abs(float(s[i, 0]) - float((e - e.max()).exp().sum())) <= 1e-5 * float((e - e.max()).exp().sum())
+    assert abs(float(m[i, 0]) - float(e.max())) <= tol
+    assert abs(float(s[i, 0]) - float((e - e.max()).exp().sum())) <= (10 * tol + 2e-5) * float((e - e.max()).exp().sum())
 
 
 @pytest.mark.gpu
@@ -372,12 +375,14 @@ def test_fused_forward_on_an_edge_list_with_empty_rows_and_under_load(dev):
     graph = npi.CSRGraph(ei.to(dev), N, self_loops=False, keep_equal=True)
     d = graph.by_dst
     h = torch.randn(N, C, generator=g).to(dev)
-    a_dst, a_src = (torch.randn(N, 1, generator=g) * 3).to(dev), (torch.randn(N, 1, generator=g) * 3).to(dev)
+    att = (torch.randn(1, 2 * C, generator=g) * (3.0 / C ** 0.5)).to(dev)
+    a_dst, a_src = NF.gat_scores(h, att, 1, C)
     bias = torch.randn(C, generator=g).to(dev)
-    out, m, s = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias)
+    out, m, s = NF.gat_aggregate_fused(d, h, None, C, a_dst, att, 0.2, bias=bias)
     m0, s0, sc = NF.gat_softmax_stats(d, a_dst, a_src, 1, 0.2, want_scores=True)
     ref = NF.gat_aggregate_scores(d, h, None, C, sc, m0, s0, bias=bias)
-    assert torch.equal(m, m0) and float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float((m - m0).abs().max()) <= 4e-6 * max(1.0, float(sc.abs().max()))
+    assert float((out - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
     empty = torch.bincount(ei[1], minlength=N).to(dev) == 0
     assert bool(empty.any()) and torch.equal(out[empty], bias.expand(int(empty.sum()), C))
     assert float(m[empty].abs().max()) == 0.0 and float(s[empty].abs().max()) == 0.0
@@ -387,6 +392,6 @@ def test_fused_forward_on_an_edge_list_with_empty_rows_and_under_load(dev):
         for _ in range(20):
             big.mul_(1.0001)
     for k in range(40):
-        o2, m2, s2 = NF.gat_aggregate_fused(d, h, None, C, a_dst, a_src, 0.2, bias=bias)
+        o2, m2, s2 = NF.gat_aggregate_fused(d, h, None, C, a_dst, att, 0.2, bias=bias)
         assert torch.equal(o2, out) and torch.equal(s2, s), k
     torch.cuda.synchronize()

@@ -389,7 +389,7 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
         torch.cuda.synchronize()
         gb = gat_bytes(E4, N4, F)
         roof = {}
-        for tag, kern in (("gat_fwd_aggregate", "segsum_kernel<f32, 4, 1, W_GAT_DST_PRE>: weighted aggregation, scores read back"),
+        for tag, kern in (("gat_fwd_aggregate", "segsum_kernel<f32, 4, 1, W_GAT_DST_FUSED>: weighted aggregation with the softmax statistics inside the launch"),
                           ("gat_bwd_fused", "segsum_kernel<f32, 4, 1, W_GAT_SRC_FUSED>: by-source aggregation + SDDMM in one gather pass")):
             tr, src = pmc_of(tag + "_bytes_per_launch", "stale_gat")
             roof[tag] = agg_roofline(tags.get(tag, []), gb[tag], tr, kern, src)

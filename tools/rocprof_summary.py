@@ -65,10 +65,11 @@ def main():
             # per aggregation launch (ONE kernel), averaged over the forward and the backward launch
             t.update({"segsum_kernel_bytes_per_launch": kb(main(0)), "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "gat":
-            t.update({"gat_fwd_aggregate_bytes_per_launch": kb(main(6)), "gat_bwd_fused_bytes_per_launch": kb(main(5)),
+            # forward: W_GAT_DST_FUSED (10: the statistics inside the launch, round 5); W_GAT_DST_PRE (6) under Schedule(gat_fused_stats=False)
+            t.update({"gat_fwd_aggregate_bytes_per_launch": kb(main(10)) or kb(main(6)), "gat_bwd_fused_bytes_per_launch": kb(main(5)),
                       "gat_from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "c5gat":      # the same two kernels on the C5 graph (bench.py --conv gat --nodes 4000000 --edges 100000000 --graph-seed 2)
-            t.update({"c5_gat_fwd_aggregate_bytes_per_launch": kb(main(6)), "c5_gat_bwd_fused_bytes_per_launch": kb(main(5)),
+            t.update({"c5_gat_fwd_aggregate_bytes_per_launch": kb(main(10)) or kb(main(6)), "c5_gat_bwd_fused_bytes_per_launch": kb(main(5)),
                       "c5_from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "gcn":
             t.update({"gcn_segsum_bytes_per_launch": kb(main(1)), "gcn_from": f"profiles/{tag}_pmc_summary.json"})
