@@ -396,12 +396,13 @@ FETCH_SCALE = 1.992            # gfx950: FETCH_SIZE under-reports the gathers' w
                                # calibrated in round 1, tools/pmc_calibrate.py, and confirmed by the uniform control: PMC = 1.00 x algorithmic)
 
 
-def live_pmc(args, timeout_s: float = 300.0):
+def live_pmc(args, timeout_s: float = 300.0, control: bool = False):
     """HBM-side bytes per launch of the headline aggregation kernel measured IN THIS RUN: two child processes, each this very
     file under `rocprofv3 --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in passes of their own, nothing else traced, as the guide
     prescribes), on a short run of the same workload; started BEFORE this process touches the GPU.  Returns
     {"bytes_per_launch", "fetch_KB_raw", "write_KB", "launches", "source"} or {"error": ...} (the offline constants of
-    profiles/pmc_traffic.json then stand in, and the line says so)."""
+    profiles/pmc_traffic.json then stand in, and the line says so).  ``control``: the same two passes over `--control-only` (the
+    uniform-source control graph of roofline.control_uniform)."""
     import csv
     import shutil
     import tempfile
@@ -414,6 +415,9 @@ def live_pmc(args, timeout_s: float = 300.0):
              "--edges", str(args.edges), "--hidden", str(args.hidden), "--graph-seed", str(args.graph_seed)]
     if args.plain_csr:
         child.append("--plain-csr")
+    if control:
+        child = [sys.executable, os.path.abspath(__file__), "--control-only", "--nodes", str(args.nodes), "--edges", str(args.edges),
+                 "--hidden", str(args.hidden)]
     env = dict(os.environ, TMPDIR="/tmp")
     means, t0 = {}, time.time()
     try:
@@ -439,13 +443,14 @@ def live_pmc(args, timeout_s: float = 300.0):
     return {"bytes_per_launch": (fetch_kb * FETCH_SCALE + write_kb) * 1024.0, "fetch_KB_raw": fetch_kb, "write_KB": write_kb,
             "launches": means["FETCH_SIZE"][1], "wall_s": round(time.time() - t0, 1),
             "source": f"LIVE: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this run (separate passes, avg over "
-                      f"{means['FETCH_SIZE'][1]} fwd+bwd aggregation launches; FETCH_SIZE x {FETCH_SCALE} gfx950 calibration + WRITE_SIZE)"}
+                      f"{means['FETCH_SIZE'][1]} {'control' if control else 'fwd+bwd aggregation'} launches; FETCH_SIZE x {FETCH_SCALE} "
+                      "gfx950 calibration + WRITE_SIZE)"}
 
 
 # ---------------------------------------------------------------------------------------------------------
 # roofline.control_uniform: the same kernel with no cache-resident hub table
 # ---------------------------------------------------------------------------------------------------------
-def control_uniform(dev, N, E, F, launches=10):
+def control_uniform(dev, N, E, F, launches=10, live=None):
     import npi_gnn_amd as npi
     from npi_gnn_amd import functional as NF
     g = torch.Generator(device=dev).manual_seed(20260311)
@@ -467,14 +472,18 @@ def control_uniform(dev, N, E, F, launches=10):
     ach = alg / (ms * 1e-3) / 1e9
     t = pmc_traffic()
     traffic = t.get("control_uniform_bytes_per_launch") if not t.get("stale") else None
+    is_live = bool(live and live.get("bytes_per_launch"))
+    if is_live:
+        traffic = live["bytes_per_launch"]
     res = {"workload": f"N={N} E={E} uniform random sources and targets (every row of the {N * F * 4 / 1e9:.2f} GB table "
                        f"equally likely: no cache-resident hub side), F={F} fp32, aggregation launches only",
            "avg_launch_ms": ms, "launches_timed": len(ev), "algorithmic_bytes_per_launch": alg,
            "achieved": ach, "frac_algorithmic": ach / HBM_PEAK_GBS,
            "traffic": traffic,
            "frac_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-           "traffic_source": t.get("control_from") if traffic else
-           (f"STALE: {t.get('control_from')} was measured on another {t.get('stale')}" if t.get("stale") else None)}
+           "traffic_source": live["source"] if is_live else (t.get("control_from") if traffic else
+           (f"STALE: {t.get('control_from')} was measured on another {t.get('stale')}" if t.get("stale") else None)),
+           "live_pmc": live}
     del graph, x
     torch.cuda.empty_cache()
     return res
@@ -747,10 +756,12 @@ def main():
     if is_worker and os.environ.get("NPI_BENCH_FAKE_WORKER"):
         raise SystemExit(fake_worker(rank, world))
     attempt = int(os.environ.get("NPI_BENCH_ATTEMPT", "0")) if is_worker else 0
-    pmc_live = None
+    pmc_live = pmc_live_control = None
     if (not sharded and not args.no_live_pmc and not args.control_only and args.conv == "sage" and args.storage == "f32"
             and not args.capture):
         pmc_live = live_pmc(args)                               # child processes; this one has made no GPU call yet
+        if not args.no_control and pmc_live.get("bytes_per_launch"):
+            pmc_live_control = live_pmc(args, control=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -1114,7 +1125,7 @@ def main():
         del x_full, go_full
         if not args.no_control and args.conv == "sage" and args.storage == "f32":
             try:
-                res["roofline"]["control_uniform"] = control_uniform(dev, N, E, F)
+                res["roofline"]["control_uniform"] = control_uniform(dev, N, E, F, live=pmc_live_control)
             except Exception as e:
                 res["roofline"]["control_uniform"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_configs and args.conv == "sage" and args.storage == "f32":
