@@ -431,7 +431,7 @@ def conv_fwd(side: CSRSide, x: torch.Tensor, w_entry: Optional[torch.Tensor], me
 
 def conv_bwd(tside: CSRSide, grad_out: torch.Tensor, out_relu: Optional[torch.Tensor], agg: torch.Tensor, weight: torch.Tensor,
              rowscale: Optional[torch.Tensor], t_w: Optional[torch.Tensor], ws_bwd: Optional[torch.Tensor], want_x: bool,
-             want_w: bool, want_bias: bool, k_valid: Optional[int]):
+             want_w: bool, want_bias: bool):
     """the backward of ``conv_fwd`` as ONE call (``npi_conv_bwd``): ``(dx, dw, db)``.  The same launches as ``relu_backward`` +
     ``linear_bwd_weight`` + ``linear_bwd_data`` + ``segsum`` over the transposed side, on one stream."""
     dev = require_gpu(grad_out, agg, weight, rowscale, t_w)
@@ -616,7 +616,7 @@ class _SageConvFn(torch.autograd.Function):
                 else:
                     grad_out = relu_backward(grad_out, ctx.saved_tensors[2])
             dx, dw, db = conv_bwd(tside() if want_x else graph.by_dst, grad_out, out_relu, agg, weight, graph.inv_count(graph.by_dst),
-                                  ctx.w_src, ctx.ws_bwd, want_x, want_w, ctx.has_bias, ctx.k_valid)
+                                  ctx.w_src, ctx.ws_bwd, want_x, want_w, ctx.has_bias)
             return dx, dw, db, None, None, None, None
         if ctx.relu:                                            # threshold_backward, as F.relu's autograd does it
             grad_out = relu_backward(grad_out, ctx.saved_tensors[2])
@@ -859,7 +859,7 @@ class _GcnAggFirstFn(torch.autograd.Function):
         overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
         if not overlap and _layer_calls_ok() and (want_w or want_x) and grad_out.dtype == torch.float32:
             dx, dw, db = conv_bwd(graph.by_src if want_x else graph.by_dst, grad_out, None, agg, weight, None, norm.by_src,
-                                  ctx.ws_bwd, want_x, want_w, ctx.has_bias, ctx.k_valid)
+                                  ctx.ws_bwd, want_x, want_w, ctx.has_bias)
             return dx, dw, db, None, None
         if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)

@@ -188,11 +188,6 @@ def build_side(key: torch.Tensor, val: torch.Tensor, n_rows: int, n_cols: int, s
     return side
 
 
-def _build_side(key: torch.Tensor, val: torch.Tensor, E: int, N: int, self_loops: bool, item: Optional[int] = None,
-                sort_columns: bool = False) -> CSRSide:
-    return build_side(key, val, N, N, self_loops, item=item, sort_columns=sort_columns)
-
-
 class CSRGraph:
     """Self-loop-augmented adjacency of one (batched) graph on one GPU.
 
