@@ -165,6 +165,7 @@ def supervise(argv, rank: int, world: int) -> int:
     through a fresh file store.  A second failure is final (exit code 1)."""
     rdv = rendezvous_dir(world)
     limit = float(os.environ.get("NPI_BENCH_PREFLIGHT_TIMEOUT", "900"))
+    total = float(os.environ.get("NPI_BENCH_TOTAL_TIMEOUT", "3000"))     # a worker that sits in a collective for ever ends here
     for attempt in (0, 1):
         env = dict(os.environ, NPI_BENCH_WORKER="1", NPI_BENCH_ATTEMPT=str(attempt), NPI_BENCH_RDV=rdv)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -184,6 +185,8 @@ def supervise(argv, rank: int, world: int) -> int:
                 failed = "another rank's worker failed"
             elif not os.path.exists(os.path.join(rdv, f"ok_{attempt}_{rank}")) and time.time() - t0 > limit:
                 failed = f"rank {rank}: set-up phase not finished after {limit:.0f} s"
+            elif time.time() - t0 > total:
+                failed = f"rank {rank}: worker still running after {total:.0f} s"
             if failed:
                 break
             time.sleep(0.2)
