@@ -1325,14 +1325,108 @@ class _GatConvFn(torch.autograd.Function):
         return dx, dw, datt, db, None, None, None, None, None
 
 
+def _valid_entries(side: CSRSide) -> torch.Tensor:
+    """``[nnz_max, 1]`` bool: entry slots that hold an entry (capacity past ``rowptr[N]`` -- dropped self loops, out-of-range ids -- is
+    never written by the CSR build and never read by a kernel; element-wise torch ops over whole entry arrays must mask it)"""
+    return (torch.arange(max(side.nnz_max, 1), device=side.rowptr.device) < side.rowptr[-1]).view(-1, 1)
+
+
+class _GatDropoutFn(torch.autograd.Function):
+    """GATConv with ATTENTION DROPOUT in training mode (PyG 1.4.2 ``GATConv.message``: ``alpha = softmax(alpha, edge_index_i)``,
+    ``alpha = F.dropout(alpha, p, training)``, ``x_j * alpha``).  ``keep`` ``[nnz_max, H]``, in by-target entry order, holds
+    ``0`` for a dropped attention weight and ``1 / (1 - p)`` for a kept one.  The layer's fast kernels never hold alpha (both
+    directions recompute it per entry), so this variant -- a regulariser for small graphs, used by nothing in the reference --
+    materialises alpha per entry and head and is COMPOSED from the per-op kernels: the score / statistics pass, one weighted
+    aggregation per head in each direction (``npi_segsum_ex`` with per-entry weights over a column block), the per-entry dots
+    ``<dOut_i, h_j>`` from ``npi_gat_edge_grad`` (called with alpha = 1, D = 0, slope = 1: its dz IS the dot), segmented row sums
+    and the element-wise softmax backward on ``[nnz, H]`` arrays in torch.  With dropout the softmax term is unchanged:
+    ``sum_j alpha_ij dalpha_ij = sum_j alpha'_ij <dOut_i, h_j> = <dOut_i, out_i - b>`` (alpha' = alpha keep)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float, keep: torch.Tensor):
+        H = int(heads)
+        C = weight.size(1) // H
+        att2 = _f32c(att.reshape(H, 2 * C), "att")
+        d = graph.by_dst
+        N = d.n_rows
+        keep = _f32c(keep, "keep")
+        if keep.shape != (max(d.nnz_max, 1), H):
+            raise ValueError(f"gat_conv: keep must be [{max(d.nnz_max, 1)}, {H}] (by-target entry order), got {tuple(keep.shape)}")
+        hfeat = linear_fwd(x, weight)
+        a_dst, a_src = gat_scores(hfeat, att2, H, C)
+        m, s, e = gat_softmax_stats(d, a_dst, a_src, H, slope, want_scores=True)
+        ri = d.rowidx.long().clamp_(0, max(N - 1, 0))                       # (slots past nnz hold garbage row ids)
+        valid = _valid_entries(d)
+        alpha = torch.where(valid, torch.exp(e - m[ri]) / (s[ri] + 1e-16), torch.zeros((), device=x.device))
+        alpha_k = torch.where(valid, alpha * keep, torch.zeros((), device=x.device))
+        out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
+        for h in range(H):
+            blk = slice(h * C, (h + 1) * C)
+            segsum(graph, d, hfeat[:, blk], w=alpha_k[:, h].contiguous(), out=out[:, blk],
+                   bias=bias[blk].contiguous() if bias is not None else None)
+        ctx.graph, ctx.H, ctx.C, ctx.slope, ctx.has_bias = graph, H, C, float(slope), bias is not None
+        ctx.save_for_backward(x, weight, att2, hfeat, e, alpha, alpha_k, keep, out,
+                              bias if bias is not None else torch.empty(0, device=x.device))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, att2, hfeat, e, alpha, alpha_k, keep, out, bias = ctx.saved_tensors
+        graph: CSRGraph = ctx.graph
+        H, C, slope = ctx.H, ctx.C, ctx.slope
+        dev = x.device
+        grad_out = _f32c(grad_out, "grad_out")
+        d, sr = graph.by_dst, graph.by_src
+        N = d.n_rows
+        D, db = gat_rowdot_colsum(grad_out, out, bias if ctx.has_bias else None, H, C,
+                                  want_colsum=ctx.has_bias and ctx.needs_input_grad[3])
+        zeros, ones = torch.zeros((N, H), device=dev), torch.ones((N, H), device=dev)
+        dots = gat_edge_grad(d, hfeat, None, grad_out, H, C, zeros, zeros, zeros, ones, zeros, 1.0, 0)    # <dOut_i, h_j>
+        ri = d.rowidx.long().clamp_(0, max(N - 1, 0))
+        zero = torch.zeros((), device=dev)
+        gprime = torch.where(e > 0, torch.ones((), device=dev), torch.full((), slope, device=dev))        # e = leaky_relu(z)
+        dz = torch.where(_valid_entries(d), alpha * (keep * dots - D[ri]) * gprime, zero)
+        tm = _transpose_map(graph)
+        g_dst = seg_rowsum(d, dz, H)
+        g_src = seg_rowsum(sr, dz, H, map_=tm)
+        # d hfeat_j = sum_i alpha'_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
+        alpha_src = torch.where(_valid_entries(sr), alpha_k[tm.long().clamp_(0, alpha_k.size(0) - 1)], zero)
+        dh = torch.empty((N, H * C), dtype=torch.float32, device=dev)
+        for h in range(H):
+            blk = slice(h * C, (h + 1) * C)
+            segsum(graph, sr, grad_out[:, blk], w=alpha_src[:, h].contiguous(), out=dh[:, blk])
+        gat_rank1_add(dh, g_dst, g_src, att2, H, C)
+        datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C) if ctx.needs_input_grad[2] else None
+        dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+        dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
+        return dx, dw, datt, db, None, None, None, None
+
+
+def gat_dropout_keep(graph: CSRGraph, heads: int, p: float) -> torch.Tensor:
+    """A fresh ``keep`` array for ``gat_conv(..., keep=)``: Bernoulli(1 - p) / (1 - p) per by-target entry and head (torch's
+    generator: the distribution of ``F.dropout``, not its random bits for a given seed)."""
+    if not 0.0 <= p < 1.0:
+        raise ValueError("gat_dropout_keep: p must be in [0, 1)")
+    d = graph.by_dst
+    return torch.empty((max(d.nnz_max, 1), int(heads)), dtype=torch.float32, device=d.rowptr.device).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
 def gat_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, att: torch.Tensor,
              bias: Optional[torch.Tensor] = None, heads: int = 1, concat: bool = True,
-             negative_slope: float = 0.2, relu: bool = False, schedule: Schedule = DEFAULT) -> torch.Tensor:
-    """PyG 1.4.2 ``GATConv.forward`` (dropout = 0) on MI355X; ``att`` is ``[1, H, 2C]``.  ``relu=True`` (an extension, as in
+             negative_slope: float = 0.2, relu: bool = False, schedule: Schedule = DEFAULT,
+             keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PyG 1.4.2 ``GATConv.forward`` on MI355X; ``att`` is ``[1, H, 2C]``.  ``relu=True`` (an extension, as in
     ``sage_conv``): ``F.relu(conv(x, edge_index))`` with the ReLU in the aggregation's row epilogue and its backward mask in the
-    pass that computes the softmax term -- one head; other shapes apply it as a separate pass."""
+    pass that computes the softmax term -- one head; other shapes apply it as a separate pass.  ``keep``: attention dropout in
+    training mode (``_GatDropoutFn``; ``gat_dropout_keep`` draws one) -- the composed, slower variant of the layer."""
     require_gpu(x, weight, att, bias)
     graph = as_graph(edge_index, x.size(0))
+    if keep is not None:
+        out = _GatDropoutFn.apply(x, weight, att, bias if concat else None, graph, heads, negative_slope, keep)
+        if not concat:
+            out = out.view(x.size(0), heads, -1).mean(dim=1)
+            out = out + bias if bias is not None else out
+        return torch.relu(out) if relu else out
     if concat:
         return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope, relu, schedule)
     out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope, False, schedule)

@@ -93,7 +93,7 @@ class GATConv(nn.Module):
     """``GATConv(in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout=0,
     bias=True)`` (PyG 1.4.2): ``weight [in, heads*out]`` and ``att [1, heads, 2*out]`` glorot,
     ``bias`` zeros (``[heads*out]`` if concat else ``[out]``).  Not used by the reference
-    (BASELINE.json configs[4] only)."""
+    (BASELINE.json configs[4] only).  ``dropout > 0`` in training mode: the composed variant ``functional._GatDropoutFn``."""
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
                  negative_slope: float = 0.2, dropout: float = 0.0, bias: bool = True, schedule: Schedule = DEFAULT, **kwargs):
@@ -121,17 +121,20 @@ class GATConv(nn.Module):
         """``relu=True`` (an extension of the PyG signature, as in ``SAGEConv``): ``F.relu(conv(x, edge_index))`` fused."""
         if size is not None:
             raise NotImplementedError("GATConv: bipartite `size` is not implemented")
-        if self.dropout > 0 and self.training:
-            # F.dropout(alpha, p, training=True) draws a fresh mask per edge and head: the kernels never hold alpha (it is
-            # recomputed per entry in both directions), so a TRAINING step with attention dropout is not served; in evaluation
-            # (model.eval(), the reference's test loop) dropout is the identity and the layer runs as usual
-            raise NotImplementedError("GATConv: attention dropout in training mode is not implemented (evaluation is)")
+        gb = None
         if isinstance(x, GraphBatch):
             gb = _only_batch(x, edge_index, "GATConv")
-            return gb.with_x(F_.gat_conv(gb.x, gb.graph(), self.weight, self.att, self.bias, self.heads, self.concat,
-                                         self.negative_slope, relu=relu, schedule=self.schedule))
-        return F_.gat_conv(x, edge_index, self.weight, self.att, self.bias, self.heads, self.concat,
-                           self.negative_slope, relu=relu, schedule=self.schedule)
+            x, edge_index = gb.x, gb.graph()
+        keep = None
+        if self.dropout > 0 and self.training:
+            # F.dropout(alpha, p, training=True): a fresh mask per entry and head.  The fast kernels never hold alpha (both
+            # directions recompute it per entry), so a training step with attention dropout takes the composed variant of the
+            # layer (functional._GatDropoutFn); in evaluation dropout is the identity and the layer runs as usual
+            edge_index = as_graph(edge_index, x.size(0))
+            keep = F_.gat_dropout_keep(edge_index, self.heads, self.dropout)
+        out = F_.gat_conv(x, edge_index, self.weight, self.att, self.bias, self.heads, self.concat,
+                          self.negative_slope, relu=relu, schedule=self.schedule, keep=keep)
+        return gb.with_x(out) if gb is not None else out
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"

@@ -184,9 +184,12 @@ def gcn_conv(x: Tensor, edge_index: Tensor, weight: Tensor, bias: Optional[Tenso
 
 def gat_conv(x: Tensor, edge_index: Tensor, weight: Tensor, att: Tensor,
              bias: Optional[Tensor] = None, heads: int = 1, concat: bool = True,
-             negative_slope: float = 0.2) -> Tensor:
-    """PyG 1.4.2 ``GATConv.forward`` (dropout=0).  ``att`` is ``[1, H, 2C]``: the first C
+             negative_slope: float = 0.2, keep_scale: Optional[Tensor] = None) -> Tensor:
+    """PyG 1.4.2 ``GATConv.forward``.  ``att`` is ``[1, H, 2C]``: the first C
     entries multiply the TARGET features x_i, the last C the SOURCE features x_j.
+    ``keep_scale`` ``[E', H]`` (E' = the columns of the self-loop-augmented edge list, loops last): what
+    ``F.dropout(alpha, p, training=True)`` multiplies alpha by -- 0 for a dropped weight, 1 / (1 - p) for a kept
+    one -- made explicit so that a test can hand the same draw to both sides; None = dropout 0 / evaluation.
     Parity unpinned (module docstring)."""
     N = x.size(0)
     H = heads
@@ -198,6 +201,8 @@ def gat_conv(x: Tensor, edge_index: Tensor, weight: Tensor, att: Tensor,
     alpha = (torch.cat([x_i, x_j], dim=-1) * att).sum(dim=-1)          # [E', H]
     alpha = F.leaky_relu(alpha, negative_slope)
     alpha = segment_softmax(alpha, ei[1], N)
+    if keep_scale is not None:
+        alpha = alpha * keep_scale
     msg = x_j * alpha.view(-1, H, 1)
     out = scatter_add(msg, ei[1], N)                                    # [N, H, C]
     out = out.reshape(N, H * C) if concat else out.mean(dim=1)

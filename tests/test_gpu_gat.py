@@ -49,6 +49,46 @@ def test_gat_conv_fwd_bwd_matches_oracle(dev, N, E, Fi, H, C):
         assert rel_max(got, want) <= GRAD_REL, rel_max(got, want)
 
 
+@pytest.mark.parametrize("N,E,Fi,H,C,concat", [(60, 300, 16, 1, 8, True), (1500, 12000, 64, 2, 32, True), (800, 6000, 32, 3, 16, False),
+                                               (3000, 40000, 128, 1, 256, True)])
+def test_gat_conv_with_attention_dropout_matches_oracle_under_the_same_mask(dev, N, E, Fi, H, C, concat):
+    """GATConv(dropout > 0) in TRAINING mode (PyG 1.4.2 GATConv.message: alpha = F.dropout(softmax(alpha), p, training)): the mask
+    drawn on the device, in by-target entry order, is carried over to the oracle's edge order (original columns without self
+    loops, then the N appended loops) through the CSR's own eid / rowidx arrays; forward and every gradient at the layer's bars."""
+    from npi_gnn_amd import functional as NF
+    ei, x, W, att, b, go = _case(N, E, Fi, H, C, seed=N + 7)
+    if not concat:
+        b, go = b[:C].clone(), go[:, :C].clone()
+    graph = npi.CSRGraph(ei.to(dev), N)
+    keep = NF.gat_dropout_keep(graph, H, 0.4)
+    d = graph.by_dst
+    nnz = int(d.rowptr[-1])
+    eid, rowidx = d.eid[:nnz].cpu().long(), d.rowidx[:nnz].cpu().long()
+    kept = ei[0] != ei[1]
+    pos, Ek = torch.cumsum(kept, 0) - 1, int(kept.sum())
+    idx = torch.where(eid >= 0, pos[eid.clamp(min=0)], Ek + rowidx)
+    assert nnz == Ek + N and idx.unique().numel() == nnz
+    ks = torch.empty(Ek + N, H, dtype=torch.float64)
+    ks[idx] = keep[:nnz].cpu().double()
+    frac = float((keep[:nnz] > 0).float().mean())
+    assert abs(frac - 0.6) < (0.15 if nnz < 1000 else 0.03) and set(keep[:nnz].unique().tolist()) <= {0.0, float(torch.tensor(1 / 0.6))}
+    xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))
+    ref = R.gat_conv(xr, ei, Wr, ar, br, heads=H, concat=concat, keep_scale=ks)
+    ref.backward(go.double())
+    xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, concat=concat, keep=keep)
+    out.backward(go.to(dev))
+    assert torch.allclose(out.detach().cpu(), ref.detach().float(), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(xd.grad.cpu(), xr.grad.float(), atol=2e-4, rtol=1e-3)
+    for got, want in ((Wd.grad, Wr.grad), (ad.grad, ar.grad), (bd.grad, br.grad)):
+        assert rel_max(got, want) <= GRAD_REL, rel_max(got, want)
+    # the mask matters (the test would not notice a path that ignored it otherwise) and keep = 1 everywhere is the plain layer
+    plain = npi.gat_conv(xd.detach(), graph, Wd.detach(), ad.detach(), bd.detach(), heads=H, concat=concat)
+    assert not torch.allclose(out.detach(), plain, atol=1e-3)
+    ones = npi.gat_conv(xd.detach(), graph, Wd.detach(), ad.detach(), bd.detach(), heads=H, concat=concat, keep=torch.ones_like(keep))
+    assert torch.allclose(ones, plain, atol=1e-5, rtol=1e-5)
+
+
 def test_gat_heavy_row_softmax(dev):
     """> 4096 entries on one target row: the workgroup-per-row statistics kernel."""
     N, E, Fi, H, C = 9000, 30000, 32, 1, 64

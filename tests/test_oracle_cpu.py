@@ -105,3 +105,25 @@ def test_sage_conv_concat_restatement_by_hand_and_gradcheck():
     ei2 = torch.randint(0, 9, (2, 30), generator=g)
     xs, Ws, bs = (torch.randn(*s, dtype=torch.float64, generator=g, requires_grad=True) for s in ((9, 5), (10, 3), (3,)))
     assert torch.autograd.gradcheck(lambda a, w, c: R.sage_conv_concat(a, ei2, w, c), (xs, Ws, bs))
+
+
+def test_gat_keep_scale_is_dropout_on_the_normalised_attention_weights():
+    """oracle.gat_conv(keep_scale=): PyG 1.4.2 GATConv.message drops attention weights AFTER the softmax
+    (``alpha = softmax(alpha, edge_index_i); alpha = F.dropout(alpha, p, training)``): a dropped edge does not renormalise the
+    others.  By hand on a 3-node graph with zero attention (alpha = 1 / in-count incl. the loop), and gradcheck."""
+    x = torch.tensor([[1.0, 0.0], [0.0, 1.0], [2.0, 2.0]], dtype=torch.float64)
+    ei = torch.tensor([[1, 2, 0], [0, 0, 1]])                  # 1 -> 0, 2 -> 0, 0 -> 1; loops (0,0) (1,1) (2,2) are appended
+    W = torch.eye(2, dtype=torch.float64)
+    att = torch.zeros(1, 1, 4, dtype=torch.float64)
+    ks = torch.tensor([[2.0], [0.0], [2.0], [2.0], [0.0], [2.0]], dtype=torch.float64)     # p = 0.5: edges 2->0 and loop (1,1) dropped
+    out = R.gat_conv(x, ei, W, att, None, heads=1, keep_scale=ks)
+    want = torch.stack([(x[1] + x[0]) * 2 / 3,                 # target 0: alpha = 1/3 each of {1, 2, loop}, 2 -> 0 dropped
+                        x[0] * 2 / 2,                          # target 1: alpha = 1/2 each of {0, loop}, the loop dropped
+                        x[2] * 2])                             # target 2: its loop only, kept
+    assert torch.allclose(out, want)
+    g = torch.Generator().manual_seed(1)
+    ei2 = _rand_graph(8, 20, 4)
+    Ek = int((ei2[0] != ei2[1]).sum())
+    ks2 = (torch.rand(Ek + 8, 2, generator=g) < 0.7).double() / 0.7
+    xs, Ws, As = (torch.randn(*s, dtype=torch.float64, generator=g, requires_grad=True) for s in ((8, 3), (3, 4), (1, 2, 4)))
+    assert torch.autograd.gradcheck(lambda a, w, t: R.gat_conv(a, ei2, w, t, None, heads=2, keep_scale=ks2), (xs, Ws, As))
