@@ -181,6 +181,11 @@ class StubCollectives(_Patched):
     def _issue(self, fn, tensors, async_op, wire_bytes: float = 0.0, group=None):
         """run ``fn`` (the stand-in copy) where the collective would run"""
         cs = self.copy_stream2 if (group is SMALL_LANE and self.copy_stream2 is not None) else self.copy_stream
+        if cs is not None and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture the stand-in runs in line: a stream of its own would be a fork of a fork (launch ->
+            # side -> copy), which takes the HIP runtime down in hipStreamEndCapture (EXPERIMENTS A3; dist.HipBackend does the
+            # same with its partial stream)
+            cs = None
         if cs is None:
             self._hold(wire_bytes, tensors[0].device)
             fn()
