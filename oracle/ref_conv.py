@@ -211,6 +211,21 @@ def gat_conv(x: Tensor, edge_index: Tensor, weight: Tensor, att: Tensor,
     return out
 
 
+def keep_scale_from_entries(edge_index: Tensor, num_nodes: int, eid: Tensor, rowidx: Tensor, keep: Tensor) -> Tensor:
+    """Carry a dropout draw made per CSR ENTRY (the build's by-target order: ``eid`` = original column of ``edge_index`` or -1 for
+    the appended self loop, ``rowidx`` = the entry's target, ``keep [nnz, H]``; all on the CPU, padding already cut off) over to
+    the order ``gat_conv`` walks: the columns of ``edge_index`` that are not self loops, then the N appended loops."""
+    eid, rowidx = eid.long(), rowidx.long()
+    kept = edge_index[0] != edge_index[1]
+    pos, n_kept = torch.cumsum(kept, 0) - 1, int(kept.sum())
+    idx = torch.where(eid >= 0, pos[eid.clamp(min=0)], n_kept + rowidx)
+    if idx.numel() != n_kept + num_nodes or idx.unique().numel() != idx.numel():
+        raise ValueError("keep_scale_from_entries: the entries are not the self-loop-augmented edge list, one entry per column")
+    ks = torch.empty(n_kept + num_nodes, keep.size(1), dtype=torch.float64)
+    ks[idx] = keep.double()
+    return ks
+
+
 # --------------------------------------------------------------------------------------
 # the rest of Net_1 (needed only so the KAT can run end to end)
 # --------------------------------------------------------------------------------------

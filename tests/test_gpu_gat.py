@@ -63,13 +63,7 @@ def test_gat_conv_with_attention_dropout_matches_oracle_under_the_same_mask(dev,
     keep = NF.gat_dropout_keep(graph, H, 0.4)
     d = graph.by_dst
     nnz = int(d.rowptr[-1])
-    eid, rowidx = d.eid[:nnz].cpu().long(), d.rowidx[:nnz].cpu().long()
-    kept = ei[0] != ei[1]
-    pos, Ek = torch.cumsum(kept, 0) - 1, int(kept.sum())
-    idx = torch.where(eid >= 0, pos[eid.clamp(min=0)], Ek + rowidx)
-    assert nnz == Ek + N and idx.unique().numel() == nnz
-    ks = torch.empty(Ek + N, H, dtype=torch.float64)
-    ks[idx] = keep[:nnz].cpu().double()
+    ks = R.keep_scale_from_entries(ei, N, d.eid[:nnz].cpu(), d.rowidx[:nnz].cpu(), keep[:nnz].cpu())
     frac = float((keep[:nnz] > 0).float().mean())
     assert abs(frac - 0.6) < (0.15 if nnz < 1000 else 0.03) and set(keep[:nnz].unique().tolist()) <= {0.0, float(torch.tensor(1 / 0.6))}
     xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))

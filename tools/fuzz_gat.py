@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised campaign for the GAT kernels against the CPU oracle (oracle/ref_conv.py): random graphs (hub rows, empty
 rows, self loops, duplicate edges), 1 / 2 / 4 / 8 heads, both item sizes (CSRGraph(item=)), rows in list or in column order
-(CSRGraph(sort_columns=)), fused ReLU on / off.
+(CSRGraph(sort_columns=)), fused ReLU on / off, attention dropout in training mode (a quarter of the cases; the same draw handed to
+the oracle).
 usage: tools/fuzz_gat.py [cases] [seed [only_case [sort_columns 0|1]]]"""
 import os, sys
 import numpy as np
@@ -49,10 +50,17 @@ for it in range(cases):
     if force_item is not None:
         big_items = force_item == 256
     graph = npi.CSRGraph(ei.to(dev), N, item=256 if big_items else 64, sort_columns=sort_columns)
-    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCHS[it & 1])
+    drop = bool(rng.random() < 0.25)
+    keep = ks = None
+    if drop:
+        from npi_gnn_amd.functional import gat_dropout_keep
+        keep = gat_dropout_keep(graph, H, float(rng.choice([0.1, 0.5, 0.8])))
+        nnz = int(graph.by_dst.rowptr[-1])
+        ks = R.keep_scale_from_entries(ei, N, graph.by_dst.eid[:nnz].cpu(), graph.by_dst.rowidx[:nnz].cpu(), keep[:nnz].cpu())
+    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCHS[it & 1], keep=keep)
     out.backward(go.to(dev))
     xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))
-    ref = R.gat_conv(xr, ei, Wr, ar, br, heads=H)
+    ref = R.gat_conv(xr, ei, Wr, ar, br, heads=H, keep_scale=ks)
     if relu:
         # the ReLU mask of the run under test: a pre-activation within rounding of zero may have either sign in the fp64
         # oracle and in the fp32 kernels, and ONE flipped element moves db by |dOut| (seed 2, case 71); outputs are still
@@ -72,10 +80,10 @@ for it in range(cases):
     if m <= 2e-4:
         worst = max(worst, m)
     if m > 2e-4:
-        print(f"MISMATCH case {it}: sort_columns={sort_columns} H={H} C={C} N={N} E={E} Fi={Fi} big_items={big_items} relu={relu}: {errs}")
+        print(f"MISMATCH case {it}: sort_columns={sort_columns} H={H} C={C} N={N} E={E} Fi={Fi} big_items={big_items} relu={relu} drop={drop}: {errs}")
         # is it the data?  the ORACLE evaluated in fp32 against itself in fp64: what rounding alone does to this case
         x32, W32, a32, b32 = (t.clone().float().requires_grad_(True) for t in (x, W, att, b))
-        r32 = R.gat_conv(x32, ei, W32, a32, b32, heads=H)
+        r32 = R.gat_conv(x32, ei, W32, a32, b32, heads=H, keep_scale=None if ks is None else ks.float())
         if relu:
             r32 = r32 * (out.detach().cpu() > 0).float()
         r32.backward(go.float())
@@ -96,7 +104,7 @@ for it in range(cases):
                           ("no scores epilogue", SCH.but(gat_scores_epilogue=False)), ("one stream", SCH.but(overlap_streams=False))):
             for use_relu in ((relu, False) if relu else (False,)):
                 xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
-                o = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=use_relu, schedule=sch)
+                o = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=use_relu, schedule=sch, keep=keep)
                 if relu and not use_relu:
                     o = torch.relu(o)
                 o.backward(go.to(dev))
