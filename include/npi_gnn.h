@@ -132,6 +132,15 @@ int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item
                   const void* x, int64_t ldx, const void* x2, int64_t split,
                   void* out, int64_t ldo, int64_t F, int dtype,
                   int mean, const float* bias, float* carry, void* stream);
+/* npi_segsum_ex that also writes, for every finished row, the power-of-two scale the projection GEMM behind the aggregation takes as
+ * `a_scales` (NPI_GEMM_SPLIT_F16X2; the same values npi_row_scales would compute from `out` in a pass of its own): a wave maximum
+ * and one 4-byte store per row.  row_scales_out: [N] or NULL (then the call IS npi_segsum_ex).  Only f32 rows of 256 columns,
+ * 16-byte aligned, on a graph with entries: npi_segsum_scales_supported(F, dtype). */
+int npi_segsum_scales_supported(int64_t F, int dtype);
+int npi_segsum_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
+                   const float* w, int64_t N, int64_t nnz_max, const void* x, int64_t ldx,
+                   const void* x2, int64_t split, void* out, int64_t ldo, int64_t F, int dtype, int mean,
+                   const float* bias, float* carry, float* row_scales_out, void* stream);
 
 /* GCNConv.norm (PyG 1.4.2): deg[j] = sum of weights of entries in row j of the BY-SOURCE CSR
  * (deg == NULL: unweighted, the row lengths of deg_rowptr are used);
@@ -233,10 +242,26 @@ int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, int64_t N);
  * CUs: 0.107 -> 0.15 ms for 125 k rows).  Costs n / 256 more tiles per workgroup when nothing else runs. */
 #define NPI_GEMM_RESERVE_CUS(n) ((((n) / 8) & 0xff) << 8)
 #define NPI_GEMM_RESERVED_CUS_OF(flags) ((((flags) >> 8) & 0xff) * 8)
+/* npi_linear_fwd_ex2 / npi_linear_bwd_data_ex2, f32: the matrix-core kernel runs on TWO fp16 pieces per operand (11 + 11
+ * significant bits) and THREE v_mfma_f32_32x32x16_f16 per product tile instead of three bf16 pieces and six products -- half the
+ * matrix work for the same f32-rounding-level result (tools/micro/mfma_f16_split.hip: 3.8e-7 of a row's largest |C| against
+ * 3.9e-7 for the six bf16 products and 5.5e-7 for an f32 FMA loop; EXPERIMENTS A33 / A34).  fp16 has five exponent bits, so every
+ * row of A (dC) is scaled by a power of two that puts its largest magnitude into [2^14, 2^15) -- `a_scales`, [M], written by
+ * npi_row_scales -- and every column of the weight operand likewise (inside the preparation); the store epilogue undoes both
+ * exactly.  Elements within 2^-28 of their row's maximum keep 22 significant bits, smaller ones an absolute error of 2^-39 of
+ * that maximum (the matrix pipe honours fp16 subnormals).  Non-finite operands behave as under NPI_GEMM_SPLIT_BF16.  A workspace
+ * handed over with NPI_GEMM_WORKSPACE_PREPARED must have been prepared with `which | NPI_PREPARE_F16X2`.  Shapes that do not take
+ * the matrix-core kernel ignore the flag. */
+#define NPI_GEMM_SPLIT_F16X2 16
+#define NPI_PREPARE_F16X2 4
 int64_t npi_linear_workspace_bytes(int64_t K, int64_t N);
+/* scales[m] = the power of two s with max_k |A[m, k]| s in [2^14, 2^15) (1 for an all-zero row or one that holds Inf; clamped so
+ * that s and 1 / s are normal f32) -- the `a_scales` of the NPI_GEMM_SPLIT_F16X2 calls.  One pass over A. */
+int npi_row_scales(const float* A, int64_t lda, int64_t M, int64_t K, float* scales, void* stream);
 /* The re-laid copies of W [K, N] (the `weight` of PyG's `torch.matmul(aggr_out, self.weight)`, reference call sites
  * src/classes.py:62,66,70) for the matrix-core kernels, in ONE launch: which = 1: the copy npi_linear_fwd_ex uses, 2: the one
- * npi_linear_bwd_data_ex uses, 3: both, the second npi_linear_workspace_bytes(K, N) bytes behind the first.  K and N
+ * npi_linear_bwd_data_ex uses, 3: both, the second npi_linear_workspace_bytes(K, N) bytes behind the first; | NPI_PREPARE_F16X2:
+ * the fp16 x 2 planes (and column scales) of NPI_GEMM_SPLIT_F16X2 calls instead of the three bf16 planes.  K and N
  * multiples of 16; workspace 16-byte aligned, npi_linear_workspace_bytes(K, N) bytes per copy. */
 int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t N, int which, int dtype, void* workspace,
                        int64_t workspace_bytes, void* stream);
@@ -252,6 +277,16 @@ int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t
                              void* dW, int64_t lddw, void* db,
                              int64_t M, int64_t K, int64_t N,
                              float* workspace, int64_t workspace_elems, int dtype, int flags, int shared, void* stream);
+/* npi_linear_fwd_ex / npi_linear_bwd_data_ex with the row scales of the left operand (NPI_GEMM_SPLIT_F16X2 in `flags`; without the
+ * flag `a_scales` is ignored and the call IS the _ex one). */
+int npi_linear_fwd_ex2(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                       const float* rowscale, void* C, int64_t ldc,
+                       int64_t M, int64_t K, int64_t N, int relu, int dtype, int flags,
+                       void* workspace, int64_t workspace_bytes, const float* a_scales, void* stream);
+int npi_linear_bwd_data_ex2(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+                            const float* rowscale, void* dA, int64_t ldda,
+                            int64_t M, int64_t K, int64_t N, int dtype, int flags,
+                            void* workspace, int64_t workspace_bytes, const float* dc_scales, void* stream);
 
 /* The same three GEMMs with A / W / C / bias / dW / db stored as `dtype` (NPI_F32 or NPI_BF16; bf16
  * storage, f32 MFMA accumulation, f32 rowscale and workspace) -- BASELINE.json configs[1]. */

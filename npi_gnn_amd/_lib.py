@@ -20,6 +20,8 @@ NPI_GEMM_EXACT_F32 = 1      # flags of the npi_linear_*_ex entry points
 NPI_GEMM_SPLIT_BF16 = 2
 NPI_GEMM_A_ZERO_PADDED = 4   # A stored with zero pad columns up to a multiple of 128 (include/npi_gnn.h)
 NPI_GEMM_WORKSPACE_PREPARED = 8   # the workspace already holds npi_linear_prepare's copy of this weight matrix
+NPI_GEMM_SPLIT_F16X2 = 16         # two fp16 pieces per operand, three matrix products per tile pair (needs the row scales of A)
+NPI_PREPARE_F16X2 = 4             # npi_linear_prepare(which | this): the fp16 x 2 planes of the weight matrix
 
 
 def NPI_GEMM_RESERVE_CUS(n: int) -> int:
@@ -44,6 +46,8 @@ PROTOTYPES = {
     "npi_edge_positions": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "npi_segsum_carry_elems": (_I, [_I, _I, _I]),
     "npi_segsum_ex": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
+    "npi_segsum_ex2": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P, _P]),
+    "npi_segsum_scales_supported": (c_int, [_I, c_int]),
     "npi_row_weight_sum": (c_int, [_P, _P, _I, _P, _P]),
     "npi_gcn_norm": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_row_inv_count": (c_int, [_P, _I, _P, _P]),
@@ -57,6 +61,9 @@ PROTOTYPES = {
     "npi_linear_workspace_bytes": (_I, [_I, _I]),
     "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
     "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
+    "npi_row_scales": (c_int, [_P, _I, _I, _I, _P, _P]),
+    "npi_linear_fwd_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P, _P]),
+    "npi_linear_bwd_data_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P, _P]),
     "npi_linear_prepare": (c_int, [_P, _I, _I, _I, c_int, c_int, _P, _I, _P]),
     "npi_hold_cus": (c_int, [c_int, _I, _P, _P]),
     "npi_linear_fwd_scores_supported": (c_int, [_I, _I, _I]),

@@ -660,6 +660,49 @@ __device__ __forceinline__ void split3_store(f32x4r v, char* img, int plane) {
     *reinterpret_cast<uint2*>(img + 2 * plane) = make_uint2(a2, b2);
 }
 
+// ---- fp16 x 2 (NPI_GEMM_SPLIT_F16X2): x s = h0 + h1 with h0 = fp16(x s), h1 = fp16(x s - h0), s a power of two that puts the
+// largest |x| of the ROW (A) / COLUMN (B) into [2^14, 2^15): two fp16 carry 22 significant bits of every element that is within
+// 2^-28 of that maximum and an ABSOLUTE error <= 2^-39 of it below (the matrix pipe honours fp16 subnormals on gfx950:
+// tools/micro/mfma_f16_split.hip), and a b = a0 b0 + a0 b1 + a1 b0 + O(2^-22 |a b|): THREE v_mfma_f32_32x32x16_f16 instead of six
+// bf16 ones for the same f32-rounding-level result (measured there: 3.8e-7 of the row's largest |C| against 3.9e-7 for the six
+// bf16 products and 5.5e-7 for an f32 FMA loop).  The epilogue undoes the scales (exact: powers of two).
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_pair(float x, float y, uint32_t& p0, uint32_t& p1) {
+    f32x2v v = {x, y};
+    const f16x2v h0 = __builtin_convertvector(v, f16x2v);
+    p0 = __builtin_bit_cast(uint32_t, h0);
+    v = v - __builtin_convertvector(h0, f32x2v);
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2v));
+}
+__device__ __forceinline__ void split2_store(f32x4r v, float sc, char* img, int plane) {
+    uint32_t a0, a1, b0, b1;
+    split2_pair(v.x * sc, v.y * sc, a0, a1);
+    split2_pair(v.z * sc, v.w * sc, b0, b1);
+    *reinterpret_cast<uint2*>(img) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(img + plane) = make_uint2(a1, b1);
+}
+// (pow2_scale_of / pow2_inverse: npi_common.h -- the aggregation kernels write the same scales for the rows they finish)
+
+// scale[r] for every row of A [M, K] (npi_row_scales): one wave per row
+__global__ void __launch_bounds__(256)
+row_scale_kernel(const float* __restrict__ A, int64_t lda, int M, int K, float* __restrict__ scale) {
+    const int r = (int)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const float* __restrict__ row = A + (int64_t)r * lda;
+    float m = 0.f;                       // (fmaxf drops a NaN: the row is scaled by its finite values and the NaN stays a NaN)
+    if (((uintptr_t)row % 16) == 0 && K % 4 == 0) {
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(row + k);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(row[k]));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if (lane == 0) scale[r] = pow2_scale_of(m);
+}
+
 // planes[p][k / 16][n][k % 16] (bf16, K % 16 == 0) of B(k, n): BMODE 0: B[k*ldb + n], BMODE 1: B[n*ldb + k].
 // k-step major: the BN x 16 tile of one k-step is BN * 32 contiguous bytes per plane, so the producer's
 // loads are whole cache lines.
@@ -678,6 +721,34 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
     planes[2 * (int64_t)N * K + o] = (uint16_t)p2;
 }
 
+// fp16 x 2: planes[p][k / 16][n][k % 16] (two fp16 planes) of B(k, n) s_n with s_n the power-of-two scale of COLUMN n, and
+// inv[n] = 1 / s_n.  One workgroup per column.
+__global__ void __launch_bounds__(256)
+split_planes_f16_kernel(const float* __restrict__ B, int64_t ldb, int K, int N, int bmode, uint16_t* __restrict__ planes,
+                        float* __restrict__ inv) {
+    const int n = (int)blockIdx.x;
+    if (n >= N) return;
+    __shared__ float red[4];
+    auto elem = [&](int k) { return bmode == 0 ? B[(int64_t)k * ldb + n] : B[(int64_t)n * ldb + k]; };
+    float m = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, fabsf(elem(k)));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float sc = pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    for (int k = threadIdx.x; k < K; k += 256) {
+        uint32_t p0, p1;
+        split2_pair(elem(k) * sc, 0.f, p0, p1);
+        const int64_t o = ((int64_t)(k / SK) * N + n) * SK + (k % SK);
+        planes[o] = (uint16_t)p0;
+        planes[(int64_t)N * K + o] = (uint16_t)p1;
+    }
+    if (threadIdx.x == 0) inv[n] = pow2_inverse(sc);
+}
+// where the column scales' inverses live in a weight workspace: behind the two planes (npi_linear_workspace_bytes covers three)
+static inline float* f16_inv_of(void* planes, int64_t K, int64_t N) { return reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + 4 * K * N); }
+
 // Epilogue of the split kernel.  Its MFMAs are issued with the operands swapped (B fragment first), so an
 // accumulator tile is C^T: the lane owns ONE row of C (m = lane & 31) and its registers run along the
 // columns, n = 8 (q >> 2) + 4 (lane >> 5) + (q & 3): four consecutive columns per register quad, i.e.
@@ -686,12 +757,15 @@ __global__ void split_planes_kernel(const float* __restrict__ B, int64_t ldb, in
 // measured 0.45 ms of a 0.9 ms kernel.)
 // EPI: 0 plain, 1 (R2) the rank-2 term, 2 (SC) this lane's share of the row dots of the stored values with two column
 // vectors (same LDS layout as the bias), returned in (*g0)[i] / (*g1)[i]
-template <int TM, int TN, int EPI = 0>
+// CS (fp16 x 2): the accumulators carry the operands' power-of-two scales -- cs_lds holds 1 / (column scale) like the bias, the
+// row's 1 / (row scale) is folded into rs by the caller; both multiplications are exact
+template <int TM, int TN, int EPI = 0, bool CS = false>
 __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
                                              const f32x16 (&acc)[TM][TN], const float* __restrict__ bias_lds /* this wave's
                                              first column (zeros without a bias) */, const float (&rs)[TM], float floor_,
                                              const float* __restrict__ u0_lds = nullptr, const float* __restrict__ u1_lds = nullptr,
-                                             float (*g0)[TM] = nullptr, float (*g1)[TM] = nullptr) {
+                                             float (*g0)[TM] = nullptr, float (*g1)[TM] = nullptr,
+                                             const float* __restrict__ cs_lds = nullptr) {
     constexpr bool R2 = EPI == 1, SC = EPI == 2;
     if constexpr (SC) {
 #pragma unroll
@@ -719,20 +793,25 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
             u0 = *reinterpret_cast<const float4*>(u0_lds + j * 32 + 8 * g + 4 * lh);
             u1 = *reinterpret_cast<const float4*>(u1_lds + j * 32 + 8 * g + 4 * lh);
         }
+        float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (CS) cs = *reinterpret_cast<const float4*>(cs_lds + j * 32 + 8 * g + 4 * lh);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float4 v;
+            float4 q = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            if constexpr (CS) { q.x *= cs.x; q.y *= cs.y; q.z *= cs.z; q.w *= cs.w; }
             if constexpr (SC) {           // plain C = A B (no bias, row scale or ReLU: npi_linear_fwd_scores): the registers go to the dots
-                v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                v = q;
+                if constexpr (CS) { v.x *= rs[i]; v.y *= rs[i]; v.z *= rs[i]; v.w *= rs[i]; }
                 (*g0)[i] = fmaf(v.w, u0.w, fmaf(v.z, u0.z, fmaf(v.y, u0.y, fmaf(v.x, u0.x, (*g0)[i]))));
                 (*g1)[i] = fmaf(v.w, u1.w, fmaf(v.z, u1.z, fmaf(v.y, u1.y, fmaf(v.x, u1.x, (*g1)[i]))));
                 *reinterpret_cast<float4*>(crow[i] + j * 32 + 8 * g) = v;
                 continue;
             }
-            v.x = fmaf(acc[i][j][4 * g + 0], rs[i], b.x);
-            v.y = fmaf(acc[i][j][4 * g + 1], rs[i], b.y);
-            v.z = fmaf(acc[i][j][4 * g + 2], rs[i], b.z);
-            v.w = fmaf(acc[i][j][4 * g + 3], rs[i], b.w);
+            v.x = fmaf(q.x, rs[i], b.x);
+            v.y = fmaf(q.y, rs[i], b.y);
+            v.z = fmaf(q.z, rs[i], b.z);
+            v.w = fmaf(q.w, rs[i], b.w);
             if constexpr (R2) {
                 const float a0 = (*g0)[i], a1 = (*g1)[i];
                 v.x = fmaf(a1, u1.x, fmaf(a0, u0.x, v.x)); v.y = fmaf(a1, u1.y, fmaf(a0, u0.y, v.y));
@@ -790,6 +869,9 @@ struct SplitArgs {
     int M, N, K;
     Epilogue ep;
     int tiles_m, tiles_n;    // full 128 x (64 TN) tiles to cover
+    // fp16 x 2 only: the power-of-two scale of every row of A ([M], npi_row_scales) and 1 / scale of every column of B ([N], written
+    // behind the planes by the preparation kernel); Bp then holds [2][K/16][N][16] fp16
+    const float* a_scale; const float* b_inv;
 };
 
 constexpr int WS_THREADS = 512;
@@ -861,19 +943,26 @@ __device__ __forceinline__ void signal(int* flag) {      // one count per wave, 
 typedef u32x4r frag_t;
 #define FRAG(x) __builtin_bit_cast(bf16x8, x)
 #define NPI_DSR(dst, addr, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory")
-template <int PL>
-__device__ __forceinline__ void ws_read3(frag_t (&f)[3], uint32_t addr) {
-    NPI_DSR(f[0], addr, 0); NPI_DSR(f[1], addr, PL); NPI_DSR(f[2], addr, 2 * PL);
+// NPL plane images per operand: 3 (bf16 x 3) or 2 (fp16 x 2, F16 below)
+template <int PL, int NPL = 3>
+__device__ __forceinline__ void ws_read3(frag_t (&f)[NPL], uint32_t addr) {
+    NPI_DSR(f[0], addr, 0); NPI_DSR(f[1], addr, PL);
+    if constexpr (NPL == 3) NPI_DSR(f[2], addr, 2 * PL);
 }
 // at most N fragment reads still outstanding; the fragments are in/out operands so that no use moves above the wait
 #define NPI_LGKM_WAIT(N, F) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : : "memory")
+#define NPI_LGKM_WAIT2(N, F) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]) : : "memory")
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define FRAGH(x) __builtin_bit_cast(f16x8, x)
 
-template <int TM, int TN, int APL, int BPL, int BUF, int NST, bool ONE_MMA = false>
+// F16 (NPL = 2): the operands are TWO fp16 pieces (scaled into fp16's range by the producer), three products a1 b0 + a0 b1 + a0 b0
+template <int TM, int TN, int APL, int BPL, int BUF, int NST, bool ONE_MMA = false, int NPL = 3, bool F16 = false>
 __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, int* empty, int g, bool more,
-                                                const int (&offa)[TM], const int (&offb)[TN], frag_t (&af)[TM][3],
-                                                frag_t (&bf)[TN][3], f32x16 (&acc)[TM][TN],
+                                                const int (&offa)[TM], const int (&offb)[TN], frag_t (&af)[TM][NPL],
+                                                frag_t (&bf)[TN][NPL], f32x16 (&acc)[TM][TN],
                                                 unsigned long long* t_wait = nullptr) {
     static_assert(TM == 2, "the wait counts below assume two row blocks");
+    static_assert(NPL == (F16 ? 2 : 3), "bf16 x 3 has three plane images per operand, fp16 x 2 two");
     const int stg = g & (NST - 1), stn = (g + 1) & (NST - 1);
     const uint32_t nx = lds_base + (uint32_t)(stn * BUF);
     // the poll of the next stage's counter is issued here and looked at after the first column block: its LDS round trip
@@ -884,8 +973,13 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (j == 0 && i == 0) NPI_LGKM_WAIT(7, af[0]);        // younger: A(1) and B(TN-1) of this step, the poll
-            if (j == 0 && i == 1) NPI_LGKM_WAIT(4, af[1]);        // younger: B(TN-1), the poll
+            if constexpr (NPL == 3) {
+                if (j == 0 && i == 0) NPI_LGKM_WAIT(7, af[0]);    // younger: A(1) and B(TN-1) of this step, the poll
+                if (j == 0 && i == 1) NPI_LGKM_WAIT(4, af[1]);    // younger: B(TN-1), the poll
+            } else {                                              // (two reads per fragment set)
+                if (j == 0 && i == 0) NPI_LGKM_WAIT2(5, af[0]);
+                if (j == 0 && i == 1) NPI_LGKM_WAIT2(3, af[1]);
+            }
             // B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t)
             f32x16 c = acc[i][j];
 #if NPI_WS_PROBE & 128
@@ -901,6 +995,11 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
                                             __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
             }
 #else
+            if constexpr (F16) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(FRAGH(bf[j][0]), FRAGH(af[i][1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(FRAGH(bf[j][1]), FRAGH(af[i][0]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(FRAGH(bf[j][0]), FRAGH(af[i][0]), c, 0, 0, 0);
+            } else {
             if (!ONE_MMA) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][2]), c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][2]), FRAG(af[i][0]), c, 0, 0, 0);
@@ -909,15 +1008,19 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][1]), FRAG(af[i][0]), c, 0, 0, 0);
             }
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][0]), c, 0, 0, 0);
+            }
 #endif
             acc[i][j] = c;
             __builtin_amdgcn_sched_barrier(0);           // row block by row block: the first one of a step needs only A(0)
-            if (j == TN - 1 && more) ws_read3<APL>(af[i], nx + (uint32_t)offa[i]);   // row block i is finished: refill its A
+            if (j == TN - 1 && more) ws_read3<APL, NPL>(af[i], nx + (uint32_t)offa[i]);   // row block i is finished: refill its A
         }
         if (j == 0) {
             // every read of this stage was issued during the previous step: this wait is free by now (it is also what
             // makes B(1..TN-1) of this step safe to use, and the poll's value)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[TN - 1][0]), "+v"(bf[TN - 1][1]), "+v"(bf[TN - 1][2]), "+v"(fullv) : : "memory");
+            if constexpr (NPL == 3)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[TN - 1][0]), "+v"(bf[TN - 1][1]), "+v"(bf[TN - 1][2]), "+v"(fullv) : : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[TN - 1][0]), "+v"(bf[TN - 1][1]), "+v"(fullv) : : "memory");
             signal(&empty[stg]);
             const unsigned long long t0_ = t_wait ? NPI_STAMP() : 0ull;
             const int target = 4 * (((g + 1) >> 2) + 1);
@@ -926,40 +1029,50 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
             // (the acquire for the stage's data: wait_ge's atomic load on the slow path, program order after the poll's
             // wait on the fast one -- LDS operations of a wave execute in order)
         }
-        if (more) ws_read3<BPL>(bf[j], nx + (uint32_t)offb[j]);
+        if (more) ws_read3<BPL, NPL>(bf[j], nx + (uint32_t)offb[j]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // first step's fragments (prologue of the pipeline above)
-template <int TM, int TN, int APL, int BPL>
+template <int TM, int TN, int APL, int BPL, int NPL = 3>
 __device__ __forceinline__ void ws_consume_first(uint32_t st, const int (&offa)[TM], const int (&offb)[TN],
-                                                 frag_t (&af)[TM][3], frag_t (&bf)[TN][3]) {
+                                                 frag_t (&af)[TM][NPL], frag_t (&bf)[TN][NPL]) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) ws_read3<BPL>(bf[j], st + (uint32_t)offb[j]);
+    for (int j = 0; j < TN; ++j) ws_read3<BPL, NPL>(bf[j], st + (uint32_t)offb[j]);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) ws_read3<APL>(af[i], st + (uint32_t)offa[i]);
+    for (int i = 0; i < TM; ++i) ws_read3<APL, NPL>(af[i], st + (uint32_t)offa[i]);
+    if constexpr (NPL == 3) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) NPI_LGKM_WAIT(0, bf[j]);
+        for (int j = 0; j < TN; ++j) NPI_LGKM_WAIT(0, bf[j]);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) NPI_LGKM_WAIT(0, af[i]);
+        for (int i = 0; i < TM; ++i) NPI_LGKM_WAIT(0, af[i]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) NPI_LGKM_WAIT2(0, bf[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) NPI_LGKM_WAIT2(0, af[i]);
+    }
 }
 
-template <int TN, int EPI = 0>
+template <int TN, int EPI = 0, bool F16 = false>
 __global__ void __launch_bounds__(WS_THREADS, 1)
 gemm_split_ws_kernel(SplitArgs a) {
     constexpr bool R2 = EPI == 1, SC = EPI == 2;
     constexpr bool UV = R2 || SC;                     // two column vectors kept in LDS beside the bias
     constexpr int TM = 2;
+    constexpr int NPL = F16 ? 2 : 3;                  // plane images per operand: bf16 x 3, or fp16 x 2 (F16)
+    static_assert(!F16 || (NPI_SPLIT_A16 == 0 && (NPI_WS_PROBE & ~16) == 0), "the fp16 x 2 variant has the cycle stamps only");
     constexpr int BN = 64 * TN;                       // 128 or 256 output columns per tile
     constexpr int APL = 128 * 32, BPL = BN * 32;      // bytes of one A / B plane image
-    constexpr int BUF = 3 * APL + 3 * BPL;            // one stage: A planes 0..2, B planes 0..2
+    constexpr int BUF = NPL * APL + NPL * BPL;        // one stage: A planes 0.., B planes 0..
     constexpr int NB = BN / 128;                      // 16-byte B chunks per producer thread and plane
     constexpr int NST = 4;                            // LDS stages (4 x 36 KiB at TN = 4)
     __shared__ __attribute__((aligned(16))) char lds[NST * BUF];
     __shared__ __attribute__((aligned(16))) float bias_s[4][2][32 * TN];   // per consumer wave: bias of its columns, by tile parity
     // R2: the two column vectors of the rank-2 term, kept exactly like the bias
     __shared__ __attribute__((aligned(16))) float r2_s[UV ? 4 : 1][2][2][UV ? 32 * TN : 4];
+    __shared__ __attribute__((aligned(16))) float cs_s[F16 ? 4 : 1][2][F16 ? 32 * TN : 4];     // F16: 1 / (column scale), kept like the bias
     // SC: the two consumer waves that share a row block (wn = 0 / 1: the two halves of the columns) meet here -- wave wn = 1
     // parks its half of the 64 rows' dots and counts up sc_flag[wm]; wave wn = 0 waits for the count of ITS tile, adds its own
     // half (fixed order: columns low + high) and stores the rows' two scalars.  By tile parity: wave 1 can be at most NST
@@ -1006,8 +1119,10 @@ gemm_split_ws_kernel(SplitArgs a) {
         char* la1 = lds + simg(ar + 64, ac >> 1) + (ac & 1) * 8;
 #endif
         // chunk c -> row c / 2, half c % 2
-        char* lb0 = lds + 3 * APL + (NB == 2 ? simg(pt, 0) : simg(pt >> 1, pt & 1));
-        char* lb1 = lds + 3 * APL + simg(pt, 1);
+        char* lb0 = lds + NPL * APL + (NB == 2 ? simg(pt, 0) : simg(pt >> 1, pt & 1));
+        char* lb1 = lds + NPL * APL + simg(pt, 1);
+        const uint32_t os0 = (uint32_t)(ar * 4), os1 = (uint32_t)((ar + 64) * 4);      // F16: this thread's two rows in a.a_scale
+        (void)os0; (void)os1;
         TileWalk wl = w;                                    // load position (runs ahead of the store position w)
         // Register ring of 4 k-steps: three steps of loads are in flight while the fourth is split and stored.
         // The loads and their waits are written in assembly: hipcc's own vmcnt bookkeeping loses the ring at the
@@ -1015,21 +1130,33 @@ gemm_split_ws_kernel(SplitArgs a) {
         // ring registers.  global_load dst, v_off, s[base]: wave-uniform base, fixed per-thread offset.
         // Loads are UNCONDITIONAL: past the last step the walk keeps pointing at a valid tile and the data is
         // dropped (with `if (more) load` the number of loads in flight is not a compile-time fact).
-#define NPI_WDECL(S) f32x4r S##a0, S##a1; u32x4r S##b0, S##b1, S##b2, S##b3, S##b4, S##b5
+#define NPI_WDECL(S) f32x4r S##a0, S##a1; u32x4r S##b0, S##b1, S##b2, S##b3, S##b4, S##b5; float S##s0 = 1.f, S##s1 = 1.f
         NPI_WDECL(r0); NPI_WDECL(r1); NPI_WDECL(r2); NPI_WDECL(r3);
 #define NPI_GL(dst, off, base, IMM)                                                                    \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(off), "s"(base) : "memory")
+#define NPI_GL1(dst, off, base)                                                                        \
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
 #define NPI_WLOAD(S)                                                                                   \
     do {                                                                                               \
         const char* ga = uniform_ptr(reinterpret_cast<const char*>(a.A) + ((int64_t)wl.row0() * a.lda + wl.kt * SK) * 4);        \
         const char* gb0 = uniform_ptr(reinterpret_cast<const char*>(a.Bp) + ((int64_t)wl.kt * a.N + wl.nt * BN) * (SK * 2));     \
         const char* gb1 = uniform_ptr(gb0 + b_plane);                                                  \
         const char* gb2 = uniform_ptr(gb0 + 2 * b_plane);                                              \
+        if constexpr (F16) {                                                                           \
+            /* two planes, and the scales of this thread's two rows: every set has the same number of loads (the waits count them) */ \
+            const char* gs = uniform_ptr(reinterpret_cast<const char*>(a.a_scale) + (int64_t)wl.row0() * 4);                       \
+            NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0);                                      \
+            NPI_GL(S##b0, ob, gb0, 0); NPI_GL(S##b1, ob, gb1, 0);                                      \
+            if constexpr (NB == 2) { NPI_GL(S##b3, ob, gb0, 16); NPI_GL(S##b4, ob, gb1, 16); }         \
+            NPI_GL1(S##s0, os0, gs); NPI_GL1(S##s1, os1, gs);                                          \
+            (void)gb2;                                                                                 \
+        } else {                                                                                       \
         if constexpr ((NPI_WS_PROBE & 32) == 0) { NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0); }                          \
         if constexpr ((NPI_WS_PROBE & 64) == 0) {                                                      \
         NPI_GL(S##b0, ob, gb0, 0); NPI_GL(S##b1, ob, gb1, 0); NPI_GL(S##b2, ob, gb2, 0);               \
         if constexpr (NB == 2) {                                                                       \
             NPI_GL(S##b3, ob, gb0, 16); NPI_GL(S##b4, ob, gb1, 16); NPI_GL(S##b5, ob, gb2, 16);        \
+        }                                                                                              \
         }                                                                                              \
         }                                                                                              \
         wl.next();                                                                                     \
@@ -1038,7 +1165,12 @@ gemm_split_ws_kernel(SplitArgs a) {
         // that no use of it can be scheduled above the wait
 #define NPI_WWAIT(S)                                                                                   \
     do {                                                                                               \
-        if constexpr (NB == 2)                                                                         \
+        if constexpr (F16 && NB == 2)        /* 2 A + 4 B + 2 scales = 8 loads per set */              \
+            asm volatile("s_waitcnt vmcnt(24)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##b0), "+v"(S##b1), "+v"(S##b3), "+v"(S##b4), \
+                         "+v"(S##s0), "+v"(S##s1) : : "memory");                                       \
+        else if constexpr (F16)              /* 2 A + 2 B + 2 scales = 6 */                            \
+            asm volatile("s_waitcnt vmcnt(18)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##b0), "+v"(S##b1), "+v"(S##s0), "+v"(S##s1) : : "memory"); \
+        else if constexpr (NB == 2)                                                                    \
             asm volatile("s_waitcnt vmcnt(24)" : "+v"(S##a0), "+v"(S##a1), "+v"(S##b0), "+v"(S##b1), "+v"(S##b2), \
                          "+v"(S##b3), "+v"(S##b4), "+v"(S##b5) : : "memory");                          \
         else                                                                                           \
@@ -1046,6 +1178,16 @@ gemm_split_ws_kernel(SplitArgs a) {
     } while (0)
 #define NPI_WSTORE(OFF, S)                                                                             \
     do {                                                                                               \
+        if constexpr (F16) {                                                                           \
+            split2_store(S##a0, S##s0, la0 + (OFF), APL); split2_store(S##a1, S##s1, la1 + (OFF), APL); \
+            *reinterpret_cast<u32x4r*>(lb0 + (OFF)) = S##b0;                                           \
+            *reinterpret_cast<u32x4r*>(lb0 + (OFF) + BPL) = S##b1;                                     \
+            if constexpr (NB == 2) {                                                                   \
+                *reinterpret_cast<u32x4r*>(lb1 + (OFF)) = S##b3;                                       \
+                *reinterpret_cast<u32x4r*>(lb1 + (OFF) + BPL) = S##b4;                                 \
+            }                                                                                          \
+            break;                                                                                     \
+        }                                                                                              \
         if constexpr (NPI_SPLIT_A16) { split3_store16(S##a0, S##a1, la0 + (OFF), APL); (void)la1; }    \
         else if constexpr ((NPI_WS_PROBE & 2) != 0) {                                                  \
             const uint2 q0_ = make_uint2(pack_bf16(S##a0.x, S##a0.y), pack_bf16(S##a0.z, S##a0.w));    \
@@ -1094,6 +1236,7 @@ gemm_split_ws_kernel(SplitArgs a) {
 #undef NPI_WDECL
 #undef NPI_WWAIT
 #undef NPI_GL
+#undef NPI_GL1
 #undef NPI_WLOAD
 #undef NPI_WSTORE
 #if NPI_WS_PROBE & 16
@@ -1115,7 +1258,7 @@ gemm_split_ws_kernel(SplitArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) offa[i] = simg(wm * 64 + i * 32 + li, lh);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) offb[j] = 3 * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
+    for (int j = 0; j < TN; ++j) offb[j] = NPL * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1131,12 +1274,12 @@ gemm_split_ws_kernel(SplitArgs a) {
     int g = 0;                                              // k-steps consumed so far: stage g % NST, use g / NST
     int tq = 0;                                             // SC: tiles this workgroup has finished
     (void)tq;
-    frag_t af[TM][3], bf[TN][3];
+    frag_t af[TM][NPL], bf[TN][NPL];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     unsigned long long ca_wait = 0, ca_epi = 0;
     const unsigned long long c_begin = NPI_STAMP();
     wait_ge(&full[0], 4);
-    ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);
+    ws_consume_first<TM, TN, APL, BPL, NPL>(lds_base, offa, offb, af, bf);
     while (w.valid()) {
         if (w.kt == 0) {
             // start of a tile: the row scales of this lane's rows and the bias of this wave's columns (into the
@@ -1144,6 +1287,11 @@ gemm_split_ws_kernel(SplitArgs a) {
             if (a.ep.rowscale) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) rs[i] = a.ep.rowscale[w.row0() + wm * 64 + i * 32 + li];
+            }
+            if constexpr (F16) {          // the row's power-of-two scale comes out again (exact)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    rs[i] = (a.ep.rowscale ? rs[i] : 1.f) * pow2_inverse(a.a_scale[w.row0() + wm * 64 + i * 32 + li]);
             }
             if constexpr (R2) {
 #pragma unroll
@@ -1161,19 +1309,21 @@ gemm_split_ws_kernel(SplitArgs a) {
                         r2_s[wave][tsel][0][c] = a.ep.r2_col0[w.nt * BN + wn * (32 * TN) + c];
                         r2_s[wave][tsel][1][c] = a.ep.r2_col1[w.nt * BN + wn * (32 * TN) + c];
                     }
+                    if constexpr (F16) cs_s[wave][tsel][c] = a.b_inv[w.nt * BN + wn * (32 * TN) + c];
                 }
             }
         }
         TileWalk wn_ = w;
         wn_.next();
-        ws_consume_step<TM, TN, APL, BPL, BUF, NST, (NPI_WS_PROBE & 1) != 0>(lds_base, full, empty, g, wn_.valid(), offa, offb, af, bf, acc,
-                                                                             (NPI_WS_PROBE & 16) ? &ca_wait : nullptr);
+        ws_consume_step<TM, TN, APL, BPL, BUF, NST, (NPI_WS_PROBE & 1) != 0, NPL, F16>(lds_base, full, empty, g, wn_.valid(), offa, offb, af, bf,
+                                                                                       acc, (NPI_WS_PROBE & 16) ? &ca_wait : nullptr);
         ++g;
         if (w.kt == nk - 1) {
             const unsigned long long e0_ = NPI_STAMP();
             if ((NPI_WS_PROBE & 4) == 0 || acc[0][0][0] == 12345.678f)
-            store_tile_t<TM, TN, EPI>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
-                                      bias_s[wave][tsel], rs, floor_, r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1);
+            store_tile_t<TM, TN, EPI, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
+                                           bias_s[wave][tsel], rs, floor_, r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1,
+                                           cs_s[F16 ? wave : 0][tsel]);
             if constexpr (SC) {
                 const int par = tq & 1;
 #pragma unroll
@@ -1781,7 +1931,10 @@ template <int AMODE, int BMODE>
 // k_valid rows (NPI_GEMM_A_ZERO_PADDED): the split kernel runs on a.K with the weight planes zero-extended, everything
 // else (guarded strips, the exact kernels) on k_valid.
 static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int dtype_in = NPI_F32, int dtype_out = NPI_F32,
-                       int mode = 1, void* scratch = nullptr, int k_valid = 0, bool prepared = false, int reserve_cus = 0) {
+                       int mode = 1, void* scratch = nullptr, int k_valid = 0, bool prepared = false, int reserve_cus = 0,
+                       const float* a_scales = nullptr) {
+    // `a_scales` (NPI_GEMM_SPLIT_F16X2): the power-of-two scale of every row of A (npi_row_scales): the split kernel then runs its
+    // fp16 x 2 variant -- three matrix products per tile pair instead of six, the same f32-level accuracy -- on fp16 weight planes
     // `reserve_cus`: the persistent kernels take that many workgroups fewer than CUs (a multiple of 8: one per XCD), so that a
     // kernel resident beside them -- a collective's -- holds CUs they do not wait for (NPI_GEMM_RESERVE_CUS)
     const int cu_slots = device_cus() - ((reserve_cus < 0 ? 0 : reserve_cus > 128 ? 128 : reserve_cus) / 8) * 8;
@@ -1843,15 +1996,30 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
             set_error("gemm: the split kernel needs the caller's workspace (npi_linear_workspace_bytes)");
             return NPI_ERR_WORKSPACE;
         }
-        if (!(prepared && scratch != nullptr))
-            split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes, kv);
+        const bool f16 = a_scales != nullptr && kv == a.K;   // (zero-padded operands keep the bf16 x 3 planes)
+        if (!(prepared && scratch != nullptr)) {
+            if (f16) split_planes_f16_kernel<<<(unsigned)a.N, 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes, f16_inv_of(planes, a.K, a.N));
+            else split_planes_kernel<<<(unsigned)ceil_div(nel, 256), 256, 0, stream>>>(a.B, a.ldb, a.K, a.N, BMODE, planes, kv);
+        }
         const bool wide_n = (a.N % 256 == 0);                // 128 x 256 tiles: each A element is split once
         const int tn = wide_n ? a.N / 256 : fn;
         split_tm = (int)ceil_div(a.M, 128);                  // a ragged last m-tile overlaps its neighbour (TileWalk::row0)
-        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, split_tm, tn};
+        SplitArgs sa{a.A, a.lda, planes, a.C, a.ldc, a.M, a.N, a.K, a.ep, split_tm, tn, f16 ? a_scales : nullptr,
+                     f16 ? f16_inv_of(planes, a.K, a.N) : nullptr};
         const int64_t ntiles = (int64_t)split_tm * tn;
         const int grid = (int)(ntiles < cu_slots ? ((ntiles + 7) / 8) * 8 : cu_slots);      // one workgroup per CU, multiple of 8 (XCDs)
-        if (a.ep.r2_row0 != nullptr) {
+        if (f16) {
+            if (a.ep.r2_row0 != nullptr) {
+                if (wide_n) gemm_split_ws_kernel<4, 1, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+                else        gemm_split_ws_kernel<2, 1, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+            } else if (a.ep.sc0 != nullptr) {
+                if (wide_n) gemm_split_ws_kernel<4, 2, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+                else        gemm_split_ws_kernel<2, 2, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+            } else {
+                if (wide_n) gemm_split_ws_kernel<4, 0, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+                else        gemm_split_ws_kernel<2, 0, true><<<grid, WS_THREADS, 0, stream>>>(sa);
+            }
+        } else if (a.ep.r2_row0 != nullptr) {
             if (wide_n) gemm_split_ws_kernel<4, 1><<<grid, WS_THREADS, 0, stream>>>(sa);
             else        gemm_split_ws_kernel<2, 1><<<grid, WS_THREADS, 0, stream>>>(sa);
         } else if (a.ep.sc0 != nullptr) {
@@ -1961,7 +2129,10 @@ extern "C" int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t
                                   int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(K > 0 && N > 0 && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_prepare: bad size");
-    NPI_REQUIRE(which >= 1 && which <= 3, "npi_linear_prepare: which must be 1 (forward), 2 (backward) or 3 (both)");
+    const bool f16 = (which & NPI_PREPARE_F16X2) != 0;        // fp16 x 2 planes (+ column scales) for NPI_GEMM_SPLIT_F16X2 calls
+    which &= ~NPI_PREPARE_F16X2;
+    NPI_REQUIRE(which >= 1 && which <= 3, "npi_linear_prepare: which must be 1 (forward), 2 (backward) or 3 (both) [| NPI_PREPARE_F16X2]");
+    NPI_REQUIRE(!f16 || dtype == NPI_F32, "npi_linear_prepare: NPI_PREPARE_F16X2 is for f32 weights");
     NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_prepare: bad dtype");
     NPI_REQUIRE(W && workspace && ldw >= N, "npi_linear_prepare: null pointer or leading dimension too small");
     NPI_REQUIRE(K % SK == 0 && N % SK == 0, "npi_linear_prepare: K and N must be multiples of 16 (the matrix-core kernels' k-step)");
@@ -1973,6 +2144,15 @@ extern "C" int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t
     }
     const dim3 grid((unsigned)ceil_div(K * N, 256), (unsigned)sets);
     const int first = which == 2 ? 1 : 0;
+    if (f16) {
+        for (int s_ = 0; s_ < sets; ++s_) {                  // set 0: B = W (contraction over K); set 1: B = W^T (contraction over N)
+            const int set = first + s_;
+            uint16_t* planes = reinterpret_cast<uint16_t*>((char*)workspace + (int64_t)s_ * one);
+            const int Kg = set == 0 ? (int)K : (int)N, Ng = set == 0 ? (int)N : (int)K;
+            split_planes_f16_kernel<<<(unsigned)Ng, 256, 0, stream>>>(fp(W), ldw, Kg, Ng, set, planes, f16_inv_of(planes, K, N));
+        }
+        return check_launch("npi_linear_prepare");
+    }
     if (dtype == NPI_F32)
         prepare_weight_kernel<float><<<grid, 256, 0, stream>>>(fp(W), ldw, (int)K, (int)N, first, (char*)workspace, one);
     else
@@ -1981,11 +2161,32 @@ extern "C" int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t
     return check_launch("npi_linear_prepare");
 }
 
+extern "C" int npi_row_scales(const float* A, int64_t lda, int64_t M, int64_t K, float* scales, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(M >= 0 && K > 0 && M < 0x7fffffff && K < 0x7fffffff && lda >= K, "npi_row_scales: bad size");
+    if (M == 0) return NPI_OK;
+    NPI_REQUIRE(A && scales, "npi_row_scales: null pointer");
+    row_scale_kernel<<<(unsigned)ceil_div(M, 4), 256, 0, stream>>>(A, lda, (int)M, (int)K, scales);
+    return check_launch("npi_row_scales");
+}
+
 extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                                  const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
                                  int64_t N, int relu, int dtype, int flags, void* workspace, int64_t workspace_bytes,
                                  void* stream_) {
+    return npi_linear_fwd_ex2(A, lda, W, ldw, bias, rowscale, C, ldc, M, K, N, relu, dtype, flags, workspace, workspace_bytes, nullptr,
+                              stream_);
+}
+
+extern "C" int npi_linear_fwd_ex2(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                                  const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
+                                  int64_t N, int relu, int dtype, int flags, void* workspace, int64_t workspace_bytes,
+                                  const float* a_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool f16 = (flags & NPI_GEMM_SPLIT_F16X2) != 0;
+    NPI_REQUIRE(!f16 || (a_scales != nullptr && dtype == NPI_F32 && !(flags & (NPI_GEMM_EXACT_F32 | NPI_GEMM_A_ZERO_PADDED))),
+                "npi_linear_fwd_ex2: NPI_GEMM_SPLIT_F16X2 needs a_scales (npi_row_scales), f32 storage, and excludes "
+                "NPI_GEMM_EXACT_F32 / NPI_GEMM_A_ZERO_PADDED");
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_fwd: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_fwd: size > int32");
     NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_fwd: bad dtype");
@@ -2008,7 +2209,8 @@ extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int6
     NPI_REQUIRE(!prepared || (workspace != nullptr && !padded), "npi_linear_fwd_ex: NPI_GEMM_WORKSPACE_PREPARED needs the workspace "
                 "npi_linear_prepare filled and excludes NPI_GEMM_A_ZERO_PADDED");
     const int rc = launch_gemm<0, 0>(vec4_ok(A, lda, Kp, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
-                                     gemm_mode_of(flags), workspace, padded ? (int)K : 0, prepared, NPI_GEMM_RESERVED_CUS_OF(flags));
+                                     gemm_mode_of(flags), workspace, padded ? (int)K : 0, prepared, NPI_GEMM_RESERVED_CUS_OF(flags),
+                                     f16 ? a_scales : nullptr);
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd");
 }
 
@@ -2017,7 +2219,18 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
                                       const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
                                       int64_t N, int dtype, int flags, void* workspace, int64_t workspace_bytes,
                                       void* stream_) {
+    return npi_linear_bwd_data_ex2(dC, lddc, W, ldw, rowscale, dA, ldda, M, K, N, dtype, flags, workspace, workspace_bytes, nullptr, stream_);
+}
+
+extern "C" int npi_linear_bwd_data_ex2(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+                                       const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
+                                       int64_t N, int dtype, int flags, void* workspace, int64_t workspace_bytes,
+                                       const float* dc_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool f16 = (flags & NPI_GEMM_SPLIT_F16X2) != 0;
+    NPI_REQUIRE(!f16 || (dc_scales != nullptr && dtype == NPI_F32 && !(flags & NPI_GEMM_EXACT_F32)),
+                "npi_linear_bwd_data_ex2: NPI_GEMM_SPLIT_F16X2 needs dc_scales (npi_row_scales of dC), f32 storage, and excludes "
+                "NPI_GEMM_EXACT_F32");
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_data: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_data: size > int32");
     NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_bwd_data: bad dtype");
@@ -2036,7 +2249,8 @@ extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* 
     NPI_REQUIRE(!prepared || workspace != nullptr, "npi_linear_bwd_data_ex: NPI_GEMM_WORKSPACE_PREPARED needs the workspace "
                 "npi_linear_prepare filled");
     const int rc = launch_gemm<0, 1>(vec4_ok(dC, lddc, N, es) && vec4_ok(W, ldw, N, es), a, 1, stream, dtype, dtype,
-                                     gemm_mode_of(flags), workspace, 0, prepared, NPI_GEMM_RESERVED_CUS_OF(flags));
+                                     gemm_mode_of(flags), workspace, 0, prepared, NPI_GEMM_RESERVED_CUS_OF(flags),
+                                     f16 ? dc_scales : nullptr);
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data");
 }
 // C = A W and, from the accumulators on their way out, sc0[m] = <C[m, :], att[:N]>, sc1[m] = <C[m, :], att[N:]>: GATConv's

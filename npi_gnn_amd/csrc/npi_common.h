@@ -41,6 +41,19 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
 
+// fp16 x 2 projection (NPI_GEMM_SPLIT_F16X2, gemm_f32.hip): power-of-two scale for a row / column whose largest magnitude is m,
+// m * scale in [2^14, 2^15) (1 for an all-zero row and for Inf / NaN -- which then propagate as in the bf16 split --; clamped so
+// that scale and 1 / scale are normal f32).  Written by npi_row_scales, by the weight preparation, and by the aggregation
+// kernels for the rows they finish (npi_segsum_ex2).
+__device__ __forceinline__ float pow2_scale_of(float m) {
+    const uint32_t eb = (__float_as_uint(m) >> 23) & 0xff;
+    if (m == 0.f || eb == 255) return 1.f;
+    int es = 268 - (int)eb;                                   // biased exponent of 2^(14 - (eb - 127))
+    es = es > 253 ? 253 : (es < 1 ? 1 : es);
+    return __uint_as_float((uint32_t)es << 23);
+}
+__device__ __forceinline__ float pow2_inverse(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
+
 // Entries per work item ("item" = what one wavefront reduces).  The item size is a PROPERTY OF THE CSR: npi_csr_build /
 // npi_csr_filter take it as an argument and cut item_row with it, and every consumer of item_row (npi_segsum*, npi_gat_*)
 // receives the same value from the caller, next to item_row -- no launch re-derives it, and the library keeps NO process-wide

@@ -38,6 +38,8 @@ struct SegParams {
                              // W_GAT_DST_PRE (one head): the leaky_relu score e_p of every entry (npi_gat_softmax_stats_ex)
     const int32_t* wmap;     // W_GAT_SRC_PRE: entry p takes w[wmap[p]] (by-source entry -> by-target position)
     const float* bias;       // [F] or null, added after scaling
+    float* scale_out;        // [N] or null: the power-of-two row scale (pow2_scale_of) of every finished row -- what the projection
+                             // GEMM behind the aggregation takes as a_scales (NPI_GEMM_SPLIT_F16X2); f32, F <= 256 only
     // GAT: H heads of C channels (F == H * C), per-node per-head scalars [N, H]
     int H, C;
     const float* a_dst;

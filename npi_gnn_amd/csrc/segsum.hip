@@ -32,6 +32,7 @@
 //              (max, sum exp) next to its partial row; parts of a cut row are merged with exp(m_part - m_row) where cut rows
 //              are resolved, and the row's (m, s) come out beside the output for the backward
 #include "segsum.h"
+
 #include <stdlib.h>
 
 namespace npi {
@@ -125,7 +126,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 template <int VEC, int NCH> struct inflight { static constexpr int value = (32 / (VEC * NCH)) > 8 ? 8 : ((32 / (VEC * NCH)) < 2 ? 2 : (32 / (VEC * NCH))); };
 
 // lane geometry shared by the main and the fix-up kernel
-template <int VEC, int NCH, int WMODE, bool EXACT>
+template <int VEC, int NCH, int WMODE, int EXACT>
 struct Lanes {
     bool act[NCH];
     int foff[NCH];
@@ -141,9 +142,54 @@ struct Lanes {
     }
 };
 
+// wave-wide max, the same value in every lane.  DPP, not __shfl_xor: six VALU instructions instead of six ds_bpermute round trips
+// (the fused GATConv forward takes one per row it opens: with the shuffles a 256-entry item of 11-entry rows spent ~7 us in them).
+// row_shr:1/2/4/8 = an inclusive max-scan inside every row of 16 lanes; row_bcast:15 folds row 0 into row 1 and row 2 into row 3,
+// row_bcast:31 rows 0-1 into rows 2-3: lane 63 then holds the maximum of all 64 (every lane must be active: wave-uniform callers).
+__device__ __forceinline__ float wave_max(float v) {
+    const int ident = __float_as_int(-3.0e38f);
+#define NPI_DPP_MAX(CTRL, ROWS) \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ident, __float_as_int(v), CTRL, ROWS, 0xf, false)))
+    NPI_DPP_MAX(0x111, 0xf);
+    NPI_DPP_MAX(0x112, 0xf);
+    NPI_DPP_MAX(0x114, 0xf);
+    NPI_DPP_MAX(0x118, 0xf);
+    NPI_DPP_MAX(0x142, 0xa);
+    NPI_DPP_MAX(0x143, 0xc);
+#undef NPI_DPP_MAX
+    return bcast_f(v, WAVE - 1);
+}
+// wave-wide sum in the same fixed DPP order (deterministic): the partial dots of the fused GATConv forward's scores
+__device__ __forceinline__ float wave_sum(float v) {
+#define NPI_DPP_ADD(CTRL, ROWS) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false))
+    NPI_DPP_ADD(0x111, 0xf);
+    NPI_DPP_ADD(0x112, 0xf);
+    NPI_DPP_ADD(0x114, 0xf);
+    NPI_DPP_ADD(0x118, 0xf);
+    NPI_DPP_ADD(0x142, 0xa);
+    NPI_DPP_ADD(0x143, 0xc);
+#undef NPI_DPP_ADD
+    return bcast_f(v, WAVE - 1);
+}
+
+// the same reduction for NON-NEGATIVE values, leaving the result in lane 63 only (no broadcast): invalid source lanes read as zero
+// (bound_ctrl), so the DPP needs no identity register -- finish_row runs at the kernel's register cap
+__device__ __forceinline__ float wave_max_nonneg_lane63(float v) {
+#define NPI_DPP_MAX0(CTRL, ROWS) \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true)))
+    NPI_DPP_MAX0(0x111, 0xf);
+    NPI_DPP_MAX0(0x112, 0xf);
+    NPI_DPP_MAX0(0x114, 0xf);
+    NPI_DPP_MAX0(0x118, 0xf);
+    NPI_DPP_MAX0(0x142, 0xa);
+    NPI_DPP_MAX0(0x143, 0xc);
+#undef NPI_DPP_MAX0
+    return v;
+}
+
 // scale, bias and epilogue of a finished row r, then the store
 // (m_val, s_val: W_GAT_DST_FUSED only -- the row's softmax statistics, complete; every other mode passes zeros)
-template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, int EXACT>
 __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, NCH, WMODE, EXACT>& L,
                                            const float (&acc)[NCH][VEC], int r, int row_len, float m_val = 0.f, float s_val = 0.f) {
     T* __restrict__ dst = reinterpret_cast<T*>(P.out) + (int64_t)r * P.ldo;
@@ -174,6 +220,14 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
 #pragma unroll
             for (int q = 0; q < VEC; ++q) t[q] += gd * at[q] + gs * at[P.C + q];
         }
+        // the row's power-of-two scale for the fp16 x 2 projection behind this aggregation (F = 256: every lane of the wave holds
+        // four columns): this lane's maximum now, the wave maximum and one 4-byte store per row BEHIND the row's own store -- the
+        // values are dead by then (the kernel runs at its 64-register cap with a batch of gathered rows in flight)
+        constexpr bool SCALES = EXACT == 2 && NCH == 1 && VEC == 4 && sizeof(T) == 4;      // (EXACT: 0 guarded, 1 unguarded, 2 unguarded + scales)
+        float mloc = 0.f;
+        if constexpr (SCALES) {
+            if (P.scale_out != nullptr) mloc = fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3])));
+        }
         if constexpr (VEC == 4 && sizeof(T) == 4) {
             // a large output is written once and read again after gigabytes of gathers: streamed past the caches it does not
             // displace gathered rows (same-box A/B at C4: 2.618 -> 2.592 ms per launch, step 6.80 -> 6.75 ms)
@@ -181,10 +235,22 @@ __device__ __forceinline__ void finish_row(const SegParams& P, const Lanes<VEC, 
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 const v4f v = {t[0], t[1], t[2], t[3]};
                 __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst + L.foff[c]));
+                if constexpr (SCALES) {
+                    if (P.scale_out != nullptr) {
+                        mloc = wave_max_nonneg_lane63(mloc);
+                        if (lane_id() == WAVE - 1) P.scale_out[r] = pow2_scale_of(mloc);
+                    }
+                }
                 continue;
             }
         }
         store_row<VEC, T>(dst + L.foff[c], t);
+        if constexpr (SCALES) {
+            if (P.scale_out != nullptr) {
+                mloc = wave_max_nonneg_lane63(mloc);
+                if (lane_id() == WAVE - 1) P.scale_out[r] = pow2_scale_of(mloc);
+            }
+        }
     }
 }
 
@@ -373,35 +439,6 @@ __device__ __forceinline__ void emit_partial(const SegParams& P, const Geo& L, c
 // parts merge as  M = max(m1, m2),  acc = acc1 exp(m1 - M) + acc2 exp(m2 - M),  s likewise (the online softmax).  A chain is
 // merged against ITS maximum: first the (m, s) pairs of the chain (lane-parallel, a wave-wide max), then the rows in chain
 // order, each scaled by exp(m_k - M) -- the same fixed order as the plain sums above, so the result stays bitwise reproducible.
-// wave-wide max, the same value in every lane.  DPP, not __shfl_xor: six VALU instructions instead of six ds_bpermute round trips
-// (the fused GATConv forward takes one per row it opens: with the shuffles a 256-entry item of 11-entry rows spent ~7 us in them).
-// row_shr:1/2/4/8 = an inclusive max-scan inside every row of 16 lanes; row_bcast:15 folds row 0 into row 1 and row 2 into row 3,
-// row_bcast:31 rows 0-1 into rows 2-3: lane 63 then holds the maximum of all 64 (every lane must be active: wave-uniform callers).
-__device__ __forceinline__ float wave_max(float v) {
-    const int ident = __float_as_int(-3.0e38f);
-#define NPI_DPP_MAX(CTRL, ROWS) \
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ident, __float_as_int(v), CTRL, ROWS, 0xf, false)))
-    NPI_DPP_MAX(0x111, 0xf);
-    NPI_DPP_MAX(0x112, 0xf);
-    NPI_DPP_MAX(0x114, 0xf);
-    NPI_DPP_MAX(0x118, 0xf);
-    NPI_DPP_MAX(0x142, 0xa);
-    NPI_DPP_MAX(0x143, 0xc);
-#undef NPI_DPP_MAX
-    return bcast_f(v, WAVE - 1);
-}
-// wave-wide sum in the same fixed DPP order (deterministic): the partial dots of the fused GATConv forward's scores
-__device__ __forceinline__ float wave_sum(float v) {
-#define NPI_DPP_ADD(CTRL, ROWS) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false))
-    NPI_DPP_ADD(0x111, 0xf);
-    NPI_DPP_ADD(0x112, 0xf);
-    NPI_DPP_ADD(0x114, 0xf);
-    NPI_DPP_ADD(0x118, 0xf);
-    NPI_DPP_ADD(0x142, 0xa);
-    NPI_DPP_ADD(0x143, 0xc);
-#undef NPI_DPP_ADD
-    return bcast_f(v, WAVE - 1);
-}
 // max of the m of n (m, s) pairs, `stride` floats apart
 __device__ __forceinline__ float chain_max(const float* ms, int64_t stride, int n) {
     float m = -3.0e38f;
@@ -614,7 +651,7 @@ __device__ __forceinline__ void resolve_block(const SegParams& P, const Geo& L, 
 }
 
 // one item: `part` = this wave's two LDS rows ([2][NCH VEC WAVE]: head partial, tail partial), `M` = what it leaves behind
-template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, int EXACT>
 __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC, NCH, WMODE, EXACT>& L, const int item,
                                             float* __restrict__ part, ItemMeta* __restrict__ M) {
     constexpr int U = inflight<VEC, NCH>::value;
@@ -1010,11 +1047,13 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
 
 // the HBM-bound kernels of the headline (one 16-byte chunk per lane, no GAT weights) must keep 8 waves per SIMD: <= 64 VGPRs
 // (W_GAT_DST_FUSED: 6 waves per SIMD -- 80 VGPRs; left alone the allocator takes 93 for the chain resolution's sake, 5 waves)
-template <int VEC, int NCH, int WMODE, bool EXACT> struct seg_min_waves {
-    static constexpr int value = (NCH == 1 && WMODE <= W_ARRAY && EXACT) ? 8 : (NCH == 1 && WMODE == W_GAT_DST_FUSED) ? 6 : 1;
+template <int VEC, int NCH, int WMODE, int EXACT> struct seg_min_waves {
+    // (EXACT == 2: the variant that also writes the finished rows' power-of-two scales -- 70 registers, 7 waves; measured at C4
+    // against the 8-wave one: no difference in the launch, EXPERIMENTS A34)
+    static constexpr int value = (NCH == 1 && WMODE <= W_ARRAY && EXACT) ? (EXACT == 2 ? 7 : 8) : (NCH == 1 && WMODE == W_GAT_DST_FUSED) ? 6 : 1;
 };
 
-template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, int EXACT>
 __global__ void __launch_bounds__(SEG_THREADS, (seg_min_waves<VEC, NCH, WMODE, EXACT>::value))
 segsum_kernel(SegParams P) {
     constexpr int ROWF = NCH * VEC * WAVE;
@@ -1190,7 +1229,7 @@ segsum_group_kernel(SegParams P) {
     resolve_block<VEC, 1, ROWF>(P, L, finish, s_part, s_meta, &s_arrived);
 }
 
-template <typename T, int VEC, int NCH, int WMODE, bool EXACT>
+template <typename T, int VEC, int NCH, int WMODE, int EXACT>
 static void launch_one(const SegParams& P, hipStream_t stream) {
     dim3 grid(seg_grid(P.n_items)), block(SEG_THREADS);
     segsum_kernel<T, VEC, NCH, WMODE, EXACT><<<grid, block, 0, stream>>>(P);
@@ -1208,7 +1247,7 @@ static int launch_group_modes(const SegParams& P, int wmode, int mean, hipStream
     return check_launch("npi_segsum");
 }
 
-template <typename T, int VEC, int NCH, bool EXACT>
+template <typename T, int VEC, int NCH, int EXACT>
 static int launch_segsum(const SegParams& P, int wmode, int mean, hipStream_t stream) {
     if constexpr (NCH == 1 && !EXACT) {
         // narrow rows: several entries per wave instruction
@@ -1257,8 +1296,11 @@ static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t str
     const bool exact = VEC == 4 && (P.F % per) == 0;
 #define NPI_SEG_CASE(NC)                                                                    \
     case NC:                                                                                \
-        if constexpr (VEC == 4) { if (exact) return launch_segsum<T, VEC, NC, true>(P, wmode, mean, stream); } \
-        return launch_segsum<T, VEC, NC, false>(P, wmode, mean, stream)
+        if constexpr (VEC == 4 && NC == 1 && sizeof(T) == 4) {                              \
+            if (exact && P.scale_out != nullptr && wmode <= W_ARRAY) return launch_segsum<T, VEC, NC, 2>(P, wmode, mean, stream); \
+        }                                                                                   \
+        if constexpr (VEC == 4) { if (exact) return launch_segsum<T, VEC, NC, 1>(P, wmode, mean, stream); } \
+        return launch_segsum<T, VEC, NC, 0>(P, wmode, mean, stream)
     switch (nch) {
         NPI_SEG_CASE(1);
         NPI_SEG_CASE(2);
@@ -1340,7 +1382,22 @@ extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const in
                              const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
                              const void* x2_, int64_t split, void* out_, int64_t ldo, int64_t F, int dtype, int mean,
                              const float* bias, float* carry, void* stream_) {
+    return npi_segsum_ex2(rowptr, col, item_row, item_edges, w, N, nnz_max, x_, ldx, x2_, split, out_, ldo, F, dtype, mean, bias, carry,
+                          nullptr, stream_);
+}
+
+extern "C" int npi_segsum_scales_supported(int64_t F, int dtype) { return (F == 256 && dtype == NPI_F32) ? 1 : 0; }
+
+extern "C" int npi_segsum_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
+                              const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
+                              const void* x2_, int64_t split, void* out_, int64_t ldo, int64_t F, int dtype, int mean,
+                              const float* bias, float* carry, float* row_scales_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(row_scales_out == nullptr || (npi_segsum_scales_supported(F, dtype) && nnz_max > 0 && ldx % 4 == 0 && ldo % 4 == 0 &&
+                                              ((uintptr_t)x_ % 16) == 0 && ((uintptr_t)out_ % 16) == 0 &&
+                                              (x2_ == nullptr || ((uintptr_t)x2_ % 16) == 0)),
+                "npi_segsum_ex2: row_scales_out needs f32 rows of 256 columns, 16-byte aligned (npi_segsum_scales_supported), and a "
+                "graph with entries");
     NPI_REQUIRE(x2_ == nullptr || (split >= 0 && split < 0x7fffffff), "npi_segsum_ex: bad split");
     NPI_REQUIRE(N >= 0 && nnz_max >= 0 && F > 0, "npi_segsum: bad size");
     NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_segsum: dtype must be NPI_F32 or NPI_BF16");
@@ -1363,5 +1420,6 @@ extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const in
     P.x2 = (const float*)x2_; P.split = (int)split;
     P.carry = carry; P.w = w; P.bias = bias;
     P.H = 1; P.C = (int)F;
+    P.scale_out = row_scales_out;
     return segsum_run(P, w ? W_ARRAY : W_NONE, mean, nnz_max, dtype, stream);
 }

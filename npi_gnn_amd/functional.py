@@ -13,8 +13,8 @@ from typing import Optional
 
 import torch
 
-from ._lib import (NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, NPI_GEMM_RESERVE_CUS, NPI_GEMM_WORKSPACE_PREPARED, check, load, ptr,
-                   require_gpu, stream_ptr)
+from ._lib import (NPI_BF16, NPI_F32, NPI_GEMM_A_ZERO_PADDED, NPI_GEMM_EXACT_F32, NPI_GEMM_RESERVE_CUS, NPI_GEMM_SPLIT_F16X2,
+                   NPI_GEMM_WORKSPACE_PREPARED, NPI_PREPARE_F16X2, check, load, ptr, require_gpu, stream_ptr)
 from .graph import CSRGraph, CSRSide, as_graph
 from .schedule import DEFAULT, Schedule
 
@@ -127,12 +127,21 @@ def _check_out(out: torch.Tensor, rows: int, cols: int, like: torch.Tensor, what
 # ---------------------------------------------------------------------------------------------
 # raw ops
 # ---------------------------------------------------------------------------------------------
+def segsum_scales_ok(side: CSRSide, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> bool:
+    """can ``segsum(..., scales_out=)`` write the finished rows' power-of-two scales (f32 rows of 256 columns, 16-byte aligned)?"""
+    return (x.dtype == torch.float32 and x.size(1) == 256 and side.nnz_max > 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and (out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)))
+
+
 def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Tensor] = None,
            mean: bool = False, bias: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None,
+           scales_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i] = scale_i * sum_{p in row i} w[p] * x[col[p]] (+ bias): fused gather + segmented
     reduction (``npi_segsum``).  ``x2``: second part of a two-part table -- entries with
-    ``col >= x.size(0)`` read ``x2[col - x.size(0)]`` (``npi_segsum_ex``; the sharded layers)."""
+    ``col >= x.size(0)`` read ``x2[col - x.size(0)]`` (``npi_segsum_ex``; the sharded layers).
+    ``scales_out`` ``[n_rows]`` f32: also the power-of-two scale of every finished row (what ``row_scales(out)`` would compute in
+    a pass of its own; ``segsum_scales_ok``) for the fp16 x 2 projection behind the aggregation."""
     dev = require_gpu(x, w, bias, x2)
     x = _fcp(x, "x")
     if bias is not None:
@@ -158,9 +167,11 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     if prof is not None:        # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(dev))
-    check(load().npi_segsum_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.item, ptr(w), N, side.nnz_max,
-                               ptr(x), x.stride(0), ptr(x2), split if x2 is not None else 0, ptr(out), out.stride(0), F,
-                               _code(x), 1 if mean else 0, ptr(bias), ptr(carry), stream_ptr(dev)), "npi_segsum")
+    if scales_out is not None and (scales_out.dtype != torch.float32 or scales_out.numel() != N or not scales_out.is_contiguous()):
+        raise ValueError("segsum: scales_out must be a contiguous float32 vector with one element per output row")
+    check(load().npi_segsum_ex2(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.item, ptr(w), N, side.nnz_max,
+                                ptr(x), x.stride(0), ptr(x2), split if x2 is not None else 0, ptr(out), out.stride(0), F,
+                                _code(x), 1 if mean else 0, ptr(bias), ptr(carry), ptr(scales_out), stream_ptr(dev)), "npi_segsum")
     if prof is not None:
         ev1.record(torch.cuda.current_stream(dev))
         prof.append((ev0, ev1))
@@ -170,6 +181,17 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
 # Arithmetic of the f32 projection GEMMs, passed PER CALL (npi_linear_*_ex flags): 0 = the default (3-way bf16 split on the bf16
 # matrix cores), NPI_GEMM_EXACT_F32 = the exact-f32 MFMA kernels.  The library has no process-wide switch (ABI 3).
 GEMM_FLAGS = 0
+
+
+#: rows from which the f32 projection GEMMs of the single-GPU layers run on two fp16 pieces per operand (NPI_GEMM_SPLIT_F16X2: three
+#: matrix products per tile pair instead of six, the same f32-rounding-level error -- EXPERIMENTS A34); None: never.  Below, the
+#: GEMMs are launch-bound and the row scales would cost a pass of their own.
+F16X2_MIN_ROWS: Optional[int] = 100_000
+
+
+def _f16x2(rows: int, K: int, N: int, dtype) -> bool:
+    return (F16X2_MIN_ROWS is not None and rows >= F16X2_MIN_ROWS and dtype == torch.float32 and GEMM_FLAGS == 0
+            and f16x2_shape(rows, K, N))
 
 
 def _gemm_workspace(K: int, N: int, dev) -> torch.Tensor:
@@ -194,33 +216,54 @@ def padded_aggregate_buffer(x: torch.Tensor, K: int, rows: int, bf16_ok: bool = 
     return torch.zeros((rows, _pad128(K)), dtype=x.dtype, device=x.device)
 
 
-def prepare_weight(weight: torch.Tensor, backward: bool = True):
+def f16x2_shape(M: int, K: int, N: int) -> bool:
+    """shapes whose f32 projection GEMMs (contraction K, output width N, M rows) take the matrix-core kernel completely, i.e. where
+    ``NPI_GEMM_SPLIT_F16X2`` applies to every output tile"""
+    return M >= 128 and K % 32 == 0 and N % 128 == 0
+
+
+def row_scales(a: torch.Tensor) -> torch.Tensor:
+    """``[M]`` power-of-two scales of the rows of ``a`` (``npi_row_scales``): the ``a_scales`` of ``linear_fwd`` /
+    ``linear_bwd_data`` under ``NPI_GEMM_SPLIT_F16X2`` (two fp16 pieces per operand, three matrix products instead of six)"""
+    dev = require_gpu(a)
+    if a.dtype != torch.float32 or a.dim() != 2 or a.stride(1) != 1:
+        raise TypeError("row_scales: a float32 matrix with unit column stride")
+    out = torch.empty(a.size(0), dtype=torch.float32, device=dev)
+    check(load().npi_row_scales(ptr(a), a.stride(0), a.size(0), a.size(1), ptr(out), stream_ptr(dev)), "npi_row_scales")
+    return out
+
+
+def prepare_weight(weight: torch.Tensor, backward: bool = True, f16: bool = False):
     """The re-laid copies of ``weight [K, N]`` the matrix-core GEMMs read (three bf16 planes for f32, a k-block-major copy for
-    bf16) for ``linear_fwd(..., ws=)`` and -- ``backward`` -- ``linear_bwd_data(..., ws=)``, written by ONE launch
+    bf16; ``f16``: the two fp16 planes + column scales of ``NPI_GEMM_SPLIT_F16X2`` calls) for ``linear_fwd(..., ws=)`` and --
+    ``backward`` -- ``linear_bwd_data(..., ws=)``, written by ONE launch
     (``npi_linear_prepare``) instead of one in front of every GEMM: ``(ws_fwd, ws_bwd or None)``, or ``(None, None)`` when the
     shape does not take those kernels anyway.  Valid while ``weight`` is unchanged (a layer's forward and its backward)."""
     K, N = weight.shape
     if (weight.dtype not in (torch.float32, torch.bfloat16) or K % 32 or N % 32 or weight.stride(1) != 1 or GEMM_FLAGS != 0
-            or not weight.is_cuda):
+            or not weight.is_cuda or (f16 and weight.dtype != torch.float32)):
         return None, None
     lib = load()
     dev = weight.device
     one = int(lib.npi_linear_workspace_bytes(K, N))
     ws = torch.empty(one * (2 if backward else 1), dtype=torch.uint8, device=dev)
-    check(lib.npi_linear_prepare(ptr(weight), weight.stride(0), K, N, 3 if backward else 1, _code(weight), ptr(ws), ws.numel(),
-                                 stream_ptr(dev)), "npi_linear_prepare")
+    check(lib.npi_linear_prepare(ptr(weight), weight.stride(0), K, N, (3 if backward else 1) | (NPI_PREPARE_F16X2 if f16 else 0),
+                                 _code(weight), ptr(ws), ws.numel(), stream_ptr(dev)), "npi_linear_prepare")
     return ws[:one], (ws[one:] if backward else None)
 
 
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                rowscale: Optional[torch.Tensor] = None, relu: bool = False, flags: Optional[int] = None,
-               out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, reserve_cus: int = 0) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, reserve_cus: int = 0,
+               a_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``a @ weight + bias``.  ``a`` may be wider than ``weight`` has rows: ``[M, Kp]`` with Kp = K rounded up to 128 and
     the columns K.. ZERO (``NPI_GEMM_A_ZERO_PADDED``: the matrix-core kernel on Kp instead of the guarded one on an odd K).
     ``out``: write into this ``[M, N]`` tensor (rows may have a pitch; same dtype) instead of a new one.  ``ws``: the forward
     copy of ``prepare_weight(weight)`` -- no preparation launch in front of the GEMM.  ``reserve_cus``: leave that many CUs (a
-    multiple of 8) to a kernel that runs beside the GEMM (``NPI_GEMM_RESERVE_CUS``; the sharded layers, ``Schedule.gemm_reserve_cus``)."""
-    dev = require_gpu(a, weight, bias, rowscale)
+    multiple of 8) to a kernel that runs beside the GEMM (``NPI_GEMM_RESERVE_CUS``; the sharded layers, ``Schedule.gemm_reserve_cus``).
+    ``a_scales``: ``row_scales(a)`` -- the GEMM then runs on two fp16 pieces per operand (``NPI_GEMM_SPLIT_F16X2``: half the matrix
+    work, the same f32-level accuracy); a ``ws`` handed over with it must come from ``prepare_weight(..., f16=True)``."""
+    dev = require_gpu(a, weight, bias, rowscale, a_scales)
     a = _fc(a, "a")
     weight = _fc(weight, "weight", a)
     if bias is not None:
@@ -236,24 +279,29 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         out = torch.empty((M, N), dtype=a.dtype, device=dev)
     elif out.shape != (M, N) or out.dtype != a.dtype or out.stride(1) != 1 or out.device != a.device:
         raise ValueError(f"linear_fwd: out must be [{M}, {N}] {a.dtype} with unit column stride on the operands' device")
+    if a_scales is not None and (a.dtype != torch.float32 or Ka != K or fl & NPI_GEMM_EXACT_F32):
+        a_scales = None                                         # (storage / flags the fp16 x 2 kernel does not serve)
+    if a_scales is not None:
+        fl |= NPI_GEMM_SPLIT_F16X2
     if ws is not None and Ka == K:
         fl |= NPI_GEMM_WORKSPACE_PREPARED
     else:
         ws = _gemm_workspace(Ka, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
-        check(load().npi_linear_fwd_ex(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
-                                       ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a),
-                                       fl, ptr(ws), ws.numel(), stream_ptr(dev)),
+        check(load().npi_linear_fwd_ex2(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
+                                        ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a),
+                                        fl, ptr(ws), ws.numel(), ptr(a_scales), stream_ptr(dev)),
               "npi_linear_fwd")
     return out
 
 
 def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
                     rowscale: Optional[torch.Tensor] = None, flags: Optional[int] = None,
-                    out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, reserve_cus: int = 0) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, reserve_cus: int = 0,
+                    dc_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``rowscale * (dc @ weight.T)``; ``out``: write into this ``[M, K]`` tensor (a row block of a larger buffer); ``ws``: the
-    backward copy of ``prepare_weight(weight)``."""
-    dev = require_gpu(dc, weight, rowscale)
+    backward copy of ``prepare_weight(weight)``; ``dc_scales``: ``row_scales(dc)`` -- the fp16 x 2 arithmetic, as in ``linear_fwd``."""
+    dev = require_gpu(dc, weight, rowscale, dc_scales)
     dc = _fc(dc, "dC")
     weight = _fc(weight, "weight", dc)
     M, N = dc.shape
@@ -265,14 +313,18 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
             raise ValueError(f"linear_bwd_data: out must be [{M}, {K}] {dc.dtype} with unit column stride on the operands' device")
         da = out
     fl = (GEMM_FLAGS if flags is None else flags) | NPI_GEMM_RESERVE_CUS(reserve_cus)
+    if dc_scales is not None and (dc.dtype != torch.float32 or fl & NPI_GEMM_EXACT_F32):
+        dc_scales = None
+    if dc_scales is not None:
+        fl |= NPI_GEMM_SPLIT_F16X2
     if ws is not None:
         fl |= NPI_GEMM_WORKSPACE_PREPARED
     else:
         ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
-        check(load().npi_linear_bwd_data_ex(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
-                                            ptr(da), da.stride(0), M, K, N, _code(dc),
-                                            fl, ptr(ws), ws.numel(), stream_ptr(dev)),
+        check(load().npi_linear_bwd_data_ex2(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
+                                             ptr(da), da.stride(0), M, K, N, _code(dc),
+                                             fl, ptr(ws), ws.numel(), ptr(dc_scales), stream_ptr(dev)),
               "npi_linear_bwd_data")
     return da
 
@@ -568,6 +620,23 @@ class _SageConvFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.sch = sch
         ctx.k_rows = None
+        f16 = (x.dtype == weight.dtype and x.size(1) == weight.size(0)
+               and _f16x2(graph.by_dst.n_rows, weight.size(0), weight.size(1), x.dtype) and segsum_scales_ok(graph.by_dst, x))
+        ctx.f16 = f16
+        if f16:
+            # large graphs, 256 features: the projection on two fp16 pieces per operand -- the aggregation writes the row scales of
+            # agg itself (a wave maximum per finished row); where it cannot, a pass over agg would cost what the GEMM saves
+            agg = torch.empty((graph.by_dst.n_rows, x.size(1)), dtype=x.dtype, device=x.device)
+            scales = torch.empty(agg.size(0), dtype=torch.float32, device=x.device)
+            segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True, out=agg, scales_out=scales)
+            wsf, _ = prepare_weight(weight, backward=False, f16=True)
+            # (the backward's dAgg = dOut W^T stays on the bf16 x 3 planes: the scales of dOut -- handed in from outside -- would
+            # cost a pass over it that takes what the three products give, EXPERIMENTS A34)
+            ctx.ws_bwd = prepare_weight(weight, backward=True)[1] if ctx.needs_input_grad[0] else None
+            out = linear_fwd(agg, weight, bias, relu=relu, ws=wsf, a_scales=scales)
+            ctx.k_valid = None
+            ctx.save_for_backward(agg, weight, *([out] if relu else []))
+            return out
         if _layer_calls_ok() and x.dtype == weight.dtype and x.dtype in (torch.float32, torch.bfloat16) and not (
                 x.dtype == torch.bfloat16 and weight.size(0) % 128 != 0 and 2 * _pad128(weight.size(0)) <= 3 * weight.size(0)):
             # the whole layer call as one entry point (the same launches; one trip through the C ABI instead of three)
@@ -607,7 +676,7 @@ class _SageConvFn(torch.autograd.Function):
         # symmetric edge list, no per-entry weights: A^T has the rows of A (graph.CSRGraph.symmetric) -- skip the second sort
         tside = (lambda: graph.by_dst) if (graph.symmetric and ctx.w_src is None) else (lambda: graph.by_src)
         overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
-        if not overlap and ctx.k_rows is None and _layer_calls_ok() and (want_w or want_x):
+        if not overlap and ctx.k_rows is None and _layer_calls_ok() and (want_w or want_x) and not ctx.f16:
             # one stream: the whole backward as one entry point (ReLU mask, dW + db, dAgg GEMM, transposed aggregation)
             out_relu = None
             if ctx.relu:
@@ -830,6 +899,21 @@ class _GcnAggFirstFn(torch.autograd.Function):
         ctx.norm = norm
         ctx.has_bias = bias is not None
         ctx.sch = sch
+        if (x.dtype == weight.dtype and x.size(1) == weight.size(0) and segsum_scales_ok(graph.by_dst, x)
+                and _f16x2(graph.by_dst.n_rows, weight.size(0), weight.size(1), x.dtype)):
+            # large graphs, 256 features: the projection on two fp16 pieces per operand, the row scales written by the aggregation
+            # (as in _SageConvFn.forward; the backward keeps the bf16 x 3 planes)
+            agg = torch.empty((graph.by_dst.n_rows, x.size(1)), dtype=x.dtype, device=x.device)
+            scales = torch.empty(agg.size(0), dtype=torch.float32, device=x.device)
+            segsum(graph, graph.by_dst, x, w=norm.by_dst, out=agg, scales_out=scales)
+            wsf, _ = prepare_weight(weight, backward=False, f16=True)
+            ctx.ws_bwd = prepare_weight(weight, backward=True)[1] if ctx.needs_input_grad[0] else None
+            out = linear_fwd(agg, weight, bias, ws=wsf, a_scales=scales)
+            ctx.k_valid = None
+            ctx.f16 = True
+            ctx.save_for_backward(agg, weight)
+            return out
+        ctx.f16 = False
         if _layer_calls_ok() and x.dtype == weight.dtype == torch.float32:
             agg, out, ctx.ws_bwd = conv_fwd(graph.by_dst, x, norm.by_dst, False, weight, bias, False, ctx.needs_input_grad[0])
             ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None

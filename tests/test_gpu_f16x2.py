@@ -1,0 +1,139 @@
+"""The f32 projection GEMMs on TWO fp16 pieces per operand (NPI_GEMM_SPLIT_F16X2: three matrix products per tile pair instead of the
+six of the bf16 x 3 split; csrc/gemm_f32.hip, EXPERIMENTS A33 / A34): accuracy against fp64 at the level of an f32 matmul, the
+power-of-two row scales (npi_row_scales; written by the aggregation launch itself through npi_segsum_ex2), and the layers that
+use the arithmetic.  The reference's op is torch.matmul(aggr_out, self.weight) (PyG 1.4.2 SAGEConv.update; call sites
+src/classes.py:62,66,70)."""
+import math
+
+import pytest
+import torch
+
+import npi_gnn_amd as npi
+from npi_gnn_amd import functional as NF
+from _util import GRAD_REL, rel_max
+from oracle import ref_conv as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(c, ref):
+    return float((c.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 256, 256), (130, 128, 128), (1000, 512, 256), (20001, 256, 128), (777, 64, 384)])
+def test_fp16x2_gemms_are_f32_accurate(dev, M, K, N):
+    """forward and backward-data, prepared planes and planes made inside the call (bit-equal), bias / row scale / ReLU epilogue:
+    max |C - C_fp64| / max |C| at f32-matmul level (the bf16 x 3 kernel: 6.3e-7, torch.matmul in f32: 7e-7)"""
+    g = torch.Generator(device=dev).manual_seed(M)
+    a = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(K, N, device=dev, generator=g) / math.sqrt(K)
+    b = torch.randn(N, device=dev, generator=g)
+    rs = torch.rand(M, device=dev, generator=g) + 0.5
+    sc = NF.row_scales(a)
+    ref_s = torch.pow(2.0, 14 - torch.floor(torch.log2(a.abs().max(dim=1).values.double()))).float()
+    assert torch.equal(sc, ref_s)                                            # max |row| * scale in [2^14, 2^15)
+    wsf, wsb = NF.prepare_weight(w, backward=True, f16=True)
+    c = NF.linear_fwd(a, w, ws=wsf, a_scales=sc)
+    assert torch.equal(c, NF.linear_fwd(a, w, a_scales=sc))
+    assert _err(c, a.double() @ w.double()) <= 1e-6
+    e = NF.linear_fwd(a, w, b, rowscale=rs, relu=True, ws=wsf, a_scales=sc)
+    assert _err(e, torch.relu(rs[:, None].double() * (a.double() @ w.double()) + b.double())) <= 1e-6
+    dc = torch.randn(M, N, device=dev, generator=g)
+    d = NF.linear_bwd_data(dc, w, rowscale=rs, ws=wsb, dc_scales=NF.row_scales(dc))
+    assert torch.equal(d, NF.linear_bwd_data(dc, w, rowscale=rs, dc_scales=NF.row_scales(dc)))
+    assert _err(d, rs[:, None].double() * (dc.double() @ w.double().t())) <= 1e-6
+    # bitwise reproducible
+    assert torch.equal(c, NF.linear_fwd(a, w, ws=wsf, a_scales=sc))
+
+
+def test_fp16x2_scales_rows_and_columns_of_any_magnitude(dev):
+    """fp16 has five exponent bits: the row scales of A and the column scales of W (inside the preparation) put every row / column
+    into range -- rows 30 decades apart, elements 8 decades apart inside a row, an all-zero row, a row of 1e-30 and one of 1e+30,
+    weight columns 6 decades apart; the error is measured against every ROW's own largest |C|"""
+    g = torch.Generator(device=dev).manual_seed(3)
+    M, K, N = 8192, 256, 256
+    a = torch.randn(M, K, device=dev, generator=g) * torch.pow(10.0, torch.rand(M, 1, device=dev, generator=g) * 30 - 15)
+    a *= torch.pow(10.0, torch.rand(M, K, device=dev, generator=g) * 8 - 4)
+    a[5] = 0
+    a[6] *= 1e-30 / a[6].abs().max()
+    a[7] *= 1e30 / a[7].abs().max()
+    w = torch.randn(K, N, device=dev, generator=g) * torch.pow(10.0, torch.rand(1, N, device=dev, generator=g) * 6 - 3)
+    ref = a.double() @ w.double()
+    c = NF.linear_fwd(a, w, a_scales=NF.row_scales(a))
+    den = ref.abs().max(dim=1, keepdim=True).values.clamp(min=1e-300)
+    assert torch.isfinite(c).all() and bool((c[5] == 0).all())
+    assert float(((c.double() - ref).abs() / den).max()) <= 2e-6
+    # and ELEMENT by element against sum_k |a||w| -- the bound an f32 matmul itself is held to (torch.matmul: 1e-6 on these operands,
+    # the bf16 x 3 kernel 7.5e-7; a column of small weights is not drowned by a large one)
+    bound = (a.abs().double() @ w.abs().double()).clamp(min=1e-300)
+    assert float(((c.double() - ref).abs() / bound).max()) <= 1e-6
+
+
+def test_fp16x2_non_finite_operands_behave_as_under_the_bf16_split(dev):
+    """NaN stays NaN; an Inf in A makes its output row NaN (Inf - Inf in the split), as the bf16 x 3 arithmetic does (include/npi_gnn.h)"""
+    g = torch.Generator(device=dev).manual_seed(4)
+    a = torch.randn(256, 128, device=dev, generator=g)
+    w = torch.randn(128, 128, device=dev, generator=g)
+    a[3, 5] = float("nan")
+    a[9, 7] = float("inf")
+    c = NF.linear_fwd(a, w, a_scales=NF.row_scales(a))
+    assert torch.isnan(c[3]).all() and torch.isnan(c[9]).all()
+    keep = torch.ones(256, dtype=torch.bool, device=dev)
+    keep[3] = keep[9] = False
+    assert torch.isfinite(c[keep]).all() and _err(c[keep], a[keep].double() @ w.double()) <= 1e-6
+
+
+def test_aggregation_writes_the_row_scales_its_projection_needs(dev):
+    """npi_segsum_ex2: the finished rows' power-of-two scales from the aggregation launch itself -- bit-equal to a pass over the
+    finished matrix (npi_row_scales), for mean / weighted sums, hub rows cut across items, empty rows, both item sizes"""
+    N, E = 30_000, 400_000
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, : E // 3] = 7                                                      # a hub row: cut across many items and workgroups
+    ei = ei[:, ei[1] != 11]                                                  # row 11: only its self loop
+    x = torch.randn(N, 256, generator=g).to(dev)
+    for item in (64, 256):
+        graph = npi.CSRGraph(ei.to(dev), N, item=item)
+        for w, mean in ((None, True), (torch.rand(graph.by_dst.nnz_max, device=dev), False)):
+            plain = NF.segsum(graph, graph.by_dst, x, w=w, mean=mean)
+            sc = torch.empty(N, device=dev)
+            out = NF.segsum(graph, graph.by_dst, x, w=w, mean=mean, scales_out=sc)
+            assert torch.equal(out, plain)                                   # the 7-wave variant sums in the same order
+            assert torch.equal(sc, NF.row_scales(out))
+    assert not NF.segsum_scales_ok(graph.by_dst, x[:, :128].contiguous())   # 256 columns only
+
+
+@pytest.mark.parametrize("kind", ["sage", "gcn"])
+def test_layers_on_fp16x2_projections_match_the_oracle(dev, kind):
+    """F16X2_MIN_ROWS = 0: the forward projection of SAGEConv / GCNConv (aggregate first) at 256 features on the fp16 x 2 kernel,
+    the scales from the aggregation launch -- outputs and every gradient at the layers' own bars, and within rounding of the
+    bf16 x 3 run"""
+    N, E, F = 3000, 30_000, 256
+    g = torch.Generator().manual_seed(6)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    x = torch.randn(N, F, generator=g)
+    go = torch.randn(N, F, generator=g)
+    conv = (npi.SAGEConv(F, F) if kind == "sage" else npi.GCNConv(F, F)).to(dev)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(F, generator=g) * 0.1)
+    graph = npi.CSRGraph(ei.to(dev), N)
+    res = {}
+    old = NF.F16X2_MIN_ROWS
+    try:
+        for rows in (None, 0):
+            NF.F16X2_MIN_ROWS = rows
+            conv.zero_grad()
+            xd = x.to(dev).requires_grad_(True)
+            out = conv(xd, graph)
+            out.backward(go.to(dev))
+            res[rows] = (out.detach(), xd.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
+    finally:
+        NF.F16X2_MIN_ROWS = old
+    assert not torch.equal(res[0][0], res[None][0]) and rel_max(res[0][0], res[None][0]) <= 2e-6     # another arithmetic, the same numbers
+    x6, W6, b6 = (t.detach().cpu().double().clone().requires_grad_(True) for t in (x, conv.weight, conv.bias))
+    ref = (R.sage_conv if kind == "sage" else R.gcn_conv)(x6, ei, W6, b6)
+    ref.backward(go.double())
+    out, dx, dW, db = res[0]
+    assert float((out.cpu().double() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((dx.cpu().double() - x6.grad).abs().max()) <= 1e-4 * max(1.0, float(x6.grad.abs().max()))
+    assert rel_max(dW, W6.grad) <= GRAD_REL and rel_max(db, b6.grad) <= GRAD_REL

@@ -46,14 +46,22 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers(built):
 
 def test_hot_kernels_keep_the_occupancy_the_design_assumes(built):
     seg = _pretty(built["segsum.hip"][0])
-    hot = {n: m for n, m in seg.items() if n.startswith("void npi::segsum_kernel<float, 4, 1, 0, true>")}
+    hot = {n: m for n, m in seg.items() if n.startswith("void npi::segsum_kernel<float, 4, 1, 0, 1>")}
     assert len(hot) == 1, list(seg)[:5]                       # f32 x 4, one chunk, unweighted, unguarded: the C4 kernel
     for n, m in hot.items():
         assert m["vgpr"] <= 64 and m["agpr"] == 0, (n, m)     # 8 waves / SIMD (512 VGPRs / 64)
+    # the same kernel when it also writes the finished rows' power-of-two scales (npi_segsum_ex2; the fp16 x 2 projection behind
+    # it): 7 waves / SIMD, no scratch -- at 8 it spilled three registers
+    sc = {n: m for n, m in seg.items() if n.startswith("void npi::segsum_kernel<float, 4, 1, 0, 2>")}
+    assert len(sc) == 1
+    for n, m in sc.items():
+        assert m["vgpr"] <= 72 and m["agpr"] == 0 and m["scratch"] == 0, (n, m)
     gemm = _pretty(built["gemm_f32.hip"][0])
     # (<4, 1>: the same kernel with the rank-2 store epilogue of GATConv's dX -- 22 registers and 8 KB of LDS more; <4, 2>: with
     # the row dots of GATConv's scores in the store epilogue -- 10 KB of LDS more)
-    for fam in ("gemm_split_ws_kernel<4, 0>", "gemm_split_ws_kernel<4, 1>", "gemm_split_ws_kernel<4, 2>", "gemm_dw_split_kernel<4, false>",
+    for fam in ("gemm_split_ws_kernel<4, 0, false>", "gemm_split_ws_kernel<4, 1, false>", "gemm_split_ws_kernel<4, 2, false>",
+                "gemm_split_ws_kernel<4, 0, true>", "gemm_split_ws_kernel<4, 1, true>", "gemm_split_ws_kernel<4, 2, true>",     # fp16 x 2
+                "gemm_dw_split_kernel<4, false>",
                 "gemm_dw_split_kernel<4, true>",
                 "gemm_bf16_ws_kernel<4>"):
         ks = {n: m for n, m in gemm.items() if fam in n}
@@ -74,8 +82,9 @@ def test_asm_gemms_hold_no_flat_access_no_sgpr_hazard_and_touch_no_in_flight_lds
             assert G.find_flat(instrs) == [], (sym, G.find_flat(instrs)[:3])
             wide = "global_load_dwordx2" if "gemm_dw_split_kernelILi4ELb1" in sym or "gemm_dw_split_kernelILi2ELb1" in sym else "global_load_dwordx4"
             assert any(i.startswith(wide) for i in instrs), sym                     # the asm loads are there at all (bf16 dW: 8 bytes)
-            assert any(i.startswith("ds_read_b128") for i in instrs) and any("v_mfma_f32_32x32x16_bf16" in i for i in instrs), sym
-    assert checked == 12                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue, dW also for bf16 operands
+            mfma = "v_mfma_f32_32x32x16_f16" if ("gemm_split_ws_kernel" in sym and sym.endswith("Lb1EEEvNS_9SplitArgsE")) else "v_mfma_f32_32x32x16_bf16"
+            assert any(i.startswith("ds_read_b128") for i in instrs) and any(mfma in i for i in instrs), (sym, mfma)
+    assert checked == 18                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue and each of those on fp16 x 2, dW also for bf16 operands
     # no FLAT memory instruction anywhere: a flat access counts on lgkmcnt as well as vmcnt (every LDS / scalar-load wait then
     # drains the gathers too) -- round 4 found all 128 aggregation kernels gathering through flat_load because the second
     # part of the table was addressed through a pointer biased with integer arithmetic
