@@ -1054,6 +1054,12 @@ def main():
                     "by_collective_ms_per_step": {k: v / args.steps for k, v in sorted(exposed.items())},
                     "note": "rank 0; stall of the waiting stream at each collective (HIP events around work.wait())"}
     split_on = NF.GEMM_FLAGS == 0 and os.environ.get("NPI_GEMM_SPLIT", "1") != "0"
+    # matrix products ISSUED per f32-equivalent product: six bf16 ones, or three fp16 ones where the forward projection runs on
+    # two fp16 pieces per operand (functional.F16X2_MIN_ROWS: SAGEConv / GCNConv, 256 features, the row scales from the aggregation)
+    f16_fwd = (split_on and not sharded and args.conv in ("sage", "gcn") and args.storage == "f32" and F == 256
+               and NF._f16x2(N, F, F, torch.float32))
+    products = {"fwd": 3.0 if f16_fwd else 6.0}
+    issued_tf = (sum(v[0] * products.get(k, 6.0) for k, v in gem.items() if k != "bwd_weight") / (solo_ms * 1e-3) / 1e12) if solo_ms else None
     res = None
     if rank == 0:
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1099,15 +1105,20 @@ def main():
                                  "note": "gather + segmented reduction, forward + transposed backward launches of one layer"},
             "projection": {
                 "bound": "mfma",
-                "kernels": "fwd + bwd_data: gemm_split_ws_kernel (f32 operands split 3-way into bf16, six "
-                           "v_mfma_f32_32x32x16_bf16 per f32 product, f32 accumulate)" if split_on else
+                "kernels": ("fwd: gemm_split_ws_kernel<.., true> (f32 operands as two scaled fp16 pieces, three v_mfma_f32_32x32x16_f16 per "
+                            "f32 product); bwd_data: gemm_split_ws_kernel (three bf16 pieces, six v_mfma_f32_32x32x16_bf16); f32 accumulate"
+                            if f16_fwd else
+                            "fwd + bwd_data: gemm_split_ws_kernel (f32 operands split 3-way into bf16, six "
+                            "v_mfma_f32_32x32x16_bf16 per f32 product, f32 accumulate)") if split_on else
                            "fwd + bwd_data: exact-f32 v_mfma_f32_32x32x2_f32 kernels",
                 "achieved_f32_equivalent": solo_tf, "unit": "TFLOP/s",
                 # the pipe the kernel runs on: six bf16 MFMA flops are issued per f32-equivalent flop
-                "achieved": (6.0 * solo_tf) if (solo_tf and split_on) else solo_tf,
+                "achieved": issued_tf if (solo_tf and split_on) else solo_tf,
                 "peak": MFMA_BF16_PEAK_TF if split_on else MFMA_F32_PEAK_TF,
-                "frac": ((6.0 * solo_tf / MFMA_BF16_PEAK_TF) if split_on else (solo_tf / MFMA_F32_PEAK_TF)) if solo_tf else None,
-                "frac_note": "issued bf16-MFMA flops (6 x f32-equivalent) / dense bf16 MFMA peak" if split_on else
+                "frac": ((issued_tf / MFMA_BF16_PEAK_TF) if split_on else (solo_tf / MFMA_F32_PEAK_TF)) if solo_tf else None,
+                "issued_products_per_f32_product": products if split_on else None,
+                "frac_note": ("issued 16-bit MFMA flops (fwd 3 x, bwd_data 6 x the f32-equivalent) / dense bf16 = fp16 MFMA peak" if f16_fwd else
+                              "issued bf16-MFMA flops (6 x f32-equivalent) / dense bf16 MFMA peak") if split_on else
                              "f32 flops / f32 MFMA peak",
                 "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},
                 "per_gemm_tflops_f32_equivalent": {k: v[0] / (v[1] * 1e-3) / 1e12 for k, v in gem.items() if v[1] > 0},
