@@ -313,6 +313,12 @@ int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t N);
 int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0, const float* row1,
                               const float* col0, const float* col1, float* dA, int64_t ldda, int64_t M, int64_t K, int64_t N,
                               void* workspace, int64_t workspace_bytes, void* stream);
+/* the same with the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) when dc_scales is not NULL: the row scales of dC, from npi_row_scales
+ * or from the launch that wrote dC (npi_gat_backward_fused_heads_ex2) */
+int npi_linear_bwd_data_rank2_ex2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
+                                  const float* row1, const float* col0, const float* col1, float* dA, int64_t ldda,
+                                  int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
+                                  const float* dc_scales, void* stream);
 
 /* The two-row products around that epilogue, one head (att = [att_dst ; att_src], [2, C]; W [K, C]; P = x^T [g_dst g_src], [2, K] from
  * npi_gat_att_grad on x):  cols: U [2, K] = att W^T, the column vectors col0 / col1 above.  tail: dW [K, C] += P^T att (the
@@ -403,6 +409,14 @@ int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, cons
                                  int64_t split, const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C,
                                  const float* tpack, const float* a_src, float negative_slope, float* dz, float* carry,
                                  void* stream);
+/* the same, also writing the power-of-two scale of every finished row of `out` (row_scales_out [N] or NULL; heads * out_channels == 256):
+ * the dc_scales of the projection behind it (npi_linear_bwd_data_rank2_ex2 / npi_linear_bwd_data_ex2) without a pass over `out` */
+int npi_gat_backward_fused_heads_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                                     const int32_t* item_row, int64_t item_edges, int64_t N, int64_t nnz_max,
+                                     const float* dout, int64_t ldd, const float* dout2, int64_t split, const float* hfeat,
+                                     int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack,
+                                     const float* a_src, float slope, float* dz, float* carry, float* row_scales_out,
+                                     void* stream);
 int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
                       int64_t N, int64_t H, int64_t C, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,

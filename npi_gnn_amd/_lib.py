@@ -70,6 +70,7 @@ PROTOTYPES = {
     "npi_linear_fwd_scores": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "npi_linear_bwd_data_rank2_supported": (c_int, [_I, _I, _I]),
     "npi_linear_bwd_data_rank2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "npi_linear_bwd_data_rank2_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "npi_gat_rank2_cols": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_gat_rank2_tail": (c_int, [_P, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     "npi_linear_bwd_weight_ex": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, c_int, c_int, _P]),
@@ -84,6 +85,8 @@ PROTOTYPES = {
     "npi_gat_pack_targets": (c_int, [_P, _P, _P, _P, _I, _P, _P]),
     "npi_gat_backward_fused_heads": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P,
                                              _P, _P]),
+    "npi_gat_backward_fused_heads_ex2": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P,
+                                                 _P, _P, _P]),
     "npi_gat_rank1_add": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "npi_gat_edge_grad_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float,

@@ -583,8 +583,21 @@ extern "C" int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t
                                             int64_t ldd, const float* dout2, int64_t split, const float* hfeat, int64_t ldh,
                                             float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack, const float* a_src,
                                             float slope, float* dz, float* carry, void* stream_) {
+    return npi_gat_backward_fused_heads_ex2(rowptr, col, rowidx, item_row, item_edges, N, nnz_max, dout, ldd, dout2, split, hfeat, ldh, out,
+                                            ldo, H, C, tpack, a_src, slope, dz, carry, nullptr, stream_);
+}
+
+extern "C" int npi_gat_backward_fused_heads_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+                                                const int32_t* item_row, int64_t item_edges, int64_t N, int64_t nnz_max,
+                                                const float* dout, int64_t ldd, const float* dout2, int64_t split, const float* hfeat,
+                                                int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack,
+                                                const float* a_src, float slope, float* dz, float* carry, float* row_scales_out,
+                                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t F = H * C;
+    NPI_REQUIRE(row_scales_out == nullptr || (F == 256 && ldd % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)dout % 16) == 0 &&
+                                              ((uintptr_t)out % 16) == 0 && (dout2 == nullptr || ((uintptr_t)dout2 % 16) == 0)),
+                "npi_gat_backward_fused_heads_ex2: row_scales_out needs heads * out_channels == 256 and 16-byte aligned rows");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C % 4 == 0 && F <= 256, "npi_gat_backward_fused_heads: needs heads * out_channels <= 256, out_channels % 4 == 0");
     NPI_REQUIRE(H == 1 || ((H == 2 || H == 4 || H == 8) && C >= 32 && (C & (C - 1)) == 0),
                 "npi_gat_backward_fused_heads: several heads need 2 / 4 / 8 heads of 32 / 64 / 128 channels");
@@ -605,6 +618,7 @@ extern "C" int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t
     P.a_dst = a_src; P.m = a_src; P.s = a_src;                                 // unused in this mode
     P.tpack = reinterpret_cast<const float4*>(tpack);                          // [n_cols, H, 4], indexed by the COLUMN id over both parts
     P.hrow = hfeat; P.ldh = ldh; P.rowidx = rowidx; P.dz_out = dz;            // dz: [nnz_max, H]
+    P.scale_out = row_scales_out;
     const int mode = H == 1 ? W_GAT_SRC_FUSED : H == 2 ? W_GAT_SRC_FUSED_H2 : H == 4 ? W_GAT_SRC_FUSED_H4 : W_GAT_SRC_FUSED_H8;
     return segsum_run(P, mode, 0, nnz_max, NPI_F32, stream);
 }

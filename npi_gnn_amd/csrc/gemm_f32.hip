@@ -2289,6 +2289,16 @@ extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const fl
                                          const float* row1, const float* col0, const float* col1, float* dA, int64_t ldda,
                                          int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
                                          void* stream_) {
+    return npi_linear_bwd_data_rank2_ex2(dC, lddc, W, ldw, row0, row1, col0, col1, dA, ldda, M, K, N, workspace, workspace_bytes, nullptr,
+                                         stream_);
+}
+
+// dc_scales != NULL: the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2), the row scales of dC from npi_row_scales or from the launch that
+// wrote dC (npi_gat_backward_fused_heads_ex2)
+extern "C" int npi_linear_bwd_data_rank2_ex2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
+                                             const float* row1, const float* col0, const float* col1, float* dA, int64_t ldda,
+                                             int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
+                                             const float* dc_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(npi_linear_bwd_data_rank2_supported(M, K, N), "npi_linear_bwd_data_rank2: shape outside the split kernel's "
                 "full coverage (M >= 128, K % 128 == 0, N % 32 == 0)");
@@ -2302,7 +2312,7 @@ extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const fl
     }
     GemmArgs a{dC, lddc, W, ldw, dA, ldda, (int)M, (int)K, (int)N, (int)align_up(N, BK), 0, 0, 0,
                Epilogue{nullptr, nullptr, 0, nullptr, row0, row1, col0, col1}};
-    const int rc = launch_gemm<0, 1>(true, a, 1, stream, NPI_F32, NPI_F32, 1, workspace);
+    const int rc = launch_gemm<0, 1>(true, a, 1, stream, NPI_F32, NPI_F32, 1, workspace, 0, false, 0, dc_scales);
     return rc != NPI_OK ? rc : check_launch("npi_linear_bwd_data_rank2");
 }
 

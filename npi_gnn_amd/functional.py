@@ -366,7 +366,7 @@ def linear_bwd_data_rank2_ok(dc: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def linear_bwd_data_rank2(dc: torch.Tensor, weight: torch.Tensor, row0: torch.Tensor, row1: torch.Tensor,
-                          col0: torch.Tensor, col1: torch.Tensor) -> torch.Tensor:
+                          col0: torch.Tensor, col1: torch.Tensor, dc_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``dc @ weight.T + row0 (x) col0 + row1 (x) col1`` with the rank-2 term added in the GEMM's store epilogue
     (``npi_linear_bwd_data_rank2``; ``row*`` are ``[M]``, ``col*`` ``[K]``)."""
     dev = require_gpu(dc, weight, row0, row1, col0, col1)
@@ -378,8 +378,8 @@ def linear_bwd_data_rank2(dc: torch.Tensor, weight: torch.Tensor, row0: torch.Te
     da = torch.empty((M, K), dtype=torch.float32, device=dev)
     ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
-        check(load().npi_linear_bwd_data_rank2(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(row0), ptr(row1),
-                                               ptr(col0), ptr(col1), ptr(da), da.stride(0), M, K, N, ptr(ws), ws.numel(),
+        check(load().npi_linear_bwd_data_rank2_ex2(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(row0), ptr(row1),
+                                               ptr(col0), ptr(col1), ptr(da), da.stride(0), M, K, N, ptr(ws), ws.numel(), ptr(dc_scales),
                                                stream_ptr(dev)), "npi_linear_bwd_data_rank2")
     return da
 
@@ -1177,10 +1177,12 @@ def gat_pack_targets(a_dst, m, s, D, out=None):
     return t
 
 
-def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H: int = 1):
+def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H: int = 1,
+                              scales_out: Optional[torch.Tensor] = None):
     """By-SOURCE side: (out [n_rows, H C] = sum_q alpha_q dout[col q], dz [nnz_max, H] per entry and head) in one gather pass;
     ``dout2``: second part of the gathered table; ``tpack`` [n_cols H, 4] indexed by (column id, head); ``hrow`` /
-    ``a_src_rows``: features and source scores of the ROW nodes.  H in {1, 2, 4, 8} (npi_gat_backward_fused_heads)."""
+    ``a_src_rows``: features and source scores of the ROW nodes.  H in {1, 2, 4, 8} (npi_gat_backward_fused_heads).
+    ``scales_out`` ``[n_rows]`` (H C == 256): also the power-of-two scale of every row of ``out``, for the fp16 x 2 GEMM behind it."""
     dev = dout.device
     dout = _f32c(dout, "dout")
     if dout2 is not None:
@@ -1194,13 +1196,16 @@ def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_
         _check_out(out, side.n_rows, H * C, dout, "gat_backward_fused_packed")
     dz = torch.empty(max(side.nnz_max, 1) * H, dtype=torch.float32, device=dev)
     if side.nnz_max == 0:
+        if scales_out is not None:
+            scales_out.fill_(1.0)
         return out.zero_(), dz
     with _tag_events("gat_bwd_fused", dev):
-        check(load().npi_gat_backward_fused_heads(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
-                                                  side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
-                                                  dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
-                                                  out.stride(0), H, C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
-                                                  ptr(side.carry(H * C)), stream_ptr(dev)), "npi_gat_backward_fused_heads")
+        check(load().npi_gat_backward_fused_heads_ex2(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
+                                                      side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
+                                                      dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
+                                                      out.stride(0), H, C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
+                                                      ptr(side.carry(H * C)), ptr(scales_out), stream_ptr(dev)),
+              "npi_gat_backward_fused_heads")
     return out, dz
 
 
@@ -1314,11 +1319,16 @@ class _GatConvFn(torch.autograd.Function):
         if gat_fused_shape(H, C):
             # (a_dst, m, 1/s, D) of every (target, head) in one float4; alpha is recomputed per entry by the lane that owns it
             tpack = gat_pack_targets(a_dst, m, s, D)                           # [N H, 4]
-            dh, dz = gat_backward_fused_packed(sr, grad_out, None, hfeat, C, tpack, a_src, slope, H=H)
+            dh = torch.empty((N, H * C), dtype=torch.float32, device=dev)
+            rank2 = (sch.gat_rank2_epilogue and H == 1 and N >= sch.gat_rank2_min_rows and ctx.needs_input_grad[0]
+                     and x.dtype == torch.float32 and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight))
+            # dX's GEMM on two fp16 pieces per operand: the row scales of d hfeat from the pass that writes it (256 channels)
+            dh_scales = (torch.empty(N, dtype=torch.float32, device=dev)
+                         if rank2 and H * C == 256 and _f16x2(N, H * C, weight.size(0), x.dtype) else None)
+            dh, dz = gat_backward_fused_packed(sr, grad_out, None, hfeat, C, tpack, a_src, slope, out=dh, H=H, scales_out=dh_scales)
             dz = dz.view(-1, H)
-            if (sch.gat_rank2_epilogue and H == 1 and N >= sch.gat_rank2_min_rows and ctx.needs_input_grad[0]
-                    and x.dtype == torch.float32 and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight)):
-                return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, dz, db, C)
+            if rank2:
+                return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, dz, db, C, dh_scales)
             g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
             g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
@@ -1355,7 +1365,7 @@ class _GatConvFn(torch.autograd.Function):
         return dx, dw, datt, db, None, None, None, None, None
 
     @staticmethod
-    def _backward_rank2(ctx, x, weight, att2, dh, dz, db, C):
+    def _backward_rank2(ctx, x, weight, att2, dh, dz, db, C, dh_scales=None):
         """The tail of the one-head backward without ever forming d hfeat' = dh + g_dst (x) a1 + g_src (x) a2 (a1 = att[:C],
         a2 = att[C:]; g_dst / g_src = row sums of dz by target / by source).  With P = [x^T g_dst; x^T g_src] ([2, K], ONE
         pass over x):
@@ -1395,7 +1405,7 @@ class _GatConvFn(torch.autograd.Function):
         if not overlap:
             dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
         main.wait_event(have_g)
-        dx = linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1])
+        dx = linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1], dc_scales=dh_scales)
         if overlap:
             for t in (x, dz, tmap, g_src):
                 t.record_stream(side)

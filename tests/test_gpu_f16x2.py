@@ -137,3 +137,50 @@ def test_layers_on_fp16x2_projections_match_the_oracle(dev, kind):
     assert float((out.cpu().double() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
     assert float((dx.cpu().double() - x6.grad).abs().max()) <= 1e-4 * max(1.0, float(x6.grad.abs().max()))
     assert rel_max(dW, W6.grad) <= GRAD_REL and rel_max(db, b6.grad) <= GRAD_REL
+
+
+def test_gat_backward_projects_on_fp16x2_with_scales_from_the_fused_pass(dev):
+    """one-head GATConv, 256 channels: dX = d hfeat W^T (+ the rank-2 attention terms in the store epilogue) on the fp16 x 2 kernel,
+    the row scales of d hfeat written by the fused by-source pass (npi_gat_backward_fused_heads_ex2) -- bit-equal to a pass over
+    d hfeat; every gradient at the layer's bars against the oracle and within rounding of the bf16 x 3 run"""
+    from npi_gnn_amd.schedule import DEFAULT
+    N, E, Fi, C = 3000, 40_000, 128, 256
+    g = torch.Generator().manual_seed(8)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[0, : E // 4] = 5                                                      # a heavy SOURCE row: cut across items in the by-source pass
+    x = torch.randn(N, Fi, generator=g)
+    W = (torch.rand(Fi, C, generator=g) * 2 - 1) * (6.0 / (Fi + C)) ** 0.5
+    att = (torch.rand(1, 1, 2 * C, generator=g) * 2 - 1) * 0.3
+    b = torch.randn(C, generator=g) * 0.1
+    go = torch.randn(N, C, generator=g)
+    graph = npi.CSRGraph(ei.to(dev), N)
+    sch = DEFAULT.but(gat_rank2_min_rows=0)
+    res = {}
+    old = NF.F16X2_MIN_ROWS
+    try:
+        for rows in (None, 0):
+            NF.F16X2_MIN_ROWS = rows
+            xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+            out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=1, schedule=sch)
+            out.backward(go.to(dev))
+            res[rows] = (out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad)
+    finally:
+        NF.F16X2_MIN_ROWS = old
+    assert torch.equal(res[0][0], res[None][0])                              # the forward is untouched
+    assert not torch.equal(res[0][1], res[None][1]) and rel_max(res[0][1], res[None][1]) <= 2e-6
+    for k in (2, 3, 4):
+        assert torch.equal(res[0][k], res[None][k])                          # dW / d att / db do not pass through that GEMM
+    xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))
+    R.gat_conv(xr, ei, Wr, ar, br, heads=1).backward(go.double())
+    assert torch.allclose(res[0][1].cpu(), xr.grad.float(), atol=2e-4, rtol=1e-3)
+    # the scales the fused pass writes are those of its output
+    sr = graph.by_src
+    hfeat = (x @ W).to(dev)
+    a_dst, a_src = NF.gat_scores(hfeat, att.view(1, 2 * C).to(dev), 1, C)
+    m, s = NF.gat_softmax_stats(graph.by_dst, a_dst, a_src, 1, 0.2)
+    D = NF.gat_rowdot(go.to(dev), torch.zeros(N, C, device=dev), None, 1, C)
+    tpack = NF.gat_pack_targets(a_dst, m, s, D)
+    sc = torch.empty(N, device=dev)
+    dh, _ = NF.gat_backward_fused_packed(sr, go.to(dev), None, hfeat, C, tpack, a_src, 0.2, scales_out=sc)
+    dh0, _ = NF.gat_backward_fused_packed(sr, go.to(dev), None, hfeat, C, tpack, a_src, 0.2)
+    assert torch.equal(dh, dh0) and torch.equal(sc, NF.row_scales(dh))
