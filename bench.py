@@ -825,6 +825,9 @@ def main():
         go = go_full.to(dev).to(st)
         norm = NF.GCNNorm(graph) if args.conv == "gcn" else None
         c4.update(graph=graph, x=x, go=go, F=F, E=E)
+        # GATConv: the row scales of the input features, once (they do not change between steps, like the CSR): the projection x W then
+        # runs on two fp16 pieces per operand (functional.gat_conv(x_scales=))
+        gat_scales = NF.row_scales(x.detach()) if (args.conv == "gat" and x.dtype == torch.float32) else None
 
         def step():
             for p in conv.parameters():
@@ -832,6 +835,8 @@ def main():
             x.grad = None
             if norm is not None:
                 out = NF.gcn_conv(x, None, conv.weight, conv.bias, norm=norm)
+            elif gat_scales is not None:
+                out = conv(x, graph, x_scales=gat_scales)
             else:
                 out = conv(x, graph)
             out.backward(go)

@@ -302,6 +302,11 @@ int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N);
 int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C, int64_t ldc,
                           float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
                           void* stream);
+/* the same on the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) when a_scales is not NULL: the row scales of A -- npi_row_scales, ONCE for
+ * a feature matrix that does not change between steps, or the launch that wrote A (npi_gat_aggregate_fused_ex2) */
+int npi_linear_fwd_scores_ex2(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C, int64_t ldc,
+                              float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
+                              const float* a_scales, void* stream);
 /* dA = dC W^T + row0 (x) col0 + row1 (x) col1 (f32; row* are [M], col* [K] vectors): npi_linear_bwd_data_ex with a rank-2 term
  * added in the store epilogue of the matrix-core kernel -- no read-modify-write pass over dA or dC.  GATConv backward
  * (PyG 1.4.2 GATConv.message's `(x_i, x_j) * att` terms, reference call site src/classes.py:48-52 via BASELINE configs[4]): the
@@ -467,6 +472,13 @@ int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col, const int
                             int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
                             int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
                             float slope, const float* bias, int relu, float* m, float* s, float* carry, void* stream);
+/* the same, also writing the power-of-two scale of every finished row of `out` -- bias and ReLU applied, as stored -- (row_scales_out [N]
+ * or NULL; 256 channels): the a_scales of the NEXT layer's projection (npi_linear_fwd_scores_ex2 / npi_linear_fwd_ex2) */
+int npi_gat_aggregate_fused_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                                int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
+                                int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
+                                float negative_slope, const float* bias, int relu, float* m, float* s, float* carry,
+                                float* row_scales_out, void* stream);
 int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C);
 /* `F.relu(conv(x))` fused (npi_gat_aggregate_scores with relu != 0 applies the ReLU in the row epilogue): b is then the ReLU
  * OUTPUT, and this form first masks the incoming gradient, a' = a where b > 0 else 0 (threshold_backward), uses a' for D and

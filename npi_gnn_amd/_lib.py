@@ -68,6 +68,7 @@ PROTOTYPES = {
     "npi_hold_cus": (c_int, [c_int, _I, _P, _P]),
     "npi_linear_fwd_scores_supported": (c_int, [_I, _I, _I]),
     "npi_linear_fwd_scores": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "npi_linear_fwd_scores_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "npi_linear_bwd_data_rank2_supported": (c_int, [_I, _I, _I]),
     "npi_linear_bwd_data_rank2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "npi_linear_bwd_data_rank2_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
@@ -79,6 +80,8 @@ PROTOTYPES = {
     "npi_conv_bwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I,
                              c_int, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P]),
     "npi_gat_aggregate_fused": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, c_int, _P, _P, _P, _P]),
+    "npi_gat_aggregate_fused_ex2": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, c_int, _P, _P, _P, _P,
+                                            _P]),
     "npi_gat_scores": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),

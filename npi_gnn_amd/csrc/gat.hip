@@ -764,7 +764,19 @@ extern "C" int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col
                                        int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
                                        int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
                                        float slope, const float* bias, int relu, float* m, float* s, float* carry, void* stream_) {
+    return npi_gat_aggregate_fused_ex2(rowptr, col, rowidx, item_row, item_edges, N, nnz_max, x, ldx, x2, split, out, ldo, C, a_dst, att,
+                                       slope, bias, relu, m, s, carry, nullptr, stream_);
+}
+
+extern "C" int npi_gat_aggregate_fused_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
+                                           int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx,
+                                           const float* x2, int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst,
+                                           const float* att, float slope, const float* bias, int relu, float* m, float* s,
+                                           float* carry, float* row_scales_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(row_scales_out == nullptr || (C == 256 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16) == 0 &&
+                                              ((uintptr_t)out % 16) == 0 && (x2 == nullptr || ((uintptr_t)x2 % 16) == 0)),
+                "npi_gat_aggregate_fused_ex2: row_scales_out needs 256 channels and 16-byte aligned rows");
     NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_fused: bad split");
     NPI_REQUIRE(item_edges_ok(item_edges), "npi_gat_aggregate_fused: item_edges must be 64 or NPI_ITEM_EDGES (the value the CSR was built with)");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_aggregate_fused: bad size (one head of at most 256 channels, a multiple of 4)");
@@ -779,6 +791,7 @@ extern "C" int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col
     P.x2 = x2; P.split = (int)split;
     P.carry = carry; P.bias = bias;
     P.H = 1; P.C = (int)C; P.a_dst = a_dst; P.att = att; P.slope = slope; P.m_out = m; P.s_out = s; P.relu = relu ? 1 : 0;
+    P.scale_out = row_scales_out;                // the scales of the rows as they are stored: bias and ReLU applied
     return segsum_run(P, W_GAT_DST_FUSED, 0, nnz_max, NPI_F32, stream);
 }
 

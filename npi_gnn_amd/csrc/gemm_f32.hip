@@ -2263,6 +2263,14 @@ extern "C" int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N) 
 extern "C" int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C,
                                      int64_t ldc, float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace,
                                      int64_t workspace_bytes, void* stream_) {
+    return npi_linear_fwd_scores_ex2(A, lda, W, ldw, att, C, ldc, sc0, sc1, M, K, N, workspace, workspace_bytes, nullptr, stream_);
+}
+
+// a_scales != NULL: the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) with the row scales of A (npi_row_scales -- once, for a feature
+// matrix that does not change between steps -- or the launch that wrote A: npi_gat_aggregate_fused_ex2)
+extern "C" int npi_linear_fwd_scores_ex2(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C,
+                                         int64_t ldc, float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace,
+                                         int64_t workspace_bytes, const float* a_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(npi_linear_fwd_scores_supported(M, K, N), "npi_linear_fwd_scores: shape outside the split kernel's one-column-"
                 "tile coverage (M >= 128, K >= 64, K % 32 == 0, N = 128 or 256)");
@@ -2276,7 +2284,7 @@ extern "C" int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W
     }
     GemmArgs a{A, lda, W, ldw, C, ldc, (int)M, (int)N, (int)K, (int)align_up(K, BK), 0, 0, 0,
                Epilogue{nullptr, nullptr, 0, nullptr, nullptr, nullptr, att, att + N, sc0, sc1}};
-    const int rc = launch_gemm<0, 0>(true, a, 1, stream, NPI_F32, NPI_F32, 1, workspace);
+    const int rc = launch_gemm<0, 0>(true, a, 1, stream, NPI_F32, NPI_F32, 1, workspace, 0, false, 0, a_scales);
     return rc != NPI_OK ? rc : check_launch("npi_linear_fwd_scores");
 }
 // dA = dC W^T + row0 (x) col0 + row1 (x) col1, the rank-2 term added in the split kernel's store epilogue (GATConv backward:

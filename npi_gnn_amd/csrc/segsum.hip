@@ -1297,7 +1297,7 @@ static int dispatch_nch(const SegParams& P, int wmode, int mean, hipStream_t str
 #define NPI_SEG_CASE(NC)                                                                    \
     case NC:                                                                                \
         if constexpr (VEC == 4 && NC == 1 && sizeof(T) == 4) {                              \
-            if (exact && P.scale_out != nullptr && (wmode <= W_ARRAY || is_fused_mode(wmode)))                        \
+            if (exact && P.scale_out != nullptr && (wmode <= W_ARRAY || is_fused_mode(wmode) || wmode == W_GAT_DST_FUSED)) \
                 return launch_segsum<T, VEC, NC, 2>(P, wmode, mean, stream);                \
         }                                                                                   \
         if constexpr (VEC == 4) { if (exact) return launch_segsum<T, VEC, NC, 1>(P, wmode, mean, stream); } \

@@ -337,7 +337,7 @@ def linear_fwd_scores_ok(a: torch.Tensor, weight: torch.Tensor) -> bool:
             and bool(load().npi_linear_fwd_scores_supported(a.size(0), weight.size(0), weight.size(1))))
 
 
-def linear_fwd_scores(a: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor):
+def linear_fwd_scores(a: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor, a_scales: Optional[torch.Tensor] = None):
     """``(h, a_dst, a_src)``: ``h = a @ weight`` and the row dots ``h @ att[:N]``, ``h @ att[N:]`` taken from the accumulators in
     the GEMM's store epilogue (``npi_linear_fwd_scores``; one head, ``att2`` holds ``2 N`` values)."""
     dev = require_gpu(a, weight, att2)
@@ -351,8 +351,8 @@ def linear_fwd_scores(a: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor)
     a_src = torch.empty((M, 1), dtype=torch.float32, device=dev)
     ws = _gemm_workspace(K, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
-        check(load().npi_linear_fwd_scores(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(att2), ptr(h), h.stride(0),
-                                           ptr(a_dst), ptr(a_src), M, K, N, ptr(ws), ws.numel(), stream_ptr(dev)),
+        check(load().npi_linear_fwd_scores_ex2(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(att2), ptr(h), h.stride(0),
+                                               ptr(a_dst), ptr(a_src), M, K, N, ptr(ws), ws.numel(), ptr(a_scales), stream_ptr(dev)),
               "npi_linear_fwd_scores")
     return h, a_dst, a_src
 
@@ -1137,11 +1137,13 @@ def gat_aggregate_scores(side: CSRSide, table, table2, C, scores, m, s, bias=Non
     return out
 
 
-def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, att2, slope, bias=None, out=None, relu: bool = False):
+def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, att2, slope, bias=None, out=None, relu: bool = False,
+                        scales_out: Optional[torch.Tensor] = None):
     """One head of at most 256 channels: ``(out, m, s)`` -- the forward aggregation together with the softmax statistics of every
     row, in ONE launch (``npi_gat_aggregate_fused``): an online softmax whose scores' source half is recomputed from the gathered
     rows (``att2``: the layer's ``[1, 2C]`` attention vector) -- no statistics pass, no per-entry score array, no gather of
-    ``a_src``.  ``a_dst`` ``[n_rows]``; ``table2``: second part of a two-part table."""
+    ``a_src``.  ``a_dst`` ``[n_rows]``; ``table2``: second part of a two-part table.  ``scales_out`` ``[n_rows]`` (256 channels): also
+    the power-of-two scale of every stored row (bias and ReLU applied) -- the ``x_scales`` of the next layer's projection."""
     dev = table.device
     table = _f32c(table, "table")
     if table2 is not None:
@@ -1155,11 +1157,11 @@ def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, att2, slope, bia
     m = torch.empty((side.n_rows, 1), dtype=torch.float32, device=dev)
     s = torch.empty((side.n_rows, 1), dtype=torch.float32, device=dev)
     with _tag_events("gat_fwd_aggregate", dev):
-        check(load().npi_gat_aggregate_fused(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
-                                             side.n_rows, side.nnz_max, ptr(table), table.stride(0), ptr(table2),
-                                             table.size(0) if table2 is not None else 0, ptr(out), out.stride(0), C,
-                                             ptr(a_dst.contiguous()), ptr(_f32c(att2.reshape(-1), "att")), float(slope), ptr(bias),
-                                             1 if relu else 0, ptr(m), ptr(s), ptr(side.carry(C)), stream_ptr(dev)),
+        check(load().npi_gat_aggregate_fused_ex2(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
+                                                 side.n_rows, side.nnz_max, ptr(table), table.stride(0), ptr(table2),
+                                                 table.size(0) if table2 is not None else 0, ptr(out), out.stride(0), C,
+                                                 ptr(a_dst.contiguous()), ptr(_f32c(att2.reshape(-1), "att")), float(slope), ptr(bias),
+                                                 1 if relu else 0, ptr(m), ptr(s), ptr(side.carry(C)), ptr(scales_out), stream_ptr(dev)),
               "npi_gat_aggregate_fused")
     return out, m, s
 
@@ -1266,20 +1268,26 @@ class _GatConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, att, bias, graph: CSRGraph, heads: int, slope: float, relu: bool = False,
-                sch: Schedule = DEFAULT):
+                sch: Schedule = DEFAULT, x_scales: Optional[torch.Tensor] = None, want_scales: bool = False):
         H = int(heads)
         C = weight.size(1) // H
         att2 = _f32c(att.reshape(H, 2 * C), "att")
         d = graph.by_dst
+        # x_scales (row_scales(x): computed once for a feature matrix that does not change between steps, or handed on by the
+        # layer in front): the projection on two fp16 pieces per operand
+        xs = x_scales if (x_scales is not None and _f16x2(x.size(0), weight.size(0), weight.size(1), x.dtype)) else None
         if H == 1 and sch.gat_scores_epilogue and linear_fwd_scores_ok(x, weight):
-            hfeat, a_dst, a_src = linear_fwd_scores(x, weight, att2)        # x @ W, both scores in its store epilogue
+            hfeat, a_dst, a_src = linear_fwd_scores(x, weight, att2, a_scales=xs)   # x @ W, both scores in its store epilogue
         else:
-            hfeat = linear_fwd(x, weight)                                    # x @ W
+            hfeat = linear_fwd(x, weight, a_scales=xs)                       # x @ W
             a_dst, a_src = gat_scores(hfeat, att2, H, C)
+        out_scales = None
         if H == 1 and C % 4 == 0 and C <= 256 and d.nnz_max > 0 and sch.gat_fused_stats:
             # the statistics inside the aggregation launch: every item computes its entries' scores, rows cut by an item boundary
             # merge their parts' (max, sum exp) where cut rows are resolved (round 5: one pass over col / rowidx and a launch less)
-            out, m, s = gat_aggregate_fused(d, hfeat, None, C, a_dst, att2, slope, bias=bias, relu=relu)
+            if want_scales and C == 256:
+                out_scales = torch.empty(d.n_rows, dtype=torch.float32, device=x.device)
+            out, m, s = gat_aggregate_fused(d, hfeat, None, C, a_dst, att2, slope, bias=bias, relu=relu, scales_out=out_scales)
         elif H == 1 and C % 4 == 0 and d.nnz_max > 0:
             # the statistics pass leaves the score of every entry; the aggregation reads it back (one coalesced load per
             # 64 entries) instead of gathering a_src[j] per entry and redoing the leaky_relu
@@ -1297,10 +1305,15 @@ class _GatConvFn(torch.autograd.Function):
         ctx.sch = sch
         ctx.save_for_backward(x, weight, att2, hfeat, a_dst, a_src, m, s, out,
                               bias if bias is not None else torch.empty(0, device=x.device))
+        if want_scales:
+            if out_scales is None:                                           # (a shape whose aggregation cannot write them)
+                out_scales = torch.empty(0, dtype=torch.float32, device=x.device)
+            ctx.mark_non_differentiable(out_scales)
+            return out, out_scales
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _grad_scales=None):
         x, weight, att2, hfeat, a_dst, a_src, m, s, out, bias = ctx.saved_tensors
         graph: CSRGraph = ctx.graph
         H, C, slope, sch = ctx.H, ctx.C, ctx.slope, ctx.sch
@@ -1362,7 +1375,7 @@ class _GatConvFn(torch.autograd.Function):
         dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
         if overlap:
             main.wait_stream(side)
-        return dx, dw, datt, db, None, None, None, None, None
+        return dx, dw, datt, db, None, None, None, None, None, None, None
 
     @staticmethod
     def _backward_rank2(ctx, x, weight, att2, dh, dz, db, C, dh_scales=None):
@@ -1416,7 +1429,7 @@ class _GatConvFn(torch.autograd.Function):
         datt = gat_rank2_tail(P, weight, A, dw, ctx.needs_input_grad[2])
         if datt is not None:
             datt = datt.view(1, 1, 2 * C)
-        return dx, dw, datt, db, None, None, None, None, None
+        return dx, dw, datt, db, None, None, None, None, None, None, None
 
 
 def _valid_entries(side: CSRSide) -> torch.Tensor:
@@ -1508,22 +1521,31 @@ def gat_dropout_keep(graph: CSRGraph, heads: int, p: float) -> torch.Tensor:
 def gat_conv(x: torch.Tensor, edge_index, weight: torch.Tensor, att: torch.Tensor,
              bias: Optional[torch.Tensor] = None, heads: int = 1, concat: bool = True,
              negative_slope: float = 0.2, relu: bool = False, schedule: Schedule = DEFAULT,
-             keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+             keep: Optional[torch.Tensor] = None, x_scales: Optional[torch.Tensor] = None, return_scales: bool = False):
     """PyG 1.4.2 ``GATConv.forward`` on MI355X; ``att`` is ``[1, H, 2C]``.  ``relu=True`` (an extension, as in
     ``sage_conv``): ``F.relu(conv(x, edge_index))`` with the ReLU in the aggregation's row epilogue and its backward mask in the
     pass that computes the softmax term -- one head; other shapes apply it as a separate pass.  ``keep``: attention dropout in
-    training mode (``_GatDropoutFn``; ``gat_dropout_keep`` draws one) -- the composed, slower variant of the layer."""
-    require_gpu(x, weight, att, bias)
+    training mode (``_GatDropoutFn``; ``gat_dropout_keep`` draws one) -- the composed, slower variant of the layer.
+    ``x_scales``: ``row_scales(x)`` -- the projection ``x @ W`` then runs on two fp16 pieces per operand (large graphs; EXPERIMENTS
+    A34).  Computed ONCE for a feature matrix that does not change between steps, or taken from the layer in front:
+    ``return_scales=True`` returns ``(out, out_scales)`` with the scales of the output's rows written by the aggregation launch
+    itself (one head of 256 channels; otherwise ``out_scales`` is None) -- what the next layer takes as its ``x_scales``."""
+    require_gpu(x, weight, att, bias, x_scales)
     graph = as_graph(edge_index, x.size(0))
     if keep is not None:
         out = _GatDropoutFn.apply(x, weight, att, bias if concat else None, graph, heads, negative_slope, keep)
         if not concat:
             out = out.view(x.size(0), heads, -1).mean(dim=1)
             out = out + bias if bias is not None else out
-        return torch.relu(out) if relu else out
+        out = torch.relu(out) if relu else out
+        return (out, None) if return_scales else out
     if concat:
-        return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope, relu, schedule)
-    out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope, False, schedule)
+        if return_scales:
+            out, sc = _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope, relu, schedule, x_scales, True)
+            return out, (sc if sc.numel() else None)
+        return _GatConvFn.apply(x, weight, att, bias, graph, heads, negative_slope, relu, schedule, x_scales, False)
+    out = _GatConvFn.apply(x, weight, att, None, graph, heads, negative_slope, False, schedule, x_scales, False)
     out = out.view(x.size(0), heads, -1).mean(dim=1)          # head average (concat=False)
     out = out + bias if bias is not None else out
-    return torch.relu(out) if relu else out
+    out = torch.relu(out) if relu else out
+    return (out, None) if return_scales else out

@@ -117,8 +117,10 @@ class GATConv(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
-    def forward(self, x, edge_index=None, size=None, *, relu: bool = False):
-        """``relu=True`` (an extension of the PyG signature, as in ``SAGEConv``): ``F.relu(conv(x, edge_index))`` fused."""
+    def forward(self, x, edge_index=None, size=None, *, relu: bool = False, x_scales=None, return_scales: bool = False):
+        """``relu=True`` (an extension of the PyG signature, as in ``SAGEConv``): ``F.relu(conv(x, edge_index))`` fused.
+        ``x_scales`` / ``return_scales`` (extensions): ``functional.row_scales(x)`` of a feature matrix that does not change between
+        steps, or the ``out_scales`` of the layer in front -- ``functional.gat_conv``."""
         if size is not None:
             raise NotImplementedError("GATConv: bipartite `size` is not implemented")
         gb = None
@@ -133,8 +135,11 @@ class GATConv(nn.Module):
             edge_index = as_graph(edge_index, x.size(0))
             keep = F_.gat_dropout_keep(edge_index, self.heads, self.dropout)
         out = F_.gat_conv(x, edge_index, self.weight, self.att, self.bias, self.heads, self.concat,
-                          self.negative_slope, relu=relu, schedule=self.schedule, keep=keep)
-        return gb.with_x(out) if gb is not None else out
+                          self.negative_slope, relu=relu, schedule=self.schedule, keep=keep, x_scales=x_scales,
+                          return_scales=return_scales)
+        if gb is not None:
+            return (gb.with_x(out[0]), out[1]) if return_scales else gb.with_x(out)
+        return out
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"

@@ -184,3 +184,50 @@ def test_gat_backward_projects_on_fp16x2_with_scales_from_the_fused_pass(dev):
     dh, _ = NF.gat_backward_fused_packed(sr, go.to(dev), None, hfeat, C, tpack, a_src, 0.2, scales_out=sc)
     dh0, _ = NF.gat_backward_fused_packed(sr, go.to(dev), None, hfeat, C, tpack, a_src, 0.2)
     assert torch.equal(dh, dh0) and torch.equal(sc, NF.row_scales(dh))
+
+
+def test_gat_stack_hands_row_scales_from_layer_to_layer(dev):
+    """gat_conv(x_scales=, return_scales=True): the scales of the input features computed once, every layer's projection x W on the
+    fp16 x 2 kernel (row-dot epilogue), the scales of a layer's output -- bias and ReLU applied -- written by its aggregation launch
+    and bit-equal to a pass over the output; outputs and gradients of the 2-layer stack within rounding of the plain run and at
+    the layers' bars against the oracle"""
+    N, E, F = 4000, 50_000, 256
+    g = torch.Generator().manual_seed(9)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, : E // 4] = 3
+    x = torch.randn(N, F, generator=g)
+    Ws = [(torch.rand(F, F, generator=g) * 2 - 1) * (6.0 / (2 * F)) ** 0.5 for _ in range(2)]
+    atts = [(torch.rand(1, 1, 2 * F, generator=g) * 2 - 1) * 0.3 for _ in range(2)]
+    bs = [torch.randn(F, generator=g) * 0.1 for _ in range(2)]
+    go = torch.randn(N, F, generator=g)
+    graph = npi.CSRGraph(ei.to(dev), N)
+    res = {}
+    old = NF.F16X2_MIN_ROWS
+    try:
+        for mode in ("plain", "scales"):
+            NF.F16X2_MIN_ROWS = None if mode == "plain" else 0
+            P = [t.to(dev).requires_grad_(True) for t in Ws + atts + bs]
+            xd = x.to(dev).requires_grad_(True)
+            h, hs = xd, (NF.row_scales(xd.detach()) if mode == "scales" else None)
+            for k in range(2):
+                h, hs = npi.gat_conv(h, graph, P[k], P[2 + k], P[4 + k], heads=1, relu=True, x_scales=hs, return_scales=True)
+                if mode == "scales":
+                    assert hs is not None and torch.equal(hs, NF.row_scales(h.detach()))
+            h.backward(go.to(dev))
+            res[mode] = [h.detach(), xd.grad] + [p.grad for p in P]
+    finally:
+        NF.F16X2_MIN_ROWS = old
+    for a, b in zip(res["scales"], res["plain"]):
+        assert rel_max(a, b) <= 5e-6
+    assert not torch.equal(res["scales"][0], res["plain"][0])
+    P6 = [t.clone().double().requires_grad_(True) for t in Ws + atts + bs]
+    x6 = x.clone().double().requires_grad_(True)
+    h = x6
+    for k in range(2):
+        h = torch.relu(R.gat_conv(h, ei, P6[k], P6[2 + k], P6[4 + k], heads=1))
+    h.backward(go.double())
+    out, dx = res["scales"][0], res["scales"][1]
+    assert float((out.cpu().double() - h.detach()).abs().max()) <= 1e-4 * max(1.0, float(h.abs().max()))
+    assert float((dx.cpu().double() - x6.grad).abs().max()) <= 2e-4 * max(1.0, float(x6.grad.abs().max()))
+    for got, want in zip(res["scales"][2:], P6):
+        assert rel_max(got, want.grad) <= 3 * GRAD_REL

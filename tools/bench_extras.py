@@ -72,19 +72,23 @@ def _stack_step(kind, weights, x, graph, dtype=torch.float32, norm=None, att=Non
     params = [(W.to(dev).to(dtype).requires_grad_(True), b.to(dev).to(dtype).requires_grad_(True)) for W, b in weights]
     atts = [a.to(dev).requires_grad_(True) for a in att] if att else None
     xin = x.to(dtype).requires_grad_(True)
+    # GATConv: the row scales of the INPUT FEATURES, computed once (the feature matrix of a full-batch run does not change between
+    # steps, like the CSR) -- the first layer's projection then runs on two fp16 pieces per operand; every layer hands the scales of
+    # its output rows (written by its aggregation launch) to the next one
+    x_scales = NF.row_scales(xin.detach()) if (kind == "gat" and dtype == torch.float32 and xin.size(1) % 4 == 0) else None
 
     def step():
         for W, b in params:
             W.grad = b.grad = None
         xin.grad = None
-        h = xin
+        h, hs = xin, x_scales
         for k, (W, b) in enumerate(params):
             if kind == "sage":
                 h = npi.sage_conv(h, graph, W, b)
             elif kind == "gcn":
                 h = NF.gcn_conv(h, None, W, b, norm=norm)
             else:
-                h = npi.gat_conv(h, graph, W, atts[k], b, heads=1, relu=True)      # F.relu(conv(h)), fused
+                h, hs = npi.gat_conv(h, graph, W, atts[k], b, heads=1, relu=True, x_scales=hs, return_scales=True)   # F.relu(conv(h)), fused
                 continue
             h = torch.relu(h)
         if go is None:
@@ -379,7 +383,8 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
             for p in conv.parameters():
                 p.grad = None
             xx.grad = None
-            conv(xx, g4).backward(go4)
+            conv(xx, g4, x_scales=xs4).backward(go4)
+        xs4 = NF.row_scales(xx.detach())        # of the input features, once: they do not change between steps (like the CSR)
         ms = _timeit(step, 10, 3)
         tags = {}
         NF._PROFILE_TAGS = tags
