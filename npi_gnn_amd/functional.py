@@ -222,6 +222,13 @@ def f16x2_shape(M: int, K: int, N: int) -> bool:
     return M >= 128 and K % 32 == 0 and N % 128 == 0
 
 
+def _check_scales(scales: Optional[torch.Tensor], rows: int, what: str) -> None:
+    """the kernels read one scale per row of the left operand: anything else would be an out-of-bounds device read"""
+    if scales is not None and (scales.dtype != torch.float32 or scales.dim() != 1 or scales.numel() != rows or not scales.is_contiguous()):
+        raise ValueError(f"{what}: the row scales must be a contiguous float32 vector with one element per row ({rows}), "
+                         f"got {tuple(scales.shape)} {scales.dtype}")
+
+
 def row_scales(a: torch.Tensor) -> torch.Tensor:
     """``[M]`` power-of-two scales of the rows of ``a`` (``npi_row_scales``): the ``a_scales`` of ``linear_fwd`` /
     ``linear_bwd_data`` under ``NPI_GEMM_SPLIT_F16X2`` (two fp16 pieces per operand, three matrix products instead of six)"""
@@ -279,6 +286,7 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         out = torch.empty((M, N), dtype=a.dtype, device=dev)
     elif out.shape != (M, N) or out.dtype != a.dtype or out.stride(1) != 1 or out.device != a.device:
         raise ValueError(f"linear_fwd: out must be [{M}, {N}] {a.dtype} with unit column stride on the operands' device")
+    _check_scales(a_scales, M, "linear_fwd")
     if a_scales is not None and (a.dtype != torch.float32 or Ka != K or fl & NPI_GEMM_EXACT_F32):
         a_scales = None                                         # (storage / flags the fp16 x 2 kernel does not serve)
     if a_scales is not None:
@@ -313,6 +321,7 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
             raise ValueError(f"linear_bwd_data: out must be [{M}, {K}] {dc.dtype} with unit column stride on the operands' device")
         da = out
     fl = (GEMM_FLAGS if flags is None else flags) | NPI_GEMM_RESERVE_CUS(reserve_cus)
+    _check_scales(dc_scales, M, "linear_bwd_data")
     if dc_scales is not None and (dc.dtype != torch.float32 or fl & NPI_GEMM_EXACT_F32):
         dc_scales = None
     if dc_scales is not None:
@@ -346,6 +355,7 @@ def linear_fwd_scores(a: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor,
     att2 = _f32c(att2.reshape(-1), "att")
     if att2.numel() != 2 * N:
         raise ValueError("linear_fwd_scores: att must hold 2 N values")
+    _check_scales(a_scales, M, "linear_fwd_scores")
     h = torch.empty((M, N), dtype=torch.float32, device=dev)
     a_dst = torch.empty((M, 1), dtype=torch.float32, device=dev)
     a_src = torch.empty((M, 1), dtype=torch.float32, device=dev)
@@ -375,6 +385,7 @@ def linear_bwd_data_rank2(dc: torch.Tensor, weight: torch.Tensor, row0: torch.Te
     if row0.numel() != M or row1.numel() != M or col0.numel() != K or col1.numel() != K:
         raise ValueError("linear_bwd_data_rank2: row vectors must have M entries, column vectors K")
     row0, row1, col0, col1 = (_f32c(t.reshape(-1), "rank-2 vector") for t in (row0, row1, col0, col1))
+    _check_scales(dc_scales, M, "linear_bwd_data_rank2")
     da = torch.empty((M, K), dtype=torch.float32, device=dev)
     ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
@@ -1275,6 +1286,7 @@ class _GatConvFn(torch.autograd.Function):
         d = graph.by_dst
         # x_scales (row_scales(x): computed once for a feature matrix that does not change between steps, or handed on by the
         # layer in front): the projection on two fp16 pieces per operand
+        _check_scales(x_scales, x.size(0), "gat_conv(x_scales=)")
         xs = x_scales if (x_scales is not None and _f16x2(x.size(0), weight.size(0), weight.size(1), x.dtype)) else None
         if H == 1 and sch.gat_scores_epilogue and linear_fwd_scores_ok(x, weight):
             hfeat, a_dst, a_src = linear_fwd_scores(x, weight, att2, a_scales=xs)   # x @ W, both scores in its store epilogue

@@ -231,3 +231,19 @@ def test_gat_stack_hands_row_scales_from_layer_to_layer(dev):
     assert float((dx.cpu().double() - x6.grad).abs().max()) <= 2e-4 * max(1.0, float(x6.grad.abs().max()))
     for got, want in zip(res["scales"][2:], P6):
         assert rel_max(got, want.grad) <= 3 * GRAD_REL
+
+
+def test_row_scales_of_the_wrong_shape_are_refused_before_any_launch(dev):
+    """one scale per row of the left operand: a shorter vector would be an out-of-bounds device read"""
+    a = torch.randn(512, 128, device=dev)
+    w = torch.randn(128, 128, device=dev)
+    for bad in (torch.ones(511, device=dev), torch.ones(512, 1, device=dev), torch.ones(512, device=dev, dtype=torch.float64),
+                torch.ones(1024, device=dev)[::2]):
+        with pytest.raises(ValueError):
+            NF.linear_fwd(a, w, a_scales=bad)
+        with pytest.raises(ValueError):
+            NF.linear_bwd_data(a, w.t().contiguous(), dc_scales=bad)
+    conv = npi.GATConv(128, 128).to(dev)
+    ei = torch.randint(0, 512, (2, 4000), device=dev)
+    with pytest.raises(ValueError):
+        conv(a, ei, x_scales=torch.ones(100, device=dev))
