@@ -1062,7 +1062,7 @@ gemm_split_ws_kernel(SplitArgs a) {
     constexpr bool UV = R2 || SC;                     // two column vectors kept in LDS beside the bias
     constexpr int TM = 2;
     constexpr int NPL = F16 ? 2 : 3;                  // plane images per operand: bf16 x 3, or fp16 x 2 (F16)
-    static_assert(!F16 || (NPI_SPLIT_A16 == 0 && (NPI_WS_PROBE & ~(16 | 4)) == 0), "the fp16 x 2 variant has the cycle stamps and the no-store build only");
+    static_assert(!F16 || (NPI_SPLIT_A16 == 0 && (NPI_WS_PROBE & ~(16 | 8 | 4)) == 0), "the fp16 x 2 variant has the cycle stamps, the no-LDS-store and the no-C-store builds only");
     constexpr int BN = 64 * TN;                       // 128 or 256 output columns per tile
     constexpr int APL = 128 * 32, BPL = BN * 32;      // bytes of one A / B plane image
     constexpr int BUF = NPL * APL + NPL * BPL;        // one stage: A planes 0.., B planes 0..
