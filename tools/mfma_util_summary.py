@@ -23,7 +23,7 @@ for (name, grid), c in sorted(agg.items()):
     ns = sum(c["ns"]) / len(c["ns"])
     out[f"{name} grid={grid}"] = {"launches": n, "mfma_busy_cycles_all_simds": busy, "elapsed_cycles": cyc, "avg_ns_under_pmc": ns,
                                   "clock_ghz": cyc / ns, "mfma_util": busy / (cyc * 1024)}
-json.dump({"what": "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1,024 SIMDs); tools/f16x2_probe.py under "
+json.dump({"what": "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1,024 SIMDs); tools/gemm_pair.py under "
                    "rocprofv3 --pmc (durations under the counters are longer than in a plain run)", "kernels": out}, open(sys.argv[2], "w"), indent=1)
 for k, v in out.items():
     print(f"{k}: util {v['mfma_util']:.3f}  clock {v['clock_ghz']:.2f} GHz  {v['avg_ns_under_pmc'] / 1e3:.0f} us  ({v['launches']} launches)")
