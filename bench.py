@@ -98,6 +98,8 @@ def parse(argv=None):
                     help="N=1: do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure the aggregation "
                          "kernel's HBM-side bytes in THIS run; roofline.traffic then comes from profiles/pmc_traffic.json (offline)")
     ap.add_argument("--setup-steps", type=int, default=SETUP_STEPS, help="untimed steps before the warm-up")
+    ap.add_argument("--detail-file", default=DETAIL_FILE,
+                    help="where the full record goes ('' = nowhere; the live PMC child passes write none)")
     ap.add_argument("--rank-check", action="store_true",
                     help="every rank prints {rank, world} and exits before any GPU call (launcher test)")
     return ap.parse_args(argv)
@@ -258,6 +260,17 @@ def gat_bytes(E: int, N: int, F: int, H: int = 1) -> dict:
             "gat_bwd_fused": nnz * (4 * F + 4 + 4 + 16 + 4) + N * (8 * F + 8)}
 
 
+def roofline_rates(alg_bytes, traffic, avg_ms):
+    """(achieved, achieved_traffic, frac_algorithmic, frac_traffic) of one aggregation launch: GB/s of SURVEY 8(d)'s algorithmic
+    bytes and of the PMC (L2-miss) bytes over the same live duration, and both as fractions of the HBM peak.  The roofline object
+    carries all four, so that `achieved / peak == frac_algorithmic` and `achieved_traffic / peak == frac_traffic == frac`."""
+    if not avg_ms:
+        return 0.0, None, 0.0, None
+    ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+    ach_t = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None
+    return ach, ach_t, ach / HBM_PEAK_GBS, (ach_t / HBM_PEAK_GBS if ach_t is not None else None)
+
+
 def agg_roofline(events, alg_bytes, traffic, kernel, traffic_source):
     """roofline block of one aggregation kernel from its live event durations"""
     ms = [a.elapsed_time(b) for a, b in events]
@@ -399,6 +412,15 @@ FETCH_SCALE = 1.992            # gfx950: FETCH_SIZE under-reports the gathers' w
                                # calibrated in round 1, tools/pmc_calibrate.py, and confirmed by the uniform control: PMC = 1.00 x algorithmic)
 
 
+def under_profiler() -> bool:
+    """is this process itself running under rocprofv3 / rocprof (its tool library preloaded, or its environment set)?  The live PMC
+    child passes are then skipped: nested counter collection conflicts with the parent's, and the wall time would be wasted"""
+    env = os.environ
+    if any("rocprof" in env.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")):
+        return True
+    return any(k.startswith(("ROCPROF_", "ROCPROFILER_", "ROCP_")) for k in env)
+
+
 def live_pmc(args, timeout_s: float = 300.0, control: bool = False):
     """HBM-side bytes per launch of the headline aggregation kernel measured IN THIS RUN: two child processes, each this very
     file under `rocprofv3 --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in passes of their own, nothing else traced, as the guide
@@ -414,7 +436,7 @@ def live_pmc(args, timeout_s: float = 300.0, control: bool = False):
         return {"error": "rocprofv3 not found"}
     tmp = tempfile.mkdtemp(prefix="npi_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--setup-steps", "2", "--no-cpu-baseline",
-             "--no-configs", "--no-control", "--virtual-world", "0", "--no-parity", "--no-live-pmc", "--nodes", str(args.nodes),
+             "--no-configs", "--no-control", "--virtual-world", "0", "--no-parity", "--no-live-pmc", "--detail-file", "", "--nodes", str(args.nodes),
              "--edges", str(args.edges), "--hidden", str(args.hidden), "--graph-seed", str(args.graph_seed)]
     if args.plain_csr:
         child.append("--plain-csr")
@@ -682,7 +704,11 @@ def compact_line(res: dict) -> str:
                           "against": _short(p.get("against"), 260), "error": _short(p.get("error"), 200)}
     r = res.get("roofline") or {}
     roof = {k: _num(r.get(k), 6) for k in ("bound", "kernel", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
-                                           "achieved", "peak", "unit", "frac", "frac_algorithmic", "frac_traffic", "traffic")}
+                                           "achieved", "achieved_traffic", "peak", "unit", "frac", "frac_algorithmic", "frac_traffic",
+                                           "traffic", "fwd_launch_ms", "bwd_launch_ms")}
+    roof["frac_basis"] = ("achieved_traffic/peak; traffic = L2-miss bytes by PMC (hits in the 256 MiB memory-side cache included): an upper bound on DRAM "
+                          "utilisation, control_uniform is the cache-free figure" if r.get("frac_traffic") is not None else
+                          "achieved/peak (algorithmic bytes; no PMC traffic on file)")
     roof["kernel"] = _short(roof.get("kernel"), 120)
     roof["traffic_source"] = _short(r.get("traffic_source"), 230)
     cu = r.get("control_uniform")
@@ -724,14 +750,17 @@ def compact_line(res: dict) -> str:
     return s
 
 
-def emit(res: dict) -> None:
+def emit(res: dict, detail_file: str = DETAIL_FILE) -> None:
     """detail file first (best effort), then the compact line as the last thing on stdout"""
-    try:
-        with open(DETAIL_FILE, "w") as f:
-            json.dump(res, f, indent=1, default=str)
-        res["detail"] = DETAIL_FILE
-    except OSError as e:
-        res["detail"] = f"not written: {e}"[:120]
+    if detail_file:
+        try:
+            with open(detail_file, "w") as f:
+                json.dump(res, f, indent=1, default=str)
+            res["detail"] = detail_file
+        except OSError as e:
+            res["detail"] = f"not written: {e}"[:120]
+    else:
+        res["detail"] = None
     sys.stdout.flush()
     print(compact_line(res), flush=True)
 
@@ -761,7 +790,7 @@ def main():
     attempt = int(os.environ.get("NPI_BENCH_ATTEMPT", "0")) if is_worker else 0
     pmc_live = pmc_live_control = None
     if (not sharded and not args.no_live_pmc and not args.control_only and args.conv == "sage" and args.storage == "f32"
-            and not args.capture):
+            and not args.capture and not under_profiler()):
         pmc_live = live_pmc(args)                               # child processes; this one has made no GPU call yet
         if not args.no_control and pmc_live.get("bytes_per_launch"):
             pmc_live_control = live_pmc(args, control=True)
@@ -1025,7 +1054,6 @@ def main():
     seg_ms = [s.elapsed_time(e) for s, e in seg_events]
     seg_avg_ms = sum(seg_ms) / max(len(seg_ms), 1)
     alg_bytes = sum(seg_launch_bytes) / len(seg_launch_bytes)          # average over the launches of one direction
-    achieved = alg_bytes / (seg_avg_ms * 1e-3) / 1e9 if seg_ms else 0.0
     pmc = pmc_traffic()
     traffic = None
     traffic_live = bool(pmc_live and pmc_live.get("bytes_per_launch"))
@@ -1033,8 +1061,7 @@ def main():
         traffic = pmc_live["bytes_per_launch"]
     elif not sharded and args.conv == "sage" and (N, E, F) == (1_000_000, 20_000_000, 256) and not pmc.get("stale"):
         traffic = pmc.get("segsum_kernel_bytes_per_launch" if args.storage == "f32" else "bf16_segsum_bytes_per_launch")
-    frac_alg = achieved / HBM_PEAK_GBS
-    frac_traffic = (traffic / (seg_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and seg_ms) else None
+    achieved, ach_traffic, frac_alg, frac_traffic = roofline_rates(alg_bytes, traffic, seg_avg_ms if seg_ms else 0.0)
 
     # aggregation-only rate beside the layer total, and the projection against the MFMA peak
     seg_total_ms = sum(seg_ms)
@@ -1067,16 +1094,28 @@ def main():
     issued_tf = (sum(v[0] * products.get(k, 6.0) for k, v in gem.items() if k != "bwd_weight") / (solo_ms * 1e-3) / 1e12) if solo_ms else None
     res = None
     if rank == 0:
+        # `achieved` = SURVEY 8(d)'s algorithmic bytes / live duration (every gathered row counted as a read, no cache credit: it can
+        # exceed the peak when caches serve gathers); `achieved_traffic` = the bytes the PMC counters saw cross the L2 <-> fabric
+        # boundary / the same duration, and `frac` = achieved_traffic / peak.  FETCH_SIZE counts the L2's fabric-side requests, so
+        # rows served by the 256 MiB Infinity Cache are still inside it (guide, HBM section): `frac` is an UPPER BOUND on DRAM
+        # utilisation; the cache-free figure is control_uniform's.
+        per_dir = None
+        if not sharded and args.conv in ("sage", "gcn") and len(seg_ms) == 2 * args.steps:
+            per_dir = (sum(seg_ms[0::2]) / args.steps, sum(seg_ms[1::2]) / args.steps)      # launched in the order forward, backward
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                # two fractions of the 8 TB/s HBM peak, both from the same live launch duration:
-                "frac_algorithmic": frac_alg,      # SURVEY 8(d) bytes (every gathered row counted, no cache credit) / time
-                "frac_traffic": frac_traffic,      # bytes that crossed the L2 <-> fabric boundary (PMC) / time
+                "achieved_traffic": ach_traffic,
+                "frac_algorithmic": frac_alg,      # SURVEY 8(d) bytes (every gathered row counted, no cache credit) / time / peak
+                "frac_traffic": frac_traffic,      # bytes that crossed the L2 <-> fabric boundary (PMC) / time / peak
                 "frac": frac_traffic if frac_traffic is not None else frac_alg,
-                "frac_basis": ("traffic: PMC bytes / live duration / peak -- the HBM-roofline fraction; frac_algorithmic "
-                               "exceeds it (and can exceed 1) because gathers of the 100k protein rows are served by the "
-                               "XCD L2s / Infinity Cache and never reach HBM") if frac_traffic is not None else
-                              "algorithmic bytes / live duration / peak (no current PMC pass on file for this configuration; "
-                              "this figure counts every gathered row as an HBM read and can exceed 1 when caches serve gathers)",
+                "frac_basis": ("achieved_traffic / peak: L2-miss bytes (PMC FETCH_SIZE x calibration + WRITE_SIZE) over the live launch "
+                               "duration.  FETCH_SIZE counts the L2's fabric-side requests, Infinity-Cache hits included, so this is an "
+                               "UPPER BOUND on DRAM utilisation; control_uniform is the cache-free HBM figure.  frac_algorithmic "
+                               "(achieved / peak) exceeds it, and can exceed 1, because gathers of the 100k protein rows hit the XCD L2s")
+                if frac_traffic is not None else
+                              "achieved / peak: algorithmic bytes over the live launch duration (no current PMC pass on file for this "
+                              "configuration; every gathered row counts as an HBM read, so this can exceed 1 when caches serve gathers)",
+                "fwd_launch_ms": per_dir[0] if per_dir else None,       # the forward launch has the chip to itself,
+                "bwd_launch_ms": per_dir[1] if per_dir else None,       # the backward one shares it with the dW GEMM
                 "traffic": traffic if traffic else ("stale" if pmc.get("stale") else None),
                 "traffic_source": (pmc_live["source"] + "; durations are live too") if traffic_live else
                 (f"OFFLINE rocprofv3 --pmc passes (FETCH_SIZE x {pmc.get('fetch_scale')} gfx950 calibration + WRITE_SIZE, "
@@ -1188,7 +1227,7 @@ def main():
         # same run as well -- the same sample as the N = 1 line, so the two are comparable
         res["cpu_baseline"] = cpu_baseline(args, ei)
     res["wall_s"] = round(time.time() - t_start, 1)
-    emit(res)
+    emit(res, args.detail_file)
 
 
 if __name__ == "__main__":

@@ -60,8 +60,8 @@ def _fat_record():
         "config": {"workload": "C4 " + prose[:300], "parallelism": "single GPU", "hip_graph_replay": False, "setup_steps": 40,
                    "csr_build_s": 0.1, "csr_sorted_columns": True, "fallback": None, "autotune": None, "communicators": None},
         "parity_max_err": 3.3e-7, "parity": {"parity_max_err": 3.3e-7, "by_tensor": {"out": 1e-7, "dX": 2e-7, "dW": 3.3e-7, "db": 1e-7}, "against": prose},
-        "roofline": {"bound": "hbm", "achieved": 8840.0, "peak": 8000.0, "unit": "GB/s", "frac_algorithmic": 1.105, "frac_traffic": 0.81,
-                     "frac": 0.81, "frac_basis": prose, "traffic": 16646937064.9, "traffic_source": prose, "kernel": prose,
+        "roofline": {"bound": "hbm", "achieved": 8840.0, "achieved_traffic": 6480.0, "peak": 8000.0, "unit": "GB/s", "frac_algorithmic": 1.105,
+                     "frac_traffic": 0.81, "frac": 0.81, "fwd_launch_ms": 2.36, "bwd_launch_ms": 2.80, "frac_basis": prose, "traffic": 16646937064.9, "traffic_source": prose, "kernel": prose,
                      "algorithmic_bytes_per_launch": 22612000000, "avg_launch_ms": 2.5588, "launches_timed": 40,
                      "control_uniform": {"workload": prose, "avg_launch_ms": 3.56, "frac_algorithmic": 0.79, "frac_traffic": 0.79, "traffic_source": prose}},
         "exchange": None, "aggregation_only": {"edges_per_s": 7.8e9, "ms_per_step": 5.1, "note": prose},
@@ -91,6 +91,9 @@ def test_the_final_line_is_compact_strict_json_with_the_contract_blocks():
     r = got["roofline"]
     assert r["bound"] == "hbm" and r["frac"] == 0.81 and r["frac_algorithmic"] == 1.105 and r["peak"] == 8000.0
     assert abs(r["achieved"] / r["peak"] - r["frac_algorithmic"]) < 1e-3 and r["control_uniform"]["frac"] == 0.79
+    # the object agrees with itself: the headline fraction follows from a rate and the peak that are both in it
+    assert abs(r["achieved_traffic"] / r["peak"] - r["frac"]) < 1e-6 and "upper bound" in r["frac_basis"]
+    assert r["fwd_launch_ms"] == 2.36 and r["bwd_launch_ms"] == 2.80
     assert set(got["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and got["cpu_baseline"]["cores"] == 32
     c = got["configs"]
     assert c["C2"] == 0.33 and c["C2_eager"] == 0.5 and c["gat_c4"] == 8.4 and c["C5_1gpu"] == 125.3
@@ -103,6 +106,19 @@ def test_the_final_line_is_compact_strict_json_with_the_contract_blocks():
     got = json.loads(line)
     assert len(line) < 6000 and got["config"]["autotune"]["chosen"] == "default" and len(got["config"]["fallback"]) <= 200
     assert got["exchange"]["exposed_ms_per_step"] == 0.4
+
+
+def test_roofline_rates_agree_with_the_fractions_the_line_prints():
+    """bench.roofline_rates is what main() fills the roofline object from: achieved / peak = frac_algorithmic and
+    achieved_traffic / peak = frac_traffic (= frac), with or without a PMC figure"""
+    sys.path.insert(0, ROOT)
+    import bench
+    ach, ach_t, fa, ft = bench.roofline_rates(22_612_000_000, 16_650_000_000.0, 2.583)
+    assert abs(ach / bench.HBM_PEAK_GBS - fa) < 1e-12 and abs(ach_t / bench.HBM_PEAK_GBS - ft) < 1e-12
+    assert abs(fa - 1.0943) < 1e-3 and abs(ft - 0.8057) < 1e-3
+    ach, ach_t, fa, ft = bench.roofline_rates(22_612_000_000, None, 2.583)
+    assert ach_t is None and ft is None and fa > 1.0
+    assert bench.roofline_rates(1, 1, 0.0) == (0.0, None, 0.0, None)
 
 
 def test_a_failed_first_attempt_restarts_every_rank_as_a_fresh_worker(tmp_path):
