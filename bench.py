@@ -1085,12 +1085,16 @@ def main():
         exchange = {"exposed_ms_per_step": sum(exposed.values()) / args.steps,
                     "by_collective_ms_per_step": {k: v / args.steps for k, v in sorted(exposed.items())},
                     "note": "rank 0; stall of the waiting stream at each collective (HIP events around work.wait())"}
-    split_on = NF.GEMM_FLAGS == 0 and os.environ.get("NPI_GEMM_SPLIT", "1") != "0"
-    # matrix products ISSUED per f32-equivalent product: six bf16 ones, or three fp16 ones where the forward projection runs on
-    # two fp16 pieces per operand (functional.F16X2_MIN_ROWS: SAGEConv / GCNConv, 256 features, the row scales from the aggregation)
-    f16_fwd = (split_on and not sharded and args.conv in ("sage", "gcn") and args.storage == "f32" and F == 256
-               and NF._f16x2(N, F, F, torch.float32))
-    products = {"fwd": 3.0 if f16_fwd else 6.0}
+    split_on = True                      # the layers' default arithmetic: f32 operands split for the 16-bit matrix cores
+    # matrix products ISSUED per f32-equivalent product: six bf16 ones, or three fp16 ones where a projection runs on two fp16
+    # pieces per operand (Schedule.f16x2_min_rows: SAGEConv / GCNConv at 256 features -- the forward GEMM with the row scales its
+    # aggregation writes, and, round 6, the backward's data GEMM: the layer runs its backward aggregate-first, dX = (A^T dOut) W^T,
+    # so the transposed aggregation writes that GEMM's left operand and its scales)
+    from npi_gnn_amd.schedule import DEFAULT as _SCH
+    f16_fwd = (not sharded and args.conv in ("sage", "gcn") and args.storage == "f32" and F == 256
+               and NF._f16x2(_SCH, N, F, F, torch.float32))
+    f16_bwd = f16_fwd and _SCH.aggregate_first_backward
+    products = {"fwd": 3.0 if f16_fwd else 6.0, "bwd_data": 3.0 if f16_bwd else 6.0}
     issued_tf = (sum(v[0] * products.get(k, 6.0) for k, v in gem.items() if k != "bwd_weight") / (solo_ms * 1e-3) / 1e12) if solo_ms else None
     res = None
     if rank == 0:
@@ -1149,7 +1153,10 @@ def main():
                                  "note": "gather + segmented reduction, forward + transposed backward launches of one layer"},
             "projection": {
                 "bound": "mfma",
-                "kernels": ("fwd: gemm_split_ws_kernel<.., true> (f32 operands as two scaled fp16 pieces, three v_mfma_f32_32x32x16_f16 per "
+                "kernels": ("fwd + bwd_data: gemm_split_ws_kernel<.., true> (f32 operands as two scaled fp16 pieces, three "
+                            "v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulate); the backward runs aggregate-first, so bwd_data is "
+                            "dX = T W^T behind the transposed aggregation that writes T and its row scales" if f16_bwd else
+                            "fwd: gemm_split_ws_kernel<.., true> (f32 operands as two scaled fp16 pieces, three v_mfma_f32_32x32x16_f16 per "
                             "f32 product); bwd_data: gemm_split_ws_kernel (three bf16 pieces, six v_mfma_f32_32x32x16_bf16); f32 accumulate"
                             if f16_fwd else
                             "fwd + bwd_data: gemm_split_ws_kernel (f32 operands split 3-way into bf16, six "
@@ -1161,7 +1168,8 @@ def main():
                 "peak": MFMA_BF16_PEAK_TF if split_on else MFMA_F32_PEAK_TF,
                 "frac": ((issued_tf / MFMA_BF16_PEAK_TF) if split_on else (solo_tf / MFMA_F32_PEAK_TF)) if solo_tf else None,
                 "issued_products_per_f32_product": products if split_on else None,
-                "frac_note": ("issued 16-bit MFMA flops (fwd 3 x, bwd_data 6 x the f32-equivalent) / dense bf16 = fp16 MFMA peak" if f16_fwd else
+                "frac_note": ("issued fp16 MFMA flops (3 x the f32-equivalent, both GEMMs) / dense fp16 = bf16 MFMA peak" if f16_bwd else
+                              "issued 16-bit MFMA flops (fwd 3 x, bwd_data 6 x the f32-equivalent) / dense bf16 = fp16 MFMA peak" if f16_fwd else
                               "issued bf16-MFMA flops (6 x f32-equivalent) / dense bf16 MFMA peak") if split_on else
                              "f32 flops / f32 MFMA peak",
                 "per_gemm_ms": {k: v[1] / v[2] for k, v in gem.items()},

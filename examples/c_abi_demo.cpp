@@ -2,7 +2,7 @@
 //   out = mean_{j in N(i) U {i}} x_j  @ W + b            (PyG 1.4.2 SAGEConv, reference src/classes.py:62)
 // on a small random graph, checked against a CPU loop.  Shows what a non-Python caller binds:
 //   npi_csr_workspace_bytes / npi_csr_build_ex  ->  npi_segsum_carry_elems / npi_segsum_ex  ->  npi_linear_workspace_bytes /
-//   npi_linear_fwd_ex  (ABI 3: every scratch buffer is the caller's; the library allocates nothing and keeps no state)
+//   npi_linear_fwd_ex  (ABI 3 on: every scratch buffer is the caller's; the library allocates nothing and keeps no state)
 // build:  hipcc --offload-arch=gfx950 -I include examples/c_abi_demo.cpp -L npi_gnn_amd -lnpi_gnn -Wl,-rpath,$PWD/npi_gnn_amd -o /tmp/c_abi_demo
 #include <hip/hip_runtime.h>
 
@@ -71,9 +71,9 @@ int main() {
     // the scratch holds arrival counters: zero it ONCE after allocating it (every launch leaves them at zero again)
     HIP_OK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)npi_segsum_carry_elems(nnz_max, item_edges, Fin), stream));
     NPI_CALL(npi_segsum_ex(rowptr, col, item_row, item_edges, /*w=*/nullptr, N, nnz_max, d_x, Fin, /*x2=*/nullptr, /*split=*/0, agg, Fin, Fin, NPI_F32,
-                           /*mean=*/1, /*bias=*/nullptr, carry, stream));
+                           /*mean=*/1, /*bias=*/nullptr, carry, /*row_scales_out=*/nullptr, stream));
     NPI_CALL(npi_linear_fwd_ex(agg, Fin, d_W, Fout, d_b, /*rowscale=*/nullptr, out, Fout, N, Fin, Fout, /*relu=*/0, NPI_F32, /*flags=*/0, gemm_ws,
-                               gemm_ws_bytes, stream));
+                               gemm_ws_bytes, /*a_scales=*/nullptr, stream));
     std::vector<float> got(N * Fout);
     HIP_OK(hipMemcpyAsync(got.data(), out, got.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));

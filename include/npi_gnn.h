@@ -127,17 +127,12 @@ int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, int64_t F);
  * col[p] - split of x2 (same leading dimension and dtype).  One rank of the sharded layers (npi_gnn_amd/dist.py, SURVEY.md
  * 8(e)) gathers from [hub rows received from all ranks ; its own rows] without copying its own rows behind the received
  * ones.  x2 == NULL (split ignored): one table. */
-int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
-                  const float* w, int64_t N, int64_t nnz_max,
-                  const void* x, int64_t ldx, const void* x2, int64_t split,
-                  void* out, int64_t ldo, int64_t F, int dtype,
-                  int mean, const float* bias, float* carry, void* stream);
-/* npi_segsum_ex that also writes, for every finished row, the power-of-two scale the projection GEMM behind the aggregation takes as
- * `a_scales` (NPI_GEMM_SPLIT_F16X2; the same values npi_row_scales would compute from `out` in a pass of its own): a wave maximum
- * and one 4-byte store per row.  row_scales_out: [N] or NULL (then the call IS npi_segsum_ex).  Only f32 rows of 256 columns,
- * 16-byte aligned, on a graph with entries: npi_segsum_scales_supported(F, dtype). */
+/* row_scales_out != NULL: the launch also writes, for every finished row, the power-of-two scale the projection GEMM behind the
+ * aggregation takes as `a_scales` (NPI_GEMM_SPLIT_F16X2; the same values npi_row_scales would compute from `out` in a pass of its
+ * own): a wave maximum and one 4-byte store per row.  [N] or NULL.  Only f32 rows of 256 columns, 16-byte aligned, on a graph
+ * with entries: npi_segsum_scales_supported(F, dtype).  (ABI 4: the separate scales-writing twin of ABI 3, folded.) */
 int npi_segsum_scales_supported(int64_t F, int dtype);
-int npi_segsum_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
+int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                    const float* w, int64_t N, int64_t nnz_max, const void* x, int64_t ldx,
                    const void* x2, int64_t split, void* out, int64_t ldo, int64_t F, int dtype, int mean,
                    const float* bias, float* carry, float* row_scales_out, void* stream);
@@ -152,6 +147,12 @@ int npi_gcn_norm(const int32_t* rowidx, const int32_t* col, const int32_t* rowpt
                  void* stream);
 /* inv_cnt[i] = 1 / max(rowptr[i+1] - rowptr[i], 1): the scatter_mean divisor, needed again by the
  * backward (dX = A^T D^-1 dAgg) */
+/* w_out[p] = table[col[p]] * w_in[p] (w_in == NULL: ones) for the entries p of one CSR, 0 behind its last entry: a per-NODE factor of
+ * the gathered row as a per-entry weight.  The layers' backward uses it with table = npi_row_inv_count of the by-target CSR over the
+ * by-source side: scatter_mean's divisor belongs to the TARGET, so dX = (A^T D^-1 dOut) W^T aggregates dOut itself with these
+ * weights and projects afterwards (autograd of `scatter_mean` + `torch.matmul`, reference src/train_with_twoDataset.PY:54). */
+int npi_entry_col_scale(const int32_t* col, const int32_t* rowptr, const float* table, const float* w_in, int64_t N, int64_t n_cols,
+                        int64_t nnz_max, float* w_out, void* stream);
 int npi_row_inv_count(const int32_t* rowptr, int64_t N, float* inv_cnt, void* stream);
 /* per-entry weights from per-edge weights: w_entry[p] = eid[p] >= 0 ? edge_w[eid[p]] : loop_w
  * (loop weight of node i = loop_w_node[i] if given else fill) */
@@ -242,7 +243,7 @@ int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, int64_t N);
  * CUs: 0.107 -> 0.15 ms for 125 k rows).  Costs n / 256 more tiles per workgroup when nothing else runs. */
 #define NPI_GEMM_RESERVE_CUS(n) ((((n) / 8) & 0xff) << 8)
 #define NPI_GEMM_RESERVED_CUS_OF(flags) ((((flags) >> 8) & 0xff) * 8)
-/* npi_linear_fwd_ex2 / npi_linear_bwd_data_ex2, f32: the matrix-core kernel runs on TWO fp16 pieces per operand (11 + 11
+/* npi_linear_fwd_ex / npi_linear_bwd_data_ex, f32: the matrix-core kernel runs on TWO fp16 pieces per operand (11 + 11
  * significant bits) and THREE v_mfma_f32_32x32x16_f16 per product tile instead of three bf16 pieces and six products -- half the
  * matrix work for the same f32-rounding-level result (tools/micro/mfma_f16_split.hip: 3.8e-7 of a row's largest |C| against
  * 3.9e-7 for the six bf16 products and 5.5e-7 for an f32 FMA loop; EXPERIMENTS A33 / A34).  fp16 has five exponent bits, so every
@@ -265,25 +266,17 @@ int npi_row_scales(const float* A, int64_t lda, int64_t M, int64_t K, float* sca
  * multiples of 16; workspace 16-byte aligned, npi_linear_workspace_bytes(K, N) bytes per copy. */
 int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t N, int which, int dtype, void* workspace,
                        int64_t workspace_bytes, void* stream);
-int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
-                      const float* rowscale, void* C, int64_t ldc,
-                      int64_t M, int64_t K, int64_t N, int relu, int dtype, int flags,
-                      void* workspace, int64_t workspace_bytes, void* stream);
-int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* W, int64_t ldw,
-                           const float* rowscale, void* dA, int64_t ldda,
-                           int64_t M, int64_t K, int64_t N, int dtype, int flags,
-                           void* workspace, int64_t workspace_bytes, void* stream);
 int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
                              void* dW, int64_t lddw, void* db,
                              int64_t M, int64_t K, int64_t N,
                              float* workspace, int64_t workspace_elems, int dtype, int flags, int shared, void* stream);
-/* npi_linear_fwd_ex / npi_linear_bwd_data_ex with the row scales of the left operand (NPI_GEMM_SPLIT_F16X2 in `flags`; without the
- * flag `a_scales` is ignored and the call IS the _ex one). */
-int npi_linear_fwd_ex2(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+/* a_scales / dc_scales: the row scales of the left operand for NPI_GEMM_SPLIT_F16X2 in `flags` (npi_row_scales, or the launch that
+ * wrote the operand); NULL / ignored without the flag.  (ABI 4: the scale-taking twins of ABI 3, folded.) */
+int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                        const float* rowscale, void* C, int64_t ldc,
                        int64_t M, int64_t K, int64_t N, int relu, int dtype, int flags,
                        void* workspace, int64_t workspace_bytes, const float* a_scales, void* stream);
-int npi_linear_bwd_data_ex2(const void* dC, int64_t lddc, const void* W, int64_t ldw,
+int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* W, int64_t ldw,
                             const float* rowscale, void* dA, int64_t ldda,
                             int64_t M, int64_t K, int64_t N, int dtype, int flags,
                             void* workspace, int64_t workspace_bytes, const float* dc_scales, void* stream);
@@ -299,12 +292,9 @@ int npi_linear_bwd_data_ex2(const void* dC, int64_t lddc, const void* W, int64_t
  * + npi_gat_scores).  Operands 16-byte aligned, leading dimensions % 4 == 0; workspace as npi_linear_fwd_ex.  Fixed
  * summation order (bitwise reproducible). */
 int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N);
+/* a_scales != NULL: the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) with the row scales of A -- npi_row_scales, ONCE for
+ * a feature matrix that does not change between steps, or the launch that wrote A (npi_gat_aggregate_fused) */
 int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C, int64_t ldc,
-                          float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
-                          void* stream);
-/* the same on the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) when a_scales is not NULL: the row scales of A -- npi_row_scales, ONCE for
- * a feature matrix that does not change between steps, or the launch that wrote A (npi_gat_aggregate_fused_ex2) */
-int npi_linear_fwd_scores_ex2(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C, int64_t ldc,
                               float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
                               const float* a_scales, void* stream);
 /* dA = dC W^T + row0 (x) col0 + row1 (x) col1 (f32; row* are [M], col* [K] vectors): npi_linear_bwd_data_ex with a rank-2 term
@@ -315,12 +305,9 @@ int npi_linear_fwd_scores_ex2(const float* A, int64_t lda, const float* W, int64
  * returns NPI_ERR_ARG (the caller adds the terms to dC with npi_gat_rank1_add instead).  Operands 16-byte aligned, leading
  * dimensions % 4 == 0; workspace as npi_linear_bwd_data_ex. */
 int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t N);
-int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0, const float* row1,
-                              const float* col0, const float* col1, float* dA, int64_t ldda, int64_t M, int64_t K, int64_t N,
-                              void* workspace, int64_t workspace_bytes, void* stream);
-/* the same with the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) when dc_scales is not NULL: the row scales of dC, from npi_row_scales
- * or from the launch that wrote dC (npi_gat_backward_fused_heads_ex2) */
-int npi_linear_bwd_data_rank2_ex2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
+/* dc_scales != NULL: the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) with the row scales of dC, from npi_row_scales
+ * or from the launch that wrote dC (npi_gat_backward_fused_heads) */
+int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
                                   const float* row1, const float* col0, const float* col1, float* dA, int64_t ldda,
                                   int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
                                   const float* dc_scales, void* stream);
@@ -409,14 +396,9 @@ int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_
  * (npi_seg_rowsum_ex over both orientations). */
 int npi_gat_pack_targets(const float* a_dst, const float* m, const float* s, const float* D, int64_t N, float* tpack,
                          void* stream);
-int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                                 int64_t item_edges, int64_t N, int64_t nnz_max, const float* dout, int64_t ldd, const float* dout2,
-                                 int64_t split, const float* hfeat, int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C,
-                                 const float* tpack, const float* a_src, float negative_slope, float* dz, float* carry,
-                                 void* stream);
-/* the same, also writing the power-of-two scale of every finished row of `out` (row_scales_out [N] or NULL; heads * out_channels == 256):
- * the dc_scales of the projection behind it (npi_linear_bwd_data_rank2_ex2 / npi_linear_bwd_data_ex2) without a pass over `out` */
-int npi_gat_backward_fused_heads_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
+/* row_scales_out != NULL ([N]; heads * out_channels == 256): the launch also writes the power-of-two scale of every finished row of `out`:
+ * the dc_scales of the projection behind it (npi_linear_bwd_data_rank2 / npi_linear_bwd_data_ex) without a pass over `out` */
+int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
                                      const int32_t* item_row, int64_t item_edges, int64_t N, int64_t nnz_max,
                                      const float* dout, int64_t ldd, const float* dout2, int64_t split, const float* hfeat,
                                      int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack,
@@ -468,13 +450,9 @@ int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* col, const in
  * exp(m_part - m_row) where cut rows are resolved, in a fixed order (bitwise reproducible).  Writes m[N], s[N] -- the row
  * maximum and the row sum of exp(e - m) that npi_gat_pack_targets / the backward need -- beside out.  (rowidx: unused, may be
  * NULL.)  The scores differ from npi_gat_scores' by the rounding of another summation order (1e-6 relative). */
+/* row_scales_out != NULL ([N]; 256 channels): the launch also writes the power-of-two scale of every finished row of `out` -- bias and
+ * ReLU applied, as stored --: the a_scales of the NEXT layer's projection (npi_linear_fwd_scores / npi_linear_fwd_ex) */
 int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                            int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
-                            int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
-                            float slope, const float* bias, int relu, float* m, float* s, float* carry, void* stream);
-/* the same, also writing the power-of-two scale of every finished row of `out` -- bias and ReLU applied, as stored -- (row_scales_out [N]
- * or NULL; 256 channels): the a_scales of the NEXT layer's projection (npi_linear_fwd_scores_ex2 / npi_linear_fwd_ex2) */
-int npi_gat_aggregate_fused_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
                                 int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
                                 int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
                                 float negative_slope, const float* bias, int relu, float* m, float* s, float* carry,

@@ -45,12 +45,12 @@ PROTOTYPES = {
     "npi_csr_build_ex": (c_int, [_P, _P, _I, _I, _I, c_int, _I, c_int, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "npi_edge_positions": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "npi_segsum_carry_elems": (_I, [_I, _I, _I]),
-    "npi_segsum_ex": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P]),
-    "npi_segsum_ex2": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P, _P]),
+    "npi_segsum_ex": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, c_int, c_int, _P, _P, _P, _P]),
     "npi_segsum_scales_supported": (c_int, [_I, c_int]),
     "npi_row_weight_sum": (c_int, [_P, _P, _I, _P, _P]),
     "npi_gcn_norm": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "npi_row_inv_count": (c_int, [_P, _I, _P, _P]),
+    "npi_entry_col_scale": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "npi_entry_weights": (c_int, [_P, _P, _P, _P, _P, c_float, _I, _I, _P, _P]),
     "npi_relu_backward": (c_int, [_P, _I, _P, _I, _I, _I, _P, _I, _P]),
     "npi_l2_normalize_rows": (c_int, [_P, _I, _I, _I, c_float, _P, _I, _P, _P]),
@@ -59,19 +59,15 @@ PROTOTYPES = {
     "npi_colsum": (c_int, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_linear_bwd_weight_workspace_elems": (_I, [_I, _I, _I]),
     "npi_linear_workspace_bytes": (_I, [_I, _I]),
-    "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
-    "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
     "npi_row_scales": (c_int, [_P, _I, _I, _I, _P, _P]),
-    "npi_linear_fwd_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P, _P]),
-    "npi_linear_bwd_data_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P, _P]),
+    "npi_linear_fwd_ex": (c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P, _P]),
+    "npi_linear_bwd_data_ex": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P, _P]),
     "npi_linear_prepare": (c_int, [_P, _I, _I, _I, c_int, c_int, _P, _I, _P]),
     "npi_hold_cus": (c_int, [c_int, _I, _P, _P]),
     "npi_linear_fwd_scores_supported": (c_int, [_I, _I, _I]),
-    "npi_linear_fwd_scores": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
-    "npi_linear_fwd_scores_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "npi_linear_fwd_scores": (c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "npi_linear_bwd_data_rank2_supported": (c_int, [_I, _I, _I]),
-    "npi_linear_bwd_data_rank2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
-    "npi_linear_bwd_data_rank2_ex2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "npi_linear_bwd_data_rank2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "npi_gat_rank2_cols": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_gat_rank2_tail": (c_int, [_P, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     "npi_linear_bwd_weight_ex": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, c_int, c_int, _P]),
@@ -79,16 +75,13 @@ PROTOTYPES = {
                              c_int, _P, _I, _P]),
     "npi_conv_bwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I,
                              c_int, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P]),
-    "npi_gat_aggregate_fused": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, c_int, _P, _P, _P, _P]),
-    "npi_gat_aggregate_fused_ex2": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, c_int, _P, _P, _P, _P,
+    "npi_gat_aggregate_fused": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, c_float, _P, c_int, _P, _P, _P, _P,
                                             _P]),
     "npi_gat_scores": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "npi_gat_aggregate_ex": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, c_float, c_int,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_gat_pack_targets": (c_int, [_P, _P, _P, _P, _I, _P, _P]),
     "npi_gat_backward_fused_heads": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P,
-                                             _P, _P]),
-    "npi_gat_backward_fused_heads_ex2": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P,
                                                  _P, _P, _P]),
     "npi_gat_rank1_add": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),

@@ -412,7 +412,7 @@ __global__ void topk_take_kernel(const uint32_t* __restrict__ graph_of, const in
 using namespace npi;
 
 extern "C" const char* npi_last_error(void) { return npi::g_err; }
-extern "C" int npi_abi_version(void) { return 3; }
+extern "C" int npi_abi_version(void) { return 4; }
 
 extern "C" int64_t npi_csr_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return -1;

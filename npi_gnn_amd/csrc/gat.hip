@@ -579,15 +579,6 @@ extern "C" int npi_gat_pack_targets(const float* a_dst, const float* m, const fl
 }
 
 extern "C" int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
-                                            const int32_t* item_row, int64_t item_edges, int64_t N, int64_t nnz_max, const float* dout,
-                                            int64_t ldd, const float* dout2, int64_t split, const float* hfeat, int64_t ldh,
-                                            float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack, const float* a_src,
-                                            float slope, float* dz, float* carry, void* stream_) {
-    return npi_gat_backward_fused_heads_ex2(rowptr, col, rowidx, item_row, item_edges, N, nnz_max, dout, ldd, dout2, split, hfeat, ldh, out,
-                                            ldo, H, C, tpack, a_src, slope, dz, carry, nullptr, stream_);
-}
-
-extern "C" int npi_gat_backward_fused_heads_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
                                                 const int32_t* item_row, int64_t item_edges, int64_t N, int64_t nnz_max,
                                                 const float* dout, int64_t ldd, const float* dout2, int64_t split, const float* hfeat,
                                                 int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack,
@@ -597,7 +588,7 @@ extern "C" int npi_gat_backward_fused_heads_ex2(const int32_t* rowptr, const int
     const int64_t F = H * C;
     NPI_REQUIRE(row_scales_out == nullptr || (F == 256 && ldd % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)dout % 16) == 0 &&
                                               ((uintptr_t)out % 16) == 0 && (dout2 == nullptr || ((uintptr_t)dout2 % 16) == 0)),
-                "npi_gat_backward_fused_heads_ex2: row_scales_out needs heads * out_channels == 256 and 16-byte aligned rows");
+                "npi_gat_backward_fused_heads: row_scales_out needs heads * out_channels == 256 and 16-byte aligned rows");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C % 4 == 0 && F <= 256, "npi_gat_backward_fused_heads: needs heads * out_channels <= 256, out_channels % 4 == 0");
     NPI_REQUIRE(H == 1 || ((H == 2 || H == 4 || H == 8) && C >= 32 && (C & (C - 1)) == 0),
                 "npi_gat_backward_fused_heads: several heads need 2 / 4 / 8 heads of 32 / 64 / 128 channels");
@@ -761,14 +752,6 @@ extern "C" int npi_gat_aggregate_scores(const int32_t* rowptr, const int32_t* co
 // statistics pass, no per-entry score array, no gather of the sources' scores (npi_gat_softmax_stats_ex +
 // npi_gat_aggregate_scores do the same in two): the source half of every score is recomputed from the gathered row
 extern "C" int npi_gat_aggregate_fused(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
-                                       int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx, const float* x2,
-                                       int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst, const float* att,
-                                       float slope, const float* bias, int relu, float* m, float* s, float* carry, void* stream_) {
-    return npi_gat_aggregate_fused_ex2(rowptr, col, rowidx, item_row, item_edges, N, nnz_max, x, ldx, x2, split, out, ldo, C, a_dst, att,
-                                       slope, bias, relu, m, s, carry, nullptr, stream_);
-}
-
-extern "C" int npi_gat_aggregate_fused_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx, const int32_t* item_row,
                                            int64_t item_edges, int64_t N, int64_t nnz_max, const float* x, int64_t ldx,
                                            const float* x2, int64_t split, float* out, int64_t ldo, int64_t C, const float* a_dst,
                                            const float* att, float slope, const float* bias, int relu, float* m, float* s,
@@ -776,7 +759,7 @@ extern "C" int npi_gat_aggregate_fused_ex2(const int32_t* rowptr, const int32_t*
     hipStream_t stream = (hipStream_t)stream_;
     NPI_REQUIRE(row_scales_out == nullptr || (C == 256 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16) == 0 &&
                                               ((uintptr_t)out % 16) == 0 && (x2 == nullptr || ((uintptr_t)x2 % 16) == 0)),
-                "npi_gat_aggregate_fused_ex2: row_scales_out needs 256 channels and 16-byte aligned rows");
+                "npi_gat_aggregate_fused: row_scales_out needs 256 channels and 16-byte aligned rows");
     NPI_REQUIRE(x2 == nullptr || (split >= 0 && split < 0x7fffffff), "npi_gat_aggregate_fused: bad split");
     NPI_REQUIRE(item_edges_ok(item_edges), "npi_gat_aggregate_fused: item_edges must be 64 or NPI_ITEM_EDGES (the value the CSR was built with)");
     NPI_REQUIRE(N >= 0 && nnz_max > 0 && C > 0 && C <= 256 && C % 4 == 0, "npi_gat_aggregate_fused: bad size (one head of at most 256 channels, a multiple of 4)");

@@ -2171,21 +2171,13 @@ extern "C" int npi_row_scales(const float* A, int64_t lda, int64_t M, int64_t K,
 }
 
 extern "C" int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
-                                 const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
-                                 int64_t N, int relu, int dtype, int flags, void* workspace, int64_t workspace_bytes,
-                                 void* stream_) {
-    return npi_linear_fwd_ex2(A, lda, W, ldw, bias, rowscale, C, ldc, M, K, N, relu, dtype, flags, workspace, workspace_bytes, nullptr,
-                              stream_);
-}
-
-extern "C" int npi_linear_fwd_ex2(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                                   const float* rowscale, void* C, int64_t ldc, int64_t M, int64_t K,
                                   int64_t N, int relu, int dtype, int flags, void* workspace, int64_t workspace_bytes,
                                   const float* a_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const bool f16 = (flags & NPI_GEMM_SPLIT_F16X2) != 0;
     NPI_REQUIRE(!f16 || (a_scales != nullptr && dtype == NPI_F32 && !(flags & (NPI_GEMM_EXACT_F32 | NPI_GEMM_A_ZERO_PADDED))),
-                "npi_linear_fwd_ex2: NPI_GEMM_SPLIT_F16X2 needs a_scales (npi_row_scales), f32 storage, and excludes "
+                "npi_linear_fwd_ex: NPI_GEMM_SPLIT_F16X2 needs a_scales (npi_row_scales), f32 storage, and excludes "
                 "NPI_GEMM_EXACT_F32 / NPI_GEMM_A_ZERO_PADDED");
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_fwd: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_fwd: size > int32");
@@ -2216,20 +2208,13 @@ extern "C" int npi_linear_fwd_ex2(const void* A, int64_t lda, const void* W, int
 
 // dA[M,K] = rowscale * (dC[M,N] @ W[K,N]^T): GEMM with "K" = N (contracted), output width K
 extern "C" int npi_linear_bwd_data_ex(const void* dC, int64_t lddc, const void* W, int64_t ldw,
-                                      const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
-                                      int64_t N, int dtype, int flags, void* workspace, int64_t workspace_bytes,
-                                      void* stream_) {
-    return npi_linear_bwd_data_ex2(dC, lddc, W, ldw, rowscale, dA, ldda, M, K, N, dtype, flags, workspace, workspace_bytes, nullptr, stream_);
-}
-
-extern "C" int npi_linear_bwd_data_ex2(const void* dC, int64_t lddc, const void* W, int64_t ldw,
                                        const float* rowscale, void* dA, int64_t ldda, int64_t M, int64_t K,
                                        int64_t N, int dtype, int flags, void* workspace, int64_t workspace_bytes,
                                        const float* dc_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const bool f16 = (flags & NPI_GEMM_SPLIT_F16X2) != 0;
     NPI_REQUIRE(!f16 || (dc_scales != nullptr && dtype == NPI_F32 && !(flags & NPI_GEMM_EXACT_F32)),
-                "npi_linear_bwd_data_ex2: NPI_GEMM_SPLIT_F16X2 needs dc_scales (npi_row_scales of dC), f32 storage, and excludes "
+                "npi_linear_bwd_data_ex: NPI_GEMM_SPLIT_F16X2 needs dc_scales (npi_row_scales of dC), f32 storage, and excludes "
                 "NPI_GEMM_EXACT_F32");
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_data: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_data: size > int32");
@@ -2260,15 +2245,9 @@ extern "C" int npi_linear_fwd_scores_supported(int64_t M, int64_t K, int64_t N) 
     // NST = 4 k-steps of 16 (with 2 k-steps wave wn = 1 could be a whole tile ahead of wave wn = 0 and overwrite its slot)
     return (M >= 128 && M < 0x7fffffff && K >= 2 * BK && K % BK == 0 && (N == 128 || N == 256)) ? 1 : 0;
 }
-extern "C" int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C,
-                                     int64_t ldc, float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace,
-                                     int64_t workspace_bytes, void* stream_) {
-    return npi_linear_fwd_scores_ex2(A, lda, W, ldw, att, C, ldc, sc0, sc1, M, K, N, workspace, workspace_bytes, nullptr, stream_);
-}
-
 // a_scales != NULL: the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2) with the row scales of A (npi_row_scales -- once, for a feature
-// matrix that does not change between steps -- or the launch that wrote A: npi_gat_aggregate_fused_ex2)
-extern "C" int npi_linear_fwd_scores_ex2(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C,
+// matrix that does not change between steps -- or the launch that wrote A: npi_gat_aggregate_fused)
+extern "C" int npi_linear_fwd_scores(const float* A, int64_t lda, const float* W, int64_t ldw, const float* att, float* C,
                                          int64_t ldc, float* sc0, float* sc1, int64_t M, int64_t K, int64_t N, void* workspace,
                                          int64_t workspace_bytes, const float* a_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -2293,17 +2272,9 @@ extern "C" int npi_linear_bwd_data_rank2_supported(int64_t M, int64_t K, int64_t
     return (M >= 128 && M < 0x7fffffff && K >= 128 && K % 128 == 0 && N >= BK && N % BK == 0 &&
             N % 4 == 0) ? 1 : 0;
 }
-extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
-                                         const float* row1, const float* col0, const float* col1, float* dA, int64_t ldda,
-                                         int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
-                                         void* stream_) {
-    return npi_linear_bwd_data_rank2_ex2(dC, lddc, W, ldw, row0, row1, col0, col1, dA, ldda, M, K, N, workspace, workspace_bytes, nullptr,
-                                         stream_);
-}
-
 // dc_scales != NULL: the fp16 x 2 arithmetic (NPI_GEMM_SPLIT_F16X2), the row scales of dC from npi_row_scales or from the launch that
-// wrote dC (npi_gat_backward_fused_heads_ex2)
-extern "C" int npi_linear_bwd_data_rank2_ex2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
+// wrote dC (npi_gat_backward_fused_heads)
+extern "C" int npi_linear_bwd_data_rank2(const float* dC, int64_t lddc, const float* W, int64_t ldw, const float* row0,
                                              const float* row1, const float* col0, const float* col1, float* dA, int64_t ldda,
                                              int64_t M, int64_t K, int64_t N, void* workspace, int64_t workspace_bytes,
                                              const float* dc_scales, void* stream_) {

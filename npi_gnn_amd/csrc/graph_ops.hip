@@ -58,12 +58,16 @@ __global__ void row_inv_count_kernel(const int32_t* __restrict__ rowptr, int N, 
     inv[i] = 1.f / (float)max(rowptr[i + 1] - rowptr[i], 1);
 }
 
-__global__ void permute_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ index,
-                                   int64_t n, float fill, float* __restrict__ dst) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int j = index[i];
-    dst[i] = j >= 0 ? src[j] : fill;
+// w_out[p] = w_in[p] * table[col[p]] (w_in null: ones) for the entries of one CSR, 0 behind the last entry: a factor that belongs
+// to the GATHERED row -- scatter_mean's 1 / in-count of the target, seen from the by-source side -- as a per-entry weight
+__global__ void entry_col_scale_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ rowptr,
+                                       const float* __restrict__ table, const float* __restrict__ w_in, int N, int n_cols,
+                                       int64_t nnz_max, float* __restrict__ w_out) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz_max) return;
+    if (p >= rowptr[N]) { w_out[p] = 0.f; return; }
+    const int c = col[p];
+    w_out[p] = ((unsigned)c < (unsigned)n_cols ? table[c] : 0.f) * (w_in ? w_in[p] : 1.f);
 }
 
 }  // namespace npi
@@ -99,6 +103,17 @@ extern "C" int npi_entry_weights(const int32_t* eid, const int32_t* rowidx, cons
     NPI_REQUIRE(eid && rowidx && rowptr && w_entry, "npi_entry_weights: null pointer");
     entry_weights_kernel<<<(unsigned)ceil_div(nnz_max, 256), 256, 0, stream>>>(eid, rowidx, rowptr, edge_w, loop_w_node, fill, (int)N, nnz_max, w_entry);
     return check_launch("npi_entry_weights");
+}
+
+extern "C" int npi_entry_col_scale(const int32_t* col, const int32_t* rowptr, const float* table, const float* w_in, int64_t N,
+                                   int64_t n_cols, int64_t nnz_max, float* w_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(N >= 0 && n_cols >= 0 && nnz_max >= 0 && N < 0x7fffffff && n_cols < 0x7fffffff, "npi_entry_col_scale: bad size");
+    if (nnz_max == 0) return NPI_OK;
+    NPI_REQUIRE(col && rowptr && table && w_out, "npi_entry_col_scale: null pointer");
+    entry_col_scale_kernel<<<(unsigned)ceil_div(nnz_max, 256), 256, 0, stream>>>(col, rowptr, table, w_in, (int)N, (int)n_cols, nnz_max,
+                                                                               w_out);
+    return check_launch("npi_entry_col_scale");
 }
 
 extern "C" int npi_row_inv_count(const int32_t* rowptr, int64_t N, float* inv_cnt, void* stream_) {

@@ -1,4 +1,4 @@
-// One conv LAYER CALL as one entry point (ABI 3): npi_conv_fwd / npi_conv_bwd issue, in order on one stream, exactly the launches
+// One conv LAYER CALL as one entry point (ABI 3 on): npi_conv_fwd / npi_conv_bwd issue, in order on one stream, exactly the launches
 // the per-op entry points issue -- aggregation, weight preparation, projection; ReLU mask, weight gradient, dAgg GEMM, transposed
 // aggregation -- and add no kernel of their own.  Why: the reference's real workload is SMALL (src/train_with_twoDataset.PY:46-57,
 // batches of 200 enclosing subgraphs; configs 1-3: 5,085 / 1,992 nodes).  There a layer's launches are 5-25 us of GPU work each and
@@ -22,7 +22,7 @@ extern "C" int npi_conv_fwd(const int32_t* rowptr, const int32_t* col, const int
                 "npi_conv_fwd: a prepared workspace excludes NPI_GEMM_A_ZERO_PADDED (as in npi_linear_fwd_ex)");
     // a2-a4: gather + segmented mean / weighted sum into the first F columns of agg
     int rc = npi_segsum_ex(rowptr, col, item_row, item_edges, w_entry, N, nnz_max, x, ldx, nullptr, 0, agg, ldagg, F, dtype, mean,
-                           nullptr, carry, stream);
+                           nullptr, carry, nullptr, stream);
     if (rc != NPI_OK) return rc;
     int flags = gemm_flags;
     if (prepare_which != 0) {
@@ -32,7 +32,7 @@ extern "C" int npi_conv_fwd(const int32_t* rowptr, const int32_t* col, const int
     }
     // a5: agg @ W + b (ReLU in the store epilogue on request)
     return npi_linear_fwd_ex(agg, ldagg, W, ldw, bias, nullptr, out, ldo, N, K, Nout, relu, dtype, flags, ws,
-                             prepare_which == 3 ? ws_bytes / 2 : ws_bytes, stream);
+                             prepare_which == 3 ? ws_bytes / 2 : ws_bytes, nullptr, stream);
 }
 
 extern "C" int npi_conv_bwd(const void* dout, int64_t lddo, const float* out_relu, int64_t ldor, float* dz, int64_t lddz, int64_t N,
@@ -60,10 +60,10 @@ extern "C" int npi_conv_bwd(const void* dout, int64_t lddo, const float* out_rel
         NPI_REQUIRE(dagg && t_rowptr && t_item_row && t_carry, "npi_conv_bwd: null pointer on the dX chain");
         int flags = gemm_flags & (NPI_GEMM_EXACT_F32 | NPI_GEMM_SPLIT_BF16);
         if (ws_prepared) flags |= NPI_GEMM_WORKSPACE_PREPARED;
-        rc = npi_linear_bwd_data_ex(g, ldg, W, ldw, rowscale, dagg, lddagg, N, K, Nout, dtype, flags, ws_bwd, ws_bwd_bytes, stream);
+        rc = npi_linear_bwd_data_ex(g, ldg, W, ldw, rowscale, dagg, lddagg, N, K, Nout, dtype, flags, ws_bwd, ws_bwd_bytes, nullptr, stream);
         if (rc != NPI_OK) return rc;
         rc = npi_segsum_ex(t_rowptr, t_col, t_item_row, t_item_edges, t_w, N, t_nnz_max, dagg, lddagg, nullptr, 0, dx, lddx, K, dtype,
-                           0, nullptr, t_carry, stream);
+                           0, nullptr, t_carry, nullptr, stream);
     }
     return rc;
 }

@@ -44,7 +44,7 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // fp16 x 2 projection (NPI_GEMM_SPLIT_F16X2, gemm_f32.hip): power-of-two scale for a row / column whose largest magnitude is m,
 // m * scale in [2^14, 2^15) (1 for an all-zero row and for Inf / NaN -- which then propagate as in the bf16 split --; clamped so
 // that scale and 1 / scale are normal f32).  Written by npi_row_scales, by the weight preparation, and by the aggregation
-// kernels for the rows they finish (npi_segsum_ex2).
+// kernels for the rows they finish (npi_segsum_ex).
 __device__ __forceinline__ float pow2_scale_of(float m) {
     const uint32_t eb = (__float_as_uint(m) >> 23) & 0xff;
     if (m == 0.f || eb == 255) return 1.f;

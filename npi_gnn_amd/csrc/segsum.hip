@@ -1379,17 +1379,9 @@ extern "C" int64_t npi_segsum_carry_elems(int64_t nnz_max, int64_t item_edges, i
     return CarryLayout(items).elems(F < 1024 ? F : 1024);
 }
 
-extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
-                             const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
-                             const void* x2_, int64_t split, void* out_, int64_t ldo, int64_t F, int dtype, int mean,
-                             const float* bias, float* carry, void* stream_) {
-    return npi_segsum_ex2(rowptr, col, item_row, item_edges, w, N, nnz_max, x_, ldx, x2_, split, out_, ldo, F, dtype, mean, bias, carry,
-                          nullptr, stream_);
-}
-
 extern "C" int npi_segsum_scales_supported(int64_t F, int dtype) { return (F == 256 && dtype == NPI_F32) ? 1 : 0; }
 
-extern "C" int npi_segsum_ex2(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
+extern "C" int npi_segsum_ex(const int32_t* rowptr, const int32_t* col, const int32_t* item_row, int64_t item_edges,
                               const float* w, int64_t N, int64_t nnz_max, const void* x_, int64_t ldx,
                               const void* x2_, int64_t split, void* out_, int64_t ldo, int64_t F, int dtype, int mean,
                               const float* bias, float* carry, float* row_scales_out, void* stream_) {
@@ -1397,7 +1389,7 @@ extern "C" int npi_segsum_ex2(const int32_t* rowptr, const int32_t* col, const i
     NPI_REQUIRE(row_scales_out == nullptr || (npi_segsum_scales_supported(F, dtype) && nnz_max > 0 && ldx % 4 == 0 && ldo % 4 == 0 &&
                                               ((uintptr_t)x_ % 16) == 0 && ((uintptr_t)out_ % 16) == 0 &&
                                               (x2_ == nullptr || ((uintptr_t)x2_ % 16) == 0)),
-                "npi_segsum_ex2: row_scales_out needs f32 rows of 256 columns, 16-byte aligned (npi_segsum_scales_supported), and a "
+                "npi_segsum_ex: row_scales_out needs f32 rows of 256 columns, 16-byte aligned (npi_segsum_scales_supported), and a "
                 "graph with entries");
     NPI_REQUIRE(x2_ == nullptr || (split >= 0 && split < 0x7fffffff), "npi_segsum_ex: bad split");
     NPI_REQUIRE(N >= 0 && nnz_max >= 0 && F > 0, "npi_segsum: bad size");

@@ -169,7 +169,7 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
         ev0.record(torch.cuda.current_stream(dev))
     if scales_out is not None and (scales_out.dtype != torch.float32 or scales_out.numel() != N or not scales_out.is_contiguous()):
         raise ValueError("segsum: scales_out must be a contiguous float32 vector with one element per output row")
-    check(load().npi_segsum_ex2(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.item, ptr(w), N, side.nnz_max,
+    check(load().npi_segsum_ex(ptr(side.rowptr), ptr(side.col), ptr(side.item_row), side.item, ptr(w), N, side.nnz_max,
                                 ptr(x), x.stride(0), ptr(x2), split if x2 is not None else 0, ptr(out), out.stride(0), F,
                                 _code(x), 1 if mean else 0, ptr(bias), ptr(carry), ptr(scales_out), stream_ptr(dev)), "npi_segsum")
     if prof is not None:
@@ -178,20 +178,15 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
     return out
 
 
-# Arithmetic of the f32 projection GEMMs, passed PER CALL (npi_linear_*_ex flags): 0 = the default (3-way bf16 split on the bf16
-# matrix cores), NPI_GEMM_EXACT_F32 = the exact-f32 MFMA kernels.  The library has no process-wide switch (ABI 3).
-GEMM_FLAGS = 0
+# Arithmetic of the f32 projection GEMMs: an argument of every call (``flags``: 0 = the split on the 16-bit matrix cores,
+# NPI_GEMM_EXACT_F32 = the exact-f32 MFMA kernels), and of every layer (``Schedule.f16x2_min_rows``: from how many rows on the
+# layers' GEMMs take two fp16 pieces per operand).  Neither the library (ABI 3 on) nor this module keeps a switch.
 
 
-#: rows from which the f32 projection GEMMs of the single-GPU layers run on two fp16 pieces per operand (NPI_GEMM_SPLIT_F16X2: three
-#: matrix products per tile pair instead of six, the same f32-rounding-level error -- EXPERIMENTS A34); None: never.  Below, the
-#: GEMMs are launch-bound and the row scales would cost a pass of their own.
-F16X2_MIN_ROWS: Optional[int] = 100_000
-
-
-def _f16x2(rows: int, K: int, N: int, dtype) -> bool:
-    return (F16X2_MIN_ROWS is not None and rows >= F16X2_MIN_ROWS and dtype == torch.float32 and GEMM_FLAGS == 0
-            and f16x2_shape(rows, K, N))
+def _f16x2(sch: Schedule, rows: int, K: int, N: int, dtype) -> bool:
+    """does a layer under schedule ``sch`` run its f32 projection GEMMs (contraction K, output width N, ``rows`` rows) on two fp16
+    pieces per operand (NPI_GEMM_SPLIT_F16X2: three matrix products per tile pair instead of six, the same f32-rounding-level error)?"""
+    return (sch.f16x2_min_rows is not None and rows >= sch.f16x2_min_rows and dtype == torch.float32 and f16x2_shape(rows, K, N))
 
 
 def _gemm_workspace(K: int, N: int, dev) -> torch.Tensor:
@@ -211,7 +206,7 @@ def padded_aggregate_buffer(x: torch.Tensor, K: int, rows: int, bf16_ok: bool = 
     padding costs less than half as much again (178 -> 256 yes, 65 -> 128 no).  (bf16 storage has no padded-operand flag: the
     layer pads its weight matrix with zero rows instead, ``_SageConvFn``.)"""
     if (x.dtype not in ((torch.float32, torch.bfloat16) if bf16_ok else (torch.float32,)) or x.size(1) != K or K % 128 == 0
-            or 2 * _pad128(K) > 3 * K or rows < 128 or GEMM_FLAGS != 0):
+            or 2 * _pad128(K) > 3 * K or rows < 128):
         return None
     return torch.zeros((rows, _pad128(K)), dtype=x.dtype, device=x.device)
 
@@ -240,6 +235,26 @@ def row_scales(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class Planes:
+    """A re-laid copy of a weight matrix for the matrix-core GEMMs (``npi_linear_prepare``) and the arithmetic it was laid out for:
+    three bf16 planes (``f16`` False; bf16 storage: one k-block-major copy) or the two fp16 planes + column scales of
+    ``NPI_GEMM_SPLIT_F16X2`` calls.  The library cannot tell the two layouts apart, so the tag travels with the buffer and
+    ``linear_fwd`` / ``linear_bwd_data`` refuse a copy of the other kind."""
+    __slots__ = ("buf", "f16")
+
+    def __init__(self, buf: torch.Tensor, f16: bool = False):
+        self.buf, self.f16 = buf, bool(f16)
+
+
+def _planes_for(ws: Optional["Planes"], f16: bool, what: str) -> torch.Tensor:
+    if not isinstance(ws, Planes):
+        raise TypeError(f"{what}: ws must come from prepare_weight (a functional.Planes)")
+    if ws.f16 != f16:
+        raise ValueError(f"{what}: the prepared weight copy holds {'fp16 x 2' if ws.f16 else 'bf16 x 3'} planes, this call runs on "
+                         f"{'fp16 x 2 (row scales given)' if f16 else 'bf16 x 3 (no row scales)'}: prepare_weight(..., f16={f16})")
+    return ws.buf
+
+
 def prepare_weight(weight: torch.Tensor, backward: bool = True, f16: bool = False):
     """The re-laid copies of ``weight [K, N]`` the matrix-core GEMMs read (three bf16 planes for f32, a k-block-major copy for
     bf16; ``f16``: the two fp16 planes + column scales of ``NPI_GEMM_SPLIT_F16X2`` calls) for ``linear_fwd(..., ws=)`` and --
@@ -247,7 +262,7 @@ def prepare_weight(weight: torch.Tensor, backward: bool = True, f16: bool = Fals
     (``npi_linear_prepare``) instead of one in front of every GEMM: ``(ws_fwd, ws_bwd or None)``, or ``(None, None)`` when the
     shape does not take those kernels anyway.  Valid while ``weight`` is unchanged (a layer's forward and its backward)."""
     K, N = weight.shape
-    if (weight.dtype not in (torch.float32, torch.bfloat16) or K % 32 or N % 32 or weight.stride(1) != 1 or GEMM_FLAGS != 0
+    if (weight.dtype not in (torch.float32, torch.bfloat16) or K % 32 or N % 32 or weight.stride(1) != 1
             or not weight.is_cuda or (f16 and weight.dtype != torch.float32)):
         return None, None
     lib = load()
@@ -256,7 +271,7 @@ def prepare_weight(weight: torch.Tensor, backward: bool = True, f16: bool = Fals
     ws = torch.empty(one * (2 if backward else 1), dtype=torch.uint8, device=dev)
     check(lib.npi_linear_prepare(ptr(weight), weight.stride(0), K, N, (3 if backward else 1) | (NPI_PREPARE_F16X2 if f16 else 0),
                                  _code(weight), ptr(ws), ws.numel(), stream_ptr(dev)), "npi_linear_prepare")
-    return ws[:one], (ws[one:] if backward else None)
+    return Planes(ws[:one], f16), (Planes(ws[one:], f16) if backward else None)
 
 
 def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -277,7 +292,7 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         bias = _fc(bias, "bias", a)
     M, Ka = a.shape
     K, N = weight.shape
-    fl = (GEMM_FLAGS if flags is None else flags) | NPI_GEMM_RESERVE_CUS(reserve_cus)
+    fl = int(flags or 0) | NPI_GEMM_RESERVE_CUS(reserve_cus)
     if Ka != K:
         if Ka != _pad128(K) or a.dtype != torch.float32:
             raise ValueError(f"a has {Ka} columns, weight {K} rows (a zero-padded a must be f32 and {_pad128(K)} wide)")
@@ -292,11 +307,12 @@ def linear_fwd(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     if a_scales is not None:
         fl |= NPI_GEMM_SPLIT_F16X2
     if ws is not None and Ka == K:
+        ws = _planes_for(ws, a_scales is not None, "linear_fwd")
         fl |= NPI_GEMM_WORKSPACE_PREPARED
     else:
         ws = _gemm_workspace(Ka, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
-        check(load().npi_linear_fwd_ex2(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
+        check(load().npi_linear_fwd_ex(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(rowscale),
                                         ptr(out), out.stride(0), M, K, N, 1 if relu else 0, _code(a),
                                         fl, ptr(ws), ws.numel(), ptr(a_scales), stream_ptr(dev)),
               "npi_linear_fwd")
@@ -320,18 +336,19 @@ def linear_bwd_data(dc: torch.Tensor, weight: torch.Tensor,
         if out.shape != (M, K) or out.dtype != dc.dtype or out.stride(1) != 1 or out.device != dc.device:
             raise ValueError(f"linear_bwd_data: out must be [{M}, {K}] {dc.dtype} with unit column stride on the operands' device")
         da = out
-    fl = (GEMM_FLAGS if flags is None else flags) | NPI_GEMM_RESERVE_CUS(reserve_cus)
+    fl = int(flags or 0) | NPI_GEMM_RESERVE_CUS(reserve_cus)
     _check_scales(dc_scales, M, "linear_bwd_data")
     if dc_scales is not None and (dc.dtype != torch.float32 or fl & NPI_GEMM_EXACT_F32):
         dc_scales = None
     if dc_scales is not None:
         fl |= NPI_GEMM_SPLIT_F16X2
     if ws is not None:
+        ws = _planes_for(ws, dc_scales is not None, "linear_bwd_data")
         fl |= NPI_GEMM_WORKSPACE_PREPARED
     else:
         ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
-        check(load().npi_linear_bwd_data_ex2(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
+        check(load().npi_linear_bwd_data_ex(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(rowscale),
                                              ptr(da), da.stride(0), M, K, N, _code(dc),
                                              fl, ptr(ws), ws.numel(), ptr(dc_scales), stream_ptr(dev)),
               "npi_linear_bwd_data")
@@ -342,7 +359,7 @@ def linear_fwd_scores_ok(a: torch.Tensor, weight: torch.Tensor) -> bool:
     """can ``linear_fwd_scores`` take these operands (f32, aligned, one column tile of the split kernel covers the output)?"""
     return (a.dtype == torch.float32 and weight.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
             and weight.stride(1) == 1 and a.stride(0) % 4 == 0 and weight.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
-            and weight.data_ptr() % 16 == 0 and GEMM_FLAGS == 0
+            and weight.data_ptr() % 16 == 0
             and bool(load().npi_linear_fwd_scores_supported(a.size(0), weight.size(0), weight.size(1))))
 
 
@@ -361,7 +378,7 @@ def linear_fwd_scores(a: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor,
     a_src = torch.empty((M, 1), dtype=torch.float32, device=dev)
     ws = _gemm_workspace(K, N, dev)
     with _gemm_events("fwd", 2.0 * M * K * N, dev):
-        check(load().npi_linear_fwd_scores_ex2(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(att2), ptr(h), h.stride(0),
+        check(load().npi_linear_fwd_scores(ptr(a), a.stride(0), ptr(weight), weight.stride(0), ptr(att2), ptr(h), h.stride(0),
                                                ptr(a_dst), ptr(a_src), M, K, N, ptr(ws), ws.numel(), ptr(a_scales), stream_ptr(dev)),
               "npi_linear_fwd_scores")
     return h, a_dst, a_src
@@ -372,7 +389,7 @@ def linear_bwd_data_rank2_ok(dc: torch.Tensor, weight: torch.Tensor) -> bool:
     M, N = dc.shape
     return (dc.dtype == torch.float32 and weight.dtype == torch.float32 and dc.stride(1) == 1 and weight.stride(1) == 1
             and dc.stride(0) % 4 == 0 and weight.stride(0) % 4 == 0 and dc.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
-            and GEMM_FLAGS == 0 and bool(load().npi_linear_bwd_data_rank2_supported(M, weight.size(0), N)))
+            and bool(load().npi_linear_bwd_data_rank2_supported(M, weight.size(0), N)))
 
 
 def linear_bwd_data_rank2(dc: torch.Tensor, weight: torch.Tensor, row0: torch.Tensor, row1: torch.Tensor,
@@ -389,7 +406,7 @@ def linear_bwd_data_rank2(dc: torch.Tensor, weight: torch.Tensor, row0: torch.Te
     da = torch.empty((M, K), dtype=torch.float32, device=dev)
     ws = _gemm_workspace(K, N, dev)
     with _gemm_events("bwd_data", 2.0 * M * K * N, dev):
-        check(load().npi_linear_bwd_data_rank2_ex2(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(row0), ptr(row1),
+        check(load().npi_linear_bwd_data_rank2(ptr(dc), dc.stride(0), ptr(weight), weight.stride(0), ptr(row0), ptr(row1),
                                                ptr(col0), ptr(col1), ptr(da), da.stride(0), M, K, N, ptr(ws), ws.numel(), ptr(dc_scales),
                                                stream_ptr(dev)), "npi_linear_bwd_data_rank2")
     return da
@@ -433,7 +450,7 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True,
     M, Ka = a.shape
     N = dc.size(1)
     K = Ka if k_valid is None else int(k_valid)
-    fl = GEMM_FLAGS if flags is None else flags
+    fl = int(flags or 0)
     if K != Ka:
         if Ka != _pad128(K) or a.dtype != torch.float32:
             raise ValueError(f"a zero-padded a must be f32 and {_pad128(K)} wide (got {Ka})")
@@ -479,8 +496,8 @@ def conv_fwd(side: CSRSide, x: torch.Tensor, w_entry: Optional[torch.Tensor], me
         # (F == Ka: x is itself the zero-padded base of the caller's features, sage_conv(pad_base=))
         raise ValueError(f"x has {F} columns, weight {K} rows (a zero-padded x / aggregate must be f32 and {_pad128(K)} wide)")
     lib = load()
-    flags = GEMM_FLAGS | (NPI_GEMM_A_ZERO_PADDED if Ka != K else 0)
-    can_prepare = (Ka == K and K % 32 == 0 and Nout % 32 == 0 and weight.stride(1) == 1 and GEMM_FLAGS == 0)
+    flags = NPI_GEMM_A_ZERO_PADDED if Ka != K else 0
+    can_prepare = (Ka == K and K % 32 == 0 and Nout % 32 == 0 and weight.stride(1) == 1)
     which = (3 if want_bwd_copy else 1) if can_prepare else 0
     one = int(lib.npi_linear_workspace_bytes(Ka, Nout))
     ws = torch.empty(one * (2 if which == 3 else 1), dtype=torch.uint8, device=dev)
@@ -489,7 +506,7 @@ def conv_fwd(side: CSRSide, x: torch.Tensor, w_entry: Optional[torch.Tensor], me
                            x.stride(0), F, 1 if mean else 0, ptr(agg), agg.stride(0), ptr(side.carry(F)), ptr(weight), weight.stride(0),
                            ptr(bias), ptr(out), out.stride(0), K, Nout, 1 if relu else 0, _code(x), flags, which, ptr(ws), ws.numel(),
                            stream_ptr(dev)), "npi_conv_fwd")
-    return agg, out, (ws[one:] if which == 3 else None)
+    return agg, out, (Planes(ws[one:], False) if which == 3 else None)
 
 
 def conv_bwd(tside: CSRSide, grad_out: torch.Tensor, out_relu: Optional[torch.Tensor], agg: torch.Tensor, weight: torch.Tensor,
@@ -502,7 +519,7 @@ def conv_bwd(tside: CSRSide, grad_out: torch.Tensor, out_relu: Optional[torch.Te
     N, Nout = grad_out.shape
     K = weight.size(0)
     Ka = agg.size(1)
-    flags = GEMM_FLAGS | (NPI_GEMM_A_ZERO_PADDED if Ka != K else 0)
+    flags = NPI_GEMM_A_ZERO_PADDED if Ka != K else 0
     dz = torch.empty((N, Nout), dtype=torch.float32, device=dev) if out_relu is not None else None
     dw = db = dws = dagg = dx = None
     n_ws = 0
@@ -512,6 +529,7 @@ def conv_bwd(tside: CSRSide, grad_out: torch.Tensor, out_relu: Optional[torch.Te
         dw = torch.empty((K, Nout), dtype=agg.dtype, device=dev)
         db = torch.empty(Nout, dtype=agg.dtype, device=dev) if want_bias else None
     prepared = ws_bwd is not None
+    ws_bwd = _planes_for(ws_bwd, False, "conv_bwd") if prepared else None
     if want_x:
         dagg = torch.empty((N, K), dtype=grad_out.dtype, device=dev)
         dx = torch.empty((N, K), dtype=grad_out.dtype, device=dev)
@@ -619,6 +637,63 @@ def entry_weights(graph: CSRGraph, edge_weight: Optional[torch.Tensor], fill: fl
     return out
 
 
+def mean_bwd_weights(graph: CSRGraph, tside: CSRSide, w_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-entry weights of the TRANSPOSED aggregation of a mean layer when it runs on dOut itself: ``scatter_mean``'s divisor
+    belongs to the target, i.e. to the GATHERED row of the by-source side -- ``w[p] = inv_count[col[p]]`` (times the entry's edge
+    weight, ``w_src``).  ``npi_entry_col_scale``; without edge weights computed once per graph and side (kept on the graph)."""
+    cache = graph.__dict__.setdefault("_mean_t_w", {})
+    key = id(tside)
+    if w_src is None and key in cache:
+        return cache[key]
+    dev = graph.device
+    inv = graph.inv_count(graph.by_dst)
+    out = torch.empty(max(tside.nnz_max, 1), dtype=torch.float32, device=dev)
+    check(load().npi_entry_col_scale(ptr(tside.col), ptr(tside.rowptr), ptr(inv), ptr(w_src), tside.n_rows, inv.numel(), tside.nnz_max,
+                                     ptr(out), stream_ptr(dev)), "npi_entry_col_scale")
+    if w_src is None:
+        cache[key] = out
+    return out
+
+
+def _aggregate_first_ok(sch: Schedule, f16: bool, weight: torch.Tensor, grad_out: torch.Tensor, tside: CSRSide, ws_bwd) -> bool:
+    """can the backward of an aggregate-then-project layer run as ``dX = (A^T dOut) W^T`` with the GEMM on fp16 x 2 -- the
+    transposed aggregation on dOut itself, writing the row scales of its output (``_backward_aggregate_first``)?"""
+    return (sch.aggregate_first_backward and f16 and isinstance(ws_bwd, Planes) and ws_bwd.f16 and grad_out.dtype == torch.float32 and grad_out.size(1) == 256
+            and segsum_scales_ok(tside, grad_out) and f16x2_shape(grad_out.size(0), grad_out.size(1), weight.size(0)))
+
+
+def _backward_aggregate_first(graph, tside: CSRSide, w_t: Optional[torch.Tensor], agg, weight, grad_out, ws_bwd: "Planes", want_w: bool,
+                              has_bias: bool, overlap: bool, k_valid=None):
+    """``dX = (A_w^T dOut) W^T`` instead of ``A_w^T (dOut W^T)`` -- the same number up to fp32 rounding (the aggregation is linear;
+    GCNConv's forward uses the same freedom).  What it buys on large graphs: the transposed aggregation now WRITES
+    the left operand of the backward's data GEMM, so it writes that operand's row scales too (``segsum(scales_out=)``) and the
+    GEMM runs on two fp16 pieces per operand -- three matrix products instead of six -- with no pass over dOut for its scales
+    (which arrive from outside the layer).  dW = agg^T dOut needs neither and goes first on the launch stream, so that it is
+    resident on every CU before the aggregation -- on the side stream -- fills the remaining wave slots (as before).
+    ``w_t``: per-entry weights of the transposed side (``mean_bwd_weights`` / the GCN norm).  Returns ``(dx, dw, db)``."""
+    dev = grad_out.device
+    N, Nout = grad_out.shape
+    t = torch.empty((N, Nout), dtype=torch.float32, device=dev)
+    t_scales = torch.empty(N, dtype=torch.float32, device=dev)
+    dw = db = None
+    if overlap and want_w:
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main)                                   # dOut (and the buffers above) are ready for the side stream
+        dw, db = linear_bwd_weight(agg, grad_out, want_bias=has_bias, shared=True, k_valid=k_valid)
+        with torch.cuda.stream(side):
+            segsum(graph, tside, grad_out, w=w_t, mean=False, out=t, scales_out=t_scales)
+        for buf in (grad_out, t, t_scales):
+            buf.record_stream(side)                              # allocated on main, used on side
+        main.wait_stream(side)
+    else:
+        if want_w:
+            dw, db = linear_bwd_weight(agg, grad_out, want_bias=has_bias, k_valid=k_valid)
+        segsum(graph, tside, grad_out, w=w_t, mean=False, out=t, scales_out=t_scales)
+    dx = linear_bwd_data(t, weight, ws=ws_bwd, dc_scales=t_scales)
+    return dx, dw, db
+
+
 # ---------------------------------------------------------------------------------------------
 # SAGEConv
 # ---------------------------------------------------------------------------------------------
@@ -632,7 +707,7 @@ class _SageConvFn(torch.autograd.Function):
         ctx.sch = sch
         ctx.k_rows = None
         f16 = (x.dtype == weight.dtype and x.size(1) == weight.size(0)
-               and _f16x2(graph.by_dst.n_rows, weight.size(0), weight.size(1), x.dtype) and segsum_scales_ok(graph.by_dst, x))
+               and _f16x2(sch, graph.by_dst.n_rows, weight.size(0), weight.size(1), x.dtype) and segsum_scales_ok(graph.by_dst, x))
         ctx.f16 = f16
         if f16:
             # large graphs, 256 features: the projection on two fp16 pieces per operand -- the aggregation writes the row scales of
@@ -640,10 +715,9 @@ class _SageConvFn(torch.autograd.Function):
             agg = torch.empty((graph.by_dst.n_rows, x.size(1)), dtype=x.dtype, device=x.device)
             scales = torch.empty(agg.size(0), dtype=torch.float32, device=x.device)
             segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True, out=agg, scales_out=scales)
-            wsf, _ = prepare_weight(weight, backward=False, f16=True)
-            # (the backward's dAgg = dOut W^T stays on the bf16 x 3 planes: the scales of dOut -- handed in from outside -- would
-            # cost a pass over it that takes what the three products give, EXPERIMENTS A34)
-            ctx.ws_bwd = prepare_weight(weight, backward=True)[1] if ctx.needs_input_grad[0] else None
+            # both fp16 x 2 copies of W in one call: the backward runs aggregate-first (_backward_aggregate_first), so its data GEMM
+            # takes the row scales the transposed aggregation writes -- no pass over dOut, which arrives from outside the layer
+            wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0], f16=True)
             out = linear_fwd(agg, weight, bias, relu=relu, ws=wsf, a_scales=scales)
             ctx.k_valid = None
             ctx.save_for_backward(agg, weight, *([out] if relu else []))
@@ -701,12 +775,18 @@ class _SageConvFn(torch.autograd.Function):
         if ctx.relu:                                            # threshold_backward, as F.relu's autograd does it
             grad_out = relu_backward(grad_out, ctx.saved_tensors[2])
         dx = dw = db = None
+        if want_x and _aggregate_first_ok(ctx.sch, ctx.f16, weight, grad_out, tside(), ctx.ws_bwd):
+            ts = tside()
+            dx, dw, db = _backward_aggregate_first(graph, ts, mean_bwd_weights(graph, ts, ctx.w_src), agg, weight, grad_out, ctx.ws_bwd,
+                                                   want_w, ctx.has_bias, overlap, ctx.k_valid)
+            return dx, dw, db, None, None, None, None
+        ws_bwd = ctx.ws_bwd if not (isinstance(ctx.ws_bwd, Planes) and ctx.ws_bwd.f16) else None     # (fp16 x 2 planes: not for this order)
         if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)   # aggT dOut, colsum
         if want_x:
             # dAgg = dOut W^T, pre-divided by the in-count of its row (fused epilogue), then
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
-            dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst), ws=ctx.ws_bwd)
+            dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst), ws=ws_bwd)
             if ctx.k_rows is not None:
                 dagg = dagg[:, : ctx.k_rows]                                 # (the pad columns of dAgg: dOut times zero rows)
             if overlap:
@@ -911,14 +991,13 @@ class _GcnAggFirstFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.sch = sch
         if (x.dtype == weight.dtype and x.size(1) == weight.size(0) and segsum_scales_ok(graph.by_dst, x)
-                and _f16x2(graph.by_dst.n_rows, weight.size(0), weight.size(1), x.dtype)):
+                and _f16x2(sch, graph.by_dst.n_rows, weight.size(0), weight.size(1), x.dtype)):
             # large graphs, 256 features: the projection on two fp16 pieces per operand, the row scales written by the aggregation
-            # (as in _SageConvFn.forward; the backward keeps the bf16 x 3 planes)
+            # (as in _SageConvFn.forward; the backward aggregates first as well)
             agg = torch.empty((graph.by_dst.n_rows, x.size(1)), dtype=x.dtype, device=x.device)
             scales = torch.empty(agg.size(0), dtype=torch.float32, device=x.device)
             segsum(graph, graph.by_dst, x, w=norm.by_dst, out=agg, scales_out=scales)
-            wsf, _ = prepare_weight(weight, backward=False, f16=True)
-            ctx.ws_bwd = prepare_weight(weight, backward=True)[1] if ctx.needs_input_grad[0] else None
+            wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0], f16=True)
             out = linear_fwd(agg, weight, bias, ws=wsf, a_scales=scales)
             ctx.k_valid = None
             ctx.f16 = True
@@ -952,14 +1031,19 @@ class _GcnAggFirstFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
         overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
-        if not overlap and _layer_calls_ok() and (want_w or want_x) and grad_out.dtype == torch.float32:
+        if not overlap and _layer_calls_ok() and (want_w or want_x) and grad_out.dtype == torch.float32 and not ctx.f16:
             dx, dw, db = conv_bwd(graph.by_src if want_x else graph.by_dst, grad_out, None, agg, weight, None, norm.by_src,
                                   ctx.ws_bwd, want_x, want_w, ctx.has_bias)
             return dx, dw, db, None, None
+        if want_x and _aggregate_first_ok(ctx.sch, ctx.f16, weight, grad_out, graph.by_src, ctx.ws_bwd):
+            dx, dw, db = _backward_aggregate_first(graph, graph.by_src, norm.by_src, agg, weight, grad_out, ctx.ws_bwd, want_w,
+                                                   ctx.has_bias, overlap, ctx.k_valid)
+            return dx, dw, db, None, None
+        ws_bwd = ctx.ws_bwd if not (isinstance(ctx.ws_bwd, Planes) and ctx.ws_bwd.f16) else None
         if want_w and not overlap:
             dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)
         if want_x:
-            dagg = linear_bwd_data(grad_out, weight, ws=ctx.ws_bwd)
+            dagg = linear_bwd_data(grad_out, weight, ws=ws_bwd)
             if overlap:                                                        # see _SageConvFn.backward
                 dev = grad_out.device
                 main = torch.cuda.current_stream(dev)
@@ -1168,7 +1252,7 @@ def gat_aggregate_fused(side: CSRSide, table, table2, C, a_dst, att2, slope, bia
     m = torch.empty((side.n_rows, 1), dtype=torch.float32, device=dev)
     s = torch.empty((side.n_rows, 1), dtype=torch.float32, device=dev)
     with _tag_events("gat_fwd_aggregate", dev):
-        check(load().npi_gat_aggregate_fused_ex2(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
+        check(load().npi_gat_aggregate_fused(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
                                                  side.n_rows, side.nnz_max, ptr(table), table.stride(0), ptr(table2),
                                                  table.size(0) if table2 is not None else 0, ptr(out), out.stride(0), C,
                                                  ptr(a_dst.contiguous()), ptr(_f32c(att2.reshape(-1), "att")), float(slope), ptr(bias),
@@ -1213,7 +1297,7 @@ def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_
             scales_out.fill_(1.0)
         return out.zero_(), dz
     with _tag_events("gat_bwd_fused", dev):
-        check(load().npi_gat_backward_fused_heads_ex2(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
+        check(load().npi_gat_backward_fused_heads(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
                                                       side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
                                                       dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
                                                       out.stride(0), H, C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
@@ -1287,7 +1371,7 @@ class _GatConvFn(torch.autograd.Function):
         # x_scales (row_scales(x): computed once for a feature matrix that does not change between steps, or handed on by the
         # layer in front): the projection on two fp16 pieces per operand
         _check_scales(x_scales, x.size(0), "gat_conv(x_scales=)")
-        xs = x_scales if (x_scales is not None and _f16x2(x.size(0), weight.size(0), weight.size(1), x.dtype)) else None
+        xs = x_scales if (x_scales is not None and _f16x2(sch, x.size(0), weight.size(0), weight.size(1), x.dtype)) else None
         if H == 1 and sch.gat_scores_epilogue and linear_fwd_scores_ok(x, weight):
             hfeat, a_dst, a_src = linear_fwd_scores(x, weight, att2, a_scales=xs)   # x @ W, both scores in its store epilogue
         else:
@@ -1349,7 +1433,7 @@ class _GatConvFn(torch.autograd.Function):
                      and x.dtype == torch.float32 and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight))
             # dX's GEMM on two fp16 pieces per operand: the row scales of d hfeat from the pass that writes it (256 channels)
             dh_scales = (torch.empty(N, dtype=torch.float32, device=dev)
-                         if rank2 and H * C == 256 and _f16x2(N, H * C, weight.size(0), x.dtype) else None)
+                         if rank2 and H * C == 256 and _f16x2(sch, N, H * C, weight.size(0), x.dtype) else None)
             dh, dz = gat_backward_fused_packed(sr, grad_out, None, hfeat, C, tpack, a_src, slope, out=dh, H=H, scales_out=dh_scales)
             dz = dz.view(-1, H)
             if rank2:

@@ -140,17 +140,10 @@ class CSRSide:
         self._carry.clear()
 
 
-#: capacity (entries) from which a NEW side gets 256-entry items when the caller names no item size; None = the library's rule
-#: (``npi_item_edges``: 2^22).  The library keeps no such state (ABI 3); tests lower this to reach the 256-entry items at
-#: test-sized inputs.  It never affects a side that exists.
-ITEM_SWITCH_ENTRIES: Optional[int] = None
-
-
 def item_hint(nnz_max: int) -> int:
-    """Recommended item size for a new CSR of this capacity (``npi_item_edges``: 64 below 2^22 entries, else 256).
-    Asked ONCE, when a side is built; the side then carries its own value."""
-    if ITEM_SWITCH_ENTRIES is not None:
-        return 64 if int(nnz_max) < ITEM_SWITCH_ENTRIES else 256
+    """Recommended item size for a new CSR of this capacity (``npi_item_edges``, a pure function: 64 below 2^22 entries, else
+    256).  Asked ONCE, when a side is built without ``item=``; the side then carries its own value.  Neither the library nor this
+    module keeps a threshold that could move (``CSRGraph(item=)`` / ``build_side(item=)`` name another size explicitly)."""
     return int(load().npi_item_edges(int(nnz_max)))
 
 

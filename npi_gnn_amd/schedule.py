@@ -9,6 +9,7 @@ a process-wide switch or an environment variable to pick a path.  Each alternati
 from __future__ import annotations
 
 from dataclasses import dataclass, replace
+from typing import Optional
 
 
 @dataclass(frozen=True)
@@ -19,6 +20,14 @@ class Schedule:
     #: HBM-bound passes of the GATConv backward under its GEMMs.  Only from ``overlap_min_rows`` rows on.
     overlap_streams: bool = True
     overlap_min_rows: int = 100_000
+    #: rows from which the f32 projection GEMMs of the single-GPU layers run on two fp16 pieces per operand (NPI_GEMM_SPLIT_F16X2:
+    #: three matrix products per tile pair instead of six, the same f32-rounding-level error -- 256 features, where the launch
+    #: that writes the left operand writes its row scales too); None: never.  Below, the GEMMs are launch-bound
+    f16x2_min_rows: Optional[int] = 100_000
+    #: large SAGEConv / GCNConv layers whose forward projection runs on fp16 x 2 (256 features): the backward as
+    #: ``dX = (A^T dOut) W^T`` -- the transposed aggregation on dOut itself, writing the row scales of its output, then the data GEMM
+    #: on fp16 x 2 (three matrix products instead of six) -- instead of ``A^T (dOut W^T)`` with the GEMM on bf16 x 3
+    aggregate_first_backward: bool = True
     #: one-head GATConv: the attention terms of dX in the store epilogue of its GEMM (rank 2) instead of a read-modify-write pass
     #: over d hfeat; from ``gat_rank2_min_rows`` rows on (below, the three [2, .] products cost more than the pass they replace)
     gat_rank2_epilogue: bool = True

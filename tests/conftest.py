@@ -20,11 +20,11 @@ def dev():
     return torch.device("cuda:0")
 
 
-# A CSR carries its own item size (64 or 256 entries); graph.ITEM_SWITCH_ENTRIES only moves the HINT for new builds (default:
-# 64-entry items below 2^22 entries of capacity; the library itself keeps no such state since ABI 3).  The kernel test modules below carry cases "just above 2^20 entries" that
-# exist to exercise the 256-ENTRY items (row ends on item boundaries, hub rows cut over many items): they run with the hint
-# switching at 2^20, so that both item sizes stay covered at test-sized inputs.  Changing the hint never affects a CSR that
-# already exists (tests/test_gpu_parity.py::test_a_csr_keeps_its_item_size_when_the_hint_moves).
+# A CSR carries its own item size (64 or 256 entries); graph.item_hint only names the size of NEW builds that pass no `item=` (the
+# library's rule: 64-entry items below 2^22 entries of capacity).  The kernel test modules below carry cases "just above 2^20
+# entries" that exist to exercise the 256-ENTRY items (row ends on item boundaries, hub rows cut over many items): for them the
+# hint FUNCTION is replaced by a stand-in that switches at 2^20, so that both item sizes stay covered at test-sized inputs.  The
+# product keeps no threshold a test (or an import) could move: tests/test_boundary_cpu.py::test_no_module_level_switch_on_the_layer_path.
 _ITEMS_AT_2P20 = ("test_gpu_fuzz", "test_gpu_parity", "test_gpu_gat")
 
 
@@ -35,6 +35,7 @@ def _item_size_switch(request):
         yield
         return
     from npi_gnn_amd import graph as NG
-    prev, NG.ITEM_SWITCH_ENTRIES = NG.ITEM_SWITCH_ENTRIES, 1 << 20
+    prev = NG.item_hint
+    NG.item_hint = lambda nnz_max: 64 if int(nnz_max) < (1 << 20) else 256
     yield
-    NG.ITEM_SWITCH_ENTRIES = prev
+    NG.item_hint = prev

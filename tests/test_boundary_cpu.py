@@ -60,7 +60,7 @@ def test_ctypes_prototypes_have_the_headers_argument_lists():
 
 def test_size_queries_without_gpu():
     lib = _lib.load()
-    assert lib.npi_abi_version() == 3
+    assert lib.npi_abi_version() == 4
     # the item size is an argument (a property of each CSR); npi_item_edges is only the HINT for a new CSR, a pure function:
     # 64-entry items below 2^22 entries of capacity, 256-entry items from there on
     T = 1 << 22
@@ -80,7 +80,7 @@ def test_size_queries_without_gpu():
 
 def test_argument_errors_do_not_need_a_gpu():
     lib = _lib.load()
-    rc = lib.npi_segsum_ex(None, None, None, 64, None, -1, 0, None, 0, None, 0, None, 0, 4, 0, 0, None, None, None)
+    rc = lib.npi_segsum_ex(None, None, None, 64, None, -1, 0, None, 0, None, 0, None, 0, 4, 0, 0, None, None, None, None)
     assert rc == -1
     assert b"npi_segsum" in lib.npi_last_error()
 
@@ -96,10 +96,10 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         # an item size that does not exist is refused by the build and by every consumer of item_row
         "npi_csr_build_ex (item)": lambda: lib.npi_csr_build_ex(8, 8, 4, 4, 4, 1, 0, 1, 8, 8, 8, 8, 8, 100, 8, 8, 1 << 20, N),
         "npi_csr_filter": lambda: lib.npi_csr_filter(8, 8, 8, 8, 8, 8, 4, 8, 8, 8, 8, 8, 8, 0, 8, 8, N),
-        "npi_segsum_ex (item)": lambda: lib.npi_segsum_ex(8, 8, 8, 128, N, 4, 16, 8, 4, N, 0, 8, 4, 4, 0, 0, N, 8, N),
+        "npi_segsum_ex (item)": lambda: lib.npi_segsum_ex(8, 8, 8, 128, N, 4, 16, 8, 4, N, 0, 8, 4, 4, 0, 0, N, 8, N, N),
         "npi_gat_aggregate_scores": lambda: lib.npi_gat_aggregate_scores(8, 8, 8, 65, 4, 16, 8, 4, N, 0, 8, 4, 4, 8, 8, 8, N, 0, 8, N),
         "npi_gat_backward_fused_heads": lambda: lib.npi_gat_backward_fused_heads(8, 8, 8, 8, 0, 4, 16, 16, 4, N, 0, 16, 4, 16, 4, 1, 4, 16,
-                                                                                 16, 0.2, 16, 16, N),
+                                                                                 16, 0.2, 16, 16, N, N),
         "npi_colsum": lambda: lib.npi_colsum(N, 0, -1, 8, N, N, 0, N),
         "npi_gat_scores": lambda: lib.npi_gat_scores(N, 0, N, 8, 0, 4, N, N, N),
         "npi_topk_score": lambda: lib.npi_topk_score(N, 0, N, 8, 0, N, N),
@@ -114,12 +114,12 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_gat_aggregate_ex": lambda: lib.npi_gat_aggregate_ex(8, 8, 8, 64, 4, 16, 8, 4, N, 0, 8, 4, 1, 4, 8, 8, 8, 8, 0.2, 0, N, N, N,
                                                                  N, 8, N, 8, N),
         "npi_seg_rowsum_ex": lambda: lib.npi_seg_rowsum_ex(N, N, N, N, -1, 0, 1, N, N, 0, N),
-        "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, 64, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N),       # bad split
-        "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N),
-        "npi_linear_bwd_data_ex": lambda: lib.npi_linear_bwd_data_ex(N, 0, N, 0, N, N, 0, 8, 8, -3, 0, 0, N, 0, N),
+        "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, 64, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N, N),       # bad split
+        "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N, N),
+        "npi_linear_bwd_data_ex": lambda: lib.npi_linear_bwd_data_ex(N, 0, N, 0, N, N, 0, 8, 8, -3, 0, 0, N, 0, N, N),
         "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 0, 1, N),
         # round 4: the row-dot epilogue serves one column tile (N = 128 / 256) only; the preparation launch wants K, N % 16 == 0
-        "npi_linear_fwd_scores": lambda: lib.npi_linear_fwd_scores(16, 256, 16, 192, 16, 16, 192, 16, 16, 1000, 256, 192, N, 0, N),
+        "npi_linear_fwd_scores": lambda: lib.npi_linear_fwd_scores(16, 256, 16, 192, 16, 16, 192, 16, 16, 1000, 256, 192, N, 0, N, N),
         "npi_linear_prepare": lambda: lib.npi_linear_prepare(16, 256, 178, 128, 3, 0, 16, 1 << 20, N),
         "npi_hold_cus": lambda: lib.npi_hold_cus(1000, 10, N, N),
         "npi_gat_edge_grad_ex": lambda: lib.npi_gat_edge_grad_ex(N, N, N, 4, 16, N, 4, N, 0, N, 4, 0, 4, N, N, N, N, N, 0.2, 1, N, N, N),
@@ -131,18 +131,55 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         assert stem.encode() in lib.npi_last_error(), (name, lib.npi_last_error())
     # a caller workspace that is too small is refused before anything is launched (status -3), and sized by a query
     assert lib.npi_linear_workspace_bytes(256, 256) >= 6 * 256 * 256 and lib.npi_linear_workspace_bytes(0, 8) == -1
-    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 0, 16, 100, N) == -3
+    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 0, 16, 100, N, N) == -3
     assert b"workspace" in lib.npi_last_error()
-    assert lib.npi_linear_bwd_data_ex(16, 256, 16, 256, N, 16, 256, 128, 256, 256, 0, 0, 24, 10 ** 9, N) == -3   # misaligned
+    assert lib.npi_linear_bwd_data_ex(16, 256, 16, 256, N, 16, 256, 128, 256, 256, 0, 0, 24, 10 ** 9, N, N) == -3   # misaligned
     assert lib.npi_linear_prepare(16, 256, 256, 256, 3, 0, 16, lib.npi_linear_workspace_bytes(256, 256), N) == -3     # both copies: 2 x
     assert lib.npi_linear_fwd_scores_supported(1000, 256, 256) == 1 and lib.npi_linear_fwd_scores_supported(1000, 256, 192) == 0
     # NPI_GEMM_WORKSPACE_PREPARED (8) without a workspace: refused like every call without one (ABI 3)
-    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 8, N, 0, N) == -3
+    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 8, N, 0, N, N) == -3
     assert lib.npi_linear_bwd_weight_workspace_elems(-1, 8, 8) == -1
     # ABI 3: the workspace is REQUIRED (nothing is allocated inside a call); a null one is refused with the workspace status
-    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 0, N, 0, N) == -3
+    assert lib.npi_linear_fwd_ex(16, 256, 16, 256, N, N, 16, 256, 128, 256, 256, 0, 0, 0, N, 0, N, N) == -3
     # the row-dot epilogue needs >= 4 k-steps per tile: K = 32 is refused, K = 64 is served
     assert lib.npi_linear_fwd_scores_supported(1000, 32, 128) == 0 and lib.npi_linear_fwd_scores_supported(1000, 64, 128) == 1
+
+
+def test_no_module_level_switch_on_the_layer_path():
+    """the default results of a model must not depend on module globals another import can move.  The three
+    that survived round 5 -- functional.GEMM_FLAGS, functional.F16X2_MIN_ROWS, graph.ITEM_SWITCH_ENTRIES -- are gone: the GEMM
+    arithmetic is a per-call ``flags`` argument / ``Schedule.f16x2_min_rows``, the item size ``CSRGraph(item=)``; and no module of
+    the package assigns an upper-case module attribute from inside a function (``global X`` / ``module.X = ...``) except the
+    documented debug and profiling hooks."""
+    import ast
+    import npi_gnn_amd.functional as NF
+    import npi_gnn_amd.graph as NG
+    from npi_gnn_amd.schedule import DEFAULT, Schedule
+    for mod, names in ((NF, ("GEMM_FLAGS", "F16X2_MIN_ROWS")), (NG, ("ITEM_SWITCH_ENTRIES",))):
+        for n in names:
+            assert not hasattr(mod, n), f"{mod.__name__}.{n} is back"
+    assert DEFAULT.f16x2_min_rows == 100_000 and DEFAULT.aggregate_first_backward is True
+    with pytest.raises(Exception):
+        DEFAULT.f16x2_min_rows = 0                                  # a Schedule is frozen: a layer's arrangement cannot be moved under it
+    assert Schedule.__dataclass_params__.frozen
+    hooks = {"_DEBUG", "_PROFILE", "_PROFILE_TAGS", "_PROFILE_GEMM", "_COMM_PROFILE", "ALWAYS_COMMUNICATE", "_LIB"}
+    pkg = os.path.join(ROOT, "npi_gnn_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        upper_globals = {t.id for node in tree.body if isinstance(node, (ast.Assign, ast.AnnAssign))
+                         for t in (node.targets if isinstance(node, ast.Assign) else [node.target])
+                         if isinstance(t, ast.Name) and t.id.isupper()}
+        # mutable-by-design module state must be declared with `global` somewhere: none beyond the hooks
+        declared = {n for node in ast.walk(tree) if isinstance(node, ast.Global) for n in node.names}
+        assert declared <= hooks | {"_lib", "_err"}, (fn, declared - hooks)
+        # and no upper-case module constant is read through `functional.X` / `graph.X` by another module of the package
+        src = open(os.path.join(pkg, fn)).read()
+        for other, names in (("NF", ("GEMM_FLAGS", "F16X2_MIN_ROWS")), ("NG", ("ITEM_SWITCH_ENTRIES",))):
+            for n in names:
+                assert n not in src, (fn, n)
+        del upper_globals
 
 
 def test_the_library_allocates_nothing_and_keeps_no_state():

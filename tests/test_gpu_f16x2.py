@@ -1,6 +1,6 @@
 """The f32 projection GEMMs on TWO fp16 pieces per operand (NPI_GEMM_SPLIT_F16X2: three matrix products per tile pair instead of the
 six of the bf16 x 3 split; csrc/gemm_f32.hip, EXPERIMENTS A33 / A34): accuracy against fp64 at the level of an f32 matmul, the
-power-of-two row scales (npi_row_scales; written by the aggregation launch itself through npi_segsum_ex2), and the layers that
+power-of-two row scales (npi_row_scales; written by the aggregation launch itself through npi_segsum_ex), and the layers that
 use the arithmetic.  The reference's op is torch.matmul(aggr_out, self.weight) (PyG 1.4.2 SAGEConv.update; call sites
 src/classes.py:62,66,70)."""
 import math
@@ -84,7 +84,7 @@ def test_fp16x2_non_finite_operands_behave_as_under_the_bf16_split(dev):
 
 
 def test_aggregation_writes_the_row_scales_its_projection_needs(dev):
-    """npi_segsum_ex2: the finished rows' power-of-two scales from the aggregation launch itself -- bit-equal to a pass over the
+    """npi_segsum_ex: the finished rows' power-of-two scales from the aggregation launch itself -- bit-equal to a pass over the
     finished matrix (npi_row_scales), for mean / weighted sums, hub rows cut across items, empty rows, both item sizes"""
     N, E = 30_000, 400_000
     g = torch.Generator().manual_seed(5)
@@ -105,9 +105,10 @@ def test_aggregation_writes_the_row_scales_its_projection_needs(dev):
 
 @pytest.mark.parametrize("kind", ["sage", "gcn"])
 def test_layers_on_fp16x2_projections_match_the_oracle(dev, kind):
-    """F16X2_MIN_ROWS = 0: the forward projection of SAGEConv / GCNConv (aggregate first) at 256 features on the fp16 x 2 kernel,
-    the scales from the aggregation launch -- outputs and every gradient at the layers' own bars, and within rounding of the
-    bf16 x 3 run"""
+    """Schedule(f16x2_min_rows=0): both projections of SAGEConv / GCNConv (aggregate first) at 256 features on the fp16 x 2 kernel --
+    the forward's row scales from the aggregation launch, the backward run aggregate-first (dX = (A^T dOut) W^T) with the scales
+    from the transposed aggregation -- outputs and every gradient at the layers' own bars, and within rounding of the bf16 x 3 run;
+    Schedule(aggregate_first_backward=False): the backward in PyG's literal order on bf16 x 3, the same numbers"""
     N, E, F = 3000, 30_000, 256
     g = torch.Generator().manual_seed(6)
     ei = torch.randint(0, N, (2, E), generator=g)
@@ -117,19 +118,22 @@ def test_layers_on_fp16x2_projections_match_the_oracle(dev, kind):
     with torch.no_grad():
         conv.bias.copy_(torch.randn(F, generator=g) * 0.1)
     graph = npi.CSRGraph(ei.to(dev), N)
+    from npi_gnn_amd.schedule import DEFAULT
     res = {}
-    old = NF.F16X2_MIN_ROWS
-    try:
-        for rows in (None, 0):
-            NF.F16X2_MIN_ROWS = rows
-            conv.zero_grad()
-            xd = x.to(dev).requires_grad_(True)
-            out = conv(xd, graph)
-            out.backward(go.to(dev))
-            res[rows] = (out.detach(), xd.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
-    finally:
-        NF.F16X2_MIN_ROWS = old
+    for rows, sch in ((None, DEFAULT.but(f16x2_min_rows=None)), (0, DEFAULT.but(f16x2_min_rows=0)),
+                      ("literal", DEFAULT.but(f16x2_min_rows=0, aggregate_first_backward=False))):
+        conv.schedule = sch
+        conv.zero_grad()
+        xd = x.to(dev).requires_grad_(True)
+        out = conv(xd, graph)
+        out.backward(go.to(dev))
+        res[rows] = (out.detach(), xd.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
     assert not torch.equal(res[0][0], res[None][0]) and rel_max(res[0][0], res[None][0]) <= 2e-6     # another arithmetic, the same numbers
+    assert torch.equal(res["literal"][0], res[0][0])                          # the forward does not depend on the backward's order
+    assert not torch.equal(res["literal"][1], res[0][1]) and rel_max(res["literal"][1], res[0][1]) <= 5e-6
+    assert rel_max(res[None][1], res[0][1]) <= 5e-6
+    for k in (2, 3):                                                         # dW / db: the same launch on the same operands either way
+        assert torch.equal(res["literal"][k], res[0][k])
     x6, W6, b6 = (t.detach().cpu().double().clone().requires_grad_(True) for t in (x, conv.weight, conv.bias))
     ref = (R.sage_conv if kind == "sage" else R.gcn_conv)(x6, ei, W6, b6)
     ref.backward(go.double())
@@ -141,7 +145,7 @@ def test_layers_on_fp16x2_projections_match_the_oracle(dev, kind):
 
 def test_gat_backward_projects_on_fp16x2_with_scales_from_the_fused_pass(dev):
     """one-head GATConv, 256 channels: dX = d hfeat W^T (+ the rank-2 attention terms in the store epilogue) on the fp16 x 2 kernel,
-    the row scales of d hfeat written by the fused by-source pass (npi_gat_backward_fused_heads_ex2) -- bit-equal to a pass over
+    the row scales of d hfeat written by the fused by-source pass (npi_gat_backward_fused_heads) -- bit-equal to a pass over
     d hfeat; every gradient at the layer's bars against the oracle and within rounding of the bf16 x 3 run"""
     from npi_gnn_amd.schedule import DEFAULT
     N, E, Fi, C = 3000, 40_000, 128, 256
@@ -154,18 +158,13 @@ def test_gat_backward_projects_on_fp16x2_with_scales_from_the_fused_pass(dev):
     b = torch.randn(C, generator=g) * 0.1
     go = torch.randn(N, C, generator=g)
     graph = npi.CSRGraph(ei.to(dev), N)
-    sch = DEFAULT.but(gat_rank2_min_rows=0)
     res = {}
-    old = NF.F16X2_MIN_ROWS
-    try:
-        for rows in (None, 0):
-            NF.F16X2_MIN_ROWS = rows
-            xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
-            out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=1, schedule=sch)
-            out.backward(go.to(dev))
-            res[rows] = (out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad)
-    finally:
-        NF.F16X2_MIN_ROWS = old
+    for rows in (None, 0):
+        sch = DEFAULT.but(gat_rank2_min_rows=0, f16x2_min_rows=rows)
+        xd, Wd, ad, bd = (t.to(dev).requires_grad_(True) for t in (x, W, att, b))
+        out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=1, schedule=sch)
+        out.backward(go.to(dev))
+        res[rows] = (out.detach(), xd.grad, Wd.grad, ad.grad, bd.grad)
     assert torch.equal(res[0][0], res[None][0])                              # the forward is untouched
     assert not torch.equal(res[0][1], res[None][1]) and rel_max(res[0][1], res[None][1]) <= 2e-6
     for k in (2, 3, 4):
@@ -201,22 +200,19 @@ def test_gat_stack_hands_row_scales_from_layer_to_layer(dev):
     bs = [torch.randn(F, generator=g) * 0.1 for _ in range(2)]
     go = torch.randn(N, F, generator=g)
     graph = npi.CSRGraph(ei.to(dev), N)
+    from npi_gnn_amd.schedule import DEFAULT
     res = {}
-    old = NF.F16X2_MIN_ROWS
-    try:
-        for mode in ("plain", "scales"):
-            NF.F16X2_MIN_ROWS = None if mode == "plain" else 0
-            P = [t.to(dev).requires_grad_(True) for t in Ws + atts + bs]
-            xd = x.to(dev).requires_grad_(True)
-            h, hs = xd, (NF.row_scales(xd.detach()) if mode == "scales" else None)
-            for k in range(2):
-                h, hs = npi.gat_conv(h, graph, P[k], P[2 + k], P[4 + k], heads=1, relu=True, x_scales=hs, return_scales=True)
-                if mode == "scales":
-                    assert hs is not None and torch.equal(hs, NF.row_scales(h.detach()))
-            h.backward(go.to(dev))
-            res[mode] = [h.detach(), xd.grad] + [p.grad for p in P]
-    finally:
-        NF.F16X2_MIN_ROWS = old
+    for mode in ("plain", "scales"):
+        sch = DEFAULT.but(f16x2_min_rows=None if mode == "plain" else 0)
+        P = [t.to(dev).requires_grad_(True) for t in Ws + atts + bs]
+        xd = x.to(dev).requires_grad_(True)
+        h, hs = xd, (NF.row_scales(xd.detach()) if mode == "scales" else None)
+        for k in range(2):
+            h, hs = npi.gat_conv(h, graph, P[k], P[2 + k], P[4 + k], heads=1, relu=True, x_scales=hs, return_scales=True, schedule=sch)
+            if mode == "scales":
+                assert hs is not None and torch.equal(hs, NF.row_scales(h.detach()))
+        h.backward(go.to(dev))
+        res[mode] = [h.detach(), xd.grad] + [p.grad for p in P]
     for a, b in zip(res["scales"], res["plain"]):
         assert rel_max(a, b) <= 5e-6
     assert not torch.equal(res["scales"][0], res["plain"][0])

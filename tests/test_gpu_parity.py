@@ -65,10 +65,10 @@ def test_csr_build_is_bit_exact(dev, N, E, loops):
         assert np.array_equal(side.col.cpu().numpy()[:nnz], col)
         assert np.array_equal(side.eid.cpu().numpy()[:nnz], eid)
         assert np.array_equal(side.rowidx.cpu().numpy()[:nnz], rowidx)
-        # item_row[i] = row holding entry item_edges * i; the side carries its item size (the hint at build time: 64-entry items
-        # below graph.ITEM_SWITCH_ENTRIES of capacity -- 2^20 in this module, tests/conftest.py -- else 256)
+        # item_row[i] = row holding entry item_edges * i; the side carries its item size (the hint at build time: in this module a
+        # stand-in that switches at 2^20 entries of capacity, tests/conftest.py)
         item_edges = side.item
-        assert item_edges == NG.item_hint(side.nnz_max) == (64 if side.nnz_max < (NG.ITEM_SWITCH_ENTRIES or 1 << 22) else 256)
+        assert item_edges == NG.item_hint(side.nnz_max) == (64 if side.nnz_max < (1 << 20) else 256)
         assert side.n_items == -(-side.nnz_max // item_edges)
         ir = side.item_row.cpu().numpy()
         for i in range(1, side.n_items):
@@ -1100,28 +1100,22 @@ def test_in_launch_chain_resolution_under_load_and_reuse(dev, item_entries):
     assert int(counters.abs().sum()) == 0
 
 
-def test_a_csr_keeps_its_item_size_when_the_hint_moves(dev):
+def test_a_csr_carries_the_item_size_it_was_built_with(dev):
     """VERDICT r3 item 4 / ADVICE r3 (medium): the item size used to be re-derived at every LAUNCH from a process-wide
-    threshold, so a CSR with 2^20 <= capacity < 2^22 built before that threshold moved and aggregated after it was
-    walked with the wrong geometry (wrong sums, out-of-range carry writes).  Now the side carries it: build with 64-entry
-    items, move the hint so that a fresh build of this capacity would take 256, and every consumer of the OLD side -- SAGE
-    aggregation (plain, weighted, bf16), the GAT forward and fused backward, the whole layers -- still matches the oracle;
-    the same the other way round."""
-    prev = NG.ITEM_SWITCH_ENTRIES                     # (since ABI 3 the hint's threshold is host-side state of graph.py only)
+    threshold, so a CSR built before that threshold moved and aggregated after it was walked with the wrong geometry.  Now
+    the side carries it and NOTHING that could move exists: the same edge list built with 64-entry and with
+    256-entry items (``CSRGraph(item=)``; the hint for this capacity names one of the two) -- every consumer of either side, SAGE
+    aggregation (plain, weighted, bf16), the GAT forward and fused backward, the whole layers, matches the oracle."""
     N, E, F = 3000, 1_200_000, 64                     # capacity 2.4M entries: between the two thresholds used below
     ei = rand_edges(N, E, seed=7)
     x = torch.randn(N, F, generator=torch.Generator().manual_seed(1))
     go = torch.randn(N, F, generator=torch.Generator().manual_seed(2))
-    try:
-        for first, then in ((1 << 40, 1), (1, 1 << 40)):           # (every build takes 64) -> (every build takes 256), and back
-            NG.ITEM_SWITCH_ENTRIES = first
-            g = npi.CSRGraph(ei.to(dev), N)
-            item = g.by_dst.item
-            assert item == (64 if first > 1 else 256) and g.by_src.item == item
+    if True:
+        for item in (64, 256):
+            g = npi.CSRGraph(ei.to(dev), N, item=item)
+            assert g.by_dst.item == item and g.by_src.item == item and NG.item_hint(g.by_dst.nnz_max) in (64, 256)
             sage = npi.SAGEConv(F, F).to(dev)
             gat = npi.GATConv(F, F).to(dev)
-            NG.ITEM_SWITCH_ENTRIES = then                             # a NEW side of this capacity would now get the other size
-            assert NG.item_hint(g.by_dst.nnz_max) != item and g.by_dst.item == item
             xd = x.to(dev).requires_grad_(True)
             out = sage(xd, g)
             out.backward(go.to(dev))
@@ -1144,8 +1138,6 @@ def test_a_csr_keeps_its_item_size_when_the_hint_moves(dev):
             ref.backward(go.double())
             assert float((og.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-4
             assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-4 * max(1.0, float(xr.grad.abs().max()))
-    finally:
-        NG.ITEM_SWITCH_ENTRIES = prev
 
 
 @pytest.mark.parametrize("M,K,N", [(5085, 128, 128), (4096, 178, 128), (70_003, 256, 256), (20, 64, 64), (33, 96, 130), (1024, 128, 64)])

@@ -31,16 +31,17 @@ def test_no_environment_switch_selects_a_path():
     fields = set(Schedule.__dataclass_fields__)
     assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "gat_scores_epilogue",
                       "direct_hub_rows", "partial_stream", "split_projection", "gat_direct", "early_hub_gather", "gemm_reserve_cus",
-                      "split_projection_reserve_cus", "gat_src_rowsum_beside_dw", "gat_fused_stats"}
+                      "split_projection_reserve_cus", "gat_src_rowsum_beside_dw", "gat_fused_stats", "aggregate_first_backward",
+                      "f16x2_min_rows"}
     assert CONSERVATIVE == DEFAULT.but(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
                                        gat_rank2_epilogue=False)
 
 
-def _graph(dev, N=120_000, E=1_200_000, seed=5):
+def _graph(dev, N=120_000, E=1_200_000, seed=5, F=128):
     from npi_gnn_amd.synth import bipartite_edge_index
     ei = bipartite_edge_index(N, E, seed=seed).to(dev)
     g = torch.Generator(device=dev).manual_seed(seed)
-    return ei, npi.CSRGraph(ei, N), torch.randn(N, 128, device=dev, generator=g), torch.randn(N, 128, device=dev, generator=g)
+    return ei, npi.CSRGraph(ei, N), torch.randn(N, F, device=dev, generator=g), torch.randn(N, F, device=dev, generator=g)
 
 
 def _run(make, graph, x, go):
@@ -57,16 +58,21 @@ def _run(make, graph, x, go):
 @pytest.mark.parametrize("kind,alt", [
     ("sage", dict(overlap_streams=False)), ("sage", dict(overlap_min_rows=10 ** 9)),
     ("gcn", dict(overlap_streams=False)),
+    # 256 features from 100,000 rows on: both projections on fp16 x 2, the backward aggregate-first -- against PyG's literal order
+    # (dAgg GEMM on bf16 x 3, then the transposed aggregation), against bf16 x 3 throughout, and on one stream
+    ("sage256", dict(aggregate_first_backward=False)), ("gcn256", dict(aggregate_first_backward=False)),
+    ("sage256", dict(f16x2_min_rows=None)), ("sage256", dict(overlap_streams=False)), ("gcn256", dict(overlap_streams=False)),
     ("gat", dict(overlap_streams=False)), ("gat", dict(gat_rank2_epilogue=False)), ("gat", dict(gat_rank2_min_rows=10 ** 9)),
     ("gat", dict(gat_scores_epilogue=False)), ("gat", dict(gat_src_rowsum_beside_dw=True)), ("gat", dict(gat_fused_stats=False)),
 ])
 def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
-    ei, graph, x, go = _graph(dev)
+    ei, graph, x, go = _graph(dev, F=256 if kind.endswith("256") else 128)
     F = x.size(1)
-    cls = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[kind]
+    cls = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[kind[:-3] if kind.endswith("256") else kind]
     ref = _run(lambda: cls(F, F), graph, x, go)
     got = _run(lambda: cls(F, F, schedule=DEFAULT.but(**alt)), graph, x, go)
-    if "gat_scores_epilogue" in alt or "gat_fused_stats" in alt:         # the scores' dots / the parts of cut rows in another association
+    if "gat_scores_epilogue" in alt or "gat_fused_stats" in alt or "f16x2_min_rows" in alt:
+        # the scores' dots / the parts of cut rows in another association; the projection in another arithmetic
         assert float((got[0] - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
     else:
         assert torch.equal(got[0], ref[0])                               # the forward is the same launches

@@ -50,7 +50,7 @@ def test_hot_kernels_keep_the_occupancy_the_design_assumes(built):
     assert len(hot) == 1, list(seg)[:5]                       # f32 x 4, one chunk, unweighted, unguarded: the C4 kernel
     for n, m in hot.items():
         assert m["vgpr"] <= 64 and m["agpr"] == 0, (n, m)     # 8 waves / SIMD (512 VGPRs / 64)
-    # the same kernel when it also writes the finished rows' power-of-two scales (npi_segsum_ex2; the fp16 x 2 projection behind
+    # the same kernel when it also writes the finished rows' power-of-two scales (npi_segsum_ex; the fp16 x 2 projection behind
     # it): 7 waves / SIMD, no scratch -- at 8 it spilled three registers
     sc = {n: m for n, m in seg.items() if n.startswith("void npi::segsum_kernel<float, 4, 1, 0, 2>")}
     assert len(sc) == 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One SAGEConv layer 256 -> 256, forward + backward at the C4 size, with the projection GEMMs on six bf16 products (default up to
-round 5) or on three fp16 products (NPI_GEMM_SPLIT_F16X2), the row scales of the aggregate written by the aggregation launch or by
+round 5), the forward one on three fp16 products (NPI_GEMM_SPLIT_F16X2; round 5), or both (round 6: the backward aggregate-first), the row scales of the aggregate written by the aggregation launch or by
 a pass of their own.  Variant libraries through NPI_GNN_LIB.  usage: tools/f16x2_layer_probe.py [--separate-scales]"""
 import os, sys
 import torch
@@ -41,14 +41,17 @@ def t(n=20):
     return e0.elapsed_time(e1) / n
 
 
+from npi_gnn_amd.schedule import DEFAULT
+VARIANTS = {"bf16x3": DEFAULT.but(f16x2_min_rows=None), "fp16x2": DEFAULT.but(aggregate_first_backward=False),
+            "fp16x2+aggfirst": DEFAULT}
 res = {}
-for name, rows in (("bf16x3", None), ("fp16x2", 100_000), ("bf16x3 again", None), ("fp16x2 again", 100_000)):
-    NF.F16X2_MIN_ROWS = rows
+for name in ("bf16x3", "fp16x2", "fp16x2+aggfirst", "bf16x3 again", "fp16x2 again", "fp16x2+aggfirst again"):
+    conv.schedule = VARIANTS[name.split()[0]]
     ms = t()
     out = step().detach()
     res[name] = (ms, out, x.grad.clone(), conv.weight.grad.clone())
     print(f"{name}: {ms:.3f} ms / step", flush=True)
-a, b = res["bf16x3"], res["fp16x2"]
+a, b = res["bf16x3"], res["fp16x2+aggfirst"]
 idx = torch.arange(0, N, 997, device=dev)[:1000]
 print("out   max |fp16x2 - bf16x3| / max:", float((a[1] - b[1]).abs().max() / a[1].abs().max()))
 print("dX    max diff / max:", float((a[2] - b[2]).abs().max() / a[2].abs().max()))

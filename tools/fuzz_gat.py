@@ -52,8 +52,7 @@ for it in range(cases):
     graph = npi.CSRGraph(ei.to(dev), N, item=256 if big_items else 64, sort_columns=sort_columns)
     # every other pair of cases: dX's GEMM on two fp16 pieces per operand wherever the shape takes it (one head of 256 channels, the
     # rank-2 epilogue), the row scales from the fused backward pass -- the product switches it on from 100,000 rows
-    import npi_gnn_amd.functional as _NF
-    _NF.F16X2_MIN_ROWS = {"off": 100_000, "on": 0}.get(os.environ.get("FUZZ_F16", "toggle"), 0 if (it & 2) else 100_000)
+    f16_rows = {"off": 100_000, "on": 0}.get(os.environ.get("FUZZ_F16", "toggle"), 0 if (it & 2) else 100_000)
     drop = bool(rng.random() < 0.25)
     keep = ks = None
     if drop:
@@ -61,7 +60,7 @@ for it in range(cases):
         keep = gat_dropout_keep(graph, H, float(rng.choice([0.1, 0.5, 0.8])))
         nnz = int(graph.by_dst.rowptr[-1])
         ks = R.keep_scale_from_entries(ei, N, graph.by_dst.eid[:nnz].cpu(), graph.by_dst.rowidx[:nnz].cpu(), keep[:nnz].cpu())
-    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCHS[it & 1], keep=keep)
+    out = npi.gat_conv(xd, graph, Wd, ad, bd, heads=H, relu=relu, schedule=SCHS[it & 1].but(f16x2_min_rows=f16_rows), keep=keep)
     out.backward(go.to(dev))
     xr, Wr, ar, br = (t.clone().double().requires_grad_(True) for t in (x, W, att, b))
     ref = R.gat_conv(xr, ei, Wr, ar, br, heads=H, keep_scale=ks)
