@@ -826,6 +826,78 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
     }
 }
 
+// The same epilogue with FULL 128-byte lines per store instruction (round 6; EPI 0).  In the accumulator layout a wave's store
+// instruction writes 32 rows x 32 bytes (the lane pair li / li + 32 of a row): a quarter of 32 different lines -- tools/micro/
+// store_pattern.hip: 18 bytes per cycle and CU, against 51 when an instruction writes 8 rows x 128 bytes and 58 for whole rows.
+// So the four rows li = 4 a .. 4 a + 3 of a quad of lanes exchange their four 16-byte column groups first -- a 4 x 4 transpose of
+// 16-byte elements inside every quad, two butterfly stages of quad_perm DPP moves and selects (4 VALU instructions per register,
+// in a phase whose VALU is otherwise idle) -- after which lane r of the quad holds column group r of ALL four rows and instruction
+// g' stores row 4 a + g': the 8 lanes (r, lh) of a row write its 128 contiguous bytes.  The lane's columns no longer depend on the
+// register, so bias / column scale are read once per 32-column block; the row scales of the quad's four rows are broadcast inside
+// the quad.  The same operations on the same values in the same order as store_tile_t: bit-identical.
+__device__ __forceinline__ float qp_xor2(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xf, 0xf, true)); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float qp_xor1(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xf, 0xf, true)); }   // quad_perm [1,0,3,2]
+template <int TM, int TN, bool CS>
+__device__ __forceinline__ void store_tile_q(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
+                                             const f32x16 (&acc)[TM][TN], const float* __restrict__ bias_lds, const float (&rs)[TM],
+                                             float floor_, const float* __restrict__ cs_lds) {
+    const bool b1 = (li & 2) != 0, b0 = (li & 1) != 0;
+    const int r = li & 3;
+    const int co = 8 * r + 4 * lh;                    // this lane's four columns inside every 32-column block, after the exchange
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // the row scales of rows 4 a + g (lane g of the quad holds its own): quad_perm [g, g, g, g]
+        const float rsq[4] = {__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0x00, 0xf, 0xf, true)),
+                              __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0x55, 0xf, 0xf, true)),
+                              __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0xAA, 0xf, 0xf, true)),
+                              __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0xFF, 0xf, 0xf, true))};
+        float* __restrict__ rowbase = C + (int64_t)(mw + i * 32 + (li & ~3)) * ldc + nw + co;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float4 b = *reinterpret_cast<const float4*>(bias_lds + j * 32 + co);
+            float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (CS) cs = *reinterpret_cast<const float4*>(cs_lds + j * 32 + co);
+            float e[4][4];                            // [column group g -> row g' after the exchange][dword]
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e[g][c] = acc[i][j][4 * g + c];
+            // (a scheduling fence behind every exchange: left to itself hipcc hoists all 32 DPP moves of a block -- and of the next
+            // blocks -- to the front and needs 60 registers more than the kernel has: 224 bytes of scratch in the first build)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)               // lanes r <-> r ^ 2, groups g <-> g ^ 2
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float lo = e[g][c], hi = e[g + 2][c];
+                    const float tlo = qp_xor2(lo), thi = qp_xor2(hi);
+                    e[g][c] = b1 ? thi : lo;
+                    e[g + 2][c] = b1 ? hi : tlo;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2)            // lanes r <-> r ^ 1, groups g <-> g ^ 1
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float lo = e[g][c], hi = e[g + 1][c];
+                    const float tlo = qp_xor1(lo), thi = qp_xor1(hi);
+                    e[g][c] = b0 ? thi : lo;
+                    e[g + 1][c] = b0 ? hi : tlo;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {             // row 4 a + g: its columns 32 j + 8 r + 4 lh .. + 3
+                float4 q = make_float4(e[g][0], e[g][1], e[g][2], e[g][3]), v;
+                if constexpr (CS) { q.x *= cs.x; q.y *= cs.y; q.z *= cs.z; q.w *= cs.w; }
+                v.x = fmaf(q.x, rsq[g], b.x); v.y = fmaf(q.y, rsq[g], b.y);
+                v.z = fmaf(q.z, rsq[g], b.z); v.w = fmaf(q.w, rsq[g], b.w);
+                v.x = v.x < floor_ ? floor_ : v.x; v.y = v.y < floor_ ? floor_ : v.y;      // keeps NaN, like torch.relu
+                v.z = v.z < floor_ ? floor_ : v.z; v.w = v.w < floor_ ? floor_ : v.w;
+                *reinterpret_cast<float4*>(rowbase + (int64_t)g * ldc + j * 32) = v;
+            }
+        }
+    }
+}
+
 // A-operand staging of gemm_split_ws_kernel.  0: a thread takes 4 consecutive k of rows r and r + 64 (two float4) and stores
 // 8-byte pieces per plane (round 1; SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles).  1: a thread takes 8 consecutive k of ONE
 // row (two adjacent float4) and stores one 16-byte half row per plane; adjacent lanes hold the two halves of a row, so the 8
@@ -1321,9 +1393,15 @@ gemm_split_ws_kernel(SplitArgs a) {
         if (w.kt == nk - 1) {
             const unsigned long long e0_ = NPI_STAMP();
             if ((NPI_WS_PROBE & 4) == 0 || acc[0][0][0] == 12345.678f)
+            {
+            if constexpr (EPI == 0)       // full 128-byte lines per store instruction (store_tile_q)
+                store_tile_q<TM, TN, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc, bias_s[wave][tsel], rs, floor_,
+                                          cs_s[F16 ? wave : 0][tsel]);
+            else
             store_tile_t<TM, TN, EPI, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
                                            bias_s[wave][tsel], rs, floor_, r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1,
                                            cs_s[F16 ? wave : 0][tsel]);
+            }
             if constexpr (SC) {
                 const int par = tq & 1;
 #pragma unroll
