@@ -64,7 +64,7 @@ int npi_abi_version(void);
  *                                swap them.
  *   Columns with key == val (existing self loops) and columns with an id outside [0,N) are
  *   dropped; the latter also set bit 0 of status[0] -- except the padding column (-1, -1) of
- *   npi_filter_adj_ex, which is dropped silently.
+ *   npi_filter_adj, which is dropped silently.
  *   add_self_loops != 0 appends (i,i) as the LAST entry of every row.
  *
  *   rowptr[N+1]  : int32, rowptr[N] = nnz (device-side; nnz <= E + N)
@@ -487,10 +487,8 @@ int npi_gat_att_grad(const float* hfeat, int64_t ldh, const float* g_dst, const 
  * ------------------------------------------------------------------------------------------ */
 int npi_topk_score(const float* x, int64_t ldx, const float* w, int64_t N, int64_t F, float* score, void* stream);
 int npi_graph_bounds(const int64_t* batch, int64_t N, int64_t B, int32_t* graph_ptr, void* stream);
-int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
-                    int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, void* stream);
 /* max_nodes: an upper bound of the largest graph of the batch, when the caller knows one (0 = unknown) */
-int npi_topk_select_ex(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
+int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
                     int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, int64_t max_nodes, void* stream);
 /* The same selection for graphs of ANY size (npi_topk_select sorts a graph's scores in LDS: at most 16,384 nodes per graph,
  * bit 1 of its status word otherwise): two stable radix sorts of the whole batch on the device -- by score, descending, ties
@@ -501,29 +499,24 @@ int64_t npi_topk_sorted_workspace_bytes(int64_t N);
 int npi_topk_select_sorted(const float* score, const int64_t* batch, const int32_t* graph_ptr, int64_t N, int64_t B,
                            float ratio, int32_t* out_ptr, int32_t* perm, int32_t* remap, void* workspace,
                            int64_t workspace_bytes, void* stream);
+/* perm64 (may be NULL) receives perm as int64 -- the LongTensor TopKPooling returns -- without a cast launch */
 int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
                     const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
-                    float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream);
-/* the same; perm64 (may be NULL) receives perm as int64 -- the LongTensor TopKPooling returns -- without a cast launch */
-int npi_topk_gather_ex(const float* x, int64_t ldx, const float* score, const int64_t* batch,
-                    const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
                     float* xo, int64_t ldo, int64_t* batch_o, float* score_o, int64_t* perm64, void* stream);
-/* int32 workspace of npi_filter_adj / _ex: one count per tile of 2,048 edges, two spare words, then E words that receive the
+/* int32 workspace of npi_filter_adj: one count per tile of 2,048 edges, two spare words, then E words that receive the
  * new position of every input edge (-1: dropped) -- npi_filter_adj_newpos_offset(E) is where those start */
 int64_t npi_filter_adj_workspace_elems(int64_t E);
-int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
-                   int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, void* stream);
-/* npi_filter_adj with the output kept at the INPUT's length: pad_tail != 0 fills out_src / out_dst[count .. E) with -1.
+/* pad_tail != 0: the output kept at the INPUT's length -- fills out_src / out_dst[count .. E) with -1.
  * A (-1, -1) column is padding everywhere downstream -- npi_csr_build_ex drops it without raising the out-of-range flag,
  * npi_filter_adj skips it -- so a caller that knows the node counts (TopKPooling keeps ceil(ratio n_g) per graph) never
  * has to read the surviving-edge count back and the whole Net_1 step runs without a host synchronisation (and captures
  * into a HIP graph).  Negative ids in src / dst are always treated as dropped.  Output arrays must not alias the input. */
-int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
+int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                       int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace, int pad_tail, void* stream);
-int64_t npi_filter_adj_newpos_offset(int64_t E);   /* npi_filter_adj_ex: workspace[offset + e] = new position of input edge e, -1 if dropped */
+int64_t npi_filter_adj_newpos_offset(int64_t E);   /* npi_filter_adj: workspace[offset + e] = new position of input edge e, -1 if dropped */
 /* The by-target CSR of the POOLED graph from the CSR of its parent, without a sort: row perm[r'] of the parent with the
  * entries whose source survived (remap[col] >= 0), in the parent's order, self loop last; eid through newpos
- * (npi_filter_adj_ex's workspace tail).  Bit-identical to npi_csr_build_ex on the filtered edge list.  nnz_max_out = capacity
+ * (npi_filter_adj's workspace tail).  Bit-identical to npi_csr_build_ex on the filtered edge list.  nnz_max_out = capacity
  * of col_o / eid_o / rowidx_o (>= the surviving entries; E_in + n_out is what a fresh build would use); item_edges: the item
  * size of the NEW CSR (independent of the parent's); workspace int32 [npi_csr_filter_workspace_elems(n_out)];
  * n_out <= npi_csr_filter_max_rows(). */

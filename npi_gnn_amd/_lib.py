@@ -98,15 +98,12 @@ PROTOTYPES = {
     "npi_gat_att_grad": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "npi_topk_score": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_graph_bounds": (c_int, [_P, _I, _I, _P, _P]),
-    "npi_topk_select": (c_int, [_P, _P, _I, _I, c_float, _P, _P, _P, _P, _P]),
-    "npi_topk_select_ex": (c_int, [_P, _P, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
+    "npi_topk_select": (c_int, [_P, _P, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
     "npi_topk_sorted_workspace_bytes": (_I, [_I]),
     "npi_topk_select_sorted": (c_int, [_P, _P, _P, _I, _I, c_float, _P, _P, _P, _P, _I, _P]),
-    "npi_topk_gather": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
-    "npi_topk_gather_ex": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "npi_topk_gather": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "npi_filter_adj_workspace_elems": (_I, [_I]),
-    "npi_filter_adj": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
-    "npi_filter_adj_ex": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, c_int, _P]),
+    "npi_filter_adj": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, c_int, _P]),
     "npi_filter_adj_newpos_offset": (_I, [_I]),
     "npi_csr_filter_max_rows": (_I, []),
     "npi_csr_filter_workspace_elems": (_I, [_I]),

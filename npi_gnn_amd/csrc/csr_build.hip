@@ -41,7 +41,7 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ key_nodes,
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     int64_t k = key_nodes[e], v = val_nodes[e];
-    // (-1, -1) is a PADDING column: npi_filter_adj_ex keeps its output at the input's length and fills the tail with it,
+    // (-1, -1) is a PADDING column: npi_filter_adj(pad_tail) keeps its output at the input's length and fills the tail with it,
     // so that the edge count never has to be read back; dropped without raising the out-of-range flag
     const bool pad = (k == -1) & (v == -1);
     bool bad = !pad & ((k < 0) | (k >= N) | (v < 0) | (v >= n_cols));

@@ -622,14 +622,6 @@ typedef float f32x4r __attribute__((ext_vector_type(4)));      // native 128-bit
 typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
 constexpr int SK = 16;                             // k-step of the split kernel = one 32x32x16 MFMA block
-// Order of the 6 x TM x TN MFMAs of a k-step in the consumer waves.  0: tile by tile (six DEPENDENT MFMAs on one
-// accumulator back to back -- each waits for the previous one's result); 1: product by product over all tiles, so that
-// consecutive MFMAs are independent.  The per-accumulator order of the six products is the same: results are bit-identical.
-// Measured neutral at 1M x 256 x 256 (same-box A/B builds, round 2: fwd 0.96-0.98 / 0.94-0.96, bwd_data 0.88-0.89 / 0.89-0.90, dW
-// 1.02 / 1.01-1.02 ms): the dependent chain is not what holds the matrix pipe at ~50 %.  Default: the original order.
-#ifndef NPI_MMA_INTERLEAVE
-#define NPI_MMA_INTERLEAVE 0
-#endif
 // LDS plane image: [row][16 bf16] = 32-byte rows, no padding; the two 16-byte halves of a row are swapped
 // on rows with bit 3 set, which makes the ds_read_b128 fragment reads (lane -> row, half lane>>5)
 // bank-conflict free for the 16-lane groups the hardware forms
@@ -898,42 +890,6 @@ __device__ __forceinline__ void store_tile_q(float* __restrict__ C, int64_t ldc,
     }
 }
 
-// A-operand staging of gemm_split_ws_kernel.  0: a thread takes 4 consecutive k of rows r and r + 64 (two float4) and stores
-// 8-byte pieces per plane (round 1; SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles).  1: a thread takes 8 consecutive k of ONE
-// row (two adjacent float4) and stores one 16-byte half row per plane; adjacent lanes hold the two halves of a row, so the 8
-// lanes of a ds_write_b128 group cover 4 consecutive rows x 2 halves = 8 different bank quads (conflict-free).
-// Measured at 1M x 256 x 256 (same-box A/B builds, round 2): 1 is 3-4 % SLOWER (bwd_data 0.92 vs 0.88 ms, fwd min 0.95 vs 0.83):
-// the bank conflicts of the 8-byte stores are not what limits the kernel.  Default 0.
-#ifndef NPI_SPLIT_A16
-#define NPI_SPLIT_A16 0
-#endif
-__device__ __forceinline__ void split3_store16(f32x4r lo, f32x4r hi, char* img, int plane) {
-    uint32_t a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
-    split3_pair(lo.x, lo.y, a0, a1, a2);
-    split3_pair(lo.z, lo.w, b0, b1, b2);
-    split3_pair(hi.x, hi.y, c0, c1, c2);
-    split3_pair(hi.z, hi.w, d0, d1, d2);
-    *reinterpret_cast<uint4*>(img) = make_uint4(a0, b0, c0, d0);
-    *reinterpret_cast<uint4*>(img + plane) = make_uint4(a1, b1, c1, d1);
-    *reinterpret_cast<uint4*>(img + 2 * plane) = make_uint4(a2, b2, c2, d2);
-}
-// measurement switches of gemm_split_ws_kernel (compile segsum-independent variant libraries with -DNPI_WS_PROBE=<bits> and load them through NPI_GNN_LIB; timing only, wrong
-// numbers): 1 = one MFMA per tile pair instead of six, 2 = no split arithmetic in the producer (plain bf16 pack into all
-// three planes), 4 = no C stores, 8 = the producer stores nothing to LDS (hand-over only), 32 = no global loads of A,
-// 64 = no global loads of the weight planes (stale registers are stored), 128 = the MFMAs as v_mfma_f32_16x16x32_bf16 (twelve per
-// tile pair: the same flops and fragment traffic in the shape that holds a higher clock)
-// 16 = cycle stamps: npi_ws_probe_read() returns, summed over the workgroups, the cycles producer wave 4 spent waiting for
-// an empty stage / for its loads / splitting + storing, its total, and consumer wave 0's wait for a full stage / epilogue /
-// total, and the k-steps counted
-#ifndef NPI_WS_PROBE
-#define NPI_WS_PROBE 0
-#endif
-#if NPI_WS_PROBE & 16
-__device__ unsigned long long npi_ws_probe_acc[8];
-#define NPI_STAMP() __builtin_readcyclecounter()
-#else
-#define NPI_STAMP() 0ull
-#endif
 struct SplitArgs {
     const float* A; int64_t lda;
     const uint16_t* Bp;      // [3][K/16][N][16]
@@ -1031,8 +987,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int TM, int TN, int APL, int BPL, int BUF, int NST, bool ONE_MMA = false, int NPL = 3, bool F16 = false>
 __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, int* empty, int g, bool more,
                                                 const int (&offa)[TM], const int (&offb)[TN], frag_t (&af)[TM][NPL],
-                                                frag_t (&bf)[TN][NPL], f32x16 (&acc)[TM][TN],
-                                                unsigned long long* t_wait = nullptr) {
+                                                frag_t (&bf)[TN][NPL], f32x16 (&acc)[TM][TN]) {
     static_assert(TM == 2, "the wait counts below assume two row blocks");
     static_assert(NPL == (F16 ? 2 : 3), "bf16 x 3 has three plane images per operand, fp16 x 2 two");
     const int stg = g & (NST - 1), stn = (g + 1) & (NST - 1);
@@ -1054,19 +1009,6 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
             }
             // B fragment as the MFMA's first operand: the tile comes out transposed (see store_tile_t)
             f32x16 c = acc[i][j];
-#if NPI_WS_PROBE & 128
-            {   // timing only: the same flops as twelve v_mfma_f32_16x16x32_bf16 (the shape that holds a higher clock)
-                typedef float f32x4m __attribute__((ext_vector_type(4)));
-                f32x4m q0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), q1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
-                f32x4m q2 = __builtin_shufflevector(c, c, 8, 9, 10, 11), q3 = __builtin_shufflevector(c, c, 12, 13, 14, 15);
-#define NPI_M16(Q, BP, AP) Q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FRAG(bf[j][BP]), FRAG(af[i][AP]), Q, 0, 0, 0)
-                NPI_M16(q0, 0, 2); NPI_M16(q1, 0, 2); NPI_M16(q2, 2, 0); NPI_M16(q3, 2, 0); NPI_M16(q0, 1, 1); NPI_M16(q1, 1, 1);
-                NPI_M16(q2, 0, 1); NPI_M16(q3, 0, 1); NPI_M16(q0, 1, 0); NPI_M16(q1, 1, 0); NPI_M16(q2, 0, 0); NPI_M16(q3, 0, 0);
-#undef NPI_M16
-                c = __builtin_shufflevector(__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7),
-                                            __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-            }
-#else
             if constexpr (F16) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(FRAGH(bf[j][0]), FRAGH(af[i][1]), c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(FRAGH(bf[j][1]), FRAGH(af[i][0]), c, 0, 0, 0);
@@ -1081,7 +1023,6 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
             }
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FRAG(bf[j][0]), FRAG(af[i][0]), c, 0, 0, 0);
             }
-#endif
             acc[i][j] = c;
             __builtin_amdgcn_sched_barrier(0);           // row block by row block: the first one of a step needs only A(0)
             if (j == TN - 1 && more) ws_read3<APL, NPL>(af[i], nx + (uint32_t)offa[i]);   // row block i is finished: refill its A
@@ -1094,10 +1035,8 @@ __device__ __forceinline__ void ws_consume_step(uint32_t lds_base, int* full, in
             else
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[TN - 1][0]), "+v"(bf[TN - 1][1]), "+v"(fullv) : : "memory");
             signal(&empty[stg]);
-            const unsigned long long t0_ = t_wait ? NPI_STAMP() : 0ull;
             const int target = 4 * (((g + 1) >> 2) + 1);
             if (more && __builtin_amdgcn_readfirstlane(fullv) < target) wait_ge(&full[stn], target);   // rare: the producer is behind
-            if (t_wait) *t_wait += NPI_STAMP() - t0_;
             // (the acquire for the stage's data: wait_ge's atomic load on the slow path, program order after the poll's
             // wait on the fast one -- LDS operations of a wave execute in order)
         }
@@ -1134,7 +1073,6 @@ gemm_split_ws_kernel(SplitArgs a) {
     constexpr bool UV = R2 || SC;                     // two column vectors kept in LDS beside the bias
     constexpr int TM = 2;
     constexpr int NPL = F16 ? 2 : 3;                  // plane images per operand: bf16 x 3, or fp16 x 2 (F16)
-    static_assert(!F16 || (NPI_SPLIT_A16 == 0 && (NPI_WS_PROBE & ~(16 | 8 | 4)) == 0), "the fp16 x 2 variant has the cycle stamps, the no-LDS-store and the no-C-store builds only");
     constexpr int BN = 64 * TN;                       // 128 or 256 output columns per tile
     constexpr int APL = 128 * 32, BPL = BN * 32;      // bytes of one A / B plane image
     constexpr int BUF = NPL * APL + NPL * BPL;        // one stage: A planes 0.., B planes 0..
@@ -1173,23 +1111,12 @@ gemm_split_ws_kernel(SplitArgs a) {
         // 32-bit byte offset fixed for the whole kernel.
         // A: float4 #(pt & 3) of rows (pt >> 2) and (pt >> 2) + 64;  B: the NB consecutive 16-B chunks NB pt ... of each plane's tile
         const int64_t b_plane = (int64_t)a.N * a.K * 2;
-#if NPI_SPLIT_A16
-        const uint32_t oa0 = (uint32_t)(((int64_t)(pt >> 1) * a.lda + (pt & 1) * 8) * 4);     // row pt / 2, k half pt % 2
-        const uint32_t oa1 = oa0 + 16;
-#else
         const uint32_t oa0 = (uint32_t)(((int64_t)(pt >> 2) * a.lda + (pt & 3) * 4) * 4);
         const uint32_t oa1 = oa0 + (uint32_t)(a.lda * 64 * 4);
-#endif
         const uint32_t ob = (uint32_t)pt * (16 * NB);
         const int ar = pt >> 2, ac = pt & 3;
-#if NPI_SPLIT_A16
-        char* la0 = lds + simg(pt >> 1, pt & 1);
-        char* la1 = la0;
-        (void)ar; (void)ac;
-#else
         char* la0 = lds + simg(ar, ac >> 1) + (ac & 1) * 8;
         char* la1 = lds + simg(ar + 64, ac >> 1) + (ac & 1) * 8;
-#endif
         // chunk c -> row c / 2, half c % 2
         char* lb0 = lds + NPL * APL + (NB == 2 ? simg(pt, 0) : simg(pt >> 1, pt & 1));
         char* lb1 = lds + NPL * APL + simg(pt, 1);
@@ -1223,12 +1150,10 @@ gemm_split_ws_kernel(SplitArgs a) {
             NPI_GL1(S##s0, os0, gs); NPI_GL1(S##s1, os1, gs);                                          \
             (void)gb2;                                                                                 \
         } else {                                                                                       \
-        if constexpr ((NPI_WS_PROBE & 32) == 0) { NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0); }                          \
-        if constexpr ((NPI_WS_PROBE & 64) == 0) {                                                      \
+        NPI_GL(S##a0, oa0, ga, 0); NPI_GL(S##a1, oa1, ga, 0);                                          \
         NPI_GL(S##b0, ob, gb0, 0); NPI_GL(S##b1, ob, gb1, 0); NPI_GL(S##b2, ob, gb2, 0);               \
         if constexpr (NB == 2) {                                                                       \
             NPI_GL(S##b3, ob, gb0, 16); NPI_GL(S##b4, ob, gb1, 16); NPI_GL(S##b5, ob, gb2, 16);        \
-        }                                                                                              \
         }                                                                                              \
         }                                                                                              \
         wl.next();                                                                                     \
@@ -1260,16 +1185,7 @@ gemm_split_ws_kernel(SplitArgs a) {
             }                                                                                          \
             break;                                                                                     \
         }                                                                                              \
-        if constexpr (NPI_SPLIT_A16) { split3_store16(S##a0, S##a1, la0 + (OFF), APL); (void)la1; }    \
-        else if constexpr ((NPI_WS_PROBE & 2) != 0) {                                                  \
-            const uint2 q0_ = make_uint2(pack_bf16(S##a0.x, S##a0.y), pack_bf16(S##a0.z, S##a0.w));    \
-            const uint2 q1_ = make_uint2(pack_bf16(S##a1.x, S##a1.y), pack_bf16(S##a1.z, S##a1.w));    \
-            for (int p_ = 0; p_ < 3; ++p_) {                                                           \
-                *reinterpret_cast<uint2*>(la0 + (OFF) + p_ * APL) = q0_;                               \
-                *reinterpret_cast<uint2*>(la1 + (OFF) + p_ * APL) = q1_;                               \
-            }                                                                                          \
-        }                                                                                              \
-        else { split3_store(S##a0, la0 + (OFF), APL); split3_store(S##a1, la1 + (OFF), APL); }         \
+        split3_store(S##a0, la0 + (OFF), APL); split3_store(S##a1, la1 + (OFF), APL);                  \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF)) = S##b0;                                               \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF) + BPL) = S##b1;                                         \
         *reinterpret_cast<u32x4r*>(lb0 + (OFF) + 2 * BPL) = S##b2;                                     \
@@ -1282,19 +1198,12 @@ gemm_split_ws_kernel(SplitArgs a) {
         // one k-step: refill the set freed by the previous step, split + store set CUR
 #define NPI_WSTEP(ST, CUR, FREE)                                                                       \
         NPI_WLOAD(FREE);                                                                               \
-        pt0 = NPI_STAMP();                                                                             \
         if (round > 0) wait_ge(&empty[ST], 4 * round);       /* the consumers are done with this stage's previous use */ \
-        pt1 = NPI_STAMP();                                                                             \
         NPI_WWAIT(CUR);                                                                                \
-        pt2 = NPI_STAMP();                                                                             \
-        if constexpr ((NPI_WS_PROBE & 8) == 0) NPI_WSTORE((ST) * BUF, CUR);                            \
+        NPI_WSTORE((ST) * BUF, CUR);                                                                   \
         signal(&full[ST]);                                                                             \
-        pt3 = NPI_STAMP();                                                                             \
-        pa_empty += pt1 - pt0; pa_vm += pt2 - pt1; pa_store += pt3 - pt2; ++pa_steps;                  \
         w.next();                                                                                      \
         if (!w.valid()) break
-        unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pa_empty = 0, pa_vm = 0, pa_store = 0, pa_steps = 0;
-        const unsigned long long p_begin = NPI_STAMP();
         NPI_WLOAD(r0);
         NPI_WLOAD(r1);
         NPI_WLOAD(r2);
@@ -1311,14 +1220,6 @@ gemm_split_ws_kernel(SplitArgs a) {
 #undef NPI_GL1
 #undef NPI_WLOAD
 #undef NPI_WSTORE
-#if NPI_WS_PROBE & 16
-        if (t == 256) {
-            atomicAdd(&npi_ws_probe_acc[0], pa_empty); atomicAdd(&npi_ws_probe_acc[1], pa_vm);
-            atomicAdd(&npi_ws_probe_acc[2], pa_store); atomicAdd(&npi_ws_probe_acc[3], NPI_STAMP() - p_begin);
-            atomicAdd(&npi_ws_probe_acc[7], pa_steps);
-        }
-#endif
-        (void)pt0; (void)pt1; (void)pt2; (void)pt3; (void)pa_empty; (void)pa_vm; (void)pa_store; (void)pa_steps; (void)p_begin;
         return;
     }
 
@@ -1348,8 +1249,6 @@ gemm_split_ws_kernel(SplitArgs a) {
     (void)tq;
     frag_t af[TM][NPL], bf[TN][NPL];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-    unsigned long long ca_wait = 0, ca_epi = 0;
-    const unsigned long long c_begin = NPI_STAMP();
     wait_ge(&full[0], 4);
     ws_consume_first<TM, TN, APL, BPL, NPL>(lds_base, offa, offb, af, bf);
     while (w.valid()) {
@@ -1387,13 +1286,9 @@ gemm_split_ws_kernel(SplitArgs a) {
         }
         TileWalk wn_ = w;
         wn_.next();
-        ws_consume_step<TM, TN, APL, BPL, BUF, NST, (NPI_WS_PROBE & 1) != 0, NPL, F16>(lds_base, full, empty, g, wn_.valid(), offa, offb, af, bf,
-                                                                                       acc, (NPI_WS_PROBE & 16) ? &ca_wait : nullptr);
+        ws_consume_step<TM, TN, APL, BPL, BUF, NST, false, NPL, F16>(lds_base, full, empty, g, wn_.valid(), offa, offb, af, bf, acc);
         ++g;
         if (w.kt == nk - 1) {
-            const unsigned long long e0_ = NPI_STAMP();
-            if ((NPI_WS_PROBE & 4) == 0 || acc[0][0][0] == 12345.678f)
-            {
             if constexpr (EPI == 0)       // full 128-byte lines per store instruction (store_tile_q)
                 store_tile_q<TM, TN, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc, bias_s[wave][tsel], rs, floor_,
                                           cs_s[F16 ? wave : 0][tsel]);
@@ -1401,7 +1296,6 @@ gemm_split_ws_kernel(SplitArgs a) {
             store_tile_t<TM, TN, EPI, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
                                            bias_s[wave][tsel], rs, floor_, r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1,
                                            cs_s[F16 ? wave : 0][tsel]);
-            }
             if constexpr (SC) {
                 const int par = tq & 1;
 #pragma unroll
@@ -1430,7 +1324,6 @@ gemm_split_ws_kernel(SplitArgs a) {
                 }
                 ++tq;
             }
-            ca_epi += NPI_STAMP() - e0_;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1440,13 +1333,6 @@ gemm_split_ws_kernel(SplitArgs a) {
         }
         w = wn_;
     }
-#if NPI_WS_PROBE & 16
-    if (t == 0) {
-        atomicAdd(&npi_ws_probe_acc[4], ca_wait); atomicAdd(&npi_ws_probe_acc[5], ca_epi);
-        atomicAdd(&npi_ws_probe_acc[6], NPI_STAMP() - c_begin);
-    }
-#endif
-    (void)ca_wait; (void)ca_epi; (void)c_begin;
 }
 
 // ---- dW on the bf16 matrix cores: both operands split on the fly --------------------------------------------------
@@ -1463,11 +1349,6 @@ gemm_split_ws_kernel(SplitArgs a) {
 // workgroups with m-tile 0 (two partial rows per slab: the two 8-node halves of a k-step).
 // The 16-byte LDS stores of 8 adjacent lanes go to 8 different bank quads: lane cg stores its columns in the rotated
 // order rho(cg) + c (see dw_rot), which with the image's half swizzle covers all 32 banks.
-// measurement switches of gemm_dw_split_kernel (variant library with -DNPI_DW_PROBE=<bits>, loaded through NPI_GNN_LIB): 1 = no start stagger,
-// 2 = cheap split (timing only, wrong numbers), 4 = one MFMA per product tile (timing only)
-#ifndef NPI_DW_PROBE
-#define NPI_DW_PROBE 0
-#endif
 struct DwArgs {
     const float* A; int64_t lda;     // [M, K]
     const float* dC; int64_t ldc;    // [M, N]
@@ -1547,7 +1428,7 @@ gemm_dw_split_kernel(DwArgs a) {
         const uint32_t voff = (uint32_t)(((int64_t)8 * half * ld + 4 * cg) * ES);
         // every slab walks its node range from a different starting step (and wraps): 256 workgroups that all start on a
         // slab boundary -- addresses a multiple of 16 KiB apart -- otherwise sweep the memory channels in lockstep
-        const int phase = (NPI_DW_PROBE & 1) || nk < 2 ? 0 : (int)(((int64_t)slab * 37) % nk);
+        const int phase = nk < 2 ? 0 : (int)(((int64_t)slab * 37) % nk);
         const bool active = isA || isB;
         if constexpr (BF16IN) {
             // ---- bf16 operands: dwordx2 loads (4 bf16 columns of one node row), one plane, no split ----
@@ -1652,8 +1533,7 @@ gemm_dw_split_kernel(DwArgs a) {
                 uint32_t p0[4], p1[4], p2[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (NPI_DW_PROBE & 2) { p0[i] = pack_bf16(v[2 * i], v[2 * i + 1]); p1[i] = p0[i]; p2[i] = p0[i]; }
-                    else split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
+                    split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
                 }
                 char* dst = st + simg(dw_row(cg, c), half);
                 *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
@@ -1722,7 +1602,7 @@ gemm_dw_split_kernel(DwArgs a) {
         wait_ge(&full[0], 4);
         ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);
         for (int g = 0; g < nk; ++g)
-            ws_consume_step<TM, TN, APL, BPL, BUF, NST, BF16IN || (NPI_DW_PROBE & 4) != 0>(lds_base, full, empty, g, g + 1 < nk, offa, offb, af, bf, acc);
+            ws_consume_step<TM, TN, APL, BPL, BUF, NST, BF16IN>(lds_base, full, empty, g, g + 1 < nk, offa, offb, af, bf, acc);
     }
     // the tile of this slab (zeros when the slab holds no node: slab_reduce adds every slab)
     // Accumulator tile = C^T of the LDS-row grid: the lane owns LDS row li of the A image, its registers run along LDS rows
@@ -2157,14 +2037,6 @@ using namespace npi;
 static inline const float* fp(const void* p) { return reinterpret_cast<const float*>(p); }
 static inline const void* advance(const void* p, int64_t elems, int es) { return reinterpret_cast<const char*>(p) + elems * es; }
 
-#if NPI_WS_PROBE & 16
-extern "C" int npi_ws_probe_read(unsigned long long* out8) {          // measurement builds only: read and reset the stamps
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(npi_ws_probe_acc), sizeof(z)) != hipSuccess) return NPI_ERR_LAUNCH;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(npi_ws_probe_acc), z, sizeof(z)) != hipSuccess) return NPI_ERR_LAUNCH;
-    return NPI_OK;
-}
-#endif
 
 // per-call arithmetic of the *_ex entry points -> launch_gemm's mode
 // (no process-wide default any more: 0 = the 3-way bf16 split wherever the shape takes it, NPI_GEMM_EXACT_F32 = the f32 MFMA kernels)

@@ -616,13 +616,9 @@ extern "C" int npi_graph_bounds(const int64_t* batch, int64_t N, int64_t B, int3
 
 // perm[out_ptr[B]] (node ids, graph-major, score-descending), remap[N] (new id or -1), out_ptr[B+1];
 // status[0] bit 1 is set when a graph has more than 16384 nodes (unsupported)
-extern "C" int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
-                               int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, void* stream_) {
-    return npi_topk_select_ex(score, graph_ptr, N, B, ratio, out_ptr, perm, remap, status, 0, stream_);
-}
 // max_nodes: an upper bound of the largest graph of the batch the CALLER knows (0 = unknown): at most 1,024 skips the launch
 // for graphs of 1,025 .. 16,384 nodes (it would find none)
-extern "C" int npi_topk_select_ex(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
+extern "C" int npi_topk_select(const float* score, const int32_t* graph_ptr, int64_t N, int64_t B, float ratio,
                                   int32_t* out_ptr, int32_t* perm, int32_t* remap, int32_t* status, int64_t max_nodes,
                                   void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -638,11 +634,6 @@ extern "C" int npi_topk_select_ex(const float* score, const int32_t* graph_ptr, 
 }
 
 extern "C" int npi_topk_gather(const float* x, int64_t ldx, const float* score, const int64_t* batch,
-                               const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
-                               float* xo, int64_t ldo, int64_t* batch_o, float* score_o, void* stream_) {
-    return npi_topk_gather_ex(x, ldx, score, batch, perm, out_ptr, B, F, n_out_max, xo, ldo, batch_o, score_o, nullptr, stream_);
-}
-extern "C" int npi_topk_gather_ex(const float* x, int64_t ldx, const float* score, const int64_t* batch,
                                   const int32_t* perm, const int32_t* out_ptr, int64_t B, int64_t F, int64_t n_out_max,
                                   float* xo, int64_t ldo, int64_t* batch_o, float* score_o, int64_t* perm64, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -653,19 +644,13 @@ extern "C" int npi_topk_gather_ex(const float* x, int64_t ldx, const float* scor
     return check_launch("npi_topk_gather");
 }
 
-// tile counts (+ 2), then -- npi_filter_adj_ex only -- the new position of every input edge (-1: dropped), which
+// tile counts (+ 2), then -- npi_filter_adj only -- the new position of every input edge (-1: dropped), which
 // npi_csr_filter takes as its `newpos`
 extern "C" int64_t npi_filter_adj_workspace_elems(int64_t E) { return ceil_div(E > 0 ? E : 1, FA_TILE) + 2 + (E > 0 ? E : 0); }
 extern "C" int64_t npi_filter_adj_newpos_offset(int64_t E) { return ceil_div(E > 0 ? E : 1, FA_TILE) + 2; }
 
 // out_src/out_dst: capacity E; count[0] = number of surviving edges (device)
 extern "C" int npi_filter_adj(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
-                              int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace,
-                              void* stream_) {
-    return npi_filter_adj_ex(src, dst, E, remap, out_src, out_dst, count, workspace, 0, stream_);
-}
-
-extern "C" int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t E, const int32_t* remap,
                                  int64_t* out_src, int64_t* out_dst, int32_t* count, int32_t* workspace,
                                  int pad_tail, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -673,7 +658,7 @@ extern "C" int npi_filter_adj_ex(const int64_t* src, const int64_t* dst, int64_t
     NPI_REQUIRE(count && workspace, "npi_filter_adj: null pointer");
     if (E == 0) { (void)hipMemsetAsync(count, 0, sizeof(int32_t), stream); return check_launch("npi_filter_adj"); }
     NPI_REQUIRE(src && dst && remap && out_src && out_dst, "npi_filter_adj: null pointer");
-    NPI_REQUIRE(!pad_tail || (out_src != src && out_dst != dst), "npi_filter_adj_ex: pad_tail needs separate output arrays");
+    NPI_REQUIRE(!pad_tail || (out_src != src && out_dst != dst), "npi_filter_adj: pad_tail needs separate output arrays");
     const int ntiles = (int)ceil_div(E, FA_TILE);
     filter_flag_kernel<<<ntiles, 256, 0, stream>>>(src, dst, E, remap, workspace, pad_tail ? out_src : nullptr,
                                                    pad_tail ? out_dst : nullptr);

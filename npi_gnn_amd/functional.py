@@ -624,7 +624,7 @@ def entry_weights(graph: CSRGraph, edge_weight: Optional[torch.Tensor], fill: fl
         if edge_weight.numel() != graph.num_edges:
             raise ValueError(f"edge_weight has {edge_weight.numel()} entries, edge_index {graph.num_edges} columns")
     src, dst = graph._src, graph._dst
-    m = (src == dst) & (src >= 0)                        # (-1, -1) columns are padding (npi_filter_adj_ex), not self loops
+    m = (src == dst) & (src >= 0)                        # (-1, -1) columns are padding (npi_filter_adj), not self loops
     if bool(m.any()):
         loop_w = torch.full((N,), fill, dtype=torch.float32, device=dev)
         loop_w[src[m]] = edge_weight[m] if edge_weight is not None else 1.0

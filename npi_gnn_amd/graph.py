@@ -407,7 +407,7 @@ def as_graph(edge_index_or_graph, num_nodes: int) -> CSRGraph:
 def filtered_side(parent: CSRSide, perm: torch.Tensor, remap: torch.Tensor, newpos: torch.Tensor, n_out: int,
                   num_edges_out: int) -> Optional[CSRSide]:
     """By-target side of the graph TopKPooling leaves -- nodes ``perm`` (int32, new -> old) of the parent, renumbered by
-    ``remap``, edges filtered in order (``newpos``: where ``npi_filter_adj_ex`` put every input edge) -- derived from the
+    ``remap``, edges filtered in order (``newpos``: where ``npi_filter_adj`` put every input edge) -- derived from the
     parent's side without a sort (``npi_csr_filter``: three launches).  Identical to ``build_side`` on the filtered edge list of length
     ``num_edges_out`` (the padded length when the list is padded).  None when the shape is outside the kernel's range."""
     lib = load()

@@ -41,12 +41,28 @@ class GraphedStack:
     def __init__(self, convs: Sequence[torch.nn.Module], graph: CSRGraph, x: torch.Tensor, grad_out: Optional[torch.Tensor] = None,
                  loss: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, relu: bool = True, optimizer=None,
                  warmup: int = 3, capture: bool = True):
-        if not isinstance(graph, CSRGraph):
-            raise TypeError("GraphedStack: graph must be a CSRGraph (a static graph is sorted once)")
         self.convs, self.graph, self.relu, self.loss, self.optimizer = list(convs), graph, bool(relu), loss, optimizer
         for c in self.convs:
             if not isinstance(c, (SAGEConv, GCNConv, GATConv)):
                 raise TypeError(f"GraphedStack: {type(c).__name__} is not a conv of this package")
+            # every layer of a stack aggregates over ONE adjacency: the self-loop-augmented CSR of `graph`.  Layer settings that mean
+            # another adjacency (PyG 1.4.2: GCNConv(normalize=False) and SAGEConv(concat=True) take the edge list as it is, no self
+            # loop) or another epilogue order are refused here -- computing the default layer in their place would differ from
+            # the module's own forward without a word
+            if isinstance(c, GCNConv) and not c.normalize:
+                raise ValueError("GraphedStack: GCNConv(normalize=False) aggregates raw edge weights over the edge list without self "
+                                 "loops; a stack shares one self-loop-augmented graph -- call the module itself")
+            if isinstance(c, SAGEConv) and c.concat:
+                raise ValueError("GraphedStack: SAGEConv(concat=True) aggregates over the edge list without self loops; a stack shares "
+                                 "one self-loop-augmented graph -- call the module itself")
+            if isinstance(c, SAGEConv) and c.normalize and relu:
+                raise ValueError("GraphedStack(relu=True): SAGEConv(normalize=True) normalises AFTER the projection; the fused ReLU "
+                                 "would come before it -- build the stack with relu=False")
+            if isinstance(c, GATConv) and c.dropout > 0.0 and c.training:
+                raise ValueError("GraphedStack: GATConv(dropout > 0) in training mode draws a new mask every step; a captured step "
+                                 "would replay one mask -- call eval() on the layer or the module itself")
+        if not isinstance(graph, CSRGraph):
+            raise TypeError("GraphedStack: graph must be a CSRGraph (a static graph is sorted once)")
         _ = graph.by_src                                            # the backward's orientation, before anything is captured
         # GCNConv's normalisation depends on the graph only: computed once, outside the step
         self._norms = [F_.GCNNorm(graph, None, c.improved) if isinstance(c, GCNConv) else None for c in self.convs]

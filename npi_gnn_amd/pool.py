@@ -95,7 +95,7 @@ def _select(gb: GraphBatch, weight: torch.Tensor, ratio: float, padded_edges: bo
         status.zero_()
         select_sorted()
     else:
-        check(lib.npi_topk_select_ex(ptr(score), ptr(gp), N, B, float(ratio), ptr(out_ptr), ptr(perm), ptr(remap),
+        check(lib.npi_topk_select(ptr(score), ptr(gp), N, B, float(ratio), ptr(out_ptr), ptr(perm), ptr(remap),
                                      ptr(status), max_nodes, st), "npi_topk_select")
     # filter_adj needs only the old->new id map, so it runs before the sizes are known
     E = edge_index.size(1)
@@ -105,11 +105,11 @@ def _select(gb: GraphBatch, weight: torch.Tensor, ratio: float, padded_edges: bo
     ws = torch.empty(int(lib.npi_filter_adj_workspace_elems(E)), **i32)
     # Host-known graph sizes (``GraphBatch.sizes``, from net1.KeyLoader or from the previous pooling layer): the kept
     # node count is ceil(ratio n_g) per graph -- computable on the host -- and the surviving edges stay in an array of the
-    # input's length whose tail is (-1, -1) padding (npi_filter_adj_ex), which every consumer drops.  No device read at
+    # input's length whose tail is (-1, -1) padding (npi_filter_adj), which every consumer drops.  No device read at
     # all: the layer, and with it the whole Net_1 step, runs without a host synchronisation and captures into a HIP graph.
     kept = _kept_sizes(sizes, ratio) if (B > 0 and padded_edges) else None
     nosync = kept is not None and kept.numel() == B
-    check(lib.npi_filter_adj_ex(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws),
+    check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws),
                                 1 if nosync else 0, st), "npi_filter_adj")
     if nosync:
         n_out, e_out = int(kept.sum()), E                # kept = ceil(ratio n_g) in the kernel's f32 arithmetic
@@ -127,7 +127,7 @@ def _select(gb: GraphBatch, weight: torch.Tensor, ratio: float, padded_edges: bo
             # beforehand: select again with the radix kernels (same rule: score descending, lower index first among equals,
             # ceil(ratio n) per graph), then filter_adj again with the new map -- all on the device.
             select_sorted()
-            check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), st),
+            check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out_ei[0]), ptr(out_ei[1]), ptr(count), ptr(ws), 0, st),
                   "npi_filter_adj")
             n_out, e_out = (int(v) for v in torch.cat([out_ptr[-1:], count]).tolist())
     sel = _Selection()
@@ -156,7 +156,7 @@ def _gather(x: torch.Tensor, sel: _Selection):
     F = x.size(1)
     xo = torch.empty((sel.n_out, F), dtype=torch.float32, device=dev)
     score_o = torch.empty(sel.n_out, dtype=torch.float32, device=dev)
-    check(load().npi_topk_gather_ex(ptr(x), x.stride(0), ptr(sel.score), ptr(sel.batch_in), ptr(sel.perm), ptr(sel.out_ptr),
+    check(load().npi_topk_gather(ptr(x), x.stride(0), ptr(sel.score), ptr(sel.batch_in), ptr(sel.perm), ptr(sel.out_ptr),
                                     sel.num_graphs, F, sel.n_out, ptr(xo), xo.stride(0), ptr(sel.batch_out), ptr(score_o),
                                     ptr(sel.perm64), stream_ptr(dev)), "npi_topk_gather")
     return xo, score_o

@@ -145,6 +145,21 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
     assert lib.npi_linear_fwd_scores_supported(1000, 32, 128) == 0 and lib.npi_linear_fwd_scores_supported(1000, 64, 128) == 1
 
 
+def test_graphed_stack_refuses_layers_it_cannot_honour():
+    """GraphedStack runs every layer over ONE self-loop-augmented graph; a GCNConv(normalize=False) or a
+    SAGEConv(concat=True) inside it used to compute the default layer silently.  Refused before anything touches the GPU."""
+    import npi_gnn_amd as npi
+    for conv, what in ((npi.GCNConv(8, 8, normalize=False), "normalize=False"), (npi.SAGEConv(8, 8, concat=True), "concat=True"),
+                       (npi.SAGEConv(8, 8, normalize=True), "normalize=True")):
+        with pytest.raises(ValueError, match=what.replace("=", "=")):
+            npi.GraphedStack([npi.SAGEConv(8, 8), conv], None, None)
+    gat = npi.GATConv(8, 8, dropout=0.5)
+    with pytest.raises(ValueError, match="dropout"):
+        npi.GraphedStack([gat], None, None)
+    with pytest.raises(TypeError, match="CSRGraph"):                      # (the layers are fine: the graph is looked at next)
+        npi.GraphedStack([gat.eval(), npi.SAGEConv(8, 8), npi.GCNConv(8, 8)], None, None)
+
+
 def test_no_module_level_switch_on_the_layer_path():
     """the default results of a model must not depend on module globals another import can move.  The three
     that survived round 5 -- functional.GEMM_FLAGS, functional.F16X2_MIN_ROWS, graph.ITEM_SWITCH_ENTRIES -- are gone: the GEMM

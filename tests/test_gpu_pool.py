@@ -455,8 +455,8 @@ def test_filter_adj_keeps_the_edge_order_on_both_tile_paths(dev, E):
     out = torch.empty((2, E), dtype=torch.int64, device=dev)
     count = torch.empty(1, dtype=torch.int32, device=dev)
     ws = torch.empty(int(lib.npi_filter_adj_workspace_elems(E)), dtype=torch.int32, device=dev)
-    check(lib.npi_filter_adj_ex(ptr(src), ptr(dst), E, ptr(remap), ptr(out[0]), ptr(out[1]), ptr(count), ptr(ws), 1,
-                                stream_ptr(dev)), "npi_filter_adj_ex")
+    check(lib.npi_filter_adj(ptr(src), ptr(dst), E, ptr(remap), ptr(out[0]), ptr(out[1]), ptr(count), ptr(ws), 1,
+                                stream_ptr(dev)), "npi_filter_adj")
     m = keep[src] & keep[dst]
     n = int(m.sum())
     assert int(count.item()) == n

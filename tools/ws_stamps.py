@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Cycle stamps of gemm_split_ws_kernel (a library built with -DNPI_WS_PROBE=16, loaded through NPI_GNN_LIB): where a producer wave
+"""Cycle stamps of gemm_split_ws_kernel (a library built from the product source + tools/micro/gemm_f32_probes.patch with
+-DNPI_WS_PROBE=16 -- `PATCH=tools/micro/gemm_f32_probes.patch tools/build_variant.sh stamps gemm_f32.hip -DNPI_WS_PROBE=16` --, loaded through NPI_GNN_LIB): where a producer wave
 and a consumer wave spend a launch, for the bf16 x 3 and the fp16 x 2 variant.  usage: NPI_GNN_LIB=... tools/ws_stamps.py [rows]"""
 import ctypes, os, sys
 import torch
