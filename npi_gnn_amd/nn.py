@@ -50,7 +50,9 @@ class SAGEConv(nn.Module):
     """``SAGEConv(in_channels, out_channels, normalize=False, concat=False, bias=True)`` --
     mean over in-neighbours and the node itself, then ``@ weight + bias``.  Both parameters are
     initialised U(+-1/sqrt(weight.size(0))) as in PyG 1.4.2.  ``concat=True``: no self loop is added, the mean over the
-    in-neighbours is concatenated behind the node's own features and ``weight`` is ``[2 in, out]``."""
+    in-neighbours is concatenated behind the node's own features and ``weight`` is ``[2 in, out]`` -- an option the reference
+    never sets, served as a COMPOSED layer (the kernels of the default layer plus torch elementwise ops on the activations in
+    its backward: three activation-sized passes more than a fused layer would make), not at the default layer's kernel quality."""
 
     def __init__(self, in_channels: int, out_channels: int, normalize: bool = False, concat: bool = False,
                  bias: bool = True, schedule: Schedule = DEFAULT, **kwargs):

@@ -69,6 +69,27 @@ def test_fp16x2_scales_rows_and_columns_of_any_magnitude(dev):
     assert float(((c.double() - ref).abs() / bound).max()) <= 1e-6
 
 
+def test_fp16x2_tiny_rows_times_tiny_columns_do_not_underflow_on_the_way_out(dev):
+    """the epilogue undoes the two power-of-two scales ONE AFTER THE OTHER, (acc 2^-eb) 2^-ea -- folded into one
+    factor their product would underflow when both a row of A and a column of W are tiny although the result is representable.
+    Rows of A at 2^-60 against columns of W at 2^-60: products at 2^-120, normal f32 numbers, within the kernel's bars; and
+    against the bf16 x 3 arithmetic on the same operands."""
+    g = torch.Generator(device=dev).manual_seed(12)
+    M, K, N = 1024, 256, 256
+    a = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(K, N, device=dev, generator=g) / K ** 0.5
+    a[::2] *= 2.0 ** -60                                                     # every other row tiny
+    w[:, ::3] *= 2.0 ** -60                                                  # every third column tiny
+    ref = a.double() @ w.double()
+    c2 = NF.linear_fwd(a, w, a_scales=NF.row_scales(a))
+    c3 = NF.linear_fwd(a, w)
+    assert float(ref[::2, ::3].abs().max()) < 2.0 ** -100 and float(ref[::2, ::3].abs().min()) > 2.0 ** -140    # tiny, normal
+    bound = (a.abs().double() @ w.abs().double())
+    for c in (c2, c3):
+        assert torch.isfinite(c).all() and bool((c[::2, ::3] != 0).all())
+        assert float(((c.double() - ref).abs() / bound).max()) <= 1e-6
+
+
 def test_fp16x2_non_finite_operands_behave_as_under_the_bf16_split(dev):
     """NaN stays NaN; an Inf in A makes its output row NaN (Inf - Inf in the split), as the bf16 x 3 arithmetic does (include/npi_gnn.h)"""
     g = torch.Generator(device=dev).manual_seed(4)
