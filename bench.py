@@ -456,7 +456,9 @@ def live_pmc(args, timeout_s: float = 300.0, control: bool = False):
                     if f.endswith("counter_collection.csv"):
                         rows += list(csv.DictReader(open(os.path.join(root_, f))))
             vals = [float(r["Counter_Value"]) for r in rows
-                    if r.get("Counter_Name", counter) == counter and "segsum_kernel<float, 4, 1, 0" in r.get("Kernel_Name", "")]
+                    if r.get("Counter_Name", counter) == counter
+                    # (forward: the unweighted mean, WMODE 0; backward, aggregate-first: per-entry weights, WMODE 1)
+                    and any(k in r.get("Kernel_Name", "") for k in ("segsum_kernel<float, 4, 1, 0", "segsum_kernel<float, 4, 1, 1"))]
             if not vals:
                 return {"error": f"no {counter} rows for the aggregation kernel (rc {cp.returncode}): {(cp.stderr or cp.stdout)[-200:]}"}
             means[counter] = (sum(vals) / len(vals), len(vals))

@@ -79,6 +79,10 @@ def check_pending() -> None:
             raise_on_status(torch.cat(ts).tolist())
 
 
+#: aggregation scratch buffers kept per side (one per (width, stream) pair in use: launch stream, side stream, partial stream, a capture's)
+CARRY_SLOTS = 6
+
+
 @dataclass
 class CSRSide:
     """One orientation.  ``rowptr[N+1]``, ``col/eid/rowidx[nnz_max]`` int32 in entry order;
@@ -117,13 +121,19 @@ class CSRSide:
         (possibly concurrently) get a buffer each.  ``reset_carry()`` after a launch that did not run to its end."""
         dev = self.rowptr.device
         key = (F, _lib.stream_ptr(dev))
-        buf = self._carry.get(key)
+        buf = self._carry.pop(key, None)
         if buf is None:
             n = int(load().npi_segsum_carry_elems(self.nnz_max, self.item, F))
             buf = torch.zeros(n, dtype=torch.float32, device=dev)
-            self._carry[key] = buf
+            # at most CARRY_SLOTS buffers per side (at the C5 size one is ~200 MB): the least recently used one goes when a new
+            # (width, stream) pair appears -- every fresh stream of a capture or a bench run used to leave its own behind for the
+            # side's lifetime.  A dropped buffer was allocated and used on ITS stream only, so the caching allocator's stream-
+            # ordered reuse keeps a launch that is still in flight on it safe; never during a capture (the graph owns its memory).
+            if len(self._carry) >= CARRY_SLOTS and not torch.cuda.is_current_stream_capturing():
+                self._carry.pop(next(iter(self._carry)))
         elif _DEBUG and not torch.cuda.is_current_stream_capturing():
             self._check_counters(buf)
+        self._carry[key] = buf                              # (re-inserted: dicts keep insertion order, the first key is the LRU)
         return buf
 
     def _check_counters(self, buf: torch.Tensor) -> None:

@@ -51,3 +51,32 @@ def test_the_library_this_box_runs_is_the_guarded_build():
                 assert G.find_flat(instrs) == [], (src, sym)
                 assert G.find_sgpr_hazards(instrs) == [], (src, sym)
                 assert G.find_inflight_touch_linear(instrs) == [], (src, sym)
+
+
+@pytest.mark.gpu
+def test_the_ctypes_stub_of_integration_md_runs_as_printed():
+    """INTEGRATION.md section 2 shows the binding a maintainer would add to the reference: that very code block, cut out of the
+    document and executed (library path made absolute), against the oracle's SAGEConv -- so the document cannot drift from the ABI
+    (ABI 4 added an optional pointer to two of the three calls it makes)."""
+    import re
+    import torch
+    from oracle import ref_conv as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = [b for b in blocks if "def sage_forward(" in b and "ctypes.CDLL" in b]
+    assert len(stub) == 1
+    code = stub[0].replace('"npi_gnn_amd/libnpi_gnn.so"', repr(os.path.join(root, "npi_gnn_amd", "libnpi_gnn.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    N, E, Fi, Fo = 2500, 30000, 178, 128
+    ei = torch.randint(0, N, (2, E), generator=g)
+    x = torch.randn(N, Fi, generator=g)
+    W = (torch.rand(Fi, Fo, generator=g) * 2 - 1) / Fi ** 0.5
+    b = (torch.rand(Fo, generator=g) * 2 - 1) / Fi ** 0.5
+    out = ns["sage_forward"](x.to(dev), ei.to(dev), W.to(dev), b.to(dev))
+    torch.cuda.synchronize()
+    ref = R.sage_conv(x, ei, W, b)
+    assert float((out.cpu() - ref).abs().max()) <= 1e-4

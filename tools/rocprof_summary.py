@@ -63,7 +63,9 @@ def main():
         t.pop("includes_fixup_kernel", None)        # (rounds 1-3: a second launch; cut rows are finished inside the launch now)
         if kind == "sage":
             # per aggregation launch (ONE kernel), averaged over the forward and the backward launch
-            t.update({"segsum_kernel_bytes_per_launch": kb(main(0)), "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json"})
+            # (forward: WMODE 0, the unweighted mean; backward, aggregate-first since round 6: WMODE 1, per-entry weights)
+            both = lambda k: "segsum_kernel<float" in k and mode(k) in (0, 1)
+            t.update({"segsum_kernel_bytes_per_launch": kb(both), "fetch_scale": scale, "from": f"profiles/{tag}_pmc_summary.json"})
         elif kind == "gat":
             # forward: W_GAT_DST_FUSED (10: the statistics inside the launch, round 5); W_GAT_DST_PRE (6) under Schedule(gat_fused_stats=False)
             t.update({"gat_fwd_aggregate_bytes_per_launch": kb(main(10)) or kb(main(6)), "gat_bwd_fused_bytes_per_launch": kb(main(5)),
