@@ -401,18 +401,29 @@ class HipBackend:
     def col_of_entry(self, side):
         return side.col[: side.nnz_max].long()
 
-    def segsum(self, side, table, mean: bool = False, table2=None, w=None, bias=None, out=None):
+    def segsum(self, side, table, mean: bool = False, table2=None, w=None, bias=None, out=None, scales_out=None):
         from . import functional as NF
-        return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2, out=out)
+        return NF.segsum(None, side, table, w=w, mean=mean, bias=bias, x2=table2, out=out, scales_out=scales_out)
 
-    def linear_fwd(self, a, w, b, out=None, ws=None, reserve_cus=0):
+    def linear_fwd(self, a, w, b, out=None, ws=None, reserve_cus=0, a_scales=None):
         from . import functional as NF
-        return NF.linear_fwd(a, w, b, out=out, ws=ws, reserve_cus=reserve_cus)
+        return NF.linear_fwd(a, w, b, out=out, ws=ws, reserve_cus=reserve_cus, a_scales=a_scales)
 
-    def prepare_weight(self, w, backward=True):
+    def prepare_weight(self, w, backward=True, f16=False):
         """(ws_fwd, ws_bwd) for linear_fwd(..., ws=) / linear_bwd_data(..., ws=): both re-laid copies of ``w`` in one launch"""
         from . import functional as NF
-        return NF.prepare_weight(w, backward)
+        return NF.prepare_weight(w, backward, f16=f16)
+
+    def light_scales(self, sch: Schedule, side, rows: torch.Tensor, n_light: int, weight: torch.Tensor):
+        """A ``[n_light]`` buffer for the power-of-two row scales of the light rows' aggregate, when their projection takes two fp16
+        pieces per operand (``Schedule.f16x2_min_rows``; 256 features: the full side's launch writes them, ``segsum(scales_out=)``),
+        else None.  The light rows are nine tenths of a rank's projection; the hub rows arrive by reduce-scatter, nobody wrote
+        their scales, and their GEMM stays on three bf16 pieces."""
+        from . import functional as NF
+        if (rows.dtype == weight.dtype and rows.size(1) == weight.size(0)
+                and NF._f16x2(sch, n_light, weight.size(0), weight.size(1), rows.dtype) and NF.segsum_scales_ok(side, rows)):
+            return torch.empty(n_light, dtype=torch.float32, device=rows.device)
+        return None
 
     bwd_data_into = True                              # linear_bwd_data takes ``out=`` (a row block of a larger buffer)
 
@@ -752,7 +763,7 @@ def scatter_hub_sums(sg: ShardedGraph, partial: torch.Tensor, async_op: bool = F
 
 
 def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, w_part, mean: bool, tag: str, bias=None,
-                   direct: bool = False, defer: bool = False, gathered=None):
+                   direct: bool = False, defer: bool = False, gathered=None, light_scales=None):
     """One direction of the hub-cut aggregation of ``rows`` [n_local, F]:
 
         table = all_gather(hub rows of ``rows``)                      | psum = segsum(partial side, rows)
@@ -796,7 +807,8 @@ def _hub_aggregate(sg: ShardedGraph, rows: torch.Tensor, full, partial, w_full, 
                 if t is not None:
                     t.record_stream(b_stream)                      # allocated on ``cur``, used on the partial stream
     _wait(g_work, tag + "_all_gather", table)
-    out = be.segsum(full, table, mean=mean, table2=rows, w=w_full, bias=bias, out=out_full[: sg.nL] if direct else None)
+    kw_sc = {"scales_out": light_scales} if light_scales is not None else {}      # (direct layout: the full side IS the light rows)
+    out = be.segsum(full, table, mean=mean, table2=rows, w=w_full, bias=bias, out=out_full[: sg.nL] if direct else None, **kw_sc)
 
     def hub_rows_arrived():
         if hsum is not None:
@@ -825,7 +837,10 @@ class _ShardedSageFn(torch.autograd.Function):
         if sg.direct_ok:
             d, w = sg.direct(), sg.direct_weights(gcn)
             split = sg.schedule.split_projection and sg.nL > 0 and sg.nH > 0 and not _solo(sg.world)
-            agg, arrived, _ = _hub_aggregate(sg, x_own, d[0], d[1], w["A"], w["B"], not gcn, "fwd", direct=True, defer=split)
+            # the light rows' projection on two fp16 pieces per operand: their scales from the aggregation launch that writes them
+            lsc = be.light_scales(sg.schedule, d[0], x_own, sg.nL, weight) if (split and hasattr(be, "light_scales")) else None
+            agg, arrived, _ = _hub_aggregate(sg, x_own, d[0], d[1], w["A"], w["B"], not gcn, "fwd", direct=True, defer=split,
+                                             light_scales=lsc)
             # both re-laid copies of W (this direction's GEMMs and the backward's) in one launch
             wsf, ws_bwd = be.prepare_weight(weight, ctx.needs_input_grad[0]) if hasattr(be, "prepare_weight") else (None, None)
             kw = {"ws": wsf} if wsf is not None else {}
@@ -838,6 +853,8 @@ class _ShardedSageFn(torch.autograd.Function):
                 kw_light = dict(kw)
                 if hasattr(be, "prepare_weight"):                  # this GEMM shares the chip with the reduce-scatter's kernel
                     kw_light["reserve_cus"] = max(kw.get("reserve_cus", 0), sg.schedule.split_projection_reserve_cus)
+                if lsc is not None:                                # (its own fp16 x 2 copy of W: one more small launch)
+                    kw_light.update(ws=be.prepare_weight(weight, False, f16=True)[0], a_scales=lsc)
                 be.linear_fwd(agg[: sg.nL], weight, bias, out=out[: sg.nL], **kw_light)
                 arrived()
                 be.linear_fwd(agg[sg.nL:], weight, bias, out=out[sg.nL:], **kw)
