@@ -22,7 +22,10 @@
  *   - return value: 0 = ok, <0 = error (text via npi_last_error(), thread-local); no C++
  *     exception crosses the ABI, nothing calls exit();
  *   - node ids in CSR arrays are int32 (N + E + 1 < 2^31); the COO input is int64 as PyG hands it
- *     over (`edge_index` LongTensor [2,E], row 0 = source j, row 1 = target i).
+ *     over (`edge_index` LongTensor [2,E], row 0 = source j, row 1 = target i);
+ *   - ABI 4 (npi_abi_version() == 4): ONE entry point per operation.  The `_ex2` forms of ABI 3 (their `_ex` / plain twins plus one
+ *     optional pointer: row scales in or out) and the plain forms of npi_topk_select / npi_topk_gather / npi_filter_adj are folded
+ *     into the base names, which now take that pointer / flag (NULL / 0 = the old behaviour); npi_entry_col_scale is new.
  */
 #ifndef NPI_GNN_H
 #define NPI_GNN_H
