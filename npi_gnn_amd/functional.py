@@ -183,10 +183,16 @@ def segsum(graph: CSRGraph, side: CSRSide, x: torch.Tensor, w: Optional[torch.Te
 # layers' GEMMs take two fp16 pieces per operand).  Neither the library (ABI 3 on) nor this module keeps a switch.
 
 
+def _gflags(sch: Schedule) -> int:
+    """the ``flags`` a layer under schedule ``sch`` hands to its projection GEMMs (``Schedule.gemm_exact_f32``)"""
+    return NPI_GEMM_EXACT_F32 if sch.gemm_exact_f32 else 0
+
+
 def _f16x2(sch: Schedule, rows: int, K: int, N: int, dtype) -> bool:
     """does a layer under schedule ``sch`` run its f32 projection GEMMs (contraction K, output width N, ``rows`` rows) on two fp16
     pieces per operand (NPI_GEMM_SPLIT_F16X2: three matrix products per tile pair instead of six, the same f32-rounding-level error)?"""
-    return (sch.f16x2_min_rows is not None and rows >= sch.f16x2_min_rows and dtype == torch.float32 and f16x2_shape(rows, K, N))
+    return (sch.f16x2_min_rows is not None and not sch.gemm_exact_f32 and rows >= sch.f16x2_min_rows and dtype == torch.float32
+            and f16x2_shape(rows, K, N))
 
 
 def _gemm_workspace(K: int, N: int, dev) -> torch.Tensor:
@@ -722,7 +728,8 @@ class _SageConvFn(torch.autograd.Function):
             ctx.k_valid = None
             ctx.save_for_backward(agg, weight, *([out] if relu else []))
             return out
-        if _layer_calls_ok() and x.dtype == weight.dtype and x.dtype in (torch.float32, torch.bfloat16) and not (
+        fl = _gflags(sch)                                       # (exact-f32 MFMA kernels on request: the per-op calls carry the flag)
+        if not fl and _layer_calls_ok() and x.dtype == weight.dtype and x.dtype in (torch.float32, torch.bfloat16) and not (
                 x.dtype == torch.bfloat16 and weight.size(0) % 128 != 0 and 2 * _pad128(weight.size(0)) <= 3 * weight.size(0)):
             # the whole layer call as one entry point (the same launches; one trip through the C ABI instead of three)
             agg, out, ctx.ws_bwd = conv_fwd(graph.by_dst, x, w_entry[0] if w_entry else None, True, weight, bias, relu,
@@ -733,7 +740,7 @@ class _SageConvFn(torch.autograd.Function):
         # a2-a4: gather + scatter_mean (w_entry: PyG's `edge_weight.view(-1, 1) * x_j`; the mean still divides by the count)
         # x may be the zero-padded base of the caller's features (sage_conv): agg then keeps the padded width -- zero
         # columns stay zero under a weighted mean -- and both GEMMs run on it (linear_fwd / linear_bwd_weight)
-        agg = padded_aggregate_buffer(x, weight.size(0), graph.by_dst.n_rows, bf16_ok=True)
+        agg = None if fl else padded_aggregate_buffer(x, weight.size(0), graph.by_dst.n_rows, bf16_ok=True)
         if agg is None:
             agg = segsum(graph, graph.by_dst, x, w=w_entry[0] if w_entry else None, mean=True)
         else:
@@ -745,8 +752,8 @@ class _SageConvFn(torch.autograd.Function):
             weight = torch.nn.functional.pad(weight.detach(), (0, 0, 0, agg.size(1) - weight.size(0)))
         # both re-laid copies of W (for this GEMM and for dAgg = dOut W^T of the backward) in one launch
         wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0]) if (
-            agg.size(1) == weight.size(0) and agg.dtype == weight.dtype) else (None, None)
-        out = linear_fwd(agg, weight, bias, relu=relu, ws=wsf)            # a5: agg @ W + b (ReLU in the epilogue on request)
+            agg.size(1) == weight.size(0) and agg.dtype == weight.dtype and not fl) else (None, None)
+        out = linear_fwd(agg, weight, bias, relu=relu, ws=wsf, flags=fl)  # a5: agg @ W + b (ReLU in the epilogue on request)
         ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None
         ctx.save_for_backward(agg, weight, *([out] if relu else []))
         return out
@@ -761,7 +768,8 @@ class _SageConvFn(torch.autograd.Function):
         # symmetric edge list, no per-entry weights: A^T has the rows of A (graph.CSRGraph.symmetric) -- skip the second sort
         tside = (lambda: graph.by_dst) if (graph.symmetric and ctx.w_src is None) else (lambda: graph.by_src)
         overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
-        if not overlap and ctx.k_rows is None and _layer_calls_ok() and (want_w or want_x) and not ctx.f16:
+        fl = _gflags(ctx.sch)
+        if not fl and not overlap and ctx.k_rows is None and _layer_calls_ok() and (want_w or want_x) and not ctx.f16:
             # one stream: the whole backward as one entry point (ReLU mask, dW + db, dAgg GEMM, transposed aggregation)
             out_relu = None
             if ctx.relu:
@@ -782,11 +790,11 @@ class _SageConvFn(torch.autograd.Function):
             return dx, dw, db, None, None, None, None
         ws_bwd = ctx.ws_bwd if not (isinstance(ctx.ws_bwd, Planes) and ctx.ws_bwd.f16) else None     # (fp16 x 2 planes: not for this order)
         if want_w and not overlap:
-            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)   # aggT dOut, colsum
+            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid, flags=fl)   # aggT dOut, colsum
         if want_x:
             # dAgg = dOut W^T, pre-divided by the in-count of its row (fused epilogue), then
             # dX[j] = sum over the entries whose SOURCE is j  ==  segsum over the by-source CSR
-            dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst), ws=ws_bwd)
+            dagg = linear_bwd_data(grad_out, weight, rowscale=graph.inv_count(graph.by_dst), ws=ws_bwd, flags=fl)
             if ctx.k_rows is not None:
                 dagg = dagg[:, : ctx.k_rows]                                 # (the pad columns of dAgg: dOut times zero rows)
             if overlap:
@@ -798,7 +806,7 @@ class _SageConvFn(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 side = _side_stream(dev)
                 side.wait_stream(main)                               # dAgg is complete for the side stream
-                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True, k_valid=ctx.k_valid)
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True, k_valid=ctx.k_valid, flags=fl)
                 with torch.cuda.stream(side):
                     dx = segsum(graph, tside(), dagg, w=ctx.w_src, mean=False)
                 dagg.record_stream(side)                             # allocated on main, read on side
@@ -1004,19 +1012,20 @@ class _GcnAggFirstFn(torch.autograd.Function):
             ctx.save_for_backward(agg, weight)
             return out
         ctx.f16 = False
-        if _layer_calls_ok() and x.dtype == weight.dtype == torch.float32:
+        fl = _gflags(sch)
+        if not fl and _layer_calls_ok() and x.dtype == weight.dtype == torch.float32:
             agg, out, ctx.ws_bwd = conv_fwd(graph.by_dst, x, norm.by_dst, False, weight, bias, False, ctx.needs_input_grad[0])
             ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None
             ctx.save_for_backward(agg, weight)
             return out
-        agg = padded_aggregate_buffer(x, weight.size(0), graph.by_dst.n_rows)
+        agg = None if fl else padded_aggregate_buffer(x, weight.size(0), graph.by_dst.n_rows)
         if agg is None:
             agg = segsum(graph, graph.by_dst, x, w=norm.by_dst)                # sum_e norm_e x[src]
         else:
             segsum(graph, graph.by_dst, x, w=norm.by_dst, out=agg[:, : x.size(1)])
         wsf, ctx.ws_bwd = prepare_weight(weight, backward=ctx.needs_input_grad[0]) if (
-            agg.size(1) == weight.size(0) and agg.dtype == weight.dtype) else (None, None)
-        out = linear_fwd(agg, weight, bias, ws=wsf)
+            agg.size(1) == weight.size(0) and agg.dtype == weight.dtype and not fl) else (None, None)
+        out = linear_fwd(agg, weight, bias, ws=wsf, flags=fl)
         ctx.k_valid = weight.size(0) if agg.size(1) != weight.size(0) else None
         ctx.save_for_backward(agg, weight)
         return out
@@ -1031,7 +1040,8 @@ class _GcnAggFirstFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_x = ctx.needs_input_grad[0]
         overlap = want_w and want_x and _overlaps(ctx.sch, grad_out.size(0))
-        if not overlap and _layer_calls_ok() and (want_w or want_x) and grad_out.dtype == torch.float32 and not ctx.f16:
+        fl = _gflags(ctx.sch)
+        if not fl and not overlap and _layer_calls_ok() and (want_w or want_x) and grad_out.dtype == torch.float32 and not ctx.f16:
             dx, dw, db = conv_bwd(graph.by_src if want_x else graph.by_dst, grad_out, None, agg, weight, None, norm.by_src,
                                   ctx.ws_bwd, want_x, want_w, ctx.has_bias)
             return dx, dw, db, None, None
@@ -1041,15 +1051,15 @@ class _GcnAggFirstFn(torch.autograd.Function):
             return dx, dw, db, None, None
         ws_bwd = ctx.ws_bwd if not (isinstance(ctx.ws_bwd, Planes) and ctx.ws_bwd.f16) else None
         if want_w and not overlap:
-            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid)
+            dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, k_valid=ctx.k_valid, flags=fl)
         if want_x:
-            dagg = linear_bwd_data(grad_out, weight, ws=ws_bwd)
+            dagg = linear_bwd_data(grad_out, weight, ws=ws_bwd, flags=fl)
             if overlap:                                                        # see _SageConvFn.backward
                 dev = grad_out.device
                 main = torch.cuda.current_stream(dev)
                 side = _side_stream(dev)
                 side.wait_stream(main)
-                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True, k_valid=ctx.k_valid)
+                dw, db = linear_bwd_weight(agg, grad_out, want_bias=ctx.has_bias, shared=True, k_valid=ctx.k_valid, flags=fl)
                 with torch.cuda.stream(side):
                     dx = segsum(graph, graph.by_src, dagg, w=norm.by_src)
                 dagg.record_stream(side)
@@ -1372,10 +1382,11 @@ class _GatConvFn(torch.autograd.Function):
         # layer in front): the projection on two fp16 pieces per operand
         _check_scales(x_scales, x.size(0), "gat_conv(x_scales=)")
         xs = x_scales if (x_scales is not None and _f16x2(sch, x.size(0), weight.size(0), weight.size(1), x.dtype)) else None
-        if H == 1 and sch.gat_scores_epilogue and linear_fwd_scores_ok(x, weight):
+        fl = _gflags(sch)                                       # (exact-f32 kernels on request: no store-epilogue fusions)
+        if H == 1 and sch.gat_scores_epilogue and not fl and linear_fwd_scores_ok(x, weight):
             hfeat, a_dst, a_src = linear_fwd_scores(x, weight, att2, a_scales=xs)   # x @ W, both scores in its store epilogue
         else:
-            hfeat = linear_fwd(x, weight, a_scales=xs)                       # x @ W
+            hfeat = linear_fwd(x, weight, a_scales=xs, flags=fl)             # x @ W
             a_dst, a_src = gat_scores(hfeat, att2, H, C)
         out_scales = None
         if H == 1 and C % 4 == 0 and C <= 256 and d.nnz_max > 0 and sch.gat_fused_stats:
@@ -1429,7 +1440,7 @@ class _GatConvFn(torch.autograd.Function):
             # (a_dst, m, 1/s, D) of every (target, head) in one float4; alpha is recomputed per entry by the lane that owns it
             tpack = gat_pack_targets(a_dst, m, s, D)                           # [N H, 4]
             dh = torch.empty((N, H * C), dtype=torch.float32, device=dev)
-            rank2 = (sch.gat_rank2_epilogue and H == 1 and N >= sch.gat_rank2_min_rows and ctx.needs_input_grad[0]
+            rank2 = (sch.gat_rank2_epilogue and not sch.gemm_exact_f32 and H == 1 and N >= sch.gat_rank2_min_rows and ctx.needs_input_grad[0]
                      and x.dtype == torch.float32 and weight.size(0) % 4 == 0 and linear_bwd_data_rank2_ok(dh, weight))
             # dX's GEMM on two fp16 pieces per operand: the row scales of d hfeat from the pass that writes it (256 channels)
             dh_scales = (torch.empty(N, dtype=torch.float32, device=dev)
@@ -1467,8 +1478,8 @@ class _GatConvFn(torch.autograd.Function):
             datt.record_stream(main)
         elif ctx.needs_input_grad[2]:
             datt = gat_att_grad(hfeat, g_dst, g_src, H, C).view(1, H, 2 * C)
-        dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
-        dx = linear_bwd_data(dh, weight) if ctx.needs_input_grad[0] else None
+        dw = linear_bwd_weight(x, dh, want_bias=False, flags=_gflags(sch))[0] if ctx.needs_input_grad[1] else None
+        dx = linear_bwd_data(dh, weight, flags=_gflags(sch)) if ctx.needs_input_grad[0] else None
         if overlap:
             main.wait_stream(side)
         return dx, dw, datt, db, None, None, None, None, None, None, None

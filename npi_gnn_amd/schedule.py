@@ -20,6 +20,11 @@ class Schedule:
     #: HBM-bound passes of the GATConv backward under its GEMMs.  Only from ``overlap_min_rows`` rows on.
     overlap_streams: bool = True
     overlap_min_rows: int = 100_000
+    #: the projection GEMMs of the single-GPU layers on the exact-f32 MFMA kernels (``NPI_GEMM_EXACT_F32``: 1/16 of the 16-bit
+    #: matrix rate) instead of the f32-accurate splits: for a model whose activations may hold ``Inf`` -- an operand split turns
+    #: ``Inf`` into ``NaN`` where ``torch.matmul`` keeps ``Inf``.  Takes the per-op path without store-epilogue
+    #: fusions.  (Round 5 had a module global for this, ``functional.GEMM_FLAGS``.)
+    gemm_exact_f32: bool = False
     #: rows from which the f32 projection GEMMs of the single-GPU layers run on two fp16 pieces per operand (NPI_GEMM_SPLIT_F16X2:
     #: three matrix products per tile pair instead of six, the same f32-rounding-level error -- 256 features, where the launch
     #: that writes the left operand writes its row scales too); None: never.  Below, the GEMMs are launch-bound

@@ -32,7 +32,7 @@ def test_no_environment_switch_selects_a_path():
     assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "gat_scores_epilogue",
                       "direct_hub_rows", "partial_stream", "split_projection", "gat_direct", "early_hub_gather", "gemm_reserve_cus",
                       "split_projection_reserve_cus", "gat_src_rowsum_beside_dw", "gat_fused_stats", "aggregate_first_backward",
-                      "f16x2_min_rows"}
+                      "f16x2_min_rows", "gemm_exact_f32"}
     assert CONSERVATIVE == DEFAULT.but(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
                                        gat_rank2_epilogue=False)
 
@@ -62,6 +62,9 @@ def _run(make, graph, x, go):
     # (dAgg GEMM on bf16 x 3, then the transposed aggregation), against bf16 x 3 throughout, and on one stream
     ("sage256", dict(aggregate_first_backward=False)), ("gcn256", dict(aggregate_first_backward=False)),
     ("sage256", dict(f16x2_min_rows=None)), ("sage256", dict(overlap_streams=False)), ("gcn256", dict(overlap_streams=False)),
+    # the exact-f32 MFMA kernels for a whole layer (what a model with Inf activations selects)
+    ("sage", dict(gemm_exact_f32=True)), ("sage256", dict(gemm_exact_f32=True)), ("gcn", dict(gemm_exact_f32=True)),
+    ("gat", dict(gemm_exact_f32=True)),
     ("gat", dict(overlap_streams=False)), ("gat", dict(gat_rank2_epilogue=False)), ("gat", dict(gat_rank2_min_rows=10 ** 9)),
     ("gat", dict(gat_scores_epilogue=False)), ("gat", dict(gat_src_rowsum_beside_dw=True)), ("gat", dict(gat_fused_stats=False)),
 ])
@@ -71,7 +74,7 @@ def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     cls = {"sage": npi.SAGEConv, "gcn": npi.GCNConv, "gat": npi.GATConv}[kind[:-3] if kind.endswith("256") else kind]
     ref = _run(lambda: cls(F, F), graph, x, go)
     got = _run(lambda: cls(F, F, schedule=DEFAULT.but(**alt)), graph, x, go)
-    if "gat_scores_epilogue" in alt or "gat_fused_stats" in alt or "f16x2_min_rows" in alt:
+    if "gat_scores_epilogue" in alt or "gat_fused_stats" in alt or "f16x2_min_rows" in alt or "gemm_exact_f32" in alt:
         # the scores' dots / the parts of cut rows in another association; the projection in another arithmetic
         assert float((got[0] - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
     else:
@@ -80,6 +83,27 @@ def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     # the rank-2 epilogue moves the attention terms into the GEMM's store)
     for a, r in zip(got[1:], ref[1:]):
         assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max())
+
+
+@pytest.mark.gpu
+def test_exact_f32_schedule_keeps_inf_where_torch_matmul_does(dev):
+    """the default projection arithmetic (an operand split) turns an Inf activation into NaN; a layer built with
+    Schedule(gemm_exact_f32=True) keeps it Inf exactly where the PyG-style torch ops do"""
+    from oracle import ref_conv as R
+    g = torch.Generator().manual_seed(2)
+    N, E, F = 600, 4000, 128
+    ei = torch.randint(0, N, (2, E), generator=g)
+    x = torch.randn(N, F, generator=g)
+    x[17, 5] = float("inf")
+    conv = npi.SAGEConv(F, F, schedule=DEFAULT.but(gemm_exact_f32=True)).to(dev)
+    out = conv(x.to(dev), ei.to(dev)).cpu()
+    ref = R.sage_conv(x, ei, conv.weight.detach().cpu(), conv.bias.detach().cpu())
+    assert bool(torch.isinf(ref).any()) and torch.equal(torch.isinf(out), torch.isinf(ref)) and torch.equal(torch.isnan(out), torch.isnan(ref))
+    fin = torch.isfinite(ref)
+    assert float((out[fin] - ref[fin]).abs().max()) <= 1e-4
+    plain = npi.SAGEConv(F, F).to(dev)
+    plain.load_state_dict(conv.state_dict())
+    assert bool(torch.isnan(plain(x.to(dev), ei.to(dev))).any())              # the documented difference of the default arithmetic
 
 
 _ALTS = [dict(direct_hub_rows=False), dict(partial_stream=False), dict(split_projection=False), dict(early_hub_gather=True), dict(gemm_reserve_cus=16), dict(split_projection_reserve_cus=0),
