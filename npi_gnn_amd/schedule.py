@@ -23,7 +23,7 @@ class Schedule:
     #: the projection GEMMs of the single-GPU layers on the exact-f32 MFMA kernels (``NPI_GEMM_EXACT_F32``: 1/16 of the 16-bit
     #: matrix rate) instead of the f32-accurate splits: for a model whose activations may hold ``Inf`` -- an operand split turns
     #: ``Inf`` into ``NaN`` where ``torch.matmul`` keeps ``Inf``.  Takes the per-op path without store-epilogue
-    #: fusions.  (Round 5 had a module global for this, ``functional.GEMM_FLAGS``.)
+    #: fusions.  (Round 5 had a module global for this.)
     gemm_exact_f32: bool = False
     #: rows from which the f32 projection GEMMs of the single-GPU layers run on two fp16 pieces per operand (NPI_GEMM_SPLIT_F16X2:
     #: three matrix products per tile pair instead of six, the same f32-rounding-level error -- 256 features, where the launch
