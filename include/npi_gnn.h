@@ -269,10 +269,22 @@ int npi_row_scales(const float* A, int64_t lda, int64_t M, int64_t K, float* sca
  * multiples of 16; workspace 16-byte aligned, npi_linear_workspace_bytes(K, N) bytes per copy. */
 int npi_linear_prepare(const void* W, int64_t ldw, int64_t K, int64_t N, int which, int dtype, void* workspace,
                        int64_t workspace_bytes, void* stream);
+/* a_col_scales [K] / dc_col_scales [N] (16-byte aligned; NULL without the flag): NPI_GEMM_SPLIT_F16X2 for the weight gradient -- two fp16
+ * pieces per operand, three matrix products per tile instead of six.  The contraction runs over the ROWS, so what factors out of
+ * the sum is a power-of-two scale per COLUMN of A and of dC: npi_col_scales.  K, N multiples of 128, M >= 4096, f32. */
 int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
                              void* dW, int64_t lddw, void* db,
                              int64_t M, int64_t K, int64_t N,
-                             float* workspace, int64_t workspace_elems, int dtype, int flags, int shared, void* stream);
+                             float* workspace, int64_t workspace_elems, int dtype, int flags, int shared,
+                             const float* a_col_scales, const float* dc_col_scales, void* stream);
+/* scales[k] = the power of two that puts column k's largest magnitude into [2^14, 2^15).  A != NULL: from the column maxima of A
+ * [M, K] (one pass over it: for a matrix that does not change between steps, once).  A == NULL: from `row_scales` [M] (npi_row_scales,
+ * or the launch that wrote the matrix): the SMALLEST row scale -- the scale of the matrix's largest magnitude -- for every column
+ * alike, without a pass over the matrix; elements more than 2^-18 below that magnitude then keep an absolute 2^-39 of it rather
+ * than 22 relative bits.  workspace: npi_col_scales_workspace_elems(M, K) floats. */
+int64_t npi_col_scales_workspace_elems(int64_t M, int64_t K);
+int npi_col_scales(const float* A, int64_t lda, int64_t M, int64_t K, const float* row_scales, float* scales,
+                   float* workspace, int64_t workspace_elems, void* stream);
 /* a_scales / dc_scales: the row scales of the left operand for NPI_GEMM_SPLIT_F16X2 in `flags` (npi_row_scales, or the launch that
  * wrote the operand); NULL / ignored without the flag.  (ABI 4: the scale-taking twins of ABI 3, folded.) */
 int npi_linear_fwd_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,

@@ -70,7 +70,9 @@ PROTOTYPES = {
     "npi_linear_bwd_data_rank2": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "npi_gat_rank2_cols": (c_int, [_P, _I, _P, _I, _I, _P, _P]),
     "npi_gat_rank2_tail": (c_int, [_P, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
-    "npi_linear_bwd_weight_ex": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, c_int, c_int, _P]),
+    "npi_linear_bwd_weight_ex": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, c_int, c_int, c_int, _P, _P, _P]),
+    "npi_col_scales_workspace_elems": (_I, [_I, _I]),
+    "npi_col_scales": (c_int, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "npi_conv_fwd": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _I, c_int, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, c_int, c_int, c_int,
                              c_int, _P, _I, _P]),
     "npi_conv_bwd": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, c_int, c_int, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I,

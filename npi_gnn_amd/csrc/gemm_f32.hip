@@ -595,6 +595,64 @@ colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, in
         part[(int64_t)blockIdx.y * N + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Power-of-two COLUMN scales for the fp16 x 2 weight-gradient GEMM (the contraction runs over the rows, so only a column scale
+// factors out of the sum).  Two sources: the column maxima of a matrix (one pass over it: static input features, once), or --
+// no pass at all -- the smallest of the ROW scales its producer wrote, i.e. the scale of the whole matrix's largest magnitude, for
+// every column alike (what an aggregation or the fused GATConv pass leaves behind; elements more than 2^-18 below that magnitude
+// then keep an absolute 2^-39 of it instead of 22 relative bits).
+__global__ void __launch_bounds__(256)
+colmax_partial_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, int rows, float* __restrict__ part) {
+    __shared__ float red[4][256];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int rbeg = blockIdx.y * rows, rend = min(M, rbeg + rows);
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+#pragma unroll 8
+        for (int r = rbeg + wave; r < rend; r += 4) {
+            const float* src = X + (int64_t)r * ldx + c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c + q < N) m[q] = fmaxf(m[q], fabsf(src[q]));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[wave][lane * 4 + q] = m[q];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < N) part[(int64_t)blockIdx.y * N + cc] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+}
+__global__ void colmax_finish_kernel(const float* __restrict__ part, int nchunks, int N, float* __restrict__ scales) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float m = 0.f;
+    for (int z = 0; z < nchunks; ++z) m = fmaxf(m, part[(int64_t)z * N + c]);
+    scales[c] = pow2_scale_of(m);
+}
+__global__ void __launch_bounds__(256)
+minscale_partial_kernel(const float* __restrict__ rs, int64_t M, float* __restrict__ part) {
+    __shared__ float red[4];
+    float m = 3.0e38f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) m = fminf(m, rs[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fminf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+__global__ void __launch_bounds__(256)
+minscale_finish_kernel(const float* __restrict__ part, int nparts, int K, float* __restrict__ scales) {
+    __shared__ float red[4];
+    float m = 3.0e38f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fminf(m, part[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fminf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    if (!(m < 3.0e38f)) m = 1.f;                          // no row at all
+    for (int k = threadIdx.x; k < K; k += 256) scales[k] = m;
+}
+
 // ---- f32 GEMM on the bf16 matrix cores: 3-way split ------------------------------------------------
 // x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): three bf16 carry the 24
 // significand bits of an f32 (the remainder is <= 2^-25 |x|; exponent range is the f32 one).  The
@@ -1358,6 +1416,9 @@ struct DwArgs {
     int64_t m_main;                  // nodes covered (multiple of 16)
     int64_t per;                     // nodes per slab (multiple of 16)
     int tiles_m, tiles_n, nslab;
+    // fp16 x 2 (F16): the power-of-two scale of every COLUMN of A ([K]) and of dC ([N]) -- the contraction runs over the rows, so
+    // only column scales factor out of the sum; null otherwise
+    const float* a_cs; const float* b_cs;
 };
 
 // LDS row of column 4 cg + c of the tile: inside every block of 32 columns the 8 x 4 (cg, c) grid is stored TRANSPOSED,
@@ -1371,14 +1432,20 @@ __device__ __forceinline__ int dw_col(int r) { return (r & ~31) + 4 * (r & 7) + 
 // consumer issues one MFMA per product tile (it still reads the three plane slots of a fragment -- the hand-tuned wait counts
 // of ws_consume_step assume them -- and ignores two).  Half the loader's bytes and a sixth of the matrix work: the kernel is
 // HBM-bound.  (Rounds 1-4 ran bf16 dW on the exact-f32 tile kernel: 1.8 ms at C4 against 0.93 for f32 storage.)
-template <int TN, bool BF16IN = false>
+// F16 (round 6; f32 operands): two fp16 pieces per operand, every COLUMN of A and of dC scaled into fp16's range by a power of two
+// (a_cs / b_cs), three products per tile pair, the slab store undoes both scales (exact).  Where dW is EXPOSED -- GATConv's
+// backward, whose big HBM-bound pass produces dW's own operand -- the kernel is bound by its consumer step (2,300 cycles for
+// 1,536 of MFMAs on three planes; EXPERIMENTS A36), which two planes shorten as they do in the forward kernel.
+template <int TN, bool BF16IN = false, bool F16 = false>
 __global__ void __launch_bounds__(WS_THREADS, 1)
 gemm_dw_split_kernel(DwArgs a) {
+    static_assert(!(BF16IN && F16), "bf16 operands need no split");
     constexpr int TM = 2;
     constexpr int ES = BF16IN ? 2 : 4;                      // bytes per stored operand element
     constexpr int BN = 64 * TN;
     constexpr int APL = 128 * 32, BPL = BN * 32;
-    constexpr int BUF = 3 * APL + 3 * BPL;
+    constexpr int NPL = F16 ? 2 : 3;                        // plane images per operand
+    constexpr int BUF = NPL * APL + NPL * BPL;
     constexpr int NST = 4;
     constexpr int BSETS = BN / 2;                           // B producer threads: BN / 4 column groups x 2 node halves
     __shared__ __attribute__((aligned(16))) char lds[NST * BUF];
@@ -1410,10 +1477,18 @@ gemm_dw_split_kernel(DwArgs a) {
         // rows x 2 halves = 8 different 16-byte bank groups (see dw_row): conflict-free without any per-lane rotation
         const int half = q & 1, cg = q >> 1;
         const int64_t ld = isA ? a.lda : a.ldc;
-        char* img = lds + (isA ? 0 : 3 * APL);
+        char* img = lds + (isA ? 0 : NPL * APL);
         const int plane = isA ? APL : BPL;
         const bool do_db = isB && a.db_slabs != nullptr && mt == 0;
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+        float cs[4] = {1.f, 1.f, 1.f, 1.f};                 // F16: the scales of this thread's four columns, for the whole launch
+        if constexpr (F16) {
+            if (isA || isB) {
+                const float4 c4 = *reinterpret_cast<const float4*>((isA ? a.a_cs + mt * 128 : a.b_cs + nt * BN) + 4 * cg);
+                cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+            }
+        }
+        (void)cs;
         // Three register sets: two k-steps of loads (16 x 16 B per thread) stay in flight while the third is split and
         // stored -- with one set ahead the kernel was latency-bound (2.1 us per k-step, 2.9 TB/s).  As in the split kernel
         // above the loads and their waits are written in assembly: hipcc's own vmcnt bookkeeping drains the ring at the
@@ -1530,15 +1605,23 @@ gemm_dw_split_kernel(DwArgs a) {
             for (int c = 0; c < 4; ++c) {
                 const float v[8] = {c0[c], c1[c], c2[c], c3[c], c4[c], c5[c], c6[c], c7[c]};
                 if (do_db) dbs[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                char* dst = st + simg(dw_row(cg, c), half);
+                if constexpr (F16) {
+                    uint32_t p0[4], p1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) split2_pair(v[2 * i] * cs[c], v[2 * i + 1] * cs[c], p0[i], p1[i]);
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+                    *reinterpret_cast<uint4*>(dst + plane) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+                } else {
                 uint32_t p0[4], p1[4], p2[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     split3_pair(v[2 * i], v[2 * i + 1], p0[i], p1[i], p2[i]);
                 }
-                char* dst = st + simg(dw_row(cg, c), half);
                 *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
                 *reinterpret_cast<uint4*>(dst + plane) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
                 *reinterpret_cast<uint4*>(dst + 2 * plane) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+                }
             }
             signal(&full[stg]);
         };
@@ -1588,7 +1671,7 @@ gemm_dw_split_kernel(DwArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) offa[i] = simg(wm * 64 + i * 32 + li, lh);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) offb[j] = 3 * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
+    for (int j = 0; j < TN; ++j) offb[j] = NPL * APL + simg(wn * (32 * TN) + j * 32 + li, lh);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1597,12 +1680,12 @@ gemm_dw_split_kernel(DwArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     if (nk > 0) {
-        frag_t af[TM][3], bf[TN][3];
+        frag_t af[TM][NPL], bf[TN][NPL];
         const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
         wait_ge(&full[0], 4);
-        ws_consume_first<TM, TN, APL, BPL>(lds_base, offa, offb, af, bf);
+        ws_consume_first<TM, TN, APL, BPL, NPL>(lds_base, offa, offb, af, bf);
         for (int g = 0; g < nk; ++g)
-            ws_consume_step<TM, TN, APL, BPL, BUF, NST, BF16IN>(lds_base, full, empty, g, g + 1 < nk, offa, offb, af, bf, acc);
+            ws_consume_step<TM, TN, APL, BPL, BUF, NST, BF16IN, NPL, F16>(lds_base, full, empty, g, g + 1 < nk, offa, offb, af, bf, acc);
     }
     // the tile of this slab (zeros when the slab holds no node: slab_reduce adds every slab)
     // Accumulator tile = C^T of the LDS-row grid: the lane owns LDS row li of the A image, its registers run along LDS rows
@@ -1611,12 +1694,16 @@ gemm_dw_split_kernel(DwArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = mt * 128 + dw_col(wm * 64 + i * 32 + li);
+        float ia = 1.f;                                     // F16: 1 / (scale of A's column = this row of dW); exact
+        if constexpr (F16) ia = pow2_inverse(a.a_cs[row]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int col = nt * BN + dw_col(wn * (32 * TN) + j * 32 + 8 * (q >> 2) + 4 * lh + (q & 3));
-                C[(int64_t)row * a.N + col] = acc[i][j][q];
+                float v = acc[i][j][q];
+                if constexpr (F16) v = (v * ia) * pow2_inverse(a.b_cs[col]);     // one after the other: no underflow on the way out
+                C[(int64_t)row * a.N + col] = v;
             }
     }
 }
@@ -2314,11 +2401,46 @@ extern "C" int64_t npi_linear_bwd_weight_workspace_elems(int64_t M, int64_t K, i
 }
 
 // dW[K,N] = A[M,K]^T @ dC[M,N] (contract over M), db[N] = colsum(dC); A, dC, dW, db stored as `dtype`
+extern "C" int64_t npi_col_scales_workspace_elems(int64_t M, int64_t K) {
+    if (M < 0 || K <= 0) return -1;
+    const int64_t a = ceil_div(M > 0 ? M : 1, (int64_t)colsum_rows(M)) * K;
+    return a > 256 ? a : 256;
+}
+
+extern "C" int npi_col_scales(const float* A, int64_t lda, int64_t M, int64_t K, const float* row_scales, float* scales,
+                              float* workspace, int64_t workspace_elems, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NPI_REQUIRE(M >= 0 && K > 0 && M < 0x7fffffff && K < 0x7fffffff, "npi_col_scales: bad size");
+    NPI_REQUIRE(scales && workspace && (A != nullptr || row_scales != nullptr), "npi_col_scales: null pointer (A or row_scales)");
+    if (workspace_elems < npi_col_scales_workspace_elems(M, K)) {
+        set_error("npi_col_scales: workspace too small (npi_col_scales_workspace_elems)");
+        return NPI_ERR_WORKSPACE;
+    }
+    if (A == nullptr) {                  // the matrix's global scale from its row scales, for every column
+        const int nparts = (int)(M < 256 * 256 ? ceil_div(M > 0 ? M : 1, 256) : 256);
+        minscale_partial_kernel<<<nparts, 256, 0, stream>>>(row_scales, M, workspace);
+        minscale_finish_kernel<<<1, 256, 0, stream>>>(workspace, nparts, (int)K, scales);
+        return check_launch("npi_col_scales");
+    }
+    NPI_REQUIRE(lda >= K, "npi_col_scales: leading dimension too small");
+    const int rows = colsum_rows(M);
+    const int nchunks = (int)ceil_div(M > 0 ? M : 1, rows);
+    dim3 cg((unsigned)ceil_div(K, 256), (unsigned)nchunks);
+    colmax_partial_kernel<<<cg, 256, 0, stream>>>(A, lda, (int)M, (int)K, rows, workspace);
+    colmax_finish_kernel<<<(unsigned)ceil_div(K, 256), 256, 0, stream>>>(workspace, nchunks, (int)K, scales);
+    return check_launch("npi_col_scales");
+}
+
 extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* dC, int64_t lddc,
                                         void* dW, int64_t lddw, void* db, int64_t M, int64_t K, int64_t N,
                                         float* workspace, int64_t workspace_elems, int dtype, int flags, int shared,
-                                        void* stream_) {
+                                        const float* a_col_scales, const float* dc_col_scales, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool f16 = (flags & NPI_GEMM_SPLIT_F16X2) != 0;
+    NPI_REQUIRE(!f16 || (a_col_scales && dc_col_scales && dtype == NPI_F32 && !(flags & (NPI_GEMM_EXACT_F32 | NPI_GEMM_A_ZERO_PADDED)) &&
+                         K % 128 == 0 && N % 128 == 0 && M >= 4096 && ((uintptr_t)a_col_scales % 16) == 0 && ((uintptr_t)dc_col_scales % 16) == 0),
+                "npi_linear_bwd_weight_ex: NPI_GEMM_SPLIT_F16X2 needs both column-scale vectors (npi_col_scales; 16-byte aligned), f32 "
+                "storage, K and N multiples of 128, M >= 4096, and excludes NPI_GEMM_EXACT_F32 / NPI_GEMM_A_ZERO_PADDED");
     NPI_REQUIRE(M >= 0 && K > 0 && N > 0, "npi_linear_bwd_weight: bad size");
     NPI_REQUIRE(M < 0x7fffffff && K < 0x7fffffff && N < 0x7fffffff, "npi_linear_bwd_weight: size > int32");
     NPI_REQUIRE(dtype == NPI_F32 || dtype == NPI_BF16, "npi_linear_bwd_weight: bad dtype");
@@ -2349,10 +2471,14 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         bool wide;
         dw_split_plan(m16, Kp, N, shared != 0, nslab, per, tm, tn, wide);
         float* db_slabs = workspace + (int64_t)(nslab + 1) * Kp * N;
-        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)Kp, (int)N, m16, per, tm, tn, nslab};
+        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)Kp, (int)N, m16, per, tm, tn, nslab,
+                 f16 ? a_col_scales : nullptr, f16 ? dc_col_scales : nullptr};
         const unsigned grid = (unsigned)(ceil_div(nslab, 8) * 8 * tm * tn);     // slots of 8 slabs (one per XCD) x tiles
-        if (wide) gemm_dw_split_kernel<4><<<grid, WS_THREADS, 0, stream>>>(d);
-        else      gemm_dw_split_kernel<2><<<grid, WS_THREADS, 0, stream>>>(d);
+        if (f16) {
+            if (wide) gemm_dw_split_kernel<4, false, true><<<grid, WS_THREADS, 0, stream>>>(d);
+            else      gemm_dw_split_kernel<2, false, true><<<grid, WS_THREADS, 0, stream>>>(d);
+        } else if (wide) gemm_dw_split_kernel<4><<<grid, WS_THREADS, 0, stream>>>(d);
+        else             gemm_dw_split_kernel<2><<<grid, WS_THREADS, 0, stream>>>(d);
         // slabs in slab order, the < 16 trailing nodes and db in one launch
         dw_finish_kernel<float><<<gwb, 256, 0, stream>>>(workspace, Kp * N, nslab, (int)K, (int)N, (float*)dW, lddw, db_slabs, 2 * nslab,
                                                   (float*)db, fp(advance(A, m16 * lda, es)), lda, fp(advance(dC, m16 * lddc, es)), lddc,
@@ -2367,7 +2493,7 @@ extern "C" int npi_linear_bwd_weight_ex(const void* A, int64_t lda, const void* 
         bool wide;
         dw_split_plan(m16, K, N, shared != 0, nslab, per, tm, tn, wide);
         float* db_slabs = workspace + (int64_t)(nslab + 1) * K * N;
-        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)K, (int)N, m16, per, tm, tn, nslab};
+        DwArgs d{fp(A), lda, fp(dC), lddc, workspace, db ? db_slabs : nullptr, (int)K, (int)N, m16, per, tm, tn, nslab, nullptr, nullptr};
         const unsigned grid = (unsigned)(ceil_div(nslab, 8) * 8 * tm * tn);
         if (wide) gemm_dw_split_kernel<4, true><<<grid, WS_THREADS, 0, stream>>>(d);
         else      gemm_dw_split_kernel<2, true><<<grid, WS_THREADS, 0, stream>>>(d);

@@ -53,7 +53,7 @@ extern "C" int npi_conv_bwd(const void* dout, int64_t lddo, const float* out_rel
     }
     if (dW != nullptr) {                           // agg^T dOut and the column sums of dOut (db may be null)
         rc = npi_linear_bwd_weight_ex(agg, ldagg, g, ldg, dW, lddw, db, N, K, Nout, dw_ws, dw_ws_elems, dtype,
-                                      gemm_flags & (NPI_GEMM_EXACT_F32 | NPI_GEMM_SPLIT_BF16 | NPI_GEMM_A_ZERO_PADDED), 0, stream);
+                                      gemm_flags & (NPI_GEMM_EXACT_F32 | NPI_GEMM_SPLIT_BF16 | NPI_GEMM_A_ZERO_PADDED), 0, nullptr, nullptr, stream);
         if (rc != NPI_OK) return rc;
     }
     if (dx != nullptr) {                           // dAgg = rowscale * (dOut W^T), then dX = A^T dAgg over the transposed CSR

@@ -445,11 +445,43 @@ def gat_rank2_tail(P: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor, dw
     return datt
 
 
+def col_scales(a: Optional[torch.Tensor] = None, row_scales: Optional[torch.Tensor] = None, cols: Optional[int] = None) -> torch.Tensor:
+    """``[K]`` power-of-two COLUMN scales for ``linear_bwd_weight(a_cs=, dc_cs=)`` (``npi_col_scales``): from the column maxima
+    of ``a`` (one pass over it -- for a matrix that does not change between steps, once), or -- ``a`` None -- the smallest of the
+    ``row_scales`` its producer wrote, for each of ``cols`` columns alike (no pass over the matrix)."""
+    lib = load()
+    if a is not None:
+        dev = require_gpu(a)
+        if a.dtype != torch.float32 or a.dim() != 2 or a.stride(1) != 1:
+            raise TypeError("col_scales: a float32 matrix with unit column stride")
+        M, K = a.shape
+    else:
+        if row_scales is None or cols is None:
+            raise ValueError("col_scales: a matrix, or its row scales and its column count")
+        dev = require_gpu(row_scales)
+        _check_scales(row_scales, row_scales.numel(), "col_scales")
+        M, K = int(row_scales.numel()), int(cols)
+    n_ws = int(lib.npi_col_scales_workspace_elems(M, K))
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+    out = torch.empty(K, dtype=torch.float32, device=dev)
+    check(lib.npi_col_scales(ptr(a), a.stride(0) if a is not None else 0, M, K, ptr(row_scales) if a is None else 0, ptr(out), ptr(ws),
+                             n_ws, stream_ptr(dev)), "npi_col_scales")
+    return out
+
+
+def dw_f16x2_shape(M: int, K: int, N: int) -> bool:
+    """shapes whose f32 weight-gradient GEMM takes the fp16 x 2 matrix-core kernel (``linear_bwd_weight(a_cs=, dc_cs=)``)"""
+    return M >= 4096 and K % 128 == 0 and N % 128 == 0
+
+
 def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True, shared: bool = False,
-                      flags: Optional[int] = None, k_valid: Optional[int] = None):
+                      flags: Optional[int] = None, k_valid: Optional[int] = None, a_cs: Optional[torch.Tensor] = None,
+                      dc_cs: Optional[torch.Tensor] = None):
     """``shared``: the GEMM will run beside an HBM-bound kernel on another stream (smaller grid; a per-call argument of
     ``npi_linear_bwd_weight_ex``, no process-wide switch is touched).  ``k_valid``: ``a`` is ``[M, Kp]`` with only the
-    first ``k_valid`` columns data and the rest ZERO (see ``linear_fwd``); dW then has ``k_valid`` rows."""
+    first ``k_valid`` columns data and the rest ZERO (see ``linear_fwd``); dW then has ``k_valid`` rows.
+    ``a_cs`` / ``dc_cs`` (both or none; ``col_scales``): the column scales of the two operands -- the GEMM then runs on two fp16
+    pieces per operand (``NPI_GEMM_SPLIT_F16X2``: three matrix products per tile instead of six; ``dw_f16x2_shape``)."""
     dev = require_gpu(a, dc)
     a = _fc(a, "a")
     dc = _fc(dc, "dC", a)
@@ -461,6 +493,15 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True,
         if Ka != _pad128(K) or a.dtype != torch.float32:
             raise ValueError(f"a zero-padded a must be f32 and {_pad128(K)} wide (got {Ka})")
         fl |= NPI_GEMM_A_ZERO_PADDED
+    if (a_cs is None) != (dc_cs is None):
+        raise ValueError("linear_bwd_weight: a_cs and dc_cs come together")
+    if a_cs is not None and (a.dtype != torch.float32 or K != Ka or fl & NPI_GEMM_EXACT_F32 or not dw_f16x2_shape(M, K, N)):
+        a_cs = dc_cs = None                                     # (storage / shape / flags the fp16 x 2 kernel does not serve)
+    if a_cs is not None:
+        for v, n, what in ((a_cs, K, "a_cs"), (dc_cs, N, "dc_cs")):
+            if v.dtype != torch.float32 or v.numel() != n or not v.is_contiguous() or v.device != a.device:
+                raise ValueError(f"linear_bwd_weight: {what} must be a contiguous float32 vector with {n} entries on the operands' device")
+        fl |= NPI_GEMM_SPLIT_F16X2
     lib = load()
     n_ws = int(lib.npi_linear_bwd_weight_workspace_elems(M, Ka, N))
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
@@ -469,7 +510,7 @@ def linear_bwd_weight(a: torch.Tensor, dc: torch.Tensor, want_bias: bool = True,
     with _gemm_events("bwd_weight", 2.0 * M * K * N, dev):
         check(lib.npi_linear_bwd_weight_ex(ptr(a), a.stride(0), ptr(dc), dc.stride(0), ptr(dw), dw.stride(0), ptr(db),
                                            M, K, N, ptr(ws), n_ws, _code(a), fl,
-                                           1 if shared else 0, stream_ptr(dev)),
+                                           1 if shared else 0, ptr(a_cs), ptr(dc_cs), stream_ptr(dev)),
               "npi_linear_bwd_weight")
     return dw, db
 
@@ -1410,6 +1451,7 @@ class _GatConvFn(torch.autograd.Function):
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, float(slope)
         ctx.has_bias = bias is not None
         ctx.sch = sch
+        ctx.x_scales = xs                                    # (the backward's dW GEMM takes its column scales from them)
         ctx.save_for_backward(x, weight, att2, hfeat, a_dst, a_src, m, s, out,
                               bias if bias is not None else torch.empty(0, device=x.device))
         if want_scales:
@@ -1505,6 +1547,13 @@ class _GatConvFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         overlap = _overlaps(ctx.sch, x.size(0))
         side = _side_stream(dev) if overlap else main
+        # dW = x^T dh is EXPOSED here (the pass that produced dh is the layer's big HBM-bound kernel): two fp16 pieces per operand
+        # when both operands come with row scales -- x's handed in (gat_conv(x_scales=)), dh's written by the fused pass -- from
+        # which their column scales follow without a pass over either matrix (col_scales(row_scales=))
+        dw_kw = {}
+        if (dh_scales is not None and ctx.x_scales is not None and ctx.needs_input_grad[1]
+                and dw_f16x2_shape(x.size(0), x.size(1), dh.size(1)) and x.dtype == torch.float32):
+            dw_kw = dict(a_cs=col_scales(row_scales=ctx.x_scales, cols=x.size(1)), dc_cs=col_scales(row_scales=dh_scales, cols=dh.size(1)))
         tmap = _inverse_transpose_map(graph)                                  # cached; built on the launch stream
         # dz is in by-source entry order: its by-source row sum is a coalesced, latency-bound pass (0.09 ms alone, 0.31 ms
         # with one wave per SIMD beside a dW workgroup), so it stays in front of dW
@@ -1514,7 +1563,7 @@ class _GatConvFn(torch.autograd.Function):
         if overlap:
             side.wait_stream(main)
             # resident before the side stream's passes ask for wave slots
-            dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+            dw = linear_bwd_weight(x, dh, want_bias=False, **dw_kw)[0] if ctx.needs_input_grad[1] else None
         with torch.cuda.stream(side):
             if src_beside:
                 g_src = seg_rowsum(graph.by_src, dz, 1)
@@ -1523,7 +1572,7 @@ class _GatConvFn(torch.autograd.Function):
             have_g.record(side)
             P = gat_att_grad(x, g_dst, g_src, 1, K).view(2, K)                # x^T g_dst, x^T g_src
         if not overlap:
-            dw = linear_bwd_weight(x, dh, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+            dw = linear_bwd_weight(x, dh, want_bias=False, **dw_kw)[0] if ctx.needs_input_grad[1] else None
         main.wait_event(have_g)
         dx = linear_bwd_data_rank2(dh, weight, g_dst, g_src, U[0], U[1], dc_scales=dh_scales)
         if overlap:

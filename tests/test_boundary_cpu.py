@@ -117,7 +117,7 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_segsum_ex": lambda: lib.npi_segsum_ex(N, N, N, 64, N, 4, 16, 8, 4, 8, -5, 8, 4, 4, 0, 0, N, 8, N, N),       # bad split
         "npi_linear_fwd_ex": lambda: lib.npi_linear_fwd_ex(N, 0, N, 0, N, N, N, 0, 8, 0, 8, 0, 0, 0, N, 0, N, N),
         "npi_linear_bwd_data_ex": lambda: lib.npi_linear_bwd_data_ex(N, 0, N, 0, N, N, 0, 8, 8, -3, 0, 0, N, 0, N, N),
-        "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 0, 1, N),
+        "npi_linear_bwd_weight_ex": lambda: lib.npi_linear_bwd_weight_ex(N, 0, N, 0, N, 0, N, 8, 0, 8, N, 0, 0, 0, 1, N, N, N),
         # round 4: the row-dot epilogue serves one column tile (N = 128 / 256) only; the preparation launch wants K, N % 16 == 0
         "npi_linear_fwd_scores": lambda: lib.npi_linear_fwd_scores(16, 256, 16, 192, 16, 16, 192, 16, 16, 1000, 256, 192, N, 0, N, N),
         "npi_linear_prepare": lambda: lib.npi_linear_prepare(16, 256, 178, 128, 3, 0, 16, 1 << 20, N),

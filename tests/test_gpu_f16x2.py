@@ -90,6 +90,37 @@ def test_fp16x2_tiny_rows_times_tiny_columns_do_not_underflow_on_the_way_out(dev
         assert float(((c.double() - ref).abs() / bound).max()) <= 1e-6
 
 
+def test_weight_gradient_on_fp16x2_with_column_scales(dev):
+    """dW = A^T dC on two fp16 pieces per operand (linear_bwd_weight(a_cs=, dc_cs=)): the contraction runs over the rows, so the
+    power-of-two scales that factor out are per COLUMN (npi_col_scales).  Against fp64 at the bar of the bf16 x 3 kernel -- max
+    |diff| / max |ref| <= 1e-5 -- with true column scales on columns 12 decades apart (then also per dW ROW), and with the uniform
+    scale derived from the operands' ROW scales (no pass over either matrix: what GATConv's backward does); db unchanged."""
+    g = torch.Generator(device=dev).manual_seed(21)
+    M, K, N = 70_001, 256, 256                                              # (a ragged tail of rows: the finishing kernel's share)
+    a = torch.randn(M, K, device=dev, generator=g)
+    dc = torch.randn(M, N, device=dev, generator=g)
+    ref = a.double().t() @ dc.double()
+    dw3, db3 = NF.linear_bwd_weight(a, dc)
+    dw2, db2 = NF.linear_bwd_weight(a, dc, a_cs=NF.col_scales(a), dc_cs=NF.col_scales(dc))
+    assert not torch.equal(dw2, dw3) and torch.equal(db2, db3)
+    assert rel_max(dw2, ref) <= GRAD_REL and rel_max(dw3, ref) <= GRAD_REL
+    # the uniform scale from the row scales
+    dwu, _ = NF.linear_bwd_weight(a, dc, a_cs=NF.col_scales(row_scales=NF.row_scales(a), cols=K),
+                                  dc_cs=NF.col_scales(row_scales=NF.row_scales(dc), cols=N))
+    assert rel_max(dwu, ref) <= GRAD_REL
+    sc = NF.col_scales(row_scales=NF.row_scales(a), cols=K)
+    assert bool((sc == sc[0]).all()) and float(sc[0]) == float(NF.row_scales(a).min())
+    # columns 12 decades apart: per-column scales keep every ROW of dW (a column of A) at its own relative accuracy
+    a2 = a * torch.pow(10.0, torch.linspace(-6, 6, K, device=dev)).view(1, K)
+    ref2 = a2.double().t() @ dc.double()
+    dwc, _ = NF.linear_bwd_weight(a2, dc, a_cs=NF.col_scales(a2), dc_cs=NF.col_scales(dc))
+    row_err = (dwc.double() - ref2).abs().max(dim=1).values / ref2.abs().max(dim=1).values
+    assert float(row_err.max()) <= GRAD_REL
+    cs = NF.col_scales(a2)
+    for k in (0, 100, 255):
+        assert float(cs[k]) == float(NF.row_scales(a2[:, k].contiguous().view(1, -1))[0])   # the column's scale = its own row scale
+
+
 def test_fp16x2_non_finite_operands_behave_as_under_the_bf16_split(dev):
     """NaN stays NaN; an Inf in A makes its output row NaN (Inf - Inf in the split), as the bf16 x 3 arithmetic does (include/npi_gnn.h)"""
     g = torch.Generator(device=dev).manual_seed(4)

@@ -61,8 +61,8 @@ def test_hot_kernels_keep_the_occupancy_the_design_assumes(built):
     # the row dots of GATConv's scores in the store epilogue -- 10 KB of LDS more)
     for fam in ("gemm_split_ws_kernel<4, 0, false>", "gemm_split_ws_kernel<4, 1, false>", "gemm_split_ws_kernel<4, 2, false>",
                 "gemm_split_ws_kernel<4, 0, true>", "gemm_split_ws_kernel<4, 1, true>", "gemm_split_ws_kernel<4, 2, true>",     # fp16 x 2
-                "gemm_dw_split_kernel<4, false>",
-                "gemm_dw_split_kernel<4, true>",
+                "gemm_dw_split_kernel<4, false, false>", "gemm_dw_split_kernel<4, false, true>",
+                "gemm_dw_split_kernel<4, true, false>",
                 "gemm_bf16_ws_kernel<4>"):
         ks = {n: m for n, m in gemm.items() if fam in n}
         assert len(ks) == 1, fam
@@ -82,9 +82,11 @@ def test_asm_gemms_hold_no_flat_access_no_sgpr_hazard_and_touch_no_in_flight_lds
             assert G.find_flat(instrs) == [], (sym, G.find_flat(instrs)[:3])
             wide = "global_load_dwordx2" if "gemm_dw_split_kernelILi4ELb1" in sym or "gemm_dw_split_kernelILi2ELb1" in sym else "global_load_dwordx4"
             assert any(i.startswith(wide) for i in instrs), sym                     # the asm loads are there at all (bf16 dW: 8 bytes)
-            mfma = "v_mfma_f32_32x32x16_f16" if ("gemm_split_ws_kernel" in sym and sym.endswith("Lb1EEEvNS_9SplitArgsE")) else "v_mfma_f32_32x32x16_bf16"
+            f16 = ("gemm_split_ws_kernel" in sym and sym.endswith("Lb1EEEvNS_9SplitArgsE")) or \
+                  ("gemm_dw_split_kernel" in sym and sym.endswith("Lb0ELb1EEEvNS_6DwArgsE"))        # <TN, BF16IN = false, F16 = true>
+            mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
             assert any(i.startswith("ds_read_b128") for i in instrs) and any(mfma in i for i in instrs), (sym, mfma)
-    assert checked == 18                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue and each of those on fp16 x 2, dW also for bf16 operands
+    assert checked == 20                                      # <4> and <2> of each family, the split kernel also with the rank-2 and the row-dot epilogue and each of those on fp16 x 2, dW also for bf16 operands and on fp16 x 2
     # no FLAT memory instruction anywhere: a flat access counts on lgkmcnt as well as vmcnt (every LDS / scalar-load wait then
     # drains the gathers too) -- round 4 found all 128 aggregation kernels gathering through flat_load because the second
     # part of the table was addressed through a pointer biased with integer arithmetic

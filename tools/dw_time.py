@@ -11,16 +11,17 @@ g = torch.Generator(device=dev).manual_seed(1)
 a = torch.randn(M, K, device=dev, generator=g)
 dc = torch.randn(M, N, device=dev, generator=g)
 res = []
-for shared in (False, True):
+acs, dcs = NF.col_scales(a), NF.col_scales(dc)
+for name, kw in (("alone", {}), ("shared", dict(shared=True)), ("alone fp16x2", dict(a_cs=acs, dc_cs=dcs)), ("shared fp16x2", dict(shared=True, a_cs=acs, dc_cs=dcs))):
     for _ in range(5):
-        dw, db = NF.linear_bwd_weight(a, dc, shared=shared)
+        dw, db = NF.linear_bwd_weight(a, dc, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        dw, db = NF.linear_bwd_weight(a, dc, shared=shared)
+        dw, db = NF.linear_bwd_weight(a, dc, **kw)
     e1.record()
     torch.cuda.synchronize()
-    res.append(f"{'shared' if shared else 'alone'} {e0.elapsed_time(e1) / 20:.4f} ms")
+    res.append(f"{name} {e0.elapsed_time(e1) / 20:.4f} ms")
 ref = a[:, :8].double().t() @ dc.double()
 err = float((dw[:8].double() - ref).abs().max() / ref.abs().max())
 print(os.path.basename(os.environ.get("NPI_GNN_LIB", "default")), M, K, N, "|", "  ".join(res), f"| dW max err / max {err:.2e}; db err {float((db.double() - dc.double().sum(0)).abs().max()):.2e}")
