@@ -412,13 +412,16 @@ int npi_gat_aggregate_ex(const int32_t* rowptr, const int32_t* col, const int32_
 int npi_gat_pack_targets(const float* a_dst, const float* m, const float* s, const float* D, int64_t N, float* tpack,
                          void* stream);
 /* row_scales_out != NULL ([N]; heads * out_channels == 256): the launch also writes the power-of-two scale of every finished row of `out`:
- * the dc_scales of the projection behind it (npi_linear_bwd_data_rank2 / npi_linear_bwd_data_ex) without a pass over `out` */
+ * the dc_scales of the projection behind it (npi_linear_bwd_data_rank2 / npi_linear_bwd_data_ex) without a pass over `out`.
+ * g_src_out != NULL ([N]; one head): the launch also leaves the row sums of dz -- what npi_seg_rowsum_ex(vals = dz) over this CSR would
+ * return -- taken by the lanes that compute dz; workspace: npi_seg_scan_workspace_elems(nnz_max, 1) floats (rows cut by an item
+ * boundary are added up by a small launch behind the pass).  NULL: workspace is not used. */
 int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t* col, const int32_t* rowidx,
                                      const int32_t* item_row, int64_t item_edges, int64_t N, int64_t nnz_max,
                                      const float* dout, int64_t ldd, const float* dout2, int64_t split, const float* hfeat,
                                      int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack,
                                      const float* a_src, float slope, float* dz, float* carry, float* row_scales_out,
-                                     void* stream);
+                                     float* g_src_out, float* workspace, int64_t workspace_elems, void* stream);
 int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,
                       int64_t N, int64_t H, int64_t C, void* stream);
 int npi_gat_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,

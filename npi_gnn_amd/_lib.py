@@ -84,7 +84,7 @@ PROTOTYPES = {
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
     "npi_gat_pack_targets": (c_int, [_P, _P, _P, _P, _I, _P, _P]),
     "npi_gat_backward_fused_heads": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, c_float, _P,
-                                                 _P, _P, _P]),
+                                                 _P, _P, _P, _P, _I, _P]),
     "npi_gat_rank1_add": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "npi_gat_rowdot": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "npi_gat_edge_grad_ex": (c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, c_float,

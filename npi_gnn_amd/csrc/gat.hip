@@ -583,7 +583,7 @@ extern "C" int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t
                                                 const float* dout, int64_t ldd, const float* dout2, int64_t split, const float* hfeat,
                                                 int64_t ldh, float* out, int64_t ldo, int64_t H, int64_t C, const float* tpack,
                                                 const float* a_src, float slope, float* dz, float* carry, float* row_scales_out,
-                                                void* stream_) {
+                                                float* g_src_out, float* workspace, int64_t workspace_elems, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t F = H * C;
     NPI_REQUIRE(row_scales_out == nullptr || (F == 256 && ldd % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)dout % 16) == 0 &&
@@ -611,7 +611,22 @@ extern "C" int npi_gat_backward_fused_heads(const int32_t* rowptr, const int32_t
     P.hrow = hfeat; P.ldh = ldh; P.rowidx = rowidx; P.dz_out = dz;            // dz: [nnz_max, H]
     P.scale_out = row_scales_out;
     const int mode = H == 1 ? W_GAT_SRC_FUSED : H == 2 ? W_GAT_SRC_FUSED_H2 : H == 4 ? W_GAT_SRC_FUSED_H4 : W_GAT_SRC_FUSED_H8;
-    return segsum_run(P, mode, 0, nnz_max, NPI_F32, stream);
+    // g_src_out [N] (one head): the row sums of dz from the same launch -- the lanes that compute dz scan it by row; rows cut by an
+    // item boundary are added up by the chain kernel of segscan.hip behind it (workspace: npi_seg_scan_workspace_elems(nnz_max, 1))
+    const int64_t n_items = num_items_of(nnz_max, (int)item_edges);
+    if (g_src_out != nullptr) {
+        NPI_REQUIRE(H == 1, "npi_gat_backward_fused_heads: g_src_out serves one head");
+        if (workspace == nullptr || workspace_elems < 3 * n_items) {
+            set_error("npi_gat_backward_fused_heads: workspace too small");
+            return NPI_ERR_WORKSPACE;
+        }
+        (void)hipMemsetAsync(g_src_out, 0, sizeof(float) * N, stream);                 // rows without an entry
+        P.rowsum_out = g_src_out; P.rs_head = workspace; P.rs_tail = workspace + n_items;
+        P.rs_tail_row = reinterpret_cast<int32_t*>(workspace + 2 * n_items);
+    }
+    const int rc = segsum_run(P, mode, 0, nnz_max, NPI_F32, stream);
+    if (rc != NPI_OK || g_src_out == nullptr) return rc;
+    return seg_chain_sum(rowptr, P.rs_head, P.rs_tail, P.rs_tail_row, g_src_out, N, n_items, (int)item_edges, stream);
 }
 
 extern "C" int npi_gat_rank1_add(float* dh, int64_t ld, const float* g_dst, const float* g_src, const float* att,

@@ -887,26 +887,40 @@ __device__ __forceinline__ void store_tile_t(float* __restrict__ C, int64_t ldc,
 // the quad.  The same operations on the same values in the same order as store_tile_t: bit-identical.
 __device__ __forceinline__ float qp_xor2(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xf, 0xf, true)); }   // quad_perm [2,3,0,1]
 __device__ __forceinline__ float qp_xor1(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xf, 0xf, true)); }   // quad_perm [1,0,3,2]
-template <int TM, int TN, bool CS>
+// EPI 1 (R2, fp16 x 2 only): the rank-2 term's row factors take the same quad broadcast as the row scales, its column vectors are read
+// like the bias (the launch has none: its four registers go to them); 0.61 -> 0.57 ms at 1M x 256 x 256.  The row-dot epilogue (EPI 2)
+// and bf16 x 3 with either epilogue keep store_tile_t: the exchange's 16 temporaries on top of their own state do not fit in 256
+// registers (92 - 632 bytes of scratch in every arrangement tried: dots before / after the exchange, reduce-scattered per block).
+__device__ __forceinline__ float quad_lane(float x, int g) {               // g is a constant after unrolling
+    const int v = __float_as_int(x);
+    return __int_as_float(g == 0 ? __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true) : g == 1 ? __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true)
+                        : g == 2 ? __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, true));
+}
+template <int TM, int TN, bool CS, int EPI = 0>
 __device__ __forceinline__ void store_tile_q(float* __restrict__ C, int64_t ldc, int mw, int nw, int li, int lh,
                                              const f32x16 (&acc)[TM][TN], const float* __restrict__ bias_lds, const float (&rs)[TM],
-                                             float floor_, const float* __restrict__ cs_lds) {
+                                             float floor_, const float* __restrict__ cs_lds,
+                                             const float* __restrict__ u0_lds = nullptr, const float* __restrict__ u1_lds = nullptr,
+                                             float (*g0)[TM] = nullptr, float (*g1)[TM] = nullptr) {
+    static_assert(EPI == 0 || EPI == 1, "the row-dot epilogue stays on store_tile_t");
+    constexpr bool R2 = EPI == 1;
     const bool b1 = (li & 2) != 0, b0 = (li & 1) != 0;
     const int r = li & 3;
     const int co = 8 * r + 4 * lh;                    // this lane's four columns inside every 32-column block, after the exchange
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        // the row scales of rows 4 a + g (lane g of the quad holds its own): quad_perm [g, g, g, g]
-        const float rsq[4] = {__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0x00, 0xf, 0xf, true)),
-                              __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0x55, 0xf, 0xf, true)),
-                              __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0xAA, 0xf, 0xf, true)),
-                              __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rs[i]), 0xFF, 0xf, 0xf, true))};
         float* __restrict__ rowbase = C + (int64_t)(mw + i * 32 + (li & ~3)) * ldc + nw + co;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float4 b = *reinterpret_cast<const float4*>(bias_lds + j * 32 + co);
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EPI == 0) b = *reinterpret_cast<const float4*>(bias_lds + j * 32 + co);     // (R2: launched without a bias)
             float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
             if constexpr (CS) cs = *reinterpret_cast<const float4*>(cs_lds + j * 32 + co);
+            float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+            if constexpr (R2) {
+                u0 = *reinterpret_cast<const float4*>(u0_lds + j * 32 + co);
+                u1 = *reinterpret_cast<const float4*>(u1_lds + j * 32 + co);
+            }
             float e[4][4];                            // [column group g -> row g' after the exchange][dword]
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -937,9 +951,15 @@ __device__ __forceinline__ void store_tile_q(float* __restrict__ C, int64_t ldc,
 #pragma unroll
             for (int g = 0; g < 4; ++g) {             // row 4 a + g: its columns 32 j + 8 r + 4 lh .. + 3
                 float4 q = make_float4(e[g][0], e[g][1], e[g][2], e[g][3]), v;
+                const float rsg = quad_lane(rs[i], g);       // the row scale of row 4 a + g (lane g of the quad holds its own)
                 if constexpr (CS) { q.x *= cs.x; q.y *= cs.y; q.z *= cs.z; q.w *= cs.w; }
-                v.x = fmaf(q.x, rsq[g], b.x); v.y = fmaf(q.y, rsq[g], b.y);
-                v.z = fmaf(q.z, rsq[g], b.z); v.w = fmaf(q.w, rsq[g], b.w);
+                v.x = fmaf(q.x, rsg, b.x); v.y = fmaf(q.y, rsg, b.y);
+                v.z = fmaf(q.z, rsg, b.z); v.w = fmaf(q.w, rsg, b.w);
+                if constexpr (R2) {               // the row factors of row 4 a + g: broadcast where they are used (8 registers less)
+                    const float a0 = quad_lane((*g0)[i], g), a1 = quad_lane((*g1)[i], g);
+                    v.x = fmaf(a1, u1.x, fmaf(a0, u0.x, v.x)); v.y = fmaf(a1, u1.y, fmaf(a0, u0.y, v.y));
+                    v.z = fmaf(a1, u1.z, fmaf(a0, u0.z, v.z)); v.w = fmaf(a1, u1.w, fmaf(a0, u0.w, v.w));
+                }
                 v.x = v.x < floor_ ? floor_ : v.x; v.y = v.y < floor_ ? floor_ : v.y;      // keeps NaN, like torch.relu
                 v.z = v.z < floor_ ? floor_ : v.z; v.w = v.w < floor_ ? floor_ : v.w;
                 *reinterpret_cast<float4*>(rowbase + (int64_t)g * ldc + j * 32) = v;
@@ -1347,13 +1367,14 @@ gemm_split_ws_kernel(SplitArgs a) {
         ws_consume_step<TM, TN, APL, BPL, BUF, NST, false, NPL, F16>(lds_base, full, empty, g, wn_.valid(), offa, offb, af, bf, acc);
         ++g;
         if (w.kt == nk - 1) {
-            if constexpr (EPI == 0)       // full 128-byte lines per store instruction (store_tile_q)
-                store_tile_q<TM, TN, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc, bias_s[wave][tsel], rs, floor_,
-                                          cs_s[F16 ? wave : 0][tsel]);
+            // full 128-byte lines per store instruction (store_tile_q) where its registers fit: plain, and fp16 x 2 with the rank-2 term
+            if constexpr ((EPI != 0 && !F16) || EPI == 2)
+                store_tile_t<TM, TN, EPI, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
+                                               bias_s[wave][tsel], rs, floor_, r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1,
+                                               cs_s[F16 ? wave : 0][tsel]);
             else
-            store_tile_t<TM, TN, EPI, F16>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc,
-                                           bias_s[wave][tsel], rs, floor_, r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1,
-                                           cs_s[F16 ? wave : 0][tsel]);
+            store_tile_q<TM, TN, F16, EPI>(a.C, a.ldc, w.row0() + wm * 64, w.nt * BN + wn * (32 * TN), li, lh, acc, bias_s[wave][tsel], rs, floor_,
+                                           cs_s[F16 ? wave : 0][tsel], r2_s[UV ? wave : 0][tsel][0], r2_s[UV ? wave : 0][tsel][1], &g0, &g1);
             if constexpr (SC) {
                 const int par = tq & 1;
 #pragma unroll
@@ -2025,7 +2046,7 @@ static int launch_gemm(bool v4, GemmArgs a, int splits, hipStream_t stream, int 
     const bool split = fast_ok && AMODE == 0 && splits == 1 && mode != 0 && a.ep.colsum == nullptr &&
                        ((uintptr_t)a.C % 16 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.ep.bias % 16 == 0);
     int split_tm = 0;                                        // m-tiles the split kernel covered (all of them, when it ran)
-    if (a.ep.r2_row0 != nullptr && !(fm > 0 && fn > 0 && split && a.N % 128 == 0 && kv == a.K)) {
+    if (a.ep.r2_row0 != nullptr && !(fm > 0 && fn > 0 && split && a.N % 128 == 0 && kv == a.K && a.ep.bias == nullptr)) {
         set_error("gemm: the rank-2 epilogue needs the split kernel over the whole output (npi_linear_bwd_data_rank2_supported)");
         return NPI_ERR_ARG;
     }

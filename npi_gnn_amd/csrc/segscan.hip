@@ -11,9 +11,9 @@
 // scan keyed by the row id (6 shuffle steps; keys are sorted) leaves every run's total in its last lane, and
 //   * a row that begins and ends inside the item is written at once,
 //   * the part of a row that began in an earlier item goes to head[item], the part of a row that continues into the next
-//     item to tail[item]; seg_chain_kernel -- one wavefront per item that holds a tail -- adds head[i + 1 .. i_end] with
-//     lanes striding over the chain (the 400k-entry hub row: 1,600 partials, 25 per lane) and folds them with a fixed
-//     xor tree, so the result does not depend on the launch order (no atomics anywhere).
+//     item to tail[item]; seg_chain_kernel adds head[i + 1 .. i_end] to it -- a lane per item for the short chains, the whole
+//     wavefront striding over a long one (the 400k-entry hub row: 1,600 partials, 25 per lane; a fixed xor tree folds them) --
+//     so the result does not depend on the launch order (no atomics anywhere).
 // The softmax statistics use the same skeleton with (max, sum) pairs merged like an online softmax.
 #include "segsum.h"
 
@@ -208,28 +208,46 @@ seg_items_kernel(ScanArgs A) {
     if (lane == 0) A.tail_row[item] = tail_r;
 }
 
-// one wavefront per item with a tail: row total = tail[i] (+) head[i + 1] (+) ... (+) head[i_end]
+// row total of every row cut by an item boundary = tail[i] (+) head[i + 1] (+) ... (+) head[i_end].  Nearly every item ends inside a
+// row (rows are 10 - 100 entries, items 64 or 256), and nearly every such chain is ONE or two heads long: a LANE per item walks a
+// short chain by itself (a wavefront per item -- round 2 to 5 -- spent 0.1 ms on launching 98k workgroups at C5); the long chains of
+// the hub rows (the 400k-entry row: 1,600 partials) are then taken one after the other by the whole wavefront, lanes striding
+// over the chain and a fixed xor tree folding them.  No atomics; a row's result depends on its chain length only.
+constexpr int CHAIN_SHORT = 4;
 template <class Op>
 __global__ void __launch_bounds__(256)
 seg_chain_kernel(ScanArgs A) {
     using V = typename Op::V;
     const int lane = lane_id();
-    const int item = uniform_i(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (item >= A.n_items) return;
-    const int r = uniform_i(A.tail_row[item]);
-    if (r < 0) return;
-    const int i_end = (A.rowptr[r + 1] - 1) / A.item;
-    const int n = i_end - item;
+    const int item = (blockIdx.x * 4 + (threadIdx.x >> 6)) * WAVE + lane;
     const int H = A.H;
-    for (int hd = 0; hd < H; ++hd) {
-        V acc = Op::identity();
-        for (int t = lane; t < n; t += WAVE) acc = Op::merge(acc, load_v<Op>(A.head, (int64_t)(item + 1 + t) * H + hd));
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {                                  // fixed tree: lower lane = earlier items
-            const V o = Op::shfl_xor(acc, d);
-            acc = (lane & d) ? Op::merge(o, acc) : Op::merge(acc, o);
+    int r = -1, n = 0;
+    if (item < A.n_items) {
+        r = A.tail_row[item];
+        if (r >= 0) n = (A.rowptr[r + 1] - 1) / A.item - item;
+    }
+    if (r >= 0 && n <= CHAIN_SHORT) {
+        for (int hd = 0; hd < H; ++hd) {
+            V acc = load_v<Op>(A.tail, (int64_t)item * H + hd);
+            for (int t = 1; t <= n; ++t) acc = Op::merge(acc, load_v<Op>(A.head, (int64_t)(item + t) * H + hd));
+            write_row<Op>(A, (int64_t)r * H + hd, acc);
         }
-        if (lane == 0) write_row<Op>(A, (int64_t)r * H + hd, Op::merge(load_v<Op>(A.tail, (int64_t)item * H + hd), acc));
+    }
+    uint64_t todo = __ballot(r >= 0 && n > CHAIN_SHORT);
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const int it = bcast_i(item, l), nn = bcast_i(n, l), rr = bcast_i(r, l);
+        for (int hd = 0; hd < H; ++hd) {
+            V acc = Op::identity();
+            for (int t = lane; t < nn; t += WAVE) acc = Op::merge(acc, load_v<Op>(A.head, (int64_t)(it + 1 + t) * H + hd));
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {                              // fixed tree: lower lane = earlier items
+                const V o = Op::shfl_xor(acc, d);
+                acc = (lane & d) ? Op::merge(o, acc) : Op::merge(acc, o);
+            }
+            if (lane == 0) write_row<Op>(A, (int64_t)rr * H + hd, Op::merge(load_v<Op>(A.tail, (int64_t)it * H + hd), acc));
+        }
     }
 }
 
@@ -262,11 +280,21 @@ int run_scan(ScanArgs A, int64_t nnz_max, float* workspace, int64_t workspace_el
         default: NPI_SCAN(1); break;
     }
 #undef NPI_SCAN
-    seg_chain_kernel<Op><<<grid, 256, 0, stream>>>(A);
+    seg_chain_kernel<Op><<<(unsigned)ceil_div(n_items, 4 * WAVE), 256, 0, stream>>>(A);
     return check_launch(what);
 }
 
 }  // namespace
+
+int seg_chain_sum(const int32_t* rowptr, float* head, float* tail, int32_t* tail_row, float* out, int64_t N, int64_t n_items, int item,
+                  hipStream_t stream) {
+    if (n_items == 0) return NPI_OK;
+    ScanArgs A{};
+    A.rowptr = rowptr; A.head = head; A.tail = tail; A.tail_row = tail_row; A.out0 = out; A.N = (int)N; A.H = 1;
+    A.n_items = (int)n_items; A.item = item;
+    seg_chain_kernel<SumOp><<<(unsigned)ceil_div(n_items, 4 * WAVE), 256, 0, stream>>>(A);
+    return check_launch("seg_chain_sum");
+}
 
 }  // namespace npi
 

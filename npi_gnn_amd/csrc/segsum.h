@@ -59,6 +59,10 @@ struct SegParams {
     int64_t ldh;
     const int32_t* rowidx;   // row of every entry (the by-source CSR's rowidx)
     float* dz_out;           // [nnz_max, H] by-source entry order
+    // W_GAT_SRC_FUSED (one head), optional: the row sums of dz -- g_src -- from the lanes that hold dz anyway.  Rows inside an item are
+    // written to rowsum_out [N]; the parts of a row cut by an item boundary go to rs_head / rs_tail / rs_tail_row [n_items] exactly as
+    // segscan.hip's seg_items_kernel leaves them, and seg_chain_sum (segscan.hip) adds them up behind the launch
+    float* rowsum_out; float* rs_head; float* rs_tail; int32_t* rs_tail_row;
     // (a_dst, m, 1 / (s + 1e-16), D) of every TARGET node AND HEAD as one float4 ([n_cols, H, 4]): one 16-byte gather per entry
     // and head, alpha recomputed by the lane that owns the entry
     const float4* tpack;
@@ -70,5 +74,8 @@ struct SegParams {
 
 // x / out / bias are stored as `dtype` (NPI_F32 or NPI_BF16; the struct's float* are reinterpreted)
 int segsum_run(SegParams P, int wmode, int mean, int64_t nnz_max, int dtype, hipStream_t stream);
+// out[r] = tail[i] + head[i + 1] + ... for every row r = tail_row[i] cut by an item boundary (segscan.hip; one head)
+int seg_chain_sum(const int32_t* rowptr, float* head, float* tail, int32_t* tail_row, float* out, int64_t N, int64_t n_items, int item,
+                  hipStream_t stream);
 
 }  // namespace npi

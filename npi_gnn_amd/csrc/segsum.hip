@@ -661,7 +661,10 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
     const int nnz = P.rowptr[N];
     const int k0 = item * P.item;
     // a CSR with capacity but no entry at all (every edge dropped): item 0 still runs and closes all N empty rows
-    if (k0 >= nnz && !(item == 0 && nnz == 0)) return;
+    if (k0 >= nnz && !(item == 0 && nnz == 0)) {
+        if (WMODE == W_GAT_SRC_FUSED && P.rowsum_out != nullptr && lane == 0) P.rs_tail_row[item] = -1;
+        return;
+    }
     const int k1 = min(k0 + P.item, nnz);
     const T* __restrict__ xT = reinterpret_cast<const T*>(P.x);
     // second part of the table, biased so that it is indexed by the column id itself (sharded layers: the gathered hub
@@ -778,9 +781,22 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
         return 1.f;
     };
 
+    // W_GAT_SRC_FUSED with rowsum_out: the row sums of dz.  rs_prev = the row that runs INTO this item (its sum here is a chain
+    // link, not a result); (rs_open_key, rs_open_val) = the row of the previous block's last entry and its sum so far
+    const bool rs_on = WMODE == W_GAT_SRC_FUSED && P.rowsum_out != nullptr;
+    const int rs_prev = head ? r : -1;
+    int rs_open_key = -1;
+    float rs_open_val = 0.f;
+    auto rs_put = [&](int key, float val) {                              // a finished row (or the last link of a chain)
+        if (key != rs_prev) P.rowsum_out[key] = val;
+        else P.rs_head[item] = val;
+    };
+    (void)rs_prev; (void)rs_open_key; (void)rs_open_val;
     for (int kb = k0; kb < k1; kb += WAVE) {
         const int nb = min(WAVE, k1 - kb);
         const int cv = (lane < nb) ? P.col[kb + lane] : 0;
+        int rlk = 0x7fffffff;            // rs_on: the row of entry kb + lane
+        (void)rlk;
         float wv = 1.f;
         if (WMODE == W_ARRAY || WMODE == W_GAT_DST_PRE) wv = (lane < nb) ? P.w[kb + lane] : 0.f;
         float dz_d = 0.f, dz_g = 0.f;    // W_GAT_SRC_FUSED, packed: D of the entry's target and leaky_relu' of its score
@@ -805,7 +821,8 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
             // alpha of entry kb + l is computed BY LANE l (one exp per entry, not per lane) from the packed target scalars
             if (lane < nb) {
                 const float4 t = P.tpack[cv];
-                const float z = t.x + P.a_src[P.rowidx[kb + lane]];
+                rlk = P.rowidx[kb + lane];
+                const float z = t.x + P.a_src[rlk];
                 wv = expf(lrelu(z, P.slope) - t.y) * t.z;
                 dz_d = t.w;
                 dz_g = z > 0.f ? 1.f : P.slope;
@@ -1022,9 +1039,46 @@ __device__ __forceinline__ void segsum_item(const SegParams& P, const Lanes<VEC,
         if (WMODE == W_GAT_SRC_FUSED) {
             // all 64 lanes turn the block's dots into dz together: dz = alpha (dot - D_i) leaky_relu'(a_dst[i] + a_src[j])
             __builtin_amdgcn_wave_barrier();
-            if (lane < nb) P.dz_out[kb + lane] = wv * (pb[lane] - dz_d) * dz_g;
+            float dzv = 0.f;
+            if (lane < nb) {
+                dzv = wv * (pb[lane] - dz_d) * dz_g;
+                P.dz_out[kb + lane] = dzv;
+            }
             __builtin_amdgcn_wave_barrier();
+            if (rs_on) {
+                // segmented inclusive scan keyed by the row id (sorted: "same key at distance d" = the whole span shares it), as
+                // segscan.hip; whether the block's LAST run is complete is only known with the next block's first key (or, behind
+                // the item's last block, from rowptr), so it always stays open
+                if (rs_open_key >= 0 && bcast_i(rlk, 0) != rs_open_key) {
+                    if (lane == 0) rs_put(rs_open_key, rs_open_val);
+                    rs_open_key = -1;
+                }
+                float xs = dzv;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const int ko = __shfl_up(rlk, d, WAVE);
+                    const float o = __shfl_up(xs, d, WAVE);
+                    if (lane >= d && ko == rlk) xs += o;
+                }
+                if (rlk == rs_open_key) xs += rs_open_val;                  // the first run continues the open row
+                const int key_next = __shfl_down(rlk, 1, WAVE);
+                if (lane < nb - 1 && key_next != rlk) rs_put(rlk, xs);
+                rs_open_key = bcast_i(rlk, nb - 1);
+                rs_open_val = bcast_f(xs, nb - 1);
+            }
         }
+    }
+    if (rs_on) {
+        int tail_r = -1;
+        if (rs_open_key >= 0) {
+            const bool complete = uniform_i(P.rowptr[rs_open_key + 1]) == k1;
+            if (lane == 0) {
+                if (complete || rs_open_key == rs_prev) rs_put(rs_open_key, rs_open_val);   // (the whole item inside one row: a link too)
+                else P.rs_tail[item] = rs_open_val;
+            }
+            if (!complete && rs_open_key != rs_prev) tail_r = rs_open_key;
+        }
+        if (lane == 0) P.rs_tail_row[item] = tail_r;
     }
     // entries exhausted at k1
     if (row_end == k1) {

@@ -1326,11 +1326,12 @@ def gat_pack_targets(a_dst, m, s, D, out=None):
 
 
 def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H: int = 1,
-                              scales_out: Optional[torch.Tensor] = None):
+                              scales_out: Optional[torch.Tensor] = None, rowsum_out: Optional[torch.Tensor] = None):
     """By-SOURCE side: (out [n_rows, H C] = sum_q alpha_q dout[col q], dz [nnz_max, H] per entry and head) in one gather pass;
     ``dout2``: second part of the gathered table; ``tpack`` [n_cols H, 4] indexed by (column id, head); ``hrow`` /
     ``a_src_rows``: features and source scores of the ROW nodes.  H in {1, 2, 4, 8} (npi_gat_backward_fused_heads).
-    ``scales_out`` ``[n_rows]`` (H C == 256): also the power-of-two scale of every row of ``out``, for the fp16 x 2 GEMM behind it."""
+    ``scales_out`` ``[n_rows]`` (H C == 256): also the power-of-two scale of every row of ``out``, for the fp16 x 2 GEMM behind it.
+    ``rowsum_out`` ``[n_rows]`` (one head): also the row sums of dz -- ``seg_rowsum(side, dz, 1)`` -- from the lanes that compute dz."""
     dev = dout.device
     dout = _f32c(dout, "dout")
     if dout2 is not None:
@@ -1343,16 +1344,24 @@ def gat_backward_fused_packed(side: CSRSide, dout, dout2, hrow, C, tpack, a_src_
     else:
         _check_out(out, side.n_rows, H * C, dout, "gat_backward_fused_packed")
     dz = torch.empty(max(side.nnz_max, 1) * H, dtype=torch.float32, device=dev)
+    if rowsum_out is not None and (H != 1 or rowsum_out.numel() != side.n_rows or rowsum_out.dtype != torch.float32
+                                   or not rowsum_out.is_contiguous()):
+        raise ValueError("gat_backward_fused_packed: rowsum_out must be a contiguous float32 [n_rows] tensor (one head)")
     if side.nnz_max == 0:
         if scales_out is not None:
             scales_out.fill_(1.0)
+        if rowsum_out is not None:
+            rowsum_out.zero_()
         return out.zero_(), dz
+    n_ws = int(load().npi_seg_scan_workspace_elems(side.nnz_max, 1)) if rowsum_out is not None else 0
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
     with _tag_events("gat_bwd_fused", dev):
         check(load().npi_gat_backward_fused_heads(ptr(side.rowptr), ptr(side.col), ptr(side.rowidx), ptr(side.item_row), side.item,
                                                       side.n_rows, side.nnz_max, ptr(dout), dout.stride(0), ptr(dout2),
                                                       dout.size(0) if dout2 is not None else 0, ptr(hrow), hrow.stride(0), ptr(out),
                                                       out.stride(0), H, C, ptr(tpack), ptr(a_src_rows.contiguous()), float(slope), ptr(dz),
-                                                      ptr(side.carry(H * C)), ptr(scales_out), stream_ptr(dev)),
+                                                      ptr(side.carry(H * C)), ptr(scales_out), ptr(rowsum_out), ptr(ws), n_ws,
+                                                      stream_ptr(dev)),
               "npi_gat_backward_fused_heads")
     return out, dz
 
@@ -1487,11 +1496,15 @@ class _GatConvFn(torch.autograd.Function):
             # dX's GEMM on two fp16 pieces per operand: the row scales of d hfeat from the pass that writes it (256 channels)
             dh_scales = (torch.empty(N, dtype=torch.float32, device=dev)
                          if rank2 and H * C == 256 and _f16x2(sch, N, H * C, weight.size(0), x.dtype) else None)
-            dh, dz = gat_backward_fused_packed(sr, grad_out, None, hfeat, C, tpack, a_src, slope, out=dh, H=H, scales_out=dh_scales)
+            # one head: the by-source row sums of dz (g_src) come out of the same launch
+            g_src = torch.empty((N, 1), dtype=torch.float32, device=dev) if (H == 1 and sch.gat_src_rowsum_fused) else None
+            dh, dz = gat_backward_fused_packed(sr, grad_out, None, hfeat, C, tpack, a_src, slope, out=dh, H=H, scales_out=dh_scales,
+                                               rowsum_out=g_src)
             dz = dz.view(-1, H)
             if rank2:
-                return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, dz, db, C, dh_scales)
-            g_src = seg_rowsum(sr, dz, H)                                         # dz is in by-source entry order here
+                return _GatConvFn._backward_rank2(ctx, x, weight, att2, dh, dz, db, C, dh_scales, g_src)
+            if g_src is None:
+                g_src = seg_rowsum(sr, dz, H)                                     # dz is in by-source entry order here
             g_dst = seg_rowsum(d, dz, H, map_=_inverse_transpose_map(graph))
             # d hfeat_j = sum_i alpha_ij dOut_i + g_dst[j] att[:C] + g_src[j] att[C:]
             gat_rank1_add(dh, g_dst, g_src, att2, H, C)
@@ -1527,7 +1540,7 @@ class _GatConvFn(torch.autograd.Function):
         return dx, dw, datt, db, None, None, None, None, None, None, None
 
     @staticmethod
-    def _backward_rank2(ctx, x, weight, att2, dh, dz, db, C, dh_scales=None):
+    def _backward_rank2(ctx, x, weight, att2, dh, dz, db, C, dh_scales=None, g_src=None):
         """The tail of the one-head backward without ever forming d hfeat' = dh + g_dst (x) a1 + g_src (x) a2 (a1 = att[:C],
         a2 = att[C:]; g_dst / g_src = row sums of dz by target / by source).  With P = [x^T g_dst; x^T g_src] ([2, K], ONE
         pass over x):
@@ -1557,8 +1570,9 @@ class _GatConvFn(torch.autograd.Function):
         tmap = _inverse_transpose_map(graph)                                  # cached; built on the launch stream
         # dz is in by-source entry order: its by-source row sum is a coalesced, latency-bound pass (0.09 ms alone, 0.31 ms
         # with one wave per SIMD beside a dW workgroup), so it stays in front of dW
-        src_beside = overlap and ctx.sch.gat_src_rowsum_beside_dw
-        if not src_beside:
+        # (g_src handed in: the fused pass has already summed it -- Schedule.gat_src_rowsum_fused)
+        src_beside = overlap and ctx.sch.gat_src_rowsum_beside_dw and g_src is None
+        if not src_beside and g_src is None:
             g_src = seg_rowsum(graph.by_src, dz, 1)
         if overlap:
             side.wait_stream(main)

@@ -47,6 +47,10 @@ class Schedule:
     #: one-head GATConv backward (rank-2 path, two streams): the by-source row sum of dz on the side stream, in front of the
     #: by-target one and beside the dW GEMM, instead of on the launch stream in front of dW
     gat_src_rowsum_beside_dw: bool = False
+    #: one-head GATConv backward: the by-source row sums of dz (g_src) taken INSIDE the fused by-source pass by the lanes that
+    #: compute dz (a segmented scan per 64 entries; rows cut by an item boundary through segscan.hip's chain kernel) instead of a
+    #: pass of their own over dz (round 6: 0.09 ms of the C4 layer, 0.35 ms per layer at the C5 size)
+    gat_src_rowsum_fused: bool = True
     # sharded layers (dist.py) --------------------------------------------------------------------------------------------------
     #: cuts without hub-hub edges: the reduce-scatter delivers the COMPLETE hub rows straight into the output (no merge pass)
     direct_hub_rows: bool = True

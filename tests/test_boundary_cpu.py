@@ -99,7 +99,7 @@ def test_every_family_rejects_bad_sizes_before_touching_the_gpu():
         "npi_segsum_ex (item)": lambda: lib.npi_segsum_ex(8, 8, 8, 128, N, 4, 16, 8, 4, N, 0, 8, 4, 4, 0, 0, N, 8, N, N),
         "npi_gat_aggregate_scores": lambda: lib.npi_gat_aggregate_scores(8, 8, 8, 65, 4, 16, 8, 4, N, 0, 8, 4, 4, 8, 8, 8, N, 0, 8, N),
         "npi_gat_backward_fused_heads": lambda: lib.npi_gat_backward_fused_heads(8, 8, 8, 8, 0, 4, 16, 16, 4, N, 0, 16, 4, 16, 4, 1, 4, 16,
-                                                                                 16, 0.2, 16, 16, N, N),
+                                                                                 16, 0.2, 16, 16, N, N, N, 0, N),
         "npi_colsum": lambda: lib.npi_colsum(N, 0, -1, 8, N, N, 0, N),
         "npi_gat_scores": lambda: lib.npi_gat_scores(N, 0, N, 8, 0, 4, N, N, N),
         "npi_topk_score": lambda: lib.npi_topk_score(N, 0, N, 8, 0, N, N),

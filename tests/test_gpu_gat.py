@@ -184,6 +184,55 @@ def test_item_parallel_row_reductions_match_torch(dev, n_rows, E, H):
     assert torch.equal(m0, m) and torch.equal(s0, s)
 
 
+@pytest.mark.parametrize("n_rows,E,item,C", [(50, 300, 64, 64), (5000, 90_000, 64, 256), (9000, 1_200_000, 256, 256),
+                                              (700, 1_100_000, 64, 128), (3000, 400_000, 256, 32), (10, 0, 64, 64)])
+def test_fused_backward_pass_also_leaves_the_row_sums_of_dz(dev, n_rows, E, item, C):
+    """npi_gat_backward_fused_heads(g_src_out=): the by-source row sums of dz from the lanes that compute dz (a segmented scan per 64
+    entries inside the pass, rows cut by an item boundary through segscan.hip's chain kernel) against npi_seg_rowsum_ex over the
+    dz the same launch wrote and against fp64 sums -- hub rows cut over thousands of items, rows ending exactly on a block or item
+    boundary, empty rows, both item sizes; dz, d hfeat and the row scales bit-equal to the launch without the row sums."""
+    from npi_gnn_amd import functional as NF
+    from npi_gnn_amd import graph as NG
+    import numpy as np
+    n_cols = n_rows + 17
+    g = torch.Generator().manual_seed(n_rows + E)
+    key = torch.randint(0, max(n_rows - 7, 1), (max(E, 1),), generator=g)[:E]
+    for k, r in enumerate((3, n_rows // 2) if E else ()):
+        key[k * (E // 4): k * (E // 4) + E // 5] = r
+    # rows that end exactly where a 64-entry block / an item ends: pad row 0 up to a multiple of the item size
+    val = torch.randint(0, n_cols, (E,), generator=g)
+    side = NG.build_side(key.to(dev), val.to(dev), n_rows, n_cols, False, 0, False, item=item)
+    nnz = int(side.rowptr[-1])
+    dout = torch.randn(n_cols, C, generator=g).to(dev)
+    hrow = torch.randn(n_rows, C, generator=g).to(dev)
+    tpack = torch.randn(n_cols, 4, generator=g)
+    tpack[:, 2] = tpack[:, 2].abs() * 0.1 + 0.01                          # 1 / s > 0
+    tpack[:, 1] = tpack[:, 1].abs() + 2.0                                 # the "row max": keeps exp(. - m) bounded
+    tpack = tpack.to(dev)
+    a_src = torch.randn(n_rows, generator=g).to(dev)
+    sc = torch.empty(n_rows, device=dev) if C == 256 else None
+    gs = torch.full((n_rows,), float("nan"), device=dev)
+    dh, dz = NF.gat_backward_fused_packed(side, dout, None, hrow, C, tpack, a_src, 0.2, scales_out=sc, rowsum_out=gs)
+    sc0 = torch.empty(n_rows, device=dev) if C == 256 else None
+    dh0, dz0 = NF.gat_backward_fused_packed(side, dout, None, hrow, C, tpack, a_src, 0.2, scales_out=sc0)
+    assert torch.equal(dh, dh0) and torch.equal(dz[:nnz], dz0[:nnz]) and (sc is None or torch.equal(sc, sc0))
+    rp = side.rowptr.cpu().numpy().astype(np.int64)
+    hn = rp[1:] > rp[:-1]
+    want = np.zeros(n_rows)
+    if nnz:
+        want[hn] = np.add.reduceat(dz[:nnz].double().cpu().numpy(), rp[:-1][hn])
+    scale = max(1.0, float(np.abs(want).max()))
+    tol = 2e-6 * scale * max(1.0, (E / max(n_rows, 1)) ** 0.5)
+    assert not bool(torch.isnan(gs).any())
+    assert float(np.abs(gs.double().cpu().numpy() - want).max()) < tol
+    if nnz:
+        ref = NF.seg_rowsum(side, dz.view(-1, 1), 1).view(-1)
+        assert float((gs - ref).abs().max()) < tol
+    gs2 = torch.empty_like(gs)
+    NF.gat_backward_fused_packed(side, dout, None, hrow, C, tpack, a_src, 0.2, rowsum_out=gs2)
+    assert torch.equal(gs, gs2)                                           # fixed orders: run-to-run bit identical
+
+
 @pytest.mark.parametrize("N,H,C", [(1000, 1, 256), (4097, 4, 64), (300_000, 1, 256), (50, 1, 8), (2000, 2, 512), (777, 3, 100)])
 def test_rowdot_and_bias_gradient_in_one_pass(dev, N, H, C):
     from npi_gnn_amd import functional as NF

@@ -32,7 +32,7 @@ def test_no_environment_switch_selects_a_path():
     assert fields == {"overlap_streams", "overlap_min_rows", "gat_rank2_epilogue", "gat_rank2_min_rows", "gat_scores_epilogue",
                       "direct_hub_rows", "partial_stream", "split_projection", "gat_direct", "early_hub_gather", "gemm_reserve_cus",
                       "split_projection_reserve_cus", "gat_src_rowsum_beside_dw", "gat_fused_stats", "aggregate_first_backward",
-                      "f16x2_min_rows", "gemm_exact_f32"}
+                      "f16x2_min_rows", "gemm_exact_f32", "gat_src_rowsum_fused"}
     assert CONSERVATIVE == DEFAULT.but(direct_hub_rows=False, partial_stream=False, split_projection=False, gat_direct=False,
                                        gat_rank2_epilogue=False)
 
@@ -67,6 +67,7 @@ def _run(make, graph, x, go):
     ("gat", dict(gemm_exact_f32=True)),
     ("gat", dict(overlap_streams=False)), ("gat", dict(gat_rank2_epilogue=False)), ("gat", dict(gat_rank2_min_rows=10 ** 9)),
     ("gat", dict(gat_scores_epilogue=False)), ("gat", dict(gat_src_rowsum_beside_dw=True)), ("gat", dict(gat_fused_stats=False)),
+    ("gat", dict(gat_src_rowsum_fused=False)), ("gat", dict(gat_src_rowsum_fused=False, gat_src_rowsum_beside_dw=True)),
 ])
 def test_single_gpu_layer_under_every_alternative_schedule(dev, kind, alt):
     ei, graph, x, go = _graph(dev, F=256 if kind.endswith("256") else 128)
