@@ -242,15 +242,21 @@ gat_rowdot_colsum_kernel(const float* __restrict__ a, int64_t lda, const float* 
         part[(int64_t)blockIdx.x * Fw + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-// out[c] = sum over the blocks of part[k, c]: 64 columns per workgroup, its four waves take the block ranges
-// [0, n/4), [n/4, n/2), ... with four independent partial sums each (k mod 4), folded in a fixed order
+// out[y, c] = sum over slice y of the blocks of part[k, c] (gridDim.y slices of ceil(nblocks / gridDim.y) blocks): 64 columns per
+// workgroup, its four waves take the quarters of the slice with four independent partial sums each (k mod 4), folded in a fixed
+// order.  One slice over ~1,000 blocks was a chain of 61 dependent load rounds in four workgroups (31 us at C4, 117 us at the C5
+// size): colsum_blocks() below cuts COLSUM_SLICES slices first and sums those with a second launch.
+constexpr int COLSUM_SLICES = 32;
 __global__ void __launch_bounds__(256)
 colsum_blocks_kernel(const float* __restrict__ part, int nblocks, int Fw, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const int per = (nblocks + 3) / 4;
-    const int kb = wave * per, ke = min(nblocks, kb + per);
+    const int per_y = (nblocks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int yb = blockIdx.y * per_y, ye = min(nblocks, yb + per_y);
+    const int per = (max(ye - yb, 0) + 3) / 4;
+    const int kb = yb + wave * per, ke = min(ye, kb + per);
+    out += (int64_t)blockIdx.y * Fw;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < Fw) {
         int k = kb;
@@ -265,6 +271,17 @@ colsum_blocks_kernel(const float* __restrict__ part, int nblocks, int Fw, float*
     red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0 && c < Fw) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// part [nblocks, Fw] -> out [Fw]; `slices` [COLSUM_SLICES, Fw] scratch behind the partials (fixed orders: deterministic)
+static void colsum_blocks(const float* part, int64_t nblocks, int64_t Fw, float* out, float* slices, hipStream_t stream) {
+    const unsigned gx = (unsigned)ceil_div(Fw, 64);
+    if (nblocks <= 4 * COLSUM_SLICES) {
+        colsum_blocks_kernel<<<gx, 256, 0, stream>>>(part, (int)nblocks, (int)Fw, out);
+        return;
+    }
+    colsum_blocks_kernel<<<dim3(gx, COLSUM_SLICES), 256, 0, stream>>>(part, (int)nblocks, (int)Fw, slices);
+    colsum_blocks_kernel<<<gx, 256, 0, stream>>>(slices, COLSUM_SLICES, (int)Fw, out);
 }
 
 static bool rows16(const void* p, int64_t ld, int64_t C) { return C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p % 16) == 0; }
@@ -672,7 +689,7 @@ static int rdc_rows(int64_t N) { return N >= (1 << 18) ? 1024 : (N >= (1 << 14) 
 
 extern "C" int64_t npi_gat_rowdot_colsum_workspace_elems(int64_t N, int64_t H, int64_t C) {
     if (N < 0 || H <= 0 || C <= 0) return -1;
-    return ceil_div(N > 0 ? N : 1, (int64_t)rdc_rows(N)) * H * C;
+    return (ceil_div(N > 0 ? N : 1, (int64_t)rdc_rows(N)) + COLSUM_SLICES) * H * C;     // the blocks' partials + their slices' sums
 }
 
 extern "C" int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -691,7 +708,7 @@ extern "C" int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const flo
     }
     const int rows = rdc_rows(N);
     const int64_t nblocks = ceil_div(N, (int64_t)rows);
-    if (colsum != nullptr && (workspace == nullptr || workspace_elems < nblocks * Fw)) {
+    if (colsum != nullptr && (workspace == nullptr || workspace_elems < (nblocks + COLSUM_SLICES) * Fw)) {
         set_error("npi_gat_rowdot_colsum: workspace too small");
         return NPI_ERR_WORKSPACE;
     }
@@ -701,8 +718,7 @@ extern "C" int npi_gat_rowdot_colsum_relu(const float* a, int64_t lda, const flo
         NPI_RDC(1); NPI_RDC(2); NPI_RDC(3); default: NPI_RDC(4);
 #undef NPI_RDC
     }
-    if (colsum != nullptr)
-        colsum_blocks_kernel<<<(unsigned)ceil_div(Fw, 64), 256, 0, stream>>>(workspace, (int)nblocks, (int)Fw, colsum);
+    if (colsum != nullptr) colsum_blocks(workspace, nblocks, Fw, colsum, workspace + nblocks * Fw, stream);
     return check_launch("npi_gat_rowdot_colsum");
 }
 

@@ -91,6 +91,7 @@ seg_items_kernel(ScanArgs A) {
     using V = typename Op::V;
     constexpr bool SOFTMAX = sizeof(V) == 8;
     const int lane = lane_id();
+    // (XCD x taking the x-th contiguous eighth of the items instead of every eighth workgroup: the mapped row sum 0.26 -> 0.33 ms at C4)
     const int item = uniform_i(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= A.n_items) return;
     const int nnz = A.rowptr[A.N];
@@ -224,7 +225,8 @@ seg_chain_kernel(ScanArgs A) {
     int r = -1, n = 0;
     if (item < A.n_items) {
         r = A.tail_row[item];
-        if (r >= 0) n = (A.rowptr[r + 1] - 1) / A.item - item;
+        if (r >= A.N) r = -1;                                                 // (never written by seg_items: nothing to trust)
+        if (r >= 0) n = min((A.rowptr[r + 1] - 1) / A.item, A.n_items - 1) - item;
     }
     if (r >= 0 && n <= CHAIN_SHORT) {
         for (int hd = 0; hd < H; ++hd) {
@@ -239,8 +241,16 @@ seg_chain_kernel(ScanArgs A) {
         todo &= todo - 1;
         const int it = bcast_i(item, l), nn = bcast_i(n, l), rr = bcast_i(r, l);
         for (int hd = 0; hd < H; ++hd) {
-            V acc = Op::identity();
-            for (int t = lane; t < nn; t += WAVE) acc = Op::merge(acc, load_v<Op>(A.head, (int64_t)(it + 1 + t) * H + hd));
+            // four independent partial sums per lane (t mod 4 WAVE): the 10,000-link chain of the C5 hub row was one wavefront's
+            // 165 dependent rounds
+            V a4[4] = {Op::identity(), Op::identity(), Op::identity(), Op::identity()};
+            int t = lane;
+            for (; t + 3 * WAVE < nn; t += 4 * WAVE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = Op::merge(a4[q], load_v<Op>(A.head, (int64_t)(it + 1 + t + q * WAVE) * H + hd));
+            }
+            for (int q = 0; t < nn; t += WAVE, ++q) a4[q] = Op::merge(a4[q], load_v<Op>(A.head, (int64_t)(it + 1 + t) * H + hd));
+            V acc = Op::merge(Op::merge(a4[0], a4[1]), Op::merge(a4[2], a4[3]));
 #pragma unroll
             for (int d = 1; d < WAVE; d <<= 1) {                              // fixed tree: lower lane = earlier items
                 const V o = Op::shfl_xor(acc, d);
