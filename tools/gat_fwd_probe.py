@@ -38,8 +38,14 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-res = {"two_pass": [], "fused": []}
+def plain():                                                        # the same gathers without any weight: SAGEConv's aggregation
+    return NF.segsum(graph, d, h, mean=True)
+
+
+res = {"two_pass": [], "fused": [], "plain": []}
 for _ in range(3):
     res["two_pass"].append(t(two_pass))
     res["fused"].append(t(fused))
-print(f"N={N} E={E}: statistics pass + aggregation {min(res['two_pass']):.3f} ms, fused {min(res['fused']):.3f} ms  ({res})")
+    res["plain"].append(t(plain))
+print(f"{os.path.basename(os.environ.get('NPI_GNN_LIB', 'default'))} N={N} E={E}: statistics pass + aggregation {min(res['two_pass']):.3f} ms, "
+      f"fused {min(res['fused']):.3f} ms, unweighted mean {min(res['plain']):.3f} ms  ({res})")
