@@ -49,3 +49,19 @@ for _ in range(3):
     res["plain"].append(t(plain))
 print(f"{os.path.basename(os.environ.get('NPI_GNN_LIB', 'default'))} N={N} E={E}: statistics pass + aggregation {min(res['two_pass']):.3f} ms, "
       f"fused {min(res['fused']):.3f} ms, unweighted mean {min(res['plain']):.3f} ms  ({res})")
+
+# the same launch BEHIND the projection that writes its table (as in the layer): events around the aggregation only
+x = torch.randn(N, C, generator=g).to(dev)
+W = (torch.randn(C, C, generator=g) / 16).to(dev)
+xs = NF.row_scales(x)
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+for k in range(23):
+    hh, ad, as_ = NF.linear_fwd_scores(x, W, att.view(-1), a_scales=xs)
+    if k >= 3:
+        ev[k - 3][0].record()
+    o = NF.gat_aggregate_fused(d, hh, None, C, ad, att, 0.2)[0]
+    if k >= 3:
+        ev[k - 3][1].record()
+torch.cuda.synchronize()
+ts = sorted(a.elapsed_time(b) for a, b in ev)
+print(f"behind the scores GEMM: fused aggregation {ts[0]:.3f} (min) {ts[len(ts) // 2]:.3f} (median) ms")
