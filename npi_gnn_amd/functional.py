@@ -9,6 +9,8 @@ Formulas (PyG 1.4.2):
 """
 from __future__ import annotations
 
+import collections
+import weakref
 from typing import Optional
 
 import torch
@@ -445,6 +447,10 @@ def gat_rank2_tail(P: torch.Tensor, weight: torch.Tensor, att2: torch.Tensor, dw
     return datt
 
 
+#: id(row-scale tensor) -> (weak reference to it, (its version, columns), its column scales): at most 8 (LRU)
+_COL_SCALES_KEPT: "collections.OrderedDict" = collections.OrderedDict()
+
+
 def col_scales(a: Optional[torch.Tensor] = None, row_scales: Optional[torch.Tensor] = None, cols: Optional[int] = None) -> torch.Tensor:
     """``[K]`` power-of-two COLUMN scales for ``linear_bwd_weight(a_cs=, dc_cs=)`` (``npi_col_scales``): from the column maxima
     of ``a`` (one pass over it -- for a matrix that does not change between steps, once), or -- ``a`` None -- the smallest of the
@@ -462,17 +468,22 @@ def col_scales(a: Optional[torch.Tensor] = None, row_scales: Optional[torch.Tens
         _check_scales(row_scales, row_scales.numel(), "col_scales")
         M, K = int(row_scales.numel()), int(cols)
         # the scales of a matrix that does not change between steps (a layer's input features) are the same tensor object every
-        # step: its column scales are kept ON it (dropped with it; recomputed when it was written in place since)
-        kept = getattr(row_scales, "_npi_col_scales", None)
-        if kept is not None and kept[0] == (row_scales._version, K) and kept[1].device == dev:
-            return kept[1]
+        # step: its column scales are kept beside a WEAK reference to it (an id reused by another tensor misses; recomputed when
+        # it was written in place since) -- no attribute on the tensor, no strong reference
+        kept = _COL_SCALES_KEPT.get(id(row_scales))
+        if kept is not None and kept[0]() is row_scales and kept[1] == (row_scales._version, K):
+            _COL_SCALES_KEPT.move_to_end(id(row_scales))
+            return kept[2]
     n_ws = int(lib.npi_col_scales_workspace_elems(M, K))
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     out = torch.empty(K, dtype=torch.float32, device=dev)
     check(lib.npi_col_scales(ptr(a), a.stride(0) if a is not None else 0, M, K, ptr(row_scales) if a is None else 0, ptr(out), ptr(ws),
                              n_ws, stream_ptr(dev)), "npi_col_scales")
     if a is None and not torch.cuda.is_current_stream_capturing():
-        row_scales._npi_col_scales = ((row_scales._version, K), out)
+        _COL_SCALES_KEPT[id(row_scales)] = (weakref.ref(row_scales), (row_scales._version, K), out)
+        _COL_SCALES_KEPT.move_to_end(id(row_scales))
+        while len(_COL_SCALES_KEPT) > 8:
+            _COL_SCALES_KEPT.popitem(last=False)
     return out
 
 
