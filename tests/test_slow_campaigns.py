@@ -25,3 +25,9 @@ def test_gat_random_campaign_full():
 
 def test_sharded_layers_random_campaign_full():
     _run("fuzz_dist.py", 24, 7, 1200)
+
+
+def test_eight_virtual_ranks_at_a_quarter_of_c4_gat(dev):
+    """the GATConv case of tests/test_dist_gpu.py's 8-rank lock-step run (its SAGEConv case runs under `-m gpu`)"""
+    import test_dist_gpu as T
+    T.test_eight_virtual_ranks_at_a_quarter_of_c4_match_the_single_gpu_layer(dev, "gat1")
