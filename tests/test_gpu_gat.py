@@ -231,6 +231,12 @@ def test_fused_backward_pass_also_leaves_the_row_sums_of_dz(dev, n_rows, E, item
     gs2 = torch.empty_like(gs)
     NF.gat_backward_fused_packed(side, dout, None, hrow, C, tpack, a_src, 0.2, rowsum_out=gs2)
     assert torch.equal(gs, gs2)                                           # fixed orders: run-to-run bit identical
+    # the gathered table in two parts (the sharded layers' hub table + own rows): the same entries, the same sums
+    cut = n_cols // 3
+    gs3 = torch.empty_like(gs)
+    dh3, dz3 = NF.gat_backward_fused_packed(side, dout[:cut].contiguous(), dout[cut:].contiguous(), hrow, C, tpack, a_src, 0.2,
+                                            rowsum_out=gs3)
+    assert torch.equal(dh3, dh) and torch.equal(dz3[:nnz], dz[:nnz]) and torch.equal(gs3, gs)
 
 
 @pytest.mark.parametrize("N,H,C", [(1000, 1, 256), (4097, 4, 64), (300_000, 1, 256), (50, 1, 8), (2000, 2, 512), (777, 3, 100)])
