@@ -1586,9 +1586,9 @@ class _GatConvFn(torch.autograd.Function):
                 and dw_f16x2_shape(x.size(0), x.size(1), dh.size(1)) and x.dtype == torch.float32):
             dw_kw = dict(a_cs=col_scales(row_scales=ctx.x_scales, cols=x.size(1)), dc_cs=col_scales(row_scales=dh_scales, cols=dh.size(1)))
         tmap = _inverse_transpose_map(graph)                                  # cached; built on the launch stream
-        # dz is in by-source entry order: its by-source row sum is a coalesced, latency-bound pass (0.09 ms alone, 0.31 ms
-        # with one wave per SIMD beside a dW workgroup), so it stays in front of dW
-        # (g_src handed in: the fused pass has already summed it -- Schedule.gat_src_rowsum_fused)
+        # g_src handed in: the fused pass has already summed dz by source row (Schedule.gat_src_rowsum_fused).  Otherwise: dz is in
+        # by-source entry order, its by-source row sum a coalesced, latency-bound pass (0.09 ms alone, 0.31 ms with one wave per
+        # SIMD beside a dW workgroup), so it stays in front of dW unless the schedule asks for it beside dW
         src_beside = overlap and ctx.sch.gat_src_rowsum_beside_dw and g_src is None
         if not src_beside and g_src is None:
             g_src = seg_rowsum(graph.by_src, dz, 1)
