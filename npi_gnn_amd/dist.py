@@ -528,9 +528,11 @@ class HipBackend:
         from . import functional as NF
         return NF.gat_pack_targets(a_dst, m, s, D, out=out)
 
-    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H=1):
+    fused_rowsum = True                               # gat_backward_fused(rowsum_out=): the pass also sums dz by its own rows (one head)
+
+    def gat_backward_fused(self, side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=None, H=1, rowsum_out=None):
         from . import functional as NF
-        return NF.gat_backward_fused_packed(side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=out, H=H)
+        return NF.gat_backward_fused_packed(side, dout, dout2, hrow, C, tpack, a_src_rows, slope, out=out, H=H, rowsum_out=rowsum_out)
 
     def gat_rank1_add(self, dh, g_dst, g_src, att2, H, C):
         from . import functional as NF
@@ -1272,17 +1274,25 @@ class _ShardedGatDirectFn(torch.autograd.Function):
         # hub SOURCES (rows of the hub table): targets = this rank's rows (its light rows; the own hubs' loops): nothing remote,
         # so this pass and its row sums run on the partial stream beside the light sources' pass
         bs = be.partial_stream(h, sg.schedule) if (not _solo(W) and hasattr(be, "partial_stream")) else None
+        # one head on the GPU backend: the by-source row sums of dz come out of the fused passes themselves (Schedule.gat_src_rowsum_fused)
+        in_pass = H == 1 and getattr(be, "fused_rowsum", False) and sg.schedule.gat_src_rowsum_fused
         with _fork(bs, (dO, tbl_h, t_own, tbl_a_src)) as fk:
-            pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope, H=H)
+            pg_src = h.new_empty((Bt.n_rows, 1)) if in_pass else None
+            kw_rs = {"rowsum_out": pg_src.view(-1)} if in_pass else {}
+            pdh, dz_bt = be.gat_backward_fused(Bt, dO, None, tbl_h, C, t_own, tbl_a_src, slope, H=H, **kw_rs)
             dz_bt = dz_bt.view(-1, H)
-            pg_src = be.seg_rowsum(Bt, dz_bt, H)
+            if not in_pass:
+                pg_src = be.seg_rowsum(Bt, dz_bt, H)
         # own light SOURCES: targets = the hub table (+ the own loop)
         dh_full = h.new_empty((nL + hp, F))
         _wait(g_work, "bwd_all_gather", tbl_dO)
+        g_src_l = h.new_empty((nL, 1)) if in_pass else None
+        kw_rs = {"rowsum_out": g_src_l.view(-1)} if in_pass else {}
         _, dz_at = be.gat_backward_fused(At, tbl_dO, dO, h[:nL], C, t_all, a_src[:nL].contiguous(), slope,
-                                         out=dh_full[:nL], H=H)
+                                         out=dh_full[:nL], H=H, **kw_rs)
         dz_at = dz_at.view(-1, H)
-        g_src_l = be.seg_rowsum(At, dz_at, H)
+        if not in_pass:
+            g_src_l = be.seg_rowsum(At, dz_at, H)
         fk.join(pdh, dz_bt, pg_src)
         dh = dh_full[: nL + nH]
         # One head on a shape the split GEMM covers: the attention terms g_dst (x) a1 + g_src (x) a2 are never added to d h --
